@@ -1,0 +1,2 @@
+from .finite_mdp import FiniteMDPEnv, MDP, DeterministicMDP, StochasticMDP, SparseMDP, Discrete  # noqa: F401
+from . import generators  # noqa: F401

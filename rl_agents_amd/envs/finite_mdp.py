@@ -1,0 +1,198 @@
+"""Finite-MDP environment: the host-side data format on the input edge of the planning path.
+
+The reference reads a finite MDP through the third-party ``finite_mdp`` package, which is NOT
+under /root/reference and not installed here.  What the reference's planners
+touch is small and fully determined by their call sites, so it is restated here:
+
+* ``env.mdp`` / ``env.unwrapped.to_finite_mdp()`` with ``mode``, ``transition``, ``reward``,
+  ``terminal``, ``state``, ``next_state(s, a)`` (+ ``next`` in sparse mode)
+  -- rl_agents/agents/dynamic_programming/value_iteration.py:12-21,31-34,52-62,91-92
+* ``env.action_space.n``, ``env.step(a) -> (obs, reward, terminated, truncated, info)``
+  -- rl_agents/agents/tree_search/abstract.py:158-161, mcts.py:145,173, deterministic.py:41
+* the config-dict wire format ``{"mode", "transition", "reward", "terminal", "max_steps"}``
+  -- scripts/configs/FiniteMDPEnv/**/env_*.json
+
+Step semantics (documented choice, ``finite_mdp`` being absent): acting in state ``s`` with
+action ``a`` yields ``reward[s, a]``, moves to ``transition[s, a]`` and reports
+``terminated = terminal[s]`` -- the flag of the state the action was taken FROM.  This is the
+only reading consistent with the reference's value iteration, which zeroes the continuation
+of *source* rows (value_iteration.py:62) and with its ``trap``/``doors`` configs, whose
+terminal states carry the +1/-1 reward that is collected by acting in them.
+``done_rule="next"`` selects the other convention (``terminated = terminal[s']``).
+``truncated`` is raised once ``max_steps`` steps were taken since ``reset`` (0/None = never).
+"""
+import copy
+
+import numpy as np
+
+
+class Discrete(object):
+    """Minimal stand-in for ``gymnasium.spaces.Discrete`` (only ``n`` is read by planners)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __repr__(self):
+        return "Discrete({})".format(self.n)
+
+
+class MDP(object):
+    mode = None
+
+    def __init__(self, transition, reward, terminal=None, state=0, done_rule="source"):
+        self.transition = transition
+        self.reward = np.ascontiguousarray(reward, dtype=np.float64)
+        n_states = self.reward.shape[0]
+        if terminal is None:
+            terminal = np.zeros(n_states, dtype=bool)
+        # configs sometimes give terminal as [[0],[1],...] (anti_vi/env_1.json)
+        self.terminal = np.asarray(terminal).reshape(n_states).astype(bool)
+        self.state = int(state)
+        if done_rule not in ("source", "next"):
+            raise ValueError("done_rule must be 'source' or 'next'")
+        self.done_rule = done_rule
+
+    @property
+    def n_states(self):
+        return self.reward.shape[0]
+
+    @property
+    def n_actions(self):
+        return self.reward.shape[1]
+
+    def next_state(self, state, action, np_random=None):
+        raise NotImplementedError
+
+    def step(self, action, np_random=None):
+        s = self.state
+        reward = float(self.reward[s, action])
+        s_next = self.next_state(s, action, np_random)
+        done = bool(self.terminal[s] if self.done_rule == "source" else self.terminal[s_next])
+        self.state = int(s_next)
+        return self.state, reward, done
+
+    def to_config(self):
+        cfg = dict(mode=self.mode,
+                   transition=np.asarray(self.transition).tolist(),
+                   reward=self.reward.tolist(),
+                   terminal=self.terminal.astype(int).tolist())
+        if self.mode == "sparse":
+            cfg["next"] = np.asarray(self.next).tolist()
+        return cfg
+
+    @staticmethod
+    def from_config(config):
+        mode = config["mode"]
+        kw = dict(terminal=config.get("terminal"), state=config.get("state", 0),
+                  done_rule=config.get("done_rule", "source"))
+        if mode == "deterministic":
+            return DeterministicMDP(config["transition"], config["reward"], **kw)
+        if mode == "stochastic":
+            return StochasticMDP(config["transition"], config["reward"], **kw)
+        if mode == "sparse":
+            return SparseMDP(config["transition"], config["next"], config["reward"], **kw)
+        raise ValueError("Unknown mode")
+
+
+class DeterministicMDP(MDP):
+    mode = "deterministic"
+
+    def __init__(self, transition, reward, **kw):
+        super().__init__(np.ascontiguousarray(transition, dtype=np.int64), reward, **kw)
+        if self.transition.shape != self.reward.shape:
+            raise ValueError("transition and reward must both be [S, A]")
+
+    def next_state(self, state, action, np_random=None):
+        return int(self.transition[state, action])
+
+
+class StochasticMDP(MDP):
+    mode = "stochastic"
+
+    def __init__(self, transition, reward, **kw):
+        super().__init__(np.ascontiguousarray(transition, dtype=np.float64), reward, **kw)
+        s, a = self.reward.shape
+        if self.transition.shape != (s, a, s):
+            raise ValueError("transition must be [S, A, S]")
+
+    def next_state(self, state, action, np_random=None):
+        rng = np_random if np_random is not None else np.random
+        return int(rng.choice(self.n_states, p=self.transition[state, action]))
+
+
+class SparseMDP(MDP):
+    """``transition[s, a, b]`` = probability of moving to ``next[s, a, b]`` (value_iteration.py:56-59)."""
+    mode = "sparse"
+
+    def __init__(self, transition, next_states, reward, **kw):
+        super().__init__(np.ascontiguousarray(transition, dtype=np.float64), reward, **kw)
+        self.next = np.ascontiguousarray(next_states, dtype=np.int64)
+        if self.next.shape != self.transition.shape:
+            raise ValueError("next and transition must both be [S, A, B]")
+
+    def next_state(self, state, action, np_random=None):
+        rng = np_random if np_random is not None else np.random
+        b = int(rng.choice(self.transition.shape[2], p=self.transition[state, action]))
+        return int(self.next[state, action, b])
+
+
+class FiniteMDPEnv(object):
+    """Gym-style environment over an :class:`MDP` (5-tuple ``step``, ``unwrapped``, ``to_finite_mdp``)."""
+
+    metadata = {}
+
+    def __init__(self, config=None):
+        self.config = {"mode": "deterministic", "transition": [[0]], "reward": [[0]], "max_steps": 0}
+        self.mdp = None
+        self.steps = 0
+        self.np_random = np.random.default_rng()
+        self.action_space = None
+        self.observation_space = None
+        if config is not None:
+            self.configure(config)
+
+    # -- gym surface ---------------------------------------------------------------------
+    @property
+    def unwrapped(self):
+        return self
+
+    def configure(self, config):
+        self.config.update(config)
+        self.mdp = MDP.from_config(self.config)
+        self.action_space = Discrete(self.mdp.n_actions)
+        self.observation_space = Discrete(self.mdp.n_states)
+        self.steps = 0
+
+    def seed(self, seed=None):
+        self.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        return [seed]
+
+    def reset(self, *, seed=None, options=None):
+        if seed is not None:
+            self.seed(seed)
+        self.mdp.state = int(self.config.get("state", 0))
+        self.steps = 0
+        return self.mdp.state, {}
+
+    def step(self, action):
+        state, reward, done = self.mdp.step(int(action), np_random=self.np_random)
+        self.steps += 1
+        max_steps = self.config.get("max_steps", 0)
+        truncated = bool(max_steps) and self.steps >= max_steps
+        return state, reward, done, truncated, {}
+
+    def to_finite_mdp(self):
+        return self.mdp
+
+    def render(self, *a, **k):
+        return None
+
+    def close(self):
+        pass
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            setattr(new, k, copy.deepcopy(v, memo))
+        return new

@@ -1,0 +1,1 @@
+from . import seeding  # noqa: F401
