@@ -1,0 +1,212 @@
+"""ctypes front-end of the CPU oracle (oracle/planning_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Parity status: pinned -- tests/test_oracle_golden.py compares every entry point with the golden
+vectors produced by the unmodified reference (tests/golden/gen/make_golden.py).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+ERR_REWARD_RANGE = -2
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "planning_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+    return _LIB
+
+
+def _p(a, ct):
+    return None if a is None else a.ctypes.data_as(C.POINTER(ct))
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _u8(a):
+    return np.ascontiguousarray(np.asarray(a).astype(np.uint8))
+
+
+def policy_cdf(p):
+    """cdf exactly as numpy's Generator.choice builds it: cumsum(p) / cumsum(p)[-1]."""
+    cdf = np.asarray(p, dtype=np.float64).cumsum()
+    cdf /= cdf[-1]
+    return cdf
+
+
+def pcg64_replay(state6, ops):
+    st = np.array(state6, dtype=np.uint64)
+    ops = np.ascontiguousarray(ops, dtype=np.int32)
+    outs = np.zeros(len(ops), dtype=np.float64)
+    lib().orc_pcg64_replay(_p(st, C.c_uint64), len(ops), _p(ops, C.c_int32), _p(outs, C.c_double))
+    return outs, st
+
+
+def pchoice_replay(state6, p, n):
+    st = np.array(state6, dtype=np.uint64)
+    cdf = policy_cdf(p)
+    outs = np.zeros(n, dtype=np.int32)
+    lib().orc_pchoice_replay(_p(st, C.c_uint64), len(cdf), _p(cdf, C.c_double), n, _p(outs, C.c_int32))
+    return outs, st
+
+
+def olop_allocation(budget, gamma):
+    e, h = C.c_int32(), C.c_int32()
+    rc = lib().orc_olop_allocation(int(budget), C.c_double(gamma), C.byref(e), C.byref(h))
+    if rc != 0:
+        raise ValueError("Could not split budget {} with gamma {}".format(budget, gamma))
+    return e.value, h.value
+
+
+_MODES = {"deterministic": 0, "stochastic": 1, "sparse": 2}
+
+
+def vi_solve(mode, transition, reward, terminal=None, gamma=1.0, iterations=100, next_states=None,
+             robust=False, rtol=1e-5, atol=1e-8, state_value=False):
+    """Q (or V) fixed point.  Plain VI: transition [S,A]/[S,A,S]/[S,A,B]; robust: leading model axis M."""
+    reward = _f64(reward)
+    if robust:
+        m, s, a = reward.shape
+    else:
+        (s, a), m = reward.shape, 1
+    mode_i = _MODES[mode]
+    t_i = _i64(transition) if mode_i == 0 else None
+    t_f = _f64(transition) if mode_i != 0 else None
+    nxt = _i64(next_states) if mode_i == 2 else None
+    b = t_f.shape[-1] if mode_i == 2 else 0
+    term = None if (terminal is None or robust) else _u8(terminal)
+    if state_value:
+        out = np.zeros(s, dtype=np.float64)
+        rc = lib().orc_vi_solve_v(mode_i, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
+                                  _p(reward, C.c_double), _p(term, C.c_uint8), C.c_double(gamma), int(iterations),
+                                  C.c_double(rtol), C.c_double(atol), _p(out, C.c_double))
+        assert rc == 0
+        return out
+    q = np.zeros((s, a), dtype=np.float64)
+    sweeps = C.c_int32()
+    rc = lib().orc_vi_solve(mode_i, m, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
+                            _p(reward, C.c_double), _p(term, C.c_uint8), int(bool(robust)), C.c_double(gamma),
+                            int(iterations), C.c_double(rtol), C.c_double(atol), _p(q, C.c_double), C.byref(sweeps))
+    assert rc == 0
+    return q, sweeps.value
+
+
+def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_state=None,
+             done_rule="source", max_plan_len=1024, want_tree=True):
+    t, r, term = _i64(transition), _f64(reward), _u8(terminal)
+    s, a = r.shape
+    cap = 1 + (budget // a) * a
+    rng = np.array(rng_state if rng_state is not None else np.zeros(6), dtype=np.uint64)
+    plan = np.full(max_plan_len, -1, dtype=np.int32)
+    plan_len, steps = C.c_int32(), C.c_int64()
+    lo, up = C.c_double(), C.c_double()
+    tree = None
+    if want_tree:
+        tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),
+                    depth=np.zeros(cap, np.int32), reward=np.zeros(cap, np.float64), lower=np.zeros(cap, np.float64),
+                    upper=np.zeros(cap, np.float64), done=np.zeros(cap, np.uint8), count=np.zeros(cap, np.int64),
+                    first_child=np.zeros(cap, np.int32))
+    tp = (lambda k, ct: _p(tree[k], ct)) if want_tree else (lambda k, ct: None)
+    rc = lib().orc_opd_plan(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
+                            int(done_rule == "next"), int(s0), int(budget), C.c_double(gamma),
+                            C.c_double(terminal_reward), _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32),
+                            C.byref(plan_len), C.byref(lo), C.byref(up), C.byref(steps),
+                            tp("parent", C.c_int32), tp("action", C.c_int32), tp("state", C.c_int32),
+                            tp("depth", C.c_int32), tp("reward", C.c_double), tp("lower", C.c_double),
+                            tp("upper", C.c_double), tp("done", C.c_uint8), tp("count", C.c_int64),
+                            tp("first_child", C.c_int32))
+    if rc == ERR_REWARD_RANGE:
+        raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")
+    assert rc == 0, rc
+    return dict(plan=plan[:plan_len.value].copy(), root_lower=lo.value, root_upper=up.value,
+                env_steps=steps.value, rng_after=rng, tree=tree)
+
+
+def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64):
+    t, r, term = _i64(transition), _f64(reward), _u8(terminal)
+    s, a = r.shape
+    cap = 1 + episodes * a
+    rng = np.array(rng_state, dtype=np.uint64)
+    prior = _f64(prior_p)
+    cdf = policy_cdf(rollout_p)
+    plan = np.full(max_plan_len, -1, dtype=np.int32)
+    plan_len, steps, nn = C.c_int32(), C.c_int64(), C.c_int32()
+    tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), count=np.zeros(cap, np.int64),
+                value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32))
+    rc = lib().orc_uct_plan(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
+                            int(done_rule == "next"), int(max_steps), int(s0), int(steps0), int(episodes),
+                            int(horizon), C.c_double(gamma), C.c_double(temperature), _p(prior, C.c_double),
+                            _p(cdf, C.c_double), _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32),
+                            C.byref(plan_len), C.byref(steps), _p(tree["parent"], C.c_int32),
+                            _p(tree["action"], C.c_int32), _p(tree["count"], C.c_int64),
+                            _p(tree["value"], C.c_double), _p(tree["first_child"], C.c_int32), C.byref(nn))
+    assert rc == 0, rc
+    tree = {k: v[:nn.value].copy() for k, v in tree.items()}
+    return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, tree=tree)
+
+
+def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                   rng_states, steps0=None, max_steps=0, done_rule="source", max_plan_len=16, n_threads=1):
+    t, r, term = _i64(transition), _f64(reward), _u8(terminal)
+    s, a = r.shape
+    s0 = np.ascontiguousarray(s0, dtype=np.int32)
+    n = len(s0)
+    st0 = None if steps0 is None else np.ascontiguousarray(steps0, dtype=np.int32)
+    rng = np.array(rng_states, dtype=np.uint64).reshape(n, 6)
+    prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
+    plans = np.full((n, max_plan_len), -1, dtype=np.int32)
+    plan_len = np.zeros(n, np.int32)
+    root_value = np.zeros(n, np.float64)
+    cc = np.zeros((n, a), np.int64)
+    cv = np.zeros((n, a), np.float64)
+    steps = np.zeros(n, np.int64)
+    rc = lib().orc_uct_plan_batch(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
+                                  int(done_rule == "next"), int(max_steps), n, _p(s0, C.c_int32), _p(st0, C.c_int32),
+                                  int(episodes), int(horizon), C.c_double(gamma), C.c_double(temperature),
+                                  _p(prior, C.c_double), _p(cdf, C.c_double), _p(rng, C.c_uint64), max_plan_len,
+                                  _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(root_value, C.c_double),
+                                  _p(cc, C.c_int64), _p(cv, C.c_double), _p(steps, C.c_int64), int(n_threads))
+    assert rc == 0, rc
+    return dict(plans=plans, plan_len=plan_len, root_value=root_value, root_child_count=cc,
+                root_child_value=cv, env_steps=steps, rng_after=rng)
+
+
+def opd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
+                   done_rule="source", max_plan_len=32, n_threads=1):
+    t, r, term = _i64(transition), _f64(reward), _u8(terminal)
+    s, a = r.shape
+    s0 = np.ascontiguousarray(s0, dtype=np.int32)
+    n = len(s0)
+    rng = (np.zeros((n, 6), np.uint64) if rng_states is None else np.array(rng_states, np.uint64).reshape(n, 6))
+    plans = np.full((n, max_plan_len), -1, dtype=np.int32)
+    plan_len = np.zeros(n, np.int32)
+    lo, up = np.zeros(n), np.zeros(n)
+    steps = np.zeros(n, np.int64)
+    status = np.zeros(n, np.int32)
+    lib().orc_opd_plan_batch(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
+                             int(done_rule == "next"), n, _p(s0, C.c_int32), int(budget), C.c_double(gamma),
+                             C.c_double(terminal_reward), _p(rng, C.c_uint64), max_plan_len, _p(plans, C.c_int32),
+                             _p(plan_len, C.c_int32), _p(lo, C.c_double), _p(up, C.c_double), _p(steps, C.c_int64),
+                             _p(status, C.c_int32), int(n_threads))
+    return dict(plans=plans, plan_len=plan_len, root_lower=lo, root_upper=up, env_steps=steps, status=status,
+                rng_after=rng)

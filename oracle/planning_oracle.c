@@ -1,0 +1,570 @@
+/*
+ * planning_oracle.c -- CPU restatement of the reference planners.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the oracle the HIP path is checked against.  It may be used only by tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg; the product (rl_agents_amd/) never
+ * imports, links or calls it.
+ *
+ * Parity status: PINNED.  tests/test_oracle_golden.py checks every function below bit-for-bit
+ * against tests/golden/{vi,opd,uct,misc}.npz, which were produced by running the unmodified Python reference
+ * (eleurent/rl-agents @ /root/reference) through tests/golden/gen/make_golden.py.
+ *
+ * Each function cites the reference lines (relative to /root/reference) it follows.  It is a
+ * plain scalar restatement: linked-list-free arrays, the reference's O(#leaves) leaf scan, the
+ * reference's evaluation order for every floating-point expression (Python float semantics =
+ * IEEE double, `**` = libm pow, no fused multiply-add: build with -ffp-contract=off).
+ *
+ * Third-party arithmetic restated because it is not under /root/reference:
+ *   - numpy.random.Generator(PCG64): pcg64 XSL-RR 128/64 step+output, next_double =
+ *     (next64 >> 11) * 2^-53, next_uint32 buffering of the high half, and the bounded-integer
+ *     draw used by Generator.integers/choice (Lemire multiply-shift with rejection on the
+ *     buffered 32-bit stream).  Pinned against numpy 2.2.6 draws in tests/golden/misc.npz.
+ *   - numpy add.reduce over a contiguous axis (pairwise summation, blocks of 128, 8 lanes),
+ *     needed for (T * v).sum(-1) in dense/sparse value iteration.
+ *   - numpy.allclose (rtol 1e-5, atol 1e-8) early exit.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_ERR_REWARD_RANGE (-2) /* deterministic.py:46-47 ValueError */
+#define ORC_ERR_ALLOC (-3)
+#define ORC_ERR_ARG (-4)
+
+/* ------------------------------------------------------------------ numpy PCG64 ---------- */
+typedef struct {
+    uint64_t s_hi, s_lo, inc_hi, inc_lo;
+    uint64_t has_uint32, uinteger; /* numpy keeps one buffered 32-bit half */
+} orc_pcg64;
+
+typedef unsigned __int128 u128;
+
+static inline uint64_t orc_pcg64_next64(orc_pcg64 *g)
+{
+    const u128 mult = ((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+    u128 s = ((u128)g->s_hi << 64) | g->s_lo;
+    u128 inc = ((u128)g->inc_hi << 64) | g->inc_lo;
+    s = s * mult + inc;
+    g->s_hi = (uint64_t)(s >> 64);
+    g->s_lo = (uint64_t)s;
+    uint64_t x = g->s_hi ^ g->s_lo;
+    unsigned rot = (unsigned)(g->s_hi >> 58);
+    return (x >> rot) | (x << ((-rot) & 63));
+}
+
+static inline uint32_t orc_pcg64_next32(orc_pcg64 *g)
+{
+    if (g->has_uint32) {
+        g->has_uint32 = 0;
+        return (uint32_t)g->uinteger;
+    }
+    uint64_t n = orc_pcg64_next64(g);
+    g->has_uint32 = 1;
+    g->uinteger = (uint32_t)(n >> 32);
+    return (uint32_t)(n & 0xffffffffu);
+}
+
+static inline double orc_pcg64_double(orc_pcg64 *g)
+{
+    return (double)(orc_pcg64_next64(g) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* Generator.integers(0, k) / Generator.choice(arange(k)) for 1 <= k < 2^32:
+ * k == 1 draws nothing; otherwise Lemire's method on the 32-bit stream. */
+static inline uint32_t orc_pcg64_below(orc_pcg64 *g, uint32_t k)
+{
+    if (k <= 1) return 0;
+    const uint32_t rng_excl = k;
+    uint64_t m = (uint64_t)orc_pcg64_next32(g) * rng_excl;
+    uint32_t leftover = (uint32_t)m;
+    if (leftover < rng_excl) {
+        const uint32_t threshold = (uint32_t)(-rng_excl) % rng_excl;
+        while (leftover < threshold) {
+            m = (uint64_t)orc_pcg64_next32(g) * rng_excl;
+            leftover = (uint32_t)m;
+        }
+    }
+    return (uint32_t)(m >> 32);
+}
+
+/* test hook: replay a mixed sequence of draws (ops[i] == 0 -> random(), k > 0 -> choice(arange(k))) */
+int orc_pcg64_replay(uint64_t *state6, int n, const int32_t *ops, double *outs)
+{
+    orc_pcg64 g = {state6[0], state6[1], state6[2], state6[3], state6[4], state6[5]};
+    for (int i = 0; i < n; ++i)
+        outs[i] = ops[i] == 0 ? orc_pcg64_double(&g) : (double)orc_pcg64_below(&g, (uint32_t)ops[i]);
+    state6[0] = g.s_hi; state6[1] = g.s_lo; state6[2] = g.inc_hi; state6[3] = g.inc_lo;
+    state6[4] = g.has_uint32; state6[5] = g.uinteger;
+    return ORC_OK;
+}
+
+/* Generator.choice(actions, 1, p=p): idx = searchsorted(cdf, random(), side='right') with
+ * cdf = cumsum(p) / cumsum(p)[-1]; the cdf is computed by the caller with numpy itself. */
+static inline int orc_cdf_pick(const double *cdf, int n, double u)
+{
+    int idx = 0;
+    while (idx < n && cdf[idx] <= u) ++idx;
+    return idx;
+}
+
+int orc_pchoice_replay(uint64_t *state6, int n_p, const double *cdf, int n, int32_t *outs)
+{
+    orc_pcg64 g = {state6[0], state6[1], state6[2], state6[3], state6[4], state6[5]};
+    for (int i = 0; i < n; ++i) outs[i] = orc_cdf_pick(cdf, n_p, orc_pcg64_double(&g));
+    state6[0] = g.s_hi; state6[1] = g.s_lo; state6[2] = g.inc_hi; state6[3] = g.inc_lo;
+    state6[4] = g.has_uint32; state6[5] = g.uinteger;
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ OLOP.allocation ------ */
+/* olop.py:42-44 */
+static int orc_olop_horizon(int episodes, double gamma)
+{
+    int h = (int)ceil(log((double)episodes) / (2.0 * log(1.0 / gamma)));
+    return h > 1 ? h : 1;
+}
+
+/* olop.py:50-62; returns ORC_ERR_ARG where the reference raises ValueError */
+int orc_olop_allocation(int budget, double gamma, int32_t *episodes_out, int32_t *horizon_out)
+{
+    for (int episodes = 1; episodes < budget; ++episodes) {
+        if ((long long)episodes * orc_olop_horizon(episodes, gamma) > budget) {
+            int e = episodes - 1 > 1 ? episodes - 1 : 1;
+            *episodes_out = e;
+            *horizon_out = orc_olop_horizon(e, gamma);
+            return ORC_OK;
+        }
+    }
+    return ORC_ERR_ARG;
+}
+
+/* ------------------------------------------------------------------ value iteration ------ */
+/* numpy pairwise summation of a contiguous double vector (add.reduce inner loop). */
+static double orc_pairwise_sum(const double *a, long n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (long i = 0; i < n; ++i) res += a[i];
+        return res;
+    } else if (n <= 128) {
+        double r[8];
+        long i;
+        for (int j = 0; j < 8; ++j) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; ++j) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += a[i];
+        return res;
+    } else {
+        long n2 = n / 2;
+        n2 -= n2 % 8;
+        return orc_pairwise_sum(a, n2) + orc_pairwise_sum(a + n2, n - n2);
+    }
+}
+
+/* numpy.isclose for one pair (a = old value, b = new value) */
+static inline int orc_isclose(double a, double b, double rtol, double atol)
+{
+    if (isfinite(a) && isfinite(b)) return fabs(a - b) <= atol + rtol * fabs(b);
+    return a == b;
+}
+
+/*
+ * One Bellman backup for M models (M = 1, robust = 0: value_iteration.py:51-63;
+ * M >= 1, robust = 1: robust_value_iteration.py:39-58).
+ *   mode 0 deterministic: T int64 [M,S,A]
+ *   mode 1 stochastic   : P double [M,S,A,S]
+ *   mode 2 sparse       : P double [S,A,B], NXT int64 [S,A,B]   (plain VI only)
+ * v[S] in, q[S,A] out.  `scratch` holds max(S, B) doubles.
+ */
+static void orc_bellman(int mode, int M, int S, int A, int B, const int64_t *T, const double *P,
+                        const int64_t *NXT, const double *R, const uint8_t *term, int robust,
+                        double gamma, const double *v, double *q, double *scratch)
+{
+    for (int s = 0; s < S; ++s) {
+        for (int a = 0; a < A; ++a) {
+            double best = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const long sa = ((long)m * S + s) * A + a;
+                double next_v;
+                if (mode == 0) {
+                    next_v = v[T[sa]];
+                } else if (mode == 1) {
+                    const double *row = P + sa * (long)S;
+                    for (int k = 0; k < S; ++k) scratch[k] = row[k] * v[k];
+                    next_v = 0.0 + orc_pairwise_sum(scratch, S);
+                } else {
+                    for (int b = 0; b < B; ++b) scratch[b] = P[sa * B + b] * v[NXT[sa * B + b]];
+                    next_v = 0.0 + orc_pairwise_sum(scratch, B);
+                }
+                if (!robust && term && term[s]) next_v = 0.0; /* value_iteration.py:62 */
+                const double qm = R[sa] + gamma * next_v;
+                if (m == 0 || qm < best) best = qm;            /* robust_value_iteration.py:46-48 */
+            }
+            q[(long)s * A + a] = best;
+        }
+    }
+}
+
+/* value_iteration.py:42-45,65-73 (fixed_point_iteration on Q, allclose early exit returns the
+ * PREVIOUS iterate) and robust_value_iteration.py:39-44. */
+int orc_vi_solve(int mode, int M, int S, int A, int B, const int64_t *T, const double *P,
+                 const int64_t *NXT, const double *R, const uint8_t *term, int robust, double gamma,
+                 int iterations, double rtol, double atol, double *q_out, int32_t *sweeps_out)
+{
+    const long n = (long)S * A;
+    double *q = calloc(n, sizeof(double)), *qn = malloc(n * sizeof(double));
+    double *v = malloc(S * sizeof(double)), *scratch = malloc(((S > B ? S : B) + 8) * sizeof(double));
+    if (!q || !qn || !v || !scratch) return ORC_ERR_ALLOC;
+    int sweeps = 0;
+    for (int it = 0; it < iterations; ++it) {
+        for (int s = 0; s < S; ++s) { /* best_action_value: q.max(axis=-1) */
+            double m = q[(long)s * A];
+            for (int a = 1; a < A; ++a) if (q[(long)s * A + a] > m) m = q[(long)s * A + a];
+            v[s] = m;
+        }
+        orc_bellman(mode, M, S, A, B, T, P, NXT, R, term, robust, gamma, v, qn, scratch);
+        ++sweeps;
+        int close = 1;
+        for (long i = 0; i < n && close; ++i) close = orc_isclose(q[i], qn[i], rtol, atol);
+        if (close) break;
+        double *t = q; q = qn; qn = t;
+    }
+    memcpy(q_out, q, n * sizeof(double));
+    if (sweeps_out) *sweeps_out = sweeps;
+    free(q); free(qn); free(v); free(scratch);
+    return ORC_OK;
+}
+
+/* value_iteration.py:37-40 get_state_value (V-form iteration) */
+int orc_vi_solve_v(int mode, int S, int A, int B, const int64_t *T, const double *P, const int64_t *NXT,
+                   const double *R, const uint8_t *term, double gamma, int iterations, double rtol,
+                   double atol, double *v_out)
+{
+    const long n = (long)S * A;
+    double *q = malloc(n * sizeof(double)), *v = calloc(S, sizeof(double)), *vn = malloc(S * sizeof(double));
+    double *scratch = malloc(((S > B ? S : B) + 8) * sizeof(double));
+    if (!q || !v || !vn || !scratch) return ORC_ERR_ALLOC;
+    for (int it = 0; it < iterations; ++it) {
+        orc_bellman(mode, 1, S, A, B, T, P, NXT, R, term, 0, gamma, v, q, scratch);
+        for (int s = 0; s < S; ++s) {
+            double m = q[(long)s * A];
+            for (int a = 1; a < A; ++a) if (q[(long)s * A + a] > m) m = q[(long)s * A + a];
+            vn[s] = m;
+        }
+        int close = 1;
+        for (int s = 0; s < S && close; ++s) close = orc_isclose(v[s], vn[s], rtol, atol);
+        if (close) break;
+        double *t = v; v = vn; vn = t;
+    }
+    memcpy(v_out, v, S * sizeof(double));
+    free(q); free(v); free(vn); free(scratch);
+    return ORC_OK;
+}
+
+/* ------------------------------------------------------------------ table environment ---- */
+/* Deterministic finite-MDP env clone: rl_agents_amd/envs/finite_mdp.py restates the absent
+ * `finite_mdp` package; a clone (common/factory.py:119-134 safe_deepcopy_env) is {state, steps}. */
+typedef struct {
+    int S, A;
+    const int64_t *T;    /* [S,A] */
+    const double *R;     /* [S,A] */
+    const uint8_t *term; /* [S]   */
+    int done_on_next;    /* 0: terminated = term[s] (default), 1: term[s'] */
+    int max_steps;       /* 0 = no truncation */
+} orc_env;
+
+static inline void orc_env_step(const orc_env *e, int32_t *s, int32_t *steps, int a, double *reward,
+                                int *terminated, int *truncated)
+{
+    const long sa = (long)(*s) * e->A + a;
+    const int32_t sn = (int32_t)e->T[sa];
+    *reward = e->R[sa];
+    *terminated = e->done_on_next ? e->term[sn] : e->term[*s];
+    *s = sn;
+    *steps += 1;
+    *truncated = e->max_steps > 0 && *steps >= e->max_steps;
+}
+
+/* ------------------------------------------------------------------ OPD ------------------ */
+/*
+ * deterministic.py:9-122 for one root.  Node arrays are in creation order (root = 0, the A
+ * children of the k-th expanded leaf = 1 + k*A ... ), capacity 1 + (budget/A)*A.
+ * Outputs may be NULL.  Returns ORC_ERR_REWARD_RANGE where the reference raises ValueError.
+ */
+int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                 int32_t s0, int budget, double gamma, double terminal_reward, uint64_t *rng6,
+                 int max_plan_len, int32_t *plan, int32_t *plan_len, double *root_lower, double *root_upper,
+                 int64_t *env_steps,
+                 /* optional tree export, capacity n_nodes = 1 + (budget/A)*A */
+                 int32_t *t_parent, int32_t *t_action, int32_t *t_state, int32_t *t_depth, double *t_reward,
+                 double *t_lower, double *t_upper, uint8_t *t_done, int64_t *t_count, int32_t *t_first_child)
+{
+    orc_env env = {S, A, T, R, term, done_on_next, 0};
+    const int K = budget / A; /* deterministic.py:118 */
+    const int cap = 1 + K * A;
+    int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
+    int32_t *state = malloc(cap * sizeof(int32_t)), *depth = malloc(cap * sizeof(int32_t));
+    int32_t *first_child = malloc(cap * sizeof(int32_t)), *leaves = malloc(cap * sizeof(int32_t));
+    double *lower = malloc(cap * sizeof(double)), *upper = malloc(cap * sizeof(double));
+    double *reward = malloc(cap * sizeof(double));
+    uint8_t *done = malloc(cap);
+    int64_t *count = malloc(cap * sizeof(int64_t));
+    if (!parent || !action || !state || !depth || !first_child || !leaves || !lower || !upper || !reward ||
+        !done || !count)
+        return ORC_ERR_ALLOC;
+    int rc = ORC_OK;
+    int64_t steps_taken = 0;
+    /* deterministic.py:10-19: root */
+    parent[0] = -1; action[0] = -1; state[0] = s0; depth[0] = 0; first_child[0] = -1;
+    lower[0] = 0; upper[0] = 0; reward[0] = 0; done[0] = 0; count[0] = 1;
+    int n_nodes = 1, n_leaves = 1;
+    leaves[0] = 0;
+    for (int k = 0; k < K && rc == ORC_OK; ++k) {
+        /* deterministic.py:110: max(self.leaves, key=U) -> first maximal element in list order */
+        int li = 0;
+        for (int i = 1; i < n_leaves; ++i)
+            if (upper[leaves[i]] > upper[leaves[li]]) li = i;
+        const int leaf = leaves[li];
+        /* deterministic.py:29: leaves.remove(self) keeps the order of the others */
+        memmove(leaves + li, leaves + li + 1, (n_leaves - li - 1) * sizeof(int32_t));
+        --n_leaves;
+        first_child[leaf] = n_nodes;
+        for (int a = 0; a < A; ++a) { /* deterministic.py:36-43 */
+            const int c = n_nodes++;
+            parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1;
+            int32_t s = state[leaf], st = 0;
+            double r; int terminated, truncated;
+            orc_env_step(&env, &s, &st, a, &r, &terminated, &truncated);
+            ++steps_taken;
+            state[c] = s;
+            leaves[n_leaves++] = c;
+            /* deterministic.py:45-65 update() */
+            if (!(0 <= r) || !(r <= 1)) { rc = ORC_ERR_REWARD_RANGE; break; }
+            const int d = depth[c];
+            reward[c] = r; done[c] = (uint8_t)terminated;
+            lower[c] = lower[leaf] + pow(gamma, d - 1) * r;
+            upper[c] = lower[c] + pow(gamma, d) / (1 - gamma);
+            if (terminated) {
+                const double nv = lower[c] + terminal_reward * pow(gamma, d) / (1 - gamma);
+                lower[c] = nv; upper[c] = nv;
+            }
+            count[c] = 1;
+            for (int n = c; n >= 0; n = parent[n]) count[n] += 1;
+        }
+        if (rc != ORC_OK) break;
+        /* deterministic.py:74-79 backup_to_root */
+        for (int n = leaf; n >= 0; n = parent[n]) {
+            double ml = lower[first_child[n]], mu = upper[first_child[n]];
+            for (int a = 1; a < A; ++a) {
+                if (lower[first_child[n] + a] > ml) ml = lower[first_child[n] + a];
+                if (upper[first_child[n] + a] > mu) mu = upper[first_child[n] + a];
+            }
+            lower[n] = ml; upper[n] = mu;
+        }
+    }
+    if (rc == ORC_OK) {
+        /* abstract.py:143-156 get_plan with deterministic.py:21-26 selection_rule */
+        orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
+        int n = 0, len = 0;
+        while (first_child[n] >= 0) {
+            const int fc = first_child[n];
+            double m = lower[fc];
+            for (int a = 1; a < A; ++a) if (lower[fc + a] > m) m = lower[fc + a];
+            int ties[64], nt = 0;
+            for (int a = 0; a < A && nt < 64; ++a) if (lower[fc + a] == m) ties[nt++] = a;
+            const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            if (plan && len < max_plan_len) plan[len] = a;
+            ++len;
+            n = fc + a;
+        }
+        if (plan) for (int i = len; i < max_plan_len; ++i) plan[i] = -1;
+        if (plan_len) *plan_len = len;
+        rng6[0] = g.s_hi; rng6[1] = g.s_lo; rng6[2] = g.inc_hi; rng6[3] = g.inc_lo;
+        rng6[4] = g.has_uint32; rng6[5] = g.uinteger;
+        if (root_lower) *root_lower = lower[0];
+        if (root_upper) *root_upper = upper[0];
+    }
+    if (env_steps) *env_steps = steps_taken;
+    for (int i = 0; i < n_nodes; ++i) {
+        if (t_parent) t_parent[i] = parent[i];
+        if (t_action) t_action[i] = action[i];
+        if (t_state) t_state[i] = state[i];
+        if (t_depth) t_depth[i] = depth[i];
+        if (t_reward) t_reward[i] = reward[i];
+        if (t_lower) t_lower[i] = lower[i];
+        if (t_upper) t_upper[i] = upper[i];
+        if (t_done) t_done[i] = done[i];
+        if (t_count) t_count[i] = count[i];
+        if (t_first_child) t_first_child[i] = first_child[i];
+    }
+    free(parent); free(action); free(state); free(depth); free(first_child); free(leaves);
+    free(lower); free(upper); free(reward); free(done); free(count);
+    return rc;
+}
+
+/* ------------------------------------------------------------------ UCT ------------------ */
+/*
+ * mcts.py:100-184 (MCTS planner) + mcts.py:203-286 (MCTSNode) for one root, open loop.
+ * prior[a] / rollout_cdf[a]: the state-independent policies of mcts.py:46-97 over actions
+ * 0..A-1 (a table env has no get_available_actions); the cdf is numpy's cumsum(p)/cumsum(p)[-1].
+ * Node arrays are in creation order: root = 0, each expansion appends A children.
+ * Capacity 1 + episodes*A (one expansion per episode at most, mcts.py:151-154).
+ */
+int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                 int max_steps, int32_t s0, int32_t steps0, int episodes, int horizon, double gamma,
+                 double temperature, const double *prior, const double *rollout_cdf, uint64_t *rng6,
+                 int max_plan_len, int32_t *plan, int32_t *plan_len, int64_t *env_steps,
+                 /* optional tree export, capacity 1 + episodes*A */
+                 int32_t *t_parent, int32_t *t_action, int64_t *t_count, double *t_value,
+                 int32_t *t_first_child, int32_t *n_nodes_out)
+{
+    orc_env env = {S, A, T, R, term, done_on_next, max_steps};
+    const int cap = 1 + episodes * A;
+    int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
+    int32_t *first_child = malloc(cap * sizeof(int32_t));
+    int64_t *count = malloc(cap * sizeof(int64_t));
+    double *value = malloc(cap * sizeof(double)), *gpow = malloc((horizon + 1) * sizeof(double));
+    double *score = malloc((A > 0 ? A : 1) * sizeof(double));
+    int *ties = malloc((A > 0 ? A : 1) * sizeof(int));
+    if (!parent || !action || !first_child || !count || !value || !gpow || !score || !ties) return ORC_ERR_ALLOC;
+    for (int h = 0; h <= horizon; ++h) gpow[h] = pow(gamma, h); /* Python: gamma ** h */
+    orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
+    /* mcts.py:129-130 reset(): fresh root (value 0, count 0, prior 1) */
+    parent[0] = -1; action[0] = -1; first_child[0] = -1; count[0] = 0; value[0] = 0;
+    int n_nodes = 1;
+    int64_t steps_taken = 0;
+    for (int ep = 0; ep < episodes; ++ep) { /* mcts.py:179-184 */
+        int32_t s = s0, st = steps0;     /* safe_deepcopy_env(state) */
+        int node = 0, depth = 0, terminal = 0, truncated = 0;
+        double total_reward = 0;
+        /* mcts.py:143-149 selection */
+        while (depth < horizon && first_child[node] >= 0 && !terminal) {
+            const int fc = first_child[node];
+            /* mcts.py:275-286: value + temperature * len(parent.children) * prior / (count + 1) */
+            double m = 0;
+            for (int a = 0; a < A; ++a) {
+                score[a] = value[fc + a] + temperature * A * prior[a] / (double)(count[fc + a] + 1);
+                if (a == 0 || score[a] > m) m = score[a];
+            }
+            int nt = 0;
+            for (int a = 0; a < A; ++a) if (score[a] == m) ties[nt++] = a; /* abstract.py:296-311 */
+            const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            double r;
+            orc_env_step(&env, &s, &st, a, &r, &terminal, &truncated);
+            ++steps_taken;
+            total_reward += gpow[depth] * r;
+            node = fc + a;
+            ++depth;
+        }
+        /* mcts.py:151-154 expansion */
+        if (first_child[node] < 0 && depth < horizon && (!terminal || node == 0)) {
+            first_child[node] = n_nodes;
+            for (int a = 0; a < A; ++a) {
+                const int c = n_nodes++;
+                parent[c] = node; action[c] = a; first_child[c] = -1; count[c] = 0; value[c] = 0;
+            }
+        }
+        /* mcts.py:156-157,160-177 rollout */
+        if (!terminal) {
+            for (int h = depth; h < horizon; ++h) {
+                const int a = orc_cdf_pick(rollout_cdf, A, orc_pcg64_double(&g));
+                double r; int term_h, trunc_h;
+                orc_env_step(&env, &s, &st, a, &r, &term_h, &trunc_h);
+                ++steps_taken;
+                total_reward += gpow[h] * r;
+                if (term_h || trunc_h) break;
+            }
+        }
+        /* mcts.py:248-265 update_branch */
+        for (int n = node; n >= 0; n = parent[n]) {
+            count[n] += 1;
+            value[n] += 1.0 / (double)count[n] * (total_reward - value[n]);
+        }
+    }
+    /* abstract.py:143-156 get_plan with mcts.py:212-218 selection_rule */
+    int n = 0, len = 0;
+    while (first_child[n] >= 0) {
+        const int fc = first_child[n];
+        int64_t mc = count[fc];
+        for (int a = 1; a < A; ++a) if (count[fc + a] > mc) mc = count[fc + a];
+        int best = -1;
+        for (int a = 0; a < A; ++a)
+            if (count[fc + a] == mc && (best < 0 || value[fc + a] > value[fc + best])) best = a;
+        if (plan && len < max_plan_len) plan[len] = best;
+        ++len;
+        n = fc + best;
+    }
+    if (plan) for (int i = len; i < max_plan_len; ++i) plan[i] = -1;
+    if (plan_len) *plan_len = len;
+    if (env_steps) *env_steps = steps_taken;
+    rng6[0] = g.s_hi; rng6[1] = g.s_lo; rng6[2] = g.inc_hi; rng6[3] = g.inc_lo;
+    rng6[4] = g.has_uint32; rng6[5] = g.uinteger;
+    for (int i = 0; i < n_nodes; ++i) {
+        if (t_parent) t_parent[i] = parent[i];
+        if (t_action) t_action[i] = action[i];
+        if (t_count) t_count[i] = count[i];
+        if (t_value) t_value[i] = value[i];
+        if (t_first_child) t_first_child[i] = first_child[i];
+    }
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+    free(parent); free(action); free(first_child); free(count); free(value); free(gpow); free(score); free(ties);
+    return ORC_OK;
+}
+
+/*
+ * Batch drivers for the cpu_baseline leg of bench.py and for many-root parity checks:
+ * independent roots, one RNG state each, OpenMP over roots (the reference's own fan-out is one
+ * process per experiment, scripts/experiments.py:105).  Per-root outputs only (no trees).
+ */
+int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                       int max_steps, int n_roots, const int32_t *s0, const int32_t *steps0, int episodes,
+                       int horizon, double gamma, double temperature, const double *prior,
+                       const double *rollout_cdf, uint64_t *rng6 /* [n_roots,6] */, int max_plan_len,
+                       int32_t *plans /* [n_roots,max_plan_len] */, int32_t *plan_len, double *root_value,
+                       int64_t *root_child_count /* [n_roots,A] */, double *root_child_value /* [n_roots,A] */,
+                       int64_t *env_steps /* [n_roots] */, int n_threads)
+{
+    int rc_all = ORC_OK;
+    const int cap = 1 + episodes * A;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n_roots; ++i) {
+        int64_t *cnt = malloc(cap * sizeof(int64_t));
+        double *val = malloc(cap * sizeof(double));
+        int32_t nn = 0;
+        int rc = orc_uct_plan(S, A, T, R, term, done_on_next, max_steps, s0[i], steps0 ? steps0[i] : 0, episodes,
+                              horizon, gamma, temperature, prior, rollout_cdf, rng6 + (long)i * 6, max_plan_len,
+                              plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
+                              env_steps ? env_steps + i : NULL, NULL, NULL, cnt, val, NULL, &nn);
+        if (rc != ORC_OK) {
+#pragma omp critical
+            rc_all = rc;
+        }
+        if (root_value) root_value[i] = val[0];
+        for (int a = 0; a < A; ++a) {
+            if (root_child_count) root_child_count[(long)i * A + a] = nn > 1 ? cnt[1 + a] : 0;
+            if (root_child_value) root_child_value[(long)i * A + a] = nn > 1 ? val[1 + a] : 0;
+        }
+        free(cnt); free(val);
+    }
+    return rc_all;
+}
+
+int orc_opd_plan_batch(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                       int n_roots, const int32_t *s0, int budget, double gamma, double terminal_reward,
+                       uint64_t *rng6, int max_plan_len, int32_t *plans, int32_t *plan_len, double *root_lower,
+                       double *root_upper, int64_t *env_steps, int32_t *status /* [n_roots] */, int n_threads)
+{
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n_roots; ++i) {
+        int rc = orc_opd_plan(S, A, T, R, term, done_on_next, s0[i], budget, gamma, terminal_reward,
+                              rng6 + (long)i * 6, max_plan_len, plans ? plans + (long)i * max_plan_len : NULL,
+                              plan_len ? plan_len + i : NULL, root_lower ? root_lower + i : NULL,
+                              root_upper ? root_upper + i : NULL, env_steps ? env_steps + i : NULL, NULL, NULL,
+                              NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+        if (status) status[i] = rc;
+    }
+    return ORC_OK;
+}

@@ -1,0 +1,155 @@
+"""Pin the CPU oracle (oracle/planning_oracle.c) to the reference: every entry point must reproduce,
+bit for bit, what the unmodified Python reference computed (tests/golden/*.npz)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.helpers import mdp_from_golden, assert_tree_equal
+
+
+def test_olop_allocation(golden):
+    z = golden["misc"]
+    for (b, g), (e, h) in zip(z["alloc/in"], z["alloc/out"]):
+        assert oracle.olop_allocation(int(b), float(g)) == (int(e), int(h))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 12345, 2 ** 40 + 17])
+def test_pcg64_matches_numpy_generator(golden, seed):
+    z = golden["misc"]
+    p = "pcg/seed{}".format(seed)
+    outs, st = oracle.pcg64_replay(z[p + "/state0"], z[p + "/ops"])
+    np.testing.assert_array_equal(outs, z[p + "/outs"])
+    np.testing.assert_array_equal(st, z[p + "/state1"])
+
+
+def test_pcg64_live_against_numpy():
+    """Same pin, regenerated live from numpy (not only from the stored fixture)."""
+    for seed in (3, 77):
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(seed)))
+        st = g.bit_generator.state
+        m = (1 << 64) - 1
+        s6 = [st["state"]["state"] >> 64, st["state"]["state"] & m, st["state"]["inc"] >> 64,
+              st["state"]["inc"] & m, st["has_uint32"], st["uinteger"]]
+        ops = np.random.Generator(np.random.PCG64(seed)).integers(0, 12, size=3000)
+        want = np.array([g.random() if k == 0 else g.choice(np.arange(k)) for k in ops], dtype=np.float64)
+        outs, _ = oracle.pcg64_replay(s6, ops)
+        np.testing.assert_array_equal(outs, want)
+
+
+def test_choice_with_probabilities(golden):
+    z = golden["misc"]
+    st = z["pchoice/state0"]
+    for j in range(4):
+        outs, st = oracle.pchoice_replay(st, z["pchoice/p{}".format(j)], 200)
+        np.testing.assert_array_equal(outs, z["pchoice/out{}".format(j)])
+    np.testing.assert_array_equal(st, z["pchoice/state1"])
+
+
+def _vi_names(golden):
+    return [str(n) for n in golden["vi"]["vi/names"]]
+
+
+def test_value_iteration_all_cases(golden):
+    z = golden["vi"]
+    for name in _vi_names(golden):
+        p = "vi/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        q, sweeps = oracle.vi_solve(cfg["mode"], cfg["transition"], cfg["reward"], cfg["terminal"],
+                                    gamma=float(z[p + "/gamma"]), iterations=int(z[p + "/iterations"]),
+                                    next_states=cfg.get("next"))
+        assert sweeps == int(z[p + "/sweeps"]), name
+        assert np.array_equal(q, z[p + "/Q"]), name
+        np.testing.assert_array_equal(q.argmax(axis=1), z[p + "/actions"])
+        v = oracle.vi_solve(cfg["mode"], cfg["transition"], cfg["reward"], cfg["terminal"],
+                            gamma=float(z[p + "/gamma"]), iterations=int(z[p + "/iterations"]),
+                            next_states=cfg.get("next"), state_value=True)
+        assert np.array_equal(v, z[p + "/V"]), name
+
+
+def test_robust_value_iteration_all_cases(golden):
+    z = golden["vi"]
+    for name in [str(n) for n in z["rvi/names"]]:
+        p = "rvi/" + name
+        q, sweeps = oracle.vi_solve(str(z[p + "/mode"]), z[p + "/transitions"], z[p + "/rewards"], None,
+                                    gamma=float(z[p + "/gamma"]), iterations=int(z[p + "/iterations"]), robust=True)
+        assert sweeps == int(z[p + "/sweeps"]), name
+        assert np.array_equal(q, z[p + "/Q"]), name
+        n = len(z[p + "/actions"])
+        np.testing.assert_array_equal(q.argmax(axis=1)[:n], z[p + "/actions"])
+
+
+def test_dense_sum_matches_numpy_at_scale():
+    """numpy pairwise summation restated: (T*v).sum(-1) bit-exact for a row length past the 128 block."""
+    rng = np.random.default_rng(0)
+    s, a = 1111, 2
+    t = rng.random((s, a, s))
+    t /= t.sum(-1, keepdims=True)
+    r = rng.random((s, a))
+    q, _ = oracle.vi_solve("stochastic", t, r, np.zeros(s, bool), gamma=0.9, iterations=3)
+    want = np.zeros((s, a))
+    for _ in range(3):
+        want = r + 0.9 * (t * want.max(-1).reshape(1, 1, s)).sum(-1)
+    assert np.array_equal(q, want)
+
+
+def test_opd_all_cases(golden):
+    z = golden["opd"]
+    for name in [str(n) for n in z["opd/names"]]:
+        p = "opd/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        out = oracle.opd_plan(cfg["transition"], cfg["reward"], cfg["terminal"], int(z[p + "/s0"]),
+                              int(z[p + "/budget"]), float(z[p + "/gamma"]), float(z[p + "/terminal_reward"]),
+                              rng_state=z[p + "/rng_before"])
+        np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+        assert out["root_lower"] == float(z[p + "/root_lower"]), name
+        assert out["root_upper"] == float(z[p + "/root_upper"]), name
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        assert out["tree"]["count"][0] == int(z[p + "/root_count"])
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"])
+        a = cfg["reward"].shape[1]
+        assert_tree_equal(z, p + "/tree", out["tree"], a,
+                          dict(count="count", lower="lower", upper="upper", reward="reward", done="done",
+                               depth="depth"))
+
+
+def test_opd_reward_range_error(golden):
+    assert bool(golden["opd"]["opd/trap_raises_valueerror"])
+    t = [[1, 2], [1, 1], [3, 4], [3, 3], [4, 4]]
+    r = [[0, 0], [0, 0], [0, 0], [1, 1], [-1, -1]]
+    with pytest.raises(ValueError):
+        oracle.opd_plan(t, r, [0, 1, 0, 1, 1], 0, 20, 0.8)
+
+
+def test_uct_all_cases(golden):
+    z = golden["uct"]
+    for name in [str(n) for n in z["uct/names"]]:
+        p = "uct/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        a = cfg["reward"].shape[1]
+        np.testing.assert_array_equal(z[p + "/prior_actions"], np.arange(a))
+        out = oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], int(z[p + "/s0"]),
+                              int(z[p + "/episodes"]), int(z[p + "/horizon"]), float(z[p + "/gamma"]),
+                              float(z[p + "/temperature"]), z[p + "/prior_p"], z[p + "/rollout_p"],
+                              z[p + "/rng_before"], steps0=int(z[p + "/steps0"]), max_steps=cfg["max_steps"])
+        np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+        assert out["tree"]["count"][0] == int(z[p + "/root_count"])
+        assert out["tree"]["value"][0] == float(z[p + "/root_value"])
+        assert_tree_equal(z, p + "/tree", out["tree"], a, dict(count="count", value="value"))
+
+
+def test_uct_batch_equals_single(golden):
+    z = golden["uct"]
+    p = "uct/highway_small_seed0"
+    cfg = mdp_from_golden(z, p + "/mdp")
+    rng = np.stack([z["uct/highway_small_seed{}/rng_before".format(s)] for s in (0, 1, 2)])
+    out = oracle.uct_plan_batch(cfg["transition"], cfg["reward"], cfg["terminal"], [0, 0, 0], 33, 30, 0.8,
+                                float(z[p + "/temperature"]), z[p + "/prior_p"], z[p + "/rollout_p"], rng,
+                                n_threads=2)
+    for i, s in enumerate((0, 1, 2)):
+        q = "uct/highway_small_seed{}".format(s)
+        n = len(z[q + "/plan"])
+        np.testing.assert_array_equal(out["plans"][i, :n], z[q + "/plan"])
+        assert out["root_value"][i] == float(z[q + "/root_value"])
+        assert out["env_steps"][i] == int(z[q + "/env_steps"])
