@@ -1,0 +1,182 @@
+/*
+ * mi355plan.h -- C ABI of libmi355plan.so, the MI355X (gfx950) planning core.
+ *
+ * The reference (eleurent/rl-agents) is pure Python and has no FFI; this header is the boundary a
+ * maintainer binds (ctypes / cffi ABI mode) to replace the bodies of the
+ * reference functions cited on each entry point.  Citations are relative to /root/reference.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative MP_ERR_* code; it never throws.
+ *     mp_last_error() returns a thread-local, human-readable message for the last failure.
+ *   - mp_ctx owns one HIP device + one stream + growable device workspaces.  Not thread-safe per
+ *     ctx; use one ctx per (process, GPU).
+ *   - array arguments are C-contiguous.  `mem` selects where the caller's arrays live:
+ *       MP_MEM_HOST   (0): host pointers; the call copies in, runs, copies out and synchronises.
+ *       MP_MEM_DEVICE (1): device pointers on the ctx device (e.g. torch tensors' data_ptr());
+ *                          the call only enqueues work on the ctx stream and returns.
+ *     Output pointers may be NULL when the caller does not want that output.
+ *   - all floating point is IEEE double evaluated in the reference's operation order with no
+ *     fused multiply-add; integer indices are int32 on the device (tables are accepted as the
+ *     int64 numpy arrays the reference holds and range-checked on upload).
+ */
+#ifndef MI355PLAN_H
+#define MI355PLAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_ABI_VERSION 1
+
+#define MP_OK 0
+#define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
+#define MP_ERR_REWARD_RANGE (-2) /* OPD: reward outside [0,1] (deterministic.py:46-47 ValueError) */
+#define MP_ERR_ALLOC (-3)
+#define MP_ERR_ARG (-4)          /* invalid argument / unsupported configuration                  */
+#define MP_ERR_MODE (-5)         /* model kind not valid for this call ("Unknown mode")           */
+
+#define MP_MEM_HOST 0
+#define MP_MEM_DEVICE 1
+
+/* model kinds (value_iteration.py:51-61 `mode`) */
+#define MP_MODE_DETERMINISTIC 0
+#define MP_MODE_STOCHASTIC 1
+#define MP_MODE_SPARSE 2
+#define MP_MODE_CARTPOLE 3
+
+typedef struct mp_ctx mp_ctx;
+typedef struct mp_model mp_model;
+
+const char *mp_last_error(void);
+int mp_abi_version(void);
+
+/* ---------------------------------------------------------------- context ------------------- */
+/* `stream`: a hipStream_t to enqueue on (e.g. torch.cuda.current_stream().cuda_stream), or NULL
+ * to let the ctx create and own a stream. */
+int mp_ctx_create(int device, void *stream, mp_ctx **out);
+int mp_ctx_destroy(mp_ctx *ctx);
+int mp_ctx_set_stream(mp_ctx *ctx, void *stream);
+int mp_ctx_synchronize(mp_ctx *ctx);
+/* device facts for reports: compute units, wavefront size, LDS bytes per workgroup, HBM bytes */
+int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *lds_bytes, int64_t *hbm_bytes,
+                       char *name, int32_t name_cap);
+
+/* ---------------------------------------------------------------- transition models ---------- */
+/*
+ * Deterministic finite-MDP tables: what the planners reach through env.step on a FiniteMDPEnv
+ * (tree_search/abstract.py:158-161) and value iteration through mdp.transition / mdp.reward /
+ * mdp.terminal (dynamic_programming/value_iteration.py:52-53,62-63).  Replaces
+ * common/factory.py:119-134 safe_deepcopy_env: a cloned environment is an (int32 state,
+ * int32 steps) pair on the device.
+ *   transition int64 [M,S,A], reward double [M,S,A], terminal uint8 [S] or NULL.
+ *   M > 1 = several models of one MDP (robust_value_iteration.py:21-27); tree search uses model 0.
+ *   done_on_next: 0 -> terminated = terminal[s] (state acted FROM), 1 -> terminal[s'].
+ *   max_steps: TimeLimit-style truncation for rollouts, 0 = none.
+ * Always host pointers (model upload is outside every timed region).
+ */
+int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition,
+                        const double *reward, const uint8_t *terminal, int32_t done_on_next, int32_t max_steps,
+                        mp_model **out);
+/*
+ * Dense stochastic model (value_iteration.py:54-55, robust_value_iteration.py:55-56):
+ *   transition double [M,S,A,S], reward double [M,S,A], terminal uint8 [S] or NULL.
+ * mem = MP_MEM_DEVICE borrows the caller's device arrays (no copy; they must outlive the model).
+ */
+int mp_model_load_dense(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const double *transition,
+                        const double *reward, const uint8_t *terminal, int32_t mem, mp_model **out);
+/* Sparse model (value_iteration.py:56-59): transition double [S,A,B], next int64 [S,A,B]. */
+int mp_model_load_sparse(mp_ctx *ctx, int32_t S, int32_t A, int32_t B, const double *transition,
+                         const int64_t *next, const double *reward, const uint8_t *terminal, mp_model **out);
+/*
+ * Closed-form CartPole (gymnasium CartPole-v0/v1 dynamics, absent from this image; restated in
+ * rl_agents_amd/envs/cartpole.py).  A clone is (x, x_dot, theta, theta_dot, steps).
+ */
+typedef struct {
+    double gravity, masscart, masspole, length, force_mag, tau;
+    double theta_threshold, x_threshold;
+    int32_t max_steps;       /* TimeLimit: 200 for CartPole-v0 */
+    int32_t euler;           /* 1 = explicit Euler (gymnasium default) */
+} mp_cartpole_params;
+int mp_model_load_cartpole(mp_ctx *ctx, const mp_cartpole_params *params, mp_model **out);
+int mp_model_free(mp_model *model);
+int mp_model_info(const mp_model *model, int32_t *mode, int32_t *M, int32_t *S, int32_t *A, int32_t *B);
+
+/* ---------------------------------------------------------------- value iteration ----------- */
+/*
+ * ValueIterationAgent.get_state_action_value (value_iteration.py:42-45) =
+ * fixed_point_iteration (:65-73) of bellman_expectation(best_action_value(q)) (:47-63) from
+ * Q0 = 0, with numpy.allclose(rtol, atol) early exit returning the PREVIOUS iterate; and, with
+ * robust = 1, RobustValueIterationAgent.get_state_action_value (robust_value_iteration.py:39-58):
+ * min over the M models, no terminal masking.
+ *   Q_out double [S,A]; sweeps_out int32 [1] = Bellman sweeps actually executed.
+ * Deterministic and sparse (B < 8) modes are bit-exact with the reference; the dense mode
+ * accumulates on the f64 matrix cores in a different order than numpy's pairwise sum
+ * (relative error ~1e-15 per sweep).
+ */
+int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                int32_t robust, double *Q_out, int32_t *sweeps_out, int32_t mem);
+/* get_state_value (value_iteration.py:37-40): the V-form iteration.  V_out double [S]. */
+int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                  double *V_out, int32_t mem);
+/* Timing hook: run exactly `sweeps` Bellman sweeps (no early exit), Q left on the device. */
+int mp_vi_sweeps(mp_ctx *ctx, mp_model *model, double gamma, int32_t sweeps, int32_t robust);
+
+/* ---------------------------------------------------------------- UCT ----------------------- */
+/*
+ * MCTS.plan (tree_search/mcts.py:179-184) for n_roots independent roots: `episodes` iterations of
+ * MCTS.run (:132-158: select by MCTSNode.selection_strategy :275-286 with random tie-break
+ * abstract.py:296-311, expand :237-246, rollout MCTS.evaluate :160-177, backup
+ * MCTSNode.update_branch :248-265), then AbstractPlanner.get_plan (abstract.py:143-156) with
+ * MCTSNode.selection_rule (mcts.py:212-218).  Open loop (closed_loop = False).
+ *   root_state  : table model int32 [n_roots]; cartpole double [n_roots,4]
+ *   root_steps  : int32 [n_roots] env.steps at plan time (TimeLimit), or NULL = 0
+ *   prior_p     : double [A]  prior over actions 0..A-1   (mcts.py:46-97 policies)
+ *   rollout_p   : double [A]  rollout distribution; sampled as numpy Generator.choice(p=...)
+ *   rng_state   : uint64 [n_roots,6] numpy PCG64 state {state_hi, state_lo, inc_hi, inc_lo,
+ *                 has_uint32, uinteger}; advanced in place exactly as the reference's
+ *                 planner.np_random would be (so plans are bit-identical at equal seeds)
+ *   plans       : int32 [n_roots,max_plan_len], -1 padded;  plan_len int32 [n_roots]
+ *   root_value  : double [n_roots];  root_child_count int64 [n_roots,A];
+ *   root_child_value double [n_roots,A];  env_steps int64 [n_roots] (= len(planner.observations))
+ */
+int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_state, const int32_t *root_steps,
+                int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
+                const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
+                int64_t *env_steps, int32_t mem);
+/* Tree of root `root` after the last mp_uct_plan on this ctx, creation order (root = node 0, the
+ * A children of an expanded node are contiguous).  Host arrays of capacity `cap` nodes. */
+int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
+                       int64_t *count, double *value, int32_t *first_child);
+
+/* ---------------------------------------------------------------- OPD ----------------------- */
+/*
+ * OptimisticDeterministicPlanner.plan (tree_search/deterministic.py:116-122) for n_roots
+ * independent roots: budget // A times run() (:106-114: leaf = first maximal upper bound in
+ * leaves order :110, DeterministicNode.expand :28-43 with update :45-65, backup_to_root :74-79),
+ * then get_plan (abstract.py:143-156) with DeterministicNode.selection_rule (:21-26, random
+ * tie-break on exactly equal lower bounds through rng_state).
+ *   status int32 [n_roots]: MP_OK or MP_ERR_REWARD_RANGE per root (the reference raises).
+ */
+int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget,
+                double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status,
+                int32_t mem);
+/* Tree of root `root` after the last mp_opd_plan, creation order; host arrays, capacity `cap`. */
+int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
+                       int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
+                       int64_t *count, int32_t *first_child);
+
+/* ---------------------------------------------------------------- helpers ------------------- */
+/* OLOP.allocation (tree_search/olop.py:50-62) with OLOP.horizon (:42-44); host arithmetic. */
+int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t *horizon);
+/* Timing of the last kernel batch enqueued by a plan / solve call, from HIP events recorded on
+ * the ctx stream around the kernel launches only (no copies).  Synchronises the stream. */
+int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI355PLAN_H */

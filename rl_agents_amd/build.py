@@ -1,0 +1,68 @@
+"""Build libmi355plan.so (HIP, gfx950 only) in-tree with hipcc.
+
+    python -m rl_agents_amd.build [--force]
+
+The library is the product's only compute path; there is no fallback.  It is built in-tree
+(rl_agents_amd/lib/) so that it travels with the source snapshot to the GPU box.
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB_DIR = os.path.join(HERE, "lib")
+LIB_PATH = os.path.join(LIB_DIR, "libmi355plan.so")
+SOURCES = ["api.hip", "vi.hip", "uct.hip", "opd.hip"]
+HEADERS = ["common.hpp", "pcg64.hpp"]
+# -ffp-contract=off: the reference evaluates a*b+c with two roundings (Python floats); a fused
+# multiply-add would change the last bit of bounds and Q values and break bit-exact parity.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
+
+
+def hipcc():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libmi355plan.so)")
+
+
+def needs_build():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "mi355plan.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
+    if not force and not needs_build():
+        return LIB_PATH
+    os.makedirs(LIB_DIR, exist_ok=True)
+    cc = hipcc()
+    objs = []
+    procs = []
+    for src in SOURCES:
+        obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
+        cmd = [cc] + FLAGS + ["-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(obj)
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on {}:\n{}".format(src, out.decode()))
+        if verbose and out:
+            print(out.decode())
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

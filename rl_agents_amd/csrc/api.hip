@@ -1,0 +1,334 @@
+// api.hip -- context, transition-model upload and host helpers of libmi355plan.so.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+
+namespace mp {
+
+thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...)
+{
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+int ws_reserve(mp_ctx *ctx, int slot, size_t bytes, void **out)
+{
+    DevBuf &b = ctx->ws[slot];
+    if (bytes > b.cap) {
+        if (b.p) {
+            // buffers may still be referenced by enqueued work
+            MP_HIP(hipStreamSynchronize(ctx->stream));
+            MP_HIP(hipFree(b.p));
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            return fail(MP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        }
+        b.cap = want;
+    }
+    *out = b.p;
+    return MP_OK;
+}
+
+int kernels_begin(mp_ctx *ctx)
+{
+    MP_HIP(hipEventRecord(ctx->ev0, ctx->stream));
+    return MP_OK;
+}
+
+int kernels_end(mp_ctx *ctx, int n_launches)
+{
+    MP_HIP(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->timed = true;
+    ctx->n_launches = n_launches;
+    return MP_OK;
+}
+
+// packs T/R/terminal of model 0 into 16-byte records
+__global__ void pack_records(int S, int A, const int32_t *__restrict__ T, const double *__restrict__ R,
+                             const uint8_t *__restrict__ term, Rec *__restrict__ rec)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)S * A) return;
+    const int s = (int)(i / A);
+    Rec r;
+    r.next = T[i];
+    r.flags = (term && term[s] ? 1u : 0u) | (term && term[r.next] ? 2u : 0u);
+    r.reward = R[i];
+    rec[i] = r;
+}
+
+} // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+const char *mp_last_error(void) { return g_err.c_str(); }
+int mp_abi_version(void) { return MP_ABI_VERSION; }
+
+int mp_ctx_create(int device, void *stream, mp_ctx **out)
+{
+    if (!out) return fail(MP_ERR_ARG, "mp_ctx_create: out is NULL");
+    int n = 0;
+    MP_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(MP_ERR_ARG, "mp_ctx_create: device %d out of range (%d visible)", device, n);
+    MP_HIP(hipSetDevice(device));
+    mp_ctx *ctx = new mp_ctx();
+    ctx->device = device;
+    if (hipGetDeviceProperties(&ctx->prop, device) != hipSuccess) {
+        delete ctx;
+        return fail(MP_ERR_HIP, "hipGetDeviceProperties failed");
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete ctx;
+            return fail(MP_ERR_HIP, "hipStreamCreate failed");
+        }
+        ctx->own_stream = true;
+    }
+    if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return fail(MP_ERR_HIP, "hipEventCreate failed");
+    }
+    *out = ctx;
+    return MP_OK;
+}
+
+int mp_ctx_destroy(mp_ctx *ctx)
+{
+    if (!ctx) return MP_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &b : ctx->ws)
+        if (b.p) hipFree(b.p);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return MP_OK;
+}
+
+int mp_ctx_set_stream(mp_ctx *ctx, void *stream)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream) {
+        MP_HIP(hipStreamDestroy(ctx->stream));
+        ctx->own_stream = false;
+    }
+    if (stream) {
+        ctx->stream = (hipStream_t)stream;
+    } else {
+        MP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+        ctx->own_stream = true;
+    }
+    return MP_OK;
+}
+
+int mp_ctx_synchronize(mp_ctx *ctx)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    return MP_OK;
+}
+
+int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *lds_bytes, int64_t *hbm_bytes,
+                       char *name, int32_t name_cap)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    if (n_cu) *n_cu = ctx->prop.multiProcessorCount;
+    if (wave_size) *wave_size = ctx->prop.warpSize;
+    if (lds_bytes) *lds_bytes = (int64_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
+    if (hbm_bytes) *hbm_bytes = (int64_t)ctx->prop.totalGlobalMem;
+    if (name && name_cap > 0) {
+        snprintf(name, (size_t)name_cap, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    }
+    return MP_OK;
+}
+
+int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    if (!ctx->timed) return fail(MP_ERR_ARG, "no timed kernel batch on this ctx yet");
+    MP_HIP(hipEventSynchronize(ctx->ev1));
+    float f = 0.f;
+    MP_HIP(hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+    if (ms) *ms = (double)f;
+    if (n_launches) *n_launches = ctx->n_launches;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------ models --------------------
+int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition,
+                        const double *reward, const uint8_t *terminal, int32_t done_on_next, int32_t max_steps,
+                        mp_model **out)
+{
+    if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_table: NULL argument");
+    if (M < 1 || S < 1 || A < 1) return fail(MP_ERR_ARG, "mp_model_load_table: bad shape M=%d S=%d A=%d", M, S, A);
+    const size_t n = (size_t)M * S * A;
+    std::vector<int32_t> t32(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t v = transition[i];
+        if (v < 0 || v >= S) return fail(MP_ERR_ARG, "mp_model_load_table: transition[%zu] = %lld outside [0, %d)", i, (long long)v, S);
+        t32[i] = (int32_t)v;
+    }
+    MP_HIP(hipSetDevice(ctx->device));
+    mp_model *m = new mp_model();
+    m->ctx = ctx; m->mode = MP_MODE_DETERMINISTIC; m->M = M; m->S = S; m->A = A;
+    m->done_on_next = done_on_next ? 1 : 0; m->max_steps = max_steps > 0 ? max_steps : 0;
+    auto bail = [&](int rc) { mp_model_free(m); return rc; };
+    if (hipMalloc(&m->T, n * sizeof(int32_t)) != hipSuccess || hipMalloc(&m->R, n * sizeof(double)) != hipSuccess ||
+        hipMalloc(&m->rec, (size_t)S * A * sizeof(Rec)) != hipSuccess)
+        return bail(fail(MP_ERR_ALLOC, "mp_model_load_table: hipMalloc failed"));
+    if (terminal && hipMalloc(&m->term, (size_t)S) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));
+    if (hipMemcpy(m->T, t32.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->R, reward, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        (terminal && hipMemcpy(m->term, terminal, (size_t)S, hipMemcpyHostToDevice) != hipSuccess))
+        return bail(fail(MP_ERR_HIP, "mp_model_load_table: upload failed"));
+    const long sa = (long)S * A;
+    hipLaunchKernelGGL(pack_records, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T, m->R,
+                       m->term, m->rec);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(MP_ERR_HIP, "pack_records failed"));
+    *out = m;
+    return MP_OK;
+}
+
+int mp_model_load_dense(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const double *transition,
+                        const double *reward, const uint8_t *terminal, int32_t mem, mp_model **out)
+{
+    if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_dense: NULL argument");
+    if (M < 1 || S < 1 || A < 1) return fail(MP_ERR_ARG, "mp_model_load_dense: bad shape");
+    MP_HIP(hipSetDevice(ctx->device));
+    mp_model *m = new mp_model();
+    m->ctx = ctx; m->mode = MP_MODE_STOCHASTIC; m->M = M; m->S = S; m->A = A;
+    auto bail = [&](int rc) { mp_model_free(m); return rc; };
+    const size_t nr = (size_t)M * S * A, np = nr * S;
+    if (mem == MP_MEM_DEVICE) {
+        m->P = transition; m->R = const_cast<double *>(reward); m->term = const_cast<uint8_t *>(terminal);
+        m->borrowed = true;
+    } else {
+        double *p = nullptr;
+        if (hipMalloc(&p, np * sizeof(double)) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc(%zu) failed", np * 8));
+        m->P = p;
+        if (hipMalloc(&m->R, nr * sizeof(double)) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));
+        if (terminal && hipMalloc(&m->term, (size_t)S) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));
+        if (hipMemcpy(p, transition, np * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(m->R, reward, nr * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+            (terminal && hipMemcpy(m->term, terminal, (size_t)S, hipMemcpyHostToDevice) != hipSuccess))
+            return bail(fail(MP_ERR_HIP, "mp_model_load_dense: upload failed"));
+    }
+    *out = m;
+    return MP_OK;
+}
+
+int mp_model_load_sparse(mp_ctx *ctx, int32_t S, int32_t A, int32_t B, const double *transition,
+                         const int64_t *next, const double *reward, const uint8_t *terminal, mp_model **out)
+{
+    if (!ctx || !out || !transition || !reward || !next) return fail(MP_ERR_ARG, "mp_model_load_sparse: NULL argument");
+    if (S < 1 || A < 1 || B < 1) return fail(MP_ERR_ARG, "mp_model_load_sparse: bad shape");
+    if (B > 128) return fail(MP_ERR_ARG, "mp_model_load_sparse: B=%d > 128 next-states per (s,a) not supported", B);
+    const size_t n = (size_t)S * A * B;
+    std::vector<int32_t> n32(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (next[i] < 0 || next[i] >= S) return fail(MP_ERR_ARG, "mp_model_load_sparse: next[%zu] out of range", i);
+        n32[i] = (int32_t)next[i];
+    }
+    MP_HIP(hipSetDevice(ctx->device));
+    mp_model *m = new mp_model();
+    m->ctx = ctx; m->mode = MP_MODE_SPARSE; m->M = 1; m->S = S; m->A = A; m->B = B;
+    auto bail = [&](int rc) { mp_model_free(m); return rc; };
+    double *p = nullptr;
+    if (hipMalloc(&p, n * sizeof(double)) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));
+    m->P = p;
+    if (hipMalloc(&m->NXT, n * sizeof(int32_t)) != hipSuccess || hipMalloc(&m->R, (size_t)S * A * sizeof(double)) != hipSuccess)
+        return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));
+    if (terminal && hipMalloc(&m->term, (size_t)S) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));
+    if (hipMemcpy(p, transition, n * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->NXT, n32.data(), n * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(m->R, reward, (size_t)S * A * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        (terminal && hipMemcpy(m->term, terminal, (size_t)S, hipMemcpyHostToDevice) != hipSuccess))
+        return bail(fail(MP_ERR_HIP, "mp_model_load_sparse: upload failed"));
+    *out = m;
+    return MP_OK;
+}
+
+int mp_model_load_cartpole(mp_ctx *ctx, const mp_cartpole_params *params, mp_model **out)
+{
+    if (!ctx || !out || !params) return fail(MP_ERR_ARG, "mp_model_load_cartpole: NULL argument");
+    mp_model *m = new mp_model();
+    m->ctx = ctx; m->mode = MP_MODE_CARTPOLE; m->M = 1; m->S = 0; m->A = 2;
+    m->cp = *params;
+    m->max_steps = params->max_steps;
+    *out = m;
+    return MP_OK;
+}
+
+int mp_model_free(mp_model *m)
+{
+    if (!m) return MP_OK;
+    if (m->ctx) hipSetDevice(m->ctx->device);
+    if (!m->borrowed) {
+        if (m->P) hipFree(const_cast<double *>(m->P));
+        if (m->R) hipFree(m->R);
+        if (m->term) hipFree(m->term);
+    }
+    if (m->T) hipFree(m->T);
+    if (m->rec) hipFree(m->rec);
+    if (m->NXT) hipFree(m->NXT);
+    delete m;
+    return MP_OK;
+}
+
+int mp_model_info(const mp_model *m, int32_t *mode, int32_t *M, int32_t *S, int32_t *A, int32_t *B)
+{
+    if (!m) return fail(MP_ERR_ARG, "model is NULL");
+    if (mode) *mode = m->mode;
+    if (M) *M = m->M;
+    if (S) *S = m->S;
+    if (A) *A = m->A;
+    if (B) *B = m->B;
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------ OLOP.allocation -----------
+// tree_search/olop.py:42-44
+static int olop_horizon(int episodes, double gamma)
+{
+    const int h = (int)ceil(log((double)episodes) / (2.0 * log(1.0 / gamma)));
+    return h > 1 ? h : 1;
+}
+
+// tree_search/olop.py:50-62 (ValueError -> MP_ERR_ARG)
+int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t *horizon)
+{
+    if (!episodes || !horizon) return fail(MP_ERR_ARG, "mp_olop_allocation: NULL output");
+    for (int e = 1; e < budget; ++e) {
+        if ((long long)e * olop_horizon(e, gamma) > budget) {
+            const int ee = e - 1 > 1 ? e - 1 : 1;
+            *episodes = ee;
+            *horizon = olop_horizon(ee, gamma);
+            return MP_OK;
+        }
+    }
+    return fail(MP_ERR_ARG, "Could not split budget %d with gamma %g", budget, gamma);
+}
+
+} // extern "C"

@@ -1,0 +1,143 @@
+// common.hpp -- context, model and error plumbing shared by the kernels of libmi355plan.so.
+// gfx950 only: wave = 64 lanes, 160 KiB LDS per CU, 256 CUs in 8 XCDs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/mi355plan.h"
+
+namespace mp {
+
+constexpr int kWave = 64;
+constexpr size_t kLdsBytes = 160 * 1024;
+
+extern thread_local std::string g_err;
+
+int fail(int code, const char *fmt, ...);
+
+#define MP_HIP(call)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (call);                                                                   \
+        if (e_ != hipSuccess)                                                                     \
+            return mp::fail(MP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_),    \
+                            __FILE__, __LINE__);                                                  \
+    } while (0)
+
+#define MP_TRY(call)                  \
+    do {                              \
+        int rc_ = (call);             \
+        if (rc_ != MP_OK) return rc_; \
+    } while (0)
+
+// One packed transition record of a deterministic table model: everything an env step needs in
+// a single 16-byte gather (replaces the reference's env.step on a deep-copied env object).
+struct alignas(16) Rec {
+    int32_t next;   // transition[s, a]
+    uint32_t flags; // bit0 = terminal[s] (state acted from), bit1 = terminal[next]
+    double reward;  // reward[s, a]
+};
+static_assert(sizeof(Rec) == 16, "Rec must be one dwordx4");
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+// what the last tree-search call left on the device (for the *_tree_export entry points)
+struct TreeMeta {
+    int kind = 0; // 0 none, 1 uct, 2 opd
+    int n_roots = 0, A = 0, cap = 0, K = 0;
+};
+
+enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,
+       WS_IO5, WS_IO6, WS_IO7, WS_IO8, WS_IO9, WS_TAB0, WS_TAB1, WS_TAB2, WS_TAB3, WS_VI0, WS_VI1, WS_VI2, WS_VI3,
+       WS_VI4, WS_COUNT };
+
+} // namespace mp
+
+struct mp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool timed = false;
+    int n_launches = 0;
+    hipDeviceProp_t prop;
+    mp::DevBuf ws[mp::WS_COUNT];
+    mp::TreeMeta tree;
+    // value-iteration state left on the device by mp_vi_sweeps (timing hook)
+    int vi_last = 0;
+};
+
+struct mp_model {
+    mp_ctx *ctx = nullptr;
+    int mode = 0, M = 1, S = 0, A = 0, B = 0;
+    int done_on_next = 0, max_steps = 0;
+    // deterministic tables, device, [M,S,A]
+    int32_t *T = nullptr;
+    double *R = nullptr;
+    uint8_t *term = nullptr; // [S] or nullptr
+    mp::Rec *rec = nullptr;  // packed model 0, [S*A]
+    // dense [M,S,A,S] / sparse [S,A,B]
+    const double *P = nullptr;
+    bool borrowed = false;
+    int32_t *NXT = nullptr;
+    mp_cartpole_params cp;
+};
+
+namespace mp {
+
+// grow-only device workspace
+int ws_reserve(mp_ctx *ctx, int slot, size_t bytes, void **out);
+
+// timing brackets around kernel launches (HIP events on the ctx stream)
+int kernels_begin(mp_ctx *ctx);
+int kernels_end(mp_ctx *ctx, int n_launches);
+
+template <typename T>
+inline int ws_get(mp_ctx *ctx, int slot, size_t count, T **out)
+{
+    void *p = nullptr;
+    int rc = ws_reserve(ctx, slot, count * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return rc;
+}
+
+// copy helper: host->device (sync on the ctx stream) or pass-through of a device pointer
+template <typename T>
+inline int stage_in(mp_ctx *ctx, int slot, const T *src, size_t count, int mem, T **dev)
+{
+    if (mem == MP_MEM_DEVICE) {
+        *dev = const_cast<T *>(src);
+        return MP_OK;
+    }
+    MP_TRY(ws_get(ctx, slot, count, dev));
+    if (src) MP_HIP(hipMemcpyAsync(*dev, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return MP_OK;
+}
+
+template <typename T>
+inline int stage_out_alloc(mp_ctx *ctx, int slot, T *dst, size_t count, int mem, T **dev)
+{
+    if (mem == MP_MEM_DEVICE) {
+        *dev = dst; // may be nullptr: kernels skip null outputs
+        return MP_OK;
+    }
+    if (!dst) {
+        *dev = nullptr;
+        return MP_OK;
+    }
+    return ws_get(ctx, slot, count, dev);
+}
+
+template <typename T>
+inline int stage_out_copy(mp_ctx *ctx, T *dst, const T *dev, size_t count, int mem)
+{
+    if (mem == MP_MEM_DEVICE || !dst || !dev) return MP_OK;
+    MP_HIP(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return MP_OK;
+}
+
+} // namespace mp

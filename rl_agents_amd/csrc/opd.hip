@@ -1,0 +1,346 @@
+// opd.hip -- optimistic planning for deterministic systems (tree_search/deterministic.py).
+//
+// Mapping: ONE ROOT PER WAVEFRONT (one 64-lane workgroup per root).  OPD is sequential per root
+// (each expansion depends on the previous backup) but every expansion starts with an argmax over
+// all current leaves -- `max(self.leaves, key=U)`, deterministic.py:110, O(#leaves) in the
+// reference and 44 % of its run time -- which is wave-parallel:
+//   * the upper bound of every node is kept in LDS, indexed by node id (creation order), with
+//     expanded nodes overwritten by -inf; 64 lanes scan it with ds_read_b64 and reduce with
+//     cross-lane shuffles on (U, id), maximal U first, lowest id among equals -- exactly the
+//     "first maximal element in list order" the reference picks, because its leaves list is in
+//     creation order (removal keeps order, children are appended, deterministic.py:29,42).
+//   * the |A| children are created by |A| lanes: one 16-byte model gather each, bounds from
+//     host-computed gamma-power tables (libm pow = Python **), node records to HBM.
+//   * backup_to_root (deterministic.py:74-79) walks up with |A| lanes reading the sibling group
+//     and a small reduction; it stops as soon as a node's (L, U) do not change, which cannot
+//     change any ancestor either -- same values as the reference's full walk.
+//   * `count` (deterministic.py:62-63) is not needed by any decision; it is reconstructed from
+//     subtree sizes at export time.
+// HBM per root: node records L, U (f64), state, depth (i32), reward (f64), done (u8), first_child
+// (i32): 37 B/node; LDS per root: 8 B/node (+ 4 B per expansion for the parent map).
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "pcg64.hpp"
+
+namespace mp {
+
+struct OpdArgs {
+    int n_roots, S, A, K, cap, done_on_next, max_plan_len;
+    const Rec *rec;
+    const int32_t *root_state;
+    const double *g1;   // g1[d]   = gamma ** (d - 1), d >= 1
+    const double *gdiv; // gdiv[d] = gamma ** d / (1 - gamma)
+    const double *tdiv; // tdiv[d] = terminal_reward * gamma ** d / (1 - gamma)
+    uint64_t *rng;
+    // per-root node arrays, root-major [n_roots][cap]
+    double *L, *U, *reward;
+    int32_t *state, *depth, *first_child;
+    uint8_t *done;
+    int32_t *expanded; // [n_roots][K] node expanded at step k (= parent of nodes 1 + kA .. 1 + kA + A - 1)
+    int32_t *n_nodes_out;
+    int32_t *plans, *plan_len, *status;
+    double *root_lower, *root_upper;
+    int64_t *env_steps;
+};
+
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, mask, 64);
+    hi = __shfl_xor(hi, mask, 64);
+    return __hiloint2double(hi, lo);
+}
+
+// all lanes receive the (max U, lowest id among maxima) pair
+__device__ __forceinline__ void wave_argmax(double &u, int &id)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const double ou = shfl_xor_f64(u, m);
+        const int oid = __shfl_xor(id, m, 64);
+        if (ou > u || (ou == u && oid < id)) { u = ou; id = oid; }
+    }
+}
+
+__device__ __forceinline__ double wave_max(double v)
+{
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const double o = shfl_xor_f64(v, m);
+        if (o > v) v = o;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    double *leafU = lds;                                             // [cap]
+    int32_t *exp_lds = reinterpret_cast<int32_t *>(lds + p.cap);     // [K]
+    const int lane = threadIdx.x;
+    const int root = blockIdx.x;
+    const int A = p.A;
+    const long base = (long)root * p.cap;
+    double *L = p.L + base, *U = p.U + base, *RW = p.reward + base;
+    int32_t *ST = p.state + base, *DP = p.depth + base, *FC = p.first_child + base;
+    uint8_t *DN = p.done + base;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+
+    // deterministic.py:10-19 root: L = U = 0, depth 0
+    if (lane == 0) {
+        L[0] = 0.0; U[0] = 0.0; RW[0] = 0.0; ST[0] = p.root_state[root]; DP[0] = 0; FC[0] = -1; DN[0] = 0;
+        leafU[0] = 0.0;
+    }
+    __syncthreads();
+    int n_nodes = 1;
+    int status = MP_OK;
+
+    for (int k = 0; k < p.K; ++k) {
+        // ---- deterministic.py:110: first maximal upper bound among the leaves
+        double bu = ninf;
+        int bid = 0x7fffffff;
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = leafU[i];
+            if (u > bu) { bu = u; bid = i; }
+        }
+        wave_argmax(bu, bid);
+        const int leaf = bid;
+        // ---- DeterministicNode.expand, deterministic.py:28-43
+        const int s_leaf = ST[leaf];
+        const int d = DP[leaf] + 1;
+        const double Lp = L[leaf];
+        const int g = n_nodes; // first child
+        double Lc = ninf, Uc = ninf;
+        bool bad = false;
+        if (lane < A) {
+            const Rec rc = p.rec[(long)s_leaf * A + lane];
+            const double r = rc.reward;
+            bad = !(0.0 <= r) || !(r <= 1.0); // deterministic.py:46-47
+            const bool dn = (rc.flags & done_bit) != 0;
+            // deterministic.py:45-65 update()
+            Lc = Lp + p.g1[d] * r;
+            Uc = Lc + p.gdiv[d];
+            if (dn) {
+                const double nv = Lc + p.tdiv[d];
+                Lc = nv; Uc = nv;
+            }
+            const int c = g + lane;
+            L[c] = Lc; U[c] = Uc; RW[c] = r; ST[c] = rc.next; DP[c] = d; FC[c] = -1; DN[c] = dn ? 1 : 0;
+            leafU[c] = Uc;
+        }
+        if (lane == 0) {
+            leafU[leaf] = ninf;
+            exp_lds[k] = leaf;
+            FC[leaf] = g;
+        }
+        n_nodes += A;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        // ---- backup_to_root, deterministic.py:74-79 (first level from registers)
+        double nl = wave_max(Lc), nu = wave_max(Uc);
+        int cur = leaf;
+        double oldL = Lp, oldU = bu; // the leaf's own bounds before the backup
+        while (true) {
+            const bool changed = !(nl == oldL && nu == oldU);
+            if (changed && lane == 0) { L[cur] = nl; U[cur] = nu; }
+            if (!changed || cur == 0) break;
+            __threadfence_block();
+            // siblings of cur (cur included) = children of its parent
+            const int kk = (cur - 1) / A;
+            const int par = exp_lds[kk];
+            const int gg = 1 + kk * A;
+            double cl = ninf, cu = ninf;
+            if (lane < A) {
+                const int c = gg + lane;
+                if (c == cur) { cl = nl; cu = nu; }
+                else { cl = L[c]; cu = U[c]; }
+            }
+            oldL = L[par]; oldU = U[par];
+            nl = wave_max(cl); nu = wave_max(cu);
+            cur = par;
+        }
+        __syncthreads(); // LDS leaf array / parent map visible to all lanes for the next scan
+    }
+
+    // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule (deterministic.py:21-26)
+    __syncthreads();
+    __threadfence_block();
+    if (status == MP_OK) {
+        Pcg64 gen;
+        gen.load(p.rng + (long)root * 6);
+        int n = 0, len = 0;
+        int fc = FC[0];
+        while (fc >= 0) {
+            const double l = lane < A ? L[fc + lane] : ninf;
+            const double m = wave_max(l);
+            const unsigned long long ties = __ballot(lane < A && l == m);
+            const int nt = __popcll(ties);
+            int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
+            unsigned long long t = ties;
+            while (pick-- > 0) t &= t - 1;
+            const int a = __ffsll((long long)t) - 1;
+            if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
+            ++len;
+            n = fc + a;
+            fc = FC[n];
+        }
+        if (lane == 0) {
+            gen.store(p.rng + (long)root * 6);
+            if (p.plans)
+                for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+            if (p.plan_len) p.plan_len[root] = len;
+            if (p.root_lower) p.root_lower[root] = L[0];
+            if (p.root_upper) p.root_upper[root] = U[0];
+        }
+    } else if (lane == 0) {
+        if (p.plans)
+            for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[root] = 0;
+    }
+    if (lane == 0) {
+        if (p.status) p.status[root] = status;
+        if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1);
+        p.n_nodes_out[root] = n_nodes;
+        for (int k = 0; k < p.K; ++k) p.expanded[(long)root * p.K + k] = k * A + 1 < n_nodes ? exp_lds[k] : -1;
+    }
+}
+
+} // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget,
+                double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status,
+                int32_t mem)
+{
+    if (!ctx || !model || !root_state || !rng_state) return fail(MP_ERR_ARG, "mp_opd_plan: NULL argument");
+    if (model->mode != MP_MODE_DETERMINISTIC)
+        return fail(MP_ERR_MODE, "mp_opd_plan: model mode %d is not a deterministic table", model->mode);
+    const int A = model->A;
+    if (A > 64) return fail(MP_ERR_ARG, "mp_opd_plan: |A| = %d > 64 actions not supported", A);
+    if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_opd_plan: bad sizes");
+    const int K = budget / A; // deterministic.py:118
+    const long cap = 1 + (long)K * A;
+    const size_t lds = (size_t)cap * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    if (lds > kLdsBytes - 1024)
+        return fail(MP_ERR_ARG, "mp_opd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds, kLdsBytes - 1024);
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    // gamma-power tables, host libm (bit-equal to Python's float **); depth <= K + 1
+    const int D = K + 2;
+    std::vector<double> tab((size_t)3 * D);
+    for (int d = 0; d < D; ++d) {
+        tab[d] = d >= 1 ? pow(gamma, (double)(d - 1)) : 0.0;
+        tab[D + d] = pow(gamma, (double)d) / (1 - gamma);
+        tab[2 * D + d] = terminal_reward * pow(gamma, (double)d) / (1 - gamma);
+    }
+    double *d_tab = nullptr;
+    MP_TRY(ws_get(ctx, WS_TAB0, tab.size(), &d_tab));
+    MP_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
+    MP_HIP(hipStreamSynchronize(st));
+
+    OpdArgs a;
+    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap;
+    a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
+    a.rec = model->rec;
+    a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;
+    const size_t nn = (size_t)n_roots * cap;
+    MP_TRY(ws_get(ctx, WS_TREE0, nn, &a.L));
+    MP_TRY(ws_get(ctx, WS_TREE1, nn, &a.U));
+    MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.reward));
+    MP_TRY(ws_get(ctx, WS_TREE3, nn, &a.state));
+    MP_TRY(ws_get(ctx, WS_TREE4, nn, &a.depth));
+    MP_TRY(ws_get(ctx, WS_TREE5, nn, &a.first_child));
+    MP_TRY(ws_get(ctx, WS_TREE6, nn, &a.done));
+    MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
+    a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
+    ctx->tree.kind = 2; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
+
+    int32_t *d_rs = nullptr;
+    MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n_roots, mem, &d_rs));
+    a.root_state = d_rs;
+    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n_roots * 6, mem, &a.rng));
+    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, mem, &a.plans));
+    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, mem, &a.plan_len));
+    MP_TRY(stage_out_alloc(ctx, WS_IO5, root_lower, (size_t)n_roots, mem, &a.root_lower));
+    MP_TRY(stage_out_alloc(ctx, WS_IO6, root_upper, (size_t)n_roots, mem, &a.root_upper));
+    MP_TRY(stage_out_alloc(ctx, WS_IO7, status, (size_t)n_roots, mem, &a.status));
+    MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
+
+    if (lds > 64 * 1024)
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(opd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    MP_TRY(kernels_begin(ctx));
+    hipLaunchKernelGGL(opd_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    MP_TRY(kernels_end(ctx, 1));
+    MP_HIP(hipGetLastError());
+
+    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n_roots * 6, mem));
+    MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n_roots * max_plan_len, mem));
+    MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, root_lower, a.root_lower, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, root_upper, a.root_upper, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, status, a.status, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, mem));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
+                       int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
+                       int64_t *count, int32_t *first_child)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    if (ctx->tree.kind != 2) return fail(MP_ERR_ARG, "mp_opd_tree_export: no OPD tree on this ctx");
+    if (root < 0 || root >= ctx->tree.n_roots) return fail(MP_ERR_ARG, "mp_opd_tree_export: root %d out of range", root);
+    const int tcap = ctx->tree.cap, A = ctx->tree.A, K = ctx->tree.K, NR = ctx->tree.n_roots;
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t *d_exp = (const int32_t *)ctx->ws[WS_TREE7].p;
+    int32_t n = 0;
+    MP_HIP(hipMemcpy(&n, d_exp + (size_t)NR * (K > 0 ? K : 1) + root, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n > cap) return fail(MP_ERR_ARG, "mp_opd_tree_export: capacity %d < %d nodes", cap, n);
+    const long base = (long)root * tcap;
+    auto pull = [&](void *dst, int slot, size_t elt) -> int {
+        if (!dst) return MP_OK;
+        MP_HIP(hipMemcpy(dst, (const char *)ctx->ws[slot].p + base * elt, (size_t)n * elt, hipMemcpyDeviceToHost));
+        return MP_OK;
+    };
+    std::vector<int32_t> fc((size_t)n), exp((size_t)(K > 0 ? K : 1));
+    MP_TRY(pull(fc.data(), WS_TREE5, sizeof(int32_t)));
+    MP_HIP(hipMemcpy(exp.data(), d_exp + (size_t)root * (K > 0 ? K : 1), (size_t)(K > 0 ? K : 1) * sizeof(int32_t),
+                     hipMemcpyDeviceToHost));
+    MP_TRY(pull(lower, WS_TREE0, sizeof(double)));
+    MP_TRY(pull(upper, WS_TREE1, sizeof(double)));
+    MP_TRY(pull(reward, WS_TREE2, sizeof(double)));
+    MP_TRY(pull(state, WS_TREE3, sizeof(int32_t)));
+    MP_TRY(pull(depth, WS_TREE4, sizeof(int32_t)));
+    MP_TRY(pull(done, WS_TREE6, sizeof(uint8_t)));
+    std::vector<int32_t> par((size_t)n);
+    par[0] = -1;
+    for (int i = 1; i < n; ++i) par[i] = exp[(i - 1) / A];
+    if (first_child) memcpy(first_child, fc.data(), (size_t)n * sizeof(int32_t));
+    for (int i = 0; i < n; ++i) {
+        if (parent) parent[i] = par[i];
+        if (action) action[i] = i == 0 ? -1 : (i - 1) % A;
+    }
+    if (count) {
+        // deterministic.py:62-63: every node on the root..child sequence gets +1 per created child;
+        // count = 1 (initial) + size of own subtree for non-root nodes, root: 1 + #descendants
+        std::vector<int64_t> sz((size_t)n, 1);
+        for (int i = n - 1; i >= 1; --i) sz[par[i]] += sz[i];
+        for (int i = 0; i < n; ++i) count[i] = i == 0 ? sz[0] : 1 + sz[i];
+    }
+    if (n_nodes) *n_nodes = n;
+    return MP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,401 @@
+// vi.hip -- Bellman sweeps of ValueIterationAgent / RobustValueIterationAgent on gfx950.
+//
+// Reference: dynamic_programming/value_iteration.py:37-73, robust_value_iteration.py:39-58.
+//   Q_{k+1} = R + gamma * mask(next_v(max_a Q_k)),   stop when allclose(Q_k, Q_{k+1}) and return Q_k.
+//
+// Kernels
+//   vi_det_sweep    deterministic tables, fused: keeps only V across sweeps (V_{k-1}, V_k -> V_{k+1}),
+//                   recomputing Q_k and Q_{k+1} from the two V's for the allclose test, so a sweep
+//                   moves 12*M*S*A + 17*S algorithmic bytes (T int32 + R f64 stream, V gather/write,
+//                   terminal flags) and never materialises Q.  Bit-exact with numpy.
+//   vi_dense_q      dense T[M,S,A,S]: the |S|x|A|x|S| contraction on the f64 matrix cores
+//                   (v_mfma_f64_16x16x4_f64), 16 (s,a) rows per wave, V staged in LDS; HBM-bound
+//                   (0.25 flop/B): 8*M*S^2*A bytes per sweep.
+//   vi_sparse_q     sparse [S,A,B] model, numpy's pairwise add.reduce order restated (bit-exact).
+//   vi_finish       V_{k+1} = max_a Q_{k+1}, allclose flag (dense / sparse paths).
+// Convergence is decided on the device: sweep k raises notclose[k] if any element moved; sweep
+// k+1 (already enqueued) turns into a no-op when notclose[k] stayed 0, freezing the iterates, so
+// the whole solve is one asynchronous batch of launches with no host round trip.
+#include <math.h>
+
+#include "common.hpp"
+
+namespace mp {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double4_u __attribute__((ext_vector_type(4), aligned(8)));
+
+__device__ __forceinline__ bool isclose_np(double a, double b, double rtol, double atol)
+{
+    // numpy.isclose(a, b): |a - b| <= atol + rtol * |b| for finite values, equality otherwise
+    if (isfinite(a) && isfinite(b)) return fabs(a - b) <= atol + rtol * fabs(b);
+    return a == b;
+}
+
+struct ViDetArgs {
+    int M, S, A, robust, vform, k;
+    const int32_t *T;
+    const double *R;
+    const uint8_t *term;
+    double gamma, rtol, atol;
+    const double *Vprev, *Vcur;
+    double *Vnext;
+    int32_t *notclose;
+};
+
+// Q[s,a] of the Bellman operator applied to V (value_iteration.py:51-63 deterministic branch;
+// robust_value_iteration.py:46-58 with the min over models)
+__device__ __forceinline__ double det_q(const ViDetArgs &p, const double *__restrict__ V, long sa, bool term_s)
+{
+    const long msa = (long)p.S * p.A;
+    if (p.robust) {
+        double best = 0.0;
+        for (int m = 0; m < p.M; ++m) {
+            const double nv = V[p.T[m * msa + sa]];
+            const double qm = p.R[m * msa + sa] + p.gamma * nv;
+            if (m == 0 || qm < best) best = qm;
+        }
+        return best;
+    }
+    const double nv = term_s ? 0.0 : V[p.T[sa]];
+    return p.R[sa] + p.gamma * nv;
+}
+
+__global__ __launch_bounds__(256) void vi_det_sweep(ViDetArgs p)
+{
+    if (p.k > 0 && p.notclose[p.k - 1] == 0) return; // converged at an earlier sweep: freeze
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.S) return;
+    const bool term_s = (!p.robust && p.term) ? p.term[s] != 0 : false;
+    bool nc = false;
+    double vmax = 0.0;
+    for (int a = 0; a < p.A; ++a) {
+        const long sa = (long)s * p.A + a;
+        const double qn = det_q(p, p.Vcur, sa, term_s);
+        if (!p.vform) {
+            const double qo = p.k == 0 ? 0.0 : det_q(p, p.Vprev, sa, term_s);
+            nc |= !isclose_np(qo, qn, p.rtol, p.atol);
+        }
+        if (a == 0 || qn > vmax) vmax = qn;
+    }
+    p.Vnext[s] = vmax;
+    if (p.vform) nc = !isclose_np(p.Vcur[s], vmax, p.rtol, p.atol);
+    if (nc) p.notclose[p.k] = 1;
+}
+
+// result[0] = sweeps executed, result[1] = j such that the returned iterate is Q_j / V_j
+__global__ void vi_find_stop(int iterations, const int32_t *notclose, int32_t *result)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    int j = iterations, sweeps = iterations;
+    for (int k = 0; k < iterations; ++k)
+        if (notclose[k] == 0) {
+            j = k;
+            sweeps = k + 1;
+            break;
+        }
+    result[0] = sweeps;
+    result[1] = j;
+}
+
+struct ViEmitArgs {
+    ViDetArgs d;            // T/R/term/gamma, V pointers unused
+    const double *Vbuf;     // 3 buffers of S doubles
+    const int32_t *result;
+    double *Q_out, *V_out;
+    int32_t *sweeps_out;
+};
+
+// Q_j = 0 if j == 0 else Bellman(V_{j-1}); V_j straight from its buffer
+__global__ __launch_bounds__(256) void vi_det_emit(ViEmitArgs e)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = e.result[1];
+    if (s == 0 && e.sweeps_out) *e.sweeps_out = e.result[0];
+    if (s >= e.d.S) return;
+    if (e.V_out) e.V_out[s] = e.Vbuf[(long)(j % 3) * e.d.S + s];
+    if (e.Q_out) {
+        const bool term_s = (!e.d.robust && e.d.term) ? e.d.term[s] != 0 : false;
+        const double *V = e.Vbuf + (long)((j + 2) % 3) * e.d.S; // V_{j-1}
+        for (int a = 0; a < e.d.A; ++a) {
+            const long sa = (long)s * e.d.A + a;
+            e.Q_out[sa] = j == 0 ? 0.0 : det_q(e.d, V, sa, term_s);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ generic (dense / sparse) ---
+struct ViGenArgs {
+    int M, S, A, B, robust, vform, k;
+    const double *P;
+    const int32_t *NXT;
+    const double *R;
+    const uint8_t *term;
+    double gamma, rtol, atol;
+    const double *Vcur; // V_k
+    const double *Qcur; // Q_k
+    double *Qnext;      // Q_{k+1}
+    double *Vnext;      // V_{k+1}
+    int32_t *notclose;
+};
+
+constexpr int kDenseChunk = 4096; // doubles of V staged in LDS per pass (32 KiB)
+
+// Rows of the (S*A) x S matrix T_m are contracted with V on v_mfma_f64_16x16x4_f64: the A operand
+// of one MFMA is a 16-row x 4-column block of T, the B operand is V broadcast into all 16 columns,
+// so every column of D holds the same 16 dot products.  Lane l feeds row (l & 15), k-slot (l >> 4);
+// it loads 4 consecutive doubles (32 B) of its row per 16-column step, so the 4 lanes of a row
+// cover one 128-B line and the k-slot <-> column map is (l >> 4) * 4 + t for MFMA t of the step
+// (the same permutation is applied to V, which is all a dot product needs).
+__global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
+{
+    if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
+    extern __shared__ __attribute__((aligned(16))) double vs[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long SA = (long)p.S * p.A;
+    const long row0 = (long)blockIdx.x * 64 + wave * 16;
+    const int i = lane & 15, q = lane >> 4;
+    long row = row0 + i;
+    if (row >= SA) row = SA - 1; // tail tile: load a valid row, discard the result
+    double best[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int m = 0; m < p.M; ++m) {
+        double4_t acc = {0.0, 0.0, 0.0, 0.0};
+        const double *prow = p.P + ((long)m * SA + row) * p.S;
+        for (int c0 = 0; c0 < p.S; c0 += kDenseChunk) {
+            const int ch = min(kDenseChunk, p.S - c0);
+            __syncthreads();
+            for (int t = threadIdx.x; t < kDenseChunk; t += 256) vs[t] = t < ch ? p.Vcur[c0 + t] : 0.0;
+            __syncthreads();
+            const double *pr = prow + c0 + q * 4;
+            const int full = ch & ~15;
+            int cc = 0;
+#pragma unroll 4
+            for (; cc < full; cc += 16) {
+                const double4_u t4 = *reinterpret_cast<const double4_u *>(pr + cc);
+                const double4_t b4 = *reinterpret_cast<const double4_t *>(vs + cc + q * 4);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.x, b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.y, b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.z, b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.w, b4.w, acc, 0, 0, 0);
+            }
+            if (cc < ch) { // ragged tail of the chunk: zero-fill beyond ch (V is zero-filled too)
+                double tv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int col = cc + q * 4 + t;
+                    tv[t] = col < ch ? pr[cc + t] : 0.0;
+                }
+                const double4_t b4 = *reinterpret_cast<const double4_t *>(vs + cc + q * 4);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[0], b4.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[1], b4.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[2], b4.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(tv[3], b4.w, acc, 0, 0, 0);
+            }
+        }
+        // f64 C/D layout: lane l, register r -> row (l >> 4) + 4 r, column l & 15
+        const double accr[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long orow = row0 + q + 4 * r;
+            if (orow < SA) {
+                const int s = (int)(orow / p.A);
+                double nv = 0.0 + accr[r];
+                if (!p.robust && p.term && p.term[s]) nv = 0.0;
+                const double qm = p.R[(long)m * SA + orow] + p.gamma * nv;
+                if (m == 0 || qm < best[r]) best[r] = qm;
+            }
+        }
+    }
+    if (i == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long orow = row0 + q + 4 * r;
+            if (orow < SA) p.Qnext[orow] = best[r];
+        }
+    }
+}
+
+// numpy add.reduce inner loop for n <= 128 contiguous doubles (pairwise summation base cases)
+template <typename F>
+__device__ __forceinline__ double np_sum_le128(int n, F elem)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += elem(i);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = elem(j);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] += elem(i + j);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += elem(i);
+    return res;
+}
+
+// value_iteration.py:56-59: (P * np.take(v, next)).sum(axis=-1)
+__global__ __launch_bounds__(256) void vi_sparse_q(ViGenArgs p)
+{
+    if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
+    const long sa = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (sa >= (long)p.S * p.A) return;
+    const int s = (int)(sa / p.A);
+    const double *pp = p.P + sa * p.B;
+    const int32_t *nn = p.NXT + sa * p.B;
+    const double *V = p.Vcur;
+    double nv = 0.0 + np_sum_le128(p.B, [&](int b) { return pp[b] * V[nn[b]]; });
+    if (p.term && p.term[s]) nv = 0.0;
+    p.Qnext[sa] = p.R[sa] + p.gamma * nv;
+}
+
+__global__ __launch_bounds__(256) void vi_finish(ViGenArgs p)
+{
+    if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= p.S) return;
+    bool nc = false;
+    double vmax = 0.0;
+    for (int a = 0; a < p.A; ++a) {
+        const long sa = (long)s * p.A + a;
+        const double qn = p.Qnext[sa];
+        if (!p.vform) nc |= !isclose_np(p.Qcur[sa], qn, p.rtol, p.atol);
+        if (a == 0 || qn > vmax) vmax = qn;
+    }
+    p.Vnext[s] = vmax;
+    if (p.vform) nc = !isclose_np(p.Vcur[s], vmax, p.rtol, p.atol);
+    if (nc) p.notclose[p.k] = 1;
+}
+
+struct ViGenEmitArgs {
+    int S, A;
+    const double *Qbuf; // 2 x S*A
+    const double *Vbuf; // 2 x S
+    const int32_t *result;
+    double *Q_out, *V_out;
+    int32_t *sweeps_out;
+};
+
+__global__ __launch_bounds__(256) void vi_gen_emit(ViGenEmitArgs e)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = e.result[1];
+    const long SA = (long)e.S * e.A;
+    if (i == 0 && e.sweeps_out) *e.sweeps_out = e.result[0];
+    if (e.Q_out && i < SA) e.Q_out[i] = e.Qbuf[(long)(j & 1) * SA + i];
+    if (e.V_out && i < e.S) e.V_out[i] = e.Vbuf[(long)(j & 1) * e.S + i];
+}
+
+static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double rtol, double atol, int robust,
+                  int vform, double *Q_out, double *V_out, int32_t *sweeps_out, int mem)
+{
+    if (!ctx || !m) return fail(MP_ERR_ARG, "vi: NULL ctx/model");
+    if (iterations < 0) return fail(MP_ERR_ARG, "vi: iterations < 0");
+    if (m->mode == MP_MODE_CARTPOLE) return fail(MP_ERR_MODE, "vi: the environment must be of type finite_mdp");
+    if (robust && m->mode == MP_MODE_SPARSE) return fail(MP_ERR_MODE, "Unknown mode"); // robust_value_iteration.py:57-58
+    MP_HIP(hipSetDevice(ctx->device));
+    const int S = m->S, A = m->A, M = robust ? m->M : 1;
+    const long SA = (long)S * A;
+    hipStream_t st = ctx->stream;
+
+    int32_t *notclose = nullptr, *result = nullptr;
+    MP_TRY(ws_get(ctx, WS_VI0, (size_t)iterations + 4, &notclose));
+    result = notclose + iterations + 1;
+    MP_HIP(hipMemsetAsync(notclose, 0, ((size_t)iterations + 4) * sizeof(int32_t), st));
+
+    double *dQ = nullptr, *dV = nullptr;
+    int32_t *dSw = nullptr;
+    MP_TRY(stage_out_alloc(ctx, WS_IO0, Q_out, (size_t)SA, mem, &dQ));
+    MP_TRY(stage_out_alloc(ctx, WS_IO1, V_out, (size_t)S, mem, &dV));
+    MP_TRY(stage_out_alloc(ctx, WS_IO2, sweeps_out, 1, mem, &dSw));
+
+    const unsigned gs = (unsigned)((S + 255) / 256);
+    int launches = 0;
+    if (m->mode == MP_MODE_DETERMINISTIC) {
+        double *Vb = nullptr;
+        MP_TRY(ws_get(ctx, WS_VI1, (size_t)3 * S, &Vb));
+        MP_HIP(hipMemsetAsync(Vb, 0, (size_t)3 * S * sizeof(double), st));
+        ViDetArgs a;
+        a.M = M; a.S = S; a.A = A; a.robust = robust; a.vform = vform;
+        a.T = m->T; a.R = m->R; a.term = m->term; a.gamma = gamma; a.rtol = rtol; a.atol = atol;
+        a.notclose = notclose;
+        MP_TRY(kernels_begin(ctx));
+        for (int k = 0; k < iterations; ++k) {
+            a.k = k;
+            a.Vprev = Vb + (long)((k + 2) % 3) * S;
+            a.Vcur = Vb + (long)(k % 3) * S;
+            a.Vnext = Vb + (long)((k + 1) % 3) * S;
+            hipLaunchKernelGGL(vi_det_sweep, dim3(gs), dim3(256), 0, st, a);
+            ++launches;
+        }
+        MP_TRY(kernels_end(ctx, launches));
+        hipLaunchKernelGGL(vi_find_stop, dim3(1), dim3(64), 0, st, iterations, notclose, result);
+        ViEmitArgs e;
+        e.d = a; e.Vbuf = Vb; e.result = result; e.Q_out = dQ; e.V_out = dV; e.sweeps_out = dSw;
+        hipLaunchKernelGGL(vi_det_emit, dim3(gs), dim3(256), 0, st, e);
+    } else {
+        double *Qb = nullptr, *Vb = nullptr;
+        MP_TRY(ws_get(ctx, WS_VI1, (size_t)2 * S, &Vb));
+        MP_TRY(ws_get(ctx, WS_VI2, (size_t)2 * SA, &Qb));
+        MP_HIP(hipMemsetAsync(Vb, 0, (size_t)2 * S * sizeof(double), st));
+        MP_HIP(hipMemsetAsync(Qb, 0, (size_t)2 * SA * sizeof(double), st));
+        ViGenArgs a;
+        a.M = M; a.S = S; a.A = A; a.B = m->B; a.robust = robust; a.vform = vform;
+        a.P = m->P; a.NXT = m->NXT; a.R = m->R; a.term = m->term; a.gamma = gamma; a.rtol = rtol; a.atol = atol;
+        a.notclose = notclose;
+        const unsigned gq_dense = (unsigned)((SA + 63) / 64), gq_sparse = (unsigned)((SA + 255) / 256);
+        MP_TRY(kernels_begin(ctx));
+        for (int k = 0; k < iterations; ++k) {
+            a.k = k;
+            a.Vcur = Vb + (long)(k & 1) * S;
+            a.Vnext = Vb + (long)((k + 1) & 1) * S;
+            a.Qcur = Qb + (long)(k & 1) * SA;
+            a.Qnext = Qb + (long)((k + 1) & 1) * SA;
+            if (m->mode == MP_MODE_STOCHASTIC)
+                hipLaunchKernelGGL(vi_dense_q, dim3(gq_dense), dim3(256), kDenseChunk * sizeof(double), st, a);
+            else
+                hipLaunchKernelGGL(vi_sparse_q, dim3(gq_sparse), dim3(256), 0, st, a);
+            hipLaunchKernelGGL(vi_finish, dim3(gs), dim3(256), 0, st, a);
+            launches += 2;
+        }
+        MP_TRY(kernels_end(ctx, launches));
+        hipLaunchKernelGGL(vi_find_stop, dim3(1), dim3(64), 0, st, iterations, notclose, result);
+        ViGenEmitArgs e;
+        e.S = S; e.A = A; e.Qbuf = Qb; e.Vbuf = Vb; e.result = result; e.Q_out = dQ; e.V_out = dV; e.sweeps_out = dSw;
+        hipLaunchKernelGGL(vi_gen_emit, dim3((unsigned)((SA + 255) / 256)), dim3(256), 0, st, e);
+    }
+    MP_HIP(hipGetLastError());
+    MP_TRY(stage_out_copy(ctx, Q_out, dQ, (size_t)SA, mem));
+    MP_TRY(stage_out_copy(ctx, V_out, dV, (size_t)S, mem));
+    MP_TRY(stage_out_copy(ctx, sweeps_out, dSw, 1, mem));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+} // namespace mp
+
+extern "C" {
+
+int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                int32_t robust, double *Q_out, int32_t *sweeps_out, int32_t mem)
+{
+    return mp::vi_run(ctx, model, gamma, iterations, rtol, atol, robust ? 1 : 0, 0, Q_out, nullptr, sweeps_out, mem);
+}
+
+int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                  double *V_out, int32_t mem)
+{
+    return mp::vi_run(ctx, model, gamma, iterations, rtol, atol, 0, 1, nullptr, V_out, nullptr, mem);
+}
+
+int mp_vi_sweeps(mp_ctx *ctx, mp_model *model, double gamma, int32_t sweeps, int32_t robust)
+{
+    // negative tolerances: |a - b| <= atol + rtol |b| is never true, so no sweep is skipped
+    return mp::vi_run(ctx, model, gamma, sweeps, -1.0, -1.0, robust ? 1 : 0, 0, nullptr, nullptr, nullptr,
+                      MP_MEM_DEVICE);
+}
+
+} // extern "C"

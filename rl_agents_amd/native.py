@@ -1,0 +1,357 @@
+"""ctypes binding of libmi355plan.so (include/mi355plan.h) -- the only compute path of this package.
+
+There is no CPU fallback: importing works anywhere (so that host logic can be unit-tested), but
+creating a :class:`Context` raises if the library is missing or no MI355X is visible.
+north_star asks for a cffi ABI-mode layer; cffi is not installed in this image, ctypes binds the
+same C ABI (INTEGRATION.md shows both).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+MP_MEM_HOST, MP_MEM_DEVICE = 0, 1
+MODE_DETERMINISTIC, MODE_STOCHASTIC, MODE_SPARSE, MODE_CARTPOLE = 0, 1, 2, 3
+ERR_REWARD_RANGE, ERR_ARG, ERR_MODE = -2, -4, -5
+
+_LIB = None
+
+c_i32, c_i64, c_f64, c_u8, c_u64 = C.c_int32, C.c_int64, C.c_double, C.c_uint8, C.c_uint64
+P = C.POINTER
+_vp = C.c_void_p
+
+# every symbol include/mi355plan.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "mp_last_error": (C.c_char_p, []),
+    "mp_abi_version": (C.c_int, []),
+    "mp_ctx_create": (C.c_int, [C.c_int, _vp, P(_vp)]),
+    "mp_ctx_destroy": (C.c_int, [_vp]),
+    "mp_ctx_set_stream": (C.c_int, [_vp, _vp]),
+    "mp_ctx_synchronize": (C.c_int, [_vp]),
+    "mp_ctx_device_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i64), P(c_i64), C.c_char_p, c_i32]),
+    "mp_model_load_table": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32, P(_vp)]),
+    "mp_model_load_dense": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
+    "mp_model_load_sparse": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, _vp, P(_vp)]),
+    "mp_model_load_cartpole": (C.c_int, [_vp, _vp, P(_vp)]),
+    "mp_model_free": (C.c_int, [_vp]),
+    "mp_model_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
+    "mp_vi_solve": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, c_i32, _vp, _vp, c_i32]),
+    "mp_vi_solve_v": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, c_i32]),
+    "mp_vi_sweeps": (C.c_int, [_vp, _vp, c_f64, c_i32, c_i32]),
+    "mp_uct_plan": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
+                              _vp, _vp, _vp, _vp, c_i32]),
+    "mp_uct_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp]),
+    "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                              c_i32]),
+    "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_olop_allocation": (C.c_int, [c_i32, c_f64, P(c_i32), P(c_i32)]),
+    "mp_last_kernel_ms": (C.c_int, [_vp, P(c_f64), P(c_i32)]),
+}
+
+
+class CartPoleParams(C.Structure):
+    _fields_ = [("gravity", c_f64), ("masscart", c_f64), ("masspole", c_f64), ("length", c_f64),
+                ("force_mag", c_f64), ("tau", c_f64), ("theta_threshold", c_f64), ("x_threshold", c_f64),
+                ("max_steps", c_i32), ("euler", c_i32)]
+
+
+class NativeError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libmi355plan error {}: {}".format(code, message))
+        self.code = code
+
+
+def lib_path():
+    return _build.LIB_PATH
+
+
+def load():
+    """Load libmi355plan.so; raises (never falls back) if it has not been built."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError("{} is missing: run `python -m rl_agents_amd.build` (hipcc, gfx950). "
+                           "There is no CPU fallback for the planning kernels.".format(path))
+    try:  # share torch's copy of the HIP runtime when torch is in the process (same soname)
+        import torch  # noqa: F401
+    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+        pass
+    lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mp_abi_version() != 1:
+        raise RuntimeError("libmi355plan ABI version mismatch")
+    _LIB = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise NativeError(rc, load().mp_last_error().decode("utf-8", "replace"))
+
+
+def _ptr(a):
+    """numpy array / torch tensor / None -> void* address."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    if hasattr(a, "data_ptr"):
+        return a.data_ptr()
+    raise TypeError("expected numpy array, torch tensor or None, got {}".format(type(a)))
+
+
+def olop_allocation(budget, gamma):
+    """OLOP.allocation (tree_search/olop.py:50-62): budget -> (episodes, horizon)."""
+    e, h = c_i32(), c_i32()
+    rc = load().mp_olop_allocation(int(budget), float(gamma), C.byref(e), C.byref(h))
+    if rc != 0:
+        raise ValueError("Could not split budget {} with gamma {}".format(budget, gamma))
+    return e.value, h.value
+
+
+class Context(object):
+    """One GPU + stream + workspaces (mp_ctx).  `stream` = raw hipStream_t (int) or None."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load()
+        h = _vp()
+        _check(self._lib.mp_ctx_create(int(device), _vp(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.device = int(device)
+
+    @classmethod
+    def on_torch_stream(cls, device=0):
+        """Context that enqueues on torch's current stream of `device` (so torch events/allocations interoperate)."""
+        import torch
+        with torch.cuda.device(device):
+            return cls(device, torch.cuda.current_stream().cuda_stream)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mp_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._lib.mp_ctx_synchronize(self._h))
+
+    def device_info(self):
+        cu, wave, lds, hbm = c_i32(), c_i32(), c_i64(), c_i64()
+        name = C.create_string_buffer(256)
+        _check(self._lib.mp_ctx_device_info(self._h, C.byref(cu), C.byref(wave), C.byref(lds), C.byref(hbm), name, 256))
+        return dict(n_cu=cu.value, wave_size=wave.value, lds_bytes=lds.value, hbm_bytes=hbm.value,
+                    name=name.value.decode())
+
+    def last_kernel_ms(self):
+        ms, n = c_f64(), c_i32()
+        _check(self._lib.mp_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- models ------------------------------------------------------------------------------
+    def load_table(self, transition, reward, terminal=None, done_rule="source", max_steps=0):
+        """Deterministic tables: transition int [S,A] or [M,S,A], reward like it, terminal [S]."""
+        t = np.ascontiguousarray(transition, dtype=np.int64)
+        r = np.ascontiguousarray(reward, dtype=np.float64)
+        if t.shape != r.shape or t.ndim not in (2, 3):
+            raise ValueError("transition and reward must both be [S, A] (or [M, S, A])")
+        m = 1 if t.ndim == 2 else t.shape[0]
+        s, a = t.shape[-2:]
+        term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).reshape(s).astype(np.uint8))
+        h = _vp()
+        _check(self._lib.mp_model_load_table(self._h, m, s, a, _ptr(t), _ptr(r), _ptr(term),
+                                             int(done_rule == "next"), int(max_steps or 0), C.byref(h)))
+        return Model(self, h, MODE_DETERMINISTIC, m, s, a, 0)
+
+    def load_dense(self, transition, reward, terminal=None):
+        """Dense model: transition float [S,A,S] or [M,S,A,S] (numpy -> copied; torch cuda tensor -> borrowed)."""
+        on_device = hasattr(transition, "data_ptr")
+        if on_device:
+            t, r, term = transition, reward, terminal
+            if not (t.is_contiguous() and r.is_contiguous()):
+                raise ValueError("device arrays must be contiguous")
+            shape = tuple(t.shape)
+            keep = (t, r, term)
+        else:
+            t = np.ascontiguousarray(transition, dtype=np.float64)
+            r = np.ascontiguousarray(reward, dtype=np.float64)
+            shape = t.shape
+            s_ = shape[-1]
+            term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).reshape(s_).astype(np.uint8))
+            keep = None
+        if len(shape) not in (3, 4) or shape[-1] != shape[-3]:
+            raise ValueError("transition must be [S, A, S] (or [M, S, A, S])")
+        m = 1 if len(shape) == 3 else shape[0]
+        s, a = shape[-3], shape[-2]
+        h = _vp()
+        _check(self._lib.mp_model_load_dense(self._h, m, s, a, _ptr(t), _ptr(r), _ptr(term),
+                                             MP_MEM_DEVICE if on_device else MP_MEM_HOST, C.byref(h)))
+        mod = Model(self, h, MODE_STOCHASTIC, m, s, a, 0)
+        mod._keep = keep
+        return mod
+
+    def load_sparse(self, transition, next_states, reward, terminal=None):
+        t = np.ascontiguousarray(transition, dtype=np.float64)
+        n = np.ascontiguousarray(next_states, dtype=np.int64)
+        r = np.ascontiguousarray(reward, dtype=np.float64)
+        if t.shape != n.shape or t.ndim != 3:
+            raise ValueError("next and transition must both be [S, A, B]")
+        s, a, b = t.shape
+        term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).reshape(s).astype(np.uint8))
+        h = _vp()
+        _check(self._lib.mp_model_load_sparse(self._h, s, a, b, _ptr(t), _ptr(n), _ptr(r), _ptr(term), C.byref(h)))
+        return Model(self, h, MODE_SPARSE, 1, s, a, b)
+
+    # ---- value iteration ---------------------------------------------------------------------
+    def vi_solve(self, model, gamma, iterations, robust=False, rtol=1e-5, atol=1e-8):
+        """-> (Q [S,A] float64, sweeps run).  value_iteration.py:42-45,65-73 / robust_value_iteration.py:39-58."""
+        q = np.zeros((model.S, model.A), dtype=np.float64)
+        sweeps = np.zeros(1, dtype=np.int32)
+        _check(self._lib.mp_vi_solve(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
+                                     int(bool(robust)), _ptr(q), _ptr(sweeps), MP_MEM_HOST))
+        return q, int(sweeps[0])
+
+    def vi_solve_v(self, model, gamma, iterations, rtol=1e-5, atol=1e-8):
+        v = np.zeros(model.S, dtype=np.float64)
+        _check(self._lib.mp_vi_solve_v(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
+                                       _ptr(v), MP_MEM_HOST))
+        return v
+
+    def vi_solve_device(self, model, gamma, iterations, q_out, sweeps_out, robust=False, rtol=1e-5, atol=1e-8):
+        """Asynchronous solve into device tensors (q_out float64 [S,A], sweeps_out int32 [1])."""
+        _check(self._lib.mp_vi_solve(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
+                                     int(bool(robust)), _ptr(q_out), _ptr(sweeps_out), MP_MEM_DEVICE))
+
+    def vi_sweeps(self, model, gamma, sweeps, robust=False):
+        _check(self._lib.mp_vi_sweeps(self._h, model._h, float(gamma), int(sweeps), int(bool(robust))))
+
+    # ---- tree search -------------------------------------------------------------------------
+    def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
+                 root_steps=None, max_plan_len=None):
+        """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place."""
+        rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
+        n = rs.shape[0]
+        st = None if root_steps is None else np.ascontiguousarray(root_steps, dtype=np.int32).reshape(n)
+        if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+                and rng_state.size == n * 6):
+            raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6]")
+        mpl = int(horizon if max_plan_len is None else max_plan_len)
+        pp = np.ascontiguousarray(prior_p, dtype=np.float64)
+        rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
+        if pp.shape != (model.A,) or rp.shape != (model.A,):
+            raise ValueError("prior_p / rollout_p must have one entry per action")
+        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
+                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        _check(self._lib.mp_uct_plan(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
+                                     float(gamma), float(temperature), _ptr(pp), _ptr(rp), _ptr(rng_state), mpl,
+                                     _ptr(out["plans"]), _ptr(out["plan_len"]), _ptr(out["root_value"]),
+                                     _ptr(out["root_child_count"]), _ptr(out["root_child_value"]),
+                                     _ptr(out["env_steps"]), MP_MEM_HOST))
+        return out
+
+    def uct_plan_device(self, model, n_roots, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                        rng_state, max_plan_len, plans=None, plan_len=None, root_value=None, root_child_count=None,
+                        root_child_value=None, env_steps=None, root_steps=None):
+        """Same, on device tensors (torch); only enqueues on the ctx stream."""
+        pp = np.ascontiguousarray(prior_p, dtype=np.float64)
+        rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
+        _check(self._lib.mp_uct_plan(self._h, model._h, int(n_roots), _ptr(root_state), _ptr(root_steps),
+                                     int(episodes), int(horizon), float(gamma), float(temperature), _ptr(pp),
+                                     _ptr(rp), _ptr(rng_state), int(max_plan_len), _ptr(plans), _ptr(plan_len),
+                                     _ptr(root_value), _ptr(root_child_count), _ptr(root_child_value),
+                                     _ptr(env_steps), MP_MEM_DEVICE))
+
+    def uct_tree(self, root, cap):
+        t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), count=np.zeros(cap, np.int64),
+                 value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32))
+        n = c_i32()
+        _check(self._lib.mp_uct_tree_export(self._h, int(root), int(cap), C.byref(n), _ptr(t["parent"]),
+                                            _ptr(t["action"]), _ptr(t["count"]), _ptr(t["value"]),
+                                            _ptr(t["first_child"])))
+        return {k: v[:n.value].copy() for k, v in t.items()}
+
+    def opd_plan(self, model, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len=64):
+        rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
+        n = rs.shape[0]
+        if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+                and rng_state.size == n * 6):
+            raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6]")
+        mpl = int(max_plan_len)
+        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                   root_lower=np.zeros(n, np.float64), root_upper=np.zeros(n, np.float64),
+                   env_steps=np.zeros(n, np.int64), status=np.zeros(n, np.int32))
+        _check(self._lib.mp_opd_plan(self._h, model._h, n, _ptr(rs), int(budget), float(gamma),
+                                     float(terminal_reward), _ptr(rng_state), mpl, _ptr(out["plans"]),
+                                     _ptr(out["plan_len"]), _ptr(out["root_lower"]), _ptr(out["root_upper"]),
+                                     _ptr(out["env_steps"]), _ptr(out["status"]), MP_MEM_HOST))
+        return out
+
+    def opd_plan_device(self, model, n_roots, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len,
+                        plans=None, plan_len=None, root_lower=None, root_upper=None, env_steps=None, status=None):
+        _check(self._lib.mp_opd_plan(self._h, model._h, int(n_roots), _ptr(root_state), int(budget), float(gamma),
+                                     float(terminal_reward), _ptr(rng_state), int(max_plan_len), _ptr(plans),
+                                     _ptr(plan_len), _ptr(root_lower), _ptr(root_upper), _ptr(env_steps),
+                                     _ptr(status), MP_MEM_DEVICE))
+
+    def opd_tree(self, root, cap):
+        t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),
+                 depth=np.zeros(cap, np.int32), reward=np.zeros(cap, np.float64), lower=np.zeros(cap, np.float64),
+                 upper=np.zeros(cap, np.float64), done=np.zeros(cap, np.uint8), count=np.zeros(cap, np.int64),
+                 first_child=np.zeros(cap, np.int32))
+        n = c_i32()
+        _check(self._lib.mp_opd_tree_export(self._h, int(root), int(cap), C.byref(n), _ptr(t["parent"]),
+                                            _ptr(t["action"]), _ptr(t["state"]), _ptr(t["depth"]), _ptr(t["reward"]),
+                                            _ptr(t["lower"]), _ptr(t["upper"]), _ptr(t["done"]), _ptr(t["count"]),
+                                            _ptr(t["first_child"])))
+        return {k: v[:n.value].copy() for k, v in t.items()}
+
+
+class Model(object):
+    """Device-resident transition model (mp_model)."""
+
+    def __init__(self, ctx, handle, mode, m, s, a, b):
+        self.ctx, self._h, self.mode, self.M, self.S, self.A, self.B = ctx, handle, mode, m, s, a, b
+        self._keep = None
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._lib.mp_model_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rng_state_from_generator(gen):
+    """numpy Generator(PCG64) -> the 6 x uint64 state record the kernels step."""
+    st = gen.bit_generator.state
+    if st["bit_generator"] != "PCG64":
+        raise ValueError("planner randomness must be a numpy PCG64 generator")
+    s, inc = st["state"]["state"], st["state"]["inc"]
+    m = (1 << 64) - 1
+    return np.array([s >> 64, s & m, inc >> 64, inc & m, st["has_uint32"], st["uinteger"]], dtype=np.uint64)
+
+
+def generator_set_state(gen, state6):
+    """Write a stepped 6 x uint64 record back into a numpy Generator (keeps host and device streams one)."""
+    st = gen.bit_generator.state
+    st["state"]["state"] = (int(state6[0]) << 64) | int(state6[1])
+    st["state"]["inc"] = (int(state6[2]) << 64) | int(state6[3])
+    st["has_uint32"] = int(state6[4])
+    st["uinteger"] = int(state6[5])
+    gen.bit_generator.state = st

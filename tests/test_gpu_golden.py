@@ -1,0 +1,134 @@
+"""HIP path vs the reference's golden vectors, through the C ABI (libmi355plan.so), bit for bit.
+
+The goldens (tests/golden/*.npz) are outputs of the unmodified Python reference; the dense VI
+path is compared with the tolerance stated in the test (the matrix cores sum in another order
+than numpy's pairwise add.reduce), everything else must be identical.
+"""
+import numpy as np
+import pytest
+
+from tests.helpers import mdp_from_golden, assert_tree_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rl_agents_amd import native
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _load(ctx, cfg):
+    if cfg["mode"] == "deterministic":
+        return ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"], max_steps=cfg["max_steps"])
+    if cfg["mode"] == "stochastic":
+        return ctx.load_dense(cfg["transition"], cfg["reward"], cfg["terminal"])
+    return ctx.load_sparse(cfg["transition"], cfg["next"], cfg["reward"], cfg["terminal"])
+
+
+def test_library_loaded_is_in_tree():
+    from rl_agents_amd import native
+    lib = native.load()
+    assert lib.mp_abi_version() == 1
+    assert "rl_agents_amd/lib/libmi355plan.so" in native.lib_path()
+
+
+def test_value_iteration_golden(ctx, golden):
+    z = golden["vi"]
+    for name in [str(n) for n in z["vi/names"]]:
+        p = "vi/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        model = _load(ctx, cfg)
+        gamma, iters = float(z[p + "/gamma"]), int(z[p + "/iterations"])
+        q, sweeps = ctx.vi_solve(model, gamma, iters)
+        v = ctx.vi_solve_v(model, gamma, iters)
+        if cfg["mode"] == "stochastic":
+            # f64 MFMA accumulation order != numpy pairwise order: tolerance 1e-12 relative
+            np.testing.assert_allclose(q, z[p + "/Q"], rtol=1e-12, atol=1e-12, err_msg=name)
+            np.testing.assert_allclose(v, z[p + "/V"], rtol=1e-12, atol=1e-12, err_msg=name)
+            assert abs(sweeps - int(z[p + "/sweeps"])) <= 1, name
+        else:
+            assert sweeps == int(z[p + "/sweeps"]), name
+            assert np.array_equal(q, z[p + "/Q"]), name
+            assert np.array_equal(v, z[p + "/V"]), name
+        np.testing.assert_array_equal(q.argmax(axis=1), z[p + "/actions"], err_msg=name)
+        model.close()
+
+
+def test_robust_value_iteration_golden(ctx, golden):
+    z = golden["vi"]
+    for name in [str(n) for n in z["rvi/names"]]:
+        p = "rvi/" + name
+        mode = str(z[p + "/mode"])
+        if mode == "deterministic":
+            model = ctx.load_table(z[p + "/transitions"], z[p + "/rewards"])
+        else:
+            model = ctx.load_dense(z[p + "/transitions"], z[p + "/rewards"])
+        q, sweeps = ctx.vi_solve(model, float(z[p + "/gamma"]), int(z[p + "/iterations"]), robust=True)
+        if mode == "deterministic":
+            assert sweeps == int(z[p + "/sweeps"]), name
+            assert np.array_equal(q, z[p + "/Q"]), name
+        else:
+            np.testing.assert_allclose(q, z[p + "/Q"], rtol=1e-12, atol=1e-12, err_msg=name)
+        n = len(z[p + "/actions"])
+        np.testing.assert_array_equal(q.argmax(axis=1)[:n], z[p + "/actions"], err_msg=name)
+        model.close()
+
+
+def test_opd_golden(ctx, golden):
+    z = golden["opd"]
+    for name in [str(n) for n in z["opd/names"]]:
+        p = "opd/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        model = _load(ctx, cfg)
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        budget = int(z[p + "/budget"])
+        out = ctx.opd_plan(model, [int(z[p + "/s0"])], budget, float(z[p + "/gamma"]),
+                           float(z[p + "/terminal_reward"]), rng, max_plan_len=budget + 1)
+        assert out["status"][0] == 0
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert out["root_lower"][0] == float(z[p + "/root_lower"]), name
+        assert out["root_upper"][0] == float(z[p + "/root_upper"]), name
+        assert out["env_steps"][0] == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        a = cfg["reward"].shape[1]
+        tree = ctx.opd_tree(0, 1 + (budget // a) * a)
+        assert tree["count"][0] == int(z[p + "/root_count"])
+        assert_tree_equal(z, p + "/tree", tree, a, dict(count="count", lower="lower", upper="upper", reward="reward",
+                                                        done="done", depth="depth"))
+        model.close()
+
+
+def test_opd_reward_range_status(ctx):
+    from rl_agents_amd import native
+    t = [[1, 2], [1, 1], [3, 4], [3, 3], [4, 4]]
+    r = [[0, 0], [0, 0], [0, 0], [1, 1], [-1, -1]]
+    model = ctx.load_table(t, r, [0, 1, 0, 1, 1])
+    out = ctx.opd_plan(model, [0], 20, 0.8, 0.0, np.zeros((1, 6), np.uint64))
+    assert out["status"][0] == native.ERR_REWARD_RANGE
+
+
+def test_uct_golden(ctx, golden):
+    z = golden["uct"]
+    for name in [str(n) for n in z["uct/names"]]:
+        p = "uct/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        model = _load(ctx, cfg)
+        a = cfg["reward"].shape[1]
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        episodes, horizon = int(z[p + "/episodes"]), int(z[p + "/horizon"])
+        out = ctx.uct_plan(model, [int(z[p + "/s0"])], episodes, horizon, float(z[p + "/gamma"]),
+                           float(z[p + "/temperature"]), z[p + "/prior_p"], z[p + "/rollout_p"], rng,
+                           root_steps=[int(z[p + "/steps0"])])
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert out["env_steps"][0] == int(z[p + "/env_steps"]), name
+        assert out["root_value"][0] == float(z[p + "/root_value"]), name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        tree = ctx.uct_tree(0, 1 + episodes * a)
+        assert tree["count"][0] == int(z[p + "/root_count"])
+        assert_tree_equal(z, p + "/tree", tree, a, dict(count="count", value="value"))
+        model.close()
