@@ -1,0 +1,373 @@
+#!/usr/bin/env python3
+"""Benchmark of the planning hot path on MI355X (contract: see the task statement / DESIGN.md §Measurement).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload uct|opd|vi|vi_dense] [--roots R]
+
+Default workload = the BASELINE.json headline: MCTS/UCT on a highway-shaped finite MDP
+(S = 10 000, |A| = 5), budget 1000 as 33 episodes x horizon 30, 4096 independent roots per GPU.
+A "step" is one batched plan() call over all roots of this rank (inputs already in HBM).
+`value` = environment transitions executed inside plan() by ALL ranks / wall time (max over ranks).
+
+Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
+roots are sharded over ranks with no data-path collective (weak scaling: 4096 roots per GPU); the
+only exchange is one RCCL all_gather of the per-root results (first action, root value) per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix peak (vendor figure; the guide lists no f64 row)
+# algorithmic HBM bytes per unit of work, SURVEY.md §8(d) / DESIGN.md §Kernels
+UCT_BYTES_PER_ENV_STEP = 28.0  # (13 H + 16 A d + 24 (d+1) + 24 A) / H at H=30, A=5, d~3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="uct", choices=["uct", "opd", "vi", "vi_dense"])
+    ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 4096 uct, 1024 opd)")
+    ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    return ap.parse_args()
+
+
+def dist_setup(n_gpus):
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(0)
+        local = 0
+    if world != n_gpus and rank == 0:
+        print("warning: --gpus {} but WORLD_SIZE {}".format(n_gpus, world), file=sys.stderr)
+    return rank, world, local
+
+
+def barrier(world):
+    import torch
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def max_over_ranks(x, world):
+    import torch
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x, world):
+    import torch
+    if world == 1:
+        return x
+    import torch.distributed as dist
+    t = torch.tensor([x], dtype=torch.float64, device="cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def seed_states(global_ids, base_seed=0):
+    """numpy PCG64 state records for roots with the given global ids (root i <- SeedSequence(base_seed + i))."""
+    from rl_agents_amd import native
+    out = np.zeros((len(global_ids), 6), dtype=np.uint64)
+    for j, i in enumerate(global_ids):
+        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(base_seed + int(i))))
+        out[j] = native.rng_state_from_generator(g)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+def bench_uct(args, rank, world, local):
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    n_roots = args.roots or 4096
+    episodes, horizon, gamma = 33, 30, 0.8
+    temperature = 2 / (1 - 0.8)                       # mcts.py:121-124 default
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    s_, a_ = r.shape
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_table(t, r, term)
+    gids = np.arange(rank * n_roots, (rank + 1) * n_roots)
+    roots_rng = np.random.Generator(np.random.PCG64(12345))
+    non_term = np.flatnonzero(~np.asarray(term))
+    all_roots = roots_rng.choice(non_term, size=world * n_roots).astype(np.int32)
+    s0 = all_roots[gids]
+    rng0 = seed_states(gids)
+    dev = torch.device("cuda", local)
+    d_s0 = torch.from_numpy(s0).to(dev)
+    d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)   # raw 64-bit words
+    mpl = 8
+    d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
+    d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
+    d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
+    p = np.ones(a_) / a_
+    gathered = [torch.empty(n_roots, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+
+    def step():
+        ctx.uct_plan_device(model, n_roots, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
+                            plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps)
+        d_total.add_(d_steps.sum())
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_gather(gathered, d_val)
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    env_steps = 0
+    kernel_ms = []
+    d_total.zero_()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = time.perf_counter() - t0
+    timed_env_steps = int(d_total.item())
+    # per-launch kernel time from HIP events on the kernel's stream (separate short pass so that the
+    # event synchronisation does not sit inside the timed region above)
+    for _ in range(min(args.steps, 10)):
+        step()
+        kernel_ms.append(ctx.last_kernel_ms()[0])
+        env_steps = int(d_steps.sum().item())
+    dt = max_over_ranks(dt, world)
+    total_env_steps = sum_over_ranks(float(timed_env_steps), world) / args.steps   # per step, all ranks
+    k_ms = float(np.mean(kernel_ms))
+    res = dict(
+        metric="rollout env-steps/sec (UCT plan(), budget=1000)", unit="env-steps/s",
+        value=total_env_steps * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
+        dtype="f64",
+        config=dict(workload="uct_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
+            s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
+            states=s_, actions=a_, episodes=episodes, horizon=horizon, gamma=gamma,
+            env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots,
+            parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
+        roofline=dict(bound="hbm", achieved=UCT_BYTES_PER_ENV_STEP * env_steps / (k_ms * 1e-3) / 1e9,
+                      peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, kernel="uct_table_kernel",
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=UCT_BYTES_PER_ENV_STEP * env_steps),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = os.cpu_count() or 1
+        n_cpu = max(2048, 64 * cores)
+        cpu_rng = seed_states(np.arange(n_cpu))
+        oracle.uct_plan_batch(t, r, term, all_roots[:64], episodes, horizon, gamma, temperature, p, p, cpu_rng[:64],
+                              n_threads=cores)
+        done, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            o = oracle.uct_plan_batch(t, r, term, np.resize(all_roots, n_cpu), episodes, horizon, gamma, temperature,
+                                      p, p, cpu_rng, n_threads=cores)
+            done += int(o["env_steps"].sum())
+        cdt = time.perf_counter() - t1
+        t2 = time.perf_counter()
+        o1 = oracle.uct_plan_batch(t, r, term, np.resize(all_roots, 256), episodes, horizon, gamma, temperature, p, p,
+                                   cpu_rng[:256], n_threads=1)
+        one = int(o1["env_steps"].sum()) / (time.perf_counter() - t2)
+        res["cpu_baseline"] = dict(value=done / cdt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="oracle/planning_oracle.c uct_plan_batch, OpenMP over roots, {} roots per "
+                                          "batch repeated for {:.1f} s, same tables/params".format(n_cpu, cdt),
+                                   value_1core=one)
+    ctx.synchronize()
+    return res
+
+
+def bench_opd(args, rank, world, local):
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    n_roots = args.roots or 1024
+    budget, gamma = 5000, 0.8
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    s_, a_ = r.shape
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_table(t, r, term)
+    roots_rng = np.random.Generator(np.random.PCG64(12345))
+    non_term = np.flatnonzero(~np.asarray(term))
+    all_roots = roots_rng.choice(non_term, size=world * n_roots).astype(np.int32)
+    s0 = all_roots[rank * n_roots:(rank + 1) * n_roots]
+    dev = torch.device("cuda", local)
+    d_s0 = torch.from_numpy(s0).to(dev)
+    d_rng = torch.zeros((n_roots, 6), dtype=torch.int64, device=dev)
+    mpl = 32
+    d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
+    d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
+    d_lo = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_up = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
+    d_status = torch.empty(n_roots, dtype=torch.int32, device=dev)
+    gathered = [torch.empty(n_roots, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+
+    def step():
+        ctx.opd_plan_device(model, n_roots, d_s0, budget, gamma, 0.0, d_rng, mpl, plans=d_plans, plan_len=d_len,
+                            root_lower=d_lo, root_upper=d_up, env_steps=d_steps, status=d_status)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_gather(gathered, d_lo)
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    step()
+    k_ms = ctx.last_kernel_ms()[0]
+    env_steps = int(d_steps.sum().item())
+    assert int(d_status.abs().sum().item()) == 0
+    total = sum_over_ranks(float(env_steps), world)
+    k = budget // a_
+    d_avg = 10.0
+    bytes_per_exp = a_ * (13 + 48) + 16 * a_ * d_avg + 16 * d_avg
+    alg = bytes_per_exp * k * n_roots
+    res = dict(
+        metric="rollout env-steps/sec (OPD plan(), budget=5000)", unit="env-steps/s",
+        value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
+        config=dict(workload="opd_highway_shaped_S{}_A{}_budget{}_roots{}_per_gpu".format(s_, a_, budget, n_roots),
+                    n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, budget=budget, gamma=gamma,
+                    plan_ms_per_root=1e3 * dt / args.steps / n_roots,
+                    parallelism="roots sharded over {} GPU(s)".format(world)),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
+                      kernel="opd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = os.cpu_count() or 1
+        n_cpu = min(cores, 256)
+        t1 = time.perf_counter()
+        o = oracle.opd_plan_batch(t, r, term, np.resize(all_roots, n_cpu), budget, gamma, 0.0, None, n_threads=cores)
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=float(o["env_steps"].sum()) / cdt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="oracle/planning_oracle.c opd_plan_batch, {} roots, OpenMP".format(n_cpu))
+    return res
+
+
+def bench_vi(args, rank, world, local, dense):
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    gamma, sweeps = 0.95, 200
+    dev = torch.device("cuda", local)
+    if dense:
+        s_, a_ = (args.states or 10000), 5
+        g = torch.Generator(device=dev)
+        g.manual_seed(0)
+        tt = torch.rand((s_, a_, s_), dtype=torch.float64, device=dev, generator=g)
+        tt /= tt.sum(-1, keepdim=True)
+        rr = torch.rand((s_, a_), dtype=torch.float64, device=dev, generator=g)
+        model = ctx.load_dense(tt, rr, None)
+        sweeps = 20
+        alg = 8.0 * s_ * s_ * a_
+        flops = 2.0 * s_ * s_ * a_
+        name = "vi_dense_q"
+    else:
+        cfg = generators.highway_shaped(10, 10, 100, seed=0)
+        t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+        s_, a_ = r.shape
+        model = ctx.load_table(t, r, term)
+        alg = 12.0 * s_ * a_ + 17.0 * s_
+        flops = 0.0
+        name = "vi_det_sweep"
+
+    def step():
+        ctx.vi_sweeps(model, gamma, sweeps)
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    step()
+    k_ms, n_launch = ctx.last_kernel_ms()
+    per_sweep_ms = k_ms / sweeps
+    res = dict(
+        metric="value-iteration Bellman sweeps/sec", unit="sweeps/s", value=world * sweeps * args.steps / dt,
+        ms_per_step=1e3 * dt / args.steps, dtype="f64",
+        config=dict(workload="{}_S{}_A{}_{}sweeps".format("vi_dense" if dense else "vi_highway_shaped", s_, a_, sweeps),
+                    states=s_, actions=a_, gamma=gamma, ms_per_sweep=1e3 * dt / args.steps / sweeps,
+                    parallelism="replicas only ({} GPU(s))".format(world)),
+        roofline=dict(bound="hbm", achieved=alg / (per_sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      traffic=None, kernel=name, kernel_ms=per_sweep_ms, algorithmic_bytes_per_launch=alg),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if dense:
+        res["roofline"]["mfma_tflops"] = flops / (per_sweep_ms * 1e-3) / 1e12
+        res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
+    if rank == 0 and not args.no_cpu_baseline and not dense:
+        from oracle import oracle
+        t1 = time.perf_counter()
+        reps = 0
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            oracle.vi_solve("deterministic", t, r, term, gamma=gamma, iterations=sweeps, rtol=-1.0, atol=-1.0)
+            reps += 1
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=reps * sweeps / cdt, unit="sweeps/s", cores=1, kind="port",
+                                   sample="oracle/planning_oracle.c orc_vi_solve, {} x {} sweeps".format(reps, sweeps))
+    return res
+
+
+def main():
+    args = parse()
+    rank, world, local = dist_setup(args.gpus)
+    import torch
+    side = torch.cuda.Stream(device=local)          # one stream for torch ops, RCCL and the HIP kernels
+    with torch.cuda.stream(side):
+        if args.workload == "uct":
+            res = bench_uct(args, rank, world, local)
+        elif args.workload == "opd":
+            res = bench_opd(args, rank, world, local)
+        else:
+            res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense")
+    res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+               vs_baseline=None, data="synthetic (highway-shaped finite MDP; real highway_env absent)")
+    res.setdefault("cpu_baseline", None)
+    if rank == 0:
+        order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+        print(json.dumps({k: res[k] for k in order}))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

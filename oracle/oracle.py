@@ -15,11 +15,24 @@ _LIB = None
 ERR_REWARD_RANGE = -2
 
 
+def _digest():
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("planning_oracle.c", "Makefile"):
+        with open(os.path.join(_HERE, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def build(force=False):
+    """Compile the C restatement (content-stamped: mtimes do not survive the snapshot to the GPU box)."""
     so = os.path.join(_HERE, "liboracle.so")
-    src = os.path.join(_HERE, "planning_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
+    stamp = so + ".stamp"
+    fresh = os.path.exists(so) and os.path.exists(stamp) and open(stamp).read().strip() == _digest()
+    if force or not fresh:
+        subprocess.check_call(["make", "-s", "-B", "-C", _HERE, "liboracle.so"])
+        with open(stamp, "w") as f:
+            f.write(_digest())
     return so
 
 

@@ -19,7 +19,8 @@ SOURCES = ["api.hip", "vi.hip", "uct.hip", "opd.hip"]
 HEADERS = ["common.hpp", "pcg64.hpp"]
 # -ffp-contract=off: the reference evaluates a*b+c with two roundings (Python floats); a fused
 # multiply-add would change the last bit of bounds and Q values and break bit-exact parity.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+# MP_PROFILE=1 in the environment builds the phase-instrumented kernels (device printf of clock64 ticks)
+FLAGS = (["-DMP_PROFILE"] if os.environ.get("MP_PROFILE") else []) + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
 
 
@@ -30,12 +31,25 @@ def hipcc():
     raise RuntimeError("hipcc not found (need ROCm >= 7.0 to build libmi355plan.so)")
 
 
+STAMP_PATH = LIB_PATH + ".stamp"
+
+
+def source_digest():
+    """sha256 over every source, header and flag that goes into the library (mtimes do not survive the
+    snapshot to the GPU box, content does)."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "mi355plan.h")]:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def needs_build():
-    if not os.path.exists(LIB_PATH):
+    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "mi355plan.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_digest()
 
 
 def build(force=False, verbose=False):
@@ -61,6 +75,8 @@ def build(force=False, verbose=False):
             print(out.decode())
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
+    with open(STAMP_PATH, "w") as f:
+        f.write(source_digest())
     return LIB_PATH
 
 

@@ -45,6 +45,23 @@ int ws_reserve(mp_ctx *ctx, int slot, size_t bytes, void **out)
     return MP_OK;
 }
 
+int upload_tables(mp_ctx *ctx, int kind, const std::vector<double> &tab, double **dev)
+{
+    double *d = nullptr;
+    const bool same = ctx->tab_kind == kind && ctx->tab_host.size() == tab.size() && ctx->ws[WS_TAB0].p &&
+                      memcmp(ctx->tab_host.data(), tab.data(), tab.size() * sizeof(double)) == 0;
+    MP_TRY(ws_get(ctx, WS_TAB0, tab.size(), &d));
+    if (!same) {
+        ctx->tab_kind = 0;
+        MP_HIP(hipMemcpyAsync(d, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        MP_HIP(hipStreamSynchronize(ctx->stream)); // pageable source: must be consumed before return
+        ctx->tab_host = tab;
+        ctx->tab_kind = kind;
+    }
+    *dev = d;
+    return MP_OK;
+}
+
 int kernels_begin(mp_ctx *ctx)
 {
     MP_HIP(hipEventRecord(ctx->ev0, ctx->stream));

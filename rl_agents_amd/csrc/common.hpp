@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <vector>
 
 #include "../../include/mi355plan.h"
 
@@ -67,8 +68,10 @@ struct mp_ctx {
     hipDeviceProp_t prop;
     mp::DevBuf ws[mp::WS_COUNT];
     mp::TreeMeta tree;
-    // value-iteration state left on the device by mp_vi_sweeps (timing hook)
-    int vi_last = 0;
+    // host mirror of the small per-call tables (gamma powers, priors, cdf) last uploaded to
+    // WS_TAB0: identical parameters on the next call skip the upload and its stream sync
+    std::vector<double> tab_host;
+    int tab_kind = 0;
 };
 
 struct mp_model {
@@ -91,6 +94,9 @@ namespace mp {
 
 // grow-only device workspace
 int ws_reserve(mp_ctx *ctx, int slot, size_t bytes, void **out);
+
+// upload `tab` to WS_TAB0 unless the same table (same kind, same bytes) is already there
+int upload_tables(mp_ctx *ctx, int kind, const std::vector<double> &tab, double **dev);
 
 // timing brackets around kernel launches (HIP events on the ctx stream)
 int kernels_begin(mp_ctx *ctx);

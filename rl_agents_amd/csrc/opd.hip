@@ -11,13 +11,19 @@
 //     creation order (removal keeps order, children are appended, deterministic.py:29,42).
 //   * the |A| children are created by |A| lanes: one 16-byte model gather each, bounds from
 //     host-computed gamma-power tables (libm pow = Python **), node records to HBM.
-//   * backup_to_root (deterministic.py:74-79) walks up with |A| lanes reading the sibling group
-//     and a small reduction; it stops as soon as a node's (L, U) do not change, which cannot
-//     change any ancestor either -- same values as the reference's full walk.
+//   * backup_to_root (deterministic.py:74-79) is NOT replayed per expansion.  No decision made
+//     during planning reads an internal node's bounds (leaf selection reads leaf U, a child's L
+//     starts from its parent's creation-time L), and after every reference backup each ancestor
+//     equals the max over its children; so the final bounds are the unique bottom-up fixed point
+//     L[n] = max_c L[c], U[n] = max_c U[c].  It is computed once at the end, in reverse expansion
+//     order (children always have larger ids than their parent), inside LDS: O(K) instead of the
+//     reference's O(K * depth) -- on highway-shaped tables, whose reward-1 lane makes the tree a
+//     chain, that removes 62 dependent HBM round trips per expansion.  max is exact, so the
+//     bounds are bit-identical to the incremental walk.
 //   * `count` (deterministic.py:62-63) is not needed by any decision; it is reconstructed from
 //     subtree sizes at export time.
-// HBM per root: node records L, U (f64), state, depth (i32), reward (f64), done (u8), first_child
-// (i32): 37 B/node; LDS per root: 8 B/node (+ 4 B per expansion for the parent map).
+// HBM per root: {L f64, state i32, depth i32} 16 B + U f64 + reward f64 + first_child i32 + done u8
+// = 37 B/node; LDS per root: 8 B/node (+ 4 B per expansion for the parent map).
 #include <math.h>
 #include <string.h>
 
@@ -37,8 +43,9 @@ struct OpdArgs {
     const double *tdiv; // tdiv[d] = terminal_reward * gamma ** d / (1 - gamma)
     uint64_t *rng;
     // per-root node arrays, root-major [n_roots][cap]
-    double *L, *U, *reward;
-    int32_t *state, *depth, *first_child;
+    double *L; // OpdNode records {L, state, depth}, 16 B per node
+    double *U, *reward;
+    int32_t *first_child;
     uint8_t *done;
     int32_t *expanded; // [n_roots][K] node expanded at step k (= parent of nodes 1 + kA .. 1 + kA + A - 1)
     int32_t *n_nodes_out;
@@ -76,6 +83,13 @@ __device__ __forceinline__ double wave_max(double v)
     return v;
 }
 
+struct alignas(16) OpdNode {
+    double L;      // lower bound (creation-time value for leaves; final value after the bottom-up pass)
+    int32_t state; // cloned-environment state
+    int32_t depth;
+};
+static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
+
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -85,52 +99,74 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     const int root = blockIdx.x;
     const int A = p.A;
     const long base = (long)root * p.cap;
-    double *L = p.L + base, *U = p.U + base, *RW = p.reward + base;
-    int32_t *ST = p.state + base, *DP = p.depth + base, *FC = p.first_child + base;
+    OpdNode *NA = reinterpret_cast<OpdNode *>(p.L) + base;
+    double *U = p.U + base, *RW = p.reward + base;
+    int32_t *FC = p.first_child + base;
     uint8_t *DN = p.done + base;
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
     const double ninf = -INFINITY;
 
     // deterministic.py:10-19 root: L = U = 0, depth 0
     if (lane == 0) {
-        L[0] = 0.0; U[0] = 0.0; RW[0] = 0.0; ST[0] = p.root_state[root]; DP[0] = 0; FC[0] = -1; DN[0] = 0;
+        OpdNode n0;
+        n0.L = 0.0; n0.state = p.root_state[root]; n0.depth = 0;
+        NA[0] = n0;
+        RW[0] = 0.0; FC[0] = -1; DN[0] = 0;
         leafU[0] = 0.0;
     }
     __syncthreads();
     int n_nodes = 1;
     int status = MP_OK;
+    int k_done = 0;
 
+#ifdef MP_PROFILE
+    long long t_scan = 0, t_exp = 0, t_all0 = clock64();
+#define PROF_T(x) const long long x = clock64()
+#else
+#define PROF_T(x)
+#endif
     for (int k = 0; k < p.K; ++k) {
+        PROF_T(c0);
         // ---- deterministic.py:110: first maximal upper bound among the leaves
         double bu = ninf;
         int bid = 0x7fffffff;
-        for (int i = lane; i < n_nodes; i += 64) {
+        int i = lane;
+        for (; i + 192 < n_nodes; i += 256) { // 4 independent LDS reads in flight per lane
+            const double u0 = leafU[i], u1 = leafU[i + 64], u2 = leafU[i + 128], u3 = leafU[i + 192];
+            if (u0 > bu) { bu = u0; bid = i; }
+            if (u1 > bu) { bu = u1; bid = i + 64; }
+            if (u2 > bu) { bu = u2; bid = i + 128; }
+            if (u3 > bu) { bu = u3; bid = i + 192; }
+        }
+        for (; i < n_nodes; i += 64) {
             const double u = leafU[i];
             if (u > bu) { bu = u; bid = i; }
         }
         wave_argmax(bu, bid);
         const int leaf = bid;
+        PROF_T(c1);
         // ---- DeterministicNode.expand, deterministic.py:28-43
-        const int s_leaf = ST[leaf];
-        const int d = DP[leaf] + 1;
-        const double Lp = L[leaf];
+        const OpdNode pn = NA[leaf];
+        const int d = pn.depth + 1;
         const int g = n_nodes; // first child
-        double Lc = ninf, Uc = ninf;
         bool bad = false;
         if (lane < A) {
-            const Rec rc = p.rec[(long)s_leaf * A + lane];
+            const Rec rc = p.rec[(long)pn.state * A + lane];
             const double r = rc.reward;
             bad = !(0.0 <= r) || !(r <= 1.0); // deterministic.py:46-47
             const bool dn = (rc.flags & done_bit) != 0;
             // deterministic.py:45-65 update()
-            Lc = Lp + p.g1[d] * r;
-            Uc = Lc + p.gdiv[d];
+            double Lc = pn.L + p.g1[d] * r;
+            double Uc = Lc + p.gdiv[d];
             if (dn) {
                 const double nv = Lc + p.tdiv[d];
                 Lc = nv; Uc = nv;
             }
             const int c = g + lane;
-            L[c] = Lc; U[c] = Uc; RW[c] = r; ST[c] = rc.next; DP[c] = d; FC[c] = -1; DN[c] = dn ? 1 : 0;
+            OpdNode cn;
+            cn.L = Lc; cn.state = rc.next; cn.depth = d;
+            NA[c] = cn;
+            RW[c] = r; FC[c] = -1; DN[c] = dn ? 1 : 0;
             leafU[c] = Uc;
         }
         if (lane == 0) {
@@ -139,44 +175,62 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             FC[leaf] = g;
         }
         n_nodes += A;
+        k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        // ---- backup_to_root, deterministic.py:74-79 (first level from registers)
-        double nl = wave_max(Lc), nu = wave_max(Uc);
-        int cur = leaf;
-        double oldL = Lp, oldU = bu; // the leaf's own bounds before the backup
-        while (true) {
-            const bool changed = !(nl == oldL && nu == oldU);
-            if (changed && lane == 0) { L[cur] = nl; U[cur] = nu; }
-            if (!changed || cur == 0) break;
-            __threadfence_block();
-            // siblings of cur (cur included) = children of its parent
-            const int kk = (cur - 1) / A;
-            const int par = exp_lds[kk];
-            const int gg = 1 + kk * A;
-            double cl = ninf, cu = ninf;
-            if (lane < A) {
-                const int c = gg + lane;
-                if (c == cur) { cl = nl; cu = nu; }
-                else { cl = L[c]; cu = U[c]; }
-            }
-            oldL = L[par]; oldU = U[par];
-            nl = wave_max(cl); nu = wave_max(cu);
-            cur = par;
-        }
-        __syncthreads(); // LDS leaf array / parent map visible to all lanes for the next scan
+        __syncthreads(); // LDS leaf array visible to all lanes for the next scan
+#ifdef MP_PROFILE
+        { const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1; }
+#endif
     }
-
-    // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule (deterministic.py:21-26)
+    PROF_T(cf0);
     __syncthreads();
-    __threadfence_block();
+
     if (status == MP_OK) {
+        // ---- all backup_to_root calls at once (deterministic.py:67-79): bottom-up max, in LDS.
+        // upper bounds: leaf entries are already in place, expanded entries hold -inf placeholders
+        for (int k = k_done - 1; k >= 0; --k) {
+            const int g = 1 + k * A;
+            double m = leafU[g];
+            for (int a = 1; a < A; ++a) {
+                const double v = leafU[g + a];
+                if (v > m) m = v;
+            }
+            if (lane == 0) leafU[exp_lds[k]] = m;
+        }
+        __syncthreads();
+        for (int i = lane; i < n_nodes; i += 64) U[i] = leafU[i];
+        const double root_upper = leafU[0];
+        __syncthreads();
+        // lower bounds: same pass over the creation-time L values
+        for (int i = lane; i < n_nodes; i += 64) leafU[i] = NA[i].L;
+        __syncthreads();
+        for (int k = k_done - 1; k >= 0; --k) {
+            const int g = 1 + k * A;
+            double m = leafU[g];
+            for (int a = 1; a < A; ++a) {
+                const double v = leafU[g + a];
+                if (v > m) m = v;
+            }
+            if (lane == 0) leafU[exp_lds[k]] = m;
+        }
+        __syncthreads();
+        for (int k = lane; k < k_done; k += 64) {
+            const int n = exp_lds[k];
+            NA[n].L = leafU[n];
+        }
+        // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
+        // (deterministic.py:21-26): random_argmax over the children's lower bounds (now in LDS)
         Pcg64 gen;
         gen.load(p.rng + (long)root * 6);
         int n = 0, len = 0;
         int fc = FC[0];
         while (fc >= 0) {
-            const double l = lane < A ? L[fc + lane] : ninf;
-            const double m = wave_max(l);
+            double m = leafU[fc];
+            for (int a = 1; a < A; ++a) {
+                const double v = leafU[fc + a];
+                if (v > m) m = v;
+            }
+            const double l = lane < A ? leafU[fc + lane] : ninf;
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
@@ -193,20 +247,25 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             if (p.plans)
                 for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[root] = len;
-            if (p.root_lower) p.root_lower[root] = L[0];
-            if (p.root_upper) p.root_upper[root] = U[0];
+            if (p.root_lower) p.root_lower[root] = leafU[0];
+            if (p.root_upper) p.root_upper[root] = root_upper;
         }
     } else if (lane == 0) {
         if (p.plans)
             for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
         if (p.plan_len) p.plan_len[root] = 0;
     }
+#ifdef MP_PROFILE
+    if (root == 0 && lane == 0)
+        printf("opd prof root0: K=%d total=%lld scan=%lld expand=%lld final=%lld (clock64 ticks)\n", p.K,
+               (long long)(clock64() - t_all0), t_scan, t_exp, (long long)(clock64() - cf0));
+#endif
     if (lane == 0) {
         if (p.status) p.status[root] = status;
         if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1);
         p.n_nodes_out[root] = n_nodes;
-        for (int k = 0; k < p.K; ++k) p.expanded[(long)root * p.K + k] = k * A + 1 < n_nodes ? exp_lds[k] : -1;
     }
+    for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
 }
 
 } // namespace mp
@@ -243,9 +302,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
         tab[2 * D + d] = terminal_reward * pow(gamma, (double)d) / (1 - gamma);
     }
     double *d_tab = nullptr;
-    MP_TRY(ws_get(ctx, WS_TAB0, tab.size(), &d_tab));
-    MP_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    MP_HIP(hipStreamSynchronize(st));
+    MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     OpdArgs a;
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap;
@@ -253,11 +310,9 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     a.rec = model->rec;
     a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;
     const size_t nn = (size_t)n_roots * cap;
-    MP_TRY(ws_get(ctx, WS_TREE0, nn, &a.L));
+    MP_TRY(ws_get(ctx, WS_TREE0, 2 * nn, &a.L)); // OpdNode records, 16 B each
     MP_TRY(ws_get(ctx, WS_TREE1, nn, &a.U));
     MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.reward));
-    MP_TRY(ws_get(ctx, WS_TREE3, nn, &a.state));
-    MP_TRY(ws_get(ctx, WS_TREE4, nn, &a.depth));
     MP_TRY(ws_get(ctx, WS_TREE5, nn, &a.first_child));
     MP_TRY(ws_get(ctx, WS_TREE6, nn, &a.done));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
@@ -318,11 +373,17 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
     MP_TRY(pull(fc.data(), WS_TREE5, sizeof(int32_t)));
     MP_HIP(hipMemcpy(exp.data(), d_exp + (size_t)root * (K > 0 ? K : 1), (size_t)(K > 0 ? K : 1) * sizeof(int32_t),
                      hipMemcpyDeviceToHost));
-    MP_TRY(pull(lower, WS_TREE0, sizeof(double)));
     MP_TRY(pull(upper, WS_TREE1, sizeof(double)));
     MP_TRY(pull(reward, WS_TREE2, sizeof(double)));
-    MP_TRY(pull(state, WS_TREE3, sizeof(int32_t)));
-    MP_TRY(pull(depth, WS_TREE4, sizeof(int32_t)));
+    {
+        std::vector<OpdNode> na((size_t)n);
+        MP_TRY(pull(na.data(), WS_TREE0, sizeof(OpdNode)));
+        for (int i = 0; i < n; ++i) {
+            if (lower) lower[i] = na[i].L;
+            if (state) state[i] = na[i].state;
+            if (depth) depth[i] = na[i].depth;
+        }
+    }
     MP_TRY(pull(done, WS_TREE6, sizeof(uint8_t)));
     std::vector<int32_t> par((size_t)n);
     par[0] = -1;

@@ -19,6 +19,7 @@
 // randomness is numpy's PCG64 stepped on the device (pcg64.hpp), so results are bit-identical
 // to the Python planner for equal seeds.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -37,6 +38,7 @@ static_assert(sizeof(UctNode) == 16, "UctNode must be one dwordx4");
 struct UctArgs {
     int n_roots, S, A, episodes, horizon, cap;
     int done_on_next, max_steps, max_plan_len;
+    int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
     const Rec *rec;
     const int32_t *root_state, *root_steps;
     const double *gpow; // gamma ** h, h = 0..horizon   (host libm pow, = Python's float **)
@@ -49,14 +51,33 @@ struct UctArgs {
     int64_t *root_child_count, *env_steps;
 };
 
+// AT > 0: |A| known at compile time (children scored from registers in one pass, tables in
+// registers); AT == 0: any |A| (three passes over the children, tables in LDS).
+template <int AT>
 __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
 {
-    extern __shared__ int32_t path[]; // [(horizon + 1)][64]
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int lane = threadIdx.x;
-    const int r = blockIdx.x * 64 + lane;
-    if (r >= p.n_roots) return;
-    const int A = p.A, H = p.horizon;
+    const int A = AT > 0 ? AT : p.A, H = p.horizon;
+    // LDS: gamma powers [H + 1] | (generic) tp [A], cdf [A] | path stack [(H + 1)][64] int32
+    double *gpow = lds_d;
+    double *tpL = gpow + (H + 1);
+    double *cdfL = tpL + (AT > 0 ? 0 : A);
+    int32_t *path = reinterpret_cast<int32_t *>(cdfL + (AT > 0 ? 0 : A));
+    for (int i = lane; i <= H; i += 64) gpow[i] = p.gpow[i];
+    if (AT == 0)
+        for (int i = lane; i < A; i += 64) { tpL[i] = p.tp[i]; cdfL[i] = p.cdf[i]; }
+    constexpr int AR = AT > 0 ? AT : 1;
+    double tp[AR], cdf[AR];
+    if (AT > 0) {
+#pragma unroll
+        for (int a = 0; a < AR; ++a) { tp[a] = p.tp[a]; cdf[a] = p.cdf[a]; }
+    }
+    __syncthreads();
+    const int r = blockIdx.x * p.lanes + lane;
+    if (lane >= p.lanes || r >= p.n_roots) return;
     UctNode *tree = p.tree + (long)r * p.cap;
+    const Rec *__restrict__ rec = p.rec;
     Pcg64 g;
     g.load(p.rng + (long)r * 6);
     const int32_t s0 = p.root_state[r];
@@ -71,7 +92,15 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
     int64_t steps_taken = 0;
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
 
+#ifdef MP_PROFILE
+    long long t_sel = 0, t_expd = 0, t_roll = 0, t_bak = 0, n_sel = 0, n_roll = 0;
+    const long long t_all0 = clock64();
+#define PROF_T(x) const long long x = clock64()
+#else
+#define PROF_T(x)
+#endif
     for (int ep = 0; ep < p.episodes; ++ep) { // mcts.py:179-184
+        PROF_T(c0);
         int32_t s = s0, st = st0;
         int node = 0, depth = 0;
         bool terminal = false;
@@ -82,39 +111,66 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
         while (depth < H && fc >= 0 && !terminal) {
             // MCTSNode.selection_strategy (mcts.py:275-286) for each child, Node.random_argmax
             // (abstract.py:296-311): exact-equality argmax set, uniform draw among >= 2 ties
-            double m = 0.0;
-            for (int a = 0; a < A; ++a) {
-                const UctNode c = tree[fc + a];
-                const double sc = c.value + p.tp[a] / (double)(c.count + 1);
-                if (a == 0 || sc > m) m = sc;
-            }
-            int nt = 0;
-            for (int a = 0; a < A; ++a) {
-                const UctNode c = tree[fc + a];
-                const double sc = c.value + p.tp[a] / (double)(c.count + 1);
-                nt += sc == m ? 1 : 0;
-            }
-            int pick = (int)g.below((uint32_t)nt);
             int act = 0;
-            for (int a = 0; a < A; ++a) {
-                const UctNode c = tree[fc + a];
-                const double sc = c.value + p.tp[a] / (double)(c.count + 1);
-                if (sc == m) {
-                    if (pick == 0) { act = a; break; }
-                    --pick;
+            if (AT > 0) {
+                UctNode c[AR];
+#pragma unroll
+                for (int a = 0; a < AR; ++a) c[a] = tree[fc + a];
+                double sc[AR];
+#pragma unroll
+                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + tp[a] / (double)(c[a].count + 1);
+                double m = sc[0];
+#pragma unroll
+                for (int a = 1; a < AR; ++a) m = sc[a] > m ? sc[a] : m;
+                int nt = 0;
+#pragma unroll
+                for (int a = 0; a < AR; ++a) nt += sc[a] == m ? 1 : 0;
+                int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
+                bool found = false;
+#pragma unroll
+                for (int a = 0; a < AR; ++a) {
+                    const bool eq = sc[a] == m;
+                    if (eq && !found && pick == 0) { act = a; found = true; }
+                    if (eq && !found) --pick;
+                }
+            } else {
+                double m = 0.0;
+                for (int a = 0; a < A; ++a) {
+                    const UctNode c = tree[fc + a];
+                    const double sc = c.value + tpL[a] / (double)(c.count + 1);
+                    if (a == 0 || sc > m) m = sc;
+                }
+                int nt = 0;
+                for (int a = 0; a < A; ++a) {
+                    const UctNode c = tree[fc + a];
+                    const double sc = c.value + tpL[a] / (double)(c.count + 1);
+                    nt += sc == m ? 1 : 0;
+                }
+                int pick = (int)g.below((uint32_t)nt);
+                for (int a = 0; a < A; ++a) {
+                    const UctNode c = tree[fc + a];
+                    const double sc = c.value + tpL[a] / (double)(c.count + 1);
+                    if (sc == m) {
+                        if (pick == 0) { act = a; break; }
+                        --pick;
+                    }
                 }
             }
-            const Rec rc = p.rec[(long)s * A + act];
+            const Rec rc = rec[(long)s * A + act];
             terminal = (rc.flags & done_bit) != 0;
             s = rc.next;
             ++st;
             ++steps_taken;
-            total += p.gpow[depth] * rc.reward;
+            total += gpow[depth] * rc.reward;
             node = fc + act;
             ++depth;
             path[depth * 64 + lane] = node;
             fc = tree[node].first_child;
+#ifdef MP_PROFILE
+            ++n_sel;
+#endif
         }
+        PROF_T(c1);
         // ---- expansion, mcts.py:151-154 / 237-246
         if (fc < 0 && depth < H && (!terminal || node == 0)) {
             tree[node].first_child = n_nodes;
@@ -123,22 +179,34 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
             for (int a = 0; a < A; ++a) tree[n_nodes + a] = n;
             n_nodes += A;
         }
+        PROF_T(c2);
         // ---- rollout, mcts.py:156-157 / 160-177
         if (!terminal) {
             for (int h = depth; h < H; ++h) {
                 const double u = g.next_double();
+                // searchsorted(cdf, u, side='right') on a non-decreasing cdf = #{a : cdf[a] <= u}
                 int act = 0;
-                while (act < A && p.cdf[act] <= u) ++act; // searchsorted(cdf, u, side='right')
-                const Rec rc = p.rec[(long)s * A + act];
+                if (AT > 0) {
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
+                } else {
+                    for (int a = 0; a < A; ++a) act += cdfL[a] <= u ? 1 : 0;
+                }
+                const double gh = gpow[h];
+                const Rec rc = rec[(long)s * A + act];
                 const bool term_h = (rc.flags & done_bit) != 0;
                 s = rc.next;
                 ++st;
                 ++steps_taken;
-                total += p.gpow[h] * rc.reward;
+                total += gh * rc.reward;
                 const bool trunc_h = p.max_steps > 0 && st >= p.max_steps;
+#ifdef MP_PROFILE
+                ++n_roll;
+#endif
                 if (term_h || trunc_h) break;
             }
         }
+        PROF_T(c3);
         // ---- backup, mcts.py:248-265: the same return for every node on the path
         for (int d = depth; d >= 0; --d) {
             const int n = path[d * 64 + lane];
@@ -147,7 +215,15 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
             c.value += 1.0 / (double)c.count * (total - c.value);
             tree[n] = c;
         }
+#ifdef MP_PROFILE
+        { const long long c4 = clock64(); t_sel += c1 - c0; t_expd += c2 - c1; t_roll += c3 - c2; t_bak += c4 - c3; }
+#endif
     }
+#ifdef MP_PROFILE
+    if (r == 0)
+        printf("uct prof wave0: total=%lld select=%lld expand=%lld rollout=%lld backup=%lld | lane0 select steps=%lld rollout steps=%lld\n",
+               (long long)(clock64() - t_all0), t_sel, t_expd, t_roll, t_bak, n_sel, n_roll);
+#endif
     g.store(p.rng + (long)r * 6);
     // ---- AbstractPlanner.get_plan (abstract.py:143-156) with MCTSNode.selection_rule
     // (mcts.py:212-218): most visited child, ties -> first maximal value among them
@@ -181,6 +257,27 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
     }
 }
 
+// Roots per wavefront.  A root's episodes are one long dependency chain, so a batch takes as long
+// as its slowest wavefront; with few roots it pays to spread them thin (fewer lanes per wave = less
+// rollout-length divergence and fewer distinct cache lines per gather) until every SIMD has a wave.
+static int uct_lanes_per_wave(const mp_ctx *ctx, int n_roots)
+{
+    if (const char *e = getenv("MP_UCT_LANES")) {
+        const int v = atoi(e);
+        if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
+    }
+    const int simds = ctx->prop.multiProcessorCount * 4;
+    int lanes = 64;
+    while (lanes > 4 && (long)n_roots < (long)simds * lanes) lanes >>= 1;
+    return lanes;
+}
+
+template <int AT>
+static void uct_launch(const UctArgs &a, size_t lds, hipStream_t st)
+{
+    hipLaunchKernelGGL(uct_table_kernel<AT>, dim3((unsigned)((a.n_roots + a.lanes - 1) / a.lanes)), dim3(64), lds, st, a);
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -200,7 +297,7 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
         return fail(MP_ERR_ARG, "mp_uct_plan: bad sizes (n_roots=%d episodes=%d horizon=%d)", n_roots, episodes, horizon);
     const int A = model->A;
-    const size_t lds = (size_t)(horizon + 1) * 64 * sizeof(int32_t);
+    const size_t lds = (size_t)(horizon + 1) * (64 * sizeof(int32_t) + sizeof(double)) + 2 * (size_t)A * sizeof(double);
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d too deep for the LDS path stack", horizon);
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -215,14 +312,12 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }             // numpy cumsum
     for (int a = 0; a < A; ++a) cdf[a] /= acc;                                     // cdf /= cdf[-1]
     double *d_tab = nullptr;
-    MP_TRY(ws_get(ctx, WS_TAB0, tab.size(), &d_tab));
-    MP_HIP(hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice, st));
-    // tab is pageable host memory: the async copy is staged before return only if we wait
-    MP_HIP(hipStreamSynchronize(st));
+    MP_TRY(upload_tables(ctx, 1, tab, &d_tab));
 
     UctArgs a;
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.episodes = episodes; a.horizon = horizon; a.cap = (int)cap;
     a.done_on_next = model->done_on_next; a.max_steps = model->max_steps; a.max_plan_len = max_plan_len;
+    a.lanes = uct_lanes_per_wave(ctx, n_roots);
     a.rec = model->rec;
     a.gpow = d_tab; a.tp = d_tab + horizon + 1; a.cdf = a.tp + A;
     MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.tree));
@@ -241,7 +336,15 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
     MP_TRY(kernels_begin(ctx));
-    hipLaunchKernelGGL(uct_table_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+    switch (A) {
+    case 2: uct_launch<2>(a, lds, st); break;
+    case 3: uct_launch<3>(a, lds, st); break;
+    case 4: uct_launch<4>(a, lds, st); break;
+    case 5: uct_launch<5>(a, lds, st); break;
+    case 6: uct_launch<6>(a, lds, st); break;
+    case 8: uct_launch<8>(a, lds, st); break;
+    default: uct_launch<0>(a, lds, st); break;
+    }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 

@@ -76,10 +76,11 @@ def load():
     if not os.path.exists(path):
         raise RuntimeError("{} is missing: run `python -m rl_agents_amd.build` (hipcc, gfx950). "
                            "There is no CPU fallback for the planning kernels.".format(path))
-    try:  # share torch's copy of the HIP runtime when torch is in the process (same soname)
-        import torch  # noqa: F401
-    except Exception:  # pragma: no cover - torch is optional for the C ABI itself
-        pass
+    if not os.environ.get("MI355PLAN_NO_TORCH"):
+        try:  # share torch's copy of the HIP runtime when torch is in the process (same soname)
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
@@ -128,10 +129,14 @@ class Context(object):
 
     @classmethod
     def on_torch_stream(cls, device=0):
-        """Context that enqueues on torch's current stream of `device` (so torch events/allocations interoperate)."""
+        """Context enqueuing on a torch side stream of `device` (kept as ``ctx.torch_stream``): run torch work
+        under ``with torch.cuda.stream(ctx.torch_stream)`` and torch events / allocations interoperate."""
         import torch
         with torch.cuda.device(device):
-            return cls(device, torch.cuda.current_stream().cuda_stream)
+            stream = torch.cuda.Stream(device=device)
+            ctx = cls(device, stream.cuda_stream)
+            ctx.torch_stream = stream
+            return ctx
 
     def close(self):
         if getattr(self, "_h", None):

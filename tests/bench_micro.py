@@ -1,0 +1,44 @@
+"""Kernel micro-benchmarks without torch (MI355PLAN_NO_TORCH=1): quick A/B of launch geometry on the GPU box.
+
+    MI355PLAN_NO_TORCH=1 python tests/bench_micro.py uct|opd [n_roots]
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MI355PLAN_NO_TORCH", "1")
+from rl_agents_amd import native  # noqa: E402
+from rl_agents_amd.envs import generators  # noqa: E402
+
+
+def main():
+    what = sys.argv[1] if len(sys.argv) > 1 else "uct"
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    ctx = native.Context(0)
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    non_term = np.flatnonzero(~cfg["terminal"])
+    s0 = np.random.Generator(np.random.PCG64(12345)).choice(non_term, size=n).astype(np.int32)
+    rng = np.random.Generator(np.random.PCG64(1)).integers(1, 2 ** 62, size=(n, 6)).astype(np.uint64)
+    rng[:, 3] |= 1
+    rng[:, 4:] = 0
+    p = np.ones(5) / 5
+    for rep in range(3):
+        t0 = time.perf_counter()
+        if what == "uct":
+            out = ctx.uct_plan(model, s0, 33, 30, 0.8, 10.0, p, p, rng, max_plan_len=8)
+        else:
+            budget = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
+            out = ctx.opd_plan(model, s0, budget, 0.8, 0.0, rng, max_plan_len=32)
+        dt = time.perf_counter() - t0
+        ms, _ = ctx.last_kernel_ms()
+        print("{} n={} lanes={} kernel {:.3f} ms  wall {:.1f} ms  env_steps {}  -> {:.3e} steps/s".format(
+            what, n, os.environ.get("MP_UCT_LANES", "auto"), ms, dt * 1e3, int(out["env_steps"].sum()),
+            out["env_steps"].sum() / (ms * 1e-3)), flush=True)
+
+
+if __name__ == "__main__":
+    main()

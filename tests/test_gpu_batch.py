@@ -1,0 +1,210 @@
+"""Batched HIP planners vs the CPU oracle on seeded synthetic tables (many roots per launch), bit for bit,
+plus size-independent properties at the BASELINE.json sizes."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rl_agents_amd import native
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _rng_states(n, base=0):
+    from rl_agents_amd import native
+    return np.stack([native.rng_state_from_generator(
+        np.random.Generator(np.random.PCG64(np.random.SeedSequence(base + i)))) for i in range(n)])
+
+
+def _cmp_uct(ctx, cfg, n_roots, episodes, horizon, gamma, temperature, prior, rollout, seed=0, max_steps=0,
+             steps0=None, done_rule="source"):
+    from oracle import oracle
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
+    s0 = np.random.Generator(np.random.PCG64(seed)).integers(0, r.shape[0], size=n_roots).astype(np.int32)
+    rng = _rng_states(n_roots, base=1000 * seed)
+    rng_ref = rng.copy()
+    out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, prior, rollout, rng, root_steps=steps0,
+                       max_plan_len=horizon)
+    ref = oracle.uct_plan_batch(t, r, term, s0, episodes, horizon, gamma, temperature, prior, rollout, rng_ref,
+                                steps0=steps0, max_steps=max_steps, done_rule=done_rule, max_plan_len=horizon,
+                                n_threads=8)
+    np.testing.assert_array_equal(out["plans"], ref["plans"])
+    np.testing.assert_array_equal(out["plan_len"], ref["plan_len"])
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(out["root_child_count"], ref["root_child_count"])
+    assert np.array_equal(out["root_child_value"], ref["root_child_value"])
+    np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    model.close()
+    return out
+
+
+def test_uct_batch_highway_headline_shape(ctx):
+    """Headline configuration (highway-shaped S=10 000, A=5, 33 episodes x horizon 30), 1536 ragged roots."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    p = np.ones(5) / 5
+    out = _cmp_uct(ctx, cfg, 1536 + 17, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=1)
+    assert out["env_steps"].max() <= 33 * 30
+
+
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 7, 8, 11])
+def test_uct_batch_action_counts(ctx, n_actions):
+    """Every compile-time |A| specialisation and the generic-|A| kernel."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(257, n_actions, seed=n_actions, terminal_rate=0.05)
+    p = np.ones(n_actions) / n_actions
+    _cmp_uct(ctx, cfg, 200, 25, 9, 0.9, 7.5, p, p, seed=n_actions)
+
+
+def test_uct_batch_preference_policy_truncation_and_next_rule(ctx):
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(500, 4, seed=21, terminal_rate=0.1)
+    pref = np.ones(4) / (4 - 1 + 3.0)
+    pref[1] *= 3.0                                     # mcts.py:76-97 preference policy, ratio 3
+    steps0 = np.random.Generator(np.random.PCG64(5)).integers(0, 6, size=300).astype(np.int32)
+    _cmp_uct(ctx, cfg, 300, 40, 12, 0.95, 3.0, pref, pref, seed=3, max_steps=10, steps0=steps0)
+    _cmp_uct(ctx, cfg, 300, 40, 12, 0.95, 3.0, pref, np.ones(4) / 4, seed=4, done_rule="next")
+
+
+def test_uct_zero_episodes_and_single_root(ctx):
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(50, 3, seed=2)
+    p = np.ones(3) / 3
+    out = _cmp_uct(ctx, cfg, 1, 0, 5, 0.8, 10.0, p, p)
+    assert out["plan_len"][0] == 0
+    _cmp_uct(ctx, cfg, 1, 90, 11, 0.8, 10.0, p, p)
+
+
+def test_uct_stream_continues_across_calls(ctx):
+    """Two plan() calls on one agent continue one PCG64 stream (tree reset in between), as the reference does."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(100, 5, seed=9)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    model = ctx.load_table(t, r, term)
+    p = np.ones(5) / 5
+    rng, rng_ref = _rng_states(64), _rng_states(64)
+    s0 = np.arange(64, dtype=np.int32)
+    for _ in range(3):
+        out = ctx.uct_plan(model, s0, 14, 6, 0.8, 10.0, p, p, rng, max_plan_len=6)
+        ref = oracle.uct_plan_batch(t, r, term, s0, 14, 6, 0.8, 10.0, p, p, rng_ref, max_plan_len=6)
+        rng_ref = ref["rng_after"]
+        np.testing.assert_array_equal(out["plans"], ref["plans"])
+        np.testing.assert_array_equal(rng, rng_ref)
+        s0 = t[s0, np.maximum(out["plans"][:, 0], 0)].astype(np.int32)
+
+
+def _cmp_opd(ctx, cfg, n_roots, budget, gamma, terminal_reward=0.0, seed=0, done_rule="source"):
+    from oracle import oracle
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    model = ctx.load_table(t, r, term, done_rule=done_rule)
+    s0 = np.random.Generator(np.random.PCG64(seed)).integers(0, r.shape[0], size=n_roots).astype(np.int32)
+    rng = _rng_states(n_roots, base=77)
+    rng_ref = rng.copy()
+    mpl = budget // r.shape[1] + 2
+    out = ctx.opd_plan(model, s0, budget, gamma, terminal_reward, rng, max_plan_len=mpl)
+    ref = oracle.opd_plan_batch(t, r, term, s0, budget, gamma, terminal_reward, rng_ref, done_rule=done_rule,
+                                max_plan_len=mpl, n_threads=8)
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    np.testing.assert_array_equal(out["plans"], ref["plans"])
+    assert np.array_equal(out["root_lower"], ref["root_lower"])
+    assert np.array_equal(out["root_upper"], ref["root_upper"])
+    np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    model.close()
+    return out
+
+
+def test_opd_batch_highway_budget5000(ctx):
+    """C4 shape: highway-shaped S=10 000, A=5, budget 5000 (1000 expansions, 40 KB of LDS per root)."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    _cmp_opd(ctx, cfg, 96, 5000, 0.8, seed=5)
+
+
+@pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (64, 640)])
+def test_opd_batch_action_counts(ctx, n_actions, budget):
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(300, n_actions, seed=40 + n_actions, terminal_rate=0.05)
+    _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
+
+
+def test_opd_ties_draw_from_the_generator(ctx):
+    """Constant rewards make every lower bound tie: the plan is drawn through the PCG64 tie-break."""
+    cfg = dict(transition=np.tile(np.arange(6).reshape(6, 1), (1, 3)), reward=np.full((6, 3), 0.5),
+               terminal=np.zeros(6, bool))
+    out = _cmp_opd(ctx, cfg, 40, 60, 0.8, seed=8)
+    assert len(set(map(tuple, out["plans"]))) > 1
+
+
+def test_opd_gridworld_c1_and_next_rule(ctx):
+    from rl_agents_amd.envs import generators
+    _cmp_opd(ctx, generators.gridworld(), 100, 100, 0.8, seed=1)
+    cfg = generators.random_deterministic(200, 4, seed=3, terminal_rate=0.2)
+    _cmp_opd(ctx, cfg, 50, 400, 0.85, terminal_reward=1.0, seed=2, done_rule="next")
+
+
+def test_opd_budget_smaller_than_actions(ctx):
+    from rl_agents_amd.envs import generators
+    out = _cmp_opd(ctx, generators.random_deterministic(20, 5, seed=1), 3, 4, 0.8)
+    assert (out["plan_len"] == 0).all() and (out["env_steps"] == 0).all()
+
+
+def test_vi_highway_c2_and_robust_c5_shapes(ctx):
+    """C2 (S=10 000) and a C5-shaped robust pair (S=50 000, M=2): bit-exact with the oracle."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    q, sweeps = ctx.vi_solve(model, 0.95, 200)
+    q_ref, sweeps_ref = oracle.vi_solve("deterministic", cfg["transition"], cfg["reward"], cfg["terminal"], gamma=0.95,
+                                        iterations=200)
+    assert sweeps == sweeps_ref and np.array_equal(q, q_ref)
+    big = generators.highway_shaped(10, 50, 100, seed=2)
+    big2 = generators.rewire(big, 0.1, seed=3)
+    tt = np.stack([big["transition"], big2["transition"]])
+    rr = np.stack([big["reward"], big2["reward"] * 0.97])
+    model = ctx.load_table(tt, rr)
+    q, sweeps = ctx.vi_solve(model, 0.9, 150, robust=True)
+    q_ref, sweeps_ref = oracle.vi_solve("deterministic", tt, rr, None, gamma=0.9, iterations=150, robust=True)
+    assert sweeps == sweeps_ref and np.array_equal(q, q_ref)
+
+
+def test_vi_sparse_and_dense_vs_oracle(ctx):
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    for b in (1, 2, 7, 8, 9, 23, 128):
+        cfg = generators.random_sparse(211, 3, b, seed=b, terminal_rate=0.1)
+        model = ctx.load_sparse(cfg["transition"], cfg["next"], cfg["reward"], cfg["terminal"])
+        q, sweeps = ctx.vi_solve(model, 0.9, 60)
+        q_ref, sweeps_ref = oracle.vi_solve("sparse", cfg["transition"], cfg["reward"], cfg["terminal"], gamma=0.9,
+                                            iterations=60, next_states=cfg["next"])
+        assert sweeps == sweeps_ref and np.array_equal(q, q_ref), b
+    for s, a in ((17, 2), (64, 3), (333, 5), (1029, 2)):       # ragged tiles: S*A % 64 != 0, S % 16 != 0
+        cfg = generators.random_stochastic(s, a, seed=s, terminal_rate=0.1)
+        model = ctx.load_dense(cfg["transition"], cfg["reward"], cfg["terminal"])
+        q, sweeps = ctx.vi_solve(model, 0.9, 40)
+        q_ref, sweeps_ref = oracle.vi_solve("stochastic", cfg["transition"], cfg["reward"], cfg["terminal"], gamma=0.9,
+                                            iterations=40)
+        # matrix-core accumulation order differs from numpy's pairwise sum: 1e-12 relative
+        np.testing.assert_allclose(q, q_ref, rtol=1e-12, atol=1e-12)
+        assert abs(sweeps - sweeps_ref) <= 1
+
+
+def test_vi_properties_at_scale(ctx):
+    """Size-independent properties on a dense S=2000 model: gamma-contraction fixed point and monotonicity in R."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_stochastic(2000, 5, seed=1)
+    model = ctx.load_dense(cfg["transition"], cfg["reward"], None)
+    q, _ = ctx.vi_solve(model, 0.9, 400, rtol=0.0, atol=1e-13)
+    v = q.max(axis=1)
+    np.testing.assert_allclose(q, cfg["reward"] + 0.9 * (cfg["transition"] @ v), rtol=1e-10, atol=1e-10)
+    model2 = ctx.load_dense(cfg["transition"], cfg["reward"] + 0.1, None)
+    q2, _ = ctx.vi_solve(model2, 0.9, 400, rtol=0.0, atol=1e-13)
+    np.testing.assert_allclose(q2 - q, 0.1 / (1 - 0.9), rtol=1e-9)   # constant reward shift -> shift / (1 - gamma)
