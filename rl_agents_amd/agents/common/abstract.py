@@ -1,0 +1,52 @@
+"""Agent interface: what ``Evaluation`` calls (reference ``rl_agents/agents/common/abstract.py:6-98``,
+call sites ``rl_agents/trainer/evaluation.py:89-90,133,168-190,301-302,317,375-376``)."""
+from abc import ABC, abstractmethod
+
+from rl_agents_amd.configuration import Configurable
+
+
+class AbstractAgent(Configurable, ABC):
+    def __init__(self, config=None):
+        super(AbstractAgent, self).__init__(config)
+        self.writer = None
+        self.directory = None
+
+    @abstractmethod
+    def record(self, state, action, reward, next_state, done, info):
+        """Record a transition (planners ignore it)."""
+
+    @abstractmethod
+    def act(self, state):
+        """Pick an action for ``state``."""
+
+    def plan(self, state):
+        """A sequence of actions; by default the single action ``act`` returns."""
+        return [self.act(state)]
+
+    @abstractmethod
+    def reset(self):
+        """Reset the agent's internal state (start of an episode)."""
+
+    @abstractmethod
+    def seed(self, seed=None):
+        """Seed the agent's randomness source; returns the list of seeds used."""
+
+    @abstractmethod
+    def save(self, filename):
+        """Save a model; planners have none and return False."""
+
+    @abstractmethod
+    def load(self, filename):
+        """Load a model; planners have none and return False."""
+
+    def eval(self):
+        """Switch to evaluation mode (no exploration); planners have a single mode."""
+
+    def set_writer(self, writer):
+        self.writer = writer
+
+    def set_directory(self, directory):
+        self.directory = directory
+
+    def set_time(self, time):
+        """Current time step, for schedules; unused by planners."""

@@ -1,0 +1,105 @@
+"""Value iteration on the MI355X planning core (reference
+``rl_agents/agents/dynamic_programming/value_iteration.py``); the sweeps run in ``mp_vi_solve``
+(rl_agents_amd/csrc/vi.hip)."""
+import logging
+
+import numpy as np
+
+from rl_agents_amd import device_model
+from rl_agents_amd.agents.common.abstract import AbstractAgent
+
+logger = logging.getLogger(__name__)
+
+
+class ValueIterationAgent(AbstractAgent):
+    """Drop-in for ``rl_agents.agents.dynamic_programming.value_iteration.ValueIterationAgent``."""
+
+    def __init__(self, env, config=None):
+        super(ValueIterationAgent, self).__init__(config)
+        self.finite_mdp = self.is_finite_mdp(env)
+        self.mdp = device_model.finite_mdp_of(env)          # raises the reference's TypeError otherwise
+        self.env = env
+        self.models = device_model.ModelCache()
+        self.sweeps = 0
+        self.state_action_value = self.get_state_action_value()
+
+    @classmethod
+    def default_config(cls):
+        return dict(gamma=1.0, iterations=100)
+
+    def act(self, state):
+        # an environment that is not itself a finite MDP is converted again on every call and the
+        # state recovered from the conversion (value_iteration.py:29-35); the device model is re-uploaded
+        # and re-solved only if the converted tables changed
+        if not self.finite_mdp:
+            self.mdp = self.env.unwrapped.to_finite_mdp()
+            state = self.mdp.state
+            self.state_action_value = self.get_state_action_value()
+        return np.argmax(self.state_action_value[state, :])
+
+    def _model(self):
+        return self.models.get(device_model.spec_from_mdp(self.mdp))
+
+    def get_state_action_value(self):
+        model = self._model()
+        cached = getattr(model, "_vi_cache", None)
+        key = (self.config["gamma"], self.config["iterations"])
+        if cached is not None and cached[0] == key:
+            self.sweeps = cached[2]
+            return cached[1]
+        q, self.sweeps = self.models.ctx.vi_solve(model, self.config["gamma"], self.config["iterations"])
+        model._vi_cache = (key, q, self.sweeps)
+        return q
+
+    def get_state_value(self):
+        return self.models.ctx.vi_solve_v(self._model(), self.config["gamma"], self.config["iterations"])
+
+    @staticmethod
+    def best_action_value(action_values):
+        return action_values.max(axis=-1)
+
+    @staticmethod
+    def is_finite_mdp(env):
+        """True when ``env`` itself is a finite-MDP environment (its ``mdp`` is used as is)."""
+        base = getattr(env, "unwrapped", env)
+        try:
+            from rl_agents_amd.envs.finite_mdp import FiniteMDPEnv
+            if isinstance(base, FiniteMDPEnv):
+                return True
+        except ImportError:  # pragma: no cover
+            pass
+        try:
+            finite_mdp = __import__("finite_mdp.envs.finite_mdp_env")
+            return isinstance(base, finite_mdp.envs.finite_mdp_env.FiniteMDPEnv)
+        except (ImportError, TypeError, AttributeError):
+            return False
+
+    def plan_trajectory(self, state, horizon=10):
+        """Greedy trajectory through the model (value_iteration.py:84-96)."""
+        action_value = self.get_state_action_value()
+        states, actions = [], []
+        for _ in range(horizon):
+            action = np.argmax(action_value[state])
+            states.append(state)
+            actions.append(action)
+            state = self.mdp.next_state(state, action)
+            if self.mdp.terminal[state]:
+                states.append(state)
+                actions.append(None)
+                break
+        return states, actions
+
+    def record(self, state, action, reward, next_state, done, info):
+        pass
+
+    def reset(self):
+        pass
+
+    def seed(self, seed=None):
+        pass
+
+    def save(self, filename):
+        return False
+
+    def load(self, filename):
+        return False

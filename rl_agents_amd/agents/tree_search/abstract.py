@@ -1,0 +1,226 @@
+"""Tree-search agent and planner bases (reference ``rl_agents/agents/tree_search/abstract.py``).
+
+``AbstractTreeSearchAgent`` keeps the reference's receding-horizon logic (abstract.py:49-96) on the host;
+``AbstractPlanner`` replaces the Python tree with a device call: ``plan(state, observation)`` extracts
+the finite MDP behind the environment object, uploads it once (cached by content) and runs the batched
+HIP planner for one root -- or ``plan_batch`` for many roots of the same model.
+"""
+import logging
+
+import numpy as np
+
+from rl_agents_amd import device_model, native
+from rl_agents_amd.agents.common.abstract import AbstractAgent
+from rl_agents_amd.agents.common.factory import preprocess_env
+from rl_agents_amd.configuration import Configurable
+
+logger = logging.getLogger(__name__)
+
+
+def np_random(seed=None):
+    """gymnasium.utils.seeding.np_random: Generator(PCG64(SeedSequence(seed))) and the entropy used."""
+    if seed is not None and not (isinstance(seed, (int, np.integer)) and seed >= 0):
+        raise ValueError("Seed must be a non-negative integer or omitted, not {}".format(seed))
+    seed_seq = np.random.SeedSequence(seed)
+    return np.random.Generator(np.random.PCG64(seed_seq)), seed_seq.entropy
+
+
+class AbstractTreeSearchAgent(AbstractAgent):
+    PLANNER_TYPE = None
+
+    def __init__(self, env, config=None):
+        super(AbstractTreeSearchAgent, self).__init__(config)
+        self.env = env
+        self.planner = self.make_planner()
+        self.previous_actions = []
+        self.remaining_horizon = 0
+        self.steps = 0
+
+    @classmethod
+    def default_config(cls):
+        return {"env_preprocessors": [], "display_tree": False, "receding_horizon": 1, "terminal_reward": 0}
+
+    def make_planner(self):
+        if not self.PLANNER_TYPE:
+            raise NotImplementedError()
+        return self.PLANNER_TYPE(self.env, self.config)
+
+    def plan(self, observation):
+        """The planned action sequence from the environment's current state (abstract.py:49-68)."""
+        self.steps += 1
+        if self.step(self.previous_actions):
+            env = preprocess_env(self.env, self.config["env_preprocessors"])
+            actions = self.planner.plan(state=env, observation=observation)
+        else:
+            actions = self.previous_actions[1:]
+        self.previous_actions = actions
+        return actions
+
+    def step(self, actions):
+        """Receding-horizon bookkeeping; True when a new plan is required (abstract.py:70-82)."""
+        replan = self.remaining_horizon == 0 or len(actions) <= 1
+        if replan:
+            self.remaining_horizon = self.config["receding_horizon"] - 1
+        else:
+            self.remaining_horizon -= 1
+        self.planner.step_tree(actions)
+        return replan
+
+    def plan_batch(self, root_states, root_steps=None):
+        """Plans for many independent roots of this agent's environment model in one launch.
+
+        ``root_states``: state indices. Returns the planner's batch result (dict of arrays)."""
+        env = preprocess_env(self.env, self.config["env_preprocessors"])
+        return self.planner.plan_batch(env, root_states, root_steps)
+
+    def reset(self):
+        self.planner.step_by_reset()
+        self.remaining_horizon = 0
+        self.steps = 0
+
+    def seed(self, seed=None):
+        return self.planner.seed(seed)
+
+    def record(self, state, action, reward, next_state, done, info):
+        pass
+
+    def act(self, state):
+        return self.plan(state)[0]
+
+    def save(self, filename):
+        return False
+
+    def load(self, filename):
+        return False
+
+
+class Node(object):
+    """Read-only view of one node of an exported device tree, with the attributes the reference's
+    tree consumers read (tree_search/graphics.py:19-37, abstract.py:246-265): children, parent, count,
+    get_value(), depth."""
+
+    def __init__(self, parent, action, count, value, depth):
+        self.parent = parent
+        self.action = action
+        self.children = {}
+        self.count = count
+        self.value = value
+        self.depth = depth
+
+    def get_value(self):
+        return self.value
+
+    def is_leaf(self):
+        return not self.children
+
+    def path(self):
+        node, actions = self, []
+        while node.parent is not None:
+            actions.append(node.action)
+            node = node.parent
+        return actions[::-1]
+
+
+def build_tree(arrays, value_key, extra=()):
+    """Creation-order arrays (parent, action, count, <value_key>, ...) -> linked :class:`Node` objects."""
+    parent, action = arrays["parent"], arrays["action"]
+    nodes = []
+    for i in range(len(parent)):
+        par = nodes[parent[i]] if parent[i] >= 0 else None
+        node = Node(par, int(action[i]), int(arrays["count"][i]), float(arrays[value_key][i]),
+                    0 if par is None else par.depth + 1)
+        for name in extra:
+            setattr(node, name, arrays[name][i].item())
+        if par is not None:
+            par.children[int(action[i])] = node
+        nodes.append(node)
+    return nodes[0]
+
+
+class AbstractPlanner(Configurable):
+    """Device-backed planner: holds the numpy Generator (source of truth of the random stream), the
+    model cache and the last batch result."""
+
+    def __init__(self, config=None):
+        super(AbstractPlanner, self).__init__(config)
+        self.np_random = None
+        self.models = device_model.ModelCache()
+        self.last = None          # dict of arrays returned by the last device call
+        self.env_steps = 0        # counterpart of len(planner.observations) (abstract.py:158-161)
+        self._root = None
+        self.reset()
+        self.seed()
+
+    @classmethod
+    def default_config(cls):
+        return dict(budget=500, gamma=0.8, step_strategy="reset")
+
+    def seed(self, seed=None):
+        self.np_random, seed = np_random(seed)
+        self._entropy = seed
+        return [seed]
+
+    # -- to be provided by subclasses ---------------------------------------------------------------
+    def plan_batch(self, state, root_states, root_steps=None, rng_states=None):
+        raise NotImplementedError()
+
+    def export_tree(self, root=0):
+        raise NotImplementedError()
+
+    # -------------------------------------------------------------------------------------------------
+    def model_for(self, state):
+        mdp = device_model.finite_mdp_of(state)
+        if mdp.mode != "deterministic":
+            raise TypeError("tree search on the device needs a deterministic finite MDP, got mode '{}'".format(mdp.mode))
+        if hasattr(getattr(state, "unwrapped", state), "get_available_actions"):
+            raise TypeError("environments restricting the available actions are not supported on the device")
+        return self.models.get(device_model.spec_from_mdp(mdp, max_steps=device_model.env_max_steps(state)))
+
+    def plan(self, state, observation):
+        """Plan from the current state of the environment object ``state`` (never stepped, never copied)."""
+        s0, steps0 = device_model.env_root_state(state)
+        rng = native.rng_state_from_generator(self.np_random).reshape(1, 6)
+        out = self.plan_batch(state, [s0], [steps0], rng_states=rng)
+        native.generator_set_state(self.np_random, rng[0])
+        n = int(out["plan_len"][0])
+        return [int(a) for a in out["plans"][0, :n]]
+
+    def get_plan(self):
+        if self.last is None:
+            return []
+        n = int(self.last["plan_len"][0])
+        return [int(a) for a in self.last["plans"][0, :n]]
+
+    @property
+    def root(self):
+        """Root :class:`Node` of the last plan's tree (root 0 of the batch), exported on demand."""
+        if self._root is None and self.last is not None:
+            self._root = self.export_tree(0)
+        return self._root
+
+    def step_tree(self, actions):
+        strategy = self.config["step_strategy"]
+        if strategy == "reset":
+            self.step_by_reset()
+        elif strategy == "subtree":
+            raise NotImplementedError("step_strategy 'subtree' (tree reuse across plans) is not available on the "
+                                      "device planner yet; use 'reset' (the reference's default)")
+        else:
+            logger.warning("Unknown step strategy: %s", strategy)
+            self.step_by_reset()
+
+    def step_by_reset(self):
+        self.reset()
+
+    def reset(self):
+        self.last = None
+        self._root = None
+
+    def batch_rng_states(self, n_roots, first_root=0):
+        """PCG64 records for a batch: root i draws from Generator(PCG64(SeedSequence([entropy, i])))."""
+        entropy = self._entropy
+        out = np.zeros((n_roots, 6), dtype=np.uint64)
+        for i in range(n_roots):
+            gen = np.random.Generator(np.random.PCG64(np.random.SeedSequence([int(entropy) % (1 << 63), first_root + i])))
+            out[i] = native.rng_state_from_generator(gen)
+        return out

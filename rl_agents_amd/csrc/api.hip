@@ -90,6 +90,16 @@ __global__ void pack_records(int S, int A, const int32_t *__restrict__ T, const 
     rec[i] = r;
 }
 
+// compact transitions for the LDS variant of the UCT kernel (S < 32768)
+__global__ void pack_t16(int S, int A, const int32_t *__restrict__ T, const uint8_t *__restrict__ term,
+                         uint16_t *__restrict__ t16)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)S * A) return;
+    const int nx = T[i];
+    t16[i] = (uint16_t)((uint32_t)nx | (term && term[nx] ? 0x8000u : 0u));
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -223,6 +233,12 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
     const long sa = (long)S * A;
     hipLaunchKernelGGL(pack_records, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T, m->R,
                        m->term, m->rec);
+    if (S < 32768) {
+        if (hipMalloc(&m->t16, (((size_t)sa * 2 + 15) & ~(size_t)15) + 16) != hipSuccess)
+            return bail(fail(MP_ERR_ALLOC, "mp_model_load_table: hipMalloc failed"));
+        hipLaunchKernelGGL(pack_t16, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T, m->term,
+                           m->t16);
+    }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(MP_ERR_HIP, "pack_records failed"));
     *out = m;
     return MP_OK;
@@ -309,6 +325,7 @@ int mp_model_free(mp_model *m)
     }
     if (m->T) hipFree(m->T);
     if (m->rec) hipFree(m->rec);
+    if (m->t16) hipFree(m->t16);
     if (m->NXT) hipFree(m->NXT);
     delete m;
     return MP_OK;

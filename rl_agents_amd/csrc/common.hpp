@@ -83,6 +83,7 @@ struct mp_model {
     double *R = nullptr;
     uint8_t *term = nullptr; // [S] or nullptr
     mp::Rec *rec = nullptr;  // packed model 0, [S*A]
+    uint16_t *t16 = nullptr; // model 0 as {bit15 = terminal[next], next}, [S*A]; only when S < 32768
     // dense [M,S,A,S] / sparse [S,A,B]
     const double *P = nullptr;
     bool borrowed = false;

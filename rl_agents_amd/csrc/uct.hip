@@ -2,22 +2,28 @@
 //
 // Mapping: ONE ROOT PER LANE.  A root's plan() is inherently sequential (every episode reads
 // the tree the previous one updated; every env step depends on the previous state), so the
-// parallel axis is roots: 64 roots per wavefront, one wavefront per workgroup so that a batch of
-// n_roots roots spreads over n_roots/64 SIMDs.  A cloned environment (reference:
-// safe_deepcopy_env, common/factory.py:119-134) is an (int32 state, int32 steps) register pair.
+// parallel axis is roots.  A cloned environment (reference: safe_deepcopy_env,
+// common/factory.py:119-134) is an (int32 state, int32 steps) register pair.  A batch takes as
+// long as its slowest lane's dependency chain, so the kernel is built to shorten that chain:
 //
-// Memory layout (HBM, all L2-resident at BASELINE sizes):
-//   model   Rec[S*A]  one 16-byte record per (s,a): {next, flags, reward} -> one dwordx4 gather
-//           per env step instead of three dependent-latency gathers from T / R / terminal.
-//   tree    Node[n_roots][cap]  root-major 16-byte records {value f64, count i32, first_child i32};
-//           the A children of a node are contiguous (80 B at A = 5: one or two cache lines per
-//           selection level).  cap = 1 + episodes*A (at most one expansion per episode).
-//   path    per-lane stack of visited node ids in LDS ([depth][lane], conflict-free), so the
-//           backup is a pipelined read-modify-write over known addresses instead of a dependent
-//           parent-pointer chase.
-// Arithmetic is the reference's, operation for operation, in IEEE double without contraction;
-// randomness is numpy's PCG64 stepped on the device (pcg64.hpp), so results are bit-identical
-// to the Python planner for equal seeds.
+//   model   LDS variant (S < 32768 and S*A*2 B fits): the transition table is staged once per
+//           workgroup into LDS as uint16 {bit15 = terminal[next], next state}; an env step on the
+//           critical chain is one ds_read_u16 (~100 cycles) instead of an L2 gather (~400).  The
+//           reward of a step is fetched from HBM/L2 off the chain (software-pipelined by one
+//           step; additions stay in the reference's order).
+//           Global variant (any S): one 16-byte record {next, flags, reward} per (s,a), a single
+//           dwordx4 gather per env step.
+//   rng     numpy PCG64 stepped per lane (pcg64.hpp); the draw for step h+1 is computed
+//           speculatively while step h's lookup is in flight and committed only if the rollout
+//           continues, so the stream stays bit-identical to the reference's.
+//   tables  gamma**h, the rollout cdf, 1/n and temperature*|A|*prior[a]/n for every visit count
+//           n are computed on the host with the reference's own operations (libm pow, IEEE
+//           divide) and read from LDS: no f64 division on the device, same bits.
+//   tree    Node[n_roots][cap] root-major 16-byte records {value f64, count i32, first_child i32}
+//           in HBM (L2-resident at BASELINE sizes); the A children of a node are contiguous.
+//           cap = 1 + episodes*A (at most one expansion per episode).
+//   path    per-lane stack of visited node ids in LDS ([depth][lane], conflict-free): the backup
+//           is a pipelined read-modify-write over known addresses, not a parent-pointer chase.
 #include <math.h>
 #include <stdlib.h>
 
@@ -39,11 +45,11 @@ struct UctArgs {
     int n_roots, S, A, episodes, horizon, cap;
     int done_on_next, max_steps, max_plan_len;
     int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
+    int waves; // wavefronts per workgroup
     const Rec *rec;
+    const uint16_t *t16; // compact transitions (LDS variant), [S*A]
     const int32_t *root_state, *root_steps;
-    const double *gpow; // gamma ** h, h = 0..horizon   (host libm pow, = Python's float **)
-    const double *tp;   // temperature * A * prior[a]
-    const double *cdf;  // cumsum(rollout_p) / cumsum(rollout_p)[-1]
+    const double *tab; // gpow[H+1] | cdf[A] | rcp[E+1] | tpdiv[A][E+2]
     uint64_t *rng;
     UctNode *tree;
     int32_t *plans, *plan_len;
@@ -51,30 +57,35 @@ struct UctArgs {
     int64_t *root_child_count, *env_steps;
 };
 
-// AT > 0: |A| known at compile time (children scored from registers in one pass, tables in
-// registers); AT == 0: any |A| (three passes over the children, tables in LDS).
-template <int AT>
-__global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
+// AT > 0: |A| known at compile time (children scored from registers in one pass);
+// AT == 0: any |A| (three passes over the children).  LDSM: transition table in LDS.
+template <int AT, bool LDSM>
+__global__ __launch_bounds__(LDSM ? 1024 : 64) void uct_kernel(UctArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
-    const int lane = threadIdx.x;
-    const int A = AT > 0 ? AT : p.A, H = p.horizon;
-    // LDS: gamma powers [H + 1] | (generic) tp [A], cdf [A] | path stack [(H + 1)][64] int32
-    double *gpow = lds_d;
-    double *tpL = gpow + (H + 1);
-    double *cdfL = tpL + (AT > 0 ? 0 : A);
-    int32_t *path = reinterpret_cast<int32_t *>(cdfL + (AT > 0 ? 0 : A));
-    for (int i = lane; i <= H; i += 64) gpow[i] = p.gpow[i];
-    if (AT == 0)
-        for (int i = lane; i < A; i += 64) { tpL[i] = p.tp[i]; cdfL[i] = p.cdf[i]; }
-    constexpr int AR = AT > 0 ? AT : 1;
-    double tp[AR], cdf[AR];
-    if (AT > 0) {
-#pragma unroll
-        for (int a = 0; a < AR; ++a) { tp[a] = p.tp[a]; cdf[a] = p.cdf[a]; }
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int A = AT > 0 ? AT : p.A, H = p.horizon, E = p.episodes;
+    const int nthreads = p.waves * 64;
+    double *gpow = lds_d;                   // [H + 1]  gamma ** h
+    double *cdf = gpow + (H + 1);           // [A]      rollout cdf
+    double *rcp = cdf + A;                  // [E + 1]  1.0 / n
+    double *tpdiv = rcp + (E + 1);          // [A][E+2] temperature * |A| * prior[a] / n
+    const int ntab = (H + 1) + A + (E + 1) + A * (E + 2);
+    int32_t *path_all = reinterpret_cast<int32_t *>(lds_d + ntab); // [H + 1][waves * 64]
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(path_all + (H + 1) * nthreads);
+    for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
+    if (LDSM) {
+        // S*A uint16 entries, staged with 16-byte loads where the tail allows
+        const int n = p.S * A;
+        const int n8 = n >> 3;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.t16);
+        uint4 *dst = reinterpret_cast<uint4 *>(t16);
+        for (int i = tid; i < n8; i += nthreads) dst[i] = src[i];
+        for (int i = (n8 << 3) + tid; i < n; i += nthreads) t16[i] = p.t16[i];
     }
     __syncthreads();
-    const int r = blockIdx.x * p.lanes + lane;
+    int32_t *path = path_all + wave * 64; // slot d of this lane: path[d * nthreads + lane]
+    const int r = (blockIdx.x * p.waves + wave) * p.lanes + lane;
     if (lane >= p.lanes || r >= p.n_roots) return;
     UctNode *tree = p.tree + (long)r * p.cap;
     const Rec *__restrict__ rec = p.rec;
@@ -82,6 +93,9 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
     g.load(p.rng + (long)r * 6);
     const int32_t s0 = p.root_state[r];
     const int32_t st0 = p.root_steps ? p.root_steps[r] : 0;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    // terminal flag of the root state itself ("source" rule): every record of a state carries it
+    const bool root_term = (rec[(long)s0 * A].flags & 1u) != 0;
     // mcts.py:129-130 reset(): fresh root
     {
         UctNode n;
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
     }
     int n_nodes = 1;
     int64_t steps_taken = 0;
-    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    constexpr int AR = AT > 0 ? AT : 1;
 
 #ifdef MP_PROFILE
     long long t_sel = 0, t_expd = 0, t_roll = 0, t_bak = 0, n_sel = 0, n_roll = 0;
@@ -99,26 +113,28 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
 #else
 #define PROF_T(x)
 #endif
-    for (int ep = 0; ep < p.episodes; ++ep) { // mcts.py:179-184
+    for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
         PROF_T(c0);
         int32_t s = s0, st = st0;
         int node = 0, depth = 0;
         bool terminal = false;
+        bool cur_term = root_term; // terminal[s] of the state the next action is taken from
         double total = 0.0;
         path[lane] = 0;
         int fc = tree[0].first_child;
         // ---- selection, mcts.py:143-149
         while (depth < H && fc >= 0 && !terminal) {
-            // MCTSNode.selection_strategy (mcts.py:275-286) for each child, Node.random_argmax
-            // (abstract.py:296-311): exact-equality argmax set, uniform draw among >= 2 ties
-            int act = 0;
+            // MCTSNode.selection_strategy (mcts.py:275-286): value + temperature*|A|*prior/(count+1);
+            // Node.random_argmax (abstract.py:296-311): exact-equality argmax set, uniform draw
+            // among >= 2 ties (no draw for a single maximum)
+            int act = 0, nfc = -1;
             if (AT > 0) {
                 UctNode c[AR];
 #pragma unroll
                 for (int a = 0; a < AR; ++a) c[a] = tree[fc + a];
                 double sc[AR];
 #pragma unroll
-                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + tp[a] / (double)(c[a].count + 1);
+                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + tpdiv[a * (E + 2) + c[a].count + 1];
                 double m = sc[0];
 #pragma unroll
                 for (int a = 1; a < AR; ++a) m = sc[a] > m ? sc[a] : m;
@@ -130,42 +146,52 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
 #pragma unroll
                 for (int a = 0; a < AR; ++a) {
                     const bool eq = sc[a] == m;
-                    if (eq && !found && pick == 0) { act = a; found = true; }
+                    if (eq && !found && pick == 0) { act = a; nfc = c[a].first_child; found = true; }
                     if (eq && !found) --pick;
                 }
             } else {
                 double m = 0.0;
                 for (int a = 0; a < A; ++a) {
                     const UctNode c = tree[fc + a];
-                    const double sc = c.value + tpL[a] / (double)(c.count + 1);
+                    const double sc = c.value + tpdiv[a * (E + 2) + c.count + 1];
                     if (a == 0 || sc > m) m = sc;
                 }
                 int nt = 0;
                 for (int a = 0; a < A; ++a) {
                     const UctNode c = tree[fc + a];
-                    const double sc = c.value + tpL[a] / (double)(c.count + 1);
-                    nt += sc == m ? 1 : 0;
+                    nt += (c.value + tpdiv[a * (E + 2) + c.count + 1]) == m ? 1 : 0;
                 }
                 int pick = (int)g.below((uint32_t)nt);
                 for (int a = 0; a < A; ++a) {
                     const UctNode c = tree[fc + a];
-                    const double sc = c.value + tpL[a] / (double)(c.count + 1);
-                    if (sc == m) {
-                        if (pick == 0) { act = a; break; }
+                    if ((c.value + tpdiv[a * (E + 2) + c.count + 1]) == m) {
+                        if (pick == 0) { act = a; nfc = c.first_child; break; }
                         --pick;
                     }
                 }
             }
-            const Rec rc = rec[(long)s * A + act];
-            terminal = (rc.flags & done_bit) != 0;
-            s = rc.next;
+            const long idx = (long)s * A + act;
+            double reward;
+            if (LDSM) {
+                const uint32_t e = t16[idx];
+                reward = rec[idx].reward;
+                const bool next_term = (e & 0x8000u) != 0;
+                terminal = p.done_on_next ? next_term : cur_term;
+                cur_term = next_term;
+                s = (int32_t)(e & 0x7fffu);
+            } else {
+                const Rec rc = rec[idx];
+                terminal = (rc.flags & done_bit) != 0;
+                reward = rc.reward;
+                s = rc.next;
+            }
             ++st;
             ++steps_taken;
-            total += gpow[depth] * rc.reward;
+            total += gpow[depth] * reward;
             node = fc + act;
             ++depth;
-            path[depth * 64 + lane] = node;
-            fc = tree[node].first_child;
+            path[depth * nthreads + lane] = node;
+            fc = nfc;
 #ifdef MP_PROFILE
             ++n_sel;
 #endif
@@ -181,38 +207,105 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
         }
         PROF_T(c2);
         // ---- rollout, mcts.py:156-157 / 160-177
-        if (!terminal) {
-            for (int h = depth; h < H; ++h) {
-                const double u = g.next_double();
-                // searchsorted(cdf, u, side='right') on a non-decreasing cdf = #{a : cdf[a] <= u}
-                int act = 0;
-                if (AT > 0) {
+        if (!terminal && depth < H) {
+            int h = depth;
+            double u = g.next_double();
+            if (LDSM) {
+                // two steps per trip so that the reward fetched for step h (HBM/L2, off the state
+                // chain) is added while step h+1's lookup is already in flight; the adds keep the
+                // reference's order (total += gamma**h * r_h for ascending h)
+                double r_a = 0.0, r_b = 0.0, g_a = 0.0, g_b = 0.0;
+                bool have_b = false, pend_a = false;
+                while (true) {
+                    {   // step "a"
+                        int act = 0;
+                        if (AT > 0) {
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
-                } else {
-                    for (int a = 0; a < A; ++a) act += cdfL[a] <= u ? 1 : 0;
-                }
-                const double gh = gpow[h];
-                const Rec rc = rec[(long)s * A + act];
-                const bool term_h = (rc.flags & done_bit) != 0;
-                s = rc.next;
-                ++st;
-                ++steps_taken;
-                total += gh * rc.reward;
-                const bool trunc_h = p.max_steps > 0 && st >= p.max_steps;
+                            for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
+                        } else {
+                            for (int a = 0; a < A; ++a) act += cdf[a] <= u ? 1 : 0;
+                        }
+                        const long idx = (long)s * A + act;
+                        const uint32_t e = t16[idx];
+                        r_a = rec[idx].reward;
+                        g_a = gpow[h];
+                        Pcg64 g2 = g;
+                        const double u2 = g2.next_double(); // speculative draw for step h + 1
+                        if (have_b) total += g_b * r_b;
+                        pend_a = true;
+                        const bool next_term = (e & 0x8000u) != 0;
+                        const bool term_h = p.done_on_next ? next_term : cur_term;
+                        cur_term = next_term;
+                        s = (int32_t)(e & 0x7fffu);
+                        ++st; ++steps_taken; ++h;
 #ifdef MP_PROFILE
-                ++n_roll;
+                        ++n_roll;
 #endif
-                if (term_h || trunc_h) break;
+                        if (term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H) break;
+                        g = g2; u = u2;
+                    }
+                    {   // step "b"
+                        int act = 0;
+                        if (AT > 0) {
+#pragma unroll
+                            for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
+                        } else {
+                            for (int a = 0; a < A; ++a) act += cdf[a] <= u ? 1 : 0;
+                        }
+                        const long idx = (long)s * A + act;
+                        const uint32_t e = t16[idx];
+                        r_b = rec[idx].reward;
+                        g_b = gpow[h];
+                        Pcg64 g2 = g;
+                        const double u2 = g2.next_double();
+                        total += g_a * r_a;
+                        pend_a = false; have_b = true;
+                        const bool next_term = (e & 0x8000u) != 0;
+                        const bool term_h = p.done_on_next ? next_term : cur_term;
+                        cur_term = next_term;
+                        s = (int32_t)(e & 0x7fffu);
+                        ++st; ++steps_taken; ++h;
+#ifdef MP_PROFILE
+                        ++n_roll;
+#endif
+                        if (term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H) break;
+                        g = g2; u = u2;
+                    }
+                }
+                total += pend_a ? g_a * r_a : g_b * r_b;
+            } else {
+                while (true) {
+                    // searchsorted(cdf, u, side='right') on a non-decreasing cdf = #{a : cdf[a] <= u}
+                    int act = 0;
+                    if (AT > 0) {
+#pragma unroll
+                        for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
+                    } else {
+                        for (int a = 0; a < A; ++a) act += cdf[a] <= u ? 1 : 0;
+                    }
+                    const Rec rc = rec[(long)s * A + act];
+                    const double gh = gpow[h];
+                    Pcg64 g2 = g;
+                    const double u2 = g2.next_double(); // speculative draw, overlaps the gather
+                    const bool term_h = (rc.flags & done_bit) != 0;
+                    s = rc.next;
+                    ++st; ++steps_taken; ++h;
+                    total += gh * rc.reward;
+#ifdef MP_PROFILE
+                    ++n_roll;
+#endif
+                    if (term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H) break;
+                    g = g2; u = u2;
+                }
             }
         }
         PROF_T(c3);
         // ---- backup, mcts.py:248-265: the same return for every node on the path
         for (int d = depth; d >= 0; --d) {
-            const int n = path[d * 64 + lane];
+            const int n = path[d * nthreads + lane];
             UctNode c = tree[n];
             c.count += 1;
-            c.value += 1.0 / (double)c.count * (total - c.value);
+            c.value += rcp[c.count] * (total - c.value);
             tree[n] = c;
         }
 #ifdef MP_PROFILE
@@ -257,25 +350,32 @@ __global__ __launch_bounds__(64) void uct_table_kernel(UctArgs p)
     }
 }
 
-// Roots per wavefront.  A root's episodes are one long dependency chain, so a batch takes as long
-// as its slowest wavefront; with few roots it pays to spread them thin (fewer lanes per wave = less
-// rollout-length divergence and fewer distinct cache lines per gather) until every SIMD has a wave.
-static int uct_lanes_per_wave(const mp_ctx *ctx, int n_roots)
+// Roots per wavefront for the global-table variant.  A root's episodes are one long dependency
+// chain, so a batch takes as long as its slowest wavefront; measured on MI355X (4096 roots,
+// highway table) dense waves are fastest: 64 lanes 0.41 ms, 16 lanes 0.44 ms, 4 lanes 0.70 ms.
+static int uct_lanes_per_wave()
 {
     if (const char *e = getenv("MP_UCT_LANES")) {
         const int v = atoi(e);
         if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) return v;
     }
-    const int simds = ctx->prop.multiProcessorCount * 4;
-    int lanes = 64;
-    while (lanes > 4 && (long)n_roots < (long)simds * lanes) lanes >>= 1;
-    return lanes;
+    return 64;
 }
 
 template <int AT>
-static void uct_launch(const UctArgs &a, size_t lds, hipStream_t st)
+static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st)
 {
-    hipLaunchKernelGGL(uct_table_kernel<AT>, dim3((unsigned)((a.n_roots + a.lanes - 1) / a.lanes)), dim3(64), lds, st, a);
+    const int roots_per_block = a.waves * a.lanes;
+    const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
+    if (ldsm) {
+        if (lds > 64 * 1024)
+            MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<AT, true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((uct_kernel<AT, true>), grid, block, lds, st, a);
+    } else {
+        hipLaunchKernelGGL((uct_kernel<AT, false>), grid, block, lds, st, a);
+    }
+    return MP_OK;
 }
 
 } // namespace mp
@@ -296,30 +396,51 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
         return fail(MP_ERR_MODE, "mp_uct_plan: model mode %d is not a deterministic table", model->mode);
     if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
         return fail(MP_ERR_ARG, "mp_uct_plan: bad sizes (n_roots=%d episodes=%d horizon=%d)", n_roots, episodes, horizon);
-    const int A = model->A;
-    const size_t lds = (size_t)(horizon + 1) * (64 * sizeof(int32_t) + sizeof(double)) + 2 * (size_t)A * sizeof(double);
-    if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d too deep for the LDS path stack", horizon);
+    const int A = model->A, H = horizon, E = episodes;
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const long cap = 1 + (long)episodes * A;
 
     // small per-call tables, computed on the host exactly as Python computes them
-    std::vector<double> tab((size_t)horizon + 1 + 2 * (size_t)A);
-    for (int h = 0; h <= horizon; ++h) tab[h] = pow(gamma, (double)h);           // gamma ** h
-    double *tp = tab.data() + horizon + 1, *cdf = tp + A;
-    for (int a = 0; a < A; ++a) tp[a] = temperature * (double)A * prior_p[a];      // mcts.py:286, left to right
+    const size_t ntab = (size_t)(H + 1) + A + (E + 1) + (size_t)A * (E + 2);
+    std::vector<double> tab(ntab);
+    double *gpow = tab.data(), *cdf = gpow + (H + 1), *rcp = cdf + A, *tpdiv = rcp + (E + 1);
+    for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);                 // gamma ** h
     double acc = 0.0;
     for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }             // numpy cumsum
     for (int a = 0; a < A; ++a) cdf[a] /= acc;                                     // cdf /= cdf[-1]
+    rcp[0] = 0.0;
+    for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                         // mcts.py:255  K / count, K = 1
+    for (int a = 0; a < A; ++a) {
+        const double tp = temperature * (double)A * prior_p[a];                   // mcts.py:286, left to right
+        tpdiv[(size_t)a * (E + 2)] = 0.0;
+        for (int n = 1; n <= E + 1; ++n) tpdiv[(size_t)a * (E + 2) + n] = tp / (double)n; // ... / (count + 1)
+    }
     double *d_tab = nullptr;
     MP_TRY(upload_tables(ctx, 1, tab, &d_tab));
 
     UctArgs a;
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.episodes = episodes; a.horizon = horizon; a.cap = (int)cap;
     a.done_on_next = model->done_on_next; a.max_steps = model->max_steps; a.max_plan_len = max_plan_len;
-    a.lanes = uct_lanes_per_wave(ctx, n_roots);
-    a.rec = model->rec;
-    a.gpow = d_tab; a.tp = d_tab + horizon + 1; a.cdf = a.tp + A;
+    a.rec = model->rec; a.t16 = model->t16; a.tab = d_tab;
+
+    // variant and geometry
+    const char *force = getenv("MP_UCT_MODEL"); // "global" / "lds": test hook
+    bool ldsm = model->t16 != nullptr && !(force && force[0] == 'g');
+    a.lanes = ldsm ? 64 : uct_lanes_per_wave();
+    // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
+    a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
+    const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
+    size_t lds = lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0);
+    if (ldsm && lds > kLdsBytes) {
+        if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
+        ldsm = false;
+        a.lanes = uct_lanes_per_wave(); a.waves = 1;
+        lds = ntab * sizeof(double) + (size_t)(H + 1) * 64 * sizeof(int32_t);
+    }
+    if (!ldsm && lds > 64 * 1024)
+        return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
+
     MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.tree));
     ctx->tree.kind = 1; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap;
 
@@ -337,13 +458,13 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
 
     MP_TRY(kernels_begin(ctx));
     switch (A) {
-    case 2: uct_launch<2>(a, lds, st); break;
-    case 3: uct_launch<3>(a, lds, st); break;
-    case 4: uct_launch<4>(a, lds, st); break;
-    case 5: uct_launch<5>(a, lds, st); break;
-    case 6: uct_launch<6>(a, lds, st); break;
-    case 8: uct_launch<8>(a, lds, st); break;
-    default: uct_launch<0>(a, lds, st); break;
+    case 2: MP_TRY(uct_launch<2>(a, ldsm, lds, st)); break;
+    case 3: MP_TRY(uct_launch<3>(a, ldsm, lds, st)); break;
+    case 4: MP_TRY(uct_launch<4>(a, ldsm, lds, st)); break;
+    case 5: MP_TRY(uct_launch<5>(a, ldsm, lds, st)); break;
+    case 6: MP_TRY(uct_launch<6>(a, ldsm, lds, st)); break;
+    case 8: MP_TRY(uct_launch<8>(a, ldsm, lds, st)); break;
+    default: MP_TRY(uct_launch<0>(a, ldsm, lds, st)); break;
     }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());

@@ -1,0 +1,127 @@
+"""Model extraction: environment object -> device-resident transition model.
+
+The reference's planners treat the environment as an opaque Python object that is deep-copied
+(``safe_deepcopy_env``, common/factory.py:119-134) and stepped (tree_search/abstract.py:158-161).
+A GPU kernel cannot call that, so the boundary extracts what the object *is* for the planners:
+
+* a finite MDP -- ``env.unwrapped.mdp`` of a FiniteMDPEnv, or ``env.unwrapped.to_finite_mdp()``
+  (highway-env and friends; the same call ValueIterationAgent makes, value_iteration.py:12-21) --
+  becomes tables ``transition[S,A]``, ``reward[S,A]``, ``terminal[S]`` on the device;
+* anything else raises ``TypeError`` (there is deliberately no CPU fallback).
+
+Uploads are cached per context and keyed by a content hash of the tables, so agents that rebuild the
+MDP on every ``act`` (value_iteration.py:29-35) only pay for an upload when the tables changed.
+"""
+import zlib
+
+import numpy as np
+
+from . import runtime
+
+
+class TableSpec(object):
+    """Host-side view of a finite MDP in the reference's wire format (mode / transition / reward / terminal)."""
+
+    def __init__(self, mode, transition, reward, terminal=None, next_states=None, done_rule="source", max_steps=0):
+        self.mode = mode
+        self.reward = np.ascontiguousarray(reward, dtype=np.float64)
+        if mode == "deterministic":
+            self.transition = np.ascontiguousarray(transition, dtype=np.int64)
+        elif mode in ("stochastic", "sparse"):
+            self.transition = np.ascontiguousarray(transition, dtype=np.float64)
+        else:
+            raise ValueError("Unknown mode")                      # value_iteration.py:60-61
+        self.next = None if next_states is None else np.ascontiguousarray(next_states, dtype=np.int64)
+        n_states = self.reward.shape[-2]
+        self.terminal = (np.zeros(n_states, dtype=np.uint8) if terminal is None
+                         else np.ascontiguousarray(np.asarray(terminal).reshape(n_states).astype(np.uint8)))
+        self.done_rule = done_rule
+        self.max_steps = int(max_steps or 0)
+
+    @property
+    def n_states(self):
+        return self.reward.shape[-2]
+
+    @property
+    def n_actions(self):
+        return self.reward.shape[-1]
+
+    def key(self):
+        h = 0
+        for arr in (self.transition, self.reward, self.terminal, self.next):
+            if arr is not None:
+                h = zlib.crc32(arr.view(np.uint8).reshape(-1), h)
+        return (self.mode, self.transition.shape, self.done_rule, self.max_steps, h)
+
+
+def finite_mdp_of(env):
+    """The finite MDP behind ``env``: ``.mdp`` of a finite-MDP env, else ``to_finite_mdp()``; TypeError otherwise."""
+    base = getattr(env, "unwrapped", env)
+    mdp = getattr(base, "mdp", None)
+    if mdp is not None and hasattr(mdp, "transition") and hasattr(mdp, "reward"):
+        return mdp
+    if hasattr(base, "to_finite_mdp"):
+        return base.to_finite_mdp()
+    raise TypeError("Environment must be of type finite_mdp.envs.finite_mdp.FiniteMDPEnv or handle a "
+                    "conversion method called 'to_finite_mdp' to such a type.")
+
+
+def spec_from_mdp(mdp, max_steps=0):
+    return TableSpec(mdp.mode, mdp.transition, mdp.reward, getattr(mdp, "terminal", None),
+                     next_states=getattr(mdp, "next", None) if mdp.mode == "sparse" else None,
+                     done_rule=getattr(mdp, "done_rule", "source"), max_steps=max_steps)
+
+
+def env_root_state(env):
+    """(state index, steps taken) of a finite-MDP environment: what a clone of it consists of on the device."""
+    base = getattr(env, "unwrapped", env)
+    mdp = finite_mdp_of(env)
+    return int(mdp.state), int(getattr(base, "steps", 0) or 0)
+
+
+def env_max_steps(env):
+    base = getattr(env, "unwrapped", env)
+    cfg = getattr(base, "config", None)
+    if isinstance(cfg, dict):
+        return int(cfg.get("max_steps", 0) or 0)
+    return 0
+
+
+class ModelCache(object):
+    """Device models of one context, keyed by table content; least-recently-used eviction."""
+
+    def __init__(self, ctx=None, capacity=8):
+        self._ctx = ctx
+        self.capacity = capacity
+        self._models = {}
+        self._order = []
+        self.uploads = 0
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            self._ctx = runtime.get_context()
+        return self._ctx
+
+    def get(self, spec):
+        key = spec.key()
+        model = self._models.get(key)
+        if model is None:
+            model = self._upload(spec)
+            self.uploads += 1
+            self._models[key] = model
+            if len(self._order) >= self.capacity:
+                old = self._order.pop(0)
+                self._models.pop(old).close()
+        else:
+            self._order.remove(key)
+        self._order.append(key)
+        return model
+
+    def _upload(self, spec):
+        if spec.mode == "deterministic":
+            return self.ctx.load_table(spec.transition, spec.reward, spec.terminal, done_rule=spec.done_rule,
+                                       max_steps=spec.max_steps)
+        if spec.mode == "stochastic":
+            return self.ctx.load_dense(spec.transition, spec.reward, spec.terminal)
+        return self.ctx.load_sparse(spec.transition, spec.next, spec.reward, spec.terminal)

@@ -1,0 +1,83 @@
+"""Multi-GPU execution of the planning path: roots shard, results gather.
+
+One process per GPU (``python -m torch.distributed.run --nproc-per-node N``; backend ``nccl`` = RCCL over
+xGMI on MI355X, ``gloo`` on CPU for tests).  Independent roots never interact, so the data path has no
+collective: rank r plans the contiguous block ``shard_bounds(n, r, world)`` of the global root list with
+random streams keyed by GLOBAL root index (results do not depend on the number of GPUs); the only
+exchange is one all_gather of the per-root results (a few bytes per root -- latency-bound, a single
+step on the fully connected xGMI mesh).  The reference's counterpart is one process per experiment
+(``scripts/experiments.py:102-106``), with no result exchange at all.
+"""
+import numpy as np
+
+
+def shard_bounds(n_items, rank, world):
+    """Contiguous, balanced block [lo, hi) of ``n_items`` for ``rank`` (first ``n % world`` ranks get one more)."""
+    base, extra = divmod(int(n_items), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def all_gather_rows(local, n_total, device=None):
+    """Gather row blocks (numpy [n_local, ...], sharded by :func:`shard_bounds`) into the full [n_total, ...] array
+    on every rank.  Blocks are padded to the largest shard so that one fixed-size all_gather suffices."""
+    import torch
+    import torch.distributed as dist
+    rank, world = rank_world()
+    local = np.ascontiguousarray(local)
+    if world == 1:
+        return local
+    per = -(-n_total // world)
+    pad = np.zeros((per,) + local.shape[1:], dtype=local.dtype)
+    pad[:local.shape[0]] = local
+    view = pad.view(np.uint8).reshape(per, -1)
+    t = torch.from_numpy(view.copy())
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    parts = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        block = out[r].cpu().numpy().reshape(-1).view(local.dtype).reshape((per,) + local.shape[1:])
+        parts.append(block[:hi - lo])
+    return np.concatenate(parts, axis=0)
+
+
+def plan_batch_sharded(agent, root_states, root_steps=None, device=None, keys=("plans", "plan_len", "env_steps")):
+    """Plan ``root_states`` (the same global list on every rank) with roots sharded over the process group.
+
+    ``agent``: a tree-search agent of this package.  Returns a dict with the gathered ``keys`` (plus any of
+    ``root_value`` / ``root_lower`` / ``root_upper`` the planner produced), identical on every rank."""
+    rank, world = rank_world()
+    root_states = np.asarray(root_states, dtype=np.int32)
+    n = len(root_states)
+    lo, hi = shard_bounds(n, rank, world)
+    steps = None if root_steps is None else np.asarray(root_steps, dtype=np.int32)[lo:hi]
+    rng = agent.planner.batch_rng_states(hi - lo, first_root=lo)
+    from rl_agents_amd.agents.common.factory import preprocess_env
+    env = preprocess_env(agent.env, agent.config["env_preprocessors"])
+    local = agent.planner.plan_batch(env, root_states[lo:hi], steps, rng_states=rng) if hi > lo else None
+    names = list(keys) + [k for k in ("root_value", "root_lower", "root_upper") if local is not None and k in local]
+    if world > 1:
+        import torch.distributed as dist
+        gathered = [None] * world
+        dist.all_gather_object(gathered, names)          # ranks with an empty shard learn the key set
+        names = max(gathered, key=len)
+    out = {}
+    for k in names:
+        if local is not None:
+            block = local[k]
+        else:
+            block = np.zeros((0,), dtype=np.float64)
+        if world > 1 and local is None:
+            raise RuntimeError("fewer roots than ranks: give every rank at least one root")
+        out[k] = all_gather_rows(block, n, device=device)
+    return out

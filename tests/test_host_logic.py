@@ -1,0 +1,191 @@
+"""CPU tests of the host side: config merge, factory, policies, receding horizon, model extraction / cache,
+C-ABI symbol table, budget allocation.  No GPU compute is called."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from rl_agents_amd import device_model, native
+from rl_agents_amd.agents.common.factory import agent_factory, load_agent_config, preprocess_env
+from rl_agents_amd.agents.tree_search import mcts as mcts_mod
+from rl_agents_amd.agents.tree_search.abstract import AbstractTreeSearchAgent, build_tree, np_random
+from rl_agents_amd.configuration import Configurable
+from rl_agents_amd.envs import FiniteMDPEnv, generators
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """The shared library loads and exports exactly the entry points include/mi355plan.h declares."""
+    header = open(os.path.join(REPO, "include", "mi355plan.h")).read()
+    declared = set(re.findall(r"\b(mp_[a-z0-9_]+)\s*\(", header))
+    declared -= {"mp_ctx", "mp_model"}
+    lib = ctypes.CDLL(native.lib_path())
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
+    assert native.load().mp_abi_version() == 1
+
+
+def test_context_fails_loudly_without_gpu_or_library(monkeypatch):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(native.NativeError):
+        native.Context(0)
+    monkeypatch.setattr(native, "_LIB", None)
+    monkeypatch.setattr(native._build, "LIB_PATH", "/nonexistent/libmi355plan.so")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.load()
+
+
+def test_olop_allocation_matches_golden(golden):
+    z = golden["misc"]
+    for (b, g), (e, h) in zip(z["alloc/in"], z["alloc/out"]):
+        assert native.olop_allocation(int(b), float(g)) == (int(e), int(h))
+    with pytest.raises(ValueError):
+        native.olop_allocation(1, 0.8)
+
+
+def test_configurable_merges_both_ways():
+    class C(Configurable):
+        @classmethod
+        def default_config(cls):
+            return {"a": 1, "nested": {"x": 1, "y": 2}}
+    user = {"nested": {"y": 5}, "extra": True}
+    c = C(user)
+    assert c.config == {"a": 1, "nested": {"x": 1, "y": 5}, "extra": True}
+    assert user == c.config and user is not c.config          # the caller's dict is completed in place
+
+
+def test_agent_factory_and_json_inheritance(tmp_path):
+    base = tmp_path / "base.json"
+    child = tmp_path / "child.json"
+    base.write_text(json.dumps({"__class__": "<class 'rl_agents_amd.agents.tree_search.mcts.MCTSAgent'>",
+                                "budget": 300, "gamma": 0.9}))
+    child.write_text(json.dumps({"base_config": str(base), "budget": 1000}))
+    cfg = load_agent_config(str(child))
+    assert cfg["budget"] == 1000 and cfg["gamma"] == 0.9 and "base_config" not in cfg
+    env = FiniteMDPEnv(generators.gridworld())
+    agent = agent_factory(env, cfg)
+    assert isinstance(agent, mcts_mod.MCTSAgent)
+    assert (agent.planner.config["episodes"], agent.planner.config["horizon"]) == native.olop_allocation(1000, 0.9)
+    with pytest.raises(ValueError):
+        agent_factory(env, {"budget": 3})
+
+
+def test_mcts_defaults_and_policies():
+    env = FiniteMDPEnv(generators.gridworld())
+    agent = mcts_mod.MCTSAgent(env, {"budget": 400, "gamma": 0.95})
+    pc = agent.planner.config
+    assert pc["temperature"] == 2 / (1 - 0.8)                  # from the DEFAULT gamma, as in the reference
+    assert pc["step_strategy"] == "reset" and pc["closed_loop"] is False
+    agent2 = mcts_mod.MCTSAgent(env, {"budget": 1000, "horizon": 30})
+    assert agent2.planner.config["episodes"] == 33            # documented deviation (reference: KeyError)
+    np.testing.assert_array_equal(mcts_mod.policy_probabilities({"type": "random"}, 4), np.ones(4) / 4)
+    p = mcts_mod.policy_probabilities({"type": "preference", "action": 1, "ratio": 3}, 4)
+    np.testing.assert_array_equal(p, np.ones(4) / (4 - 1 + 3) * np.array([1, 3, 1, 1]))
+    np.testing.assert_array_equal(mcts_mod.policy_probabilities({"type": "preference", "action": 9, "ratio": 3}, 4),
+                                  np.ones(4) / 4)
+    with pytest.raises(ValueError):
+        mcts_mod.MCTSAgent(env, {"prior_policy": {"type": "nope"}})
+    with pytest.raises(NotImplementedError):
+        mcts_mod.MCTSAgent(env, {"closed_loop": True})
+
+
+def test_receding_horizon_bookkeeping():
+    calls = []
+
+    class FakePlanner(object):
+        def plan(self, state, observation):
+            calls.append(observation)
+            return [0, 1, 2, 3]
+
+        def step_tree(self, actions):
+            pass
+
+        def step_by_reset(self):
+            pass
+
+    class Agent(AbstractTreeSearchAgent):
+        def make_planner(self):
+            return FakePlanner()
+
+    agent = Agent(env=object(), config={"receding_horizon": 3})
+    assert [agent.plan(i)[0] for i in range(7)] == [0, 1, 2, 0, 1, 2, 0]
+    assert calls == [0, 3, 6]                                   # re-plans every 3rd step
+    agent.reset()
+    assert agent.remaining_horizon == 0 and agent.steps == 0
+
+
+def test_seeding_matches_gymnasium_convention():
+    g, entropy = np_random(5)
+    ref = np.random.Generator(np.random.PCG64(np.random.SeedSequence(5)))
+    assert entropy == 5 and g.random() == ref.random()
+    st = native.rng_state_from_generator(ref)
+    g2 = np.random.Generator(np.random.PCG64(0))
+    native.generator_set_state(g2, st)
+    assert g2.random() == ref.random()
+    with pytest.raises(ValueError):
+        np_random(-1)
+
+
+def test_model_extraction_and_cache():
+    cfg = generators.highway_shaped(3, 4, 10, seed=3)
+    env = FiniteMDPEnv(dict(cfg, state=7, max_steps=12))
+    env.reset()
+    env.step(1)
+    mdp = device_model.finite_mdp_of(env)
+    spec = device_model.spec_from_mdp(mdp, max_steps=device_model.env_max_steps(env))
+    assert spec.mode == "deterministic" and spec.n_states == 120 and spec.n_actions == 5 and spec.max_steps == 12
+    assert device_model.env_root_state(env) == (int(cfg["transition"][7, 1]), 1)
+    with pytest.raises(TypeError):
+        device_model.finite_mdp_of(object())
+
+    class FakeCtx(object):
+        def load_table(self, *a, **k):
+            class M(object):
+                def close(self):
+                    pass
+            return M()
+
+    cache = device_model.ModelCache(FakeCtx(), capacity=2)
+    m1 = cache.get(spec)
+    assert cache.get(device_model.spec_from_mdp(mdp, max_steps=12)) is m1 and cache.uploads == 1
+    changed = np.array(cfg["reward"], copy=True)
+    changed[0, 0] += 0.125
+    spec2 = device_model.TableSpec("deterministic", cfg["transition"], changed, cfg["terminal"])
+    assert cache.get(spec2) is not m1 and cache.uploads == 2
+    with pytest.raises(ValueError):
+        device_model.TableSpec("bogus", cfg["transition"], cfg["reward"])
+
+
+def test_preprocess_env_and_tree_view():
+    class Env(object):
+        unwrapped = None
+
+        def simplify(self):
+            return "simplified"
+    e = Env()
+    e.unwrapped = e
+    assert preprocess_env(e, [{"method": "simplify"}]) == "simplified"
+    assert preprocess_env(e, [{"method": "missing"}]) is e
+    arrays = dict(parent=np.array([-1, 0, 0, 1, 1]), action=np.array([-1, 0, 1, 0, 1]),
+                  count=np.array([5, 3, 2, 2, 1]), value=np.array([.5, .6, .4, .7, .1]))
+    root = build_tree(arrays, "value")
+    assert sorted(root.children) == [0, 1] and root.children[0].children[1].path() == [0, 1]
+    assert root.children[0].children[0].depth == 2 and root.children[1].is_leaf() and root.get_value() == .5
+
+
+def test_shard_bounds_cover_everything():
+    from rl_agents_amd.distributed import shard_bounds
+    for n in (0, 1, 7, 8, 4096, 8193):
+        for world in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(b[1] == c[0] for b, c in zip(blocks, blocks[1:]))
+            sizes = [hi - lo for lo, hi in blocks]
+            assert max(sizes) - min(sizes) <= 1
