@@ -36,11 +36,24 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="uct", choices=["uct", "opd", "vi", "vi_dense"])
-    ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 4096 uct, 1024 opd)")
+    ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     return ap.parse_args()
+
+
+def host_cores():
+    """Cores this process may really use: min(affinity, cgroup cpu.max quota) -- the GPU box reports 256 logical
+    CPUs but its container is capped (cpu.max 1600000/100000 = 16 CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def dist_setup(n_gpus):
@@ -106,7 +119,7 @@ def bench_uct(args, rank, world, local):
     import torch
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
-    n_roots = args.roots or 4096
+    n_roots = args.roots or 262144
     episodes, horizon, gamma = 33, 30, 0.8
     temperature = 2 / (1 - 0.8)                       # mcts.py:121-124 default
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
@@ -162,6 +175,21 @@ def bench_uct(args, rank, world, local):
         env_steps = int(d_steps.sum().item())
     dt = max_over_ranks(dt, world)
     total_env_steps = sum_over_ranks(float(timed_env_steps), world) / args.steps   # per step, all ranks
+    # latency figures of the metric's second half ("plan() wall-ms per root"): small batches, rank 0's GPU
+    latency = {}
+    for nl in (1, 4096):
+        if nl > n_roots:
+            continue
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ctx.uct_plan_device(model, nl, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
+                                plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        latency["plan_wall_ms_batch_of_{}".format(nl)] = 1e3 * float(np.median(ts))
+        latency["kernel_ms_batch_of_{}".format(nl)] = ctx.last_kernel_ms()[0]
     k_ms = float(np.mean(kernel_ms))
     res = dict(
         metric="rollout env-steps/sec (UCT plan(), budget=1000)", unit="env-steps/s",
@@ -170,7 +198,7 @@ def bench_uct(args, rank, world, local):
         config=dict(workload="uct_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
             s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
             states=s_, actions=a_, episodes=episodes, horizon=horizon, gamma=gamma,
-            env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots,
+            env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots, latency=latency,
             parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
         roofline=dict(bound="hbm", achieved=UCT_BYTES_PER_ENV_STEP * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, kernel="uct_table_kernel",
@@ -179,7 +207,7 @@ def bench_uct(args, rank, world, local):
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle
-        cores = os.cpu_count() or 1
+        cores = host_cores()
         n_cpu = max(2048, 64 * cores)
         cpu_rng = seed_states(np.arange(n_cpu))
         oracle.uct_plan_batch(t, r, term, all_roots[:64], episodes, horizon, gamma, temperature, p, p, cpu_rng[:64],
@@ -219,7 +247,7 @@ def bench_opd(args, rank, world, local):
     s0 = all_roots[rank * n_roots:(rank + 1) * n_roots]
     dev = torch.device("cuda", local)
     d_s0 = torch.from_numpy(s0).to(dev)
-    d_rng = torch.zeros((n_roots, 6), dtype=torch.int64, device=dev)
+    d_rng = torch.from_numpy(seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots)).view(np.int64)).to(dev)
     mpl = 32
     d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
     d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
@@ -266,10 +294,11 @@ def bench_opd(args, rank, world, local):
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     if rank == 0 and not args.no_cpu_baseline:
         from oracle import oracle
-        cores = os.cpu_count() or 1
-        n_cpu = min(cores, 256)
+        cores = host_cores()
+        n_cpu = 4 * cores
         t1 = time.perf_counter()
-        o = oracle.opd_plan_batch(t, r, term, np.resize(all_roots, n_cpu), budget, gamma, 0.0, None, n_threads=cores)
+        o = oracle.opd_plan_batch(t, r, term, np.resize(all_roots, n_cpu), budget, gamma, 0.0, seed_states(np.arange(n_cpu)),
+                                  n_threads=cores)
         cdt = time.perf_counter() - t1
         res["cpu_baseline"] = dict(value=float(o["env_steps"].sum()) / cdt, unit="env-steps/s", cores=cores, kind="port",
                                    sample="oracle/planning_oracle.c opd_plan_batch, {} roots, OpenMP".format(n_cpu))
@@ -345,6 +374,9 @@ def bench_vi(args, rank, world, local, dense):
 
 
 def main():
+    if os.environ.get("BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
     args = parse()
     rank, world, local = dist_setup(args.gpus)
     import torch

@@ -210,7 +210,10 @@ def opd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_rew
     s, a = r.shape
     s0 = np.ascontiguousarray(s0, dtype=np.int32)
     n = len(s0)
-    rng = (np.zeros((n, 6), np.uint64) if rng_states is None else np.array(rng_states, np.uint64).reshape(n, 6))
+    if rng_states is None:  # any valid PCG64 record (odd increment); an all-zero one would never leave the rejection loop
+        rng = np.tile(np.array([0, 1, 0, 1, 0, 0], np.uint64), (n, 1))
+    else:
+        rng = np.array(rng_states, np.uint64).reshape(n, 6)
     plans = np.full((n, max_plan_len), -1, dtype=np.int32)
     plan_len = np.zeros(n, np.int32)
     lo, up = np.zeros(n), np.zeros(n)

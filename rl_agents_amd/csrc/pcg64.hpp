@@ -22,7 +22,9 @@ struct Pcg64 {
 
     __device__ __forceinline__ void load(const uint64_t *p)
     {
-        s_hi = p[0]; s_lo = p[1]; inc_hi = p[2]; inc_lo = p[3];
+        // a PCG64 increment is odd by construction (numpy: inc = (seq << 1) | 1); forcing the bit keeps a
+        // malformed (e.g. all-zero) record from turning the rejection loop of below() into a hang
+        s_hi = p[0]; s_lo = p[1]; inc_hi = p[2]; inc_lo = p[3] | 1ULL;
         has_uint32 = (uint32_t)p[4]; uinteger = (uint32_t)p[5];
     }
     __device__ __forceinline__ void store(uint64_t *p) const

@@ -107,7 +107,7 @@ def test_opd_reward_range_status(ctx):
     t = [[1, 2], [1, 1], [3, 4], [3, 3], [4, 4]]
     r = [[0, 0], [0, 0], [0, 0], [1, 1], [-1, -1]]
     model = ctx.load_table(t, r, [0, 1, 0, 1, 1])
-    out = ctx.opd_plan(model, [0], 20, 0.8, 0.0, np.zeros((1, 6), np.uint64))
+    out = ctx.opd_plan(model, [0], 20, 0.8, 0.0, np.array([[1, 2, 3, 5, 0, 0]], np.uint64))
     assert out["status"][0] == native.ERR_REWARD_RANGE
 
 
