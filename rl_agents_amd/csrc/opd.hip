@@ -36,6 +36,7 @@ namespace mp {
 
 struct OpdArgs {
     int n_roots, S, A, K, cap, done_on_next, max_plan_len;
+    int T; // LDS row length of a residue class: odd, >= ceil(cap / 64)
     const Rec *rec;
     const int32_t *root_state;
     const double *g1;   // g1[d]   = gamma ** (d - 1), d >= 1
@@ -54,33 +55,33 @@ struct OpdArgs {
     int64_t *env_steps;
 };
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask)
+// ---- cross-lane argmax on (U, id) with DPP (row_shr 1/2/4/8, row_bcast 15/31): VALU-speed data
+// movement instead of 18 ds_bpermute round trips.  Maximal U first, lowest id among equal U.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void argmax_step(double &u, int &id)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __shfl_xor(lo, mask, 64);
-    hi = __shfl_xor(hi, mask, 64);
-    return __hiloint2double(hi, lo);
+    const int lo = __double2loint(u), hi = __double2hiint(u);
+    // old = own value: lanes without a valid DPP source compare with themselves (no change)
+    const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    const int oid = __builtin_amdgcn_update_dpp(id, id, CTRL, ROW_MASK, 0xf, false);
+    const double ou = __hiloint2double(ohi, olo);
+    if (ou > u || (ou == u && oid < id)) { u = ou; id = oid; }
 }
 
-// all lanes receive the (max U, lowest id among maxima) pair
+// every lane returns the wave-wide (max U, lowest id among maxima)
 __device__ __forceinline__ void wave_argmax(double &u, int &id)
 {
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const double ou = shfl_xor_f64(u, m);
-        const int oid = __shfl_xor(id, m, 64);
-        if (ou > u || (ou == u && oid < id)) { u = ou; id = oid; }
-    }
-}
-
-__device__ __forceinline__ double wave_max(double v)
-{
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        const double o = shfl_xor_f64(v, m);
-        if (o > v) v = o;
-    }
-    return v;
+    argmax_step<0x111, 0xf>(u, id); // row_shr:1
+    argmax_step<0x112, 0xf>(u, id); // row_shr:2
+    argmax_step<0x114, 0xf>(u, id); // row_shr:4
+    argmax_step<0x118, 0xf>(u, id); // row_shr:8   -> lane 15 of each row holds the row result
+    argmax_step<0x142, 0xa>(u, id); // row_bcast:15 -> rows 1, 3
+    argmax_step<0x143, 0xc>(u, id); // row_bcast:31 -> rows 2, 3: lane 63 holds the wave result
+    const int lo = __builtin_amdgcn_readlane(__double2loint(u), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(u), 63);
+    u = __hiloint2double(hi, lo);
+    id = __builtin_amdgcn_readlane(id, 63);
 }
 
 struct alignas(16) OpdNode {
@@ -90,11 +91,18 @@ struct alignas(16) OpdNode {
 };
 static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 
+// LDS layout of the upper-bound array: node id -> (id & 63) * T + (id >> 6).  Lane l owns the ids
+// congruent to l mod 64 ("class" l), stored contiguously, and caches the best leaf of its class in
+// registers.  An expansion then costs: one 64-lane argmax over the cached class maxima, one
+// cooperative re-scan of the winner's class only (cap/64 entries, contiguous, conflict-free), and
+// one compare per lane for the new children -- instead of a scan of all cap entries.
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double *leafU = lds;                                             // [cap]
-    int32_t *exp_lds = reinterpret_cast<int32_t *>(lds + p.cap);     // [K]
+    const int T = p.T;                                                // odd, >= ceil(cap / 64)
+    double *leafU = lds;                                              // [64 * T]
+    int32_t *exp_lds = reinterpret_cast<int32_t *>(lds + 64 * T);     // [K]
+#define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x;
     const int root = blockIdx.x;
     const int A = p.A;
@@ -112,12 +120,15 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         n0.L = 0.0; n0.state = p.root_state[root]; n0.depth = 0;
         NA[0] = n0;
         RW[0] = 0.0; FC[0] = -1; DN[0] = 0;
-        leafU[0] = 0.0;
+        LU(0) = 0.0;
     }
     __syncthreads();
     int n_nodes = 1;
     int status = MP_OK;
     int k_done = 0;
+    // best leaf of this lane's class (ids == lane mod 64); -inf / INT_MAX when the class has no leaf
+    double cbu = lane == 0 ? 0.0 : ninf;
+    int cbid = lane == 0 ? 0 : 0x7fffffff;
 
 #ifdef MP_PROFILE
     long long t_scan = 0, t_exp = 0, t_all0 = clock64();
@@ -128,22 +139,25 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     for (int k = 0; k < p.K; ++k) {
         PROF_T(c0);
         // ---- deterministic.py:110: first maximal upper bound among the leaves
-        double bu = ninf;
-        int bid = 0x7fffffff;
-        int i = lane;
-        for (; i + 192 < n_nodes; i += 256) { // 4 independent LDS reads in flight per lane
-            const double u0 = leafU[i], u1 = leafU[i + 64], u2 = leafU[i + 128], u3 = leafU[i + 192];
-            if (u0 > bu) { bu = u0; bid = i; }
-            if (u1 > bu) { bu = u1; bid = i + 64; }
-            if (u2 > bu) { bu = u2; bid = i + 128; }
-            if (u3 > bu) { bu = u3; bid = i + 192; }
+        double bu = cbu;
+        int leaf = cbid;
+        wave_argmax(bu, leaf);
+        const int cls = leaf & 63;
+        // the selected leaf stops being one; re-derive the best leaf of its class from LDS
+        if (lane == 0) LU(leaf) = ninf;
+        __syncthreads();
+        {
+            const double *row = leafU + cls * T;
+            const int cnt = (n_nodes - cls + 63) >> 6; // ids cls, cls + 64, ... < n_nodes
+            double ru = ninf;
+            int rid = 0x7fffffff;
+            for (int t = lane; t < cnt; t += 64) {
+                const double u = row[t];
+                if (u > ru) { ru = u; rid = cls + (t << 6); }
+            }
+            wave_argmax(ru, rid);
+            if (lane == cls) { cbu = ru; cbid = rid; }
         }
-        for (; i < n_nodes; i += 64) {
-            const double u = leafU[i];
-            if (u > bu) { bu = u; bid = i; }
-        }
-        wave_argmax(bu, bid);
-        const int leaf = bid;
         PROF_T(c1);
         // ---- DeterministicNode.expand, deterministic.py:28-43
         const OpdNode pn = NA[leaf];
@@ -167,17 +181,26 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             cn.L = Lc; cn.state = rc.next; cn.depth = d;
             NA[c] = cn;
             RW[c] = r; FC[c] = -1; DN[c] = dn ? 1 : 0;
-            leafU[c] = Uc;
+            LU(c) = Uc;
         }
         if (lane == 0) {
-            leafU[leaf] = ninf;
             exp_lds[k] = leaf;
             FC[leaf] = g;
         }
         n_nodes += A;
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads(); // LDS leaf array visible to all lanes for the next scan
+        __syncthreads();
+        // the (at most one, |A| <= 64) new child that falls in this lane's class may beat its cached
+        // best; on equality the older (lower id) leaf stays, as in the reference's list order
+        {
+            const int j = (lane - g) & 63;
+            if (j < A) {
+                const int id = g + j;
+                const double u = LU(id);
+                if (u > cbu) { cbu = u; cbid = id; }
+            }
+        }
 #ifdef MP_PROFILE
         { const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1; }
 #endif
@@ -190,47 +213,50 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         // upper bounds: leaf entries are already in place, expanded entries hold -inf placeholders
         for (int k = k_done - 1; k >= 0; --k) {
             const int g = 1 + k * A;
-            double m = leafU[g];
+            double m = LU(g);
             for (int a = 1; a < A; ++a) {
-                const double v = leafU[g + a];
+                const double v = LU(g + a);
                 if (v > m) m = v;
             }
-            if (lane == 0) leafU[exp_lds[k]] = m;
+            if (lane == 0) LU(exp_lds[k]) = m;
         }
         __syncthreads();
-        for (int i = lane; i < n_nodes; i += 64) U[i] = leafU[i];
-        const double root_upper = leafU[0];
+        for (int i = lane; i < n_nodes; i += 64) U[i] = LU(i);
+        const double root_upper = LU(0);
         __syncthreads();
         // lower bounds: same pass over the creation-time L values
-        for (int i = lane; i < n_nodes; i += 64) leafU[i] = NA[i].L;
+        for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
         __syncthreads();
         for (int k = k_done - 1; k >= 0; --k) {
             const int g = 1 + k * A;
-            double m = leafU[g];
+            double m = LU(g);
             for (int a = 1; a < A; ++a) {
-                const double v = leafU[g + a];
+                const double v = LU(g + a);
                 if (v > m) m = v;
             }
-            if (lane == 0) leafU[exp_lds[k]] = m;
+            if (lane == 0) LU(exp_lds[k]) = m;
         }
         __syncthreads();
         for (int k = lane; k < k_done; k += 64) {
             const int n = exp_lds[k];
-            NA[n].L = leafU[n];
+            NA[n].L = LU(n);
         }
         // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
-        // (deterministic.py:21-26): random_argmax over the children's lower bounds (now in LDS)
+        // (deterministic.py:21-26): random_argmax over the children's lower bounds (in LDS).
+        // A node's children are group 1 + k*A where k is its expansion index; a chosen child's own
+        // index is found by searching the parent map forward (children are expanded after parents).
         Pcg64 gen;
         gen.load(p.rng + (long)root * 6);
-        int n = 0, len = 0;
-        int fc = FC[0];
-        while (fc >= 0) {
-            double m = leafU[fc];
+        int len = 0;
+        int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
+        while (kcur >= 0) {
+            const int fc = 1 + kcur * A;
+            double m = LU(fc);
             for (int a = 1; a < A; ++a) {
-                const double v = leafU[fc + a];
+                const double v = LU(fc + a);
                 if (v > m) m = v;
             }
-            const double l = lane < A ? leafU[fc + lane] : ninf;
+            const double l = lane < A ? LU(fc + lane) : ninf;
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
@@ -239,15 +265,21 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             const int a = __ffsll((long long)t) - 1;
             if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
             ++len;
-            n = fc + a;
-            fc = FC[n];
+            const int child = fc + a;
+            int knext = -1;
+            for (int b = kcur + 1; b < k_done; b += 64) {
+                const int idx = b + lane;
+                const unsigned long long hit = __ballot(idx < k_done && exp_lds[idx] == child);
+                if (hit) { knext = b + __ffsll((long long)hit) - 1; break; }
+            }
+            kcur = knext;
         }
         if (lane == 0) {
             gen.store(p.rng + (long)root * 6);
             if (p.plans)
                 for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[root] = len;
-            if (p.root_lower) p.root_lower[root] = leafU[0];
+            if (p.root_lower) p.root_lower[root] = LU(0);
             if (p.root_upper) p.root_upper[root] = root_upper;
         }
     } else if (lane == 0) {
@@ -266,6 +298,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         p.n_nodes_out[root] = n_nodes;
     }
     for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
+#undef LU
 }
 
 } // namespace mp
@@ -287,7 +320,8 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_opd_plan: bad sizes");
     const int K = budget / A; // deterministic.py:118
     const long cap = 1 + (long)K * A;
-    const size_t lds = (size_t)cap * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    const int T = (int)((cap + 63) / 64) | 1;
+    const size_t lds = (size_t)64 * T * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
     if (lds > kLdsBytes - 1024)
         return fail(MP_ERR_ARG, "mp_opd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds, kLdsBytes - 1024);
     MP_HIP(hipSetDevice(ctx->device));
@@ -305,7 +339,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     OpdArgs a;
-    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap;
+    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T;
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec;
     a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;
