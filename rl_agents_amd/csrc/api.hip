@@ -144,6 +144,7 @@ int mp_ctx_destroy(mp_ctx *ctx)
     if (!ctx) return MP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->vi_graph_exec) hipGraphExecDestroy((hipGraphExec_t)ctx->vi_graph_exec);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);

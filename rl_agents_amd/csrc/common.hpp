@@ -56,6 +56,13 @@ enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6,
        WS_IO5, WS_IO6, WS_IO7, WS_IO8, WS_IO9, WS_TAB0, WS_TAB1, WS_TAB2, WS_TAB3, WS_VI0, WS_VI1, WS_VI2, WS_VI3,
        WS_VI4, WS_COUNT };
 
+// everything a captured chain of deterministic VI sweeps bakes into its kernel arguments
+struct ViGraphKey {
+    const void *model, *T, *R, *term, *Vb, *notclose;
+    int iterations, M, S, A, robust, vform;
+    double gamma, rtol, atol;
+};
+
 } // namespace mp
 
 struct mp_ctx {
@@ -72,6 +79,9 @@ struct mp_ctx {
     // WS_TAB0: identical parameters on the next call skip the upload and its stream sync
     std::vector<double> tab_host;
     int tab_kind = 0;
+    // cached hipGraphExec of the last deterministic VI sweep chain
+    void *vi_graph_exec = nullptr;
+    mp::ViGraphKey vi_graph_key;
 };
 
 struct mp_model {

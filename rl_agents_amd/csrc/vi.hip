@@ -17,6 +17,8 @@
 // k+1 (already enqueued) turns into a no-op when notclose[k] stayed 0, freezing the iterates, so
 // the whole solve is one asynchronous batch of launches with no host round trip.
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 #include "common.hpp"
 
@@ -61,7 +63,10 @@ __device__ __forceinline__ double det_q(const ViDetArgs &p, const double *__rest
     return p.R[sa] + p.gamma * nv;
 }
 
-__global__ __launch_bounds__(256) void vi_det_sweep(ViDetArgs p)
+// AT > 0: |A| known at compile time -- every table load and V gather of a state is issued before the
+// first use (two dependent round trips per sweep instead of 2*|A|); AT == 0: any |A|.
+template <int AT>
+__global__ __launch_bounds__(64) void vi_det_sweep(ViDetArgs p)
 {
     if (p.k > 0 && p.notclose[p.k - 1] == 0) return; // converged at an earlier sweep: freeze
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -69,18 +74,52 @@ __global__ __launch_bounds__(256) void vi_det_sweep(ViDetArgs p)
     const bool term_s = (!p.robust && p.term) ? p.term[s] != 0 : false;
     bool nc = false;
     double vmax = 0.0;
-    for (int a = 0; a < p.A; ++a) {
-        const long sa = (long)s * p.A + a;
-        const double qn = det_q(p, p.Vcur, sa, term_s);
-        if (!p.vform) {
-            const double qo = p.k == 0 ? 0.0 : det_q(p, p.Vprev, sa, term_s);
-            nc |= !isclose_np(qo, qn, p.rtol, p.atol);
+    if (AT > 0 && !p.robust) {
+        constexpr int AR = AT > 0 ? AT : 1;
+        const long sa0 = (long)s * AR;
+        int32_t t[AR];
+        double r[AR], vc[AR], vp[AR];
+#pragma unroll
+        for (int a = 0; a < AR; ++a) { t[a] = p.T[sa0 + a]; r[a] = p.R[sa0 + a]; }
+#pragma unroll
+        for (int a = 0; a < AR; ++a) { vc[a] = p.Vcur[t[a]]; vp[a] = p.Vprev[t[a]]; }
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            const double qn = r[a] + p.gamma * (term_s ? 0.0 : vc[a]);
+            if (!p.vform) {
+                const double qo = p.k == 0 ? 0.0 : r[a] + p.gamma * (term_s ? 0.0 : vp[a]);
+                nc |= !isclose_np(qo, qn, p.rtol, p.atol);
+            }
+            if (a == 0 || qn > vmax) vmax = qn;
         }
-        if (a == 0 || qn > vmax) vmax = qn;
+    } else {
+        for (int a = 0; a < p.A; ++a) {
+            const long sa = (long)s * p.A + a;
+            const double qn = det_q(p, p.Vcur, sa, term_s);
+            if (!p.vform) {
+                const double qo = p.k == 0 ? 0.0 : det_q(p, p.Vprev, sa, term_s);
+                nc |= !isclose_np(qo, qn, p.rtol, p.atol);
+            }
+            if (a == 0 || qn > vmax) vmax = qn;
+        }
     }
     p.Vnext[s] = vmax;
     if (p.vform) nc = !isclose_np(p.Vcur[s], vmax, p.rtol, p.atol);
     if (nc) p.notclose[p.k] = 1;
+}
+
+static void vi_det_launch(const ViDetArgs &a, hipStream_t st)
+{
+    const dim3 grid((unsigned)((a.S + 63) / 64)), block(64);
+    switch (a.robust ? 0 : a.A) {
+    case 2: hipLaunchKernelGGL(vi_det_sweep<2>, grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL(vi_det_sweep<3>, grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL(vi_det_sweep<4>, grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL(vi_det_sweep<5>, grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL(vi_det_sweep<6>, grid, block, 0, st, a); break;
+    case 8: hipLaunchKernelGGL(vi_det_sweep<8>, grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL(vi_det_sweep<0>, grid, block, 0, st, a); break;
+    }
 }
 
 // result[0] = sweeps executed, result[1] = j such that the returned iterate is Q_j / V_j
@@ -322,16 +361,52 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
         a.M = M; a.S = S; a.A = A; a.robust = robust; a.vform = vform;
         a.T = m->T; a.R = m->R; a.term = m->term; a.gamma = gamma; a.rtol = rtol; a.atol = atol;
         a.notclose = notclose;
+        // The sweep chain is launch-bound (a sweep moves < 1 MB): capture it once into a hipGraph and replay
+        // it, so the host enqueues one graph instead of `iterations` kernels.  The graph is keyed by every
+        // value baked into its kernel arguments.
+        ViGraphKey key;
+        memset(&key, 0, sizeof(key));
+        key.model = m; key.T = m->T; key.R = m->R; key.term = m->term; key.Vb = Vb; key.notclose = notclose;
+        key.iterations = iterations; key.M = M; key.S = S; key.A = A; key.robust = robust; key.vform = vform;
+        key.gamma = gamma; key.rtol = rtol; key.atol = atol;
+        const bool use_graph = iterations >= 8 && !getenv("MP_VI_NO_GRAPH");
         MP_TRY(kernels_begin(ctx));
-        for (int k = 0; k < iterations; ++k) {
-            a.k = k;
-            a.Vprev = Vb + (long)((k + 2) % 3) * S;
-            a.Vcur = Vb + (long)(k % 3) * S;
-            a.Vnext = Vb + (long)((k + 1) % 3) * S;
-            hipLaunchKernelGGL(vi_det_sweep, dim3(gs), dim3(256), 0, st, a);
-            ++launches;
+        if (use_graph) {
+            if (!ctx->vi_graph_exec || memcmp(&ctx->vi_graph_key, &key, sizeof(key)) != 0) {
+                if (ctx->vi_graph_exec) {
+                    MP_HIP(hipGraphExecDestroy((hipGraphExec_t)ctx->vi_graph_exec));
+                    ctx->vi_graph_exec = nullptr;
+                }
+                hipGraph_t graph = nullptr;
+                MP_HIP(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                for (int k = 0; k < iterations; ++k) {
+                    a.k = k;
+                    a.Vprev = Vb + (long)((k + 2) % 3) * S;
+                    a.Vcur = Vb + (long)(k % 3) * S;
+                    a.Vnext = Vb + (long)((k + 1) % 3) * S;
+                    vi_det_launch(a, st);
+                }
+                MP_HIP(hipStreamEndCapture(st, &graph));
+                hipGraphExec_t exec = nullptr;
+                MP_HIP(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+                MP_HIP(hipGraphDestroy(graph));
+                ctx->vi_graph_exec = exec;
+                memcpy(&ctx->vi_graph_key, &key, sizeof(key));
+            }
+            MP_HIP(hipGraphLaunch((hipGraphExec_t)ctx->vi_graph_exec, st));
+            launches = iterations;
+        } else {
+            for (int k = 0; k < iterations; ++k) {
+                a.k = k;
+                a.Vprev = Vb + (long)((k + 2) % 3) * S;
+                a.Vcur = Vb + (long)(k % 3) * S;
+                a.Vnext = Vb + (long)((k + 1) % 3) * S;
+                vi_det_launch(a, st);
+                ++launches;
+            }
         }
         MP_TRY(kernels_end(ctx, launches));
+        a.k = 0;
         hipLaunchKernelGGL(vi_find_stop, dim3(1), dim3(64), 0, st, iterations, notclose, result);
         ViEmitArgs e;
         e.d = a; e.Vbuf = Vb; e.result = result; e.Q_out = dQ; e.V_out = dV; e.sweeps_out = dSw;
