@@ -154,8 +154,22 @@ def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.
                 env_steps=steps.value, rng_after=rng, tree=tree)
 
 
+CARTPOLE_KEYS = ("gravity", "masscart", "masspole", "length", "force_mag", "tau", "theta_threshold", "x_threshold")
+
+
+def cartpole_params(params):
+    """dict (rl_agents_amd.envs.CartPoleEnv.cartpole_params()) -> (8 doubles, max_steps)."""
+    return np.array([params[k] for k in CARTPOLE_KEYS], dtype=np.float64), int(params.get("max_steps", 0))
+
+
 def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
-             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64):
+             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64, cartpole=None):
+    """One root. Table env: transition/reward/terminal + integer s0. CartPole: cartpole=params dict, s0 = 4 doubles."""
+    cp = x0 = None
+    if cartpole is not None:
+        cp, max_steps = cartpole_params(cartpole)
+        x0 = _f64(s0).reshape(4)
+        transition, reward, terminal, s0 = np.zeros((1, 2), np.int64), np.zeros((1, 2)), np.zeros(1, np.uint8), 0
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
     cap = 1 + episodes * a
@@ -172,14 +186,22 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
                             _p(cdf, C.c_double), _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32),
                             C.byref(plan_len), C.byref(steps), _p(tree["parent"], C.c_int32),
                             _p(tree["action"], C.c_int32), _p(tree["count"], C.c_int64),
-                            _p(tree["value"], C.c_double), _p(tree["first_child"], C.c_int32), C.byref(nn))
+                            _p(tree["value"], C.c_double), _p(tree["first_child"], C.c_int32), C.byref(nn),
+                            _p(cp, C.c_double), _p(x0, C.c_double))
     assert rc == 0, rc
     tree = {k: v[:nn.value].copy() for k, v in tree.items()}
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, tree=tree)
 
 
 def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
-                   rng_states, steps0=None, max_steps=0, done_rule="source", max_plan_len=16, n_threads=1):
+                   rng_states, steps0=None, max_steps=0, done_rule="source", max_plan_len=16, n_threads=1,
+                   cartpole=None):
+    cp = x0 = None
+    if cartpole is not None:
+        cp, max_steps = cartpole_params(cartpole)
+        x0 = _f64(s0).reshape(-1, 4)
+        transition, reward, terminal = np.zeros((1, 2), np.int64), np.zeros((1, 2)), np.zeros(1, np.uint8)
+        s0 = np.zeros(len(x0), np.int32)
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
     s0 = np.ascontiguousarray(s0, dtype=np.int32)
@@ -198,7 +220,8 @@ def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, t
                                   int(episodes), int(horizon), C.c_double(gamma), C.c_double(temperature),
                                   _p(prior, C.c_double), _p(cdf, C.c_double), _p(rng, C.c_uint64), max_plan_len,
                                   _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(root_value, C.c_double),
-                                  _p(cc, C.c_int64), _p(cv, C.c_double), _p(steps, C.c_int64), int(n_threads))
+                                  _p(cc, C.c_int64), _p(cv, C.c_double), _p(steps, C.c_int64), int(n_threads),
+                                  _p(cp, C.c_double), _p(x0, C.c_double))
     assert rc == 0, rc
     return dict(plans=plans, plan_len=plan_len, root_value=root_value, root_child_count=cc,
                 root_child_value=cv, env_steps=steps, rng_after=rng)

@@ -274,7 +274,35 @@ typedef struct {
     const uint8_t *term; /* [S]   */
     int done_on_next;    /* 0: terminated = term[s] (default), 1: term[s'] */
     int max_steps;       /* 0 = no truncation */
+    /* closed-form CartPole clone (rl_agents_amd/envs/cartpole.py restates gymnasium's CartPole, absent here):
+     * cp = {gravity, masscart, masspole, length, force_mag, tau, theta_threshold, x_threshold}, NULL = table env */
+    const double *cp;
 } orc_env;
+
+/* rl_agents_amd/envs/cartpole.py step(), operation for operation (Python floats, libm sin/cos) */
+static inline void orc_cartpole_step(const orc_env *e, double *x4, int32_t *steps, int a, double *reward,
+                                     int *terminated, int *truncated)
+{
+    const double gravity = e->cp[0], masscart = e->cp[1], masspole = e->cp[2], length = e->cp[3];
+    const double force_mag = e->cp[4], tau = e->cp[5], theta_thr = e->cp[6], x_thr = e->cp[7];
+    const double total_mass = masspole + masscart, polemass_length = masspole * length;
+    double x = x4[0], x_dot = x4[1], theta = x4[2], theta_dot = x4[3];
+    const double force = a == 1 ? force_mag : -force_mag;
+    const double costheta = cos(theta), sintheta = sin(theta);
+    const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
+    const double thetaacc = (gravity * sintheta - costheta * temp) /
+                            (length * (4.0 / 3.0 - masspole * (costheta * costheta) / total_mass));
+    const double xacc = temp - polemass_length * thetaacc * costheta / total_mass;
+    x = x + tau * x_dot;
+    x_dot = x_dot + tau * xacc;
+    theta = theta + tau * theta_dot;
+    theta_dot = theta_dot + tau * thetaacc;
+    x4[0] = x; x4[1] = x_dot; x4[2] = theta; x4[3] = theta_dot;
+    *terminated = x < -x_thr || x > x_thr || theta < -theta_thr || theta > theta_thr;
+    *reward = 1.0; /* a clone is never stepped again after its first termination inside a planner */
+    *steps += 1;
+    *truncated = e->max_steps > 0 && *steps >= e->max_steps;
+}
 
 static inline void orc_env_step(const orc_env *e, int32_t *s, int32_t *steps, int a, double *reward,
                                 int *terminated, int *truncated)
@@ -302,7 +330,7 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
                  int32_t *t_parent, int32_t *t_action, int32_t *t_state, int32_t *t_depth, double *t_reward,
                  double *t_lower, double *t_upper, uint8_t *t_done, int64_t *t_count, int32_t *t_first_child)
 {
-    orc_env env = {S, A, T, R, term, done_on_next, 0};
+    orc_env env = {S, A, T, R, term, done_on_next, 0, NULL};
     const int K = budget / A; /* deterministic.py:118 */
     const int cap = 1 + K * A;
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
@@ -419,9 +447,11 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
                  int max_plan_len, int32_t *plan, int32_t *plan_len, int64_t *env_steps,
                  /* optional tree export, capacity 1 + episodes*A */
                  int32_t *t_parent, int32_t *t_action, int64_t *t_count, double *t_value,
-                 int32_t *t_first_child, int32_t *n_nodes_out)
+                 int32_t *t_first_child, int32_t *n_nodes_out,
+                 /* CartPole roots: cp = 8 parameters, x0 = root state (4 doubles); NULL, NULL = table env */
+                 const double *cp, const double *x0)
 {
-    orc_env env = {S, A, T, R, term, done_on_next, max_steps};
+    orc_env env = {S, A, T, R, term, done_on_next, max_steps, cp};
     const int cap = 1 + episodes * A;
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
     int32_t *first_child = malloc(cap * sizeof(int32_t));
@@ -438,6 +468,8 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
     int64_t steps_taken = 0;
     for (int ep = 0; ep < episodes; ++ep) { /* mcts.py:179-184 */
         int32_t s = s0, st = steps0;     /* safe_deepcopy_env(state) */
+        double x4[4] = {0, 0, 0, 0};
+        if (cp) memcpy(x4, x0, sizeof(x4));
         int node = 0, depth = 0, terminal = 0, truncated = 0;
         double total_reward = 0;
         /* mcts.py:143-149 selection */
@@ -453,7 +485,8 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
             for (int a = 0; a < A; ++a) if (score[a] == m) ties[nt++] = a; /* abstract.py:296-311 */
             const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
             double r;
-            orc_env_step(&env, &s, &st, a, &r, &terminal, &truncated);
+            if (cp) orc_cartpole_step(&env, x4, &st, a, &r, &terminal, &truncated);
+            else orc_env_step(&env, &s, &st, a, &r, &terminal, &truncated);
             ++steps_taken;
             total_reward += gpow[depth] * r;
             node = fc + a;
@@ -472,7 +505,8 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
             for (int h = depth; h < horizon; ++h) {
                 const int a = orc_cdf_pick(rollout_cdf, A, orc_pcg64_double(&g));
                 double r; int term_h, trunc_h;
-                orc_env_step(&env, &s, &st, a, &r, &term_h, &trunc_h);
+                if (cp) orc_cartpole_step(&env, x4, &st, a, &r, &term_h, &trunc_h);
+                else orc_env_step(&env, &s, &st, a, &r, &term_h, &trunc_h);
                 ++steps_taken;
                 total_reward += gpow[h] * r;
                 if (term_h || trunc_h) break;
@@ -525,7 +559,8 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
                        const double *rollout_cdf, uint64_t *rng6 /* [n_roots,6] */, int max_plan_len,
                        int32_t *plans /* [n_roots,max_plan_len] */, int32_t *plan_len, double *root_value,
                        int64_t *root_child_count /* [n_roots,A] */, double *root_child_value /* [n_roots,A] */,
-                       int64_t *env_steps /* [n_roots] */, int n_threads)
+                       int64_t *env_steps /* [n_roots] */, int n_threads,
+                       const double *cp, const double *x0 /* [n_roots,4] or NULL */)
 {
     int rc_all = ORC_OK;
     const int cap = 1 + episodes * A;
@@ -534,10 +569,11 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
         int64_t *cnt = malloc(cap * sizeof(int64_t));
         double *val = malloc(cap * sizeof(double));
         int32_t nn = 0;
-        int rc = orc_uct_plan(S, A, T, R, term, done_on_next, max_steps, s0[i], steps0 ? steps0[i] : 0, episodes,
+        int rc = orc_uct_plan(S, A, T, R, term, done_on_next, max_steps, s0 ? s0[i] : 0, steps0 ? steps0[i] : 0, episodes,
                               horizon, gamma, temperature, prior, rollout_cdf, rng6 + (long)i * 6, max_plan_len,
                               plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
-                              env_steps ? env_steps + i : NULL, NULL, NULL, cnt, val, NULL, &nn);
+                              env_steps ? env_steps + i : NULL, NULL, NULL, cnt, val, NULL, &nn, cp,
+                              x0 ? x0 + (long)i * 4 : NULL);
         if (rc != ORC_OK) {
 #pragma omp critical
             rc_all = rc;

@@ -168,7 +168,13 @@ class AbstractPlanner(Configurable):
         raise NotImplementedError()
 
     # -------------------------------------------------------------------------------------------------
+    supports_cartpole = False
+
     def model_for(self, state):
+        if device_model.is_cartpole(state):
+            if not self.supports_cartpole:
+                raise TypeError("this planner needs a finite-MDP environment")
+            return self.models.get_cartpole(getattr(state, "unwrapped", state).cartpole_params())
         mdp = device_model.finite_mdp_of(state)
         if mdp.mode != "deterministic":
             raise TypeError("tree search on the device needs a deterministic finite MDP, got mode '{}'".format(mdp.mode))

@@ -36,7 +36,8 @@ def policy_probabilities(policy_config, n_actions):
 
 
 class MCTS(AbstractPlanner):
-    """UCT planner (mcts.py:100-200) for one or many roots of one finite MDP."""
+    """UCT planner (mcts.py:100-200) for one or many roots of one finite MDP (or closed-form CartPole)."""
+    supports_cartpole = True
 
     def __init__(self, env, prior_policy, rollout_policy, config=None):
         super(MCTS, self).__init__(config)

@@ -218,6 +218,13 @@ class Context(object):
         _check(self._lib.mp_model_load_sparse(self._h, s, a, b, _ptr(t), _ptr(n), _ptr(r), _ptr(term), C.byref(h)))
         return Model(self, h, MODE_SPARSE, 1, s, a, b)
 
+    def load_cartpole(self, params):
+        """Closed-form CartPole model from ``CartPoleEnv.cartpole_params()`` (dict)."""
+        cp = CartPoleParams(**{k: params[k] for k, _ in CartPoleParams._fields_})
+        h = _vp()
+        _check(self._lib.mp_model_load_cartpole(self._h, C.addressof(cp), C.byref(h)))
+        return Model(self, h, MODE_CARTPOLE, 1, 0, 2, 0)
+
     # ---- value iteration ---------------------------------------------------------------------
     def vi_solve(self, model, gamma, iterations, robust=False, rtol=1e-5, atol=1e-8):
         """-> (Q [S,A] float64, sweeps run).  value_iteration.py:42-45,65-73 / robust_value_iteration.py:39-58."""
@@ -245,7 +252,10 @@ class Context(object):
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
                  root_steps=None, max_plan_len=None):
         """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place."""
-        rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
+        if model.mode == MODE_CARTPOLE:      # roots are (x, x_dot, theta, theta_dot) rows
+            rs = np.ascontiguousarray(root_state, dtype=np.float64).reshape(-1, 4)
+        else:
+            rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
         n = rs.shape[0]
         st = None if root_steps is None else np.ascontiguousarray(root_steps, dtype=np.int32).reshape(n)
         if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous

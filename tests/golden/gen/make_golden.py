@@ -33,7 +33,7 @@ import numpy as np  # noqa: E402
 
 from rl_agents.agents.common.factory import agent_factory  # noqa: E402
 from rl_agents.agents.tree_search.olop import OLOP  # noqa: E402
-from rl_agents_amd.envs import FiniteMDPEnv, generators  # noqa: E402
+from rl_agents_amd.envs import CartPoleEnv, FiniteMDPEnv, generators  # noqa: E402
 
 CFG = os.path.join(REF, "scripts", "configs", "FiniteMDPEnv")
 VI = "<class 'rl_agents.agents.dynamic_programming.value_iteration.ValueIterationAgent'>"
@@ -327,6 +327,72 @@ def golden_uct():
     return store
 
 
+def golden_uct_cartpole():
+    """MCTS on the restated CartPole (BASELINE config C3): single-root plans with full trees, and the
+    reference's own functional test (tests/agents/tree_search/test_mcts.py:5-19) as a survival count."""
+    store, names = {}, []
+    cases = [
+        # name, reset seed, warm-up steps (random actions) before planning, agent cfg, planner seeds
+        ("b400_t200", 0, 0, dict(budget=400, temperature=200), [0, 1]),
+        ("b1000_h50", 1, 0, dict(budget=1000, horizon=50, episodes=20), [0, 3]),
+        ("b1000_h50_late", 2, 170, dict(budget=1000, horizon=50, episodes=20), [5]),       # TimeLimit inside the horizon
+        ("b300_g095", 3, 12, dict(budget=300, gamma=0.95), [2]),
+        ("b200_pref", 4, 5, dict(budget=200, prior_policy={"type": "preference", "action": 0, "ratio": 2},
+                                  rollout_policy={"type": "preference", "action": 1, "ratio": 4}), [7]),
+    ]
+    for name, reset_seed, warm, agent_cfg, seeds in cases:
+        for seed in seeds:
+            env = CartPoleEnv()
+            env.seed(reset_seed)
+            env.reset()
+            warm_agent = agent_factory(env, dict(__class__=UCT, budget=400, temperature=200))
+            warm_agent.seed(reset_seed + 100)
+            for _ in range(warm):            # the reference planner itself drives the env to a later state
+                _, _, term, trunc, _ = env.step(warm_agent.act(None))
+                assert not term
+            agent = agent_factory(env, dict(agent_cfg, __class__=UCT))
+            agent.seed(seed)
+            st0 = rng_state(agent.planner.np_random)
+            state0, steps0 = np.asarray(env.state, dtype=np.float64), env.steps
+            plan = agent.plan(None)
+            assert np.array_equal(np.asarray(env.state), state0) and env.steps == steps0   # root env untouched
+            root = agent.planner.root
+            tree = bfs_tree(root, [("count", lambda n: n.count, np.int64),
+                                   ("value", lambda n: float(n.value), np.float64)])
+            pc = agent.planner.config
+            _, prior_p = agent.planner.prior_policy(env, None)
+            _, roll_p = agent.planner.rollout_policy(env, None)
+            p = "cartpole/{}_seed{}".format(name, seed)
+            put(store, p, dict(state0=state0, steps0=steps0, seed=seed, budget=pc["budget"], gamma=pc["gamma"],
+                               episodes=pc["episodes"], horizon=pc["horizon"], temperature=pc["temperature"],
+                               prior_p=np.asarray(prior_p, np.float64), rollout_p=np.asarray(roll_p, np.float64),
+                               plan=np.asarray(plan, np.int32), root_count=root.count, root_value=float(root.value),
+                               env_steps=len(agent.planner.observations),
+                               rng_before=st0, rng_after=rng_state(agent.planner.np_random)))
+            put(store, p + "/tree", tree)
+            names.append("{}_seed{}".format(name, seed))
+    store["cartpole/names"] = np.asarray(names)
+    store["cartpole/params"] = np.asarray([CartPoleEnv().cartpole_params()[k] for k in
+                                           ("gravity", "masscart", "masspole", "length", "force_mag", "tau",
+                                            "theta_threshold", "x_threshold", "max_steps", "euler")], dtype=np.float64)
+    # the reference's functional test on this env: budget 400, temperature 200, one full episode
+    env = CartPoleEnv()
+    env.seed(0)
+    obs, _ = env.reset()
+    agent = agent_factory(env, dict(__class__=UCT, budget=400, temperature=200))
+    agent.seed(0)
+    steps, done, actions = 0, False, []
+    while not done:
+        a = agent.act(obs)
+        actions.append(a)
+        obs, _, term, trunc, _ = env.step(a)
+        steps += 1
+        done = term or trunc
+    store["cartpole/episode_steps"] = np.asarray(steps)
+    store["cartpole/episode_actions"] = np.asarray(actions, np.int32)
+    return store
+
+
 # ----------------------------------------------------------------------------- misc pins
 def golden_misc():
     store = {}
@@ -366,7 +432,11 @@ def golden_misc():
 
 def main():
     out = os.path.join(REPO, "tests", "golden")
-    for name, fn in (("vi", golden_vi), ("opd", golden_opd), ("uct", golden_uct), ("misc", golden_misc)):
+    only = sys.argv[1:]
+    for name, fn in (("vi", golden_vi), ("opd", golden_opd), ("uct", golden_uct), ("uct_cartpole", golden_uct_cartpole),
+                     ("misc", golden_misc)):
+        if only and name not in only:
+            continue
         store = fn()
         path = os.path.join(out, name + ".npz")
         np.savez_compressed(path, **store)

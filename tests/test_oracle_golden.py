@@ -153,3 +153,40 @@ def test_uct_batch_equals_single(golden):
         np.testing.assert_array_equal(out["plans"][i, :n], z[q + "/plan"])
         assert out["root_value"][i] == float(z[q + "/root_value"])
         assert out["env_steps"][i] == int(z[q + "/env_steps"])
+
+
+def test_uct_cartpole_all_cases(golden):
+    """The C restatement of UCT on the closed-form CartPole reproduces the reference planner on
+    rl_agents_amd.envs.CartPoleEnv bit for bit (same libm sin/cos as CPython's math module)."""
+    from rl_agents_amd.envs import CartPoleEnv
+    z = golden["uct_cartpole"]
+    params = CartPoleEnv().cartpole_params()
+    np.testing.assert_array_equal(z["cartpole/params"][:8], [params[k] for k in oracle.CARTPOLE_KEYS])
+    for name in [str(n) for n in z["cartpole/names"]]:
+        p = "cartpole/" + name
+        out = oracle.uct_plan(None, None, None, z[p + "/state0"], int(z[p + "/episodes"]), int(z[p + "/horizon"]),
+                              float(z[p + "/gamma"]), float(z[p + "/temperature"]), z[p + "/prior_p"],
+                              z[p + "/rollout_p"], z[p + "/rng_before"], steps0=int(z[p + "/steps0"]),
+                              cartpole=params)
+        np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+        assert out["tree"]["value"][0] == float(z[p + "/root_value"])
+        assert_tree_equal(z, p + "/tree", out["tree"], 2, dict(count="count", value="value"))
+
+
+def test_cartpole_env_matches_golden_episode(golden):
+    """The restated env + the recorded reference actions replay to the recorded 200-step survival."""
+    from rl_agents_amd.envs import CartPoleEnv
+    z = golden["uct_cartpole"]
+    env = CartPoleEnv()
+    env.seed(0)
+    env.reset()
+    steps, done = 0, False
+    for a in z["cartpole/episode_actions"]:
+        _, _, term, trunc, _ = env.step(int(a))
+        steps += 1
+        done = term or trunc
+        if done:
+            break
+    assert steps == int(z["cartpole/episode_steps"]) == 200 and not term
