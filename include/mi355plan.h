@@ -86,6 +86,14 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
  */
 int mp_model_load_dense(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const double *transition,
                         const double *reward, const uint8_t *terminal, int32_t mem, mp_model **out);
+/*
+ * A block of source-state rows of a dense model, for value iteration sharded over GPUs: this
+ * rank owns rows [row0, row0 + S_rows) of every model, i.e. transition double [M,S_rows,A,S_cols] (S_cols = |S|),
+ * reward double [M,S_rows,A], terminal uint8 [S_rows] (flags of the owned rows) or NULL.  Use with mp_vi_backup.
+ */
+int mp_model_load_dense_rows(mp_ctx *ctx, int32_t M, int32_t S_rows, int32_t A, int32_t S_cols,
+                             const double *transition, const double *reward, const uint8_t *terminal, int32_t mem,
+                             mp_model **out);
 /* Sparse model (value_iteration.py:56-59): transition double [S,A,B], next int64 [S,A,B]. */
 int mp_model_load_sparse(mp_ctx *ctx, int32_t S, int32_t A, int32_t B, const double *transition,
                          const int64_t *next, const double *reward, const uint8_t *terminal, mp_model **out);
@@ -120,6 +128,12 @@ int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, 
 /* get_state_value (value_iteration.py:37-40): the V-form iteration.  V_out double [S]. */
 int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
                   double *V_out, int32_t mem);
+/*
+ * One Bellman backup of a dense (or row-block) model: Q[rows,A] = min_m (R_m + gamma * mask(T_m . V)), the body of
+ * bellman_expectation (value_iteration.py:54-55,62-63; robust_value_iteration.py:46-58).  V double [S_cols] in,
+ * Q double [S_rows,A] out.  The row-sharded driver (rl_agents_amd/distributed.py) all_gathers V between backups.
+ */
+int mp_vi_backup(mp_ctx *ctx, mp_model *model, double gamma, int32_t robust, const double *V, double *Q, int32_t mem);
 /* Timing hook: run exactly `sweeps` Bellman sweeps (no early exit), Q left on the device. */
 int mp_vi_sweeps(mp_ctx *ctx, mp_model *model, double gamma, int32_t sweeps, int32_t robust);
 

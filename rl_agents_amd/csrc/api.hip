@@ -220,7 +220,7 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
     }
     MP_HIP(hipSetDevice(ctx->device));
     mp_model *m = new mp_model();
-    m->ctx = ctx; m->mode = MP_MODE_DETERMINISTIC; m->M = M; m->S = S; m->A = A;
+    m->ctx = ctx; m->mode = MP_MODE_DETERMINISTIC; m->M = M; m->S = S; m->A = A; m->Sc = S;
     m->done_on_next = done_on_next ? 1 : 0; m->max_steps = max_steps > 0 ? max_steps : 0;
     auto bail = [&](int rc) { mp_model_free(m); return rc; };
     if (hipMalloc(&m->T, n * sizeof(int32_t)) != hipSuccess || hipMalloc(&m->R, n * sizeof(double)) != hipSuccess ||
@@ -248,13 +248,19 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
 int mp_model_load_dense(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const double *transition,
                         const double *reward, const uint8_t *terminal, int32_t mem, mp_model **out)
 {
+    return mp_model_load_dense_rows(ctx, M, S, A, S, transition, reward, terminal, mem, out);
+}
+
+int mp_model_load_dense_rows(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, int32_t S_cols, const double *transition,
+                             const double *reward, const uint8_t *terminal, int32_t mem, mp_model **out)
+{
     if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_dense: NULL argument");
-    if (M < 1 || S < 1 || A < 1) return fail(MP_ERR_ARG, "mp_model_load_dense: bad shape");
+    if (M < 1 || S < 1 || A < 1 || S_cols < 1) return fail(MP_ERR_ARG, "mp_model_load_dense: bad shape");
     MP_HIP(hipSetDevice(ctx->device));
     mp_model *m = new mp_model();
-    m->ctx = ctx; m->mode = MP_MODE_STOCHASTIC; m->M = M; m->S = S; m->A = A;
+    m->ctx = ctx; m->mode = MP_MODE_STOCHASTIC; m->M = M; m->S = S; m->A = A; m->Sc = S_cols;
     auto bail = [&](int rc) { mp_model_free(m); return rc; };
-    const size_t nr = (size_t)M * S * A, np = nr * S;
+    const size_t nr = (size_t)M * S * A, np = nr * S_cols;
     if (mem == MP_MEM_DEVICE) {
         m->P = transition; m->R = const_cast<double *>(reward); m->term = const_cast<uint8_t *>(terminal);
         m->borrowed = true;
@@ -287,7 +293,7 @@ int mp_model_load_sparse(mp_ctx *ctx, int32_t S, int32_t A, int32_t B, const dou
     }
     MP_HIP(hipSetDevice(ctx->device));
     mp_model *m = new mp_model();
-    m->ctx = ctx; m->mode = MP_MODE_SPARSE; m->M = 1; m->S = S; m->A = A; m->B = B;
+    m->ctx = ctx; m->mode = MP_MODE_SPARSE; m->M = 1; m->S = S; m->A = A; m->B = B; m->Sc = S;
     auto bail = [&](int rc) { mp_model_free(m); return rc; };
     double *p = nullptr;
     if (hipMalloc(&p, n * sizeof(double)) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "hipMalloc failed"));

@@ -87,6 +87,7 @@ struct mp_ctx {
 struct mp_model {
     mp_ctx *ctx = nullptr;
     int mode = 0, M = 1, S = 0, A = 0, B = 0;
+    int Sc = 0; // dense models: number of next-state columns (= S, or the full |S| for a block of rows)
     int done_on_next = 0, max_steps = 0;
     // deterministic tables, device, [M,S,A]
     int32_t *T = nullptr;

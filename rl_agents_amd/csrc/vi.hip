@@ -166,6 +166,7 @@ __global__ __launch_bounds__(256) void vi_det_emit(ViEmitArgs e)
 // ------------------------------------------------------------------ generic (dense / sparse) ---
 struct ViGenArgs {
     int M, S, A, B, robust, vform, k;
+    int Sc; // columns of a dense model (= S unless the model holds a block of source-state rows)
     const double *P;
     const int32_t *NXT;
     const double *R;
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
     double best[4] = {0.0, 0.0, 0.0, 0.0};
     for (int m = 0; m < p.M; ++m) {
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
-        const double *prow = p.P + ((long)m * SA + row) * p.S;
-        for (int c0 = 0; c0 < p.S; c0 += kDenseChunk) {
-            const int ch = min(kDenseChunk, p.S - c0);
+        const double *prow = p.P + ((long)m * SA + row) * p.Sc;
+        for (int c0 = 0; c0 < p.Sc; c0 += kDenseChunk) {
+            const int ch = min(kDenseChunk, p.Sc - c0);
             __syncthreads();
             for (int t = threadIdx.x; t < kDenseChunk; t += 256) vs[t] = t < ch ? p.Vcur[c0 + t] : 0.0;
             __syncthreads();
@@ -335,6 +336,7 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
     if (iterations < 0) return fail(MP_ERR_ARG, "vi: iterations < 0");
     if (m->mode == MP_MODE_CARTPOLE) return fail(MP_ERR_MODE, "vi: the environment must be of type finite_mdp");
     if (robust && m->mode == MP_MODE_SPARSE) return fail(MP_ERR_MODE, "Unknown mode"); // robust_value_iteration.py:57-58
+    if (m->Sc != m->S) return fail(MP_ERR_MODE, "vi: a row-block model can only be used with mp_vi_backup");
     MP_HIP(hipSetDevice(ctx->device));
     const int S = m->S, A = m->A, M = robust ? m->M : 1;
     const long SA = (long)S * A;
@@ -418,7 +420,7 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
         MP_HIP(hipMemsetAsync(Vb, 0, (size_t)2 * S * sizeof(double), st));
         MP_HIP(hipMemsetAsync(Qb, 0, (size_t)2 * SA * sizeof(double), st));
         ViGenArgs a;
-        a.M = M; a.S = S; a.A = A; a.B = m->B; a.robust = robust; a.vform = vform;
+        a.M = M; a.S = S; a.A = A; a.B = m->B; a.robust = robust; a.vform = vform; a.Sc = S;
         a.P = m->P; a.NXT = m->NXT; a.R = m->R; a.term = m->term; a.gamma = gamma; a.rtol = rtol; a.atol = atol;
         a.notclose = notclose;
         const unsigned gq_dense = (unsigned)((SA + 63) / 64), gq_sparse = (unsigned)((SA + 255) / 256);
@@ -450,9 +452,40 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
     return MP_OK;
 }
 
+// One Bellman backup Q = min_m (R_m + gamma * mask(T_m . V)) of a dense (possibly row-block) model.
+static int vi_backup(mp_ctx *ctx, mp_model *m, double gamma, int robust, const double *V, double *Q, int mem)
+{
+    if (!ctx || !m || !V || !Q) return fail(MP_ERR_ARG, "mp_vi_backup: NULL argument");
+    if (m->mode != MP_MODE_STOCHASTIC) return fail(MP_ERR_MODE, "mp_vi_backup: dense models only");
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const long SA = (long)m->S * m->A;
+    double *dV = nullptr, *dQ = nullptr;
+    MP_TRY(stage_in(ctx, WS_IO0, V, (size_t)m->Sc, mem, &dV));
+    MP_TRY(stage_out_alloc(ctx, WS_IO1, Q, (size_t)SA, mem, &dQ));
+    int32_t *flag = nullptr;
+    MP_TRY(ws_get(ctx, WS_VI3, 4, &flag));
+    ViGenArgs a;
+    memset(&a, 0, sizeof(a));
+    a.M = robust ? m->M : 1; a.S = m->S; a.A = m->A; a.Sc = m->Sc; a.robust = robust; a.k = 0;
+    a.P = m->P; a.R = m->R; a.term = m->term; a.gamma = gamma; a.Vcur = dV; a.Qnext = dQ; a.notclose = flag;
+    MP_TRY(kernels_begin(ctx));
+    hipLaunchKernelGGL(vi_dense_q, dim3((unsigned)((SA + 63) / 64)), dim3(256), kDenseChunk * sizeof(double), st, a);
+    MP_TRY(kernels_end(ctx, 1));
+    MP_HIP(hipGetLastError());
+    MP_TRY(stage_out_copy(ctx, Q, dQ, (size_t)SA, mem));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
 } // namespace mp
 
 extern "C" {
+
+int mp_vi_backup(mp_ctx *ctx, mp_model *model, double gamma, int32_t robust, const double *V, double *Q, int32_t mem)
+{
+    return mp::vi_backup(ctx, model, gamma, robust ? 1 : 0, V, Q, mem);
+}
 
 int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
                 int32_t robust, double *Q_out, int32_t *sweeps_out, int32_t mem)

@@ -81,3 +81,47 @@ def plan_batch_sharded(agent, root_states, root_steps=None, device=None, keys=("
             raise RuntimeError("fewer roots than ranks: give every rank at least one root")
         out[k] = all_gather_rows(block, n, device=device)
     return out
+
+
+def vi_solve_row_sharded(ctx, transition, reward, terminal=None, gamma=1.0, iterations=100, robust=False,
+                         rtol=1e-5, atol=1e-8, rows=None):
+    """Dense (robust) value iteration with source-state rows sharded over the process group.
+
+    ``transition``: [S,A,S] or [M,S,A,S] -- either the full array (this rank slices its row block) or, with
+    ``rows=(lo, hi)``, already this rank's block [.., hi-lo, A, S]; same for ``reward`` / ``terminal``.
+    Each sweep: every rank backs up its rows on its GPU (``mp_vi_backup``), takes max_a, and the ranks
+    all_gather V (8*S bytes) -- the one real exchange of the path; the ``allclose`` early exit of
+    value_iteration.py:65-73 becomes an all_reduce(AND) of the per-rank tests.  Returns (Q [S,A], sweeps) on every rank.
+    """
+    rank, world = rank_world()
+    t = np.asarray(transition)
+    r = np.asarray(reward)
+    n_states = t.shape[-1]
+    if rows is None:
+        lo, hi = shard_bounds(n_states, rank, world)
+        t, r = t[..., lo:hi, :, :], r[..., lo:hi, :]
+        term = None if (terminal is None or robust) else np.asarray(terminal).reshape(n_states)[lo:hi]
+    else:
+        lo, hi = rows
+        term = None if (terminal is None or robust) else np.asarray(terminal).reshape(hi - lo)
+    n_actions = r.shape[-1]
+    model = ctx.load_dense_rows(t, r, term)
+    v = np.zeros(n_states)
+    q_local = np.zeros((hi - lo, n_actions))
+    sweeps = 0
+    for _ in range(int(iterations)):
+        q_next = ctx.vi_backup(model, gamma, v, robust=robust)
+        sweeps += 1
+        close = bool(np.allclose(q_local, q_next, rtol=rtol, atol=atol))
+        if world > 1:
+            import torch
+            import torch.distributed as dist
+            flag = torch.tensor([1 if close else 0], dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            close = bool(flag.item())
+        if close:
+            break
+        q_local = q_next
+        v = all_gather_rows(q_local.max(axis=-1), n_states)
+    model.close()
+    return all_gather_rows(q_local, n_states), sweeps

@@ -33,6 +33,8 @@ SIGNATURES = {
     "mp_ctx_device_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i64), P(c_i64), C.c_char_p, c_i32]),
     "mp_model_load_table": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32, P(_vp)]),
     "mp_model_load_dense": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
+    "mp_model_load_dense_rows": (C.c_int, [_vp, c_i32, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
+    "mp_vi_backup": (C.c_int, [_vp, _vp, c_f64, c_i32, _vp, _vp, c_i32]),
     "mp_model_load_sparse": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, _vp, P(_vp)]),
     "mp_model_load_cartpole": (C.c_int, [_vp, _vp, P(_vp)]),
     "mp_model_free": (C.c_int, [_vp]),
@@ -205,6 +207,41 @@ class Context(object):
         mod = Model(self, h, MODE_STOCHASTIC, m, s, a, 0)
         mod._keep = keep
         return mod
+
+    def load_dense_rows(self, transition, reward, terminal=None):
+        """Row block of a dense model: transition [S_rows,A,S] or [M,S_rows,A,S] (numpy copied / torch borrowed),
+        reward [..,S_rows,A], terminal [S_rows] flags of the owned rows."""
+        on_device = hasattr(transition, "data_ptr")
+        if on_device:
+            t, r, term = transition, reward, terminal
+            shape = tuple(t.shape)
+            keep = (t, r, term)
+        else:
+            t = np.ascontiguousarray(transition, dtype=np.float64)
+            r = np.ascontiguousarray(reward, dtype=np.float64)
+            shape = t.shape
+            term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).astype(np.uint8))
+            keep = None
+        m = 1 if len(shape) == 3 else shape[0]
+        rows, a, cols = shape[-3], shape[-2], shape[-1]
+        h = _vp()
+        _check(self._lib.mp_model_load_dense_rows(self._h, m, rows, a, cols, _ptr(t), _ptr(r), _ptr(term),
+                                                  MP_MEM_DEVICE if on_device else MP_MEM_HOST, C.byref(h)))
+        mod = Model(self, h, MODE_STOCHASTIC, m, rows, a, 0)
+        mod.S_cols = cols
+        mod._keep = keep
+        return mod
+
+    def vi_backup(self, model, gamma, v, q_out=None, robust=False):
+        """One Bellman backup of a dense / row-block model. numpy in -> numpy out; torch tensors -> enqueued only."""
+        if hasattr(v, "data_ptr"):
+            _check(self._lib.mp_vi_backup(self._h, model._h, float(gamma), int(bool(robust)), _ptr(v), _ptr(q_out),
+                                          MP_MEM_DEVICE))
+            return q_out
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        q = np.zeros((model.S, model.A), dtype=np.float64) if q_out is None else q_out
+        _check(self._lib.mp_vi_backup(self._h, model._h, float(gamma), int(bool(robust)), _ptr(v), _ptr(q), MP_MEM_HOST))
+        return q
 
     def load_sparse(self, transition, next_states, reward, terminal=None):
         t = np.ascontiguousarray(transition, dtype=np.float64)

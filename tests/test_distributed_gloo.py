@@ -82,3 +82,64 @@ def test_sharded_plans_equal_unsharded(n_roots):
     single = plan_batch_sharded(FakeAgent(cfg), np.arange(n_roots, dtype=np.int32) % 120)   # world size 1
     for k in ("plans", "plan_len", "env_steps", "root_value"):
         assert np.array_equal(sharded[k], single[k]), k
+
+
+class NumpyBackupCtx(object):
+    """Stands in for the device context of the row-sharded VI driver: same load_dense_rows / vi_backup contract."""
+
+    class Block(object):
+        def __init__(self, t, r, term):
+            self.t, self.r, self.term = np.asarray(t), np.asarray(r), term
+
+        def close(self):
+            pass
+
+    def load_dense_rows(self, t, r, term=None):
+        return self.Block(t, r, term)
+
+    def vi_backup(self, model, gamma, v, robust=False):
+        nv = (model.t * v.reshape((1,) * (model.t.ndim - 1) + (-1,))).sum(axis=-1)
+        if robust:
+            return (model.r + gamma * nv).min(axis=0)
+        if model.term is not None:
+            nv[np.asarray(model.term, bool)] = 0
+        return model.r + gamma * nv
+
+
+def _vi_worker(rank, world, port, queue):
+    sys.path.insert(0, REPO)
+    import torch.distributed as dist
+    from rl_agents_amd.distributed import vi_solve_row_sharded
+    from rl_agents_amd.envs import generators
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{}".format(port), rank=rank, world_size=world)
+    try:
+        cfg = generators.random_stochastic(57, 3, seed=2, terminal_rate=0.1)
+        q, sweeps = vi_solve_row_sharded(NumpyBackupCtx(), cfg["transition"], cfg["reward"], cfg["terminal"],
+                                         gamma=0.9, iterations=200)
+        if rank == 0:
+            queue.put((q, sweeps))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_value_iteration_matches_reference_semantics():
+    """World size 2: per-sweep all_gather of V + all_reduce of the allclose test reproduce the reference's
+    fixed_point_iteration (value_iteration.py:65-73), i.e. the oracle's Q and sweep count."""
+    import torch.multiprocessing as mp
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    ctx = mp.get_context("spawn")
+    queue = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_vi_worker, args=(r, 2, port, queue)) for r in range(2)]
+    for p in procs:
+        p.start()
+    q, sweeps = queue.get()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    cfg = generators.random_stochastic(57, 3, seed=2, terminal_rate=0.1)
+    q_ref, sweeps_ref = oracle.vi_solve("stochastic", cfg["transition"], cfg["reward"], cfg["terminal"], gamma=0.9,
+                                        iterations=200)
+    assert sweeps == sweeps_ref
+    np.testing.assert_allclose(q, q_ref, rtol=1e-13, atol=1e-13)

@@ -208,3 +208,31 @@ def test_vi_properties_at_scale(ctx):
     model2 = ctx.load_dense(cfg["transition"], cfg["reward"] + 0.1, None)
     q2, _ = ctx.vi_solve(model2, 0.9, 400, rtol=0.0, atol=1e-13)
     np.testing.assert_allclose(q2 - q, 0.1 / (1 - 0.9), rtol=1e-9)   # constant reward shift -> shift / (1 - gamma)
+
+
+def test_row_block_backup_and_sharded_driver_world1(ctx):
+    """mp_vi_backup on row blocks reassembles the full backup; the sharded driver at world size 1 returns
+    exactly what mp_vi_solve returns (same kernel, same order)."""
+    from rl_agents_amd.distributed import vi_solve_row_sharded
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_stochastic(301, 3, seed=5, terminal_rate=0.1)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    full = ctx.load_dense(t, r, term)
+    v = np.random.Generator(np.random.PCG64(1)).random(301)
+    q_full = ctx.vi_backup(full, 0.9, v)
+    parts = []
+    for lo, hi in ((0, 100), (100, 101), (101, 301)):
+        blk = ctx.load_dense_rows(t[lo:hi], r[lo:hi], term[lo:hi])
+        parts.append(ctx.vi_backup(blk, 0.9, v))
+    assert np.array_equal(np.concatenate(parts), q_full)
+    np.testing.assert_allclose(q_full, r + 0.9 * np.where(term[:, None], 0.0, t @ v), rtol=1e-13)
+    q, sweeps = ctx.vi_solve(full, 0.9, 80)
+    q2, sweeps2 = vi_solve_row_sharded(ctx, t, r, term, gamma=0.9, iterations=80)
+    assert sweeps == sweeps2 and np.array_equal(q, q2)
+    # robust pair
+    cfg2 = generators.random_stochastic(301, 3, seed=6)
+    tt, rr = np.stack([t, cfg2["transition"]]), np.stack([r, cfg2["reward"]])
+    both = ctx.load_dense(tt, rr)
+    qr, sr = ctx.vi_solve(both, 0.9, 60, robust=True)
+    qr2, sr2 = vi_solve_row_sharded(ctx, tt, rr, None, gamma=0.9, iterations=60, robust=True)
+    assert sr == sr2 and np.array_equal(qr, qr2)
