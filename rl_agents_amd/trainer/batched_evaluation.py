@@ -1,0 +1,79 @@
+"""Batched evaluation: N episodes advanced in lock-step, one batched ``plan`` call per step.
+
+The reference evaluates one environment per process (``Evaluation.run_episodes``,
+``rl_agents/trainer/evaluation.py:139-194``; ``scripts/experiments.py:102-106`` fans processes out).  With a
+device planner the natural caller is the opposite: many episodes of one finite MDP side by side, their current
+states being the roots of a single launch.  Per step, for every live episode i:
+
+    actions = agent.plan(observation)        (evaluation.py:168)   ->  one row of planner.plan_batch(...)
+    env.step(actions[0])                     (evaluation.py:180)   ->  a table lookup, vectorised over episodes
+
+Episode i draws from its own PCG64 stream -- the one a sequential ``Evaluation`` would give a fresh agent
+seeded with ``seed + i`` (evaluation.py:375 seeds the agent with ``sim_seed + episode``) -- and the stream
+continues from step to step exactly as ``planner.np_random`` does, so a batched run reproduces N sequential
+runs action for action (tests/test_gpu_agents.py).
+"""
+import time
+
+import numpy as np
+
+from rl_agents_amd import device_model, native
+from rl_agents_amd.agents.common.factory import preprocess_env
+from rl_agents_amd.agents.tree_search.abstract import np_random
+
+
+class BatchedEvaluation(object):
+    def __init__(self, env, agent, num_episodes=64, sim_seed=0, max_steps=None):
+        """``env``: a finite-MDP environment (template of every episode); ``agent``: a tree-search agent of this
+        package built on it.  ``max_steps``: episode length cap (defaults to the env's ``max_steps``, else 100)."""
+        self.env, self.agent = env, agent
+        self.num_episodes = int(num_episodes)
+        self.sim_seed = sim_seed
+        mdp = device_model.finite_mdp_of(env)
+        if mdp.mode != "deterministic":
+            raise TypeError("batched evaluation steps a deterministic finite MDP")
+        self.transition = np.asarray(mdp.transition)
+        self.reward = np.asarray(mdp.reward)
+        self.terminal = np.asarray(mdp.terminal, dtype=bool)
+        self.done_rule = getattr(mdp, "done_rule", "source")
+        self.initial_state = int(getattr(getattr(env, "unwrapped", env), "config", {}).get("state", mdp.state))
+        self.max_steps = int(max_steps or device_model.env_max_steps(env) or 100)
+
+    def run(self, initial_states=None):
+        """Run all episodes to termination / truncation. Returns dict(returns, lengths, actions, fps, plan_seconds)."""
+        n = self.num_episodes
+        planner = self.agent.planner
+        states = (np.full(n, self.initial_state, dtype=np.int32) if initial_states is None
+                  else np.asarray(initial_states, dtype=np.int32).copy())
+        steps = np.zeros(n, dtype=np.int32)
+        alive = np.ones(n, dtype=bool)
+        returns = np.zeros(n)
+        gamma_returns = np.zeros(n)
+        gamma = float(self.agent.config.get("gamma", 1))
+        rng = np.stack([native.rng_state_from_generator(np_random(self.sim_seed + i)[0]) for i in range(n)])
+        actions_log = np.full((n, self.max_steps), -1, dtype=np.int32)
+        env = preprocess_env(self.env, self.agent.config["env_preprocessors"])
+        t0, plan_seconds, env_steps = time.perf_counter(), 0.0, 0
+        while alive.any():
+            idx = np.flatnonzero(alive)
+            sub_rng = np.ascontiguousarray(rng[idx])
+            t1 = time.perf_counter()
+            out = planner.plan_batch(env, states[idx], steps[idx], rng_states=sub_rng)
+            plan_seconds += time.perf_counter() - t1
+            rng[idx] = sub_rng
+            act = out["plans"][:, 0].astype(np.int64)
+            act[act < 0] = 0                                   # an empty plan (budget < |A|) falls back to action 0
+            s = states[idx]
+            r = self.reward[s, act]
+            s_next = self.transition[s, act].astype(np.int32)
+            done = self.terminal[s] if self.done_rule == "source" else self.terminal[s_next]
+            actions_log[idx, steps[idx]] = act
+            gamma_returns[idx] += r * gamma ** steps[idx]
+            returns[idx] += r
+            states[idx] = s_next
+            steps[idx] += 1
+            env_steps += len(idx)
+            alive[idx] = ~(done | (steps[idx] >= self.max_steps))
+        wall = time.perf_counter() - t0
+        return dict(returns=returns, discounted_returns=gamma_returns, lengths=steps.copy(), actions=actions_log,
+                    fps=env_steps / wall, plan_seconds=plan_seconds, planner_env_steps=planner.env_steps)

@@ -157,3 +157,30 @@ def test_plan_batch_api(golden):
     again = MCTSAgent(env, dict(budget=1000, horizon=30, episodes=33))
     again.seed(3)
     np.testing.assert_array_equal(again.plan_batch(np.arange(512) * 7 % 10000)["plans"], out["plans"])
+
+
+def test_batched_evaluation_equals_sequential_episodes():
+    """N lock-step episodes (one batched plan per step) reproduce N sequential agent/env loops action for action."""
+    from rl_agents_amd.agents.tree_search.mcts import MCTSAgent
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    cfg = dict(generators.highway_shaped(3, 4, 10, seed=3), state=2, max_steps=9)
+    env = FiniteMDPEnv(cfg)
+    env.reset()
+    agent_cfg = dict(budget=120, gamma=0.9)
+    out = BatchedEvaluation(env, MCTSAgent(env, dict(agent_cfg)), num_episodes=6, sim_seed=40).run()
+    for i in range(6):
+        e = FiniteMDPEnv(cfg)
+        e.reset()
+        agent = MCTSAgent(e, dict(agent_cfg))
+        agent.seed(40 + i)
+        actions, total, done = [], 0.0, False
+        while not done:
+            a = agent.act(e.mdp.state)
+            _, r, term, trunc, _ = e.step(a)
+            actions.append(a)
+            total += r
+            done = term or trunc
+        assert out["lengths"][i] == len(actions)
+        np.testing.assert_array_equal(out["actions"][i, :len(actions)], actions)
+        assert out["returns"][i] == pytest.approx(total, abs=1e-12)
