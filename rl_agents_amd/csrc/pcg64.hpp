@@ -34,12 +34,23 @@ struct Pcg64 {
     }
     __device__ __forceinline__ uint64_t next64()
     {
-        const uint64_t m_hi = 0x2360ED051FC65DA4ULL, m_lo = 0x4385DF649FCCF645ULL;
-        // (s_hi:s_lo) * (m_hi:m_lo) mod 2^128
-        uint64_t lo = s_lo * m_lo;
-        uint64_t hi = __umul64hi(s_lo, m_lo) + s_hi * m_lo + s_lo * m_hi;
-        // + inc with carry
-        uint64_t lo2 = lo + inc_lo;
+        // state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), schoolbook on 32-bit limbs:
+        // the 6 partial products that feed carries as 32x32+64 multiply-adds, the 4 of the top limb as
+        // low-half multiplies -- 10 multiplies (the generic 64-bit formulation compiles to 18).
+        const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
+        const uint32_t a0 = (uint32_t)s_lo, a1 = (uint32_t)(s_lo >> 32), a2 = (uint32_t)s_hi, a3 = (uint32_t)(s_hi >> 32);
+        const uint64_t c0 = (uint64_t)a0 * m0;
+        const uint64_t t1 = (uint64_t)a0 * m1 + (c0 >> 32);
+        const uint64_t u1 = (uint64_t)a1 * m0 + (uint32_t)t1;
+        const uint64_t k2 = (t1 >> 32) + (u1 >> 32);
+        const uint64_t v2 = (uint64_t)a0 * m2 + k2;
+        const uint64_t w2 = (uint64_t)a1 * m1 + (uint32_t)v2;
+        const uint64_t x2 = (uint64_t)a2 * m0 + (uint32_t)w2;
+        const uint32_t k3 = (uint32_t)(v2 >> 32) + (uint32_t)(w2 >> 32) + (uint32_t)(x2 >> 32);
+        const uint32_t r3 = a0 * m3 + a1 * m2 + a2 * m1 + a3 * m0 + k3;
+        const uint64_t lo = (uint64_t)(uint32_t)c0 | ((uint64_t)(uint32_t)u1 << 32);
+        uint64_t hi = (uint64_t)(uint32_t)x2 | ((uint64_t)r3 << 32);
+        const uint64_t lo2 = lo + inc_lo;
         hi += inc_hi + (lo2 < lo ? 1ULL : 0ULL);
         s_hi = hi; s_lo = lo2;
         const uint64_t x = hi ^ lo2;

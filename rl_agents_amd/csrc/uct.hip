@@ -26,6 +26,7 @@
 //           is a pipelined read-modify-write over known addresses, not a parent-pointer chase.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <vector>
 
@@ -51,7 +52,7 @@ struct UctArgs {
     const int32_t *root_state, *root_steps;
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
-    const double *tab; // gpow[H+1] | cdf[A] | rcp[E+1] | tpdiv[A][E+2]
+    const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | rcp[E+1] | tpdiv[A][E+2]
     uint64_t *rng;
     UctNode *tree;
     int32_t *plans, *plan_len;
@@ -95,8 +96,10 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
     const int A = AT > 0 ? AT : p.A, H = p.horizon, E = p.episodes;
     const int nthreads = p.waves * 64;
     double *gpow = lds_d;                   // [H + 1]  gamma ** h
-    double *cdf = gpow + (H + 1);           // [A]      rollout cdf
-    double *rcp = cdf + A;                  // [E + 1]  1.0 / n
+    // rollout policy as integer thresholds: u = k * 2^-53 with k = next64 >> 11, and
+    // searchsorted(cdf, u, 'right') = #{a : cdf[a] <= u} = #{a : ceil(cdf[a] * 2^53) <= k}
+    const uint64_t *thr = reinterpret_cast<const uint64_t *>(gpow + (H + 1)); // [A]
+    double *rcp = gpow + (H + 1) + A;       // [E + 1]  1.0 / n
     double *tpdiv = rcp + (E + 1);          // [A][E+2] temperature * |A| * prior[a] / n
     const int ntab = (H + 1) + A + (E + 1) + A * (E + 2);
     int32_t *path_all = reinterpret_cast<int32_t *>(lds_d + ntab); // [H + 1][waves * 64]
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
         tree[0] = n;
     }
     int n_nodes = 1;
-    int64_t steps_taken = 0;
+    int steps_taken = 0;
     constexpr int AR = AT > 0 ? AT : 1;
 
 #ifdef MP_PROFILE
@@ -243,108 +246,71 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
             n_nodes += A;
         }
         PROF_T(c2);
-        // ---- rollout, mcts.py:156-157 / 160-177
+        // ---- rollout, mcts.py:156-157 / 160-177.  Two steps per trip over two generator copies (ga, gb):
+        // step "a" consumes the draw in `u`, advances gb = next(ga) speculatively while its lookup is in flight
+        // and commits it only if the rollout continues; step "b" mirrors it.  No register copies per step,
+        // and a rollout that stops leaves the stream exactly where the reference's would be.  In the LDS
+        // variant the reward of a step (HBM/L2, off the state chain) is added one step later, in order.
         if (!terminal && depth < H) {
             int h = depth;
-            double u = g.next_double();
-            if (LDSM) {
-                // two steps per trip so that the reward fetched for step h (HBM/L2, off the state
-                // chain) is added while step h+1's lookup is already in flight; the adds keep the
-                // reference's order (total += gamma**h * r_h for ascending h)
-                double r_a = 0.0, r_b = 0.0, g_a = 0.0, g_b = 0.0;
-                bool have_b = false, pend_a = false;
-                while (true) {
-                    {   // step "a"
-                        int act = 0;
-                        if (AT > 0) {
+            Pcg64 ga = g, gb = g;
+            uint64_t u = ga.next64() >> 11; // the 53 random bits of Generator.random()
+            bool stopped_in_a = true;
+            double r_a = 0.0, r_b = 0.0, g_a = 0.0, g_b = 0.0;
+            bool have_b = false;
+            // one rollout step; returns true when the rollout must stop after it
+            auto step = [&](double &r_mine, double &g_mine, const double r_prev, const double g_prev, bool add_prev,
+                            const Pcg64 &gcur, Pcg64 &gspec, uint64_t &unext) -> bool {
+                // searchsorted(cdf, u, 'right') = #{a : cdf[a] <= u} = #{a : thr[a] <= k}
+                int act = 0;
+                if (AT > 0) {
 #pragma unroll
-                            for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
-                        } else {
-                            for (int a = 0; a < A; ++a) act += cdf[a] <= u ? 1 : 0;
-                        }
-                        const long idx = (long)s * A + act;
-                        const uint32_t e = t16[idx];
-                        r_a = rec[idx].reward;
-                        g_a = gpow[h];
-                        Pcg64 g2 = g;
-                        const double u2 = g2.next_double(); // speculative draw for step h + 1
-                        if (have_b) total += g_b * r_b;
-                        pend_a = true;
-                        const bool next_term = (e & 0x8000u) != 0;
-                        const bool term_h = p.done_on_next ? next_term : cur_term;
-                        cur_term = next_term;
-                        s = (int32_t)(e & 0x7fffu);
-                        ++st; ++steps_taken; ++h;
-#ifdef MP_PROFILE
-                        ++n_roll;
-#endif
-                        if (term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H) break;
-                        g = g2; u = u2;
-                    }
-                    {   // step "b"
-                        int act = 0;
-                        if (AT > 0) {
-#pragma unroll
-                            for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
-                        } else {
-                            for (int a = 0; a < A; ++a) act += cdf[a] <= u ? 1 : 0;
-                        }
-                        const long idx = (long)s * A + act;
-                        const uint32_t e = t16[idx];
-                        r_b = rec[idx].reward;
-                        g_b = gpow[h];
-                        Pcg64 g2 = g;
-                        const double u2 = g2.next_double();
-                        total += g_a * r_a;
-                        pend_a = false; have_b = true;
-                        const bool next_term = (e & 0x8000u) != 0;
-                        const bool term_h = p.done_on_next ? next_term : cur_term;
-                        cur_term = next_term;
-                        s = (int32_t)(e & 0x7fffu);
-                        ++st; ++steps_taken; ++h;
-#ifdef MP_PROFILE
-                        ++n_roll;
-#endif
-                        if (term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H) break;
-                        g = g2; u = u2;
-                    }
+                    for (int a = 0; a < AR; ++a) act += thr[a] <= u ? 1 : 0;
+                } else {
+                    for (int a = 0; a < A; ++a) act += thr[a] <= u ? 1 : 0;
                 }
-                total += pend_a ? g_a * r_a : g_b * r_b;
-            } else {
-                while (true) {
-                    // searchsorted(cdf, u, side='right') on a non-decreasing cdf = #{a : cdf[a] <= u}
-                    int act = 0;
-                    if (AT > 0) {
-#pragma unroll
-                        for (int a = 0; a < AR; ++a) act += cdf[a] <= u ? 1 : 0;
-                    } else {
-                        for (int a = 0; a < A; ++a) act += cdf[a] <= u ? 1 : 0;
-                    }
-                    const double gh = gpow[h];
-                    bool term_h;
-                    double reward;
-                    Pcg64 g2 = g;
-                    double u2;
-                    if (CART) {
-                        term_h = cartpole_step(p.cp, x4, act);
-                        reward = 1.0;
-                        u2 = g2.next_double();
-                    } else {
-                        const Rec rc = rec[(long)s * A + act];
-                        u2 = g2.next_double(); // speculative draw, overlaps the gather
-                        term_h = (rc.flags & done_bit) != 0;
-                        reward = rc.reward;
-                        s = rc.next;
-                    }
-                    ++st; ++steps_taken; ++h;
-                    total += gh * reward;
-#ifdef MP_PROFILE
-                    ++n_roll;
-#endif
-                    if (term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H) break;
-                    g = g2; u = u2;
+                g_mine = gpow[h];
+                bool term_h;
+                if (CART) {
+                    gspec = gcur;
+                    unext = gspec.next64() >> 11;
+                    term_h = cartpole_step(p.cp, x4, act);
+                    total += g_mine * 1.0;
+                } else if (LDSM) {
+                    const long idx = (long)s * A + act;
+                    const uint32_t e = t16[idx];
+                    r_mine = rec[idx].reward;
+                    gspec = gcur;
+                    unext = gspec.next64() >> 11;
+                    if (add_prev) total += g_prev * r_prev;
+                    const bool next_term = (e & 0x8000u) != 0;
+                    term_h = p.done_on_next ? next_term : cur_term;
+                    cur_term = next_term;
+                    s = (int32_t)(e & 0x7fffu);
+                } else {
+                    const Rec rc = rec[(long)s * A + act];
+                    gspec = gcur;
+                    unext = gspec.next64() >> 11; // overlaps the gather
+                    term_h = (rc.flags & done_bit) != 0;
+                    s = rc.next;
+                    total += g_mine * rc.reward;
                 }
+                ++st; ++steps_taken; ++h;
+#ifdef MP_PROFILE
+                ++n_roll;
+#endif
+                return term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H;
+            };
+            while (true) {
+                uint64_t un;
+                if (step(r_a, g_a, r_b, g_b, have_b, ga, gb, un)) { stopped_in_a = true; break; }
+                u = un;
+                have_b = true;
+                if (step(r_b, g_b, r_a, g_a, true, gb, ga, un)) { stopped_in_a = false; break; }
+                u = un;
             }
+            if (LDSM) total += stopped_in_a ? g_a * r_a : g_b * r_b;
+            g = stopped_in_a ? ga : gb; // the generator whose draw was consumed last
         }
         PROF_T(c3);
         // ---- backup, mcts.py:248-265: the same return for every node on the path
@@ -389,7 +355,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
         if (p.plan_len) p.plan_len[r] = len;
     }
     if (p.root_value) p.root_value[r] = tree[0].value;
-    if (p.env_steps) p.env_steps[r] = steps_taken;
+    if (p.env_steps) p.env_steps[r] = (int64_t)steps_taken;
     const int rfc = tree[0].first_child;
     for (int a = 0; a < A; ++a) {
         if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? tree[rfc + a].count : 0;
@@ -457,6 +423,13 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     double acc = 0.0;
     for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }             // numpy cumsum
     for (int a = 0; a < A; ++a) cdf[a] /= acc;                                     // cdf /= cdf[-1]
+    for (int a = 0; a < A; ++a) {
+        // Generator.choice(p=...): idx = searchsorted(cdf, u, 'right') with u = k * 2^-53, k < 2^53 integer;
+        // cdf[a] <= u  <=>  ceil(cdf[a] * 2^53) <= k  (the scaling by 2^53 is exact)
+        const double scaled = ceil(ldexp(cdf[a], 53));
+        const uint64_t t = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
+        memcpy(&cdf[a], &t, sizeof(t));
+    }
     rcp[0] = 0.0;
     for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                         // mcts.py:255  K / count, K = 1
     for (int a = 0; a < A; ++a) {
@@ -474,8 +447,11 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     a.cp = model->cp; a.root_x = nullptr;
 
     // variant and geometry
-    const char *force = getenv("MP_UCT_MODEL"); // "global" / "lds": test hook
-    bool ldsm = !cart && model->t16 != nullptr && !(force && force[0] == 'g');
+    // Measured on MI355X (highway table, 4096 roots): global-record variant 0.338 ms, LDS-table variant 0.376 ms --
+    // the per-step chain is instruction-bound (PCG64's 128-bit multiply), not gather-latency bound, so the
+    // single-gather variant is the default; MP_UCT_MODEL=lds selects the LDS-resident transition table.
+    const char *force = getenv("MP_UCT_MODEL"); // "global" (default) / "lds"
+    bool ldsm = !cart && model->t16 != nullptr && force && force[0] == 'l';
     a.lanes = ldsm ? 64 : uct_lanes_per_wave();
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;

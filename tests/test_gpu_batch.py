@@ -44,19 +44,24 @@ def _cmp_uct(ctx, cfg, n_roots, episodes, horizon, gamma, temperature, prior, ro
     return out
 
 
-def test_uct_batch_highway_headline_shape(ctx):
-    """Headline configuration (highway-shaped S=10 000, A=5, 33 episodes x horizon 30), 1536 ragged roots."""
+@pytest.mark.parametrize("variant", ["global", "lds"])
+def test_uct_batch_highway_headline_shape(ctx, variant, monkeypatch):
+    """Headline configuration (highway-shaped S=10 000, A=5, 33 episodes x horizon 30), 1536 ragged roots,
+    with the model gathered from HBM/L2 records (default) and with the transition table staged in LDS."""
     from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_MODEL", variant)
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     p = np.ones(5) / 5
     out = _cmp_uct(ctx, cfg, 1536 + 17, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=1)
     assert out["env_steps"].max() <= 33 * 30
 
 
+@pytest.mark.parametrize("variant", ["global", "lds"])
 @pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 7, 8, 11])
-def test_uct_batch_action_counts(ctx, n_actions):
-    """Every compile-time |A| specialisation and the generic-|A| kernel."""
+def test_uct_batch_action_counts(ctx, n_actions, variant, monkeypatch):
+    """Every compile-time |A| specialisation and the generic-|A| kernel, both model placements."""
     from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_MODEL", variant)
     cfg = generators.random_deterministic(257, n_actions, seed=n_actions, terminal_rate=0.05)
     p = np.ones(n_actions) / n_actions
     _cmp_uct(ctx, cfg, 200, 25, 9, 0.9, 7.5, p, p, seed=n_actions)
