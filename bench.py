@@ -30,12 +30,33 @@ MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix peak (vendor figure; the gui
 UCT_BYTES_PER_ENV_STEP = 28.0  # (13 H + 16 A d + 24 (d+1) + 24 A) / H at H=30, A=5, d~3
 
 
+def pmc_traffic(workload, kernel_substr, grid_threads):
+    """HBM bytes per launch of one kernel from the committed PMC summary (profiles/*_pmc.json, produced by
+    tools/profile_gpu.sh + tools/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    passes of this same command): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- counters are in KB and, on gfx950, FETCH_SIZE
+    tallies the 128-B requests of 16-B-per-lane loads at 64 B (MI355X_MICROARCH.md §HBM; calibrated here on
+    vi_dense_q's known 4.0 GB stream).  None when no summary for this launch geometry is committed."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
+    if not files:
+        return None
+    try:
+        entry = json.load(open(files[-1])).get(workload, {})
+    except (OSError, ValueError):
+        return None
+    for key, v in entry.items():
+        if kernel_substr in key and key.endswith("grid={}".format(grid_threads)):
+            if "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
+                return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "opd", "vi", "vi_dense"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_cartpole", "opd", "vi", "vi_dense"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -201,7 +222,8 @@ def bench_uct(args, rank, world, local):
             env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots, latency=latency,
             parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
         roofline=dict(bound="hbm", achieved=UCT_BYTES_PER_ENV_STEP * env_steps / (k_ms * 1e-3) / 1e9,
-                      peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, kernel="uct_table_kernel",
+                      peak=HBM_PEAK_GBS, unit="GB/s", traffic=pmc_traffic("uct", "uct_kernel", n_roots),
+                      kernel="uct_kernel<5, ENV_TABLE>",
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=UCT_BYTES_PER_ENV_STEP * env_steps),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
@@ -227,6 +249,80 @@ def bench_uct(args, rank, world, local):
                                           "batch repeated for {:.1f} s, same tables/params".format(n_cpu, cdt),
                                    value_1core=one)
     ctx.synchronize()
+    return res
+
+
+def bench_uct_cartpole(args, rank, world, local):
+    """BASELINE config C3: UCT on closed-form CartPole-v0, budget 1000 as 20 episodes x horizon 50, 4096 roots per GPU."""
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import CartPoleEnv
+    n_roots = args.roots or 4096
+    episodes, horizon, gamma, temperature = 20, 50, 0.8, 2 / (1 - 0.8)
+    params = CartPoleEnv().cartpole_params()
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_cartpole(params)
+    gids = np.arange(rank * n_roots, (rank + 1) * n_roots)
+    x0 = np.random.Generator(np.random.PCG64(0)).uniform(-0.05, 0.05, size=(world * n_roots, 4))[gids]
+    dev = torch.device("cuda", local)
+    d_x0 = torch.from_numpy(np.ascontiguousarray(x0)).to(dev)
+    d_rng = torch.from_numpy(seed_states(gids).view(np.int64)).to(dev)
+    mpl = 8
+    d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
+    d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
+    d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    p = np.ones(2) / 2
+
+    def step():
+        ctx.uct_plan_device(model, n_roots, d_x0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
+                            plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps)
+        d_total.add_(d_steps.sum())
+
+    for _ in range(args.warmup):
+        step()
+    d_total.zero_()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    timed = int(d_total.item())
+    step()
+    k_ms = ctx.last_kernel_ms()[0]
+    env_steps = int(d_steps.sum().item())
+    total = sum_over_ranks(float(timed), world) / args.steps
+    # closed-form env: no model bytes; per root 32 B state in + tree terms (SURVEY.md §8d): 16*A*d + 24*(d+1) + 24*A per episode
+    alg = n_roots * (32.0 + episodes * (16 * 2 * 3 + 24 * 4 + 24 * 2))
+    res = dict(
+        metric="rollout env-steps/sec (UCT plan(), CartPole-v0, budget=1000)", unit="env-steps/s",
+        value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
+        config=dict(workload="uct_cartpole_v0_budget1000_e{}xh{}_roots{}_per_gpu".format(episodes, horizon, n_roots),
+                    n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, episodes=episodes, horizon=horizon,
+                    gamma=gamma, env_steps_per_step=total, plan_ms_per_root=1e3 * dt / args.steps / n_roots,
+                    parallelism="roots sharded over {} GPU(s)".format(world)),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
+                      kernel="uct_kernel<2, ENV_CARTPOLE>", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg,
+                      note="state lives in registers: compute/latency bound by construction"),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = host_cores()
+        n_cpu = 64 * cores
+        xs = np.resize(x0, (n_cpu, 4))
+        cpu_rng = seed_states(np.arange(n_cpu))
+        done, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            o = oracle.uct_plan_batch(None, None, None, xs, episodes, horizon, gamma, temperature, p, p, cpu_rng,
+                                      n_threads=cores, cartpole=params)
+            done += int(o["env_steps"].sum())
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=done / cdt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="oracle/planning_oracle.c uct_plan_batch (CartPole), OpenMP over {} roots "
+                                          "per batch for {:.1f} s".format(n_cpu, cdt))
     return res
 
 
@@ -288,7 +384,8 @@ def bench_opd(args, rank, world, local):
                     n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, budget=budget, gamma=gamma,
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots,
                     parallelism="roots sharded over {} GPU(s)".format(world)),
-        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      traffic=pmc_traffic("opd", "opd_kernel", n_roots * 64),
                       kernel="opd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
@@ -354,7 +451,8 @@ def bench_vi(args, rank, world, local, dense):
                     states=s_, actions=a_, gamma=gamma, ms_per_sweep=1e3 * dt / args.steps / sweeps,
                     parallelism="replicas only ({} GPU(s))".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (per_sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                      traffic=None, kernel=name, kernel_ms=per_sweep_ms, algorithmic_bytes_per_launch=alg),
+                      traffic=pmc_traffic("vi_dense", "vi_dense_q", ((s_ * a_ + 63) // 64) * 256) if dense else None,
+                      kernel=name, kernel_ms=per_sweep_ms, algorithmic_bytes_per_launch=alg),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     if dense:
@@ -384,6 +482,8 @@ def main():
     with torch.cuda.stream(side):
         if args.workload == "uct":
             res = bench_uct(args, rank, world, local)
+        elif args.workload == "uct_cartpole":
+            res = bench_uct_cartpole(args, rank, world, local)
         elif args.workload == "opd":
             res = bench_opd(args, rank, world, local)
         else:

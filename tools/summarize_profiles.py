@@ -23,11 +23,23 @@ def kernel_stats(path, top=8):
 
 
 def pmc(path, counter):
+    """mean counter value per (kernel, grid size): one bench run launches the same kernel on several batch sizes"""
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(path)):
         if row["Counter_Name"] == counter and "mp::" in row["Kernel_Name"]:
-            agg[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+            agg["{} grid={}".format(row["Kernel_Name"], row["Grid_Size"])].append(float(row["Counter_Value"]))
     return {k: (len(v), sum(v) / len(v)) for k, v in agg.items()}
+
+
+def trace_by_grid(path):
+    """(kernel, grid) -> (calls, mean us, min us, max us) for this library's kernels, from the raw kernel trace"""
+    agg = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        if "mp::" in row["Kernel_Name"]:
+            key = (row["Kernel_Name"][:70], int(row["Grid_Size_X"]), int(row["Workgroup_Size_X"]), int(row["VGPR_Count"]),
+                   int(row["LDS_Block_Size"]))
+            agg[key].append((int(row["End_Timestamp"]) - int(row["Start_Timestamp"])) / 1e3)
+    return {k: (len(v), sum(v) / len(v), min(v), max(v)) for k, v in agg.items()}
 
 
 def main():
@@ -38,7 +50,7 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "opd", "vi", "vi_dense"):
+    for wl in ("uct", "uct_cartpole", "opd", "vi", "vi_dense"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
@@ -46,6 +58,15 @@ def main():
         for name, calls, avg, pct in kernel_stats(f):
             lines.append("| `{}` | {} | {:.2f} | {:.2f} |".format(name.replace("|", "/"), calls, avg, pct))
         lines.append("")
+        tr = os.path.join(src, "trace_" + wl, wl + "_kernel_trace.csv")
+        if os.path.exists(tr):
+            lines += ["Per launch geometry (same kernel, different batch sizes are separate rows):", "",
+                      "| kernel | grid (threads) | block | VGPRs | LDS B | calls | avg us | min us | max us |",
+                      "|---|---|---|---|---|---|---|---|---|"]
+            for (name, grid, wg, vgpr, ldsb), (n, mean, lo, hi) in sorted(trace_by_grid(tr).items(), key=lambda kv: -kv[1][1]):
+                lines.append("| `{}` | {} | {} | {} | {} | {} | {:.2f} | {:.2f} | {:.2f} |".format(
+                    name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
+            lines.append("")
     traffic = {}
     for wl in ("uct", "vi_dense", "opd"):
         entry = {}
