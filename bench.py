@@ -86,9 +86,15 @@ def dist_setup(n_gpus):
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # BENCH_SAME_DEVICE=1 BENCH_BACKEND=gloo: dry run of the N > 1 code path on a box with a single GPU
+        if os.environ.get("BENCH_SAME_DEVICE"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local))
+        backend = os.environ.get("BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
         local = 0
