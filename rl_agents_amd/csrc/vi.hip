@@ -179,7 +179,13 @@ struct ViGenArgs {
     int32_t *notclose;
 };
 
-constexpr int kDenseChunk = 4096; // doubles of V staged in LDS per pass (32 KiB)
+#ifndef MP_DENSE_CHUNK
+#define MP_DENSE_CHUNK 4096
+#endif
+#ifndef MP_DENSE_UNROLL
+#define MP_DENSE_UNROLL 4
+#endif
+constexpr int kDenseChunk = MP_DENSE_CHUNK; // doubles of V staged in LDS per pass (32 KiB)
 
 // Rows of the (S*A) x S matrix T_m are contracted with V on v_mfma_f64_16x16x4_f64: the A operand
 // of one MFMA is a 16-row x 4-column block of T, the B operand is V broadcast into all 16 columns,
@@ -209,9 +215,13 @@ __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
             const double *pr = prow + c0 + q * 4;
             const int full = ch & ~15;
             int cc = 0;
-#pragma unroll 4
+#pragma unroll MP_DENSE_UNROLL
             for (; cc < full; cc += 16) {
+#ifdef MP_DENSE_NT
+                const double4_u t4 = __builtin_nontemporal_load(reinterpret_cast<const double4_u *>(pr + cc));
+#else
                 const double4_u t4 = *reinterpret_cast<const double4_u *>(pr + cc);
+#endif
                 const double4_t b4 = *reinterpret_cast<const double4_t *>(vs + cc + q * 4);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.x, b4.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.y, b4.y, acc, 0, 0, 0);

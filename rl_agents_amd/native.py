@@ -66,7 +66,8 @@ class NativeError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB_PATH
+    """The in-tree library; MI355PLAN_LIB points at another build of the same sources (kernel A/B experiments)."""
+    return os.environ.get("MI355PLAN_LIB") or _build.LIB_PATH
 
 
 def load():
