@@ -160,6 +160,17 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
                 const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
                 int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
                 int64_t *env_steps, int32_t mem);
+/*
+ * AbstractPlanner.step_tree with step_strategy "subtree" (abstract.py:172-206): before the next mp_uct_plan, replace
+ * the tree of every root left on this ctx by the last mp_uct_plan with the subtree of the root's child `actions[i]`
+ * (a root that was never expanded starts a fresh tree, like step_by_reset).  The next mp_uct_plan must have the same
+ * n_roots and model; it then continues on the kept statistics instead of starting from empty roots.
+ * mp_uct_reset_tree drops the kept trees (step_by_reset, mcts.py:129-130).
+ */
+int mp_uct_step_tree(mp_ctx *ctx, int32_t n_roots, const int32_t *actions, int32_t mem);
+int mp_uct_reset_tree(mp_ctx *ctx);
+/* Node capacity per root of the trees currently on this ctx (array size for mp_uct_tree_export). */
+int mp_uct_tree_capacity(mp_ctx *ctx, int32_t *cap);
 /* Tree of root `root` after the last mp_uct_plan on this ctx, creation order (root = node 0, the
  * A children of an expanded node are contiguous).  Host arrays of capacity `cap` nodes. */
 int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,

@@ -163,8 +163,9 @@ def cartpole_params(params):
 
 
 def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
-             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64, cartpole=None):
-    """One root. Table env: transition/reward/terminal + integer s0. CartPole: cartpole=params dict, s0 = 4 doubles."""
+             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64, cartpole=None, init_tree=None):
+    """One root. Table env: transition/reward/terminal + integer s0. CartPole: cartpole=params dict, s0 = 4 doubles.
+    init_tree: dict(count, value, first_child) kept from the previous plan (step_strategy "subtree")."""
     cp = x0 = None
     if cartpole is not None:
         cp, max_steps = cartpole_params(cartpole)
@@ -172,7 +173,11 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
         transition, reward, terminal, s0 = np.zeros((1, 2), np.int64), np.zeros((1, 2)), np.zeros(1, np.uint8), 0
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
-    cap = 1 + episodes * a
+    n_init = 0 if init_tree is None else len(init_tree["count"])
+    ic = None if not n_init else _i64(init_tree["count"])
+    iv = None if not n_init else _f64(init_tree["value"])
+    ifc = None if not n_init else np.ascontiguousarray(init_tree["first_child"], dtype=np.int32)
+    cap = max(n_init, 1) + episodes * a
     rng = np.array(rng_state, dtype=np.uint64)
     prior = _f64(prior_p)
     cdf = policy_cdf(rollout_p)
@@ -187,10 +192,26 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
                             C.byref(plan_len), C.byref(steps), _p(tree["parent"], C.c_int32),
                             _p(tree["action"], C.c_int32), _p(tree["count"], C.c_int64),
                             _p(tree["value"], C.c_double), _p(tree["first_child"], C.c_int32), C.byref(nn),
-                            _p(cp, C.c_double), _p(x0, C.c_double))
+                            _p(cp, C.c_double), _p(x0, C.c_double), int(n_init), _p(ic, C.c_int64), _p(iv, C.c_double),
+                            _p(ifc, C.c_int32))
     assert rc == 0, rc
     tree = {k: v[:nn.value].copy() for k, v in tree.items()}
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, tree=tree)
+
+
+def uct_reroot(tree, action, n_actions):
+    """AbstractPlanner.step_by_subtree on an exported tree dict -> re-rooted tree dict, or None for a fresh tree."""
+    n = len(tree["count"])
+    oc, ov, ofc = np.zeros(n, np.int64), np.zeros(n, np.float64), np.zeros(n, np.int32)
+    n_out = C.c_int32()
+    rc = lib().orc_uct_reroot(int(n_actions), n, _p(_i64(tree["count"]), C.c_int64), _p(_f64(tree["value"]), C.c_double),
+                              _p(np.ascontiguousarray(tree["first_child"], np.int32), C.c_int32), int(action),
+                              _p(oc, C.c_int64), _p(ov, C.c_double), _p(ofc, C.c_int32), C.byref(n_out))
+    assert rc == 0
+    if n_out.value == 0:
+        return None
+    k = n_out.value
+    return dict(count=oc[:k], value=ov[:k], first_child=ofc[:k])
 
 
 def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,

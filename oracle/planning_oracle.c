@@ -449,10 +449,14 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
                  int32_t *t_parent, int32_t *t_action, int64_t *t_count, double *t_value,
                  int32_t *t_first_child, int32_t *n_nodes_out,
                  /* CartPole roots: cp = 8 parameters, x0 = root state (4 doubles); NULL, NULL = table env */
-                 const double *cp, const double *x0)
+                 const double *cp, const double *x0,
+                 /* step_strategy "subtree" (abstract.py:195-206): the tree kept from the previous plan, creation
+                  * order with contiguous children (n_init = 0: fresh root).  Tree exports then need capacity
+                  * n_init + episodes*A. */
+                 int n_init, const int64_t *init_count, const double *init_value, const int32_t *init_first_child)
 {
     orc_env env = {S, A, T, R, term, done_on_next, max_steps, cp};
-    const int cap = 1 + episodes * A;
+    const int cap = (n_init > 0 ? n_init : 1) + episodes * A;
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
     int32_t *first_child = malloc(cap * sizeof(int32_t));
     int64_t *count = malloc(cap * sizeof(int64_t));
@@ -465,6 +469,14 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
     /* mcts.py:129-130 reset(): fresh root (value 0, count 0, prior 1) */
     parent[0] = -1; action[0] = -1; first_child[0] = -1; count[0] = 0; value[0] = 0;
     int n_nodes = 1;
+    if (n_init > 0) { /* continue on the re-rooted tree */
+        for (int i = 0; i < n_init; ++i) {
+            count[i] = init_count[i]; value[i] = init_value[i]; first_child[i] = init_first_child[i];
+            if (first_child[i] >= 0)
+                for (int a = 0; a < A; ++a) { parent[first_child[i] + a] = i; action[first_child[i] + a] = a; }
+        }
+        n_nodes = n_init;
+    }
     int64_t steps_taken = 0;
     for (int ep = 0; ep < episodes; ++ep) { /* mcts.py:179-184 */
         int32_t s = s0, st = steps0;     /* safe_deepcopy_env(state) */
@@ -549,6 +561,37 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
 }
 
 /*
+ * AbstractPlanner.step_by_subtree (abstract.py:195-206): the tree is replaced by the subtree of the root's child
+ * `action`; an unexpanded root or child-less choice starts a new tree (n_out = 0 -> caller plans from a fresh root).
+ * Nodes are re-numbered breadth-first so that children stay contiguous.  Arrays of capacity n_in.
+ */
+int orc_uct_reroot(int A, int n_in, const int64_t *count, const double *value, const int32_t *first_child, int action,
+                   int64_t *o_count, double *o_value, int32_t *o_first_child, int32_t *n_out)
+{
+    if (n_in < 1 || first_child[0] < 0 || action < 0 || action >= A) { *n_out = 0; return ORC_OK; }
+    int32_t *src = malloc((size_t)n_in * sizeof(int32_t));
+    if (!src) return ORC_ERR_ALLOC;
+    int head = 0, tail = 1;
+    src[0] = first_child[0] + action;
+    while (head < tail) {
+        const int o = src[head];
+        o_count[head] = count[o];
+        o_value[head] = value[o];
+        if (first_child[o] >= 0) {
+            o_first_child[head] = tail;
+            for (int a = 0; a < A; ++a) src[tail + a] = first_child[o] + a;
+            tail += A;
+        } else {
+            o_first_child[head] = -1;
+        }
+        ++head;
+    }
+    *n_out = tail;
+    free(src);
+    return ORC_OK;
+}
+
+/*
  * Batch drivers for the cpu_baseline leg of bench.py and for many-root parity checks:
  * independent roots, one RNG state each, OpenMP over roots (the reference's own fan-out is one
  * process per experiment, scripts/experiments.py:105).  Per-root outputs only (no trees).
@@ -573,7 +616,7 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
                               horizon, gamma, temperature, prior, rollout_cdf, rng6 + (long)i * 6, max_plan_len,
                               plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
                               env_steps ? env_steps + i : NULL, NULL, NULL, cnt, val, NULL, &nn, cp,
-                              x0 ? x0 + (long)i * 4 : NULL);
+                              x0 ? x0 + (long)i * 4 : NULL, 0, NULL, NULL, NULL);
         if (rc != ORC_OK) {
 #pragma omp critical
             rc_all = rc;

@@ -209,14 +209,20 @@ class AbstractPlanner(Configurable):
         if strategy == "reset":
             self.step_by_reset()
         elif strategy == "subtree":
-            raise NotImplementedError("step_strategy 'subtree' (tree reuse across plans) is not available on the "
-                                      "device planner yet; use 'reset' (the reference's default)")
+            if actions:
+                self.step_by_subtree(actions[0])
+            else:
+                self.step_by_reset()
         else:
             logger.warning("Unknown step strategy: %s", strategy)
             self.step_by_reset()
 
     def step_by_reset(self):
         self.reset()
+
+    def step_by_subtree(self, action):
+        """Keep the subtree under the root's child ``action`` for the next plan (abstract.py:195-206)."""
+        raise NotImplementedError("step_strategy 'subtree' is not available for this planner on the device")
 
     def reset(self):
         self.last = None

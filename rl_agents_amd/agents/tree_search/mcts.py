@@ -60,24 +60,46 @@ class MCTS(AbstractPlanner):
         cfg.update({"temperature": 2 / (1 - cfg["gamma"]), "closed_loop": False})
         return cfg
 
-    def plan_batch(self, state, root_states, root_steps=None, rng_states=None):
+    def reset(self):
+        super(MCTS, self).reset()
+        self._keep_action = None
+
+    def step_by_subtree(self, action):
+        """Tree reuse: the device re-roots the kept trees at the start of the next plan, provided the trees on the
+        context are still this planner's (nothing else planned in between); otherwise the tree is reset."""
+        ctx = self.models.ctx
+        if self.last is None or getattr(ctx, "_uct_tree_owner", None) is not self:
+            self.step_by_reset()
+            return
+        self._keep_action = int(action)
+        self.last, self._root = None, None
+
+    def plan_batch(self, state, root_states, root_steps=None, rng_states=None, keep_actions=None):
         model = self.model_for(state)
         n = len(root_states)
         if rng_states is None:
             rng_states = self.batch_rng_states(n)
         cfg = self.config
+        ctx = self.models.ctx
+        if keep_actions is None and getattr(self, "_keep_action", None) is not None and n == 1:
+            keep_actions = [self._keep_action]
+        self._keep_action = None
+        if keep_actions is not None and getattr(ctx, "_uct_tree_owner", None) is self:
+            ctx.uct_step_tree(keep_actions)
+        else:
+            ctx.uct_reset_tree()
         out = self.models.ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"],
                                        cfg["temperature"], policy_probabilities(self.prior_policy, model.A),
                                        policy_probabilities(self.rollout_policy, model.A), rng_states,
                                        root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1))
         out["rng_states"] = rng_states
         self.last, self._root, self._last_actions = out, None, model.A
+        ctx._uct_tree_owner = self
         self.env_steps += int(out["env_steps"].sum())
         return out
 
     def export_tree(self, root=0):
-        cap = 1 + self.config["episodes"] * self._last_actions
-        return build_tree(self.models.ctx.uct_tree(root, cap), "value")
+        return build_tree(self.models.ctx.uct_tree(root), "value")
 
 
 class MCTSAgent(AbstractTreeSearchAgent):

@@ -50,6 +50,8 @@ struct DevBuf {
 struct TreeMeta {
     int kind = 0; // 0 none, 1 uct, 2 opd
     int n_roots = 0, A = 0, cap = 0, K = 0;
+    int buf = 0;        // UCT: which of the two tree workspaces (WS_TREE0 / WS_TREE2) holds the current trees
+    bool armed = false; // UCT: mp_uct_step_tree was called; the next plan re-roots and continues
 };
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,

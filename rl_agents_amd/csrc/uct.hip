@@ -52,9 +52,11 @@ struct UctArgs {
     const int32_t *root_state, *root_steps;
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
-    const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | rcp[E+1] | tpdiv[A][E+2]
+    const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[E+1] | tpdiv[A][E+2]
     uint64_t *rng;
     UctNode *tree;
+    const int32_t *n_nodes_in; // kept (re-rooted) tree sizes, nullptr = every root starts fresh
+    int32_t *n_nodes_out;
     int32_t *plans, *plan_len;
     double *root_value, *root_child_value;
     int64_t *root_child_count, *env_steps;
@@ -99,9 +101,14 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
     // rollout policy as integer thresholds: u = k * 2^-53 with k = next64 >> 11, and
     // searchsorted(cdf, u, 'right') = #{a : cdf[a] <= u} = #{a : ceil(cdf[a] * 2^53) <= k}
     const uint64_t *thr = reinterpret_cast<const uint64_t *>(gpow + (H + 1)); // [A]
-    double *rcp = gpow + (H + 1) + A;       // [E + 1]  1.0 / n
+    double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
+    double *rcp = tp + A;                   // [E + 1]  1.0 / n
     double *tpdiv = rcp + (E + 1);          // [A][E+2] temperature * |A| * prior[a] / n
-    const int ntab = (H + 1) + A + (E + 1) + A * (E + 2);
+    const int ntab = (H + 1) + 2 * A + (E + 1) + A * (E + 2);
+    // visit counts beyond the tables (trees kept across plans, step_strategy "subtree") take the IEEE division
+    // itself -- the same correctly rounded quotient the host put in the tables
+    auto explore = [&](int a, int cnt1) { return cnt1 <= E + 1 ? tpdiv[a * (E + 2) + cnt1] : tp[a] / (double)cnt1; };
+    auto inv = [&](int c) { return c <= E ? rcp[c] : 1.0 / (double)c; };
     int32_t *path_all = reinterpret_cast<int32_t *>(lds_d + ntab); // [H + 1][waves * 64]
     uint16_t *t16 = reinterpret_cast<uint16_t *>(path_all + (H + 1) * nthreads);
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
@@ -132,13 +139,14 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
 #pragma unroll
         for (int i = 0; i < 4; ++i) x0[i] = p.root_x[(long)r * 4 + i];
     }
-    // mcts.py:129-130 reset(): fresh root
-    {
+    int n_nodes = p.n_nodes_in ? p.n_nodes_in[r] : 0; // > 0: tree kept by step_strategy "subtree"
+    if (n_nodes < 1) {
+        // mcts.py:129-130 reset(): fresh root
         UctNode n;
         n.value = 0.0; n.count = 0; n.first_child = -1;
         tree[0] = n;
+        n_nodes = 1;
     }
-    int n_nodes = 1;
     int steps_taken = 0;
     constexpr int AR = AT > 0 ? AT : 1;
 
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
                 for (int a = 0; a < AR; ++a) c[a] = tree[fc + a];
                 double sc[AR];
 #pragma unroll
-                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + tpdiv[a * (E + 2) + c[a].count + 1];
+                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
                 double m = sc[0];
 #pragma unroll
                 for (int a = 1; a < AR; ++a) m = sc[a] > m ? sc[a] : m;
@@ -190,18 +198,18 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
                 double m = 0.0;
                 for (int a = 0; a < A; ++a) {
                     const UctNode c = tree[fc + a];
-                    const double sc = c.value + tpdiv[a * (E + 2) + c.count + 1];
+                    const double sc = c.value + explore(a, c.count + 1);
                     if (a == 0 || sc > m) m = sc;
                 }
                 int nt = 0;
                 for (int a = 0; a < A; ++a) {
                     const UctNode c = tree[fc + a];
-                    nt += (c.value + tpdiv[a * (E + 2) + c.count + 1]) == m ? 1 : 0;
+                    nt += (c.value + explore(a, c.count + 1)) == m ? 1 : 0;
                 }
                 int pick = (int)g.below((uint32_t)nt);
                 for (int a = 0; a < A; ++a) {
                     const UctNode c = tree[fc + a];
-                    if ((c.value + tpdiv[a * (E + 2) + c.count + 1]) == m) {
+                    if ((c.value + explore(a, c.count + 1)) == m) {
                         if (pick == 0) { act = a; nfc = c.first_child; break; }
                         --pick;
                     }
@@ -318,7 +326,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
             const int n = path[d * nthreads + lane];
             UctNode c = tree[n];
             c.count += 1;
-            c.value += rcp[c.count] * (total - c.value);
+            c.value += inv(c.count) * (total - c.value);
             tree[n] = c;
         }
 #ifdef MP_PROFILE
@@ -354,6 +362,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
             for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
         if (p.plan_len) p.plan_len[r] = len;
     }
+    if (p.n_nodes_out) p.n_nodes_out[r] = n_nodes;
     if (p.root_value) p.root_value[r] = tree[0].value;
     if (p.env_steps) p.env_steps[r] = (int64_t)steps_taken;
     const int rfc = tree[0].first_child;
@@ -361,6 +370,46 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(U
         if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? tree[rfc + a].count : 0;
         if (p.root_child_value) p.root_child_value[(long)r * A + a] = rfc >= 0 ? tree[rfc + a].value : 0.0;
     }
+}
+
+// AbstractPlanner.step_by_subtree (abstract.py:195-206), one root per lane: the subtree of the root's child
+// `action` is re-numbered breadth-first into the other tree buffer (children stay contiguous).  While a node
+// waits in the BFS queue its first_child field holds its OLD id.  A never-expanded root gives size 0 (fresh tree).
+__global__ __launch_bounds__(64) void uct_reroot_kernel(int n_roots, int A, int cap_old, int cap_new,
+                                                        const UctNode *__restrict__ old_trees, UctNode *__restrict__ new_trees,
+                                                        const int32_t *__restrict__ n_old, const int32_t *__restrict__ actions,
+                                                        int32_t *__restrict__ n_new)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_roots) return;
+    const UctNode *o = old_trees + (long)r * cap_old;
+    UctNode *n = new_trees + (long)r * cap_new;
+    const int a = actions[r];
+    if (n_old[r] < 1 || o[0].first_child < 0 || a < 0 || a >= A) {
+        n_new[r] = 0;
+        return;
+    }
+    int head = 0, tail = 1;
+    UctNode first;
+    first.first_child = o[0].first_child + a;
+    n[0] = first;
+    while (head < tail) {
+        const UctNode src = o[n[head].first_child];
+        UctNode out;
+        out.value = src.value; out.count = src.count; out.first_child = -1;
+        if (src.first_child >= 0) {
+            out.first_child = tail;
+            for (int c = 0; c < A; ++c) {
+                UctNode q;
+                q.value = 0.0; q.count = 0; q.first_child = src.first_child + c;
+                n[tail + c] = q;
+            }
+            tail += A;
+        }
+        n[head] = out;
+        ++head;
+    }
+    n_new[r] = tail;
 }
 
 // Roots per wavefront for the global-table variant.  A root's episodes are one long dependency
@@ -416,9 +465,9 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     const long cap = 1 + (long)episodes * A;
 
     // small per-call tables, computed on the host exactly as Python computes them
-    const size_t ntab = (size_t)(H + 1) + A + (E + 1) + (size_t)A * (E + 2);
+    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (E + 1) + (size_t)A * (E + 2);
     std::vector<double> tab(ntab);
-    double *gpow = tab.data(), *cdf = gpow + (H + 1), *rcp = cdf + A, *tpdiv = rcp + (E + 1);
+    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (E + 1);
     for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);                 // gamma ** h
     double acc = 0.0;
     for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }             // numpy cumsum
@@ -434,6 +483,7 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                         // mcts.py:255  K / count, K = 1
     for (int a = 0; a < A; ++a) {
         const double tp = temperature * (double)A * prior_p[a];                   // mcts.py:286, left to right
+        tpv[a] = tp;
         tpdiv[(size_t)a * (E + 2)] = 0.0;
         for (int n = 1; n <= E + 1; ++n) tpdiv[(size_t)a * (E + 2) + n] = tp / (double)n; // ... / (count + 1)
     }
@@ -466,8 +516,32 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     if (!ldsm && lds > 64 * 1024)
         return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
 
-    MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.tree));
-    ctx->tree.kind = 1; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap;
+    // trees: fresh ones, or (step_strategy "subtree") the kept ones re-rooted into the other buffer with room
+    // for this plan's expansions
+    int32_t *d_nn = nullptr;
+    MP_TRY(ws_get(ctx, WS_TREE1, (size_t)2 * n_roots, &d_nn)); // [0, n): sizes after a plan, [n, 2n): after re-rooting
+    a.n_nodes_in = nullptr;
+    a.n_nodes_out = d_nn;
+    long cap_use = cap;
+    const bool cont = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
+    ctx->tree.armed = false;
+    if (cont) {
+        const int old_slot = ctx->tree.buf ? WS_TREE2 : WS_TREE0, new_slot = ctx->tree.buf ? WS_TREE0 : WS_TREE2;
+        cap_use = (long)ctx->tree.cap + (long)episodes * A;
+        UctNode *nw = nullptr;
+        MP_TRY(ws_get(ctx, new_slot, (size_t)n_roots * cap_use, &nw));
+        const int32_t *acts = (const int32_t *)ctx->ws[WS_TREE3].p;
+        hipLaunchKernelGGL(uct_reroot_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), 0, st, n_roots, A,
+                           ctx->tree.cap, (int)cap_use, (const UctNode *)ctx->ws[old_slot].p, nw, d_nn, acts, d_nn + n_roots);
+        a.tree = nw;
+        a.n_nodes_in = d_nn + n_roots;
+        ctx->tree.buf ^= 1;
+    } else {
+        ctx->tree.buf = 0;
+        MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap_use, &a.tree));
+    }
+    a.cap = (int)cap_use;
+    ctx->tree.kind = 1; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap_use;
 
     int32_t *d_rs = nullptr, *d_st = nullptr;
     if (cart) {
@@ -515,6 +589,36 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     return MP_OK;
 }
 
+int mp_uct_step_tree(mp_ctx *ctx, int32_t n_roots, const int32_t *actions, int32_t mem)
+{
+    if (!ctx || !actions) return fail(MP_ERR_ARG, "mp_uct_step_tree: NULL argument");
+    if (ctx->tree.kind != 1 || ctx->tree.n_roots != n_roots)
+        return fail(MP_ERR_ARG, "mp_uct_step_tree: no UCT trees of %d roots on this ctx", n_roots);
+    MP_HIP(hipSetDevice(ctx->device));
+    int32_t *d = nullptr;
+    MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots, &d));
+    MP_HIP(hipMemcpyAsync(d, actions, (size_t)n_roots * sizeof(int32_t),
+                          mem == MP_MEM_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tree.armed = true;
+    return MP_OK;
+}
+
+int mp_uct_tree_capacity(mp_ctx *ctx, int32_t *cap)
+{
+    if (!ctx || !cap) return fail(MP_ERR_ARG, "mp_uct_tree_capacity: NULL argument");
+    if (ctx->tree.kind != 1) return fail(MP_ERR_ARG, "mp_uct_tree_capacity: no UCT tree on this ctx");
+    *cap = ctx->tree.cap;
+    return MP_OK;
+}
+
+int mp_uct_reset_tree(mp_ctx *ctx)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    ctx->tree.armed = false;
+    return MP_OK;
+}
+
 int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                        int64_t *count, double *value, int32_t *first_child)
 {
@@ -525,7 +629,8 @@ int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
     std::vector<UctNode> h((size_t)tcap);
     MP_HIP(hipSetDevice(ctx->device));
     MP_HIP(hipStreamSynchronize(ctx->stream));
-    MP_HIP(hipMemcpy(h.data(), (const UctNode *)ctx->ws[WS_TREE0].p + (long)root * tcap, (size_t)tcap * sizeof(UctNode),
+    MP_HIP(hipMemcpy(h.data(), (const UctNode *)ctx->ws[ctx->tree.buf ? WS_TREE2 : WS_TREE0].p + (long)root * tcap,
+                     (size_t)tcap * sizeof(UctNode),
                      hipMemcpyDeviceToHost));
     // nodes are appended A at a time; the tree in use is the closure of first_child links
     int n = 1;

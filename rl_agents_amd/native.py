@@ -44,6 +44,9 @@ SIGNATURES = {
     "mp_vi_sweeps": (C.c_int, [_vp, _vp, c_f64, c_i32, c_i32]),
     "mp_uct_plan": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, c_i32]),
+    "mp_uct_step_tree": (C.c_int, [_vp, c_i32, _vp, c_i32]),
+    "mp_uct_reset_tree": (C.c_int, [_vp]),
+    "mp_uct_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
     "mp_uct_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp]),
     "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               c_i32]),
@@ -326,7 +329,19 @@ class Context(object):
                                      _ptr(root_value), _ptr(root_child_count), _ptr(root_child_value),
                                      _ptr(env_steps), MP_MEM_DEVICE))
 
-    def uct_tree(self, root, cap):
+    def uct_step_tree(self, actions):
+        """step_strategy 'subtree': keep, for the next uct_plan, the subtree under each root's child actions[i]."""
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)
+        _check(self._lib.mp_uct_step_tree(self._h, a.shape[0], _ptr(a), MP_MEM_HOST))
+
+    def uct_reset_tree(self):
+        _check(self._lib.mp_uct_reset_tree(self._h))
+
+    def uct_tree(self, root, cap=None):
+        if cap is None:
+            c = c_i32()
+            _check(self._lib.mp_uct_tree_capacity(self._h, C.byref(c)))
+            cap = c.value
         t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), count=np.zeros(cap, np.int64),
                  value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32))
         n = c_i32()

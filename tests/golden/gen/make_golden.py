@@ -324,6 +324,33 @@ def golden_uct():
         env.step(plans[-1][0])
     store["uct/sequence_large1_b200_seed0/first_actions"] = np.asarray([p[0] for p in plans], np.int32)
     store["uct/sequence_large1_b200_seed0/states"] = np.asarray([0], np.int32)
+
+    # step_strategy "subtree" (abstract.py:172-206): the tree is re-rooted at the executed action between plans
+    for tag, cfg, s_start, acfg in (("subtree_large1", large1_nolimit, 0, dict(budget=150, step_strategy="subtree")),
+                                    ("subtree_highway", hw, 5, dict(budget=300, horizon=12, episodes=25,
+                                                                    step_strategy="subtree"))):
+        env = make_env(cfg, state=s_start)
+        agent = agent_factory(env, dict(acfg, __class__=UCT))
+        agent.seed(11)
+        p = "uct/" + tag
+        put_mdp(store, p + "/mdp", cfg)
+        pc = agent.planner.config
+        store[p + "/rng_before"] = rng_state(agent.planner.np_random)
+        states = []
+        for step in range(5):
+            states.append(env.mdp.state)
+            plan = agent.plan(env.mdp.state)
+            root = agent.planner.root
+            tree = bfs_tree(root, [("count", lambda n: n.count, np.int64), ("value", lambda n: float(n.value), np.float64)])
+            put(store, "{}/step{}".format(p, step), dict(plan=np.asarray(plan, np.int32), root_count=root.count,
+                                                         root_value=float(root.value),
+                                                         rng_after=rng_state(agent.planner.np_random)))
+            put(store, "{}/step{}/tree".format(p, step), tree)
+            _, _, term, trunc, _ = env.step(plan[0])
+            if term or trunc:
+                break
+        put(store, p, dict(states=np.asarray(states, np.int32), n_steps=len(states), gamma=pc["gamma"],
+                           episodes=pc["episodes"], horizon=pc["horizon"], temperature=pc["temperature"]))
     return store
 
 

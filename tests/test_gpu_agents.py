@@ -184,3 +184,23 @@ def test_batched_evaluation_equals_sequential_episodes():
         assert out["lengths"][i] == len(actions)
         np.testing.assert_array_equal(out["actions"][i, :len(actions)], actions)
         assert out["returns"][i] == pytest.approx(total, abs=1e-12)
+
+
+@pytest.mark.parametrize("tag,agent_cfg", [("subtree_large1", dict(budget=150)),
+                                           ("subtree_highway", dict(budget=300, horizon=12, episodes=25))])
+def test_mcts_agent_subtree_strategy(golden, tag, agent_cfg):
+    """An agent configured with step_strategy 'subtree' reproduces the reference's episode plan for plan."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    z = golden["uct"]
+    p = "uct/" + tag
+    cfg = mdp_from_golden(z, p + "/mdp")
+    env = _env(cfg, state=int(z[p + "/states"][0]))
+    agent = agent_factory(env, dict(agent_cfg, __class__=UCT, step_strategy="subtree"))
+    agent.seed(11)
+    for step in range(int(z[p + "/n_steps"])):
+        assert env.mdp.state == int(z[p + "/states"][step])
+        plan = agent.plan(env.mdp.state)
+        q = "{}/step{}".format(p, step)
+        np.testing.assert_array_equal(plan, z[q + "/plan"], err_msg=q)
+        assert agent.planner.root.count == int(z[q + "/root_count"])
+        env.step(plan[0])

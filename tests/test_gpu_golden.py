@@ -132,3 +132,32 @@ def test_uct_golden(ctx, golden):
         assert tree["count"][0] == int(z[p + "/root_count"])
         assert_tree_equal(z, p + "/tree", tree, a, dict(count="count", value="value"))
         model.close()
+
+
+@pytest.mark.parametrize("tag", ["subtree_large1", "subtree_highway"])
+def test_uct_subtree_strategy_golden(ctx, golden, tag):
+    """step_strategy 'subtree': mp_uct_step_tree re-roots the kept tree, the next mp_uct_plan continues on it;
+    plans, trees and generator state equal the reference's over a 5-step episode."""
+    z = golden["uct"]
+    p = "uct/" + tag
+    cfg = mdp_from_golden(z, p + "/mdp")
+    model = _load(ctx, cfg)
+    a = cfg["reward"].shape[1]
+    rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+    prob = np.ones(a) / a
+    ctx.uct_reset_tree()
+    prev = None
+    for step in range(int(z[p + "/n_steps"])):
+        if prev is not None:
+            ctx.uct_step_tree([prev])
+        out = ctx.uct_plan(model, [int(z[p + "/states"][step])], int(z[p + "/episodes"]), int(z[p + "/horizon"]),
+                           float(z[p + "/gamma"]), float(z[p + "/temperature"]), prob, prob, rng)
+        q = "{}/step{}".format(p, step)
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[q + "/plan"], err_msg=q)
+        np.testing.assert_array_equal(rng[0], z[q + "/rng_after"], err_msg=q)
+        tree = ctx.uct_tree(0)
+        assert tree["count"][0] == int(z[q + "/root_count"]) and tree["value"][0] == float(z[q + "/root_value"])
+        assert_tree_equal(z, q + "/tree", tree, a, dict(count="count", value="value"))
+        prev = int(out["plans"][0, 0])
+    model.close()

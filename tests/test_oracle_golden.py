@@ -190,3 +190,32 @@ def test_cartpole_env_matches_golden_episode(golden):
         if done:
             break
     assert steps == int(z["cartpole/episode_steps"]) == 200 and not term
+
+
+def _subtree_sequence(golden, tag, plan_fn, reroot_fn):
+    """Replay a step_strategy='subtree' agent: plan, execute plan[0], re-root, plan again (abstract.py:172-206)."""
+    z = golden["uct"]
+    p = "uct/" + tag
+    cfg = mdp_from_golden(z, p + "/mdp")
+    a = cfg["reward"].shape[1]
+    rng = np.array(z[p + "/rng_before"], dtype=np.uint64)
+    tree, prev_action = None, None
+    for step in range(int(z[p + "/n_steps"])):
+        if tree is not None:
+            tree = reroot_fn(tree, prev_action, a)
+        out = plan_fn(cfg, int(z[p + "/states"][step]), int(z[p + "/episodes"]), int(z[p + "/horizon"]),
+                      float(z[p + "/gamma"]), float(z[p + "/temperature"]), np.ones(a) / a, rng, tree)
+        q = "{}/step{}".format(p, step)
+        np.testing.assert_array_equal(out["plan"], z[q + "/plan"], err_msg=q)
+        np.testing.assert_array_equal(out["rng_after"], z[q + "/rng_after"], err_msg=q)
+        assert out["tree"]["count"][0] == int(z[q + "/root_count"]) and out["tree"]["value"][0] == float(z[q + "/root_value"])
+        assert_tree_equal(z, q + "/tree", out["tree"], a, dict(count="count", value="value"))
+        tree, prev_action, rng = out["tree"], int(out["plan"][0]), out["rng_after"]
+
+
+@pytest.mark.parametrize("tag", ["subtree_large1", "subtree_highway"])
+def test_uct_subtree_strategy_sequences(golden, tag):
+    def plan_fn(cfg, s0, episodes, horizon, gamma, temperature, p, rng, tree):
+        return oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], s0, episodes, horizon, gamma,
+                               temperature, p, p, rng, max_steps=cfg["max_steps"], init_tree=tree)
+    _subtree_sequence(golden, tag, plan_fn, oracle.uct_reroot)
