@@ -241,3 +241,49 @@ def test_row_block_backup_and_sharded_driver_world1(ctx):
     qr, sr = ctx.vi_solve(both, 0.9, 60, robust=True)
     qr2, sr2 = vi_solve_row_sharded(ctx, tt, rr, None, gamma=0.9, iterations=60, robust=True)
     assert sr == sr2 and np.array_equal(qr, qr2)
+
+
+def test_limits_and_error_codes(ctx):
+    """Unsupported configurations fail loudly with the documented error codes (no silent fallback)."""
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    small = generators.random_deterministic(30, 3, seed=1)
+    model = ctx.load_table(small["transition"], small["reward"], small["terminal"])
+    rng = _rng_states(2)
+    p = np.ones(3) / 3
+    with pytest.raises(native.NativeError) as e:                      # horizon too deep for the LDS path stack
+        ctx.uct_plan(model, [0, 1], 4, 5000, 0.9, 1.0, p, p, rng, max_plan_len=4)
+    assert e.value.code == native.ERR_ARG
+    with pytest.raises(native.NativeError) as e:                      # OPD budget whose leaf array exceeds LDS
+        ctx.opd_plan(model, [0, 1], 200000, 0.9, 0.0, rng)
+    assert e.value.code == native.ERR_ARG
+    with pytest.raises(ValueError):                                   # wrong policy length
+        ctx.uct_plan(model, [0, 1], 4, 5, 0.9, 1.0, np.ones(2) / 2, p, rng)
+    with pytest.raises(native.NativeError) as e:                      # transition index out of range
+        ctx.load_table([[0, 7]], [[0.0, 0.0]])
+    assert e.value.code == native.ERR_ARG
+    dense = generators.random_stochastic(12, 2, seed=1)
+    dmodel = ctx.load_dense(dense["transition"], dense["reward"], None)
+    with pytest.raises(native.NativeError) as e:                      # tree search needs a deterministic table
+        ctx.uct_plan(dmodel, [0, 1], 4, 5, 0.9, 1.0, np.ones(2) / 2, np.ones(2) / 2, rng)
+    assert e.value.code == native.ERR_MODE
+    sparse = generators.random_sparse(12, 2, 2, seed=1)
+    smodel = ctx.load_sparse(sparse["transition"], sparse["next"], sparse["reward"], None)
+    with pytest.raises(native.NativeError) as e:                      # robust VI has no sparse mode ("Unknown mode")
+        ctx.vi_solve(smodel, 0.9, 5, robust=True)
+    assert e.value.code == native.ERR_MODE
+
+
+def test_uct_large_state_space_without_compact_table(ctx):
+    """S >= 32768: no uint16 transition table exists; the record-gather kernel handles it (also with MP_UCT_MODEL=lds)."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(40000, 4, seed=12, terminal_rate=0.02)
+    p = np.ones(4) / 4
+    _cmp_uct(ctx, cfg, 300, 20, 10, 0.9, 5.0, p, p, seed=2)
+
+
+def test_uct_many_actions_generic_kernel(ctx):
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(64, 40, seed=13)
+    p = np.ones(40) / 40
+    _cmp_uct(ctx, cfg, 100, 12, 4, 0.8, 10.0, p, p, seed=3)
