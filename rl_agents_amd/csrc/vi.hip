@@ -108,6 +108,108 @@ __global__ __launch_bounds__(64) void vi_det_sweep(ViDetArgs p)
     if (nc) p.notclose[p.k] = 1;
 }
 
+// Small deterministic problems (12*M*S*A + 24*S bytes fit LDS, e.g. the reference's own S = 100 fixtures): the
+// whole fixed-point iteration in ONE launch of one workgroup -- tables and the three V iterates live in LDS, a
+// sweep is separated from the next by a workgroup barrier (~0.2 us) instead of a kernel boundary (~3 us), and the
+// allclose early exit is a uniform branch.  Same arithmetic, same order, same returned iterate as the chained version.
+struct ViSmallArgs {
+    ViDetArgs d; // T / R / term in global memory, gamma, tolerances, M, S, A, robust, vform
+    int iterations;
+    double *Q_out, *V_out;
+    int32_t *sweeps_out;
+};
+
+template <int AT>
+__global__ __launch_bounds__(1024) void vi_det_small(ViSmallArgs q)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_v[];
+    const ViDetArgs &p = q.d;
+    const int S = p.S, A = AT > 0 ? AT : p.A, M = p.M, tid = threadIdx.x, nt = blockDim.x;
+    const long msa = (long)S * A, n_sa = (long)M * msa;
+    double *Vb = lds_v;                                        // [3][S]
+    double *R = Vb + 3 * (long)S;                              // [M*S*A]
+    int32_t *T = reinterpret_cast<int32_t *>(R + n_sa);        // [M*S*A]
+    __shared__ int flag;
+    for (long i = tid; i < 3L * S; i += nt) Vb[i] = 0.0;
+    for (long i = tid; i < n_sa; i += nt) { R[i] = p.R[i]; T[i] = p.T[i]; }
+    // this thread's states: s = tid, tid + nt, ... ; their terminal flags never change
+    constexpr int kMaxOwn = 8;
+    bool term_own[kMaxOwn];
+#pragma unroll
+    for (int i = 0; i < kMaxOwn; ++i) {
+        const int s = tid + i * nt;
+        term_own[i] = (!p.robust && p.term && s < S) ? p.term[s] != 0 : false;
+    }
+    __syncthreads();
+    // Q[s, 0..A) of the Bellman operator applied to V, all loads of the row issued before the first use
+    auto qrow = [&](const double *V, int s, bool term_s, double *out) {
+        const long sa0 = (long)s * A;
+        if (p.robust) {
+            for (int a = 0; a < A; ++a) {
+                double best = 0.0;
+                for (int m = 0; m < M; ++m) {
+                    const double qm = R[m * msa + sa0 + a] + p.gamma * V[T[m * msa + sa0 + a]];
+                    if (m == 0 || qm < best) best = qm;
+                }
+                out[a] = best;
+            }
+        } else {
+            for (int a = 0; a < A; ++a) out[a] = R[sa0 + a] + p.gamma * (term_s ? 0.0 : V[T[sa0 + a]]);
+        }
+    };
+    constexpr int AR = AT > 0 ? AT : 64;
+    int j = q.iterations, sweeps = q.iterations;
+    for (int k = 0; k < q.iterations; ++k) {
+        if (tid == 0) flag = 0;
+        __syncthreads();
+        const double *Vprev = Vb + (long)((k + 2) % 3) * S, *Vcur = Vb + (long)(k % 3) * S;
+        double *Vnext = Vb + (long)((k + 1) % 3) * S;
+        bool nc = false;
+        int own = 0;
+        for (int s = tid; s < S; s += nt, ++own) {
+            const bool term_s = own < kMaxOwn ? term_own[own] : ((!p.robust && p.term) ? p.term[s] != 0 : false);
+            double qn[AR], qo[AR];
+            qrow(Vcur, s, term_s, qn);
+            if (!p.vform && k > 0) qrow(Vprev, s, term_s, qo);
+            double vmax = qn[0];
+#pragma unroll
+            for (int a = 0; a < AR; ++a) {
+                if (a < A) {
+                    if (!p.vform) nc |= !isclose_np(k == 0 ? 0.0 : qo[a], qn[a], p.rtol, p.atol);
+                    if (a > 0 && qn[a] > vmax) vmax = qn[a];
+                }
+            }
+            Vnext[s] = vmax;
+            if (p.vform) nc |= !isclose_np(Vcur[s], vmax, p.rtol, p.atol);
+        }
+        if (nc) flag = 1;
+        __syncthreads();
+        if (flag == 0) { j = k; sweeps = k + 1; break; } // uniform: every thread reads the same flag
+        __syncthreads();
+    }
+    if (tid == 0 && q.sweeps_out) *q.sweeps_out = sweeps;
+    const double *Vj = Vb + (long)(j % 3) * S, *Vjm1 = Vb + (long)((j + 2) % 3) * S;
+    for (int s = tid; s < S; s += nt) {
+        if (q.V_out) q.V_out[s] = Vj[s];
+        if (q.Q_out) {
+            const bool term_s = (!p.robust && p.term) ? p.term[s] != 0 : false;
+            double qj[AR];
+            qrow(Vjm1, s, term_s, qj);
+            for (int a = 0; a < A; ++a) q.Q_out[(long)s * A + a] = j == 0 ? 0.0 : qj[a];
+        }
+    }
+}
+
+template <int AT>
+static int vi_small_launch(const ViSmallArgs &q, size_t lds, int threads, hipStream_t st)
+{
+    if (lds > 64 * 1024)
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vi_det_small<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds));
+    hipLaunchKernelGGL(vi_det_small<AT>, dim3(1), dim3((unsigned)threads), lds, st, q);
+    return MP_OK;
+}
+
 static void vi_det_launch(const ViDetArgs &a, hipStream_t st)
 {
     const dim3 grid((unsigned)((a.S + 63) / 64)), block(64);
@@ -365,7 +467,29 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
 
     const unsigned gs = (unsigned)((S + 255) / 256);
     int launches = 0;
-    if (m->mode == MP_MODE_DETERMINISTIC) {
+    const size_t small_lds = (size_t)3 * S * sizeof(double) + (size_t)M * SA * (sizeof(double) + sizeof(int32_t));
+    if (m->mode == MP_MODE_DETERMINISTIC && small_lds <= kLdsBytes - 2048 && A <= 64 && !getenv("MP_VI_NO_SMALL")) {
+        ViSmallArgs q;
+        memset(&q, 0, sizeof(q));
+        q.d.M = M; q.d.S = S; q.d.A = A; q.d.robust = robust; q.d.vform = vform;
+        q.d.T = m->T; q.d.R = m->R; q.d.term = m->term; q.d.gamma = gamma; q.d.rtol = rtol; q.d.atol = atol;
+        q.iterations = iterations; q.Q_out = dQ; q.V_out = dV; q.sweeps_out = dSw;
+        MP_TRY(kernels_begin(ctx));
+        const int threads = S >= 1024 ? 1024 : ((S + 63) / 64) * 64;
+        switch (A) {
+        case 2: MP_TRY(vi_small_launch<2>(q, small_lds, threads, st)); break;
+        case 3: MP_TRY(vi_small_launch<3>(q, small_lds, threads, st)); break;
+        case 4: MP_TRY(vi_small_launch<4>(q, small_lds, threads, st)); break;
+        case 5: MP_TRY(vi_small_launch<5>(q, small_lds, threads, st)); break;
+        case 6: MP_TRY(vi_small_launch<6>(q, small_lds, threads, st)); break;
+        case 8: MP_TRY(vi_small_launch<8>(q, small_lds, threads, st)); break;
+        default:
+            if (A > 64) return fail(MP_ERR_ARG, "vi: |A| = %d > 64 not supported by the single-launch kernel", A);
+            MP_TRY(vi_small_launch<0>(q, small_lds, threads, st));
+            break;
+        }
+        MP_TRY(kernels_end(ctx, 1));
+    } else if (m->mode == MP_MODE_DETERMINISTIC) {
         double *Vb = nullptr;
         MP_TRY(ws_get(ctx, WS_VI1, (size_t)3 * S, &Vb));
         MP_HIP(hipMemsetAsync(Vb, 0, (size_t)3 * S * sizeof(double), st));
