@@ -29,7 +29,8 @@ def main():
     for rep in range(3):
         t0 = time.perf_counter()
         if what == "uct":
-            out = ctx.uct_plan(model, s0, 33, 30, 0.8, 10.0, p, p, rng, max_plan_len=8)
+            out = ctx.uct_plan(model, s0, int(os.environ.get("EPISODES", "33")), int(os.environ.get("HORIZON", "30")), 0.8, 10.0, p, p,
+                               rng, max_plan_len=8)
         else:
             budget = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
             out = ctx.opd_plan(model, s0, budget, 0.8, 0.0, rng, max_plan_len=32)
