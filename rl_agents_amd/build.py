@@ -21,7 +21,6 @@ HEADERS = ["common.hpp", "pcg64.hpp"]
 # multiply-add would change the last bit of bounds and Q values and break bit-exact parity.
 # MP_PROFILE=1 in the environment builds the phase-instrumented kernels (device printf of clock64 ticks)
 FLAGS = (["-DMP_PROFILE"] if os.environ.get("MP_PROFILE") else []) + \
-        (["-DMP_DENSE_NT"] if os.environ.get("MP_DENSE_NT") else []) + \
         [f for f in os.environ.get("MP_EXTRA_FLAGS", "").split() if f] + ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
 

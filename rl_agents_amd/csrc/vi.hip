@@ -319,11 +319,7 @@ __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
             int cc = 0;
 #pragma unroll MP_DENSE_UNROLL
             for (; cc < full; cc += 16) {
-#ifdef MP_DENSE_NT
-                const double4_u t4 = __builtin_nontemporal_load(reinterpret_cast<const double4_u *>(pr + cc));
-#else
                 const double4_u t4 = *reinterpret_cast<const double4_u *>(pr + cc);
-#endif
                 const double4_t b4 = *reinterpret_cast<const double4_t *>(vs + cc + q * 4);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.x, b4.x, acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f64_16x16x4f64(t4.y, b4.y, acc, 0, 0, 0);

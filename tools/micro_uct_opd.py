@@ -1,6 +1,6 @@
 """Kernel micro-benchmarks without torch (MI355PLAN_NO_TORCH=1): quick A/B of launch geometry on the GPU box.
 
-    MI355PLAN_NO_TORCH=1 python tests/bench_micro.py uct|opd [n_roots]
+    MI355PLAN_NO_TORCH=1 python tools/micro_uct_opd.py uct|opd [n_roots]
 """
 import os
 import sys

@@ -1,4 +1,4 @@
-"""VI micro-benchmark without torch: MI355PLAN_NO_TORCH=1 python tests/bench_micro_vi.py [sweeps]"""
+"""VI micro-benchmark without torch: MI355PLAN_NO_TORCH=1 python tools/micro_vi.py [sweeps]"""
 import os
 import sys
 import time

@@ -1,4 +1,4 @@
-"""Dense VI micro-benchmark without torch: MI355PLAN_NO_TORCH=1 python tests/bench_micro_dense.py [S] [A]"""
+"""Dense VI micro-benchmark without torch: MI355PLAN_NO_TORCH=1 python tools/micro_vi_dense.py [S] [A]"""
 import os
 import sys
 import time

@@ -1,4 +1,4 @@
-"""Small-MDP VI latency: MI355PLAN_NO_TORCH=1 python tests/bench_micro_vi_small.py"""
+"""Small-MDP VI latency: MI355PLAN_NO_TORCH=1 python tools/micro_vi_small.py"""
 import os
 import sys
 import time
