@@ -15,8 +15,9 @@
 //     during planning reads an internal node's bounds (leaf selection reads leaf U, a child's L
 //     starts from its parent's creation-time L), and after every reference backup each ancestor
 //     equals the max over its children; so the final bounds are the unique bottom-up fixed point
-//     L[n] = max_c L[c], U[n] = max_c U[c].  It is computed once at the end, in reverse expansion
-//     order (children always have larger ids than their parent), inside LDS: O(K) instead of the
+//     L[n] = max_c L[c], U[n] = max_c U[c].  L is computed once at the end, in reverse expansion
+//     order (children always have larger ids than their parent), inside LDS; the root's U is one
+//     reduction over the leaves and the other internal U's are filled in at export: O(K) instead of the
 //     reference's O(K * depth) -- on highway-shaped tables, whose reward-1 lane makes the tree a
 //     chain, that removes 62 dependent HBM round trips per expansion.  max is exact, so the
 //     bounds are bit-identical to the incremental walk.
@@ -209,20 +210,20 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     __syncthreads();
 
     if (status == MP_OK) {
-        // ---- all backup_to_root calls at once (deterministic.py:67-79): bottom-up max, in LDS.
-        // upper bounds: leaf entries are already in place, expanded entries hold -inf placeholders
-        for (int k = k_done - 1; k >= 0; --k) {
-            const int g = 1 + k * A;
-            double m = LU(g);
-            for (int a = 1; a < A; ++a) {
-                const double v = LU(g + a);
-                if (v > m) m = v;
-            }
-            if (lane == 0) LU(exp_lds[k]) = m;
+        // ---- all backup_to_root calls at once (deterministic.py:67-79): bottom-up max.
+        // Upper bounds: an internal node's U is the max leaf U of its subtree, so the root's is the max over
+        // all leaves -- one parallel reduction; the other internal U's are only ever read by a tree export,
+        // which fills them in on the host from the leaf values stored here (-inf marks an internal node).
+        double root_upper = ninf;
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = LU(i);
+            U[i] = u;
+            if (u > root_upper) root_upper = u;
         }
-        __syncthreads();
-        for (int i = lane; i < n_nodes; i += 64) U[i] = LU(i);
-        const double root_upper = LU(0);
+        {
+            int dummy = 0;
+            wave_argmax(root_upper, dummy);
+        }
         __syncthreads();
         // lower bounds: same pass over the creation-time L values
         for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
@@ -422,6 +423,17 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
     std::vector<int32_t> par((size_t)n);
     par[0] = -1;
     for (int i = 1; i < n; ++i) par[i] = exp[(i - 1) / A];
+    if (upper) {
+        // the kernel stores leaf upper bounds only (-inf marks an expanded node): U[n] = max over children,
+        // bottom-up in reverse creation order (children have larger ids than their parent)
+        for (int i = n - 1; i >= 0; --i)
+            if (fc[i] >= 0) {
+                double m = upper[fc[i]];
+                for (int a = 1; a < A; ++a)
+                    if (upper[fc[i] + a] > m) m = upper[fc[i] + a];
+                upper[i] = m;
+            }
+    }
     if (first_child) memcpy(first_child, fc.data(), (size_t)n * sizeof(int32_t));
     for (int i = 0; i < n; ++i) {
         if (parent) parent[i] = par[i];
