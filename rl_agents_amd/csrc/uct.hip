@@ -88,8 +88,11 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 
 // AT > 0: |A| known at compile time (children scored from registers in one pass);
 // AT == 0: any |A| (three passes over the children).  ENV: where an env step comes from.
+#ifndef MP_UCT_MIN_WAVES
+#define MP_UCT_MIN_WAVES 1
+#endif
 template <int AT, int ENV>
-__global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64) void uct_kernel(UctArgs p)
+__global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_LDS ? 1 : MP_UCT_MIN_WAVES) void uct_kernel(UctArgs p)
 {
     constexpr bool LDSM = ENV == ENV_TABLE_LDS;
     constexpr bool CART = ENV == ENV_CARTPOLE;
