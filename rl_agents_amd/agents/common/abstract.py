@@ -50,3 +50,23 @@ class AbstractAgent(Configurable, ABC):
 
     def set_time(self, time):
         """Current time step, for schedules; unused by planners."""
+
+
+class StatelessPlannerAgent(AbstractAgent):
+    """Base of agents that hold no learnt model and no randomness of their own (value iteration): recording,
+    resetting, seeding, saving and loading are no-ops, as in the reference (``value_iteration.py:98-111``)."""
+
+    def record(self, state, action, reward, next_state, done, info):
+        return None
+
+    def reset(self):
+        return None
+
+    def seed(self, seed=None):
+        return None
+
+    def save(self, filename):
+        return False        # nothing to checkpoint
+
+    def load(self, filename):
+        return False

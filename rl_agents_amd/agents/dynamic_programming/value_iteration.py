@@ -6,12 +6,12 @@ import logging
 import numpy as np
 
 from rl_agents_amd import device_model
-from rl_agents_amd.agents.common.abstract import AbstractAgent
+from rl_agents_amd.agents.common.abstract import StatelessPlannerAgent
 
 logger = logging.getLogger(__name__)
 
 
-class ValueIterationAgent(AbstractAgent):
+class ValueIterationAgent(StatelessPlannerAgent):
     """Drop-in for ``rl_agents.agents.dynamic_programming.value_iteration.ValueIterationAgent``."""
 
     def __init__(self, env, config=None):
@@ -60,46 +60,30 @@ class ValueIterationAgent(AbstractAgent):
 
     @staticmethod
     def is_finite_mdp(env):
-        """True when ``env`` itself is a finite-MDP environment (its ``mdp`` is used as is)."""
+        """True when ``env`` itself is a finite-MDP environment, whose ``mdp`` is then used as is -- this package's
+        FiniteMDPEnv or, when installed, the ``finite_mdp`` package's (value_iteration.py:75-82)."""
         base = getattr(env, "unwrapped", env)
+        from rl_agents_amd.envs.finite_mdp import FiniteMDPEnv
+        candidates = [FiniteMDPEnv]
         try:
-            from rl_agents_amd.envs.finite_mdp import FiniteMDPEnv
-            if isinstance(base, FiniteMDPEnv):
-                return True
-        except ImportError:  # pragma: no cover
+            import importlib
+            candidates.append(importlib.import_module("finite_mdp.envs.finite_mdp_env").FiniteMDPEnv)
+        except (ImportError, AttributeError):
             pass
-        try:
-            finite_mdp = __import__("finite_mdp.envs.finite_mdp_env")
-            return isinstance(base, finite_mdp.envs.finite_mdp_env.FiniteMDPEnv)
-        except (ImportError, TypeError, AttributeError):
-            return False
+        return isinstance(base, tuple(candidates))
 
     def plan_trajectory(self, state, horizon=10):
-        """Greedy trajectory through the model (value_iteration.py:84-96)."""
-        action_value = self.get_state_action_value()
-        states, actions = [], []
+        """Greedy roll-out of the solved Q table through the model (value_iteration.py:84-96): the visited states
+        and greedy actions, ending with ``(terminal_state, None)`` when a terminal state is entered."""
+        q = self.get_state_action_value()
+        visited, chosen = [], []
         for _ in range(horizon):
-            action = np.argmax(action_value[state])
-            states.append(state)
-            actions.append(action)
-            state = self.mdp.next_state(state, action)
+            greedy = np.argmax(q[state])
+            visited.append(state)
+            chosen.append(greedy)
+            state = self.mdp.next_state(state, greedy)
             if self.mdp.terminal[state]:
-                states.append(state)
-                actions.append(None)
+                visited.append(state)
+                chosen.append(None)
                 break
-        return states, actions
-
-    def record(self, state, action, reward, next_state, done, info):
-        pass
-
-    def reset(self):
-        pass
-
-    def seed(self, seed=None):
-        pass
-
-    def save(self, filename):
-        return False
-
-    def load(self, filename):
-        return False
+        return visited, chosen
