@@ -169,7 +169,7 @@ def bench_uct(args, rank, world, local):
     d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
     d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
     p = np.ones(a_) / a_
-    gathered = [torch.empty(n_roots, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = torch.empty(world * n_roots, dtype=torch.float64, device=dev) if world > 1 else None
 
     d_total = torch.zeros(1, dtype=torch.int64, device=dev)
 
@@ -179,7 +179,7 @@ def bench_uct(args, rank, world, local):
         d_total.add_(d_steps.sum())
         if world > 1:
             import torch.distributed as dist
-            dist.all_gather(gathered, d_val)
+            dist.all_gather_into_tensor(gathered, d_val)     # per-root results to every rank: the path's only exchange
 
     for _ in range(args.warmup):
         step()
@@ -357,14 +357,14 @@ def bench_opd(args, rank, world, local):
     d_up = torch.empty(n_roots, dtype=torch.float64, device=dev)
     d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
     d_status = torch.empty(n_roots, dtype=torch.int32, device=dev)
-    gathered = [torch.empty(n_roots, dtype=torch.float64, device=dev) for _ in range(world)] if world > 1 else None
+    gathered = torch.empty(world * n_roots, dtype=torch.float64, device=dev) if world > 1 else None
 
     def step():
         ctx.opd_plan_device(model, n_roots, d_s0, budget, gamma, 0.0, d_rng, mpl, plans=d_plans, plan_len=d_len,
                             root_lower=d_lo, root_upper=d_up, env_steps=d_steps, status=d_status)
         if world > 1:
             import torch.distributed as dist
-            dist.all_gather(gathered, d_lo)
+            dist.all_gather_into_tensor(gathered, d_lo)
 
     for _ in range(args.warmup):
         step()
