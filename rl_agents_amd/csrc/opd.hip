@@ -26,6 +26,7 @@
 // HBM per root: {L f64, state i32, depth i32} 16 B + U f64 + reward f64 + first_child i32 + done u8
 // = 37 B/node; LDS per root: 8 B/node (+ 4 B per expansion for the parent map).
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -49,6 +50,7 @@ struct OpdArgs {
     double *U, *reward;
     int32_t *first_child;
     uint8_t *done;
+    double *leaf_global; // [n_roots][64 * T]: the upper-bound array of the high-occupancy variant (else nullptr)
     int32_t *expanded; // [n_roots][K] node expanded at step k (= parent of nodes 1 + kA .. 1 + kA + A - 1)
     int32_t *n_nodes_out;
     int32_t *plans, *plan_len, *status;
@@ -97,12 +99,19 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 // registers.  An expansion then costs: one 64-lane argmax over the cached class maxima, one
 // cooperative re-scan of the winner's class only (cap/64 entries, contiguous, conflict-free), and
 // one compare per lane for the new children -- instead of a scan of all cap entries.
+// GLB = false: the upper-bound array lives in LDS (44 KB per root at budget 5000 -> 3 roots per CU: lowest latency
+//               per root, the choice while all roots of the batch are resident anyway).
+// GLB = true : it lives in HBM/L2 (class-contiguous, so a class re-scan is one coalesced read) and LDS only holds
+//              the 4-byte-per-expansion parent map: 8 waves per SIMD instead of 3 per CU.  A wave of this kernel
+//              is a chain of dependent round trips (argmax -> leaf record -> model record), i.e. latency bound:
+//              ten times more resident roots hide that latency and multiply the batch throughput.
+template <bool GLB>
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = p.T;                                                // odd, >= ceil(cap / 64)
-    double *leafU = lds;                                              // [64 * T]
-    int32_t *exp_lds = reinterpret_cast<int32_t *>(lds + 64 * T);     // [K]
+    double *leafU = GLB ? p.leaf_global + (long)blockIdx.x * 64 * T : lds;      // [64 * T]
+    int32_t *exp_lds = reinterpret_cast<int32_t *>(GLB ? lds : lds + 64 * T);   // [K]
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x;
     const int root = blockIdx.x;
@@ -236,6 +245,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 if (v > m) m = v;
             }
             if (lane == 0) LU(exp_lds[k]) = m;
+            if (GLB) __syncthreads(); // the next step may read this node through memory, from other lanes
         }
         __syncthreads();
         for (int k = lane; k < k_done; k += 64) {
@@ -322,9 +332,17 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     const int K = budget / A; // deterministic.py:118
     const long cap = 1 + (long)K * A;
     const int T = (int)((cap + 63) / 64) | 1;
-    const size_t lds = (size_t)64 * T * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
-    if (lds > kLdsBytes - 1024)
-        return fail(MP_ERR_ARG, "mp_opd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds, kLdsBytes - 1024);
+    const size_t lds_full = (size_t)64 * T * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    const size_t lds_map = (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    if (lds_map > kLdsBytes - 1024)
+        return fail(MP_ERR_ARG, "mp_opd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds_map, kLdsBytes - 1024);
+    // variant: LDS-resident bounds while every root of the batch fits on the chip that way, else high occupancy
+    const char *force = getenv("MP_OPD_MODEL"); // "lds" / "global": test hook
+    const long lds_roots = (long)ctx->prop.multiProcessorCount * (long)((kLdsBytes - 1024) / (lds_full ? lds_full : 1));
+    bool glb = lds_full > kLdsBytes - 1024 || n_roots > lds_roots;
+    if (force && force[0] == 'g') glb = true;
+    if (force && force[0] == 'l' && lds_full <= kLdsBytes - 1024) glb = false;
+    const size_t lds = glb ? lds_map : lds_full;
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
@@ -350,6 +368,8 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.reward));
     MP_TRY(ws_get(ctx, WS_TREE5, nn, &a.first_child));
     MP_TRY(ws_get(ctx, WS_TREE6, nn, &a.done));
+    a.leaf_global = nullptr;
+    if (glb) MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots * 64 * T, &a.leaf_global));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
     a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
     ctx->tree.kind = 2; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
@@ -366,10 +386,11 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
     if (lds > 64 * 1024)
-        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(opd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds));
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(glb ? opd_kernel<true> : opd_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    hipLaunchKernelGGL(opd_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (glb) hipLaunchKernelGGL(opd_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL(opd_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 

@@ -126,16 +126,28 @@ def _cmp_opd(ctx, cfg, n_roots, budget, gamma, terminal_reward=0.0, seed=0, done
     return out
 
 
-def test_opd_batch_highway_budget5000(ctx):
-    """C4 shape: highway-shaped S=10 000, A=5, budget 5000 (1000 expansions, 40 KB of LDS per root)."""
+@pytest.mark.parametrize("variant", ["lds", "global"])
+def test_opd_batch_highway_budget5000(ctx, variant, monkeypatch):
+    """C4 shape: highway-shaped S=10 000, A=5, budget 5000 (1000 expansions), with the upper-bound array in LDS
+    (40 KB per root) and in HBM/L2 (the high-occupancy variant used for big batches)."""
     from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     _cmp_opd(ctx, cfg, 96, 5000, 0.8, seed=5)
 
 
-@pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (64, 640)])
-def test_opd_batch_action_counts(ctx, n_actions, budget):
+def test_opd_budget_beyond_lds(ctx):
+    """budget 25 000 (40 K of LDS would be 200 KB): only the HBM-resident bounds array can hold it."""
     from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(500, 5, seed=77, terminal_rate=0.02)
+    _cmp_opd(ctx, cfg, 6, 25000, 0.9, seed=6)
+
+
+@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (64, 640)])
+def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
     cfg = generators.random_deterministic(300, n_actions, seed=40 + n_actions, terminal_rate=0.05)
     _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
 
@@ -254,7 +266,7 @@ def test_limits_and_error_codes(ctx):
     with pytest.raises(native.NativeError) as e:                      # horizon too deep for the LDS path stack
         ctx.uct_plan(model, [0, 1], 4, 5000, 0.9, 1.0, p, p, rng, max_plan_len=4)
     assert e.value.code == native.ERR_ARG
-    with pytest.raises(native.NativeError) as e:                      # OPD budget whose leaf array exceeds LDS
+    with pytest.raises(native.NativeError) as e:                      # OPD budget whose parent map exceeds LDS
         ctx.opd_plan(model, [0, 1], 200000, 0.9, 0.0, rng)
     assert e.value.code == native.ERR_ARG
     with pytest.raises(ValueError):                                   # wrong policy length
