@@ -204,3 +204,23 @@ def test_mcts_agent_subtree_strategy(golden, tag, agent_cfg):
         np.testing.assert_array_equal(plan, z[q + "/plan"], err_msg=q)
         assert agent.planner.root.count == int(z[q + "/root_count"])
         env.step(plan[0])
+
+
+def test_plan_trajectory_follows_greedy_policy(golden):
+    """ValueIterationAgent.plan_trajectory (value_iteration.py:84-96): greedy roll-out through the model."""
+    from rl_agents_amd.agents.dynamic_programming.value_iteration import ValueIterationAgent
+    z = golden["vi"]
+    cfg = mdp_from_golden(z, "vi/highway_small/mdp")
+    env = _env(cfg)
+    agent = ValueIterationAgent(env, dict(gamma=0.95, iterations=200))
+    states, actions = agent.plan_trajectory(0, horizon=8)
+    q = z["vi/highway_small/Q"]
+    s = 0
+    for i, (st, a) in enumerate(zip(states, actions)):
+        assert st == s
+        if a is None:
+            assert cfg["terminal"][st] and i == len(states) - 1
+            break
+        assert a == np.argmax(q[st])
+        s = int(cfg["transition"][st, a])
+    assert len(states) == len(actions) <= 9
