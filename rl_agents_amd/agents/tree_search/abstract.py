@@ -113,6 +113,24 @@ class Node(object):
     def is_leaf(self):
         return not self.children
 
+    def selection_rule(self):
+        """Greedy child (no exploration) as the viewers highlight it (tree_search/graphics.py:71): for UCT nodes the
+        most visited child, ties to the larger value (mcts.py:212-218); for OPD nodes the largest lower bound
+        (deterministic.py:21-26, first maximum: a viewer must not consume the planner's random stream)."""
+        if not self.children:
+            return None
+        actions = list(self.children.keys())
+        if hasattr(self, "value_lower"):
+            return max(actions, key=lambda a: self.children[a].value_lower)
+        top = max(self.children[a].count for a in actions)
+        return max((a for a in actions if self.children[a].count == top), key=lambda a: self.children[a].get_value())
+
+    def selection_strategy(self, temperature):
+        """UCT exploration score of this node under its parent (mcts.py:275-286)."""
+        if self.parent is None:
+            return self.get_value()
+        return self.get_value() + temperature * len(self.parent.children) * getattr(self, "prior", 1.0) / (self.count + 1)
+
     def path(self):
         node, actions = self, []
         while node.parent is not None:
@@ -121,8 +139,9 @@ class Node(object):
         return actions[::-1]
 
 
-def build_tree(arrays, value_key, extra=()):
-    """Creation-order arrays (parent, action, count, <value_key>, ...) -> linked :class:`Node` objects."""
+def build_tree(arrays, value_key, extra=(), prior=None):
+    """Creation-order arrays (parent, action, count, <value_key>, ...) -> linked :class:`Node` objects.
+    ``prior``: per-action prior probabilities, attached to the nodes as ``node.prior`` (mcts.py:237-246)."""
     parent, action = arrays["parent"], arrays["action"]
     nodes = []
     for i in range(len(parent)):
@@ -131,6 +150,8 @@ def build_tree(arrays, value_key, extra=()):
                     0 if par is None else par.depth + 1)
         for name in extra:
             setattr(node, name, arrays[name][i].item())
+        if prior is not None:
+            node.prior = 1.0 if par is None else float(prior[int(action[i])])
         if par is not None:
             par.children[int(action[i])] = node
         nodes.append(node)

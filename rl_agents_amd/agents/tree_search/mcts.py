@@ -99,7 +99,8 @@ class MCTS(AbstractPlanner):
         return out
 
     def export_tree(self, root=0):
-        return build_tree(self.models.ctx.uct_tree(root), "value")
+        return build_tree(self.models.ctx.uct_tree(root), "value",
+                          prior=policy_probabilities(self.prior_policy, self._last_actions))
 
 
 class MCTSAgent(AbstractTreeSearchAgent):

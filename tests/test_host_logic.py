@@ -178,6 +178,10 @@ def test_preprocess_env_and_tree_view():
     root = build_tree(arrays, "value")
     assert sorted(root.children) == [0, 1] and root.children[0].children[1].path() == [0, 1]
     assert root.children[0].children[0].depth == 2 and root.children[1].is_leaf() and root.get_value() == .5
+    assert root.selection_rule() == 0 and root.children[0].selection_rule() == 0 and root.children[1].selection_rule() is None
+    with_prior = build_tree(arrays, "value", prior=[0.25, 0.75])
+    child = with_prior.children[1]
+    assert child.prior == 0.75 and child.selection_strategy(10.0) == .4 + 10.0 * 2 * 0.75 / (2 + 1)
 
 
 def test_shard_bounds_cover_everything():
