@@ -25,12 +25,23 @@ def rank_world():
     return 0, 1
 
 
+def collective_device():
+    """Device the process group's collectives need their tensors on: the current GPU for nccl (= RCCL), CPU for gloo."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return None
+
+
 def all_gather_rows(local, n_total, device=None):
     """Gather row blocks (numpy [n_local, ...], sharded by :func:`shard_bounds`) into the full [n_total, ...] array
     on every rank.  Blocks are padded to the largest shard so that one fixed-size all_gather suffices."""
     import torch
     import torch.distributed as dist
     rank, world = rank_world()
+    if device is None:
+        device = collective_device()
     local = np.ascontiguousarray(local)
     if world == 1:
         return local
@@ -116,7 +127,7 @@ def vi_solve_row_sharded(ctx, transition, reward, terminal=None, gamma=1.0, iter
         if world > 1:
             import torch
             import torch.distributed as dist
-            flag = torch.tensor([1 if close else 0], dtype=torch.int32)
+            flag = torch.tensor([1 if close else 0], dtype=torch.int32, device=collective_device() or "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             close = bool(flag.item())
         if close:
