@@ -172,6 +172,13 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
         }
     }
     int steps_taken = 0;
+    // statistics of the path nodes at depths 2..5 as read by the selection of this episode (nobody else writes
+    // them in between): the backup then needs no read for them (~16 % of the saturated kernel's time was those reads)
+    constexpr int KEEP = (AT > 0 && AT <= 5) ? 4 : 2; // register budget: stay within 128 VGPRs (4 waves per SIMD)
+    double kv[KEEP];
+    int kc[KEEP];
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) { kv[i] = 0.0; kc[i] = 0; }
 
 #ifdef MP_PROFILE
     long long t_sel = 0, t_expd = 0, t_roll = 0, t_bak = 0, n_sel = 0, n_roll = 0;
@@ -216,12 +223,20 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                 for (int a = 0; a < AR; ++a) nt += sc[a] == m ? 1 : 0;
                 int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
                 bool found = false;
+                double sel_v = 0.0;
+                int sel_c = 0;
 #pragma unroll
                 for (int a = 0; a < AR; ++a) {
                     const bool eq = sc[a] == m;
-                    if (eq && !found && pick == 0) { act = a; nfc = c[a].first_child; found = true; }
+                    if (eq && !found && pick == 0) {
+                        act = a; nfc = c[a].first_child; found = true;
+                        sel_v = c[a].value; sel_c = c[a].count;
+                    }
                     if (eq && !found) --pick;
                 }
+#pragma unroll
+                for (int i = 0; i < KEEP; ++i)
+                    if (depth + 1 == 2 + i) { kv[i] = sel_v; kc[i] = sel_c; }
             } else {
                 double m = 0.0;
                 for (int a = 0; a < A; ++a) {
@@ -359,10 +374,22 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
         // ---- backup, mcts.py:248-265: the same return for every node on the path
         for (int d = depth; d >= (RC ? 2 : 0); --d) {
             const int n = path[d * nthreads + lane];
-            UctNode c = tree[n];
-            c.count += 1;
-            c.value += inv(c.count) * (total - c.value);
-            tree[n] = c;
+            if (RC && d < 2 + KEEP) {
+                double v = kv[0];
+                int cnt = kc[0];
+#pragma unroll
+                for (int i = 1; i < KEEP; ++i) { v = d == 2 + i ? kv[i] : v; cnt = d == 2 + i ? kc[i] : cnt; }
+                cnt += 1;
+                v += inv(cnt) * (total - v);
+                tree[n].value = v;       // first_child is left alone (the node may just have been expanded)
+                tree[n].count = cnt;
+            } else {
+                UctNode c = tree[n];
+                c.count += 1;
+                c.value += inv(c.count) * (total - c.value);
+                tree[n].value = c.value;
+                tree[n].count = c.count;
+            }
         }
         if (RC) {
             if (depth >= 1) {
