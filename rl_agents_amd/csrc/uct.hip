@@ -6,24 +6,26 @@
 // common/factory.py:119-134) is an (int32 state, int32 steps) register pair.  A batch takes as
 // long as its slowest lane's dependency chain, so the kernel is built to shorten that chain:
 //
-//   model   LDS variant (S < 32768 and S*A*2 B fits): the transition table is staged once per
-//           workgroup into LDS as uint16 {bit15 = terminal[next], next state}; an env step on the
-//           critical chain is one ds_read_u16 (~100 cycles) instead of an L2 gather (~400).  The
-//           reward of a step is fetched from HBM/L2 off the chain (software-pipelined by one
-//           step; additions stay in the reference's order).
-//           Global variant (any S): one 16-byte record {next, flags, reward} per (s,a), a single
-//           dwordx4 gather per env step.
-//   rng     numpy PCG64 stepped per lane (pcg64.hpp); the draw for step h+1 is computed
-//           speculatively while step h's lookup is in flight and committed only if the rollout
-//           continues, so the stream stays bit-identical to the reference's.
-//   tables  gamma**h, the rollout cdf, 1/n and temperature*|A|*prior[a]/n for every visit count
-//           n are computed on the host with the reference's own operations (libm pow, IEEE
-//           divide) and read from LDS: no f64 division on the device, same bits.
+//   model   default: one 16-byte record {next, flags, reward} per (s,a), a single dwordx4 gather per
+//           env step (any S).  MP_UCT_MODEL=lds (S < 32768 and S*A*2 B fits): the transition table is
+//           staged once per workgroup into LDS as uint16 {bit15 = terminal[next], next state} and the
+//           step's reward is fetched off the chain, added one step later in the reference's order.
+//           Measured slower (0.376 vs 0.338 ms at 4096 roots): the chain is instruction-bound.
+//           ENV_CARTPOLE: closed-form dynamics, state in registers.
+//   rng     numpy PCG64 stepped per lane (pcg64.hpp, 128-bit multiply on 32-bit limbs); the draw for
+//           step h+1 is computed on a second generator copy while step h's lookup is in flight and
+//           kept only if the rollout continues, so the stream stays bit-identical to the reference's.
+//           Rollout actions come from integer thresholds ceil(cdf * 2^53) <= (next64 >> 11).
+//   tables  gamma**h, the thresholds, 1/n and temperature*|A|*prior[a]/n for every visit count n of a
+//           fresh tree are computed on the host with the reference's own operations (libm pow, IEEE
+//           divide) and read from LDS; larger counts (kept trees) use the device's IEEE division.
 //   tree    Node[n_roots][cap] root-major 16-byte records {value f64, count i32, first_child i32}
-//           in HBM (L2-resident at BASELINE sizes); the A children of a node are contiguous.
-//           cap = 1 + episodes*A (at most one expansion per episode).
+//           in HBM; the A children of a node are contiguous.  cap = 1 + episodes*A (+ the kept tree).
+//           The root and its children (ids 0..A) live in registers for the whole plan, and the path
+//           nodes of depths 2..5 keep the statistics their selection read until the backup: the
+//           saturated kernel is bound by L2/HBM requests, and these remove a third of them.
 //   path    per-lane stack of visited node ids in LDS ([depth][lane], conflict-free): the backup
-//           is a pipelined read-modify-write over known addresses, not a parent-pointer chase.
+//           walks known addresses, not parent pointers.
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
