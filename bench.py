@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_cartpole", "opd", "vi", "vi_dense"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_cartpole", "opd", "vi", "rvi", "vi_dense"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -408,14 +408,28 @@ def bench_opd(args, rank, world, local):
     return res
 
 
-def bench_vi(args, rank, world, local, dense):
+def bench_vi(args, rank, world, local, dense, robust=False):
     import torch
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
     ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
     gamma, sweeps = 0.95, 200
     dev = torch.device("cuda", local)
-    if dense:
+    n_models = 1
+    if robust:
+        # BASELINE config C5, deterministic form: intersection-shaped table S = 50 000, A = 5, M = 2 models
+        # (the second with 10 % of the transitions rewired), min over models in every backup
+        cfg = generators.highway_shaped(10, 50, 100, seed=2)
+        cfg2 = generators.rewire(cfg, 0.1, seed=3)
+        t = np.stack([cfg["transition"], cfg2["transition"]])
+        r = np.stack([cfg["reward"], cfg2["reward"] * 0.97])
+        term = None
+        n_models, (s_, a_) = 2, cfg["reward"].shape
+        model = ctx.load_table(t, r)
+        alg = 12.0 * n_models * s_ * a_ + 17.0 * s_
+        flops = 0.0
+        name = "vi_det_sweep (robust, M=2)"
+    elif dense:
         s_, a_ = (args.states or 10000), 5
         g = torch.Generator(device=dev)
         g.manual_seed(0)
@@ -437,7 +451,7 @@ def bench_vi(args, rank, world, local, dense):
         name = "vi_det_sweep"
 
     def step():
-        ctx.vi_sweeps(model, gamma, sweeps)
+        ctx.vi_sweeps(model, gamma, sweeps, robust=robust)
 
     for _ in range(args.warmup):
         step()
@@ -453,7 +467,8 @@ def bench_vi(args, rank, world, local, dense):
     res = dict(
         metric="value-iteration Bellman sweeps/sec", unit="sweeps/s", value=world * sweeps * args.steps / dt,
         ms_per_step=1e3 * dt / args.steps, dtype="f64",
-        config=dict(workload="{}_S{}_A{}_{}sweeps".format("vi_dense" if dense else "vi_highway_shaped", s_, a_, sweeps),
+        config=dict(workload="{}_S{}_A{}_{}sweeps".format("robust_vi_intersection_shaped_M2" if robust else
+                                                       ("vi_dense" if dense else "vi_highway_shaped"), s_, a_, sweeps),
                     states=s_, actions=a_, gamma=gamma, ms_per_sweep=1e3 * dt / args.steps / sweeps,
                     parallelism="replicas only ({} GPU(s))".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (per_sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
@@ -469,7 +484,8 @@ def bench_vi(args, rank, world, local, dense):
         t1 = time.perf_counter()
         reps = 0
         while time.perf_counter() - t1 < args.cpu_seconds:
-            oracle.vi_solve("deterministic", t, r, term, gamma=gamma, iterations=sweeps, rtol=-1.0, atol=-1.0)
+            oracle.vi_solve("deterministic", t, r, term, gamma=gamma, iterations=sweeps, rtol=-1.0, atol=-1.0,
+                            robust=robust)
             reps += 1
         cdt = time.perf_counter() - t1
         res["cpu_baseline"] = dict(value=reps * sweeps / cdt, unit="sweeps/s", cores=1, kind="port",
@@ -493,7 +509,7 @@ def main():
         elif args.workload == "opd":
             res = bench_opd(args, rank, world, local)
         else:
-            res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense")
+            res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
     res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                vs_baseline=None, data="synthetic (highway-shaped finite MDP; real highway_env absent)")
     res.setdefault("cpu_baseline", None)

@@ -92,6 +92,30 @@ __global__ __launch_bounds__(64) void vi_det_sweep(ViDetArgs p)
             }
             if (a == 0 || qn > vmax) vmax = qn;
         }
+    } else if (AT > 0) {
+        // robust (robust_value_iteration.py:46-58): min over models, per model all |A| loads issued together
+        constexpr int AR = AT > 0 ? AT : 1;
+        const long msa = (long)p.S * AR, sa0 = (long)s * AR;
+        double bn[AR], bo[AR];
+        for (int m = 0; m < p.M; ++m) {
+            int32_t t[AR];
+            double r[AR], vc[AR], vp[AR];
+#pragma unroll
+            for (int a = 0; a < AR; ++a) { t[a] = p.T[m * msa + sa0 + a]; r[a] = p.R[m * msa + sa0 + a]; }
+#pragma unroll
+            for (int a = 0; a < AR; ++a) { vc[a] = p.Vcur[t[a]]; vp[a] = p.Vprev[t[a]]; }
+#pragma unroll
+            for (int a = 0; a < AR; ++a) {
+                const double qm = r[a] + p.gamma * vc[a], qp = r[a] + p.gamma * vp[a];
+                if (m == 0 || qm < bn[a]) bn[a] = qm;
+                if (m == 0 || qp < bo[a]) bo[a] = qp;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < AR; ++a) {
+            if (!p.vform) nc |= !isclose_np(p.k == 0 ? 0.0 : bo[a], bn[a], p.rtol, p.atol);
+            if (a == 0 || bn[a] > vmax) vmax = bn[a];
+        }
     } else {
         for (int a = 0; a < p.A; ++a) {
             const long sa = (long)s * p.A + a;
@@ -213,7 +237,7 @@ static int vi_small_launch(const ViSmallArgs &q, size_t lds, int threads, hipStr
 static void vi_det_launch(const ViDetArgs &a, hipStream_t st)
 {
     const dim3 grid((unsigned)((a.S + 63) / 64)), block(64);
-    switch (a.robust ? 0 : a.A) {
+    switch (a.A) {
     case 2: hipLaunchKernelGGL(vi_det_sweep<2>, grid, block, 0, st, a); break;
     case 3: hipLaunchKernelGGL(vi_det_sweep<3>, grid, block, 0, st, a); break;
     case 4: hipLaunchKernelGGL(vi_det_sweep<4>, grid, block, 0, st, a); break;
