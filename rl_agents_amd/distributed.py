@@ -136,3 +136,59 @@ def vi_solve_row_sharded(ctx, transition, reward, terminal=None, gamma=1.0, iter
         v = all_gather_rows(q_local.max(axis=-1), n_states)
     model.close()
     return all_gather_rows(q_local, n_states), sweeps
+
+
+def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows, n_states, rows, gamma=1.0,
+                                iterations=100, robust=False, rtol=1e-5, atol=1e-8):
+    """Device-resident form of :func:`vi_solve_row_sharded`: this rank's row block is already on the GPU.
+
+    ``transition_rows`` / ``reward_rows``: torch CUDA tensors [.., hi-lo, A, S] / [.., hi-lo, A] (borrowed, not
+    copied: at C5 size a block is 12.5 GB per model); ``terminal_rows``: torch uint8 [hi-lo] or None; ``rows`` =
+    (lo, hi).  Every sweep stays on the device: ``mp_vi_backup`` enqueues on the ctx stream, max_a / isclose run as
+    torch ops, V is exchanged with one ``all_gather_into_tensor`` (RCCL) -- shards are padded to equal length -- and
+    only the 4-byte convergence flag comes back to the host.  ``ctx`` must enqueue on torch's current stream
+    (``native.Context(device, torch.cuda.current_stream().cuda_stream)``).  Returns (Q [S, A] tensor, sweeps)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = rank_world()
+    lo, hi = rows
+    dev = transition_rows.device
+    n_actions = reward_rows.shape[-1]
+    model = ctx.load_dense_rows(transition_rows, reward_rows, None if robust else terminal_rows)
+    per = -(-n_states // world)                                # padded shard length
+    v = torch.zeros(n_states, dtype=torch.float64, device=dev)
+    v_pad = torch.zeros(world * per, dtype=torch.float64, device=dev)
+    v_loc = torch.zeros(per, dtype=torch.float64, device=dev)
+    q_local = torch.zeros((hi - lo, n_actions), dtype=torch.float64, device=dev)
+    q_next = torch.empty_like(q_local)
+    sweeps = 0
+    for _ in range(int(iterations)):
+        ctx.vi_backup(model, gamma, v, q_out=q_next, robust=robust)
+        sweeps += 1
+        close = torch.isclose(q_local, q_next, rtol=rtol, atol=atol).all().to(torch.int32).reshape(1)
+        if world > 1:
+            dist.all_reduce(close, op=dist.ReduceOp.MIN)
+        if bool(close.item()):
+            break
+        q_local, q_next = q_next, q_local
+        v_loc.zero_()
+        v_loc[:hi - lo] = q_local.max(dim=-1).values
+        if world > 1:
+            dist.all_gather_into_tensor(v_pad, v_loc)
+            for r in range(world):
+                rlo, rhi = shard_bounds(n_states, r, world)
+                v[rlo:rhi] = v_pad[r * per:r * per + (rhi - rlo)]
+        else:
+            v[lo:hi] = v_loc[:hi - lo]
+    model.close()
+    if world > 1:
+        q_pad = torch.zeros((per, n_actions), dtype=torch.float64, device=dev)
+        q_pad[:hi - lo] = q_local
+        q_all = torch.empty((world * per, n_actions), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(q_all, q_pad)
+        parts = []
+        for r in range(world):
+            rlo, rhi = shard_bounds(n_states, r, world)
+            parts.append(q_all[r * per:r * per + (rhi - rlo)])
+        return torch.cat(parts), sweeps
+    return q_local, sweeps
