@@ -55,6 +55,7 @@ struct UctArgs {
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
     const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[E+1] | tpdiv[A][E+2]
+    uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8): kernel arguments live in SGPRs
     uint64_t *rng;
     UctNode *tree;
     const int32_t *n_nodes_in; // kept (re-rooted) tree sizes, nullptr = every root starts fresh
@@ -325,11 +326,13 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                 int act = 0;
                 if (AT > 0) {
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) act += thr[a] <= u ? 1 : 0;
+                    for (int a = 0; a < AR; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands
                 } else {
                     for (int a = 0; a < A; ++a) act += thr[a] <= u ? 1 : 0;
                 }
                 g_mine = gpow[h];
+                // 32-bit record index (S * |A| < 2^31): one multiply-add instead of a 64-bit address chain
+                const unsigned ridx = (unsigned)(s * A + act);
                 bool term_h;
                 if (CART) {
                     gspec = gcur;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                     term_h = cartpole_step(p.cp, x4, act);
                     total += g_mine * 1.0;
                 } else if (LDSM) {
-                    const long idx = (long)s * A + act;
+                    const unsigned idx = ridx;
                     const uint32_t e = t16[idx];
                     r_mine = rec[idx].reward;
                     gspec = gcur;
@@ -348,7 +351,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                     cur_term = next_term;
                     s = (int32_t)(e & 0x7fffu);
                 } else {
-                    const Rec rc = rec[(long)s * A + act];
+                    const Rec rc = rec[ridx];
                     gspec = gcur;
                     unext = gspec.next64() >> 11; // overlaps the gather
                     term_h = (rc.flags & done_bit) != 0;
@@ -585,6 +588,10 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.episodes = episodes; a.horizon = horizon; a.cap = (int)cap;
     a.done_on_next = model->done_on_next; a.max_steps = model->max_steps; a.max_plan_len = max_plan_len;
     a.rec = model->rec; a.t16 = model->t16; a.tab = d_tab;
+    for (int i = 0; i < 8; ++i) {
+        a.thr_arg[i] = ~0ULL;
+        if (i < A) memcpy(&a.thr_arg[i], &cdf[i], sizeof(uint64_t));
+    }
     a.cp = model->cp; a.root_x = nullptr;
 
     // variant and geometry
