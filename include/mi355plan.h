@@ -161,6 +161,23 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
                 int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
                 int64_t *env_steps, int32_t mem);
 /*
+ * Per-state prior / rollout policies: MCTSWithPriorPolicyAgent (tree_search/mcts_with_prior.py:8-71) replaces the
+ * planner's two policies by agent_policy_available (:47-62), the action distribution a prior agent gives for the state
+ * the policy is asked about.  On a finite MDP that is a table:
+ *   prior   double [S,A]  prior[s,a]   = probability handed to MCTSNode.expand when a node reached in state s is expanded
+ *   rollout double [S,A]  rollout[s,:] = distribution MCTS.evaluate samples from in state s (Generator.choice(p=...))
+ * Host pointers (policy upload is outside every timed region, like model upload).  |A| must be one of 2,3,4,5,6,8.
+ * mp_uct_plan_policy = mp_uct_plan with (prior_p, rollout_p) looked up per state; everything else is identical,
+ * including mp_uct_step_tree / mp_uct_tree_export on the trees it leaves.
+ */
+typedef struct mp_policy mp_policy;
+int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, mp_policy **out);
+int mp_policy_free(mp_policy *policy);
+int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const void *root_state,
+                       const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                       uint64_t *rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
+                       int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem);
+/*
  * AbstractPlanner.step_tree with step_strategy "subtree" (abstract.py:172-206): before the next mp_uct_plan, replace
  * the tree of every root left on this ctx by the last mp_uct_plan with the subtree of the root's child `actions[i]`
  * (a root that was never expanded starts a fresh tree, like step_by_reset).  The next mp_uct_plan must have the same

@@ -60,8 +60,11 @@ def _u8(a):
 
 
 def policy_cdf(p):
-    """cdf exactly as numpy's Generator.choice builds it: cumsum(p) / cumsum(p)[-1]."""
-    cdf = np.asarray(p, dtype=np.float64).cumsum()
+    """cdf exactly as numpy's Generator.choice builds it: cumsum(p) / cumsum(p)[-1] (row by row for a [S, A] table)."""
+    p = np.asarray(p, dtype=np.float64)
+    if p.ndim == 2:
+        return np.ascontiguousarray(np.stack([policy_cdf(row) for row in p]))
+    cdf = p.cumsum()
     cdf /= cdf[-1]
     return cdf
 
@@ -165,7 +168,8 @@ def cartpole_params(params):
 def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
              rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64, cartpole=None, init_tree=None):
     """One root. Table env: transition/reward/terminal + integer s0. CartPole: cartpole=params dict, s0 = 4 doubles.
-    init_tree: dict(count, value, first_child) kept from the previous plan (step_strategy "subtree")."""
+    init_tree: dict(count, value, first_child[, prior]) kept from the previous plan (step_strategy "subtree").
+    prior_p / rollout_p of shape [S, A]: per-state policies (mcts_with_prior.py:47-62)."""
     cp = x0 = None
     if cartpole is not None:
         cp, max_steps = cartpole_params(cartpole)
@@ -180,11 +184,14 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
     cap = max(n_init, 1) + episodes * a
     rng = np.array(rng_state, dtype=np.uint64)
     prior = _f64(prior_p)
+    state_policy = int(prior.ndim == 2)
+    assert state_policy == int(np.ndim(rollout_p) == 2)
     cdf = policy_cdf(rollout_p)
+    ip = None if not (n_init and "prior" in init_tree) else _f64(init_tree["prior"])
     plan = np.full(max_plan_len, -1, dtype=np.int32)
     plan_len, steps, nn = C.c_int32(), C.c_int64(), C.c_int32()
     tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), count=np.zeros(cap, np.int64),
-                value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32))
+                value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32), prior=np.zeros(cap, np.float64))
     rc = lib().orc_uct_plan(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
                             int(done_rule == "next"), int(max_steps), int(s0), int(steps0), int(episodes),
                             int(horizon), C.c_double(gamma), C.c_double(temperature), _p(prior, C.c_double),
@@ -193,7 +200,7 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
                             _p(tree["action"], C.c_int32), _p(tree["count"], C.c_int64),
                             _p(tree["value"], C.c_double), _p(tree["first_child"], C.c_int32), C.byref(nn),
                             _p(cp, C.c_double), _p(x0, C.c_double), int(n_init), _p(ic, C.c_int64), _p(iv, C.c_double),
-                            _p(ifc, C.c_int32))
+                            _p(ifc, C.c_int32), state_policy, _p(tree["prior"], C.c_double), _p(ip, C.c_double))
     assert rc == 0, rc
     tree = {k: v[:nn.value].copy() for k, v in tree.items()}
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, tree=tree)
@@ -203,15 +210,21 @@ def uct_reroot(tree, action, n_actions):
     """AbstractPlanner.step_by_subtree on an exported tree dict -> re-rooted tree dict, or None for a fresh tree."""
     n = len(tree["count"])
     oc, ov, ofc = np.zeros(n, np.int64), np.zeros(n, np.float64), np.zeros(n, np.int32)
+    pr = _f64(tree["prior"]) if "prior" in tree else None
+    opr = np.zeros(n, np.float64) if pr is not None else None
     n_out = C.c_int32()
     rc = lib().orc_uct_reroot(int(n_actions), n, _p(_i64(tree["count"]), C.c_int64), _p(_f64(tree["value"]), C.c_double),
                               _p(np.ascontiguousarray(tree["first_child"], np.int32), C.c_int32), int(action),
-                              _p(oc, C.c_int64), _p(ov, C.c_double), _p(ofc, C.c_int32), C.byref(n_out))
+                              _p(oc, C.c_int64), _p(ov, C.c_double), _p(ofc, C.c_int32), C.byref(n_out),
+                              _p(pr, C.c_double), _p(opr, C.c_double))
     assert rc == 0
     if n_out.value == 0:
         return None
     k = n_out.value
-    return dict(count=oc[:k], value=ov[:k], first_child=ofc[:k])
+    out = dict(count=oc[:k], value=ov[:k], first_child=ofc[:k])
+    if opr is not None:
+        out["prior"] = opr[:k]
+    return out
 
 
 def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
@@ -230,6 +243,7 @@ def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, t
     st0 = None if steps0 is None else np.ascontiguousarray(steps0, dtype=np.int32)
     rng = np.array(rng_states, dtype=np.uint64).reshape(n, 6)
     prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
+    state_policy = int(prior.ndim == 2)
     plans = np.full((n, max_plan_len), -1, dtype=np.int32)
     plan_len = np.zeros(n, np.int32)
     root_value = np.zeros(n, np.float64)
@@ -242,7 +256,7 @@ def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, t
                                   _p(prior, C.c_double), _p(cdf, C.c_double), _p(rng, C.c_uint64), max_plan_len,
                                   _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(root_value, C.c_double),
                                   _p(cc, C.c_int64), _p(cv, C.c_double), _p(steps, C.c_int64), int(n_threads),
-                                  _p(cp, C.c_double), _p(x0, C.c_double))
+                                  _p(cp, C.c_double), _p(x0, C.c_double), state_policy)
     assert rc == 0, rc
     return dict(plans=plans, plan_len=plan_len, root_value=root_value, root_child_count=cc,
                 root_child_value=cv, env_steps=steps, rng_after=rng)

@@ -438,6 +438,9 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
  * mcts.py:100-184 (MCTS planner) + mcts.py:203-286 (MCTSNode) for one root, open loop.
  * prior[a] / rollout_cdf[a]: the state-independent policies of mcts.py:46-97 over actions
  * 0..A-1 (a table env has no get_available_actions); the cdf is numpy's cumsum(p)/cumsum(p)[-1].
+ * state_policy != 0: prior / rollout_cdf are [S][A] tables indexed by the state the policy is asked about
+ * (MCTSWithPriorPolicyAgent.agent_policy, mcts_with_prior.py:47-62: both policies come from a prior agent's
+ * action distribution in that state).  A child's prior is stored when its parent is expanded (mcts.py:237-246).
  * Node arrays are in creation order: root = 0, each expansion appends A children.
  * Capacity 1 + episodes*A (one expansion per episode at most, mcts.py:151-154).
  */
@@ -453,27 +456,34 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
                  /* step_strategy "subtree" (abstract.py:195-206): the tree kept from the previous plan, creation
                   * order with contiguous children (n_init = 0: fresh root).  Tree exports then need capacity
                   * n_init + episodes*A. */
-                 int n_init, const int64_t *init_count, const double *init_value, const int32_t *init_first_child)
+                 int n_init, const int64_t *init_count, const double *init_value, const int32_t *init_first_child,
+                 /* per-state policies; t_prior / init_prior: the stored child priors (export / kept tree), or NULL */
+                 int state_policy, double *t_prior, const double *init_prior)
 {
     orc_env env = {S, A, T, R, term, done_on_next, max_steps, cp};
+    if (state_policy && cp) return ORC_ERR_ARG;
     const int cap = (n_init > 0 ? n_init : 1) + episodes * A;
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
     int32_t *first_child = malloc(cap * sizeof(int32_t));
     int64_t *count = malloc(cap * sizeof(int64_t));
     double *value = malloc(cap * sizeof(double)), *gpow = malloc((horizon + 1) * sizeof(double));
+    double *nprior = malloc(cap * sizeof(double));
     double *score = malloc((A > 0 ? A : 1) * sizeof(double));
     int *ties = malloc((A > 0 ? A : 1) * sizeof(int));
-    if (!parent || !action || !first_child || !count || !value || !gpow || !score || !ties) return ORC_ERR_ALLOC;
+    if (!parent || !action || !first_child || !count || !value || !gpow || !nprior || !score || !ties) return ORC_ERR_ALLOC;
     for (int h = 0; h <= horizon; ++h) gpow[h] = pow(gamma, h); /* Python: gamma ** h */
     orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
     /* mcts.py:129-130 reset(): fresh root (value 0, count 0, prior 1) */
-    parent[0] = -1; action[0] = -1; first_child[0] = -1; count[0] = 0; value[0] = 0;
+    parent[0] = -1; action[0] = -1; first_child[0] = -1; count[0] = 0; value[0] = 0; nprior[0] = 1;
     int n_nodes = 1;
     if (n_init > 0) { /* continue on the re-rooted tree */
         for (int i = 0; i < n_init; ++i) {
             count[i] = init_count[i]; value[i] = init_value[i]; first_child[i] = init_first_child[i];
             if (first_child[i] >= 0)
-                for (int a = 0; a < A; ++a) { parent[first_child[i] + a] = i; action[first_child[i] + a] = a; }
+                for (int a = 0; a < A; ++a) {
+                    parent[first_child[i] + a] = i; action[first_child[i] + a] = a;
+                    nprior[first_child[i] + a] = init_prior ? init_prior[first_child[i] + a] : prior[a];
+                }
         }
         n_nodes = n_init;
     }
@@ -490,7 +500,7 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
             /* mcts.py:275-286: value + temperature * len(parent.children) * prior / (count + 1) */
             double m = 0;
             for (int a = 0; a < A; ++a) {
-                score[a] = value[fc + a] + temperature * A * prior[a] / (double)(count[fc + a] + 1);
+                score[a] = value[fc + a] + temperature * A * nprior[fc + a] / (double)(count[fc + a] + 1);
                 if (a == 0 || score[a] > m) m = score[a];
             }
             int nt = 0;
@@ -510,12 +520,13 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
             for (int a = 0; a < A; ++a) {
                 const int c = n_nodes++;
                 parent[c] = node; action[c] = a; first_child[c] = -1; count[c] = 0; value[c] = 0;
+                nprior[c] = state_policy ? prior[(long)s * A + a] : prior[a]; /* prior_policy(state, observation) */
             }
         }
         /* mcts.py:156-157,160-177 rollout */
         if (!terminal) {
             for (int h = depth; h < horizon; ++h) {
-                const int a = orc_cdf_pick(rollout_cdf, A, orc_pcg64_double(&g));
+                const int a = orc_cdf_pick(state_policy ? rollout_cdf + (long)s * A : rollout_cdf, A, orc_pcg64_double(&g));
                 double r; int term_h, trunc_h;
                 if (cp) orc_cartpole_step(&env, x4, &st, a, &r, &term_h, &trunc_h);
                 else orc_env_step(&env, &s, &st, a, &r, &term_h, &trunc_h);
@@ -554,9 +565,10 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
         if (t_count) t_count[i] = count[i];
         if (t_value) t_value[i] = value[i];
         if (t_first_child) t_first_child[i] = first_child[i];
+        if (t_prior) t_prior[i] = nprior[i];
     }
     if (n_nodes_out) *n_nodes_out = n_nodes;
-    free(parent); free(action); free(first_child); free(count); free(value); free(gpow); free(score); free(ties);
+    free(parent); free(action); free(first_child); free(count); free(value); free(gpow); free(nprior); free(score); free(ties);
     return ORC_OK;
 }
 
@@ -566,7 +578,8 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
  * Nodes are re-numbered breadth-first so that children stay contiguous.  Arrays of capacity n_in.
  */
 int orc_uct_reroot(int A, int n_in, const int64_t *count, const double *value, const int32_t *first_child, int action,
-                   int64_t *o_count, double *o_value, int32_t *o_first_child, int32_t *n_out)
+                   int64_t *o_count, double *o_value, int32_t *o_first_child, int32_t *n_out,
+                   const double *prior, double *o_prior /* stored child priors, or NULL */)
 {
     if (n_in < 1 || first_child[0] < 0 || action < 0 || action >= A) { *n_out = 0; return ORC_OK; }
     int32_t *src = malloc((size_t)n_in * sizeof(int32_t));
@@ -577,6 +590,7 @@ int orc_uct_reroot(int A, int n_in, const int64_t *count, const double *value, c
         const int o = src[head];
         o_count[head] = count[o];
         o_value[head] = value[o];
+        if (prior && o_prior) o_prior[head] = prior[o];
         if (first_child[o] >= 0) {
             o_first_child[head] = tail;
             for (int a = 0; a < A; ++a) src[tail + a] = first_child[o] + a;
@@ -603,7 +617,7 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
                        int32_t *plans /* [n_roots,max_plan_len] */, int32_t *plan_len, double *root_value,
                        int64_t *root_child_count /* [n_roots,A] */, double *root_child_value /* [n_roots,A] */,
                        int64_t *env_steps /* [n_roots] */, int n_threads,
-                       const double *cp, const double *x0 /* [n_roots,4] or NULL */)
+                       const double *cp, const double *x0 /* [n_roots,4] or NULL */, int state_policy)
 {
     int rc_all = ORC_OK;
     const int cap = 1 + episodes * A;
@@ -616,7 +630,7 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
                               horizon, gamma, temperature, prior, rollout_cdf, rng6 + (long)i * 6, max_plan_len,
                               plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
                               env_steps ? env_steps + i : NULL, NULL, NULL, cnt, val, NULL, &nn, cp,
-                              x0 ? x0 + (long)i * 4 : NULL, 0, NULL, NULL, NULL);
+                              x0 ? x0 + (long)i * 4 : NULL, 0, NULL, NULL, NULL, state_policy, NULL, NULL);
         if (rc != ORC_OK) {
 #pragma omp critical
             rc_all = rc;

@@ -104,6 +104,17 @@ struct mp_model {
     mp_cartpole_params cp;
 };
 
+// per-state prior / rollout policies of one model (mcts_with_prior.py:47-62), device
+struct mp_policy {
+    mp_ctx *ctx = nullptr;
+    int S = 0, A = 0;
+    int stride = 0;             // doubles per row of prior / thr: A rounded up to even (16-byte rows)
+    int frq = 0;                // 16-byte chunks per fused record: 1 + A/2
+    double *prior = nullptr;    // [S][stride]  prior[s][a]
+    uint64_t *thr = nullptr;    // [S][stride]  ceil(cdf[s][a] * 2^53), a < A-1 (the last threshold is never reached)
+    uint4 *frec = nullptr;      // [S*A][frq]   {Rec of (s,a); thr row of the state it leads to}
+};
+
 namespace mp {
 
 // grow-only device workspace

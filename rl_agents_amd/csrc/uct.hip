@@ -30,6 +30,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <new>
 #include <vector>
 
 #include "common.hpp"
@@ -56,6 +57,12 @@ struct UctArgs {
     mp_cartpole_params cp;
     const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[E+1] | tpdiv[A][E+2]
     uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8): kernel arguments live in SGPRs
+    // per-state policies (mp_policy): nullptr / 0 for the state-independent ones
+    const double *pol_prior; // [S][pol_stride]
+    const uint64_t *pol_thr; // [S][pol_stride]
+    const uint4 *pol_frec;   // [S*A][1 + A/2]
+    int pol_stride;
+    double TA;               // temperature * |A|  (mcts.py:286, left to right)
     uint64_t *rng;
     UctNode *tree;
     const int32_t *n_nodes_in; // kept (re-rooted) tree sizes, nullptr = every root starts fresh
@@ -94,9 +101,17 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 #ifndef MP_UCT_MIN_WAVES
 #define MP_UCT_MIN_WAVES 1
 #endif
-template <int AT, int ENV>
+// SP: the prior and the rollout distribution are rows of per-state tables (mcts_with_prior.py:47-62).  The env is
+// deterministic, so the state a node is reached in is a function of its action sequence and the prior stored in a
+// child at expansion (mcts.py:237-246) is prior[state of the parent][action]: it is looked up with the state the
+// descent is in, not stored.  Rollouts read a fused 16*(1 + A/2)-byte record per step -- the (s,a) record followed by
+// the sampling thresholds of the state it leads to -- so the per-step dependency chain stays one gather long.
+template <int AT, int ENV, bool SP = false>
 __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_LDS ? 1 : MP_UCT_MIN_WAVES) void uct_kernel(UctArgs p)
 {
+    static_assert(!SP || (AT > 0 && ENV == ENV_TABLE), "per-state policies: table env, |A| known at compile time");
+    constexpr int NQ = AT / 2;  // 16-byte chunks holding the AT-1 thresholds of a state
+    constexpr int NTH = AT > 1 ? AT - 1 : 1;
     constexpr bool LDSM = ENV == ENV_TABLE_LDS;
     constexpr bool CART = ENV == ENV_CARTPOLE;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
@@ -174,6 +189,9 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
             }
         }
     }
+    double tp0[AR]; // SP: temperature * |A| * prior[s0][a], the root's children
+#pragma unroll
+    for (int a = 0; a < AR; ++a) tp0[a] = SP ? p.TA * p.pol_prior[(long)s0 * p.pol_stride + a] : 0.0;
     int steps_taken = 0;
     // statistics of the path nodes at depths 2..5 as read by the selection of this episode (nobody else writes
     // them in between): the backup then needs no read for them (~16 % of the saturated kernel's time was those reads)
@@ -216,8 +234,22 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                     for (int a = 0; a < AR; ++a) c[a] = tree[fc + a];
                 }
                 double sc[AR];
+                if (SP) {
+                    double tpl[AR];
+                    if (depth == 0) {
 #pragma unroll
-                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
+                        for (int a = 0; a < AR; ++a) tpl[a] = tp0[a];
+                    } else {
+                        const double *pr = p.pol_prior + (long)s * p.pol_stride;
+#pragma unroll
+                        for (int a = 0; a < AR; ++a) tpl[a] = p.TA * pr[a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) sc[a] = c[a].value + tpl[a] / (double)(c[a].count + 1);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
+                }
                 double m = sc[0];
 #pragma unroll
                 for (int a = 1; a < AR; ++a) m = sc[a] > m ? sc[a] : m;
@@ -319,12 +351,25 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
             bool stopped_in_a = true;
             double r_a = 0.0, r_b = 0.0, g_a = 0.0, g_b = 0.0;
             bool have_b = false;
+            uint64_t tcur[NTH]; // SP: thresholds of the state the rollout is in
+            if (SP) {
+                const uint4 *tr = reinterpret_cast<const uint4 *>(p.pol_thr + (long)s * p.pol_stride);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    const uint4 v = tr[q];
+                    if (2 * q < NTH) tcur[2 * q] = ((uint64_t)v.y << 32) | v.x;
+                    if (2 * q + 1 < NTH) tcur[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+                }
+            }
             // one rollout step; returns true when the rollout must stop after it
             auto step = [&](double &r_mine, double &g_mine, const double r_prev, const double g_prev, bool add_prev,
                             const Pcg64 &gcur, Pcg64 &gspec, uint64_t &unext) -> bool {
                 // searchsorted(cdf, u, 'right') = #{a : cdf[a] <= u} = #{a : thr[a] <= k}
                 int act = 0;
-                if (AT > 0) {
+                if (SP) {
+#pragma unroll
+                    for (int a = 0; a < NTH; ++a) act += tcur[a] <= u ? 1 : 0;
+                } else if (AT > 0) {
 #pragma unroll
                     for (int a = 0; a < AR; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands
                 } else {
@@ -350,6 +395,22 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                     term_h = p.done_on_next ? next_term : cur_term;
                     cur_term = next_term;
                     s = (int32_t)(e & 0x7fffu);
+                } else if (SP) {
+                    const uint4 *fr = p.pol_frec + (size_t)ridx * (1 + NQ);
+                    const uint4 q0 = fr[0];
+                    uint4 qt[NQ > 0 ? NQ : 1];
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) qt[q] = fr[1 + q];
+                    gspec = gcur;
+                    unext = gspec.next64() >> 11; // overlaps the gather
+                    term_h = (q0.y & done_bit) != 0;
+                    s = (int32_t)q0.x;
+                    total += g_mine * __hiloint2double((int)q0.w, (int)q0.z);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        if (2 * q < NTH) tcur[2 * q] = ((uint64_t)qt[q].y << 32) | qt[q].x;
+                        if (2 * q + 1 < NTH) tcur[2 * q + 1] = ((uint64_t)qt[q].w << 32) | qt[q].z;
+                    }
                 } else {
                     const Rec rc = rec[ridx];
                     gspec = gcur;
@@ -519,11 +580,13 @@ static int uct_lanes_per_wave()
 }
 
 template <int AT>
-static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st)
+static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp)
 {
     const int roots_per_block = a.waves * a.lanes;
     const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
-    if (ldsm) {
+    if (sp) {
+        if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true>), grid, block, lds, st, a);
+    } else if (ldsm) {
         if (lds > 64 * 1024)
             MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<AT, ENV_TABLE_LDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -538,17 +601,17 @@ static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st)
 
 using namespace mp;
 
-extern "C" {
-
-int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_state, const int32_t *root_steps,
-                int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
-                const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
-                int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
-                int64_t *env_steps, int32_t mem)
+static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int32_t n_roots, const void *root_state,
+                         const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                         const double *prior_p, const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len,
+                         int32_t *plans, int32_t *plan_len, double *root_value, int64_t *root_child_count,
+                         double *root_child_value, int64_t *env_steps, int32_t mem)
 {
-    if (!ctx || !model || !root_state || !prior_p || !rollout_p || !rng_state)
+    if (!ctx || !model || !root_state || !rng_state || (!pol && (!prior_p || !rollout_p)))
         return fail(MP_ERR_ARG, "mp_uct_plan: NULL argument");
     const bool cart = model->mode == MP_MODE_CARTPOLE;
+    if (pol && (cart || pol->S != model->S || pol->A != model->A || pol->ctx != ctx))
+        return fail(MP_ERR_ARG, "mp_uct_plan_policy: the policy was not loaded for this model");
     if (model->mode != MP_MODE_DETERMINISTIC && !cart)
         return fail(MP_ERR_MODE, "mp_uct_plan: model mode %d is neither a deterministic table nor CartPole", model->mode);
     if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
@@ -564,7 +627,7 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (E + 1);
     for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);                 // gamma ** h
     double acc = 0.0;
-    for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }             // numpy cumsum
+    for (int a = 0; a < A; ++a) { acc += pol ? 1.0 : rollout_p[a]; cdf[a] = acc; } // numpy cumsum
     for (int a = 0; a < A; ++a) cdf[a] /= acc;                                     // cdf /= cdf[-1]
     for (int a = 0; a < A; ++a) {
         // Generator.choice(p=...): idx = searchsorted(cdf, u, 'right') with u = k * 2^-53, k < 2^53 integer;
@@ -576,7 +639,7 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     rcp[0] = 0.0;
     for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                         // mcts.py:255  K / count, K = 1
     for (int a = 0; a < A; ++a) {
-        const double tp = temperature * (double)A * prior_p[a];                   // mcts.py:286, left to right
+        const double tp = temperature * (double)A * (pol ? 0.0 : prior_p[a]);     // mcts.py:286, left to right
         tpv[a] = tp;
         tpdiv[(size_t)a * (E + 2)] = 0.0;
         for (int n = 1; n <= E + 1; ++n) tpdiv[(size_t)a * (E + 2) + n] = tp / (double)n; // ... / (count + 1)
@@ -593,13 +656,16 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
         if (i < A) memcpy(&a.thr_arg[i], &cdf[i], sizeof(uint64_t));
     }
     a.cp = model->cp; a.root_x = nullptr;
+    a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_frec = pol ? pol->frec : nullptr;
+    a.pol_stride = pol ? pol->stride : 0;
+    a.TA = temperature * (double)A;
 
     // variant and geometry
     // Measured on MI355X (highway table, 4096 roots): global-record variant 0.338 ms, LDS-table variant 0.376 ms --
     // the per-step chain is instruction-bound (PCG64's 128-bit multiply), not gather-latency bound, so the
     // single-gather variant is the default; MP_UCT_MODEL=lds selects the LDS-resident transition table.
     const char *force = getenv("MP_UCT_MODEL"); // "global" (default) / "lds"
-    bool ldsm = !cart && model->t16 != nullptr && force && force[0] == 'l';
+    bool ldsm = !cart && !pol && model->t16 != nullptr && force && force[0] == 'l';
     a.lanes = ldsm ? 64 : uct_lanes_per_wave();
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
@@ -665,13 +731,16 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
         hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, st, a);
     } else
     switch (A) {
-    case 2: MP_TRY(uct_launch<2>(a, ldsm, lds, st)); break;
-    case 3: MP_TRY(uct_launch<3>(a, ldsm, lds, st)); break;
-    case 4: MP_TRY(uct_launch<4>(a, ldsm, lds, st)); break;
-    case 5: MP_TRY(uct_launch<5>(a, ldsm, lds, st)); break;
-    case 6: MP_TRY(uct_launch<6>(a, ldsm, lds, st)); break;
-    case 8: MP_TRY(uct_launch<8>(a, ldsm, lds, st)); break;
-    default: MP_TRY(uct_launch<0>(a, ldsm, lds, st)); break;
+    case 2: MP_TRY(uct_launch<2>(a, ldsm, lds, st, pol != nullptr)); break;
+    case 3: MP_TRY(uct_launch<3>(a, ldsm, lds, st, pol != nullptr)); break;
+    case 4: MP_TRY(uct_launch<4>(a, ldsm, lds, st, pol != nullptr)); break;
+    case 5: MP_TRY(uct_launch<5>(a, ldsm, lds, st, pol != nullptr)); break;
+    case 6: MP_TRY(uct_launch<6>(a, ldsm, lds, st, pol != nullptr)); break;
+    case 8: MP_TRY(uct_launch<8>(a, ldsm, lds, st, pol != nullptr)); break;
+    default:
+        if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
+        MP_TRY(uct_launch<0>(a, ldsm, lds, st, false));
+        break;
     }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
@@ -684,6 +753,94 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
     MP_TRY(stage_out_copy(ctx, root_child_value, a.root_child_value, (size_t)n_roots * A, mem));
     MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, mem));
     if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+extern "C" {
+
+int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_state, const int32_t *root_steps,
+                int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
+                const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
+                int64_t *env_steps, int32_t mem)
+{
+    return uct_plan_impl(ctx, model, nullptr, n_roots, root_state, root_steps, episodes, horizon, gamma, temperature,
+                         prior_p, rollout_p, rng_state, max_plan_len, plans, plan_len, root_value, root_child_count,
+                         root_child_value, env_steps, mem);
+}
+
+int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const void *root_state,
+                       const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                       uint64_t *rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
+                       int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem)
+{
+    if (!policy) return fail(MP_ERR_ARG, "mp_uct_plan_policy: policy is NULL");
+    return uct_plan_impl(ctx, model, policy, n_roots, root_state, root_steps, episodes, horizon, gamma, temperature,
+                         nullptr, nullptr, rng_state, max_plan_len, plans, plan_len, root_value, root_child_count,
+                         root_child_value, env_steps, mem);
+}
+
+// mcts_with_prior.py:47-62 as tables: per state, the prior row and the integer sampling thresholds of the rollout row
+// (computed exactly as mp_uct_plan computes them for one distribution), plus one fused record per (s, a).
+int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, mp_policy **out)
+{
+    if (!ctx || !model || !prior || !rollout || !out) return fail(MP_ERR_ARG, "mp_policy_load: NULL argument");
+    if (model->mode != MP_MODE_DETERMINISTIC || !model->rec)
+        return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a deterministic table model");
+    const int S = model->S, A = model->A;
+    if (!(A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8))
+        return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not one of 2,3,4,5,6,8", A);
+    MP_HIP(hipSetDevice(ctx->device));
+    const int stride = (A + 1) & ~1, frq = 1 + A / 2;
+    std::vector<double> hp((size_t)S * stride, 0.0);
+    std::vector<uint64_t> ht((size_t)S * stride, ~0ULL);
+    for (int s = 0; s < S; ++s) {
+        double cdf[8], acc = 0.0;
+        for (int a = 0; a < A; ++a) {
+            const double q = rollout[(size_t)s * A + a], pr = prior[(size_t)s * A + a];
+            if (!(q >= 0.0) || !(pr >= 0.0)) return fail(MP_ERR_ARG, "mp_policy_load: negative or NaN probability in state %d", s);
+            hp[(size_t)s * stride + a] = pr;
+            acc += q; cdf[a] = acc;                                                // numpy cumsum
+        }
+        if (!(acc > 0.0)) return fail(MP_ERR_ARG, "mp_policy_load: rollout distribution of state %d sums to 0", s);
+        for (int a = 0; a < A; ++a) {
+            const double scaled = ceil(ldexp(cdf[a] / acc, 53));                   // cdf /= cdf[-1]; see mp_uct_plan
+            ht[(size_t)s * stride + a] = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
+        }
+    }
+    std::vector<Rec> hrec((size_t)S * A);
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    MP_HIP(hipMemcpy(hrec.data(), model->rec, hrec.size() * sizeof(Rec), hipMemcpyDeviceToHost));
+    std::vector<uint64_t> hf((size_t)S * A * frq * 2, ~0ULL);
+    for (size_t i = 0; i < (size_t)S * A; ++i) {
+        uint64_t *f = hf.data() + i * frq * 2;
+        memcpy(f, &hrec[i], sizeof(Rec));
+        const int nx = hrec[i].next;
+        if (nx < 0 || nx >= S) return fail(MP_ERR_ARG, "mp_policy_load: transition out of range");
+        for (int a = 0; a + 1 < A; ++a) f[2 + a] = ht[(size_t)nx * stride + a];
+    }
+    mp_policy *pol = new (std::nothrow) mp_policy;
+    if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
+    pol->ctx = ctx; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq;
+    if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
+        hipMalloc(&pol->frec, hf.size() * 8) != hipSuccess) {
+        mp_policy_free(pol);
+        return fail(MP_ERR_ALLOC, "mp_policy_load: device allocation failed");
+    }
+    MP_HIP(hipMemcpy(pol->prior, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
+    MP_HIP(hipMemcpy(pol->thr, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
+    MP_HIP(hipMemcpy(pol->frec, hf.data(), hf.size() * 8, hipMemcpyHostToDevice));
+    *out = pol;
+    return MP_OK;
+}
+
+int mp_policy_free(mp_policy *policy)
+{
+    if (!policy) return MP_OK;
+    if (policy->prior) (void)hipFree(policy->prior);
+    if (policy->thr) (void)hipFree(policy->thr);
+    if (policy->frec) (void)hipFree(policy->frec);
+    delete policy;
     return MP_OK;
 }
 

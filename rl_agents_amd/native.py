@@ -44,6 +44,10 @@ SIGNATURES = {
     "mp_vi_sweeps": (C.c_int, [_vp, _vp, c_f64, c_i32, c_i32]),
     "mp_uct_plan": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, c_i32]),
+    "mp_policy_load": (C.c_int, [_vp, _vp, _vp, _vp, P(_vp)]),
+    "mp_policy_free": (C.c_int, [_vp]),
+    "mp_uct_plan_policy": (C.c_int, [_vp, _vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, c_i32]),
     "mp_uct_step_tree": (C.c_int, [_vp, c_i32, _vp, c_i32]),
     "mp_uct_reset_tree": (C.c_int, [_vp]),
     "mp_uct_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
@@ -290,9 +294,20 @@ class Context(object):
         _check(self._lib.mp_vi_sweeps(self._h, model._h, float(gamma), int(sweeps), int(bool(robust))))
 
     # ---- tree search -------------------------------------------------------------------------
+    def load_policy(self, model, prior, rollout):
+        """Per-state prior / rollout policies [S, A] of a table model (mcts_with_prior.py:47-62) -> Policy."""
+        pr = np.ascontiguousarray(prior, dtype=np.float64)
+        ro = np.ascontiguousarray(rollout, dtype=np.float64)
+        if pr.shape != (model.S, model.A) or ro.shape != (model.S, model.A):
+            raise ValueError("prior / rollout must be [S, A] = [{}, {}]".format(model.S, model.A))
+        h = _vp()
+        _check(self._lib.mp_policy_load(self._h, model._h, _ptr(pr), _ptr(ro), C.byref(h)))
+        return Policy(self, h)
+
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
-                 root_steps=None, max_plan_len=None):
-        """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place."""
+                 root_steps=None, max_plan_len=None, policy=None):
+        """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place.
+        policy (load_policy): per-state policies instead of prior_p / rollout_p."""
         if model.mode == MODE_CARTPOLE:      # roots are (x, x_dot, theta, theta_dot) rows
             rs = np.ascontiguousarray(root_state, dtype=np.float64).reshape(-1, 4)
         else:
@@ -303,13 +318,20 @@ class Context(object):
                 and rng_state.size == n * 6):
             raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6]")
         mpl = int(horizon if max_plan_len is None else max_plan_len)
+        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
+                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        if policy is not None:
+            _check(self._lib.mp_uct_plan_policy(self._h, model._h, policy._h, n, _ptr(rs), _ptr(st), int(episodes),
+                                                int(horizon), float(gamma), float(temperature), _ptr(rng_state), mpl,
+                                                _ptr(out["plans"]), _ptr(out["plan_len"]), _ptr(out["root_value"]),
+                                                _ptr(out["root_child_count"]), _ptr(out["root_child_value"]),
+                                                _ptr(out["env_steps"]), MP_MEM_HOST))
+            return out
         pp = np.ascontiguousarray(prior_p, dtype=np.float64)
         rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
         if pp.shape != (model.A,) or rp.shape != (model.A,):
             raise ValueError("prior_p / rollout_p must have one entry per action")
-        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
-                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
-                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
         _check(self._lib.mp_uct_plan(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
                                      float(gamma), float(temperature), _ptr(pp), _ptr(rp), _ptr(rng_state), mpl,
                                      _ptr(out["plans"]), _ptr(out["plan_len"]), _ptr(out["root_value"]),
@@ -319,8 +341,15 @@ class Context(object):
 
     def uct_plan_device(self, model, n_roots, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p,
                         rng_state, max_plan_len, plans=None, plan_len=None, root_value=None, root_child_count=None,
-                        root_child_value=None, env_steps=None, root_steps=None):
+                        root_child_value=None, env_steps=None, root_steps=None, policy=None):
         """Same, on device tensors (torch); only enqueues on the ctx stream."""
+        if policy is not None:
+            _check(self._lib.mp_uct_plan_policy(self._h, model._h, policy._h, int(n_roots), _ptr(root_state),
+                                                _ptr(root_steps), int(episodes), int(horizon), float(gamma),
+                                                float(temperature), _ptr(rng_state), int(max_plan_len), _ptr(plans),
+                                                _ptr(plan_len), _ptr(root_value), _ptr(root_child_count),
+                                                _ptr(root_child_value), _ptr(env_steps), MP_MEM_DEVICE))
+            return
         pp = np.ascontiguousarray(prior_p, dtype=np.float64)
         rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
         _check(self._lib.mp_uct_plan(self._h, model._h, int(n_roots), _ptr(root_state), _ptr(root_steps),
@@ -396,6 +425,24 @@ class Model(object):
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             self.ctx._lib.mp_model_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Policy(object):
+    """Device-resident per-state prior / rollout policy tables (mp_policy)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx, self._h = ctx, handle
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._lib.mp_policy_free(self._h)
         self._h = None
 
     def __del__(self):

@@ -17,6 +17,7 @@ Files written (all small):
   vi.npz    value iteration / robust value iteration Q tables, sweep counts, greedy actions
   opd.npz   optimistic deterministic planner plans, root bounds and full trees
   uct.npz   MCTS/UCT plans, trees, env-step counts and PCG64 states before/after plan()
+  uct_prior.npz  MCTSWithPriorPolicyAgent (per-state prior/rollout policies from a prior agent) plans and trees
   misc.npz  OLOP.allocation table, numpy Generator draw sequences used to pin the PCG64 port
 """
 import json
@@ -27,7 +28,7 @@ sys.dont_write_bytecode = True
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.abspath(os.path.join(HERE, "..", "..", ".."))
 REF = "/root/reference"
-sys.path[:0] = [os.path.join(HERE, "stubs"), REF, REPO]
+sys.path[:0] = [os.path.join(HERE, "stubs"), REF, REPO, HERE]
 
 import numpy as np  # noqa: E402
 
@@ -40,6 +41,8 @@ VI = "<class 'rl_agents.agents.dynamic_programming.value_iteration.ValueIteratio
 RVI = "<class 'rl_agents.agents.dynamic_programming.robust_value_iteration.RobustValueIterationAgent'>"
 OPD = "<class 'rl_agents.agents.tree_search.deterministic.DeterministicPlannerAgent'>"
 UCT = "<class 'rl_agents.agents.tree_search.mcts.MCTSAgent'>"
+UCTP = "<class 'rl_agents.agents.tree_search.mcts_with_prior.MCTSWithPriorPolicyAgent'>"
+PRIOR = "<class 'prior_agents.BoltzmannQAgent'>"
 
 
 def load_env_config(rel):
@@ -354,6 +357,87 @@ def golden_uct():
     return store
 
 
+def golden_uct_prior():
+    """MCTSWithPriorPolicyAgent (mcts_with_prior.py): prior and rollout policies that depend on the state."""
+    store, names = {}, []
+    large1 = {k: v for k, v in load_env_config("large/env_1.json").items() if k != "max_steps"}
+    hw = generators.highway_shaped(3, 4, 10, seed=3)
+    hw_mid = generators.highway_shaped(5, 5, 20, seed=4)
+    doors = load_env_config("doors/env_1.json")
+    cases = [
+        # name, mdp cfg, s0, agent cfg, prior-agent cfg, separate rollout temperature (None = same policy), seeds
+        ("large1_b200", large1, 0, dict(budget=200), dict(gamma=0.9, temperature=0.5), None, [0, 1, 2]),
+        ("large1_b1000_t02", large1, 7, dict(budget=1000), dict(gamma=0.9, temperature=0.2), None, [0, 3]),
+        ("large1_h30e33", large1, 11, dict(budget=1000, horizon=30, episodes=33), dict(gamma=0.8, temperature=1.0), None, [5]),
+        ("large1_masked", large1, 4, dict(budget=400), dict(gamma=0.9, temperature=0.5, mask=7), None, [0, 1]),
+        ("large1_two_policies", large1, 9, dict(budget=400, temperature=40), dict(gamma=0.9, temperature=0.3), 2.0, [2, 8]),
+        ("highway_small", hw, 0, dict(budget=1000, horizon=30, episodes=33), dict(gamma=0.95, temperature=0.3), None, [0, 1]),
+        ("highway_mid", hw_mid, 22, dict(budget=1000, horizon=30, episodes=33), dict(gamma=0.95, temperature=0.1, mask=3), 1.0, [0]),
+        ("doors", doors, 0, dict(budget=400, temperature=3000), dict(gamma=0.9, temperature=1.0), None, [0, 1]),
+    ]
+    import prior_agents
+    for name, cfg, s0, agent_cfg, prior_cfg, roll_temp, seeds in cases:
+        for seed in seeds:
+            env = make_env(cfg, state=s0)
+            agent = agent_factory(env, dict(agent_cfg, __class__=UCTP, prior_agent=dict(prior_cfg, __class__=PRIOR)))
+            prior_table = np.array(agent.prior_agent.table)
+            rollout_table = prior_table
+            if roll_temp is not None:
+                # a second policy for the rollouts, installed the way the reference installs its own
+                # (mcts_with_prior.py:31-32 assigns planner.rollout_policy)
+                rollout_table = prior_agents.boltzmann_table(agent.prior_agent.q, roll_temp)
+                agent.planner.rollout_policy = \
+                    lambda state, observation, t=rollout_table: (list(range(t.shape[1])), list(t[observation]))
+            agent.seed(seed)
+            st0 = rng_state(agent.planner.np_random)
+            plan = agent.plan(s0)
+            root = agent.planner.root
+            tree = bfs_tree(root, [("count", lambda n: n.count, np.int64),
+                                   ("value", lambda n: float(n.value), np.float64),
+                                   ("prior", lambda n: float(n.prior), np.float64)])
+            pc = agent.planner.config
+            p = "uct_prior/{}_seed{}".format(name, seed)
+            put_mdp(store, p + "/mdp", cfg)
+            put(store, p, dict(s0=s0, seed=seed, budget=pc["budget"], gamma=pc["gamma"], episodes=pc["episodes"],
+                               horizon=pc["horizon"], temperature=pc["temperature"], prior_table=prior_table,
+                               rollout_table=rollout_table, q=np.array(agent.prior_agent.q),
+                               prior_gamma=prior_cfg["gamma"], prior_temperature=prior_cfg["temperature"],
+                               plan=np.asarray(plan, np.int32), root_count=root.count, root_value=float(root.value),
+                               env_steps=len(agent.planner.observations),
+                               rng_before=st0, rng_after=rng_state(agent.planner.np_random)))
+            put(store, p + "/tree", tree)
+            names.append("{}_seed{}".format(name, seed))
+    store["uct_prior/names"] = np.asarray(names)
+
+    # step_strategy "subtree" with a state-dependent prior (the reference's vi_prior.json uses it)
+    env = make_env(hw, state=5)
+    agent = agent_factory(env, dict(__class__=UCTP, budget=300, horizon=12, episodes=25, step_strategy="subtree",
+                                    prior_agent=dict(__class__=PRIOR, gamma=0.95, temperature=0.3)))
+    agent.seed(11)
+    p = "uct_prior/subtree_highway"
+    put_mdp(store, p + "/mdp", hw)
+    pc = agent.planner.config
+    store[p + "/rng_before"] = rng_state(agent.planner.np_random)
+    store[p + "/prior_table"] = np.array(agent.prior_agent.table)
+    states = []
+    for step in range(5):
+        states.append(env.mdp.state)
+        plan = agent.plan(env.mdp.state)
+        root = agent.planner.root
+        tree = bfs_tree(root, [("count", lambda n: n.count, np.int64), ("value", lambda n: float(n.value), np.float64),
+                               ("prior", lambda n: float(n.prior), np.float64)])
+        put(store, "{}/step{}".format(p, step), dict(plan=np.asarray(plan, np.int32), root_count=root.count,
+                                                     root_value=float(root.value),
+                                                     rng_after=rng_state(agent.planner.np_random)))
+        put(store, "{}/step{}/tree".format(p, step), tree)
+        _, _, term, trunc, _ = env.step(plan[0])
+        if term or trunc:
+            break
+    put(store, p, dict(states=np.asarray(states, np.int32), n_steps=len(states), gamma=pc["gamma"],
+                       episodes=pc["episodes"], horizon=pc["horizon"], temperature=pc["temperature"]))
+    return store
+
+
 def golden_uct_cartpole():
     """MCTS on the restated CartPole (BASELINE config C3): single-root plans with full trees, and the
     reference's own functional test (tests/agents/tree_search/test_mcts.py:5-19) as a survival count."""
@@ -461,7 +545,7 @@ def main():
     out = os.path.join(REPO, "tests", "golden")
     only = sys.argv[1:]
     for name, fn in (("vi", golden_vi), ("opd", golden_opd), ("uct", golden_uct), ("uct_cartpole", golden_uct_cartpole),
-                     ("misc", golden_misc)):
+                     ("uct_prior", golden_uct_prior), ("misc", golden_misc)):
         if only and name not in only:
             continue
         store = fn()

@@ -319,3 +319,91 @@ def test_row_sharded_driver_device_resident():
         q, sweeps_ref = c.vi_solve(full, 0.9, 80)
         assert sweeps == sweeps_ref and np.array_equal(q_dev.cpu().numpy(), q)
         c.close()
+
+
+def _random_policy_tables(s, a, seed, zero_rate=0.15):
+    """Seeded per-state distributions with some exactly-zero entries (never a whole row)."""
+    g = np.random.Generator(np.random.PCG64(seed))
+    w = g.random((2, s, a)) ** 3
+    drop = g.random((2, s, a)) < zero_rate
+    drop[:, np.arange(s), g.integers(0, a, size=s)] = False
+    w = np.where(drop, 0.0, w)
+    return w[0] / w[0].sum(axis=1, keepdims=True), w[1] / w[1].sum(axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 8])
+def test_uct_state_policies_batch_action_counts(ctx, n_actions):
+    """Per-state prior / rollout tables (mcts_with_prior.py:47-62), every |A| specialisation, 300 roots vs the oracle."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(301, n_actions, seed=40 + n_actions, terminal_rate=0.04)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    prior, rollout = _random_policy_tables(301, n_actions, seed=n_actions)
+    model = ctx.load_table(t, r, term, max_steps=40)
+    policy = ctx.load_policy(model, prior, rollout)
+    n = 300
+    s0 = np.random.Generator(np.random.PCG64(5)).integers(0, 301, size=n).astype(np.int32)
+    rng = _rng_states(n, base=777)
+    rng_ref = rng.copy()
+    out = ctx.uct_plan(model, s0, 30, 12, 0.9, 6.5, None, None, rng, max_plan_len=12, policy=policy)
+    ref = oracle.uct_plan_batch(t, r, term, s0, 30, 12, 0.9, 6.5, prior, rollout, rng_ref, max_steps=40,
+                                max_plan_len=12, n_threads=8)
+    for k in ("plans", "plan_len", "root_child_count", "env_steps"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    assert np.array_equal(out["root_child_value"], ref["root_child_value"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    policy.close()
+    model.close()
+
+
+def test_uct_state_policies_headline_shape_and_uniform_equivalence(ctx):
+    """Highway-shaped S=10 000, A=5: (i) Boltzmann-like per-state tables vs the oracle on 1100 ragged roots;
+    (ii) uniform tables give exactly what the state-independent uniform policy gives (same stream, same plans)."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    model = ctx.load_table(t, r, term)
+    prior, rollout = _random_policy_tables(10000, 5, seed=9, zero_rate=0.05)
+    policy = ctx.load_policy(model, prior, rollout)
+    n = 1100 + 13
+    s0 = np.random.Generator(np.random.PCG64(3)).integers(0, 10000, size=n).astype(np.int32)
+    rng = _rng_states(n, base=31)
+    rng_ref = rng.copy()
+    out = ctx.uct_plan(model, s0, 33, 30, 0.8, 10.0, None, None, rng, max_plan_len=30, policy=policy)
+    ref = oracle.uct_plan_batch(t, r, term, s0, 33, 30, 0.8, 10.0, prior, rollout, rng_ref, max_plan_len=30, n_threads=8)
+    for k in ("plans", "plan_len", "root_child_count", "env_steps"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    uni = np.full((10000, 5), 0.2)
+    upol = ctx.load_policy(model, uni, uni)
+    rng_a, rng_b = _rng_states(n, base=99), _rng_states(n, base=99)
+    a = ctx.uct_plan(model, s0, 33, 30, 0.8, 10.0, None, None, rng_a, max_plan_len=30, policy=upol)
+    b = ctx.uct_plan(model, s0, 33, 30, 0.8, 10.0, np.full(5, 0.2), np.full(5, 0.2), rng_b, max_plan_len=30)
+    for k in ("plans", "root_child_count", "env_steps"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.array_equal(a["root_value"], b["root_value"])
+    np.testing.assert_array_equal(rng_a, rng_b)
+    for x in (policy, upol, model):
+        x.close()
+
+
+def test_policy_load_errors(ctx):
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(50, 7, seed=1)
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    with pytest.raises(native.NativeError):   # |A| = 7 has no compile-time specialisation
+        ctx.load_policy(model, np.full((50, 7), 1 / 7), np.full((50, 7), 1 / 7))
+    model.close()
+    cfg = generators.random_deterministic(50, 4, seed=1)
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    bad = np.full((50, 4), 0.25)
+    bad[3, 1] = -0.1
+    with pytest.raises(native.NativeError):
+        ctx.load_policy(model, bad, np.full((50, 4), 0.25))
+    with pytest.raises(native.NativeError):
+        ctx.load_policy(model, np.full((50, 4), 0.25), np.zeros((50, 4)))
+    model.close()

@@ -161,3 +161,58 @@ def test_uct_subtree_strategy_golden(ctx, golden, tag):
         assert_tree_equal(z, q + "/tree", tree, a, dict(count="count", value="value"))
         prev = int(out["plans"][0, 0])
     model.close()
+
+
+def test_uct_state_policies_golden(ctx, golden):
+    """mp_uct_plan_policy vs the unmodified MCTSWithPriorPolicyAgent (mcts_with_prior.py) driven by a prior agent:
+    plans, trees, env-step counts and generator states, bit for bit."""
+    z = golden["uct_prior"]
+    for name in [str(n) for n in z["uct_prior/names"]]:
+        p = "uct_prior/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        model = _load(ctx, cfg)
+        policy = ctx.load_policy(model, z[p + "/prior_table"], z[p + "/rollout_table"])
+        a = cfg["reward"].shape[1]
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        episodes, horizon = int(z[p + "/episodes"]), int(z[p + "/horizon"])
+        ctx.uct_reset_tree()
+        out = ctx.uct_plan(model, [int(z[p + "/s0"])], episodes, horizon, float(z[p + "/gamma"]),
+                           float(z[p + "/temperature"]), None, None, rng, policy=policy)
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert out["env_steps"][0] == int(z[p + "/env_steps"]), name
+        assert out["root_value"][0] == float(z[p + "/root_value"]), name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        tree = ctx.uct_tree(0, 1 + episodes * a)
+        assert tree["count"][0] == int(z[p + "/root_count"])
+        assert_tree_equal(z, p + "/tree", tree, a, dict(count="count", value="value"))
+        policy.close()
+        model.close()
+
+
+def test_uct_state_policies_subtree_golden(ctx, golden):
+    z = golden["uct_prior"]
+    p = "uct_prior/subtree_highway"
+    cfg = mdp_from_golden(z, p + "/mdp")
+    model = _load(ctx, cfg)
+    policy = ctx.load_policy(model, z[p + "/prior_table"], z[p + "/prior_table"])
+    a = cfg["reward"].shape[1]
+    rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+    ctx.uct_reset_tree()
+    prev = None
+    for step in range(int(z[p + "/n_steps"])):
+        if prev is not None:
+            ctx.uct_step_tree([prev])
+        out = ctx.uct_plan(model, [int(z[p + "/states"][step])], int(z[p + "/episodes"]), int(z[p + "/horizon"]),
+                           float(z[p + "/gamma"]), float(z[p + "/temperature"]), None, None, rng, policy=policy)
+        q = "{}/step{}".format(p, step)
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[q + "/plan"], err_msg=q)
+        np.testing.assert_array_equal(rng[0], z[q + "/rng_after"], err_msg=q)
+        tree = ctx.uct_tree(0)
+        assert tree["count"][0] == int(z[q + "/root_count"]) and tree["value"][0] == float(z[q + "/root_value"])
+        assert_tree_equal(z, q + "/tree", tree, a, dict(count="count", value="value"))
+        prev = int(out["plans"][0, 0])
+    ctx.uct_reset_tree()
+    policy.close()
+    model.close()

@@ -192,19 +192,20 @@ def test_cartpole_env_matches_golden_episode(golden):
     assert steps == int(z["cartpole/episode_steps"]) == 200 and not term
 
 
-def _subtree_sequence(golden, tag, plan_fn, reroot_fn):
+def _subtree_sequence(golden, tag, plan_fn, reroot_fn, group="uct"):
     """Replay a step_strategy='subtree' agent: plan, execute plan[0], re-root, plan again (abstract.py:172-206)."""
-    z = golden["uct"]
-    p = "uct/" + tag
+    z = golden[group]
+    p = group + "/" + tag
     cfg = mdp_from_golden(z, p + "/mdp")
     a = cfg["reward"].shape[1]
     rng = np.array(z[p + "/rng_before"], dtype=np.uint64)
+    policy = z[p + "/prior_table"] if group == "uct_prior" else np.ones(a) / a
     tree, prev_action = None, None
     for step in range(int(z[p + "/n_steps"])):
         if tree is not None:
             tree = reroot_fn(tree, prev_action, a)
         out = plan_fn(cfg, int(z[p + "/states"][step]), int(z[p + "/episodes"]), int(z[p + "/horizon"]),
-                      float(z[p + "/gamma"]), float(z[p + "/temperature"]), np.ones(a) / a, rng, tree)
+                      float(z[p + "/gamma"]), float(z[p + "/temperature"]), policy, rng, tree)
         q = "{}/step{}".format(p, step)
         np.testing.assert_array_equal(out["plan"], z[q + "/plan"], err_msg=q)
         np.testing.assert_array_equal(out["rng_after"], z[q + "/rng_after"], err_msg=q)
@@ -219,3 +220,28 @@ def test_uct_subtree_strategy_sequences(golden, tag):
         return oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], s0, episodes, horizon, gamma,
                                temperature, p, p, rng, max_steps=cfg["max_steps"], init_tree=tree)
     _subtree_sequence(golden, tag, plan_fn, oracle.uct_reroot)
+
+
+def test_uct_state_policies_all_cases(golden):
+    """MCTSWithPriorPolicyAgent (mcts_with_prior.py): prior and rollout distributions looked up per state."""
+    z = golden["uct_prior"]
+    for name in [str(n) for n in z["uct_prior/names"]]:
+        p = "uct_prior/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        a = cfg["reward"].shape[1]
+        out = oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], int(z[p + "/s0"]),
+                              int(z[p + "/episodes"]), int(z[p + "/horizon"]), float(z[p + "/gamma"]),
+                              float(z[p + "/temperature"]), z[p + "/prior_table"], z[p + "/rollout_table"],
+                              z[p + "/rng_before"], max_steps=cfg["max_steps"])
+        np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+        assert out["tree"]["value"][0] == float(z[p + "/root_value"])
+        assert_tree_equal(z, p + "/tree", out["tree"], a, dict(count="count", value="value", prior="prior"))
+
+
+def test_uct_state_policies_subtree_sequence(golden):
+    def plan_fn(cfg, s0, episodes, horizon, gamma, temperature, p, rng, tree):
+        return oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], s0, episodes, horizon, gamma,
+                               temperature, p, p, rng, max_steps=cfg["max_steps"], init_tree=tree)
+    _subtree_sequence(golden, "subtree_highway", plan_fn, oracle.uct_reroot, group="uct_prior")

@@ -26,11 +26,15 @@ def main():
     rng[:, 3] |= 1
     rng[:, 4:] = 0
     p = np.ones(5) / 5
+    policy = None
+    if os.environ.get("POLICY"):  # per-state prior / rollout tables (mp_uct_plan_policy)
+        w = np.random.Generator(np.random.PCG64(2)).random((2, 10000, 5)) ** 2
+        policy = ctx.load_policy(model, w[0] / w[0].sum(1, keepdims=True), w[1] / w[1].sum(1, keepdims=True))
     for rep in range(3):
         t0 = time.perf_counter()
         if what == "uct":
             out = ctx.uct_plan(model, s0, int(os.environ.get("EPISODES", "33")), int(os.environ.get("HORIZON", "30")), 0.8, 10.0, p, p,
-                               rng, max_plan_len=8)
+                               rng, max_plan_len=8, policy=policy)
         else:
             budget = int(sys.argv[3]) if len(sys.argv) > 3 else 5000
             out = ctx.opd_plan(model, s0, budget, 0.8, 0.0, rng, max_plan_len=32)
