@@ -51,6 +51,22 @@ class ValueIterationAgent(StatelessPlannerAgent):
         model._vi_cache = (key, q, self.sweeps)
         return q
 
+    def policy_table(self):
+        """Boltzmann distribution over the solved Q table, one row per state: softmax(Q[s, :] / temperature) with
+        ``config["temperature"]`` (default 1).  Not in the reference, whose ValueIterationAgent cannot serve as the
+        prior agent its own vi_prior.json asks for (no ``action_distribution``); see mcts_with_prior.py."""
+        if not self.finite_mdp:     # converted environments: same refresh as act()
+            self.mdp = self.env.unwrapped.to_finite_mdp()
+            self.state_action_value = self.get_state_action_value()
+        q = self.state_action_value
+        z = np.exp((q - q.max(axis=1, keepdims=True)) / self.config.get("temperature", 1.0))
+        return z / z.sum(axis=1, keepdims=True)
+
+    def action_distribution(self, state):
+        """{action: probability} in ``state`` (AbstractStochasticAgent.action_distribution, common/abstract.py:105)."""
+        row = self.policy_table()[state]
+        return {a: row[a] for a in range(len(row))}
+
     def get_state_value(self):
         return self.models.ctx.vi_solve_v(self._model(), self.config["gamma"], self.config["iterations"])
 

@@ -193,3 +193,39 @@ def test_shard_bounds_cover_everything():
             assert all(b[1] == c[0] for b, c in zip(blocks, blocks[1:]))
             sizes = [hi - lo for lo, hi in blocks]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_tabulate_prior_agent_queries_like_the_reference():
+    """mcts_with_prior.py:47-54: act(observation) then action_distribution(observation), keys in any order."""
+    from rl_agents_amd.agents.tree_search.mcts_with_prior import tabulate_prior_agent
+
+    class Prior(object):
+        def __init__(self):
+            self.calls = []
+
+        def act(self, s):
+            self.calls.append(("act", s))
+
+        def action_distribution(self, s):
+            self.calls.append(("dist", s))
+            return {2: 0.5, 0: 0.25 + 0.01 * s, 1: 0.25 - 0.01 * s}
+
+    prior = Prior()
+    table = tabulate_prior_agent(prior, 3, 3)
+    assert prior.calls == [("act", 0), ("dist", 0), ("act", 1), ("dist", 1), ("act", 2), ("dist", 2)]
+    np.testing.assert_array_equal(table[1], [0.26, 0.24, 0.5])
+
+    class Fast(object):
+        def policy_table(self):
+            return np.full((3, 3), 1 / 3)
+
+    assert tabulate_prior_agent(Fast(), 3, 3).shape == (3, 3)
+    with pytest.raises(ValueError):
+        tabulate_prior_agent(Fast(), 4, 3)
+
+    class Partial(Prior):
+        def action_distribution(self, s):
+            return {0: 1.0}
+
+    with pytest.raises(ValueError):
+        tabulate_prior_agent(Partial(), 2, 3)
