@@ -60,8 +60,9 @@ struct UctArgs {
     // per-state policies (mp_policy): nullptr / 0 for the state-independent ones
     const double *pol_prior; // [S][pol_stride]
     const uint64_t *pol_thr; // [S][pol_stride]
-    const uint4 *pol_frec;   // [S*A][1 + A/2]
+    const uint4 *pol_frec;   // [S*A][1 + ceil((A-1)/4)]
     int pol_stride;
+    int pol_shift;           // fused thresholds = min(thr >> pol_shift, 2^32 - 1); 21 = the top 32 of 53 bits
     double TA;               // temperature * |A|  (mcts.py:286, left to right)
     uint64_t *rng;
     UctNode *tree;
@@ -104,14 +105,17 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 // SP: the prior and the rollout distribution are rows of per-state tables (mcts_with_prior.py:47-62).  The env is
 // deterministic, so the state a node is reached in is a function of its action sequence and the prior stored in a
 // child at expansion (mcts.py:237-246) is prior[state of the parent][action]: it is looked up with the state the
-// descent is in, not stored.  Rollouts read a fused 16*(1 + A/2)-byte record per step -- the (s,a) record followed by
-// the sampling thresholds of the state it leads to -- so the per-step dependency chain stays one gather long.
+// descent is in, not stored.  Rollouts read one fused 32-byte (|A| <= 5) or 48-byte record per step -- the (s,a)
+// record followed by the sampling thresholds of the state it leads to -- so the per-step dependency chain stays one
+// gather long.  The fused thresholds are the top 32 of the 53 bits: they decide the draw unless one of them equals
+// the draw's top 32 bits (probability ~|A| * 2^-32 per step), in which case the exact 53-bit row is fetched.
 template <int AT, int ENV, bool SP = false>
 __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_LDS ? 1 : MP_UCT_MIN_WAVES) void uct_kernel(UctArgs p)
 {
     static_assert(!SP || (AT > 0 && ENV == ENV_TABLE), "per-state policies: table env, |A| known at compile time");
-    constexpr int NQ = AT / 2;  // 16-byte chunks holding the AT-1 thresholds of a state
-    constexpr int NTH = AT > 1 ? AT - 1 : 1;
+    constexpr int NTH = AT > 1 ? AT - 1 : 1; // thresholds that can be reached (the last one is 2^53: never)
+    constexpr int NQ = (NTH + 1) / 2;        // 16-byte chunks of a row of exact (uint64) thresholds
+    constexpr int NQ32 = (NTH + 3) / 4;      // 16-byte chunks of the fused record's 32-bit thresholds
     constexpr bool LDSM = ENV == ENV_TABLE_LDS;
     constexpr bool CART = ENV == ENV_CARTPOLE;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
@@ -351,14 +355,19 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
             bool stopped_in_a = true;
             double r_a = 0.0, r_b = 0.0, g_a = 0.0, g_b = 0.0;
             bool have_b = false;
-            uint64_t tcur[NTH]; // SP: thresholds of the state the rollout is in
+            uint32_t tcur[NTH]; // SP: top 32 bits of the thresholds of the state the rollout is in (saturated)
             if (SP) {
                 const uint4 *tr = reinterpret_cast<const uint4 *>(p.pol_thr + (long)s * p.pol_stride);
+                const int shift = p.pol_shift;
+                auto coarse = [shift](uint32_t lo, uint32_t hi) { // min(thr >> shift, 2^32 - 1)
+                    const uint64_t c = (((uint64_t)hi << 32) | lo) >> shift;
+                    return c > 0xffffffffULL ? 0xffffffffu : (uint32_t)c;
+                };
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     const uint4 v = tr[q];
-                    if (2 * q < NTH) tcur[2 * q] = ((uint64_t)v.y << 32) | v.x;
-                    if (2 * q + 1 < NTH) tcur[2 * q + 1] = ((uint64_t)v.w << 32) | v.z;
+                    if (2 * q < NTH) tcur[2 * q] = coarse(v.x, v.y);
+                    if (2 * q + 1 < NTH) tcur[2 * q + 1] = coarse(v.z, v.w);
                 }
             }
             // one rollout step; returns true when the rollout must stop after it
@@ -367,8 +376,21 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                 // searchsorted(cdf, u, 'right') = #{a : cdf[a] <= u} = #{a : thr[a] <= k}
                 int act = 0;
                 if (SP) {
+                    // thr <= k is decided by the top bits unless they are equal: th < kh => thr < (th+1) << shift
+                    // <= k;  th > kh => thr >= th << shift > k (also for the saturated th of thr = 2^53)
+                    const uint32_t kh = (uint32_t)(u >> p.pol_shift);
+                    bool ambiguous = false;
 #pragma unroll
-                    for (int a = 0; a < NTH; ++a) act += tcur[a] <= u ? 1 : 0;
+                    for (int a = 0; a < NTH; ++a) {
+                        act += tcur[a] < kh ? 1 : 0;
+                        ambiguous |= tcur[a] == kh;
+                    }
+                    if (ambiguous) {
+                        const uint64_t *tx = p.pol_thr + (long)s * p.pol_stride;
+                        act = 0;
+#pragma unroll
+                        for (int a = 0; a < NTH; ++a) act += tx[a] <= u ? 1 : 0;
+                    }
                 } else if (AT > 0) {
 #pragma unroll
                     for (int a = 0; a < AR; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands
@@ -396,20 +418,22 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                     cur_term = next_term;
                     s = (int32_t)(e & 0x7fffu);
                 } else if (SP) {
-                    const uint4 *fr = p.pol_frec + (size_t)ridx * (1 + NQ);
+                    const uint4 *fr = p.pol_frec + (size_t)ridx * (1 + NQ32);
                     const uint4 q0 = fr[0];
-                    uint4 qt[NQ > 0 ? NQ : 1];
+                    uint4 qt[NQ32];
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) qt[q] = fr[1 + q];
+                    for (int q = 0; q < NQ32; ++q) qt[q] = fr[1 + q];
                     gspec = gcur;
                     unext = gspec.next64() >> 11; // overlaps the gather
                     term_h = (q0.y & done_bit) != 0;
                     s = (int32_t)q0.x;
                     total += g_mine * __hiloint2double((int)q0.w, (int)q0.z);
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
-                        if (2 * q < NTH) tcur[2 * q] = ((uint64_t)qt[q].y << 32) | qt[q].x;
-                        if (2 * q + 1 < NTH) tcur[2 * q + 1] = ((uint64_t)qt[q].w << 32) | qt[q].z;
+                    for (int q = 0; q < NQ32; ++q) {
+                        if (4 * q < NTH) tcur[4 * q] = qt[q].x;
+                        if (4 * q + 1 < NTH) tcur[4 * q + 1] = qt[q].y;
+                        if (4 * q + 2 < NTH) tcur[4 * q + 2] = qt[q].z;
+                        if (4 * q + 3 < NTH) tcur[4 * q + 3] = qt[q].w;
                     }
                 } else {
                     const Rec rc = rec[ridx];
@@ -658,6 +682,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.cp = model->cp; a.root_x = nullptr;
     a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_frec = pol ? pol->frec : nullptr;
     a.pol_stride = pol ? pol->stride : 0;
+    a.pol_shift = pol ? pol->shift : 21;
     a.TA = temperature * (double)A;
 
     // variant and geometry
@@ -791,7 +816,7 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
     if (!(A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8))
         return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not one of 2,3,4,5,6,8", A);
     MP_HIP(hipSetDevice(ctx->device));
-    const int stride = (A + 1) & ~1, frq = 1 + A / 2;
+    const int stride = (A + 1) & ~1, frq = 1 + (A - 1 + 3) / 4;
     std::vector<double> hp((size_t)S * stride, 0.0);
     std::vector<uint64_t> ht((size_t)S * stride, ~0ULL);
     for (int s = 0; s < S; ++s) {
@@ -811,25 +836,35 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
     std::vector<Rec> hrec((size_t)S * A);
     MP_HIP(hipStreamSynchronize(ctx->stream));
     MP_HIP(hipMemcpy(hrec.data(), model->rec, hrec.size() * sizeof(Rec), hipMemcpyDeviceToHost));
-    std::vector<uint64_t> hf((size_t)S * A * frq * 2, ~0ULL);
+    // MP_UCT_COARSE_BITS=n (1..32, default 32): keep only the top n bits in the fused records -- a test knob that
+    // makes the exact-row fallback frequent (probability ~|A| * 2^-n per step)
+    int shift = 21;
+    if (const char *e = getenv("MP_UCT_COARSE_BITS")) {
+        const int n = atoi(e);
+        if (n >= 1 && n <= 32) shift = 53 - n;
+    }
+    std::vector<uint32_t> hf((size_t)S * A * frq * 4, 0xffffffffu);
     for (size_t i = 0; i < (size_t)S * A; ++i) {
-        uint64_t *f = hf.data() + i * frq * 2;
+        uint32_t *f = hf.data() + i * frq * 4;
         memcpy(f, &hrec[i], sizeof(Rec));
         const int nx = hrec[i].next;
         if (nx < 0 || nx >= S) return fail(MP_ERR_ARG, "mp_policy_load: transition out of range");
-        for (int a = 0; a + 1 < A; ++a) f[2 + a] = ht[(size_t)nx * stride + a];
+        for (int a = 0; a + 1 < A; ++a) {
+            const uint64_t hi = ht[(size_t)nx * stride + a] >> shift;              // top bits of the 53, saturated
+            f[4 + a] = hi > 0xffffffffULL ? 0xffffffffu : (uint32_t)hi;
+        }
     }
     mp_policy *pol = new (std::nothrow) mp_policy;
     if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
-    pol->ctx = ctx; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq;
+    pol->ctx = ctx; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift;
     if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
-        hipMalloc(&pol->frec, hf.size() * 8) != hipSuccess) {
+        hipMalloc(&pol->frec, hf.size() * 4) != hipSuccess) {
         mp_policy_free(pol);
         return fail(MP_ERR_ALLOC, "mp_policy_load: device allocation failed");
     }
     MP_HIP(hipMemcpy(pol->prior, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
     MP_HIP(hipMemcpy(pol->thr, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
-    MP_HIP(hipMemcpy(pol->frec, hf.data(), hf.size() * 8, hipMemcpyHostToDevice));
+    MP_HIP(hipMemcpy(pol->frec, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     *out = pol;
     return MP_OK;
 }

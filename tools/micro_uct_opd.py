@@ -29,6 +29,8 @@ def main():
     policy = None
     if os.environ.get("POLICY"):  # per-state prior / rollout tables (mp_uct_plan_policy)
         w = np.random.Generator(np.random.PCG64(2)).random((2, 10000, 5)) ** 2
+        if os.environ["POLICY"] == "uniform":  # same plans as the state-independent uniform policy: kernel A/B
+            w = np.ones((2, 10000, 5))
         policy = ctx.load_policy(model, w[0] / w[0].sum(1, keepdims=True), w[1] / w[1].sum(1, keepdims=True))
     for rep in range(3):
         t0 = time.perf_counter()
