@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_cartpole", "opd", "vi", "rvi", "vi_dense"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "opd", "vi", "rvi", "vi_dense"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -142,7 +142,9 @@ def seed_states(global_ids, base_seed=0):
 
 
 # ---------------------------------------------------------------------------------------------
-def bench_uct(args, rank, world, local):
+def bench_uct(args, rank, world, local, with_prior=False):
+    """with_prior: MCTSWithPriorPolicyAgent's path -- value iteration on the device, its Boltzmann
+    distribution as per-state prior and rollout policy (tables built and uploaded outside the timed region)."""
     import torch
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
@@ -169,13 +171,20 @@ def bench_uct(args, rank, world, local):
     d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
     d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
     p = np.ones(a_) / a_
+    policy, tables = None, None
+    if with_prior:
+        q, _ = ctx.vi_solve(model, 0.95, 200)
+        z = np.exp((q - q.max(axis=1, keepdims=True)) / 0.3)
+        tables = z / z.sum(axis=1, keepdims=True)
+        policy = ctx.load_policy(model, tables, tables)
+        p = tables                                           # the oracle takes the [S, A] tables in p's place
     gathered = torch.empty(world * n_roots, dtype=torch.float64, device=dev) if world > 1 else None
 
     d_total = torch.zeros(1, dtype=torch.int64, device=dev)
 
     def step():
         ctx.uct_plan_device(model, n_roots, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
-                            plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps)
+                            plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps, policy=policy)
         d_total.add_(d_steps.sum())
         if world > 1:
             import torch.distributed as dist
@@ -212,25 +221,29 @@ def bench_uct(args, rank, world, local):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             ctx.uct_plan_device(model, nl, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
-                                plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps)
+                                plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps, policy=policy)
             torch.cuda.synchronize()
             ts.append(time.perf_counter() - t1)
         latency["plan_wall_ms_batch_of_{}".format(nl)] = 1e3 * float(np.median(ts))
         latency["kernel_ms_batch_of_{}".format(nl)] = ctx.last_kernel_ms()[0]
     k_ms = float(np.mean(kernel_ms))
+    # per-state policies add, per env step, the rollout distribution of the state (|A|-1 thresholds of 8 B) and,
+    # per selection level, |A| priors of 8 B (already inside the 16 B/child select term of SURVEY.md 8d: +8 B/child)
+    bytes_per_step = UCT_BYTES_PER_ENV_STEP + (8 * (a_ - 1) + 4 if with_prior else 0)
     res = dict(
         metric="rollout env-steps/sec (UCT plan(), budget=1000)", unit="env-steps/s",
         value=total_env_steps * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
         dtype="f64",
-        config=dict(workload="uct_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
-            s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
+        config=dict(workload="{}_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
+            "uct_with_vi_boltzmann_prior" if with_prior else "uct", s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
             states=s_, actions=a_, episodes=episodes, horizon=horizon, gamma=gamma,
             env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots, latency=latency,
             parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
-        roofline=dict(bound="hbm", achieved=UCT_BYTES_PER_ENV_STEP * env_steps / (k_ms * 1e-3) / 1e9,
-                      peak=HBM_PEAK_GBS, unit="GB/s", traffic=pmc_traffic("uct", "uct_kernel", n_roots),
-                      kernel="uct_kernel<5, ENV_TABLE>",
-                      kernel_ms=k_ms, algorithmic_bytes_per_launch=UCT_BYTES_PER_ENV_STEP * env_steps),
+        roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
+                      peak=HBM_PEAK_GBS, unit="GB/s",
+                      traffic=None if with_prior else pmc_traffic("uct", "uct_kernel", n_roots),
+                      kernel="uct_kernel<5, ENV_TABLE, {}>".format("true" if with_prior else "false"),
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     if rank == 0 and not args.no_cpu_baseline:
@@ -502,7 +515,9 @@ def main():
     import torch
     side = torch.cuda.Stream(device=local)          # one stream for torch ops, RCCL and the HIP kernels
     with torch.cuda.stream(side):
-        if args.workload == "uct":
+        if args.workload == "uct_prior":
+            res = bench_uct(args, rank, world, local, with_prior=True)
+        elif args.workload == "uct":
             res = bench_uct(args, rank, world, local)
         elif args.workload == "uct_cartpole":
             res = bench_uct_cartpole(args, rank, world, local)
