@@ -284,3 +284,68 @@ def opd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_rew
                              _p(status, C.c_int32), int(n_threads))
     return dict(plans=plans, plan_len=plan_len, root_lower=lo, root_upper=up, env_steps=steps, status=status,
                 rng_after=rng)
+
+
+class StateAwarePlannerState(object):
+    """The state a reference StateAwarePlanner object carries across plan() calls (state_aware.py:76-83): every node
+    ever created (arena, creation order) and the two per-state dictionaries."""
+
+    FIELDS = (("parent", np.int32), ("action", np.int32), ("state", np.int32), ("depth", np.int32),
+              ("reward", np.float64), ("lower", np.float64), ("done", np.uint8), ("count", np.int64),
+              ("first_child", np.int32), ("alive", np.uint8), ("next_same", np.int32))
+
+    def __init__(self, n_states):
+        self.n_nodes, self.root, self.cap = 0, -1, 0
+        self.nodes = {k: np.zeros(0, dt) for k, dt in self.FIELDS}
+        self.sv = np.zeros(n_states, np.float64)
+        self.head = np.zeros(n_states, np.int32)
+        self.tail = np.zeros(n_states, np.int32)
+
+    def reserve(self, extra):
+        if self.n_nodes + extra > self.cap:
+            self.cap = self.n_nodes + extra
+            for k, dt in self.FIELDS:
+                grown = np.zeros(self.cap, dt)
+                grown[:self.n_nodes] = self.nodes[k][:self.n_nodes]
+                self.nodes[k] = grown
+
+
+def saopd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_state=None, planner=None,
+               accuracy=0.0, backup_aggregated_nodes=True, prune_suboptimal_leaves=True, done_rule="source",
+               max_plan_len=64):
+    """StateAwarePlanner.plan for one root (tree_search/state_aware.py).  planner: the StateAwarePlannerState of the
+    planner object this plan() is called on (None = a new planner); returned in the result for the next call."""
+    t, r, term = _i64(transition), _f64(reward), _u8(terminal)
+    s, a = r.shape
+    fresh = planner is None
+    if fresh:
+        planner = StateAwarePlannerState(s)
+    planner.reserve(1 + (budget // a) * a)
+    rng = np.array([0, 1, 0, 1, 0, 0] if rng_state is None else rng_state, dtype=np.uint64)
+    plan = np.full(max_plan_len, -1, dtype=np.int32)
+    plan_len, nn, root = C.c_int32(), C.c_int32(planner.n_nodes), C.c_int32()
+    steps, updates = C.c_int64(), C.c_int64()
+    nd = planner.nodes
+    rc = lib().orc_saopd_plan(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"),
+                              int(s0), int(budget), C.c_double(gamma), C.c_double(terminal_reward), C.c_double(accuracy),
+                              int(bool(backup_aggregated_nodes)), int(bool(prune_suboptimal_leaves)),
+                              _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32), C.byref(plan_len),
+                              C.byref(steps), C.byref(updates), int(fresh), planner.cap, C.byref(nn), C.byref(root),
+                              _p(nd["parent"], C.c_int32), _p(nd["action"], C.c_int32), _p(nd["state"], C.c_int32),
+                              _p(nd["depth"], C.c_int32), _p(nd["reward"], C.c_double), _p(nd["lower"], C.c_double),
+                              _p(nd["done"], C.c_uint8), _p(nd["count"], C.c_int64), _p(nd["first_child"], C.c_int32),
+                              _p(nd["alive"], C.c_uint8), _p(nd["next_same"], C.c_int32), _p(planner.sv, C.c_double),
+                              _p(planner.head, C.c_int32), _p(planner.tail, C.c_int32))
+    if rc == -2:
+        raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")
+    if rc == -4:
+        raise ValueError("max() arg is an empty sequence")
+    assert rc == 0, rc
+    planner.n_nodes, planner.root = nn.value, root.value
+    # the tree of this plan: arena ids [root, n_nodes), re-based so that the root is node 0
+    lo, hi = root.value, nn.value
+    tree = {k: nd[k][lo:hi].copy() for k in nd}
+    for k in ("parent", "first_child"):
+        tree[k] = np.where(tree[k] >= 0, tree[k] - lo, -1).astype(np.int32)
+    return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, updates=updates.value, rng_after=rng, tree=tree,
+                state_values=planner.sv.copy(), planner=planner)

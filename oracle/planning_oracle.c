@@ -661,3 +661,168 @@ int orc_opd_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
     }
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------ state-aware OPD -------- */
+/*
+ * tree_search/state_aware.py:10-137 (StateAwareNode / StateAwarePlanner) for one root, over deterministic.py's
+ * expand/update.  Observations of a finite-MDP env are state indices, so the planner's two dictionaries keyed by
+ * str(observation) are arrays over states:
+ *   sv[s]            state_values (defaultdict of 1/(1-gamma), state_aware.py:83)
+ *   head/tail[s] + next_same[node]   state_nodes[s], the list of nodes observed in s, in append order (:20-22)
+ * The planner object -- and with it both dictionaries and every node ever created -- outlives plan() calls:
+ * reset() (deterministic.py:102-104) only installs a new root and a new leaves list, and plan() (:117-123) only
+ * re-initialises the root state's entries.  So the node arrays are an ARENA over all plans of one planner
+ * (fresh != 0 starts a new planner); nodes of earlier trees still take part in prune() and backup_to_root()
+ * through state_nodes, exactly as in the reference.  alive[n] = "n in planner.leaves".
+ * Returns ORC_ERR_ARG where the reference raises (max() of an empty leaves list, arena too small).
+ */
+int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                   int32_t s0, int budget, double gamma, double terminal_reward, double accuracy,
+                   int backup_aggregated_nodes, int prune_suboptimal_leaves, uint64_t *rng6, int max_plan_len,
+                   int32_t *plan, int32_t *plan_len, int64_t *env_steps, int64_t *updates_total,
+                   /* planner state: arena of capacity cap nodes, n_nodes in/out, root out */
+                   int fresh, int cap, int32_t *n_nodes_io, int32_t *root_out, int32_t *parent, int32_t *action,
+                   int32_t *state, int32_t *depth, double *reward, double *lower, uint8_t *done, int64_t *count,
+                   int32_t *first_child, uint8_t *alive, int32_t *next_same, double *sv, int32_t *head, int32_t *tail)
+{
+    orc_env env = {S, A, T, R, term, done_on_next, 0, NULL};
+    const int K = budget / A; /* deterministic.py:118 */
+    const double vmax = 1 / (1 - gamma);
+    int n_nodes = fresh ? 0 : *n_nodes_io;
+    if (n_nodes + 1 + K * A > cap) return ORC_ERR_ARG;
+    if (fresh)
+        for (int s = 0; s < S; ++s) { sv[s] = vmax; head[s] = -1; tail[s] = -1; }
+    double *gpow = malloc((K + 3) * sizeof(double));
+    int qcap = 1024, qh = 0, qt = 0;
+    int32_t *queue = malloc(qcap * sizeof(int32_t));
+    if (!gpow || !queue) return ORC_ERR_ALLOC;
+    for (int d = 0; d < K + 3; ++d) gpow[d] = pow(gamma, d);
+#define SA_U(n) (lower[n] + gpow[depth[n]] * sv[state[n]]) /* state_aware.py:65-67 */
+    /* reset(): the previous leaves list is dropped, a new root is created */
+    for (int i = 0; i < n_nodes; ++i) alive[i] = 0;
+    const int root = n_nodes++;
+    parent[root] = -1; action[root] = -1; state[root] = s0; depth[root] = 0; reward[root] = 0; lower[root] = 0;
+    done[root] = 0; count[root] = 1; first_child[root] = -1; alive[root] = 1; next_same[root] = -1;
+    /* plan(), state_aware.py:117-121 */
+    head[s0] = tail[s0] = root;
+    sv[s0] = vmax;
+    int rc = ORC_OK;
+    int64_t steps_taken = 0, updates = 0;
+    for (int k = 0; k < K && rc == ORC_OK; ++k) {
+        /* run(), :96-107: first maximal U in leaves order (= creation order of the surviving leaves) */
+        int leaf = -1;
+        double bu = 0;
+        for (int i = root; i < n_nodes; ++i)
+            if (alive[i]) {
+                const double u = SA_U(i);
+                if (leaf < 0 || u > bu) { leaf = i; bu = u; }
+            }
+        if (leaf < 0) { rc = ORC_ERR_ARG; break; } /* max() arg is an empty sequence */
+        /* deterministic.py:28-43 expand */
+        alive[leaf] = 0;
+        first_child[leaf] = n_nodes;
+        for (int a = 0; a < A; ++a) {
+            const int c = n_nodes++;
+            parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1;
+            int32_t s = state[leaf], st = 0;
+            double r; int terminated, truncated;
+            orc_env_step(&env, &s, &st, a, &r, &terminated, &truncated);
+            ++steps_taken;
+            state[c] = s;
+            alive[c] = 1;
+            /* deterministic.py:45-65 update(), called by state_aware.py:15-16 */
+            if (!(0 <= r) || !(r <= 1)) { rc = ORC_ERR_REWARD_RANGE; break; }
+            const int d = depth[c];
+            reward[c] = r; done[c] = (uint8_t)terminated;
+            lower[c] = lower[leaf] + gpow[d - 1] * r;
+            if (terminated) lower[c] = lower[c] + terminal_reward * gpow[d] / (1 - gamma);
+            count[c] = 1;
+            for (int n = c; n >= 0; n = parent[n]) count[n] += 1;
+            /* state_aware.py:19-22 */
+            next_same[c] = -1;
+            if (head[s] < 0) head[s] = c; else next_same[tail[s]] = c;
+            tail[s] = c;
+            /* :24-26 terminal states are worth 0 */
+            if (terminated && sv[s] - 0 > 0) sv[s] = 0;
+        }
+        if (rc != ORC_OK) break;
+        /* state_aware.py:42-63 backup_to_root */
+        qh = qt = 0;
+        queue[qt++] = leaf;
+        while (qh < qt) {
+            const int node = queue[qh++];
+            double delta = 0;
+            if (first_child[node] >= 0) {
+                int bc = first_child[node];
+                double bcu = SA_U(bc);
+                for (int a = 1; a < A; ++a) {
+                    const double u = SA_U(first_child[node] + a);
+                    if (u > bcu) { bc = first_child[node] + a; bcu = u; }
+                }
+                const double backup = reward[bc] + gamma * sv[state[bc]];
+                delta = sv[state[node]] - backup; /* update_value, :109-119 */
+                if (delta > 0) sv[state[node]] = backup;
+                ++updates;
+            }
+            for (int nb = head[state[node]]; nb >= 0; nb = next_same[nb])
+                if (parent[nb] >= 0 && (nb == node || backup_aggregated_nodes) &&
+                    delta > accuracy * (1 - gamma) * gpow[depth[nb] - 1]) {
+                    if (qt == qcap) {
+                        if (qh > 0) { memmove(queue, queue + qh, (qt - qh) * sizeof(int32_t)); qt -= qh; qh = 0; }
+                        if (qt == qcap) {
+                            qcap *= 2;
+                            queue = realloc(queue, qcap * sizeof(int32_t));
+                            if (!queue) { free(gpow); return ORC_ERR_ALLOC; }
+                        }
+                    }
+                    queue[qt++] = parent[nb];
+                }
+        }
+        /* run(), :106-107 + prune(), :28-40: leaves in reverse order */
+        if (prune_suboptimal_leaves)
+            for (int i = n_nodes - 1; i >= root; --i) {
+                if (!alive[i]) continue;
+                const double vub = SA_U(i);
+                for (int nd = head[state[i]]; nd >= 0; nd = next_same[nd])
+                    if (nd != i && SA_U(nd) >= vub && depth[nd] >= depth[i] && (first_child[nd] >= 0 || alive[nd])) {
+                        alive[i] = 0;
+                        break;
+                    }
+            }
+    }
+#undef SA_U
+    if (rc == ORC_OK) {
+        /* abstract.py:143-156 get_plan with deterministic.py:21-26 selection_rule (value_lower is the path's
+         * discounted reward: state_aware.py never backs lower bounds up) */
+        orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
+        int len = 0;
+        /* get_plan() runs TWICE per plan(): OptimisticDeterministicPlanner.plan returns one (deterministic.py:122)
+         * that StateAwarePlanner.plan drops before calling it again (state_aware.py:122-127); both descents draw
+         * from the generator on ties, the second one is returned */
+        for (int pass = 0; pass < 2; ++pass) {
+            int n = root;
+            len = 0;
+            while (first_child[n] >= 0) {
+                const int fc = first_child[n];
+                double m = lower[fc];
+                for (int a = 1; a < A; ++a) if (lower[fc + a] > m) m = lower[fc + a];
+                int ties[64], nt = 0;
+                for (int a = 0; a < A && nt < 64; ++a) if (lower[fc + a] == m) ties[nt++] = a;
+                const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+                if (plan && len < max_plan_len) plan[len] = a;
+                ++len;
+                n = fc + a;
+            }
+        }
+        if (plan) for (int i = len; i < max_plan_len; ++i) plan[i] = -1;
+        if (plan_len) *plan_len = len;
+        rng6[0] = g.s_hi; rng6[1] = g.s_lo; rng6[2] = g.inc_hi; rng6[3] = g.inc_lo;
+        rng6[4] = g.has_uint32; rng6[5] = g.uinteger;
+    }
+    if (env_steps) *env_steps = steps_taken;
+    if (updates_total) *updates_total = updates;
+    *n_nodes_io = n_nodes;
+    if (root_out) *root_out = root;
+    free(gpow); free(queue);
+    return rc;
+}

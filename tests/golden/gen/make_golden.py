@@ -18,6 +18,7 @@ Files written (all small):
   opd.npz   optimistic deterministic planner plans, root bounds and full trees
   uct.npz   MCTS/UCT plans, trees, env-step counts and PCG64 states before/after plan()
   uct_prior.npz  MCTSWithPriorPolicyAgent (per-state prior/rollout policies from a prior agent) plans and trees
+  state_aware.npz  StateAwarePlannerAgent multi-plan episodes: plans, trees, leaves, state values
   misc.npz  OLOP.allocation table, numpy Generator draw sequences used to pin the PCG64 port
 """
 import json
@@ -43,6 +44,7 @@ OPD = "<class 'rl_agents.agents.tree_search.deterministic.DeterministicPlannerAg
 UCT = "<class 'rl_agents.agents.tree_search.mcts.MCTSAgent'>"
 UCTP = "<class 'rl_agents.agents.tree_search.mcts_with_prior.MCTSWithPriorPolicyAgent'>"
 PRIOR = "<class 'prior_agents.BoltzmannQAgent'>"
+SAOPD = "<class 'rl_agents.agents.tree_search.state_aware.StateAwarePlannerAgent'>"
 
 
 def load_env_config(rel):
@@ -438,6 +440,73 @@ def golden_uct_prior():
     return store
 
 
+def golden_state_aware():
+    """StateAwarePlannerAgent (tree_search/state_aware.py): episodes of consecutive plan() calls on ONE agent -- the
+    planner's state_nodes / state_values dictionaries (and the nodes of earlier trees in them) persist across plans."""
+    store, names = {}, []
+    large1 = load_env_config("large/env_1.json")
+    hw = generators.highway_shaped(3, 4, 10, seed=3)
+    grid = generators.gridworld()
+    loop = load_env_config("env_loop.json")
+    cases = [
+        # name, mdp cfg, start state, agent cfg, seed, number of plan() calls
+        ("grid_b500", grid, 0, dict(budget=500, gamma=0.8), 0, 4),          # the reference's state-aware.json config
+        ("grid_b100_g09", grid, 55, dict(budget=100, gamma=0.9), 3, 3),
+        ("grid_accuracy", grid, 12, dict(budget=300, gamma=0.8, accuracy=0.05), 1, 3),
+        ("grid_no_aggregation", grid, 0, dict(budget=300, gamma=0.8, backup_aggregated_nodes=False), 2, 3),
+        ("grid_no_pruning", grid, 0, dict(budget=200, gamma=0.8, prune_suboptimal_leaves=False), 2, 2),
+        ("large1_b500", large1, 0, dict(budget=500, gamma=0.8), 0, 3),
+        ("large1_b37_g05", large1, 3, dict(budget=37, gamma=0.5), 2, 2),
+        ("highway_small", hw, 0, dict(budget=300, gamma=0.8), 0, 4),
+        ("highway_small_tr05", hw, 41, dict(budget=300, gamma=0.9, terminal_reward=0.5), 3, 3),
+        ("loop_b60", loop, 0, dict(budget=60, gamma=0.7), 4, 3),
+    ]
+    for name, cfg, s_start, agent_cfg, seed, n_plans in cases:
+        env = make_env(cfg, state=s_start)
+        agent = agent_factory(env, dict(agent_cfg, __class__=SAOPD))
+        agent.seed(seed)
+        p = "sa/" + name
+        put_mdp(store, p + "/mdp", cfg)
+        pc = agent.planner.config
+        n_states = np.asarray(cfg["reward"]).shape[0]
+        store[p + "/rng_before"] = rng_state(agent.planner.np_random)
+        states = []
+        for step in range(n_plans):
+            states.append(env.mdp.state)
+            try:
+                plan = agent.plan(env.mdp.state)
+            except ValueError as e:     # every leaf pruned: max() of an empty leaves list (state_aware.py:95)
+                assert "empty" in str(e)
+                store[p + "/raises_at_step"] = np.asarray(step)
+                break
+            planner = agent.planner
+            leaves = set(id(n) for n in planner.leaves)
+            tree = bfs_tree(planner.root, [("count", lambda n: n.count, np.int64),
+                                           ("lower", lambda n: float(n.value_lower), np.float64),
+                                           ("reward", lambda n: float(n.reward), np.float64),
+                                           ("done", lambda n: bool(n.done), bool),
+                                           ("depth", lambda n: n.depth, np.int32),
+                                           ("obs", lambda n: int(n.observation), np.int64),
+                                           ("is_leaf", lambda n: id(n) in leaves, bool)])
+            sv = np.array([planner.state_values[str(s)] if str(s) in planner.state_values else np.nan
+                           for s in range(n_states)])
+            q = "{}/step{}".format(p, step)
+            put(store, q, dict(plan=np.asarray(plan, np.int32), state_values=sv, n_leaves=len(planner.leaves),
+                               n_state_nodes=sum(len(v) for v in planner.state_nodes.values()),
+                               env_steps=len(planner.observations), rng_after=rng_state(planner.np_random)))
+            put(store, q + "/tree", tree)
+            _, _, term, trunc, _ = env.step(plan[0])
+            if term or trunc:
+                break
+        put(store, p, dict(states=np.asarray(states, np.int32), n_steps=len(states), seed=seed, budget=pc["budget"],
+                           gamma=pc["gamma"], terminal_reward=agent.config["terminal_reward"], accuracy=pc["accuracy"],
+                           backup_aggregated_nodes=pc["backup_aggregated_nodes"],
+                           prune_suboptimal_leaves=pc["prune_suboptimal_leaves"]))
+        names.append(name)
+    store["sa/names"] = np.asarray(names)
+    return store
+
+
 def golden_uct_cartpole():
     """MCTS on the restated CartPole (BASELINE config C3): single-root plans with full trees, and the
     reference's own functional test (tests/agents/tree_search/test_mcts.py:5-19) as a survival count."""
@@ -545,7 +614,7 @@ def main():
     out = os.path.join(REPO, "tests", "golden")
     only = sys.argv[1:]
     for name, fn in (("vi", golden_vi), ("opd", golden_opd), ("uct", golden_uct), ("uct_cartpole", golden_uct_cartpole),
-                     ("uct_prior", golden_uct_prior), ("misc", golden_misc)):
+                     ("uct_prior", golden_uct_prior), ("state_aware", golden_state_aware), ("misc", golden_misc)):
         if only and name not in only:
             continue
         store = fn()

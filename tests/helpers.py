@@ -39,3 +39,43 @@ def assert_tree_equal(z, prefix, tree, n_actions, fields):
         got = np.asarray(tree[mine])[order]
         want = z[prefix + "/" + gold_name]
         assert np.array_equal(got.astype(want.dtype), want), "tree field {} differs".format(gold_name)
+
+
+def replay_state_aware_episode(z, name, plan_fn):
+    """Replay one golden StateAwarePlannerAgent episode (consecutive plan() calls on one planner) and compare every
+    plan, tree, leaves set, state-value table, env-step count and generator state with the reference's.
+
+    plan_fn(cfg, s0, params, rng, planner_state) -> dict(plan, env_steps, rng_after, tree, state_values, planner);
+    raises ValueError where the reference does.  tree: creation-order arrays re-based at the root."""
+    import pytest
+    p = "sa/" + name
+    cfg = mdp_from_golden(z, p + "/mdp")
+    a = cfg["reward"].shape[1]
+    params = dict(budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
+                  terminal_reward=float(z[p + "/terminal_reward"]), accuracy=float(z[p + "/accuracy"]),
+                  backup_aggregated_nodes=bool(z[p + "/backup_aggregated_nodes"]),
+                  prune_suboptimal_leaves=bool(z[p + "/prune_suboptimal_leaves"]))
+    rng = np.array(z[p + "/rng_before"], dtype=np.uint64)
+    raises_at = int(z[p + "/raises_at_step"]) if p + "/raises_at_step" in z.files else -1
+    planner, env_steps = None, 0
+    for step in range(int(z[p + "/n_steps"])):
+        s0 = int(z[p + "/states"][step])
+        if step == raises_at:
+            with pytest.raises(ValueError):
+                plan_fn(cfg, s0, params, rng, planner)
+            break
+        out = plan_fn(cfg, s0, params, rng, planner)
+        q = "{}/step{}".format(p, step)
+        np.testing.assert_array_equal(out["plan"], z[q + "/plan"], err_msg=q)
+        np.testing.assert_array_equal(out["rng_after"], z[q + "/rng_after"], err_msg=q)
+        env_steps += int(out["env_steps"])
+        assert env_steps == int(z[q + "/env_steps"]), q
+        tree = out["tree"]
+        assert int(tree["alive"].sum()) == int(z[q + "/n_leaves"]), q
+        assert_tree_equal(z, q + "/tree", tree, a, dict(count="count", lower="lower", reward="reward", done="done",
+                                                        depth="depth", obs="state", is_leaf="alive"))
+        want = z[q + "/state_values"]
+        seen = ~np.isnan(want)              # states the reference's defaultdict holds; the others are at the default
+        assert np.array_equal(out["state_values"][seen], want[seen]), q
+        assert np.all(out["state_values"][~seen] == 1 / (1 - params["gamma"])), q
+        planner, rng = out["planner"], out["rng_after"]

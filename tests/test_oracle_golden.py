@@ -245,3 +245,20 @@ def test_uct_state_policies_subtree_sequence(golden):
         return oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], s0, episodes, horizon, gamma,
                                temperature, p, p, rng, max_steps=cfg["max_steps"], init_tree=tree)
     _subtree_sequence(golden, "subtree_highway", plan_fn, oracle.uct_reroot, group="uct_prior")
+
+
+def _sa_names(golden):
+    return [str(n) for n in golden["state_aware"]["sa/names"]]
+
+
+def test_state_aware_planner_episodes(golden):
+    """StateAwarePlannerAgent (tree_search/state_aware.py) over multi-plan episodes, planner state carried across
+    plans as the reference's planner object carries it; includes the episodes where the reference raises because
+    every leaf was pruned."""
+    from tests.helpers import replay_state_aware_episode
+
+    def plan_fn(cfg, s0, params, rng, planner):
+        return oracle.saopd_plan(cfg["transition"], cfg["reward"], cfg["terminal"], s0, rng_state=rng, planner=planner,
+                                 max_plan_len=params["budget"] + 1, **params)
+    for name in _sa_names(golden):
+        replay_state_aware_episode(golden["state_aware"], name, plan_fn)
