@@ -211,6 +211,37 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
                        int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
                        int64_t *count, int32_t *first_child);
 
+/* ---------------------------------------------------------------- state-aware OPD ----------- */
+/*
+ * StateAwarePlanner / StateAwareNode (tree_search/state_aware.py:10-137) over DeterministicNode.expand/update
+ * (deterministic.py:28-65): optimistic planning that aggregates the tree nodes observed in the same state.
+ * An mp_saopd holds, for n_planners independent planners of one table model, what a reference planner OBJECT holds
+ * across plan() calls: state_values and state_nodes (dictionaries keyed by str(observation) = the state index, :81-83)
+ * and every node ever created -- reset() (deterministic.py:102-104) only installs a new root and leaves list, so nodes
+ * of earlier trees keep taking part in prune() (:28-40) and backup_to_root() (:42-63) through state_nodes.
+ * mp_saopd_plan = step_by_reset + StateAwarePlanner.plan (:117-127) for every planner:
+ *   root_state int32 [n]; budget // |A| iterations of run() (:93-107); accuracy / backup_aggregated_nodes /
+ *   prune_suboptimal_leaves = the config of default_config (:85-91); gamma must not change between plans.
+ *   rng_state uint64 [n,6]: get_plan's random tie-breaks (deterministic.py:21-26), drawn twice per plan as the
+ *   reference does (deterministic.py:122 + state_aware.py:127).
+ *   plans int32 [n,max_plan_len] (-1 padded), plan_len int32 [n], env_steps / updates int64 [n] (planner.step calls /
+ *   Bellman backups of this plan), status int32 [n]: MP_OK, MP_ERR_REWARD_RANGE (ValueError, deterministic.py:46-47),
+ *   MP_ERR_ARG (every leaf pruned: the reference's max() of an empty list, :95) or MP_ERR_ALLOC (backup queue full).
+ * mp_saopd_export: arena of one planner in creation order (node rows [root, n_nodes) are the current tree; `alive` =
+ * "in planner.leaves"), arrays of capacity >= n_nodes (mp_saopd_info), and state_values double [S].
+ */
+typedef struct mp_saopd mp_saopd;
+int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd **out);
+int mp_saopd_free(mp_saopd *planners);
+int mp_saopd_plan(mp_ctx *ctx, mp_saopd *planners, const int32_t *root_state, int32_t budget, double gamma,
+                  double terminal_reward, double accuracy, int32_t backup_aggregated_nodes,
+                  int32_t prune_suboptimal_leaves, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                  int32_t *plan_len, int64_t *env_steps, int64_t *updates, int32_t *status, int32_t mem);
+int mp_saopd_info(mp_saopd *planners, int32_t *n_planners, int32_t *n_nodes, int32_t *root, int32_t *n_states);
+int mp_saopd_export(mp_saopd *planners, int32_t planner, int32_t cap, int32_t *parent, int32_t *action, int32_t *state,
+                    int32_t *depth, double *reward, double *lower, uint8_t *done, int64_t *count, int32_t *first_child,
+                    uint8_t *alive, double *state_values);
+
 /* ---------------------------------------------------------------- helpers ------------------- */
 /* OLOP.allocation (tree_search/olop.py:50-62) with OLOP.horizon (:42-44); host arithmetic. */
 int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t *horizon);

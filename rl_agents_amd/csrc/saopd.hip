@@ -1,0 +1,475 @@
+// saopd.hip -- state-aware optimistic planning (tree_search/state_aware.py) for many independent planners.
+//
+// The reference's StateAwarePlanner keeps, next to the OPD tree, two dictionaries keyed by str(observation):
+// state_values (an upper bound of V per observed state) and state_nodes (every node observed in that state).
+// One iteration (run(), :93-107) = argmax-U leaf over ALL leaves (U depends on the moving state values, so no leaf
+// order can be cached), expand, a queue-driven Bellman backup over aggregated nodes (backup_to_root, :42-63) and a
+// prune pass over all leaves in reverse order (:28-40).  Both dictionaries and every node ever created outlive
+// plan() calls (reset() only installs a new root and leaves list), so the planner state is an arena.
+//
+// Mapping: ONE PLANNER PER LANE.  The backup queue and the prune pass are order-dependent chains (first-in-first-out
+// processing against moving state values; pruned leaves stop dominating later ones), so a planner is sequential
+// and the parallel axis is planners.  All planners of a batch run the same number of iterations on the same node
+// ids, so the per-node arrays are laid out node-major, [node][planner]: the loops over "all nodes" (leaf scan,
+// expansion writes) are coalesced 64-wide, and only the per-state dictionaries and the list walks are gathers.
+//
+//   node   SaNode[cap][n] 16 B = {f64 lower, i32 next_same (state_nodes list link), u32 meta}
+//          meta = depth | HAS_CHILDREN | ALIVE ("in planner.leaves"): a list walk costs one dwordx4 per element
+//          state / parent / first_child i32 [cap][n], reward f64 [cap][n], done u8 [cap][n]
+//   state  sv f64 [S][n] (state_values, default 1/(1-gamma)), head / tail i32 [S][n] (state_nodes)
+//   queue  i32 [n][qcap] ring buffer per planner (the reference's list.pop(0) queue holds duplicates: thousands of
+//          entries at a few hundred nodes); overflow is reported per planner, never dropped silently
+//   tables gamma**d, terminal_reward*gamma**d/(1-gamma), accuracy*(1-gamma)*gamma**(d-1) from the host (libm pow)
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "common.hpp"
+#include "pcg64.hpp"
+
+namespace mp {
+
+struct alignas(16) SaNode {
+    double lower;
+    int32_t next_same;
+    uint32_t meta;
+};
+static_assert(sizeof(SaNode) == 16, "SaNode must be one dwordx4");
+constexpr uint32_t SA_ALIVE = 0x80000000u, SA_CHILDREN = 0x40000000u, SA_DEPTH = 0x3fffffffu;
+
+} // namespace mp
+
+// the planners of a batch: everything a reference StateAwarePlanner object holds across plan() calls
+struct mp_saopd {
+    mp_ctx *ctx = nullptr;
+    mp_model *model = nullptr;
+    int n = 0, S = 0, A = 0;
+    int cap = 0;        // node rows allocated
+    int n_nodes = 0;    // node rows in use (same for every planner of the batch)
+    int root = -1;      // row of the current roots
+    int qcap = 0;
+    double gamma = 0.0; // fixed at the first plan (sv defaults depend on it)
+    mp::SaNode *node = nullptr;
+    int32_t *state = nullptr, *parent = nullptr, *first_child = nullptr;
+    double *reward = nullptr;
+    uint8_t *done = nullptr;
+    double *sv = nullptr;
+    int32_t *head = nullptr, *tail = nullptr, *queue = nullptr;
+};
+
+namespace mp {
+
+struct SaArgs {
+    int n, S, A, K, root, n_prev, prev_root, qcap, done_on_next, max_plan_len;
+    int backup_aggregated, prune, fresh;
+    double gamma, vmax;
+    const Rec *rec;
+    const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
+    const int32_t *root_state;
+    uint64_t *rng;
+    SaNode *node;
+    int32_t *state, *parent, *first_child;
+    double *reward;
+    uint8_t *done;
+    double *sv;
+    int32_t *head, *tail, *queue;
+    int32_t *plans, *plan_len, *status;
+    int64_t *env_steps, *updates;
+};
+
+__global__ __launch_bounds__(64) void saopd_init_kernel(int n, int S, double vmax, double *sv, int32_t *head, int32_t *tail)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * S) return;
+    sv[i] = vmax; head[i] = -1; tail[i] = -1;
+}
+
+__global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int ntab = 3 * (p.K + 3);
+    for (int i = threadIdx.x; i < ntab; i += blockDim.x) lds_d[i] = p.tab[i];
+    __syncthreads();
+    const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.n) return;
+    const long n = p.n;
+    const int A = p.A;
+    // [row][planner] addressing
+    auto ND = [&](int i) -> SaNode & { return p.node[(long)i * n + r]; };
+    auto ST = [&](int i) -> int32_t & { return p.state[(long)i * n + r]; };
+    auto PA = [&](int i) -> int32_t & { return p.parent[(long)i * n + r]; };
+    auto FC = [&](int i) -> int32_t & { return p.first_child[(long)i * n + r]; };
+    auto RW = [&](int i) -> double & { return p.reward[(long)i * n + r]; };
+    auto SV = [&](int s) -> double & { return p.sv[(long)s * n + r]; };
+    auto HD = [&](int s) -> int32_t & { return p.head[(long)s * n + r]; };
+    auto TL = [&](int s) -> int32_t & { return p.tail[(long)s * n + r]; };
+    int32_t *queue = p.queue + (long)r * p.qcap;
+    const int qmask = p.qcap - 1;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+
+    // reset() (deterministic.py:102-104): the previous leaves list is dropped, a new root is installed
+    for (int i = p.prev_root; i < p.n_prev; ++i) {
+        const uint32_t m = ND(i).meta;
+        if (m & SA_ALIVE) ND(i).meta = m & ~SA_ALIVE;
+    }
+    const int root = p.root;
+    const int32_t s0 = p.root_state[r];
+    {
+        SaNode nd;
+        nd.lower = 0.0; nd.next_same = -1; nd.meta = SA_ALIVE; // depth 0
+        ND(root) = nd;
+        ST(root) = s0; PA(root) = -1; FC(root) = -1; RW(root) = 0.0;
+        p.done[(long)root * n + r] = 0;
+    }
+    // plan() (state_aware.py:117-121): the root state's entries start over
+    HD(s0) = root; TL(s0) = root;
+    SV(s0) = p.vmax;
+    int n_nodes = root + 1;
+    int status = MP_OK;
+    long steps_taken = 0, updates = 0;
+    // U of a node (state_aware.py:65-67): value_lower + gamma**depth * state_values[observation]
+    auto U_of = [&](const SaNode &nd, int i) { return nd.lower + gpow[nd.meta & SA_DEPTH] * SV(ST(i)); };
+
+    for (int k = 0; k < p.K && status == MP_OK; ++k) {
+        // ---- run() :95: max(leaves, key=U), first maximum in leaves order = ascending node id among the alive
+        int leaf = -1;
+        double bu = 0.0;
+        for (int i = root; i < n_nodes; ++i) {
+            const SaNode nd = ND(i);
+            if (nd.meta & SA_ALIVE) {
+                const double u = U_of(nd, i);
+                if (leaf < 0 || u > bu) { leaf = i; bu = u; }
+            }
+        }
+        if (leaf < 0) { status = MP_ERR_ARG; break; } // the reference raises: max() of an empty sequence
+        // ---- expand (deterministic.py:28-43) + update (:45-65, state_aware.py:15-26)
+        const SaNode lf = ND(leaf);
+        const int dl = (int)(lf.meta & SA_DEPTH);
+        ND(leaf).meta = (lf.meta & ~SA_ALIVE) | SA_CHILDREN;
+        FC(leaf) = n_nodes;
+        const int32_t sl = ST(leaf);
+        for (int a = 0; a < A; ++a) {
+            const int c = n_nodes + a;
+            const Rec rc = p.rec[(long)sl * A + a];
+            const bool terminated = (rc.flags & done_bit) != 0;
+            ++steps_taken;
+            if (!(0.0 <= rc.reward) || !(rc.reward <= 1.0)) { status = MP_ERR_REWARD_RANGE; break; }
+            const int d = dl + 1;
+            double lower = lf.lower + gpow[d - 1] * rc.reward;
+            if (terminated) lower = lower + trg[d];
+            const int32_t s = rc.next;
+            SaNode nd;
+            nd.lower = lower; nd.next_same = -1; nd.meta = SA_ALIVE | (uint32_t)d;
+            ND(c) = nd;
+            ST(c) = s; PA(c) = leaf; FC(c) = -1; RW(c) = rc.reward;
+            p.done[(long)c * n + r] = terminated ? 1 : 0;
+            // state_nodes[str(observation)].append(self)
+            const int32_t t = TL(s);
+            if (t < 0) HD(s) = c; else ND(t).next_same = c;
+            TL(s) = c;
+            // terminal states are worth 0 (update_value(observation, 0))
+            if (terminated && SV(s) - 0.0 > 0.0) SV(s) = 0.0;
+        }
+        if (status != MP_OK) break;
+        n_nodes += A;
+        // ---- backup_to_root (state_aware.py:42-63): first-in-first-out over a queue that holds duplicates
+        unsigned qh = 0, qt = 0;
+        queue[(qt++) & qmask] = leaf;
+        while (qh != qt) {
+            const int node = queue[(qh++) & qmask];
+            const int32_t sn = ST(node);
+            double delta = 0.0;
+            const int fc = FC(node);
+            if (fc >= 0) {
+                int bc = fc;
+                double bcu = U_of(ND(fc), fc);
+                for (int a = 1; a < A; ++a) {
+                    const double u = U_of(ND(fc + a), fc + a);
+                    if (u > bcu) { bc = fc + a; bcu = u; }
+                }
+                const double backup = RW(bc) + p.gamma * SV(ST(bc));
+                const double old = SV(sn);
+                delta = old - backup; // update_value (:109-119)
+                if (delta > 0.0) SV(sn) = backup;
+                ++updates;
+            }
+            for (int nb = HD(sn); nb >= 0;) {
+                const SaNode nd = ND(nb);
+                const int par = PA(nb);
+                if (par >= 0 && (nb == node || p.backup_aggregated) && delta > acc[nd.meta & SA_DEPTH]) {
+                    if (qt - qh >= (unsigned)p.qcap) { status = MP_ERR_ALLOC; break; }
+                    queue[(qt++) & qmask] = par;
+                }
+                nb = nd.next_same;
+            }
+            if (status != MP_OK) break;
+        }
+        if (status != MP_OK) break;
+        // ---- prune (run() :106-107, prune() :28-40): leaves in reverse order; a pruned leaf stops dominating
+        if (p.prune)
+            for (int i = n_nodes - 1; i >= root; --i) {
+                const SaNode me = ND(i);
+                if (!(me.meta & SA_ALIVE)) continue;
+                const int32_t s = ST(i);
+                const double svs = SV(s); // every node of the list is in state s
+                const int dm = (int)(me.meta & SA_DEPTH);
+                const double vub = me.lower + gpow[dm] * svs;
+                for (int nd_i = HD(s); nd_i >= 0;) {
+                    const SaNode nd = ND(nd_i);
+                    const int dn = (int)(nd.meta & SA_DEPTH);
+                    if (nd_i != i && nd.lower + gpow[dn] * svs >= vub && dn >= dm && (nd.meta & (SA_CHILDREN | SA_ALIVE))) {
+                        ND(i).meta = me.meta & ~SA_ALIVE;
+                        break;
+                    }
+                    nd_i = nd.next_same;
+                }
+            }
+    }
+    // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule (deterministic.py:21-26), TWICE:
+    // OptimisticDeterministicPlanner.plan computes one (deterministic.py:122) that StateAwarePlanner.plan drops
+    // before computing the one it returns (state_aware.py:122-127); both draw from the generator on ties
+    int len = 0;
+    if (status == MP_OK) {
+        Pcg64 g;
+        g.load(p.rng + (long)r * 6);
+        for (int pass = 0; pass < 2; ++pass) {
+            int node = root;
+            len = 0;
+            int fc = FC(node);
+            while (fc >= 0) {
+                double m = ND(fc).lower;
+                for (int a = 1; a < A; ++a) {
+                    const double l = ND(fc + a).lower;
+                    m = l > m ? l : m;
+                }
+                int nt = 0;
+                for (int a = 0; a < A; ++a) nt += ND(fc + a).lower == m ? 1 : 0;
+                int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
+                int act = 0;
+                for (int a = 0; a < A; ++a)
+                    if (ND(fc + a).lower == m) {
+                        if (pick == 0) { act = a; break; }
+                        --pick;
+                    }
+                if (pass == 1 && p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = act;
+                ++len;
+                node = fc + act;
+                fc = FC(node);
+            }
+        }
+        g.store(p.rng + (long)r * 6);
+    }
+    if (p.plans)
+        for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+    if (p.plan_len) p.plan_len[r] = len;
+    if (p.status) p.status[r] = status;
+    if (p.env_steps) p.env_steps[r] = steps_taken;
+    if (p.updates) p.updates[r] = updates;
+}
+
+template <typename T>
+static int grow_rows(T **buf, size_t old_rows, size_t new_rows, size_t n, hipStream_t st)
+{
+    T *nw = nullptr;
+    MP_HIP(hipMalloc(&nw, new_rows * n * sizeof(T)));
+    if (*buf) {
+        MP_HIP(hipMemcpyAsync(nw, *buf, old_rows * n * sizeof(T), hipMemcpyDeviceToDevice, st));
+        MP_HIP(hipStreamSynchronize(st));
+        MP_HIP(hipFree(*buf));
+    }
+    *buf = nw;
+    return MP_OK;
+}
+
+} // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd **out)
+{
+    if (!ctx || !model || !out) return fail(MP_ERR_ARG, "mp_saopd_create: NULL argument");
+    if (model->mode != MP_MODE_DETERMINISTIC || !model->rec)
+        return fail(MP_ERR_MODE, "mp_saopd_create: state-aware planning needs a deterministic table model");
+    if (n_planners < 1) return fail(MP_ERR_ARG, "mp_saopd_create: n_planners = %d", n_planners);
+    MP_HIP(hipSetDevice(ctx->device));
+    mp_saopd *pl = new (std::nothrow) mp_saopd;
+    if (!pl) return fail(MP_ERR_ALLOC, "mp_saopd_create: out of memory");
+    pl->ctx = ctx; pl->model = model; pl->n = n_planners; pl->S = model->S; pl->A = model->A;
+    // ring-buffer entries per planner (power of two); the reference's queue holds duplicates and reaches thousands
+    // of entries at a few hundred nodes.  MP_SAOPD_QUEUE overrides.
+    int q = 1 << 16;
+    if (const char *e = getenv("MP_SAOPD_QUEUE")) {
+        const int v = atoi(e);
+        if (v >= 2 && (v & (v - 1)) == 0) q = v;
+    }
+    pl->qcap = q;
+    const size_t sn = (size_t)pl->S * pl->n;
+    if (hipMalloc(&pl->sv, sn * 8) != hipSuccess || hipMalloc(&pl->head, sn * 4) != hipSuccess ||
+        hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->queue, (size_t)pl->n * q * 4) != hipSuccess) {
+        mp_saopd_free(pl);
+        return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
+    }
+    *out = pl;
+    return MP_OK;
+}
+
+int mp_saopd_free(mp_saopd *pl)
+{
+    if (!pl) return MP_OK;
+    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->sv, pl->head, pl->tail, pl->queue};
+    for (void *b : bufs)
+        if (b) (void)hipFree(b);
+    delete pl;
+    return MP_OK;
+}
+
+int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t budget, double gamma,
+                  double terminal_reward, double accuracy, int32_t backup_aggregated_nodes,
+                  int32_t prune_suboptimal_leaves, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                  int32_t *plan_len, int64_t *env_steps, int64_t *updates, int32_t *status, int32_t mem)
+{
+    if (!ctx || !pl || !root_state || !rng_state) return fail(MP_ERR_ARG, "mp_saopd_plan: NULL argument");
+    if (pl->ctx != ctx) return fail(MP_ERR_ARG, "mp_saopd_plan: planners belong to another context");
+    if (budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_saopd_plan: bad sizes");
+    if (!(gamma >= 0.0 && gamma < 1.0)) return fail(MP_ERR_ARG, "mp_saopd_plan: gamma must be in [0, 1)");
+    const bool fresh = pl->n_nodes == 0;
+    if (!fresh && gamma != pl->gamma)
+        return fail(MP_ERR_ARG, "mp_saopd_plan: gamma changed (%g -> %g) on a planner that holds state values", pl->gamma, gamma);
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int A = pl->A, n = pl->n;
+    const int K = budget / A; // deterministic.py:118
+    if (K + 2 > (int)SA_DEPTH) return fail(MP_ERR_ARG, "mp_saopd_plan: budget too large");
+    const int need = pl->n_nodes + 1 + K * A;
+    if (need > pl->cap) {
+        const int new_cap = need + (need - pl->cap < 4096 ? need / 2 : 0); // some slack for the following plans
+        const size_t o = (size_t)pl->n_nodes;
+        MP_TRY(grow_rows(&pl->node, o, new_cap, n, st));
+        MP_TRY(grow_rows(&pl->state, o, new_cap, n, st));
+        MP_TRY(grow_rows(&pl->parent, o, new_cap, n, st));
+        MP_TRY(grow_rows(&pl->first_child, o, new_cap, n, st));
+        MP_TRY(grow_rows(&pl->reward, o, new_cap, n, st));
+        MP_TRY(grow_rows(&pl->done, o, new_cap, n, st));
+        pl->cap = new_cap;
+    }
+    // tables with the reference's own operations
+    std::vector<double> tab((size_t)3 * (K + 3));
+    double *gpow = tab.data(), *trg = gpow + (K + 3), *acc = trg + (K + 3);
+    for (int d = 0; d < K + 3; ++d) {
+        gpow[d] = pow(gamma, (double)d);                                          // gamma ** depth
+        trg[d] = terminal_reward * gpow[d] / (1 - gamma);                          // deterministic.py:60
+        acc[d] = d >= 1 ? accuracy * (1 - gamma) * pow(gamma, (double)(d - 1)) : 0.0; // state_aware.py:62
+    }
+    double *d_tab = nullptr;
+    MP_TRY(upload_tables(ctx, 3, tab, &d_tab));
+
+    SaArgs a;
+    a.n = n; a.S = pl->S; a.A = A; a.K = K; a.root = pl->n_nodes; a.n_prev = pl->n_nodes;
+    a.prev_root = pl->root < 0 ? 0 : pl->root; a.qcap = pl->qcap;
+    a.done_on_next = pl->model->done_on_next; a.max_plan_len = max_plan_len;
+    a.backup_aggregated = backup_aggregated_nodes ? 1 : 0; a.prune = prune_suboptimal_leaves ? 1 : 0; a.fresh = fresh;
+    a.gamma = gamma; a.vmax = 1 / (1 - gamma);
+    a.rec = pl->model->rec; a.tab = d_tab;
+    a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
+    a.reward = pl->reward; a.done = pl->done; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
+    int32_t *d_rs = nullptr;
+    MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
+    a.root_state = d_rs;
+    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n * 6, mem, &a.rng));
+    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n * max_plan_len, mem, &a.plans));
+    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n, mem, &a.plan_len));
+    MP_TRY(stage_out_alloc(ctx, WS_IO5, status, (size_t)n, mem, &a.status));
+    MP_TRY(stage_out_alloc(ctx, WS_IO6, env_steps, (size_t)n, mem, &a.env_steps));
+    MP_TRY(stage_out_alloc(ctx, WS_IO7, updates, (size_t)n, mem, &a.updates));
+
+    const size_t lds = tab.size() * sizeof(double);
+    if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_saopd_plan: budget %d needs %zu B of LDS tables (> 64 KiB)", budget, lds);
+    MP_TRY(kernels_begin(ctx));
+    if (fresh) {
+        const long tot = (long)n * pl->S;
+        hipLaunchKernelGGL(saopd_init_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, n, pl->S, a.vmax, pl->sv,
+                           pl->head, pl->tail);
+    }
+    hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
+    MP_TRY(kernels_end(ctx, fresh ? 2 : 1));
+    MP_HIP(hipGetLastError());
+    pl->gamma = gamma;
+    pl->root = pl->n_nodes;
+    pl->n_nodes = need;
+
+    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n * 6, mem));
+    MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n * max_plan_len, mem));
+    MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n, mem));
+    MP_TRY(stage_out_copy(ctx, status, a.status, (size_t)n, mem));
+    MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n, mem));
+    MP_TRY(stage_out_copy(ctx, updates, a.updates, (size_t)n, mem));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+int mp_saopd_info(mp_saopd *pl, int32_t *n_planners, int32_t *n_nodes, int32_t *root, int32_t *n_states)
+{
+    if (!pl) return fail(MP_ERR_ARG, "mp_saopd_info: planner is NULL");
+    if (n_planners) *n_planners = pl->n;
+    if (n_nodes) *n_nodes = pl->n_nodes;
+    if (root) *root = pl->root;
+    if (n_states) *n_states = pl->S;
+    return MP_OK;
+}
+
+int mp_saopd_export(mp_saopd *pl, int32_t planner, int32_t cap, int32_t *parent, int32_t *action, int32_t *state,
+                    int32_t *depth, double *reward, double *lower, uint8_t *done, int64_t *count, int32_t *first_child,
+                    uint8_t *alive, double *state_values)
+{
+    if (!pl) return fail(MP_ERR_ARG, "mp_saopd_export: planner is NULL");
+    if (planner < 0 || planner >= pl->n) return fail(MP_ERR_ARG, "mp_saopd_export: planner %d out of range", planner);
+    if (cap < pl->n_nodes) return fail(MP_ERR_ARG, "mp_saopd_export: capacity %d < %d nodes", cap, pl->n_nodes);
+    MP_HIP(hipSetDevice(pl->ctx->device));
+    MP_HIP(hipStreamSynchronize(pl->ctx->stream));
+    const size_t nn = (size_t)pl->n_nodes, n = (size_t)pl->n;
+    // column `planner` of the [row][planner] arrays
+    auto column = [&](void *dst, const void *src, size_t elem, size_t rows) -> int {
+        MP_HIP(hipMemcpy2D(dst, elem, (const char *)src + (size_t)planner * elem, n * elem, elem, rows, hipMemcpyDeviceToHost));
+        return MP_OK;
+    };
+    std::vector<SaNode> hn(nn);
+    std::vector<int32_t> hpar(nn), hfc(nn);
+    if (nn) {
+        MP_TRY(column(hn.data(), pl->node, sizeof(SaNode), nn));
+        MP_TRY(column(hpar.data(), pl->parent, 4, nn));
+        MP_TRY(column(hfc.data(), pl->first_child, 4, nn));
+        if (state) MP_TRY(column(state, pl->state, 4, nn));
+        if (reward) MP_TRY(column(reward, pl->reward, 8, nn));
+        if (done) MP_TRY(column(done, pl->done, 1, nn));
+    }
+    if (state_values) MP_TRY(column(state_values, pl->sv, 8, (size_t)pl->S));
+    for (size_t i = 0; i < nn; ++i) {
+        if (parent) parent[i] = hpar[i];
+        if (first_child) first_child[i] = hfc[i];
+        if (lower) lower[i] = hn[i].lower;
+        if (depth) depth[i] = (int32_t)(hn[i].meta & SA_DEPTH);
+        if (alive) alive[i] = (hn[i].meta & SA_ALIVE) ? 1 : 0;
+        if (action) action[i] = -1;
+    }
+    if (action)
+        for (size_t i = 0; i < nn; ++i)
+            if (hfc[i] >= 0)
+                for (int a = 0; a < pl->A; ++a) action[hfc[i] + a] = a;
+    if (count) {
+        // DeterministicNode starts at count 1 and update() adds 1 along the whole root->child sequence
+        // (deterministic.py:17,64-65): count = 1 + subtree size, the root of a tree (no update of its own) one less
+        for (size_t i = 0; i < nn; ++i) count[i] = 1;
+        for (size_t i = nn; i-- > 0;)
+            if (hpar[i] >= 0) count[hpar[i]] += count[i];
+        for (size_t i = 0; i < nn; ++i) count[i] = hpar[i] >= 0 ? count[i] + 1 : count[i];
+    }
+    return MP_OK;
+}
+
+} // extern "C"

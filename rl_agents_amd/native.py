@@ -13,6 +13,7 @@ import numpy as np
 from . import build as _build
 
 MP_MEM_HOST, MP_MEM_DEVICE = 0, 1
+MP_OK, MP_ERR_HIP, MP_ERR_REWARD_RANGE, MP_ERR_ALLOC, MP_ERR_ARG, MP_ERR_MODE = 0, -1, -2, -3, -4, -5
 MODE_DETERMINISTIC, MODE_STOCHASTIC, MODE_SPARSE, MODE_CARTPOLE = 0, 1, 2, 3
 ERR_REWARD_RANGE, ERR_ARG, ERR_MODE = -2, -4, -5
 
@@ -55,6 +56,12 @@ SIGNATURES = {
     "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               c_i32]),
     "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_saopd_create": (C.c_int, [_vp, _vp, c_i32, P(_vp)]),
+    "mp_saopd_free": (C.c_int, [_vp]),
+    "mp_saopd_plan": (C.c_int, [_vp, _vp, _vp, c_i32, c_f64, c_f64, c_f64, c_i32, c_i32, _vp, c_i32, _vp, _vp, _vp, _vp,
+                                _vp, c_i32]),
+    "mp_saopd_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
+    "mp_saopd_export": (C.c_int, [_vp, c_i32, c_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_olop_allocation": (C.c_int, [c_i32, c_f64, P(c_i32), P(c_i32)]),
     "mp_last_kernel_ms": (C.c_int, [_vp, P(c_f64), P(c_i32)]),
 }
@@ -425,6 +432,71 @@ class Model(object):
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
             self.ctx._lib.mp_model_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class StateAwarePlanners(object):
+    """A batch of device-resident StateAwarePlanner objects (mp_saopd): state values, state-node lists and the node
+    arena persist across plan() calls, as in the reference (tree_search/state_aware.py:76-83)."""
+
+    def __init__(self, ctx, model, n_planners):
+        self.ctx, self.model, self.n = ctx, model, int(n_planners)
+        self._h = _vp()
+        _check(ctx._lib.mp_saopd_create(ctx._h, model._h, self.n, C.byref(self._h)))
+
+    def plan(self, root_state, budget, gamma, terminal_reward, rng_state, accuracy=0.0, backup_aggregated_nodes=True,
+             prune_suboptimal_leaves=True, max_plan_len=None):
+        rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
+        if rs.shape[0] != self.n:
+            raise ValueError("one root state per planner ({}), got {}".format(self.n, rs.shape[0]))
+        if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+                and rng_state.size == self.n * 6):
+            raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_planners, 6]")
+        mpl = int(budget + 1 if max_plan_len is None else max_plan_len)
+        out = dict(plans=np.full((self.n, mpl), -1, np.int32), plan_len=np.zeros(self.n, np.int32),
+                   env_steps=np.zeros(self.n, np.int64), updates=np.zeros(self.n, np.int64),
+                   status=np.zeros(self.n, np.int32))
+        _check(self.ctx._lib.mp_saopd_plan(self.ctx._h, self._h, _ptr(rs), int(budget), float(gamma),
+                                           float(terminal_reward), float(accuracy), int(bool(backup_aggregated_nodes)),
+                                           int(bool(prune_suboptimal_leaves)), _ptr(rng_state), mpl, _ptr(out["plans"]),
+                                           _ptr(out["plan_len"]), _ptr(out["env_steps"]), _ptr(out["updates"]),
+                                           _ptr(out["status"]), MP_MEM_HOST))
+        return out
+
+    def info(self):
+        n, nn, root, s = c_i32(), c_i32(), c_i32(), c_i32()
+        _check(self.ctx._lib.mp_saopd_info(self._h, C.byref(n), C.byref(nn), C.byref(root), C.byref(s)))
+        return dict(n_planners=n.value, n_nodes=nn.value, root=root.value, n_states=s.value)
+
+    def export(self, planner=0, current_tree_only=True):
+        """Arena of one planner; current_tree_only: the nodes of the last plan's tree, ids re-based at its root."""
+        inf = self.info()
+        cap = inf["n_nodes"]
+        t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),
+                 depth=np.zeros(cap, np.int32), reward=np.zeros(cap, np.float64), lower=np.zeros(cap, np.float64),
+                 done=np.zeros(cap, np.uint8), count=np.zeros(cap, np.int64), first_child=np.zeros(cap, np.int32),
+                 alive=np.zeros(cap, np.uint8))
+        sv = np.zeros(inf["n_states"], np.float64)
+        _check(self.ctx._lib.mp_saopd_export(self._h, int(planner), cap, _ptr(t["parent"]), _ptr(t["action"]),
+                                             _ptr(t["state"]), _ptr(t["depth"]), _ptr(t["reward"]), _ptr(t["lower"]),
+                                             _ptr(t["done"]), _ptr(t["count"]), _ptr(t["first_child"]), _ptr(t["alive"]),
+                                             _ptr(sv)))
+        if current_tree_only:
+            lo = inf["root"]
+            t = {k: v[lo:].copy() for k, v in t.items()}
+            for k in ("parent", "first_child"):
+                t[k] = np.where(t[k] >= 0, t[k] - lo, -1).astype(np.int32)
+        return t, sv
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._lib.mp_saopd_free(self._h)
         self._h = None
 
     def __del__(self):

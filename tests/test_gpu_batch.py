@@ -412,3 +412,52 @@ def test_policy_load_errors(ctx):
     with pytest.raises(native.NativeError):
         ctx.load_policy(model, np.full((50, 4), 0.25), np.zeros((50, 4)))
     model.close()
+
+
+@pytest.mark.parametrize("shape", ["grid", "garnet", "highway"])
+def test_state_aware_batch_vs_oracle(ctx, shape):
+    """200 planners per launch, three consecutive plans each (planner state kept on the device), vs the oracle run
+    planner by planner; ragged outcomes included (planners whose leaves all get pruned report MP_ERR_ARG)."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    cfg, budget, gamma = {"grid": (generators.gridworld(), 120, 0.8),
+                          "garnet": (generators.random_deterministic(40, 3, seed=5, terminal_rate=0.1), 90, 0.7),
+                          "highway": (generators.highway_shaped(3, 4, 10, seed=3), 150, 0.9)}[shape]
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    n = 200
+    model = ctx.load_table(t, r, term)
+    planners = native.StateAwarePlanners(ctx, model, n)
+    g = np.random.Generator(np.random.PCG64(17))
+    states = g.integers(0, r.shape[0], size=n).astype(np.int32)
+    rng = _rng_states(n, base=4242)
+    ref_rng = rng.copy()
+    ref_planner = [None] * n
+    dead = np.zeros(n, bool)
+    for step in range(3):
+        out = planners.plan(states, budget, gamma, 0.0, rng)
+        for i in range(n):
+            if dead[i]:
+                continue
+            try:
+                o = oracle.saopd_plan(t, r, term, int(states[i]), budget, gamma, rng_state=ref_rng[i],
+                                      planner=ref_planner[i], max_plan_len=budget + 1)
+            except ValueError:
+                assert out["status"][i] == native.MP_ERR_ARG, (step, i)
+                dead[i] = True
+                continue
+            assert out["status"][i] == 0, (step, i)
+            np.testing.assert_array_equal(out["plans"][i, :out["plan_len"][i]], o["plan"], err_msg=str((step, i)))
+            assert out["env_steps"][i] == o["env_steps"] and out["updates"][i] == o["updates"], (step, i)
+            np.testing.assert_array_equal(rng[i], o["rng_after"])
+            ref_rng[i], ref_planner[i] = o["rng_after"], o["planner"]
+            if i % 37 == 0:
+                tree, sv = planners.export(i)
+                assert np.array_equal(sv, o["state_values"]), (step, i)
+                for k in ("parent", "first_child", "state", "depth", "lower", "reward", "alive", "count"):
+                    assert np.array_equal(tree[k], o["tree"][k]), (step, i, k)
+        # every planner moves on along its own plan (dead ones stay put; their results are no longer compared)
+        states = np.where(out["plan_len"] > 0, t[states, np.maximum(out["plans"][:, 0], 0)], states).astype(np.int32)
+    assert (~dead).sum() > 20      # garnets prune themselves empty often; most grids and highways survive
+    planners.close()
+    model.close()
