@@ -289,3 +289,44 @@ def test_mcts_with_prior_agent_subtree_episode(golden):
         np.testing.assert_array_equal([n.count for n in nodes], z[q + "/tree/count"])
         assert np.array_equal(np.array([n.prior for n in nodes][1:]), z[q + "/tree/prior"][1:])
         env.step(plan[0])
+
+
+SAOPD = "<class 'rl_agents_amd.agents.tree_search.state_aware.StateAwarePlannerAgent'>"
+
+
+def test_state_aware_agent_episodes_match_reference(golden):
+    """StateAwarePlannerAgent through agent_factory: consecutive plan() calls of one agent along an episode equal the
+    reference agent's (the planner's state values and state-node lists persist across plans), and the agent raises
+    the reference's ValueError where every leaf gets pruned."""
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    z = golden["state_aware"]
+    for name in [str(n) for n in z["sa/names"]]:
+        p = "sa/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        env = _env(cfg, state=int(z[p + "/states"][0]))
+        agent = agent_factory(env, dict(__class__=SAOPD, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
+                                        terminal_reward=float(z[p + "/terminal_reward"]), accuracy=float(z[p + "/accuracy"]),
+                                        backup_aggregated_nodes=bool(z[p + "/backup_aggregated_nodes"]),
+                                        prune_suboptimal_leaves=bool(z[p + "/prune_suboptimal_leaves"])))
+        agent.seed(int(z[p + "/seed"]))
+        raises_at = int(z[p + "/raises_at_step"]) if p + "/raises_at_step" in z.files else -1
+        for step in range(int(z[p + "/n_steps"])):
+            assert env.mdp.state == int(z[p + "/states"][step])
+            if step == raises_at:
+                with pytest.raises(ValueError):
+                    agent.plan(env.mdp.state)
+                break
+            plan = agent.plan(env.mdp.state)
+            q = "{}/step{}".format(p, step)
+            np.testing.assert_array_equal(plan, z[q + "/plan"], err_msg=q)
+            assert agent.planner.env_steps == int(z[q + "/env_steps"])
+            np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[q + "/rng_after"])
+            nodes = _bfs_nodes(agent.planner.root)
+            np.testing.assert_array_equal([n.count for n in nodes], z[q + "/tree/count"])
+            assert np.array_equal(np.array([n.value_lower for n in nodes]), z[q + "/tree/lower"])
+            np.testing.assert_array_equal([bool(n.alive) for n in nodes], z[q + "/tree/is_leaf"])
+            want = z[q + "/state_values"]
+            seen = ~np.isnan(want)
+            assert np.array_equal(agent.planner.state_values[seen], want[seen]), q
+            env.step(plan[0])
