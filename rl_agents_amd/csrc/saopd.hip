@@ -17,7 +17,12 @@
 //          meta = depth | HAS_CHILDREN | ALIVE ("in planner.leaves"): a list walk costs one dwordx4 per element
 //          state / parent / first_child i32 [cap][n], reward f64 [cap][n], done u8 [cap][n]
 //   state  sv f64 [S][n] (state_values, default 1/(1-gamma)), head / tail i32 [S][n] (state_nodes)
-//   queue  i32 [n][qcap] ring buffer per planner (the reference's list.pop(0) queue holds duplicates: thousands of
+//   stamp  i32 [S][n]: the last iteration in which a state's value or node list changed.  prune() of a leaf depends
+//          only on its state's value and list (U of same-state nodes, depths, has-children / in-leaves flags, and
+//          those flags only ever change in the direction that removes dominators), so a leaf that survived the
+//          previous pass survives this one unless its state changed: the pass walks the lists of the leaves in
+//          changed states only -- same result, a small fraction of the reference's O(leaves x list) work
+//   queue  i32 [qcap][n] ring buffer per planner (the reference's list.pop(0) queue holds duplicates: thousands of
 //          entries at a few hundred nodes); overflow is reported per planner, never dropped silently
 //   tables gamma**d, terminal_reward*gamma**d/(1-gamma), accuracy*(1-gamma)*gamma**(d-1) from the host (libm pow)
 #include <math.h>
@@ -57,14 +62,15 @@ struct mp_saopd {
     double *reward = nullptr;
     uint8_t *done = nullptr;
     double *sv = nullptr;
-    int32_t *head = nullptr, *tail = nullptr, *queue = nullptr;
+    int32_t *head = nullptr, *tail = nullptr, *queue = nullptr, *stamp = nullptr;
+    int iters = 0;      // iterations run so far (stamps are unique across plans)
 };
 
 namespace mp {
 
 struct SaArgs {
     int n, S, A, K, root, n_prev, prev_root, qcap, done_on_next, max_plan_len;
-    int backup_aggregated, prune, fresh;
+    int backup_aggregated, prune, fresh, iter_base;
     double gamma, vmax;
     const Rec *rec;
     const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
@@ -75,16 +81,17 @@ struct SaArgs {
     double *reward;
     uint8_t *done;
     double *sv;
-    int32_t *head, *tail, *queue;
+    int32_t *head, *tail, *queue, *stamp;
     int32_t *plans, *plan_len, *status;
     int64_t *env_steps, *updates;
 };
 
-__global__ __launch_bounds__(64) void saopd_init_kernel(int n, int S, double vmax, double *sv, int32_t *head, int32_t *tail)
+__global__ __launch_bounds__(64) void saopd_init_kernel(int n, int S, double vmax, double *sv, int32_t *head, int32_t *tail,
+                                                        int32_t *stamp)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)n * S) return;
-    sv[i] = vmax; head[i] = -1; tail[i] = -1;
+    sv[i] = vmax; head[i] = -1; tail[i] = -1; stamp[i] = -1;
 }
 
 __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
@@ -107,8 +114,11 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
     auto SV = [&](int s) -> double & { return p.sv[(long)s * n + r]; };
     auto HD = [&](int s) -> int32_t & { return p.head[(long)s * n + r]; };
     auto TL = [&](int s) -> int32_t & { return p.tail[(long)s * n + r]; };
-    int32_t *queue = p.queue + (long)r * p.qcap;
+    auto SM = [&](int s) -> int32_t & { return p.stamp[(long)s * n + r]; };
+    // ring-buffer slot q of this planner (slot-major: a planner-major layout puts the 64 lanes of a wave 4*qcap bytes
+    // apart, i.e. in one cache set and one L2 channel)
     const int qmask = p.qcap - 1;
+    auto QU = [&](unsigned q) -> int32_t & { return p.queue[(long)(q & (unsigned)qmask) * n + r]; };
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
 
     // reset() (deterministic.py:102-104): the previous leaves list is dropped, a new root is installed
@@ -136,14 +146,28 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 
     for (int k = 0; k < p.K && status == MP_OK; ++k) {
         // ---- run() :95: max(leaves, key=U), first maximum in leaves order = ascending node id among the alive
+        const int cur = p.iter_base + k; // stamp of this iteration
         int leaf = -1;
         double bu = 0.0;
-        for (int i = root; i < n_nodes; ++i) {
-            const SaNode nd = ND(i);
-            if (nd.meta & SA_ALIVE) {
-                const double u = U_of(nd, i);
-                if (leaf < 0 || u > bu) { leaf = i; bu = u; }
+        constexpr int UN = 8; // rows in flight: the loads of a chunk are independent, only the compare is ordered
+        for (int i0 = root; i0 < n_nodes; i0 += UN) {
+            SaNode nd[UN];
+            int32_t st[UN];
+            double sv[UN];
+#pragma unroll
+            for (int j = 0; j < UN; ++j) {
+                const int i = min(i0 + j, n_nodes - 1);
+                nd[j] = ND(i);
+                st[j] = ST(i);
             }
+#pragma unroll
+            for (int j = 0; j < UN; ++j) sv[j] = (nd[j].meta & SA_ALIVE) ? SV(st[j]) : 0.0;
+#pragma unroll
+            for (int j = 0; j < UN; ++j)
+                if (i0 + j < n_nodes && (nd[j].meta & SA_ALIVE)) {
+                    const double u = nd[j].lower + gpow[nd[j].meta & SA_DEPTH] * sv[j];
+                    if (leaf < 0 || u > bu) { leaf = i0 + j; bu = u; }
+                }
         }
         if (leaf < 0) { status = MP_ERR_ARG; break; } // the reference raises: max() of an empty sequence
         // ---- expand (deterministic.py:28-43) + update (:45-65, state_aware.py:15-26)
@@ -171,63 +195,100 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
             const int32_t t = TL(s);
             if (t < 0) HD(s) = c; else ND(t).next_same = c;
             TL(s) = c;
+            SM(s) = cur;
             // terminal states are worth 0 (update_value(observation, 0))
             if (terminated && SV(s) - 0.0 > 0.0) SV(s) = 0.0;
         }
         if (status != MP_OK) break;
         n_nodes += A;
-        // ---- backup_to_root (state_aware.py:42-63): first-in-first-out over a queue that holds duplicates
-        unsigned qh = 0, qt = 0;
-        queue[(qt++) & qmask] = leaf;
-        while (qh != qt) {
-            const int node = queue[(qh++) & qmask];
-            const int32_t sn = ST(node);
+        // ---- backup_to_root (state_aware.py:42-63): first-in-first-out over a queue that holds duplicates.
+        // Planners of a wave have queues and lists of different lengths, so the nested loops (pop / walk the list
+        // of the popped node's state) are flattened into ONE loop in which every lane does one step of its own
+        // state machine per trip: a trip count of max-over-lanes(total steps) instead of a sum of per-pop maxima.
+        {
+            unsigned qh = 0, qt = 0;
+            QU(qt++) = leaf;
+            int node = -1, nb = -1;
             double delta = 0.0;
-            const int fc = FC(node);
-            if (fc >= 0) {
-                int bc = fc;
-                double bcu = U_of(ND(fc), fc);
-                for (int a = 1; a < A; ++a) {
-                    const double u = U_of(ND(fc + a), fc + a);
-                    if (u > bcu) { bc = fc + a; bcu = u; }
+            bool active = true;
+            while (active) {
+                if (nb < 0) { // pop, Bellman-back the popped node up (:49-56), then start on its state's list
+                    if (qh == qt) { active = false; continue; }
+                    node = QU(qh++);
+                    const int32_t sn = ST(node);
+                    const int fc = FC(node);
+                    delta = 0.0;
+                    if (fc >= 0) {
+                        int bc = fc;
+                        double bcu = U_of(ND(fc), fc);
+                        for (int a = 1; a < A; ++a) {
+                            const double u = U_of(ND(fc + a), fc + a);
+                            if (u > bcu) { bc = fc + a; bcu = u; }
+                        }
+                        const double backup = RW(bc) + p.gamma * SV(ST(bc));
+                        const double old = SV(sn);
+                        delta = old - backup; // update_value (:109-119)
+                        if (delta > 0.0) { SV(sn) = backup; SM(sn) = cur; }
+                        ++updates;
+                    }
+                    nb = HD(sn);
+                } else { // one neighbour (:58-63)
+                    const SaNode nd = ND(nb);
+                    const int par = PA(nb);
+                    if (par >= 0 && (nb == node || p.backup_aggregated) && delta > acc[nd.meta & SA_DEPTH]) {
+                        if (qt - qh >= (unsigned)p.qcap) { status = MP_ERR_ALLOC; active = false; continue; }
+                        QU(qt++) = par;
+                    }
+                    nb = nd.next_same;
                 }
-                const double backup = RW(bc) + p.gamma * SV(ST(bc));
-                const double old = SV(sn);
-                delta = old - backup; // update_value (:109-119)
-                if (delta > 0.0) SV(sn) = backup;
-                ++updates;
             }
-            for (int nb = HD(sn); nb >= 0;) {
-                const SaNode nd = ND(nb);
-                const int par = PA(nb);
-                if (par >= 0 && (nb == node || p.backup_aggregated) && delta > acc[nd.meta & SA_DEPTH]) {
-                    if (qt - qh >= (unsigned)p.qcap) { status = MP_ERR_ALLOC; break; }
-                    queue[(qt++) & qmask] = par;
-                }
-                nb = nd.next_same;
-            }
-            if (status != MP_OK) break;
         }
         if (status != MP_OK) break;
-        // ---- prune (run() :106-107, prune() :28-40): leaves in reverse order; a pruned leaf stops dominating
-        if (p.prune)
-            for (int i = n_nodes - 1; i >= root; --i) {
-                const SaNode me = ND(i);
-                if (!(me.meta & SA_ALIVE)) continue;
-                const int32_t s = ST(i);
-                const double svs = SV(s); // every node of the list is in state s
-                const int dm = (int)(me.meta & SA_DEPTH);
-                const double vub = me.lower + gpow[dm] * svs;
-                for (int nd_i = HD(s); nd_i >= 0;) {
+        // ---- prune (run() :106-107, prune() :28-40): leaves in reverse order; a pruned leaf stops dominating.
+        // Pass 1 (uniform over rows, coalesced): the alive leaves whose state changed this iteration, in reverse
+        // order, into the (now idle) queue buffer.  Pass 2: the list walks, flattened like the backup loop.
+        if (p.prune) {
+            int nc = 0;
+            for (int i0 = n_nodes - 1; i0 >= root; i0 -= UN) {
+                SaNode mes[UN];
+                int32_t sts[UN], stamps[UN];
+#pragma unroll
+                for (int j = 0; j < UN; ++j) {
+                    const int i = max(i0 - j, root);
+                    mes[j] = ND(i);
+                    sts[j] = ST(i);
+                }
+#pragma unroll
+                for (int j = 0; j < UN; ++j) stamps[j] = (mes[j].meta & SA_ALIVE) ? SM(sts[j]) : -1;
+#pragma unroll
+                for (int j = 0; j < UN; ++j)
+                    if (i0 - j >= root && (mes[j].meta & SA_ALIVE) && stamps[j] == cur) QU((unsigned)nc++) = i0 - j;
+            }
+            int ci = 0, i = -1, nd_i = -1, dm = 0;
+            uint32_t my_meta = 0;
+            double svs = 0.0, vub = 0.0;
+            while (ci < nc || nd_i >= 0) {
+                if (nd_i < 0) { // next candidate leaf
+                    i = QU((unsigned)ci++);
+                    const SaNode me = ND(i);
+                    const int32_t s = ST(i);
+                    svs = SV(s); // every node of the list is in state s
+                    my_meta = me.meta;
+                    dm = (int)(me.meta & SA_DEPTH);
+                    vub = me.lower + gpow[dm] * svs;
+                    nd_i = HD(s);
+                } else { // one node of state_nodes[str(observation)]
                     const SaNode nd = ND(nd_i);
                     const int dn = (int)(nd.meta & SA_DEPTH);
                     if (nd_i != i && nd.lower + gpow[dn] * svs >= vub && dn >= dm && (nd.meta & (SA_CHILDREN | SA_ALIVE))) {
-                        ND(i).meta = me.meta & ~SA_ALIVE;
-                        break;
+                        ND(i).meta = my_meta & ~SA_ALIVE;
+                        nd_i = -1;
+                    } else {
+                        nd_i = nd.next_same;
                     }
-                    nd_i = nd.next_same;
                 }
             }
+        }
     }
     // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule (deterministic.py:21-26), TWICE:
     // OptimisticDeterministicPlanner.plan computes one (deterministic.py:122) that StateAwarePlanner.plan drops
@@ -301,17 +362,9 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
     mp_saopd *pl = new (std::nothrow) mp_saopd;
     if (!pl) return fail(MP_ERR_ALLOC, "mp_saopd_create: out of memory");
     pl->ctx = ctx; pl->model = model; pl->n = n_planners; pl->S = model->S; pl->A = model->A;
-    // ring-buffer entries per planner (power of two); the reference's queue holds duplicates and reaches thousands
-    // of entries at a few hundred nodes.  MP_SAOPD_QUEUE overrides.
-    int q = 1 << 16;
-    if (const char *e = getenv("MP_SAOPD_QUEUE")) {
-        const int v = atoi(e);
-        if (v >= 2 && (v & (v - 1)) == 0) q = v;
-    }
-    pl->qcap = q;
     const size_t sn = (size_t)pl->S * pl->n;
     if (hipMalloc(&pl->sv, sn * 8) != hipSuccess || hipMalloc(&pl->head, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->queue, (size_t)pl->n * q * 4) != hipSuccess) {
+        hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
     }
@@ -322,7 +375,8 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
 int mp_saopd_free(mp_saopd *pl)
 {
     if (!pl) return MP_OK;
-    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->sv, pl->head, pl->tail, pl->queue};
+    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->sv, pl->head, pl->tail, pl->queue,
+                    pl->stamp};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete pl;
@@ -346,6 +400,24 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     const int A = pl->A, n = pl->n;
     const int K = budget / A; // deterministic.py:118
     if (K + 2 > (int)SA_DEPTH) return fail(MP_ERR_ARG, "mp_saopd_plan: budget too large");
+    // backup queue: the reference's list holds duplicates and reaches ~10x the node count of a plan (4 600 entries at
+    // 325 nodes on the 10x10 grid); 32 entries per node of this plan, at least 4096, a power of two.  MP_SAOPD_QUEUE
+    // sets the entries per planner; a full queue is reported per planner (MP_ERR_ALLOC), never dropped silently.
+    // The queue is empty between plans, so it can be replaced when a larger budget comes along.
+    {
+        long want = 32L * (1 + K * A);
+        int q = 4096;
+        if (const char *e = getenv("MP_SAOPD_QUEUE")) { want = atol(e); q = 2; }
+        while (q < want && q < (1 << 28)) q <<= 1;
+        if (q > pl->qcap) {
+            if (pl->queue) { MP_HIP(hipStreamSynchronize(ctx->stream)); MP_HIP(hipFree(pl->queue)); pl->queue = nullptr; }
+            if (hipMalloc(&pl->queue, (size_t)pl->n * q * 4) != hipSuccess)
+                return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", (size_t)pl->n * q * 4);
+            pl->qcap = q;
+        }
+        if (1 + K * A > pl->qcap) // the prune pass lists its candidate leaves in the idle queue
+            return fail(MP_ERR_ARG, "mp_saopd_plan: queue of %d entries is smaller than the %d nodes of a plan", pl->qcap, 1 + K * A);
+    }
     const int need = pl->n_nodes + 1 + K * A;
     if (need > pl->cap) {
         const int new_cap = need + (need - pl->cap < 4096 ? need / 2 : 0); // some slack for the following plans
@@ -378,6 +450,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.rec = pl->model->rec; a.tab = d_tab;
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
     a.reward = pl->reward; a.done = pl->done; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
+    a.stamp = pl->stamp; a.iter_base = pl->iters;
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
     a.root_state = d_rs;
@@ -394,12 +467,13 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     if (fresh) {
         const long tot = (long)n * pl->S;
         hipLaunchKernelGGL(saopd_init_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, n, pl->S, a.vmax, pl->sv,
-                           pl->head, pl->tail);
+                           pl->head, pl->tail, pl->stamp);
     }
     hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, fresh ? 2 : 1));
     MP_HIP(hipGetLastError());
     pl->gamma = gamma;
+    pl->iters += K;
     pl->root = pl->n_nodes;
     pl->n_nodes = need;
 

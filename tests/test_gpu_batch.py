@@ -461,3 +461,18 @@ def test_state_aware_batch_vs_oracle(ctx, shape):
     assert (~dead).sum() > 20      # garnets prune themselves empty often; most grids and highways survive
     planners.close()
     model.close()
+
+
+def test_state_aware_queue_overflow_is_reported(ctx, monkeypatch):
+    """A backup queue that is too small is a per-planner MP_ERR_ALLOC status, not a silent truncation."""
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    cfg = generators.gridworld()
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    monkeypatch.setenv("MP_SAOPD_QUEUE", "512")      # >= 1 + budget (the prune pass lists candidates in it)
+    planners = native.StateAwarePlanners(ctx, model, 64)
+    rng = _rng_states(64, base=5)
+    out = planners.plan(np.arange(64, dtype=np.int32), 400, 0.8, 0.0, rng, max_plan_len=4)
+    assert (out["status"] == native.MP_ERR_ALLOC).any() and set(np.unique(out["status"])) <= {0, native.MP_ERR_ALLOC}
+    planners.close()
+    model.close()

@@ -32,6 +32,24 @@ def main():
         if os.environ["POLICY"] == "uniform":  # same plans as the state-independent uniform policy: kernel A/B
             w = np.ones((2, 10000, 5))
         policy = ctx.load_policy(model, w[0] / w[0].sum(1, keepdims=True), w[1] / w[1].sum(1, keepdims=True))
+    if what == "saopd":  # state-aware OPD, the reference's GridWorld config (budget 500, gamma 0.8), 3 consecutive plans
+        cfg = generators.gridworld()
+        model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+        budget = int(sys.argv[3]) if len(sys.argv) > 3 else 500
+        planners = native.StateAwarePlanners(ctx, model, n)
+        states = np.random.Generator(np.random.PCG64(3)).integers(0, 100, size=n).astype(np.int32)
+        for rep in range(3):
+            t0 = time.perf_counter()
+            out = planners.plan(states, budget, 0.8, 0.0, rng, max_plan_len=8)
+            dt = time.perf_counter() - t0
+            ms, _ = ctx.last_kernel_ms()
+            ok = out["status"] == 0
+            print("saopd n={} budget={} plan#{} kernel {:.3f} ms wall {:.1f} ms  ok {}  updates/planner {:.0f}  -> {:.3e} "
+                  "expansion-steps/s".format(n, budget, rep, ms, dt * 1e3, int(ok.sum()), out["updates"][ok].mean(),
+                                             out["env_steps"].sum() / (ms * 1e-3)))
+            states = np.where(out["plan_len"] > 0, cfg["transition"][states, np.maximum(out["plans"][:, 0], 0)],
+                              states).astype(np.int32)
+        return
     for rep in range(3):
         t0 = time.perf_counter()
         if what == "uct":
