@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "opd", "vi", "rvi", "vi_dense"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "opd", "saopd", "vi", "rvi", "vi_dense"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -421,6 +421,79 @@ def bench_opd(args, rank, world, local):
     return res
 
 
+def bench_saopd(args, rank, world, local):
+    """State-aware OPD (tree_search/state_aware.py) at the reference's own GridWorld configuration
+    (scripts/configs/GridWorld/agents/state-aware.json: budget 500, gamma 0.8; 10x10 grid).  A step = the first plan()
+    of a fresh batch of planners (the costly one: ~4 200 Bellman backups per planner), planner creation included."""
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    n_roots = args.roots or 16384
+    budget, gamma = 500, 0.8
+    cfg = generators.gridworld()
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    s_, a_ = r.shape
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_table(t, r, term)
+    all_roots = np.random.Generator(np.random.PCG64(12345)).integers(0, s_, size=world * n_roots).astype(np.int32)
+    s0 = all_roots[rank * n_roots:(rank + 1) * n_roots]
+    rng0 = seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots))
+    last = {}
+
+    def step():
+        planners = native.StateAwarePlanners(ctx, model, n_roots)
+        out = planners.plan(s0, budget, gamma, 0.0, rng0.copy(), max_plan_len=8)
+        last.update(out=out, ms=ctx.last_kernel_ms()[0])
+        planners.close()
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    out, k_ms = last["out"], last["ms"]
+    assert (out["status"] == 0).all()
+    env_steps = int(out["env_steps"].sum())
+    total = sum_over_ranks(float(env_steps), world)
+    k = budget // a_
+    # algorithmic bytes of one plan: per expansion |A| model records (13 B) and node records (37 B); per iteration
+    # the leaf argmax reads (lower, depth, state, state value) = 28 B of every leaf (~1/3 of the nodes are leaves),
+    # per Bellman backup |A| children (28 B) + two state values; list walks of pruning / aggregation are not counted
+    alg = float(n_roots) * (k * a_ * (13 + 37) + sum(28.0 * (1 + i * a_) / 3 for i in range(k))) + \
+        float(out["updates"].sum()) * (28 * a_ + 16)
+    res = dict(
+        metric="rollout env-steps/sec (state-aware OPD plan(), budget=500)", unit="env-steps/s",
+        value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
+        config=dict(workload="state_aware_opd_gridworld_S{}_A{}_budget{}_planners{}_per_gpu".format(s_, a_, budget, n_roots),
+                    n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, budget=budget, gamma=gamma,
+                    plan_ms_per_root=1e3 * dt / args.steps / n_roots,
+                    bellman_backups_per_planner=float(out["updates"].mean()),
+                    parallelism="planners sharded over {} GPU(s)".format(world)),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
+                      kernel="saopd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = host_cores()
+        n_cpu = 64 * cores
+        oracle.saopd_plan_batch(t, r, term, all_roots[:cores], budget, gamma, n_threads=cores)
+        done, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            o = oracle.saopd_plan_batch(t, r, term, np.resize(all_roots, n_cpu), budget, gamma,
+                                        rng_states=np.resize(rng0, (n_cpu, 6)), n_threads=cores)
+            done += int(o["env_steps"].sum())
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=done / cdt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="oracle/planning_oracle.c orc_saopd_plan_batch, first plan of fresh planners, OpenMP, {} "
+                                          "planners per batch for {:.1f} s".format(n_cpu, cdt))
+    ctx.synchronize()
+    return res
+
+
 def bench_vi(args, rank, world, local, dense, robust=False):
     import torch
     from rl_agents_amd import native
@@ -523,6 +596,8 @@ def main():
             res = bench_uct_cartpole(args, rank, world, local)
         elif args.workload == "opd":
             res = bench_opd(args, rank, world, local)
+        elif args.workload == "saopd":
+            res = bench_saopd(args, rank, world, local)
         else:
             res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
     res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",

@@ -349,3 +349,26 @@ def saopd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=
         tree[k] = np.where(tree[k] >= 0, tree[k] - lo, -1).astype(np.int32)
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, updates=updates.value, rng_after=rng, tree=tree,
                 state_values=planner.sv.copy(), planner=planner)
+
+
+def saopd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
+                     accuracy=0.0, backup_aggregated_nodes=True, prune_suboptimal_leaves=True, done_rule="source",
+                     max_plan_len=8, n_threads=1):
+    """First plan() of len(s0) fresh planners (no planner state returned): per-planner plans, env steps, status."""
+    t, r, term = _i64(transition), _f64(reward), _u8(terminal)
+    s, a = r.shape
+    s0 = np.ascontiguousarray(s0, dtype=np.int32)
+    n = len(s0)
+    rng = (np.tile(np.array([0, 1, 0, 1, 0, 0], np.uint64), (n, 1)) if rng_states is None
+           else np.array(rng_states, dtype=np.uint64).reshape(n, 6))
+    plans = np.full((n, max_plan_len), -1, np.int32)
+    plan_len, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    steps, updates = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    rc = lib().orc_saopd_plan_batch(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"),
+                                    n, _p(s0, C.c_int32), int(budget), C.c_double(gamma), C.c_double(terminal_reward),
+                                    C.c_double(accuracy), int(bool(backup_aggregated_nodes)),
+                                    int(bool(prune_suboptimal_leaves)), _p(rng, C.c_uint64), max_plan_len,
+                                    _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(steps, C.c_int64),
+                                    _p(updates, C.c_int64), _p(status, C.c_int32), int(n_threads))
+    assert rc == 0
+    return dict(plans=plans, plan_len=plan_len, env_steps=steps, updates=updates, status=status, rng_after=rng)

@@ -826,3 +826,32 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
     free(gpow); free(queue);
     return rc;
 }
+
+/* First plan() of n fresh StateAwarePlanner objects, OpenMP over planners (cpu_baseline leg of bench.py). */
+int orc_saopd_plan_batch(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                         int n, const int32_t *s0, int budget, double gamma, double terminal_reward, double accuracy,
+                         int backup_aggregated_nodes, int prune_suboptimal_leaves, uint64_t *rng6 /* [n,6] */,
+                         int max_plan_len, int32_t *plans, int32_t *plan_len, int64_t *env_steps, int64_t *updates,
+                         int32_t *status, int n_threads)
+{
+    const int cap = 1 + (budget / A) * A;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n; ++i) {
+        int32_t *i32 = malloc((size_t)cap * 6 * sizeof(int32_t) + (size_t)S * 2 * sizeof(int32_t));
+        double *f64 = malloc((size_t)cap * 2 * sizeof(double) + (size_t)S * sizeof(double));
+        int64_t *cnt = malloc((size_t)cap * sizeof(int64_t));
+        uint8_t *u8 = malloc((size_t)cap * 2);
+        int32_t nn = 0, root = 0;
+        int rc = ORC_ERR_ALLOC;
+        if (i32 && f64 && cnt && u8)
+            rc = orc_saopd_plan(S, A, T, R, term, done_on_next, s0[i], budget, gamma, terminal_reward, accuracy,
+                                backup_aggregated_nodes, prune_suboptimal_leaves, rng6 + (long)i * 6, max_plan_len,
+                                plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
+                                env_steps ? env_steps + i : NULL, updates ? updates + i : NULL, 1, cap, &nn, &root,
+                                i32, i32 + cap, i32 + 2 * cap, i32 + 3 * cap, f64, f64 + cap, u8, cnt, i32 + 4 * cap,
+                                u8 + cap, i32 + 5 * cap, f64 + 2 * cap, i32 + 6 * cap, i32 + 6 * cap + S);
+        if (status) status[i] = rc;
+        free(i32); free(f64); free(cnt); free(u8);
+    }
+    return ORC_OK;
+}

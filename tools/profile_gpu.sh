@@ -9,7 +9,7 @@ OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-for wl in uct uct_cartpole opd vi vi_dense; do
+for wl in uct uct_prior uct_cartpole opd saopd vi rvi vi_dense; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- \
       python /root/repo/bench.py --workload $wl --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace_$wl.log 2>&1
 done

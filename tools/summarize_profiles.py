@@ -50,7 +50,7 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "uct_cartpole", "opd", "vi", "vi_dense"):
+    for wl in ("uct", "uct_prior", "uct_cartpole", "opd", "saopd", "vi", "rvi", "vi_dense"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
