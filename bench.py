@@ -178,17 +178,36 @@ def bench_uct(args, rank, world, local, with_prior=False):
         tables = z / z.sum(axis=1, keepdims=True)
         policy = ctx.load_policy(model, tables, tables)
         p = tables                                           # the oracle takes the [S, A] tables in p's place
-    gathered = torch.empty(world * n_roots, dtype=torch.float64, device=dev) if world > 1 else None
-
+    # N > 1: the path's only exchange is the all_gather of the per-root results.  Nothing in the next plan depends
+    # on it, so it runs on its own stream, double-buffered, behind the next launch (the closing barrier of the timed
+    # region waits for the last one).
     d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        comm = torch.cuda.Stream(device=dev)
+        d_vals = [d_val, torch.empty_like(d_val)]
+        gathered = [torch.empty(world * n_roots, dtype=torch.float64, device=dev) for _ in range(2)]
+        kernel_done = [torch.cuda.Event(), torch.cuda.Event()]
+        gather_done = [None, None]
+    turn = [0]
 
     def step():
+        b = turn[0] & 1
+        turn[0] += 1
+        main = torch.cuda.current_stream()
+        if world > 1 and gather_done[b] is not None:
+            main.wait_event(gather_done[b])              # buffer b is free again
         ctx.uct_plan_device(model, n_roots, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
-                            plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps, policy=policy)
+                            plans=d_plans, plan_len=d_len, root_value=d_vals[b] if world > 1 else d_val, env_steps=d_steps,
+                            policy=policy)
         d_total.add_(d_steps.sum())
         if world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(gathered, d_val)     # per-root results to every rank: the path's only exchange
+            kernel_done[b].record(main)
+            with torch.cuda.stream(comm):
+                comm.wait_event(kernel_done[b])
+                dist.all_gather_into_tensor(gathered[b], d_vals[b])   # per-root results to every rank
+                gather_done[b] = torch.cuda.Event()
+                gather_done[b].record(comm)
 
     for _ in range(args.warmup):
         step()
@@ -246,7 +265,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
         n_cpu = max(2048, 64 * cores)
@@ -327,7 +346,7 @@ def bench_uct_cartpole(args, rank, world, local):
                       note="state lives in registers: compute/latency bound by construction"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
         n_cpu = 64 * cores
@@ -408,7 +427,7 @@ def bench_opd(args, rank, world, local):
                       kernel="opd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
         n_cpu = 4 * cores
@@ -476,7 +495,7 @@ def bench_saopd(args, rank, world, local):
                       kernel="saopd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
         n_cpu = 64 * cores
