@@ -167,6 +167,8 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
  *   prior   double [S,A]  prior[s,a]   = probability handed to MCTSNode.expand when a node reached in state s is expanded
  *   rollout double [S,A]  rollout[s,:] = distribution MCTS.evaluate samples from in state s (Generator.choice(p=...))
  * Host pointers (policy upload is outside every timed region, like model upload).  |A| must be one of 2,3,4,5,6,8.
+ * A policy is tied to the model it was loaded for (its records are fused into the policy tables): use it with that
+ * model only (checked) and free it before the model.
  * mp_uct_plan_policy = mp_uct_plan with (prior_p, rollout_p) looked up per state; everything else is identical,
  * including mp_uct_step_tree / mp_uct_tree_export on the trees it leaves.
  */
@@ -227,6 +229,7 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
  *   plans int32 [n,max_plan_len] (-1 padded), plan_len int32 [n], env_steps / updates int64 [n] (planner.step calls /
  *   Bellman backups of this plan), status int32 [n]: MP_OK, MP_ERR_REWARD_RANGE (ValueError, deterministic.py:46-47),
  *   MP_ERR_ARG (every leaf pruned: the reference's max() of an empty list, :95) or MP_ERR_ALLOC (backup queue full).
+ * The model must outlive the planners (they read its transition records).
  * mp_saopd_export: arena of one planner in creation order (node rows [root, n_nodes) are the current tree; `alive` =
  * "in planner.leaves"), arrays of capacity >= n_nodes (mp_saopd_info), and state_values double [S].
  */

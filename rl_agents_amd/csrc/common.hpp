@@ -86,8 +86,17 @@ struct mp_ctx {
     mp::ViGraphKey vi_graph_key;
 };
 
+namespace mp {
+inline uint64_t next_model_serial()
+{
+    static uint64_t serial = 0; // models are created under the caller's serialisation of a ctx (see mi355plan.h)
+    return ++serial;
+}
+} // namespace mp
+
 struct mp_model {
     mp_ctx *ctx = nullptr;
+    uint64_t serial = mp::next_model_serial(); // distinguishes a model from a later one at the same address
     int mode = 0, M = 1, S = 0, A = 0, B = 0;
     int Sc = 0; // dense models: number of next-state columns (= S, or the full |S| for a block of rows)
     int done_on_next = 0, max_steps = 0;
@@ -107,6 +116,8 @@ struct mp_model {
 // per-state prior / rollout policies of one model (mcts_with_prior.py:47-62), device
 struct mp_policy {
     mp_ctx *ctx = nullptr;
+    const mp_model *model = nullptr; // the model whose records are fused into frec
+    uint64_t model_serial = 0;
     int S = 0, A = 0;
     int stride = 0;             // doubles per row of prior / thr: A rounded up to even (16-byte rows)
     int frq = 0;                // 16-byte chunks per fused record: 1 + ceil((A-1)/4)

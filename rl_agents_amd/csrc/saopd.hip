@@ -51,6 +51,7 @@ constexpr uint32_t SA_ALIVE = 0x80000000u, SA_CHILDREN = 0x40000000u, SA_DEPTH =
 struct mp_saopd {
     mp_ctx *ctx = nullptr;
     mp_model *model = nullptr;
+    uint64_t model_serial = 0;
     int n = 0, S = 0, A = 0;
     int cap = 0;        // node rows allocated
     int n_nodes = 0;    // node rows in use (same for every planner of the batch)
@@ -361,7 +362,7 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
     MP_HIP(hipSetDevice(ctx->device));
     mp_saopd *pl = new (std::nothrow) mp_saopd;
     if (!pl) return fail(MP_ERR_ALLOC, "mp_saopd_create: out of memory");
-    pl->ctx = ctx; pl->model = model; pl->n = n_planners; pl->S = model->S; pl->A = model->A;
+    pl->ctx = ctx; pl->model = model; pl->model_serial = model->serial; pl->n = n_planners; pl->S = model->S; pl->A = model->A;
     const size_t sn = (size_t)pl->S * pl->n;
     if (hipMalloc(&pl->sv, sn * 8) != hipSuccess || hipMalloc(&pl->head, sn * 4) != hipSuccess ||
         hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess) {

@@ -634,7 +634,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     if (!ctx || !model || !root_state || !rng_state || (!pol && (!prior_p || !rollout_p)))
         return fail(MP_ERR_ARG, "mp_uct_plan: NULL argument");
     const bool cart = model->mode == MP_MODE_CARTPOLE;
-    if (pol && (cart || pol->S != model->S || pol->A != model->A || pol->ctx != ctx))
+    if (pol && (cart || pol->model != model || pol->model_serial != model->serial || pol->ctx != ctx))
         return fail(MP_ERR_ARG, "mp_uct_plan_policy: the policy was not loaded for this model");
     if (model->mode != MP_MODE_DETERMINISTIC && !cart)
         return fail(MP_ERR_MODE, "mp_uct_plan: model mode %d is neither a deterministic table nor CartPole", model->mode);
@@ -856,7 +856,7 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
     }
     mp_policy *pol = new (std::nothrow) mp_policy;
     if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
-    pol->ctx = ctx; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift;
+    pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift;
     if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
         hipMalloc(&pol->frec, hf.size() * 4) != hipSuccess) {
         mp_policy_free(pol);

@@ -309,7 +309,7 @@ class Context(object):
             raise ValueError("prior / rollout must be [S, A] = [{}, {}]".format(model.S, model.A))
         h = _vp()
         _check(self._lib.mp_policy_load(self._h, model._h, _ptr(pr), _ptr(ro), C.byref(h)))
-        return Policy(self, h)
+        return Policy(self, h, model)
 
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
                  root_steps=None, max_plan_len=None, policy=None):
@@ -509,8 +509,8 @@ class StateAwarePlanners(object):
 class Policy(object):
     """Device-resident per-state prior / rollout policy tables (mp_policy)."""
 
-    def __init__(self, ctx, handle):
-        self.ctx, self._h = ctx, handle
+    def __init__(self, ctx, handle, model=None):
+        self.ctx, self._h, self.model = ctx, handle, model      # keeps the model it is tied to alive
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):

@@ -411,6 +411,14 @@ def test_policy_load_errors(ctx):
         ctx.load_policy(model, bad, np.full((50, 4), 0.25))
     with pytest.raises(native.NativeError):
         ctx.load_policy(model, np.full((50, 4), 0.25), np.zeros((50, 4)))
+    # a policy carries the fused records of ITS model: another model of the same shape is refused
+    policy = ctx.load_policy(model, np.full((50, 4), 0.25), np.full((50, 4), 0.25))
+    other = generators.random_deterministic(50, 4, seed=2)
+    model2 = ctx.load_table(other["transition"], other["reward"], other["terminal"])
+    with pytest.raises(native.NativeError):
+        ctx.uct_plan(model2, [0], 5, 5, 0.8, 10.0, None, None, _rng_states(1), policy=policy)
+    policy.close()
+    model2.close()
     model.close()
 
 
