@@ -17,7 +17,8 @@ from rl_agents_amd.envs import generators  # noqa: E402
 def main():
     what = sys.argv[1] if len(sys.argv) > 1 else "uct"
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
-    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    shape = [int(x) for x in os.environ.get("SHAPE", "10,10,100").split(",")]   # SHAPE=3,4,10: a table that fits L1
+    cfg = generators.highway_shaped(*shape, seed=0)
     ctx = native.Context(0)
     model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
     non_term = np.flatnonzero(~cfg["terminal"])
@@ -28,9 +29,9 @@ def main():
     p = np.ones(5) / 5
     policy = None
     if os.environ.get("POLICY"):  # per-state prior / rollout tables (mp_uct_plan_policy)
-        w = np.random.Generator(np.random.PCG64(2)).random((2, 10000, 5)) ** 2
+        w = np.random.Generator(np.random.PCG64(2)).random((2, shape[0] * shape[1] * shape[2], 5)) ** 2
         if os.environ["POLICY"] == "uniform":  # same plans as the state-independent uniform policy: kernel A/B
-            w = np.ones((2, 10000, 5))
+            w = np.ones((2, shape[0] * shape[1] * shape[2], 5))
         policy = ctx.load_policy(model, w[0] / w[0].sum(1, keepdims=True), w[1] / w[1].sum(1, keepdims=True))
     if what == "saopd":  # state-aware OPD, the reference's GridWorld config (budget 500, gamma 0.8), 3 consecutive plans
         cfg = generators.gridworld()
