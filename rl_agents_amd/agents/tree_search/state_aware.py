@@ -35,6 +35,8 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
         held = self._device
         if held is None or held[0] is not model or held[1] != n:
             if held is not None:
+                logger.warning("state-aware planner: model or batch size changed (%d -> %d planners); the state values and "
+                               "state-node lists kept from earlier plans are dropped", held[1], n)
                 held[2].close()
             held = self._device = (model, n, native.StateAwarePlanners(self.models.ctx, model, n))
         return held[2]
