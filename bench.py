@@ -584,7 +584,24 @@ def bench_vi(args, rank, world, local, dense, robust=False):
     if dense:
         res["roofline"]["mfma_tflops"] = flops / (per_sweep_ms * 1e-3) / 1e12
         res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
-    if rank == 0 and not args.no_cpu_baseline and not dense:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and dense:
+        # bounded sample: the oracle's dense sweep (numpy's pairwise add.reduce restated, one thread) costs
+        # O(S^2 |A|); time it at S = 2000 (160 MB of transitions) and scale by (2000 / S)^2
+        from oracle import oracle
+        s_cpu = min(2000, s_)
+        g_cpu = np.random.Generator(np.random.PCG64(0))
+        t_cpu = g_cpu.random((s_cpu, a_, s_cpu))
+        t_cpu /= t_cpu.sum(-1, keepdims=True)
+        r_cpu = g_cpu.random((s_cpu, a_))
+        t1, reps, n_sw = time.perf_counter(), 0, 5
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            oracle.vi_solve("stochastic", t_cpu, r_cpu, None, gamma=gamma, iterations=n_sw, rtol=-1.0, atol=-1.0)
+            reps += 1
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=reps * n_sw / cdt * (s_cpu / s_) ** 2, unit="sweeps/s", cores=1, kind="port",
+                                   sample="oracle/planning_oracle.c orc_vi_solve (dense), {} x {} sweeps at S = {} in {:.1f} s, "
+                                          "scaled by (S_sample / S)^2 to S = {}".format(reps, n_sw, s_cpu, cdt, s_))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dense:
         from oracle import oracle
         t1 = time.perf_counter()
         reps = 0

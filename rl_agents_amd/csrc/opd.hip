@@ -105,13 +105,18 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 //              the 4-byte-per-expansion parent map: 8 waves per SIMD instead of 3 per CU.  A wave of this kernel
 //              is a chain of dependent round trips (argmax -> leaf record -> model record), i.e. latency bound:
 //              ten times more resident roots hide that latency and multiply the batch throughput.
-template <bool GLB>
+// EXPG (with GLB = false): the parent map goes to HBM as well (it is written once per expansion, off the chain, and
+//              read back in coalesced chunks by the closing passes), leaving 64*T*8 B of LDS per root: at budget 5000
+//              that is 40 448 B, FOUR roots per CU instead of three -- the 1024-root shard of BASELINE C4 stays on the
+//              low-latency variant (2.0 ms instead of 2.7 ms).
+template <bool GLB, bool EXPG = false>
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = p.T;                                                // odd, >= ceil(cap / 64)
     double *leafU = GLB ? p.leaf_global + (long)blockIdx.x * 64 * T : lds;      // [64 * T]
-    int32_t *exp_lds = reinterpret_cast<int32_t *>(GLB ? lds : lds + 64 * T);   // [K]
+    int32_t *exp_lds = EXPG ? p.expanded + (long)blockIdx.x * (p.K > 0 ? p.K : 1)
+                            : reinterpret_cast<int32_t *>(GLB ? lds : lds + 64 * T);   // [K]
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x;
     const int root = blockIdx.x;
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         // lower bounds: same pass over the creation-time L values
         for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
         __syncthreads();
+        int ek = 0; // EXPG: 64 entries of the parent map per coalesced read
         for (int k = k_done - 1; k >= 0; --k) {
             const int g = 1 + k * A;
             double m = LU(g);
@@ -244,7 +250,14 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 const double v = LU(g + a);
                 if (v > m) m = v;
             }
-            if (lane == 0) LU(exp_lds[k]) = m;
+            int parent_k;
+            if (EXPG) {
+                if (k == k_done - 1 || (k & 63) == 63) ek = (k & ~63) + lane < k_done ? exp_lds[(k & ~63) + lane] : 0;
+                parent_k = __builtin_amdgcn_readlane(ek, k & 63);
+            } else {
+                parent_k = exp_lds[k];
+            }
+            if (lane == 0) LU(parent_k) = m;
             if (GLB) __syncthreads(); // the next step may read this node through memory, from other lanes
         }
         __syncthreads();
@@ -308,7 +321,11 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1);
         p.n_nodes_out[root] = n_nodes;
     }
-    for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
+    if (EXPG) {
+        for (int k = k_done + lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = -1;
+    } else {
+        for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
+    }
 #undef LU
 }
 
@@ -334,15 +351,21 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     const int T = (int)((cap + 63) / 64) | 1;
     const size_t lds_full = (size_t)64 * T * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
     const size_t lds_map = (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    const size_t lds_bounds = (size_t)64 * T * sizeof(double); // bounds only, parent map in HBM (EXPG)
     if (lds_map > kLdsBytes - 1024)
         return fail(MP_ERR_ARG, "mp_opd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds_map, kLdsBytes - 1024);
     // variant: LDS-resident bounds while every root of the batch fits on the chip that way, else high occupancy
     const char *force = getenv("MP_OPD_MODEL"); // "lds" / "global": test hook
-    const long lds_roots = (long)ctx->prop.multiProcessorCount * (long)((kLdsBytes - 1024) / (lds_full ? lds_full : 1));
-    bool glb = lds_full > kLdsBytes - 1024 || n_roots > lds_roots;
+    const long cus = ctx->prop.multiProcessorCount;
+    const long lds_roots = cus * (long)((kLdsBytes - 1024) / (lds_full ? lds_full : 1));
+    const long expg_roots = cus * (long)((kLdsBytes - 1024) / (lds_bounds ? lds_bounds : 1));
+    bool glb = lds_bounds > kLdsBytes - 1024 || n_roots > expg_roots;
     if (force && force[0] == 'g') glb = true;
-    if (force && force[0] == 'l' && lds_full <= kLdsBytes - 1024) glb = false;
-    const size_t lds = glb ? lds_map : lds_full;
+    if (force && force[0] == 'l' && lds_bounds <= kLdsBytes - 1024) glb = false;
+    // bounds in LDS: keep the parent map there too while that costs no residency
+    bool expg = !glb && (lds_full > kLdsBytes - 1024 || n_roots > lds_roots);
+    if (force && !glb && force[1] == 'd' && force[2] == 's' && force[3] == 'x') expg = true; // "ldsx": test hook
+    const size_t lds = glb ? lds_map : (expg ? lds_bounds : lds_full);
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
@@ -386,11 +409,13 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
     if (lds > 64 * 1024)
-        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(glb ? opd_kernel<true> : opd_kernel<false>),
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(glb ? opd_kernel<true, false>
+                                                                      : (expg ? opd_kernel<false, true> : opd_kernel<false, false>)),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    if (glb) hipLaunchKernelGGL(opd_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL(opd_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (glb) hipLaunchKernelGGL((opd_kernel<true, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (expg) hipLaunchKernelGGL((opd_kernel<false, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((opd_kernel<false, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 

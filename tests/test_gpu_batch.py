@@ -126,10 +126,11 @@ def _cmp_opd(ctx, cfg, n_roots, budget, gamma, terminal_reward=0.0, seed=0, done
     return out
 
 
-@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
 def test_opd_batch_highway_budget5000(ctx, variant, monkeypatch):
     """C4 shape: highway-shaped S=10 000, A=5, budget 5000 (1000 expansions), with the upper-bound array in LDS
-    (40 KB per root) and in HBM/L2 (the high-occupancy variant used for big batches)."""
+    (40 KB per root; "ldsx": parent map in HBM so that four roots fit a CU) and in HBM/L2 (the high-occupancy
+    variant used for big batches)."""
     from rl_agents_amd.envs import generators
     monkeypatch.setenv("MP_OPD_MODEL", variant)
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
@@ -143,7 +144,7 @@ def test_opd_budget_beyond_lds(ctx):
     _cmp_opd(ctx, cfg, 6, 25000, 0.9, seed=6)
 
 
-@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
 @pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (64, 640)])
 def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     from rl_agents_amd.envs import generators
