@@ -23,6 +23,8 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
             rng_states = self.batch_rng_states(n)
         cfg = self.config
         budget = int(cfg["budget"])
+        if cfg["gamma"] == 1 and budget >= model.A:
+            raise ZeroDivisionError("float division by zero")       # gamma ** depth / (1 - gamma), deterministic.py:53
         out = self.models.ctx.opd_plan(model, root_states, budget, cfg["gamma"], cfg.get("terminal_reward", 0),
                                        rng_states, max_plan_len=budget // model.A + 1)
         if (out["status"] == native.ERR_REWARD_RANGE).any():

@@ -47,6 +47,8 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
         if rng_states is None:
             rng_states = self.batch_rng_states(n)
         cfg = self.config
+        if cfg["gamma"] == 1:
+            raise ZeroDivisionError("division by zero")              # 1 / (1 - gamma), state_aware.py:83,120
         planners = self.device_planners(model, n)
         out = planners.plan(root_states, int(cfg["budget"]), cfg["gamma"], cfg.get("terminal_reward", 0), rng_states,
                             accuracy=cfg["accuracy"], backup_aggregated_nodes=cfg["backup_aggregated_nodes"],

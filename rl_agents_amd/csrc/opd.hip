@@ -347,6 +347,8 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     if (A > 64) return fail(MP_ERR_ARG, "mp_opd_plan: |A| = %d > 64 actions not supported", A);
     if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_opd_plan: bad sizes");
     const int K = budget / A; // deterministic.py:118
+    if (K > 0 && !(gamma != 1.0))
+        return fail(MP_ERR_ARG, "mp_opd_plan: gamma = 1 (the reference divides by 1 - gamma, deterministic.py:53: ZeroDivisionError)");
     const long cap = 1 + (long)K * A;
     const int T = (int)((cap + 63) / 64) | 1;
     const size_t lds_full = (size_t)64 * T * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);

@@ -330,3 +330,13 @@ def test_state_aware_agent_episodes_match_reference(golden):
             seen = ~np.isnan(want)
             assert np.array_equal(agent.planner.state_values[seen], want[seen]), q
             env.step(plan[0])
+
+
+def test_gamma_one_raises_like_the_reference(golden):
+    """OPD / state-aware planning divide by 1 - gamma (deterministic.py:53, state_aware.py:83): ZeroDivisionError."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    cfg = mdp_from_golden(golden["opd"], "opd/grid_c1/mdp")
+    for cls in (OPD, SAOPD):
+        agent = agent_factory(_env(cfg), dict(__class__=cls, budget=40, gamma=1.0))
+        with pytest.raises(ZeroDivisionError):
+            agent.plan(0)
