@@ -34,6 +34,7 @@
 
 #include "common.hpp"
 #include "pcg64.hpp"
+#include "wave.hpp"
 
 namespace mp {
 
@@ -65,6 +66,13 @@ struct mp_saopd {
     double *sv = nullptr;
     int32_t *head = nullptr, *tail = nullptr, *queue = nullptr, *stamp = nullptr;
     int iters = 0;      // iterations run so far (stamps are unique across plans)
+    int wave = 0;       // 1: one planner per wavefront, planner-major arrays ([planner][node], [planner][state],
+                        //    [planner][slot]); 0: one planner per lane, node-major arrays
+    // element (row i, planner r) of a node array = i * node_si + r * node_sr, likewise states and queue slots
+    long node_si() const { return wave ? 1 : n; }
+    long node_sr() const { return wave ? cap : 1; }
+    long state_si() const { return wave ? 1 : n; }
+    long state_sr() const { return wave ? S : 1; }
 };
 
 namespace mp {
@@ -72,6 +80,7 @@ namespace mp {
 struct SaArgs {
     int n, S, A, K, root, n_prev, prev_root, qcap, done_on_next, max_plan_len;
     int backup_aggregated, prune, fresh, iter_base;
+    int cap; // wave kernel: node rows allocated per planner
     double gamma, vmax;
     const Rec *rec;
     const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
@@ -333,13 +342,248 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
     if (p.updates) p.updates[r] = updates;
 }
 
+
+// ---- one planner per WAVEFRONT (planner-major arrays).  The order-dependent parts (backup queue, list walks, list
+// appends, plan descent) run as uniform code -- every lane computes the same thing, lane 0 stores -- so a dependent
+// access is one cache line for the whole wave instead of 64 scattered ones; the data-parallel parts use the lanes:
+// leaf argmax over 64 rows per trip (DPP reduction), the |A| children of an expansion and of a Bellman backup one
+// per lane, the candidate leaves of a prune pass 64 rows per trip (ballot).  Same results as saopd_kernel; a plan's
+// latency is that of ONE planner's chain (~12x shorter than a lane's, whose wave waits for its slowest lane and
+// pays 64 scattered lines per access), and there are 64x more waves to hide it.
+__global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int ntab = 3 * (p.K + 3);
+    const int lane = threadIdx.x;
+    for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
+    __syncthreads();
+    const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
+    const int r = blockIdx.x;
+    const int A = p.A;
+    const long nb = (long)r * p.cap, sb = (long)r * p.S, qb = (long)r * p.qcap;
+    auto ND = [&](int i) -> SaNode & { return p.node[nb + i]; };
+    auto ST = [&](int i) -> int32_t & { return p.state[nb + i]; };
+    auto PA = [&](int i) -> int32_t & { return p.parent[nb + i]; };
+    auto FC = [&](int i) -> int32_t & { return p.first_child[nb + i]; };
+    auto RW = [&](int i) -> double & { return p.reward[nb + i]; };
+    auto SV = [&](int s) -> double & { return p.sv[sb + s]; };
+    auto HD = [&](int s) -> int32_t & { return p.head[sb + s]; };
+    auto TL = [&](int s) -> int32_t & { return p.tail[sb + s]; };
+    auto SM = [&](int s) -> int32_t & { return p.stamp[sb + s]; };
+    const unsigned qmask = (unsigned)p.qcap - 1u;
+    auto QU = [&](unsigned q) -> int32_t & { return p.queue[qb + (q & qmask)]; };
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+    const bool l0 = lane == 0;
+
+    // reset(): drop the previous leaves list (64 rows per trip), install the new root
+    for (int i = p.prev_root + lane; i < p.n_prev; i += 64) {
+        const uint32_t m = ND(i).meta;
+        if (m & SA_ALIVE) ND(i).meta = m & ~SA_ALIVE;
+    }
+    const int root = p.root;
+    const int32_t s0 = p.root_state[r];
+    if (l0) {
+        SaNode nd;
+        nd.lower = 0.0; nd.next_same = -1; nd.meta = SA_ALIVE;
+        ND(root) = nd;
+        ST(root) = s0; PA(root) = -1; FC(root) = -1; RW(root) = 0.0;
+        p.done[nb + root] = 0;
+        HD(s0) = root; TL(s0) = root; // plan(): the root state's entries start over
+        SV(s0) = p.vmax;
+    }
+    __syncthreads();
+    int n_nodes = root + 1;
+    int status = MP_OK;
+    long steps_taken = 0, updates = 0;
+
+    for (int k = 0; k < p.K && status == MP_OK; ++k) {
+        const int cur = p.iter_base + k;
+        // ---- max(leaves, key=U): 64 rows per trip, then (max U, lowest id) across the lanes
+        double bu = ninf;
+        int leaf = 0x7fffffff;
+        for (int i = root + lane; i < n_nodes; i += 64) {
+            const SaNode nd = ND(i);
+            if (nd.meta & SA_ALIVE) {
+                const double u = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(ST(i));
+                if (u > bu || leaf == 0x7fffffff) { bu = u; leaf = i; } // ascending ids within a lane: first maximum
+            }
+        }
+        wave_argmax(bu, leaf);
+        if (leaf == 0x7fffffff) { status = MP_ERR_ARG; break; } // max() of an empty leaves list
+        // ---- expand + update: one child per lane, then the list appends in action order
+        const SaNode lf = ND(leaf);
+        const int dl = (int)(lf.meta & SA_DEPTH);
+        const int32_t sl = ST(leaf);
+        const int g = n_nodes;
+        bool bad = false, term_c = false;
+        int32_t s_c = 0;
+        if (lane < A) {
+            const Rec rc = p.rec[(long)sl * A + lane];
+            term_c = (rc.flags & done_bit) != 0;
+            bad = !(0.0 <= rc.reward) || !(rc.reward <= 1.0);
+            const int d = dl + 1;
+            double lower = lf.lower + gpow[d - 1] * rc.reward;
+            if (term_c) lower = lower + trg[d];
+            s_c = rc.next;
+            const int c = g + lane;
+            SaNode nd;
+            nd.lower = lower; nd.next_same = -1; nd.meta = SA_ALIVE | (uint32_t)d;
+            ND(c) = nd;
+            ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = rc.reward;
+            p.done[nb + c] = term_c ? 1 : 0;
+        }
+        if (l0) {
+            ND(leaf).meta = (lf.meta & ~SA_ALIVE) | SA_CHILDREN;
+            FC(leaf) = g;
+        }
+        steps_taken += A;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads();
+        for (int a = 0; a < A; ++a) { // state_nodes[str(observation)].append(child), update_value(observation, 0)
+            const int32_t s = __shfl(s_c, a);
+            const bool term = __shfl((int)term_c, a) != 0;
+            const int c = g + a;
+            const int32_t t = TL(s);
+            const double svs = SV(s);
+            if (l0) {
+                if (t < 0) HD(s) = c; else ND(t).next_same = c;
+                TL(s) = c;
+                SM(s) = cur;
+                if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
+            }
+            __syncthreads();
+        }
+        n_nodes += A;
+        // ---- backup_to_root: uniform first-in-first-out loop, the |A| children of a popped node one per lane
+        {
+            unsigned qh = 0, qt = 0;
+            if (l0) QU(qt) = leaf;
+            ++qt;
+            __syncthreads();
+            while (qh != qt && status == MP_OK) {
+                const int node = QU(qh++);
+                const int32_t sn = ST(node);
+                const int fc = FC(node);
+                double delta = 0.0;
+                if (fc >= 0) {
+                    double u = ninf, bk = 0.0;
+                    int a_id = 0x7fffffff;
+                    if (lane < A) {
+                        const int c = fc + lane;
+                        const SaNode nd = ND(c);
+                        const double svc = SV(ST(c));
+                        u = nd.lower + gpow[nd.meta & SA_DEPTH] * svc;
+                        bk = RW(c) + p.gamma * svc;
+                        a_id = lane;
+                    }
+                    wave_argmax(u, a_id); // first maximal U in action order
+                    const double backup = __shfl(bk, a_id);
+                    const double old = SV(sn);
+                    delta = old - backup;
+                    if (delta > 0.0 && l0) { SV(sn) = backup; SM(sn) = cur; }
+                    ++updates;
+                }
+                __syncthreads();
+                for (int nbr = HD(sn); nbr >= 0;) {
+                    const SaNode nd = ND(nbr);
+                    const int par = PA(nbr);
+                    if (par >= 0 && (nbr == node || p.backup_aggregated) && delta > acc[nd.meta & SA_DEPTH]) {
+                        if (qt - qh >= (unsigned)p.qcap) { status = MP_ERR_ALLOC; break; }
+                        if (l0) QU(qt) = par;
+                        ++qt;
+                    }
+                    nbr = nd.next_same;
+                }
+                __syncthreads();
+            }
+        }
+        if (status != MP_OK) break;
+        // ---- prune: candidate leaves (alive, state changed this iteration) 64 rows per trip in reverse order, each
+        // candidate's list walked as uniform code
+        if (p.prune)
+            for (int i0 = n_nodes - 1; i0 >= root; i0 -= 64) {
+                const int i_mine = i0 - lane;
+                bool cand = false;
+                if (i_mine >= root) {
+                    const uint32_t m = ND(i_mine).meta;
+                    cand = (m & SA_ALIVE) && SM(ST(i_mine)) == cur;
+                }
+                unsigned long long todo = __ballot(cand);
+                while (todo) {
+                    const int j = __ffsll((long long)todo) - 1; // lane 0 holds the highest row of the chunk
+                    todo &= todo - 1;
+                    const int i = i0 - j;
+                    const SaNode me = ND(i);
+                    const int32_t s = ST(i);
+                    const double svs = SV(s);
+                    const int dm = (int)(me.meta & SA_DEPTH);
+                    const double vub = me.lower + gpow[dm] * svs;
+                    for (int nd_i = HD(s); nd_i >= 0;) {
+                        const SaNode nd = ND(nd_i);
+                        const int dn = (int)(nd.meta & SA_DEPTH);
+                        if (nd_i != i && nd.lower + gpow[dn] * svs >= vub && dn >= dm && (nd.meta & (SA_CHILDREN | SA_ALIVE))) {
+                            if (l0) ND(i).meta = me.meta & ~SA_ALIVE;
+                            break;
+                        }
+                        nd_i = nd.next_same;
+                    }
+                    __syncthreads();
+                }
+            }
+    }
+    // ---- get_plan, twice (see saopd_kernel), uniform
+    int len = 0;
+    if (status == MP_OK) {
+        Pcg64 gen;
+        gen.load(p.rng + (long)r * 6);
+        for (int pass = 0; pass < 2; ++pass) {
+            int node = root;
+            len = 0;
+            int fc = FC(node);
+            while (fc >= 0) {
+                const double l = lane < A ? ND(fc + lane).lower : ninf;
+                double m = l;
+                int dummy = lane;
+                wave_argmax(m, dummy);
+                const unsigned long long ties = __ballot(lane < A && l == m);
+                const int nt = __popcll(ties);
+                int pick = nt > 1 ? (int)gen.below((uint32_t)nt) : 0;
+                unsigned long long t = ties;
+                while (pick-- > 0) t &= t - 1;
+                const int act = __ffsll((long long)t) - 1;
+                if (pass == 1 && l0 && p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = act;
+                ++len;
+                node = fc + act;
+                fc = FC(node);
+            }
+        }
+        if (l0) gen.store(p.rng + (long)r * 6);
+    }
+    if (l0) {
+        if (p.plans)
+            for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[r] = len;
+        if (p.status) p.status[r] = status;
+        if (p.env_steps) p.env_steps[r] = steps_taken;
+        if (p.updates) p.updates[r] = updates;
+    }
+}
+
+// grow a node array from old_cap to new_cap rows per planner, keeping the used_rows rows in use
 template <typename T>
-static int grow_rows(T **buf, size_t old_rows, size_t new_rows, size_t n, hipStream_t st)
+static int grow_rows(T **buf, size_t used_rows, size_t old_cap, size_t new_cap, size_t n, bool planner_major, hipStream_t st)
 {
     T *nw = nullptr;
-    MP_HIP(hipMalloc(&nw, new_rows * n * sizeof(T)));
+    MP_HIP(hipMalloc(&nw, new_cap * n * sizeof(T)));
     if (*buf) {
-        MP_HIP(hipMemcpyAsync(nw, *buf, old_rows * n * sizeof(T), hipMemcpyDeviceToDevice, st));
+        if (planner_major) { // [planner][row]: every planner's prefix moves to its new pitch
+            if (used_rows)
+                MP_HIP(hipMemcpy2DAsync(nw, new_cap * sizeof(T), *buf, old_cap * sizeof(T), used_rows * sizeof(T), n,
+                                        hipMemcpyDeviceToDevice, st));
+        } else {             // [row][planner]: one contiguous prefix
+            MP_HIP(hipMemcpyAsync(nw, *buf, used_rows * n * sizeof(T), hipMemcpyDeviceToDevice, st));
+        }
         MP_HIP(hipStreamSynchronize(st));
         MP_HIP(hipFree(*buf));
     }
@@ -363,6 +607,10 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
     mp_saopd *pl = new (std::nothrow) mp_saopd;
     if (!pl) return fail(MP_ERR_ALLOC, "mp_saopd_create: out of memory");
     pl->ctx = ctx; pl->model = model; pl->model_serial = model->serial; pl->n = n_planners; pl->S = model->S; pl->A = model->A;
+    // one planner per wavefront unless asked otherwise (MP_SAOPD_MODEL=lane: one per lane, the first implementation)
+    const char *force = getenv("MP_SAOPD_MODEL");
+    pl->wave = !(force && force[0] == 'l');
+    if (pl->wave && model->A > 64) pl->wave = 0;
     const size_t sn = (size_t)pl->S * pl->n;
     if (hipMalloc(&pl->sv, sn * 8) != hipSuccess || hipMalloc(&pl->head, sn * 4) != hipSuccess ||
         hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess) {
@@ -422,13 +670,14 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     const int need = pl->n_nodes + 1 + K * A;
     if (need > pl->cap) {
         const int new_cap = need + (need - pl->cap < 4096 ? need / 2 : 0); // some slack for the following plans
-        const size_t o = (size_t)pl->n_nodes;
-        MP_TRY(grow_rows(&pl->node, o, new_cap, n, st));
-        MP_TRY(grow_rows(&pl->state, o, new_cap, n, st));
-        MP_TRY(grow_rows(&pl->parent, o, new_cap, n, st));
-        MP_TRY(grow_rows(&pl->first_child, o, new_cap, n, st));
-        MP_TRY(grow_rows(&pl->reward, o, new_cap, n, st));
-        MP_TRY(grow_rows(&pl->done, o, new_cap, n, st));
+        const size_t o = (size_t)pl->n_nodes, oc = (size_t)pl->cap;
+        const bool pm = pl->wave != 0;
+        MP_TRY(grow_rows(&pl->node, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(&pl->state, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(&pl->parent, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(&pl->first_child, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(&pl->reward, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(&pl->done, o, oc, new_cap, n, pm, st));
         pl->cap = new_cap;
     }
     // tables with the reference's own operations
@@ -451,7 +700,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.rec = pl->model->rec; a.tab = d_tab;
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
     a.reward = pl->reward; a.done = pl->done; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
-    a.stamp = pl->stamp; a.iter_base = pl->iters;
+    a.stamp = pl->stamp; a.iter_base = pl->iters; a.cap = pl->cap;
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
     a.root_state = d_rs;
@@ -470,7 +719,8 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         hipLaunchKernelGGL(saopd_init_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, n, pl->S, a.vmax, pl->sv,
                            pl->head, pl->tail, pl->stamp);
     }
-    hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
+    if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel, dim3((unsigned)n), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, fresh ? 2 : 1));
     MP_HIP(hipGetLastError());
     pl->gamma = gamma;
@@ -508,11 +758,16 @@ int mp_saopd_export(mp_saopd *pl, int32_t planner, int32_t cap, int32_t *parent,
     MP_HIP(hipSetDevice(pl->ctx->device));
     MP_HIP(hipStreamSynchronize(pl->ctx->stream));
     const size_t nn = (size_t)pl->n_nodes, n = (size_t)pl->n;
-    // column `planner` of the [row][planner] arrays
-    auto column = [&](void *dst, const void *src, size_t elem, size_t rows) -> int {
-        MP_HIP(hipMemcpy2D(dst, elem, (const char *)src + (size_t)planner * elem, n * elem, elem, rows, hipMemcpyDeviceToHost));
+    // the entries of one planner: element (i, planner) of an array with row stride si and planner stride sr
+    auto column_of = [&](void *dst, const void *src, size_t elem, size_t rows, long si, long sr) -> int {
+        MP_HIP(hipMemcpy2D(dst, elem, (const char *)src + (size_t)planner * sr * elem, (size_t)si * elem, elem, rows,
+                           hipMemcpyDeviceToHost));
         return MP_OK;
     };
+    auto column = [&](void *dst, const void *src, size_t elem, size_t rows) -> int {
+        return column_of(dst, src, elem, rows, pl->node_si(), pl->node_sr());
+    };
+    (void)n;
     std::vector<SaNode> hn(nn);
     std::vector<int32_t> hpar(nn), hfc(nn);
     if (nn) {
@@ -523,7 +778,7 @@ int mp_saopd_export(mp_saopd *pl, int32_t planner, int32_t cap, int32_t *parent,
         if (reward) MP_TRY(column(reward, pl->reward, 8, nn));
         if (done) MP_TRY(column(done, pl->done, 1, nn));
     }
-    if (state_values) MP_TRY(column(state_values, pl->sv, 8, (size_t)pl->S));
+    if (state_values) MP_TRY(column_of(state_values, pl->sv, 8, (size_t)pl->S, pl->state_si(), pl->state_sr()));
     for (size_t i = 0; i < nn; ++i) {
         if (parent) parent[i] = hpar[i];
         if (first_child) first_child[i] = hfc[i];

@@ -426,13 +426,15 @@ def test_policy_load_errors(ctx):
     model.close()
 
 
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
 @pytest.mark.parametrize("shape", ["grid", "garnet", "highway"])
-def test_state_aware_batch_vs_oracle(ctx, shape):
+def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     """200 planners per launch, three consecutive plans each (planner state kept on the device), vs the oracle run
     planner by planner; ragged outcomes included (planners whose leaves all get pruned report MP_ERR_ARG)."""
     from oracle import oracle
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_SAOPD_MODEL", mapping)
     cfg, budget, gamma = {"grid": (generators.gridworld(), 120, 0.8),
                           "garnet": (generators.random_deterministic(40, 3, seed=5, terminal_rate=0.1), 90, 0.7),
                           "highway": (generators.highway_shaped(3, 4, 10, seed=3), 150, 0.9)}[shape]

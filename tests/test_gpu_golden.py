@@ -218,12 +218,14 @@ def test_uct_state_policies_subtree_golden(ctx, golden):
     model.close()
 
 
-def test_state_aware_planner_golden_episodes(ctx, golden):
-    """mp_saopd_plan vs the unmodified StateAwarePlannerAgent over multi-plan episodes: plans, trees, leaves sets,
+@pytest.mark.parametrize("mapping", ["wave", "lane"])
+def test_state_aware_planner_golden_episodes(ctx, golden, mapping, monkeypatch):
+    """(one planner per wavefront / per lane) mp_saopd_plan vs the unmodified StateAwarePlannerAgent over multi-plan episodes: plans, trees, leaves sets,
     state-value tables, env-step counts and generator state, with the planner state carried across plans; where
     the reference raises (every leaf pruned) the planner reports MP_ERR_ARG."""
     from rl_agents_amd import native
     from tests.helpers import replay_state_aware_episode
+    monkeypatch.setenv("MP_SAOPD_MODEL", mapping)
     z = golden["state_aware"]
     for name in [str(n) for n in z["sa/names"]]:
         cfg = mdp_from_golden(z, "sa/{}/mdp".format(name))
