@@ -402,11 +402,26 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
         // ---- max(leaves, key=U): 64 rows per trip, then (max U, lowest id) across the lanes
         double bu = ninf;
         int leaf = 0x7fffffff;
-        for (int i = root + lane; i < n_nodes; i += 64) {
-            const SaNode nd = ND(i);
-            if (nd.meta & SA_ALIVE) {
-                const double u = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(ST(i));
-                if (u > bu || leaf == 0x7fffffff) { bu = u; leaf = i; } // ascending ids within a lane: first maximum
+        constexpr int WU = 4; // 4 x 64 rows per trip: the three levels of loads (node, state, state value) each in flight together
+        for (int i0 = root + lane; i0 < n_nodes; i0 += 64 * WU) {
+            SaNode nd[WU];
+            int32_t st[WU];
+            double sv[WU];
+#pragma unroll
+            for (int j = 0; j < WU; ++j) {
+                const int i = min(i0 + 64 * j, n_nodes - 1);
+                nd[j] = ND(i);
+                st[j] = ST(i);
+            }
+#pragma unroll
+            for (int j = 0; j < WU; ++j) sv[j] = (nd[j].meta & SA_ALIVE) ? SV(st[j]) : 0.0;
+#pragma unroll
+            for (int j = 0; j < WU; ++j) {
+                const int i = i0 + 64 * j;
+                if (i < n_nodes && (nd[j].meta & SA_ALIVE)) {
+                    const double u = nd[j].lower + gpow[nd[j].meta & SA_DEPTH] * sv[j];
+                    if (u > bu || leaf == 0x7fffffff) { bu = u; leaf = i; } // ascending ids within a lane: first maximum
+                }
             }
         }
         wave_argmax(bu, leaf);
@@ -502,14 +517,28 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
         // ---- prune: candidate leaves (alive, state changed this iteration) 64 rows per trip in reverse order, each
         // candidate's list walked as uniform code
         if (p.prune)
-            for (int i0 = n_nodes - 1; i0 >= root; i0 -= 64) {
-                const int i_mine = i0 - lane;
-                bool cand = false;
-                if (i_mine >= root) {
-                    const uint32_t m = ND(i_mine).meta;
-                    cand = (m & SA_ALIVE) && SM(ST(i_mine)) == cur;
+            for (int ib = n_nodes - 1; ib >= root; ib -= 64 * WU) {
+              // candidate flags of 4 x 64 rows with the loads of each level in flight together
+              bool cands[WU];
+              {
+                uint32_t ms[WU];
+                int32_t sts[WU], stamps[WU];
+#pragma unroll
+                for (int j = 0; j < WU; ++j) {
+                    const int i = max(ib - 64 * j - lane, root);
+                    ms[j] = ND(i).meta;
+                    sts[j] = ST(i);
                 }
-                unsigned long long todo = __ballot(cand);
+#pragma unroll
+                for (int j = 0; j < WU; ++j) stamps[j] = (ms[j] & SA_ALIVE) ? SM(sts[j]) : -1;
+#pragma unroll
+                for (int j = 0; j < WU; ++j) cands[j] = ib - 64 * j - lane >= root && (ms[j] & SA_ALIVE) && stamps[j] == cur;
+              }
+#pragma unroll
+              for (int jc = 0; jc < WU; ++jc) {
+                const int i0 = ib - 64 * jc;
+                if (i0 < root) break;
+                unsigned long long todo = __ballot(cands[jc]);
                 while (todo) {
                     const int j = __ffsll((long long)todo) - 1; // lane 0 holds the highest row of the chunk
                     todo &= todo - 1;
@@ -530,6 +559,7 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
                     }
                     __syncthreads();
                 }
+              }
             }
     }
     // ---- get_plan, twice (see saopd_kernel), uniform
