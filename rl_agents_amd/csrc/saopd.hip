@@ -7,11 +7,16 @@
 // prune pass over all leaves in reverse order (:28-40).  Both dictionaries and every node ever created outlive
 // plan() calls (reset() only installs a new root and leaves list), so the planner state is an arena.
 //
-// Mapping: ONE PLANNER PER LANE.  The backup queue and the prune pass are order-dependent chains (first-in-first-out
-// processing against moving state values; pruned leaves stop dominating later ones), so a planner is sequential
-// and the parallel axis is planners.  All planners of a batch run the same number of iterations on the same node
-// ids, so the per-node arrays are laid out node-major, [node][planner]: the loops over "all nodes" (leaf scan,
-// expansion writes) are coalesced 64-wide, and only the per-state dictionaries and the list walks are gathers.
+// Mapping.  The backup queue and the prune pass are order-dependent chains (first-in-first-out processing against
+// moving state values; pruned leaves stop dominating later ones), so a planner is sequential and the parallel axis is
+// planners.  Two kernels, same results:
+//   saopd_wave_kernel (default)  one planner per WAVEFRONT, planner-major arrays: the serial phases run as uniform code
+//                                (a dependent access is one cache line per wave), scans / children / prune candidates
+//                                use the 64 lanes.  Lowest latency, and 64x more waves to hide it.
+//   saopd_kernel (MP_SAOPD_MODEL=lane)  one planner per LANE, node-major arrays [node][planner]: all planners of a batch
+//                                run the same iterations on the same node ids, so the loops over "all nodes" are
+//                                coalesced 64-wide; per-state dictionaries and list walks are gathers.
+// Layouts below are given for the lane mapping ([row][planner]); the wave mapping transposes them.
 //
 //   node   SaNode[cap][n] 16 B = {f64 lower, i32 next_same (state_nodes list link), u32 meta}
 //          meta = depth | HAS_CHILDREN | ALIVE ("in planner.leaves"): a list walk costs one dwordx4 per element
