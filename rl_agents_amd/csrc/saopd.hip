@@ -85,7 +85,8 @@ namespace mp {
 struct SaArgs {
     int n, S, A, K, root, n_prev, prev_root, qcap, done_on_next, max_plan_len;
     int backup_aggregated, prune, fresh, iter_base;
-    int cap; // wave kernel: node rows allocated per planner
+    int cap;  // wave kernel: node rows allocated per planner
+    int scap; // wave kernel: scratch entries per lane in the prune pass (qcap / 64 unless MP_SAOPD_LANE_SCRATCH)
     double gamma, vmax;
     const Rec *rec;
     const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
@@ -363,6 +364,10 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
     for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
     __syncthreads();
     const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
+    // states whose value or node list changed in the current iteration (each once): the prune pass handles them one
+    // per lane; more than DCAP of them (or more leaves of one state than a lane's scratch holds) take the serial pass
+    constexpr int DCAP = 128;
+    int32_t *dirty = reinterpret_cast<int32_t *>(lds_d + ntab);
     const int r = blockIdx.x;
     const int A = p.A;
     const long nb = (long)r * p.cap, sb = (long)r * p.S, qb = (long)r * p.qcap;
@@ -404,6 +409,7 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
 
     for (int k = 0; k < p.K && status == MP_OK; ++k) {
         const int cur = p.iter_base + k;
+        int ndirty = 0;
         // ---- max(leaves, key=U): 64 rows per trip, then (max U, lowest id) across the lanes
         double bu = ninf;
         int leaf = 0x7fffffff;
@@ -466,12 +472,15 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
             const int c = g + a;
             const int32_t t = TL(s);
             const double svs = SV(s);
+            const int stm = SM(s);
             if (l0) {
                 if (t < 0) HD(s) = c; else ND(t).next_same = c;
                 TL(s) = c;
                 SM(s) = cur;
                 if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
+                if (stm != cur && ndirty < DCAP) dirty[ndirty] = s;
             }
+            ndirty += stm != cur ? 1 : 0;
             __syncthreads();
         }
         n_nodes += A;
@@ -500,8 +509,15 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
                     wave_argmax(u, a_id); // first maximal U in action order
                     const double backup = __shfl(bk, a_id);
                     const double old = SV(sn);
+                    const int stm = SM(sn);
                     delta = old - backup;
-                    if (delta > 0.0 && l0) { SV(sn) = backup; SM(sn) = cur; }
+                    if (delta > 0.0) {
+                        if (l0) {
+                            SV(sn) = backup; SM(sn) = cur;
+                            if (stm != cur && ndirty < DCAP) dirty[ndirty] = sn;
+                        }
+                        ndirty += stm != cur ? 1 : 0;
+                    }
                     ++updates;
                 }
                 __syncthreads();
@@ -521,7 +537,50 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
         if (status != MP_OK) break;
         // ---- prune: candidate leaves (alive, state changed this iteration) 64 rows per trip in reverse order, each
         // candidate's list walked as uniform code
-        if (p.prune)
+        // Leaves of different states never interact in the pass, and within one state the pass order is descending id:
+        // one changed state per lane -- pass A stacks the alive leaves of its list (ascending ids) in the lane's slice
+        // of the idle queue buffer, pass B pops them (descending) and walks the list for a dominator.
+        bool serial_prune = p.prune != 0;
+        if (p.prune && ndirty <= DCAP) {
+            const int scap = p.scap; // scratch entries per lane
+            int32_t *stk = p.queue + qb + (long)lane * (p.qcap >> 6);
+            bool overflow = false;
+            for (int base = 0; base < ndirty && !overflow; base += 64) {
+                const int32_t s = base + lane < ndirty ? dirty[base + lane] : -1;
+                int cnt = 0;
+                if (s >= 0)
+                    for (int nd_i = HD(s); nd_i >= 0;) {
+                        const SaNode nd = ND(nd_i);
+                        if (nd.meta & SA_ALIVE) {
+                            if (cnt < scap) stk[cnt] = nd_i;
+                            ++cnt;
+                        }
+                        nd_i = nd.next_same;
+                    }
+                if (__any(cnt > scap)) { overflow = true; break; }
+                if (s >= 0) {
+                    const double svs = SV(s);
+                    for (int c = cnt - 1; c >= 0; --c) {
+                        const int i = stk[c];
+                        const SaNode me = ND(i);
+                        const int dm = (int)(me.meta & SA_DEPTH);
+                        const double vub = me.lower + gpow[dm] * svs;
+                        for (int nd_i = HD(s); nd_i >= 0;) {
+                            const SaNode nd = ND(nd_i);
+                            const int dn = (int)(nd.meta & SA_DEPTH);
+                            if (nd_i != i && nd.lower + gpow[dn] * svs >= vub && dn >= dm && (nd.meta & (SA_CHILDREN | SA_ALIVE))) {
+                                ND(i).meta = me.meta & ~SA_ALIVE;
+                                break;
+                            }
+                            nd_i = nd.next_same;
+                        }
+                    }
+                }
+            }
+            serial_prune = overflow; // (re-running the serial pass over states already done changes nothing)
+            __syncthreads();
+        }
+        if (serial_prune)
             for (int ib = n_nodes - 1; ib >= root; ib -= 64 * WU) {
               // candidate flags of 4 x 64 rows with the loads of each level in flight together
               bool cands[WU];
@@ -736,6 +795,11 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
     a.reward = pl->reward; a.done = pl->done; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
     a.stamp = pl->stamp; a.iter_base = pl->iters; a.cap = pl->cap;
+    a.scap = pl->qcap >> 6;
+    if (const char *e = getenv("MP_SAOPD_LANE_SCRATCH")) { // test knob: a tiny slice forces the serial prune pass
+        const int v = atoi(e);
+        if (v >= 0 && v < a.scap) a.scap = v;
+    }
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
     a.root_state = d_rs;
@@ -746,7 +810,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     MP_TRY(stage_out_alloc(ctx, WS_IO6, env_steps, (size_t)n, mem, &a.env_steps));
     MP_TRY(stage_out_alloc(ctx, WS_IO7, updates, (size_t)n, mem, &a.updates));
 
-    const size_t lds = tab.size() * sizeof(double);
+    const size_t lds = tab.size() * sizeof(double) + 128 * sizeof(int32_t); // tables + the wave kernel's changed-state list
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_saopd_plan: budget %d needs %zu B of LDS tables (> 64 KiB)", budget, lds);
     MP_TRY(kernels_begin(ctx));
     if (fresh) {

@@ -426,7 +426,7 @@ def test_policy_load_errors(ctx):
     model.close()
 
 
-@pytest.mark.parametrize("mapping", ["wave", "lane"])
+@pytest.mark.parametrize("mapping", ["wave", "wave-serial-prune", "lane"])
 @pytest.mark.parametrize("shape", ["grid", "garnet", "highway"])
 def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     """200 planners per launch, three consecutive plans each (planner state kept on the device), vs the oracle run
@@ -434,7 +434,9 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     from oracle import oracle
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_SAOPD_MODEL", mapping)
+    monkeypatch.setenv("MP_SAOPD_MODEL", mapping.split("-")[0])
+    if mapping == "wave-serial-prune":      # one scratch entry per lane: states with two leaves take the serial prune pass
+        monkeypatch.setenv("MP_SAOPD_LANE_SCRATCH", "1")
     cfg, budget, gamma = {"grid": (generators.gridworld(), 120, 0.8),
                           "garnet": (generators.random_deterministic(40, 3, seed=5, terminal_rate=0.1), 90, 0.7),
                           "highway": (generators.highway_shaped(3, 4, 10, seed=3), 150, 0.9)}[shape]
