@@ -23,7 +23,10 @@
 //     bounds are bit-identical to the incremental walk.
 //   * `count` (deterministic.py:62-63) is not needed by any decision; it is reconstructed from
 //     subtree sizes at export time.
-// HBM per root: {L f64, state i32, depth i32} 16 B + U f64 + reward f64 + first_child i32 + done u8
+// HBM per root: {L f64, state i32, depth i32 | done << 30} 16 B + U f64 + reward f64; first_child is derived from the
+// parent map by the export.  Every vector memory instruction costs the texture-address unit its slot whatever it
+// moves (TA busy 72-84 % at 8192 roots), so an expansion issues as few as possible: one record store per child
+// instead of four, gamma tables through the scalar cache (the depth is wave-uniform)
 // = 37 B/node; LDS per root: 8 B/node (+ 4 B per expansion for the parent map).
 #include <math.h>
 #include <stdlib.h>
@@ -49,8 +52,6 @@ struct OpdArgs {
     // per-root node arrays, root-major [n_roots][cap]
     double *L; // OpdNode records {L, state, depth}, 16 B per node
     double *U, *reward;
-    int32_t *first_child;
-    uint8_t *done;
     double *leaf_global; // [n_roots][64 * T]: the upper-bound array of the high-occupancy variant (else nullptr)
     int32_t *expanded; // [n_roots][K] node expanded at step k (= parent of nodes 1 + kA .. 1 + kA + A - 1)
     int32_t *n_nodes_out;
@@ -96,8 +97,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     const long base = (long)root * p.cap;
     OpdNode *NA = reinterpret_cast<OpdNode *>(p.L) + base;
     double *U = p.U + base, *RW = p.reward + base;
-    int32_t *FC = p.first_child + base;
-    uint8_t *DN = p.done + base;
+    constexpr int32_t DONE_FLAG = 1 << 30; // in OpdNode::depth
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
     const double ninf = -INFINITY;
 
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         OpdNode n0;
         n0.L = 0.0; n0.state = p.root_state[root]; n0.depth = 0;
         NA[0] = n0;
-        RW[0] = 0.0; FC[0] = -1; DN[0] = 0;
+        RW[0] = 0.0;
         LU(0) = 0.0;
     }
     __syncthreads();
@@ -147,32 +147,41 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         }
         PROF_T(c1);
         // ---- DeterministicNode.expand, deterministic.py:28-43
-        const OpdNode pn = NA[leaf];
-        const int d = pn.depth + 1;
+        OpdNode pn;
+        {   // one dwordx4 (the compiler splits the struct load when a field is read first)
+            const uint4 raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
+            pn.L = __hiloint2double((int)raw.y, (int)raw.x); pn.state = (int32_t)raw.z; pn.depth = (int32_t)raw.w;
+        }
+        // wave-uniform depth in an SGPR: the three gamma tables come through the scalar cache, not the TA
+        const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
+        typedef const double __attribute__((address_space(4))) *scalar_f64; // constant address space: s_load
+        const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
+                     tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
         const int g = n_nodes; // first child
         bool bad = false;
+        double Uc_mine = 0.0;
         if (lane < A) {
             const Rec rc = p.rec[(long)pn.state * A + lane];
             const double r = rc.reward;
             bad = !(0.0 <= r) || !(r <= 1.0); // deterministic.py:46-47
             const bool dn = (rc.flags & done_bit) != 0;
             // deterministic.py:45-65 update()
-            double Lc = pn.L + p.g1[d] * r;
-            double Uc = Lc + p.gdiv[d];
+            double Lc = pn.L + g1d * r;
+            double Uc = Lc + gdivd;
             if (dn) {
-                const double nv = Lc + p.tdiv[d];
+                const double nv = Lc + tdivd;
                 Lc = nv; Uc = nv;
             }
             const int c = g + lane;
             OpdNode cn;
-            cn.L = Lc; cn.state = rc.next; cn.depth = d;
+            cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
             NA[c] = cn;
-            RW[c] = r; FC[c] = -1; DN[c] = dn ? 1 : 0;
+            RW[c] = r;
             LU(c) = Uc;
+            Uc_mine = Uc;
         }
         if (lane == 0) {
             exp_lds[k] = leaf;
-            FC[leaf] = g;
         }
         n_nodes += A;
         k_done = k + 1;
@@ -182,9 +191,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         // best; on equality the older (lower id) leaf stays, as in the reference's list order
         {
             const int j = (lane - g) & 63;
+            const double u = __shfl(Uc_mine, j & 63); // child j was made by lane j: no trip through memory
             if (j < A) {
                 const int id = g + j;
-                const double u = LU(id);
                 if (u > cbu) { cbu = u; cbid = id; }
             }
         }
@@ -363,8 +372,6 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(ws_get(ctx, WS_TREE0, 2 * nn, &a.L)); // OpdNode records, 16 B each
     MP_TRY(ws_get(ctx, WS_TREE1, nn, &a.U));
     MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.reward));
-    MP_TRY(ws_get(ctx, WS_TREE5, nn, &a.first_child));
-    MP_TRY(ws_get(ctx, WS_TREE6, nn, &a.done));
     a.leaf_global = nullptr;
     if (glb) MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots * 64 * T, &a.leaf_global));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
@@ -424,10 +431,12 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
         MP_HIP(hipMemcpy(dst, (const char *)ctx->ws[slot].p + base * elt, (size_t)n * elt, hipMemcpyDeviceToHost));
         return MP_OK;
     };
-    std::vector<int32_t> fc((size_t)n), exp((size_t)(K > 0 ? K : 1));
-    MP_TRY(pull(fc.data(), WS_TREE5, sizeof(int32_t)));
+    std::vector<int32_t> fc((size_t)n, -1), exp((size_t)(K > 0 ? K : 1));
     MP_HIP(hipMemcpy(exp.data(), d_exp + (size_t)root * (K > 0 ? K : 1), (size_t)(K > 0 ? K : 1) * sizeof(int32_t),
                      hipMemcpyDeviceToHost));
+    // the k-th expansion created nodes 1 + kA .. 1 + kA + A - 1 under exp[k]
+    for (int k = 0; k < K && 1 + (k + 1) * A <= n; ++k)
+        if (exp[k] >= 0 && exp[k] < n) fc[exp[k]] = 1 + k * A;
     MP_TRY(pull(upper, WS_TREE1, sizeof(double)));
     MP_TRY(pull(reward, WS_TREE2, sizeof(double)));
     {
@@ -436,10 +445,10 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
         for (int i = 0; i < n; ++i) {
             if (lower) lower[i] = na[i].L;
             if (state) state[i] = na[i].state;
-            if (depth) depth[i] = na[i].depth;
+            if (depth) depth[i] = na[i].depth & ((1 << 30) - 1);
+            if (done) done[i] = (uint8_t)((na[i].depth >> 30) & 1);
         }
     }
-    MP_TRY(pull(done, WS_TREE6, sizeof(uint8_t)));
     std::vector<int32_t> par((size_t)n);
     par[0] = -1;
     for (int i = 1; i < n; ++i) par[i] = exp[(i - 1) / A];
