@@ -130,9 +130,14 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         int leaf = cbid;
         wave_argmax(bu, leaf);
         const int cls = leaf & 63;
+        // the leaf's record is needed by the expansion only: fetch it now, under the class re-scan
+        const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
         // the selected leaf stops being one; re-derive the best leaf of its class from LDS
         if (lane == 0) LU(leaf) = ninf;
-        __syncthreads();
+        // A workgroup is ONE wavefront: its LDS (and vector-memory) operations execute in program order, so lane 0's
+        // store is seen by the other lanes' later reads without a barrier.  The LDS variants only order the compiler
+        // here -- a full __syncthreads() would also wait for the record fetch above.
+        if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         {
             const double *row = leafU + cls * T;
             const int cnt = (n_nodes - cls + 63) >> 6; // ids cls, cls + 64, ... < n_nodes
@@ -147,11 +152,8 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         }
         PROF_T(c1);
         // ---- DeterministicNode.expand, deterministic.py:28-43
-        OpdNode pn;
-        {   // one dwordx4 (the compiler splits the struct load when a field is read first)
-            const uint4 raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
-            pn.L = __hiloint2double((int)raw.y, (int)raw.x); pn.state = (int32_t)raw.z; pn.depth = (int32_t)raw.w;
-        }
+        OpdNode pn; // (one dwordx4: the compiler splits the struct load when a field is read first)
+        pn.L = __hiloint2double((int)leaf_raw.y, (int)leaf_raw.x); pn.state = (int32_t)leaf_raw.z; pn.depth = (int32_t)leaf_raw.w;
         // wave-uniform depth in an SGPR: the three gamma tables come through the scalar cache, not the TA
         const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
         typedef const double __attribute__((address_space(4))) *scalar_f64; // constant address space: s_load
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         n_nodes += A;
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads();
+        if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
         // the (at most one, |A| <= 64) new child that falls in this lane's class may beat its cached
         // best; on equality the older (lower id) leaf stays, as in the reference's list order
         {
