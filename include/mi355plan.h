@@ -228,7 +228,9 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
  *   reference does (deterministic.py:122 + state_aware.py:127).
  *   plans int32 [n,max_plan_len] (-1 padded), plan_len int32 [n], env_steps / updates int64 [n] (planner.step calls /
  *   Bellman backups of this plan), status int32 [n]: MP_OK, MP_ERR_REWARD_RANGE (ValueError, deterministic.py:46-47),
- *   MP_ERR_ARG (every leaf pruned: the reference's max() of an empty list, :95) or MP_ERR_ALLOC (backup queue full).
+ *   MP_ERR_ARG (every leaf pruned: the reference's max() of an empty list, :95) or MP_ERR_ALLOC (backup queue full and
+ *   no room to grow it: a full queue normally rolls the plan back and runs it again with a larger one).
+ *   The call reads one overflow flag back per attempt, i.e. it synchronises the stream even with mem = MP_MEM_DEVICE.
  * The model must outlive the planners (they read its transition records).
  * mp_saopd_export: arena of one planner in creation order (node rows [root, n_nodes) are the current tree; `alive` =
  * "in planner.leaves"), arrays of capacity >= n_nodes (mp_saopd_info), and state_values double [S].

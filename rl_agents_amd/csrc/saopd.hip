@@ -27,8 +27,9 @@
 //          those flags only ever change in the direction that removes dominators), so a leaf that survived the
 //          previous pass survives this one unless its state changed: the pass walks the lists of the leaves in
 //          changed states only -- same result, a small fraction of the reference's O(leaves x list) work
-//   queue  i32 [qcap][n] ring buffer per planner (the reference's list.pop(0) queue holds duplicates: thousands of
-//          entries at a few hundred nodes); overflow is reported per planner, never dropped silently
+//   queue  ring buffer per planner of 16-byte descriptors {state, node, delta}: the reference's list.pop(0) queue kept
+//          lazily (one entry per pending state update, expanded into "the parents of that state's nodes" when it
+//          reaches the front); overflow is reported per planner, never dropped silently
 //   tables gamma**d, terminal_reward*gamma**d/(1-gamma), accuracy*(1-gamma)*gamma**(d-1) from the host (libm pow)
 #include <math.h>
 #include <stdlib.h>
@@ -71,6 +72,11 @@ struct mp_saopd {
     double *sv = nullptr;
     int32_t *head = nullptr, *tail = nullptr, *queue = nullptr, *stamp = nullptr;
     int iters = 0;      // iterations run so far (stamps are unique across plans)
+    // copies of the per-state dictionaries and the generator states taken before a plan: a plan whose backup queue
+    // overflows is rolled back and run again with a larger queue
+    double *snap_sv = nullptr;
+    int32_t *snap_head = nullptr, *snap_tail = nullptr, *snap_stamp = nullptr, *overflow = nullptr;
+    uint64_t *snap_rng = nullptr;
     int wave = 0;       // 1: one planner per wavefront, planner-major arrays ([planner][node], [planner][state],
                         //    [planner][slot]); 0: one planner per lane, node-major arrays
     // element (row i, planner r) of a node array = i * node_si + r * node_sr, likewise states and queue slots
@@ -85,6 +91,7 @@ namespace mp {
 struct SaArgs {
     int n, S, A, K, root, n_prev, prev_root, qcap, done_on_next, max_plan_len;
     int backup_aggregated, prune, fresh, iter_base;
+    int32_t *overflow; // set when a planner's backup queue is full
     int cap;  // wave kernel: node rows allocated per planner
     int scap; // wave kernel: scratch entries per lane in the prune pass (qcap / 64 unless MP_SAOPD_LANE_SCRATCH)
     double gamma, vmax;
@@ -135,6 +142,8 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
     // apart, i.e. in one cache set and one L2 channel)
     const int qmask = p.qcap - 1;
     auto QU = [&](unsigned q) -> int32_t & { return p.queue[(long)(q & (unsigned)qmask) * n + r]; };
+    const unsigned dcap = (unsigned)p.qcap >> 2; // backup-queue descriptors: 4 ints each
+    auto QD = [&](unsigned q, int f) -> int32_t & { return p.queue[(long)(((q & (dcap - 1)) << 2) + f) * n + r]; };
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
 
     // reset() (deterministic.py:102-104): the previous leaves list is dropped, a new root is installed
@@ -221,19 +230,40 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
         // Planners of a wave have queues and lists of different lengths, so the nested loops (pop / walk the list
         // of the popped node's state) are flattened into ONE loop in which every lane does one step of its own
         // state machine per trip: a trip count of max-over-lanes(total steps) instead of a sum of per-pop maxima.
+        // The reference's queue is kept LAZILY: an update of state s by node x appends "the parents of the nodes of
+        // list(s)" -- one 16-byte descriptor {s, x, delta} -- and the list is walked when the descriptor reaches the
+        // front.  Lists, parents and thresholds do not change during a backup, so the order of the pops is the
+        // reference's, while the ring holds one entry per pending update instead of one per list element (tiny state
+        // spaces put most of the tree in one list: materialised, 120 nodes over 3 states overflowed 4096 entries).
         {
             unsigned qh = 0, qt = 0;
-            QU(qt++) = leaf;
-            int node = -1, nb = -1;
-            double delta = 0.0;
+            QD(qt, 0) = -1; QD(qt, 1) = leaf; // {-1, node}: a single node (the expanded leaf itself)
+            ++qt;
+            int src = -1, nb = -1;
+            double src_delta = 0.0;
             bool active = true;
             while (active) {
-                if (nb < 0) { // pop, Bellman-back the popped node up (:49-56), then start on its state's list
+                int target = -1; // the node this trip pops (:48)
+                if (nb < 0) {    // front descriptor
                     if (qh == qt) { active = false; continue; }
-                    node = QU(qh++);
-                    const int32_t sn = ST(node);
-                    const int fc = FC(node);
-                    delta = 0.0;
+                    const int32_t ds = QD(qh, 0);
+                    src = QD(qh, 1);
+                    if (ds < 0) {
+                        target = src;
+                    } else {
+                        src_delta = __hiloint2double(QD(qh, 3), QD(qh, 2));
+                        nb = HD(ds);
+                    }
+                    ++qh;
+                } else {         // one neighbour (:58-63)
+                    const SaNode nd = ND(nb);
+                    const int par = PA(nb);
+                    if (par >= 0 && (nb == src || p.backup_aggregated) && src_delta > acc[nd.meta & SA_DEPTH]) target = par;
+                    nb = nd.next_same;
+                }
+                if (target >= 0) { // Bellman backup of the popped node (:49-56)
+                    const int32_t sn = ST(target);
+                    const int fc = FC(target);
                     if (fc >= 0) {
                         int bc = fc;
                         double bcu = U_of(ND(fc), fc);
@@ -243,19 +273,16 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
                         }
                         const double backup = RW(bc) + p.gamma * SV(ST(bc));
                         const double old = SV(sn);
-                        delta = old - backup; // update_value (:109-119)
-                        if (delta > 0.0) { SV(sn) = backup; SM(sn) = cur; }
+                        const double delta = old - backup; // update_value (:109-119)
                         ++updates;
+                        if (delta > 0.0) { // (thresholds are >= 0: nothing is appended otherwise)
+                            SV(sn) = backup; SM(sn) = cur;
+                            if (qt - qh >= dcap) { status = MP_ERR_ALLOC; *p.overflow = 1; active = false; continue; }
+                            QD(qt, 0) = sn; QD(qt, 1) = target;
+                            QD(qt, 2) = __double2loint(delta); QD(qt, 3) = __double2hiint(delta);
+                            ++qt;
+                        }
                     }
-                    nb = HD(sn);
-                } else { // one neighbour (:58-63)
-                    const SaNode nd = ND(nb);
-                    const int par = PA(nb);
-                    if (par >= 0 && (nb == node || p.backup_aggregated) && delta > acc[nd.meta & SA_DEPTH]) {
-                        if (qt - qh >= (unsigned)p.qcap) { status = MP_ERR_ALLOC; active = false; continue; }
-                        QU(qt++) = par;
-                    }
-                    nb = nd.next_same;
                 }
             }
         }
@@ -380,8 +407,8 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
     auto HD = [&](int s) -> int32_t & { return p.head[sb + s]; };
     auto TL = [&](int s) -> int32_t & { return p.tail[sb + s]; };
     auto SM = [&](int s) -> int32_t & { return p.stamp[sb + s]; };
-    const unsigned qmask = (unsigned)p.qcap - 1u;
-    auto QU = [&](unsigned q) -> int32_t & { return p.queue[qb + (q & qmask)]; };
+    const unsigned dcap = (unsigned)p.qcap >> 2; // backup-queue descriptors: 4 ints each
+    auto QD = [&](unsigned q, int f) -> int32_t & { return p.queue[qb + ((q & (dcap - 1)) << 2) + f]; };
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
     const double ninf = -INFINITY;
     const bool l0 = lane == 0;
@@ -485,16 +512,35 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
         }
         n_nodes += A;
         // ---- backup_to_root: uniform first-in-first-out loop, the |A| children of a popped node one per lane
+        // (lazy queue of {state, node, delta} descriptors: see saopd_kernel)
         {
             unsigned qh = 0, qt = 0;
-            if (l0) QU(qt) = leaf;
+            if (l0) { QD(qt, 0) = -1; QD(qt, 1) = leaf; }
             ++qt;
             __syncthreads();
-            while (qh != qt && status == MP_OK) {
-                const int node = QU(qh++);
+            int src = -1, nbr = -1;
+            double src_delta = 0.0;
+            while ((nbr >= 0 || qh != qt) && status == MP_OK) {
+                int node = -1;
+                if (nbr < 0) { // front descriptor
+                    const int32_t ds = QD(qh, 0);
+                    src = QD(qh, 1);
+                    if (ds < 0) {
+                        node = src;
+                    } else {
+                        src_delta = __hiloint2double(QD(qh, 3), QD(qh, 2));
+                        nbr = HD(ds);
+                    }
+                    ++qh;
+                } else {       // one neighbour
+                    const SaNode nd = ND(nbr);
+                    const int par = PA(nbr);
+                    if (par >= 0 && (nbr == src || p.backup_aggregated) && src_delta > acc[nd.meta & SA_DEPTH]) node = par;
+                    nbr = nd.next_same;
+                }
+                if (node < 0) continue;
                 const int32_t sn = ST(node);
                 const int fc = FC(node);
-                double delta = 0.0;
                 if (fc >= 0) {
                     double u = ninf, bk = 0.0;
                     int a_id = 0x7fffffff;
@@ -510,28 +556,21 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
                     const double backup = __shfl(bk, a_id);
                     const double old = SV(sn);
                     const int stm = SM(sn);
-                    delta = old - backup;
+                    const double delta = old - backup;
+                    ++updates;
                     if (delta > 0.0) {
+                        if (qt - qh >= dcap) { status = MP_ERR_ALLOC; if (l0) *p.overflow = 1; break; }
                         if (l0) {
                             SV(sn) = backup; SM(sn) = cur;
                             if (stm != cur && ndirty < DCAP) dirty[ndirty] = sn;
+                            QD(qt, 0) = sn; QD(qt, 1) = node;
+                            QD(qt, 2) = __double2loint(delta); QD(qt, 3) = __double2hiint(delta);
                         }
                         ndirty += stm != cur ? 1 : 0;
-                    }
-                    ++updates;
-                }
-                __syncthreads();
-                for (int nbr = HD(sn); nbr >= 0;) {
-                    const SaNode nd = ND(nbr);
-                    const int par = PA(nbr);
-                    if (par >= 0 && (nbr == node || p.backup_aggregated) && delta > acc[nd.meta & SA_DEPTH]) {
-                        if (qt - qh >= (unsigned)p.qcap) { status = MP_ERR_ALLOC; break; }
-                        if (l0) QU(qt) = par;
                         ++qt;
+                        __syncthreads();
                     }
-                    nbr = nd.next_same;
                 }
-                __syncthreads();
             }
         }
         if (status != MP_OK) break;
@@ -665,6 +704,17 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
 }
 
 // grow a node array from old_cap to new_cap rows per planner, keeping the used_rows rows in use
+// undo the list appends of a rolled-back plan: after the tails are restored, every tail is the end of its list again
+__global__ __launch_bounds__(64) void saopd_fix_tails_kernel(int n, int S, long node_si, long node_sr, long state_si, long state_sr,
+                                                             const int32_t *tail, SaNode *node)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)n * S) return;
+    const long r = i / S, st = i % S;
+    const int32_t t = tail[st * state_si + r * state_sr];
+    if (t >= 0) node[(long)t * node_si + r * node_sr].next_same = -1;
+}
+
 template <typename T>
 static int grow_rows(T **buf, size_t used_rows, size_t old_cap, size_t new_cap, size_t n, bool planner_major, hipStream_t st)
 {
@@ -707,7 +757,10 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
     if (pl->wave && model->A > 64) pl->wave = 0;
     const size_t sn = (size_t)pl->S * pl->n;
     if (hipMalloc(&pl->sv, sn * 8) != hipSuccess || hipMalloc(&pl->head, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess) {
+        hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess ||
+        hipMalloc(&pl->snap_sv, sn * 8) != hipSuccess || hipMalloc(&pl->snap_head, sn * 4) != hipSuccess ||
+        hipMalloc(&pl->snap_tail, sn * 4) != hipSuccess || hipMalloc(&pl->snap_stamp, sn * 4) != hipSuccess ||
+        hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
     }
@@ -719,7 +772,7 @@ int mp_saopd_free(mp_saopd *pl)
 {
     if (!pl) return MP_OK;
     void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->sv, pl->head, pl->tail, pl->queue,
-                    pl->stamp};
+                    pl->stamp, pl->snap_sv, pl->snap_head, pl->snap_tail, pl->snap_stamp, pl->snap_rng, pl->overflow};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
     delete pl;
@@ -795,11 +848,15 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
     a.reward = pl->reward; a.done = pl->done; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
     a.stamp = pl->stamp; a.iter_base = pl->iters; a.cap = pl->cap;
-    a.scap = pl->qcap >> 6;
-    if (const char *e = getenv("MP_SAOPD_LANE_SCRATCH")) { // test knob: a tiny slice forces the serial prune pass
-        const int v = atoi(e);
-        if (v >= 0 && v < a.scap) a.scap = v;
-    }
+    auto lane_scratch = [&]() {
+        int v = pl->qcap >> 6;
+        if (const char *e = getenv("MP_SAOPD_LANE_SCRATCH")) { // test knob: a tiny slice forces the serial prune pass
+            const int w = atoi(e);
+            if (w >= 0 && w < v) v = w;
+        }
+        return v;
+    };
+    a.scap = lane_scratch();
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
     a.root_state = d_rs;
@@ -812,15 +869,59 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
 
     const size_t lds = tab.size() * sizeof(double) + 128 * sizeof(int32_t); // tables + the wave kernel's changed-state list
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_saopd_plan: budget %d needs %zu B of LDS tables (> 64 KiB)", budget, lds);
-    MP_TRY(kernels_begin(ctx));
-    if (fresh) {
-        const long tot = (long)n * pl->S;
-        hipLaunchKernelGGL(saopd_init_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, n, pl->S, a.vmax, pl->sv,
-                           pl->head, pl->tail, pl->stamp);
+    // what a plan changes outside its own node rows: the per-state dictionaries, the list links of older tail nodes
+    // and the generator states.  They are copied first, so that a plan that fills its backup queue (values decaying
+    // to floating-point underflow make the reference run tens of thousands of backups) can be rolled back and run
+    // again with a larger queue.  Costs one 4-byte read-back (a stream synchronisation) per call.
+    const size_t sn = (size_t)pl->S * n;
+    a.overflow = pl->overflow;
+    if (!fresh) {
+        MP_HIP(hipMemcpyAsync(pl->snap_sv, pl->sv, sn * 8, hipMemcpyDeviceToDevice, st));
+        MP_HIP(hipMemcpyAsync(pl->snap_head, pl->head, sn * 4, hipMemcpyDeviceToDevice, st));
+        MP_HIP(hipMemcpyAsync(pl->snap_tail, pl->tail, sn * 4, hipMemcpyDeviceToDevice, st));
+        MP_HIP(hipMemcpyAsync(pl->snap_stamp, pl->stamp, sn * 4, hipMemcpyDeviceToDevice, st));
     }
-    if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel, dim3((unsigned)n), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
-    MP_TRY(kernels_end(ctx, fresh ? 2 : 1));
+    MP_HIP(hipMemcpyAsync(pl->snap_rng, a.rng, (size_t)n * 48, hipMemcpyDeviceToDevice, st));
+    size_t max_queue_bytes = (size_t)8 << 30; // per batch; MP_SAOPD_QUEUE_LIMIT_MB overrides
+    if (const char *e = getenv("MP_SAOPD_QUEUE_LIMIT_MB")) max_queue_bytes = (size_t)atol(e) << 20;
+    int launches = 0;
+    MP_TRY(kernels_begin(ctx));
+    for (;;) {
+        MP_HIP(hipMemsetAsync(pl->overflow, 0, 4, st));
+        if (fresh) {
+            const long tot = (long)n * pl->S;
+            hipLaunchKernelGGL(saopd_init_kernel, dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, st, n, pl->S, a.vmax, pl->sv,
+                               pl->head, pl->tail, pl->stamp);
+            ++launches;
+        }
+        if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel, dim3((unsigned)n), dim3(64), lds, st, a);
+        else hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
+        ++launches;
+        int32_t ovf = 0;
+        MP_HIP(hipMemcpyAsync(&ovf, pl->overflow, 4, hipMemcpyDeviceToHost, st));
+        MP_HIP(hipStreamSynchronize(st));
+        MP_HIP(hipGetLastError());
+        const size_t bigger = (size_t)n * pl->qcap * 4 * 4;
+        if (!ovf || bigger > max_queue_bytes) break; // done, or out of room: the full planners keep MP_ERR_ALLOC
+        // roll back and run again with a queue four times as large
+        MP_HIP(hipFree(pl->queue));
+        pl->queue = nullptr;
+        if (hipMalloc(&pl->queue, bigger) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", bigger);
+        pl->qcap *= 4;
+        a.queue = pl->queue; a.qcap = pl->qcap;
+        a.scap = lane_scratch();
+        if (!fresh) {
+            MP_HIP(hipMemcpyAsync(pl->sv, pl->snap_sv, sn * 8, hipMemcpyDeviceToDevice, st));
+            MP_HIP(hipMemcpyAsync(pl->head, pl->snap_head, sn * 4, hipMemcpyDeviceToDevice, st));
+            MP_HIP(hipMemcpyAsync(pl->tail, pl->snap_tail, sn * 4, hipMemcpyDeviceToDevice, st));
+            MP_HIP(hipMemcpyAsync(pl->stamp, pl->snap_stamp, sn * 4, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(saopd_fix_tails_kernel, dim3((unsigned)((sn + 63) / 64)), dim3(64), 0, st, n, pl->S, pl->node_si(),
+                               pl->node_sr(), pl->state_si(), pl->state_sr(), pl->tail, pl->node);
+            ++launches;
+        }
+        MP_HIP(hipMemcpyAsync(a.rng, pl->snap_rng, (size_t)n * 48, hipMemcpyDeviceToDevice, st));
+    }
+    MP_TRY(kernels_end(ctx, launches));
     MP_HIP(hipGetLastError());
     pl->gamma = gamma;
     pl->iters += K;

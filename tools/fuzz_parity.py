@@ -1,0 +1,173 @@
+"""Randomised parity sweep: HIP planners vs the CPU oracle on random finite MDPs and random parameters.
+
+    MI355PLAN_NO_TORCH=1 python tools/fuzz_parity.py [n_cases] [seed]
+
+Every case draws an MDP (states, actions, terminal rate, reward pattern), planner parameters (budget / episodes /
+horizon / gamma / temperature / terminal reward / truncation / done rule) and a batch of roots, and compares every
+output of the device with the oracle's, bit for bit.  tests/test_gpu_fuzz.py runs a bounded number of cases.
+"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("MI355PLAN_NO_TORCH", "1")
+from oracle import oracle  # noqa: E402
+from rl_agents_amd import native  # noqa: E402
+
+
+def random_mdp(g):
+    s = int(g.choice([1, 2, 3, 7, 40, 257, 1500]))
+    a = int(g.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 13]))
+    t = g.integers(0, s, size=(s, a), dtype=np.int64)
+    kind = g.integers(0, 4)
+    if kind == 0:
+        r = g.random((s, a))
+    elif kind == 1:
+        r = g.integers(0, 2, size=(s, a)).astype(np.float64)          # many exact ties
+    elif kind == 2:
+        r = np.round(g.random((s, a)), 1)                              # few distinct values
+    else:
+        r = np.full((s, a), float(g.choice([0.0, 0.5, 1.0])))         # constant: everything ties
+    term = g.random(s) < g.choice([0.0, 0.05, 0.4])
+    return t, r, term
+
+
+def rng_states(g, n):
+    out = g.integers(1, 2 ** 62, size=(n, 6)).astype(np.uint64)
+    out[:, 3] |= 1
+    out[:, 4] = g.integers(0, 2, size=n)          # some streams start with a buffered 32-bit half
+    out[:, 5] = g.integers(0, 2 ** 32, size=n)
+    return out
+
+
+def eq(a, b, what, case):
+    if not np.array_equal(np.asarray(a), np.asarray(b)):
+        raise AssertionError("{} differs in case {}".format(what, case))
+
+
+def one_case(ctx, g, case):
+    t, r, term = random_mdp(g)
+    s, a = r.shape
+    done_rule = "next" if g.random() < 0.3 else "source"
+    max_steps = int(g.choice([0, 0, 3, 17]))
+    gamma = float(g.choice([0.0, 0.3, 0.8, 0.95, 0.999]))
+    n = int(g.choice([1, 3, 64, 65, 200]))
+    s0 = g.integers(0, s, size=n).astype(np.int32)
+    rng = rng_states(g, n)
+    model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
+    kind = ["uct", "uct_policy", "opd", "saopd"][int(g.integers(0, 4))]
+    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps)
+    if kind in ("uct", "uct_policy"):
+        episodes, horizon = int(g.choice([0, 1, 5, 33, 60])), int(g.choice([1, 2, 9, 30]))
+        temperature = float(g.choice([0.0, 1.0, 10.0, 3000.0]))
+        steps0 = g.integers(0, 3, size=n).astype(np.int32) if max_steps else None
+        desc.update(episodes=episodes, horizon=horizon, temperature=temperature)
+        if kind == "uct_policy" and a in (2, 3, 4, 5, 6, 8):
+            w = g.random((2, s, a)) ** 2
+            w[g.random((2, s, a)) < 0.2] = 0.0
+            w[:, np.arange(s), g.integers(0, a, size=s)] += 0.1
+            prior, rollout = w[0] / w[0].sum(1, keepdims=True), w[1] / w[1].sum(1, keepdims=True)
+            policy = ctx.load_policy(model, prior, rollout)
+            rng_dev = rng.copy()
+            out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, None, None, rng_dev, root_steps=steps0,
+                               max_plan_len=horizon, policy=policy)
+            policy.close()
+        else:
+            prior = g.random(a) + 0.01
+            prior /= prior.sum()
+            rollout = g.random(a) + 0.01
+            if g.random() < 0.3:
+                rollout[g.integers(0, a)] = 0.0
+                rollout += 1e-3 if rollout.sum() == 0 else 0.0
+            rollout /= rollout.sum()
+            rng_dev = rng.copy()
+            out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, prior, rollout, rng_dev, root_steps=steps0,
+                               max_plan_len=horizon)
+        ref = oracle.uct_plan_batch(t, r, term, s0, episodes, horizon, gamma, temperature, prior, rollout, rng.copy(),
+                                    steps0=steps0, max_steps=max_steps, done_rule=done_rule, max_plan_len=horizon, n_threads=8)
+        for k in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+    elif kind == "opd":
+        budget = int(g.choice([0, 1, a, 3 * a + 1, 100, 700]))
+        tr = float(g.choice([0.0, 0.25, 1.0]))
+        if gamma >= 0.999:
+            gamma = 0.95
+        desc.update(budget=budget, terminal_reward=tr, gamma=gamma)
+        rng_dev = rng.copy()
+        out = ctx.opd_plan(model, s0, budget, gamma, tr, rng_dev, max_plan_len=budget // a + 1)
+        ref = oracle.opd_plan_batch(t, r, term, s0, budget, gamma, tr, rng.copy(), done_rule=done_rule,
+                                    max_plan_len=budget // a + 1, n_threads=8)
+        for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+    else:
+        budget = int(g.choice([0, a, 5 * a, 120, 300]))
+        tr = float(g.choice([0.0, 0.5]))
+        if gamma >= 0.999:
+            gamma = 0.9
+        n = min(n, 65)
+        s0, rng = s0[:n], rng[:n]
+        cfgs = dict(accuracy=float(g.choice([0.0, 0.0, 0.05])), backup_aggregated_nodes=bool(g.random() < 0.8),
+                    prune_suboptimal_leaves=bool(g.random() < 0.8))
+        desc.update(budget=budget, terminal_reward=tr, gamma=gamma, n=n, **cfgs)
+        planners = native.StateAwarePlanners(ctx, model, n)
+        ref_pl, ref_rng, states, dead = [None] * n, rng.copy(), s0.copy(), np.zeros(n, bool)
+        for step in range(2):
+            out = planners.plan(states, budget, gamma, tr, rng, **cfgs)
+            for i in range(n):
+                if dead[i]:
+                    continue
+                try:
+                    o = oracle.saopd_plan(t, r, term, int(states[i]), budget, gamma, terminal_reward=tr, rng_state=ref_rng[i],
+                                          planner=ref_pl[i], done_rule=done_rule, max_plan_len=budget + 1, **cfgs)
+                except ValueError:
+                    if out["status"][i] != native.MP_ERR_ARG:
+                        raise AssertionError("status {} where the reference raises, case {}".format(out["status"][i], desc))
+                    dead[i] = True
+                    continue
+                if out["status"][i] != 0:
+                    if os.environ.get("FUZZ_DUMP"):
+                        np.savez(os.environ["FUZZ_DUMP"], t=t, r=r, term=term, s0=states[i], rng=ref_rng[i], step=step)
+                    raise AssertionError("status {} in case {}".format(out["status"][i], desc))
+                eq(out["plans"][i, :out["plan_len"][i]], o["plan"], "plan", desc)
+                eq(out["updates"][i], o["updates"], "updates", desc)
+                eq(rng[i], o["rng_after"], "rng", desc)
+                ref_pl[i], ref_rng[i] = o["planner"], o["rng_after"]
+                if i % 16 == 0:
+                    tree, sv = planners.export(i)
+                    eq(sv, o["state_values"], "state values", desc)
+                    eq(tree["alive"], o["tree"]["alive"], "leaves", desc)
+            nxt = np.where(out["plan_len"] > 0, t[states, np.maximum(out["plans"][:, 0], 0)], states)
+            states = nxt.astype(np.int32)
+        planners.close()
+    model.close()
+    return desc
+
+
+def run(n_cases, seed, ctx=None, verbose=False):
+    own = ctx is None
+    ctx = ctx or native.Context(0)
+    g = np.random.Generator(np.random.PCG64(seed))
+    kinds = {}
+    for case in range(n_cases):
+        try:
+            d = one_case(ctx, g, case)
+        except AssertionError:
+            raise
+        except Exception as e:     # a device error code: say which case it was
+            raise RuntimeError("case {} (seed {}): {}".format(case, seed, e))
+        kinds[d["kind"]] = kinds.get(d["kind"], 0) + 1
+        if verbose:
+            print(d)
+    if own:
+        ctx.close()
+    return kinds
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    print("ok", run(n, seed, verbose=os.environ.get("FUZZ_VERBOSE") == "1"))
