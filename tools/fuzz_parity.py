@@ -57,9 +57,54 @@ def one_case(ctx, g, case):
     s0 = g.integers(0, s, size=n).astype(np.int32)
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
-    kind = ["uct", "uct_policy", "opd", "saopd"][int(g.integers(0, 4))]
+    kind = ["uct", "uct_policy", "opd", "saopd", "vi"][int(g.integers(0, 5))]
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps)
-    if kind in ("uct", "uct_policy"):
+    if kind == "vi":
+        model.close()
+        iterations = int(g.choice([1, 7, 100, 300]))
+        rewards = r * float(g.choice([1.0, -1.0, 10.0]))             # VI takes any reward range
+        which = int(g.integers(0, 4))
+        desc.update(iterations=iterations, vi=["det", "robust", "sparse", "dense"][which])
+        if which == 0:
+            model = ctx.load_table(t, rewards, term)
+            q, sweeps = ctx.vi_solve(model, gamma, iterations)
+            q_ref, sweeps_ref = oracle.vi_solve("deterministic", t, rewards, term, gamma=gamma, iterations=iterations)
+            eq(q, q_ref, "Q", desc)
+            eq(ctx.vi_solve_v(model, gamma, iterations),
+               oracle.vi_solve("deterministic", t, rewards, term, gamma=gamma, iterations=iterations, state_value=True), "V", desc)
+        elif which == 1:
+            m = int(g.choice([1, 2, 3]))
+            tm = np.stack([g.integers(0, s, size=(s, a), dtype=np.int64) for _ in range(m)])
+            rm = np.stack([rewards * float(g.uniform(0.5, 1.0)) for _ in range(m)])
+            model = ctx.load_table(tm, rm)
+            q, sweeps = ctx.vi_solve(model, gamma, iterations, robust=True)
+            q_ref, sweeps_ref = oracle.vi_solve("deterministic", tm, rm, None, gamma=gamma, iterations=iterations, robust=True)
+            eq(q, q_ref, "robust Q", desc)
+        elif which == 2:
+            b = int(g.choice([1, 2, 5]))
+            nxt = g.integers(0, s, size=(s, a, b), dtype=np.int64)
+            pr = g.random((s, a, b)) + 0.01
+            pr /= pr.sum(-1, keepdims=True)
+            model = ctx.load_sparse(pr, nxt, rewards, term)
+            q, sweeps = ctx.vi_solve(model, gamma, iterations)
+            q_ref, sweeps_ref = oracle.vi_solve("sparse", pr, rewards, term, gamma=gamma, iterations=iterations, next_states=nxt)
+            eq(q, q_ref, "sparse Q", desc)
+        else:
+            sd = min(s, 300)
+            pr = g.random((sd, a, sd)) ** 3 + 1e-3
+            pr /= pr.sum(-1, keepdims=True)
+            rd, td = rewards[:sd], term[:sd]
+            model = ctx.load_dense(pr, rd, td)
+            q, sweeps = ctx.vi_solve(model, gamma, iterations)
+            q_ref, sweeps_ref = oracle.vi_solve("stochastic", pr, rd, td, gamma=gamma, iterations=iterations)
+            if not np.allclose(q, q_ref, rtol=1e-12, atol=1e-12 * max(1.0, float(np.abs(q_ref).max()))):
+                raise AssertionError("dense Q differs beyond 1e-12 in case {}".format(desc))
+            if abs(sweeps - sweeps_ref) > 1:
+                raise AssertionError("dense sweeps {} vs {} in case {}".format(sweeps, sweeps_ref, desc))
+            sweeps = sweeps_ref
+        if sweeps != sweeps_ref:
+            raise AssertionError("sweeps {} vs {} in case {}".format(sweeps, sweeps_ref, desc))
+    elif kind in ("uct", "uct_policy"):
         episodes, horizon = int(g.choice([0, 1, 5, 33, 60])), int(g.choice([1, 2, 9, 30]))
         temperature = float(g.choice([0.0, 1.0, 10.0, 3000.0]))
         steps0 = g.integers(0, 3, size=n).astype(np.int32) if max_steps else None
