@@ -14,4 +14,4 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_random_cases_match_the_oracle(seed):
     import fuzz_parity
     kinds = fuzz_parity.run(150, seed)
-    assert sum(kinds.values()) == 150 and len(kinds) == 5
+    assert sum(kinds.values()) == 150 and len(kinds) == 6

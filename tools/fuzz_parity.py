@@ -57,7 +57,7 @@ def one_case(ctx, g, case):
     s0 = g.integers(0, s, size=n).astype(np.int32)
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
-    kind = ["uct", "uct_policy", "opd", "saopd", "vi"][int(g.integers(0, 5))]
+    kind = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree"][int(g.integers(0, 6))]
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps)
     if kind == "vi":
         model.close()
@@ -104,6 +104,35 @@ def one_case(ctx, g, case):
             sweeps = sweeps_ref
         if sweeps != sweeps_ref:
             raise AssertionError("sweeps {} vs {} in case {}".format(sweeps, sweeps_ref, desc))
+    elif kind == "uct_subtree":     # step_strategy "subtree": plan, re-root at the executed action, plan again
+        n = min(n, 6)
+        s0, rng = s0[:n].copy(), rng[:n]
+        episodes, horizon = int(g.choice([1, 5, 20])), int(g.choice([2, 6, 12]))
+        temperature = float(g.choice([1.0, 10.0]))
+        desc.update(episodes=episodes, horizon=horizon, temperature=temperature, n=n)
+        prior = g.random(a) + 0.01
+        prior /= prior.sum()
+        trees, ref_rng = [None] * n, rng.copy()
+        ctx.uct_reset_tree()
+        prev = None
+        for step in range(3):
+            if prev is not None:
+                ctx.uct_step_tree(prev)
+            out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, prior, prior, rng, max_plan_len=horizon)
+            for i in range(n):
+                if trees[i] is not None:
+                    trees[i] = oracle.uct_reroot(trees[i], int(prev[i]), a)
+                o = oracle.uct_plan(t, r, term, int(s0[i]), episodes, horizon, gamma, temperature, prior, prior, ref_rng[i],
+                                    max_steps=max_steps, done_rule=done_rule, max_plan_len=horizon, init_tree=trees[i])
+                eq(out["plans"][i, :out["plan_len"][i]], o["plan"], "plan", desc)
+                eq(rng[i], o["rng_after"], "rng", desc)
+                tree = ctx.uct_tree(i)
+                for k in ("count", "value", "first_child"):
+                    eq(tree[k], o["tree"][k], "tree " + k, desc)
+                trees[i], ref_rng[i] = o["tree"], o["rng_after"]
+            prev = np.where(out["plan_len"] > 0, out["plans"][:, 0], 0).astype(np.int32)
+            s0 = t[s0, prev].astype(np.int32)
+        ctx.uct_reset_tree()
     elif kind in ("uct", "uct_policy"):
         episodes, horizon = int(g.choice([0, 1, 5, 33, 60])), int(g.choice([1, 2, 9, 30]))
         temperature = float(g.choice([0.0, 1.0, 10.0, 3000.0]))
