@@ -27,6 +27,8 @@ UCT = "<class 'rl_agents.agents.tree_search.mcts.MCTSAgent'>"
 OPD = "<class 'rl_agents.agents.tree_search.deterministic.DeterministicPlannerAgent'>"
 SAOPD = "<class 'rl_agents.agents.tree_search.state_aware.StateAwarePlannerAgent'>"
 VI = "<class 'rl_agents.agents.dynamic_programming.value_iteration.ValueIterationAgent'>"
+UCTP = "<class 'rl_agents.agents.tree_search.mcts_with_prior.MCTSWithPriorPolicyAgent'>"
+PRIOR = "<class 'prior_agents.BoltzmannQAgent'>"
 
 
 def random_mdp(g):
@@ -56,7 +58,7 @@ def one_case(g, case):
     gamma = float(g.choice([0.3, 0.8, 0.95]))
     done_rule = "next" if g.random() < 0.3 else "source"
     seed = int(g.integers(0, 1000))
-    kind = ["uct", "opd", "saopd", "vi"][int(g.integers(0, 4))]
+    kind = ["uct", "opd", "saopd", "vi", "uct_prior"][int(g.integers(0, 5))]
     desc = dict(case=case, kind=kind, S=s, A=a, s0=s0, gamma=gamma, done_rule=done_rule, seed=seed)
     if kind == "uct":
         max_steps = int(g.choice([0, 0, 5]))
@@ -79,6 +81,26 @@ def one_case(g, case):
         _, roll_p = agent.planner.rollout_policy(env, None)
         o = oracle.uct_plan(t, r, term, s0, pc["episodes"], pc["horizon"], pc["gamma"], pc["temperature"], prior_p, roll_p, st0,
                             steps0=steps0, max_steps=max_steps, done_rule=done_rule, max_plan_len=pc["horizon"] + 1)
+        assert list(plan) == list(o["plan"]), (desc, plan, o["plan"])
+        assert len(agent.planner.observations) == o["env_steps"], desc
+        assert np.array_equal(rng_state(agent.planner.np_random), o["rng_after"]), desc
+        assert agent.planner.root.count == o["tree"]["count"][0] and float(agent.planner.root.value) == o["tree"]["value"][0], desc
+    elif kind == "uct_prior":
+        env = env_of(t, r, term, s0, 0, done_rule)
+        cfg = dict(__class__=UCTP, budget=int(g.choice([20, 100, 300])), gamma=gamma, temperature=float(g.choice([0.5, 10.0, 200.0])),
+                   prior_agent=dict(__class__=PRIOR, gamma=float(g.choice([0.5, 0.9])), temperature=float(g.choice([0.1, 1.0])),
+                                    mask=int(g.choice([0, 3]))))
+        if g.random() < 0.5:
+            cfg.update(horizon=int(g.choice([3, 9])), episodes=int(g.choice([4, 15])))
+        desc.update(cfg=cfg)
+        agent = agent_factory(env, cfg)
+        agent.seed(seed)
+        st0 = rng_state(agent.planner.np_random)
+        table = np.array(agent.prior_agent.table)
+        plan = agent.plan(s0)
+        pc = agent.planner.config
+        o = oracle.uct_plan(t, r, term, s0, pc["episodes"], pc["horizon"], pc["gamma"], pc["temperature"], table, table, st0,
+                            done_rule=done_rule, max_plan_len=pc["horizon"] + 1)
         assert list(plan) == list(o["plan"]), (desc, plan, o["plan"])
         assert len(agent.planner.observations) == o["env_steps"], desc
         assert np.array_equal(rng_state(agent.planner.np_random), o["rng_after"]), desc
