@@ -47,13 +47,16 @@ def eq(a, b, what, case):
         raise AssertionError("{} differs in case {}".format(what, case))
 
 
+HEAVY = os.environ.get("FUZZ_HEAVY") == "1"   # larger budgets / horizons / batches (slower: the oracle is the long pole)
+
+
 def one_case(ctx, g, case):
     t, r, term = random_mdp(g)
     s, a = r.shape
     done_rule = "next" if g.random() < 0.3 else "source"
     max_steps = int(g.choice([0, 0, 3, 17]))
     gamma = float(g.choice([0.0, 0.3, 0.8, 0.95, 0.999]))
-    n = int(g.choice([1, 3, 64, 65, 200]))
+    n = int(g.choice([1, 3, 64, 65, 200] + ([1000, 3000] if HEAVY else [])))
     s0 = g.integers(0, s, size=n).astype(np.int32)
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
@@ -134,7 +137,7 @@ def one_case(ctx, g, case):
             s0 = t[s0, prev].astype(np.int32)
         ctx.uct_reset_tree()
     elif kind in ("uct", "uct_policy"):
-        episodes, horizon = int(g.choice([0, 1, 5, 33, 60])), int(g.choice([1, 2, 9, 30]))
+        episodes, horizon = int(g.choice([0, 1, 5, 33, 60] + ([150, 400] if HEAVY else []))), int(g.choice([1, 2, 9, 30] + ([60] if HEAVY else [])))
         temperature = float(g.choice([0.0, 1.0, 10.0, 3000.0]))
         steps0 = g.integers(0, 3, size=n).astype(np.int32) if max_steps else None
         desc.update(episodes=episodes, horizon=horizon, temperature=temperature)
@@ -165,7 +168,7 @@ def one_case(ctx, g, case):
             eq(out[k], ref[k], k, desc)
         eq(rng_dev, ref["rng_after"], "rng", desc)
     elif kind == "opd":
-        budget = int(g.choice([0, 1, a, 3 * a + 1, 100, 700]))
+        budget = int(g.choice([0, 1, a, 3 * a + 1, 100, 700] + ([3000, 6000] if HEAVY else [])))
         tr = float(g.choice([0.0, 0.25, 1.0]))
         if gamma >= 0.999:
             gamma = 0.95
@@ -178,7 +181,7 @@ def one_case(ctx, g, case):
             eq(out[k], ref[k], k, desc)
         eq(rng_dev, ref["rng_after"], "rng", desc)
     else:
-        budget = int(g.choice([0, a, 5 * a, 120, 300]))
+        budget = int(g.choice([0, a, 5 * a, 120, 300] + ([1000] if HEAVY else [])))
         tr = float(g.choice([0.0, 0.5]))
         if gamma >= 0.999:
             gamma = 0.9
