@@ -20,6 +20,7 @@ logger = logging.getLogger(__name__)
 
 class StateAwarePlanner(OptimisticDeterministicPlanner):
     """State-aware planner (state_aware.py:70-127) for one or many independent planners of one finite MDP."""
+    carries_state = True    # per-slot state on the device: callers keep the batch composition fixed
 
     def __init__(self, env, config=None):
         super(StateAwarePlanner, self).__init__(env, config)
@@ -41,6 +42,12 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
             held = self._device = (model, n, native.StateAwarePlanners(self.models.ctx, model, n))
         return held[2]
 
+    def forget(self):
+        """Drop the planners' kept state (a new planner object in the reference's terms)."""
+        if self._device is not None:
+            self._device[2].close()
+            self._device = None
+
     def plan_batch(self, state, root_states, root_steps=None, rng_states=None):
         model = self.model_for(state)
         n = len(root_states)
@@ -54,16 +61,23 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
                             accuracy=cfg["accuracy"], backup_aggregated_nodes=cfg["backup_aggregated_nodes"],
                             prune_suboptimal_leaves=cfg["prune_suboptimal_leaves"],
                             max_plan_len=int(cfg["budget"]) // model.A + 1)
-        if (out["status"] == native.MP_ERR_REWARD_RANGE).any():
-            raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
-        if (out["status"] == native.MP_ERR_ARG).any():
-            raise ValueError("max() arg is an empty sequence")     # every leaf pruned (state_aware.py:95)
-        if (out["status"] != 0).any():
-            raise RuntimeError("state-aware planner: backup queue overflow on the device (raise MP_SAOPD_QUEUE)")
+        if not getattr(self, "defer_errors", False):               # (a batched caller checks its live slots only)
+            self.raise_for_status(out["status"])
         out["rng_states"] = rng_states
         self.last, self._root, self._last_actions = out, None, model.A
         self.env_steps += int(out["env_steps"].sum())
         return out
+
+    @staticmethod
+    def raise_for_status(status):
+        """The reference's exceptions for the per-planner status codes."""
+        status = np.asarray(status)
+        if (status == native.MP_ERR_REWARD_RANGE).any():
+            raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
+        if (status == native.MP_ERR_ARG).any():
+            raise ValueError("max() arg is an empty sequence")     # every leaf pruned (state_aware.py:95)
+        if (status != 0).any():
+            raise RuntimeError("state-aware planner: backup queue overflow on the device (MP_SAOPD_QUEUE_LIMIT_MB)")
 
     def export_tree(self, root=0):
         arrays, state_values = self._device[2].export(root)

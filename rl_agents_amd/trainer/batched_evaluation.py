@@ -12,6 +12,11 @@ Episode i draws from its own PCG64 stream -- the one a sequential ``Evaluation``
 seeded with ``seed + i`` (evaluation.py:375 seeds the agent with ``sim_seed + episode``) -- and the stream
 continues from step to step exactly as ``planner.np_random`` does, so a batched run reproduces N sequential
 runs action for action (tests/test_gpu_agents.py).
+
+Planners that carry state from one ``plan()`` to the next -- MCTS with ``step_strategy="subtree"`` (the kept trees),
+the state-aware planner (its state values and state-node lists) -- keep that state per batch slot on the device, so
+for them every step plans the FULL batch (finished episodes stay where they ended and their results are ignored):
+slot i then sees exactly the sequence of plans a sequential agent i would make.
 """
 import time
 
@@ -53,16 +58,42 @@ class BatchedEvaluation(object):
         rng = np.stack([native.rng_state_from_generator(np_random(self.sim_seed + i)[0]) for i in range(n)])
         actions_log = np.full((n, self.max_steps), -1, dtype=np.int32)
         env = preprocess_env(self.env, self.agent.config["env_preprocessors"])
+        subtree = planner.config.get("step_strategy") == "subtree" and hasattr(planner, "step_by_subtree")
+        stateful = subtree or getattr(planner, "carries_state", False)
+        if stateful:
+            planner.step_by_reset()
+            if hasattr(planner, "forget"):
+                planner.forget()                               # every episode starts with a new planner object
+        previous = None                                        # first actions of the previous step's plans (all slots)
+        planner.defer_errors = stateful                        # errors of finished slots must not end the run
         t0, plan_seconds, env_steps = time.perf_counter(), 0.0, 0
+        try:
+            return self._loop(planner, env, n, stateful, subtree, previous, states, steps, alive, returns, gamma_returns, gamma,
+                              rng, actions_log, t0)
+        finally:
+            planner.defer_errors = False
+
+    def _loop(self, planner, env, n, stateful, subtree, previous, states, steps, alive, returns, gamma_returns, gamma, rng,
+              actions_log, t0):
+        plan_seconds, env_steps = 0.0, 0
         while alive.any():
-            idx = np.flatnonzero(alive)
+            idx = np.arange(n) if stateful else np.flatnonzero(alive)
             sub_rng = np.ascontiguousarray(rng[idx])
             t1 = time.perf_counter()
-            out = planner.plan_batch(env, states[idx], steps[idx], rng_states=sub_rng)
+            if subtree:                                        # AbstractPlanner.step_tree -> step_by_subtree(actions[0])
+                out = planner.plan_batch(env, states[idx], steps[idx], rng_states=sub_rng, keep_actions=previous)
+            else:
+                out = planner.plan_batch(env, states[idx], steps[idx], rng_states=sub_rng)
             plan_seconds += time.perf_counter() - t1
             rng[idx] = sub_rng
             act = out["plans"][:, 0].astype(np.int64)
             act[act < 0] = 0                                   # an empty plan (budget < |A|) falls back to action 0
+            if stateful:
+                previous = act.astype(np.int32)
+                live = alive[idx]
+                if "status" in out and hasattr(planner, "raise_for_status"):
+                    planner.raise_for_status(np.asarray(out["status"])[live])   # what a sequential agent would raise
+                idx, act = idx[live], act[live]
             s = states[idx]
             r = self.reward[s, act]
             s_next = self.transition[s, act].astype(np.int32)

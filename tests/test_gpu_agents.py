@@ -340,3 +340,39 @@ def test_gamma_one_raises_like_the_reference(golden):
         agent = agent_factory(_env(cfg), dict(__class__=cls, budget=40, gamma=1.0))
         with pytest.raises(ZeroDivisionError):
             agent.plan(0)
+
+
+@pytest.mark.parametrize("kind", ["mcts_subtree", "state_aware"])
+def test_batched_evaluation_with_planners_that_carry_state(kind):
+    """Planners that keep state between plans (kept UCT trees, state-aware dictionaries) hold it per batch slot:
+    N lock-step episodes still reproduce N sequential agents action for action, also after some episodes ended."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    if kind == "mcts_subtree":
+        cfg = dict(generators.highway_shaped(3, 4, 10, seed=3), state=2, max_steps=9)
+        agent_cfg = dict(__class__=UCT, budget=120, gamma=0.9, step_strategy="subtree")
+    else:
+        cfg = dict(generators.gridworld(), state=0, max_steps=6)
+        agent_cfg = dict(__class__=SAOPD, budget=100, gamma=0.9, prune_suboptimal_leaves=False)   # (pruning can empty the
+        # leaves list, where the reference raises -- and so does a batched run for a live episode)
+    cfg.pop("original_shape", None)
+    env = FiniteMDPEnv(cfg)
+    env.reset()
+    n = 5
+    starts = [2, 5, 7, 11, 13] if kind == "mcts_subtree" else [0, 12, 55, 37, 99]
+    out = BatchedEvaluation(env, agent_factory(env, dict(agent_cfg)), num_episodes=n, sim_seed=70).run(initial_states=starts)
+    for i in range(n):
+        e = FiniteMDPEnv(dict(cfg, state=starts[i]))
+        e.reset()
+        agent = agent_factory(e, dict(agent_cfg))
+        agent.seed(70 + i)
+        actions, done = [], False
+        while not done:
+            a = agent.act(e.mdp.state)
+            _, _, term, trunc, _ = e.step(a)
+            actions.append(a)
+            done = term or trunc
+        assert out["lengths"][i] == len(actions), (kind, i)
+        np.testing.assert_array_equal(out["actions"][i, :len(actions)], actions, err_msg=str((kind, i)))
+    assert len(set(out["lengths"].tolist())) >= 1
