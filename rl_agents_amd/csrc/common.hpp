@@ -121,7 +121,9 @@ struct mp_policy {
     int S = 0, A = 0;
     int stride = 0;             // doubles per row of prior / thr: A rounded up to even (16-byte rows)
     int frq = 0;                // 16-byte chunks per fused record: 1 + ceil((A-1)/4)
-    int shift = 21;             // fused thresholds keep thr >> shift (saturated to 32 bits)
+    int shift = 21;             // fused thresholds keep thr >> shift (saturated to 32 bits; 43 and 10 bits when packed)
+    int packed = 0;             // 1: frec16 holds 16-byte records {next:20|th0:10, flags:2|th1:10|th2:10|th3:10, reward}
+    uint4 *frec16 = nullptr;    // [S*A]
     double *prior = nullptr;    // [S][stride]  prior[s][a]
     uint64_t *thr = nullptr;    // [S][stride]  ceil(cdf[s][a] * 2^53), a < A-1 (the last threshold is never reached)
     uint4 *frec = nullptr;      // [S*A][frq]   {Rec of (s,a); top 32 bits of the thr row of the state it leads to}
