@@ -260,7 +260,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
             parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      traffic=None if with_prior else pmc_traffic("uct", "uct_kernel", n_roots),
+                      traffic=pmc_traffic("uct_prior" if with_prior else "uct", "uct_kernel", n_roots),
                       kernel="uct_kernel<5, ENV_TABLE, {}>".format("true" if with_prior else "false"),
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps),
     )
@@ -491,8 +491,9 @@ def bench_saopd(args, rank, world, local):
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots,
                     bellman_backups_per_planner=float(out["updates"].mean()),
                     parallelism="planners sharded over {} GPU(s)".format(world)),
-        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
-                      kernel="saopd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      traffic=pmc_traffic("saopd", "saopd_wave_kernel", n_roots * 64),
+                      kernel="saopd_wave_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure

@@ -15,7 +15,7 @@ for wl in uct uct_prior uct_cartpole opd saopd vi rvi vi_dense; do
 done
 # HBM traffic: FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots) -> two runs each; counters only,
 # no tracing domains besides the kernel trace
-for wl in uct vi_dense opd; do
+for wl in uct uct_prior vi_dense opd saopd; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o $wl -- \
         python /root/repo/bench.py --workload $wl --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${wl}_$ctr.log 2>&1
