@@ -27,28 +27,72 @@ if REPO not in sys.path:
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix peak (vendor figure; the guide lists no f64 row)
 # algorithmic HBM bytes per unit of work, SURVEY.md §8(d) / DESIGN.md §Kernels
-UCT_BYTES_PER_ENV_STEP = 28.0  # (13 H + 16 A d + 24 (d+1) + 24 A) / H at H=30, A=5, d~3
 
 
-def pmc_traffic(workload, kernel_substr, grid_threads):
+def calibration():
+    """FETCH_SIZE / WRITE_SIZE correction factors measured on this repo's own access patterns
+    (tools/gather_calib.hip -> profiles/*_gather_calib.json, 'factors'): true fabric bytes per byte the counter tallies,
+    for wide coalesced streams and for the scattered 16-byte records of the tree-search kernels.  Without a committed
+    calibration only the guide's stream factor (x2 on FETCH_SIZE) is known and scattered traffic is reported raw."""
+    import glob
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_gather_calib.json")))
+    if files:
+        try:
+            f = json.load(open(files[-1])).get("factors")
+            if f:
+                return dict(f, source=os.path.basename(files[-1]))
+        except (OSError, ValueError):
+            pass
+    return dict(fetch_stream=2.0, write_stream=1.0, fetch_scattered=1.0, write_scattered=1.0, source="uncalibrated (raw)")
+
+
+def pmc_traffic(workload, kernel_substr, grid_threads, pattern="scattered"):
     """HBM bytes per launch of one kernel from the committed PMC summary (profiles/*_pmc.json, produced by
     tools/profile_gpu.sh + tools/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-    passes of this same command): (2 * FETCH_SIZE + WRITE_SIZE) * 1024 -- counters are in KB and, on gfx950, FETCH_SIZE
-    tallies the 128-B requests of 16-B-per-lane loads at 64 B (MI355X_MICROARCH.md §HBM; calibrated here on
-    vi_dense_q's known 4.0 GB stream).  None when no summary for this launch geometry is committed."""
+    passes of this same command): (f_fetch * FETCH_SIZE + f_write * WRITE_SIZE) * 1024 with the factors of
+    calibration() for this kernel's access pattern ("stream": wide coalesced loads, e.g. vi_dense_q; "scattered":
+    16-byte records at random addresses, the tree-search kernels).  -> (bytes, raw dict) or (None, None) when no
+    summary for this launch geometry is committed."""
     import glob
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
     if not files:
-        return None
+        return None, None
     try:
         entry = json.load(open(files[-1])).get(workload, {})
     except (OSError, ValueError):
-        return None
+        return None, None
+    cal = calibration()
     for key, v in entry.items():
         if kernel_substr in key and key.endswith("grid={}".format(grid_threads)):
             if "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
-                return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
-    return None
+                ff, fw = cal["fetch_" + pattern], cal["write_" + pattern]
+                raw = dict(FETCH_SIZE_bytes=v["FETCH_SIZE_KB_per_launch"] * 1024.0,
+                           WRITE_SIZE_bytes=v["WRITE_SIZE_KB_per_launch"] * 1024.0, fetch_factor=ff, write_factor=fw,
+                           calibration=cal["source"], summary=os.path.basename(files[-1]))
+                return ff * raw["FETCH_SIZE_bytes"] + fw * raw["WRITE_SIZE_bytes"], raw
+    return None, None
+
+
+def add_traffic(roofline, workload, kernel_substr, grid_threads, pattern="scattered"):
+    """roofline.traffic (+ traffic_frac = traffic / kernel time / peak, the MEASURED HBM fraction, next to the contract's
+    algorithmic one) from the committed PMC passes."""
+    traffic, raw = pmc_traffic(workload, kernel_substr, grid_threads, pattern)
+    roofline["traffic"] = traffic
+    roofline["traffic_frac"] = None if traffic is None else traffic / (roofline["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+    roofline["traffic_counters"] = raw
+    roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+
+
+def reference_python(workload):
+    """profiles/reference_cpu.json[workload]: the unmodified reference timed by tests/golden/gen/time_reference.py."""
+    try:
+        rec = json.load(open(os.path.join(REPO, "profiles", "reference_cpu.json")))
+    except (OSError, ValueError):
+        return None
+    entry = rec.get("workloads", {}).get(workload)
+    if entry is None:
+        return None
+    return dict(entry, host=rec.get("host"), generated_by="tests/golden/gen/time_reference.py")
 
 
 def parse():
@@ -230,7 +274,23 @@ def bench_uct(args, rank, world, local, with_prior=False):
         env_steps = int(d_steps.sum().item())
     dt = max_over_ranks(dt, world)
     total_env_steps = sum_over_ranks(float(timed_env_steps), world) / args.steps   # per step, all ranks
-    # latency figures of the metric's second half ("plan() wall-ms per root"): small batches, rank 0's GPU
+    # Algorithmic bytes of THIS run, SURVEY.md 8(d): per env step 13 B of model (T 4 + R 8 + term 1); per selection
+    # level |A| children x 16 B; per episode a backup read-modify-write of 24 B on each of its depth + 1 path nodes; per
+    # expansion |A| node records of 24 B.  Depth and expansion counts are MEASURED on the trees this launch left
+    # (sum of the visit counts of the non-root nodes = selection steps; nodes with children = expansions), not assumed.
+    sample = np.unique(np.linspace(0, n_roots - 1, 257).astype(np.int64))
+    sel_steps = expansions = sample_env = 0
+    smp_steps = d_steps[torch.from_numpy(sample).to(dev)].cpu().numpy()
+    for i, root in enumerate(sample):
+        tr = ctx.uct_tree(int(root))
+        sel_steps += int(tr["count"][1:].sum())
+        expansions += int((tr["first_child"] >= 0).sum())
+        sample_env += int(smp_steps[i])
+    n_smp = len(sample)
+    mean_depth = sel_steps / float(n_smp * episodes)
+    bytes_per_step = (13.0 * sample_env + 16.0 * a_ * sel_steps + 24.0 * (sel_steps + n_smp * episodes)
+                      + 24.0 * a_ * expansions) / sample_env
+    # metric half (ii) and the 8(d) definition: small batches and the host-inclusive call, rank 0's GPU
     latency = {}
     for nl in (1, 4096):
         if nl > n_roots:
@@ -245,26 +305,59 @@ def bench_uct(args, rank, world, local, with_prior=False):
             ts.append(time.perf_counter() - t1)
         latency["plan_wall_ms_batch_of_{}".format(nl)] = 1e3 * float(np.median(ts))
         latency["kernel_ms_batch_of_{}".format(nl)] = ctx.last_kernel_ms()[0]
+        latency["env_steps_batch_of_{}".format(nl)] = int(d_steps[:nl].sum().item())
+
+    def host_inclusive(nr, reps):
+        """SURVEY.md 8(d) as written: wall time of the batched plan() handing over HOST arrays (MP_MEM_HOST: root
+        states and generator records uploaded, plans / values / counts / env-step counters downloaded, stream
+        synchronised inside the call); the model upload is excluded, as there."""
+        s0h = np.ascontiguousarray(s0[:nr])
+        rngh = rng0[:nr].copy()
+        kw = dict(max_plan_len=mpl, policy=policy)
+        ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, None if with_prior else p,
+                     None if with_prior else p, rngh, **kw)
+        steps, t1 = 0, time.perf_counter()
+        for _ in range(reps):
+            o = ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, None if with_prior else p,
+                             None if with_prior else p, rngh, **kw)
+            steps += int(o["env_steps"].sum())
+        w = time.perf_counter() - t1
+        return steps / w, 1e3 * w / reps
+
+    hi_val, hi_ms = host_inclusive(n_roots, 5)
+    hi4_val, hi4_ms = host_inclusive(min(4096, n_roots), 10)
+    hi1_val, hi1_ms = host_inclusive(1, 20)
     k_ms = float(np.mean(kernel_ms))
-    # per-state policies add, per env step, the rollout distribution of the state (|A|-1 thresholds of 8 B) and,
-    # per selection level, |A| priors of 8 B (already inside the 16 B/child select term of SURVEY.md 8d: +8 B/child)
-    bytes_per_step = UCT_BYTES_PER_ENV_STEP + (8 * (a_ - 1) + 4 if with_prior else 0)
+    nl4 = min(4096, n_roots)
     res = dict(
         metric="rollout env-steps/sec (UCT plan(), budget=1000)", unit="env-steps/s",
         value=total_env_steps * args.steps / dt, ms_per_step=1e3 * dt / args.steps,
+        # the same metric on SURVEY.md 8(d)'s own terms: host arrays in / out (PCIe inclusive) and the 4096-root batch
+        value_host_inclusive=sum_over_ranks(hi_val, world), host_inclusive_ms_per_step=hi_ms,
+        value_roots4096=latency.get("env_steps_batch_of_4096", 0) / (latency.get("plan_wall_ms_batch_of_4096", float("inf")) * 1e-3),
+        value_roots4096_host_inclusive=hi4_val,
+        plan_wall_ms_per_root=dict(batch_262144_device=1e3 * dt / args.steps / n_roots,
+                                   batch_4096_device=latency.get("plan_wall_ms_batch_of_4096", float("nan")) / nl4,
+                                   batch_4096_host_inclusive=hi4_ms / nl4,
+                                   single_root_device=latency.get("plan_wall_ms_batch_of_1"),
+                                   single_root_host_inclusive=hi1_ms),
         dtype="f64",
         config=dict(workload="{}_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
             "uct_with_vi_boltzmann_prior" if with_prior else "uct", s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
             states=s_, actions=a_, episodes=episodes, horizon=horizon, gamma=gamma,
             env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots, latency=latency,
+            measured_mean_selection_depth=mean_depth, measured_expansions_per_episode=expansions / float(n_smp * episodes),
+            algorithmic_bytes_per_env_step=bytes_per_step,
             parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      traffic=pmc_traffic("uct_prior" if with_prior else "uct", "uct_kernel", n_roots),
                       kernel="uct_kernel<5, ENV_TABLE, {}>".format("true" if with_prior else "false"),
-                      kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps),
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps,
+                      note="algorithmic bytes = SURVEY 8(d) terms with the depth / expansions measured on this launch's "
+                           "trees" + ("; the per-state policy tables (L2-resident by construction, like the 800 KB model) "
+                                      "are not charged" if with_prior else "")),
     )
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -423,10 +516,9 @@ def bench_opd(args, rank, world, local):
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots,
                     parallelism="roots sharded over {} GPU(s)".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                      traffic=pmc_traffic("opd", "opd_kernel", n_roots * 64),
                       kernel="opd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    add_traffic(res["roofline"], "opd", "opd_kernel", n_roots * 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -492,10 +584,9 @@ def bench_saopd(args, rank, world, local):
                     bellman_backups_per_planner=float(out["updates"].mean()),
                     parallelism="planners sharded over {} GPU(s)".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                      traffic=pmc_traffic("saopd", "saopd_wave_kernel", n_roots * 64),
                       kernel="saopd_wave_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    add_traffic(res["roofline"], "saopd", "saopd_wave_kernel", n_roots * 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -578,10 +669,12 @@ def bench_vi(args, rank, world, local, dense, robust=False):
                     states=s_, actions=a_, gamma=gamma, ms_per_sweep=1e3 * dt / args.steps / sweeps,
                     parallelism="replicas only ({} GPU(s))".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (per_sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                      traffic=pmc_traffic("vi_dense", "vi_dense_q", ((s_ * a_ + 63) // 64) * 256) if dense else None,
                       kernel=name, kernel_ms=per_sweep_ms, algorithmic_bytes_per_launch=alg),
     )
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if dense:
+        add_traffic(res["roofline"], "vi_dense", "vi_dense_q", ((s_ * a_ + 63) // 64) * 256, pattern="stream")
+    else:
+        res["roofline"].update(traffic=None, traffic_frac=None, frac=res["roofline"]["achieved"] / HBM_PEAK_GBS)
     if dense:
         res["roofline"]["mfma_tflops"] = flops / (per_sweep_ms * 1e-3) / 1e12
         res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
@@ -640,9 +733,17 @@ def main():
     res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                vs_baseline=None, data="synthetic (highway-shaped finite MDP; real highway_env absent)")
     res.setdefault("cpu_baseline", None)
+    if isinstance(res["cpu_baseline"], dict):
+        # the reference's own (pure Python) CPU path on the same tables: it cannot travel to the GPU box, so its timing is
+        # a committed, script-generated record of the build container (tests/golden/gen/time_reference.py), printed
+        # beside the C port that is timed live on this host
+        ref = reference_python(args.workload)
+        if ref is not None:
+            res["cpu_baseline"]["reference_python"] = ref
     if rank == 0:
         order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
+        order += [k for k in res if k not in order]
         print(json.dumps({k: res[k] for k in order}))
     if world > 1:
         import torch.distributed as dist
