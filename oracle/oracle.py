@@ -127,9 +127,11 @@ def vi_solve(mode, transition, reward, terminal=None, gamma=1.0, iterations=100,
 
 
 def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_state=None,
-             done_rule="source", max_plan_len=1024, want_tree=True):
+             done_rule="source", max_plan_len=1024, want_tree=True, available=None):
+    """available: bool [S, A] = the actions state.get_available_actions() lists per state (deterministic.py:32-35)."""
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
+    av = None if available is None else _u8(np.asarray(available).reshape(s, a))
     cap = 1 + (budget // a) * a
     rng = np.array(rng_state if rng_state is not None else np.zeros(6), dtype=np.uint64)
     plan = np.full(max_plan_len, -1, dtype=np.int32)
@@ -140,8 +142,9 @@ def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.
         tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),
                     depth=np.zeros(cap, np.int32), reward=np.zeros(cap, np.float64), lower=np.zeros(cap, np.float64),
                     upper=np.zeros(cap, np.float64), done=np.zeros(cap, np.uint8), count=np.zeros(cap, np.int64),
-                    first_child=np.zeros(cap, np.int32))
+                    first_child=np.zeros(cap, np.int32), n_children=np.zeros(cap, np.int32))
     tp = (lambda k, ct: _p(tree[k], ct)) if want_tree else (lambda k, ct: None)
+    nn = C.c_int32()
     rc = lib().orc_opd_plan(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
                             int(done_rule == "next"), int(s0), int(budget), C.c_double(gamma),
                             C.c_double(terminal_reward), _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32),
@@ -149,10 +152,12 @@ def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.
                             tp("parent", C.c_int32), tp("action", C.c_int32), tp("state", C.c_int32),
                             tp("depth", C.c_int32), tp("reward", C.c_double), tp("lower", C.c_double),
                             tp("upper", C.c_double), tp("done", C.c_uint8), tp("count", C.c_int64),
-                            tp("first_child", C.c_int32))
+                            tp("first_child", C.c_int32), _p(av, C.c_uint8), tp("n_children", C.c_int32), C.byref(nn))
     if rc == ERR_REWARD_RANGE:
         raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")
     assert rc == 0, rc
+    if want_tree:
+        tree = {k: v[:nn.value] for k, v in tree.items()}
     return dict(plan=plan[:plan_len.value].copy(), root_lower=lo.value, root_upper=up.value,
                 env_steps=steps.value, rng_after=rng, tree=tree)
 
@@ -165,11 +170,42 @@ def cartpole_params(params):
     return np.array([params[k] for k in CARTPOLE_KEYS], dtype=np.float64), int(params.get("max_steps", 0))
 
 
+def listed_policy(actions, probabilities, n_actions, cdf=False):
+    """Per-state policy outputs -- actions[s] (list of ints), probabilities[s] (list of floats), as a reference policy
+    function returns them for a state that may restrict its actions -- packed as (n [S] int32, act [S, A] int32,
+    p [S, A] float64); cdf=True stores numpy's Generator.choice cdf of each list instead of the probabilities."""
+    s = len(actions)
+    n = np.zeros(s, np.int32)
+    act = np.full((s, n_actions), -1, np.int32)
+    p = np.zeros((s, n_actions), np.float64)
+    for i in range(s):
+        k = len(actions[i])
+        n[i] = k
+        act[i, :k] = actions[i]
+        p[i, :k] = policy_cdf(probabilities[i]) if cdf else probabilities[i]
+    return n, act, p
+
+
+def _policy_args(prior_p, rollout_p, n_states, n_actions):
+    """-> (prior, cdf, state_policy, pol_n, pol_act) for the three policy forms of orc_uct_plan."""
+    if isinstance(prior_p, dict):       # listed policies: dict(actions=[...per state], p=[...per state])
+        pn, pact, pp = listed_policy(prior_p["actions"], prior_p["p"], n_actions)
+        rn, ract, rc = listed_policy(rollout_p["actions"], rollout_p["p"], n_actions, cdf=True)
+        return (np.ascontiguousarray(pp), np.ascontiguousarray(rc), 2, np.ascontiguousarray(np.concatenate([pn, rn])),
+                np.ascontiguousarray(np.concatenate([pact.reshape(-1), ract.reshape(-1)])))
+    prior = _f64(prior_p)
+    state_policy = int(prior.ndim == 2)
+    assert state_policy == int(np.ndim(rollout_p) == 2)
+    return prior, policy_cdf(rollout_p), state_policy, None, None
+
+
 def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
-             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64, cartpole=None, init_tree=None):
+             rng_state, steps0=0, max_steps=0, done_rule="source", max_plan_len=64, cartpole=None, init_tree=None,
+             closed_loop=False):
     """One root. Table env: transition/reward/terminal + integer s0. CartPole: cartpole=params dict, s0 = 4 doubles.
-    init_tree: dict(count, value, first_child[, prior]) kept from the previous plan (step_strategy "subtree").
-    prior_p / rollout_p of shape [S, A]: per-state policies (mcts_with_prior.py:47-62)."""
+    init_tree: dict(count, value, first_child[, prior, n_children, action]) kept from the previous plan (step_strategy
+    "subtree").  prior_p / rollout_p: [A] (one distribution), [S, A] (per-state tables, mcts_with_prior.py:47-62) or
+    dict(actions=, p=) lists per state (policies over restricted action sets).  closed_loop: mcts.py:147."""
     cp = x0 = None
     if cartpole is not None:
         cp, max_steps = cartpole_params(cartpole)
@@ -181,17 +217,17 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
     ic = None if not n_init else _i64(init_tree["count"])
     iv = None if not n_init else _f64(init_tree["value"])
     ifc = None if not n_init else np.ascontiguousarray(init_tree["first_child"], dtype=np.int32)
-    cap = max(n_init, 1) + episodes * a
+    inc = None if not (n_init and "n_children" in init_tree) else np.ascontiguousarray(init_tree["n_children"], dtype=np.int32)
+    iact = None if not (n_init and "action" in init_tree) else np.ascontiguousarray(init_tree["action"], dtype=np.int32)
+    cap = (max(n_init, 1) + episodes * a) * (2 if closed_loop else 1)
     rng = np.array(rng_state, dtype=np.uint64)
-    prior = _f64(prior_p)
-    state_policy = int(prior.ndim == 2)
-    assert state_policy == int(np.ndim(rollout_p) == 2)
-    cdf = policy_cdf(rollout_p)
+    prior, cdf, state_policy, pol_n, pol_act = _policy_args(prior_p, rollout_p, s, a)
     ip = None if not (n_init and "prior" in init_tree) else _f64(init_tree["prior"])
     plan = np.full(max_plan_len, -1, dtype=np.int32)
     plan_len, steps, nn = C.c_int32(), C.c_int64(), C.c_int32()
     tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), count=np.zeros(cap, np.int64),
-                value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32), prior=np.zeros(cap, np.float64))
+                value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32), prior=np.zeros(cap, np.float64),
+                n_children=np.zeros(cap, np.int32), is_obs=np.zeros(cap, np.uint8))
     rc = lib().orc_uct_plan(s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8),
                             int(done_rule == "next"), int(max_steps), int(s0), int(steps0), int(episodes),
                             int(horizon), C.c_double(gamma), C.c_double(temperature), _p(prior, C.c_double),
@@ -200,7 +236,10 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
                             _p(tree["action"], C.c_int32), _p(tree["count"], C.c_int64),
                             _p(tree["value"], C.c_double), _p(tree["first_child"], C.c_int32), C.byref(nn),
                             _p(cp, C.c_double), _p(x0, C.c_double), int(n_init), _p(ic, C.c_int64), _p(iv, C.c_double),
-                            _p(ifc, C.c_int32), state_policy, _p(tree["prior"], C.c_double), _p(ip, C.c_double))
+                            _p(ifc, C.c_int32), state_policy, _p(tree["prior"], C.c_double), _p(ip, C.c_double),
+                            _p(pol_n, C.c_int32), _p(pol_act, C.c_int32), int(bool(closed_loop)),
+                            _p(tree["n_children"], C.c_int32), _p(tree["is_obs"], C.c_uint8), _p(inc, C.c_int32),
+                            _p(iact, C.c_int32))
     assert rc == 0, rc
     tree = {k: v[:nn.value].copy() for k, v in tree.items()}
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, tree=tree)
@@ -210,18 +249,22 @@ def uct_reroot(tree, action, n_actions):
     """AbstractPlanner.step_by_subtree on an exported tree dict -> re-rooted tree dict, or None for a fresh tree."""
     n = len(tree["count"])
     oc, ov, ofc = np.zeros(n, np.int64), np.zeros(n, np.float64), np.zeros(n, np.int32)
+    onc, oact = np.zeros(n, np.int32), np.zeros(n, np.int32)
     pr = _f64(tree["prior"]) if "prior" in tree else None
     opr = np.zeros(n, np.float64) if pr is not None else None
+    nc = np.ascontiguousarray(tree["n_children"], np.int32) if "n_children" in tree else None
+    act = np.ascontiguousarray(tree["action"], np.int32) if "n_children" in tree else None
     n_out = C.c_int32()
     rc = lib().orc_uct_reroot(int(n_actions), n, _p(_i64(tree["count"]), C.c_int64), _p(_f64(tree["value"]), C.c_double),
                               _p(np.ascontiguousarray(tree["first_child"], np.int32), C.c_int32), int(action),
                               _p(oc, C.c_int64), _p(ov, C.c_double), _p(ofc, C.c_int32), C.byref(n_out),
-                              _p(pr, C.c_double), _p(opr, C.c_double))
+                              _p(pr, C.c_double), _p(opr, C.c_double), _p(nc, C.c_int32), _p(act, C.c_int32),
+                              _p(onc, C.c_int32), _p(oact, C.c_int32))
     assert rc == 0
     if n_out.value == 0:
         return None
     k = n_out.value
-    out = dict(count=oc[:k], value=ov[:k], first_child=ofc[:k])
+    out = dict(count=oc[:k], value=ov[:k], first_child=ofc[:k], n_children=onc[:k], action=oact[:k])
     if opr is not None:
         out["prior"] = opr[:k]
     return out
@@ -242,8 +285,7 @@ def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, t
     n = len(s0)
     st0 = None if steps0 is None else np.ascontiguousarray(steps0, dtype=np.int32)
     rng = np.array(rng_states, dtype=np.uint64).reshape(n, 6)
-    prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
-    state_policy = int(prior.ndim == 2)
+    prior, cdf, state_policy, pol_n, pol_act = _policy_args(prior_p, rollout_p, s, a)
     plans = np.full((n, max_plan_len), -1, dtype=np.int32)
     plan_len = np.zeros(n, np.int32)
     root_value = np.zeros(n, np.float64)
@@ -256,16 +298,18 @@ def uct_plan_batch(transition, reward, terminal, s0, episodes, horizon, gamma, t
                                   _p(prior, C.c_double), _p(cdf, C.c_double), _p(rng, C.c_uint64), max_plan_len,
                                   _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(root_value, C.c_double),
                                   _p(cc, C.c_int64), _p(cv, C.c_double), _p(steps, C.c_int64), int(n_threads),
-                                  _p(cp, C.c_double), _p(x0, C.c_double), state_policy)
+                                  _p(cp, C.c_double), _p(x0, C.c_double), state_policy, _p(pol_n, C.c_int32),
+                                  _p(pol_act, C.c_int32))
     assert rc == 0, rc
     return dict(plans=plans, plan_len=plan_len, root_value=root_value, root_child_count=cc,
                 root_child_value=cv, env_steps=steps, rng_after=rng)
 
 
 def opd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
-                   done_rule="source", max_plan_len=32, n_threads=1):
+                   done_rule="source", max_plan_len=32, n_threads=1, available=None):
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
+    av = None if available is None else _u8(np.asarray(available).reshape(s, a))
     s0 = np.ascontiguousarray(s0, dtype=np.int32)
     n = len(s0)
     if rng_states is None:  # any valid PCG64 record (odd increment); an all-zero one would never leave the rejection loop
@@ -281,7 +325,7 @@ def opd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_rew
                              int(done_rule == "next"), n, _p(s0, C.c_int32), int(budget), C.c_double(gamma),
                              C.c_double(terminal_reward), _p(rng, C.c_uint64), max_plan_len, _p(plans, C.c_int32),
                              _p(plan_len, C.c_int32), _p(lo, C.c_double), _p(up, C.c_double), _p(steps, C.c_int64),
-                             _p(status, C.c_int32), int(n_threads))
+                             _p(status, C.c_int32), int(n_threads), _p(av, C.c_uint8))
     return dict(plans=plans, plan_len=plan_len, root_lower=lo, root_upper=up, env_steps=steps, status=status,
                 rng_after=rng)
 

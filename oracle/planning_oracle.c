@@ -318,8 +318,10 @@ static inline void orc_env_step(const orc_env *e, int32_t *s, int32_t *steps, in
 
 /* ------------------------------------------------------------------ OPD ------------------ */
 /*
- * deterministic.py:9-122 for one root.  Node arrays are in creation order (root = 0, the A
- * children of the k-th expanded leaf = 1 + k*A ... ), capacity 1 + (budget/A)*A.
+ * deterministic.py:9-122 for one root.  Node arrays are in creation order (root = 0, the children of an expanded
+ * leaf are contiguous), capacity 1 + (budget/A)*A.
+ * avail: uint8 [S*A] flags of the actions state.get_available_actions() lists in each state (deterministic.py:32-35;
+ * NULL = range(action_space.n)): an expansion creates one child per available action, in increasing action order.
  * Outputs may be NULL.  Returns ORC_ERR_REWARD_RANGE where the reference raises ValueError.
  */
 int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
@@ -328,7 +330,8 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
                  int64_t *env_steps,
                  /* optional tree export, capacity n_nodes = 1 + (budget/A)*A */
                  int32_t *t_parent, int32_t *t_action, int32_t *t_state, int32_t *t_depth, double *t_reward,
-                 double *t_lower, double *t_upper, uint8_t *t_done, int64_t *t_count, int32_t *t_first_child)
+                 double *t_lower, double *t_upper, uint8_t *t_done, int64_t *t_count, int32_t *t_first_child,
+                 const uint8_t *avail, int32_t *t_n_children, int32_t *n_nodes_out)
 {
     orc_env env = {S, A, T, R, term, done_on_next, 0, NULL};
     const int K = budget / A; /* deterministic.py:118 */
@@ -336,17 +339,18 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
     int32_t *state = malloc(cap * sizeof(int32_t)), *depth = malloc(cap * sizeof(int32_t));
     int32_t *first_child = malloc(cap * sizeof(int32_t)), *leaves = malloc(cap * sizeof(int32_t));
+    int32_t *n_children = malloc(cap * sizeof(int32_t));
     double *lower = malloc(cap * sizeof(double)), *upper = malloc(cap * sizeof(double));
     double *reward = malloc(cap * sizeof(double));
     uint8_t *done = malloc(cap);
     int64_t *count = malloc(cap * sizeof(int64_t));
-    if (!parent || !action || !state || !depth || !first_child || !leaves || !lower || !upper || !reward ||
+    if (!parent || !action || !state || !depth || !first_child || !leaves || !n_children || !lower || !upper || !reward ||
         !done || !count)
         return ORC_ERR_ALLOC;
     int rc = ORC_OK;
     int64_t steps_taken = 0;
     /* deterministic.py:10-19: root */
-    parent[0] = -1; action[0] = -1; state[0] = s0; depth[0] = 0; first_child[0] = -1;
+    parent[0] = -1; action[0] = -1; state[0] = s0; depth[0] = 0; first_child[0] = -1; n_children[0] = 0;
     lower[0] = 0; upper[0] = 0; reward[0] = 0; done[0] = 0; count[0] = 1;
     int n_nodes = 1, n_leaves = 1;
     leaves[0] = 0;
@@ -360,9 +364,11 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
         memmove(leaves + li, leaves + li + 1, (n_leaves - li - 1) * sizeof(int32_t));
         --n_leaves;
         first_child[leaf] = n_nodes;
-        for (int a = 0; a < A; ++a) { /* deterministic.py:36-43 */
+        for (int a = 0; a < A; ++a) { /* deterministic.py:32-43 */
+            if (avail && !avail[(long)state[leaf] * A + a]) continue;
             const int c = n_nodes++;
-            parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1;
+            ++n_children[leaf];
+            parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1; n_children[c] = 0;
             int32_t s = state[leaf], st = 0;
             double r; int terminated, truncated;
             orc_env_step(&env, &s, &st, a, &r, &terminated, &truncated);
@@ -385,10 +391,11 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
         if (rc != ORC_OK) break;
         /* deterministic.py:74-79 backup_to_root */
         for (int n = leaf; n >= 0; n = parent[n]) {
+            if (n_children[n] == 0) break; /* `if self.children:` -- unreachable while every state lists an action */
             double ml = lower[first_child[n]], mu = upper[first_child[n]];
-            for (int a = 1; a < A; ++a) {
-                if (lower[first_child[n] + a] > ml) ml = lower[first_child[n] + a];
-                if (upper[first_child[n] + a] > mu) mu = upper[first_child[n] + a];
+            for (int j = 1; j < n_children[n]; ++j) {
+                if (lower[first_child[n] + j] > ml) ml = lower[first_child[n] + j];
+                if (upper[first_child[n] + j] > mu) mu = upper[first_child[n] + j];
             }
             lower[n] = ml; upper[n] = mu;
         }
@@ -397,16 +404,16 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
         /* abstract.py:143-156 get_plan with deterministic.py:21-26 selection_rule */
         orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
         int n = 0, len = 0;
-        while (first_child[n] >= 0) {
-            const int fc = first_child[n];
+        while (n_children[n] > 0) {
+            const int fc = first_child[n], kc = n_children[n];
             double m = lower[fc];
-            for (int a = 1; a < A; ++a) if (lower[fc + a] > m) m = lower[fc + a];
+            for (int j = 1; j < kc; ++j) if (lower[fc + j] > m) m = lower[fc + j];
             int ties[64], nt = 0;
-            for (int a = 0; a < A && nt < 64; ++a) if (lower[fc + a] == m) ties[nt++] = a;
-            const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
-            if (plan && len < max_plan_len) plan[len] = a;
+            for (int j = 0; j < kc && nt < 64; ++j) if (lower[fc + j] == m) ties[nt++] = j;
+            const int j = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            if (plan && len < max_plan_len) plan[len] = action[fc + j];
             ++len;
-            n = fc + a;
+            n = fc + j;
         }
         if (plan) for (int i = len; i < max_plan_len; ++i) plan[i] = -1;
         if (plan_len) *plan_len = len;
@@ -426,29 +433,41 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
         if (t_upper) t_upper[i] = upper[i];
         if (t_done) t_done[i] = done[i];
         if (t_count) t_count[i] = count[i];
-        if (t_first_child) t_first_child[i] = first_child[i];
+        if (t_first_child) t_first_child[i] = n_children[i] > 0 ? first_child[i] : -1;
+        if (t_n_children) t_n_children[i] = n_children[i];
     }
-    free(parent); free(action); free(state); free(depth); free(first_child); free(leaves);
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+    free(parent); free(action); free(state); free(depth); free(first_child); free(leaves); free(n_children);
     free(lower); free(upper); free(reward); free(done); free(count);
     return rc;
 }
 
 /* ------------------------------------------------------------------ UCT ------------------ */
 /*
- * mcts.py:100-184 (MCTS planner) + mcts.py:203-286 (MCTSNode) for one root, open loop.
- * prior[a] / rollout_cdf[a]: the state-independent policies of mcts.py:46-97 over actions
- * 0..A-1 (a table env has no get_available_actions); the cdf is numpy's cumsum(p)/cumsum(p)[-1].
- * state_policy != 0: prior / rollout_cdf are [S][A] tables indexed by the state the policy is asked about
- * (MCTSWithPriorPolicyAgent.agent_policy, mcts_with_prior.py:47-62: both policies come from a prior agent's
- * action distribution in that state).  A child's prior is stored when its parent is expanded (mcts.py:237-246).
- * Node arrays are in creation order: root = 0, each expansion appends A children.
- * Capacity 1 + episodes*A (one expansion per episode at most, mcts.py:151-154).
+ * mcts.py:100-184 (MCTS planner) + mcts.py:203-286 (MCTSNode) for one root.
+ * Policies (mcts.py:46-97, mcts_with_prior.py:47-62), selected by state_policy:
+ *   0  prior[a] / rollout_cdf[a]: one distribution over actions 0..A-1 for every state (a table env without
+ *      get_available_actions); the cdf is numpy's cumsum(p)/cumsum(p)[-1].
+ *   1  prior / rollout_cdf are [S][A] tables indexed by the state the policy is asked about
+ *      (MCTSWithPriorPolicyAgent.agent_policy: both policies come from a prior agent's distribution in that state).
+ *   2  LISTED policies, what a policy function literally returns for a state that may restrict its actions
+ *      (state.get_available_actions(), mcts.py:59-73,88-97, mcts_with_prior.py:56-62): for state s the prior policy
+ *      returns the pol_n[s] actions pol_act[s][0..n) with probabilities prior[s][0..n), the rollout policy the
+ *      pol_n[S + s] actions pol_act[S*A + s*A + 0..n) with cdf rollout_cdf[s][0..n).  MCTSNode.expand creates one child
+ *      per listed action (mcts.py:237-246), so nodes have a variable number of children.
+ * A child's prior is stored when its parent is expanded (mcts.py:237-246).
+ * closed_loop != 0 (mcts.py:147, MCTSNode.get_child :267-273): after every selection step the node reached is the
+ *   child of the action node keyed by str(observation) -- created on first visit with prior 0 -- where the observation
+ *   of a finite-MDP env is the index of the state reached.  The env is deterministic, so an action node can only ever
+ *   observe one state (checked: ORC_ERR_ARG otherwise).
+ * Node arrays are in creation order; the children made by one expansion are contiguous (first_child, n_children).
+ * Capacity: 1 + episodes*A nodes (one expansion per episode at most, mcts.py:151-154), twice that with closed_loop.
  */
 int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
                  int max_steps, int32_t s0, int32_t steps0, int episodes, int horizon, double gamma,
                  double temperature, const double *prior, const double *rollout_cdf, uint64_t *rng6,
                  int max_plan_len, int32_t *plan, int32_t *plan_len, int64_t *env_steps,
-                 /* optional tree export, capacity 1 + episodes*A */
+                 /* optional tree export, capacity as above */
                  int32_t *t_parent, int32_t *t_action, int64_t *t_count, double *t_value,
                  int32_t *t_first_child, int32_t *n_nodes_out,
                  /* CartPole roots: cp = 8 parameters, x0 = root state (4 doubles); NULL, NULL = table env */
@@ -458,75 +477,106 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
                   * n_init + episodes*A. */
                  int n_init, const int64_t *init_count, const double *init_value, const int32_t *init_first_child,
                  /* per-state policies; t_prior / init_prior: the stored child priors (export / kept tree), or NULL */
-                 int state_policy, double *t_prior, const double *init_prior)
+                 int state_policy, double *t_prior, const double *init_prior,
+                 /* listed policies (state_policy == 2), closed loop, and the matching export / kept-tree arrays */
+                 const int32_t *pol_n, const int32_t *pol_act, int closed_loop, int32_t *t_n_children,
+                 uint8_t *t_is_obs, const int32_t *init_n_children, const int32_t *init_action)
 {
     orc_env env = {S, A, T, R, term, done_on_next, max_steps, cp};
     if (state_policy && cp) return ORC_ERR_ARG;
-    const int cap = (n_init > 0 ? n_init : 1) + episodes * A;
+    if (state_policy == 2 && (!pol_n || !pol_act)) return ORC_ERR_ARG;
+    if (closed_loop && (cp || n_init > 0)) return ORC_ERR_ARG; /* the reference's subtree step breaks on observation keys */
+    const int cap = ((n_init > 0 ? n_init : 1) + episodes * A) * (closed_loop ? 2 : 1);
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
-    int32_t *first_child = malloc(cap * sizeof(int32_t));
+    int32_t *first_child = malloc(cap * sizeof(int32_t)), *n_children = malloc(cap * sizeof(int32_t));
+    uint8_t *is_obs = malloc(cap);
     int64_t *count = malloc(cap * sizeof(int64_t));
     double *value = malloc(cap * sizeof(double)), *gpow = malloc((horizon + 1) * sizeof(double));
     double *nprior = malloc(cap * sizeof(double));
     double *score = malloc((A > 0 ? A : 1) * sizeof(double));
     int *ties = malloc((A > 0 ? A : 1) * sizeof(int));
-    if (!parent || !action || !first_child || !count || !value || !gpow || !nprior || !score || !ties) return ORC_ERR_ALLOC;
+    if (!parent || !action || !first_child || !n_children || !is_obs || !count || !value || !gpow || !nprior || !score || !ties)
+        return ORC_ERR_ALLOC;
     for (int h = 0; h <= horizon; ++h) gpow[h] = pow(gamma, h); /* Python: gamma ** h */
     orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
     /* mcts.py:129-130 reset(): fresh root (value 0, count 0, prior 1) */
-    parent[0] = -1; action[0] = -1; first_child[0] = -1; count[0] = 0; value[0] = 0; nprior[0] = 1;
+    parent[0] = -1; action[0] = -1; first_child[0] = -1; n_children[0] = 0; is_obs[0] = 0; count[0] = 0; value[0] = 0; nprior[0] = 1;
     int n_nodes = 1;
-    if (n_init > 0) { /* continue on the re-rooted tree */
+    int rc = ORC_OK;
+    if (n_init > 0) { /* continue on the re-rooted tree (the new root keeps the prior it had as a child) */
+        if (init_prior) nprior[0] = init_prior[0];
         for (int i = 0; i < n_init; ++i) {
-            count[i] = init_count[i]; value[i] = init_value[i]; first_child[i] = init_first_child[i];
-            if (first_child[i] >= 0)
-                for (int a = 0; a < A; ++a) {
-                    parent[first_child[i] + a] = i; action[first_child[i] + a] = a;
-                    nprior[first_child[i] + a] = init_prior ? init_prior[first_child[i] + a] : prior[a];
-                }
+            count[i] = init_count[i]; value[i] = init_value[i]; first_child[i] = init_first_child[i]; is_obs[i] = 0;
+            n_children[i] = first_child[i] < 0 ? 0 : (init_n_children ? init_n_children[i] : A);
+            for (int j = 0; j < n_children[i]; ++j) {
+                const int c = first_child[i] + j;
+                parent[c] = i; action[c] = init_action ? init_action[c] : j;
+                nprior[c] = init_prior ? init_prior[c] : prior[action[c]];
+            }
         }
         n_nodes = n_init;
     }
     int64_t steps_taken = 0;
-    for (int ep = 0; ep < episodes; ++ep) { /* mcts.py:179-184 */
+    for (int ep = 0; ep < episodes && rc == ORC_OK; ++ep) { /* mcts.py:179-184 */
         int32_t s = s0, st = steps0;     /* safe_deepcopy_env(state) */
         double x4[4] = {0, 0, 0, 0};
         if (cp) memcpy(x4, x0, sizeof(x4));
         int node = 0, depth = 0, terminal = 0, truncated = 0;
         double total_reward = 0;
         /* mcts.py:143-149 selection */
-        while (depth < horizon && first_child[node] >= 0 && !terminal) {
-            const int fc = first_child[node];
+        while (depth < horizon && n_children[node] > 0 && !terminal) {
+            const int fc = first_child[node], k = n_children[node];
             /* mcts.py:275-286: value + temperature * len(parent.children) * prior / (count + 1) */
             double m = 0;
-            for (int a = 0; a < A; ++a) {
-                score[a] = value[fc + a] + temperature * A * nprior[fc + a] / (double)(count[fc + a] + 1);
-                if (a == 0 || score[a] > m) m = score[a];
+            for (int j = 0; j < k; ++j) {
+                score[j] = value[fc + j] + temperature * k * nprior[fc + j] / (double)(count[fc + j] + 1);
+                if (j == 0 || score[j] > m) m = score[j];
             }
             int nt = 0;
-            for (int a = 0; a < A; ++a) if (score[a] == m) ties[nt++] = a; /* abstract.py:296-311 */
-            const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            for (int j = 0; j < k; ++j) if (score[j] == m) ties[nt++] = j; /* abstract.py:296-311 */
+            const int j = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            const int a = action[fc + j];
             double r;
             if (cp) orc_cartpole_step(&env, x4, &st, a, &r, &terminal, &truncated);
             else orc_env_step(&env, &s, &st, a, &r, &terminal, &truncated);
             ++steps_taken;
             total_reward += gpow[depth] * r;
-            node = fc + a;
+            node = fc + j;
+            if (closed_loop) { /* MCTSNode.get_child(action, observation), mcts.py:267-273 */
+                if (n_children[node] == 0) {
+                    const int c = n_nodes++;
+                    parent[c] = node; action[c] = s; is_obs[c] = 1; first_child[c] = -1; n_children[c] = 0;
+                    count[c] = 0; value[c] = 0; nprior[c] = 0;
+                    first_child[node] = c; n_children[node] = 1;
+                } else if (action[first_child[node]] != s) {
+                    rc = ORC_ERR_ARG;
+                    break;
+                }
+                node = first_child[node];
+            }
             ++depth;
         }
-        /* mcts.py:151-154 expansion */
-        if (first_child[node] < 0 && depth < horizon && (!terminal || node == 0)) {
-            first_child[node] = n_nodes;
-            for (int a = 0; a < A; ++a) {
+        if (rc != ORC_OK) break;
+        /* mcts.py:151-154 expansion: one child per action the prior policy lists for this state */
+        if (n_children[node] == 0 && depth < horizon && (!terminal || node == 0)) {
+            const int k = state_policy == 2 ? pol_n[s] : A;
+            first_child[node] = n_nodes; n_children[node] = k;
+            for (int j = 0; j < k; ++j) {
                 const int c = n_nodes++;
-                parent[c] = node; action[c] = a; first_child[c] = -1; count[c] = 0; value[c] = 0;
-                nprior[c] = state_policy ? prior[(long)s * A + a] : prior[a]; /* prior_policy(state, observation) */
+                const int a = state_policy == 2 ? pol_act[(long)s * A + j] : j;
+                parent[c] = node; action[c] = a; first_child[c] = -1; n_children[c] = 0; is_obs[c] = 0; count[c] = 0; value[c] = 0;
+                nprior[c] = state_policy ? prior[(long)s * A + j] : prior[j]; /* prior_policy(state, observation) */
             }
         }
         /* mcts.py:156-157,160-177 rollout */
         if (!terminal) {
             for (int h = depth; h < horizon; ++h) {
-                const int a = orc_cdf_pick(state_policy ? rollout_cdf + (long)s * A : rollout_cdf, A, orc_pcg64_double(&g));
+                const double u = orc_pcg64_double(&g);
+                int a;
+                if (state_policy == 2)
+                    a = pol_act[(long)S * A + (long)s * A + orc_cdf_pick(rollout_cdf + (long)s * A, pol_n[S + s], u)];
+                else
+                    a = orc_cdf_pick(state_policy ? rollout_cdf + (long)s * A : rollout_cdf, A, u);
                 double r; int term_h, trunc_h;
                 if (cp) orc_cartpole_step(&env, x4, &st, a, &r, &term_h, &trunc_h);
                 else orc_env_step(&env, &s, &st, a, &r, &term_h, &trunc_h);
@@ -541,16 +591,17 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
             value[n] += 1.0 / (double)count[n] * (total_reward - value[n]);
         }
     }
-    /* abstract.py:143-156 get_plan with mcts.py:212-218 selection_rule */
+    /* abstract.py:143-156 get_plan with mcts.py:212-218 selection_rule; under an action node of a closed-loop tree the
+     * "action" is the observation key of its single child */
     int n = 0, len = 0;
-    while (first_child[n] >= 0) {
-        const int fc = first_child[n];
+    while (rc == ORC_OK && n_children[n] > 0) {
+        const int fc = first_child[n], k = n_children[n];
         int64_t mc = count[fc];
-        for (int a = 1; a < A; ++a) if (count[fc + a] > mc) mc = count[fc + a];
+        for (int j = 1; j < k; ++j) if (count[fc + j] > mc) mc = count[fc + j];
         int best = -1;
-        for (int a = 0; a < A; ++a)
-            if (count[fc + a] == mc && (best < 0 || value[fc + a] > value[fc + best])) best = a;
-        if (plan && len < max_plan_len) plan[len] = best;
+        for (int j = 0; j < k; ++j)
+            if (count[fc + j] == mc && (best < 0 || value[fc + j] > value[fc + best])) best = j;
+        if (plan && len < max_plan_len) plan[len] = action[fc + best];
         ++len;
         n = fc + best;
     }
@@ -566,35 +617,54 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
         if (t_value) t_value[i] = value[i];
         if (t_first_child) t_first_child[i] = first_child[i];
         if (t_prior) t_prior[i] = nprior[i];
+        if (t_n_children) t_n_children[i] = n_children[i];
+        if (t_is_obs) t_is_obs[i] = is_obs[i];
     }
     if (n_nodes_out) *n_nodes_out = n_nodes;
-    free(parent); free(action); free(first_child); free(count); free(value); free(gpow); free(nprior); free(score); free(ties);
-    return ORC_OK;
+    free(parent); free(action); free(first_child); free(n_children); free(is_obs); free(count); free(value); free(gpow);
+    free(nprior); free(score); free(ties);
+    return rc;
 }
 
 /*
  * AbstractPlanner.step_by_subtree (abstract.py:195-206): the tree is replaced by the subtree of the root's child
  * `action`; an unexpanded root or child-less choice starts a new tree (n_out = 0 -> caller plans from a fresh root).
  * Nodes are re-numbered breadth-first so that children stay contiguous.  Arrays of capacity n_in.
+ * n_children / node_action: per-node child counts and action keys of trees with restricted action sets (NULL: every
+ * expanded node has the A children 0..A-1).
  */
 int orc_uct_reroot(int A, int n_in, const int64_t *count, const double *value, const int32_t *first_child, int action,
                    int64_t *o_count, double *o_value, int32_t *o_first_child, int32_t *n_out,
-                   const double *prior, double *o_prior /* stored child priors, or NULL */)
+                   const double *prior, double *o_prior /* stored child priors, or NULL */,
+                   const int32_t *n_children, const int32_t *node_action, int32_t *o_n_children, int32_t *o_action)
 {
-    if (n_in < 1 || first_child[0] < 0 || action < 0 || action >= A) { *n_out = 0; return ORC_OK; }
-    int32_t *src = malloc((size_t)n_in * sizeof(int32_t));
+    *n_out = 0;
+    if (n_in < 1 || first_child[0] < 0) return ORC_OK;
+    int chosen = -1; /* `if action in self.root.children` */
+    const int k0 = n_children ? n_children[0] : A;
+    for (int j = 0; j < k0; ++j)
+        if ((node_action ? node_action[first_child[0] + j] : j) == action) chosen = first_child[0] + j;
+    if (chosen < 0) return ORC_OK;
+    int32_t *src = malloc((size_t)n_in * 2 * sizeof(int32_t));
     if (!src) return ORC_ERR_ALLOC;
+    int32_t *src_act = src + n_in;
     int head = 0, tail = 1;
-    src[0] = first_child[0] + action;
+    src[0] = chosen; src_act[0] = -1;
     while (head < tail) {
         const int o = src[head];
         o_count[head] = count[o];
         o_value[head] = value[o];
         if (prior && o_prior) o_prior[head] = prior[o];
-        if (first_child[o] >= 0) {
+        if (o_action) o_action[head] = src_act[head];
+        const int k = first_child[o] < 0 ? 0 : (n_children ? n_children[o] : A);
+        if (o_n_children) o_n_children[head] = k;
+        if (k > 0) {
             o_first_child[head] = tail;
-            for (int a = 0; a < A; ++a) src[tail + a] = first_child[o] + a;
-            tail += A;
+            for (int j = 0; j < k; ++j) {
+                src[tail + j] = first_child[o] + j;
+                src_act[tail + j] = node_action ? node_action[first_child[o] + j] : j;
+            }
+            tail += k;
         } else {
             o_first_child[head] = -1;
         }
@@ -617,7 +687,8 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
                        int32_t *plans /* [n_roots,max_plan_len] */, int32_t *plan_len, double *root_value,
                        int64_t *root_child_count /* [n_roots,A] */, double *root_child_value /* [n_roots,A] */,
                        int64_t *env_steps /* [n_roots] */, int n_threads,
-                       const double *cp, const double *x0 /* [n_roots,4] or NULL */, int state_policy)
+                       const double *cp, const double *x0 /* [n_roots,4] or NULL */, int state_policy,
+                       const int32_t *pol_n, const int32_t *pol_act)
 {
     int rc_all = ORC_OK;
     const int cap = 1 + episodes * A;
@@ -625,22 +696,28 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
     for (int i = 0; i < n_roots; ++i) {
         int64_t *cnt = malloc(cap * sizeof(int64_t));
         double *val = malloc(cap * sizeof(double));
+        int32_t *act = malloc(cap * sizeof(int32_t)), *nch = malloc(cap * sizeof(int32_t));
         int32_t nn = 0;
         int rc = orc_uct_plan(S, A, T, R, term, done_on_next, max_steps, s0 ? s0[i] : 0, steps0 ? steps0[i] : 0, episodes,
                               horizon, gamma, temperature, prior, rollout_cdf, rng6 + (long)i * 6, max_plan_len,
                               plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
-                              env_steps ? env_steps + i : NULL, NULL, NULL, cnt, val, NULL, &nn, cp,
-                              x0 ? x0 + (long)i * 4 : NULL, 0, NULL, NULL, NULL, state_policy, NULL, NULL);
+                              env_steps ? env_steps + i : NULL, NULL, act, cnt, val, NULL, &nn, cp,
+                              x0 ? x0 + (long)i * 4 : NULL, 0, NULL, NULL, NULL, state_policy, NULL, NULL,
+                              pol_n, pol_act, 0, nch, NULL, NULL, NULL);
         if (rc != ORC_OK) {
 #pragma omp critical
             rc_all = rc;
         }
         if (root_value) root_value[i] = val[0];
         for (int a = 0; a < A; ++a) {
-            if (root_child_count) root_child_count[(long)i * A + a] = nn > 1 ? cnt[1 + a] : 0;
-            if (root_child_value) root_child_value[(long)i * A + a] = nn > 1 ? val[1 + a] : 0;
+            if (root_child_count) root_child_count[(long)i * A + a] = 0;
+            if (root_child_value) root_child_value[(long)i * A + a] = 0;
         }
-        free(cnt); free(val);
+        for (int j = 0; nn > 1 && j < nch[0]; ++j) { /* the root's children are nodes 1 .. n_children(root) */
+            if (root_child_count) root_child_count[(long)i * A + act[1 + j]] = cnt[1 + j];
+            if (root_child_value) root_child_value[(long)i * A + act[1 + j]] = val[1 + j];
+        }
+        free(cnt); free(val); free(act); free(nch);
     }
     return rc_all;
 }
@@ -648,7 +725,8 @@ int orc_uct_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
 int orc_opd_plan_batch(int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
                        int n_roots, const int32_t *s0, int budget, double gamma, double terminal_reward,
                        uint64_t *rng6, int max_plan_len, int32_t *plans, int32_t *plan_len, double *root_lower,
-                       double *root_upper, int64_t *env_steps, int32_t *status /* [n_roots] */, int n_threads)
+                       double *root_upper, int64_t *env_steps, int32_t *status /* [n_roots] */, int n_threads,
+                       const uint8_t *avail)
 {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
     for (int i = 0; i < n_roots; ++i) {
@@ -656,7 +734,7 @@ int orc_opd_plan_batch(int S, int A, const int64_t *T, const double *R, const ui
                               rng6 + (long)i * 6, max_plan_len, plans ? plans + (long)i * max_plan_len : NULL,
                               plan_len ? plan_len + i : NULL, root_lower ? root_lower + i : NULL,
                               root_upper ? root_upper + i : NULL, env_steps ? env_steps + i : NULL, NULL, NULL,
-                              NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+                              NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, avail, NULL, NULL);
         if (status) status[i] = rc;
     }
     return ORC_OK;

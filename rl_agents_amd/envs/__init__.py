@@ -1,3 +1,3 @@
-from .finite_mdp import FiniteMDPEnv, MDP, DeterministicMDP, StochasticMDP, SparseMDP, Discrete  # noqa: F401
+from .finite_mdp import FiniteMDPEnv, MaskedFiniteMDPEnv, MDP, DeterministicMDP, StochasticMDP, SparseMDP, Discrete  # noqa: F401
 from . import generators  # noqa: F401
 from .cartpole import CartPoleEnv  # noqa: F401

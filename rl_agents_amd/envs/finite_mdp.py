@@ -196,3 +196,26 @@ class FiniteMDPEnv(object):
         for k, v in self.__dict__.items():
             setattr(new, k, copy.deepcopy(v, memo))
         return new
+
+
+class MaskedFiniteMDPEnv(FiniteMDPEnv):
+    """A finite-MDP environment that restricts the actions available in each state, the way highway-env's
+    ``get_available_actions`` does (no lane change off the road, no speed change beyond the limits).  The reference's
+    planners query it through ``state.get_available_actions()`` (mcts.py:59-73,88-91, deterministic.py:32-35); here the
+    restriction is a table ``config["available"][S][A]`` of 0/1 flags (at least one action per state), also exposed as
+    ``env.mdp.available`` -- which is what the device planners upload as a per-state action bitmask.  Stepping an
+    unavailable action is still defined by the tables (the reference's ``random`` policy does it)."""
+
+    def configure(self, config):
+        super().configure(config)
+        avail = self.config.get("available")
+        if avail is None:
+            avail = np.ones(self.mdp.reward.shape, dtype=bool)
+        avail = np.asarray(avail).astype(bool).reshape(self.mdp.reward.shape)
+        if not avail.any(axis=1).all():
+            raise ValueError("every state needs at least one available action")
+        self.mdp.available = avail
+
+    def get_available_actions(self):
+        """Sorted list of the actions available in the current state."""
+        return [int(a) for a in np.flatnonzero(self.mdp.available[self.mdp.state])]

@@ -106,3 +106,22 @@ def random_sparse(n_states, n_actions, branching=2, seed=0, terminal_rate=0.0):
     reward = rng.random((n_states, n_actions))
     terminal = rng.random(n_states) < terminal_rate
     return dict(mode="sparse", transition=p, next=nxt, reward=reward, terminal=terminal)
+
+
+def highway_available(config):
+    """Action availability of a highway-shaped table in highway-env's style [from memory, package absent]: no
+    LANE_LEFT in the leftmost lane, no LANE_RIGHT in the rightmost, no FASTER at the top speed, no SLOWER at the lowest;
+    IDLE is always available.  -> bool [S, 5]."""
+    n_speeds, n_lanes, n_times = config["original_shape"]
+    v, l, _ = np.meshgrid(np.arange(n_speeds), np.arange(n_lanes), np.arange(n_times), indexing="ij")
+    v, l = v.ravel(), l.ravel()
+    return np.stack([l > 0, np.ones_like(l, dtype=bool), l < n_lanes - 1, v < n_speeds - 1, v > 0], axis=1)
+
+
+def random_available(n_states, n_actions, seed=0, rate=0.3):
+    """Seeded availability table: each (state, action) unavailable with probability ``rate``, at least one action
+    available in every state."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    avail = rng.random((n_states, n_actions)) >= rate
+    avail[np.arange(n_states), rng.integers(0, n_actions, size=n_states)] = True
+    return avail

@@ -79,3 +79,71 @@ def replay_state_aware_episode(z, name, plan_fn):
         assert np.array_equal(out["state_values"][seen], want[seen]), q
         assert np.all(out["state_values"][~seen] == 1 / (1 - params["gamma"])), q
         planner, rng = out["planner"], out["rng_after"]
+
+
+def bfs_children(first_child, n_children):
+    """Creation-order trees whose nodes have a variable number of (contiguous) children -> BFS permutation and the BFS
+    parent index of every node (the order make_golden_variants.keyed_tree lists a reference tree in)."""
+    order, bpar = [0], [-1]
+    i = 0
+    while i < len(order):
+        n = order[i]
+        for j in range(int(n_children[n])):
+            order.append(int(first_child[n]) + j)
+            bpar.append(i)
+        i += 1
+    return np.asarray(order), np.asarray(bpar, np.int32)
+
+
+def assert_keyed_tree_equal(z, prefix, tree, fields):
+    """Compare a creation-order tree with per-node `action` keys and `n_children` with a golden keyed BFS tree."""
+    order, bpar = bfs_children(tree["first_child"], tree["n_children"])
+    assert len(order) == len(z[prefix + "/parent"]), (len(order), len(z[prefix + "/parent"]))
+    np.testing.assert_array_equal(bpar, z[prefix + "/parent"])
+    np.testing.assert_array_equal(np.asarray(tree["action"])[order], z[prefix + "/action"])
+    for gold_name, mine in fields.items():
+        got = np.asarray(tree[mine])[order]
+        want = z[prefix + "/" + gold_name]
+        assert np.array_equal(got.astype(want.dtype), want), "tree field {} differs".format(gold_name)
+
+
+def reference_policy_lists(policy_config, available):
+    """What the reference's policy functions return, state by state, on an environment whose
+    get_available_actions() lists flatnonzero(available[s]) (mcts.py:46-97): dict(actions=[...], p=[...]).
+    Restated here for the tests only (the oracle consumes the lists; the product builds [S, A] tables of its own)."""
+    available = np.asarray(available).astype(bool)
+    n_states, n_actions = available.shape
+    actions, probs = [], []
+    for s in range(n_states):
+        av = np.flatnonzero(available[s])
+        kind = policy_config["type"]
+        if kind == "random":                                  # mcts.py:46-57: ignores availability
+            a, p = np.arange(n_actions), np.ones(n_actions) / n_actions
+        elif kind == "random_available":                      # mcts.py:59-73
+            a, p = av, np.ones(len(av)) / len(av)
+        elif kind == "preference":                            # mcts.py:75-97
+            a, p = av, np.ones(len(av)) / len(av)
+            for i in range(len(av)):
+                if av[i] == policy_config["action"]:
+                    p = np.ones(len(av)) / (len(av) - 1 + policy_config["ratio"])
+                    p[i] *= policy_config["ratio"]
+                    break
+        else:
+            raise ValueError("Unknown policy type")
+        actions.append([int(x) for x in a])
+        probs.append(np.asarray(p, dtype=np.float64))
+    return dict(actions=actions, p=probs)
+
+
+def restricted_agent_policy_lists(table, available):
+    """MCTSWithPriorPolicyAgent.agent_policy_available (mcts_with_prior.py:56-62): the prior agent's distribution
+    restricted to the available actions and renormalised with numpy's sum."""
+    available = np.asarray(available).astype(bool)
+    actions, probs = [], []
+    for s in range(available.shape[0]):
+        av = np.flatnonzero(available[s])
+        p = np.array([table[s, a] for a in av])
+        p /= np.sum(p)
+        actions.append([int(x) for x in av])
+        probs.append(p)
+    return dict(actions=actions, p=probs)
