@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 1
+#define MP_ABI_VERSION 2
 
 #define MP_OK 0
 #define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
@@ -79,6 +79,15 @@ int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *
 int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition,
                         const double *reward, const uint8_t *terminal, int32_t done_on_next, int32_t max_steps,
                         mp_model **out);
+/*
+ * Environments that restrict the actions available in a state -- state.get_available_actions(), read by
+ * DeterministicNode.expand (deterministic.py:32-35) -- as a table:
+ *   available uint8 [S,A], non-zero = action a is listed in state s; every state needs at least one (else MP_ERR_ARG).
+ * Host pointer.  Applies to the deterministic table model it is called on; mp_opd_plan then expands the available
+ * actions only.  Policies loaded earlier for the model become invalid.  (MCTS reads availability through its POLICIES,
+ * mcts.py:59-97: see mp_policy_load_listed.)
+ */
+int mp_model_set_available(mp_model *model, const uint8_t *available);
 /*
  * Dense stochastic model (value_iteration.py:54-55, robust_value_iteration.py:55-56):
  *   transition double [M,S,A,S], reward double [M,S,A], terminal uint8 [S] or NULL.
@@ -174,6 +183,18 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
  */
 typedef struct mp_policy mp_policy;
 int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, mp_policy **out);
+/*
+ * Policies over restricted action sets: random_available_policy / preference_policy (mcts.py:59-97) and
+ * agent_policy_available (mcts_with_prior.py:56-62) list, for a state, only the actions state.get_available_actions()
+ * returns; MCTSNode.expand (mcts.py:237-246) creates one child per LISTED action and the exploration term scales with
+ * len(children) = their number (mcts.py:286).
+ *   listed uint8 [S,A]: non-zero = the prior policy lists action a in state s (an action may be listed with prior
+ *   probability 0: it still gets a child); NULL = every action in every state (= mp_policy_load).  At least one action
+ *   per state.  Unlisted actions must have rollout probability 0 unless the rollout policy ignores availability
+ *   (random_policy, mcts.py:46-57) -- rollout[s,:] is simply the distribution to sample from.  |A| <= 8.
+ */
+int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout,
+                          const uint8_t *listed, mp_policy **out);
 int mp_policy_free(mp_policy *policy);
 int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const void *root_state,
                        const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
@@ -191,9 +212,10 @@ int mp_uct_reset_tree(mp_ctx *ctx);
 /* Node capacity per root of the trees currently on this ctx (array size for mp_uct_tree_export). */
 int mp_uct_tree_capacity(mp_ctx *ctx, int32_t *cap);
 /* Tree of root `root` after the last mp_uct_plan on this ctx, creation order (root = node 0, the
- * A children of an expanded node are contiguous).  Host arrays of capacity `cap` nodes. */
+ * children of an expanded node are contiguous: first_child, n_children of them -- |A|, or the number of actions a
+ * listed policy lists in the node's state).  Host arrays of capacity `cap` nodes. */
 int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
-                       int64_t *count, double *value, int32_t *first_child);
+                       int64_t *count, double *value, int32_t *first_child, int32_t *n_children);
 
 /* ---------------------------------------------------------------- OPD ----------------------- */
 /*
@@ -208,10 +230,11 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
                 double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
                 int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status,
                 int32_t mem);
-/* Tree of root `root` after the last mp_opd_plan, creation order; host arrays, capacity `cap`. */
+/* Tree of root `root` after the last mp_opd_plan, creation order (the n_children children of an expanded node are
+ * contiguous from first_child: |A|, or the available actions of its state); host arrays, capacity `cap`. */
 int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                        int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
-                       int64_t *count, int32_t *first_child);
+                       int64_t *count, int32_t *first_child, int32_t *n_children);
 
 /* ---------------------------------------------------------------- state-aware OPD ----------- */
 /*

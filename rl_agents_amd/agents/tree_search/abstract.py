@@ -190,6 +190,7 @@ class AbstractPlanner(Configurable):
 
     # -------------------------------------------------------------------------------------------------
     supports_cartpole = False
+    supports_restricted_actions = True
 
     def model_for(self, state):
         if device_model.is_cartpole(state):
@@ -199,9 +200,11 @@ class AbstractPlanner(Configurable):
         mdp = device_model.finite_mdp_of(state)
         if mdp.mode != "deterministic":
             raise TypeError("tree search on the device needs a deterministic finite MDP, got mode '{}'".format(mdp.mode))
-        if hasattr(getattr(state, "unwrapped", state), "get_available_actions"):
-            raise TypeError("environments restricting the available actions are not supported on the device")
-        return self.models.get(device_model.spec_from_mdp(mdp, max_steps=device_model.env_max_steps(state)))
+        available = device_model.available_actions_of(state, mdp)
+        if available is not None and not self.supports_restricted_actions:
+            raise NotImplementedError("this planner does not handle environments that restrict the available actions")
+        return self.models.get(device_model.spec_from_mdp(mdp, max_steps=device_model.env_max_steps(state),
+                                                          available=available))
 
     def plan(self, state, observation):
         """Plan from the current state of the environment object ``state`` (never stepped, never copied)."""

@@ -3,10 +3,21 @@
 Same class names, config keys and results as the reference; the episodes run in ``mp_uct_plan``
 (rl_agents_amd/csrc/uct.hip).  Deviations, all documented in DESIGN.md:
 * ``horizon`` given without ``episodes``: the reference raises KeyError (mcts.py:116-118,180); here
-  ``episodes = budget // horizon``;
-* ``closed_loop=True`` and environments exposing ``get_available_actions`` raise (open loop over
-  ``range(action_space.n)`` only), instead of silently running something else.
+  ``episodes = budget // horizon``.
+
+``closed_loop=True`` (mcts.py:147, MCTSNode.get_child :267-273) inserts, under every action node, one child per
+observation seen after that action.  The environments the device plans on are deterministic, so an action node only
+ever sees ONE observation, and that observation node receives exactly the updates of its action node (both lie on
+every path through either): the statistics, the generator stream and the actions of a closed-loop plan are those of
+the open-loop plan, which is what the device computes; the observation layer -- ``str(observation)`` keys in
+``plan()``'s result and in the exported tree, prior 0 -- is rebuilt on the host by replaying the actions on a copy of
+the environment.  Pinned on reference runs with ``closed_loop: true`` (tests/golden/variants.npz).
+
+Environments exposing ``get_available_actions`` (mcts.py:59-97): the policy configs become per-state tables over the
+available actions plus the table of actions the prior policy lists (``mp_policy_load_listed``): children exist for
+listed actions only and ``len(children)`` in the exploration term is their number.
 """
+import copy
 import logging
 
 import numpy as np
@@ -36,6 +47,33 @@ def policy_probabilities(policy_config, n_actions):
     raise ValueError("Unknown policy type")
 
 
+def policy_tables(policy_config, available):
+    """A prior / rollout policy config on an environment that restricts the available actions (bool ``available``
+    [S, A]) -> (probabilities [S, A], listed bool [S, A]): row s is what the reference's policy function returns in
+    state s (mcts.py:46-97), zero on the actions it does not list.  Arithmetic as there: ``ones(k) / k``,
+    ``ones(k) / (k - 1 + ratio)`` then ``*= ratio`` on the preferred action."""
+    available = np.asarray(available).astype(bool)
+    n_states, n_actions = available.shape
+    kind = policy_config["type"]
+    if kind == "random":                                          # ignores availability (mcts.py:46-57)
+        return np.ones((n_states, n_actions)) / n_actions, np.ones((n_states, n_actions), dtype=bool)
+    k = available.sum(axis=1)
+    uniform = np.where(available, (np.ones(n_states) / k)[:, None], 0.0)
+    if kind == "random_available":
+        return uniform, available
+    if kind == "preference":
+        action, ratio = policy_config["action"], policy_config.get("ratio", 2)
+        table = uniform
+        if 0 <= action < n_actions:
+            has = available[:, action]
+            base = np.ones(n_states) / (k - 1 + ratio)
+            pref = np.where(available, base[:, None], 0.0)
+            pref[:, action] = np.where(has, base * ratio, 0.0)
+            table = np.where(has[:, None], pref, uniform)
+        return table, available
+    raise ValueError("Unknown policy type")
+
+
 class MCTS(AbstractPlanner):
     """UCT planner (mcts.py:100-200) for one or many roots of one finite MDP (or closed-form CartPole)."""
     supports_cartpole = True
@@ -53,8 +91,8 @@ class MCTS(AbstractPlanner):
                                                                               self.config["gamma"])
         elif not self.config.get("episodes"):
             self.config["episodes"] = max(self.config["budget"] // self.config["horizon"], 1)
-        if self.config["closed_loop"]:
-            raise NotImplementedError("closed_loop MCTS is not available on the device planner")
+        self._closed_plan = None
+        self._restricted = {}      # id(model) -> (model, prior, rollout, listed) tables of a restricted-action env
 
     @classmethod
     def default_config(cls):
@@ -71,6 +109,10 @@ class MCTS(AbstractPlanner):
     def step_by_subtree(self, action):
         """Tree reuse: the device re-roots the kept trees at the start of the next plan, provided the trees on the
         context are still this planner's (nothing else planned in between); otherwise the tree is reset."""
+        if self.config["closed_loop"]:
+            # the reference re-roots at the ACTION node, whose children are keyed by observation strings: its next
+            # run() would step the environment with such a key (abstract.py:195-206 + mcts.py:143-146)
+            raise NotImplementedError("step_strategy 'subtree' does not work on closed-loop trees (in the reference either)")
         ctx = self.models.ctx
         if self.last is None or getattr(ctx, "_uct_tree_owner", None) is not self:
             self.step_by_reset()
@@ -92,11 +134,16 @@ class MCTS(AbstractPlanner):
             ctx.uct_step_tree(keep_actions)
         else:
             ctx.uct_reset_tree()
-        if self.policy_source is not None:
-            prior, rollout = self.policy_source(state, model)
+        available = getattr(model, "available", None)
+        if self.policy_source is not None or available is not None:
+            if self.policy_source is not None:
+                prior, rollout = self.policy_source(state, model)      # (restricted to the available actions there)
+                listed = available
+            else:
+                prior, rollout, listed = self.restricted_policy_tables(model, available)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
                                None, None, rng_states, root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1),
-                               policy=self.device_policy(model, prior, rollout))
+                               policy=self.device_policy(model, prior, rollout, listed))
             self._last_tables = (np.asarray(device_model.finite_mdp_of(state).transition), prior,
                                  np.asarray(root_states, dtype=np.int64))
         else:
@@ -106,23 +153,97 @@ class MCTS(AbstractPlanner):
                                root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1))
             self._last_tables = None
         out["rng_states"] = rng_states
-        self.last, self._root, self._last_actions = out, None, model.A
+        self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
         ctx._uct_tree_owner = self
         self.env_steps += int(out["env_steps"].sum())
         return out
 
-    def device_policy(self, model, prior, rollout):
+    def restricted_policy_tables(self, model, available):
+        """(prior, rollout, listed) tables of this planner's policy configs on a restricted-action model, kept per model."""
+        hit = self._restricted.get(id(model))
+        if hit is None or hit[0] is not model:
+            prior, listed = policy_tables(self.prior_policy, available)
+            rollout, _ = policy_tables(self.rollout_policy, available)
+            if len(self._restricted) >= 4:
+                self._restricted.clear()
+            hit = self._restricted[id(model)] = (model, prior, rollout, listed)
+        return hit[1], hit[2], hit[3]
+
+    def device_policy(self, model, prior, rollout, listed=None):
         """Upload (once per model and table contents) the per-state policy tables."""
         key = (id(model), id(prior), id(rollout))
         hit = self._policies.get(key)
         if hit is None or hit[0] is not model or hit[1] is not prior or hit[2] is not rollout:
             if len(self._policies) >= 4:
                 self._policies.clear()
-            hit = (model, prior, rollout, self.models.ctx.load_policy(model, prior, rollout))
+            hit = (model, prior, rollout, self.models.ctx.load_policy(model, prior, rollout, listed=listed))
             self._policies[key] = hit
         return hit[3]
 
+    # -- closed loop: the observation-keyed layer, rebuilt on the host (see the module docstring) ----------------
+    def plan(self, state, observation):
+        actions = super(MCTS, self).plan(state, observation)
+        self._closed_plan = None
+        if self.config["closed_loop"]:
+            self._closed_plan = self._with_observation_keys(state, actions)
+            return list(self._closed_plan)
+        return actions
+
+    def get_plan(self):
+        if self.config["closed_loop"] and self._closed_plan is not None:
+            return list(self._closed_plan)
+        return super(MCTS, self).get_plan()
+
+    def _with_observation_keys(self, state, actions):
+        """[a0, a1, ...] -> [a0, str(obs1), a1, str(obs2), ...] as AbstractPlanner.get_plan walks a closed-loop tree
+        (abstract.py:143-156): the key of an action node's child is the observation that followed the action; the last
+        action is followed by one only if its node was visited (an unvisited action node has no child yet)."""
+        if not actions:
+            return []
+        tree = self.models.ctx.uct_tree(0)
+        node = 0
+        for a in actions:       # creation-order arrays: children of `node` are contiguous from first_child
+            fc, k = int(tree["first_child"][node]), int(tree["n_children"][node])
+            node = next(fc + j for j in range(k) if int(tree["action"][fc + j]) == a)
+        last_visited = int(tree["count"][node]) > 0
+        env = copy.deepcopy(getattr(state, "unwrapped", state))     # never the live environment
+        out = []
+        for i, a in enumerate(actions):
+            out.append(a)
+            if i + 1 < len(actions) or last_visited:
+                out.append(str(env.step(a)[0]))
+        return out
+
     def export_tree(self, root=0):
+        tree = self._export_open_loop(root)
+        if self.config["closed_loop"]:
+            self._insert_observation_nodes(tree, root)
+        return tree
+
+    def _insert_observation_nodes(self, tree, root):
+        """Closed loop: every visited action node gets its single observation child (key str(observation), prior 0,
+        the action node's own statistics -- both are updated by exactly the same episodes) holding the action node's
+        children (mcts.py:267-273)."""
+        from rl_agents_amd.agents.tree_search.abstract import Node
+        env0 = getattr(self, "_last_env", None)
+        if env0 is None:
+            raise RuntimeError("closed-loop tree export needs the environment of the last plan")
+        stack = [(tree, copy.deepcopy(getattr(env0, "unwrapped", env0)))]
+        while stack:
+            node, env = stack.pop()
+            for action, child in list(node.children.items()):
+                if child.count <= 0:
+                    continue
+                e = copy.deepcopy(env)
+                observation = e.step(action)[0]
+                obs_node = Node(child, str(observation), child.count, child.value, child.depth)
+                obs_node.prior = 0
+                obs_node.children, child.children = child.children, {str(observation): obs_node}
+                for grandchild in obs_node.children.values():
+                    grandchild.parent = obs_node
+                stack.append((obs_node, e))
+
+    def _export_open_loop(self, root=0):
         arrays = self.models.ctx.uct_tree(root)
         if self._last_tables is None:
             return build_tree(arrays, "value", prior=policy_probabilities(self.prior_policy, self._last_actions))

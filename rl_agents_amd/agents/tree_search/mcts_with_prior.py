@@ -63,6 +63,16 @@ class MCTSWithPriorPolicyAgent(MCTSAgent):
         """(prior, rollout) tables for the model behind ``state``: one distribution serves both (:31-32)."""
         self.prior_agent.env = state                    # "reset prior agent environment" (:49)
         table = tabulate_prior_agent(self.prior_agent, model.S, model.A)
+        available = getattr(model, "available", None)
+        if available is not None:
+            # agent_policy_available (:56-62): the distribution over the available actions, renormalised by numpy's sum
+            restricted = np.zeros_like(table)
+            for s in range(model.S):
+                av = np.flatnonzero(available[s])
+                p = np.array([table[s, a] for a in av])
+                p /= np.sum(p)
+                restricted[s, av] = p
+            table = restricted
         key = hashlib.sha1(table.tobytes()).hexdigest()
         return self._tables.setdefault(key, table), self._tables[key]
 

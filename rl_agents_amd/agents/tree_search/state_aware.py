@@ -21,6 +21,7 @@ logger = logging.getLogger(__name__)
 class StateAwarePlanner(OptimisticDeterministicPlanner):
     """State-aware planner (state_aware.py:70-127) for one or many independent planners of one finite MDP."""
     carries_state = True    # per-slot state on the device: callers keep the batch composition fixed
+    supports_restricted_actions = False
 
     def __init__(self, env, config=None):
         super(StateAwarePlanner, self).__init__(env, config)

@@ -78,14 +78,14 @@ int kernels_end(mp_ctx *ctx, int n_launches)
 
 // packs T/R/terminal of model 0 into 16-byte records
 __global__ void pack_records(int S, int A, const int32_t *__restrict__ T, const double *__restrict__ R,
-                             const uint8_t *__restrict__ term, Rec *__restrict__ rec)
+                             const uint8_t *__restrict__ term, const uint8_t *__restrict__ avail, Rec *__restrict__ rec)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)S * A) return;
     const int s = (int)(i / A);
     Rec r;
     r.next = T[i];
-    r.flags = (term && term[s] ? 1u : 0u) | (term && term[r.next] ? 2u : 0u);
+    r.flags = (term && term[s] ? 1u : 0u) | (term && term[r.next] ? 2u : 0u) | (!avail || avail[i] ? 4u : 0u);
     r.reward = R[i];
     rec[i] = r;
 }
@@ -233,7 +233,7 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
         return bail(fail(MP_ERR_HIP, "mp_model_load_table: upload failed"));
     const long sa = (long)S * A;
     hipLaunchKernelGGL(pack_records, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T, m->R,
-                       m->term, m->rec);
+                       m->term, (const uint8_t *)nullptr, m->rec);
     if (S < 32768) {
         if (hipMalloc(&m->t16, (((size_t)sa * 2 + 15) & ~(size_t)15) + 16) != hipSuccess)
             return bail(fail(MP_ERR_ALLOC, "mp_model_load_table: hipMalloc failed"));
@@ -242,6 +242,30 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(MP_ERR_HIP, "pack_records failed"));
     *out = m;
+    return MP_OK;
+}
+
+int mp_model_set_available(mp_model *m, const uint8_t *available)
+{
+    if (!m || !available) return fail(MP_ERR_ARG, "mp_model_set_available: NULL argument");
+    if (m->mode != MP_MODE_DETERMINISTIC || !m->rec) return fail(MP_ERR_MODE, "mp_model_set_available: deterministic table models only");
+    mp_ctx *ctx = m->ctx;
+    const int S = m->S, A = m->A;
+    for (int s = 0; s < S; ++s) {
+        bool any = false;
+        for (int a = 0; a < A; ++a) any |= available[(size_t)s * A + a] != 0;
+        if (!any) return fail(MP_ERR_ARG, "mp_model_set_available: state %d has no available action", s);
+    }
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    if (!m->avail && hipMalloc(&m->avail, (size_t)S * A) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_model_set_available: hipMalloc failed");
+    MP_HIP(hipMemcpy(m->avail, available, (size_t)S * A, hipMemcpyHostToDevice));
+    const long sa = (long)S * A;
+    hipLaunchKernelGGL(pack_records, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T, m->R, m->term,
+                       (const uint8_t *)m->avail, m->rec);
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    m->masked = true;
+    m->serial = mp::next_model_serial(); // policies fused from the old records no longer belong to this model
     return MP_OK;
 }
 
@@ -333,6 +357,7 @@ int mp_model_free(mp_model *m)
     if (m->T) hipFree(m->T);
     if (m->rec) hipFree(m->rec);
     if (m->t16) hipFree(m->t16);
+    if (m->avail) hipFree(m->avail);
     if (m->NXT) hipFree(m->NXT);
     delete m;
     return MP_OK;

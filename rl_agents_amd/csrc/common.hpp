@@ -36,7 +36,8 @@ int fail(int code, const char *fmt, ...);
 // a single 16-byte gather (replaces the reference's env.step on a deep-copied env object).
 struct alignas(16) Rec {
     int32_t next;   // transition[s, a]
-    uint32_t flags; // bit0 = terminal[s] (state acted from), bit1 = terminal[next]
+    uint32_t flags; // bit0 = terminal[s] (state acted from), bit1 = terminal[next], bit2 = action available in s
+                    // (fused policy records, mp_policy: bits 8-15 = actions the prior policy lists in `next`, 16-23 = in s)
     double reward;  // reward[s, a]
 };
 static_assert(sizeof(Rec) == 16, "Rec must be one dwordx4");
@@ -100,6 +101,8 @@ struct mp_model {
     int mode = 0, M = 1, S = 0, A = 0, B = 0;
     int Sc = 0; // dense models: number of next-state columns (= S, or the full |S| for a block of rows)
     int done_on_next = 0, max_steps = 0;
+    bool masked = false;     // mp_model_set_available restricted the action sets (state.get_available_actions())
+    uint8_t *avail = nullptr; // device [S*A] flags, only when masked
     // deterministic tables, device, [M,S,A]
     int32_t *T = nullptr;
     double *R = nullptr;
@@ -122,6 +125,7 @@ struct mp_policy {
     int stride = 0;             // doubles per row of prior / thr: A rounded up to even (16-byte rows)
     int frq = 0;                // 16-byte chunks per fused record: 1 + ceil((A-1)/4)
     int shift = 21;             // fused thresholds keep thr >> shift (saturated to 32 bits; 43 and 10 bits when packed)
+    int listed = 0;             // 1: the prior policy lists a subset of the actions per state (masks in the fused records)
     int packed = 0;             // 1: frec16 holds 16-byte records {next:20|th0:10, flags:2|th1:10|th2:10|th3:10, reward}
     uint4 *frec16 = nullptr;    // [S*A]
     double *prior = nullptr;    // [S][stride]  prior[s][a]

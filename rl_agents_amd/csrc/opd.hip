@@ -111,6 +111,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     }
     __syncthreads();
     int n_nodes = 1;
+    int n_real = 0; // children of available actions = planner.step calls (deterministic.py:41)
     int status = MP_OK;
     int k_done = 0;
     // best leaf of this lane's class (ids == lane mod 64); -inf / INT_MAX when the class has no leaf
@@ -160,12 +161,17 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
                      tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
         const int g = n_nodes; // first child
-        bool bad = false;
+        bool bad = false, avail = false;
         double Uc_mine = 0.0;
         if (lane < A) {
             const Rec rc = p.rec[(long)pn.state * A + lane];
             const double r = rc.reward;
-            bad = !(0.0 <= r) || !(r <= 1.0); // deterministic.py:46-47
+            // deterministic.py:32-35: only the actions state.get_available_actions() lists get a child.  The slot of
+            // an unavailable action stays in the id space (ids advance by |A| per expansion in every root) as a
+            // PHANTOM with L = U = -inf: never the best leaf, never a maximum of a backup, never a tie of the plan;
+            // the tree export drops it.
+            avail = (rc.flags & 4u) != 0;
+            bad = avail && (!(0.0 <= r) || !(r <= 1.0)); // deterministic.py:46-47
             const bool dn = (rc.flags & done_bit) != 0;
             // deterministic.py:45-65 update()
             double Lc = pn.L + g1d * r;
@@ -174,6 +180,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 const double nv = Lc + tdivd;
                 Lc = nv; Uc = nv;
             }
+            if (!avail) { Lc = ninf; Uc = ninf; }
             const int c = g + lane;
             OpdNode cn;
             cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
@@ -186,6 +193,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             exp_lds[k] = leaf;
         }
         n_nodes += A;
+        n_real += __popcll(__ballot(avail));
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 #endif
     if (lane == 0) {
         if (p.status) p.status[root] = status;
-        if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1);
+        if (p.env_steps) p.env_steps[root] = (int64_t)n_real;
         p.n_nodes_out[root] = n_nodes;
     }
     if (EXPG) {
@@ -415,7 +423,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
 
 int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                        int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
-                       int64_t *count, int32_t *first_child)
+                       int64_t *count, int32_t *first_child, int32_t *n_children)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
     if (ctx->tree.kind != 2) return fail(MP_ERR_ARG, "mp_opd_tree_export: no OPD tree on this ctx");
@@ -426,58 +434,72 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
     const int32_t *d_exp = (const int32_t *)ctx->ws[WS_TREE7].p;
     int32_t n = 0;
     MP_HIP(hipMemcpy(&n, d_exp + (size_t)NR * (K > 0 ? K : 1) + root, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (n > cap) return fail(MP_ERR_ARG, "mp_opd_tree_export: capacity %d < %d nodes", cap, n);
     const long base = (long)root * tcap;
     auto pull = [&](void *dst, int slot, size_t elt) -> int {
-        if (!dst) return MP_OK;
         MP_HIP(hipMemcpy(dst, (const char *)ctx->ws[slot].p + base * elt, (size_t)n * elt, hipMemcpyDeviceToHost));
         return MP_OK;
     };
     std::vector<int32_t> fc((size_t)n, -1), exp((size_t)(K > 0 ? K : 1));
     MP_HIP(hipMemcpy(exp.data(), d_exp + (size_t)root * (K > 0 ? K : 1), (size_t)(K > 0 ? K : 1) * sizeof(int32_t),
                      hipMemcpyDeviceToHost));
-    // the k-th expansion created nodes 1 + kA .. 1 + kA + A - 1 under exp[k]
+    // the k-th expansion created node slots 1 + kA .. 1 + kA + A - 1 under exp[k]
     for (int k = 0; k < K && 1 + (k + 1) * A <= n; ++k)
         if (exp[k] >= 0 && exp[k] < n) fc[exp[k]] = 1 + k * A;
-    MP_TRY(pull(upper, WS_TREE1, sizeof(double)));
-    MP_TRY(pull(reward, WS_TREE2, sizeof(double)));
-    {
-        std::vector<OpdNode> na((size_t)n);
-        MP_TRY(pull(na.data(), WS_TREE0, sizeof(OpdNode)));
-        for (int i = 0; i < n; ++i) {
-            if (lower) lower[i] = na[i].L;
-            if (state) state[i] = na[i].state;
-            if (depth) depth[i] = na[i].depth & ((1 << 30) - 1);
-            if (done) done[i] = (uint8_t)((na[i].depth >> 30) & 1);
-        }
-    }
+    std::vector<double> up((size_t)n), rw((size_t)n);
+    std::vector<OpdNode> na((size_t)n);
+    MP_TRY(pull(up.data(), WS_TREE1, sizeof(double)));
+    MP_TRY(pull(rw.data(), WS_TREE2, sizeof(double)));
+    MP_TRY(pull(na.data(), WS_TREE0, sizeof(OpdNode)));
     std::vector<int32_t> par((size_t)n);
     par[0] = -1;
     for (int i = 1; i < n; ++i) par[i] = exp[(i - 1) / A];
-    if (upper) {
-        // the kernel stores leaf upper bounds only (-inf marks an expanded node): U[n] = max over children,
-        // bottom-up in reverse creation order (children have larger ids than their parent)
-        for (int i = n - 1; i >= 0; --i)
-            if (fc[i] >= 0) {
-                double m = upper[fc[i]];
-                for (int a = 1; a < A; ++a)
-                    if (upper[fc[i] + a] > m) m = upper[fc[i] + a];
-                upper[i] = m;
-            }
+    // the kernel stores leaf upper bounds only (-inf marks an expanded node): U[n] = max over children,
+    // bottom-up in reverse creation order (children have larger ids than their parent)
+    for (int i = n - 1; i >= 0; --i)
+        if (fc[i] >= 0) {
+            double m = up[fc[i]];
+            for (int a = 1; a < A; ++a)
+                if (up[fc[i] + a] > m) m = up[fc[i] + a];
+            up[i] = m;
+        }
+    // slots of unavailable actions (deterministic.py:32-35) are phantoms with L = -inf: not nodes of the tree
+    std::vector<int32_t> id((size_t)n, -1);
+    int kept = 0;
+    for (int i = 0; i < n; ++i)
+        if (!(na[i].L == -INFINITY)) id[i] = kept++;
+    if (kept > cap) return fail(MP_ERR_ARG, "mp_opd_tree_export: capacity %d < %d nodes", cap, kept);
+    // deterministic.py:62-63: every node on the root..child sequence gets +1 per created child;
+    // count = 1 (initial) + size of own subtree for non-root nodes, root: 1 + #descendants
+    std::vector<int64_t> sz((size_t)n, 0);
+    for (int i = n - 1; i >= 0; --i) {
+        if (id[i] < 0) continue;
+        sz[i] += 1;
+        if (i > 0) sz[par[i]] += sz[i];
     }
-    if (first_child) memcpy(first_child, fc.data(), (size_t)n * sizeof(int32_t));
     for (int i = 0; i < n; ++i) {
-        if (parent) parent[i] = par[i];
-        if (action) action[i] = i == 0 ? -1 : (i - 1) % A;
+        if (id[i] < 0) continue;
+        const int o = id[i];
+        if (lower) lower[o] = na[i].L;
+        if (state) state[o] = na[i].state;
+        if (depth) depth[o] = na[i].depth & ((1 << 30) - 1);
+        if (done) done[o] = (uint8_t)((na[i].depth >> 30) & 1);
+        if (upper) upper[o] = up[i];
+        if (reward) reward[o] = rw[i];
+        if (parent) parent[o] = i == 0 ? -1 : id[par[i]];
+        if (action) action[o] = i == 0 ? -1 : (i - 1) % A;
+        if (count) count[o] = i == 0 ? sz[0] : 1 + sz[i];
+        int first = -1, nc = 0;
+        if (fc[i] >= 0)
+            for (int a = 0; a < A; ++a) {
+                const int c = id[fc[i] + a];
+                if (c < 0) continue;
+                if (first < 0) first = c;
+                ++nc;
+            }
+        if (first_child) first_child[o] = first;
+        if (n_children) n_children[o] = nc;
     }
-    if (count) {
-        // deterministic.py:62-63: every node on the root..child sequence gets +1 per created child;
-        // count = 1 (initial) + size of own subtree for non-root nodes, root: 1 + #descendants
-        std::vector<int64_t> sz((size_t)n, 1);
-        for (int i = n - 1; i >= 1; --i) sz[par[i]] += sz[i];
-        for (int i = 0; i < n; ++i) count[i] = i == 0 ? sz[0] : 1 + sz[i];
-    }
-    if (n_nodes) *n_nodes = n;
+    if (n_nodes) *n_nodes = kept;
     return MP_OK;
 }
 

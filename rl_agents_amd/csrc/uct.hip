@@ -66,6 +66,7 @@ struct UctArgs {
     uint32_t pol_sat;        // 2^32 - 1, or 1023 for the packed 16-byte records
     int pol_packed;          // 1: 16-byte records {next:20 | th0:10, flags:2 | th1:10 | th2:10 | th3:10, reward f64}
     double TA;               // temperature * |A|  (mcts.py:286, left to right)
+    double temperature;      // listed policies: the factor is temperature * len(children) of the node being scored
     uint64_t *rng;
     UctNode *tree;
     const int32_t *n_nodes_in; // kept (re-rooted) tree sizes, nullptr = every root starts fresh
@@ -111,10 +112,16 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 // record followed by the sampling thresholds of the state it leads to -- so the per-step dependency chain stays one
 // gather long.  The fused thresholds are the top 32 of the 53 bits: they decide the draw unless one of them equals
 // the draw's top 32 bits (probability ~|A| * 2^-32 per step), in which case the exact 53-bit row is fetched.
-template <int AT, int ENV, bool SP = false>
+// MK (with SP): the prior policy lists only a subset of the actions per state (restricted action sets, mcts.py:59-97).  An
+// expansion still appends |A| node slots so that ids stay lock-step across lanes, but the slots of unlisted actions are
+// PHANTOMS (count = -1): never scored, never visited, dropped by the tree export.  The listed-action masks of the state
+// reached / acted from ride in bits 8-15 / 16-23 of the fused records' flags word, so the descent always knows the mask
+// of the state it is in without another gather; len(children) in the exploration term is the mask's population count.
+template <int AT, int ENV, bool SP = false, bool MK = false>
 __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_LDS ? 1 : MP_UCT_MIN_WAVES) void uct_kernel(UctArgs p)
 {
     static_assert(!SP || (AT > 0 && ENV == ENV_TABLE), "per-state policies: table env, |A| known at compile time");
+    static_assert(!MK || SP, "listed policies are per-state policies");
     constexpr int NTH = AT > 1 ? AT - 1 : 1; // thresholds that can be reached (the last one is 2^53: never)
     constexpr int NQ = (NTH + 1) / 2;        // 16-byte chunks of a row of exact (uint64) thresholds
     constexpr int NQ32 = (NTH + 3) / 4;      // 16-byte chunks of the fused record's 32-bit thresholds
@@ -196,8 +203,11 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
         }
     }
     double tp0[AR]; // SP: temperature * |A| * prior[s0][a], the root's children
+    uint32_t mask0 = 0xffu; // MK: actions the prior policy lists in the root state
+    if (MK) mask0 = (p.pol_frec[(size_t)((unsigned)s0 * A) * (1 + NQ32)].y >> 16) & 0xffu;
+    const double TA0 = MK ? p.temperature * (double)__popc(mask0) : p.TA;
 #pragma unroll
-    for (int a = 0; a < AR; ++a) tp0[a] = SP ? p.TA * p.pol_prior[(long)s0 * p.pol_stride + a] : 0.0;
+    for (int a = 0; a < AR; ++a) tp0[a] = SP ? TA0 * p.pol_prior[(long)s0 * p.pol_stride + a] : 0.0;
     int steps_taken = 0;
     // statistics of the path nodes at depths 2..5 as read by the selection of this episode (nobody else writes
     // them in between): the backup then needs no read for them (~16 % of the saturated kernel's time was those reads)
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
         bool terminal = false;
         bool cur_term = root_term; // terminal[s] of the state the next action is taken from
         double total = 0.0;
+        uint32_t cur_mask = mask0; // MK: listed actions of the state the descent is in
         path[lane] = 0;
         int fc = RC ? tf0 : tree[0].first_child;
         // ---- selection, mcts.py:143-149
@@ -247,11 +258,15 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                         for (int a = 0; a < AR; ++a) tpl[a] = tp0[a];
                     } else {
                         const double *pr = p.pol_prior + (long)s * p.pol_stride;
+                        const double TAk = MK ? p.temperature * (double)__popc(cur_mask) : p.TA;
 #pragma unroll
-                        for (int a = 0; a < AR; ++a) tpl[a] = p.TA * pr[a];
+                        for (int a = 0; a < AR; ++a) tpl[a] = TAk * pr[a];
                     }
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) sc[a] = c[a].value + tpl[a] / (double)(c[a].count + 1);
+                    for (int a = 0; a < AR; ++a) {
+                        sc[a] = c[a].value + tpl[a] / (double)(c[a].count + 1);
+                        if (MK && c[a].count < 0) sc[a] = -INFINITY; // phantom slot: not a child
+                    }
                 } else {
 #pragma unroll
                     for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
@@ -311,6 +326,12 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                 terminal = p.done_on_next ? next_term : cur_term;
                 cur_term = next_term;
                 s = (int32_t)(e & 0x7fffu);
+            } else if (MK) {
+                const uint4 q0 = p.pol_frec[(size_t)idx * (1 + NQ32)]; // the (s, a) record with the policy's masks
+                terminal = (q0.y & done_bit) != 0;
+                reward = __hiloint2double((int)q0.w, (int)q0.z);
+                s = (int32_t)q0.x;
+                cur_mask = (q0.y >> 8) & 0xffu;
             } else {
                 const Rec rc = rec[idx];
                 terminal = (rc.flags & done_bit) != 0;
@@ -340,7 +361,17 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
             } else {
                 tree[node].first_child = n_nodes;
             }
-            if (!(RC && node == 0)) // the root's children were zero-initialised in registers
+            if (MK) {
+                if (node == 0) {
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) tc[a] = (cur_mask >> a) & 1u ? 0 : -1;
+                } else {
+                    for (int a = 0; a < A; ++a) {
+                        n.count = (cur_mask >> a) & 1u ? 0 : -1;
+                        tree[n_nodes + a] = n;
+                    }
+                }
+            } else if (!(RC && node == 0)) // the root's children were zero-initialised in registers
                 for (int a = 0; a < A; ++a) tree[n_nodes + a] = n;
             n_nodes += A;
         }
@@ -562,7 +593,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
     if (p.env_steps) p.env_steps[r] = (int64_t)steps_taken;
     const int rfc = tree[0].first_child;
     for (int a = 0; a < A; ++a) {
-        if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? tree[rfc + a].count : 0;
+        if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? max(tree[rfc + a].count, 0) : 0;
         if (p.root_child_value) p.root_child_value[(long)r * A + a] = rfc >= 0 ? tree[rfc + a].value : 0.0;
     }
 }
@@ -580,7 +611,8 @@ __global__ __launch_bounds__(64) void uct_reroot_kernel(int n_roots, int A, int 
     const UctNode *o = old_trees + (long)r * cap_old;
     UctNode *n = new_trees + (long)r * cap_new;
     const int a = actions[r];
-    if (n_old[r] < 1 || o[0].first_child < 0 || a < 0 || a >= A) {
+    // `if action in self.root.children` (abstract.py:201): an unlisted action has a phantom slot, not a child
+    if (n_old[r] < 1 || o[0].first_child < 0 || a < 0 || a >= A || o[o[0].first_child + a].count < 0) {
         n_new[r] = 0;
         return;
     }
@@ -620,11 +652,13 @@ static int uct_lanes_per_wave()
 }
 
 template <int AT>
-static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp)
+static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed)
 {
     const int roots_per_block = a.waves * a.lanes;
     const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
-    if (sp) {
+    if (sp && listed) {
+        if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true>), grid, block, lds, st, a);
+    } else if (sp) {
         if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true>), grid, block, lds, st, a);
     } else if (ldsm) {
         if (lds > 64 * 1024)
@@ -654,6 +688,9 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         return fail(MP_ERR_ARG, "mp_uct_plan_policy: the policy was not loaded for this model");
     if (model->mode != MP_MODE_DETERMINISTIC && !cart)
         return fail(MP_ERR_MODE, "mp_uct_plan: model mode %d is neither a deterministic table nor CartPole", model->mode);
+    if (model->masked && !(pol && pol->listed))
+        return fail(MP_ERR_ARG, "mp_uct_plan: the model restricts its action sets (mp_model_set_available): MCTS reads "
+                                "availability through its policies -- plan with a policy from mp_policy_load_listed");
     if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
         return fail(MP_ERR_ARG, "mp_uct_plan: bad sizes (n_roots=%d episodes=%d horizon=%d)", n_roots, episodes, horizon);
     const int A = model->A, H = horizon, E = episodes;
@@ -701,11 +738,14 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // 16-byte records for saturated batches (see mp_policy_load)
     bool use16 = pol && pol->packed && n_roots > 16384;
     if (const char *rf = getenv("MP_UCT_POLICY_RECORD")) use16 = pol && pol->packed && rf[0] == 'p' ? true : (rf[0] == 'f' ? false : use16);
+    const bool listed = pol && pol->listed;
+    if (listed) use16 = false; // the listed-action masks live in the fused records' flags word
     a.pol_shift = pol ? (use16 ? 43 : pol->shift) : 21;
     a.pol_sat = use16 ? 1023u : 0xffffffffu;
     a.pol_packed = use16 ? 1 : 0;
     if (use16) a.pol_frec = pol->frec16;
     a.TA = temperature * (double)A;
+    a.temperature = temperature;
 
     // variant and geometry
     // Measured on MI355X (highway table, 4096 roots): global-record variant 0.338 ms, LDS-table variant 0.376 ms --
@@ -778,15 +818,15 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, st, a);
     } else
     switch (A) {
-    case 2: MP_TRY(uct_launch<2>(a, ldsm, lds, st, pol != nullptr)); break;
-    case 3: MP_TRY(uct_launch<3>(a, ldsm, lds, st, pol != nullptr)); break;
-    case 4: MP_TRY(uct_launch<4>(a, ldsm, lds, st, pol != nullptr)); break;
-    case 5: MP_TRY(uct_launch<5>(a, ldsm, lds, st, pol != nullptr)); break;
-    case 6: MP_TRY(uct_launch<6>(a, ldsm, lds, st, pol != nullptr)); break;
-    case 8: MP_TRY(uct_launch<8>(a, ldsm, lds, st, pol != nullptr)); break;
+    case 2: MP_TRY(uct_launch<2>(a, ldsm, lds, st, pol != nullptr, listed)); break;
+    case 3: MP_TRY(uct_launch<3>(a, ldsm, lds, st, pol != nullptr, listed)); break;
+    case 4: MP_TRY(uct_launch<4>(a, ldsm, lds, st, pol != nullptr, listed)); break;
+    case 5: MP_TRY(uct_launch<5>(a, ldsm, lds, st, pol != nullptr, listed)); break;
+    case 6: MP_TRY(uct_launch<6>(a, ldsm, lds, st, pol != nullptr, listed)); break;
+    case 8: MP_TRY(uct_launch<8>(a, ldsm, lds, st, pol != nullptr, listed)); break;
     default:
         if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
-        MP_TRY(uct_launch<0>(a, ldsm, lds, st, false));
+        MP_TRY(uct_launch<0>(a, ldsm, lds, st, false, false));
         break;
     }
     MP_TRY(kernels_end(ctx, 1));
@@ -831,6 +871,12 @@ int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t 
 // (computed exactly as mp_uct_plan computes them for one distribution), plus one fused record per (s, a).
 int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, mp_policy **out)
 {
+    return mp_policy_load_listed(ctx, model, prior, rollout, nullptr, out);
+}
+
+int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, const uint8_t *listed,
+                          mp_policy **out)
+{
     if (!ctx || !model || !prior || !rollout || !out) return fail(MP_ERR_ARG, "mp_policy_load: NULL argument");
     if (model->mode != MP_MODE_DETERMINISTIC || !model->rec)
         return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a deterministic table model");
@@ -868,13 +914,22 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
     // record formats: always 32 / 48 bytes with 32 coarse bits per threshold; when |A| <= 5 and S <= 2^20 also 16 bytes
     // (10 coarse bits per threshold in the spare bits of next and flags), which saturated batches use (one gather per
     // rollout step instead of two: +5-9 % there, -5 % on a lone wave).  MP_UCT_POLICY_RECORD=fused / packed forces one.
-    const bool can_pack = A <= 5 && S <= (1 << 20) && !getenv("MP_UCT_COARSE_BITS");
+    const bool can_pack = A <= 5 && S <= (1 << 20) && !getenv("MP_UCT_COARSE_BITS") && !listed;
+    std::vector<uint32_t> lmask((size_t)S, (1u << A) - 1u); // actions the prior policy lists per state
+    if (listed)
+        for (int s = 0; s < S; ++s) {
+            uint32_t m = 0;
+            for (int a = 0; a < A; ++a) m |= (listed[(size_t)s * A + a] ? 1u : 0u) << a;
+            if (!m) return fail(MP_ERR_ARG, "mp_policy_load_listed: the prior policy lists no action in state %d", s);
+            lmask[(size_t)s] = m;
+        }
     std::vector<uint32_t> hf((size_t)S * A * frq * 4, 0xffffffffu), hp16(can_pack ? (size_t)S * A * 4 : 0);
     for (size_t i = 0; i < (size_t)S * A; ++i) {
         uint32_t *f = hf.data() + i * frq * 4;
         memcpy(f, &hrec[i], sizeof(Rec));
         const int nx = hrec[i].next;
         if (nx < 0 || nx >= S) return fail(MP_ERR_ARG, "mp_policy_load: transition out of range");
+        f[1] = (hrec[i].flags & 0xffu) | (lmask[(size_t)nx] << 8) | (lmask[i / (size_t)A] << 16);
         uint32_t th[4] = {1023u, 1023u, 1023u, 1023u};
         for (int a = 0; a + 1 < A; ++a) {
             const uint64_t t53 = ht[(size_t)nx * stride + a];
@@ -891,7 +946,7 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
     }
     mp_policy *pol = new (std::nothrow) mp_policy;
     if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
-    pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift; pol->packed = can_pack ? 1 : 0;
+    pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift; pol->packed = can_pack ? 1 : 0; pol->listed = listed ? 1 : 0;
     if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
         hipMalloc(&pol->frec, hf.size() * 4) != hipSuccess ||
         (can_pack && hipMalloc(&pol->frec16, hp16.size() * 4) != hipSuccess)) {
@@ -948,7 +1003,7 @@ int mp_uct_reset_tree(mp_ctx *ctx)
 }
 
 int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
-                       int64_t *count, double *value, int32_t *first_child)
+                       int64_t *count, double *value, int32_t *first_child, int32_t *n_children)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
     if (ctx->tree.kind != 1) return fail(MP_ERR_ARG, "mp_uct_tree_export: no UCT tree on this ctx");
@@ -960,24 +1015,37 @@ int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
     MP_HIP(hipMemcpy(h.data(), (const UctNode *)ctx->ws[ctx->tree.buf ? WS_TREE2 : WS_TREE0].p + (long)root * tcap,
                      (size_t)tcap * sizeof(UctNode),
                      hipMemcpyDeviceToHost));
-    // nodes are appended A at a time; the tree in use is the closure of first_child links
+    // node slots are appended A at a time; the tree in use is the closure of first_child links.  Slots with
+    // count < 0 are the phantoms of actions a listed policy did not list (uct_kernel<.., MK>): they are not nodes.
     int n = 1;
     for (int i = 0; i < n && i < tcap; ++i)
         if (h[i].first_child >= 0 && h[i].first_child + A > n) n = h[i].first_child + A;
-    if (n > cap) return fail(MP_ERR_ARG, "mp_uct_tree_export: capacity %d < %d nodes", cap, n);
+    std::vector<int32_t> id((size_t)n, -1);
+    int kept = 0;
+    for (int i = 0; i < n; ++i)
+        if (h[i].count >= 0) id[i] = kept++;
+    if (kept > cap) return fail(MP_ERR_ARG, "mp_uct_tree_export: capacity %d < %d nodes", cap, kept);
     if (parent) parent[0] = -1;
     if (action) action[0] = -1;
     for (int i = 0; i < n; ++i) {
-        if (count) count[i] = h[i].count;
-        if (value) value[i] = h[i].value;
-        if (first_child) first_child[i] = h[i].first_child;
+        if (id[i] < 0) continue;
+        const int o = id[i];
+        if (count) count[o] = h[i].count;
+        if (value) value[o] = h[i].value;
+        int first = -1, nc = 0;
         if (h[i].first_child >= 0)
             for (int a = 0; a < A; ++a) {
-                if (parent) parent[h[i].first_child + a] = i;
-                if (action) action[h[i].first_child + a] = a;
+                const int c = id[h[i].first_child + a];
+                if (c < 0) continue;
+                if (first < 0) first = c;
+                ++nc;
+                if (parent) parent[c] = o;
+                if (action) action[c] = a;
             }
+        if (first_child) first_child[o] = first;
+        if (n_children) n_children[o] = nc;
     }
-    if (n_nodes) *n_nodes = n;
+    if (n_nodes) *n_nodes = kept;
     return MP_OK;
 }
 

@@ -12,7 +12,7 @@ A GPU kernel cannot call that, so the boundary extracts what the object *is* for
 Uploads are cached per context and keyed by a content hash of the tables, so agents that rebuild the
 MDP on every ``act`` (value_iteration.py:29-35) only pay for an upload when the tables changed.
 """
-import zlib
+import hashlib
 
 import numpy as np
 
@@ -22,7 +22,8 @@ from . import runtime
 class TableSpec(object):
     """Host-side view of a finite MDP in the reference's wire format (mode / transition / reward / terminal)."""
 
-    def __init__(self, mode, transition, reward, terminal=None, next_states=None, done_rule="source", max_steps=0):
+    def __init__(self, mode, transition, reward, terminal=None, next_states=None, done_rule="source", max_steps=0,
+                 available=None):
         self.mode = mode
         self.reward = np.ascontiguousarray(reward, dtype=np.float64)
         if mode == "deterministic":
@@ -37,6 +38,9 @@ class TableSpec(object):
                          else np.ascontiguousarray(np.asarray(terminal).reshape(n_states).astype(np.uint8)))
         self.done_rule = done_rule
         self.max_steps = int(max_steps or 0)
+        # actions state.get_available_actions() lists per state (bool [S, A]); None = no restriction
+        self.available = (None if available is None else
+                          np.ascontiguousarray(np.asarray(available).reshape(self.reward.shape[-2:]).astype(np.uint8)))
 
     @property
     def n_states(self):
@@ -47,11 +51,10 @@ class TableSpec(object):
         return self.reward.shape[-1]
 
     def key(self):
-        h = 0
-        for arr in (self.transition, self.reward, self.terminal, self.next):
-            if arr is not None:
-                h = zlib.crc32(arr.view(np.uint8).reshape(-1), h)
-        return (self.mode, self.transition.shape, self.done_rule, self.max_steps, h)
+        h = hashlib.blake2b(digest_size=16)      # a strong digest: a collision would silently serve a stale model
+        for arr in (self.transition, self.reward, self.terminal, self.next, self.available):
+            h.update(b"-" if arr is None else arr.view(np.uint8).reshape(-1))
+        return (self.mode, self.transition.shape, self.done_rule, self.max_steps, h.hexdigest())
 
 
 def finite_mdp_of(env):
@@ -66,10 +69,25 @@ def finite_mdp_of(env):
                     "conversion method called 'to_finite_mdp' to such a type.")
 
 
-def spec_from_mdp(mdp, max_steps=0):
+def spec_from_mdp(mdp, max_steps=0, available=None):
     return TableSpec(mdp.mode, mdp.transition, mdp.reward, getattr(mdp, "terminal", None),
                      next_states=getattr(mdp, "next", None) if mdp.mode == "sparse" else None,
-                     done_rule=getattr(mdp, "done_rule", "source"), max_steps=max_steps)
+                     done_rule=getattr(mdp, "done_rule", "source"), max_steps=max_steps, available=available)
+
+
+def available_actions_of(env, mdp):
+    """The action restriction of an environment exposing ``get_available_actions`` as a table bool [S, A] (None when
+    the environment has no such method).  The reference asks the env object state by state (mcts.py:59-97,
+    deterministic.py:32-35); a device planner needs the whole table, which table environments expose as
+    ``mdp.available`` (rl_agents_amd.envs.MaskedFiniteMDPEnv)."""
+    base = getattr(env, "unwrapped", env)
+    if not hasattr(base, "get_available_actions"):
+        return None
+    available = getattr(mdp, "available", None)
+    if available is None:
+        raise TypeError("the environment restricts its available actions but its finite MDP has no `available` [S, A] "
+                        "table: the device planners cannot query get_available_actions() state by state")
+    return np.asarray(available).astype(bool)
 
 
 def is_cartpole(env):
@@ -140,7 +158,7 @@ class ModelCache(object):
     def _upload(self, spec):
         if spec.mode == "deterministic":
             return self.ctx.load_table(spec.transition, spec.reward, spec.terminal, done_rule=spec.done_rule,
-                                       max_steps=spec.max_steps)
+                                       max_steps=spec.max_steps, available=spec.available)
         if spec.mode == "stochastic":
             return self.ctx.load_dense(spec.transition, spec.reward, spec.terminal)
         return self.ctx.load_sparse(spec.transition, spec.next, spec.reward, spec.terminal)

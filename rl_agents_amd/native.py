@@ -52,10 +52,12 @@ SIGNATURES = {
     "mp_uct_step_tree": (C.c_int, [_vp, c_i32, _vp, c_i32]),
     "mp_uct_reset_tree": (C.c_int, [_vp]),
     "mp_uct_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
-    "mp_uct_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp]),
+    "mp_uct_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_model_set_available": (C.c_int, [_vp, _vp]),
+    "mp_policy_load_listed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, P(_vp)]),
     "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               c_i32]),
-    "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_saopd_create": (C.c_int, [_vp, _vp, c_i32, P(_vp)]),
     "mp_saopd_free": (C.c_int, [_vp]),
     "mp_saopd_plan": (C.c_int, [_vp, _vp, _vp, c_i32, c_f64, c_f64, c_f64, c_i32, c_i32, _vp, c_i32, _vp, _vp, _vp, _vp,
@@ -103,7 +105,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 1:
+    if lib.mp_abi_version() != 2:
         raise RuntimeError("libmi355plan ABI version mismatch")
     _LIB = lib
     return lib
@@ -182,8 +184,9 @@ class Context(object):
         return ms.value, n.value
 
     # ---- models ------------------------------------------------------------------------------
-    def load_table(self, transition, reward, terminal=None, done_rule="source", max_steps=0):
-        """Deterministic tables: transition int [S,A] or [M,S,A], reward like it, terminal [S]."""
+    def load_table(self, transition, reward, terminal=None, done_rule="source", max_steps=0, available=None):
+        """Deterministic tables: transition int [S,A] or [M,S,A], reward like it, terminal [S].
+        available: bool [S,A], the actions state.get_available_actions() lists per state (None = all)."""
         t = np.ascontiguousarray(transition, dtype=np.int64)
         r = np.ascontiguousarray(reward, dtype=np.float64)
         if t.shape != r.shape or t.ndim not in (2, 3):
@@ -194,7 +197,12 @@ class Context(object):
         h = _vp()
         _check(self._lib.mp_model_load_table(self._h, m, s, a, _ptr(t), _ptr(r), _ptr(term),
                                              int(done_rule == "next"), int(max_steps or 0), C.byref(h)))
-        return Model(self, h, MODE_DETERMINISTIC, m, s, a, 0)
+        model = Model(self, h, MODE_DETERMINISTIC, m, s, a, 0)
+        if available is not None:
+            av = np.ascontiguousarray(np.asarray(available).reshape(s, a).astype(np.uint8))
+            _check(self._lib.mp_model_set_available(h, _ptr(av)))
+            model.available = av.astype(bool)
+        return model
 
     def load_dense(self, transition, reward, terminal=None):
         """Dense model: transition float [S,A,S] or [M,S,A,S] (numpy -> copied; torch cuda tensor -> borrowed)."""
@@ -301,14 +309,20 @@ class Context(object):
         _check(self._lib.mp_vi_sweeps(self._h, model._h, float(gamma), int(sweeps), int(bool(robust))))
 
     # ---- tree search -------------------------------------------------------------------------
-    def load_policy(self, model, prior, rollout):
-        """Per-state prior / rollout policies [S, A] of a table model (mcts_with_prior.py:47-62) -> Policy."""
+    def load_policy(self, model, prior, rollout, listed=None):
+        """Per-state prior / rollout policies [S, A] of a table model (mcts_with_prior.py:47-62) -> Policy.
+        listed: bool [S, A], the actions the prior policy lists per state (restricted action sets, mcts.py:59-97):
+        only those get a child at expansion; None = all."""
         pr = np.ascontiguousarray(prior, dtype=np.float64)
         ro = np.ascontiguousarray(rollout, dtype=np.float64)
         if pr.shape != (model.S, model.A) or ro.shape != (model.S, model.A):
             raise ValueError("prior / rollout must be [S, A] = [{}, {}]".format(model.S, model.A))
         h = _vp()
-        _check(self._lib.mp_policy_load(self._h, model._h, _ptr(pr), _ptr(ro), C.byref(h)))
+        if listed is None:
+            _check(self._lib.mp_policy_load(self._h, model._h, _ptr(pr), _ptr(ro), C.byref(h)))
+        else:
+            li = np.ascontiguousarray(np.asarray(listed).reshape(model.S, model.A).astype(np.uint8))
+            _check(self._lib.mp_policy_load_listed(self._h, model._h, _ptr(pr), _ptr(ro), _ptr(li), C.byref(h)))
         return Policy(self, h, model)
 
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
@@ -379,11 +393,11 @@ class Context(object):
             _check(self._lib.mp_uct_tree_capacity(self._h, C.byref(c)))
             cap = c.value
         t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), count=np.zeros(cap, np.int64),
-                 value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32))
+                 value=np.zeros(cap, np.float64), first_child=np.zeros(cap, np.int32), n_children=np.zeros(cap, np.int32))
         n = c_i32()
         _check(self._lib.mp_uct_tree_export(self._h, int(root), int(cap), C.byref(n), _ptr(t["parent"]),
                                             _ptr(t["action"]), _ptr(t["count"]), _ptr(t["value"]),
-                                            _ptr(t["first_child"])))
+                                            _ptr(t["first_child"]), _ptr(t["n_children"])))
         return {k: v[:n.value].copy() for k, v in t.items()}
 
     def opd_plan(self, model, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len=64):
@@ -413,12 +427,12 @@ class Context(object):
         t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),
                  depth=np.zeros(cap, np.int32), reward=np.zeros(cap, np.float64), lower=np.zeros(cap, np.float64),
                  upper=np.zeros(cap, np.float64), done=np.zeros(cap, np.uint8), count=np.zeros(cap, np.int64),
-                 first_child=np.zeros(cap, np.int32))
+                 first_child=np.zeros(cap, np.int32), n_children=np.zeros(cap, np.int32))
         n = c_i32()
         _check(self._lib.mp_opd_tree_export(self._h, int(root), int(cap), C.byref(n), _ptr(t["parent"]),
                                             _ptr(t["action"]), _ptr(t["state"]), _ptr(t["depth"]), _ptr(t["reward"]),
                                             _ptr(t["lower"]), _ptr(t["upper"]), _ptr(t["done"]), _ptr(t["count"]),
-                                            _ptr(t["first_child"])))
+                                            _ptr(t["first_child"]), _ptr(t["n_children"])))
         return {k: v[:n.value].copy() for k, v in t.items()}
 
 

@@ -1,0 +1,308 @@
+"""Round-2 planner variants on the device against the reference's golden vectors (tests/golden/variants.npz) and
+against the oracle on seeded batches: closed-loop MCTS, MCTS / OPD on environments that restrict the available
+actions (phantom node slots on the device, dropped by the exports)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests.helpers import (assert_keyed_tree_equal, mdp_from_golden, reference_policy_lists,
+                           restricted_agent_policy_lists)
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+UCT = "<class 'rl_agents_amd.agents.tree_search.mcts.MCTSAgent'>"
+UCTP = "<class 'rl_agents_amd.agents.tree_search.mcts_with_prior.MCTSWithPriorPolicyAgent'>"
+OPD = "<class 'rl_agents_amd.agents.tree_search.deterministic.DeterministicPlannerAgent'>"
+SAOPD = "<class 'rl_agents_amd.agents.tree_search.state_aware.StateAwarePlannerAgent'>"
+VI = "<class 'rl_agents_amd.agents.dynamic_programming.value_iteration.ValueIterationAgent'>"
+
+
+@pytest.fixture(scope="module")
+def z():
+    return np.load(os.path.join(REPO, "tests", "golden", "variants.npz"))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rl_agents_amd import native
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def names(z, group):
+    return [str(n) for n in z[group + "/names"]]
+
+
+def _env(cfg, state=0, steps=0, available=None):
+    from rl_agents_amd.envs import FiniteMDPEnv, MaskedFiniteMDPEnv
+    c = dict(mode=cfg["mode"], transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"],
+             max_steps=cfg["max_steps"], state=int(state))
+    if available is not None:
+        c["available"] = np.asarray(available)
+    env = (FiniteMDPEnv if available is None else MaskedFiniteMDPEnv)(c)
+    env.reset()
+    env.steps = int(steps)
+    return env
+
+
+def _agent_tree(root):
+    """Node objects -> keyed BFS arrays (children in dict order), as make_golden_variants.keyed_tree lists them."""
+    nodes, parents, keys, is_obs = [root], [-1], [-1], [False]
+    i = 0
+    while i < len(nodes):
+        for k, c in nodes[i].children.items():
+            nodes.append(c)
+            parents.append(i)
+            keys.append(int(k))
+            is_obs.append(isinstance(k, str))
+        i += 1
+    return dict(parent=np.asarray(parents, np.int32), action=np.asarray(keys, np.int32), is_obs=np.asarray(is_obs),
+                count=np.asarray([n.count for n in nodes], np.int64), value=np.asarray([n.get_value() for n in nodes]),
+                prior=np.asarray([float(getattr(n, "prior", np.nan)) for n in nodes]))
+
+
+def _assert_agent_tree(z, prefix, root, fields=("count", "value", "prior", "is_obs")):
+    t = _agent_tree(root)
+    np.testing.assert_array_equal(t["parent"], z[prefix + "/parent"])
+    np.testing.assert_array_equal(t["action"], z[prefix + "/action"])
+    for f in fields:
+        assert np.array_equal(t[f].astype(z[prefix + "/" + f].dtype), z[prefix + "/" + f]), f
+
+
+def _uct_cfg(z, p, **extra):
+    cfg = dict(__class__=UCT, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
+               temperature=float(z[p + "/temperature"]), horizon=int(z[p + "/horizon"]), episodes=int(z[p + "/episodes"]))
+    cfg.update(extra)
+    return cfg
+
+
+# ------------------------------------------------------------------------------------------- closed loop
+def test_closed_loop_mcts_agent_matches_reference(z):
+    """MCTSAgent with closed_loop: true (the shipped HighwayEnv/agents/MCTSAgent/closed_loop.json switch): plans with the
+    observation keys in them, trees with the observation layer, env-step counts and generator states."""
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    for name in names(z, "closed"):
+        p = "closed/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        extra = dict(closed_loop=True)
+        if "pref" in name:
+            extra.update(prior_policy={"type": "preference", "action": 1, "ratio": 3},
+                         rollout_policy={"type": "preference", "action": 1, "ratio": 3})
+        env = _env(cfg, state=int(z[p + "/s0"]), steps=int(z[p + "/steps0"]))
+        agent = agent_factory(env, _uct_cfg(z, p, **extra))
+        agent.seed(int(z[p + "/seed"]))
+        plan = agent.plan(int(z[p + "/s0"]))
+        assert [isinstance(x, str) for x in plan] == list(z[p + "/plan_is_obs"]), name
+        np.testing.assert_array_equal([int(x) for x in plan], z[p + "/plan"], err_msg=name)
+        assert plan == agent.planner.get_plan()
+        assert agent.planner.env_steps == int(z[p + "/env_steps"])
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        _assert_agent_tree(z, p + "/tree", agent.planner.root)
+        assert env.mdp.state == int(z[p + "/s0"])       # the live environment was never stepped
+    # an episode: act() after act()
+    q = "closed/episode_highway"
+    cfg = mdp_from_golden(z, q + "/mdp")
+    env = _env(cfg, state=int(z[q + "/states"][0]))
+    agent = agent_factory(env, dict(__class__=UCT, budget=300, horizon=12, episodes=25, closed_loop=True))
+    agent.seed(3)
+    for step, want in enumerate(z[q + "/first_actions"]):
+        assert env.mdp.state == int(z[q + "/states"][step])
+        a = agent.act(env.mdp.state)
+        assert a == int(want)
+        env.step(a)
+    with pytest.raises(NotImplementedError):            # closed loop + tree re-use: broken in the reference as well
+        ag = agent_factory(env, dict(__class__=UCT, budget=50, closed_loop=True, step_strategy="subtree"))
+        ag.act(env.mdp.state)
+        ag.act(env.mdp.state)
+
+
+# ------------------------------------------------------------------------------------------- restricted actions, UCT
+def _device_tables(lists, n_states, n_actions):
+    """dict(actions, p) lists -> ([S, A] probabilities with zeros on unlisted actions, listed bool [S, A])."""
+    table = np.zeros((n_states, n_actions))
+    listed = np.zeros((n_states, n_actions), bool)
+    for s in range(n_states):
+        table[s, lists["actions"][s]] = lists["p"][s]
+        listed[s, lists["actions"][s]] = True
+    return table, listed
+
+
+def test_uct_restricted_actions_c_abi_goldens(ctx, z):
+    """mp_policy_load_listed + mp_uct_plan_policy against the reference on MaskedFiniteMDPEnv-style environments."""
+    for name in names(z, "uct_masked"):
+        p = "uct_masked/" + name
+        if bool(z[p + "/closed_loop"]):
+            continue                                    # agent level (the observation layer is host-side)
+        cfg = mdp_from_golden(z, p + "/mdp")
+        s_, a_ = cfg["reward"].shape
+        avail = z[p + "/available"]
+        prior, listed = _device_tables(reference_policy_lists(json.loads(str(z[p + "/prior_policy_json"])), avail), s_, a_)
+        rollout, _ = _device_tables(reference_policy_lists(json.loads(str(z[p + "/rollout_policy_json"])), avail), s_, a_)
+        model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"], max_steps=cfg["max_steps"])
+        policy = ctx.load_policy(model, prior, rollout, listed=listed)
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        out = ctx.uct_plan(model, [int(z[p + "/s0"])], int(z[p + "/episodes"]), int(z[p + "/horizon"]),
+                           float(z[p + "/gamma"]), float(z[p + "/temperature"]), None, None, rng,
+                           max_plan_len=int(z[p + "/horizon"]), policy=policy)
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert int(out["env_steps"][0]) == int(z[p + "/env_steps"]), name
+        assert out["root_value"][0] == float(z[p + "/root_value"]), name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        assert_keyed_tree_equal(z, p + "/tree", ctx.uct_tree(0), dict(count="count", value="value"))
+        policy.close()
+        model.close()
+
+
+def test_uct_restricted_actions_agents_match_reference(z):
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    for name in names(z, "uct_masked"):
+        p = "uct_masked/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        env = _env(cfg, state=int(z[p + "/s0"]), available=z[p + "/available"])
+        agent = agent_factory(env, _uct_cfg(z, p, closed_loop=bool(z[p + "/closed_loop"]),
+                                            prior_policy=json.loads(str(z[p + "/prior_policy_json"])),
+                                            rollout_policy=json.loads(str(z[p + "/rollout_policy_json"]))))
+        agent.seed(int(z[p + "/seed"]))
+        plan = agent.plan(int(z[p + "/s0"]))
+        np.testing.assert_array_equal([int(x) for x in plan], z[p + "/plan"], err_msg=name)
+        assert [isinstance(x, str) for x in plan] == list(z[p + "/plan_is_obs"]), name
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        _assert_agent_tree(z, p + "/tree", agent.planner.root)
+    # tree re-use on a restricted-action environment
+    p = "uct_masked/subtree_highway"
+    cfg = mdp_from_golden(z, p + "/mdp")
+    env = _env(cfg, state=int(z[p + "/states"][0]), available=z[p + "/available"])
+    agent = agent_factory(env, dict(__class__=UCT, budget=300, horizon=12, episodes=25, step_strategy="subtree"))
+    agent.seed(11)
+    for step in range(int(z[p + "/n_steps"])):
+        assert env.mdp.state == int(z[p + "/states"][step])
+        plan = agent.plan(env.mdp.state)
+        q = "{}/step{}".format(p, step)
+        np.testing.assert_array_equal(plan, z[q + "/plan"], err_msg=q)
+        _assert_agent_tree(z, q + "/tree", agent.planner.root, fields=("count", "value"))
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[q + "/rng_after"])
+        env.step(plan[0])
+    # MCTSWithPriorPolicyAgent: the prior agent's distribution restricted to the available actions
+    for name in names(z, "uct_prior_masked"):
+        p = "uct_prior_masked/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        env = _env(cfg, state=int(z[p + "/s0"]), available=z[p + "/available"])
+        agent = agent_factory(env, _uct_cfg(z, p, __class__=UCTP,
+                                            prior_agent=dict(__class__=VI, gamma=float(z[p + "/prior_gamma"]),
+                                                             temperature=float(z[p + "/prior_temperature"]))))
+        assert np.array_equal(agent.prior_agent.policy_table(), z[p + "/prior_table"]), name
+        agent.seed(int(z[p + "/seed"]))
+        plan = agent.plan(int(z[p + "/s0"]))
+        np.testing.assert_array_equal(plan, z[p + "/plan"], err_msg=name)
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        _assert_agent_tree(z, p + "/tree", agent.planner.root, fields=("count", "value", "prior"))
+
+
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 8])
+def test_uct_restricted_actions_batch_vs_oracle(ctx, n_actions):
+    """300 roots per |A| specialisation: listed policies (random restrictions, preference policy that falls back where
+    its action is unavailable, a rollout policy that ignores availability) against the oracle's literal lists."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    s_ = 211
+    cfg = generators.random_deterministic(s_, n_actions, seed=70 + n_actions, terminal_rate=0.04)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    avail = generators.random_available(s_, n_actions, seed=n_actions, rate=0.4)
+    prior_l = reference_policy_lists({"type": "preference", "action": 1, "ratio": 2.5}, avail)
+    roll_l = reference_policy_lists({"type": "random"} if n_actions % 2 else {"type": "random_available"}, avail)
+    prior, listed = _device_tables(prior_l, s_, n_actions)
+    rollout, _ = _device_tables(roll_l, s_, n_actions)
+    model = ctx.load_table(t, r, term, max_steps=40)
+    policy = ctx.load_policy(model, prior, rollout, listed=listed)
+    n = 300
+    s0 = np.random.Generator(np.random.PCG64(5)).integers(0, s_, size=n).astype(np.int32)
+    g = np.random.Generator(np.random.PCG64(6))
+    rng = g.integers(0, 2 ** 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+    rng[:, 3] |= np.uint64(1)
+    rng[:, 4:] = 0
+    rng_ref = rng.copy()
+    out = ctx.uct_plan(model, s0, 30, 12, 0.9, 6.5, None, None, rng, max_plan_len=12, policy=policy)
+    ref = oracle.uct_plan_batch(t, r, term, s0, 30, 12, 0.9, 6.5, prior_l, roll_l, rng_ref, max_steps=40,
+                                max_plan_len=12, n_threads=8)
+    for k in ("plans", "plan_len", "root_child_count", "env_steps"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    assert np.array_equal(out["root_child_value"], ref["root_child_value"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    # a model carrying restrictions refuses the state-independent entry point
+    from rl_agents_amd import native
+    masked = ctx.load_table(t, r, term, available=avail)
+    with pytest.raises(native.NativeError):
+        ctx.uct_plan(masked, s0[:2], 5, 5, 0.9, 1.0, np.ones(n_actions) / n_actions, np.ones(n_actions) / n_actions, rng[:2].copy())
+    for x in (policy, model, masked):
+        x.close()
+
+
+# ------------------------------------------------------------------------------------------- restricted actions, OPD
+def test_opd_restricted_actions_goldens(ctx, z):
+    from rl_agents_amd.agents.common.factory import agent_factory
+    for name in names(z, "opd_masked"):
+        p = "opd_masked/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        avail = z[p + "/available"]
+        a_ = cfg["reward"].shape[1]
+        budget = int(z[p + "/budget"])
+        model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"], available=avail)
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        out = ctx.opd_plan(model, [int(z[p + "/s0"])], budget, float(z[p + "/gamma"]), float(z[p + "/terminal_reward"]), rng,
+                           max_plan_len=budget // a_ + 1)
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert out["root_lower"][0] == float(z[p + "/root_lower"]) and out["root_upper"][0] == float(z[p + "/root_upper"])
+        assert int(out["env_steps"][0]) == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        tree = ctx.opd_tree(0, 1 + (budget // a_) * a_)
+        tree["obs"] = np.where(np.arange(len(tree["state"])) == 0, -1, tree["state"])
+        assert_keyed_tree_equal(z, p + "/tree", tree, dict(count="count", lower="lower", upper="upper", reward="reward",
+                                                          done="done", depth="depth", obs="obs"))
+        model.close()
+        # agent level
+        env = _env(cfg, state=int(z[p + "/s0"]), available=avail)
+        agent = agent_factory(env, dict(__class__=OPD, budget=budget, gamma=float(z[p + "/gamma"]),
+                                        terminal_reward=float(z[p + "/terminal_reward"])))
+        agent.seed(int(z[p + "/seed"]))
+        np.testing.assert_array_equal(agent.plan(int(z[p + "/s0"])), z[p + "/plan"], err_msg=name)
+        root = agent.planner.root
+        assert root.value_lower == float(z[p + "/root_lower"]) and root.count == int(z[p + "/root_count"])
+    # the state-aware planner does not take restricted action sets (documented)
+    env = _env(cfg, state=0, available=avail)
+    with pytest.raises(NotImplementedError):
+        agent_factory(env, dict(__class__=SAOPD, budget=40)).plan(0)
+
+
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("n_actions,budget", [(2, 101), (4, 100), (5, 500), (7, 300), (64, 640)])
+def test_opd_restricted_actions_batch_vs_oracle(ctx, n_actions, budget, variant, monkeypatch):
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    cfg = generators.random_deterministic(300, n_actions, seed=90 + n_actions, terminal_rate=0.05)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    avail = generators.random_available(300, n_actions, seed=n_actions, rate=0.45)
+    model = ctx.load_table(t, r, term, available=avail)
+    n = 70
+    s0 = np.random.Generator(np.random.PCG64(n_actions)).integers(0, 300, size=n).astype(np.int32)
+    g = np.random.Generator(np.random.PCG64(7))
+    rng = g.integers(0, 2 ** 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+    rng[:, 3] |= np.uint64(1)
+    rng[:, 4:] = 0
+    rng_ref = rng.copy()
+    mpl = budget // n_actions + 2
+    out = ctx.opd_plan(model, s0, budget, 0.9, 0.25, rng, max_plan_len=mpl)
+    ref = oracle.opd_plan_batch(t, r, term, s0, budget, 0.9, 0.25, rng_ref, max_plan_len=mpl, n_threads=8, available=avail)
+    for k in ("status", "plans", "plan_len", "env_steps"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    assert np.array_equal(out["root_lower"], ref["root_lower"]) and np.array_equal(out["root_upper"], ref["root_upper"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    model.close()

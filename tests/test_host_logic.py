@@ -27,7 +27,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
-    assert native.load().mp_abi_version() == 1
+    assert native.load().mp_abi_version() == 2
 
 
 def test_context_fails_loudly_without_gpu_or_library(monkeypatch):
@@ -92,8 +92,19 @@ def test_mcts_defaults_and_policies():
                                   np.ones(4) / 4)
     with pytest.raises(ValueError):
         mcts_mod.MCTSAgent(env, {"prior_policy": {"type": "nope"}})
-    with pytest.raises(NotImplementedError):
-        mcts_mod.MCTSAgent(env, {"closed_loop": True})
+    assert mcts_mod.MCTSAgent(env, {"closed_loop": True}).planner.config["closed_loop"] is True
+    # policies over restricted action sets, state by state as the reference's policy functions return them (mcts.py:46-97)
+    from tests.helpers import reference_policy_lists
+    from rl_agents_amd.envs import generators
+    avail = generators.random_available(23, 5, seed=3, rate=0.5)
+    for pol in ({"type": "random"}, {"type": "random_available"}, {"type": "preference", "action": 2, "ratio": 3},
+                {"type": "preference", "action": 4, "ratio": 2.5}, {"type": "preference", "action": 7, "ratio": 2}):
+        table, listed = mcts_mod.policy_tables(pol, avail)
+        ref = reference_policy_lists(pol, avail)
+        for s in range(23):
+            assert list(np.flatnonzero(listed[s])) == ref["actions"][s]
+            assert np.array_equal(table[s, ref["actions"][s]], ref["p"][s]) and table[s].sum() == pytest.approx(1.0)
+            assert (table[s, ~listed[s]] == 0).all()
 
 
 def test_receding_horizon_bookkeeping():
