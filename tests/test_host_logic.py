@@ -95,7 +95,6 @@ def test_mcts_defaults_and_policies():
     assert mcts_mod.MCTSAgent(env, {"closed_loop": True}).planner.config["closed_loop"] is True
     # policies over restricted action sets, state by state as the reference's policy functions return them (mcts.py:46-97)
     from tests.helpers import reference_policy_lists
-    from rl_agents_amd.envs import generators
     avail = generators.random_available(23, 5, seed=3, rate=0.5)
     for pol in ({"type": "random"}, {"type": "random_available"}, {"type": "preference", "action": 2, "ratio": 3},
                 {"type": "preference", "action": 4, "ratio": 2.5}, {"type": "preference", "action": 7, "ratio": 2}):
