@@ -416,3 +416,57 @@ def saopd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_r
                                     _p(updates, C.c_int64), _p(status, C.c_int32), int(n_threads))
     assert rc == 0
     return dict(plans=plans, plan_len=plan_len, env_steps=steps, updates=updates, status=status, rng_after=rng)
+
+
+def ropd_plan(transitions, rewards, terminals, s0, budget, gamma, terminal_reward=0.0, rng_state=None,
+              done_rule="source", max_plan_len=1024):
+    """DiscreteRobustPlanner.plan for one root over M models (agents/robust/robust.py:28-50).
+    transitions int [M,S,A], rewards [M,S,A], terminals [M,S] or None, s0 int [M] (the joint state)."""
+    t, r = _i64(transitions), _f64(rewards)
+    m, s, a = r.shape
+    term = None if terminals is None else _u8(np.asarray(terminals).reshape(m, s))
+    s0 = np.ascontiguousarray(np.broadcast_to(np.asarray(s0, dtype=np.int32), (m,)))
+    cap = 1 + (budget // a) * a
+    rng = np.array(rng_state if rng_state is not None else [0, 1, 0, 1, 0, 0], dtype=np.uint64)
+    plan = np.full(max_plan_len, -1, dtype=np.int32)
+    plan_len, steps, nn = C.c_int32(), C.c_int64(), C.c_int32()
+    lo, up = C.c_double(), C.c_double()
+    tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros((cap, m), np.int32),
+                depth=np.zeros(cap, np.int32), reward=np.zeros((cap, m), np.float64), lower=np.zeros((cap, m), np.float64),
+                upper=np.zeros((cap, m), np.float64), done=np.zeros((cap, m), np.uint8), count=np.zeros(cap, np.int64),
+                first_child=np.zeros(cap, np.int32))
+    rc = lib().orc_ropd_plan(m, s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"),
+                             _p(s0, C.c_int32), int(budget), C.c_double(gamma), C.c_double(terminal_reward),
+                             _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32), C.byref(plan_len), C.byref(lo),
+                             C.byref(up), C.byref(steps), _p(tree["parent"], C.c_int32), _p(tree["action"], C.c_int32),
+                             _p(tree["state"], C.c_int32), _p(tree["depth"], C.c_int32), _p(tree["reward"], C.c_double),
+                             _p(tree["lower"], C.c_double), _p(tree["upper"], C.c_double), _p(tree["done"], C.c_uint8),
+                             _p(tree["count"], C.c_int64), _p(tree["first_child"], C.c_int32), C.byref(nn))
+    if rc == ERR_REWARD_RANGE:
+        raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")
+    assert rc == 0, rc
+    tree = {k: v[:nn.value] for k, v in tree.items()}
+    tree["n_children"] = np.where(tree["first_child"] >= 0, a, 0).astype(np.int32)
+    return dict(plan=plan[:plan_len.value].copy(), root_lower=lo.value, root_upper=up.value, env_steps=steps.value,
+                rng_after=rng, tree=tree)
+
+
+def ropd_plan_batch(transitions, rewards, terminals, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
+                    done_rule="source", max_plan_len=32, n_threads=1):
+    t, r = _i64(transitions), _f64(rewards)
+    m, s, a = r.shape
+    term = None if terminals is None else _u8(np.asarray(terminals).reshape(m, s))
+    s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.int32).reshape(-1, m))
+    n = len(s0)
+    rng = (np.tile(np.array([0, 1, 0, 1, 0, 0], np.uint64), (n, 1)) if rng_states is None
+           else np.array(rng_states, np.uint64).reshape(n, 6))
+    plans = np.full((n, max_plan_len), -1, dtype=np.int32)
+    plan_len, status = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    lo, up = np.zeros(n), np.zeros(n)
+    steps = np.zeros(n, np.int64)
+    lib().orc_ropd_plan_batch(m, s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"),
+                              n, _p(s0, C.c_int32), int(budget), C.c_double(gamma), C.c_double(terminal_reward),
+                              _p(rng, C.c_uint64), max_plan_len, _p(plans, C.c_int32), _p(plan_len, C.c_int32),
+                              _p(lo, C.c_double), _p(up, C.c_double), _p(steps, C.c_int64), _p(status, C.c_int32),
+                              int(n_threads))
+    return dict(plans=plans, plan_len=plan_len, root_lower=lo, root_upper=up, env_steps=steps, status=status, rng_after=rng)

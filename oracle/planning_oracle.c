@@ -442,6 +442,157 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
     return rc;
 }
 
+/* ------------------------------------------------------------------ discrete robust OPD ---- */
+/*
+ * agents/robust/robust.py:28-50 (DiscreteRobustPlanner / RobustNode) over deterministic.py:28-79, for one root.
+ * The planner's `state` is a joint environment of M models stepped together (robust.py:9-16 JointEnv): a joint state
+ * is M state indices, a step returns M rewards and M terminal flags (ndarrays), so DeterministicNode.update takes its
+ * ndarray branch (deterministic.py:54-59) and a LEAF's value_lower / value_upper are vectors over the models.
+ * RobustNode reads them through np.min (robust.py:42-49): the leaf to expand is the first maximal min_m U (robust.py:37),
+ * backup_to_root (deterministic.py:74-79) replaces an expanded node's bounds by the SCALARS max_c min_m L_c / max_c
+ * min_m U_c, and the plan follows max min_m L with random ties (deterministic.py:21-26).
+ *   T int64 [M,S,A], R double [M,S,A], term uint8 [M,S] (NULL = none), s0 int32 [M].
+ * Tree export (capacity 1 + (budget/A)*A): t_lower / t_upper [cap*M] hold a node's vector (an expanded node's scalar
+ * repeated M times), t_state / t_reward / t_done [cap*M] the joint observation, rewards and flags.
+ */
+int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                  const int32_t *s0, int budget, double gamma, double terminal_reward, uint64_t *rng6,
+                  int max_plan_len, int32_t *plan, int32_t *plan_len, double *root_lower, double *root_upper,
+                  int64_t *env_steps,
+                  int32_t *t_parent, int32_t *t_action, int32_t *t_state, int32_t *t_depth, double *t_reward,
+                  double *t_lower, double *t_upper, uint8_t *t_done, int64_t *t_count, int32_t *t_first_child,
+                  int32_t *n_nodes_out)
+{
+    const int K = budget / A; /* deterministic.py:118: budget // state.action_space.n */
+    const int cap = 1 + K * A;
+    int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
+    int32_t *state = malloc((size_t)cap * M * sizeof(int32_t)), *depth = malloc(cap * sizeof(int32_t));
+    int32_t *first_child = malloc(cap * sizeof(int32_t)), *leaves = malloc(cap * sizeof(int32_t));
+    double *lower = malloc((size_t)cap * M * sizeof(double)), *upper = malloc((size_t)cap * M * sizeof(double));
+    double *reward = calloc((size_t)cap * M, sizeof(double));
+    uint8_t *done = calloc((size_t)cap * M, 1);
+    int64_t *count = malloc(cap * sizeof(int64_t));
+    if (!parent || !action || !state || !depth || !first_child || !leaves || !lower || !upper || !reward || !done || !count)
+        return ORC_ERR_ALLOC;
+#define VMIN(v, n) ({ double m_ = (v)[(long)(n) * M]; for (int q_ = 1; q_ < M; ++q_) if ((v)[(long)(n) * M + q_] < m_) m_ = (v)[(long)(n) * M + q_]; m_; })
+    int rc = ORC_OK;
+    int64_t steps_taken = 0;
+    parent[0] = -1; action[0] = -1; depth[0] = 0; first_child[0] = -1; count[0] = 1;
+    for (int m = 0; m < M; ++m) { state[m] = s0[m]; lower[m] = 0; upper[m] = 0; }
+    int n_nodes = 1, n_leaves = 1;
+    leaves[0] = 0;
+    for (int k = 0; k < K && rc == ORC_OK; ++k) {
+        /* robust.py:37: max(self.leaves, key=np.min(value_upper)) -> first maximal element in list order */
+        int li = 0;
+        double best = VMIN(upper, leaves[0]);
+        for (int i = 1; i < n_leaves; ++i) {
+            const double u = VMIN(upper, leaves[i]);
+            if (u > best) { best = u; li = i; }
+        }
+        const int leaf = leaves[li];
+        memmove(leaves + li, leaves + li + 1, (n_leaves - li - 1) * sizeof(int32_t));
+        --n_leaves;
+        first_child[leaf] = n_nodes;
+        for (int a = 0; a < A && rc == ORC_OK; ++a) { /* deterministic.py:36-43 */
+            const int c = n_nodes++;
+            parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1;
+            const int d = depth[c];
+            ++steps_taken; /* one planner.step (of the joint environment) per child */
+            leaves[n_leaves++] = c;
+            for (int m = 0; m < M; ++m) { /* JointEnv.step: every model steps its own state */
+                const int32_t sm = state[(long)leaf * M + m];
+                const long sa = ((long)m * S + sm) * A + a;
+                const int32_t sn = (int32_t)T[sa];
+                const double r = R[sa];
+                const int terminated = term ? (done_on_next ? term[(long)m * S + sn] : term[(long)m * S + sm]) : 0;
+                state[(long)c * M + m] = sn;
+                reward[(long)c * M + m] = r; done[(long)c * M + m] = (uint8_t)terminated;
+                if (!(0 <= r) || !(r <= 1)) rc = ORC_ERR_REWARD_RANGE; /* np.all(0 <= reward), np.all(reward <= 1) */
+                /* deterministic.py:51-59 with ndarray reward / done */
+                double lo = lower[(long)leaf * M + m] + pow(gamma, d - 1) * r;
+                double up = lo + pow(gamma, d) / (1 - gamma);
+                if (terminated) {
+                    const double nv = lo + terminal_reward * pow(gamma, d) / (1 - gamma);
+                    lo = nv; up = nv;
+                }
+                lower[(long)c * M + m] = lo; upper[(long)c * M + m] = up;
+            }
+            if (rc != ORC_OK) break;
+            count[c] = 1;
+            for (int n = c; n >= 0; n = parent[n]) count[n] += 1;
+        }
+        if (rc != ORC_OK) break;
+        /* deterministic.py:74-79 backup_to_root with RobustNode.get_value_*_bound = np.min (robust.py:42-46) */
+        for (int n = leaf; n >= 0; n = parent[n]) {
+            double ml = VMIN(lower, first_child[n]), mu = VMIN(upper, first_child[n]);
+            for (int a = 1; a < A; ++a) {
+                const double l = VMIN(lower, first_child[n] + a), u = VMIN(upper, first_child[n] + a);
+                if (l > ml) ml = l;
+                if (u > mu) mu = u;
+            }
+            for (int m = 0; m < M; ++m) { lower[(long)n * M + m] = ml; upper[(long)n * M + m] = mu; }
+        }
+    }
+    if (rc == ORC_OK) {
+        orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
+        int n = 0, len = 0;
+        while (first_child[n] >= 0) {
+            const int fc = first_child[n];
+            double m = VMIN(lower, fc);
+            for (int a = 1; a < A; ++a) { const double l = VMIN(lower, fc + a); if (l > m) m = l; }
+            int ties[64], nt = 0;
+            for (int a = 0; a < A && nt < 64; ++a) if (VMIN(lower, fc + a) == m) ties[nt++] = a;
+            const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            if (plan && len < max_plan_len) plan[len] = a;
+            ++len;
+            n = fc + a;
+        }
+        if (plan) for (int i = len; i < max_plan_len; ++i) plan[i] = -1;
+        if (plan_len) *plan_len = len;
+        rng6[0] = g.s_hi; rng6[1] = g.s_lo; rng6[2] = g.inc_hi; rng6[3] = g.inc_lo;
+        rng6[4] = g.has_uint32; rng6[5] = g.uinteger;
+        if (root_lower) *root_lower = VMIN(lower, 0);
+        if (root_upper) *root_upper = VMIN(upper, 0);
+    }
+#undef VMIN
+    if (env_steps) *env_steps = steps_taken;
+    for (int i = 0; i < n_nodes; ++i) {
+        if (t_parent) t_parent[i] = parent[i];
+        if (t_action) t_action[i] = action[i];
+        if (t_depth) t_depth[i] = depth[i];
+        if (t_count) t_count[i] = count[i];
+        if (t_first_child) t_first_child[i] = first_child[i];
+        for (int m = 0; m < M; ++m) {
+            if (t_state) t_state[(long)i * M + m] = state[(long)i * M + m];
+            if (t_reward) t_reward[(long)i * M + m] = reward[(long)i * M + m];
+            if (t_lower) t_lower[(long)i * M + m] = lower[(long)i * M + m];
+            if (t_upper) t_upper[(long)i * M + m] = upper[(long)i * M + m];
+            if (t_done) t_done[(long)i * M + m] = done[(long)i * M + m];
+        }
+    }
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+    free(parent); free(action); free(state); free(depth); free(first_child); free(leaves);
+    free(lower); free(upper); free(reward); free(done); free(count);
+    return rc;
+}
+
+int orc_ropd_plan_batch(int M, int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
+                        int n_roots, const int32_t *s0 /* [n_roots,M] */, int budget, double gamma, double terminal_reward,
+                        uint64_t *rng6, int max_plan_len, int32_t *plans, int32_t *plan_len, double *root_lower,
+                        double *root_upper, int64_t *env_steps, int32_t *status, int n_threads)
+{
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n_roots; ++i) {
+        int rc = orc_ropd_plan(M, S, A, T, R, term, done_on_next, s0 + (long)i * M, budget, gamma, terminal_reward,
+                               rng6 + (long)i * 6, max_plan_len, plans ? plans + (long)i * max_plan_len : NULL,
+                               plan_len ? plan_len + i : NULL, root_lower ? root_lower + i : NULL,
+                               root_upper ? root_upper + i : NULL, env_steps ? env_steps + i : NULL, NULL, NULL, NULL, NULL,
+                               NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+        if (status) status[i] = rc;
+    }
+    return ORC_OK;
+}
+
 /* ------------------------------------------------------------------ UCT ------------------ */
 /*
  * mcts.py:100-184 (MCTS planner) + mcts.py:203-286 (MCTSNode) for one root.

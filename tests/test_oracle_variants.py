@@ -126,3 +126,38 @@ def test_opd_with_restricted_actions(z):
         tree["obs"] = np.where(np.arange(len(tree["state"])) == 0, -1, tree["state"])
         assert_keyed_tree_equal(z, p + "/tree", tree, dict(count="count", lower="lower", upper="upper", reward="reward",
                                                           done="done", depth="depth", obs="obs"))
+
+
+def robust_models(z, p):
+    m = int(z[p + "/n_models"])
+    cfgs = [mdp_from_golden(z, "{}/mdp{}".format(p, i)) for i in range(m)]
+    return (np.stack([c["transition"] for c in cfgs]), np.stack([c["reward"] for c in cfgs]),
+            np.stack([c["terminal"] for c in cfgs]))
+
+
+ROBUST_FIELDS = dict(count="count", depth="depth", lower="lower", upper="upper", reward="reward", done="done")
+
+
+def test_discrete_robust_planner(z):
+    """DiscreteRobustPlanner / RobustNode (agents/robust/robust.py:28-50): vector bounds per leaf, min over models."""
+    from oracle import oracle
+    for name in names(z, "robust"):
+        p = "robust/" + name
+        t, r, term = robust_models(z, p)
+        out = oracle.ropd_plan(t, r, term, int(z[p + "/s0"]), int(z[p + "/budget"]), float(z[p + "/gamma"]),
+                               float(z[p + "/terminal_reward"]), z[p + "/rng_before"])
+        np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+        assert out["root_lower"] == float(z[p + "/root_lower"]) and out["root_upper"] == float(z[p + "/root_upper"]), name
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+        tree = out["tree"]
+        assert_keyed_tree_equal(z, p + "/tree", tree, ROBUST_FIELDS)
+        from tests.helpers import bfs_children
+        order, _ = bfs_children(tree["first_child"], tree["n_children"])
+        assert np.array_equal(tree["state"][order][1:], z[p + "/tree/obs"][1:]), name
+        assert np.array_equal(tree["lower"].min(axis=1)[order], z[p + "/tree/lower_min"])
+    assert bool(z["robust/trap_raises_valueerror"])
+    with pytest.raises(ValueError):
+        trap_t = np.array([[[1, 2], [1, 1], [3, 4], [3, 3], [4, 4]]] * 2)
+        trap_r = np.array([[[0, 0], [0, 0], [0, 0], [1, 1], [-1, -1]]] * 2, dtype=float)
+        oracle.ropd_plan(trap_t, trap_r, np.array([[0, 1, 0, 1, 1]] * 2), 0, 20, 0.8)
