@@ -236,6 +236,34 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
                        int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
                        int64_t *count, int32_t *first_child, int32_t *n_children);
 
+/* ---------------------------------------------------------------- discrete robust OPD ------- */
+/*
+ * A joint environment of M models of one decision problem stepped together (agents/robust/robust.py:9-26 JointEnv): the
+ * planner's clone is the M state indices, a step returns M rewards and M terminal flags.
+ *   transition int64 [M,S,A], reward double [M,S,A], terminal uint8 [M,S] or NULL (each model has its own flags).
+ * The model is also a table model (M models) for the other entry points, which use model 0 for tree search.
+ */
+int mp_model_load_joint(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition, const double *reward,
+                        const uint8_t *terminal, int32_t done_on_next, mp_model **out);
+/*
+ * DiscreteRobustPlanner.plan (agents/robust/robust.py:28-40 over tree_search/deterministic.py:116-122) for n_roots
+ * independent roots of a joint model: budget // A times { leaf = first maximal min_m U among the leaves (robust.py:37,
+ * RobustNode.get_value_upper_bound :45-46); DeterministicNode.expand (deterministic.py:28-43) with the ndarray branch of
+ * update (:45-65): per-model lower / upper bounds; backup_to_root (:74-79) on the minima over the models }, then get_plan
+ * with selection_rule (:21-26) on min_m L.  Rewards outside [0,1] in ANY model: status MP_ERR_REWARD_RANGE.
+ *   root_state int32 [n_roots,M] (usually the same state M times); root_lower / root_upper = min over the models of
+ *   the root's bounds; everything else as mp_opd_plan.  At most 16 models, 64 actions.
+ */
+int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget, double gamma,
+                 double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len,
+                 double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status, int32_t mem);
+/* Tree of root `root` after the last mp_ropd_plan, creation order (A children per expanded node); host arrays of capacity
+ * `cap` nodes; state / reward / lower / upper / done are [cap,M]: a leaf's per-model values, an expanded node's
+ * backed-up scalars repeated M times. */
+int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
+                        int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
+                        int64_t *count, int32_t *first_child);
+
 /* ---------------------------------------------------------------- state-aware OPD ----------- */
 /*
  * StateAwarePlanner / StateAwareNode (tree_search/state_aware.py:10-137) over DeterministicNode.expand/update

@@ -1,0 +1,153 @@
+"""Discrete robust planning on the MI355X planning core (reference ``rl_agents/agents/robust/robust.py:9-71``).
+
+``DiscreteRobustPlannerAgent`` plans over a finite set of candidate models of the environment: ``config["models"]`` is
+a list of preprocessor lists, each turning the true environment into one model (robust.py:67-70); the planner maximises
+the worst case over the models (``RobustNode``: ``np.min`` of per-model bounds, robust.py:42-49).  Here every model must
+be a deterministic finite MDP over the same states and actions: their tables go to the device as one joint model
+(``mp_model_load_joint``) and the expansions run in ``mp_ropd_plan`` (rl_agents_amd/csrc/ropd.hip).
+
+Note on the reference: its ``JointEnv.step`` (robust.py:13-16) still returns the old 4-tuple, which
+``DeterministicNode.expand`` (deterministic.py:41) cannot unpack, so ``DiscreteRobustPlannerAgent`` raises on current
+environments.  The planner classes themselves run unmodified over a joint environment with a 5-tuple step; that is how
+the golden vectors this agent reproduces were made (tests/golden/gen/make_golden_robust.py).
+"""
+import hashlib
+import logging
+
+import numpy as np
+
+from rl_agents_amd import device_model, native
+from rl_agents_amd.agents.common.factory import preprocess_env
+from rl_agents_amd.agents.tree_search.abstract import build_tree
+from rl_agents_amd.agents.tree_search.deterministic import DeterministicPlannerAgent, OptimisticDeterministicPlanner
+
+logger = logging.getLogger(__name__)
+
+
+class JointEnv(object):
+    """The environments of all models, stepped together (robust.py:9-26) -- with the 5-tuple ``step`` of the
+    environments it wraps.  The device planner never steps it: it reads the models' tables and current states."""
+
+    def __init__(self, envs):
+        self.joint_state = envs
+
+    def step(self, action):
+        transitions = [state.step(action) for state in self.joint_state]
+        observations, rewards, terminals, truncated, info = zip(*transitions)
+        return observations, np.array(rewards), np.array(terminals), np.array(truncated), info
+
+    @property
+    def action_space(self):
+        return self.joint_state[0].action_space
+
+    def get_available_actions(self):
+        return list(set().union(*[s.get_available_actions() if hasattr(s, "get_available_actions")
+                                  else range(s.action_space.n)
+                                  for s in self.joint_state]))
+
+
+class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
+    """robust.py:28-40 for one or many roots of one set of models."""
+    supports_restricted_actions = False
+
+    def __init__(self, env, config=None):
+        super(DiscreteRobustPlanner, self).__init__(env, config)
+        self._joint = {}
+
+    def joint_model(self, state):
+        """Device model of a :class:`JointEnv` (or any object with ``joint_state``: a list of finite-MDP envs)."""
+        envs = getattr(state, "joint_state", None)
+        if not envs:
+            raise TypeError("the discrete robust planner plans on a JointEnv of at least one model")
+        mdps = [device_model.finite_mdp_of(e) for e in envs]
+        for e, mdp in zip(envs, mdps):
+            if mdp.mode != "deterministic":
+                raise TypeError("every model must be a deterministic finite MDP, got mode '{}'".format(mdp.mode))
+            if device_model.available_actions_of(e, mdp) is not None:
+                raise NotImplementedError("the robust planner does not handle models that restrict the available actions")
+        shapes = {np.asarray(m.transition).shape for m in mdps}
+        if len(shapes) != 1:
+            raise ValueError("all models must share the state and action spaces, got tables of shapes {}".format(shapes))
+        t = np.ascontiguousarray(np.stack([np.asarray(m.transition, dtype=np.int64) for m in mdps]))
+        r = np.ascontiguousarray(np.stack([np.asarray(m.reward, dtype=np.float64) for m in mdps]))
+        term = np.ascontiguousarray(np.stack([np.asarray(m.terminal).reshape(-1).astype(np.uint8) for m in mdps]))
+        rule = getattr(mdps[0], "done_rule", "source")
+        h = hashlib.blake2b(digest_size=16)
+        for arr in (t, r, term):
+            h.update(arr.view(np.uint8).reshape(-1))
+        key = (t.shape, rule, h.hexdigest())
+        model = self._joint.get(key)
+        if model is None:
+            if len(self._joint) >= 4:
+                for old in self._joint.values():
+                    old.close()
+                self._joint.clear()
+            model = self._joint[key] = self.models.ctx.load_joint(t, r, term, done_rule=rule)
+        return model, [int(m.state) for m in mdps]
+
+    def plan(self, state, observation):
+        model, joint_state = self.joint_model(state)
+        rng = native.rng_state_from_generator(self.np_random).reshape(1, 6)
+        out = self.plan_batch(state, [joint_state], rng_states=rng, model=model)
+        native.generator_set_state(self.np_random, rng[0])
+        n = int(out["plan_len"][0])
+        return [int(a) for a in out["plans"][0, :n]]
+
+    def plan_batch(self, state, root_states, root_steps=None, rng_states=None, model=None):
+        """root_states: [n] (all models start in the same state) or [n, M] joint states."""
+        if model is None:
+            model, _ = self.joint_model(state)
+        rs = np.asarray(root_states, dtype=np.int32)
+        n = rs.shape[0]
+        if rng_states is None:
+            rng_states = self.batch_rng_states(n)
+        cfg = self.config
+        budget = int(cfg["budget"])
+        if cfg["gamma"] == 1 and budget >= model.A:
+            raise ZeroDivisionError("float division by zero")       # gamma ** depth / (1 - gamma), deterministic.py:53
+        out = self.models.ctx.ropd_plan(model, rs, budget, cfg["gamma"], cfg.get("terminal_reward", 0), rng_states,
+                                        max_plan_len=budget // model.A + 1)
+        if (out["status"] == native.ERR_REWARD_RANGE).any():
+            raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
+        out["rng_states"] = rng_states
+        self.last, self._root, self._last_actions, self._last_models = out, None, model.A, model.M
+        self.env_steps += int(out["env_steps"].sum())
+        return out
+
+    def export_tree(self, root=0):
+        a, m = self._last_actions, self._last_models
+        arrays = self.models.ctx.ropd_tree(root, 1 + (int(self.config["budget"]) // a) * a, m)
+        lower, upper = arrays["lower"], arrays["upper"]
+        arrays["value_lower_min"], arrays["value_upper_min"] = lower.min(axis=1), upper.min(axis=1)
+        tree = build_tree(arrays, "value_upper_min", extra=("value_lower_min", "value_upper_min"))
+        # per-model vectors as the reference's nodes hold them: ndarrays on leaves, the backed-up scalars once expanded
+        by_id = [tree] + [None] * (len(arrays["parent"]) - 1)
+        for i in range(1, len(by_id)):       # creation order: parents come first
+            by_id[i] = by_id[int(arrays["parent"][i])].children[int(arrays["action"][i])]
+        for i, node in enumerate(by_id):
+            expanded = arrays["first_child"][i] >= 0 or i == 0
+            node.value_lower = float(lower[i, 0]) if expanded else lower[i].copy()
+            node.value_upper = float(upper[i, 0]) if expanded else upper[i].copy()
+            node.reward, node.done = arrays["reward"][i].copy(), arrays["done"][i].astype(bool)
+            node.observation = tuple(int(s) for s in arrays["state"][i])
+        return tree
+
+
+class DiscreteRobustPlannerAgent(DeterministicPlannerAgent):
+    """Drop-in for ``rl_agents.agents.robust.robust.DiscreteRobustPlannerAgent``."""
+    PLANNER_TYPE = DiscreteRobustPlanner
+
+    def __init__(self, env, config=None):
+        self.true_env = env
+        super(DiscreteRobustPlannerAgent, self).__init__(env, config)
+
+    @classmethod
+    def default_config(cls):
+        config = super(DiscreteRobustPlannerAgent, cls).default_config()
+        config.update(dict(models=[]))
+        return config
+
+    def plan(self, observation):
+        envs = [preprocess_env(self.true_env, preprocessors) for preprocessors in self.config["models"]]
+        self.env = JointEnv(envs)
+        return super(DiscreteRobustPlannerAgent, self).plan(observation)

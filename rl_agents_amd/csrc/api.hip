@@ -245,6 +245,29 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
     return MP_OK;
 }
 
+int mp_model_load_joint(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition, const double *reward,
+                        const uint8_t *terminal, int32_t done_on_next, mp_model **out)
+{
+    if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_joint: NULL argument");
+    // tables, value-iteration view and model 0's records as for any table model (terminal flags of model 0)
+    MP_TRY(mp_model_load_table(ctx, M, S, A, transition, reward, terminal, done_on_next, 0, out));
+    mp_model *m = *out;
+    auto bail = [&](int rc) { mp_model_free(m); *out = nullptr; return rc; };
+    const long sa = (long)S * A;
+    if (hipMalloc(&m->rec_all, (size_t)M * sa * sizeof(Rec)) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "mp_model_load_joint: hipMalloc failed"));
+    if (terminal) {
+        if (hipMalloc(&m->term_all, (size_t)M * S) != hipSuccess) return bail(fail(MP_ERR_ALLOC, "mp_model_load_joint: hipMalloc failed"));
+        if (hipMemcpy(m->term_all, terminal, (size_t)M * S, hipMemcpyHostToDevice) != hipSuccess)
+            return bail(fail(MP_ERR_HIP, "mp_model_load_joint: upload failed"));
+    }
+    for (int k = 0; k < M; ++k)
+        hipLaunchKernelGGL(pack_records, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T + k * sa,
+                           m->R + k * sa, m->term_all ? (const uint8_t *)(m->term_all + (size_t)k * S) : (const uint8_t *)nullptr,
+                           (const uint8_t *)nullptr, m->rec_all + k * sa);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(MP_ERR_HIP, "mp_model_load_joint: pack_records failed"));
+    return MP_OK;
+}
+
 int mp_model_set_available(mp_model *m, const uint8_t *available)
 {
     if (!m || !available) return fail(MP_ERR_ARG, "mp_model_set_available: NULL argument");
@@ -358,6 +381,8 @@ int mp_model_free(mp_model *m)
     if (m->rec) hipFree(m->rec);
     if (m->t16) hipFree(m->t16);
     if (m->avail) hipFree(m->avail);
+    if (m->rec_all) hipFree(m->rec_all);
+    if (m->term_all) hipFree(m->term_all);
     if (m->NXT) hipFree(m->NXT);
     delete m;
     return MP_OK;

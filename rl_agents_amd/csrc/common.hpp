@@ -49,8 +49,9 @@ struct DevBuf {
 
 // what the last tree-search call left on the device (for the *_tree_export entry points)
 struct TreeMeta {
-    int kind = 0; // 0 none, 1 uct, 2 opd
-    int n_roots = 0, A = 0, cap = 0, K = 0;
+    int kind = 0; // 0 none, 1 uct, 2 opd, 3 robust opd
+    int n_roots = 0, A = 0, cap = 0, K = 0, M = 1;
+    double gamma = 0.0; // robust opd: the export recomputes leaf upper-bound vectors
     int buf = 0;        // UCT: which of the two tree workspaces (WS_TREE0 / WS_TREE2) holds the current trees
     bool armed = false; // UCT: mp_uct_step_tree was called; the next plan re-roots and continues
 };
@@ -108,6 +109,8 @@ struct mp_model {
     double *R = nullptr;
     uint8_t *term = nullptr; // [S] or nullptr
     mp::Rec *rec = nullptr;  // packed model 0, [S*A]
+    mp::Rec *rec_all = nullptr;  // joint models (mp_model_load_joint): packed records of every model, [M][S*A]; rec = rec_all
+    uint8_t *term_all = nullptr; // joint models: terminal flags per model, [M][S]
     uint16_t *t16 = nullptr; // model 0 as {bit15 = terminal[next], next}, [S*A]; only when S < 32768
     // dense [M,S,A,S] / sparse [S,A,B]
     const double *P = nullptr;

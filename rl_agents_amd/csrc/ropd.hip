@@ -1,0 +1,400 @@
+// ropd.hip -- discrete robust optimistic planning (agents/robust/robust.py:28-50 over tree_search/deterministic.py).
+//
+// DiscreteRobustPlanner plans on a JOINT environment of M models stepped together (robust.py:9-16): a joint state is M
+// state indices, a step yields M rewards and M terminal flags, so DeterministicNode.update takes its ndarray branch
+// (deterministic.py:54-59) and a leaf's lower / upper bounds are VECTORS over the models, which RobustNode reads
+// through np.min (robust.py:42-49):
+//   * leaf to expand   = first maximal  min_m U[m]   in leaves order            (robust.py:37)
+//   * children         L_c[m] = L_leaf[m] + gamma^(d-1) r_m,  U_c[m] = L_c[m] + gamma^d / (1 - gamma),
+//                      terminal models: L_c[m] = U_c[m] = L_c[m] + terminal_reward gamma^d / (1 - gamma)
+//   * backup_to_root   an expanded node's bounds become the SCALARS max_c min_m L_c, max_c min_m U_c
+//                      (deterministic.py:74-79 with RobustNode.get_value_*_bound)
+//   * plan             children with maximal min_m L, random ties                (deterministic.py:21-26)
+//
+// Mapping = opd.hip's: ONE ROOT PER WAVEFRONT; the scalar key min_m U of every node lives in the class-contiguous
+// upper-bound array (LDS, or HBM/L2 for big batches) with the two-level cached argmax; lane a creates child a, looping
+// over the M models (one 16-byte model-record gather per model, all M in flight together); the scalar backups are
+// deferred to one bottom-up pass at the end exactly as in opd.hip -- no planning decision reads an expanded node's
+// bounds, children start from their parent's CREATION-TIME vector, and max is exact.
+// HBM per node: M x {L f64, state i32, reward f64} + {min_m L, min_m U, depth, done bits}.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "pcg64.hpp"
+#include "wave.hpp"
+
+namespace mp {
+
+constexpr int kMaxModels = 16;
+
+struct ROpdArgs {
+    int n_roots, M, S, A, K, cap, done_on_next, max_plan_len;
+    int T; // row length of a residue class in the upper-bound array: odd, >= ceil(cap / 64)
+    const Rec *rec;            // [M][S*A] packed records of every model
+    const int32_t *root_state; // [n_roots][M]
+    const double *g1, *gdiv, *tdiv;
+    uint64_t *rng;
+    double *Lv;        // [n_roots][cap][M] creation-time lower-bound vectors
+    int32_t *Sv;       // [n_roots][cap][M] joint states
+    double *Rv;        // [n_roots][cap][M] rewards
+    double *Lmin;      // [n_roots][cap]    min_m L at creation; the backed-up scalar for expanded nodes at the end
+    double *Umin;      // [n_roots][cap]    min_m U of leaves, -inf for expanded nodes (export fills those in)
+    int32_t *meta;     // [n_roots][cap][2] depth, done bits
+    double *leaf_global; // [n_roots][64 * T] upper-bound array of the high-occupancy variant (else nullptr)
+    int32_t *expanded; // [n_roots][K]
+    int32_t *n_nodes_out;
+    int32_t *plans, *plan_len, *status;
+    double *root_lower, *root_upper;
+    int64_t *env_steps;
+};
+
+template <bool GLB>
+__global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int T = p.T;
+    double *leafU = GLB ? p.leaf_global + (long)blockIdx.x * 64 * T : lds;
+    int32_t *exp_lds = reinterpret_cast<int32_t *>(GLB ? lds : lds + 64 * T);
+#define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
+    const int lane = threadIdx.x, root = blockIdx.x, A = p.A, M = p.M;
+    const long base = (long)root * p.cap, SA = (long)p.S * A;
+    double *Lv = p.Lv + base * M, *Rv = p.Rv + base * M, *Lmin = p.Lmin + base, *Umin = p.Umin + base;
+    int32_t *Sv = p.Sv + base * M, *meta = p.meta + base * 2;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+
+    // deterministic.py:10-19 root: L = U = 0 (scalars), depth 0
+    if (lane == 0) {
+        for (int m = 0; m < M; ++m) { Lv[m] = 0.0; Sv[m] = p.root_state[(long)root * M + m]; Rv[m] = 0.0; }
+        Lmin[0] = 0.0; meta[0] = 0; meta[1] = 0;
+        LU(0) = 0.0;
+    }
+    __syncthreads();
+    int n_nodes = 1, status = MP_OK, k_done = 0;
+    double cbu = lane == 0 ? 0.0 : ninf; // best leaf of this lane's class (ids == lane mod 64)
+    int cbid = lane == 0 ? 0 : 0x7fffffff;
+
+    for (int k = 0; k < p.K; ++k) {
+        // ---- robust.py:37: first maximal min_m U among the leaves
+        double bu = cbu;
+        int leaf = cbid;
+        wave_argmax(bu, leaf);
+        const int cls = leaf & 63;
+        const int dleaf = meta[2 * leaf]; // (uniform address: one broadcast load, in flight under the class re-scan)
+        if (lane == 0) LU(leaf) = ninf;
+        if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        {
+            const double *row = leafU + cls * T;
+            const int cnt = (n_nodes - cls + 63) >> 6;
+            double ru = ninf;
+            int rid = 0x7fffffff;
+            for (int t = lane; t < cnt; t += 64) {
+                const double u = row[t];
+                if (u > ru) { ru = u; rid = cls + (t << 6); }
+            }
+            wave_argmax(ru, rid);
+            if (lane == cls) { cbu = ru; cbid = rid; }
+        }
+        // ---- DeterministicNode.expand (deterministic.py:28-43), update() with ndarray reward / done (:45-65)
+        const int d = __builtin_amdgcn_readfirstlane(dleaf) + 1;
+        typedef const double __attribute__((address_space(4))) *scalar_f64;
+        const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
+                     tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
+        const int g = n_nodes;
+        bool bad = false;
+        double Uc_mine = 0.0;
+        if (lane < A) {
+            const int c = g + lane;
+            double lmin = 0.0, umin = 0.0;
+            uint32_t dbits = 0;
+            const double *Lp = Lv + (long)leaf * M;
+            const int32_t *Sp = Sv + (long)leaf * M;
+            for (int m = 0; m < M; ++m) { // JointEnv.step: every model steps its own state (robust.py:13-16)
+                const Rec rc = p.rec[(long)m * SA + (long)Sp[m] * A + lane];
+                const double r = rc.reward;
+                bad |= !(0.0 <= r) || !(r <= 1.0); // np.all(0 <= reward), np.all(reward <= 1)
+                const bool dn = (rc.flags & done_bit) != 0;
+                double Lc = Lp[m] + g1d * r;
+                double Uc = Lc + gdivd;
+                if (dn) {
+                    const double nv = Lc + tdivd;
+                    Lc = nv; Uc = nv;
+                }
+                Lv[(long)c * M + m] = Lc;
+                Sv[(long)c * M + m] = rc.next;
+                Rv[(long)c * M + m] = r;
+                dbits |= (dn ? 1u : 0u) << m;
+                if (m == 0 || Lc < lmin) lmin = Lc; // np.min
+                if (m == 0 || Uc < umin) umin = Uc;
+            }
+            Lmin[c] = lmin;
+            meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
+            LU(c) = umin;
+            Uc_mine = umin;
+        }
+        if (lane == 0) exp_lds[k] = leaf;
+        n_nodes += A;
+        k_done = k + 1;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads(); // the next expansion may read these children's vectors (global memory, other lanes)
+        {
+            const int j = (lane - g) & 63;
+            const double u = __shfl(Uc_mine, j & 63);
+            if (j < A) {
+                const int id = g + j;
+                if (u > cbu) { cbu = u; cbid = id; }
+            }
+        }
+    }
+    __syncthreads();
+
+    if (status == MP_OK) {
+        // ---- all backup_to_root calls at once: the bottom-up fixed point of L = max_c L_c, U = max_c U_c on the
+        // scalars min_m (see opd.hip).  Upper bounds: leaves keep their own, the root's is the max over all leaves,
+        // the other expanded nodes' are filled in by the export.
+        double root_upper = ninf;
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = LU(i);
+            Umin[i] = u;
+            if (u > root_upper) root_upper = u;
+        }
+        {
+            int dummy = 0;
+            wave_argmax(root_upper, dummy);
+        }
+        __syncthreads();
+        for (int i = lane; i < n_nodes; i += 64) LU(i) = Lmin[i];
+        __syncthreads();
+        for (int k = k_done - 1; k >= 0; --k) {
+            const int g = 1 + k * A;
+            double m = LU(g);
+            for (int a = 1; a < A; ++a) {
+                const double v = LU(g + a);
+                if (v > m) m = v;
+            }
+            if (lane == 0) LU(exp_lds[k]) = m;
+            if (GLB) __syncthreads();
+        }
+        __syncthreads();
+        for (int k = lane; k < k_done; k += 64) {
+            const int n = exp_lds[k];
+            Lmin[n] = LU(n);
+        }
+        // ---- get_plan with DeterministicNode.selection_rule over get_value_lower_bound = np.min
+        Pcg64 gen;
+        gen.load(p.rng + (long)root * 6);
+        int len = 0;
+        int kcur = k_done > 0 ? 0 : -1;
+        while (kcur >= 0) {
+            const int fc = 1 + kcur * A;
+            double m = LU(fc);
+            for (int a = 1; a < A; ++a) {
+                const double v = LU(fc + a);
+                if (v > m) m = v;
+            }
+            const double l = lane < A ? LU(fc + lane) : ninf;
+            const unsigned long long ties = __ballot(lane < A && l == m);
+            const int nt = __popcll(ties);
+            int pick = (int)gen.below((uint32_t)nt);
+            unsigned long long t = ties;
+            while (pick-- > 0) t &= t - 1;
+            const int a = __ffsll((long long)t) - 1;
+            if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
+            ++len;
+            const int child = fc + a;
+            int knext = -1;
+            for (int b = kcur + 1; b < k_done; b += 64) {
+                const int idx = b + lane;
+                const unsigned long long hit = __ballot(idx < k_done && exp_lds[idx] == child);
+                if (hit) { knext = b + __ffsll((long long)hit) - 1; break; }
+            }
+            kcur = knext;
+        }
+        if (lane == 0) {
+            gen.store(p.rng + (long)root * 6);
+            if (p.plans)
+                for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+            if (p.plan_len) p.plan_len[root] = len;
+            if (p.root_lower) p.root_lower[root] = LU(0);
+            if (p.root_upper) p.root_upper[root] = root_upper;
+        }
+    } else if (lane == 0) {
+        if (p.plans)
+            for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[root] = 0;
+    }
+    if (lane == 0) {
+        if (p.status) p.status[root] = status;
+        if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1); // one joint step per child (deterministic.py:41)
+        p.n_nodes_out[root] = n_nodes;
+    }
+    for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
+#undef LU
+}
+
+} // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget, double gamma,
+                 double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len,
+                 double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status, int32_t mem)
+{
+    if (!ctx || !model || !root_state || !rng_state) return fail(MP_ERR_ARG, "mp_ropd_plan: NULL argument");
+    if (model->mode != MP_MODE_DETERMINISTIC || !model->rec_all)
+        return fail(MP_ERR_MODE, "mp_ropd_plan: needs a joint model (mp_model_load_joint)");
+    const int A = model->A, M = model->M;
+    if (A > 64) return fail(MP_ERR_ARG, "mp_ropd_plan: |A| = %d > 64 actions not supported", A);
+    if (M > kMaxModels) return fail(MP_ERR_ARG, "mp_ropd_plan: %d models > %d not supported", M, kMaxModels);
+    if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_ropd_plan: bad sizes");
+    const int K = budget / A; // deterministic.py:118
+    if (K > 0 && !(gamma != 1.0))
+        return fail(MP_ERR_ARG, "mp_ropd_plan: gamma = 1 (the reference divides by 1 - gamma, deterministic.py:53)");
+    const long cap = 1 + (long)K * A;
+    const int T = (int)((cap + 63) / 64) | 1;
+    const size_t lds_map = (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    const size_t lds_full = (size_t)64 * T * sizeof(double) + lds_map;
+    if (lds_map > kLdsBytes - 1024)
+        return fail(MP_ERR_ARG, "mp_ropd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds_map, kLdsBytes - 1024);
+    const char *force = getenv("MP_OPD_MODEL"); // "lds" / "global": test hook (shared with mp_opd_plan)
+    const long lds_roots = (long)ctx->prop.multiProcessorCount * (long)((kLdsBytes - 1024) / lds_full);
+    bool glb = lds_full > kLdsBytes - 1024 || n_roots > lds_roots;
+    if (force && force[0] == 'g') glb = true;
+    if (force && force[0] == 'l' && lds_full <= kLdsBytes - 1024) glb = false;
+    const size_t lds = glb ? lds_map : lds_full;
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+
+    const int D = K + 2;
+    std::vector<double> tab((size_t)3 * D);
+    for (int d = 0; d < D; ++d) { // host libm, bit-equal to Python's float ** (as in mp_opd_plan)
+        tab[d] = d >= 1 ? pow(gamma, (double)(d - 1)) : 0.0;
+        tab[D + d] = pow(gamma, (double)d) / (1 - gamma);
+        tab[2 * D + d] = terminal_reward * pow(gamma, (double)d) / (1 - gamma);
+    }
+    double *d_tab = nullptr;
+    MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
+
+    ROpdArgs a;
+    a.n_roots = n_roots; a.M = M; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T;
+    a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
+    a.rec = model->rec_all;
+    a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;
+    const size_t nn = (size_t)n_roots * cap;
+    MP_TRY(ws_get(ctx, WS_TREE0, nn * M, &a.Lv));
+    MP_TRY(ws_get(ctx, WS_TREE1, nn * M, &a.Sv));
+    MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.Lmin));
+    MP_TRY(ws_get(ctx, WS_TREE3, nn, &a.Umin));
+    MP_TRY(ws_get(ctx, WS_TREE4, nn * M, &a.Rv));
+    MP_TRY(ws_get(ctx, WS_TREE5, nn * 2, &a.meta));
+    a.leaf_global = nullptr;
+    if (glb) MP_TRY(ws_get(ctx, WS_TREE6, (size_t)n_roots * 64 * T, &a.leaf_global));
+    MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
+    a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
+    ctx->tree.kind = 3; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
+    ctx->tree.M = M; ctx->tree.gamma = gamma;
+
+    int32_t *d_rs = nullptr;
+    MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n_roots * M, mem, &d_rs));
+    a.root_state = d_rs;
+    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n_roots * 6, mem, &a.rng));
+    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, mem, &a.plans));
+    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, mem, &a.plan_len));
+    MP_TRY(stage_out_alloc(ctx, WS_IO5, root_lower, (size_t)n_roots, mem, &a.root_lower));
+    MP_TRY(stage_out_alloc(ctx, WS_IO6, root_upper, (size_t)n_roots, mem, &a.root_upper));
+    MP_TRY(stage_out_alloc(ctx, WS_IO7, status, (size_t)n_roots, mem, &a.status));
+    MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
+
+    if (lds > 64 * 1024)
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(glb ? ropd_kernel<true> : ropd_kernel<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    MP_TRY(kernels_begin(ctx));
+    if (glb) hipLaunchKernelGGL((ropd_kernel<true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((ropd_kernel<false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    MP_TRY(kernels_end(ctx, 1));
+    MP_HIP(hipGetLastError());
+
+    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n_roots * 6, mem));
+    MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n_roots * max_plan_len, mem));
+    MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, root_lower, a.root_lower, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, root_upper, a.root_upper, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, status, a.status, (size_t)n_roots, mem));
+    MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, mem));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
+                        int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
+                        int64_t *count, int32_t *first_child)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    if (ctx->tree.kind != 3) return fail(MP_ERR_ARG, "mp_ropd_tree_export: no robust OPD tree on this ctx");
+    if (root < 0 || root >= ctx->tree.n_roots) return fail(MP_ERR_ARG, "mp_ropd_tree_export: root %d out of range", root);
+    const int tcap = ctx->tree.cap, A = ctx->tree.A, K = ctx->tree.K, NR = ctx->tree.n_roots, M = ctx->tree.M;
+    const double gamma = ctx->tree.gamma;
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    const int32_t *d_exp = (const int32_t *)ctx->ws[WS_TREE7].p;
+    int32_t n = 0;
+    MP_HIP(hipMemcpy(&n, d_exp + (size_t)NR * (K > 0 ? K : 1) + root, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n > cap) return fail(MP_ERR_ARG, "mp_ropd_tree_export: capacity %d < %d nodes", cap, n);
+    const long base = (long)root * tcap;
+    auto pull = [&](void *dst, int slot, size_t elt) -> int {
+        MP_HIP(hipMemcpy(dst, (const char *)ctx->ws[slot].p + base * elt, (size_t)n * elt, hipMemcpyDeviceToHost));
+        return MP_OK;
+    };
+    std::vector<double> lv((size_t)n * M), rv((size_t)n * M), lmin((size_t)n), umin((size_t)n);
+    std::vector<int32_t> sv((size_t)n * M), meta((size_t)n * 2), fc((size_t)n, -1), exp((size_t)(K > 0 ? K : 1)), par((size_t)n);
+    MP_TRY(pull(lv.data(), WS_TREE0, sizeof(double) * M));
+    MP_TRY(pull(sv.data(), WS_TREE1, sizeof(int32_t) * M));
+    MP_TRY(pull(lmin.data(), WS_TREE2, sizeof(double)));
+    MP_TRY(pull(umin.data(), WS_TREE3, sizeof(double)));
+    MP_TRY(pull(rv.data(), WS_TREE4, sizeof(double) * M));
+    MP_TRY(pull(meta.data(), WS_TREE5, sizeof(int32_t) * 2));
+    MP_HIP(hipMemcpy(exp.data(), d_exp + (size_t)root * (K > 0 ? K : 1), (size_t)(K > 0 ? K : 1) * sizeof(int32_t),
+                     hipMemcpyDeviceToHost));
+    for (int k = 0; k < K && 1 + (k + 1) * A <= n; ++k)
+        if (exp[k] >= 0 && exp[k] < n) fc[exp[k]] = 1 + k * A;
+    par[0] = -1;
+    for (int i = 1; i < n; ++i) par[i] = exp[(i - 1) / A];
+    for (int i = n - 1; i >= 0; --i) // expanded nodes: U = max over children of their scalar (bottom-up)
+        if (fc[i] >= 0) {
+            double m = umin[fc[i]];
+            for (int a = 1; a < A; ++a)
+                if (umin[fc[i] + a] > m) m = umin[fc[i] + a];
+            umin[i] = m;
+        }
+    std::vector<int64_t> sz((size_t)n, 1);
+    for (int i = n - 1; i >= 1; --i) sz[par[i]] += sz[i];
+    for (int i = 0; i < n; ++i) {
+        const int d = meta[2 * i];
+        if (parent) parent[i] = par[i];
+        if (action) action[i] = i == 0 ? -1 : (i - 1) % A;
+        if (depth) depth[i] = d;
+        if (count) count[i] = i == 0 ? sz[0] : 1 + sz[i];
+        if (first_child) first_child[i] = fc[i];
+        for (int m = 0; m < M; ++m) {
+            const bool dn = ((uint32_t)meta[2 * i + 1] >> m) & 1u;
+            const size_t j = (size_t)i * M + m;
+            if (state) state[j] = sv[j];
+            if (reward) reward[j] = rv[j];
+            if (done) done[j] = (uint8_t)dn;
+            // a leaf keeps its vectors (U recomputed as update() computed it, deterministic.py:51-59: same host
+            // operations as the planning tables); an expanded node holds the backed-up scalars
+            if (lower) lower[j] = fc[i] >= 0 ? lmin[i] : lv[j];
+            if (upper) upper[j] = fc[i] >= 0 ? umin[i] : (i == 0 ? 0.0 : (dn ? lv[j] : lv[j] + pow(gamma, (double)d) / (1 - gamma)));
+        }
+    }
+    if (n_nodes) *n_nodes = n;
+    return MP_OK;
+}
+
+} // extern "C"

@@ -184,6 +184,17 @@ class FiniteMDPEnv(object):
     def to_finite_mdp(self):
         return self.mdp
 
+    def copy_with_config(self, config):
+        """A copy of this environment -- same current state and step count -- with ``config`` applied: the
+        preprocessor the reference's model lists use to derive candidate models of a finite MDP
+        (scripts/configs/FiniteMDPEnv/large/agents/discrete_robust_planner.json: ``{"method": "copy_with_config",
+        "args": {mode, transition, reward, terminal}}``).  [restated: ``finite_mdp`` is absent from this image]"""
+        new = copy.deepcopy(self)
+        state, steps = self.mdp.state, self.steps
+        new.configure(dict(config))
+        new.mdp.state, new.steps = state, steps
+        return new
+
     def render(self, *a, **k):
         return None
 

@@ -58,6 +58,9 @@ SIGNATURES = {
     "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               c_i32]),
     "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_model_load_joint": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
+    "mp_ropd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp, c_i32]),
+    "mp_ropd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_saopd_create": (C.c_int, [_vp, _vp, c_i32, P(_vp)]),
     "mp_saopd_free": (C.c_int, [_vp]),
     "mp_saopd_plan": (C.c_int, [_vp, _vp, _vp, c_i32, c_f64, c_f64, c_f64, c_i32, c_i32, _vp, c_i32, _vp, _vp, _vp, _vp,
@@ -203,6 +206,20 @@ class Context(object):
             _check(self._lib.mp_model_set_available(h, _ptr(av)))
             model.available = av.astype(bool)
         return model
+
+    def load_joint(self, transitions, rewards, terminals=None, done_rule="source"):
+        """A joint environment of M models (agents/robust/robust.py:9-26): transitions int [M,S,A], rewards [M,S,A],
+        terminals [M,S] (each model's own flags) or None."""
+        t = np.ascontiguousarray(transitions, dtype=np.int64)
+        r = np.ascontiguousarray(rewards, dtype=np.float64)
+        if t.shape != r.shape or t.ndim != 3:
+            raise ValueError("transitions and rewards must both be [M, S, A]")
+        m, s, a = t.shape
+        term = None if terminals is None else np.ascontiguousarray(np.asarray(terminals).reshape(m, s).astype(np.uint8))
+        h = _vp()
+        _check(self._lib.mp_model_load_joint(self._h, m, s, a, _ptr(t), _ptr(r), _ptr(term), int(done_rule == "next"),
+                                             C.byref(h)))
+        return Model(self, h, MODE_DETERMINISTIC, m, s, a, 0)
 
     def load_dense(self, transition, reward, terminal=None):
         """Dense model: transition float [S,A,S] or [M,S,A,S] (numpy -> copied; torch cuda tensor -> borrowed)."""
@@ -422,6 +439,49 @@ class Context(object):
                                      float(terminal_reward), _ptr(rng_state), int(max_plan_len), _ptr(plans),
                                      _ptr(plan_len), _ptr(root_lower), _ptr(root_upper), _ptr(env_steps),
                                      _ptr(status), MP_MEM_DEVICE))
+
+    def ropd_plan(self, model, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len=64):
+        """DiscreteRobustPlanner.plan for a batch of roots of a joint model; root_state int [n] (every model starts in
+        the same state) or [n, M]."""
+        rs = np.asarray(root_state, dtype=np.int32)
+        if rs.ndim == 1:
+            rs = np.repeat(rs[:, None], model.M, axis=1)
+        rs = np.ascontiguousarray(rs.reshape(-1, model.M))
+        n = rs.shape[0]
+        if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+                and rng_state.size == n * 6):
+            raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6]")
+        mpl = int(max_plan_len)
+        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                   root_lower=np.zeros(n, np.float64), root_upper=np.zeros(n, np.float64),
+                   env_steps=np.zeros(n, np.int64), status=np.zeros(n, np.int32))
+        _check(self._lib.mp_ropd_plan(self._h, model._h, n, _ptr(rs), int(budget), float(gamma), float(terminal_reward),
+                                      _ptr(rng_state), mpl, _ptr(out["plans"]), _ptr(out["plan_len"]),
+                                      _ptr(out["root_lower"]), _ptr(out["root_upper"]), _ptr(out["env_steps"]),
+                                      _ptr(out["status"]), MP_MEM_HOST))
+        return out
+
+    def ropd_plan_device(self, model, n_roots, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len,
+                         plans=None, plan_len=None, root_lower=None, root_upper=None, env_steps=None, status=None):
+        _check(self._lib.mp_ropd_plan(self._h, model._h, int(n_roots), _ptr(root_state), int(budget), float(gamma),
+                                      float(terminal_reward), _ptr(rng_state), int(max_plan_len), _ptr(plans),
+                                      _ptr(plan_len), _ptr(root_lower), _ptr(root_upper), _ptr(env_steps),
+                                      _ptr(status), MP_MEM_DEVICE))
+
+    def ropd_tree(self, root, cap, n_models):
+        m = int(n_models)
+        t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros((cap, m), np.int32),
+                 depth=np.zeros(cap, np.int32), reward=np.zeros((cap, m), np.float64), lower=np.zeros((cap, m), np.float64),
+                 upper=np.zeros((cap, m), np.float64), done=np.zeros((cap, m), np.uint8), count=np.zeros(cap, np.int64),
+                 first_child=np.zeros(cap, np.int32))
+        n = c_i32()
+        _check(self._lib.mp_ropd_tree_export(self._h, int(root), int(cap), C.byref(n), _ptr(t["parent"]),
+                                             _ptr(t["action"]), _ptr(t["state"]), _ptr(t["depth"]), _ptr(t["reward"]),
+                                             _ptr(t["lower"]), _ptr(t["upper"]), _ptr(t["done"]), _ptr(t["count"]),
+                                             _ptr(t["first_child"])))
+        t = {k: v[:n.value].copy() for k, v in t.items()}
+        t["n_children"] = np.where(t["first_child"] >= 0, int(t["action"].max(initial=-1)) + 1, 0).astype(np.int32)
+        return t
 
     def opd_tree(self, root, cap):
         t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),

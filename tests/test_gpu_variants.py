@@ -306,3 +306,104 @@ def test_opd_restricted_actions_batch_vs_oracle(ctx, n_actions, budget, variant,
     assert np.array_equal(out["root_lower"], ref["root_lower"]) and np.array_equal(out["root_upper"], ref["root_upper"])
     np.testing.assert_array_equal(rng, ref["rng_after"])
     model.close()
+
+
+# ------------------------------------------------------------------------------------------- discrete robust OPD
+DRP = "<class 'rl_agents_amd.agents.robust.robust.DiscreteRobustPlannerAgent'>"
+
+
+def _robust_models(z, p):
+    m = int(z[p + "/n_models"])
+    cfgs = [mdp_from_golden(z, "{}/mdp{}".format(p, i)) for i in range(m)]
+    return cfgs, (np.stack([c["transition"] for c in cfgs]), np.stack([c["reward"] for c in cfgs]),
+                  np.stack([c["terminal"] for c in cfgs]))
+
+
+@pytest.mark.parametrize("variant", ["lds", "global"])
+def test_discrete_robust_planner_goldens(ctx, z, variant, monkeypatch):
+    """mp_ropd_plan against the reference's DiscreteRobustPlanner / RobustNode: plans, min-over-model root bounds, full
+    trees with per-model vectors, generator states."""
+    from tests.helpers import bfs_children
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    for name in names(z, "robust"):
+        p = "robust/" + name
+        cfgs, (t, r, term) = _robust_models(z, p)
+        m, _, a_ = r.shape
+        budget = int(z[p + "/budget"])
+        model = ctx.load_joint(t, r, term)
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        out = ctx.ropd_plan(model, [int(z[p + "/s0"])], budget, float(z[p + "/gamma"]), float(z[p + "/terminal_reward"]), rng,
+                            max_plan_len=budget // a_ + 1)
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert out["root_lower"][0] == float(z[p + "/root_lower"]) and out["root_upper"][0] == float(z[p + "/root_upper"])
+        assert int(out["env_steps"][0]) == int(z[p + "/env_steps"]) and out["status"][0] == 0, name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        tree = ctx.ropd_tree(0, 1 + (budget // a_) * a_, m)
+        assert_keyed_tree_equal(z, p + "/tree", tree, dict(count="count", depth="depth", lower="lower", upper="upper",
+                                                          reward="reward", done="done"))
+        order, _ = bfs_children(tree["first_child"], tree["n_children"])
+        assert np.array_equal(tree["state"][order][1:], z[p + "/tree/obs"][1:]), name
+        model.close()
+
+
+def test_discrete_robust_planner_agent(z):
+    """DiscreteRobustPlannerAgent through agent_factory: `models` = preprocessor lists (copy_with_config) as in the
+    reference's configs; plan, root bounds and the exported tree's per-model vectors."""
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    for name in ("large_pair_b100", "highway_triple_tr05", "garnet_pair_terminals"):
+        p = "robust/" + name
+        cfgs, _ = _robust_models(z, p)
+        env = _env(cfgs[0], state=int(z[p + "/s0"]))
+        models = [[{"method": "copy_with_config",
+                    "args": dict(mode="deterministic", transition=c["transition"].tolist(), reward=c["reward"].tolist(),
+                                 terminal=c["terminal"].astype(int).tolist())}] for c in cfgs]
+        agent = agent_factory(env, dict(__class__=DRP, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
+                                        terminal_reward=float(z[p + "/terminal_reward"]), models=models))
+        agent.seed(int(z[p + "/seed"]))
+        plan = agent.plan(int(z[p + "/s0"]))
+        np.testing.assert_array_equal(plan, z[p + "/plan"], err_msg=name)
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        root = agent.planner.root
+        assert root.count == int(z[p + "/root_count"]) and root.value_lower == float(z[p + "/root_lower"])
+        assert root.value_upper == float(z[p + "/root_upper"])
+        leaf = root
+        while leaf.children:
+            leaf = leaf.children[max(leaf.children)]
+        assert isinstance(leaf.value_lower, np.ndarray) and leaf.value_lower.shape == (len(cfgs),)
+        assert env.mdp.state == int(z[p + "/s0"])
+    trap = _env(dict(mode="deterministic", transition=np.array([[1, 2], [1, 1], [3, 4], [3, 3], [4, 4]]),
+                     reward=np.array([[0, 0], [0, 0], [0, 0], [1, 1], [-1, -1]], dtype=float),
+                     terminal=np.array([0, 1, 0, 1, 1]), max_steps=0))
+    with pytest.raises(ValueError):
+        agent_factory(trap, dict(__class__=DRP, budget=20, models=[[], []])).plan(0)
+
+
+@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("n_models,n_actions,budget", [(1, 3, 200), (2, 5, 500), (3, 4, 100), (5, 2, 101), (16, 7, 300)])
+def test_discrete_robust_planner_batch_vs_oracle(ctx, n_models, n_actions, budget, variant, monkeypatch):
+    """70 roots with distinct joint states (every model in its own state) per launch vs the oracle."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    cfgs = [generators.random_deterministic(300, n_actions, seed=100 * n_models + i, terminal_rate=0.05) for i in range(n_models)]
+    t = np.stack([c["transition"] for c in cfgs])
+    r = np.stack([c["reward"] for c in cfgs])
+    term = np.stack([c["terminal"] for c in cfgs])
+    model = ctx.load_joint(t, r, term)
+    n = 70
+    s0 = np.random.Generator(np.random.PCG64(n_actions)).integers(0, 300, size=(n, n_models)).astype(np.int32)
+    g = np.random.Generator(np.random.PCG64(7))
+    rng = g.integers(0, 2 ** 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+    rng[:, 3] |= np.uint64(1)
+    rng[:, 4:] = 0
+    rng_ref = rng.copy()
+    mpl = budget // n_actions + 2
+    out = ctx.ropd_plan(model, s0, budget, 0.9, 0.25, rng, max_plan_len=mpl)
+    ref = oracle.ropd_plan_batch(t, r, term, s0, budget, 0.9, 0.25, rng_ref, max_plan_len=mpl, n_threads=8)
+    for k in ("status", "plans", "plan_len", "env_steps"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    assert np.array_equal(out["root_lower"], ref["root_lower"]) and np.array_equal(out["root_upper"], ref["root_upper"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    model.close()
