@@ -224,6 +224,206 @@ __global__ __launch_bounds__(1024) void vi_det_small(ViSmallArgs q)
     }
 }
 
+// ------------------------------------------------------------------ persistent deterministic VI ---
+// Deterministic problems too big for one workgroup's LDS but small enough that every state can own a thread of ONE
+// co-resident grid (S <= 256 x 1024): the whole fixed-point iteration in ONE launch, synchronised by DATAFLOW.
+//   * a thread keeps its state's T / R rows and its last Q rows in REGISTERS for the whole solve, so a sweep gathers
+//     |A| V values, not 2|A| (the allclose test needs Q_k, which the chained launches recompute from V_{k-1});
+//   * V lives in a ring of kRing slots of 16-byte entries = two self-validating 8-byte granules {sweep tag, half of the
+//     f64}, written write-through and read L1-bypassing with relaxed agent-scope accesses (cdna_hip_programming.md
+//     Guideline 16, form R2: "the data is the flag"): a thread starts sweep k as soon as ITS |A| successors carry tag
+//     k -- no grid barrier, no fence, nothing but the data dependency of the algorithm on the critical path;
+//   * the only global agreement the reference needs -- did ANY element move in sweep j (np.allclose) -- is taken off
+//     that path: workgroups add {1 arrival, moved flag} to a per-sweep word and every workgroup reads the word of sweep
+//     k - kLag at sweep k (by then complete in steady state: the wait is a lagged barrier that also bounds how far
+//     workgroups drift apart: a writer in sweep k knows that everybody has left sweep k - 1 - kLag, so the slot it
+//     overwrites -- V_{k+1-kRing} -- has no reader left with kRing = kLag + 2 slots).  Threads keep their last kLag + 1
+//     Q rows, so the first sweep j with no movement -- found kLag sweeps late -- still returns the reference's Q_j.
+struct ViPersistArgs {
+    ViDetArgs d;      // T / R / term, gamma, tolerances, M, S, A, robust, vform
+    int iterations, n_wg, block;
+    unsigned long long *Vring; // [kRing][S][2] granules
+    unsigned *sync;   // [0] timeout flag, [1 + k] arrivals (low 16 bits) + moved count (high bits) of sweep k
+    double *Q_out, *V_out;
+    int32_t *sweeps_out;
+};
+
+constexpr int kLag = 2, kRing = kLag + 2;
+typedef __attribute__((address_space(1))) unsigned gu32_t;
+typedef __attribute__((address_space(1))) unsigned long long gu64_t;
+#define MP_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+constexpr unsigned kSpinLimit = 1u << 22;
+
+template <int AT, int MT>
+__global__ __launch_bounds__(1024) void vi_det_persist(ViPersistArgs q)
+{
+    const ViDetArgs &p = q.d;
+    const int S = p.S, tid = threadIdx.x;
+    const int s = blockIdx.x * blockDim.x + tid;
+    const bool own = s < S;
+    const long msa = (long)S * AT, sa0 = (long)(own ? s : 0) * AT;
+    __shared__ unsigned bcast[4];
+    int32_t t[MT][AT];
+    double r[MT][AT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int a = 0; a < AT; ++a) { t[m][a] = p.T[m * msa + sa0 + a]; r[m][a] = p.R[m * msa + sa0 + a]; }
+    const bool term_s = (!p.robust && p.term && own) ? p.term[s] != 0 : false;
+    gu32_t *tmo = (gu32_t *)q.sync, *words = (gu32_t *)(q.sync + 1);
+    gu64_t *ring = (gu64_t *)q.Vring;
+    // Q_k, Q_{k-1}, ..., Q_{k-kLag} and the matching own V values; Q_0 = 0 (value_iteration.py:43)
+    double qh[kLag + 1][AT], vh[kLag + 1];
+#pragma unroll
+    for (int h = 0; h <= kLag; ++h) {
+        vh[h] = 0.0;
+#pragma unroll
+        for (int a = 0; a < AT; ++a) qh[h][a] = 0.0;
+    }
+    int stop = -1;      // first sweep j whose allclose test passed (returned iterate = Q_j)
+    int hist = 0;       // which held row is the returned iterate
+    bool failed = false;
+    for (int k = 0; k < q.iterations; ++k) {
+        // the verdict word of sweep k - kLag is normally complete by now: read it under the gather (off the chain)
+        unsigned early = 0;
+        if (tid == 0 && k >= kLag) early = __hip_atomic_load(words + (k - kLag), MP_RLX_AGENT);
+        // ---- gather V_k at the successors: poll the granules until they carry tag k (V_0 = 0 needs none)
+        double qn[AT];
+        bool ok = true;
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+            double vc[AT];
+#pragma unroll
+            for (int a = 0; a < AT; ++a) vc[a] = 0.0;
+            if (k > 0 && own) {
+                const gu64_t *slot = ring + (long)(k % kRing) * S * 2;
+                unsigned spins = 0;
+                while (true) {
+                    bool all = true;
+#pragma unroll
+                    for (int a = 0; a < AT; ++a) {
+                        const unsigned long long lo = __hip_atomic_load(slot + 2L * t[m][a], MP_RLX_AGENT);
+                        const unsigned long long hi = __hip_atomic_load(slot + 2L * t[m][a] + 1, MP_RLX_AGENT);
+                        all &= (unsigned)(lo >> 32) == (unsigned)k && (unsigned)(hi >> 32) == (unsigned)k;
+                        vc[a] = __hiloint2double((int)(unsigned)hi, (int)(unsigned)lo);
+                    }
+                    if (all) break;
+                    if (++spins > kSpinLimit || __hip_atomic_load(tmo, MP_RLX_AGENT)) { ok = false; break; }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < AT; ++a) {
+                const double qm = r[m][a] + p.gamma * (term_s ? 0.0 : vc[a]);
+                if (m == 0 || qm < qn[a]) qn[a] = qm;       // robust_value_iteration.py:46-48 (MT = 1: plain VI)
+            }
+        }
+        bool nc = false;
+        double vmax = qn[0];
+#pragma unroll
+        for (int a = 0; a < AT; ++a) {
+            if (!p.vform) nc |= !isclose_np(qh[0][a], qn[a], p.rtol, p.atol);
+            if (a > 0 && qn[a] > vmax) vmax = qn[a];
+        }
+        if (p.vform) nc = !isclose_np(vh[0], vmax, p.rtol, p.atol);
+        if (own && ok) { // publish V_{k+1}[s]: two granules tagged k + 1 (write-through)
+            gu64_t *dst = ring + ((long)((k + 1) % kRing) * S + s) * 2;
+            const unsigned long long tag = (unsigned long long)(unsigned)(k + 1) << 32;
+            __hip_atomic_store(dst, tag | (unsigned)__double2loint(vmax), MP_RLX_AGENT);
+            __hip_atomic_store(dst + 1, tag | (unsigned)__double2hiint(vmax), MP_RLX_AGENT);
+        }
+        // ---- per-workgroup: aggregate "moved" (bit 0) and "timed out" (bit 1), arrive for sweep k, publish the verdict
+        // of sweep k - kLag to the other waves
+        const int agg = __syncthreads_or((own && nc ? 1 : 0) | (ok ? 0 : 2));
+        unsigned *bc = bcast + 2 * (k & 1);                 // double-buffered: one barrier per sweep
+        if (tid == 0) {
+            unsigned bad = (agg & 2) ? 1u : 0u, verdict = 1u;
+            if (!bad) __hip_atomic_fetch_add(words + k, 1u + ((agg & 1) ? 0x10000u : 0u), MP_RLX_AGENT);
+            if (!bad && k >= kLag) {
+                unsigned spins = 0, w = early;
+                while ((w & 0xffffu) < (unsigned)q.n_wg) {  // (steady state: complete already)
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit || __hip_atomic_load(tmo, MP_RLX_AGENT)) { bad = 1; break; }
+                    w = __hip_atomic_load(words + (k - kLag), MP_RLX_AGENT);
+                }
+                verdict = w >> 16;
+            }
+            if (bad) __hip_atomic_store(tmo, 1u, MP_RLX_AGENT);
+            bc[0] = bad; bc[1] = verdict;
+        }
+        __syncthreads();
+        const unsigned bad = bc[0], verdict = bc[1];
+        if (bad) { failed = true; break; }
+        // rows held here: qh[h] = Q_{k-h}.  allclose(Q_j, Q_{j+1}) held at j = k - kLag: return Q_j = qh[kLag]
+        if (k >= kLag && verdict == 0) { stop = k - kLag; hist = kLag; break; }
+        // shift the history: qh[0] = Q_{k+1}
+#pragma unroll
+        for (int h = kLag; h > 0; --h) {
+            vh[h] = vh[h - 1];
+#pragma unroll
+            for (int a = 0; a < AT; ++a) qh[h][a] = qh[h - 1][a];
+        }
+        vh[0] = vmax;
+#pragma unroll
+        for (int a = 0; a < AT; ++a) qh[0][a] = qn[a];
+    }
+    // ---- all `iterations` sweeps ran: rows qh[h] = Q_{N-h}.  The last kLag sweeps have not been judged yet; their
+    // words are complete once every workgroup has arrived for them (bounded wait).
+    if (!failed && stop < 0) {
+        const int n_it = q.iterations;
+        if (tid == 0) {
+            unsigned bad = 0, first = 0xffffffffu;
+            for (int j = max(0, n_it - kLag); j < n_it && !bad; ++j) {
+                unsigned spins = 0, w;
+                while (((w = __hip_atomic_load(words + j, MP_RLX_AGENT)) & 0xffffu) < (unsigned)q.n_wg) {
+                    __builtin_amdgcn_s_sleep(1);
+                    if (++spins > kSpinLimit || __hip_atomic_load(tmo, MP_RLX_AGENT)) { bad = 1; break; }
+                }
+                if (!bad && (w >> 16) == 0 && first == 0xffffffffu) first = (unsigned)j;
+            }
+            if (bad) __hip_atomic_store(tmo, 1u, MP_RLX_AGENT);
+            bcast[0] = bad; bcast[1] = first;
+        }
+        __syncthreads();
+        if (bcast[0]) failed = true;
+        else if (bcast[1] != 0xffffffffu) { stop = (int)bcast[1]; hist = n_it - stop; }
+    }
+    const int sweeps = failed ? -1 : (stop >= 0 ? stop + 1 : q.iterations);
+    if (blockIdx.x == 0 && tid == 0 && q.sweeps_out) *q.sweeps_out = sweeps;
+    if (own) {
+        double vout = vh[0], qout[AT];
+#pragma unroll
+        for (int a = 0; a < AT; ++a) qout[a] = qh[0][a];
+#pragma unroll
+        for (int h = 1; h <= kLag; ++h)
+            if (hist == h) {
+                vout = vh[h];
+#pragma unroll
+                for (int a = 0; a < AT; ++a) qout[a] = qh[h][a];
+            }
+        if (q.V_out) q.V_out[s] = failed ? NAN : vout;
+        if (q.Q_out)
+#pragma unroll
+            for (int a = 0; a < AT; ++a) q.Q_out[sa0 + a] = failed ? NAN : qout[a];
+    }
+}
+
+template <int AT, int MT>
+static void vi_persist_launch(const ViPersistArgs &q, hipStream_t st)
+{
+    hipLaunchKernelGGL((vi_det_persist<AT, MT>), dim3((unsigned)q.n_wg), dim3((unsigned)q.block), 0, st, q);
+}
+
+// every (|A|, models) pair the persistent kernel is instantiated for; false = use the chained launches
+static bool vi_persist_dispatch(const ViPersistArgs &q, int A, int M, hipStream_t st)
+{
+#define MP_VP(a, m) if (A == a && M == m) { vi_persist_launch<a, m>(q, st); return true; }
+    MP_VP(2, 1) MP_VP(3, 1) MP_VP(4, 1) MP_VP(5, 1) MP_VP(6, 1) MP_VP(8, 1)
+    MP_VP(2, 2) MP_VP(3, 2) MP_VP(4, 2) MP_VP(5, 2) MP_VP(6, 2) MP_VP(8, 2)
+    MP_VP(2, 3) MP_VP(3, 3) MP_VP(4, 3) MP_VP(5, 3) MP_VP(2, 4) MP_VP(3, 4) MP_VP(4, 4)
+#undef MP_VP
+    return false;
+}
+
 template <int AT>
 static int vi_small_launch(const ViSmallArgs &q, size_t lds, int threads, hipStream_t st)
 {
@@ -461,6 +661,36 @@ __global__ __launch_bounds__(256) void vi_gen_emit(ViGenEmitArgs e)
     if (e.V_out && i < e.S) e.V_out[i] = e.Vbuf[(long)(j & 1) * e.S + i];
 }
 
+// The persistent kernel needs the whole grid co-resident (at most one workgroup per CU is used, well inside what the
+// hardware admits) and an instantiation for (|A|, models).  MP_VI_NO_PERSIST=1: chained launches.
+// threads per workgroup: few waves per CU keep the consumer's memory queue short (the hand-off latency sits there),
+// few workgroups keep the per-sweep arrival atomics (one word, ~12 ns each) off the throughput limit
+static int vi_persist_block(int S)
+{
+    if (const char *e = getenv("MP_VI_PERSIST_BLOCK")) {
+        const int v = atoi(e);
+        if (v == 64 || v == 128 || v == 256 || v == 512 || v == 1024) return v;
+    }
+    (void)S;
+    return 256;
+}
+
+static bool vi_persist_ok(mp_ctx *ctx, int S, int A, int M)
+{
+    if (getenv("MP_VI_NO_PERSIST")) return false;
+    const int n_wg = (S + vi_persist_block(S) - 1) / vi_persist_block(S);
+    if (n_wg > ctx->prop.multiProcessorCount) return false;
+    // Measured on MI355X (tools/micro_vi_persist.py): 40 workgroups (S = 10 000) 2.6 us per sweep against
+    // 3.0 us for the chained launches, and the early exit really ends the solve; 196 workgroups (S = 50 000, M = 2)
+    // 5.4 us against 4.2 us -- the per-sweep arrivals serialise on one word and the hand-offs queue behind each other.
+    if (n_wg > 64 && !getenv("MP_VI_PERSIST_BLOCK")) return false;
+    const bool at = A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8;
+    if (!at || M < 1 || M > 4) return false;
+    if (M == 3 && A > 5) return false;
+    if (M == 4 && A > 4) return false;
+    return true;
+}
+
 static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double rtol, double atol, int robust,
                   int vform, double *Q_out, double *V_out, int32_t *sweeps_out, int mem)
 {
@@ -508,6 +738,24 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
             MP_TRY(vi_small_launch<0>(q, small_lds, threads, st));
             break;
         }
+        MP_TRY(kernels_end(ctx, 1));
+    } else if (m->mode == MP_MODE_DETERMINISTIC && vi_persist_ok(ctx, S, A, M)) {
+        // one persistent launch: every state owns a thread of a co-resident grid (see vi_det_persist)
+        ViPersistArgs q;
+        memset(&q, 0, sizeof(q));
+        q.d.M = M; q.d.S = S; q.d.A = A; q.d.robust = robust; q.d.vform = vform;
+        q.d.T = m->T; q.d.R = m->R; q.d.term = m->term; q.d.gamma = gamma; q.d.rtol = rtol; q.d.atol = atol;
+        q.iterations = iterations;
+        q.block = vi_persist_block(S);
+        q.n_wg = (S + q.block - 1) / q.block;
+        q.Q_out = dQ; q.V_out = dV; q.sweeps_out = dSw;
+        MP_TRY(ws_get(ctx, WS_VI1, (size_t)kRing * S * 2, &q.Vring));
+        MP_TRY(ws_get(ctx, WS_VI3, (size_t)iterations + 4, &q.sync));
+        // Guideline 16: every polled word is re-initialised by every call (tags 0 never match a sweep >= 1)
+        MP_HIP(hipMemsetAsync(q.Vring, 0, (size_t)kRing * S * 2 * sizeof(unsigned long long), st));
+        MP_HIP(hipMemsetAsync(q.sync, 0, ((size_t)iterations + 4) * sizeof(unsigned), st));
+        MP_TRY(kernels_begin(ctx));
+        if (!vi_persist_dispatch(q, A, M, st)) return fail(MP_ERR_ARG, "vi: no persistent kernel for |A| = %d, M = %d", A, M);
         MP_TRY(kernels_end(ctx, 1));
     } else if (m->mode == MP_MODE_DETERMINISTIC) {
         double *Vb = nullptr;
