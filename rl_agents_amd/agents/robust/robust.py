@@ -111,10 +111,12 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
             raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
         out["rng_states"] = rng_states
         self.last, self._root, self._last_actions, self._last_models = out, None, model.A, model.M
+        self.claim_device_tree()
         self.env_steps += int(out["env_steps"].sum())
         return out
 
     def export_tree(self, root=0):
+        self.require_device_tree()
         a, m = self._last_actions, self._last_models
         arrays = self.models.ctx.ropd_tree(root, 1 + (int(self.config["budget"]) // a) * a, m)
         lower, upper = arrays["lower"], arrays["upper"]

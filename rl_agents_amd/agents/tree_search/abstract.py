@@ -228,6 +228,19 @@ class AbstractPlanner(Configurable):
             self._root = self.export_tree(0)
         return self._root
 
+    # The trees of the last plan live in workspaces of the process-wide device context, shared by every planner of the
+    # process: a planner claims them when it plans and may only read them back while the claim still stands.
+    def claim_device_tree(self):
+        self.models.ctx._tree_owner = self
+
+    def owns_device_tree(self):
+        return getattr(self.models.ctx, "_tree_owner", None) is self
+
+    def require_device_tree(self):
+        if not self.owns_device_tree():
+            raise RuntimeError("the tree of this planner's last plan is no longer on the device: another planner of the "
+                               "process has planned since (export `planner.root` before planning with another agent)")
+
     def step_tree(self, actions):
         strategy = self.config["step_strategy"]
         if strategy == "reset":

@@ -31,10 +31,12 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
             raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
         out["rng_states"] = rng_states
         self.last, self._root, self._last_actions = out, None, model.A
+        self.claim_device_tree()
         self.env_steps += int(out["env_steps"].sum())
         return out
 
     def export_tree(self, root=0):
+        self.require_device_tree()
         a = self._last_actions
         cap = 1 + (int(self.config["budget"]) // a) * a
         arrays = self.models.ctx.opd_tree(root, cap)

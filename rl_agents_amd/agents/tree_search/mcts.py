@@ -104,7 +104,7 @@ class MCTS(AbstractPlanner):
 
     def reset(self):
         super(MCTS, self).reset()
-        self._keep_action = None
+        self._armed = False         # the device holds kept trees armed for re-rooting by this planner
 
     def step_by_subtree(self, action):
         """Tree reuse: the device re-roots the kept trees at the start of the next plan, provided the trees on the
@@ -113,12 +113,15 @@ class MCTS(AbstractPlanner):
             # the reference re-roots at the ACTION node, whose children are keyed by observation strings: its next
             # run() would step the environment with such a key (abstract.py:195-206 + mcts.py:143-146)
             raise NotImplementedError("step_strategy 'subtree' does not work on closed-loop trees (in the reference either)")
-        ctx = self.models.ctx
-        if self.last is None or getattr(ctx, "_uct_tree_owner", None) is not self:
+        # every act() steps the tree (abstract.py:70-82), also between two plans when receding_horizon > 1: the device
+        # descends one level per call (a pending re-rooting is applied when the next one is armed)
+        live = self.last is not None or self._armed
+        if not live or not self.owns_device_tree():
             self.step_by_reset()
             return
-        self._keep_action = int(action)
+        self.models.ctx.uct_step_tree([int(action)])
         self.last, self._root = None, None
+        self._armed = True
 
     def plan_batch(self, state, root_states, root_steps=None, rng_states=None, keep_actions=None):
         model = self.model_for(state)
@@ -127,12 +130,10 @@ class MCTS(AbstractPlanner):
             rng_states = self.batch_rng_states(n)
         cfg = self.config
         ctx = self.models.ctx
-        if keep_actions is None and getattr(self, "_keep_action", None) is not None and n == 1:
-            keep_actions = [self._keep_action]
-        self._keep_action = None
-        if keep_actions is not None and getattr(ctx, "_uct_tree_owner", None) is self:
-            ctx.uct_step_tree(keep_actions)
-        else:
+        armed, self._armed = self._armed and n == 1, False
+        if keep_actions is not None and self.owns_device_tree():
+            ctx.uct_step_tree(keep_actions)             # batched callers hand the executed actions over here
+        elif not (armed and self.owns_device_tree()):
             ctx.uct_reset_tree()
         available = getattr(model, "available", None)
         if self.policy_source is not None or available is not None:
@@ -154,7 +155,7 @@ class MCTS(AbstractPlanner):
             self._last_tables = None
         out["rng_states"] = rng_states
         self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
-        ctx._uct_tree_owner = self
+        self.claim_device_tree()
         self.env_steps += int(out["env_steps"].sum())
         return out
 
@@ -200,6 +201,7 @@ class MCTS(AbstractPlanner):
         action is followed by one only if its node was visited (an unvisited action node has no child yet)."""
         if not actions:
             return []
+        self.require_device_tree()
         tree = self.models.ctx.uct_tree(0)
         node = 0
         for a in actions:       # creation-order arrays: children of `node` are contiguous from first_child
@@ -244,6 +246,7 @@ class MCTS(AbstractPlanner):
                 stack.append((obs_node, e))
 
     def _export_open_loop(self, root=0):
+        self.require_device_tree()
         arrays = self.models.ctx.uct_tree(root)
         if self._last_tables is None:
             return build_tree(arrays, "value", prior=policy_probabilities(self.prior_policy, self._last_actions))

@@ -54,6 +54,7 @@ struct TreeMeta {
     double gamma = 0.0; // robust opd: the export recomputes leaf upper-bound vectors
     int buf = 0;        // UCT: which of the two tree workspaces (WS_TREE0 / WS_TREE2) holds the current trees
     bool armed = false; // UCT: mp_uct_step_tree was called; the next plan re-roots and continues
+    long kept_bound = 0; // UCT: upper bound on the nodes a kept (re-rooted) tree can hold, see uct_plan_impl
 };
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,

@@ -603,8 +603,8 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
 // waits in the BFS queue its first_child field holds its OLD id.  A never-expanded root gives size 0 (fresh tree).
 __global__ __launch_bounds__(64) void uct_reroot_kernel(int n_roots, int A, int cap_old, int cap_new,
                                                         const UctNode *__restrict__ old_trees, UctNode *__restrict__ new_trees,
-                                                        const int32_t *__restrict__ n_old, const int32_t *__restrict__ actions,
-                                                        int32_t *__restrict__ n_new)
+                                                        const int32_t *n_old, const int32_t *__restrict__ actions,
+                                                        int32_t *n_new) // (n_old and n_new may be the same array)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_roots) return;
@@ -674,6 +674,25 @@ static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, b
 } // namespace mp
 
 using namespace mp;
+
+// Apply the re-rooting armed by mp_uct_step_tree: every kept tree -> the subtree under its root's child actions[i], written
+// into the other tree workspace with node stride cap_new (>= the current tree sizes); sizes are updated in place.
+static int uct_reroot_now(mp_ctx *ctx, long cap_new)
+{
+    const int n_roots = ctx->tree.n_roots, A = ctx->tree.A;
+    const int old_slot = ctx->tree.buf ? WS_TREE2 : WS_TREE0, new_slot = ctx->tree.buf ? WS_TREE0 : WS_TREE2;
+    UctNode *nw = nullptr;
+    MP_TRY(ws_get(ctx, new_slot, (size_t)n_roots * cap_new, &nw));
+    int32_t *sizes = (int32_t *)ctx->ws[WS_TREE1].p;
+    const int32_t *acts = (const int32_t *)ctx->ws[WS_TREE3].p;
+    hipLaunchKernelGGL(uct_reroot_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), 0, ctx->stream, n_roots, A,
+                       ctx->tree.cap, (int)cap_new, (const UctNode *)ctx->ws[old_slot].p, nw, sizes, acts, sizes);
+    MP_HIP(hipGetLastError());
+    ctx->tree.buf ^= 1;
+    ctx->tree.cap = (int)cap_new;
+    ctx->tree.armed = false;
+    return MP_OK;
+}
 
 static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int32_t n_roots, const void *root_state,
                          const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
@@ -770,25 +789,26 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // trees: fresh ones, or (step_strategy "subtree") the kept ones re-rooted into the other buffer with room
     // for this plan's expansions
     int32_t *d_nn = nullptr;
-    MP_TRY(ws_get(ctx, WS_TREE1, (size_t)2 * n_roots, &d_nn)); // [0, n): sizes after a plan, [n, 2n): after re-rooting
+    MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &d_nn)); // per-root tree sizes (updated in place by re-rooting and planning)
     a.n_nodes_in = nullptr;
     a.n_nodes_out = d_nn;
     long cap_use = cap;
     const bool cont = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
-    ctx->tree.armed = false;
     if (cont) {
-        const int old_slot = ctx->tree.buf ? WS_TREE2 : WS_TREE0, new_slot = ctx->tree.buf ? WS_TREE0 : WS_TREE2;
-        cap_use = (long)ctx->tree.cap + (long)episodes * A;
-        UctNode *nw = nullptr;
-        MP_TRY(ws_get(ctx, new_slot, (size_t)n_roots * cap_use, &nw));
-        const int32_t *acts = (const int32_t *)ctx->ws[WS_TREE3].p;
-        hipLaunchKernelGGL(uct_reroot_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), 0, st, n_roots, A,
-                           ctx->tree.cap, (int)cap_use, (const UctNode *)ctx->ws[old_slot].p, nw, d_nn, acts, d_nn + n_roots);
-        a.tree = nw;
-        a.n_nodes_in = d_nn + n_roots;
-        ctx->tree.buf ^= 1;
+        // a kept subtree only holds nodes created by the last `horizon` plans (a node at depth d survives d re-rootings
+        // and d <= horizon), so the stride stays O(horizon * episodes * |A|) however long the episode runs
+        // (the largest horizon * episodes of the plans since the last fresh tree, should the caller vary them)
+        const long now = 1 + (long)horizon * episodes * A;
+        if (now > ctx->tree.kept_bound) ctx->tree.kept_bound = now;
+        const long bound = ctx->tree.kept_bound;
+        cap_use = (ctx->tree.cap < bound ? (long)ctx->tree.cap : bound) + (long)episodes * A;
+        MP_TRY(uct_reroot_now(ctx, cap_use));
+        a.tree = (UctNode *)ctx->ws[ctx->tree.buf ? WS_TREE2 : WS_TREE0].p;
+        a.n_nodes_in = d_nn;
     } else {
+        ctx->tree.armed = false;
         ctx->tree.buf = 0;
+        ctx->tree.kept_bound = 1 + (long)horizon * episodes * A;
         MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap_use, &a.tree));
     }
     a.cap = (int)cap_use;
@@ -978,6 +998,9 @@ int mp_uct_step_tree(mp_ctx *ctx, int32_t n_roots, const int32_t *actions, int32
     if (ctx->tree.kind != 1 || ctx->tree.n_roots != n_roots)
         return fail(MP_ERR_ARG, "mp_uct_step_tree: no UCT trees of %d roots on this ctx", n_roots);
     MP_HIP(hipSetDevice(ctx->device));
+    // a second step before the next plan (receding_horizon > 1: abstract.py:70-82 steps the tree on every act) descends
+    // one more level: apply the pending re-rooting now, then arm the new one
+    if (ctx->tree.armed) MP_TRY(uct_reroot_now(ctx, ctx->tree.cap));
     int32_t *d = nullptr;
     MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots, &d));
     MP_HIP(hipMemcpyAsync(d, actions, (size_t)n_roots * sizeof(int32_t),

@@ -70,6 +70,8 @@ def plan_batch_sharded(agent, root_states, root_steps=None, device=None, keys=("
     rank, world = rank_world()
     root_states = np.asarray(root_states, dtype=np.int32)
     n = len(root_states)
+    if n < world:       # decided identically on every rank BEFORE any collective: nobody is left waiting in one
+        raise RuntimeError("fewer roots ({}) than ranks ({}): give every rank at least one root".format(n, world))
     lo, hi = shard_bounds(n, rank, world)
     steps = None if root_steps is None else np.asarray(root_steps, dtype=np.int32)[lo:hi]
     rng = agent.planner.batch_rng_states(hi - lo, first_root=lo)
@@ -88,8 +90,6 @@ def plan_batch_sharded(agent, root_states, root_steps=None, device=None, keys=("
             block = local[k]
         else:
             block = np.zeros((0,), dtype=np.float64)
-        if world > 1 and local is None:
-            raise RuntimeError("fewer roots than ranks: give every rank at least one root")
         out[k] = all_gather_rows(block, n, device=device)
     return out
 
@@ -139,15 +139,18 @@ def vi_solve_row_sharded(ctx, transition, reward, terminal=None, gamma=1.0, iter
 
 
 def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows, n_states, rows, gamma=1.0,
-                                iterations=100, robust=False, rtol=1e-5, atol=1e-8):
+                                iterations=100, robust=False, rtol=1e-5, atol=1e-8, check_every=8):
     """Device-resident form of :func:`vi_solve_row_sharded`: this rank's row block is already on the GPU.
 
     ``transition_rows`` / ``reward_rows``: torch CUDA tensors [.., hi-lo, A, S] / [.., hi-lo, A] (borrowed, not
     copied: at C5 size a block is 12.5 GB per model); ``terminal_rows``: torch uint8 [hi-lo] or None; ``rows`` =
-    (lo, hi).  Every sweep stays on the device: ``mp_vi_backup`` enqueues on the ctx stream, max_a / isclose run as
-    torch ops, V is exchanged with one ``all_gather_into_tensor`` (RCCL) -- shards are padded to equal length -- and
-    only the 4-byte convergence flag comes back to the host.  ``ctx`` must enqueue on torch's current stream
-    (``native.Context(device, torch.cuda.current_stream().cuda_stream)``).  Returns (Q [S, A] tensor, sweeps)."""
+    (lo, hi).  Every sweep stays on the device and NOTHING returns to the host per sweep: ``mp_vi_backup`` enqueues on
+    the ctx stream, max_a / isclose run as torch ops, V is exchanged with one ``all_gather_into_tensor`` (RCCL; shards
+    padded to equal length, re-ordered by one index op) and the ``allclose`` verdict with one 4-byte ``all_reduce``;
+    once the verdict is "close" a device-side ``done`` flag freezes the iterate (the reference returns the PREVIOUS
+    one, value_iteration.py:69-71) and the host only looks at that flag every ``check_every`` sweeps to leave the loop.
+    ``ctx`` must enqueue on torch's current stream (``native.Context(device, torch.cuda.current_stream().cuda_stream)``).
+    Returns (Q [S, A] tensor, sweeps)."""
     import torch
     import torch.distributed as dist
     rank, world = rank_world()
@@ -159,36 +162,40 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
     v = torch.zeros(n_states, dtype=torch.float64, device=dev)
     v_pad = torch.zeros(world * per, dtype=torch.float64, device=dev)
     v_loc = torch.zeros(per, dtype=torch.float64, device=dev)
+    even = world * per == n_states
+    if world > 1 and not even:                                 # state s lives at v_pad[order[s]]
+        order = torch.cat([torch.arange(r * per, r * per + (shard_bounds(n_states, r, world)[1] -
+                                                           shard_bounds(n_states, r, world)[0]), device=dev)
+                           for r in range(world)])
     q_local = torch.zeros((hi - lo, n_actions), dtype=torch.float64, device=dev)
     q_next = torch.empty_like(q_local)
-    sweeps = 0
-    for _ in range(int(iterations)):
+    done = torch.zeros(1, dtype=torch.int32, device=dev)      # 1 once allclose held: the iterate is frozen
+    sweeps_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+    for it in range(int(iterations)):
         ctx.vi_backup(model, gamma, v, q_out=q_next, robust=robust)
-        sweeps += 1
         close = torch.isclose(q_local, q_next, rtol=rtol, atol=atol).all().to(torch.int32).reshape(1)
         if world > 1:
             dist.all_reduce(close, op=dist.ReduceOp.MIN)
-        if bool(close.item()):
-            break
-        q_local, q_next = q_next, q_local
+        active = 1 - done
+        sweeps_dev += active                                   # a sweep counts until (and including) the close one
+        advance = (active * (1 - close)).to(torch.bool)        # value = next only if not close and not frozen
+        q_local = torch.where(advance, q_next, q_local)
+        done = torch.maximum(done, close)
         v_loc.zero_()
-        v_loc[:hi - lo] = q_local.max(dim=-1).values
+        v_loc[:hi - lo] = q_local.max(dim=-1).values           # (unchanged once frozen)
         if world > 1:
             dist.all_gather_into_tensor(v_pad, v_loc)
-            for r in range(world):
-                rlo, rhi = shard_bounds(n_states, r, world)
-                v[rlo:rhi] = v_pad[r * per:r * per + (rhi - rlo)]
+            v = v_pad if even else v_pad[order]
         else:
             v[lo:hi] = v_loc[:hi - lo]
+        if (it + 1) % int(check_every) == 0 and bool(done.item()):
+            break
+    sweeps = int(sweeps_dev.item())
     model.close()
     if world > 1:
         q_pad = torch.zeros((per, n_actions), dtype=torch.float64, device=dev)
         q_pad[:hi - lo] = q_local
         q_all = torch.empty((world * per, n_actions), dtype=torch.float64, device=dev)
         dist.all_gather_into_tensor(q_all, q_pad)
-        parts = []
-        for r in range(world):
-            rlo, rhi = shard_bounds(n_states, r, world)
-            parts.append(q_all[r * per:r * per + (rhi - rlo)])
-        return torch.cat(parts), sweeps
+        return (q_all if even else q_all[order]), sweeps
     return q_local, sweeps

@@ -376,3 +376,65 @@ def test_batched_evaluation_with_planners_that_carry_state(kind):
         assert out["lengths"][i] == len(actions), (kind, i)
         np.testing.assert_array_equal(out["actions"][i, :len(actions)], actions, err_msg=str((kind, i)))
     assert len(set(out["lengths"].tolist())) >= 1
+
+
+def test_mcts_subtree_with_receding_horizon_descends_every_step():
+    """step_strategy 'subtree' with receding_horizon 2: the agent steps its tree on EVERY act (abstract.py:70-82), so
+    two levels are descended between two plans -- compared with the oracle driven by the same bookkeeping."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    cfg = generators.highway_shaped(3, 4, 10, seed=3)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    env = FiniteMDPEnv(dict(mode="deterministic", transition=t, reward=r, terminal=term, state=5))
+    env.reset()
+    agent = agent_factory(env, dict(__class__=UCT, budget=300, horizon=12, episodes=25, step_strategy="subtree",
+                                    receding_horizon=2))
+    agent.seed(4)
+    rng = native.rng_state_from_generator(agent.planner.np_random)
+    p = np.ones(5) / 5
+    tree, prev, remaining, replans = None, [], 0, 0
+    for step in range(8):
+        replan = remaining == 0 or len(prev) <= 1
+        remaining = 1 if replan else remaining - 1
+        tree = oracle.uct_reroot(tree, prev[0], 5) if (prev and tree is not None) else None
+        if replan:
+            out = oracle.uct_plan(t, r, term, env.mdp.state, 25, 12, 0.8, 2 / (1 - 0.8), p, p, rng, max_plan_len=12,
+                                  init_tree=tree)
+            tree, rng, want = out["tree"], out["rng_after"], [int(a) for a in out["plan"]]
+            replans += 1
+        else:
+            want = prev[1:]
+        got = agent.plan(env.mdp.state)
+        assert got == want, (step, got, want)
+        prev = want
+        _, _, done, trunc, _ = env.step(want[0])
+        if done or trunc:
+            break
+    assert replans >= 3
+    np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), rng)
+
+
+def test_tree_export_checks_ownership():
+    """planner.root reads the shared device context: after another planner has planned it raises instead of silently
+    returning that planner's tree."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    cfg = generators.gridworld()
+    env = FiniteMDPEnv(dict(mode="deterministic", transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"]))
+    env.reset()
+    a = agent_factory(env, dict(__class__=UCT, budget=100))
+    b = agent_factory(env, dict(__class__=OPD, budget=100))
+    a.seed(0), b.seed(0)
+    a.plan(0)
+    assert a.planner.root.count > 0
+    a.plan(0)
+    b.plan(0)
+    assert b.planner.root.count == 101
+    with pytest.raises(RuntimeError):
+        a.planner.root
+    a.plan(0)
+    assert a.planner.root.count > 0
+    with pytest.raises(RuntimeError):
+        b.planner.export_tree(0)
