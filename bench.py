@@ -100,7 +100,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "opd", "saopd", "vi", "rvi", "vi_dense"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -709,6 +709,127 @@ def bench_vi(args, rank, world, local, dense, robust=False):
     return res
 
 
+def bench_rvi_dense_shard(args, rank, world, local):
+    """BASELINE config C5 in its dense form -- robust VI, S = 50 000, A = 5, M = 2 models, 8*M*S^2*A = 200 GB of fp64
+    transitions, row-sharded over the 8 GPUs of a node -- timed at the size it exists for: every rank owns
+    6 250 source-state rows of both models (25 GB, generated on the device and borrowed by the library), a step is ONE
+    sweep of the sharded solver's loop: mp_vi_backup on the rank's rows (min over models fused), max_a, the allclose
+    test, and the exchange of V (all_gather_into_tensor over RCCL; at N = 1 a single-rank process group stands in for it,
+    which measures the collective's software path but no wire time).  N < 8 ranks cover N * 6250 of the 50 000 source
+    rows (weak scaling: the per-GPU work is the C5 rank's; the missing rows' values stay 0 -- a timing harness, the
+    solver's results are covered by the tests at small sizes)."""
+    import torch
+    import torch.distributed as dist
+    from rl_agents_amd import native
+    s_, a_, m_ = (args.states or 50000), 5, 2
+    rows = args.roots or s_ // 8
+    gamma = 0.95
+    dev = torch.device("cuda", local)
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1000 + rank)
+    tt = torch.empty((m_, rows, a_, s_), dtype=torch.float64, device=dev)
+    for m in range(m_):                                   # row-stochastic blocks, normalised in place model by model
+        tt[m].uniform_(generator=g)
+        tt[m] /= tt[m].sum(-1, keepdim=True)
+    rr = torch.rand((m_, rows, a_), dtype=torch.float64, device=dev, generator=g)
+    model = ctx.load_dense_rows(tt, rr, None)
+    lo = rank * rows
+    group = world > 1
+    standin = None
+    if world == 1 and os.environ.get("BENCH_RCCL_STANDIN"):
+        # (opt-in: RCCL prints its version banner on stdout, which would follow the JSON line)
+        try:                                              # single-rank RCCL group: the collective's launch path, no wire
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            group, standin = True, "single-rank RCCL process group (software path only)"
+        except Exception as e:                            # pragma: no cover - depends on the box
+            standin = "unavailable ({})".format(type(e).__name__)
+    n_cover = max(world, 1) * rows
+    v = torch.zeros(s_, dtype=torch.float64, device=dev)
+    v_all = torch.zeros(n_cover, dtype=torch.float64, device=dev)
+    q_local = torch.zeros((rows, a_), dtype=torch.float64, device=dev)
+    q_next = torch.empty_like(q_local)
+    done = torch.zeros(1, dtype=torch.int32, device=dev)
+    t_gather = []
+
+    def step(timed_gather=False):
+        nonlocal q_local, q_next, done
+        ctx.vi_backup(model, gamma, v, q_out=q_next, robust=True)
+        close = torch.isclose(q_local, q_next, rtol=0.0, atol=0.0).all().to(torch.int32).reshape(1)   # (exact equality: never close here)
+        if group:
+            dist.all_reduce(close, op=dist.ReduceOp.MIN)
+        done = torch.maximum(done, close)
+        q_local, q_next = q_next, q_local
+        v_loc = q_local.max(dim=-1).values
+        if group:
+            if timed_gather:
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+            dist.all_gather_into_tensor(v_all, v_loc)
+            if timed_gather:
+                torch.cuda.synchronize()
+                t_gather.append(time.perf_counter() - t1)
+            v[:n_cover] = v_all
+        else:
+            v[lo:lo + rows] = v_loc
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world if world > 1 else 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world if world > 1 else 1)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    k_ms = []
+    for _ in range(5):
+        step(timed_gather=True)
+        k_ms.append(ctx.last_kernel_ms()[0])
+    k_ms = float(np.mean(k_ms))
+    alg = 8.0 * m_ * rows * a_ * s_
+    flops = 2.0 * m_ * rows * a_ * s_
+    gather_ms = 1e3 * float(np.median(t_gather)) if t_gather else None
+    ms_sweep = 1e3 * dt / args.steps
+    res = dict(
+        metric="value-iteration Bellman sweeps/sec (dense robust VI, one C5 rank's row block per GPU)", unit="sweeps/s",
+        value=args.steps / dt, ms_per_step=ms_sweep, dtype="f64",
+        config=dict(workload="robust_vi_dense_row_shard_S{}_A{}_M{}_rows{}_per_gpu".format(s_, a_, m_, rows), states=s_,
+                    actions=a_, models=m_, rows_per_gpu=rows, block_bytes=alg, gamma=gamma, ms_per_sweep=ms_sweep,
+                    kernel_ms_per_sweep=k_ms, all_gather_ms=gather_ms, all_gather_standin=standin,
+                    projection_8_ranks=dict(
+                        note="C5 = 8 such ranks: a sweep costs max over ranks of (backup + torch epilogue) + the V exchange; "
+                             "the exchange moves 8*S = {} B and is latency-bound on the xGMI mesh".format(8 * s_),
+                        ms_per_sweep=ms_sweep, sweeps_per_s=args.steps / dt,
+                        full_model_bytes_per_sweep=8.0 * alg, aggregate_tb_per_s=8.0 * alg / (ms_sweep * 1e-3) / 1e12),
+                    parallelism="rows sharded over {} GPU(s) ({} of 8 C5 ranks), all_gather of V + 4-byte all_reduce per sweep".format(world, world)),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel="vi_dense_q (robust, row block)",
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg, mfma_tflops=flops / (k_ms * 1e-3) / 1e12),
+    )
+    res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
+    add_traffic(res["roofline"], "rvi_dense_shard", "vi_dense_q", ((rows * a_ + 63) // 64) * 256, pattern="stream")
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        s_cpu = 1000
+        g_cpu = np.random.Generator(np.random.PCG64(0))
+        t_cpu = g_cpu.random((m_, s_cpu, a_, s_cpu))
+        t_cpu /= t_cpu.sum(-1, keepdims=True)
+        r_cpu = g_cpu.random((m_, s_cpu, a_))
+        t1, reps, n_sw = time.perf_counter(), 0, 5
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            oracle.vi_solve("stochastic", t_cpu, r_cpu, None, gamma=gamma, iterations=n_sw, rtol=-1.0, atol=-1.0, robust=True)
+            reps += 1
+        cdt = time.perf_counter() - t1
+        scale = (float(m_) * s_cpu * a_ * s_cpu) / (float(m_) * rows * a_ * s_)
+        res["cpu_baseline"] = dict(value=reps * n_sw / cdt * scale, unit="sweeps/s", cores=1, kind="port",
+                                   sample="oracle/planning_oracle.c orc_vi_solve (dense, robust M=2), {} x {} sweeps at S = {} in "
+                                          "{:.1f} s, scaled by bytes to this rank's block".format(reps, n_sw, s_cpu, cdt))
+    if world == 1 and group and dist.is_initialized():
+        dist.destroy_process_group()
+    return res
+
+
 def main():
     if os.environ.get("BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
@@ -728,6 +849,8 @@ def main():
             res = bench_opd(args, rank, world, local)
         elif args.workload == "saopd":
             res = bench_saopd(args, rank, world, local)
+        elif args.workload == "rvi_dense_shard":
+            res = bench_rvi_dense_shard(args, rank, world, local)
         else:
             res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
     res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",

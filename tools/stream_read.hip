@@ -2,6 +2,7 @@
 // Build: hipcc --offload-arch=gfx950 -O3 tools/stream_read.hip -o build_variants/stream_read
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 typedef double double2_t __attribute__((ext_vector_type(2)));
 __global__ void rd(const double2_t *__restrict__ p, size_t n, double *out)
 {
@@ -15,9 +16,9 @@ __global__ void rd(const double2_t *__restrict__ p, size_t n, double *out)
     for (; i < n; i += stride) acc += p[i].x + p[i].y;
     if (acc == 123.456) out[0] = acc;
 }
-int main()
+int main(int argc, char **argv)
 {
-    const size_t bytes = 4000000000ull, n = bytes / 16;
+    const size_t bytes = argc > 1 ? strtoull(argv[1], nullptr, 10) : 4000000000ull, n = bytes / 16;
     double2_t *p; double *o;
     hipMalloc(&p, bytes); hipMalloc(&o, 8);
     hipMemset(p, 0, bytes);
@@ -28,7 +29,7 @@ int main()
         for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(rd, dim3(blocks), dim3(256), 0, 0, p, n, o);
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
-        printf("read-only stream, %d blocks x 256: %.3f ms per 4 GB -> %.2f TB/s\n", blocks, ms / 5, bytes / (ms / 5 * 1e-3) / 1e12);
+        printf("read-only stream, %d blocks x 256: %.3f ms per %.1f GB -> %.2f TB/s\n", blocks, ms / 5, bytes / 1e9, bytes / (ms / 5 * 1e-3) / 1e12);
     }
     return 0;
 }
