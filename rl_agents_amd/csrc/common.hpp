@@ -54,6 +54,7 @@ struct TreeMeta {
     double gamma = 0.0; // robust opd: the export recomputes leaf upper-bound vectors
     int buf = 0;        // UCT: which of the two tree workspaces (WS_TREE0 / WS_TREE2) holds the current trees
     bool armed = false; // UCT: mp_uct_step_tree was called; the next plan re-roots and continues
+    int il = 0;          // UCT: 1 = wave-interleaved tree layout (see uct.hip TreeRef)
     long kept_bound = 0; // UCT: upper bound on the nodes a kept (re-rooted) tree can hold, see uct_plan_impl
 };
 

@@ -45,8 +45,50 @@ struct alignas(16) UctNode {
 };
 static_assert(sizeof(UctNode) == 16, "UctNode must be one dwordx4");
 
+// One root's tree inside the batch buffer.  LAY selects the layout (A/B: profiles/r02_uct_tree_layout.md):
+//   0 root-major       Node[n_roots][cap]: a root's nodes contiguous -- the |A| children of a node share one or two
+//                      cache lines, but neighbouring lanes are a whole tree apart: nothing a wave does coalesces.
+//   1 interleaved      Node[n_roots / 64][cap][64]: the same node id of a wavefront's 64 roots contiguous -- accesses
+//                      that hit the same id in every lane (expansions: ids advance in lock-step) fill whole lines, but a
+//                      node's |A| children now lie in |A| different lines.
+//   2 group-interleaved Node[n_roots / 64][groups][64][|A|]: node ids come in groups of |A| siblings (1 + g|A| .. ;
+//                      the root fills the last slot of group 0); a lane's sibling group stays contiguous (one or two
+//                      lines per scored level, as root-major) AND the same group of the 64 lanes is contiguous
+//                      (expansions write 64 x |A| x 16 B = one run).  Needs |A| at compile time.
+// Hot sites address a child through its sibling group (child / handle: one add and a shift); operator[] maps any id.
+template <int LAY, int AT>
+struct TreeRef {
+    UctNode *base;
+    int A; // runtime |A| (generic ids only)
+    __device__ __forceinline__ static unsigned idx01(int n) { return LAY == 1 ? (unsigned)n << 6 : (unsigned)n; }
+    // node fc + a where fc is the first child of some node (fc = 1 mod |A|)
+    __device__ __forceinline__ int handle(int fc, int a) const { return LAY == 2 ? ((fc - 1 + AT) << 6) + a : fc + a; }
+    __device__ __forceinline__ int root_handle() const { return LAY == 2 ? AT - 1 : 0; }
+    __device__ __forceinline__ UctNode &at(int h) const { return base[LAY == 2 ? (unsigned)h : idx01(h)]; }
+    __device__ __forceinline__ UctNode &child(int fc, int a) const { return at(handle(fc, a)); }
+    __device__ __forceinline__ UctNode &operator[](int n) const
+    {
+        if (LAY != 2) return base[idx01(n)];
+        const int x = n + A - 1, q = x / A;          // group q (root: group 0, last slot), slot x - q|A|
+        return base[(unsigned)(q * A * 64 + (x - q * A))];
+    }
+};
+template <int LAY, int AT>
+__device__ __forceinline__ TreeRef<LAY, AT> tree_of(UctNode *trees, int r, int cap, int A)
+{
+    TreeRef<LAY, AT> t;
+    t.A = A;
+    if (LAY == 2) t.base = trees + ((long)(r >> 6) * (cap + A) * 64 + (long)(r & 63) * A);
+    else if (LAY == 1) t.base = trees + ((long)(r >> 6) * cap * 64 + (r & 63));
+    else t.base = trees + (long)r * cap;
+    return t;
+}
+// nodes to allocate per root for a layout
+static inline size_t tree_stride_alloc(int lay, long cap, int A) { return (size_t)(lay == 2 ? cap + A : cap); }
+
 struct UctArgs {
     int n_roots, S, A, episodes, horizon, cap;
+    int tree_il; // tree layout (TreeRef): 0 root-major, 1 interleaved, 2 group-interleaved
     int done_on_next, max_steps, max_plan_len;
     int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
     int waves; // wavefronts per workgroup
@@ -117,7 +159,7 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 // PHANTOMS (count = -1): never scored, never visited, dropped by the tree export.  The listed-action masks of the state
 // reached / acted from ride in bits 8-15 / 16-23 of the fused records' flags word, so the descent always knows the mask
 // of the state it is in without another gather; len(children) in the exploration term is the mask's population count.
-template <int AT, int ENV, bool SP = false, bool MK = false>
+template <int AT, int ENV, bool SP = false, bool MK = false, int IL = 0>
 __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_LDS ? 1 : MP_UCT_MIN_WAVES) void uct_kernel(UctArgs p)
 {
     static_assert(!SP || (AT > 0 && ENV == ENV_TABLE), "per-state policies: table env, |A| known at compile time");
@@ -159,7 +201,8 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
     int32_t *path = path_all + wave * 64; // slot d of this lane: path[d * nthreads + lane]
     const int r = (blockIdx.x * p.waves + wave) * p.lanes + lane;
     if (lane >= p.lanes || r >= p.n_roots) return;
-    UctNode *tree = p.tree + (long)r * p.cap;
+    static_assert(IL != 2 || AT > 0, "the group-interleaved layout needs |A| at compile time");
+    const TreeRef<IL, AT> tree = tree_of<IL, AT>(p.tree, r, p.cap, A);
     const Rec *__restrict__ rec = p.rec;
     Pcg64 g;
     g.load(p.rng + (long)r * 6);
@@ -197,7 +240,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
         if (tf0 == 1) {
 #pragma unroll
             for (int a = 0; a < AR; ++a) {
-                const UctNode ca = tree[1 + a];
+                const UctNode ca = tree.child(1, a);
                 tv[a] = ca.value; tc[a] = ca.count; tf[a] = ca.first_child;
             }
         }
@@ -233,7 +276,8 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
         bool cur_term = root_term; // terminal[s] of the state the next action is taken from
         double total = 0.0;
         uint32_t cur_mask = mask0; // MK: listed actions of the state the descent is in
-        path[lane] = 0;
+        path[lane] = tree.root_handle();
+        int hnode = tree.root_handle(); // where `node` lives (TreeRef handle)
         int fc = RC ? tf0 : tree[0].first_child;
         // ---- selection, mcts.py:143-149
         while (depth < H && fc >= 0 && !terminal) {
@@ -248,7 +292,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                     for (int a = 0; a < AR; ++a) { c[a].value = tv[a]; c[a].count = tc[a]; c[a].first_child = tf[a]; }
                 } else {
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) c[a] = tree[fc + a];
+                    for (int a = 0; a < AR; ++a) c[a] = tree.child(fc, a);
                 }
                 double sc[AR];
                 if (SP) {
@@ -296,18 +340,18 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
             } else {
                 double m = 0.0;
                 for (int a = 0; a < A; ++a) {
-                    const UctNode c = tree[fc + a];
+                    const UctNode c = tree.child(fc, a);
                     const double sc = c.value + explore(a, c.count + 1);
                     if (a == 0 || sc > m) m = sc;
                 }
                 int nt = 0;
                 for (int a = 0; a < A; ++a) {
-                    const UctNode c = tree[fc + a];
+                    const UctNode c = tree.child(fc, a);
                     nt += (c.value + explore(a, c.count + 1)) == m ? 1 : 0;
                 }
                 int pick = (int)g.below((uint32_t)nt);
                 for (int a = 0; a < A; ++a) {
-                    const UctNode c = tree[fc + a];
+                    const UctNode c = tree.child(fc, a);
                     if ((c.value + explore(a, c.count + 1)) == m) {
                         if (pick == 0) { act = a; nfc = c.first_child; break; }
                         --pick;
@@ -342,8 +386,9 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
             ++steps_taken;
             total += gpow[depth] * reward;
             node = fc + act;
+            hnode = tree.handle(fc, act);
             ++depth;
-            path[depth * nthreads + lane] = node;
+            path[depth * nthreads + lane] = hnode;
             fc = nfc;
 #ifdef MP_PROFILE
             ++n_sel;
@@ -359,7 +404,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
 #pragma unroll
                 for (int a = 0; a < AR; ++a) tf[a] = node == 1 + a ? n_nodes : tf[a];
             } else {
-                tree[node].first_child = n_nodes;
+                tree.at(hnode).first_child = n_nodes;
             }
             if (MK) {
                 if (node == 0) {
@@ -368,11 +413,11 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                 } else {
                     for (int a = 0; a < A; ++a) {
                         n.count = (cur_mask >> a) & 1u ? 0 : -1;
-                        tree[n_nodes + a] = n;
+                        tree.child(n_nodes, a) = n;
                     }
                 }
             } else if (!(RC && node == 0)) // the root's children were zero-initialised in registers
-                for (int a = 0; a < A; ++a) tree[n_nodes + a] = n;
+                for (int a = 0; a < A; ++a) tree.child(n_nodes, a) = n;
             n_nodes += A;
         }
         PROF_T(c2);
@@ -518,27 +563,27 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
                 for (int i = 1; i < KEEP; ++i) { v = d == 2 + i ? kv[i] : v; cnt = d == 2 + i ? kc[i] : cnt; }
                 cnt += 1;
                 v += inv(cnt) * (total - v);
-                tree[n].value = v;       // first_child is left alone (the node may just have been expanded)
-                tree[n].count = cnt;
+                tree.at(n).value = v;       // first_child is left alone (the node may just have been expanded)
+                tree.at(n).count = cnt;
             } else {
-                UctNode c = tree[n];
+                UctNode c = tree.at(n);
                 c.count += 1;
                 c.value += inv(c.count) * (total - c.value);
-                tree[n].value = c.value;
-                tree[n].count = c.count;
+                tree.at(n).value = c.value;
+                tree.at(n).count = c.count;
             }
         }
         if (RC) {
             if (depth >= 1) {
-                const int n = path[nthreads + lane]; // level-1 node, id in 1..A
+                const int n = path[nthreads + lane] - tree.handle(1, 0); // level-1 node: which child of the root
                 double v = tv[0];
                 int cnt = tc[0];
 #pragma unroll
-                for (int a = 1; a < AR; ++a) { v = n == 1 + a ? tv[a] : v; cnt = n == 1 + a ? tc[a] : cnt; }
+                for (int a = 1; a < AR; ++a) { v = n == a ? tv[a] : v; cnt = n == a ? tc[a] : cnt; }
                 cnt += 1;
                 v += inv(cnt) * (total - v);
 #pragma unroll
-                for (int a = 0; a < AR; ++a) { tv[a] = n == 1 + a ? v : tv[a]; tc[a] = n == 1 + a ? cnt : tc[a]; }
+                for (int a = 0; a < AR; ++a) { tv[a] = n == a ? v : tv[a]; tc[a] = n == a ? cnt : tc[a]; }
             }
             tc0 += 1;
             tv0 += inv(tc0) * (total - tv0);
@@ -560,7 +605,7 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
 #pragma unroll
             for (int a = 0; a < AR; ++a) {
                 w.value = tv[a]; w.count = tc[a]; w.first_child = tf[a];
-                tree[1 + a] = w;
+                tree.child(1, a) = w;
             }
         }
     }
@@ -568,21 +613,20 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
     // ---- AbstractPlanner.get_plan (abstract.py:143-156) with MCTSNode.selection_rule
     // (mcts.py:212-218): most visited child, ties -> first maximal value among them
     {
-        int node = 0, len = 0;
+        int len = 0;
         int fc = tree[0].first_child;
         while (fc >= 0) {
-            int mc = tree[fc].count;
-            for (int a = 1; a < A; ++a) mc = max(mc, tree[fc + a].count);
+            int mc = tree.child(fc, 0).count;
+            for (int a = 1; a < A; ++a) mc = max(mc, tree.child(fc, a).count);
             int best = -1;
             double bv = 0.0;
             for (int a = 0; a < A; ++a) {
-                const UctNode c = tree[fc + a];
+                const UctNode c = tree.child(fc, a);
                 if (c.count == mc && (best < 0 || c.value > bv)) { best = a; bv = c.value; }
             }
             if (p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = best;
             ++len;
-            node = fc + best;
-            fc = tree[node].first_child;
+            fc = tree.child(fc, best).first_child;
         }
         if (p.plans)
             for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
@@ -593,14 +637,15 @@ __global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_
     if (p.env_steps) p.env_steps[r] = (int64_t)steps_taken;
     const int rfc = tree[0].first_child;
     for (int a = 0; a < A; ++a) {
-        if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? max(tree[rfc + a].count, 0) : 0;
-        if (p.root_child_value) p.root_child_value[(long)r * A + a] = rfc >= 0 ? tree[rfc + a].value : 0.0;
+        if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? max(tree.child(rfc, a).count, 0) : 0;
+        if (p.root_child_value) p.root_child_value[(long)r * A + a] = rfc >= 0 ? tree.child(rfc, a).value : 0.0;
     }
 }
 
 // AbstractPlanner.step_by_subtree (abstract.py:195-206), one root per lane: the subtree of the root's child
 // `action` is re-numbered breadth-first into the other tree buffer (children stay contiguous).  While a node
 // waits in the BFS queue its first_child field holds its OLD id.  A never-expanded root gives size 0 (fresh tree).
+template <int IL>
 __global__ __launch_bounds__(64) void uct_reroot_kernel(int n_roots, int A, int cap_old, int cap_new,
                                                         const UctNode *__restrict__ old_trees, UctNode *__restrict__ new_trees,
                                                         const int32_t *n_old, const int32_t *__restrict__ actions,
@@ -608,8 +653,8 @@ __global__ __launch_bounds__(64) void uct_reroot_kernel(int n_roots, int A, int 
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_roots) return;
-    const UctNode *o = old_trees + (long)r * cap_old;
-    UctNode *n = new_trees + (long)r * cap_new;
+    const TreeRef<IL, 0> o = tree_of<IL, 0>(const_cast<UctNode *>(old_trees), r, cap_old, A); // (generic ids: operator[])
+    const TreeRef<IL, 0> n = tree_of<IL, 0>(new_trees, r, cap_new, A);
     const int a = actions[r];
     // `if action in self.root.children` (abstract.py:201): an unlisted action has a phantom slot, not a child
     if (n_old[r] < 1 || o[0].first_child < 0 || a < 0 || a >= A || o[o[0].first_child + a].count < 0) {
@@ -657,14 +702,26 @@ static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, b
     const int roots_per_block = a.waves * a.lanes;
     const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
     if (sp && listed) {
-        if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true>), grid, block, lds, st, a);
+        if constexpr (AT > 0) {
+            if (a.tree_il == 2) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true, 2>), grid, block, lds, st, a);
+            else if (a.tree_il == 1) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true, 1>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true, 0>), grid, block, lds, st, a);
+        }
     } else if (sp) {
-        if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true>), grid, block, lds, st, a);
+        if constexpr (AT > 0) {
+            if (a.tree_il == 2) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, false, 2>), grid, block, lds, st, a);
+            else if (a.tree_il == 1) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, false, 1>), grid, block, lds, st, a);
+            else hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, false, 0>), grid, block, lds, st, a);
+        }
     } else if (ldsm) {
         if (lds > 64 * 1024)
             MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<AT, ENV_TABLE_LDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_LDS>), grid, block, lds, st, a);
+    } else if (a.tree_il == 2) {
+        if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, false, false, 2>), grid, block, lds, st, a);
+    } else if (a.tree_il == 1) {
+        hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, false, false, 1>), grid, block, lds, st, a);
     } else {
         hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE>), grid, block, lds, st, a);
     }
@@ -682,11 +739,17 @@ static int uct_reroot_now(mp_ctx *ctx, long cap_new)
     const int n_roots = ctx->tree.n_roots, A = ctx->tree.A;
     const int old_slot = ctx->tree.buf ? WS_TREE2 : WS_TREE0, new_slot = ctx->tree.buf ? WS_TREE0 : WS_TREE2;
     UctNode *nw = nullptr;
-    MP_TRY(ws_get(ctx, new_slot, (size_t)n_roots * cap_new, &nw));
+    MP_TRY(ws_get(ctx, new_slot, (size_t)((n_roots + 63) & ~63) * tree_stride_alloc(ctx->tree.il, cap_new, A), &nw));
     int32_t *sizes = (int32_t *)ctx->ws[WS_TREE1].p;
     const int32_t *acts = (const int32_t *)ctx->ws[WS_TREE3].p;
-    hipLaunchKernelGGL(uct_reroot_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), 0, ctx->stream, n_roots, A,
-                       ctx->tree.cap, (int)cap_new, (const UctNode *)ctx->ws[old_slot].p, nw, sizes, acts, sizes);
+    const dim3 rgrid((unsigned)((n_roots + 63) / 64));
+    const UctNode *od = (const UctNode *)ctx->ws[old_slot].p;
+    if (ctx->tree.il == 2)
+        hipLaunchKernelGGL(uct_reroot_kernel<2>, rgrid, dim3(64), 0, ctx->stream, n_roots, A, ctx->tree.cap, (int)cap_new, od, nw, sizes, acts, sizes);
+    else if (ctx->tree.il == 1)
+        hipLaunchKernelGGL(uct_reroot_kernel<1>, rgrid, dim3(64), 0, ctx->stream, n_roots, A, ctx->tree.cap, (int)cap_new, od, nw, sizes, acts, sizes);
+    else
+        hipLaunchKernelGGL(uct_reroot_kernel<0>, rgrid, dim3(64), 0, ctx->stream, n_roots, A, ctx->tree.cap, (int)cap_new, od, nw, sizes, acts, sizes);
     MP_HIP(hipGetLastError());
     ctx->tree.buf ^= 1;
     ctx->tree.cap = (int)cap_new;
@@ -771,7 +834,12 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // the per-step chain is instruction-bound (PCG64's 128-bit multiply), not gather-latency bound, so the
     // single-gather variant is the default; MP_UCT_MODEL=lds selects the LDS-resident transition table.
     const char *force = getenv("MP_UCT_MODEL"); // "global" (default) / "lds"
-    bool ldsm = !cart && !pol && model->t16 != nullptr && force && force[0] == 'l';
+    const char *lay = getenv("MP_UCT_TREE"); // "rootmajor" / "interleaved" / "group": tree layout (TreeRef)
+    const bool at_known = A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8;
+    // default: group-interleaved wherever |A| has a compile-time specialisation (262 144 roots: 1.05-1.07 ms against
+    // 1.16 ms root-major and 1.09 ms interleaved; 4 096 roots and single roots: no difference)
+    const int want_il = !lay ? (at_known ? 2 : 0) : (lay[0] == 'i' ? 1 : (lay[0] == 'g' && at_known ? 2 : 0));
+    bool ldsm = !cart && !pol && model->t16 != nullptr && force && force[0] == 'l'; // (the LDS variant keeps root-major trees)
     a.lanes = ldsm ? 64 : uct_lanes_per_wave();
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
@@ -809,9 +877,11 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         ctx->tree.armed = false;
         ctx->tree.buf = 0;
         ctx->tree.kept_bound = 1 + (long)horizon * episodes * A;
-        MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap_use, &a.tree));
+        ctx->tree.il = (!cart && !ldsm) ? want_il : 0;
+        MP_TRY(ws_get(ctx, WS_TREE0, (size_t)((n_roots + 63) & ~63) * tree_stride_alloc(ctx->tree.il, cap_use, A), &a.tree));
     }
     a.cap = (int)cap_use;
+    a.tree_il = ctx->tree.il;
     ctx->tree.kind = 1; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap_use;
 
     int32_t *d_rs = nullptr, *d_st = nullptr;
@@ -1035,9 +1105,19 @@ int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
     std::vector<UctNode> h((size_t)tcap);
     MP_HIP(hipSetDevice(ctx->device));
     MP_HIP(hipStreamSynchronize(ctx->stream));
-    MP_HIP(hipMemcpy(h.data(), (const UctNode *)ctx->ws[ctx->tree.buf ? WS_TREE2 : WS_TREE0].p + (long)root * tcap,
-                     (size_t)tcap * sizeof(UctNode),
-                     hipMemcpyDeviceToHost));
+    const UctNode *trees = (const UctNode *)ctx->ws[ctx->tree.buf ? WS_TREE2 : WS_TREE0].p;
+    if (ctx->tree.il == 2) {
+        // sibling groups of |A| nodes at stride 64 |A|; group 0 holds the root in its last slot, group g >= 1 the ids 1 + (g-1)|A| ..
+        const int groups = (tcap - 1) / A + 1;
+        std::vector<UctNode> g((size_t)groups * A);
+        MP_HIP(hipMemcpy2D(g.data(), (size_t)A * sizeof(UctNode), trees + ((long)(root >> 6) * (tcap + A) * 64 + (long)(root & 63) * A),
+                           (size_t)64 * A * sizeof(UctNode), (size_t)A * sizeof(UctNode), (size_t)groups, hipMemcpyDeviceToHost));
+        for (int i = 0; i < tcap; ++i) h[i] = g[(size_t)(i + A - 1)];
+    } else if (ctx->tree.il == 1) // node i of root r sits at [(r / 64) * cap + i][r % 64]: a strided column
+        MP_HIP(hipMemcpy2D(h.data(), sizeof(UctNode), trees + ((long)(root >> 6) * tcap * 64 + (root & 63)), 64 * sizeof(UctNode),
+                           sizeof(UctNode), (size_t)tcap, hipMemcpyDeviceToHost));
+    else
+        MP_HIP(hipMemcpy(h.data(), trees + (long)root * tcap, (size_t)tcap * sizeof(UctNode), hipMemcpyDeviceToHost));
     // node slots are appended A at a time; the tree in use is the closure of first_child links.  Slots with
     // count < 0 are the phantoms of actions a listed policy did not list (uct_kernel<.., MK>): they are not nodes.
     int n = 1;
