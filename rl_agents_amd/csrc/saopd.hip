@@ -94,6 +94,7 @@ struct SaArgs {
     int32_t *overflow; // set when a planner's backup queue is full
     int cap;  // wave kernel: node rows allocated per planner
     int scap; // wave kernel: scratch entries per lane in the prune pass (qcap / 64 unless MP_SAOPD_LANE_SCRATCH)
+    int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
     double gamma, vmax;
     const Rec *rec;
     const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
@@ -383,13 +384,18 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 // per lane, the candidate leaves of a prune pass 64 rows per trip (ballot).  Same results as saopd_kernel; a plan's
 // latency is that of ONE planner's chain (~12x shorter than a lane's, whose wave waits for its slowest lane and
 // pays 64 scattered lines per access), and there are 64x more waves to hide it.
+// LDSR: the planner's whole working set -- every node row of its arena, the per-state dictionaries, the backup queue --
+// is staged into LDS for the plan and written back at the end (39 KB at the reference's GridWorld configuration: four
+// planners per CU).  The kernel is a chain of dependent accesses (queue front -> list element -> parent -> children ->
+// state values), ~15 000 per plan: from LDS each costs ~100 cycles instead of a ~600-2 000-cycle L2 / HBM round trip.
+// The host selects it while the arena fits (first plans of a planner; later plans fall back to the global-memory form).
+template <bool LDSR>
 __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int ntab = 3 * (p.K + 3);
     const int lane = threadIdx.x;
     for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
-    __syncthreads();
     const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
     // states whose value or node list changed in the current iteration (each once): the prune pass handles them one
     // per lane; more than DCAP of them (or more leaves of one state than a lane's scratch holds) take the serial pass
@@ -398,17 +404,52 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
     const int r = blockIdx.x;
     const int A = p.A;
     const long nb = (long)r * p.cap, sb = (long)r * p.S, qb = (long)r * p.qcap;
-    auto ND = [&](int i) -> SaNode & { return p.node[nb + i]; };
-    auto ST = [&](int i) -> int32_t & { return p.state[nb + i]; };
-    auto PA = [&](int i) -> int32_t & { return p.parent[nb + i]; };
-    auto FC = [&](int i) -> int32_t & { return p.first_child[nb + i]; };
-    auto RW = [&](int i) -> double & { return p.reward[nb + i]; };
-    auto SV = [&](int s) -> double & { return p.sv[sb + s]; };
-    auto HD = [&](int s) -> int32_t & { return p.head[sb + s]; };
-    auto TL = [&](int s) -> int32_t & { return p.tail[sb + s]; };
-    auto SM = [&](int s) -> int32_t & { return p.stamp[sb + s]; };
-    const unsigned dcap = (unsigned)p.qcap >> 2; // backup-queue descriptors: 4 ints each
-    auto QD = [&](unsigned q, int f) -> int32_t & { return p.queue[qb + ((q & (dcap - 1)) << 2) + f]; };
+    // LDS carve (LDSR): [tables | dirty 128 i32 | node rows 16 B | reward f64 | sv f64 | state, parent, first_child i32 rows |
+    // head, tail, stamp i32 [S] | queue i32]
+    const int LR = p.lds_rows;
+    SaNode *l_node = reinterpret_cast<SaNode *>(lds_d + ((ntab + DCAP / 2 + 1) & ~1)); // 16-byte aligned
+    double *l_reward = reinterpret_cast<double *>(l_node + LR);
+    double *l_sv = l_reward + LR;
+    int32_t *l_state = reinterpret_cast<int32_t *>(l_sv + p.S);
+    int32_t *l_parent = l_state + LR, *l_fc = l_parent + LR;
+    int32_t *l_head = l_fc + LR, *l_tail = l_head + p.S, *l_stamp = l_tail + p.S;
+    int32_t *l_queue = l_stamp + p.S;
+    SaNode *const node_b = LDSR ? l_node : p.node + nb;
+    int32_t *const state_b = LDSR ? l_state : p.state + nb;
+    int32_t *const parent_b = LDSR ? l_parent : p.parent + nb;
+    int32_t *const fc_b = LDSR ? l_fc : p.first_child + nb;
+    double *const reward_b = LDSR ? l_reward : p.reward + nb;
+    double *const sv_b = LDSR ? l_sv : p.sv + sb;
+    int32_t *const head_b = LDSR ? l_head : p.head + sb;
+    int32_t *const tail_b = LDSR ? l_tail : p.tail + sb;
+    int32_t *const stamp_b = LDSR ? l_stamp : p.stamp + sb;
+    int32_t *const queue_b = LDSR ? l_queue : p.queue + qb;
+    const int qcap = LDSR ? p.lds_qcap : p.qcap;
+    if (LDSR) { // stage in: the rows of earlier plans and the dictionaries (a fresh planner starts from the defaults)
+        for (int i = lane; i < p.n_prev; i += 64) {
+            l_node[i] = p.node[nb + i];
+            l_state[i] = p.state[nb + i]; l_parent[i] = p.parent[nb + i]; l_fc[i] = p.first_child[nb + i];
+            l_reward[i] = p.reward[nb + i];
+        }
+        for (int s = lane; s < p.S; s += 64) {
+            l_sv[s] = p.fresh ? p.vmax : p.sv[sb + s];
+            l_head[s] = p.fresh ? -1 : p.head[sb + s];
+            l_tail[s] = p.fresh ? -1 : p.tail[sb + s];
+            l_stamp[s] = p.fresh ? -1 : p.stamp[sb + s];
+        }
+    }
+    __syncthreads();
+    auto ND = [&](int i) -> SaNode & { return node_b[i]; };
+    auto ST = [&](int i) -> int32_t & { return state_b[i]; };
+    auto PA = [&](int i) -> int32_t & { return parent_b[i]; };
+    auto FC = [&](int i) -> int32_t & { return fc_b[i]; };
+    auto RW = [&](int i) -> double & { return reward_b[i]; };
+    auto SV = [&](int s) -> double & { return sv_b[s]; };
+    auto HD = [&](int s) -> int32_t & { return head_b[s]; };
+    auto TL = [&](int s) -> int32_t & { return tail_b[s]; };
+    auto SM = [&](int s) -> int32_t & { return stamp_b[s]; };
+    const unsigned dcap = (unsigned)qcap >> 2; // backup-queue descriptors: 4 ints each
+    auto QD = [&](unsigned q, int f) -> int32_t & { return queue_b[((q & (dcap - 1)) << 2) + f]; };
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
     const double ninf = -INFINITY;
     const bool l0 = lane == 0;
@@ -582,7 +623,7 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
         bool serial_prune = p.prune != 0;
         if (p.prune && ndirty <= DCAP) {
             const int scap = p.scap; // scratch entries per lane
-            int32_t *stk = p.queue + qb + (long)lane * (p.qcap >> 6);
+            int32_t *stk = queue_b + (long)lane * (qcap >> 6);
             bool overflow = false;
             for (int base = 0; base < ndirty && !overflow; base += 64) {
                 const int32_t s = base + lane < ndirty ? dirty[base + lane] : -1;
@@ -700,6 +741,18 @@ __global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
         if (p.status) p.status[r] = status;
         if (p.env_steps) p.env_steps[r] = steps_taken;
         if (p.updates) p.updates[r] = updates;
+    }
+    if (LDSR) { // write back: every node record (flags and list links of older rows change too), this plan's rows, the dictionaries
+        __syncthreads();
+        for (int i = lane; i < n_nodes; i += 64) p.node[nb + i] = l_node[i];
+        for (int i = root + lane; i < n_nodes; i += 64) {
+            p.state[nb + i] = l_state[i]; p.parent[nb + i] = l_parent[i]; p.first_child[nb + i] = l_fc[i];
+            p.reward[nb + i] = l_reward[i];
+        }
+        for (int i = p.prev_root + lane; i < root; i += 64) p.first_child[nb + i] = l_fc[i]; // (unchanged; kept simple)
+        for (int s = lane; s < p.S; s += 64) {
+            p.sv[sb + s] = l_sv[s]; p.head[sb + s] = l_head[s]; p.tail[sb + s] = l_tail[s]; p.stamp[sb + s] = l_stamp[s];
+        }
     }
 }
 
@@ -869,6 +922,22 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
 
     const size_t lds = tab.size() * sizeof(double) + 128 * sizeof(int32_t); // tables + the wave kernel's changed-state list
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_saopd_plan: budget %d needs %zu B of LDS tables (> 64 KiB)", budget, lds);
+    // LDS-resident variant of the wave kernel: the arena after this plan, the dictionaries and a (smaller) queue in LDS.
+    // A queue overflow there rolls the plan back like any other and the retry runs on the global-memory form.
+    a.lds_rows = need;
+    a.lds_qcap = 4096;
+    while (a.lds_qcap < 2 * (1 + K * A) && a.lds_qcap < (1 << 20)) a.lds_qcap <<= 1; // the prune pass lists a plan's leaves in it
+    if (getenv("MP_SAOPD_QUEUE") && pl->qcap < a.lds_qcap) a.lds_qcap = pl->qcap; // (test knob: a deliberately small queue)
+    const size_t lds_res = ((lds + 15) & ~(size_t)15) + 16 + (size_t)need * (16 + 8 + 12) + (size_t)pl->S * (8 + 12) + (size_t)a.lds_qcap * 4;
+    // Measured (GridWorld 10x10, budget 500, first plan / following plans): 1 planner 4.8 / 2.4 ms against 6.1 / 3.1 ms
+    // from global memory, 64 planners 11.6 / 5.6 ms against 14.4 / 7.0 ms -- but 4 096 planners 32 / 40 ms against
+    // 22 / 16 ms: the chain is bound by the wave's own instruction latency (~300 ns per dependent step even from LDS), so
+    // what a big batch needs is resident waves, which 39 KB of LDS per planner takes away.  Hence: latency mode only,
+    // at most one planner per CU.
+    bool use_lds = pl->wave && lds_res <= kLdsBytes - 1024 && n <= ctx->prop.multiProcessorCount;
+    if (const char *e = getenv("MP_SAOPD_LDS")) use_lds = pl->wave && lds_res <= kLdsBytes - 1024 && e[0] == '1';
+    const int scap_global = a.scap;
+    if (use_lds) a.scap = a.lds_qcap >> 6 < a.scap ? a.lds_qcap >> 6 : a.scap;
     // what a plan changes outside its own node rows: the per-state dictionaries, the list links of older tail nodes
     // and the generator states.  They are copied first, so that a plan that fills its backup queue (values decaying
     // to floating-point underflow make the reference run tens of thousands of backups) can be rolled back and run
@@ -894,7 +963,12 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
                                pl->head, pl->tail, pl->stamp);
             ++launches;
         }
-        if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel, dim3((unsigned)n), dim3(64), lds, st, a);
+        if (pl->wave && use_lds) {
+            if (lds_res > 64 * 1024)
+                MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(saopd_wave_kernel<true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res));
+            hipLaunchKernelGGL(saopd_wave_kernel<true>, dim3((unsigned)n), dim3(64), lds_res, st, a);
+        } else if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel<false>, dim3((unsigned)n), dim3(64), lds, st, a);
         else hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
         ++launches;
         int32_t ovf = 0;
@@ -902,14 +976,21 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         MP_HIP(hipStreamSynchronize(st));
         MP_HIP(hipGetLastError());
         const size_t bigger = (size_t)n * pl->qcap * 4 * 4;
-        if (!ovf || bigger > max_queue_bytes) break; // done, or out of room: the full planners keep MP_ERR_ALLOC
-        // roll back and run again with a queue four times as large
-        MP_HIP(hipFree(pl->queue));
-        pl->queue = nullptr;
-        if (hipMalloc(&pl->queue, bigger) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", bigger);
-        pl->qcap *= 4;
-        a.queue = pl->queue; a.qcap = pl->qcap;
-        a.scap = lane_scratch();
+        if (!ovf) break;
+        if (use_lds) {
+            // the small LDS queue filled up: roll back and run the plan on the global-memory form (full-size queue)
+            use_lds = false;
+            a.scap = scap_global;
+        } else {
+            if (bigger > max_queue_bytes) break; // out of room: the full planners keep MP_ERR_ALLOC
+            // roll back and run again with a queue four times as large
+            MP_HIP(hipFree(pl->queue));
+            pl->queue = nullptr;
+            if (hipMalloc(&pl->queue, bigger) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", bigger);
+            pl->qcap *= 4;
+            a.queue = pl->queue; a.qcap = pl->qcap;
+            a.scap = lane_scratch();
+        }
         if (!fresh) {
             MP_HIP(hipMemcpyAsync(pl->sv, pl->snap_sv, sn * 8, hipMemcpyDeviceToDevice, st));
             MP_HIP(hipMemcpyAsync(pl->head, pl->snap_head, sn * 4, hipMemcpyDeviceToDevice, st));
