@@ -13,5 +13,5 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 @pytest.mark.parametrize("seed", [11, 12])
 def test_random_cases_match_the_oracle(seed):
     import fuzz_parity
-    kinds = fuzz_parity.run(150, seed)
-    assert sum(kinds.values()) == 150 and len(kinds) == 6
+    kinds = fuzz_parity.run(200, seed)
+    assert sum(kinds.values()) == 200 and len(kinds) == 9

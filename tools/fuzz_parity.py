@@ -60,7 +60,7 @@ def one_case(ctx, g, case):
     s0 = g.integers(0, s, size=n).astype(np.int32)
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
-    kind = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree"][int(g.integers(0, 6))]
+    kind = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree", "uct_listed", "opd_masked", "ropd"][int(g.integers(0, 9))]
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps)
     if kind == "vi":
         model.close()
@@ -165,6 +165,75 @@ def one_case(ctx, g, case):
         ref = oracle.uct_plan_batch(t, r, term, s0, episodes, horizon, gamma, temperature, prior, rollout, rng.copy(),
                                     steps0=steps0, max_steps=max_steps, done_rule=done_rule, max_plan_len=horizon, n_threads=8)
         for k in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+    elif kind == "uct_listed":      # policies over restricted action sets (mcts.py:59-97): listed-policy kernel variant
+        from tests.helpers import reference_policy_lists
+        if a not in (2, 3, 4, 5, 6, 8):
+            model.close()
+            return desc
+        avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
+        avail[np.arange(s), g.integers(0, a, size=s)] = True
+        kinds = [{"type": "random"}, {"type": "random_available"},
+                 {"type": "preference", "action": int(g.integers(0, a + 1)), "ratio": float(g.choice([2, 3, 0.5]))}]
+        pl, rl = reference_policy_lists(kinds[int(g.integers(0, 3))], avail), reference_policy_lists(kinds[int(g.integers(0, 3))], avail)
+        prior, rollout, listed = np.zeros((s, a)), np.zeros((s, a)), np.zeros((s, a), bool)
+        for i in range(s):
+            prior[i, pl["actions"][i]] = pl["p"][i]
+            listed[i, pl["actions"][i]] = True
+            rollout[i, rl["actions"][i]] = rl["p"][i]
+        episodes, horizon = int(g.choice([0, 1, 5, 33, 60])), int(g.choice([1, 2, 9, 30]))
+        temperature = float(g.choice([0.0, 1.0, 10.0, 3000.0]))
+        steps0 = g.integers(0, 3, size=n).astype(np.int32) if max_steps else None
+        desc.update(episodes=episodes, horizon=horizon, temperature=temperature)
+        policy = ctx.load_policy(model, prior, rollout, listed=listed)
+        rng_dev = rng.copy()
+        out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, None, None, rng_dev, root_steps=steps0,
+                           max_plan_len=horizon, policy=policy)
+        policy.close()
+        ref = oracle.uct_plan_batch(t, r, term, s0, episodes, horizon, gamma, temperature, pl, rl, rng.copy(), steps0=steps0,
+                                    max_steps=max_steps, done_rule=done_rule, max_plan_len=horizon, n_threads=8)
+        for k in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+    elif kind == "opd_masked":      # deterministic.py:32-35 on environments that restrict the available actions
+        avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
+        avail[np.arange(s), g.integers(0, a, size=s)] = True
+        model.close()
+        model = ctx.load_table(t, r, term, done_rule=done_rule, available=avail)
+        budget = int(g.choice([0, 1, a, 3 * a + 1, 100, 700]))
+        tr = float(g.choice([0.0, 0.25, 1.0]))
+        if gamma >= 0.999:
+            gamma = 0.95
+        desc.update(budget=budget, terminal_reward=tr, gamma=gamma)
+        rng_dev = rng.copy()
+        out = ctx.opd_plan(model, s0, budget, gamma, tr, rng_dev, max_plan_len=budget // a + 1)
+        ref = oracle.opd_plan_batch(t, r, term, s0, budget, gamma, tr, rng.copy(), done_rule=done_rule,
+                                    max_plan_len=budget // a + 1, n_threads=8, available=avail)
+        for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+    elif kind == "ropd":            # discrete robust OPD (agents/robust/robust.py:28-50): M models, joint states
+        m = int(g.choice([1, 2, 3, 7]))
+        tm = np.stack([t] + [g.integers(0, s, size=(s, a), dtype=np.int64) for _ in range(m - 1)])
+        rm = np.stack([r] + [np.clip(r * float(g.uniform(0.5, 1.0)), 0.0, 1.0) for _ in range(m - 1)])
+        termm = np.stack([term] + [g.random(s) < 0.1 for _ in range(m - 1)])
+        model.close()
+        model = ctx.load_joint(tm, rm, termm, done_rule=done_rule)
+        budget = int(g.choice([0, 1, a, 3 * a + 1, 100, 400]))
+        tr = float(g.choice([0.0, 0.25, 1.0]))
+        if gamma >= 0.999:
+            gamma = 0.95
+        n = min(n, 200)
+        joint = g.integers(0, s, size=(n, m)).astype(np.int32)
+        if g.random() < 0.5:
+            joint[:] = joint[:, :1]                                   # every model in the same state (the usual root)
+        desc.update(budget=budget, terminal_reward=tr, gamma=gamma, M=m, n=n)
+        rng_dev = rng[:n].copy()
+        out = ctx.ropd_plan(model, joint, budget, gamma, tr, rng_dev, max_plan_len=budget // a + 1)
+        ref = oracle.ropd_plan_batch(tm, rm, termm, joint, budget, gamma, tr, rng[:n].copy(), done_rule=done_rule,
+                                     max_plan_len=budget // a + 1, n_threads=8)
+        for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
             eq(out[k], ref[k], k, desc)
         eq(rng_dev, ref["rng_after"], "rng", desc)
     elif kind == "opd":

@@ -50,7 +50,7 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "uct_prior", "uct_cartpole", "opd", "saopd", "vi", "rvi", "vi_dense"):
+    for wl in ("uct", "uct_prior", "uct_cartpole", "opd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
@@ -68,7 +68,7 @@ def main():
                     name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
             lines.append("")
     traffic = {}
-    for wl in ("uct", "uct_prior", "vi_dense", "opd", "saopd"):
+    for wl in ("uct", "uct_prior", "vi_dense", "rvi_dense_shard", "opd", "saopd"):
         entry = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             f = os.path.join(src, "pmc_{}_{}".format(wl, ctr), wl + "_counter_collection.csv")
@@ -80,10 +80,9 @@ def main():
             traffic[wl] = entry
     if traffic:
         lines += ["## HBM traffic (PMC, separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`)", "",
-                  "Per launch, KB as rocprofv3 reports them. gfx950 correction (MI355X_MICROARCH.md §HBM): FETCH_SIZE "
-                  "counts half the bytes of a wide (16 B/lane) coalesced stream -- vi_dense_q streams 4.0 GB per "
-                  "sweep with dwordx4 loads and reads 1.95 GB raw, i.e. exactly that factor 2 (calibration on a known "
-                  "byte count); narrow random gathers (uct) are uncalibrated, raw values are shown.", "",
+                  "Per launch, KB as rocprofv3 reports them.  To bytes: x2 for FETCH_SIZE (streams AND scattered 16-byte gathers: "
+                  "every 128-byte line request is tallied at 64 B), x1 for WRITE_SIZE -- calibrated on known request counts in "
+                  "these kernels' own access patterns, profiles/r02_gather_calib.md.", "",
                   "| workload | kernel | FETCH_SIZE KB | WRITE_SIZE KB |", "|---|---|---|---|"]
         for wl, entry in traffic.items():
             for k, v in entry.items():
