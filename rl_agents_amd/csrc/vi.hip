@@ -493,6 +493,8 @@ __global__ __launch_bounds__(256) void vi_det_emit(ViEmitArgs e)
 struct ViGenArgs {
     int M, S, A, B, robust, vform, k;
     int Sc; // columns of a dense model (= S unless the model holds a block of source-state rows)
+    int nseg, seg_cols; // dense: column segments (blockIdx.y), columns per segment (a multiple of the V chunk); 1 = unsplit
+    double *partial;    // dense, nseg > 1: per-segment dot products [M][nseg][S*A]
     const double *P;
     const int32_t *NXT;
     const double *R;
@@ -512,6 +514,10 @@ struct ViGenArgs {
 #define MP_DENSE_UNROLL 4
 #endif
 constexpr int kDenseChunk = MP_DENSE_CHUNK; // doubles of V staged in LDS per pass (32 KiB)
+#ifndef MP_DENSE_SEG_CHUNKS
+#define MP_DENSE_SEG_CHUNKS 2
+#endif
+constexpr int kDenseSegCols = MP_DENSE_SEG_CHUNKS * MP_DENSE_CHUNK; // columns per segment of the column split
 
 // Rows of the (S*A) x S matrix T_m are contracted with V on v_mfma_f64_16x16x4_f64: the A operand
 // of one MFMA is a 16-row x 4-column block of T, the B operand is V broadcast into all 16 columns,
@@ -519,6 +525,10 @@ constexpr int kDenseChunk = MP_DENSE_CHUNK; // doubles of V staged in LDS per pa
 // it loads 4 consecutive doubles (32 B) of its row per 16-column step, so the 4 lanes of a row
 // cover one 128-B line and the k-slot <-> column map is (l >> 4) * 4 + t for MFMA t of the step
 // (the same permutation is applied to V, which is all a dot product needs).
+// Column split (nseg > 1): long rows (Sc > kDenseSegCols) are cut into segments of kDenseSegCols columns handled by
+// different workgroups (blockIdx.y) -- a row block of a sharded model has few (s,a) rows (C5: 31 250 per rank = 489
+// workgroups for 256 CUs), too few to keep enough loads in flight; the segments' partial dot products are summed in
+// segment order by vi_dense_combine, so the result depends on Sc only (a row block reassembles the full backup bit for bit).
 __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
 {
     if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
@@ -529,12 +539,14 @@ __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
     const int i = lane & 15, q = lane >> 4;
     long row = row0 + i;
     if (row >= SA) row = SA - 1; // tail tile: load a valid row, discard the result
+    const int seg = blockIdx.y;
+    const int col_lo = seg * p.seg_cols, col_hi = min(p.Sc, col_lo + p.seg_cols);
     double best[4] = {0.0, 0.0, 0.0, 0.0};
     for (int m = 0; m < p.M; ++m) {
         double4_t acc = {0.0, 0.0, 0.0, 0.0};
         const double *prow = p.P + ((long)m * SA + row) * p.Sc;
-        for (int c0 = 0; c0 < p.Sc; c0 += kDenseChunk) {
-            const int ch = min(kDenseChunk, p.Sc - c0);
+        for (int c0 = col_lo; c0 < col_hi; c0 += kDenseChunk) {
+            const int ch = min(kDenseChunk, col_hi - c0);
             __syncthreads();
             for (int t = threadIdx.x; t < kDenseChunk; t += 256) vs[t] = t < ch ? p.Vcur[c0 + t] : 0.0;
             __syncthreads();
@@ -570,6 +582,10 @@ __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
         for (int r = 0; r < 4; ++r) {
             const long orow = row0 + q + 4 * r;
             if (orow < SA) {
+                if (p.nseg > 1) {
+                    if (i == 0) p.partial[((long)m * p.nseg + seg) * SA + orow] = accr[r];
+                    continue;
+                }
                 const int s = (int)(orow / p.A);
                 double nv = 0.0 + accr[r];
                 if (!p.robust && p.term && p.term[s]) nv = 0.0;
@@ -578,13 +594,50 @@ __global__ __launch_bounds__(256) void vi_dense_q(ViGenArgs p)
             }
         }
     }
-    if (i == 0) {
+    if (i == 0 && p.nseg == 1) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long orow = row0 + q + 4 * r;
             if (orow < SA) p.Qnext[orow] = best[r];
         }
     }
+}
+
+// nseg > 1: Q[row] = min_m (R_m + gamma * mask(sum over segments, in segment order))
+__global__ __launch_bounds__(256) void vi_dense_combine(ViGenArgs p)
+{
+    if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
+    const long SA = (long)p.S * p.A;
+    const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= SA) return;
+    const int s = (int)(row / p.A);
+    double best = 0.0;
+    for (int m = 0; m < p.M; ++m) {
+        double nv = 0.0;
+        for (int g = 0; g < p.nseg; ++g) nv += p.partial[((long)m * p.nseg + g) * SA + row];
+        if (!p.robust && p.term && p.term[s]) nv = 0.0;
+        const double qm = p.R[(long)m * SA + row] + p.gamma * nv;
+        if (m == 0 || qm < best) best = qm;
+    }
+    p.Qnext[row] = best;
+}
+
+// launch the dense backup (split by column segments when the rows are long)
+static int vi_dense_launch(mp_ctx *ctx, ViGenArgs &a, hipStream_t st, int *launches)
+{
+    const long SA = (long)a.S * a.A;
+    a.seg_cols = kDenseSegCols;
+    a.nseg = a.Sc > kDenseSegCols && !getenv("MP_DENSE_NO_SPLIT") ? (a.Sc + kDenseSegCols - 1) / kDenseSegCols : 1;
+    if (a.nseg == 1) a.seg_cols = a.Sc;
+    a.partial = nullptr;
+    if (a.nseg > 1) MP_TRY(ws_get(ctx, WS_VI4, (size_t)a.M * a.nseg * SA, &a.partial));
+    hipLaunchKernelGGL(vi_dense_q, dim3((unsigned)((SA + 63) / 64), (unsigned)a.nseg), dim3(256), kDenseChunk * sizeof(double), st, a);
+    if (launches) ++*launches;
+    if (a.nseg > 1) {
+        hipLaunchKernelGGL(vi_dense_combine, dim3((unsigned)((SA + 255) / 256)), dim3(256), 0, st, a);
+        if (launches) ++*launches;
+    }
+    return MP_OK;
 }
 
 // numpy add.reduce inner loop for n <= 128 contiguous doubles (pairwise summation base cases)
@@ -825,7 +878,7 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
         a.M = M; a.S = S; a.A = A; a.B = m->B; a.robust = robust; a.vform = vform; a.Sc = S;
         a.P = m->P; a.NXT = m->NXT; a.R = m->R; a.term = m->term; a.gamma = gamma; a.rtol = rtol; a.atol = atol;
         a.notclose = notclose;
-        const unsigned gq_dense = (unsigned)((SA + 63) / 64), gq_sparse = (unsigned)((SA + 255) / 256);
+        const unsigned gq_sparse = (unsigned)((SA + 255) / 256);
         MP_TRY(kernels_begin(ctx));
         for (int k = 0; k < iterations; ++k) {
             a.k = k;
@@ -833,12 +886,14 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
             a.Vnext = Vb + (long)((k + 1) & 1) * S;
             a.Qcur = Qb + (long)(k & 1) * SA;
             a.Qnext = Qb + (long)((k + 1) & 1) * SA;
-            if (m->mode == MP_MODE_STOCHASTIC)
-                hipLaunchKernelGGL(vi_dense_q, dim3(gq_dense), dim3(256), kDenseChunk * sizeof(double), st, a);
-            else
+            if (m->mode == MP_MODE_STOCHASTIC) {
+                MP_TRY(vi_dense_launch(ctx, a, st, &launches));
+            } else {
                 hipLaunchKernelGGL(vi_sparse_q, dim3(gq_sparse), dim3(256), 0, st, a);
+                ++launches;
+            }
             hipLaunchKernelGGL(vi_finish, dim3(gs), dim3(256), 0, st, a);
-            launches += 2;
+            ++launches;
         }
         MP_TRY(kernels_end(ctx, launches));
         hipLaunchKernelGGL(vi_find_stop, dim3(1), dim3(64), 0, st, iterations, notclose, result);
@@ -872,8 +927,9 @@ static int vi_backup(mp_ctx *ctx, mp_model *m, double gamma, int robust, const d
     a.M = robust ? m->M : 1; a.S = m->S; a.A = m->A; a.Sc = m->Sc; a.robust = robust; a.k = 0;
     a.P = m->P; a.R = m->R; a.term = m->term; a.gamma = gamma; a.Vcur = dV; a.Qnext = dQ; a.notclose = flag;
     MP_TRY(kernels_begin(ctx));
-    hipLaunchKernelGGL(vi_dense_q, dim3((unsigned)((SA + 63) / 64)), dim3(256), kDenseChunk * sizeof(double), st, a);
-    MP_TRY(kernels_end(ctx, 1));
+    int launches = 0;
+    MP_TRY(vi_dense_launch(ctx, a, st, &launches));
+    MP_TRY(kernels_end(ctx, launches));
     MP_HIP(hipGetLastError());
     MP_TRY(stage_out_copy(ctx, Q, dQ, (size_t)SA, mem));
     if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
