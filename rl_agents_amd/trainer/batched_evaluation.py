@@ -108,3 +108,62 @@ class BatchedEvaluation(object):
         wall = time.perf_counter() - t0
         return dict(returns=returns, discounted_returns=gamma_returns, lengths=steps.copy(), actions=actions_log,
                     fps=env_steps / wall, plan_seconds=plan_seconds, planner_env_steps=planner.env_steps)
+
+
+# --------------------------------------------------------------------------------------------- benchmark mode
+def load_env(env_config):
+    """An environment from a reference-style env config: a dict or the path of a JSON file holding the finite-MDP
+    tables (``scripts/configs/FiniteMDPEnv/**/env_*.json``: mode / transition / reward / terminal / max_steps, next to
+    the ``id`` / ``import_module`` keys that name the absent ``finite_mdp`` package)."""
+    import json
+    from rl_agents_amd.envs import FiniteMDPEnv, MaskedFiniteMDPEnv
+    if not isinstance(env_config, dict):
+        with open(env_config) as f:
+            env_config = json.load(f)
+    cfg = {k: v for k, v in env_config.items() if k in ("mode", "transition", "reward", "terminal", "next", "max_steps",
+                                                         "state", "done_rule", "available")}
+    if "transition" not in cfg:
+        raise ValueError("batched benchmark: the environment config must hold finite-MDP tables")
+    env = (MaskedFiniteMDPEnv if "available" in cfg else FiniteMDPEnv)(cfg)
+    env.reset()
+    return env
+
+
+def generate_agent_configs(benchmark_config):
+    """``scripts/experiments.py:118-143`` without the temporary files: a ``base_agent`` config varied over ``values`` of
+    ``key`` becomes the ``agents`` list (dicts)."""
+    from rl_agents_amd.agents.common.factory import load_agent_config
+    agents = list(benchmark_config.get("agents", []))
+    if "base_agent" in benchmark_config:
+        base = benchmark_config["base_agent"]
+        base = dict(base) if isinstance(base, dict) else load_agent_config(base)
+        agents += [dict(base, **{benchmark_config["key"]: value}) for value in benchmark_config["values"]]
+    return agents
+
+
+def batched_benchmark(benchmark_config, episodes=64, seed=0, max_steps=None):
+    """The reference's benchmark mode (``scripts/experiments.py:85-116``: the product of ``environments`` x ``agents``,
+    one process per experiment, ``--episodes`` sequential episodes each) on the device planners: every experiment
+    becomes ONE :class:`BatchedEvaluation` whose ``episodes`` episodes -- seeded ``seed + i`` like
+    ``Evaluation(sim_seed=seed)`` seeds episode i -- share each step's batched ``plan`` launch.  Returns one summary dict per
+    experiment, in product order (the reference writes the run directories of its evaluations to a summary file)."""
+    from itertools import product
+    from rl_agents_amd.agents.common.factory import load_agent
+    if not isinstance(benchmark_config, dict):
+        import json
+        with open(benchmark_config) as f:
+            benchmark_config = json.load(f)
+    results = []
+    for env_config, agent_config in product(benchmark_config["environments"], generate_agent_configs(benchmark_config)):
+        env = load_env(env_config)
+        agent = load_agent(agent_config, env)
+        out = BatchedEvaluation(env, agent, num_episodes=episodes, sim_seed=seed, max_steps=max_steps).run()
+        results.append(dict(environment=env_config if not isinstance(env_config, dict) else "<dict>",
+                            agent=agent_config if not isinstance(agent_config, dict) else
+                            {k: v for k, v in agent_config.items() if not isinstance(v, (list, dict)) or k == "__class__"},
+                            episodes=int(episodes), mean_return=float(out["returns"].mean()),
+                            mean_discounted_return=float(out["discounted_returns"].mean()),
+                            mean_length=float(out["lengths"].mean()), fps=float(out["fps"]),
+                            plan_seconds=float(out["plan_seconds"]), returns=out["returns"], lengths=out["lengths"],
+                            actions=out["actions"]))
+    return results

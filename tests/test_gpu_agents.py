@@ -438,3 +438,34 @@ def test_tree_export_checks_ownership():
     assert a.planner.root.count > 0
     with pytest.raises(RuntimeError):
         b.planner.export_tree(0)
+
+
+def test_batched_benchmark_equals_individual_evaluations(tmp_path):
+    """Benchmark mode (scripts/experiments.py:85-116): environments x agents (a base agent varied over a key), every
+    experiment one batched evaluation -- same episodes as running each experiment alone."""
+    import json
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation, batched_benchmark
+    envs = []
+    for i, cfg in enumerate((generators.highway_shaped(3, 4, 10, seed=3), generators.gridworld())):
+        path = tmp_path / "env_{}.json".format(i)
+        path.write_text(json.dumps(dict(id="finite-mdp-v0", import_module="finite_mdp", mode="deterministic",
+                                        transition=cfg["transition"].tolist(), reward=cfg["reward"].tolist(),
+                                        terminal=cfg["terminal"].astype(int).tolist(), max_steps=12)))
+        envs.append(str(path))
+    base = tmp_path / "agent.json"
+    base.write_text(json.dumps(dict(__class__=UCT, gamma=0.9)))
+    bench = dict(environments=envs, base_agent=str(base), key="budget", values=[60, 150],
+                 agents=[dict(__class__=OPD, budget=80, gamma=0.8)])
+    results = batched_benchmark(bench, episodes=9, seed=5)
+    assert len(results) == 2 * 3
+    # one experiment re-run alone
+    cfg = json.loads(open(envs[1]).read())
+    env = FiniteMDPEnv({k: cfg[k] for k in ("mode", "transition", "reward", "terminal", "max_steps")})
+    env.reset()
+    alone = BatchedEvaluation(env, agent_factory(env, dict(__class__=UCT, gamma=0.9, budget=150)), num_episodes=9, sim_seed=5).run()
+    r = results[3 + 2]      # second environment; agents: the OPD config, then budget 60, budget 150
+    np.testing.assert_array_equal(r["actions"], alone["actions"])
+    assert np.array_equal(r["returns"], alone["returns"]) and r["episodes"] == 9
+    assert results[0]["agent"]["__class__"] == OPD and results[1]["agent"]["budget"] == 60
