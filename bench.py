@@ -532,6 +532,80 @@ def bench_opd(args, rank, world, local):
     return res
 
 
+def bench_ropd(args, rank, world, local):
+    """Discrete robust OPD (agents/robust/robust.py:28-50) at C4's shape with M = 2 models: highway-shaped S = 10 000,
+    A = 5 and the same table with 10 % of the transitions rewired, budget 5000 (1000 expansions), 1024 roots per GPU."""
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    n_roots = args.roots or 1024
+    budget, gamma, m_ = 5000, 0.8, 2
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    cfg2 = generators.rewire(cfg, 0.1, seed=1)
+    t = np.stack([cfg["transition"], cfg2["transition"]])
+    r = np.stack([cfg["reward"], cfg2["reward"]])
+    term = np.stack([cfg["terminal"], cfg2["terminal"]])
+    _, s_, a_ = r.shape
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_joint(t, r, term)
+    non_term = np.flatnonzero(~np.asarray(cfg["terminal"]))
+    all_roots = np.random.Generator(np.random.PCG64(12345)).choice(non_term, size=world * n_roots).astype(np.int32)
+    s0 = np.repeat(all_roots[rank * n_roots:(rank + 1) * n_roots, None], m_, axis=1)
+    dev = torch.device("cuda", local)
+    d_s0 = torch.from_numpy(np.ascontiguousarray(s0)).to(dev)
+    d_rng = torch.from_numpy(seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots)).view(np.int64)).to(dev)
+    mpl = 32
+    d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
+    d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
+    d_lo = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_up = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
+    d_status = torch.empty(n_roots, dtype=torch.int32, device=dev)
+
+    def step():
+        ctx.ropd_plan_device(model, n_roots, d_s0, budget, gamma, 0.0, d_rng, mpl, plans=d_plans, plan_len=d_len,
+                             root_lower=d_lo, root_upper=d_up, env_steps=d_steps, status=d_status)
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    step()
+    k_ms = ctx.last_kernel_ms()[0]
+    joint_steps = int(d_steps.sum().item())
+    assert int(d_status.abs().sum().item()) == 0
+    total = sum_over_ranks(float(joint_steps), world) * m_          # every joint step steps M model environments
+    k = budget // a_
+    d_avg = 10.0
+    bytes_per_exp = a_ * m_ * (13 + 20) + a_ * 24 + 16 * a_ * d_avg + 16 * d_avg   # per model: record + {L, state, reward}; per child: minima + meta
+    alg = bytes_per_exp * k * n_roots
+    res = dict(
+        metric="rollout env-steps/sec (discrete robust OPD plan(), budget=5000, M=2 models)", unit="env-steps/s",
+        value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
+        config=dict(workload="robust_opd_highway_shaped_S{}_A{}_M{}_budget{}_roots{}_per_gpu".format(s_, a_, m_, budget, n_roots),
+                    n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, budget=budget, gamma=gamma, models=m_,
+                    plan_ms_per_root=1e3 * dt / args.steps / n_roots, parallelism="roots sharded over {} GPU(s)".format(world)),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel="ropd_kernel",
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+    )
+    add_traffic(res["roofline"], "ropd", "ropd_kernel", n_roots * 64)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = host_cores()
+        n_cpu = 4 * cores
+        t1 = time.perf_counter()
+        o = oracle.ropd_plan_batch(t, r, term, np.resize(s0, (n_cpu, m_)), budget, gamma, 0.0, seed_states(np.arange(n_cpu)),
+                                   n_threads=cores)
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=float(o["env_steps"].sum()) * m_ / cdt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="oracle/planning_oracle.c orc_ropd_plan_batch, {} roots, OpenMP".format(n_cpu))
+    return res
+
+
 def bench_saopd(args, rank, world, local):
     """State-aware OPD (tree_search/state_aware.py) at the reference's own GridWorld configuration
     (scripts/configs/GridWorld/agents/state-aware.json: budget 500, gamma 0.8; 10x10 grid).  A step = the first plan()
@@ -660,6 +734,8 @@ def bench_vi(args, rank, world, local, dense, robust=False):
     dt = max_over_ranks(time.perf_counter() - t0, world)
     step()
     k_ms, n_launch = ctx.last_kernel_ms()
+    if not dense and n_launch == 1:
+        name = "vi_det_persist (one launch, {} sweeps)".format(sweeps)
     per_sweep_ms = k_ms / sweeps
     res = dict(
         metric="value-iteration Bellman sweeps/sec", unit="sweeps/s", value=world * sweeps * args.steps / dt,
@@ -847,6 +923,8 @@ def main():
             res = bench_uct_cartpole(args, rank, world, local)
         elif args.workload == "opd":
             res = bench_opd(args, rank, world, local)
+        elif args.workload == "ropd":
+            res = bench_ropd(args, rank, world, local)
         elif args.workload == "saopd":
             res = bench_saopd(args, rank, world, local)
         elif args.workload == "rvi_dense_shard":
