@@ -111,7 +111,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     }
     __syncthreads();
     int n_nodes = 1;
-    int n_real = 0; // children of available actions = planner.step calls (deterministic.py:41)
+    // children of available actions = planner.step calls (deterministic.py:41), counted per lane: the GLB variant sits at
+    // 80 SGPRs = the last count that still admits 8 waves per SIMD, a wave-uniform counter would cost the occupancy
+    int real_mine = 0;
     int status = MP_OK;
     int k_done = 0;
     // best leaf of this lane's class (ids == lane mod 64); -inf / INT_MAX when the class has no leaf
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             exp_lds[k] = leaf;
         }
         n_nodes += A;
-        n_real += __popcll(__ballot(avail));
+        real_mine += avail ? 1 : 0;
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
@@ -307,6 +309,8 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         printf("opd prof root0: K=%d total=%lld scan=%lld expand=%lld final=%lld (clock64 ticks)\n", p.K,
                (long long)(clock64() - t_all0), t_scan, t_exp, (long long)(clock64() - cf0));
 #endif
+    int n_real = real_mine;
+    for (int off = 32; off > 0; off >>= 1) n_real += __shfl_xor(n_real, off);
     if (lane == 0) {
         if (p.status) p.status[root] = status;
         if (p.env_steps) p.env_steps[root] = (int64_t)n_real;

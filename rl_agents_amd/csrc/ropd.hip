@@ -53,7 +53,7 @@ struct ROpdArgs {
 };
 
 template <bool GLB>
-__global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
+__global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GLB: the register allocation must admit 8 waves per SIMD
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = p.T;

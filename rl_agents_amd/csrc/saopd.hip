@@ -389,8 +389,11 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 // planners per CU).  The kernel is a chain of dependent accesses (queue front -> list element -> parent -> children ->
 // state values), ~15 000 per plan: from LDS each costs ~100 cycles instead of a ~600-2 000-cycle L2 / HBM round trip.
 // The host selects it while the arena fits (first plans of a planner; later plans fall back to the global-memory form).
+#ifndef MP_SAOPD_MIN_WAVES
+#define MP_SAOPD_MIN_WAVES 8 // waves per SIMD the register allocation must admit (106 SGPRs would cap the kernel at 6)
+#endif
 template <bool LDSR>
-__global__ __launch_bounds__(64) void saopd_wave_kernel(SaArgs p)
+__global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_kernel(SaArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int ntab = 3 * (p.K + 3);
