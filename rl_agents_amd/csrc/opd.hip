@@ -227,22 +227,20 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             U[i] = u;
             if (u > root_upper) root_upper = u;
         }
-        {
-            int dummy = 0;
-            wave_argmax(root_upper, dummy);
-        }
+        root_upper = wave_max(root_upper);
         __syncthreads();
+        PROF_T(cf1);
         // lower bounds: same pass over the creation-time L values
         for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
         __syncthreads();
+        PROF_T(cf2);
         int ek = 0; // EXPG: 64 entries of the parent map per coalesced read
         for (int k = k_done - 1; k >= 0; --k) {
             const int g = 1 + k * A;
-            double m = LU(g);
-            for (int a = 1; a < A; ++a) {
-                const double v = LU(g + a);
-                if (v > m) m = v;
-            }
+            // the |A| children in one read, lane a its child a; the maximum on DPP (a wave is one instruction stream and
+            // this loop is a K-long dependent chain: |A| reads one after the other were 900 cycles per step)
+            const double mine = lane < A ? LU(g + lane) : ninf;
+            const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
             int parent_k;
             if (EXPG) {
                 if (k == k_done - 1 || (k & 63) == 63) ek = (k & ~63) + lane < k_done ? exp_lds[(k & ~63) + lane] : 0;
@@ -254,10 +252,12 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             if (GLB) __syncthreads(); // the next step may read this node through memory, from other lanes
         }
         __syncthreads();
+        PROF_T(cf3);
         for (int k = lane; k < k_done; k += 64) {
             const int n = exp_lds[k];
             NA[n].L = LU(n);
         }
+        PROF_T(cf4);
         // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
         // (deterministic.py:21-26): random_argmax over the children's lower bounds (in LDS).
         // A node's children are group 1 + k*A where k is its expansion index; a chosen child's own
@@ -268,12 +268,8 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
-            double m = LU(fc);
-            for (int a = 1; a < A; ++a) {
-                const double v = LU(fc + a);
-                if (v > m) m = v;
-            }
             const double l = lane < A ? LU(fc + lane) : ninf;
+            const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
@@ -291,6 +287,12 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             }
             kcur = knext;
         }
+#ifdef MP_PROFILE
+        if (root == 0 && lane == 0)
+            printf("opd prof root0 final: U %lld  Lload %lld  backward %lld  Lstore %lld  descent %lld (len %d)\n",
+                   (long long)(cf1 - cf0), (long long)(cf2 - cf1), (long long)(cf3 - cf2), (long long)(cf4 - cf3),
+                   (long long)(clock64() - cf4), len);
+#endif
         if (lane == 0) {
             gen.store(p.rng + (long)root * 6);
             if (p.plans)

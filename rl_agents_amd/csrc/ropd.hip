@@ -162,20 +162,14 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
             Umin[i] = u;
             if (u > root_upper) root_upper = u;
         }
-        {
-            int dummy = 0;
-            wave_argmax(root_upper, dummy);
-        }
+        root_upper = wave_max(root_upper);
         __syncthreads();
         for (int i = lane; i < n_nodes; i += 64) LU(i) = Lmin[i];
         __syncthreads();
         for (int k = k_done - 1; k >= 0; --k) {
             const int g = 1 + k * A;
-            double m = LU(g);
-            for (int a = 1; a < A; ++a) {
-                const double v = LU(g + a);
-                if (v > m) m = v;
-            }
+            const double mine = lane < A ? LU(g + lane) : ninf; // the |A| children in one read, maximum on DPP (opd.hip)
+            const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
             if (lane == 0) LU(exp_lds[k]) = m;
             if (GLB) __syncthreads();
         }
@@ -191,12 +185,8 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
         int kcur = k_done > 0 ? 0 : -1;
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
-            double m = LU(fc);
-            for (int a = 1; a < A; ++a) {
-                const double v = LU(fc + a);
-                if (v > m) m = v;
-            }
             const double l = lane < A ? LU(fc + lane) : ninf;
+            const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt);

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         bk = RW(c) + p.gamma * svc;
                         a_id = lane;
                     }
-                    wave_argmax(u, a_id); // first maximal U in action order
+                    if (A <= 16) row0_argmax(u, a_id); else wave_argmax(u, a_id); // first maximal U in action order
                     const double backup = __shfl(bk, a_id);
                     const double old = SV(sn);
                     const int stm = SM(sn);
@@ -720,9 +720,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             int fc = FC(node);
             while (fc >= 0) {
                 const double l = lane < A ? ND(fc + lane).lower : ninf;
-                double m = l;
-                int dummy = lane;
-                wave_argmax(m, dummy);
+                const double m = A <= 16 ? row0_max(l) : wave_max(l);
                 const unsigned long long ties = __ballot(lane < A && l == m);
                 const int nt = __popcll(ties);
                 int pick = nt > 1 ? (int)gen.below((uint32_t)nt) : 0;
