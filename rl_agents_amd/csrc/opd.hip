@@ -43,6 +43,7 @@ namespace mp {
 struct OpdArgs {
     int n_roots, S, A, K, cap, done_on_next, max_plan_len;
     int T; // LDS row length of a residue class: odd, >= ceil(cap / 64)
+    int chunk; // GLB: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
     const Rec *rec;
     const int32_t *root_state;
     const double *g1;   // g1[d]   = gamma ** (d - 1), d >= 1
@@ -83,13 +84,14 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 //              that is 40 448 B, FOUR roots per CU instead of three -- the 1024-root shard of BASELINE C4 stays on the
 //              low-latency variant (2.0 ms instead of 2.7 ms).
 template <bool GLB, bool EXPG = false>
-__global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
+__global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = p.T;                                                // odd, >= ceil(cap / 64)
+    constexpr bool EXPH = GLB || EXPG;                                          // parent map in HBM
     double *leafU = GLB ? p.leaf_global + (long)blockIdx.x * 64 * T : lds;      // [64 * T]
-    int32_t *exp_lds = EXPG ? p.expanded + (long)blockIdx.x * (p.K > 0 ? p.K : 1)
-                            : reinterpret_cast<int32_t *>(GLB ? lds : lds + 64 * T);   // [K]
+    int32_t *exp_lds = EXPH ? p.expanded + (long)blockIdx.x * (p.K > 0 ? p.K : 1)
+                            : reinterpret_cast<int32_t *>(lds + 64 * T);        // [K]
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x;
     const int root = blockIdx.x;
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     int cbid = lane == 0 ? 0 : 0x7fffffff;
 
 #ifdef MP_PROFILE
-    long long t_scan = 0, t_exp = 0, t_all0 = clock64();
+    long long t_scan = 0, t_exp = 0, t_all0 = clock64(), t_f[5] = {0, 0, 0, 0, 0};
 #define PROF_T(x) const long long x = clock64()
 #else
 #define PROF_T(x)
@@ -230,6 +232,44 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         root_upper = wave_max(root_upper);
         __syncthreads();
         PROF_T(cf1);
+        if (GLB) {
+            // Lower bounds without the bounds array: the creation-time L of every node sits in its record, and the reverse
+            // sweep only ever READS the |A| children of the step at hand -- a window of ids that slides down by |A| per
+            // step -- so `chunk` steps are served from an LDS window of chunk * |A| values (2.5 KB at |A| = 5), filled by
+            // one coalesced read of the records.  A step is LDS read -> DPP max -> LDS write (when the parent is inside the
+            // window) + one fire-and-forget 8-byte store of the final L into the parent's record; the stores are waited
+            // for once per window, before the next fill (parents below the window are read back then).  Through the L2
+            // every step was two dependent round trips (3 400 cycles at 8 waves per SIMD; 37 % of the kernel).
+            double *win = lds;
+            const int C = p.chunk;
+            PROF_T(cf2);
+            for (int k0 = k_done - 1; k0 >= 0;) {
+                const int kb = k0 & ~(C - 1);
+                const int lo = 1 + kb * A, n_win = (k0 - kb + 1) * A;
+                __syncthreads(); // (one wavefront: s_waitcnt vmcnt(0)) the record stores of the windows above have landed
+                for (int i = lane; i < n_win; i += 64) win[i] = NA[lo + i].L;
+                const int ek = lane <= k0 - kb ? exp_lds[kb + lane] : 0;
+                __syncthreads();
+                for (int k = k0; k >= kb; --k) {
+                    const int g = (k - kb) * A;
+                    const double mine = lane < A ? win[g + lane] : ninf;
+                    const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
+                    const int parent_k = __builtin_amdgcn_readlane(ek, k - kb);
+                    if (lane == 0) {
+                        NA[parent_k].L = m;
+                        if (parent_k >= lo) win[parent_k - lo] = m;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                k0 = kb - 1;
+            }
+            __syncthreads();
+            PROF_T(cf3);
+            PROF_T(cf4);
+#ifdef MP_PROFILE
+            t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
+#endif
+        } else {
         // lower bounds: same pass over the creation-time L values
         for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
         __syncthreads();
@@ -249,7 +289,6 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 parent_k = exp_lds[k];
             }
             if (lane == 0) LU(parent_k) = m;
-            if (GLB) __syncthreads(); // the next step may read this node through memory, from other lanes
         }
         __syncthreads();
         PROF_T(cf3);
@@ -258,6 +297,10 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             NA[n].L = LU(n);
         }
         PROF_T(cf4);
+#ifdef MP_PROFILE
+        t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
+#endif
+        }
         // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
         // (deterministic.py:21-26): random_argmax over the children's lower bounds (in LDS).
         // A node's children are group 1 + k*A where k is its expansion index; a chosen child's own
@@ -268,7 +311,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
-            const double l = lane < A ? LU(fc + lane) : ninf;
+            const double l = lane < A ? (GLB ? NA[fc + lane].L : LU(fc + lane)) : ninf;
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -288,17 +331,14 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             kcur = knext;
         }
 #ifdef MP_PROFILE
-        if (root == 0 && lane == 0)
-            printf("opd prof root0 final: U %lld  Lload %lld  backward %lld  Lstore %lld  descent %lld (len %d)\n",
-                   (long long)(cf1 - cf0), (long long)(cf2 - cf1), (long long)(cf3 - cf2), (long long)(cf4 - cf3),
-                   (long long)(clock64() - cf4), len);
+        t_f[4] = clock64() - t_f[4];
 #endif
         if (lane == 0) {
             gen.store(p.rng + (long)root * 6);
             if (p.plans)
                 for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[root] = len;
-            if (p.root_lower) p.root_lower[root] = LU(0);
+            if (p.root_lower) p.root_lower[root] = GLB ? NA[0].L : LU(0);
             if (p.root_upper) p.root_upper[root] = root_upper;
         }
     } else if (lane == 0) {
@@ -308,8 +348,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     }
 #ifdef MP_PROFILE
     if (root == 0 && lane == 0)
-        printf("opd prof root0: K=%d total=%lld scan=%lld expand=%lld final=%lld (clock64 ticks)\n", p.K,
-               (long long)(clock64() - t_all0), t_scan, t_exp, (long long)(clock64() - cf0));
+        printf("opd prof root0: K=%d total=%lld scan=%lld expand=%lld final=%lld [U %lld  Lload %lld  backward %lld  Lstore %lld  "
+               "descent %lld] (clock64 ticks)\n", p.K, (long long)(clock64() - t_all0), t_scan, t_exp, (long long)(clock64() - cf0),
+               t_f[0], t_f[1], t_f[2], t_f[3], t_f[4]);
 #endif
     int n_real = real_mine;
     for (int off = 32; off > 0; off >>= 1) n_real += __shfl_xor(n_real, off);
@@ -318,7 +359,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         if (p.env_steps) p.env_steps[root] = (int64_t)n_real;
         p.n_nodes_out[root] = n_nodes;
     }
-    if (EXPG) {
+    if (EXPH) {
         for (int k = k_done + lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = -1;
     } else {
         for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
@@ -349,10 +390,11 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     const long cap = 1 + (long)K * A;
     const int T = (int)((cap + 63) / 64) | 1;
     const size_t lds_full = (size_t)64 * T * sizeof(double) + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
-    const size_t lds_map = (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
-    const size_t lds_bounds = (size_t)64 * T * sizeof(double); // bounds only, parent map in HBM (EXPG)
-    if (lds_map > kLdsBytes - 1024)
-        return fail(MP_ERR_ARG, "mp_opd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds_map, kLdsBytes - 1024);
+        const size_t lds_bounds = (size_t)64 * T * sizeof(double); // bounds only, parent map in HBM (EXPG)
+    // high-occupancy variant: LDS only holds the window of the closing lower-bound pass, `chunk` expansions x |A| doubles
+    int chunk = 64;
+    while (chunk > 1 && (size_t)chunk * A * sizeof(double) > 4096) chunk >>= 1;
+    const size_t lds_win = (size_t)chunk * A * sizeof(double);
     // variant: LDS-resident bounds while every root of the batch fits on the chip that way, else high occupancy
     const char *force = getenv("MP_OPD_MODEL"); // "lds" / "global": test hook
     const long cus = ctx->prop.multiProcessorCount;
@@ -364,7 +406,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     // bounds in LDS: keep the parent map there too while that costs no residency
     bool expg = !glb && (lds_full > kLdsBytes - 1024 || n_roots > lds_roots);
     if (force && !glb && force[1] == 'd' && force[2] == 's' && force[3] == 'x') expg = true; // "ldsx": test hook
-    const size_t lds = glb ? lds_map : (expg ? lds_bounds : lds_full);
+    const size_t lds = glb ? lds_win : (expg ? lds_bounds : lds_full);
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
@@ -380,7 +422,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     OpdArgs a;
-    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T;
+    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk;
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec;
     a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;

@@ -111,7 +111,7 @@ def _cmp_opd(ctx, cfg, n_roots, budget, gamma, terminal_reward=0.0, seed=0, done
     model = ctx.load_table(t, r, term, done_rule=done_rule)
     s0 = np.random.Generator(np.random.PCG64(seed)).integers(0, r.shape[0], size=n_roots).astype(np.int32)
     rng = _rng_states(n_roots, base=77)
-    rng_ref = rng.copy()
+    rng_ref, rng0 = rng.copy(), rng.copy()
     mpl = budget // r.shape[1] + 2
     out = ctx.opd_plan(model, s0, budget, gamma, terminal_reward, rng, max_plan_len=mpl)
     ref = oracle.opd_plan_batch(t, r, term, s0, budget, gamma, terminal_reward, rng_ref, done_rule=done_rule,
@@ -122,6 +122,16 @@ def _cmp_opd(ctx, cfg, n_roots, budget, gamma, terminal_reward=0.0, seed=0, done
     assert np.array_equal(out["root_upper"], ref["root_upper"])
     np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
     np.testing.assert_array_equal(rng, ref["rng_after"])
+    # the whole tree of the first and the last root (bounds after the deferred backup, counts, links), node for node
+    cap = 1 + (budget // r.shape[1]) * r.shape[1]
+    for root in sorted({0, n_roots - 1}):
+        if out["status"][root] != 0:
+            continue
+        tree = ctx.opd_tree(root, cap)
+        one = oracle.opd_plan(t, r, term, int(s0[root]), budget, gamma, terminal_reward, rng0[root].copy(),
+                              done_rule=done_rule, max_plan_len=mpl)["tree"]
+        for k in one:
+            np.testing.assert_array_equal(tree[k], one[k], err_msg="tree[{}] of root {}".format(k, root))
     model.close()
     return out
 
@@ -145,7 +155,8 @@ def test_opd_budget_beyond_lds(ctx):
 
 
 @pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
-@pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (64, 640)])
+@pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (13, 1300), (20, 2000),
+                                              (64, 640)])
 def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     from rl_agents_amd.envs import generators
     monkeypatch.setenv("MP_OPD_MODEL", variant)

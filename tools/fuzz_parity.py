@@ -61,7 +61,12 @@ def one_case(ctx, g, case):
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
     kind = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree", "uct_listed", "opd_masked", "ropd"][int(g.integers(0, 9))]
-    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps)
+    # OPD kernels: let the host choose the variant, or force one ("ldsx": parent map in HBM; "global": bounds in HBM)
+    variant = str(g.choice(["", "lds", "ldsx", "global"]))
+    os.environ.pop("MP_OPD_MODEL", None)
+    if variant and kind in ("opd", "opd_masked", "ropd"):
+        os.environ["MP_OPD_MODEL"] = variant
+    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant)
     if kind == "vi":
         model.close()
         iterations = int(g.choice([1, 7, 100, 300]))
@@ -249,6 +254,13 @@ def one_case(ctx, g, case):
         for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
             eq(out[k], ref[k], k, desc)
         eq(rng_dev, ref["rng_after"], "rng", desc)
+        root = int(g.integers(0, n))
+        if out["status"][root] == 0:                                  # one whole tree, node for node
+            tree = ctx.opd_tree(root, 1 + (budget // a) * a)
+            one = oracle.opd_plan(t, r, term, int(s0[root]), budget, gamma, tr, rng[root].copy(), done_rule=done_rule,
+                                  max_plan_len=budget // a + 1)["tree"]
+            for k in one:
+                eq(tree[k], one[k], "tree " + k, desc)
     else:
         budget = int(g.choice([0, a, 5 * a, 120, 300] + ([1000] if HEAVY else [])))
         tr = float(g.choice([0.0, 0.5]))
