@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
         // ---- deterministic.py:110: first maximal upper bound among the leaves
         double bu = cbu;
         int leaf = cbid;
-        wave_argmax(bu, leaf);
+        if (GLB) wave_argmax_keys(bu, leaf); else wave_argmax(bu, leaf);
         const int cls = leaf & 63;
         // the leaf's record is needed by the expansion only: fetch it now, under the class re-scan
         const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
@@ -148,11 +148,13 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
             const int cnt = (n_nodes - cls + 63) >> 6; // ids cls, cls + 64, ... < n_nodes
             double ru = ninf;
             int rid = 0x7fffffff;
-            for (int t = lane; t < cnt; t += 64) {
-                const double u = row[t];
-                if (u > ru) { ru = u; rid = cls + (t << 6); }
+            for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip (budget 5000: 79 entries per class)
+                const double u0 = row[t];
+                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
-            wave_argmax(ru, rid);
+            if (GLB) wave_argmax_keys(ru, rid); else wave_argmax(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         PROF_T(c1);

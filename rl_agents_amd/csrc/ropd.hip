@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
         // ---- robust.py:37: first maximal min_m U among the leaves
         double bu = cbu;
         int leaf = cbid;
-        wave_argmax(bu, leaf);
+        if (GLB) wave_argmax_keys(bu, leaf); else wave_argmax(bu, leaf);
         const int cls = leaf & 63;
         const int dleaf = meta[2 * leaf]; // (uniform address: one broadcast load, in flight under the class re-scan)
         if (lane == 0) LU(leaf) = ninf;
@@ -92,11 +92,13 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
             const int cnt = (n_nodes - cls + 63) >> 6;
             double ru = ninf;
             int rid = 0x7fffffff;
-            for (int t = lane; t < cnt; t += 64) {
-                const double u = row[t];
-                if (u > ru) { ru = u; rid = cls + (t << 6); }
+            for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip (budget 5000: 79 entries per class)
+                const double u0 = row[t];
+                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
-            wave_argmax(ru, rid);
+            if (GLB) wave_argmax_keys(ru, rid); else wave_argmax(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         // ---- DeterministicNode.expand (deterministic.py:28-43), update() with ndarray reward / done (:45-65)

@@ -4,6 +4,23 @@
 
 namespace mp {
 
+// ---- 32-bit DPP reductions written as ONE instruction per step: `v_op_dpp v, v, v` computes op(dpp(v), v) in place and
+// lanes without a valid DPP source keep their value (bound_ctrl off = the lane is disabled for the instruction).  The
+// builtin route (update_dpp, then the operation) costs a register copy, the DPP move and the operation per step -- three
+// issue slots where the hardware needs one; a planner wave at 8 waves per SIMD is bound by VALU issue.  `s_nop 1`: a DPP
+// read of a VGPR written by the previous VALU instruction needs two wait states, and the hazard recogniser does not
+// look inside inline assembly.  Call with all 64 lanes active.
+#define MP_DPP_STEP(op, v, ctrl) asm("s_nop 1\n\t" op " %0, %0, %0 " ctrl : "+v"(v))
+#define MP_DPP_REDUCE_ROW(op, v)                                  \
+    MP_DPP_STEP(op, v, "row_shr:1 row_mask:0xf bank_mask:0xf");   \
+    MP_DPP_STEP(op, v, "row_shr:2 row_mask:0xf bank_mask:0xf");   \
+    MP_DPP_STEP(op, v, "row_shr:4 row_mask:0xf bank_mask:0xf");   \
+    MP_DPP_STEP(op, v, "row_shr:8 row_mask:0xf bank_mask:0xf")
+#define MP_DPP_REDUCE_WAVE(op, v)                                 \
+    MP_DPP_REDUCE_ROW(op, v);                                     \
+    MP_DPP_STEP(op, v, "row_bcast:15 row_mask:0xa bank_mask:0xf"); \
+    MP_DPP_STEP(op, v, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+
 // One DPP reduction step on a double: lanes without a valid DPP source read their own value (old = own), so the
 // step leaves them unchanged.  v_max_f64 is written out because the planners' bounds are never NaN (rewards are
 // range-checked, the only special value is -inf) and `fmax` would add a canonicalisation of both inputs per step.
@@ -17,13 +34,6 @@ __device__ __forceinline__ double max_step(double u)
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(ou));
     return r;
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int min_step(int v)
-{
-    const int o = __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false);
-    return o < v ? o : v;
 }
 
 __device__ __forceinline__ double bcast_lane(double u, int lane)
@@ -57,29 +67,50 @@ __device__ __forceinline__ double row0_max(double u)
 
 __device__ __forceinline__ int wave_min(int v)
 {
-    v = min_step<0x111, 0xf>(v);
-    v = min_step<0x112, 0xf>(v);
-    v = min_step<0x114, 0xf>(v);
-    v = min_step<0x118, 0xf>(v);
-    v = min_step<0x142, 0xa>(v);
-    v = min_step<0x143, 0xc>(v);
+    MP_DPP_REDUCE_WAVE("v_min_i32_dpp", v);
     return __builtin_amdgcn_readlane(v, 63);
 }
 
 __device__ __forceinline__ int row0_min(int v)
 {
-    v = min_step<0x111, 0xf>(v);
-    v = min_step<0x112, 0xf>(v);
-    v = min_step<0x114, 0xf>(v);
-    v = min_step<0x118, 0xf>(v);
+    MP_DPP_REDUCE_ROW("v_min_i32_dpp", v);
     return __builtin_amdgcn_readlane(v, 15);
 }
 
 // ---- cross-lane argmax on (U, id): maximal U first, lowest id among equal U; every lane returns the pair.
-// Two separable reductions -- the maximum of U (3 instructions per step), then the minimum id among the lanes that hold
-// it (2 per step) -- instead of one lexicographic reduction whose compare-and-select on a 96-bit pair costs ~28
-// instructions per step: a planner wave is ONE instruction stream, and the two argmaxes of an OPD expansion were
-// two thirds of the instructions it issued.
+// U is mapped to an order-preserving (signed high word, unsigned low word) key -- flip the magnitude bits of negative
+// values -- and the argmax is three separable 32-bit reductions: the maximal high word, the maximal low word among the
+// lanes that hold it, the minimal id among the lanes that hold both.  18 single-instruction DPP steps where the
+// lexicographic (U, id) reduction took ~170 instructions and the (v_max_f64, v_min_i32) pair on builtins ~60.
+// U is never NaN here (rewards are range-checked; the only special value is -inf); `+ 0.0` folds a -0.0 into +0.0 so
+// that equal values have equal keys.
+template <bool ROW0>
+__device__ __forceinline__ void argmax_keys(double &u, int &id)
+{
+    const double uc = u + 0.0;
+    const int hi = __double2hiint(uc), sg = hi >> 31;
+    int kh = hi ^ (sg & 0x7fffffff);
+    const unsigned kl = (unsigned)(__double2loint(uc) ^ sg);
+    const int kh_own = kh;
+    if (ROW0) { MP_DPP_REDUCE_ROW("v_max_i32_dpp", kh); } else { MP_DPP_REDUCE_WAVE("v_max_i32_dpp", kh); }
+    const int mh = __builtin_amdgcn_readlane(kh, ROW0 ? 15 : 63);
+    const bool c1 = kh_own == mh;
+    unsigned l1 = c1 ? kl : 0u;
+    if (ROW0) { MP_DPP_REDUCE_ROW("v_max_u32_dpp", l1); } else { MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1); }
+    const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, ROW0 ? 15 : 63);
+    int i2 = (c1 && kl == ml) ? id : 0x7fffffff;
+    if (ROW0) { MP_DPP_REDUCE_ROW("v_min_i32_dpp", i2); } else { MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2); }
+    id = __builtin_amdgcn_readlane(i2, ROW0 ? 15 : 63);
+    const int ms = mh >> 31;
+    u = __hiloint2double(mh ^ (ms & 0x7fffffff), (int)(ml ^ (unsigned)ms));
+}
+
+// Three dependent reductions (18 steps) but the fewest instructions: the choice of the kernels that run 8 waves per SIMD
+// and are bound by VALU issue (OPD high-occupancy variant: 8192 roots 3.83 -> 3.60 ms).
+__device__ __forceinline__ void wave_argmax_keys(double &u, int &id) { argmax_keys<false>(u, id); }
+
+// Two dependent reductions (12 steps; v_max_f64 has no DPP form, so a step of the maximum is two DPP moves and the
+// operation): the choice of the latency-bound kernels (one wave per SIMD: OPD with the bounds in LDS 1.15 vs 1.20 ms).
 __device__ __forceinline__ void wave_argmax(double &u, int &id)
 {
     const double m = wave_max(u);

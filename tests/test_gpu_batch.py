@@ -278,9 +278,6 @@ def test_limits_and_error_codes(ctx):
     with pytest.raises(native.NativeError) as e:                      # horizon too deep for the LDS path stack
         ctx.uct_plan(model, [0, 1], 4, 5000, 0.9, 1.0, p, p, rng, max_plan_len=4)
     assert e.value.code == native.ERR_ARG
-    with pytest.raises(native.NativeError) as e:                      # OPD budget whose parent map exceeds LDS
-        ctx.opd_plan(model, [0, 1], 200000, 0.9, 0.0, rng)
-    assert e.value.code == native.ERR_ARG
     with pytest.raises(native.NativeError) as e:                      # gamma = 1: the reference divides by 1 - gamma
         ctx.opd_plan(model, [0, 1], 30, 1.0, 0.0, rng)
     assert e.value.code == native.ERR_ARG
