@@ -42,8 +42,8 @@ namespace mp {
 
 struct OpdArgs {
     int n_roots, S, A, K, cap, done_on_next, max_plan_len;
-    int T; // LDS row length of a residue class: odd, >= ceil(cap / 64)
-    int chunk; // GLB: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
+    int T; // row length of a residue class: odd, >= ceil(cap / 64)
+    int chunk; // opd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
     const Rec *rec;
     const int32_t *root_state;
     const double *g1;   // g1[d]   = gamma ** (d - 1), d >= 1
@@ -73,24 +73,23 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 // registers.  An expansion then costs: one 64-lane argmax over the cached class maxima, one
 // cooperative re-scan of the winner's class only (cap/64 entries, contiguous, conflict-free), and
 // one compare per lane for the new children -- instead of a scan of all cap entries.
-// GLB = false: the upper-bound array lives in LDS (44 KB per root at budget 5000 -> 3 roots per CU: lowest latency
-//               per root, the choice while all roots of the batch are resident anyway).
-// GLB = true : it lives in HBM/L2 (class-contiguous, so a class re-scan is one coalesced read) and LDS only holds
-//              the 4-byte-per-expansion parent map: 8 waves per SIMD instead of 3 per CU.  A wave of this kernel
-//              is a chain of dependent round trips (argmax -> leaf record -> model record), i.e. latency bound:
-//              ten times more resident roots hide that latency and multiply the batch throughput.
-// EXPG (with GLB = false): the parent map goes to HBM as well (it is written once per expansion, off the chain, and
-//              read back in coalesced chunks by the closing passes), leaving 64*T*8 B of LDS per root: at budget 5000
-//              that is 40 448 B, FOUR roots per CU instead of three -- the 1024-root shard of BASELINE C4 stays on the
-//              low-latency variant (2.0 ms instead of 2.7 ms).
-template <bool GLB, bool EXPG = false>
-__global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
+// opd_kernel<EXPG = false>: the upper-bound array AND the parent map live in LDS (44 KB per root at budget 5000 -> 3 roots
+//              per CU: lowest latency per root, the choice while all roots of the batch are resident anyway).
+// opd_kernel<EXPG = true>: the parent map goes to HBM (it is written once per expansion, off the chain, and read back in
+//              coalesced chunks by the closing passes), leaving 64*T*8 B of LDS per root: at budget 5000 that is
+//              40 448 B, FOUR roots per CU instead of three -- the 1024-root shard of BASELINE C4 stays on the
+//              low-latency variant.
+// opd_wide_kernel (below): the bounds array lives in HBM/L2 (class-contiguous, so a class re-scan is one coalesced read)
+//              and LDS only holds the window of the closing pass: 8 waves per SIMD instead of 3-4 per CU.  A wave of this
+//              planner is a chain of dependent round trips (argmax -> leaf record -> model record): ten times more
+//              resident roots hide that latency and multiply the batch throughput.
+template <bool EXPG>
+__global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = p.T;                                                // odd, >= ceil(cap / 64)
-    constexpr bool EXPH = GLB || EXPG;                                          // parent map in HBM
-    double *leafU = GLB ? p.leaf_global + (long)blockIdx.x * 64 * T : lds;      // [64 * T]
-    int32_t *exp_lds = EXPH ? p.expanded + (long)blockIdx.x * (p.K > 0 ? p.K : 1)
+    double *leafU = lds;                                                        // [64 * T]
+    int32_t *exp_lds = EXPG ? p.expanded + (long)blockIdx.x * (p.K > 0 ? p.K : 1) // parent map in HBM
                             : reinterpret_cast<int32_t *>(lds + 64 * T);        // [K]
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x;
@@ -113,8 +112,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
     }
     __syncthreads();
     int n_nodes = 1;
-    // children of available actions = planner.step calls (deterministic.py:41), counted per lane: the GLB variant sits at
-    // 80 SGPRs = the last count that still admits 8 waves per SIMD, a wave-uniform counter would cost the occupancy
+    // children of available actions = planner.step calls (deterministic.py:41), counted per lane
     int real_mine = 0;
     int status = MP_OK;
     int k_done = 0;
@@ -133,16 +131,16 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
         // ---- deterministic.py:110: first maximal upper bound among the leaves
         double bu = cbu;
         int leaf = cbid;
-        if (GLB) wave_argmax_keys(bu, leaf); else wave_argmax(bu, leaf);
+        wave_argmax(bu, leaf);
         const int cls = leaf & 63;
         // the leaf's record is needed by the expansion only: fetch it now, under the class re-scan
         const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
         // the selected leaf stops being one; re-derive the best leaf of its class from LDS
         if (lane == 0) LU(leaf) = ninf;
-        // A workgroup is ONE wavefront: its LDS (and vector-memory) operations execute in program order, so lane 0's
-        // store is seen by the other lanes' later reads without a barrier.  The LDS variants only order the compiler
-        // here -- a full __syncthreads() would also wait for the record fetch above.
-        if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        // A workgroup is ONE wavefront: its LDS operations execute in program order, so lane 0's store is seen by the
+        // other lanes' later reads without a barrier.  Only the compiler is ordered here -- a full __syncthreads() would
+        // also wait for the record fetch above.
+        __builtin_amdgcn_wave_barrier();
         {
             const double *row = leafU + cls * T;
             const int cnt = (n_nodes - cls + 63) >> 6; // ids cls, cls + 64, ... < n_nodes
@@ -154,7 +152,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
                 if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
                 if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
-            if (GLB) wave_argmax_keys(ru, rid); else wave_argmax(ru, rid);
+            wave_argmax(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         PROF_T(c1);
@@ -202,7 +200,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
         real_mine += avail ? 1 : 0;
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();
         // the (at most one, |A| <= 64) new child that falls in this lane's class may beat its cached
         // best; on equality the older (lower id) leaf stays, as in the reference's list order
         {
@@ -234,44 +232,6 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
         root_upper = wave_max(root_upper);
         __syncthreads();
         PROF_T(cf1);
-        if (GLB) {
-            // Lower bounds without the bounds array: the creation-time L of every node sits in its record, and the reverse
-            // sweep only ever READS the |A| children of the step at hand -- a window of ids that slides down by |A| per
-            // step -- so `chunk` steps are served from an LDS window of chunk * |A| values (2.5 KB at |A| = 5), filled by
-            // one coalesced read of the records.  A step is LDS read -> DPP max -> LDS write (when the parent is inside the
-            // window) + one fire-and-forget 8-byte store of the final L into the parent's record; the stores are waited
-            // for once per window, before the next fill (parents below the window are read back then).  Through the L2
-            // every step was two dependent round trips (3 400 cycles at 8 waves per SIMD; 37 % of the kernel).
-            double *win = lds;
-            const int C = p.chunk;
-            PROF_T(cf2);
-            for (int k0 = k_done - 1; k0 >= 0;) {
-                const int kb = k0 & ~(C - 1);
-                const int lo = 1 + kb * A, n_win = (k0 - kb + 1) * A;
-                __syncthreads(); // (one wavefront: s_waitcnt vmcnt(0)) the record stores of the windows above have landed
-                for (int i = lane; i < n_win; i += 64) win[i] = NA[lo + i].L;
-                const int ek = lane <= k0 - kb ? exp_lds[kb + lane] : 0;
-                __syncthreads();
-                for (int k = k0; k >= kb; --k) {
-                    const int g = (k - kb) * A;
-                    const double mine = lane < A ? win[g + lane] : ninf;
-                    const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
-                    const int parent_k = __builtin_amdgcn_readlane(ek, k - kb);
-                    if (lane == 0) {
-                        NA[parent_k].L = m;
-                        if (parent_k >= lo) win[parent_k - lo] = m;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-                k0 = kb - 1;
-            }
-            __syncthreads();
-            PROF_T(cf3);
-            PROF_T(cf4);
-#ifdef MP_PROFILE
-            t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
-#endif
-        } else {
         // lower bounds: same pass over the creation-time L values
         for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
         __syncthreads();
@@ -302,7 +262,6 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
 #ifdef MP_PROFILE
         t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
 #endif
-        }
         // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
         // (deterministic.py:21-26): random_argmax over the children's lower bounds (in LDS).
         // A node's children are group 1 + k*A where k is its expansion index; a chosen child's own
@@ -313,7 +272,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
         int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
-            const double l = lane < A ? (GLB ? NA[fc + lane].L : LU(fc + lane)) : ninf;
+            const double l = lane < A ? LU(fc + lane) : ninf;
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -340,7 +299,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
             if (p.plans)
                 for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[root] = len;
-            if (p.root_lower) p.root_lower[root] = GLB ? NA[0].L : LU(0);
+            if (p.root_lower) p.root_lower[root] = LU(0);
             if (p.root_upper) p.root_upper[root] = root_upper;
         }
     } else if (lane == 0) {
@@ -361,11 +320,226 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void opd_kernel(OpdArgs p)
         if (p.env_steps) p.env_steps[root] = (int64_t)n_real;
         p.n_nodes_out[root] = n_nodes;
     }
-    if (EXPH) {
+    if (EXPG) {
         for (int k = k_done + lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = -1;
     } else {
         for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
     }
+#undef LU
+}
+
+
+// ---- the high-occupancy variant as its own kernel (8 waves per SIMD; 8192 roots of BASELINE C4 and beyond).
+// At that occupancy the chip is busy, not waiting: VALU issue 68-72 % of all SIMD cycles (profiles/r02_opd_units.md), so
+// what counts is the number of instructions an expansion issues:
+//   * the argmaxes use the key form (wave.hpp: 18 single-instruction DPP steps);
+//   * the selected leaf's slot of the bounds array gets a negative quiet NaN whose payload is the expansion index k
+//     instead of -inf: a NaN never compares greater, so it is as dead to every selection as -inf, and it makes the bounds
+//     array the node -> k map.  The parent map (k -> node) is then not stored per expansion at all -- the closing pass
+//     over the bounds array, which exists anyway, scatters it -- and the plan descent reads a child's k from its slot
+//     (one round trip per level) instead of searching the map.
+// Tried and dropped here: one 8-byte store instruction for everything 8 bytes wide (children's bounds, the leaf's slot,
+// the children's rewards from lanes |A|+1..2|A| that gather the same records) plus a pair-wise dwordx4 class re-scan that
+// skips the leaf in registers -- five vector-memory instructions per expansion instead of nine, but ten more VALU
+// instructions for the lane roles: 3.66 ms against 3.49 at 8192 roots.  TA_BUSY did not move (74 %): it counts a unit
+// with requests in flight, not a unit out of issue slots.
+__global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int T = p.T;
+    double *leafU = p.leaf_global + (long)blockIdx.x * 64 * T;
+#define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
+    const int lane = threadIdx.x, root = blockIdx.x, A = p.A;
+    const long base = (long)root * p.cap;
+    OpdNode *NA = reinterpret_cast<OpdNode *>(p.L) + base;
+    double *RW = p.reward + base;
+    constexpr int32_t DONE_FLAG = 1 << 30;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+
+    if (lane == 0) {
+        OpdNode n0;
+        n0.L = 0.0; n0.state = p.root_state[root]; n0.depth = 0;
+        NA[0] = n0;
+        RW[0] = 0.0;
+        LU(0) = 0.0;
+    }
+    __syncthreads();
+    int n_nodes = 1, real_mine = 0, status = MP_OK, k_done = 0;
+    double cbu = lane == 0 ? 0.0 : ninf;
+    int cbid = lane == 0 ? 0 : 0x7fffffff;
+
+    for (int k = 0; k < p.K; ++k) {
+        // ---- deterministic.py:110: first maximal upper bound among the leaves
+        double bu = cbu;
+        int leaf = cbid;
+        wave_argmax_keys(bu, leaf);
+        const int cls = leaf & 63;
+        const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
+        // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry
+        if (lane == 0) LU(leaf) = __hiloint2double((int)0xFFF80000, k);
+        __syncthreads(); // the re-scan reads that slot through memory, from another lane
+        {
+            const double *row = leafU + cls * T;
+            const int cnt = (n_nodes - cls + 63) >> 6;
+            double ru = ninf;
+            int rid = 0x7fffffff;
+            for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip (budget 5000: 79 entries per class)
+                const double u0 = row[t];
+                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+            }
+            wave_argmax_keys(ru, rid);
+            if (lane == cls) { cbu = ru; cbid = rid; }
+        }
+        // ---- DeterministicNode.expand, deterministic.py:28-43
+        OpdNode pn;
+        pn.L = __hiloint2double((int)leaf_raw.y, (int)leaf_raw.x); pn.state = (int32_t)leaf_raw.z; pn.depth = (int32_t)leaf_raw.w;
+        const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
+        typedef const double __attribute__((address_space(4))) *scalar_f64;
+        const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
+                     tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
+        const int g = n_nodes;
+        bool bad = false, avail = false;
+        double Uc_mine = 0.0;
+        if (lane < A) {
+            const Rec rc = p.rec[(long)pn.state * A + lane];
+            const double r = rc.reward;
+            avail = (rc.flags & 4u) != 0;                 // deterministic.py:32-35 (phantom slots: see opd_kernel)
+            bad = avail && (!(0.0 <= r) || !(r <= 1.0));  // deterministic.py:46-47
+            const bool dn = (rc.flags & done_bit) != 0;
+            double Lc = pn.L + g1d * r;                   // deterministic.py:45-65 update()
+            double Uc = Lc + gdivd;
+            if (dn) {
+                const double nv = Lc + tdivd;
+                Lc = nv; Uc = nv;
+            }
+            if (!avail) { Lc = ninf; Uc = ninf; }
+            const int c = g + lane;
+            OpdNode cn;
+            cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
+            NA[c] = cn;
+            RW[c] = r;
+            LU(c) = Uc;
+            Uc_mine = Uc;
+        }
+        n_nodes += A;
+        real_mine += avail ? 1 : 0;
+        k_done = k + 1;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads(); // the next re-scan may read these children through memory, from other lanes
+        {
+            const int j = (lane - g) & 63;
+            const double u = __shfl(Uc_mine, j & 63);
+            if (j < A) {
+                const int id = g + j;
+                if (u > cbu) { cbu = u; cbid = id; }
+            }
+        }
+    }
+    __syncthreads();
+
+    // Everything only the closing passes need is read from the kernel-argument segment HERE: loaded at entry (as the
+    // compiler does with by-value arguments) those twelve pointers sit in SGPRs through the main loop, which at the 80
+    // SGPRs of 8 waves per SIMD meant 17 spill reloads per expansion (a tenth of its VALU instructions).
+    const OpdArgs __attribute__((address_space(4))) *q;
+    {
+        unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka)); // the loads below cannot move above this point
+        q = (const OpdArgs __attribute__((address_space(4))) *)ka;
+    }
+    double *U = q->U + base;
+    int32_t *exp_map = q->expanded + (long)root * (q->K > 0 ? q->K : 1);
+    int32_t *const plans = q->plans, *const plan_len = q->plan_len;
+    const int max_plan_len = q->max_plan_len;
+
+    // closing pass over the bounds array: leaf upper bounds out, the root's upper bound, and the parent map scattered from
+    // the NaN payloads (every expanded node carries its k)
+    double root_upper = ninf;
+    for (int i = lane; i < n_nodes; i += 64) {
+        const double u = LU(i);
+        U[i] = u != u ? ninf : u; // (-inf marks an expanded node for the export, as in the other variants)
+        if (u > root_upper) root_upper = u;
+        if (u != u) exp_map[__double2loint(u)] = i;
+    }
+    root_upper = wave_max(root_upper);
+    __syncthreads();
+
+    if (status == MP_OK) {
+        // Lower bounds without the bounds array: the creation-time L of every node sits in its record, and the reverse
+        // sweep only ever READS the |A| children of the step at hand -- a window of ids that slides down by |A| per
+        // step -- so `chunk` steps are served from an LDS window of chunk * |A| values (2.5 KB at |A| = 5), filled by
+        // one coalesced read of the records.  A step is LDS read -> DPP max -> LDS write (when the parent is inside the
+        // window) + one fire-and-forget 8-byte store of the final L into the parent's record; the stores are waited
+        // for once per window, before the next fill (parents below the window are read back then).  Through the L2
+        // every step was two dependent round trips (3 400 cycles at 8 waves per SIMD; 37 % of the kernel).
+        double *win = lds;
+        const int C = q->chunk;
+        for (int k0 = k_done - 1; k0 >= 0;) {
+            const int kb = k0 & ~(C - 1);
+            const int lo = 1 + kb * A, n_win = (k0 - kb + 1) * A;
+            __syncthreads();
+            for (int i = lane; i < n_win; i += 64) win[i] = NA[lo + i].L;
+            const int ek = lane <= k0 - kb ? exp_map[kb + lane] : 0;
+            __syncthreads();
+            for (int k = k0; k >= kb; --k) {
+                const int g = (k - kb) * A;
+                const double mine = lane < A ? win[g + lane] : ninf;
+                const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
+                const int parent_k = __builtin_amdgcn_readlane(ek, k - kb);
+                if (lane == 0) {
+                    NA[parent_k].L = m;
+                    if (parent_k >= lo) win[parent_k - lo] = m;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            k0 = kb - 1;
+        }
+        __syncthreads();
+        // ---- get_plan with DeterministicNode.selection_rule: a level is ONE round trip (the children's lower bounds and
+        // their slots of the bounds array together); the chosen child's slot says which expansion made its children
+        Pcg64 gen;
+        gen.load(q->rng + (long)root * 6);
+        int len = 0;
+        int kcur = k_done > 0 ? 0 : -1;
+        while (kcur >= 0) {
+            const int fc = 1 + kcur * A;
+            const double l = lane < A ? NA[fc + lane].L : ninf;
+            const double slot = lane < A ? LU(fc + lane) : 0.0;
+            const double m = A <= 16 ? row0_max(l) : wave_max(l);
+            const unsigned long long ties = __ballot(lane < A && l == m);
+            const int nt = __popcll(ties);
+            int pick = (int)gen.below((uint32_t)nt);
+            unsigned long long t = ties;
+            while (pick-- > 0) t &= t - 1;
+            const int a = __ffsll((long long)t) - 1;
+            if (lane == 0 && plans && len < max_plan_len) plans[(long)root * max_plan_len + len] = a;
+            ++len;
+            const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
+            kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
+        }
+        if (lane == 0) {
+            gen.store(q->rng + (long)root * 6);
+            if (plans)
+                for (int i = len; i < max_plan_len; ++i) plans[(long)root * max_plan_len + i] = -1;
+            if (plan_len) plan_len[root] = len;
+            if (q->root_lower) q->root_lower[root] = NA[0].L;
+            if (q->root_upper) q->root_upper[root] = root_upper;
+        }
+    } else if (lane == 0) {
+        if (plans)
+            for (int i = 0; i < max_plan_len; ++i) plans[(long)root * max_plan_len + i] = -1;
+        if (plan_len) plan_len[root] = 0;
+    }
+    int n_real = real_mine;
+    for (int off = 32; off > 0; off >>= 1) n_real += __shfl_xor(n_real, off);
+    if (lane == 0) {
+        if (q->status) q->status[root] = status;
+        if (q->env_steps) q->env_steps[root] = (int64_t)n_real;
+        q->n_nodes_out[root] = n_nodes;
+    }
+    for (int k = k_done + lane; k < q->K; k += 64) exp_map[k] = -1;
 #undef LU
 }
 
@@ -450,13 +624,12 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
     if (lds > 64 * 1024)
-        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(glb ? opd_kernel<true, false>
-                                                                      : (expg ? opd_kernel<false, true> : opd_kernel<false, false>)),
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(expg ? opd_kernel<true> : opd_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    if (glb) hipLaunchKernelGGL((opd_kernel<true, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else if (expg) hipLaunchKernelGGL((opd_kernel<false, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((opd_kernel<false, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (glb) hipLaunchKernelGGL(opd_wide_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (expg) hipLaunchKernelGGL((opd_kernel<true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((opd_kernel<false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 
