@@ -34,6 +34,7 @@ constexpr int kMaxModels = 16;
 struct ROpdArgs {
     int n_roots, M, S, A, K, cap, done_on_next, max_plan_len;
     int T; // row length of a residue class in the upper-bound array: odd, >= ceil(cap / 64)
+    int chunk; // ropd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
     const Rec *rec;            // [M][S*A] packed records of every model
     const int32_t *root_state; // [n_roots][M]
     const double *g1, *gdiv, *tdiv;
@@ -52,13 +53,16 @@ struct ROpdArgs {
     int64_t *env_steps;
 };
 
-template <bool GLB>
-__global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GLB: the register allocation must admit 8 waves per SIMD
+// ropd_kernel<EXPG = false>: upper-bound array and parent map in LDS (44 KB per root at budget 5000: 3 roots per CU);
+// ropd_kernel<EXPG = true>: the parent map in HBM (40 448 B: 4 roots per CU, so a 1024-root batch stays on this
+// low-latency form); ropd_wide_kernel below: the bounds array in HBM/L2, 8 waves per SIMD (see opd.hip for all three).
+template <bool EXPG>
+__global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = p.T;
-    double *leafU = GLB ? p.leaf_global + (long)blockIdx.x * 64 * T : lds;
-    int32_t *exp_lds = reinterpret_cast<int32_t *>(GLB ? lds : lds + 64 * T);
+    double *leafU = lds;
+    int32_t *exp_lds = EXPG ? p.expanded + (long)blockIdx.x * (p.K > 0 ? p.K : 1) : reinterpret_cast<int32_t *>(lds + 64 * T);
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x, root = blockIdx.x, A = p.A, M = p.M;
     const long base = (long)root * p.cap, SA = (long)p.S * A;
@@ -82,11 +86,11 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
         // ---- robust.py:37: first maximal min_m U among the leaves
         double bu = cbu;
         int leaf = cbid;
-        if (GLB) wave_argmax_keys(bu, leaf); else wave_argmax(bu, leaf);
+        wave_argmax(bu, leaf);
         const int cls = leaf & 63;
         const int dleaf = meta[2 * leaf]; // (uniform address: one broadcast load, in flight under the class re-scan)
         if (lane == 0) LU(leaf) = ninf;
-        if (GLB) __syncthreads(); else __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_wave_barrier();
         {
             const double *row = leafU + cls * T;
             const int cnt = (n_nodes - cls + 63) >> 6;
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
                 if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
                 if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
-            if (GLB) wave_argmax_keys(ru, rid); else wave_argmax(ru, rid);
+            wave_argmax(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         // ---- DeterministicNode.expand (deterministic.py:28-43), update() with ndarray reward / done (:45-65)
@@ -168,12 +172,19 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
         __syncthreads();
         for (int i = lane; i < n_nodes; i += 64) LU(i) = Lmin[i];
         __syncthreads();
+        int ek = 0; // EXPG: 64 entries of the parent map per coalesced read
         for (int k = k_done - 1; k >= 0; --k) {
             const int g = 1 + k * A;
             const double mine = lane < A ? LU(g + lane) : ninf; // the |A| children in one read, maximum on DPP (opd.hip)
             const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
-            if (lane == 0) LU(exp_lds[k]) = m;
-            if (GLB) __syncthreads();
+            int parent_k;
+            if (EXPG) {
+                if (k == k_done - 1 || (k & 63) == 63) ek = (k & ~63) + lane < k_done ? exp_lds[(k & ~63) + lane] : 0;
+                parent_k = __builtin_amdgcn_readlane(ek, k & 63);
+            } else {
+                parent_k = exp_lds[k];
+            }
+            if (lane == 0) LU(parent_k) = m;
         }
         __syncthreads();
         for (int k = lane; k < k_done; k += 64) {
@@ -224,7 +235,200 @@ __global__ __launch_bounds__(64, GLB ? 8 : 1) void ropd_kernel(ROpdArgs p) // GL
         if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1); // one joint step per child (deterministic.py:41)
         p.n_nodes_out[root] = n_nodes;
     }
-    for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
+    if (EXPG) {
+        for (int k = k_done + lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = -1;
+    } else {
+        for (int k = lane; k < p.K; k += 64) p.expanded[(long)root * p.K + k] = k < k_done ? exp_lds[k] : -1;
+    }
+#undef LU
+}
+
+// The high-occupancy form (opd.hip's opd_wide_kernel on the minima): bounds array in HBM/L2 with the key argmax, the
+// selected leaf's slot NaN-boxed with its expansion index (node -> k map; the k -> node map is scattered by the closing
+// pass; the plan descent needs no search), the closing lower-bound sweep through a sliding LDS window over Lmin[], and
+// the arguments only the closing passes need loaded after the main loop (SGPR budget of 8 waves per SIMD).
+__global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int T = p.T;
+    double *leafU = p.leaf_global + (long)blockIdx.x * 64 * T;
+#define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
+    const int lane = threadIdx.x, root = blockIdx.x, A = p.A, M = p.M;
+    const long base = (long)root * p.cap, SA = (long)p.S * A;
+    double *Lv = p.Lv + base * M, *Rv = p.Rv + base * M, *Lmin = p.Lmin + base;
+    int32_t *Sv = p.Sv + base * M, *meta = p.meta + base * 2;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+
+    if (lane == 0) {
+        for (int m = 0; m < M; ++m) { Lv[m] = 0.0; Sv[m] = p.root_state[(long)root * M + m]; Rv[m] = 0.0; }
+        Lmin[0] = 0.0; meta[0] = 0; meta[1] = 0;
+        LU(0) = 0.0;
+    }
+    __syncthreads();
+    int n_nodes = 1, status = MP_OK, k_done = 0;
+    double cbu = lane == 0 ? 0.0 : ninf;
+    int cbid = lane == 0 ? 0 : 0x7fffffff;
+
+    for (int k = 0; k < p.K; ++k) {
+        // ---- robust.py:37: first maximal min_m U among the leaves
+        double bu = cbu;
+        int leaf = cbid;
+        wave_argmax_keys(bu, leaf);
+        const int cls = leaf & 63;
+        const int dleaf = meta[2 * leaf];
+        if (lane == 0) LU(leaf) = __hiloint2double((int)0xFFF80000, k); // dead to every selection; carries k
+        __syncthreads();
+        {
+            const double *row = leafU + cls * T;
+            const int cnt = (n_nodes - cls + 63) >> 6;
+            double ru = ninf;
+            int rid = 0x7fffffff;
+            for (int t = lane; t < cnt; t += 128) {
+                const double u0 = row[t];
+                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+            }
+            wave_argmax_keys(ru, rid);
+            if (lane == cls) { cbu = ru; cbid = rid; }
+        }
+        // ---- DeterministicNode.expand (deterministic.py:28-43), update() with ndarray reward / done (:45-65)
+        const int d = __builtin_amdgcn_readfirstlane(dleaf) + 1;
+        typedef const double __attribute__((address_space(4))) *scalar_f64;
+        const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
+                     tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
+        const int g = n_nodes;
+        bool bad = false;
+        double Uc_mine = 0.0;
+        if (lane < A) {
+            const int c = g + lane;
+            double lmin = 0.0, umin = 0.0;
+            uint32_t dbits = 0;
+            const double *Lp = Lv + (long)leaf * M;
+            const int32_t *Sp = Sv + (long)leaf * M;
+            for (int m = 0; m < M; ++m) { // JointEnv.step: every model steps its own state (robust.py:13-16)
+                const Rec rc = p.rec[(long)m * SA + (long)Sp[m] * A + lane];
+                const double r = rc.reward;
+                bad |= !(0.0 <= r) || !(r <= 1.0); // np.all(0 <= reward), np.all(reward <= 1)
+                const bool dn = (rc.flags & done_bit) != 0;
+                double Lc = Lp[m] + g1d * r;
+                double Uc = Lc + gdivd;
+                if (dn) {
+                    const double nv = Lc + tdivd;
+                    Lc = nv; Uc = nv;
+                }
+                Lv[(long)c * M + m] = Lc;
+                Sv[(long)c * M + m] = rc.next;
+                Rv[(long)c * M + m] = r;
+                dbits |= (dn ? 1u : 0u) << m;
+                if (m == 0 || Lc < lmin) lmin = Lc; // np.min
+                if (m == 0 || Uc < umin) umin = Uc;
+            }
+            Lmin[c] = lmin;
+            meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
+            LU(c) = umin;
+            Uc_mine = umin;
+        }
+        n_nodes += A;
+        k_done = k + 1;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads();
+        {
+            const int j = (lane - g) & 63;
+            const double u = __shfl(Uc_mine, j & 63);
+            if (j < A) {
+                const int id = g + j;
+                if (u > cbu) { cbu = u; cbid = id; }
+            }
+        }
+    }
+    __syncthreads();
+
+    const ROpdArgs __attribute__((address_space(4))) *q; // closing-only arguments: read here, not held through the loop
+    {
+        unsigned long long ka = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+        q = (const ROpdArgs __attribute__((address_space(4))) *)ka;
+    }
+    double *Umin = q->Umin + base;
+    int32_t *exp_map = q->expanded + (long)root * (q->K > 0 ? q->K : 1);
+    int32_t *const plans = q->plans, *const plan_len = q->plan_len;
+    const int max_plan_len = q->max_plan_len;
+
+    double root_upper = ninf;
+    for (int i = lane; i < n_nodes; i += 64) {
+        const double u = LU(i);
+        Umin[i] = u != u ? ninf : u;
+        if (u > root_upper) root_upper = u;
+        if (u != u) exp_map[__double2loint(u)] = i;
+    }
+    root_upper = wave_max(root_upper);
+    __syncthreads();
+
+    if (status == MP_OK) {
+        double *win = lds;
+        const int C = q->chunk;
+        for (int k0 = k_done - 1; k0 >= 0;) {
+            const int kb = k0 & ~(C - 1);
+            const int lo = 1 + kb * A, n_win = (k0 - kb + 1) * A;
+            __syncthreads();
+            for (int i = lane; i < n_win; i += 64) win[i] = Lmin[lo + i];
+            const int ek = lane <= k0 - kb ? exp_map[kb + lane] : 0;
+            __syncthreads();
+            for (int k = k0; k >= kb; --k) {
+                const int g = (k - kb) * A;
+                const double mine = lane < A ? win[g + lane] : ninf;
+                const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
+                const int parent_k = __builtin_amdgcn_readlane(ek, k - kb);
+                if (lane == 0) {
+                    Lmin[parent_k] = m;
+                    if (parent_k >= lo) win[parent_k - lo] = m;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            k0 = kb - 1;
+        }
+        __syncthreads();
+        Pcg64 gen;
+        gen.load(q->rng + (long)root * 6);
+        int len = 0;
+        int kcur = k_done > 0 ? 0 : -1;
+        while (kcur >= 0) {
+            const int fc = 1 + kcur * A;
+            const double l = lane < A ? Lmin[fc + lane] : ninf;
+            const double slot = lane < A ? LU(fc + lane) : 0.0;
+            const double m = A <= 16 ? row0_max(l) : wave_max(l);
+            const unsigned long long ties = __ballot(lane < A && l == m);
+            const int nt = __popcll(ties);
+            int pick = (int)gen.below((uint32_t)nt);
+            unsigned long long t = ties;
+            while (pick-- > 0) t &= t - 1;
+            const int a = __ffsll((long long)t) - 1;
+            if (lane == 0 && plans && len < max_plan_len) plans[(long)root * max_plan_len + len] = a;
+            ++len;
+            const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
+            kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1;
+        }
+        if (lane == 0) {
+            gen.store(q->rng + (long)root * 6);
+            if (plans)
+                for (int i = len; i < max_plan_len; ++i) plans[(long)root * max_plan_len + i] = -1;
+            if (plan_len) plan_len[root] = len;
+            if (q->root_lower) q->root_lower[root] = Lmin[0];
+            if (q->root_upper) q->root_upper[root] = root_upper;
+        }
+    } else if (lane == 0) {
+        if (plans)
+            for (int i = 0; i < max_plan_len; ++i) plans[(long)root * max_plan_len + i] = -1;
+        if (plan_len) plan_len[root] = 0;
+    }
+    if (lane == 0) {
+        if (q->status) q->status[root] = status;
+        if (q->env_steps) q->env_steps[root] = (int64_t)(n_nodes - 1);
+        q->n_nodes_out[root] = n_nodes;
+    }
+    for (int k = k_done + lane; k < q->K; k += 64) exp_map[k] = -1;
 #undef LU
 }
 
@@ -250,16 +454,21 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
         return fail(MP_ERR_ARG, "mp_ropd_plan: gamma = 1 (the reference divides by 1 - gamma, deterministic.py:53)");
     const long cap = 1 + (long)K * A;
     const int T = (int)((cap + 63) / 64) | 1;
-    const size_t lds_map = (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
-    const size_t lds_full = (size_t)64 * T * sizeof(double) + lds_map;
-    if (lds_map > kLdsBytes - 1024)
-        return fail(MP_ERR_ARG, "mp_ropd_plan: budget %d needs %zu B of LDS per root (> %zu)", budget, lds_map, kLdsBytes - 1024);
-    const char *force = getenv("MP_OPD_MODEL"); // "lds" / "global": test hook (shared with mp_opd_plan)
-    const long lds_roots = (long)ctx->prop.multiProcessorCount * (long)((kLdsBytes - 1024) / lds_full);
-    bool glb = lds_full > kLdsBytes - 1024 || n_roots > lds_roots;
+    const size_t lds_bounds = (size_t)64 * T * sizeof(double); // bounds only, parent map in HBM (EXPG)
+    const size_t lds_full = lds_bounds + (size_t)(K > 0 ? K : 1) * sizeof(int32_t);
+    int chunk = 64; // high-occupancy variant: LDS only holds the window of the closing pass
+    while (chunk > 1 && (size_t)chunk * A * sizeof(double) > 4096) chunk >>= 1;
+    const size_t lds_win = (size_t)chunk * A * sizeof(double);
+    const char *force = getenv("MP_OPD_MODEL"); // "lds" / "ldsx" / "global": test hook (shared with mp_opd_plan)
+    const long cus = ctx->prop.multiProcessorCount;
+    const long lds_roots = cus * (long)((kLdsBytes - 1024) / lds_full);
+    const long expg_roots = cus * (long)((kLdsBytes - 1024) / lds_bounds);
+    bool glb = lds_bounds > kLdsBytes - 1024 || n_roots > expg_roots;
     if (force && force[0] == 'g') glb = true;
-    if (force && force[0] == 'l' && lds_full <= kLdsBytes - 1024) glb = false;
-    const size_t lds = glb ? lds_map : lds_full;
+    if (force && force[0] == 'l' && lds_bounds <= kLdsBytes - 1024) glb = false;
+    bool expg = !glb && (lds_full > kLdsBytes - 1024 || n_roots > lds_roots);
+    if (force && !glb && force[1] == 'd' && force[2] == 's' && force[3] == 'x') expg = true;
+    const size_t lds = glb ? lds_win : (expg ? lds_bounds : lds_full);
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
 
@@ -274,7 +483,7 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     ROpdArgs a;
-    a.n_roots = n_roots; a.M = M; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T;
+    a.n_roots = n_roots; a.M = M; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk;
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec_all;
     a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;
@@ -304,10 +513,11 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
     if (lds > 64 * 1024)
-        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(glb ? ropd_kernel<true> : ropd_kernel<false>),
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(expg ? ropd_kernel<true> : ropd_kernel<false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    if (glb) hipLaunchKernelGGL((ropd_kernel<true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (glb) hipLaunchKernelGGL(ropd_wide_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (expg) hipLaunchKernelGGL((ropd_kernel<true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else hipLaunchKernelGGL((ropd_kernel<false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());

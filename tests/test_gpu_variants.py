@@ -319,7 +319,7 @@ def _robust_models(z, p):
                   np.stack([c["terminal"] for c in cfgs]))
 
 
-@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
 def test_discrete_robust_planner_goldens(ctx, z, variant, monkeypatch):
     """mp_ropd_plan against the reference's DiscreteRobustPlanner / RobustNode: plans, min-over-model root bounds, full
     trees with per-model vectors, generator states."""
@@ -380,7 +380,7 @@ def test_discrete_robust_planner_agent(z):
         agent_factory(trap, dict(__class__=DRP, budget=20, models=[[], []])).plan(0)
 
 
-@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
 @pytest.mark.parametrize("n_models,n_actions,budget", [(1, 3, 200), (2, 5, 500), (3, 4, 100), (5, 2, 101), (16, 7, 300)])
 def test_discrete_robust_planner_batch_vs_oracle(ctx, n_models, n_actions, budget, variant, monkeypatch):
     """70 roots with distinct joint states (every model in its own state) per launch vs the oracle."""
