@@ -516,9 +516,10 @@ def bench_opd(args, rank, world, local):
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots,
                     parallelism="roots sharded over {} GPU(s)".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                      kernel="opd_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+                      kernel="opd_kernel<EXPG> (bounds in LDS) or opd_wide_kernel (bounds in HBM), chosen by the host per batch size",
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
-    add_traffic(res["roofline"], "opd", "opd_kernel", n_roots * 64)
+    add_traffic(res["roofline"], "opd", "opd_", n_roots * 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -589,10 +590,11 @@ def bench_ropd(args, rank, world, local):
         config=dict(workload="robust_opd_highway_shaped_S{}_A{}_M{}_budget{}_roots{}_per_gpu".format(s_, a_, m_, budget, n_roots),
                     n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, budget=budget, gamma=gamma, models=m_,
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots, parallelism="roots sharded over {} GPU(s)".format(world)),
-        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel="ropd_kernel",
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      kernel="ropd_kernel<EXPG> or ropd_wide_kernel, chosen by the host per batch size",
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
-    add_traffic(res["roofline"], "ropd", "ropd_kernel", n_roots * 64)
+    add_traffic(res["roofline"], "ropd", "ropd_", n_roots * 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         cores = host_cores()

@@ -50,11 +50,12 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "uct_prior", "uct_cartpole", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
+    for wl in ("uct", "uct_prior", "uct_cartpole", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
-        lines += ["## " + wl, "", "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
+        lines += ["## " + wl + (" (= --workload opd --roots 8192)" if wl == "opd8192" else ""), "",
+                  "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
         for name, calls, avg, pct in kernel_stats(f):
             lines.append("| `{}` | {} | {:.2f} | {:.2f} |".format(name.replace("|", "/"), calls, avg, pct))
         lines.append("")
@@ -68,7 +69,7 @@ def main():
                     name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
             lines.append("")
     traffic = {}
-    for wl in ("uct", "uct_prior", "vi_dense", "rvi_dense_shard", "opd", "ropd", "saopd"):
+    for wl in ("uct", "uct_prior", "vi_dense", "rvi_dense_shard", "opd", "opd8192", "ropd", "saopd"):
         entry = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             f = os.path.join(src, "pmc_{}_{}".format(wl, ctr), wl + "_counter_collection.csv")
@@ -76,8 +77,8 @@ def main():
                 for k, (n, mean_kb) in pmc(f, ctr).items():
                     entry.setdefault(k, {})[ctr + "_KB_per_launch"] = mean_kb
                     entry[k]["launches_" + ctr] = n
-        if entry:
-            traffic[wl] = entry
+        if entry:  # (bench.py looks a launch up by workload and grid size: the 8192-root pass belongs to "opd")
+            traffic.setdefault("opd" if wl == "opd8192" else wl, {}).update(entry)
     if traffic:
         lines += ["## HBM traffic (PMC, separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`)", "",
                   "Per launch, KB as rocprofv3 reports them.  To bytes: x2 for FETCH_SIZE (streams AND scattered 16-byte gathers: "
