@@ -63,7 +63,9 @@ def pmc_traffic(workload, kernel_substr, grid_threads, pattern="scattered"):
         return None, None
     cal = calibration()
     for key, v in entry.items():
-        if kernel_substr in key and key.endswith("grid={}".format(grid_threads)):
+        # grid_threads None: the kernel is launched on one geometry only in this workload (dense VI: the column split
+        # decides the grid, not the bench)
+        if kernel_substr in key and (grid_threads is None or key.endswith("grid={}".format(grid_threads))):
             if "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
                 ff, fw = cal["fetch_" + pattern], cal["write_" + pattern]
                 raw = dict(FETCH_SIZE_bytes=v["FETCH_SIZE_KB_per_launch"] * 1024.0,
@@ -750,7 +752,7 @@ def bench_vi(args, rank, world, local, dense, robust=False):
                       kernel=name, kernel_ms=per_sweep_ms, algorithmic_bytes_per_launch=alg),
     )
     if dense:
-        add_traffic(res["roofline"], "vi_dense", "vi_dense_q", ((s_ * a_ + 63) // 64) * 256, pattern="stream")
+        add_traffic(res["roofline"], "vi_dense", "vi_dense_q", None, pattern="stream")
     else:
         res["roofline"].update(traffic=None, traffic_frac=None, frac=res["roofline"]["achieved"] / HBM_PEAK_GBS)
     if dense:
@@ -886,7 +888,7 @@ def bench_rvi_dense_shard(args, rank, world, local):
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=alg, mfma_tflops=flops / (k_ms * 1e-3) / 1e12),
     )
     res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
-    add_traffic(res["roofline"], "rvi_dense_shard", "vi_dense_q", ((rows * a_ + 63) // 64) * 256, pattern="stream")
+    add_traffic(res["roofline"], "rvi_dense_shard", "vi_dense_q", None, pattern="stream")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         s_cpu = 1000
