@@ -392,6 +392,15 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 #ifndef MP_SAOPD_MIN_WAVES
 #define MP_SAOPD_MIN_WAVES 8 // waves per SIMD the register allocation must admit (106 SGPRs would cap the kernel at 6)
 #endif
+// Ordering of the wave kernel's uniform phases: lane 0 stores, all lanes load later.  A workgroup is one wavefront and
+// the texture path takes a wavefront's vector-memory operations in order (a store that hits in the L1 updates the line),
+// so a later load sees an earlier store without waiting for its acknowledgement; only the compiler must keep the order.
+// MP_SAOPD_SYNC restores the waits (A/B).
+#ifdef MP_SAOPD_SYNC
+#define SA_ORDER() __syncthreads()
+#else
+#define SA_ORDER() __builtin_amdgcn_wave_barrier()
+#endif
 template <bool LDSR>
 __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_kernel(SaArgs p)
 {
@@ -460,7 +469,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     // reset(): drop the previous leaves list (64 rows per trip), install the new root
     for (int i = p.prev_root + lane; i < p.n_prev; i += 64) {
         const uint32_t m = ND(i).meta;
-        if (m & SA_ALIVE) ND(i).meta = m & ~SA_ALIVE;
+        // (bit 1 of done[]: the row is DEAD -- neither an alive leaf nor a node with children: it can neither be pruned nor
+        // dominate, and the prune scan skips it)
+        if (m & SA_ALIVE) { ND(i).meta = m & ~SA_ALIVE; p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2); }
     }
     const int root = p.root;
     const int32_t s0 = p.root_state[r];
@@ -477,10 +488,18 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     int n_nodes = root + 1;
     int status = MP_OK;
     long steps_taken = 0, updates = 0;
+#ifdef MP_PROFILE
+    long long t_ph[5] = {0, 0, 0, 0, 0}, t_mark = clock64();
+    long pf_nd = 0; int pf_fallback = 0, pf_ndmax = 0;
+#define SA_PROF(i) do { const long long t_now = clock64(); t_ph[i] += t_now - t_mark; t_mark = t_now; } while (0)
+#else
+#define SA_PROF(i)
+#endif
 
     for (int k = 0; k < p.K && status == MP_OK; ++k) {
         const int cur = p.iter_base + k;
         int ndirty = 0;
+        SA_PROF(4);
         // ---- max(leaves, key=U): 64 rows per trip, then (max U, lowest id) across the lanes
         double bu = ninf;
         int leaf = 0x7fffffff;
@@ -508,6 +527,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         }
         wave_argmax(bu, leaf);
         if (leaf == 0x7fffffff) { status = MP_ERR_ARG; break; } // max() of an empty leaves list
+        SA_PROF(0);
         // ---- expand + update: one child per lane, then the list appends in action order
         const SaNode lf = ND(leaf);
         const int dl = (int)(lf.meta & SA_DEPTH);
@@ -552,16 +572,17 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                 if (stm != cur && ndirty < DCAP) dirty[ndirty] = s;
             }
             ndirty += stm != cur ? 1 : 0;
-            __syncthreads();
+            SA_ORDER();
         }
         n_nodes += A;
+        SA_PROF(1);
         // ---- backup_to_root: uniform first-in-first-out loop, the |A| children of a popped node one per lane
         // (lazy queue of {state, node, delta} descriptors: see saopd_kernel)
         {
             unsigned qh = 0, qt = 0;
             if (l0) { QD(qt, 0) = -1; QD(qt, 1) = leaf; }
             ++qt;
-            __syncthreads();
+            SA_ORDER();
             int src = -1, nbr = -1;
             double src_delta = 0.0;
             while ((nbr >= 0 || qh != qt) && status == MP_OK) {
@@ -612,55 +633,110 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         }
                         ndirty += stm != cur ? 1 : 0;
                         ++qt;
-                        __syncthreads();
+                        SA_ORDER();
                     }
                 }
             }
         }
         if (status != MP_OK) break;
+        SA_PROF(2);
         // ---- prune: candidate leaves (alive, state changed this iteration) 64 rows per trip in reverse order, each
         // candidate's list walked as uniform code
         // Leaves of different states never interact in the pass, and within one state the pass order is descending id:
         // one changed state per lane -- pass A stacks the alive leaves of its list (ascending ids) in the lane's slice
         // of the idle queue buffer, pass B pops them (descending) and walks the list for a dominator.
         bool serial_prune = p.prune != 0;
-        if (p.prune && ndirty <= DCAP) {
-            const int scap = p.scap; // scratch entries per lane
-            int32_t *stk = queue_b + (long)lane * (qcap >> 6);
-            bool overflow = false;
-            for (int base = 0; base < ndirty && !overflow; base += 64) {
-                const int32_t s = base + lane < ndirty ? dirty[base + lane] : -1;
-                int cnt = 0;
-                if (s >= 0)
-                    for (int nd_i = HD(s); nd_i >= 0;) {
-                        const SaNode nd = ND(nd_i);
-                        if (nd.meta & SA_ALIVE) {
-                            if (cnt < scap) stk[cnt] = nd_i;
-                            ++cnt;
-                        }
-                        nd_i = nd.next_same;
+        // Prune as ONE scan of the arena instead of list walks.  A leaf's test reads its state's value and node list; only
+        // leaves of states whose value or list changed in this iteration can newly fail it (stamp == cur).  Walking those
+        // lists is a chain of dependent reads (17-24 links on average, 84 at most on the reference's grid, 1.6-1.9 alive
+        // leaves per changed state each walking it again: 65-75 % of a later plan's time).  The rows of the changed
+        // states are instead COLLECTED by a coalesced scan of state[] over the whole arena (independent reads: 24-40 per
+        // lane, all in flight) into the idle queue buffer, in id order; at most 256 of them (4.3 changed states x ~20
+        // rows per iteration on the grid: 80-100 on average, 240 at most) are then held one per lane in four register sets, and every candidate leaf --
+        // descending id, as the reference's reversed leaves list -- is tested against all of them at once with one
+        // ballot per set; alive flags are updated in the registers (a pruned leaf stops dominating later candidates)
+        // and written back at the end.  More rows than that, or the test knob, take the serial pass below.
+        if (p.prune && p.scap >= 2) {
+            int32_t *recs = queue_b; // {row, state} pairs of the rows whose state is dirty
+            constexpr int NS = 4; // register sets of 64 rows
+            const int rcap = min(64 * NS, qcap >> 1);
+            int n_d = 0;
+            const unsigned long long lt = (1ULL << lane) - 1ULL;
+            for (int i0 = 0; i0 < n_nodes; i0 += 64 * WU) {
+                int32_t sts[WU], stamps[WU], heads[WU];
+                uint8_t dead[WU];
+#pragma unroll
+                for (int j = 0; j < WU; ++j) {
+                    const int i = min(i0 + 64 * j + lane, n_nodes - 1);
+                    sts[j] = ST(i);
+                    dead[j] = p.done[nb + i];
+                }
+#pragma unroll
+                for (int j = 0; j < WU; ++j) { stamps[j] = SM(sts[j]); heads[j] = HD(sts[j]); }
+#pragma unroll
+                for (int j = 0; j < WU; ++j) {
+                    const int i = i0 + 64 * j + lane;
+                    // a state's list = its rows from the list head on (lists are in id order; plan() starts the root
+                    // state's list over, which drops that state's older rows)
+                    const bool hit = i < n_nodes && stamps[j] == cur && i >= heads[j] && !(dead[j] & 2);
+                    const unsigned long long bm = __ballot(hit);
+                    if (hit) {
+                        const int pos = n_d + __popcll(bm & lt);
+                        if (pos < rcap) { recs[2 * pos] = i; recs[2 * pos + 1] = sts[j]; }
                     }
-                if (__any(cnt > scap)) { overflow = true; break; }
-                if (s >= 0) {
-                    const double svs = SV(s);
-                    for (int c = cnt - 1; c >= 0; --c) {
-                        const int i = stk[c];
-                        const SaNode me = ND(i);
-                        const int dm = (int)(me.meta & SA_DEPTH);
-                        const double vub = me.lower + gpow[dm] * svs;
-                        for (int nd_i = HD(s); nd_i >= 0;) {
-                            const SaNode nd = ND(nd_i);
-                            const int dn = (int)(nd.meta & SA_DEPTH);
-                            if (nd_i != i && nd.lower + gpow[dn] * svs >= vub && dn >= dm && (nd.meta & (SA_CHILDREN | SA_ALIVE))) {
-                                ND(i).meta = me.meta & ~SA_ALIVE;
-                                break;
-                            }
-                            nd_i = nd.next_same;
-                        }
-                    }
+                    n_d += __popcll(bm);
                 }
             }
-            serial_prune = overflow; // (re-running the serial pass over states already done changes nothing)
+#ifdef MP_PROFILE
+            pf_nd += n_d; pf_fallback += n_d > rcap ? 1 : 0; pf_ndmax = n_d > pf_ndmax ? n_d : pf_ndmax;
+#endif
+            if (n_d <= rcap) {
+                __syncthreads(); // the pairs are read back by other lanes
+                // NS register sets: record lane + 64 q = {state, meta, value}; a record is identified by (set, lane)
+                int rst[NS];
+                uint32_t rmeta[NS];
+                double rval[NS];
+                uint32_t changed = 0;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    const int j = lane + 64 * q;
+                    rst[q] = -1; rmeta[q] = 0; rval[q] = ninf;
+                    if (j < n_d) {
+                        const int i = recs[2 * j];
+                        rst[q] = recs[2 * j + 1];
+                        const SaNode nd = ND(i);
+                        rmeta[q] = nd.meta;
+                        rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
+                    }
+                }
+                // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it
+#pragma unroll
+                for (int q = NS - 1; q >= 0; --q) {
+                    if (64 * q >= n_d) continue;
+                    unsigned long long todo = __ballot(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
+                    while (todo) {
+                        const int l = 63 - __clzll((long long)todo);
+                        todo &= ~(1ULL << l);
+                        const int cs = __builtin_amdgcn_readlane(rst[q], l);
+                        const int cd = (int)(__builtin_amdgcn_readlane((int)rmeta[q], l) & SA_DEPTH);
+                        const double cv = bcast_lane(rval[q], l);
+                        bool dom = false;
+#pragma unroll
+                        for (int t = 0; t < NS; ++t)
+                            dom |= rst[t] == cs && (t != q || lane != l) && rval[t] >= cv && (int)(rmeta[t] & SA_DEPTH) >= cd &&
+                                   (rmeta[t] & (SA_CHILDREN | SA_ALIVE)) != 0;
+                        if (__any(dom) && lane == l) { rmeta[q] &= ~SA_ALIVE; changed |= 1u << q; }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    if (changed & (1u << q)) { // a pruned leaf: not alive, no children -- dead from now on
+                        const int i = recs[2 * (lane + 64 * q)];
+                        ND(i).meta = rmeta[q];
+                        p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2);
+                    }
+                serial_prune = false;
+            }
             __syncthreads();
         }
         if (serial_prune)
@@ -699,7 +775,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         const SaNode nd = ND(nd_i);
                         const int dn = (int)(nd.meta & SA_DEPTH);
                         if (nd_i != i && nd.lower + gpow[dn] * svs >= vub && dn >= dm && (nd.meta & (SA_CHILDREN | SA_ALIVE))) {
-                            if (l0) ND(i).meta = me.meta & ~SA_ALIVE;
+                            if (l0) { ND(i).meta = me.meta & ~SA_ALIVE; p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2); }
                             break;
                         }
                         nd_i = nd.next_same;
@@ -708,7 +784,14 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                 }
               }
             }
+        SA_PROF(3);
     }
+#ifdef MP_PROFILE
+    if (r == 0 && l0)
+        printf("saopd prof planner0: leaf-scan %lld  expand+append %lld  backup %lld  prune %lld  other %lld (clock64 ticks), nodes %d..%d\n",
+               t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4], root, n_nodes);
+    if (r == 0 && l0) printf("saopd prof planner0: rows of dirty states %ld over %d iterations (max %d), serial fallbacks %d\n", pf_nd, p.K, pf_ndmax, pf_fallback);
+#endif
     // ---- get_plan, twice (see saopd_kernel), uniform
     int len = 0;
     if (status == MP_OK) {
@@ -1067,6 +1150,7 @@ int mp_saopd_export(mp_saopd *pl, int32_t planner, int32_t cap, int32_t *parent,
         if (lower) lower[i] = hn[i].lower;
         if (depth) depth[i] = (int32_t)(hn[i].meta & SA_DEPTH);
         if (alive) alive[i] = (hn[i].meta & SA_ALIVE) ? 1 : 0;
+        if (done) done[i] &= 1; // (bit 1 is the wave kernel's dead-row mark)
         if (action) action[i] = -1;
     }
     if (action)
