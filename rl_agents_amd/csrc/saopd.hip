@@ -50,7 +50,22 @@ struct alignas(16) SaNode {
     uint32_t meta;
 };
 static_assert(sizeof(SaNode) == 16, "SaNode must be one dwordx4");
-constexpr uint32_t SA_ALIVE = 0x80000000u, SA_CHILDREN = 0x40000000u, SA_DEPTH = 0x3fffffffu;
+constexpr uint32_t SA_ALIVE = 0x80000000u, SA_CHILDREN = 0x40000000u, SA_DEPTH = 0x00ffffffu;
+// bits 24..29 of meta: the action that led to the node (wave kernel: its sibling group starts at id - action, so a
+// backup finds the children of a node's parent without reading the parent's first_child)
+// A node record as ONE 16-byte load: the compiler otherwise splits the struct load into a dwordx2 and one or two dword
+// loads when the fields are used apart, and at 8 waves per SIMD the wave kernel is bound by the number of vector-memory
+// instructions it issues.
+__device__ __forceinline__ SaNode load_node(const SaNode *p)
+{
+    uint4 r = *reinterpret_cast<const uint4 *>(p);
+    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); // (all four words live here)
+    SaNode n;
+    n.lower = __hiloint2double((int)r.y, (int)r.x); n.next_same = (int32_t)r.z; n.meta = r.w;
+    return n;
+}
+constexpr int SA_ACT_SHIFT = 24;
+constexpr uint32_t SA_ACT = 0x3f000000u;
 
 } // namespace mp
 
@@ -461,7 +476,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     auto TL = [&](int s) -> int32_t & { return tail_b[s]; };
     auto SM = [&](int s) -> int32_t & { return stamp_b[s]; };
     const unsigned dcap = (unsigned)qcap >> 2; // backup-queue descriptors: 4 ints each
-    auto QD = [&](unsigned q, int f) -> int32_t & { return queue_b[((q & (dcap - 1)) << 2) + f]; };
+    // one 16-byte descriptor {state, node, delta lo, delta hi} per slot: one vector-memory instruction per push / pop (at 8
+    // waves per SIMD the backup is bound by the number of vector-memory instructions it issues, ~8 cycles each per CU)
+    auto QD4 = [&](unsigned q) -> int4 & { return reinterpret_cast<int4 *>(queue_b)[q & (dcap - 1)]; };
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
     const double ninf = -INFINITY;
     const bool l0 = lane == 0;
@@ -511,7 +528,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
 #pragma unroll
             for (int j = 0; j < WU; ++j) {
                 const int i = min(i0 + 64 * j, n_nodes - 1);
-                nd[j] = ND(i);
+                nd[j] = load_node(&ND(i));
                 st[j] = ST(i);
             }
 #pragma unroll
@@ -529,7 +546,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         if (leaf == 0x7fffffff) { status = MP_ERR_ARG; break; } // max() of an empty leaves list
         SA_PROF(0);
         // ---- expand + update: one child per lane, then the list appends in action order
-        const SaNode lf = ND(leaf);
+        const SaNode lf = load_node(&ND(leaf));
         const int dl = (int)(lf.meta & SA_DEPTH);
         const int32_t sl = ST(leaf);
         const int g = n_nodes;
@@ -545,7 +562,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             s_c = rc.next;
             const int c = g + lane;
             SaNode nd;
-            nd.lower = lower; nd.next_same = -1; nd.meta = SA_ALIVE | (uint32_t)d;
+            nd.lower = lower; nd.next_same = -1; nd.meta = SA_ALIVE | ((uint32_t)lane << SA_ACT_SHIFT) | (uint32_t)d;
             ND(c) = nd;
             ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = rc.reward;
             p.done[nb + c] = term_c ? 1 : 0;
@@ -580,47 +597,60 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         // (lazy queue of {state, node, delta} descriptors: see saopd_kernel)
         {
             unsigned qh = 0, qt = 0;
-            if (l0) { QD(qt, 0) = -1; QD(qt, 1) = leaf; }
+            if (l0) QD4(qt) = make_int4(-1, leaf, 0, 0);
             ++qt;
             SA_ORDER();
             int src = -1, nbr = -1;
             double src_delta = 0.0;
+            // The walk of a popped state's list is software-pipelined: the record and the parent of the NEXT list element
+            // are requested as soon as the current element's link is known, so they arrive while the current element's
+            // backup (two more round trips) is in flight.  Nothing the backup writes (state values, stamps, queue) is
+            // part of a node record, so the early read sees what a late one would.
+            SaNode nd_nbr;
+            nd_nbr.lower = 0.0; nd_nbr.next_same = -1; nd_nbr.meta = 0;
+            int par_nbr = -1;
             while ((nbr >= 0 || qh != qt) && status == MP_OK) {
-                int node = -1;
+                int node = -1, group = -1; // group: first child of `node` when it is known without reading FC(node)
                 if (nbr < 0) { // front descriptor
-                    const int32_t ds = QD(qh, 0);
-                    src = QD(qh, 1);
+                    const int4 dq = QD4(qh);
+                    const int32_t ds = dq.x;
+                    src = dq.y;
                     if (ds < 0) {
                         node = src;
                     } else {
-                        src_delta = __hiloint2double(QD(qh, 3), QD(qh, 2));
+                        src_delta = __hiloint2double(dq.w, dq.z);
                         nbr = HD(ds);
+                        if (nbr >= 0) { nd_nbr = load_node(&ND(nbr)); par_nbr = PA(nbr); }
                     }
                     ++qh;
                 } else {       // one neighbour
-                    const SaNode nd = ND(nbr);
-                    const int par = PA(nbr);
-                    if (par >= 0 && (nbr == src || p.backup_aggregated) && src_delta > acc[nd.meta & SA_DEPTH]) node = par;
+                    const SaNode nd = nd_nbr;
+                    const int par = par_nbr;
+                    if (par >= 0 && (nbr == src || p.backup_aggregated) && src_delta > acc[nd.meta & SA_DEPTH]) {
+                        node = par;
+                        group = nbr - (int)((nd.meta & SA_ACT) >> SA_ACT_SHIFT); // the siblings of nbr = the children of par
+                    }
                     nbr = nd.next_same;
+                    if (nbr >= 0) { nd_nbr = load_node(&ND(nbr)); par_nbr = PA(nbr); }
                 }
                 if (node < 0) continue;
                 const int32_t sn = ST(node);
-                const int fc = FC(node);
+                const int fc = group >= 0 ? group : FC(node);
                 if (fc >= 0) {
                     double u = ninf, bk = 0.0;
                     int a_id = 0x7fffffff;
                     if (lane < A) {
                         const int c = fc + lane;
-                        const SaNode nd = ND(c);
+                        const SaNode nd = load_node(&ND(c));
                         const double svc = SV(ST(c));
                         u = nd.lower + gpow[nd.meta & SA_DEPTH] * svc;
                         bk = RW(c) + p.gamma * svc;
                         a_id = lane;
                     }
+                    const double old = SV(sn); // (requested with the children's values, not after the argmax)
+                    const int stm = SM(sn);
                     if (A <= 16) row0_argmax(u, a_id); else wave_argmax(u, a_id); // first maximal U in action order
                     const double backup = __shfl(bk, a_id);
-                    const double old = SV(sn);
-                    const int stm = SM(sn);
                     const double delta = old - backup;
                     ++updates;
                     if (delta > 0.0) {
@@ -628,8 +658,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         if (l0) {
                             SV(sn) = backup; SM(sn) = cur;
                             if (stm != cur && ndirty < DCAP) dirty[ndirty] = sn;
-                            QD(qt, 0) = sn; QD(qt, 1) = node;
-                            QD(qt, 2) = __double2loint(delta); QD(qt, 3) = __double2hiint(delta);
+                            QD4(qt) = make_int4(sn, node, __double2loint(delta), __double2hiint(delta));
                         }
                         ndirty += stm != cur ? 1 : 0;
                         ++qt;
@@ -704,7 +733,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                     if (j < n_d) {
                         const int i = recs[2 * j];
                         rst[q] = recs[2 * j + 1];
-                        const SaNode nd = ND(i);
+                        const SaNode nd = load_node(&ND(i));
                         rmeta[q] = nd.meta;
                         rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
                     }
