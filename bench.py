@@ -665,6 +665,15 @@ def bench_saopd(args, rank, world, local):
                       kernel="saopd_wave_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
     add_traffic(res["roofline"], "saopd", "saopd_wave_kernel", n_roots * 64)
+    if rank == 0:   # outside the timed region: what the FOLLOWING plans of the same planners cost (receding horizon)
+        planners = native.StateAwarePlanners(ctx, model, n_roots)
+        states, rng, follow = s0.copy(), rng0.copy(), []
+        for _ in range(3):
+            o = planners.plan(states, budget, gamma, 0.0, rng, max_plan_len=8)
+            follow.append(round(ctx.last_kernel_ms()[0], 3))
+            states = np.where(o["plan_len"] > 0, t[states, np.maximum(o["plans"][:, 0], 0)], states).astype(np.int32)
+        planners.close()
+        res["config"]["kernel_ms_first_and_following_plans"] = follow
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()

@@ -424,10 +424,8 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     const int lane = threadIdx.x;
     for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
     const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
-    // states whose value or node list changed in the current iteration (each once): the prune pass handles them one
-    // per lane; more than DCAP of them (or more leaves of one state than a lane's scratch holds) take the serial pass
-    constexpr int DCAP = 128;
-    int32_t *dirty = reinterpret_cast<int32_t *>(lds_d + ntab);
+    constexpr int DCAP = 128; // (512 B of LDS after the tables, reserved by the host's size computation; unused since the
+                              // prune pass finds the rows of changed states by their stamps)
     const int r = blockIdx.x;
     const int A = p.A;
     const long nb = (long)r * p.cap, sb = (long)r * p.S, qb = (long)r * p.qcap;
@@ -515,7 +513,6 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
 
     for (int k = 0; k < p.K && status == MP_OK; ++k) {
         const int cur = p.iter_base + k;
-        int ndirty = 0;
         SA_PROF(4);
         // ---- max(leaves, key=U): 64 rows per trip, then (max U, lowest id) across the lanes
         double bu = ninf;
@@ -580,15 +577,12 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             const int c = g + a;
             const int32_t t = TL(s);
             const double svs = SV(s);
-            const int stm = SM(s);
             if (l0) {
                 if (t < 0) HD(s) = c; else ND(t).next_same = c;
                 TL(s) = c;
-                SM(s) = cur;
+                SM(s) = cur; // the state's list changed in this iteration: its leaves are prune candidates
                 if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
-                if (stm != cur && ndirty < DCAP) dirty[ndirty] = s;
             }
-            ndirty += stm != cur ? 1 : 0;
             SA_ORDER();
         }
         n_nodes += A;
@@ -648,7 +642,6 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         a_id = lane;
                     }
                     const double old = SV(sn); // (requested with the children's values, not after the argmax)
-                    const int stm = SM(sn);
                     if (A <= 16) row0_argmax(u, a_id); else wave_argmax(u, a_id); // first maximal U in action order
                     const double backup = __shfl(bk, a_id);
                     const double delta = old - backup;
@@ -657,10 +650,8 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         if (qt - qh >= dcap) { status = MP_ERR_ALLOC; if (l0) *p.overflow = 1; break; }
                         if (l0) {
                             SV(sn) = backup; SM(sn) = cur;
-                            if (stm != cur && ndirty < DCAP) dirty[ndirty] = sn;
                             QD4(qt) = make_int4(sn, node, __double2loint(delta), __double2hiint(delta));
                         }
-                        ndirty += stm != cur ? 1 : 0;
                         ++qt;
                         SA_ORDER();
                     }
