@@ -281,7 +281,11 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
  *   Bellman backups of this plan), status int32 [n]: MP_OK, MP_ERR_REWARD_RANGE (ValueError, deterministic.py:46-47),
  *   MP_ERR_ARG (every leaf pruned: the reference's max() of an empty list, :95) or MP_ERR_ALLOC (backup queue full and
  *   no room to grow it: a full queue normally rolls the plan back and runs it again with a larger one).
- *   The call reads one overflow flag back per attempt, i.e. it synchronises the stream even with mem = MP_MEM_DEVICE.
+ *   mem = MP_MEM_HOST: the call synchronises (it returns host arrays), reads the overflow flag and retries by itself.
+ *   mem = MP_MEM_DEVICE: ASYNCHRONOUS, one launch and nothing read back; a planner whose queue fills up then reports
+ *   MP_ERR_ALLOC in `status`, cannot be rolled back, and stays failed: every later call reports MP_ERR_ALLOC for it again
+ *   (the other planners of the batch are unaffected).  The same holds for the planners left full when a host-mode call
+ *   runs out of room to grow the queue.
  * The model must outlive the planners (they read its transition records).
  * mp_saopd_export: arena of one planner in creation order (node rows [root, n_nodes) are the current tree; `alive` =
  * "in planner.leaves"), arrays of capacity >= n_nodes (mp_saopd_info), and state_values double [S].

@@ -106,7 +106,8 @@ namespace mp {
 struct SaArgs {
     int n, S, A, K, root, n_prev, prev_root, qcap, done_on_next, max_plan_len;
     int backup_aggregated, prune, fresh, iter_base;
-    int32_t *overflow; // set when a planner's backup queue is full
+    int32_t *overflow; // [0]: set when a planner's backup queue is full; [1 + r]: planner r FAILED for good (sticky)
+    int sticky;        // 1: a full queue marks the planner failed (asynchronous device mode: no roll-back, no retry)
     int cap;  // wave kernel: node rows allocated per planner
     int scap; // wave kernel: scratch entries per lane in the prune pass (qcap / 64 unless MP_SAOPD_LANE_SCRATCH)
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
@@ -142,6 +143,15 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
     const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= p.n) return;
+    if (p.overflow[1 + r]) { // a planner whose backup queue overflowed in an asynchronous call: its dictionaries are broken
+        if (p.plans)
+            for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[r] = 0;
+        if (p.status) p.status[r] = MP_ERR_ALLOC;
+        if (p.env_steps) p.env_steps[r] = 0;
+        if (p.updates) p.updates[r] = 0;
+        return;
+    }
     const long n = p.n;
     const int A = p.A;
     // [row][planner] addressing
@@ -293,7 +303,11 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
                         ++updates;
                         if (delta > 0.0) { // (thresholds are >= 0: nothing is appended otherwise)
                             SV(sn) = backup; SM(sn) = cur;
-                            if (qt - qh >= dcap) { status = MP_ERR_ALLOC; *p.overflow = 1; active = false; continue; }
+                            if (qt - qh >= dcap) {
+                                status = MP_ERR_ALLOC; *p.overflow = 1; active = false;
+                                if (p.sticky) p.overflow[1 + r] = 1;
+                                continue;
+                            }
                             QD(qt, 0) = sn; QD(qt, 1) = target;
                             QD(qt, 2) = __double2loint(delta); QD(qt, 3) = __double2hiint(delta);
                             ++qt;
@@ -428,6 +442,17 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                               // prune pass finds the rows of changed states by their stamps)
     const int r = blockIdx.x;
     const int A = p.A;
+    if (p.overflow[1 + r]) { // failed for good in an earlier asynchronous call (see saopd_kernel)
+        if (lane == 0) {
+            if (p.plans)
+                for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+            if (p.plan_len) p.plan_len[r] = 0;
+            if (p.status) p.status[r] = MP_ERR_ALLOC;
+            if (p.env_steps) p.env_steps[r] = 0;
+            if (p.updates) p.updates[r] = 0;
+        }
+        return;
+    }
     const long nb = (long)r * p.cap, sb = (long)r * p.S, qb = (long)r * p.qcap;
     // LDS carve (LDSR): [tables | dirty 128 i32 | node rows 16 B | reward f64 | sv f64 | state, parent, first_child i32 rows |
     // head, tail, stamp i32 [S] | queue i32]
@@ -647,7 +672,11 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                     const double delta = old - backup;
                     ++updates;
                     if (delta > 0.0) {
-                        if (qt - qh >= dcap) { status = MP_ERR_ALLOC; if (l0) *p.overflow = 1; break; }
+                        if (qt - qh >= dcap) {
+                            status = MP_ERR_ALLOC;
+                            if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = 1; }
+                            break;
+                        }
                         if (l0) {
                             SV(sn) = backup; SM(sn) = cur;
                             QD4(qt) = make_int4(sn, node, __double2loint(delta), __double2hiint(delta));
@@ -862,6 +891,13 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
 
 // grow a node array from old_cap to new_cap rows per planner, keeping the used_rows rows in use
 // undo the list appends of a rolled-back plan: after the tails are restored, every tail is the end of its list again
+// host mode, no room left to grow the queue: the planners that still report MP_ERR_ALLOC stay failed
+__global__ __launch_bounds__(64) void saopd_mark_failed_kernel(int n, const int32_t *status, int32_t *overflow)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && status[r] == MP_ERR_ALLOC) overflow[1 + r] = 1;
+}
+
 __global__ __launch_bounds__(64) void saopd_fix_tails_kernel(int n, int S, long node_si, long node_sr, long state_si, long state_sr,
                                                              const int32_t *tail, SaNode *node)
 {
@@ -917,9 +953,13 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
         hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess ||
         hipMalloc(&pl->snap_sv, sn * 8) != hipSuccess || hipMalloc(&pl->snap_head, sn * 4) != hipSuccess ||
         hipMalloc(&pl->snap_tail, sn * 4) != hipSuccess || hipMalloc(&pl->snap_stamp, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4) != hipSuccess) {
+        hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
+    }
+    if (hipMemset(pl->overflow, 0, 4 * (size_t)(1 + pl->n)) != hipSuccess) {
+        mp_saopd_free(pl);
+        return fail(MP_ERR_HIP, "mp_saopd_create: hipMemset failed");
     }
     *out = pl;
     return MP_OK;
@@ -1040,6 +1080,13 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     // at most one planner per CU.
     bool use_lds = pl->wave && lds_res <= kLdsBytes - 1024 && n <= ctx->prop.multiProcessorCount;
     if (const char *e = getenv("MP_SAOPD_LDS")) use_lds = pl->wave && lds_res <= kLdsBytes - 1024 && e[0] == '1';
+    // mem = MP_MEM_DEVICE: ASYNCHRONOUS -- one launch, nothing read back.  A planner whose backup queue fills up cannot be
+    // rolled back and retried then: it reports MP_ERR_ALLOC and stays failed (every later call reports it again), the
+    // other planners of the batch are unaffected.  With host arrays the call synchronises anyway, reads the overflow
+    // word and retries with a larger queue.
+    const bool async = mem == MP_MEM_DEVICE;
+    a.sticky = async ? 1 : 0;
+    if (async) use_lds = false; // (its small queue relies on the retry)
     const int scap_global = a.scap;
     if (use_lds) a.scap = a.lds_qcap >> 6 < a.scap ? a.lds_qcap >> 6 : a.scap;
     // what a plan changes outside its own node rows: the per-state dictionaries, the list links of older tail nodes
@@ -1075,6 +1122,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         } else if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel<false>, dim3((unsigned)n), dim3(64), lds, st, a);
         else hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
         ++launches;
+        if (async) break;
         int32_t ovf = 0;
         MP_HIP(hipMemcpyAsync(&ovf, pl->overflow, 4, hipMemcpyDeviceToHost, st));
         MP_HIP(hipStreamSynchronize(st));
@@ -1086,7 +1134,13 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
             use_lds = false;
             a.scap = scap_global;
         } else {
-            if (bigger > max_queue_bytes) break; // out of room: the full planners keep MP_ERR_ALLOC
+            if (bigger > max_queue_bytes) { // out of room: the full planners keep MP_ERR_ALLOC, now and in later calls
+                if (a.status) {
+                    hipLaunchKernelGGL(saopd_mark_failed_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, n, a.status, pl->overflow);
+                    ++launches;
+                }
+                break;
+            }
             // roll back and run again with a queue four times as large
             MP_HIP(hipFree(pl->queue));
             pl->queue = nullptr;

@@ -543,6 +543,18 @@ class StateAwarePlanners(object):
                                            _ptr(out["status"]), MP_MEM_HOST))
         return out
 
+    def plan_device(self, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len, accuracy=0.0,
+                    backup_aggregated_nodes=True, prune_suboptimal_leaves=True, plans=None, plan_len=None, env_steps=None,
+                    updates=None, status=None):
+        """Asynchronous form: every array is a device buffer (torch tensors on the context's device: root_state int32
+        [n], rng_state uint64-as-int64 [n, 6], plans int32 [n, max_plan_len], plan_len / status int32 [n], env_steps /
+        updates int64 [n]); one launch on the context's stream, nothing read back.  A planner whose backup queue fills up
+        reports MP_ERR_ALLOC in ``status`` and stays failed for every later call (mi355plan.h)."""
+        _check(self.ctx._lib.mp_saopd_plan(self.ctx._h, self._h, _ptr(root_state), int(budget), float(gamma),
+                                           float(terminal_reward), float(accuracy), int(bool(backup_aggregated_nodes)),
+                                           int(bool(prune_suboptimal_leaves)), _ptr(rng_state), int(max_plan_len), _ptr(plans),
+                                           _ptr(plan_len), _ptr(env_steps), _ptr(updates), _ptr(status), MP_MEM_DEVICE))
+
     def info(self):
         n, nn, root, s = c_i32(), c_i32(), c_i32(), c_i32()
         _check(self.ctx._lib.mp_saopd_info(self._h, C.byref(n), C.byref(nn), C.byref(root), C.byref(s)))

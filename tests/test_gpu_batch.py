@@ -501,6 +501,58 @@ def test_state_aware_queue_overflow_is_reported(ctx, monkeypatch):
     rng = _rng_states(64, base=5)
     out = planners.plan(np.arange(64, dtype=np.int32), 400, 0.8, 0.0, rng, max_plan_len=4)
     assert (out["status"] == native.MP_ERR_ALLOC).any() and set(np.unique(out["status"])) <= {0, native.MP_ERR_ALLOC}
+    # a planner left with a full queue has lost backups: it stays failed, loudly, in every later call
+    again = planners.plan(np.arange(64, dtype=np.int32), 8, 0.8, 0.0, rng, max_plan_len=4)
+    full = out["status"] == native.MP_ERR_ALLOC
+    assert (again["status"][full] == native.MP_ERR_ALLOC).all() and (again["plan_len"][full] == 0).all()
+    assert (again["status"][~full] == 0).any()   # (the others go on; some may fill the tiny queue now)
+    planners.close()
+    model.close()
+
+
+def test_state_aware_device_mode_is_asynchronous_and_loud(ctx, monkeypatch):
+    """mem = MP_MEM_DEVICE: one launch, nothing read back.  Results equal the host-mode call's; a planner whose queue
+    fills up reports MP_ERR_ALLOC (no roll-back possible then) and keeps reporting it, the others are unaffected."""
+    torch = pytest.importorskip("torch")
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    cfg = generators.gridworld()
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    n, budget, mpl = 64, 400, 4
+    s0 = np.arange(n, dtype=np.int32)
+    dev = torch.device("cuda", 0)
+
+    def device_plan(planners, rng_np, b):
+        d = dict(root=torch.from_numpy(s0).to(dev), rng=torch.from_numpy(rng_np.view(np.int64)).to(dev),
+                 plans=torch.zeros((n, mpl), dtype=torch.int32, device=dev), plan_len=torch.zeros(n, dtype=torch.int32, device=dev),
+                 env_steps=torch.zeros(n, dtype=torch.int64, device=dev), updates=torch.zeros(n, dtype=torch.int64, device=dev),
+                 status=torch.zeros(n, dtype=torch.int32, device=dev))
+        torch.cuda.synchronize()  # (the uploads ran on torch's stream, the plan runs on the context's)
+        planners.plan_device(d["root"], b, 0.8, 0.0, d["rng"], mpl, plans=d["plans"], plan_len=d["plan_len"],
+                             env_steps=d["env_steps"], updates=d["updates"], status=d["status"])
+        ctx.synchronize()
+        return {k: v.cpu().numpy() for k, v in d.items()}
+
+    # a comfortable queue: the asynchronous call gives what the synchronous one gives
+    ref_planners = native.StateAwarePlanners(ctx, model, n)
+    rng = _rng_states(n, base=5)
+    ref = ref_planners.plan(s0, budget, 0.8, 0.0, rng.copy(), max_plan_len=mpl)
+    ref_planners.close()
+    planners = native.StateAwarePlanners(ctx, model, n)
+    out = device_plan(planners, rng.copy(), budget)
+    for k in ("plans", "plan_len", "env_steps", "updates", "status"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    planners.close()
+    # a queue that is too small: reported per planner, sticky, the others still equal the reference
+    monkeypatch.setenv("MP_SAOPD_QUEUE", "512")
+    planners = native.StateAwarePlanners(ctx, model, n)
+    out = device_plan(planners, rng.copy(), budget)
+    full = out["status"] == native.MP_ERR_ALLOC
+    assert full.any() and not full.all()
+    for k in ("plans", "plan_len", "env_steps", "updates"):
+        np.testing.assert_array_equal(out[k][~full], ref[k][~full], err_msg=k)
+    again = device_plan(planners, rng.copy(), 8)
+    assert (again["status"][full] == native.MP_ERR_ALLOC).all() and (again["status"][~full] == 0).any()
     planners.close()
     model.close()
 
