@@ -84,6 +84,7 @@ struct mp_saopd {
     int32_t *state = nullptr, *parent = nullptr, *first_child = nullptr;
     double *reward = nullptr;
     uint8_t *done = nullptr;
+    int32_t *oldlive = nullptr; // wave kernel: ids of the rows of earlier plans that have children (rebuilt by every plan)
     double *sv = nullptr;
     int32_t *head = nullptr, *tail = nullptr, *queue = nullptr, *stamp = nullptr;
     int iters = 0;      // iterations run so far (stamps are unique across plans)
@@ -120,6 +121,7 @@ struct SaArgs {
     int32_t *state, *parent, *first_child;
     double *reward;
     uint8_t *done;
+    int32_t *oldlive; // [planner][cap] scratch of the wave kernel's prune scan
     double *sv;
     int32_t *head, *tail, *queue, *stamp;
     int32_t *plans, *plan_len, *status;
@@ -525,6 +527,22 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         SV(s0) = p.vmax;
     }
     __syncthreads();
+    // the rows of EARLIER plans that can still matter to a prune test: those with children (their leaves were dropped by
+    // reset()).  Listed once per plan, in id order, so that the per-iteration scan below reads a quarter of the old arena
+    // and nothing of its dead rows -- the scan's cost would otherwise grow with every plan of an episode.
+    int32_t *old_b = p.oldlive + nb;
+    int n_old = 0;
+    if (p.prune) {
+        const unsigned long long lt0 = (1ULL << lane) - 1ULL;
+        for (int i0 = 0; i0 < root; i0 += 64) {
+            const int i = i0 + lane;
+            const bool live = i < root && (ND(i).meta & SA_CHILDREN) != 0;
+            const unsigned long long bm = __ballot(live);
+            if (live) old_b[n_old + __popcll(bm & lt0)] = i;
+            n_old += __popcll(bm);
+        }
+        __syncthreads();
+    }
     int n_nodes = root + 1;
     int status = MP_OK;
     long steps_taken = 0, updates = 0;
@@ -711,23 +729,29 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             const int rcap = min(64 * NS, qcap >> 1);
             int n_d = 0;
             const unsigned long long lt = (1ULL << lane) - 1ULL;
-            for (int i0 = 0; i0 < n_nodes; i0 += 64 * WU) {
-                int32_t sts[WU], stamps[WU], heads[WU];
+            // scan positions: the listed old rows, then the rows of this plan (root .. n_nodes - 1)
+            const int n_pos = n_old + (n_nodes - root);
+            for (int i0 = 0; i0 < n_pos; i0 += 64 * WU) {
+                int32_t rows[WU], sts[WU], stamps[WU], heads[WU];
                 uint8_t dead[WU];
 #pragma unroll
                 for (int j = 0; j < WU; ++j) {
-                    const int i = min(i0 + 64 * j + lane, n_nodes - 1);
-                    sts[j] = ST(i);
-                    dead[j] = p.done[nb + i];
+                    const int q = min(i0 + 64 * j + lane, n_pos - 1);
+                    rows[j] = q < n_old ? old_b[q] : root + (q - n_old);
+                }
+#pragma unroll
+                for (int j = 0; j < WU; ++j) {
+                    sts[j] = ST(rows[j]);
+                    dead[j] = p.done[nb + rows[j]];
                 }
 #pragma unroll
                 for (int j = 0; j < WU; ++j) { stamps[j] = SM(sts[j]); heads[j] = HD(sts[j]); }
 #pragma unroll
                 for (int j = 0; j < WU; ++j) {
-                    const int i = i0 + 64 * j + lane;
+                    const int i = rows[j];
                     // a state's list = its rows from the list head on (lists are in id order; plan() starts the root
                     // state's list over, which drops that state's older rows)
-                    const bool hit = i < n_nodes && stamps[j] == cur && i >= heads[j] && !(dead[j] & 2);
+                    const bool hit = i0 + 64 * j + lane < n_pos && stamps[j] == cur && i >= heads[j] && !(dead[j] & 2);
                     const unsigned long long bm = __ballot(hit);
                     if (hit) {
                         const int pos = n_d + __popcll(bm & lt);
@@ -968,7 +992,7 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
 int mp_saopd_free(mp_saopd *pl)
 {
     if (!pl) return MP_OK;
-    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->sv, pl->head, pl->tail, pl->queue,
+    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->oldlive, pl->sv, pl->head, pl->tail, pl->queue,
                     pl->stamp, pl->snap_sv, pl->snap_head, pl->snap_tail, pl->snap_stamp, pl->snap_rng, pl->overflow};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -1022,6 +1046,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         MP_TRY(grow_rows(&pl->first_child, o, oc, new_cap, n, pm, st));
         MP_TRY(grow_rows(&pl->reward, o, oc, new_cap, n, pm, st));
         MP_TRY(grow_rows(&pl->done, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(&pl->oldlive, o, oc, new_cap, n, pm, st));
         pl->cap = new_cap;
     }
     // tables with the reference's own operations
@@ -1043,7 +1068,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.gamma = gamma; a.vmax = 1 / (1 - gamma);
     a.rec = pl->model->rec; a.tab = d_tab;
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
-    a.reward = pl->reward; a.done = pl->done; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
+    a.reward = pl->reward; a.done = pl->done; a.oldlive = pl->oldlive; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
     a.stamp = pl->stamp; a.iter_base = pl->iters; a.cap = pl->cap;
     auto lane_scratch = [&]() {
         int v = pl->qcap >> 6;

@@ -39,7 +39,7 @@ def main():
         budget = int(sys.argv[3]) if len(sys.argv) > 3 else 500
         planners = native.StateAwarePlanners(ctx, model, n)
         states = np.random.Generator(np.random.PCG64(3)).integers(0, 100, size=n).astype(np.int32)
-        for rep in range(3):
+        for rep in range(int(os.environ.get("PLANS", "3"))):   # PLANS=12: a longer receding-horizon episode
             t0 = time.perf_counter()
             out = planners.plan(states, budget, 0.8, 0.0, rng, max_plan_len=8)
             dt = time.perf_counter() - t0
