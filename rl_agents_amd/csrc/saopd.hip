@@ -111,6 +111,7 @@ struct SaArgs {
     int sticky;        // 1: a full queue marks the planner failed (asynchronous device mode: no roll-back, no retry)
     int cap;  // wave kernel: node rows allocated per planner
     int scap; // wave kernel: scratch entries per lane in the prune pass (qcap / 64 unless MP_SAOPD_LANE_SCRATCH)
+    int prune_rows; // wave kernel: rows the prune pass takes through its register sets (256; MP_SAOPD_PRUNE_ROWS: test knob)
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
     double gamma, vmax;
     const Rec *rec;
@@ -726,7 +727,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         if (p.prune && p.scap >= 2) {
             int32_t *recs = queue_b; // {row, state} pairs of the rows whose state is dirty
             constexpr int NS = 4; // register sets of 64 rows
-            const int rcap = min(64 * NS, qcap >> 1);
+            const int pcap = (qcap - 64 * NS) >> 1; // pairs that fit in front of the per-state selection area
             int n_d = 0;
             const unsigned long long lt = (1ULL << lane) - 1ULL;
             // scan positions: the listed old rows, then the rows of this plan (root .. n_nodes - 1)
@@ -755,60 +756,151 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                     const unsigned long long bm = __ballot(hit);
                     if (hit) {
                         const int pos = n_d + __popcll(bm & lt);
-                        if (pos < rcap) { recs[2 * pos] = i; recs[2 * pos + 1] = sts[j]; }
+                        if (pos < pcap) { recs[2 * pos] = i; recs[2 * pos + 1] = sts[j]; }
                     }
                     n_d += __popcll(bm);
                 }
             }
 #ifdef MP_PROFILE
-            pf_nd += n_d; pf_fallback += n_d > rcap ? 1 : 0; pf_ndmax = n_d > pf_ndmax ? n_d : pf_ndmax;
+            pf_nd += n_d; pf_fallback += n_d > 64 * NS ? 1 : 0; pf_ndmax = n_d > pf_ndmax ? n_d : pf_ndmax;
 #endif
-            if (n_d <= rcap) {
+            if (n_d <= pcap) {
                 __syncthreads(); // the pairs are read back by other lanes
-                // NS register sets: record lane + 64 q = {state, meta, value}; a record is identified by (set, lane)
-                int rst[NS];
-                uint32_t rmeta[NS];
-                double rval[NS];
-                uint32_t changed = 0;
+                // One group of rows (record j: row id_at(j), state st_at(j), j < cnt <= 64 NS, ascending id) through NS
+                // register sets: record lane + 64 q = {state, meta, value}; a record is identified by (set, lane).
+                auto process = [&](int cnt, auto id_at, auto st_at) {
+                    int rst[NS];
+                    uint32_t rmeta[NS];
+                    double rval[NS];
+                    uint32_t changed = 0;
 #pragma unroll
-                for (int q = 0; q < NS; ++q) {
-                    const int j = lane + 64 * q;
-                    rst[q] = -1; rmeta[q] = 0; rval[q] = ninf;
-                    if (j < n_d) {
-                        const int i = recs[2 * j];
-                        rst[q] = recs[2 * j + 1];
-                        const SaNode nd = load_node(&ND(i));
-                        rmeta[q] = nd.meta;
-                        rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
+                    for (int q = 0; q < NS; ++q) {
+                        const int j = lane + 64 * q;
+                        rst[q] = -1; rmeta[q] = 0; rval[q] = ninf;
+                        if (j < cnt) {
+                            rst[q] = st_at(j);
+                            const SaNode nd = load_node(&ND(id_at(j)));
+                            rmeta[q] = nd.meta;
+                            rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
+                        }
                     }
+                    // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it
+#pragma unroll
+                    for (int q = NS - 1; q >= 0; --q) {
+                        if (64 * q >= cnt) continue;
+                        unsigned long long todo = __ballot(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
+                        while (todo) {
+                            const int l = 63 - __clzll((long long)todo);
+                            todo &= ~(1ULL << l);
+                            const int cs = __builtin_amdgcn_readlane(rst[q], l);
+                            const int cd = (int)(__builtin_amdgcn_readlane((int)rmeta[q], l) & SA_DEPTH);
+                            const double cv = bcast_lane(rval[q], l);
+                            bool dom = false;
+#pragma unroll
+                            for (int t = 0; t < NS; ++t)
+                                dom |= rst[t] == cs && (t != q || lane != l) && rval[t] >= cv && (int)(rmeta[t] & SA_DEPTH) >= cd &&
+                                       (rmeta[t] & (SA_CHILDREN | SA_ALIVE)) != 0;
+                            if (__any(dom) && lane == l) { rmeta[q] &= ~SA_ALIVE; changed |= 1u << q; }
+                        }
+                    }
+#pragma unroll
+                    for (int q = 0; q < NS; ++q)
+                        if (changed & (1u << q)) { // a pruned leaf: not alive, no children -- dead from now on
+                            const int i = id_at(lane + 64 * q);
+                            ND(i).meta = rmeta[q];
+                            p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2);
+                        }
+                };
+                if (n_d <= p.prune_rows) { // the usual case: every changed state at once
+                    process(n_d, [&](int j) { return recs[2 * j]; }, [&](int j) { return recs[2 * j + 1]; });
+                    serial_prune = false;
+                } else {
+                    // long episodes (lists grow with every plan): one changed state per round through the same register
+                    // sets -- its rows are picked out of the pairs in order and marked done; only rows that do not fit the
+                    // scratch buffer take the serial pass
+                    int32_t *sel = recs + 2 * n_d;
+                    const int selcap = ((qcap - 2 * n_d) >> 2) & ~1; // room for {row, meta, value} of one state's rows
+                    // One state with more listed rows than the register sets hold (an agent that stays in a small region
+                    // for many plans): its rows' {meta, value} are computed once into the scratch area and every
+                    // candidate streams them back in coalesced chunks -- still no list walk.
+                    auto process_long = [&](int cnt, int st_u) {
+                        int32_t *mt = sel + selcap;
+                        double *vl = reinterpret_cast<double *>(mt + selcap);
+                        const double svs = SV(st_u);
+                        for (int j = lane; j < cnt; j += 64) {
+                            const SaNode nd = load_node(&ND(sel[j]));
+                            mt[j] = (int32_t)nd.meta;
+                            vl[j] = nd.lower + gpow[nd.meta & SA_DEPTH] * svs;
+                        }
+                        __syncthreads();
+                        for (int c0 = (cnt - 1) & ~63; c0 >= 0; c0 -= 64) {
+                            const int jc = c0 + lane;
+                            const uint32_t mc = jc < cnt ? (uint32_t)mt[jc] : 0u;
+                            const double vc = jc < cnt ? vl[jc] : ninf;
+                            unsigned long long todo = __ballot(jc < cnt && (mc & SA_ALIVE));
+                            while (todo) {
+                                const int l = 63 - __clzll((long long)todo);
+                                todo &= ~(1ULL << l);
+                                const int cd = (int)(__builtin_amdgcn_readlane((int)mc, l) & SA_DEPTH);
+                                const double cv = bcast_lane(vc, l);
+                                bool dom = false;
+                                for (int t0 = 0; t0 < cnt; t0 += 64) {
+                                    const int jt = t0 + lane;
+                                    if (jt < cnt && jt != c0 + l) {
+                                        const uint32_t m2 = (uint32_t)mt[jt];
+                                        dom |= vl[jt] >= cv && (int)(m2 & SA_DEPTH) >= cd && (m2 & (SA_CHILDREN | SA_ALIVE)) != 0;
+                                    }
+                                }
+                                if (__any(dom)) {
+                                    if (lane == l) {
+                                        const uint32_t nm = (uint32_t)mt[jc] & ~SA_ALIVE;
+                                        mt[jc] = (int32_t)nm;
+                                        const int i = sel[jc];
+                                        ND(i).meta = nm;
+                                        p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2);
+                                    }
+                                    __syncthreads(); // later candidates read the flag through memory
+                                }
+                            }
+                        }
+                    };
+                    bool too_long = false;
+                    int start = 0;
+                    for (;;) {
+                        int pj = -1, ps = -1;
+                        for (int j0 = start; j0 < n_d; j0 += 64) {
+                            const int j = j0 + lane;
+                            const int stj = j < n_d ? recs[2 * j + 1] : -1;
+                            const unsigned long long bm = __ballot(stj >= 0);
+                            if (bm) {
+                                const int l = __ffsll((long long)bm) - 1;
+                                pj = j0 + l; ps = __builtin_amdgcn_readlane(stj, l);
+                                break;
+                            }
+                            start = j0 + 64;
+                        }
+                        if (pj < 0) break;
+                        int m = 0;
+                        for (int j0 = pj & ~63; j0 < n_d; j0 += 64) {
+                            const int j = j0 + lane;
+                            const int stj = j < n_d ? recs[2 * j + 1] : -1;
+                            const bool hit = stj == ps;
+                            const unsigned long long bm = __ballot(hit);
+                            if (hit) {
+                                const int pos = m + __popcll(bm & lt);
+                                if (pos < selcap) sel[pos] = recs[2 * j];
+                                recs[2 * j + 1] = -1 - stj;
+                            }
+                            m += __popcll(bm);
+                        }
+                        if (m > selcap) { too_long = true; break; }
+                        __syncthreads();
+                        if (m <= p.prune_rows) process(m, [&](int j) { return sel[j]; }, [&](int) { return ps; });
+                        else process_long(m, ps);
+                        __syncthreads();
+                    }
+                    serial_prune = too_long;
                 }
-                // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it
-#pragma unroll
-                for (int q = NS - 1; q >= 0; --q) {
-                    if (64 * q >= n_d) continue;
-                    unsigned long long todo = __ballot(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
-                    while (todo) {
-                        const int l = 63 - __clzll((long long)todo);
-                        todo &= ~(1ULL << l);
-                        const int cs = __builtin_amdgcn_readlane(rst[q], l);
-                        const int cd = (int)(__builtin_amdgcn_readlane((int)rmeta[q], l) & SA_DEPTH);
-                        const double cv = bcast_lane(rval[q], l);
-                        bool dom = false;
-#pragma unroll
-                        for (int t = 0; t < NS; ++t)
-                            dom |= rst[t] == cs && (t != q || lane != l) && rval[t] >= cv && (int)(rmeta[t] & SA_DEPTH) >= cd &&
-                                   (rmeta[t] & (SA_CHILDREN | SA_ALIVE)) != 0;
-                        if (__any(dom) && lane == l) { rmeta[q] &= ~SA_ALIVE; changed |= 1u << q; }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < NS; ++q)
-                    if (changed & (1u << q)) { // a pruned leaf: not alive, no children -- dead from now on
-                        const int i = recs[2 * (lane + 64 * q)];
-                        ND(i).meta = rmeta[q];
-                        p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2);
-                    }
-                serial_prune = false;
             }
             __syncthreads();
         }
@@ -1079,6 +1171,11 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         return v;
     };
     a.scap = lane_scratch();
+    a.prune_rows = 256;
+    if (const char *e = getenv("MP_SAOPD_PRUNE_ROWS")) { // test knob: 0 = every changed state through the streamed form
+        const int v = atoi(e);
+        a.prune_rows = v < 0 ? 0 : (v > 256 ? 256 : v);
+    }
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
     a.root_state = d_rs;

@@ -489,6 +489,58 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     model.close()
 
 
+@pytest.mark.parametrize("prune_rows", [None, 64, 0])
+@pytest.mark.parametrize("n_states,n_actions,budget", [(2, 3, 420), (3, 2, 500), (6, 4, 480)])
+def test_state_aware_long_lists_vs_oracle(ctx, n_states, n_actions, budget, prune_rows, monkeypatch):
+    """Tiny state spaces over several plans: a state's node list grows to many hundred rows, which takes the prune pass
+    off its register sets (more than 256 rows of changed states -> one state per round; one state with more than 256 rows
+    -> the streamed form).  Every plan, alive flag and state value vs the oracle."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    if prune_rows is not None:   # test knob: fewer rows through the register sets (0: everything through the streamed form)
+        monkeypatch.setenv("MP_SAOPD_PRUNE_ROWS", str(prune_rows))
+    g = np.random.Generator(np.random.PCG64(100 + n_states))
+    t = g.integers(0, n_states, size=(n_states, n_actions), dtype=np.int64)
+    r = np.round(g.random((n_states, n_actions)), 1)
+    term = np.zeros(n_states, bool)
+    n = 24
+    model = ctx.load_table(t, r, term)
+    planners = native.StateAwarePlanners(ctx, model, n)
+    states = g.integers(0, n_states, size=n).astype(np.int32)
+    rng = _rng_states(n, base=99)
+    ref_rng = rng.copy()
+    ref_planner = [None] * n
+    dead = np.zeros(n, bool)
+    compared = 0
+    for step in range(5):
+        out = planners.plan(states, budget, 0.9, 0.0, rng)
+        for i in range(n):
+            if dead[i]:
+                continue
+            try:
+                o = oracle.saopd_plan(t, r, term, int(states[i]), budget, 0.9, rng_state=ref_rng[i], planner=ref_planner[i],
+                                      max_plan_len=budget + 1)
+            except ValueError:
+                assert out["status"][i] == native.MP_ERR_ARG, (step, i)
+                dead[i] = True
+                continue
+            assert out["status"][i] == 0, (step, i)
+            np.testing.assert_array_equal(out["plans"][i, :out["plan_len"][i]], o["plan"], err_msg=str((step, i)))
+            assert out["env_steps"][i] == o["env_steps"] and out["updates"][i] == o["updates"], (step, i)
+            np.testing.assert_array_equal(rng[i], o["rng_after"])
+            ref_rng[i], ref_planner[i] = o["rng_after"], o["planner"]
+            if i % 5 == 0:
+                tree, sv = planners.export(i)
+                assert np.array_equal(sv, o["state_values"]), (step, i)
+                for k in ("parent", "first_child", "state", "depth", "lower", "reward", "alive", "count"):
+                    assert np.array_equal(tree[k], o["tree"][k]), (step, i, k)
+            compared += 1
+        states = np.where(out["plan_len"] > 0, t[states, np.maximum(out["plans"][:, 0], 0)], states).astype(np.int32)
+    assert compared > 40
+    planners.close()
+    model.close()
+
+
 def test_state_aware_queue_overflow_is_reported(ctx, monkeypatch):
     """A backup queue that is too small is a per-planner MP_ERR_ALLOC status, not a silent truncation."""
     from rl_agents_amd import native
