@@ -1,0 +1,53 @@
+"""Wall time of one agent.act() -- what a user of the reference's agents sees per environment step -- on the bench
+tables: MCTSAgent (budget 1000), DeterministicPlannerAgent (budget 5000), StateAwarePlannerAgent (GridWorld config,
+budget 500), ValueIterationAgent (S = 10 000).  The reference's own Python times are in profiles/reference_cpu.json.
+
+    python tools/agent_latency.py
+"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from rl_agents_amd.agents.common.factory import agent_factory  # noqa: E402
+from rl_agents_amd.envs import FiniteMDPEnv, generators  # noqa: E402
+
+P = "rl_agents_amd.agents."
+CASES = [
+    ("MCTSAgent budget 1000", generators.highway_shaped(10, 10, 100, seed=0),
+     dict(__class__="<class '%stree_search.mcts.MCTSAgent'>" % P, budget=1000, gamma=0.8, horizon=30, episodes=33)),
+    ("DeterministicPlannerAgent budget 5000", generators.highway_shaped(10, 10, 100, seed=0),
+     dict(__class__="<class '%stree_search.deterministic.DeterministicPlannerAgent'>" % P, budget=5000, gamma=0.8)),
+    ("StateAwarePlannerAgent budget 500", generators.gridworld(),
+     dict(__class__="<class '%stree_search.state_aware.StateAwarePlannerAgent'>" % P, budget=500, gamma=0.8)),
+    ("ValueIterationAgent S=10000", generators.highway_shaped(10, 10, 100, seed=0),
+     dict(__class__="<class '%sdynamic_programming.value_iteration.ValueIterationAgent'>" % P, gamma=0.95, iterations=200)),
+]
+
+
+def main():
+    for name, cfg, agent_cfg in CASES:
+        env = FiniteMDPEnv(dict(mode="deterministic", transition=cfg["transition"], reward=cfg["reward"],
+                                terminal=cfg["terminal"]))
+        obs = env.reset()
+        obs = obs[0] if isinstance(obs, tuple) else obs
+        agent = agent_factory(env, agent_cfg)
+        agent.seed(0)
+        times = []
+        for step in range(12):
+            t0 = time.perf_counter()
+            action = agent.act(obs)
+            times.append(1e3 * (time.perf_counter() - t0))
+            out = env.step(action)
+            obs, done = out[0], bool(out[2]) or (len(out) > 4 and bool(out[3]))
+            if done:
+                obs = env.reset()
+                obs = obs[0] if isinstance(obs, tuple) else obs
+        print("{:42s} act(): first {:8.2f} ms, then median {:7.2f} ms (min {:.2f})".format(
+            name, times[0], float(np.median(times[1:])), min(times[1:])), flush=True)
+
+
+if __name__ == "__main__":
+    main()
