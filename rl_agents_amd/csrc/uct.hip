@@ -160,7 +160,11 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 // reached / acted from ride in bits 8-15 / 16-23 of the fused records' flags word, so the descent always knows the mask
 // of the state it is in without another gather; len(children) in the exploration term is the mask's population count.
 template <int AT, int ENV, bool SP = false, bool MK = false, int IL = 0>
-__global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64, ENV == ENV_TABLE_LDS ? 1 : MP_UCT_MIN_WAVES) void uct_kernel(UctArgs p)
+// Per-state-policy kernels with |A| <= 5 are held to the registers of 4 waves per SIMD (they would take 134-140 VGPRs = 3
+// waves; TA 52 %, VALU 45 %, L1 28 % busy: latency-bound -- 2.14 -> 1.91 ms at 262 144 roots with the fourth wave).
+__global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64,
+                             ENV == ENV_TABLE_LDS ? 1 : (SP && AT > 0 && AT <= 5 && MP_UCT_MIN_WAVES < 4 ? 4 : MP_UCT_MIN_WAVES))
+void uct_kernel(UctArgs p)
 {
     static_assert(!SP || (AT > 0 && ENV == ENV_TABLE), "per-state policies: table env, |A| known at compile time");
     static_assert(!MK || SP, "listed policies are per-state policies");
