@@ -85,6 +85,10 @@ struct mp_saopd {
     double *reward = nullptr;
     uint8_t *done = nullptr;
     int32_t *oldlive = nullptr; // wave kernel: ids of the rows of earlier plans that have children (rebuilt by every plan)
+    // wave kernel: every state's node list again as chunks of 15 ids + link (16 ints), rebuilt from the linked lists by every
+    // plan and kept up to date by its appends: the backup reads a popped state's list 15 neighbours per load
+    int32_t *lcount = nullptr, *lhead = nullptr, *ltail = nullptr, *lpool = nullptr; // [n][S] x 3, [n][pool_ints]
+    long pool_ints = 0;
     double *sv = nullptr;
     int32_t *head = nullptr, *tail = nullptr, *queue = nullptr, *stamp = nullptr;
     int iters = 0;      // iterations run so far (stamps are unique across plans)
@@ -123,6 +127,8 @@ struct SaArgs {
     double *reward;
     uint8_t *done;
     int32_t *oldlive; // [planner][cap] scratch of the wave kernel's prune scan
+    int32_t *lcount, *lhead, *ltail, *lpool; // chunked per-state lists (wave kernel)
+    long pool_ints;
     double *sv;
     int32_t *head, *tail, *queue, *stamp;
     int32_t *plans, *plan_len, *status;
@@ -544,6 +550,41 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         }
         __syncthreads();
     }
+    // Every state's node list a second time as CHUNKS of 15 ids + a link (16 ints = one 64-byte line): the backup below
+    // reads a popped state's list 15 neighbours per load and evaluates their parents' backups in 15 lanes at once,
+    // instead of chasing next_same one element per dependent round trip.  The linked lists stay the authority (the
+    // other passes, the lane kernel and the roll-back use them): the chunks are rebuilt from them here, by every plan,
+    // and kept up to date by this plan's appends.
+    constexpr int CH = 15;
+    const bool par_backup = A <= 32; // the parallel backup: a group of |A| lanes per list element, at least two groups
+    int32_t *lc_b = p.lcount + sb, *lh_b = p.lhead + sb, *lt_b = p.ltail + sb, *pool_b = p.lpool + (long)r * p.pool_ints;
+    auto PL = [&](int chunk, int f) -> int32_t & { return pool_b[(chunk << 4) + f]; };
+    int pool_top = 0;
+    if (par_backup) {
+        // one walk per state, the states spread over the lanes; chunks are handed out by a counter in LDS (the 512 bytes
+        // after the tables), so a state's chunks need not be adjacent -- they are linked
+        int *ctr = reinterpret_cast<int *>(lds_d + ntab);
+        if (l0) *ctr = 0;
+        __syncthreads();
+        for (int s = lane; s < p.S; s += 64) {
+            int c = 0, chunk = -1, kq = CH;
+            int first = -1;
+            for (int i = HD(s); i >= 0; i = ND(i).next_same) {
+                if (kq == CH) {
+                    const int nc = atomicAdd(ctr, 1);
+                    if (chunk >= 0) PL(chunk, CH) = nc; else first = nc;
+                    chunk = nc; kq = 0;
+                }
+                PL(chunk, kq) = i;
+                ++kq; ++c;
+            }
+            if (chunk >= 0) PL(chunk, CH) = -1;
+            lc_b[s] = c; lh_b[s] = first; lt_b[s] = chunk;
+        }
+        __syncthreads();
+        pool_top = *ctr;
+        __syncthreads();
+    }
     int n_nodes = root + 1;
     int status = MP_OK;
     long steps_taken = 0, updates = 0;
@@ -627,6 +668,21 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                 SM(s) = cur; // the state's list changed in this iteration: its leaves are prune candidates
                 if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
             }
+            if (par_backup) { // the same append on the chunked list
+                const int cnt = lc_b[s], tl = lt_b[s];
+                const bool fresh_chunk = cnt % CH == 0;
+                const int chunk = fresh_chunk ? pool_top : tl;
+                if (l0) {
+                    if (fresh_chunk) {
+                        if (cnt == 0) lh_b[s] = chunk; else PL(tl, CH) = chunk;
+                        lt_b[s] = chunk;
+                        PL(chunk, CH) = -1;
+                    }
+                    PL(chunk, cnt % CH) = c;
+                    lc_b[s] = cnt + 1;
+                }
+                pool_top += fresh_chunk ? 1 : 0;
+            }
             SA_ORDER();
         }
         n_nodes += A;
@@ -638,70 +694,186 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             if (l0) QD4(qt) = make_int4(-1, leaf, 0, 0);
             ++qt;
             SA_ORDER();
-            int src = -1, nbr = -1;
-            double src_delta = 0.0;
-            // The walk of a popped state's list is software-pipelined: the record and the parent of the NEXT list element
-            // are requested as soon as the current element's link is known, so they arrive while the current element's
-            // backup (two more round trips) is in flight.  Nothing the backup writes (state values, stamps, queue) is
-            // part of a node record, so the early read sees what a late one would.
-            SaNode nd_nbr;
-            nd_nbr.lower = 0.0; nd_nbr.next_same = -1; nd_nbr.meta = 0;
-            int par_nbr = -1;
-            while ((nbr >= 0 || qh != qt) && status == MP_OK) {
-                int node = -1, group = -1; // group: first child of `node` when it is known without reading FC(node)
-                if (nbr < 0) { // front descriptor
-                    const int4 dq = QD4(qh);
-                    const int32_t ds = dq.x;
-                    src = dq.y;
-                    if (ds < 0) {
-                        node = src;
-                    } else {
-                        src_delta = __hiloint2double(dq.w, dq.z);
-                        nbr = HD(ds);
+            if (!par_backup) {
+                int src = -1, nbr = -1;
+                double src_delta = 0.0;
+                // The walk of a popped state's list is software-pipelined: the record and the parent of the NEXT list element
+                // are requested as soon as the current element's link is known, so they arrive while the current element's
+                // backup (two more round trips) is in flight.  Nothing the backup writes (state values, stamps, queue) is
+                // part of a node record, so the early read sees what a late one would.
+                SaNode nd_nbr;
+                nd_nbr.lower = 0.0; nd_nbr.next_same = -1; nd_nbr.meta = 0;
+                int par_nbr = -1;
+                while ((nbr >= 0 || qh != qt) && status == MP_OK) {
+                    int node = -1, group = -1; // group: first child of `node` when it is known without reading FC(node)
+                    if (nbr < 0) { // front descriptor
+                        const int4 dq = QD4(qh);
+                        const int32_t ds = dq.x;
+                        src = dq.y;
+                        if (ds < 0) {
+                            node = src;
+                        } else {
+                            src_delta = __hiloint2double(dq.w, dq.z);
+                            nbr = HD(ds);
+                            if (nbr >= 0) { nd_nbr = load_node(&ND(nbr)); par_nbr = PA(nbr); }
+                        }
+                        ++qh;
+                    } else {       // one neighbour
+                        const SaNode nd = nd_nbr;
+                        const int par = par_nbr;
+                        if (par >= 0 && (nbr == src || p.backup_aggregated) && src_delta > acc[nd.meta & SA_DEPTH]) {
+                            node = par;
+                            group = nbr - (int)((nd.meta & SA_ACT) >> SA_ACT_SHIFT); // the siblings of nbr = the children of par
+                        }
+                        nbr = nd.next_same;
                         if (nbr >= 0) { nd_nbr = load_node(&ND(nbr)); par_nbr = PA(nbr); }
                     }
-                    ++qh;
-                } else {       // one neighbour
-                    const SaNode nd = nd_nbr;
-                    const int par = par_nbr;
-                    if (par >= 0 && (nbr == src || p.backup_aggregated) && src_delta > acc[nd.meta & SA_DEPTH]) {
-                        node = par;
-                        group = nbr - (int)((nd.meta & SA_ACT) >> SA_ACT_SHIFT); // the siblings of nbr = the children of par
+                    if (node < 0) continue;
+                    const int32_t sn = ST(node);
+                    const int fc = group >= 0 ? group : FC(node);
+                    if (fc >= 0) {
+                        double u = ninf, bk = 0.0;
+                        int a_id = 0x7fffffff;
+                        if (lane < A) {
+                            const int c = fc + lane;
+                            const SaNode nd = load_node(&ND(c));
+                            const double svc = SV(ST(c));
+                            u = nd.lower + gpow[nd.meta & SA_DEPTH] * svc;
+                            bk = RW(c) + p.gamma * svc;
+                            a_id = lane;
+                        }
+                        const double old = SV(sn); // (requested with the children's values, not after the argmax)
+                        if (A <= 16) row0_argmax(u, a_id); else wave_argmax(u, a_id); // first maximal U in action order
+                        const double backup = __shfl(bk, a_id);
+                        const double delta = old - backup;
+                        ++updates;
+                        if (delta > 0.0) {
+                            if (qt - qh >= dcap) {
+                                status = MP_ERR_ALLOC;
+                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = 1; }
+                                break;
+                            }
+                            if (l0) {
+                                SV(sn) = backup; SM(sn) = cur;
+                                QD4(qt) = make_int4(sn, node, __double2loint(delta), __double2hiint(delta));
+                            }
+                            ++qt;
+                            SA_ORDER();
+                        }
                     }
-                    nbr = nd.next_same;
-                    if (nbr >= 0) { nd_nbr = load_node(&ND(nbr)); par_nbr = PA(nbr); }
                 }
-                if (node < 0) continue;
-                const int32_t sn = ST(node);
-                const int fc = group >= 0 ? group : FC(node);
-                if (fc >= 0) {
-                    double u = ninf, bk = 0.0;
-                    int a_id = 0x7fffffff;
-                    if (lane < A) {
-                        const int c = fc + lane;
-                        const SaNode nd = load_node(&ND(c));
-                        const double svc = SV(ST(c));
-                        u = nd.lower + gpow[nd.meta & SA_DEPTH] * svc;
-                        bk = RW(c) + p.gamma * svc;
-                        a_id = lane;
+        
+            } else {
+                // ---- the backups of a popped state's neighbours, up to 64 / |A| at a time.  PARALLEL: a GROUP of |A| lanes takes
+                // one list element -- all of them its record, its parent and the parent state's value (one line each per
+                // group), lane a of the group child a of the parent (sibling group of the element: record, state, that
+                // state's value, reward) -- and the group computes the parent's Bellman backup from the state values as
+                // they are NOW: eight vector-memory instructions serve 12-16 neighbours where the element-by-element
+                // loop issued eight per neighbour.  SEQUENTIAL, in list order: compare with the parent state's value,
+                // count, write and push as the reference does.  A write changes ONE state value; it reaches a later group
+                // either as its `old` (same parent state: patched in the register) or through one of its children's states
+                // (each lane keeps its child's state: the group is re-evaluated when its turn comes).  Nothing else the
+                // evaluation reads changes during a backup (node records, lists), so every group's numbers are those of
+                // the reference's turn-by-turn loop.
+                const int my_g = lane / A, my_a = lane - my_g * A, npp = 64 / A; // group, action, groups per pass
+                const int g_lead = my_g * A;
+                int v_node = -1, v_sn = -1, v_sc = -1;
+                double v_old = 0.0, v_backup = 0.0;
+                bool v_cond = false;
+                // node_given >= 0: the descriptor names the node itself (the expanded leaf); otherwise the node is the parent
+                // of list element `nbr`.  Every lane of a taking group runs this with the same nbr.
+                auto eval = [&](bool mine, int nbr, int node_given, int src_, double src_delta_) {
+                    if (!mine) return;
+                    int node_ = node_given, fc = -1;
+                    v_cond = false;
+                    if (node_given >= 0) {
+                        fc = FC(node_given);
+                    } else {
+                        const SaNode nd = load_node(&ND(nbr));
+                        const int par = PA(nbr);
+                        if (par >= 0 && (nbr == src_ || p.backup_aggregated) && src_delta_ > acc[nd.meta & SA_DEPTH]) {
+                            node_ = par;
+                            fc = nbr - (int)((nd.meta & SA_ACT) >> SA_ACT_SHIFT); // the siblings of nbr = the children of par
+                        }
                     }
-                    const double old = SV(sn); // (requested with the children's values, not after the argmax)
-                    if (A <= 16) row0_argmax(u, a_id); else wave_argmax(u, a_id); // first maximal U in action order
-                    const double backup = __shfl(bk, a_id);
-                    const double delta = old - backup;
-                    ++updates;
-                    if (delta > 0.0) {
-                        if (qt - qh >= dcap) {
-                            status = MP_ERR_ALLOC;
-                            if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = 1; }
-                            break;
+                    if (node_ < 0 || fc < 0) return;
+                    v_cond = true;
+                    v_node = node_;
+                    v_sn = ST(node_);
+                    v_old = SV(v_sn);
+                    const int c = fc + my_a;
+                    const SaNode cd = load_node(&ND(c));
+                    v_sc = ST(c);
+                    const double svc = SV(v_sc);
+                    const double u = cd.lower + gpow[cd.meta & SA_DEPTH] * svc;
+                    const double bk = RW(c) + p.gamma * svc;
+                    double bu = ninf, bkb = 0.0; // first maximal U in action order, over the lanes of the group
+                    for (int q = 0; q < A; ++q) {
+                        const double uq = __shfl(u, g_lead + q), bq = __shfl(bk, g_lead + q);
+                        if (q == 0 || uq > bu) { bu = uq; bkb = bq; }
+                    }
+                    v_backup = bkb;
+                };
+                // the sequential half over the group leaders in `todo` (ascending = list order)
+                auto apply = [&](unsigned long long todo, int src_, double src_delta_, int my_nbr) {
+                    unsigned long long dirty = 0ULL;
+                    const unsigned long long gmask = (A == 64 ? ~0ULL : ((1ULL << A) - 1ULL));
+                    while (todo && status == MP_OK) {
+                        const int j = __ffsll((long long)todo) - 1; // the group's first lane
+                        todo &= todo - 1;
+                        if (dirty & (gmask << j)) eval(lane >= j && lane < j + A, my_nbr, -1, src_, src_delta_); // a child's state value moved
+                        const double backup = bcast_lane(v_backup, j), old = bcast_lane(v_old, j);
+                        const int sn = __builtin_amdgcn_readlane(v_sn, j), node = __builtin_amdgcn_readlane(v_node, j);
+                        const double delta = old - backup;
+                        ++updates;
+                        if (delta > 0.0) {
+                            if (qt - qh >= dcap) {
+                                status = MP_ERR_ALLOC;
+                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = 1; }
+                                break;
+                            }
+                            if (l0) {
+                                SV(sn) = backup; SM(sn) = cur;
+                                QD4(qt) = make_int4(sn, node, __double2loint(delta), __double2hiint(delta));
+                            }
+                            ++qt;
+                            SA_ORDER();
+                            bool hit = false;
+                            if (v_cond && lane >= j + A) {
+                                if (v_sn == sn) v_old = backup;
+                                hit = v_sc == sn;
+                            }
+                            dirty |= __ballot(hit);
                         }
-                        if (l0) {
-                            SV(sn) = backup; SM(sn) = cur;
-                            QD4(qt) = make_int4(sn, node, __double2loint(delta), __double2hiint(delta));
+                    }
+                };
+                while (qh != qt && status == MP_OK) {
+                    const int4 dq = QD4(qh);
+                    ++qh;
+                    if (dq.x < 0) { // the expanded leaf itself: group 0
+                        v_cond = false;
+                        eval(my_g == 0, -1, dq.y, -1, 0.0);
+                        apply(__ballot(lane == 0 && v_cond), -1, 0.0, -1);
+                        continue;
+                    }
+                    const int src_ = dq.y;
+                    const double src_delta_ = __hiloint2double(dq.w, dq.z);
+                    int remaining = lc_b[dq.x];
+                    int w = (remaining > 0 && lane <= CH) ? PL(lh_b[dq.x], lane) : -1; // 15 ids + the link in one 64-byte read
+                    while (remaining > 0 && status == MP_OK) {
+                        const int here = remaining < CH ? remaining : CH;
+                        const int nxt = __builtin_amdgcn_readlane(w, CH);
+                        const int w_now = w;
+                        remaining -= here;
+                        if (remaining > 0) w = lane <= CH ? PL(nxt, lane) : -1; // the next chunk arrives under this one's work
+                        for (int t0 = 0; t0 < here && status == MP_OK; t0 += npp) {
+                            const int t = t0 + my_g;
+                            const int nb_t = __shfl(w_now, t & 63);
+                            const int my_nbr = (my_g < npp && t < here) ? nb_t : -1;
+                            v_cond = false;
+                            eval(my_nbr >= 0, my_nbr, -1, src_, src_delta_);
+                            apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr);
                         }
-                        ++qt;
-                        SA_ORDER();
                     }
                 }
             }
@@ -1069,7 +1241,8 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
         hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess ||
         hipMalloc(&pl->snap_sv, sn * 8) != hipSuccess || hipMalloc(&pl->snap_head, sn * 4) != hipSuccess ||
         hipMalloc(&pl->snap_tail, sn * 4) != hipSuccess || hipMalloc(&pl->snap_stamp, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess) {
+        hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess ||
+        hipMalloc(&pl->lcount, sn * 4) != hipSuccess || hipMalloc(&pl->lhead, sn * 4) != hipSuccess || hipMalloc(&pl->ltail, sn * 4) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
     }
@@ -1084,7 +1257,7 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
 int mp_saopd_free(mp_saopd *pl)
 {
     if (!pl) return MP_OK;
-    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->oldlive, pl->sv, pl->head, pl->tail, pl->queue,
+    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->oldlive, pl->lcount, pl->lhead, pl->ltail, pl->lpool, pl->sv, pl->head, pl->tail, pl->queue,
                     pl->stamp, pl->snap_sv, pl->snap_head, pl->snap_tail, pl->snap_stamp, pl->snap_rng, pl->overflow};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -1141,6 +1314,16 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         MP_TRY(grow_rows(&pl->oldlive, o, oc, new_cap, n, pm, st));
         pl->cap = new_cap;
     }
+    {   // chunk pool: at most one partly filled chunk per non-empty state, contents rebuilt by every plan (nothing to keep)
+        const long states = pl->S < pl->cap ? pl->S : pl->cap;
+        const long want = 16L * (states + pl->cap / 15 + 2);
+        if (want > pl->pool_ints) {
+            if (pl->lpool) { MP_HIP(hipStreamSynchronize(st)); MP_HIP(hipFree(pl->lpool)); pl->lpool = nullptr; }
+            if (hipMalloc(&pl->lpool, (size_t)n * want * 4) != hipSuccess)
+                return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the state-list chunks", (size_t)n * want * 4);
+            pl->pool_ints = want;
+        }
+    }
     // tables with the reference's own operations
     std::vector<double> tab((size_t)3 * (K + 3));
     double *gpow = tab.data(), *trg = gpow + (K + 3), *acc = trg + (K + 3);
@@ -1160,7 +1343,8 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.gamma = gamma; a.vmax = 1 / (1 - gamma);
     a.rec = pl->model->rec; a.tab = d_tab;
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
-    a.reward = pl->reward; a.done = pl->done; a.oldlive = pl->oldlive; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
+    a.reward = pl->reward; a.done = pl->done; a.oldlive = pl->oldlive; a.lcount = pl->lcount; a.lhead = pl->lhead; a.ltail = pl->ltail;
+    a.lpool = pl->lpool; a.pool_ints = pl->pool_ints; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
     a.stamp = pl->stamp; a.iter_base = pl->iters; a.cap = pl->cap;
     auto lane_scratch = [&]() {
         int v = pl->qcap >> 6;
