@@ -590,7 +590,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     long steps_taken = 0, updates = 0;
 #ifdef MP_PROFILE
     long long t_ph[5] = {0, 0, 0, 0, 0}, t_mark = clock64();
-    long pf_nd = 0; int pf_fallback = 0, pf_ndmax = 0;
+    long pf_nd = 0; int pf_fallback = 0, pf_ndmax = 0; long pf_reval = 0, pf_pass = 0, pf_pops = 0;
 #define SA_PROF(i) do { const long long t_now = clock64(); t_ph[i] += t_now - t_mark; t_mark = t_now; } while (0)
 #else
 #define SA_PROF(i)
@@ -821,7 +821,12 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                     while (todo && status == MP_OK) {
                         const int j = __ffsll((long long)todo) - 1; // the group's first lane
                         todo &= todo - 1;
-                        if (dirty & (gmask << j)) eval(lane >= j && lane < j + A, my_nbr, -1, src_, src_delta_); // a child's state value moved
+                        if (dirty & (gmask << j)) {
+                            eval(lane >= j && lane < j + A, my_nbr, -1, src_, src_delta_); // a child's state value moved
+#ifdef MP_PROFILE
+                            ++pf_reval;
+#endif
+                        }
                         const double backup = bcast_lane(v_backup, j), old = bcast_lane(v_old, j);
                         const int sn = __builtin_amdgcn_readlane(v_sn, j), node = __builtin_amdgcn_readlane(v_node, j);
                         const double delta = old - backup;
@@ -871,6 +876,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                             const int nb_t = __shfl(w_now, t & 63);
                             const int my_nbr = (my_g < npp && t < here) ? nb_t : -1;
                             v_cond = false;
+#ifdef MP_PROFILE
+                            ++pf_pass;
+#endif
                             eval(my_nbr >= 0, my_nbr, -1, src_, src_delta_);
                             apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr);
                         }
@@ -1127,6 +1135,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     if (r == 0 && l0)
         printf("saopd prof planner0: leaf-scan %lld  expand+append %lld  backup %lld  prune %lld  other %lld (clock64 ticks), nodes %d..%d\n",
                t_ph[0], t_ph[1], t_ph[2], t_ph[3], t_ph[4], root, n_nodes);
+    if (r == 0 && l0) printf("saopd prof planner0: backup passes %ld, re-evaluated groups %ld, updates %ld\n", pf_pass, pf_reval, updates);
     if (r == 0 && l0) printf("saopd prof planner0: rows of dirty states %ld over %d iterations (max %d), serial fallbacks %d\n", pf_nd, p.K, pf_ndmax, pf_fallback);
 #endif
     // ---- get_plan, twice (see saopd_kernel), uniform
