@@ -489,6 +489,50 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     model.close()
 
 
+@pytest.mark.parametrize("n_actions", [9, 16, 33, 40])
+def test_state_aware_many_actions_vs_oracle(ctx, n_actions):
+    """|A| from 9 to 40: the grouped parallel backup runs 7, 4 and (|A| > 32) no groups per pass -- the last is the
+    element-by-element loop."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    g = np.random.Generator(np.random.PCG64(300 + n_actions))
+    n_states = 14
+    t = g.integers(0, n_states, size=(n_states, n_actions), dtype=np.int64)
+    r = np.round(g.random((n_states, n_actions)), 2)
+    term = g.random(n_states) < 0.1
+    n, budget = 20, 12 * n_actions
+    model = ctx.load_table(t, r, term)
+    planners = native.StateAwarePlanners(ctx, model, n)
+    states = g.integers(0, n_states, size=n).astype(np.int32)
+    rng = _rng_states(n, base=31)
+    ref_rng = rng.copy()
+    ref_planner = [None] * n
+    dead = np.zeros(n, bool)
+    compared = 0
+    for step in range(3):
+        out = planners.plan(states, budget, 0.85, 0.0, rng)
+        for i in range(n):
+            if dead[i]:
+                continue
+            try:
+                o = oracle.saopd_plan(t, r, term, int(states[i]), budget, 0.85, rng_state=ref_rng[i], planner=ref_planner[i],
+                                      max_plan_len=budget + 1)
+            except ValueError:
+                assert out["status"][i] == native.MP_ERR_ARG, (step, i)
+                dead[i] = True
+                continue
+            assert out["status"][i] == 0, (step, i)
+            np.testing.assert_array_equal(out["plans"][i, :out["plan_len"][i]], o["plan"], err_msg=str((step, i)))
+            assert out["env_steps"][i] == o["env_steps"] and out["updates"][i] == o["updates"], (step, i)
+            np.testing.assert_array_equal(rng[i], o["rng_after"])
+            ref_rng[i], ref_planner[i] = o["rng_after"], o["planner"]
+            compared += 1
+        states = np.where(out["plan_len"] > 0, t[states, np.maximum(out["plans"][:, 0], 0)], states).astype(np.int32)
+    assert compared > 20
+    planners.close()
+    model.close()
+
+
 @pytest.mark.parametrize("prune_rows", [None, 64, 0])
 @pytest.mark.parametrize("n_states,n_actions,budget", [(2, 3, 420), (3, 2, 500), (6, 4, 480)])
 def test_state_aware_long_lists_vs_oracle(ctx, n_states, n_actions, budget, prune_rows, monkeypatch):
