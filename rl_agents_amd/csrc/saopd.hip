@@ -87,7 +87,8 @@ struct mp_saopd {
     int32_t *oldlive = nullptr; // wave kernel: ids of the rows of earlier plans that have children (rebuilt by every plan)
     // wave kernel: every state's node list again as chunks of 15 ids + link (16 ints), rebuilt from the linked lists by every
     // plan and kept up to date by its appends: the backup reads a popped state's list 15 neighbours per load
-    int32_t *lcount = nullptr, *lhead = nullptr, *ltail = nullptr, *lpool = nullptr; // [n][S] x 3, [n][pool_ints]
+    int4 *lstate = nullptr;     // [n][S] {count, head chunk, tail chunk, -}
+    int32_t *lpool = nullptr;   // [n][pool_ints]
     long pool_ints = 0;
     double *sv = nullptr;
     int32_t *head = nullptr, *tail = nullptr, *queue = nullptr, *stamp = nullptr;
@@ -127,7 +128,8 @@ struct SaArgs {
     double *reward;
     uint8_t *done;
     int32_t *oldlive; // [planner][cap] scratch of the wave kernel's prune scan
-    int32_t *lcount, *lhead, *ltail, *lpool; // chunked per-state lists (wave kernel)
+    int4 *lstate;     // chunked per-state lists (wave kernel): {count, head chunk, tail chunk, -} per state
+    int32_t *lpool;
     long pool_ints;
     double *sv;
     int32_t *head, *tail, *queue, *stamp;
@@ -557,7 +559,8 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     // and kept up to date by this plan's appends.
     constexpr int CH = 15;
     const bool par_backup = A <= 32; // the parallel backup: a group of |A| lanes per list element, at least two groups
-    int32_t *lc_b = p.lcount + sb, *lh_b = p.lhead + sb, *lt_b = p.ltail + sb, *pool_b = p.lpool + (long)r * p.pool_ints;
+    int4 *ls_b = p.lstate + sb; // one 16-byte record per state: one load / one store where three arrays took three
+    int32_t *pool_b = p.lpool + (long)r * p.pool_ints;
     auto PL = [&](int chunk, int f) -> int32_t & { return pool_b[(chunk << 4) + f]; };
     int pool_top = 0;
     if (par_backup) {
@@ -579,7 +582,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                 ++kq; ++c;
             }
             if (chunk >= 0) PL(chunk, CH) = -1;
-            lc_b[s] = c; lh_b[s] = first; lt_b[s] = chunk;
+            ls_b[s] = make_int4(c, first, chunk, 0);
         }
         __syncthreads();
         pool_top = *ctr;
@@ -669,17 +672,17 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                 if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
             }
             if (par_backup) { // the same append on the chunked list
-                const int cnt = lc_b[s], tl = lt_b[s];
+                const int4 ls = ls_b[s];
+                const int cnt = ls.x, tl = ls.z;
                 const bool fresh_chunk = cnt % CH == 0;
                 const int chunk = fresh_chunk ? pool_top : tl;
                 if (l0) {
                     if (fresh_chunk) {
-                        if (cnt == 0) lh_b[s] = chunk; else PL(tl, CH) = chunk;
-                        lt_b[s] = chunk;
+                        if (cnt != 0) PL(tl, CH) = chunk;
                         PL(chunk, CH) = -1;
                     }
                     PL(chunk, cnt % CH) = c;
-                    lc_b[s] = cnt + 1;
+                    ls_b[s] = make_int4(cnt + 1, cnt == 0 ? chunk : ls.y, chunk, 0);
                 }
                 pool_top += fresh_chunk ? 1 : 0;
             }
@@ -863,8 +866,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                     }
                     const int src_ = dq.y;
                     const double src_delta_ = __hiloint2double(dq.w, dq.z);
-                    int remaining = lc_b[dq.x];
-                    int w = (remaining > 0 && lane <= CH) ? PL(lh_b[dq.x], lane) : -1; // 15 ids + the link in one 64-byte read
+                    const int4 ls = ls_b[dq.x];
+                    int remaining = ls.x;
+                    int w = (remaining > 0 && lane <= CH) ? PL(ls.y, lane) : -1; // 15 ids + the link in one 64-byte read
                     while (remaining > 0 && status == MP_OK) {
                         const int here = remaining < CH ? remaining : CH;
                         const int nxt = __builtin_amdgcn_readlane(w, CH);
@@ -1251,7 +1255,7 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
         hipMalloc(&pl->snap_sv, sn * 8) != hipSuccess || hipMalloc(&pl->snap_head, sn * 4) != hipSuccess ||
         hipMalloc(&pl->snap_tail, sn * 4) != hipSuccess || hipMalloc(&pl->snap_stamp, sn * 4) != hipSuccess ||
         hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess ||
-        hipMalloc(&pl->lcount, sn * 4) != hipSuccess || hipMalloc(&pl->lhead, sn * 4) != hipSuccess || hipMalloc(&pl->ltail, sn * 4) != hipSuccess) {
+        hipMalloc(&pl->lstate, sn * 16) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
     }
@@ -1266,7 +1270,7 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
 int mp_saopd_free(mp_saopd *pl)
 {
     if (!pl) return MP_OK;
-    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->oldlive, pl->lcount, pl->lhead, pl->ltail, pl->lpool, pl->sv, pl->head, pl->tail, pl->queue,
+    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->oldlive, pl->lstate, pl->lpool, pl->sv, pl->head, pl->tail, pl->queue,
                     pl->stamp, pl->snap_sv, pl->snap_head, pl->snap_tail, pl->snap_stamp, pl->snap_rng, pl->overflow};
     for (void *b : bufs)
         if (b) (void)hipFree(b);
@@ -1352,7 +1356,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     a.gamma = gamma; a.vmax = 1 / (1 - gamma);
     a.rec = pl->model->rec; a.tab = d_tab;
     a.node = pl->node; a.state = pl->state; a.parent = pl->parent; a.first_child = pl->first_child;
-    a.reward = pl->reward; a.done = pl->done; a.oldlive = pl->oldlive; a.lcount = pl->lcount; a.lhead = pl->lhead; a.ltail = pl->ltail;
+    a.reward = pl->reward; a.done = pl->done; a.oldlive = pl->oldlive; a.lstate = pl->lstate;
     a.lpool = pl->lpool; a.pool_ints = pl->pool_ints; a.sv = pl->sv; a.head = pl->head; a.tail = pl->tail; a.queue = pl->queue;
     a.stamp = pl->stamp; a.iter_base = pl->iters; a.cap = pl->cap;
     auto lane_scratch = [&]() {
