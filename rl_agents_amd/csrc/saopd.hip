@@ -117,6 +117,7 @@ struct SaArgs {
     int cap;  // wave kernel: node rows allocated per planner
     int scap; // wave kernel: scratch entries per lane in the prune pass (qcap / 64 unless MP_SAOPD_LANE_SCRATCH)
     int prune_rows; // wave kernel: rows the prune pass takes through its register sets (256; MP_SAOPD_PRUNE_ROWS: test knob)
+    int par_backup; // wave kernel: 1 = grouped parallel backup over chunked state lists (host: the first plan of fresh planners)
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
     double gamma, vmax;
     const Rec *rec;
@@ -558,7 +559,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     // other passes, the lane kernel and the roll-back use them): the chunks are rebuilt from them here, by every plan,
     // and kept up to date by this plan's appends.
     constexpr int CH = 15;
-    const bool par_backup = A <= 32; // the parallel backup: a group of |A| lanes per list element, at least two groups
+    const bool par_backup = p.par_backup != 0 && A <= 32; // a group of |A| lanes per list element, at least two groups per pass
     int4 *ls_b = p.lstate + sb; // one 16-byte record per state: one load / one store where three arrays took three
     int32_t *pool_b = p.lpool + (long)r * p.pool_ints;
     auto PL = [&](int chunk, int f) -> int32_t & { return pool_b[(chunk << 4) + f]; };
@@ -1368,6 +1369,11 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         return v;
     };
     a.scap = lane_scratch();
+    // The grouped parallel backup pays where the backups are: the first plan of fresh planners runs ~4 200 of them, the
+    // following plans ~200 -- there the upkeep of the chunked lists (rebuild at the start, two more accesses per append)
+    // costs more than it saves (16 384 planners: 7.8 / 9.0 ms against 6.9 / 7.9).  MP_SAOPD_PAR_BACKUP=0|1 forces it.
+    a.par_backup = fresh ? 1 : 0;
+    if (const char *e = getenv("MP_SAOPD_PAR_BACKUP")) a.par_backup = e[0] == '1';
     a.prune_rows = 256;
     if (const char *e = getenv("MP_SAOPD_PRUNE_ROWS")) { // test knob: 0 = every changed state through the streamed form
         const int v = atoi(e);

@@ -436,7 +436,7 @@ def test_policy_load_errors(ctx):
     model.close()
 
 
-@pytest.mark.parametrize("mapping", ["wave", "wave-serial-prune", "lane"])
+@pytest.mark.parametrize("mapping", ["wave", "wave-serial-prune", "wave-par-backup", "wave-seq-backup", "lane"])
 @pytest.mark.parametrize("shape", ["grid", "garnet", "highway"])
 def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     """200 planners per launch, three consecutive plans each (planner state kept on the device), vs the oracle run
@@ -447,6 +447,10 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     monkeypatch.setenv("MP_SAOPD_MODEL", mapping.split("-")[0])
     if mapping == "wave-serial-prune":      # one scratch entry per lane: states with two leaves take the serial prune pass
         monkeypatch.setenv("MP_SAOPD_LANE_SCRATCH", "1")
+    if mapping == "wave-par-backup":        # the grouped parallel backup in EVERY plan (default: the first plan only): the
+        monkeypatch.setenv("MP_SAOPD_PAR_BACKUP", "1")   # chunked lists are rebuilt from the linked ones by the later plans
+    if mapping == "wave-seq-backup":        # ... and in none: the element-by-element loop
+        monkeypatch.setenv("MP_SAOPD_PAR_BACKUP", "0")
     cfg, budget, gamma = {"grid": (generators.gridworld(), 120, 0.8),
                           "garnet": (generators.random_deterministic(40, 3, seed=5, terminal_rate=0.1), 90, 0.7),
                           "highway": (generators.highway_shaped(3, 4, 10, seed=3), 150, 0.9)}[shape]
