@@ -819,14 +819,14 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                     v_backup = bkb;
                 };
                 // the sequential half over the group leaders in `todo` (ascending = list order)
-                auto apply = [&](unsigned long long todo, int src_, double src_delta_, int my_nbr) {
+                auto apply = [&](unsigned long long todo, int src_, double src_delta_, int my_nbr, int my_given) {
                     unsigned long long dirty = 0ULL;
                     const unsigned long long gmask = (A == 64 ? ~0ULL : ((1ULL << A) - 1ULL));
                     while (todo && status == MP_OK) {
                         const int j = __ffsll((long long)todo) - 1; // the group's first lane
                         todo &= todo - 1;
                         if (dirty & (gmask << j)) {
-                            eval(lane >= j && lane < j + A, my_nbr, -1, src_, src_delta_); // a child's state value moved
+                            eval(lane >= j && lane < j + A, my_nbr, my_given, src_, src_delta_); // a child's state value moved
 #ifdef MP_PROFILE
                             ++pf_reval;
 #endif
@@ -856,15 +856,53 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         }
                     }
                 };
+                const int nq_max = npp < 16 ? npp : 16;
                 while (qh != qt && status == MP_OK) {
-                    const int4 dq = QD4(qh);
-                    ++qh;
-                    if (dq.x < 0) { // the expanded leaf itself: group 0
+                    // ---- several pending descriptors per pass.  Early in a plan a state's list holds a handful of nodes, so
+                    // one descriptor fills three or four of the 64 / |A| groups; the descriptors behind it are already in
+                    // the queue (first in, first out: whatever this pass pushes comes after them), so the longest run of
+                    // leading descriptors whose lists are single chunks and fit the groups together is evaluated in ONE
+                    // pass and applied in queue order, list order within a descriptor -- the order of the
+                    // element-by-element loop, with the same register patching when a state value moves.
+                    const int nq = (int)(qt - qh) < nq_max ? (int)(qt - qh) : nq_max;
+                    int4 dq_l = make_int4(-1, -1, 0, 0);
+                    int cnt_l = 0, head_l = -1;
+                    if (lane < nq) {
+                        dq_l = QD4(qh + lane);
+                        cnt_l = 1; // (ds < 0: the expanded leaf itself is one item)
+                        if (dq_l.x >= 0) { const int4 ls = ls_b[dq_l.x]; cnt_l = ls.x; head_l = ls.y; }
+                    }
+                    int incl = cnt_l; // inclusive prefix sum of the item counts over the descriptor lanes
+                    for (int d = 1; d < 16; d <<= 1) {
+                        const int o = __shfl_up(incl, d);
+                        if (lane >= d) incl += o;
+                    }
+                    const unsigned long long okm = __ballot(lane < nq && cnt_l <= CH && incl <= npp);
+                    const int nb = okm == ~0ULL ? 64 : __ffsll((long long)~okm) - 1; // leading descriptors of the batch
+                    if (nb > 0) {
+                        const int total = __builtin_amdgcn_readlane(incl, nb - 1);
+                        int own = 0; // the descriptor group my_g's item belongs to
+                        for (int i = 0; i < nb; ++i) own += __shfl(incl, i) <= my_g ? 1 : 0;
+                        own = own < nb ? own : nb - 1;
+                        const int incl_prev = __shfl(incl, (own - 1) & 63); // (unconditional: a cross-lane read under a divergent
+                        const int before = own ? incl_prev : 0;            //  branch would read lanes that sit the branch out)
+                        const int ds_o = __shfl(dq_l.x, own), src_o = __shfl(dq_l.y, own), head_o = __shfl(head_l, own);
+                        const double delta_o = __hiloint2double(__shfl(dq_l.w, own), __shfl(dq_l.z, own));
+                        const bool mine = my_g < total && my_g < npp;
+                        const int my_nbr = (mine && ds_o >= 0) ? PL(head_o, my_g - before) : -1;
+                        const int my_given = (mine && ds_o < 0) ? src_o : -1;
+                        qh += nb;
                         v_cond = false;
-                        eval(my_g == 0, -1, dq.y, -1, 0.0);
-                        apply(__ballot(lane == 0 && v_cond), -1, 0.0, -1);
+#ifdef MP_PROFILE
+                        ++pf_pass;
+#endif
+                        eval(mine, my_nbr, my_given, ds_o < 0 ? -1 : src_o, delta_o);
+                        apply(__ballot(mine && v_cond && my_a == 0), ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
                         continue;
                     }
+                    // the first pending descriptor alone is longer than a pass: chunk by chunk
+                    const int4 dq = QD4(qh);
+                    ++qh;
                     const int src_ = dq.y;
                     const double src_delta_ = __hiloint2double(dq.w, dq.z);
                     const int4 ls = ls_b[dq.x];
@@ -885,7 +923,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                             ++pf_pass;
 #endif
                             eval(my_nbr >= 0, my_nbr, -1, src_, src_delta_);
-                            apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr);
+                            apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr, -1);
                         }
                     }
                 }
