@@ -31,6 +31,15 @@
 //          lazily (one entry per pending state update, expanded into "the parents of that state's nodes" when it
 //          reaches the front); overflow is reported per planner, never dropped silently
 //   tables gamma**d, terminal_reward*gamma**d/(1-gamma), accuracy*(1-gamma)*gamma**(d-1) from the host (libm pow)
+//
+// Round 2 of the wave kernel (same results, the order-dependent semantics kept by sequential halves over registers):
+//   prune   the rows of the changed states are COLLECTED by one coalesced scan of state[] (dead rows marked in bit 1 of
+//           done[], the old arena represented by a per-plan list of its rows with children), held one per lane in four
+//           register sets and tested against every candidate leaf with one ballot -- no list walk
+//   backup  every state's list also exists as chunks of 15 ids (lstate / lpool); a group of |A| lanes evaluates one
+//           neighbour's parent, 64 / |A| neighbours of several pending descriptors per pass; applied in queue and list
+//           order with register patching / re-evaluation when a state value moves (first plan of fresh planners)
+//   meta    bits 24..29 = the action that led to the node (its sibling group = the children of its parent)
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
