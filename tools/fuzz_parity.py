@@ -310,16 +310,22 @@ def run(n_cases, seed, ctx=None, verbose=False):
     ctx = ctx or native.Context(0)
     g = np.random.Generator(np.random.PCG64(seed))
     kinds = {}
-    for case in range(n_cases):
-        try:
-            d = one_case(ctx, g, case)
-        except AssertionError:
-            raise
-        except Exception as e:     # a device error code: say which case it was
-            raise RuntimeError("case {} (seed {}): {}".format(case, seed, e))
-        kinds[d["kind"]] = kinds.get(d["kind"], 0) + 1
-        if verbose:
-            print(d)
+    forced = os.environ.get("MP_OPD_MODEL")        # the cases force kernel variants through the environment: put it back
+    try:
+        for case in range(n_cases):
+            try:
+                d = one_case(ctx, g, case)
+            except AssertionError:
+                raise
+            except Exception as e:     # a device error code: say which case it was
+                raise RuntimeError("case {} (seed {}): {}".format(case, seed, e))
+            kinds[d["kind"]] = kinds.get(d["kind"], 0) + 1
+            if verbose:
+                print(d)
+    finally:
+        os.environ.pop("MP_OPD_MODEL", None)
+        if forced is not None:
+            os.environ["MP_OPD_MODEL"] = forced
     if own:
         ctx.close()
     return kinds
