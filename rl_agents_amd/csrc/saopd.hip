@@ -669,32 +669,50 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         steps_taken += A;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         __syncthreads();
-        for (int a = 0; a < A; ++a) { // state_nodes[str(observation)].append(child), update_value(observation, 0)
-            const int32_t s = __shfl(s_c, a);
-            const bool term = __shfl((int)term_c, a) != 0;
-            const int c = g + a;
-            const int32_t t = TL(s);
-            const double svs = SV(s);
-            if (l0) {
-                if (t < 0) HD(s) = c; else ND(t).next_same = c;
-                TL(s) = c;
-                SM(s) = cur; // the state's list changed in this iteration: its leaves are prune candidates
-                if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
+        // state_nodes[str(observation)].append(child), update_value(observation, 0), child by child in action order.  What an
+        // append reads -- its state's list tail, value (and chunk record) -- is fetched for ALL children at once, lane a
+        // for child a (one round trip instead of |A|); the appends then run in order over registers, and a later sibling
+        // in the SAME state gets the earlier one's result patched into its registers, as if it had read it.
+        {
+            int32_t my_t = -1;
+            double my_sv = 0.0;
+            int4 my_ls = make_int4(0, -1, -1, 0);
+            if (lane < A) {
+                my_t = TL(s_c);
+                my_sv = SV(s_c);
+                if (par_backup) my_ls = ls_b[s_c];
             }
-            if (par_backup) { // the same append on the chunked list
-                const int4 ls = ls_b[s];
-                const int cnt = ls.x, tl = ls.z;
-                const bool fresh_chunk = cnt % CH == 0;
-                const int chunk = fresh_chunk ? pool_top : tl;
+            for (int a = 0; a < A; ++a) {
+                const int32_t s = __builtin_amdgcn_readlane(s_c, a);
+                const bool term = __builtin_amdgcn_readlane((int)term_c, a) != 0;
+                const int c = g + a;
+                const int32_t t = __builtin_amdgcn_readlane(my_t, a);
+                const double svs = bcast_lane(my_sv, a);
+                const double sv_new = (term && svs - 0.0 > 0.0) ? 0.0 : svs;
                 if (l0) {
-                    if (fresh_chunk) {
-                        if (cnt != 0) PL(tl, CH) = chunk;
-                        PL(chunk, CH) = -1;
-                    }
-                    PL(chunk, cnt % CH) = c;
-                    ls_b[s] = make_int4(cnt + 1, cnt == 0 ? chunk : ls.y, chunk, 0);
+                    if (t < 0) HD(s) = c; else ND(t).next_same = c;
+                    TL(s) = c;
+                    SM(s) = cur; // the state's list changed in this iteration: its leaves are prune candidates
+                    if (term && svs - 0.0 > 0.0) SV(s) = 0.0;
                 }
-                pool_top += fresh_chunk ? 1 : 0;
+                int4 ls_new = make_int4(0, -1, -1, 0);
+                if (par_backup) { // the same append on the chunked list
+                    const int cnt = __builtin_amdgcn_readlane(my_ls.x, a), hd = __builtin_amdgcn_readlane(my_ls.y, a),
+                              tl = __builtin_amdgcn_readlane(my_ls.z, a);
+                    const bool fresh_chunk = cnt % CH == 0;
+                    const int chunk = fresh_chunk ? pool_top : tl;
+                    ls_new = make_int4(cnt + 1, cnt == 0 ? chunk : hd, chunk, 0);
+                    if (l0) {
+                        if (fresh_chunk) {
+                            if (cnt != 0) PL(tl, CH) = chunk;
+                            PL(chunk, CH) = -1;
+                        }
+                        PL(chunk, cnt % CH) = c;
+                        ls_b[s] = ls_new;
+                    }
+                    pool_top += fresh_chunk ? 1 : 0;
+                }
+                if (lane > a && lane < A && s_c == s) { my_t = c; my_sv = sv_new; my_ls = ls_new; }
             }
             SA_ORDER();
         }
