@@ -149,6 +149,24 @@ def dist_setup(n_gpus):
     return rank, world, local
 
 
+def ranks_record(rank, world, local):
+    """Proof of N ranks for a SCALE record: the size and backend of the process group the timed region ran on and, per
+    rank, the device it computed on (index, name, PCI bus id / uuid where torch exposes them) -- gathered, so a run whose
+    ranks all sat on one GPU (BENCH_SAME_DEVICE dry runs) is visible as such."""
+    import torch
+    prop = torch.cuda.get_device_properties(local)
+    mine = dict(rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), device_index=local, device_name=prop.name,
+                pci_bus_id=getattr(prop, "pci_bus_id", None), uuid=str(getattr(prop, "uuid", "")) or None,
+                pid=os.getpid())
+    if world == 1:
+        return dict(ranks_seen=1, backend=None, devices=[mine], distinct_devices=1)
+    import torch.distributed as dist
+    everyone = [None] * world
+    dist.all_gather_object(everyone, mine)
+    distinct = len({(d["device_index"], d["pci_bus_id"], d["uuid"]) for d in everyone})
+    return dict(ranks_seen=dist.get_world_size(), backend=dist.get_backend(), devices=everyone, distinct_devices=distinct)
+
+
 def barrier(world):
     import torch
     if world > 1:
@@ -507,9 +525,24 @@ def bench_opd(args, rank, world, local):
     assert int(d_status.abs().sum().item()) == 0
     total = sum_over_ranks(float(env_steps), world)
     k = budget // a_
-    d_avg = 10.0
-    bytes_per_exp = a_ * (13 + 48) + 16 * a_ * d_avg + 16 * d_avg
-    alg = bytes_per_exp * k * n_roots
+    # Algorithmic bytes of THIS launch (task 2): the terms of SURVEY.md 8(d) the kernel really executes, with
+    # the quantities measured on the trees the timed launch left.  Per expansion: |A| model records (13 B: T 4 + R 8 +
+    # term 1) and |A| node records written (48 B).  The reference's backup_to_root after EVERY expansion (8(d)'s
+    # 16 |A| d + 16 d) is NOT executed -- no decision reads an internal node's bounds, so the bounds are the bottom-up
+    # fixed point computed ONCE: every expanded node reads its |A| children's (L, U) and writes its own,
+    # i.e. the 8(d) backup term with d = 1.  Expansions and depth come from exported trees, not from assumptions.
+    sample = np.unique(np.linspace(0, n_roots - 1, 33).astype(np.int64))
+    n_exp = depth_sum = 0
+    for root in sample:
+        tr = ctx.opd_tree(int(root), 1 + k * a_)
+        expanded = tr["first_child"] >= 0
+        n_exp += int(expanded.sum())
+        depth_sum += int(tr["depth"][expanded].sum())
+    exp_per_root = n_exp / float(len(sample))
+    d_avg = depth_sum / float(max(n_exp, 1))            # mean depth of an expanded leaf = length of the walk NOT replayed
+    bytes_per_exp = a_ * (13 + 48) + 16 * a_ + 16
+    alg = bytes_per_exp * exp_per_root * n_roots
+    alg_survey = (a_ * (13 + 48) + 16 * a_ * d_avg + 16 * d_avg) * exp_per_root * n_roots
     res = dict(
         metric="rollout env-steps/sec (OPD plan(), budget=5000)", unit="env-steps/s",
         value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
@@ -519,7 +552,12 @@ def bench_opd(args, rank, world, local):
                     parallelism="roots sharded over {} GPU(s)".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel="opd_kernel<EXPG> (bounds in LDS) or opd_wide_kernel (bounds in HBM), chosen by the host per batch size",
-                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg, bytes_per_expansion=bytes_per_exp,
+                      measured_expansions_per_root=exp_per_root, measured_mean_expanded_depth=d_avg,
+                      survey_formula_bytes_with_per_expansion_backup=alg_survey,
+                      note="algorithmic bytes = the SURVEY 8(d) terms this kernel executes (model gathers, node records, ONE "
+                           "deferred bottom-up backup); the reference's per-expansion backup walk of measured depth d is "
+                           "reported separately and not charged"),
     )
     add_traffic(res["roofline"], "opd", "opd_", n_roots * 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
@@ -583,9 +621,20 @@ def bench_ropd(args, rank, world, local):
     assert int(d_status.abs().sum().item()) == 0
     total = sum_over_ranks(float(joint_steps), world) * m_          # every joint step steps M model environments
     k = budget // a_
-    d_avg = 10.0
-    bytes_per_exp = a_ * m_ * (13 + 20) + a_ * 24 + 16 * a_ * d_avg + 16 * d_avg   # per model: record + {L, state, reward}; per child: minima + meta
-    alg = bytes_per_exp * k * n_roots
+    # executed terms only, measured expansions / depth (see bench_opd): per expansion and child, per model one model record
+    # (13 B) + {L, state, reward} (20 B), per child the minima + meta (24 B); ONE deferred bottom-up backup (16 |A| + 16).
+    sample = np.unique(np.linspace(0, n_roots - 1, 33).astype(np.int64))
+    n_exp = depth_sum = 0
+    for root in sample:
+        tr = ctx.ropd_tree(int(root), 1 + k * a_, m_)
+        expanded = tr["first_child"] >= 0
+        n_exp += int(expanded.sum())
+        depth_sum += int(tr["depth"][expanded].sum())
+    exp_per_root = n_exp / float(len(sample))
+    d_avg = depth_sum / float(max(n_exp, 1))
+    bytes_per_exp = a_ * m_ * (13 + 20) + a_ * 24 + 16 * a_ + 16
+    alg = bytes_per_exp * exp_per_root * n_roots
+    alg_survey = (a_ * m_ * (13 + 20) + a_ * 24 + 16 * a_ * d_avg + 16 * d_avg) * exp_per_root * n_roots
     res = dict(
         metric="rollout env-steps/sec (discrete robust OPD plan(), budget=5000, M=2 models)", unit="env-steps/s",
         value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
@@ -594,7 +643,10 @@ def bench_ropd(args, rank, world, local):
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots, parallelism="roots sharded over {} GPU(s)".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel="ropd_kernel<EXPG> or ropd_wide_kernel, chosen by the host per batch size",
-                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg, bytes_per_expansion=bytes_per_exp,
+                      measured_expansions_per_root=exp_per_root, measured_mean_expanded_depth=d_avg,
+                      survey_formula_bytes_with_per_expansion_backup=alg_survey,
+                      note="executed terms only (one deferred bottom-up backup), expansions / depth measured on exported trees"),
     )
     add_traffic(res["roofline"], "ropd", "ropd_", n_roots * 64)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -946,6 +998,7 @@ def main():
             res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
     res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
                vs_baseline=None, data="synthetic (highway-shaped finite MDP; real highway_env absent)")
+    res["ranks"] = ranks_record(rank, world, local)
     res.setdefault("cpu_baseline", None)
     if isinstance(res["cpu_baseline"], dict):
         # the reference's own (pure Python) CPU path on the same tables: it cannot travel to the GPU box, so its timing is

@@ -131,6 +131,11 @@ int mp_model_info(const mp_model *model, int32_t *mode, int32_t *M, int32_t *S, 
  * Deterministic and sparse (B < 8) modes are bit-exact with the reference; the dense mode
  * accumulates on the f64 matrix cores in a different order than numpy's pairwise sum
  * (relative error ~1e-15 per sweep).
+ * Deterministic models with |S| <= 16 384 are solved by ONE persistent launch whose workgroups hand V to each other and
+ * therefore must all be resident at once.  On a GPU shared with other work that can fail (bounded spins, no hang):
+ *   mem = MP_MEM_HOST  : the call notices and transparently solves again on the chained launches;
+ *   mem = MP_MEM_DEVICE: asynchronous, nothing is read back: sweeps_out[0] = -1 and NaN in Q_out report the failure --
+ *                        check sweeps_out, or set MP_VI_NO_PERSIST=1 to always use the chained launches.
  */
 int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
                 int32_t robust, double *Q_out, int32_t *sweeps_out, int32_t mem);

@@ -126,6 +126,23 @@ def vi_solve(mode, transition, reward, terminal=None, gamma=1.0, iterations=100,
     return q, sweeps.value
 
 
+def dense_backup_rows(transition_rows, reward_rows, terminal_rows, v, gamma, robust=False):
+    """One dense Bellman backup of a block of source-state rows: transition_rows [rows,A,S] (or [M,rows,A,S]),
+    reward_rows [rows,A] (or [M,rows,A]), terminal_rows [rows] or None, v [S] -> Q [rows,A] (numpy's pairwise order)."""
+    p, r = _f64(transition_rows), _f64(reward_rows)
+    if p.ndim == 3:
+        p, r = p[None], r[None]
+    m, rows, a, s_cols = p.shape
+    term = None if (terminal_rows is None or robust) else _u8(np.asarray(terminal_rows).reshape(rows))
+    v = _f64(v)
+    assert v.shape == (s_cols,) and r.shape == (m, rows, a)
+    q = np.zeros((rows, a), dtype=np.float64)
+    rc = lib().orc_dense_backup_rows(m, rows, a, s_cols, _p(p, C.c_double), _p(r, C.c_double), _p(term, C.c_uint8),
+                                     int(bool(robust)), C.c_double(gamma), _p(v, C.c_double), _p(q, C.c_double))
+    assert rc == 0
+    return q
+
+
 def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_state=None,
              done_rule="source", max_plan_len=1024, want_tree=True, available=None):
     """available: bool [S, A] = the actions state.get_available_actions() lists per state (deterministic.py:32-35)."""

@@ -208,6 +208,37 @@ static void orc_bellman(int mode, int M, int S, int A, int B, const int64_t *T, 
     }
 }
 
+/*
+ * The stochastic branch of orc_bellman for a BLOCK of source-state rows (value_iteration.py:54-55,62-63;
+ * robust_value_iteration.py:46-58): the backup of row s reads only P[m,s,:,:], R[m,s,:], term[s] and the whole v, so
+ * a checker can walk a model that does not fit host memory block by block (tests/test_gpu_bench_sizes.py) and the
+ * row-sharded solver's ranks can be checked one at a time.  P double [M,rows,A,S_cols], R double [M,rows,A],
+ * term uint8 [rows] or NULL, v double [S_cols] in, q double [rows,A] out.
+ */
+int orc_dense_backup_rows(int M, int rows, int A, int S_cols, const double *P, const double *R, const uint8_t *term,
+                          int robust, double gamma, const double *v, double *q)
+{
+    double *scratch = malloc(((long)S_cols + 8) * sizeof(double));
+    if (!scratch) return ORC_ERR_ALLOC;
+    for (int s = 0; s < rows; ++s) {
+        for (int a = 0; a < A; ++a) {
+            double best = 0.0;
+            for (int m = 0; m < M; ++m) {
+                const long sa = ((long)m * rows + s) * A + a;
+                const double *row = P + sa * (long)S_cols;
+                for (int k = 0; k < S_cols; ++k) scratch[k] = row[k] * v[k];
+                double next_v = 0.0 + orc_pairwise_sum(scratch, S_cols);
+                if (!robust && term && term[s]) next_v = 0.0;
+                const double qm = R[sa] + gamma * next_v;
+                if (m == 0 || qm < best) best = qm;
+            }
+            q[(long)s * A + a] = best;
+        }
+    }
+    free(scratch);
+    return ORC_OK;
+}
+
 /* value_iteration.py:42-45,65-73 (fixed_point_iteration on Q, allclose early exit returns the
  * PREVIOUS iterate) and robust_value_iteration.py:39-44. */
 int orc_vi_solve(int mode, int M, int S, int A, int B, const int64_t *T, const double *P,

@@ -71,7 +71,10 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
         t = np.ascontiguousarray(np.stack([np.asarray(m.transition, dtype=np.int64) for m in mdps]))
         r = np.ascontiguousarray(np.stack([np.asarray(m.reward, dtype=np.float64) for m in mdps]))
         term = np.ascontiguousarray(np.stack([np.asarray(m.terminal).reshape(-1).astype(np.uint8) for m in mdps]))
-        rule = getattr(mdps[0], "done_rule", "source")
+        rules = {getattr(m, "done_rule", "source") for m in mdps}
+        if len(rules) != 1:     # one terminal convention per joint model (the first model's used to win silently)
+            raise ValueError("all models of a joint environment must share one done_rule, got {}".format(sorted(rules)))
+        rule = rules.pop()
         h = hashlib.blake2b(digest_size=16)
         for arr in (t, r, term):
             h.update(arr.view(np.uint8).reshape(-1))
@@ -149,7 +152,13 @@ class DiscreteRobustPlannerAgent(DeterministicPlannerAgent):
         config.update(dict(models=[]))
         return config
 
+    def joint_env(self):
+        """The candidate models of the true environment, stepped together (robust.py:67-70)."""
+        return JointEnv([preprocess_env(self.true_env, preprocessors) for preprocessors in self.config["models"]])
+
+    def planning_env(self):
+        self.env = self.joint_env()
+        return preprocess_env(self.env, self.config["env_preprocessors"])
+
     def plan(self, observation):
-        envs = [preprocess_env(self.true_env, preprocessors) for preprocessors in self.config["models"]]
-        self.env = JointEnv(envs)
         return super(DiscreteRobustPlannerAgent, self).plan(observation)

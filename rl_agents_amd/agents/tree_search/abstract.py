@@ -49,8 +49,7 @@ class AbstractTreeSearchAgent(AbstractAgent):
         """The planned action sequence from the environment's current state (abstract.py:49-68)."""
         self.steps += 1
         if self.step(self.previous_actions):
-            env = preprocess_env(self.env, self.config["env_preprocessors"])
-            actions = self.planner.plan(state=env, observation=observation)
+            actions = self.planner.plan(state=self.planning_env(), observation=observation)
         else:
             actions = self.previous_actions[1:]
         self.previous_actions = actions
@@ -70,8 +69,11 @@ class AbstractTreeSearchAgent(AbstractAgent):
         """Plans for many independent roots of this agent's environment model in one launch.
 
         ``root_states``: state indices. Returns the planner's batch result (dict of arrays)."""
-        env = preprocess_env(self.env, self.config["env_preprocessors"])
-        return self.planner.plan_batch(env, root_states, root_steps)
+        return self.planner.plan_batch(self.planning_env(), root_states, root_steps)
+
+    def planning_env(self):
+        """The environment object the planner plans on (abstract.py:59-61: the preprocessed copy of ``self.env``)."""
+        return preprocess_env(self.env, self.config["env_preprocessors"])
 
     def reset(self):
         self.planner.step_by_reset()

@@ -105,6 +105,7 @@ class MCTS(AbstractPlanner):
     def reset(self):
         super(MCTS, self).reset()
         self._armed = False         # the device holds kept trees armed for re-rooting by this planner
+        self._tree_roots = 0        # number of roots of the trees this planner's last plan left on the device
 
     def step_by_subtree(self, action):
         """Tree reuse: the device re-roots the kept trees at the start of the next plan, provided the trees on the
@@ -116,7 +117,9 @@ class MCTS(AbstractPlanner):
         # every act() steps the tree (abstract.py:70-82), also between two plans when receding_horizon > 1: the device
         # descends one level per call (a pending re-rooting is applied when the next one is armed)
         live = self.last is not None or self._armed
-        if not live or not self.owns_device_tree():
+        # the kept trees must be ONE tree: after a multi-root plan_batch the reference's "action not in children" path
+        # (abstract.py:200-206) is the nearest meaning -- start over (used to surface MP_ERR_ARG from act())
+        if not live or not self.owns_device_tree() or self._tree_roots != 1:
             self.step_by_reset()
             return
         self.models.ctx.uct_step_tree([int(action)])
@@ -155,6 +158,7 @@ class MCTS(AbstractPlanner):
             self._last_tables = None
         out["rng_states"] = rng_states
         self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
+        self._tree_roots = n
         self.claim_device_tree()
         self.env_steps += int(out["env_steps"].sum())
         return out

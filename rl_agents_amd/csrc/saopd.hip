@@ -1485,13 +1485,14 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     // again with a larger queue.  Costs one 4-byte read-back (a stream synchronisation) per call.
     const size_t sn = (size_t)pl->S * n;
     a.overflow = pl->overflow;
-    if (!fresh) {
+    // (an asynchronous call never rolls back -- a full queue is sticky there -- so it takes no snapshot: ADVICE r2)
+    if (!fresh && !async) {
         MP_HIP(hipMemcpyAsync(pl->snap_sv, pl->sv, sn * 8, hipMemcpyDeviceToDevice, st));
         MP_HIP(hipMemcpyAsync(pl->snap_head, pl->head, sn * 4, hipMemcpyDeviceToDevice, st));
         MP_HIP(hipMemcpyAsync(pl->snap_tail, pl->tail, sn * 4, hipMemcpyDeviceToDevice, st));
         MP_HIP(hipMemcpyAsync(pl->snap_stamp, pl->stamp, sn * 4, hipMemcpyDeviceToDevice, st));
     }
-    MP_HIP(hipMemcpyAsync(pl->snap_rng, a.rng, (size_t)n * 48, hipMemcpyDeviceToDevice, st));
+    if (!async) MP_HIP(hipMemcpyAsync(pl->snap_rng, a.rng, (size_t)n * 48, hipMemcpyDeviceToDevice, st));
     size_t max_queue_bytes = (size_t)8 << 30; // per batch; MP_SAOPD_QUEUE_LIMIT_MB overrides
     if (const char *e = getenv("MP_SAOPD_QUEUE_LIMIT_MB")) max_queue_bytes = (size_t)atol(e) << 20;
     int launches = 0;

@@ -413,6 +413,13 @@ static void vi_persist_launch(const ViPersistArgs &q, hipStream_t st)
     hipLaunchKernelGGL((vi_det_persist<AT, MT>), dim3((unsigned)q.n_wg), dim3((unsigned)q.block), 0, st, q);
 }
 
+// The timeout word is the authority on "the grid was not co-resident" (a workgroup that finished before another one
+// gave up has already written its own verdict): fold it into the caller's sweep count.
+__global__ void vi_persist_status(const unsigned *sync, int32_t *sweeps_out)
+{
+    if (sync[0] && sweeps_out) *sweeps_out = -1;
+}
+
 // every (|A|, models) pair the persistent kernel is instantiated for; false = use the chained launches
 static bool vi_persist_dispatch(const ViPersistArgs &q, int A, int M, hipStream_t st)
 {
@@ -744,8 +751,9 @@ static bool vi_persist_ok(mp_ctx *ctx, int S, int A, int M)
     return true;
 }
 
-static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double rtol, double atol, int robust,
-                  int vform, double *Q_out, double *V_out, int32_t *sweeps_out, int mem)
+static int vi_run_impl(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double rtol, double atol, int robust,
+                       int vform, double *Q_out, double *V_out, int32_t *sweeps_out, int mem, bool allow_persist,
+                       bool *persist_failed)
 {
     if (!ctx || !m) return fail(MP_ERR_ARG, "vi: NULL ctx/model");
     if (iterations < 0) return fail(MP_ERR_ARG, "vi: iterations < 0");
@@ -770,6 +778,8 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
 
     const unsigned gs = (unsigned)((S + 255) / 256);
     int launches = 0;
+    bool persisted = false;
+    unsigned *persist_sync = nullptr;
     const size_t small_lds = (size_t)3 * S * sizeof(double) + (size_t)M * SA * (sizeof(double) + sizeof(int32_t));
     if (m->mode == MP_MODE_DETERMINISTIC && small_lds <= kLdsBytes - 2048 && A <= 64 && !getenv("MP_VI_NO_SMALL")) {
         ViSmallArgs q;
@@ -792,8 +802,9 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
             break;
         }
         MP_TRY(kernels_end(ctx, 1));
-    } else if (m->mode == MP_MODE_DETERMINISTIC && vi_persist_ok(ctx, S, A, M)) {
+    } else if (m->mode == MP_MODE_DETERMINISTIC && allow_persist && vi_persist_ok(ctx, S, A, M)) {
         // one persistent launch: every state owns a thread of a co-resident grid (see vi_det_persist)
+        persisted = true;
         ViPersistArgs q;
         memset(&q, 0, sizeof(q));
         q.d.M = M; q.d.S = S; q.d.A = A; q.d.robust = robust; q.d.vform = vform;
@@ -807,9 +818,13 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
         // Guideline 16: every polled word is re-initialised by every call (tags 0 never match a sweep >= 1)
         MP_HIP(hipMemsetAsync(q.Vring, 0, (size_t)kRing * S * 2 * sizeof(unsigned long long), st));
         MP_HIP(hipMemsetAsync(q.sync, 0, ((size_t)iterations + 4) * sizeof(unsigned), st));
+        // test hook: a raised timeout word is what a grid that is not co-resident ends in (after its bounded spins)
+        if (getenv("MP_VI_PERSIST_INJECT_TIMEOUT")) MP_HIP(hipMemsetAsync(q.sync, 1, 1, st));
+        persist_sync = q.sync;
         MP_TRY(kernels_begin(ctx));
         if (!vi_persist_dispatch(q, A, M, st)) return fail(MP_ERR_ARG, "vi: no persistent kernel for |A| = %d, M = %d", A, M);
         MP_TRY(kernels_end(ctx, 1));
+        hipLaunchKernelGGL(vi_persist_status, dim3(1), dim3(1), 0, st, q.sync, dSw);
     } else if (m->mode == MP_MODE_DETERMINISTIC) {
         double *Vb = nullptr;
         MP_TRY(ws_get(ctx, WS_VI1, (size_t)3 * S, &Vb));
@@ -905,7 +920,31 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
     MP_TRY(stage_out_copy(ctx, Q_out, dQ, (size_t)SA, mem));
     MP_TRY(stage_out_copy(ctx, V_out, dV, (size_t)S, mem));
     MP_TRY(stage_out_copy(ctx, sweeps_out, dSw, 1, mem));
-    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    if (mem == MP_MEM_HOST) {
+        unsigned timed_out = 0;
+        if (persisted) MP_HIP(hipMemcpyAsync(&timed_out, persist_sync, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        MP_HIP(hipStreamSynchronize(st));
+        if (persisted && timed_out && persist_failed) *persist_failed = true;
+    }
+    return MP_OK;
+}
+
+// vi_det_persist spins across workgroups, i.e. it needs its whole grid co-resident.  The grid is at most 64
+// workgroups on a 256-CU device, but a GPU shared with another stream / process / rank can still leave part of it
+// waiting; every workgroup then gives up after its bounded spins, raises the timeout word and the outputs are NaN with
+// sweeps = -1.  With host arrays the call has synchronised anyway: it reads the word and, when raised, solves again on
+// the chained launches (which need no residency) -- the caller never sees the failure.  With device arrays the call is
+// asynchronous: `sweeps_out` = -1 (and NaN in Q / V) is the documented report (mi355plan.h), which the Python wrappers
+// turn into an exception.
+static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double rtol, double atol, int robust,
+                  int vform, double *Q_out, double *V_out, int32_t *sweeps_out, int mem)
+{
+    bool persist_failed = false;
+    MP_TRY(vi_run_impl(ctx, m, gamma, iterations, rtol, atol, robust, vform, Q_out, V_out, sweeps_out, mem, true,
+                       &persist_failed));
+    if (persist_failed)
+        return vi_run_impl(ctx, m, gamma, iterations, rtol, atol, robust, vform, Q_out, V_out, sweeps_out, mem, false,
+                           nullptr);
     return MP_OK;
 }
 

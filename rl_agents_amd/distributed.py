@@ -34,64 +34,85 @@ def collective_device():
     return None
 
 
-def all_gather_rows(local, n_total, device=None):
+def _group_active(force=False):
+    """True when collectives must run: more than one rank, or ``force`` with an initialised (single-rank) group --
+    the way a one-GPU box exercises RCCL's launch path on the product tensors (tests/test_gpu_distributed.py)."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or bool(force)
+
+
+def all_gather_rows(local, n_total, device=None, force=False):
     """Gather row blocks (numpy [n_local, ...], sharded by :func:`shard_bounds`) into the full [n_total, ...] array
     on every rank.  Blocks are padded to the largest shard so that one fixed-size all_gather suffices."""
+    local = np.ascontiguousarray(local)
+    if not _group_active(force):
+        return local
+    return all_gather_packed({"x": local}, n_total, device=device, force=force)["x"]
+
+
+def all_gather_packed(local, n_total, device=None, force=False):
+    """Gather several per-root arrays with ONE collective: ``local`` maps names to row blocks [n_local, ...] (this
+    rank's shard of ``n_total`` rows, :func:`shard_bounds`); the rows of all arrays are packed side by side into one
+    ``uint8 [per, row_bytes]`` buffer (``per`` = the largest shard: fixed-size blocks), exchanged by one
+    ``all_gather_into_tensor`` -- on the GPU when the group is RCCL, on the host for gloo -- and unpacked.  A planning
+    call therefore costs one latency-bound exchange of a few bytes per root whatever the number of outputs."""
     import torch
     import torch.distributed as dist
+    names = list(local)
+    blocks = [np.ascontiguousarray(local[k]) for k in names]
+    if not _group_active(force):
+        return dict(zip(names, blocks))
     rank, world = rank_world()
     if device is None:
         device = collective_device()
-    local = np.ascontiguousarray(local)
-    if world == 1:
-        return local
     per = -(-n_total // world)
-    pad = np.zeros((per,) + local.shape[1:], dtype=local.dtype)
-    pad[:local.shape[0]] = local
-    view = pad.view(np.uint8).reshape(per, -1)
-    t = torch.from_numpy(view.copy())
+    n_local = blocks[0].shape[0]
+    widths = [int(b.dtype.itemsize * int(np.prod(b.shape[1:], dtype=np.int64))) for b in blocks]
+    packed = np.zeros((per, sum(widths)), dtype=np.uint8)
+    off = 0
+    for b, w in zip(blocks, widths):
+        packed[:n_local, off:off + w] = b.reshape(n_local, -1).view(np.uint8).reshape(n_local, w)
+        off += w
+    t = torch.from_numpy(packed)
     if device is not None:
         t = t.to(device)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    parts = []
-    for r in range(world):
-        lo, hi = shard_bounds(n_total, r, world)
-        block = out[r].cpu().numpy().reshape(-1).view(local.dtype).reshape((per,) + local.shape[1:])
-        parts.append(block[:hi - lo])
-    return np.concatenate(parts, axis=0)
+    out = torch.empty((world * per, packed.shape[1]), dtype=torch.uint8, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    full = out.cpu().numpy().reshape(world, per, -1)
+    keep = np.concatenate([full[r, :shard_bounds(n_total, r, world)[1] - shard_bounds(n_total, r, world)[0]]
+                           for r in range(world)], axis=0)
+    res, off = {}, 0
+    for k, b, w in zip(names, blocks, widths):
+        res[k] = np.ascontiguousarray(keep[:, off:off + w]).view(b.dtype).reshape((n_total,) + b.shape[1:])
+        off += w
+    return res
 
 
-def plan_batch_sharded(agent, root_states, root_steps=None, device=None, keys=("plans", "plan_len", "env_steps")):
+def plan_batch_sharded(agent, root_states, root_steps=None, device=None, keys=("plans", "plan_len", "env_steps"),
+                       force_collective=False):
     """Plan ``root_states`` (the same global list on every rank) with roots sharded over the process group.
 
     ``agent``: a tree-search agent of this package.  Returns a dict with the gathered ``keys`` (plus any of
-    ``root_value`` / ``root_lower`` / ``root_upper`` the planner produced), identical on every rank."""
+    ``root_value`` / ``root_lower`` / ``root_upper`` the planner produced), identical on every rank and identical to the
+    single-process result: random streams are keyed by the GLOBAL root index.  One collective per call."""
     rank, world = rank_world()
     root_states = np.asarray(root_states, dtype=np.int32)
     n = len(root_states)
     if n < world:       # decided identically on every rank BEFORE any collective: nobody is left waiting in one
         raise RuntimeError("fewer roots ({}) than ranks ({}): give every rank at least one root".format(n, world))
-    lo, hi = shard_bounds(n, rank, world)
+    lo, hi = shard_bounds(n, rank, world)           # (n >= world: no shard is empty)
     steps = None if root_steps is None else np.asarray(root_steps, dtype=np.int32)[lo:hi]
     rng = agent.planner.batch_rng_states(hi - lo, first_root=lo)
-    from rl_agents_amd.agents.common.factory import preprocess_env
-    env = preprocess_env(agent.env, agent.config["env_preprocessors"])
-    local = agent.planner.plan_batch(env, root_states[lo:hi], steps, rng_states=rng) if hi > lo else None
-    names = list(keys) + [k for k in ("root_value", "root_lower", "root_upper") if local is not None and k in local]
-    if world > 1:
-        import torch.distributed as dist
-        gathered = [None] * world
-        dist.all_gather_object(gathered, names)          # ranks with an empty shard learn the key set
-        names = max(gathered, key=len)
-    out = {}
-    for k in names:
-        if local is not None:
-            block = local[k]
-        else:
-            block = np.zeros((0,), dtype=np.float64)
-        out[k] = all_gather_rows(block, n, device=device)
-    return out
+    if hasattr(agent, "planning_env"):
+        env = agent.planning_env()
+    else:
+        from rl_agents_amd.agents.common.factory import preprocess_env
+        env = preprocess_env(agent.env, agent.config["env_preprocessors"])
+    local = agent.planner.plan_batch(env, root_states[lo:hi], steps, rng_states=rng)
+    names = list(keys) + [k for k in ("root_value", "root_lower", "root_upper") if k in local]
+    return all_gather_packed({k: local[k] for k in names}, n, device=device, force=force_collective)
 
 
 def vi_solve_row_sharded(ctx, transition, reward, terminal=None, gamma=1.0, iterations=100, robust=False,
@@ -139,7 +160,8 @@ def vi_solve_row_sharded(ctx, transition, reward, terminal=None, gamma=1.0, iter
 
 
 def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows, n_states, rows, gamma=1.0,
-                                iterations=100, robust=False, rtol=1e-5, atol=1e-8, check_every=8):
+                                iterations=100, robust=False, rtol=1e-5, atol=1e-8, check_every=8,
+                                force_collective=False):
     """Device-resident form of :func:`vi_solve_row_sharded`: this rank's row block is already on the GPU.
 
     ``transition_rows`` / ``reward_rows``: torch CUDA tensors [.., hi-lo, A, S] / [.., hi-lo, A] (borrowed, not
@@ -150,10 +172,12 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
     once the verdict is "close" a device-side ``done`` flag freezes the iterate (the reference returns the PREVIOUS
     one, value_iteration.py:69-71) and the host only looks at that flag every ``check_every`` sweeps to leave the loop.
     ``ctx`` must enqueue on torch's current stream (``native.Context(device, torch.cuda.current_stream().cuda_stream)``).
+    ``force_collective``: run the collectives also on a single-rank group (exercises RCCL on a one-GPU box).
     Returns (Q [S, A] tensor, sweeps)."""
     import torch
     import torch.distributed as dist
     rank, world = rank_world()
+    grouped = _group_active(force_collective)   # world > 1, or a single-rank group whose collectives are to run
     lo, hi = rows
     dev = transition_rows.device
     n_actions = reward_rows.shape[-1]
@@ -163,7 +187,7 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
     v_pad = torch.zeros(world * per, dtype=torch.float64, device=dev)
     v_loc = torch.zeros(per, dtype=torch.float64, device=dev)
     even = world * per == n_states
-    if world > 1 and not even:                                 # state s lives at v_pad[order[s]]
+    if grouped and not even:                                 # state s lives at v_pad[order[s]]
         order = torch.cat([torch.arange(r * per, r * per + (shard_bounds(n_states, r, world)[1] -
                                                            shard_bounds(n_states, r, world)[0]), device=dev)
                            for r in range(world)])
@@ -174,7 +198,7 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
     for it in range(int(iterations)):
         ctx.vi_backup(model, gamma, v, q_out=q_next, robust=robust)
         close = torch.isclose(q_local, q_next, rtol=rtol, atol=atol).all().to(torch.int32).reshape(1)
-        if world > 1:
+        if grouped:
             dist.all_reduce(close, op=dist.ReduceOp.MIN)
         active = 1 - done
         sweeps_dev += active                                   # a sweep counts until (and including) the close one
@@ -183,7 +207,7 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
         done = torch.maximum(done, close)
         v_loc.zero_()
         v_loc[:hi - lo] = q_local.max(dim=-1).values           # (unchanged once frozen)
-        if world > 1:
+        if grouped:
             dist.all_gather_into_tensor(v_pad, v_loc)
             v = v_pad if even else v_pad[order]
         else:
@@ -192,7 +216,7 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
             break
     sweeps = int(sweeps_dev.item())
     model.close()
-    if world > 1:
+    if grouped:
         q_pad = torch.zeros((per, n_actions), dtype=torch.float64, device=dev)
         q_pad[:hi - lo] = q_local
         q_all = torch.empty((world * per, n_actions), dtype=torch.float64, device=dev)

@@ -309,6 +309,8 @@ class Context(object):
         sweeps = np.zeros(1, dtype=np.int32)
         _check(self._lib.mp_vi_solve(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
                                      int(bool(robust)), _ptr(q), _ptr(sweeps), MP_MEM_HOST))
+        if sweeps[0] < 0:       # (the host-mode call re-solves by itself when the persistent kernel gives up: not reached)
+            raise NativeError(MP_ERR_HIP, "value iteration failed on the device (sweeps = {})".format(int(sweeps[0])))
         return q, int(sweeps[0])
 
     def vi_solve_v(self, model, gamma, iterations, rtol=1e-5, atol=1e-8):
@@ -318,7 +320,10 @@ class Context(object):
         return v
 
     def vi_solve_device(self, model, gamma, iterations, q_out, sweeps_out, robust=False, rtol=1e-5, atol=1e-8):
-        """Asynchronous solve into device tensors (q_out float64 [S,A], sweeps_out int32 [1])."""
+        """Asynchronous solve into device tensors (q_out float64 [S,A], sweeps_out int32 [1]).  Nothing is read back:
+        ``sweeps_out[0] == -1`` (with NaN in ``q_out``) reports that the single-launch solver of small deterministic
+        models could not keep its grid resident (GPU shared with other work) -- check it where the result is consumed
+        (:func:`check_device_sweeps`), or use :meth:`vi_solve`, which re-solves by itself."""
         _check(self._lib.mp_vi_solve(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
                                      int(bool(robust)), _ptr(q_out), _ptr(sweeps_out), MP_MEM_DEVICE))
 
@@ -608,6 +613,15 @@ class Policy(object):
             self.close()
         except Exception:
             pass
+
+
+def check_device_sweeps(sweeps_out):
+    """Raise if an asynchronous ``vi_solve_device`` reported failure (sweeps = -1); returns the sweep count."""
+    n = int(sweeps_out.reshape(-1)[0].item())
+    if n < 0:
+        raise NativeError(MP_ERR_HIP, "value iteration failed on the device: the persistent kernel's grid was not "
+                                      "resident (set MP_VI_NO_PERSIST=1 or use Context.vi_solve)")
+    return n
 
 
 def rng_state_from_generator(gen):

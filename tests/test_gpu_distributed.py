@@ -1,0 +1,194 @@
+"""N > 1 with the REAL kernels (task 1): world-size-2 process groups whose ranks both run the HIP planners /
+the dense backup on the one GPU of the box (gloo rendezvous; RCCL refuses two ranks on one device), asserted equal to
+the single-process result -- root sharding with global-index random streams + the packed result gather for UCT, OPD and
+discrete robust OPD, and the row-sharded dense (robust) value iteration with an uneven shard.  A second group of tests
+runs RCCL itself (backend "nccl", one rank, collectives forced) on the very tensors the product exchanges.
+tests/test_distributed_gloo.py covers the same host logic on CPU with stand-ins; this file has no stand-ins."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+UCT = "<class 'rl_agents_amd.agents.tree_search.mcts.MCTSAgent'>"
+OPD = "<class 'rl_agents_amd.agents.tree_search.deterministic.DeterministicPlannerAgent'>"
+DRP = "<class 'rl_agents_amd.agents.robust.robust.DiscreteRobustPlannerAgent'>"
+
+N_ROOTS = 203           # uneven over two ranks (102 + 101); more than three wavefronts per rank
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _models():
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(4, 5, 12, seed=5)
+    cfg2 = generators.rewire(cfg, 0.15, seed=6)
+    return cfg, cfg2
+
+
+def _agents():
+    """(name, agent, keys) for the three tree-search planners, seeded: the same objects in every process."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv
+    cfg, cfg2 = _models()
+
+    def table(c):
+        return dict(mode="deterministic", transition=c["transition"].tolist(), reward=c["reward"].tolist(),
+                    terminal=np.asarray(c["terminal"]).astype(int).tolist())
+    env = FiniteMDPEnv(table(cfg))
+    env.reset()
+    out = []
+    uct = agent_factory(env, dict(__class__=UCT, budget=400, gamma=0.8))
+    opd = agent_factory(env, dict(__class__=OPD, budget=300, gamma=0.8))
+    drp = agent_factory(env, dict(__class__=DRP, budget=300, gamma=0.8,
+                                  models=[[], [{"method": "copy_with_config", "args": table(cfg2)}]]))
+    for name, agent in (("uct", uct), ("opd", opd), ("ropd", drp)):
+        agent.seed(77)
+        out.append((name, agent))
+    return out, cfg
+
+
+def _plan_all(force_collective=False):
+    from rl_agents_amd.distributed import plan_batch_sharded
+    agents, cfg = _agents()
+    non_term = np.flatnonzero(~np.asarray(cfg["terminal"]))
+    roots = np.random.Generator(np.random.PCG64(3)).choice(non_term, size=N_ROOTS).astype(np.int32)
+    res = {}
+    for name, agent in agents:
+        res[name] = plan_batch_sharded(agent, roots, force_collective=force_collective)
+    return res
+
+
+def _vi_problem(robust):
+    from rl_agents_amd.envs import generators
+    s = 301                                         # 151 + 150 rows
+    cfg = generators.random_stochastic(s, 3, seed=21, terminal_rate=0.08)
+    if not robust:
+        return cfg["transition"], cfg["reward"], cfg["terminal"], s
+    cfg2 = generators.random_stochastic(s, 3, seed=22)
+    return (np.stack([cfg["transition"], cfg2["transition"]]), np.stack([cfg["reward"], cfg2["reward"] * 0.9]), None, s)
+
+
+def _vi_sharded(robust, force_collective=False):
+    """This rank's row block through vi_solve_row_sharded_device (every sweep on the device, V exchanged per sweep)."""
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.distributed import rank_world, shard_bounds, vi_solve_row_sharded_device
+    t, r, term, s = _vi_problem(robust)
+    rank, world = rank_world()
+    lo, hi = shard_bounds(s, rank, world)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        c = native.Context(0, torch.cuda.current_stream().cuda_stream)
+        d_t = torch.from_numpy(np.ascontiguousarray(t[..., lo:hi, :, :])).cuda()
+        d_r = torch.from_numpy(np.ascontiguousarray(r[..., lo:hi, :])).cuda()
+        d_term = None if term is None else torch.from_numpy(np.asarray(term[lo:hi]).astype(np.uint8)).cuda()
+        q, sweeps = vi_solve_row_sharded_device(c, d_t, d_r, d_term, s, (lo, hi), gamma=0.9, iterations=120,
+                                                robust=robust, check_every=4, force_collective=force_collective)
+        q = q.cpu().numpy()
+        c.close()
+    return q, sweeps
+
+
+def _worker(rank, world, port, backend, queue):
+    sys.path.insert(0, REPO)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    kw = dict(device_id=torch.device("cuda", 0)) if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method="tcp://127.0.0.1:{}".format(port), rank=rank, world_size=world, **kw)
+    try:
+        force = world == 1
+        res = dict(plans=_plan_all(force_collective=force), vi=_vi_sharded(False, force), rvi=_vi_sharded(True, force),
+                   backend=dist.get_backend(), world=dist.get_world_size())
+        from rl_agents_amd import native
+        res["lib"] = native.lib_path()
+        if rank == 0:
+            queue.put(res)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_group(world, backend):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    queue = ctx.SimpleQueue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, backend, queue)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = queue.get()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    return res
+
+
+@pytest.fixture(scope="module")
+def single():
+    """World size 1, no process group: the reference result of every comparison below."""
+    return dict(plans=_plan_all(), vi=_vi_sharded(False), rvi=_vi_sharded(True))
+
+
+def _assert_same(res, single):
+    for name in ("uct", "opd", "ropd"):
+        a, b = res["plans"][name], single["plans"][name]
+        assert set(a) == set(b), (name, set(a), set(b))
+        for k in a:
+            assert a[k].shape[0] == N_ROOTS
+            np.testing.assert_array_equal(a[k], b[k], err_msg="{}/{}".format(name, k))
+    for k in ("vi", "rvi"):
+        assert res[k][1] == single[k][1], k                       # same sweep count
+        np.testing.assert_array_equal(res[k][0], single[k][0], err_msg=k)
+
+
+def test_single_process_results_match_the_oracle(single):
+    """Anchor: what the sharded runs are compared with is itself the oracle's result (UCT / OPD plans; dense VI Q)."""
+    from oracle import oracle
+    cfg, _ = _models()
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    agents, _ = _agents()
+    non_term = np.flatnonzero(~np.asarray(term))
+    roots = np.random.Generator(np.random.PCG64(3)).choice(non_term, size=N_ROOTS).astype(np.int32)
+    uct = agents[0][1]
+    rng = uct.planner.batch_rng_states(N_ROOTS)
+    c = uct.planner.config
+    p = np.ones(r.shape[1]) / r.shape[1]
+    ref = oracle.uct_plan_batch(t, r, term, roots, c["episodes"], c["horizon"], c["gamma"], c["temperature"], p, p, rng,
+                                max_plan_len=c["horizon"])
+    np.testing.assert_array_equal(single["plans"]["uct"]["plans"], ref["plans"])
+    np.testing.assert_array_equal(single["plans"]["uct"]["env_steps"], ref["env_steps"])
+    opd = agents[1][1]
+    rng = opd.planner.batch_rng_states(N_ROOTS)
+    ref = oracle.opd_plan_batch(t, r, term, roots, 300, 0.8, 0.0, rng, max_plan_len=single["plans"]["opd"]["plans"].shape[1])
+    np.testing.assert_array_equal(single["plans"]["opd"]["plans"], ref["plans"])
+    np.testing.assert_array_equal(single["plans"]["opd"]["root_lower"], ref["root_lower"])
+    tt, rr, tm, _ = _vi_problem(False)
+    q_ref, sweeps_ref = oracle.vi_solve("stochastic", tt, rr, tm, gamma=0.9, iterations=120)
+    assert single["vi"][1] == sweeps_ref
+    np.testing.assert_allclose(single["vi"][0], q_ref, rtol=1e-12, atol=1e-12)
+
+
+def test_world2_real_kernels_equal_world1(single):
+    """Two ranks, both on this GPU, gloo rendezvous: sharded UCT / OPD / robust-OPD plans and row-sharded dense VI / robust
+    VI (uneven shards) are bit-identical to the single-process results."""
+    res = _run_group(2, "gloo")
+    assert res["world"] == 2 and res["lib"].endswith("libmi355plan.so")
+    _assert_same(res, single)
+
+
+def test_rccl_single_rank_collectives_on_product_tensors(single):
+    """backend "nccl" (= RCCL) with one rank and the collectives forced: all_gather_into_tensor of the packed per-root
+    results and of V, all_reduce of the allclose verdict run through RCCL on the product's device tensors."""
+    res = _run_group(1, "nccl")
+    assert res["backend"] == "nccl" and res["world"] == 1
+    _assert_same(res, single)
