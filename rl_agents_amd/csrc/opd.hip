@@ -555,6 +555,9 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
                 int32_t mem)
 {
     if (!ctx || !model || !root_state || !rng_state) return fail(MP_ERR_ARG, "mp_opd_plan: NULL argument");
+    if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_opd_plan: unknown mem flags %d", mem);
+    const int rmem = mem_rng(mem); // MP_MEM_RNG_DEVICE: the generator records are device-resident (mp_rng) also with host arrays
+    mem = mem_arrays(mem);
     if (model->mode != MP_MODE_DETERMINISTIC)
         return fail(MP_ERR_MODE, "mp_opd_plan: model mode %d is not a deterministic table", model->mode);
     const int A = model->A;
@@ -615,7 +618,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n_roots, mem, &d_rs));
     a.root_state = d_rs;
-    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n_roots * 6, mem, &a.rng));
+    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n_roots * 6, rmem, &a.rng));
     MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, mem, &a.plans));
     MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, mem, &a.plan_len));
     MP_TRY(stage_out_alloc(ctx, WS_IO5, root_lower, (size_t)n_roots, mem, &a.root_lower));
@@ -633,7 +636,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 
-    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n_roots * 6, mem));
+    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n_roots * 6, rmem));
     MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n_roots * max_plan_len, mem));
     MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n_roots, mem));
     MP_TRY(stage_out_copy(ctx, root_lower, a.root_lower, (size_t)n_roots, mem));

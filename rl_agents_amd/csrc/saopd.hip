@@ -1350,6 +1350,9 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
                   int32_t *plan_len, int64_t *env_steps, int64_t *updates, int32_t *status, int32_t mem)
 {
     if (!ctx || !pl || !root_state || !rng_state) return fail(MP_ERR_ARG, "mp_saopd_plan: NULL argument");
+    if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_saopd_plan: unknown mem flags %d", mem);
+    const int rmem = mem_rng(mem); // MP_MEM_RNG_DEVICE: the generator records are device-resident (mp_rng) also with host arrays
+    mem = mem_arrays(mem);
     if (pl->ctx != ctx) return fail(MP_ERR_ARG, "mp_saopd_plan: planners belong to another context");
     if (budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_saopd_plan: bad sizes");
     if (!(gamma >= 0.0 && gamma < 1.0)) return fail(MP_ERR_ARG, "mp_saopd_plan: gamma must be in [0, 1)");
@@ -1447,7 +1450,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     int32_t *d_rs = nullptr;
     MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n, mem, &d_rs));
     a.root_state = d_rs;
-    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n * 6, mem, &a.rng));
+    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n * 6, rmem, &a.rng));
     MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n * max_plan_len, mem, &a.plans));
     MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n, mem, &a.plan_len));
     MP_TRY(stage_out_alloc(ctx, WS_IO5, status, (size_t)n, mem, &a.status));
@@ -1558,7 +1561,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     pl->root = pl->n_nodes;
     pl->n_nodes = need;
 
-    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n * 6, mem));
+    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n * 6, rmem));
     MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n * max_plan_len, mem));
     MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n, mem));
     MP_TRY(stage_out_copy(ctx, status, a.status, (size_t)n, mem));

@@ -779,6 +779,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
                                 "availability through its policies -- plan with a policy from mp_policy_load_listed");
     if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
         return fail(MP_ERR_ARG, "mp_uct_plan: bad sizes (n_roots=%d episodes=%d horizon=%d)", n_roots, episodes, horizon);
+    if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_uct_plan: unknown mem flags %d", mem);
     const int A = model->A, H = horizon, E = episodes;
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
@@ -888,52 +889,108 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.tree_il = ctx->tree.il;
     ctx->tree.kind = 1; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap_use;
 
+    // ---- staging.  Device arrays are used in place; host arrays get device twins (no copy yet: the copies are issued
+    // per chunk, below).  The generator records follow their own flag (MP_MEM_RNG_DEVICE: an mp_rng).
+    const int amem = mem_arrays(mem), rmem = mem_rng(mem);
+    const bool host = amem == MP_MEM_HOST;
     int32_t *d_rs = nullptr, *d_st = nullptr;
-    if (cart) {
-        double *d_rx = nullptr;
-        MP_TRY(stage_in(ctx, WS_IO9, (const double *)root_state, (size_t)n_roots * 4, mem, &d_rx));
-        a.root_x = d_rx;
+    double *d_rx = nullptr;
+    if (!host) {
+        if (cart) d_rx = (double *)const_cast<void *>(root_state); else d_rs = (int32_t *)const_cast<void *>(root_state);
+        d_st = const_cast<int32_t *>(root_steps);
     } else {
-        MP_TRY(stage_in(ctx, WS_IO0, (const int32_t *)root_state, (size_t)n_roots, mem, &d_rs));
+        if (cart) MP_TRY(ws_get(ctx, WS_IO9, (size_t)n_roots * 4, &d_rx)); else MP_TRY(ws_get(ctx, WS_IO0, (size_t)n_roots, &d_rs));
+        if (root_steps) MP_TRY(ws_get(ctx, WS_IO1, (size_t)n_roots, &d_st));
     }
-    if (root_steps) MP_TRY(stage_in(ctx, WS_IO1, root_steps, (size_t)n_roots, mem, &d_st));
-    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n_roots * 6, mem, &a.rng));
-    a.root_state = d_rs; a.root_steps = d_st;
-    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, mem, &a.plans));
-    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, mem, &a.plan_len));
-    MP_TRY(stage_out_alloc(ctx, WS_IO5, root_value, (size_t)n_roots, mem, &a.root_value));
-    MP_TRY(stage_out_alloc(ctx, WS_IO6, root_child_count, (size_t)n_roots * A, mem, &a.root_child_count));
-    MP_TRY(stage_out_alloc(ctx, WS_IO7, root_child_value, (size_t)n_roots * A, mem, &a.root_child_value));
-    MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
+    if (rmem == MP_MEM_DEVICE) a.rng = rng_state; else MP_TRY(ws_get(ctx, WS_IO2, (size_t)n_roots * 6, &a.rng));
+    a.root_x = d_rx; a.root_state = d_rs; a.root_steps = d_st;
+    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, amem, &a.plans));
+    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, amem, &a.plan_len));
+    MP_TRY(stage_out_alloc(ctx, WS_IO5, root_value, (size_t)n_roots, amem, &a.root_value));
+    MP_TRY(stage_out_alloc(ctx, WS_IO6, root_child_count, (size_t)n_roots * A, amem, &a.root_child_count));
+    MP_TRY(stage_out_alloc(ctx, WS_IO7, root_child_value, (size_t)n_roots * A, amem, &a.root_child_value));
+    MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, amem, &a.env_steps));
 
+    // ---- one chunk of roots [r0, r1): copies in, the kernel, copies out, all on stream `s`.  A chunk is the same launch
+    // on shifted pointers (r0 is a multiple of 1024: whole wavefront blocks of the interleaved tree layouts and whole
+    // workgroups of every variant), so chunked and unchunked calls leave identical trees and results.
+    const long tree_off_per_block = ctx->tree.il == 2 ? (cap_use + A) * 64 : (ctx->tree.il == 1 ? cap_use * 64 : cap_use * 64);
+    auto run_chunk = [&](int r0, int r1, hipStream_t s) -> int {
+        const size_t cnt = (size_t)(r1 - r0);
+        if (host) {
+            if (cart) MP_HIP(hipMemcpyAsync(d_rx + (size_t)r0 * 4, (const double *)root_state + (size_t)r0 * 4, cnt * 32, hipMemcpyHostToDevice, s));
+            else MP_HIP(hipMemcpyAsync(d_rs + r0, (const int32_t *)root_state + r0, cnt * 4, hipMemcpyHostToDevice, s));
+            if (root_steps) MP_HIP(hipMemcpyAsync(d_st + r0, root_steps + r0, cnt * 4, hipMemcpyHostToDevice, s));
+        }
+        if (rmem == MP_MEM_HOST) MP_HIP(hipMemcpyAsync(a.rng + (size_t)r0 * 6, rng_state + (size_t)r0 * 6, cnt * 48, hipMemcpyHostToDevice, s));
+        UctArgs c = a;
+        c.n_roots = r1 - r0;
+        if (c.root_x) c.root_x += (size_t)r0 * 4;
+        if (c.root_state) c.root_state += r0;
+        if (c.root_steps) c.root_steps += r0;
+        c.rng += (size_t)r0 * 6;
+        c.tree += (long)(r0 >> 6) * tree_off_per_block;
+        if (c.n_nodes_in) c.n_nodes_in += r0;
+        c.n_nodes_out += r0;
+        if (c.plans) c.plans += (size_t)r0 * max_plan_len;
+        if (c.plan_len) c.plan_len += r0;
+        if (c.root_value) c.root_value += r0;
+        if (c.root_child_count) c.root_child_count += (size_t)r0 * A;
+        if (c.root_child_value) c.root_child_value += (size_t)r0 * A;
+        if (c.env_steps) c.env_steps += r0;
+        if (cart) {
+            const dim3 grid((unsigned)((c.n_roots + c.lanes - 1) / c.lanes)), block(64);
+            hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
+        } else
+        switch (A) {
+        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        default:
+            if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
+            MP_TRY(uct_launch<0>(c, ldsm, lds, s, false, false));
+            break;
+        }
+        if (rmem == MP_MEM_HOST) MP_HIP(hipMemcpyAsync(rng_state + (size_t)r0 * 6, c.rng, cnt * 48, hipMemcpyDeviceToHost, s));
+        if (host) {
+            if (plans && max_plan_len) MP_HIP(hipMemcpyAsync(plans + (size_t)r0 * max_plan_len, c.plans, cnt * max_plan_len * 4, hipMemcpyDeviceToHost, s));
+            if (plan_len) MP_HIP(hipMemcpyAsync(plan_len + r0, c.plan_len, cnt * 4, hipMemcpyDeviceToHost, s));
+            if (root_value) MP_HIP(hipMemcpyAsync(root_value + r0, c.root_value, cnt * 8, hipMemcpyDeviceToHost, s));
+            if (root_child_count) MP_HIP(hipMemcpyAsync(root_child_count + (size_t)r0 * A, c.root_child_count, cnt * A * 8, hipMemcpyDeviceToHost, s));
+            if (root_child_value) MP_HIP(hipMemcpyAsync(root_child_value + (size_t)r0 * A, c.root_child_value, cnt * A * 8, hipMemcpyDeviceToHost, s));
+            if (env_steps) MP_HIP(hipMemcpyAsync(env_steps + r0, c.env_steps, cnt * 8, hipMemcpyDeviceToHost, s));
+        }
+        return MP_OK;
+    };
+
+    // ---- host arrays and a big batch: chunks pipelined over side streams (H2D of chunk i+1 and D2H of chunk i-1 run
+    // under the kernel of chunk i, and kernels of different chunks share the chip).  Everything else: one chunk on the
+    // ctx stream, as ever.
+    int chunk = 32768, n_streams = 4;
+    if (const char *e = getenv("MP_PIPE_CHUNK")) chunk = atoi(e) > 0 ? ((atoi(e) + 1023) & ~1023) : 0;
+    if (const char *e = getenv("MP_PIPE_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 8) n_streams = v; }
+    const bool piped = host && chunk > 0 && n_roots > chunk;
     MP_TRY(kernels_begin(ctx));
-    if (cart) {
-        const dim3 grid((unsigned)((n_roots + a.lanes - 1) / a.lanes)), block(64);
-        hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, st, a);
-    } else
-    switch (A) {
-    case 2: MP_TRY(uct_launch<2>(a, ldsm, lds, st, pol != nullptr, listed)); break;
-    case 3: MP_TRY(uct_launch<3>(a, ldsm, lds, st, pol != nullptr, listed)); break;
-    case 4: MP_TRY(uct_launch<4>(a, ldsm, lds, st, pol != nullptr, listed)); break;
-    case 5: MP_TRY(uct_launch<5>(a, ldsm, lds, st, pol != nullptr, listed)); break;
-    case 6: MP_TRY(uct_launch<6>(a, ldsm, lds, st, pol != nullptr, listed)); break;
-    case 8: MP_TRY(uct_launch<8>(a, ldsm, lds, st, pol != nullptr, listed)); break;
-    default:
-        if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
-        MP_TRY(uct_launch<0>(a, ldsm, lds, st, false, false));
-        break;
+    int launches = 1;
+    if (piped) {
+        const int n_chunks = (n_roots + chunk - 1) / chunk;
+        if (n_streams > n_chunks) n_streams = n_chunks;
+        MP_TRY(pipe_fork(ctx, n_streams));
+        for (int c = 0; c < n_chunks; ++c) {
+            const int r0 = c * chunk, r1 = r0 + chunk < n_roots ? r0 + chunk : n_roots;
+            MP_TRY(run_chunk(r0, r1, ctx->pipe[c % n_streams]));
+        }
+        MP_TRY(pipe_join(ctx, n_streams));
+        launches = n_chunks;
+    } else {
+        MP_TRY(run_chunk(0, n_roots, st));
     }
-    MP_TRY(kernels_end(ctx, 1));
+    MP_TRY(kernels_end(ctx, launches));
     MP_HIP(hipGetLastError());
-
-    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n_roots * 6, mem));
-    MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n_roots * max_plan_len, mem));
-    MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n_roots, mem));
-    MP_TRY(stage_out_copy(ctx, root_value, a.root_value, (size_t)n_roots, mem));
-    MP_TRY(stage_out_copy(ctx, root_child_count, a.root_child_count, (size_t)n_roots * A, mem));
-    MP_TRY(stage_out_copy(ctx, root_child_value, a.root_child_value, (size_t)n_roots * A, mem));
-    MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, mem));
-    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    if (host) MP_HIP(hipStreamSynchronize(st));
     return MP_OK;
 }
 

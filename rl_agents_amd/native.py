@@ -12,7 +12,7 @@ import numpy as np
 
 from . import build as _build
 
-MP_MEM_HOST, MP_MEM_DEVICE = 0, 1
+MP_MEM_HOST, MP_MEM_DEVICE, MP_MEM_RNG_DEVICE = 0, 1, 2
 MP_OK, MP_ERR_HIP, MP_ERR_REWARD_RANGE, MP_ERR_ALLOC, MP_ERR_ARG, MP_ERR_MODE = 0, -1, -2, -3, -4, -5
 MODE_DETERMINISTIC, MODE_STOCHASTIC, MODE_SPARSE, MODE_CARTPOLE = 0, 1, 2, 3
 ERR_REWARD_RANGE, ERR_ARG, ERR_MODE = -2, -4, -5
@@ -69,6 +69,15 @@ SIGNATURES = {
     "mp_saopd_export": (C.c_int, [_vp, c_i32, c_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_olop_allocation": (C.c_int, [c_i32, c_f64, P(c_i32), P(c_i32)]),
     "mp_last_kernel_ms": (C.c_int, [_vp, P(c_f64), P(c_i32)]),
+    "mp_host_alloc": (C.c_int, [_vp, c_i64, P(_vp)]),
+    "mp_host_free": (C.c_int, [_vp, _vp]),
+    "mp_rng_create": (C.c_int, [_vp, c_i32, P(_vp)]),
+    "mp_rng_free": (C.c_int, [_vp]),
+    "mp_rng_set": (C.c_int, [_vp, c_i32, c_i32, _vp]),
+    "mp_rng_get": (C.c_int, [_vp, c_i32, c_i32, _vp]),
+    "mp_rng_seed_sequence": (C.c_int, [_vp, c_i32, c_i32, _vp, c_i32, c_i64]),
+    "mp_rng_device_ptr": (_vp, [_vp, c_i32]),
+    "mp_seed_sequence_states": (C.c_int, [_vp, c_i32, c_i64, c_i32, _vp]),
 }
 
 
@@ -108,7 +117,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 2:
+    if lib.mp_abi_version() != 3:
         raise RuntimeError("libmi355plan ABI version mismatch")
     _LIB = lib
     return lib
@@ -128,6 +137,34 @@ def _ptr(a):
     if hasattr(a, "data_ptr"):
         return a.data_ptr()
     raise TypeError("expected numpy array, torch tensor or None, got {}".format(type(a)))
+
+
+def entropy_words(entropy):
+    """numpy's split of entropy integers into little-endian uint32 words (bit_generator.pyx _coerce_to_uint32_array):
+    an int or a sequence of ints, each non-negative; 0 -> [0]."""
+    ints = [entropy] if isinstance(entropy, (int, np.integer)) else list(entropy)
+    words = []
+    for v in ints:
+        v = int(v)
+        if v < 0:
+            raise ValueError("expected non-negative integer")
+        if v == 0:
+            words.append(0)
+        while v > 0:
+            words.append(v & 0xFFFFFFFF)
+            v >>= 32
+    return np.asarray(words, dtype=np.uint32)
+
+
+def seed_sequence_states(entropy, first_key, count):
+    """PCG64 records uint64 [count, 6] of Generator(PCG64(SeedSequence(list(entropy) + [first_key + i]))), i < count --
+    numpy's SeedSequence hashing and PCG64 seeding restated in C (mp_seed_sequence_states: host arithmetic, no GPU),
+    ~1000x faster than constructing the generators in Python (262 144 roots: seconds -> milliseconds).  ``entropy``:
+    int, sequence of ints, or () for SeedSequence(first_key + i)."""
+    w = entropy_words(entropy) if not (hasattr(entropy, "__len__") and len(entropy) == 0) else np.zeros(0, np.uint32)
+    out = np.zeros((int(count), 6), dtype=np.uint64)
+    _check(load().mp_seed_sequence_states(_ptr(w) if len(w) else None, len(w), int(first_key), int(count), _ptr(out)))
+    return out
 
 
 def olop_allocation(budget, gamma):
@@ -185,6 +222,34 @@ class Context(object):
         ms, n = c_f64(), c_i32()
         _check(self._lib.mp_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    # ---- host-inclusive fast path: pinned arrays, device-resident generator records -------------------------
+    def pinned(self, spec):
+        """``{name: (shape, dtype)}`` -> :class:`PinnedArrays`: numpy views of ONE pinned host block (mp_host_alloc).
+        Copies from / to them are asynchronous DMA; pass them where host arrays are expected."""
+        return PinnedArrays(self, spec)
+
+    def plan_buffers(self, n_roots, max_plan_len, n_actions=None, outputs=("plans", "plan_len", "root_value", "env_steps")):
+        """Pinned, reusable host arrays for batched plan() calls of ``n_roots`` roots: the ``root_state`` input and the
+        requested ``outputs`` (``uct_plan(..., out=buffers)`` fills exactly those; outputs not listed are not computed
+        into host memory at all).  The caller owns them: a later call with the same buffers overwrites the results."""
+        n, mpl = int(n_roots), int(max_plan_len)
+        shapes = dict(root_state=((n,), np.int32), plans=((n, mpl), np.int32), plan_len=((n,), np.int32),
+                      root_value=((n,), np.float64), env_steps=((n,), np.int64), root_lower=((n,), np.float64),
+                      root_upper=((n,), np.float64), status=((n,), np.int32))
+        if n_actions is not None:
+            shapes.update(root_child_count=((n, int(n_actions)), np.int64), root_child_value=((n, int(n_actions)), np.float64))
+        names = ["root_state"] + [k for k in outputs]
+        return PinnedArrays(self, {k: shapes[k] for k in names})
+
+    def device_rng(self, states_or_n):
+        """Generator records resident on the device (mp_rng): an int n (uninitialised) or a uint64 [n, 6] array."""
+        if isinstance(states_or_n, (int, np.integer)):
+            return DeviceRng(self, int(states_or_n))
+        st = np.ascontiguousarray(states_or_n, dtype=np.uint64).reshape(-1, 6)
+        rng = DeviceRng(self, st.shape[0])
+        rng.set(st)
+        return rng
 
     # ---- models ------------------------------------------------------------------------------
     def load_table(self, transition, reward, terminal=None, done_rule="source", max_steps=0, available=None):
@@ -348,39 +413,55 @@ class Context(object):
         return Policy(self, h, model)
 
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
-                 root_steps=None, max_plan_len=None, policy=None):
-        """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place.
-        policy (load_policy): per-state policies instead of prior_p / rollout_p."""
+                 root_steps=None, max_plan_len=None, policy=None, out=None):
+        """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place (or a
+        :class:`DeviceRng`, advanced on the device).  policy (load_policy): per-state policies instead of prior_p /
+        rollout_p.  out (plan_buffers): caller-owned pinned result arrays; only the outputs they hold are produced."""
         if model.mode == MODE_CARTPOLE:      # roots are (x, x_dot, theta, theta_dot) rows
             rs = np.ascontiguousarray(root_state, dtype=np.float64).reshape(-1, 4)
         else:
             rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
         n = rs.shape[0]
         st = None if root_steps is None else np.ascontiguousarray(root_steps, dtype=np.int32).reshape(n)
-        if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
-                and rng_state.size == n * 6):
-            raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6]")
-        mpl = int(horizon if max_plan_len is None else max_plan_len)
-        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
-                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
-                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        mem, rng_ptr = self._rng_arg(rng_state, n)
+        if out is not None:                     # caller-owned (pinned) buffers: only the outputs they hold are produced
+            mpl = out["plans"].shape[1] if "plans" in out else 0
+            for k in out:
+                if k != "root_state" and out[k].shape[0] != n:
+                    raise ValueError("output buffer '{}' holds {} roots, the batch has {}".format(k, out[k].shape[0], n))
+        else:
+            mpl = int(horizon if max_plan_len is None else max_plan_len)
+            out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                       root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
+                       root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        o = [_ptr(out[k]) if k in out else None for k in ("plans", "plan_len", "root_value", "root_child_count",
+                                                           "root_child_value", "env_steps")]
         if policy is not None:
             _check(self._lib.mp_uct_plan_policy(self._h, model._h, policy._h, n, _ptr(rs), _ptr(st), int(episodes),
-                                                int(horizon), float(gamma), float(temperature), _ptr(rng_state), mpl,
-                                                _ptr(out["plans"]), _ptr(out["plan_len"]), _ptr(out["root_value"]),
-                                                _ptr(out["root_child_count"]), _ptr(out["root_child_value"]),
-                                                _ptr(out["env_steps"]), MP_MEM_HOST))
+                                                int(horizon), float(gamma), float(temperature), rng_ptr, mpl,
+                                                o[0], o[1], o[2], o[3], o[4], o[5], mem))
             return out
         pp = np.ascontiguousarray(prior_p, dtype=np.float64)
         rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
         if pp.shape != (model.A,) or rp.shape != (model.A,):
             raise ValueError("prior_p / rollout_p must have one entry per action")
         _check(self._lib.mp_uct_plan(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
-                                     float(gamma), float(temperature), _ptr(pp), _ptr(rp), _ptr(rng_state), mpl,
-                                     _ptr(out["plans"]), _ptr(out["plan_len"]), _ptr(out["root_value"]),
-                                     _ptr(out["root_child_count"]), _ptr(out["root_child_value"]),
-                                     _ptr(out["env_steps"]), MP_MEM_HOST))
+                                     float(gamma), float(temperature), _ptr(pp), _ptr(rp), rng_ptr, mpl,
+                                     o[0], o[1], o[2], o[3], o[4], o[5], mem))
         return out
+
+    @staticmethod
+    def _rng_arg(rng_state, n):
+        """(mem flags, pointer) for the generator records of a host-array call: a uint64 [n, 6] numpy array (copied in
+        and out) or a :class:`DeviceRng` (resident: MP_MEM_RNG_DEVICE)."""
+        if isinstance(rng_state, DeviceRng):
+            if rng_state.n < n:
+                raise ValueError("the device generator holds {} records, the batch has {} roots".format(rng_state.n, n))
+            return MP_MEM_HOST | MP_MEM_RNG_DEVICE, rng_state.ptr(0)
+        if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
+                and rng_state.size == n * 6):
+            raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6] or a DeviceRng")
+        return MP_MEM_HOST, rng_state.ctypes.data
 
     def uct_plan_device(self, model, n_roots, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p,
                         rng_state, max_plan_len, plans=None, plan_len=None, root_value=None, root_child_count=None,
@@ -499,6 +580,81 @@ class Context(object):
                                             _ptr(t["lower"]), _ptr(t["upper"]), _ptr(t["done"]), _ptr(t["count"]),
                                             _ptr(t["first_child"]), _ptr(t["n_children"])))
         return {k: v[:n.value].copy() for k, v in t.items()}
+
+
+class PinnedArrays(dict):
+    """``{name: ndarray}`` views of one pinned host allocation (mp_host_alloc); 64-byte aligned members."""
+
+    def __init__(self, ctx, spec):
+        super(PinnedArrays, self).__init__()
+        self.ctx = ctx
+        offs, total = {}, 0
+        for name, (shape, dtype) in spec.items():
+            offs[name] = total
+            total += (int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize + 63) & ~63
+        self._ptr = _vp()
+        _check(ctx._lib.mp_host_alloc(ctx._h, max(total, 64), C.byref(self._ptr)))
+        self.nbytes = total
+        raw = np.ctypeslib.as_array((C.c_uint8 * max(total, 64)).from_address(self._ptr.value))
+        for name, (shape, dtype) in spec.items():
+            n = int(np.prod(shape, dtype=np.int64)) * np.dtype(dtype).itemsize
+            self[name] = raw[offs[name]:offs[name] + n].view(dtype).reshape(shape)
+
+    def close(self):
+        if getattr(self, "_ptr", None) is not None and getattr(self.ctx, "_h", None):
+            self.clear()
+            self.ctx._lib.mp_host_free(self.ctx._h, self._ptr)
+        self._ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceRng(object):
+    """numpy-PCG64 generator records of a batch of roots, resident on the device (mp_rng): the planners advance them in
+    place and nothing crosses PCIe until ``get`` is asked for."""
+
+    def __init__(self, ctx, n):
+        self.ctx, self.n = ctx, int(n)
+        self._h = _vp()
+        _check(ctx._lib.mp_rng_create(ctx._h, self.n, C.byref(self._h)))
+
+    def set(self, states, first=0):
+        st = np.ascontiguousarray(states, dtype=np.uint64).reshape(-1, 6)
+        _check(self.ctx._lib.mp_rng_set(self._h, int(first), st.shape[0], _ptr(st)))
+
+    def get(self, first=0, count=None):
+        count = self.n - int(first) if count is None else int(count)
+        out = np.zeros((count, 6), dtype=np.uint64)
+        _check(self.ctx._lib.mp_rng_get(self._h, int(first), count, _ptr(out)))
+        return out
+
+    def seed_sequence(self, entropy, first_key=0, first=0, count=None):
+        """Record first + i <- Generator(PCG64(SeedSequence(list(entropy) + [first_key + i]))) (see seed_sequence_states)."""
+        count = self.n - int(first) if count is None else int(count)
+        w = entropy_words(entropy) if not (hasattr(entropy, "__len__") and len(entropy) == 0) else np.zeros(0, np.uint32)
+        _check(self.ctx._lib.mp_rng_seed_sequence(self._h, int(first), count, _ptr(w) if len(w) else None, len(w),
+                                                  int(first_key)))
+
+    def ptr(self, first=0):
+        p = self.ctx._lib.mp_rng_device_ptr(self._h, int(first))
+        if not p:
+            raise NativeError(MP_ERR_ARG, load().mp_last_error().decode("utf-8", "replace"))
+        return p
+
+    def close(self):
+        if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):
+            self.ctx._lib.mp_rng_free(self._h)
+        self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Model(object):

@@ -27,7 +27,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
-    assert native.load().mp_abi_version() == 2
+    assert native.load().mp_abi_version() == 3
 
 
 def test_context_fails_loudly_without_gpu_or_library(monkeypatch):
@@ -239,3 +239,28 @@ def test_tabulate_prior_agent_queries_like_the_reference():
 
     with pytest.raises(ValueError):
         tabulate_prior_agent(Partial(), 2, 3)
+
+
+def test_seed_sequence_states_equal_numpy():
+    """mp_seed_sequence_states restates numpy's SeedSequence (pool of 4, entropy words little-endian, no spawn key) and
+    PCG64's seeding from generate_state(4, uint64): records identical to the generators numpy builds -- for
+    SeedSequence(k), SeedSequence([entropy, k]) with entropies of one and two words, zero, and more words than the pool."""
+    from rl_agents_amd import native
+
+    def numpy_records(make, n):
+        out = np.zeros((n, 6), dtype=np.uint64)
+        for i in range(n):
+            out[i] = native.rng_state_from_generator(np.random.Generator(np.random.PCG64(np.random.SeedSequence(make(i)))))
+        return out
+    assert np.array_equal(native.seed_sequence_states((), 0, 70), numpy_records(lambda i: i, 70))
+    assert np.array_equal(native.seed_sequence_states((), 2 ** 32 - 3, 8), numpy_records(lambda i: 2 ** 32 - 3 + i, 8))
+    for e in (0, 1234, 2 ** 40 + 17, (1 << 63) - 1):
+        assert np.array_equal(native.seed_sequence_states([e], 5, 33), numpy_records(lambda i: [e, 5 + i], 33)), e
+    assert np.array_equal(native.seed_sequence_states([5, 6, 2 ** 70, 9], 0, 9), numpy_records(lambda i: [5, 6, 2 ** 70, 9, i], 9))
+    # the planners' batch streams: root i of a batch draws from SeedSequence([entropy, first_root + i])
+    from rl_agents_amd.agents.tree_search.abstract import AbstractPlanner
+
+    class P(object):
+        _entropy = 340282366920938463463374607431768211455 % (1 << 63)
+    got = AbstractPlanner.batch_rng_states(P(), 5, first_root=11)
+    assert np.array_equal(got, numpy_records(lambda i: [P._entropy, 11 + i], 5))
