@@ -84,19 +84,54 @@ def spec_from_mdp(mdp, max_steps=0, available=None):
                      done_rule=getattr(mdp, "done_rule", "source"), max_steps=max_steps, available=available)
 
 
+def grid_available(original_shape):
+    """Action availability of a (speed V, lane L, time T) time-to-collision grid in highway-env's style [from memory,
+    package absent]: LANE_LEFT (0) needs a lane to the left, LANE_RIGHT (2) one to the right, FASTER (3) a higher and
+    SLOWER (4) a lower target speed; IDLE (1) is always available.  -> bool [V * L * T, 5]."""
+    n_speeds, n_lanes, n_times = (int(x) for x in original_shape)
+    v, l, _ = np.meshgrid(np.arange(n_speeds), np.arange(n_lanes), np.arange(n_times), indexing="ij")
+    v, l = v.ravel(), l.ravel()
+    return np.stack([l > 0, np.ones_like(l, dtype=bool), l < n_lanes - 1, v < n_speeds - 1, v > 0], axis=1)
+
+
 def available_actions_of(env, mdp):
     """The action restriction of an environment exposing ``get_available_actions`` as a table bool [S, A] (None when
-    the environment has no such method).  The reference asks the env object state by state (mcts.py:59-97,
-    deterministic.py:32-35); a device planner needs the whole table, which table environments expose as
-    ``mdp.available`` (rl_agents_amd.envs.MaskedFiniteMDPEnv)."""
+    the environment has no such method).  The reference asks the env object node by node (mcts.py:59-97,
+    deterministic.py:32-35); a device planner needs the whole table, taken from, in this order:
+
+    1. ``mdp.available`` -- table environments (rl_agents_amd.envs.MaskedFiniteMDPEnv);
+    2. ``env.unwrapped.available_table(mdp)`` -- the documented hook for environments that keep the restriction on the
+       env object: return bool [S, A] in the MDP's state numbering;
+    3. for MDPs carrying ``original_shape = (V, L, T)`` with 5 actions -- what highway-env's ``to_finite_mdp()`` returns
+       (value_iteration.py:12-21; the restriction stays on the env there) -- the lane / speed edge rule of
+       :func:`grid_available`.
+
+    A derived table (2, 3) is cross-checked against the env itself for the state it is in, on every call: if
+    ``get_available_actions()`` and the table row of ``mdp.state`` disagree the planner refuses (``ValueError``) rather
+    than plan on a guessed restriction.  Anything else raises ``TypeError`` as before."""
     base = getattr(env, "unwrapped", env)
     if not hasattr(base, "get_available_actions"):
         return None
-    available = getattr(mdp, "available", None)
+    reward = np.asarray(mdp.reward)
+    n_states, n_actions = reward.shape[-2:]
+    available, source = getattr(mdp, "available", None), "mdp.available"
+    if available is None and hasattr(base, "available_table"):
+        available, source = base.available_table(mdp), "env.available_table(mdp)"
+    shape = getattr(mdp, "original_shape", None)
+    if available is None and shape is not None and len(shape) == 3 and n_actions == 5 and int(np.prod(shape)) == n_states:
+        available, source = grid_available(shape), "the (V, L, T) grid rule on mdp.original_shape"
     if available is None:
-        raise TypeError("the environment restricts its available actions but its finite MDP has no `available` [S, A] "
-                        "table: the device planners cannot query get_available_actions() state by state")
-    return np.asarray(available).astype(bool)
+        raise TypeError("the environment restricts its available actions but neither its finite MDP has an `available` "
+                        "[S, A] table, nor the env an `available_table(mdp)` hook, nor the MDP a (V, L, T) "
+                        "`original_shape`: the device planners cannot query get_available_actions() node by node")
+    available = np.asarray(available).astype(bool).reshape(n_states, n_actions)
+    if source != "mdp.available":
+        listed = sorted(int(a) for a in base.get_available_actions())
+        row = [int(a) for a in np.flatnonzero(available[int(mdp.state)])]
+        if listed != row:
+            raise ValueError("availability table from {} lists actions {} in state {} but the environment's "
+                             "get_available_actions() returns {}".format(source, row, int(mdp.state), listed))
+    return available
 
 
 def is_cartpole(env):

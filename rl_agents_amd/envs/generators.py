@@ -112,10 +112,8 @@ def highway_available(config):
     """Action availability of a highway-shaped table in highway-env's style [from memory, package absent]: no
     LANE_LEFT in the leftmost lane, no LANE_RIGHT in the rightmost, no FASTER at the top speed, no SLOWER at the lowest;
     IDLE is always available.  -> bool [S, 5]."""
-    n_speeds, n_lanes, n_times = config["original_shape"]
-    v, l, _ = np.meshgrid(np.arange(n_speeds), np.arange(n_lanes), np.arange(n_times), indexing="ij")
-    v, l = v.ravel(), l.ravel()
-    return np.stack([l > 0, np.ones_like(l, dtype=bool), l < n_lanes - 1, v < n_speeds - 1, v > 0], axis=1)
+    from rl_agents_amd.device_model import grid_available
+    return grid_available(config["original_shape"])
 
 
 def random_available(n_states, n_actions, seed=0, rate=0.3):
