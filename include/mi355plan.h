@@ -70,13 +70,16 @@ int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *
 /*
  * SURVEY.md 8(d) measures plan() with host arrays in and out (trainer/evaluation.py:168: agent.plan(observation) is a host
  * call).  Three things make that path fast; none changes a result:
- *   - pinned host memory for the arrays a caller hands over: mp_host_alloc / mp_host_free (hipHostMalloc).  Copies from /
- *     to pinned memory are real asynchronous DMA; from pageable memory the runtime stages them through a bounce buffer.
- *     Any host pointer is still accepted everywhere.
- *   - mp_uct_plan with mem = MP_MEM_HOST splits batches of more than 32 768 roots into chunks and pipelines
- *     H2D(roots) -> kernel -> D2H(results) of different chunks over several HIP streams owned by the ctx (same kernels,
- *     same trees, same results: a root's plan depends on its own state and stream only).  mp_last_kernel_ms then covers
- *     the whole pipelined region.  MP_PIPE_CHUNK=<roots> / MP_PIPE_STREAMS=<1..8> override; MP_PIPE_CHUNK=0 disables.
+ *   - ZERO-COPY: mp_host_alloc / mp_host_free hand out host memory that is pinned AND mapped into the device's address
+ *     space (hipHostMalloc, portable | mapped).  When every array of a MP_MEM_HOST call lies in such memory, the kernels
+ *     read the root states from and write the results to the caller's arrays directly over the bus: the call is one
+ *     launch and one synchronisation, no copy is issued (every plan entry point; MP_NO_ZERO_COPY=1 disables).
+ *     Any other host pointer is still accepted everywhere and goes through staging copies.
+ *   - mp_uct_plan with mem = MP_MEM_HOST and ordinary (pageable) arrays splits batches of more than 65 536 roots into
+ *     chunks and pipelines H2D(roots) -> kernel -> D2H(results) of different chunks over several HIP streams owned by
+ *     the ctx (same kernels, same trees, same results: a root's plan depends on its own state and stream only).
+ *     mp_last_kernel_ms then covers the whole pipelined region.  MP_PIPE_CHUNK=<roots> / MP_PIPE_STREAMS=<1..8>
+ *     override; MP_PIPE_CHUNK=0 disables.
  *   - mp_rng: generator records resident on the device (see MP_MEM_RNG_DEVICE).
  */
 int mp_host_alloc(mp_ctx *ctx, int64_t bytes, void **out);

@@ -1,6 +1,7 @@
 // api.hip -- context, transition-model upload and host helpers of libmi355plan.so.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -245,8 +246,12 @@ int mp_host_alloc(mp_ctx *ctx, int64_t bytes, void **out)
     if (!ctx || !out || bytes < 0) return fail(MP_ERR_ARG, "mp_host_alloc: bad argument");
     MP_HIP(hipSetDevice(ctx->device));
     void *p = nullptr;
-    if (hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 1), hipHostMallocDefault) != hipSuccess)
+    const size_t n = (size_t)(bytes > 0 ? bytes : 1);
+    if (hipHostMalloc(&p, n, hipHostMallocPortable | hipHostMallocMapped) != hipSuccess)
         return fail(MP_ERR_ALLOC, "mp_host_alloc: hipHostMalloc(%lld) failed", (long long)bytes);
+    void *d = nullptr;
+    if (!getenv("MP_NO_ZERO_COPY") && hipHostGetDevicePointer(&d, p, 0) == hipSuccess && d)
+        ctx->pinned.push_back({static_cast<const char *>(p), static_cast<char *>(d), n});
     *out = p;
     return MP_OK;
 }
@@ -257,6 +262,8 @@ int mp_host_free(mp_ctx *ctx, void *ptr)
     if (!ptr) return MP_OK;
     MP_HIP(hipSetDevice(ctx->device));
     MP_HIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < ctx->pinned.size(); ++i)
+        if (ctx->pinned[i].host == ptr) { ctx->pinned.erase(ctx->pinned.begin() + (long)i); break; }
     MP_HIP(hipHostFree(ptr));
     return MP_OK;
 }

@@ -92,6 +92,10 @@ struct mp_ctx {
     hipStream_t pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pipe_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pipe_fork = nullptr;
+    // host blocks handed out by mp_host_alloc: pinned AND mapped into the device's address space, so a kernel can read
+    // root states from / write results to them directly (zero-copy: no hipMemcpy call at all on the host-array path)
+    struct Pinned { const char *host; char *dev; size_t bytes; };
+    std::vector<Pinned> pinned;
 };
 
 // device-resident numpy-PCG64 generator records of a batch of roots
@@ -179,7 +183,17 @@ inline bool mem_valid(int mem) { return mem >= 0 && mem <= 3; }
 int pipe_fork(mp_ctx *ctx, int n);
 int pipe_join(mp_ctx *ctx, int n);
 
-// copy helper: host->device (sync on the ctx stream) or pass-through of a device pointer
+// device alias of a host range inside an mp_host_alloc block (nullptr: not such memory) -- a range check, no HIP call
+inline void *pinned_alias(const mp_ctx *ctx, const void *p, size_t bytes)
+{
+    const char *c = static_cast<const char *>(p);
+    for (const auto &b : ctx->pinned)
+        if (c >= b.host && c + bytes <= b.host + b.bytes) return b.dev + (c - b.host);
+    return nullptr;
+}
+
+// copy helper: host->device (sync on the ctx stream) or pass-through of a device pointer; host arrays that live in
+// mp_host_alloc memory are passed through as well (the kernels read them over the bus: zero-copy)
 template <typename T>
 inline int stage_in(mp_ctx *ctx, int slot, const T *src, size_t count, int mem, T **dev)
 {
@@ -187,6 +201,11 @@ inline int stage_in(mp_ctx *ctx, int slot, const T *src, size_t count, int mem, 
         *dev = const_cast<T *>(src);
         return MP_OK;
     }
+    if (src)
+        if (void *alias = pinned_alias(ctx, src, count * sizeof(T))) {
+            *dev = static_cast<T *>(alias);
+            return MP_OK;
+        }
     MP_TRY(ws_get(ctx, slot, count, dev));
     if (src) MP_HIP(hipMemcpyAsync(*dev, src, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
     return MP_OK;
@@ -203,6 +222,10 @@ inline int stage_out_alloc(mp_ctx *ctx, int slot, T *dst, size_t count, int mem,
         *dev = nullptr;
         return MP_OK;
     }
+    if (void *alias = pinned_alias(ctx, dst, count * sizeof(T))) { // zero-copy: the kernel writes the caller's array
+        *dev = static_cast<T *>(alias);
+        return MP_OK;
+    }
     return ws_get(ctx, slot, count, dev);
 }
 
@@ -210,6 +233,7 @@ template <typename T>
 inline int stage_out_copy(mp_ctx *ctx, T *dst, const T *dev, size_t count, int mem)
 {
     if (mem == MP_MEM_DEVICE || !dst || !dev) return MP_OK;
+    if (pinned_alias(ctx, dst, count * sizeof(T)) == static_cast<const void *>(dev)) return MP_OK; // written in place
     MP_HIP(hipMemcpyAsync(dst, dev, count * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
     return MP_OK;
 }

@@ -64,7 +64,7 @@ def _pipe_case(ctx, n, seed):
     return (t, r, term), model, roots, rng0
 
 
-@pytest.mark.parametrize("n,chunk,streams", [(70000, None, None), (5000, 1024, 3), (2049, 1024, 8), (3072, 1024, 1)])
+@pytest.mark.parametrize("n,chunk,streams", [(140000, None, None), (5000, 1024, 3), (2049, 1024, 8), (3072, 1024, 1)])
 def test_pipelined_host_plan_equals_the_single_launch(ctx, n, chunk, streams, monkeypatch):
     """VERDICT r2 task 3: mp_uct_plan with host arrays pipelines chunks of roots (H2D -> kernel -> D2H) over side streams.
     A chunk is the same launch on shifted pointers, so everything must be bit-identical to the one-launch call: plans,
@@ -89,7 +89,7 @@ def test_pipelined_host_plan_equals_the_single_launch(ctx, n, chunk, streams, mo
         monkeypatch.setenv("MP_PIPE_STREAMS", str(streams))
     rng_b = rng0.copy()
     out = ctx.uct_plan(model, roots, *args, rng_b, max_plan_len=7)
-    assert ctx.last_kernel_ms()[1] == -(-n // (chunk or 32768)), "the call is expected to run chunked"
+    assert ctx.last_kernel_ms()[1] == -(-n // (chunk or 65536)), "the call is expected to run chunked"
     for k in ref:
         np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
     np.testing.assert_array_equal(rng_b, rng_a)
@@ -102,6 +102,7 @@ def test_pipelined_host_plan_equals_the_single_launch(ctx, n, chunk, streams, mo
     bufs["root_state"][:] = roots
     dev_rng = ctx.device_rng(rng0)
     out2 = ctx.uct_plan(model, bufs["root_state"], *args, dev_rng, out=bufs)
+    assert ctx.last_kernel_ms()[1] == 1, "mp_host_alloc arrays are read / written in place: one launch, no copies"
     assert set(out2) == {"root_state", "plans", "plan_len", "env_steps"}
     for k in ("plans", "plan_len", "env_steps"):
         np.testing.assert_array_equal(out2[k], ref[k], err_msg=k)
@@ -112,6 +113,21 @@ def test_pipelined_host_plan_equals_the_single_launch(ctx, n, chunk, streams, mo
     out3 = ctx.uct_plan(model, bufs["root_state"], *args, dev_rng, out=bufs)
     np.testing.assert_array_equal(out3["plans"], ref2["plans"])
     np.testing.assert_array_equal(dev_rng.get(first=n - 5), rng_c[n - 5:])
+    # the same pinned arrays through the copy path (zero-copy switched off), and pinned generator records on the host side
+    monkeypatch.setenv("MP_NO_ZERO_COPY", "1")
+    dev_rng.set(rng0)
+    out4 = ctx.uct_plan(model, bufs["root_state"], *args, dev_rng, out=bufs)
+    np.testing.assert_array_equal(out4["plans"], ref["plans"])
+    monkeypatch.delenv("MP_NO_ZERO_COPY")
+    pin = ctx.pinned(dict(rng=((n, 6), np.uint64), root_value=((n,), np.float64), counts=((n, model.A), np.int64)))
+    pin["rng"][:] = rng0
+    out5 = ctx.uct_plan(model, bufs["root_state"], *args, pin["rng"], out=dict(root_value=pin["root_value"],
+                                                                              root_child_count=pin["counts"]))
+    assert ctx.last_kernel_ms()[1] == 1
+    np.testing.assert_array_equal(out5["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(out5["root_child_count"], ref["root_child_count"])
+    np.testing.assert_array_equal(pin["rng"], rng_a)
+    pin.close()
     idx = np.random.Generator(np.random.PCG64(1)).choice(n, size=min(n, 512), replace=False)
     chk = oracle.uct_plan_batch(t, r, term, roots[idx], *args, rng0[idx].copy(), max_plan_len=7)
     np.testing.assert_array_equal(ref["plans"][idx], chk["plans"])
@@ -175,5 +191,20 @@ def test_device_rng_with_the_other_planners(ctx):
     with pytest.raises(native.NativeError):
         native._check(ctx._lib.mp_opd_plan(ctx._h, model._h, n, native._ptr(roots), 60, 0.7, 0.0, dev.ptr(), 24, None, None,
                                            None, None, None, None, 7))
+    # zero-copy: every array in mp_host_alloc memory -> the kernel works on the caller's arrays (OPD through the shared
+    # staging helpers; also the state-aware planners)
+    pin = ctx.pinned(dict(roots=((n,), np.int32), rng=((n, 6), np.uint64), plans=((n, 24), np.int32), plan_len=((n,), np.int32),
+                          root_lower=((n,), np.float64), root_upper=((n,), np.float64), env_steps=((n,), np.int64),
+                          status=((n,), np.int32)))
+    pin["roots"][:] = roots
+    pin["rng"][:] = rng0
+    native._check(ctx._lib.mp_opd_plan(ctx._h, model._h, n, native._ptr(pin["roots"]), 60, 0.7, 0.0, native._ptr(pin["rng"]), 24,
+                                       native._ptr(pin["plans"]), native._ptr(pin["plan_len"]), native._ptr(pin["root_lower"]),
+                                       native._ptr(pin["root_upper"]), native._ptr(pin["env_steps"]), native._ptr(pin["status"]),
+                                       native.MP_MEM_HOST))
+    for k in out:
+        np.testing.assert_array_equal(pin[k], ref[k], err_msg="zero-copy " + k)
+    np.testing.assert_array_equal(pin["rng"], rng_h)
+    pin.close()
     dev.close()
     model.close()

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /root/repo
 mkdir -p gpurun_out/r03
-python -m pytest tests/test_gpu_round3.py tests/test_gpu_batch.py tests/test_gpu_agents.py -x -q > gpurun_out/r03/pytest2.log 2>&1
+python -m pytest tests/test_gpu_round3.py tests/test_gpu_env_restrictions.py tests/test_gpu_batch.py tests/test_gpu_agents.py tests/test_gpu_variants.py -x -q > gpurun_out/r03/pytest2.log 2>&1
 echo "pytest rc=$?" >> gpurun_out/r03/pytest2.log
 tail -15 gpurun_out/r03/pytest2.log
 for cfg in "32768 4" "16384 4" "65536 4" "32768 8" "16384 8" "8192 8" "32768 2"; do
