@@ -185,6 +185,10 @@ int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, 
 /* get_state_value (value_iteration.py:37-40): the V-form iteration.  V_out double [S]. */
 int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
                   double *V_out, int32_t mem);
+/* RobustValueIterationAgent.get_state_value (robust_value_iteration.py:32-37): V <- max_a min_m (R_m + gamma next_v_m(V)),
+ * allclose on V, no terminal masking; deterministic and dense models. */
+int mp_vi_solve_v_robust(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                         double *V_out, int32_t mem);
 /*
  * One Bellman backup of a dense (or row-block) model: Q[rows,A] = min_m (R_m + gamma * mask(T_m . V)), the body of
  * bellman_expectation (value_iteration.py:54-55,62-63; robust_value_iteration.py:46-58).  V double [S_cols] in,
@@ -294,6 +298,14 @@ int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes,
 int mp_model_load_joint(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition, const double *reward,
                         const uint8_t *terminal, int32_t done_on_next, mp_model **out);
 /*
+ * Models that restrict their available actions: JointEnv.get_available_actions (robust.py:22-25) lists, for a joint
+ * state, the UNION of what each model's env lists in its own state (a model without get_available_actions lists every
+ * action); DeterministicNode.expand (deterministic.py:32-35) creates one child per listed action.
+ *   available uint8 [M,S,A], host pointer; every (model, state) needs at least one action.  A tree node has
+ *   n_children <= A children (mp_ropd_tree_export), env_steps counts one joint step per real child.
+ */
+int mp_model_set_available_joint(mp_model *model, const uint8_t *available);
+/*
  * DiscreteRobustPlanner.plan (agents/robust/robust.py:28-40 over tree_search/deterministic.py:116-122) for n_roots
  * independent roots of a joint model: budget // A times { leaf = first maximal min_m U among the leaves (robust.py:37,
  * RobustNode.get_value_upper_bound :45-46); DeterministicNode.expand (deterministic.py:28-43) with the ndarray branch of
@@ -307,10 +319,11 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
                  double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status, int32_t mem);
 /* Tree of root `root` after the last mp_ropd_plan, creation order (A children per expanded node); host arrays of capacity
  * `cap` nodes; state / reward / lower / upper / done are [cap,M]: a leaf's per-model values, an expanded node's
- * backed-up scalars repeated M times. */
+ * backed-up scalars repeated M times; n_children: children per node (contiguous from first_child; < A with restricted
+ * action sets). */
 int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                         int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
-                        int64_t *count, int32_t *first_child);
+                        int64_t *count, int32_t *first_child, int32_t *n_children);
 
 /* ---------------------------------------------------------------- state-aware OPD ----------- */
 /*

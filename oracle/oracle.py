@@ -112,9 +112,9 @@ def vi_solve(mode, transition, reward, terminal=None, gamma=1.0, iterations=100,
     term = None if (terminal is None or robust) else _u8(terminal)
     if state_value:
         out = np.zeros(s, dtype=np.float64)
-        rc = lib().orc_vi_solve_v(mode_i, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
-                                  _p(reward, C.c_double), _p(term, C.c_uint8), C.c_double(gamma), int(iterations),
-                                  C.c_double(rtol), C.c_double(atol), _p(out, C.c_double))
+        rc = lib().orc_vi_solve_v(mode_i, m, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
+                                  _p(reward, C.c_double), _p(term, C.c_uint8), int(bool(robust)), C.c_double(gamma),
+                                  int(iterations), C.c_double(rtol), C.c_double(atol), _p(out, C.c_double))
         assert rc == 0
         return out
     q = np.zeros((s, a), dtype=np.float64)
@@ -436,11 +436,13 @@ def saopd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_r
 
 
 def ropd_plan(transitions, rewards, terminals, s0, budget, gamma, terminal_reward=0.0, rng_state=None,
-              done_rule="source", max_plan_len=1024):
+              done_rule="source", max_plan_len=1024, available=None):
     """DiscreteRobustPlanner.plan for one root over M models (agents/robust/robust.py:28-50).
-    transitions int [M,S,A], rewards [M,S,A], terminals [M,S] or None, s0 int [M] (the joint state)."""
+    transitions int [M,S,A], rewards [M,S,A], terminals [M,S] or None, s0 int [M] (the joint state).
+    available: bool [M,S,A], each model's own get_available_actions(); the joint env lists their union (robust.py:22-25)."""
     t, r = _i64(transitions), _f64(rewards)
     m, s, a = r.shape
+    av = None if available is None else _u8(np.asarray(available).reshape(m, s, a))
     term = None if terminals is None else _u8(np.asarray(terminals).reshape(m, s))
     s0 = np.ascontiguousarray(np.broadcast_to(np.asarray(s0, dtype=np.int32), (m,)))
     cap = 1 + (budget // a) * a
@@ -451,27 +453,28 @@ def ropd_plan(transitions, rewards, terminals, s0, budget, gamma, terminal_rewar
     tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros((cap, m), np.int32),
                 depth=np.zeros(cap, np.int32), reward=np.zeros((cap, m), np.float64), lower=np.zeros((cap, m), np.float64),
                 upper=np.zeros((cap, m), np.float64), done=np.zeros((cap, m), np.uint8), count=np.zeros(cap, np.int64),
-                first_child=np.zeros(cap, np.int32))
+                first_child=np.zeros(cap, np.int32), n_children=np.zeros(cap, np.int32))
     rc = lib().orc_ropd_plan(m, s, a, _p(t, C.c_int64), _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"),
                              _p(s0, C.c_int32), int(budget), C.c_double(gamma), C.c_double(terminal_reward),
                              _p(rng, C.c_uint64), max_plan_len, _p(plan, C.c_int32), C.byref(plan_len), C.byref(lo),
                              C.byref(up), C.byref(steps), _p(tree["parent"], C.c_int32), _p(tree["action"], C.c_int32),
                              _p(tree["state"], C.c_int32), _p(tree["depth"], C.c_int32), _p(tree["reward"], C.c_double),
                              _p(tree["lower"], C.c_double), _p(tree["upper"], C.c_double), _p(tree["done"], C.c_uint8),
-                             _p(tree["count"], C.c_int64), _p(tree["first_child"], C.c_int32), C.byref(nn))
+                             _p(tree["count"], C.c_int64), _p(tree["first_child"], C.c_int32), C.byref(nn),
+                             _p(av, C.c_uint8), _p(tree["n_children"], C.c_int32))
     if rc == ERR_REWARD_RANGE:
         raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")
     assert rc == 0, rc
     tree = {k: v[:nn.value] for k, v in tree.items()}
-    tree["n_children"] = np.where(tree["first_child"] >= 0, a, 0).astype(np.int32)
     return dict(plan=plan[:plan_len.value].copy(), root_lower=lo.value, root_upper=up.value, env_steps=steps.value,
                 rng_after=rng, tree=tree)
 
 
 def ropd_plan_batch(transitions, rewards, terminals, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
-                    done_rule="source", max_plan_len=32, n_threads=1):
+                    done_rule="source", max_plan_len=32, n_threads=1, available=None):
     t, r = _i64(transitions), _f64(rewards)
     m, s, a = r.shape
+    av = None if available is None else _u8(np.asarray(available).reshape(m, s, a))
     term = None if terminals is None else _u8(np.asarray(terminals).reshape(m, s))
     s0 = np.ascontiguousarray(np.asarray(s0, dtype=np.int32).reshape(-1, m))
     n = len(s0)
@@ -485,5 +488,5 @@ def ropd_plan_batch(transitions, rewards, terminals, s0, budget, gamma, terminal
                               n, _p(s0, C.c_int32), int(budget), C.c_double(gamma), C.c_double(terminal_reward),
                               _p(rng, C.c_uint64), max_plan_len, _p(plans, C.c_int32), _p(plan_len, C.c_int32),
                               _p(lo, C.c_double), _p(up, C.c_double), _p(steps, C.c_int64), _p(status, C.c_int32),
-                              int(n_threads))
+                              int(n_threads), _p(av, C.c_uint8))
     return dict(plans=plans, plan_len=plan_len, root_lower=lo, root_upper=up, env_steps=steps, status=status, rng_after=rng)

@@ -269,9 +269,9 @@ int orc_vi_solve(int mode, int M, int S, int A, int B, const int64_t *T, const d
     return ORC_OK;
 }
 
-/* value_iteration.py:37-40 get_state_value (V-form iteration) */
-int orc_vi_solve_v(int mode, int S, int A, int B, const int64_t *T, const double *P, const int64_t *NXT,
-                   const double *R, const uint8_t *term, double gamma, int iterations, double rtol,
+/* value_iteration.py:37-40 get_state_value (V-form iteration); robust_value_iteration.py:32-37 with robust = 1 */
+int orc_vi_solve_v(int mode, int M, int S, int A, int B, const int64_t *T, const double *P, const int64_t *NXT,
+                   const double *R, const uint8_t *term, int robust, double gamma, int iterations, double rtol,
                    double atol, double *v_out)
 {
     const long n = (long)S * A;
@@ -279,7 +279,8 @@ int orc_vi_solve_v(int mode, int S, int A, int B, const int64_t *T, const double
     double *scratch = malloc(((S > B ? S : B) + 8) * sizeof(double));
     if (!q || !v || !vn || !scratch) return ORC_ERR_ALLOC;
     for (int it = 0; it < iterations; ++it) {
-        orc_bellman(mode, 1, S, A, B, T, P, NXT, R, term, 0, gamma, v, q, scratch);
+        /* robust: best_action_value(worst_case(bellman_expectation(v))), robust_value_iteration.py:32-37 */
+        orc_bellman(mode, M, S, A, B, T, P, NXT, R, term, robust, gamma, v, q, scratch);
         for (int s = 0; s < S; ++s) {
             double m = q[(long)s * A];
             for (int a = 1; a < A; ++a) if (q[(long)s * A + a] > m) m = q[(long)s * A + a];
@@ -492,13 +493,18 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
                   int64_t *env_steps,
                   int32_t *t_parent, int32_t *t_action, int32_t *t_state, int32_t *t_depth, double *t_reward,
                   double *t_lower, double *t_upper, uint8_t *t_done, int64_t *t_count, int32_t *t_first_child,
-                  int32_t *n_nodes_out)
+                  int32_t *n_nodes_out,
+                  /* restricted action sets: avail [M,S,A] flags of each model's own get_available_actions(); the joint
+                   * environment lists the UNION over the models' current states, ascending (robust.py:22-25); NULL = all.
+                   * t_n_children: children per node (they are contiguous from first_child, keyed by t_action). */
+                  const uint8_t *avail, int32_t *t_n_children)
 {
     const int K = budget / A; /* deterministic.py:118: budget // state.action_space.n */
     const int cap = 1 + K * A;
     int32_t *parent = malloc(cap * sizeof(int32_t)), *action = malloc(cap * sizeof(int32_t));
     int32_t *state = malloc((size_t)cap * M * sizeof(int32_t)), *depth = malloc(cap * sizeof(int32_t));
     int32_t *first_child = malloc(cap * sizeof(int32_t)), *leaves = malloc(cap * sizeof(int32_t));
+    int32_t *n_children = calloc(cap, sizeof(int32_t));
     double *lower = malloc((size_t)cap * M * sizeof(double)), *upper = malloc((size_t)cap * M * sizeof(double));
     double *reward = calloc((size_t)cap * M, sizeof(double));
     uint8_t *done = calloc((size_t)cap * M, 1);
@@ -524,8 +530,14 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
         memmove(leaves + li, leaves + li + 1, (n_leaves - li - 1) * sizeof(int32_t));
         --n_leaves;
         first_child[leaf] = n_nodes;
-        for (int a = 0; a < A && rc == ORC_OK; ++a) { /* deterministic.py:36-43 */
+        for (int a = 0; a < A && rc == ORC_OK; ++a) { /* deterministic.py:32-43 over state.get_available_actions() */
+            if (avail) {
+                int listed = 0;
+                for (int m = 0; m < M; ++m) listed |= avail[((long)m * S + state[(long)leaf * M + m]) * A + a] != 0;
+                if (!listed) continue;
+            }
             const int c = n_nodes++;
+            n_children[leaf] += 1;
             parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1;
             const int d = depth[c];
             ++steps_taken; /* one planner.step (of the joint environment) per child */
@@ -556,7 +568,7 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
         /* deterministic.py:74-79 backup_to_root with RobustNode.get_value_*_bound = np.min (robust.py:42-46) */
         for (int n = leaf; n >= 0; n = parent[n]) {
             double ml = VMIN(lower, first_child[n]), mu = VMIN(upper, first_child[n]);
-            for (int a = 1; a < A; ++a) {
+            for (int a = 1; a < n_children[n]; ++a) {
                 const double l = VMIN(lower, first_child[n] + a), u = VMIN(upper, first_child[n] + a);
                 if (l > ml) ml = l;
                 if (u > mu) mu = u;
@@ -570,11 +582,11 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
         while (first_child[n] >= 0) {
             const int fc = first_child[n];
             double m = VMIN(lower, fc);
-            for (int a = 1; a < A; ++a) { const double l = VMIN(lower, fc + a); if (l > m) m = l; }
+            for (int a = 1; a < n_children[n]; ++a) { const double l = VMIN(lower, fc + a); if (l > m) m = l; }
             int ties[64], nt = 0;
-            for (int a = 0; a < A && nt < 64; ++a) if (VMIN(lower, fc + a) == m) ties[nt++] = a;
+            for (int a = 0; a < n_children[n] && nt < 64; ++a) if (VMIN(lower, fc + a) == m) ties[nt++] = a;
             const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
-            if (plan && len < max_plan_len) plan[len] = a;
+            if (plan && len < max_plan_len) plan[len] = action[fc + a];
             ++len;
             n = fc + a;
         }
@@ -593,6 +605,7 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
         if (t_depth) t_depth[i] = depth[i];
         if (t_count) t_count[i] = count[i];
         if (t_first_child) t_first_child[i] = first_child[i];
+        if (t_n_children) t_n_children[i] = n_children[i];
         for (int m = 0; m < M; ++m) {
             if (t_state) t_state[(long)i * M + m] = state[(long)i * M + m];
             if (t_reward) t_reward[(long)i * M + m] = reward[(long)i * M + m];
@@ -602,7 +615,7 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
         }
     }
     if (n_nodes_out) *n_nodes_out = n_nodes;
-    free(parent); free(action); free(state); free(depth); free(first_child); free(leaves);
+    free(parent); free(action); free(state); free(depth); free(first_child); free(leaves); free(n_children);
     free(lower); free(upper); free(reward); free(done); free(count);
     return rc;
 }
@@ -610,7 +623,7 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
 int orc_ropd_plan_batch(int M, int S, int A, const int64_t *T, const double *R, const uint8_t *term, int done_on_next,
                         int n_roots, const int32_t *s0 /* [n_roots,M] */, int budget, double gamma, double terminal_reward,
                         uint64_t *rng6, int max_plan_len, int32_t *plans, int32_t *plan_len, double *root_lower,
-                        double *root_upper, int64_t *env_steps, int32_t *status, int n_threads)
+                        double *root_upper, int64_t *env_steps, int32_t *status, int n_threads, const uint8_t *avail)
 {
 #pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
     for (int i = 0; i < n_roots; ++i) {
@@ -618,7 +631,7 @@ int orc_ropd_plan_batch(int M, int S, int A, const int64_t *T, const double *R, 
                                rng6 + (long)i * 6, max_plan_len, plans ? plans + (long)i * max_plan_len : NULL,
                                plan_len ? plan_len + i : NULL, root_lower ? root_lower + i : NULL,
                                root_upper ? root_upper + i : NULL, env_steps ? env_steps + i : NULL, NULL, NULL, NULL, NULL,
-                               NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+                               NULL, NULL, NULL, NULL, NULL, NULL, NULL, avail, NULL);
         if (status) status[i] = rc;
     }
     return ORC_OK;

@@ -57,7 +57,8 @@ class RobustValueIterationAgent(ValueIterationAgent):
         return np.argmax(self.get_state_action_value()[state, :])
 
     def get_state_value(self):
-        raise NotImplementedError("the V-form robust iteration is not on the device path; use get_state_action_value")
+        """V <- max_a min_m (R_m + gamma next_v_m(V)) to its fixed point (robust_value_iteration.py:32-37), on the device."""
+        return self.models.ctx.vi_solve_v(self._model(), self.config["gamma"], self.config["iterations"], robust=True)
 
     @staticmethod
     def worst_case(model_action_values):

@@ -48,7 +48,6 @@ class JointEnv(object):
 
 class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
     """robust.py:28-40 for one or many roots of one set of models."""
-    supports_restricted_actions = False
 
     def __init__(self, env, config=None):
         super(DiscreteRobustPlanner, self).__init__(env, config)
@@ -60,11 +59,11 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
         if not envs:
             raise TypeError("the discrete robust planner plans on a JointEnv of at least one model")
         mdps = [device_model.finite_mdp_of(e) for e in envs]
+        masks = []
         for e, mdp in zip(envs, mdps):
             if mdp.mode != "deterministic":
                 raise TypeError("every model must be a deterministic finite MDP, got mode '{}'".format(mdp.mode))
-            if device_model.available_actions_of(e, mdp) is not None:
-                raise NotImplementedError("the robust planner does not handle models that restrict the available actions")
+            masks.append(device_model.available_actions_of(e, mdp))
         shapes = {np.asarray(m.transition).shape for m in mdps}
         if len(shapes) != 1:
             raise ValueError("all models must share the state and action spaces, got tables of shapes {}".format(shapes))
@@ -75,8 +74,13 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
         if len(rules) != 1:     # one terminal convention per joint model (the first model's used to win silently)
             raise ValueError("all models of a joint environment must share one done_rule, got {}".format(sorted(rules)))
         rule = rules.pop()
+        # JointEnv.get_available_actions (robust.py:22-25): the union over the models of what each lists in its own
+        # state; a model whose env has no get_available_actions lists everything
+        available = None
+        if any(m is not None for m in masks):
+            available = np.ascontiguousarray(np.stack([np.ones(t.shape[1:], dtype=bool) if m is None else m for m in masks]))
         h = hashlib.blake2b(digest_size=16)
-        for arr in (t, r, term):
+        for arr in (t, r, term) + (() if available is None else (available,)):
             h.update(arr.view(np.uint8).reshape(-1))
         key = (t.shape, rule, h.hexdigest())
         model = self._joint.get(key)
@@ -85,7 +89,7 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
                 for old in self._joint.values():
                     old.close()
                 self._joint.clear()
-            model = self._joint[key] = self.models.ctx.load_joint(t, r, term, done_rule=rule)
+            model = self._joint[key] = self.models.ctx.load_joint(t, r, term, done_rule=rule, available=available)
         return model, [int(m.state) for m in mdps]
 
     def plan(self, state, observation):

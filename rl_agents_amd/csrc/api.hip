@@ -486,6 +486,37 @@ int mp_model_set_available(mp_model *m, const uint8_t *available)
     return MP_OK;
 }
 
+int mp_model_set_available_joint(mp_model *m, const uint8_t *available)
+{
+    if (!m || !available) return fail(MP_ERR_ARG, "mp_model_set_available_joint: NULL argument");
+    if (m->mode != MP_MODE_DETERMINISTIC || !m->rec_all) return fail(MP_ERR_MODE, "mp_model_set_available_joint: joint models only");
+    mp_ctx *ctx = m->ctx;
+    const int S = m->S, A = m->A, M = m->M;
+    for (long sm = 0; sm < (long)M * S; ++sm) {
+        bool any = false;
+        for (int a = 0; a < A; ++a) any |= available[(size_t)sm * A + a] != 0;
+        if (!any) return fail(MP_ERR_ARG, "mp_model_set_available_joint: model %ld state %ld has no available action", sm / S, sm % S);
+    }
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    uint8_t *d = nullptr;
+    if (hipMalloc(&d, (size_t)M * S * A) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_model_set_available_joint: hipMalloc failed");
+    if (hipMemcpy(d, available, (size_t)M * S * A, hipMemcpyHostToDevice) != hipSuccess) {
+        (void)hipFree(d);
+        return fail(MP_ERR_HIP, "mp_model_set_available_joint: upload failed");
+    }
+    const long sa = (long)S * A;
+    for (int k = 0; k < M; ++k)
+        hipLaunchKernelGGL(pack_records, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T + k * sa,
+                           m->R + k * sa, m->term_all ? (const uint8_t *)(m->term_all + (size_t)k * S) : (const uint8_t *)nullptr,
+                           (const uint8_t *)(d + (size_t)k * sa), m->rec_all + k * sa);
+    const hipError_t e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(MP_ERR_HIP, "mp_model_set_available_joint: pack_records failed");
+    m->masked = true;
+    return MP_OK;
+}
+
 int mp_model_load_dense(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const double *transition,
                         const double *reward, const uint8_t *terminal, int32_t mem, mp_model **out)
 {

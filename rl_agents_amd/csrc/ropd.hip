@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
     }
     __syncthreads();
     int n_nodes = 1, status = MP_OK, k_done = 0;
+    int real_steps = 0; // children of listed actions = planner.step calls of the joint environment
     double cbu = lane == 0 ? 0.0 : ninf; // best leaf of this lane's class (ids == lane mod 64)
     int cbid = lane == 0 ? 0 : 0x7fffffff;
 
@@ -111,7 +112,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
         const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
                      tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
         const int g = n_nodes;
-        bool bad = false;
+        bool bad = false, avail = false;
         double Uc_mine = 0.0;
         if (lane < A) {
             const int c = g + lane;
@@ -122,6 +123,8 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
             for (int m = 0; m < M; ++m) { // JointEnv.step: every model steps its own state (robust.py:13-16)
                 const Rec rc = p.rec[(long)m * SA + (long)Sp[m] * A + lane];
                 const double r = rc.reward;
+                // robust.py:22-25: the joint env lists the UNION of the actions its models list in their own states
+                avail |= (rc.flags & 4u) != 0;
                 bad |= !(0.0 <= r) || !(r <= 1.0); // np.all(0 <= reward), np.all(reward <= 1)
                 const bool dn = (rc.flags & done_bit) != 0;
                 double Lc = Lp[m] + g1d * r;
@@ -137,11 +140,17 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                 if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                 if (m == 0 || Uc < umin) umin = Uc;
             }
+            // deterministic.py:32-35: an action no model lists gets no child; its slot stays in the id space as a PHANTOM
+            // with min L = min U = -inf (never the best leaf, never a maximum of the backup, never a tie of the plan;
+            // dropped by the export) -- see opd.hip
+            bad = bad && avail;
+            if (!avail) { lmin = ninf; umin = ninf; }
             Lmin[c] = lmin;
             meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
             LU(c) = umin;
             Uc_mine = umin;
         }
+        real_steps += __popcll(__ballot(avail));
         if (lane == 0) exp_lds[k] = leaf;
         n_nodes += A;
         k_done = k + 1;
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
     }
     if (lane == 0) {
         if (p.status) p.status[root] = status;
-        if (p.env_steps) p.env_steps[root] = (int64_t)(n_nodes - 1); // one joint step per child (deterministic.py:41)
+        if (p.env_steps) p.env_steps[root] = (int64_t)real_steps; // one joint step per (real) child (deterministic.py:41)
         p.n_nodes_out[root] = n_nodes;
     }
     if (EXPG) {
@@ -267,6 +276,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
     }
     __syncthreads();
     int n_nodes = 1, status = MP_OK, k_done = 0;
+    int real_steps = 0; // children of listed actions = planner.step calls of the joint environment
     double cbu = lane == 0 ? 0.0 : ninf;
     int cbid = lane == 0 ? 0 : 0x7fffffff;
 
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
                      tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
         const int g = n_nodes;
-        bool bad = false;
+        bool bad = false, avail = false;
         double Uc_mine = 0.0;
         if (lane < A) {
             const int c = g + lane;
@@ -310,6 +320,8 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
             for (int m = 0; m < M; ++m) { // JointEnv.step: every model steps its own state (robust.py:13-16)
                 const Rec rc = p.rec[(long)m * SA + (long)Sp[m] * A + lane];
                 const double r = rc.reward;
+                // robust.py:22-25: the joint env lists the UNION of the actions its models list in their own states
+                avail |= (rc.flags & 4u) != 0;
                 bad |= !(0.0 <= r) || !(r <= 1.0); // np.all(0 <= reward), np.all(reward <= 1)
                 const bool dn = (rc.flags & done_bit) != 0;
                 double Lc = Lp[m] + g1d * r;
@@ -325,11 +337,17 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
                 if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                 if (m == 0 || Uc < umin) umin = Uc;
             }
+            // deterministic.py:32-35: an action no model lists gets no child; its slot stays in the id space as a PHANTOM
+            // with min L = min U = -inf (never the best leaf, never a maximum of the backup, never a tie of the plan;
+            // dropped by the export) -- see opd.hip
+            bad = bad && avail;
+            if (!avail) { lmin = ninf; umin = ninf; }
             Lmin[c] = lmin;
             meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
             LU(c) = umin;
             Uc_mine = umin;
         }
+        real_steps += __popcll(__ballot(avail));
         n_nodes += A;
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
@@ -425,7 +443,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
     }
     if (lane == 0) {
         if (q->status) q->status[root] = status;
-        if (q->env_steps) q->env_steps[root] = (int64_t)(n_nodes - 1);
+        if (q->env_steps) q->env_steps[root] = (int64_t)real_steps;
         q->n_nodes_out[root] = n_nodes;
     }
     for (int k = k_done + lane; k < q->K; k += 64) exp_map[k] = -1;
@@ -538,7 +556,7 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
 
 int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                         int32_t *state, int32_t *depth, double *reward, double *lower, double *upper, uint8_t *done,
-                        int64_t *count, int32_t *first_child)
+                        int64_t *count, int32_t *first_child, int32_t *n_children)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
     if (ctx->tree.kind != 3) return fail(MP_ERR_ARG, "mp_ropd_tree_export: no robust OPD tree on this ctx");
@@ -550,7 +568,6 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
     const int32_t *d_exp = (const int32_t *)ctx->ws[WS_TREE7].p;
     int32_t n = 0;
     MP_HIP(hipMemcpy(&n, d_exp + (size_t)NR * (K > 0 ? K : 1) + root, sizeof(int32_t), hipMemcpyDeviceToHost));
-    if (n > cap) return fail(MP_ERR_ARG, "mp_ropd_tree_export: capacity %d < %d nodes", cap, n);
     const long base = (long)root * tcap;
     auto pull = [&](void *dst, int slot, size_t elt) -> int {
         MP_HIP(hipMemcpy(dst, (const char *)ctx->ws[slot].p + base * elt, (size_t)n * elt, hipMemcpyDeviceToHost));
@@ -577,28 +594,50 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
                 if (umin[fc[i] + a] > m) m = umin[fc[i] + a];
             umin[i] = m;
         }
-    std::vector<int64_t> sz((size_t)n, 1);
-    for (int i = n - 1; i >= 1; --i) sz[par[i]] += sz[i];
+    // slots of actions no model lists (deterministic.py:32-35 over JointEnv.get_available_actions) are phantoms with
+    // min L = -inf: not nodes of the tree
+    std::vector<int32_t> id((size_t)n, -1);
+    int kept = 0;
+    for (int i = 0; i < n; ++i)
+        if (!(lmin[i] == -INFINITY)) id[i] = kept++;
+    if (kept > cap) return fail(MP_ERR_ARG, "mp_ropd_tree_export: capacity %d < %d nodes", cap, kept);
+    std::vector<int64_t> sz((size_t)n, 0);
+    for (int i = n - 1; i >= 0; --i) {
+        if (id[i] < 0) continue;
+        sz[i] += 1;
+        if (i > 0) sz[par[i]] += sz[i];
+    }
     for (int i = 0; i < n; ++i) {
+        if (id[i] < 0) continue;
+        const int o = id[i];
         const int d = meta[2 * i];
-        if (parent) parent[i] = par[i];
-        if (action) action[i] = i == 0 ? -1 : (i - 1) % A;
-        if (depth) depth[i] = d;
-        if (count) count[i] = i == 0 ? sz[0] : 1 + sz[i];
-        if (first_child) first_child[i] = fc[i];
+        if (parent) parent[o] = i == 0 ? -1 : id[par[i]];
+        if (action) action[o] = i == 0 ? -1 : (i - 1) % A;
+        if (depth) depth[o] = d;
+        if (count) count[o] = i == 0 ? sz[0] : 1 + sz[i];
+        int first = -1, nc = 0;
+        if (fc[i] >= 0)
+            for (int a = 0; a < A; ++a) {
+                const int c = id[fc[i] + a];
+                if (c < 0) continue;
+                if (first < 0) first = c;
+                ++nc;
+            }
+        if (first_child) first_child[o] = first;
+        if (n_children) n_children[o] = nc;
         for (int m = 0; m < M; ++m) {
             const bool dn = ((uint32_t)meta[2 * i + 1] >> m) & 1u;
-            const size_t j = (size_t)i * M + m;
-            if (state) state[j] = sv[j];
-            if (reward) reward[j] = rv[j];
-            if (done) done[j] = (uint8_t)dn;
+            const size_t j = (size_t)i * M + m, jo = (size_t)o * M + m;
+            if (state) state[jo] = sv[j];
+            if (reward) reward[jo] = rv[j];
+            if (done) done[jo] = (uint8_t)dn;
             // a leaf keeps its vectors (U recomputed as update() computed it, deterministic.py:51-59: same host
             // operations as the planning tables); an expanded node holds the backed-up scalars
-            if (lower) lower[j] = fc[i] >= 0 ? lmin[i] : lv[j];
-            if (upper) upper[j] = fc[i] >= 0 ? umin[i] : (i == 0 ? 0.0 : (dn ? lv[j] : lv[j] + pow(gamma, (double)d) / (1 - gamma)));
+            if (lower) lower[jo] = fc[i] >= 0 ? lmin[i] : lv[j];
+            if (upper) upper[jo] = fc[i] >= 0 ? umin[i] : (i == 0 ? 0.0 : (dn ? lv[j] : lv[j] + pow(gamma, (double)d) / (1 - gamma)));
         }
     }
-    if (n_nodes) *n_nodes = n;
+    if (n_nodes) *n_nodes = kept;
     return MP_OK;
 }
 

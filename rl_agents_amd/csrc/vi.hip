@@ -996,6 +996,12 @@ int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations
     return mp::vi_run(ctx, model, gamma, iterations, rtol, atol, 0, 1, nullptr, V_out, nullptr, mem);
 }
 
+int mp_vi_solve_v_robust(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                         double *V_out, int32_t mem)
+{
+    return mp::vi_run(ctx, model, gamma, iterations, rtol, atol, 1, 1, nullptr, V_out, nullptr, mem);
+}
+
 int mp_vi_sweeps(mp_ctx *ctx, mp_model *model, double gamma, int32_t sweeps, int32_t robust)
 {
     // negative tolerances: |a - b| <= atol + rtol |b| is never true, so no sweep is skipped

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mp_model_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i32), P(c_i32), P(c_i32)]),
     "mp_vi_solve": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, c_i32, _vp, _vp, c_i32]),
     "mp_vi_solve_v": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, c_i32]),
+    "mp_vi_solve_v_robust": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, c_i32]),
     "mp_vi_sweeps": (C.c_int, [_vp, _vp, c_f64, c_i32, c_i32]),
     "mp_uct_plan": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, c_i32]),
@@ -60,7 +61,8 @@ SIGNATURES = {
     "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_model_load_joint": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
     "mp_ropd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp, c_i32]),
-    "mp_ropd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_ropd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_model_set_available_joint": (C.c_int, [_vp, _vp]),
     "mp_saopd_create": (C.c_int, [_vp, _vp, c_i32, P(_vp)]),
     "mp_saopd_free": (C.c_int, [_vp]),
     "mp_saopd_plan": (C.c_int, [_vp, _vp, _vp, c_i32, c_f64, c_f64, c_f64, c_i32, c_i32, _vp, c_i32, _vp, _vp, _vp, _vp,
@@ -272,9 +274,10 @@ class Context(object):
             model.available = av.astype(bool)
         return model
 
-    def load_joint(self, transitions, rewards, terminals=None, done_rule="source"):
+    def load_joint(self, transitions, rewards, terminals=None, done_rule="source", available=None):
         """A joint environment of M models (agents/robust/robust.py:9-26): transitions int [M,S,A], rewards [M,S,A],
-        terminals [M,S] (each model's own flags) or None."""
+        terminals [M,S] (each model's own flags) or None.  available: bool [M,S,A], what each model's env lists in
+        get_available_actions() (the joint env lists the union over its models' states, robust.py:22-25); None = all."""
         t = np.ascontiguousarray(transitions, dtype=np.int64)
         r = np.ascontiguousarray(rewards, dtype=np.float64)
         if t.shape != r.shape or t.ndim != 3:
@@ -284,7 +287,12 @@ class Context(object):
         h = _vp()
         _check(self._lib.mp_model_load_joint(self._h, m, s, a, _ptr(t), _ptr(r), _ptr(term), int(done_rule == "next"),
                                              C.byref(h)))
-        return Model(self, h, MODE_DETERMINISTIC, m, s, a, 0)
+        model = Model(self, h, MODE_DETERMINISTIC, m, s, a, 0)
+        if available is not None:
+            av = np.ascontiguousarray(np.asarray(available).reshape(m, s, a).astype(np.uint8))
+            _check(self._lib.mp_model_set_available_joint(h, _ptr(av)))
+            model.available = av.astype(bool)
+        return model
 
     def load_dense(self, transition, reward, terminal=None):
         """Dense model: transition float [S,A,S] or [M,S,A,S] (numpy -> copied; torch cuda tensor -> borrowed)."""
@@ -378,10 +386,11 @@ class Context(object):
             raise NativeError(MP_ERR_HIP, "value iteration failed on the device (sweeps = {})".format(int(sweeps[0])))
         return q, int(sweeps[0])
 
-    def vi_solve_v(self, model, gamma, iterations, rtol=1e-5, atol=1e-8):
+    def vi_solve_v(self, model, gamma, iterations, rtol=1e-5, atol=1e-8, robust=False):
+        """get_state_value: value_iteration.py:37-40, or robust_value_iteration.py:32-37 with robust=True."""
         v = np.zeros(model.S, dtype=np.float64)
-        _check(self._lib.mp_vi_solve_v(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
-                                       _ptr(v), MP_MEM_HOST))
+        fn = self._lib.mp_vi_solve_v_robust if robust else self._lib.mp_vi_solve_v
+        _check(fn(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol), _ptr(v), MP_MEM_HOST))
         return v
 
     def vi_solve_device(self, model, gamma, iterations, q_out, sweeps_out, robust=False, rtol=1e-5, atol=1e-8):
@@ -559,15 +568,13 @@ class Context(object):
         t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros((cap, m), np.int32),
                  depth=np.zeros(cap, np.int32), reward=np.zeros((cap, m), np.float64), lower=np.zeros((cap, m), np.float64),
                  upper=np.zeros((cap, m), np.float64), done=np.zeros((cap, m), np.uint8), count=np.zeros(cap, np.int64),
-                 first_child=np.zeros(cap, np.int32))
+                 first_child=np.zeros(cap, np.int32), n_children=np.zeros(cap, np.int32))
         n = c_i32()
         _check(self._lib.mp_ropd_tree_export(self._h, int(root), int(cap), C.byref(n), _ptr(t["parent"]),
                                              _ptr(t["action"]), _ptr(t["state"]), _ptr(t["depth"]), _ptr(t["reward"]),
                                              _ptr(t["lower"]), _ptr(t["upper"]), _ptr(t["done"]), _ptr(t["count"]),
-                                             _ptr(t["first_child"])))
-        t = {k: v[:n.value].copy() for k, v in t.items()}
-        t["n_children"] = np.where(t["first_child"] >= 0, int(t["action"].max(initial=-1)) + 1, 0).astype(np.int32)
-        return t
+                                             _ptr(t["first_child"]), _ptr(t["n_children"])))
+        return {k: v[:n.value].copy() for k, v in t.items()}
 
     def opd_tree(self, root, cap):
         t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), state=np.zeros(cap, np.int32),

@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Golden vectors of the round-3 additions, produced by the UNMODIFIED reference (same set-up as make_golden.py; a
+separate script and file so that the earlier fixtures stay byte-identical):
+
+    PYTHONDONTWRITEBYTECODE=1 python3 tests/golden/gen/make_golden_round3.py
+
+  round3.npz
+    rvi_v/*          RobustValueIterationAgent.get_state_value (robust_value_iteration.py:32-37) on the model lists of
+                     vi.npz's rvi/* cases (inputs are read from there)
+    robust_masked/*  DiscreteRobustPlanner over joint environments whose models restrict their available actions: the
+                     joint env lists the union (agents/robust/robust.py:22-25), DeterministicNode.expand creates one
+                     child per listed action (deterministic.py:32-35)
+"""
+import json
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+
+import make_golden as mg  # noqa: E402  (sets up sys.path for the reference, the stubs and this repo)
+import make_golden_robust as mgr  # noqa: E402
+from make_golden_variants import make_masked_env  # noqa: E402
+from rl_agents.agents.common.factory import agent_factory  # noqa: E402
+from rl_agents.agents.robust.robust import DiscreteRobustPlanner  # noqa: E402
+from rl_agents_amd.envs import generators  # noqa: E402
+
+
+def golden_rvi_v(store):
+    z = np.load(os.path.join(mg.REPO, "tests", "golden", "vi.npz"))
+    names = [str(n) for n in z["rvi/names"]]
+    for name in names:
+        p = "rvi/" + name
+        mode = str(z[p + "/mode"])
+        models = [dict(mode=mode, transition=t.tolist(), reward=r.tolist())
+                  for t, r in zip(z[p + "/transitions"], z[p + "/rewards"])]
+        env = mg.make_env(dict(mode="deterministic", transition=[[0]], reward=[[0.0]]))
+        agent = agent_factory(env, dict(__class__=mg.RVI, models=models, gamma=float(z[p + "/gamma"]),
+                                        iterations=int(z[p + "/iterations"])))
+        v = np.array(agent.get_state_value(), dtype=np.float64)
+        store["rvi_v/{}/V".format(name)] = v
+    store["rvi_v/names"] = np.asarray(names)
+
+
+def robust_keyed_tree(root, m):
+    """make_golden_robust.robust_tree + the per-node child count (children are keyed by the listed actions)."""
+    t = mgr.robust_tree(root, m)
+    nodes, i = [root], 0
+    while i < len(nodes):
+        nodes.extend(nodes[i].children.values())
+        i += 1
+    t["n_children"] = np.asarray([len(n.children) for n in nodes], np.int32)
+    return t
+
+
+def golden_robust_masked(store):
+    names = []
+    large1 = {k: v for k, v in mg.load_env_config("large/env_1.json").items() if k != "max_steps"}
+    large2 = {k: v for k, v in mg.load_env_config("large/env_2.json").items() if k != "max_steps"}
+    hw = generators.highway_shaped(3, 4, 10, seed=3)
+    hw2 = generators.rewire(hw, 0.15, seed=10)
+    g1 = generators.random_deterministic(60, 4, seed=31, terminal_rate=0.1)
+    g2 = generators.random_deterministic(60, 4, seed=32, terminal_rate=0.1)
+    g3 = generators.random_deterministic(60, 4, seed=33)
+    av_l1 = generators.random_available(100, 5, seed=1, rate=0.5)
+    av_l2 = generators.random_available(100, 5, seed=2, rate=0.5)
+    av_hw = generators.highway_available(hw)
+    av_g = [generators.random_available(60, 4, seed=s, rate=0.6) for s in (7, 8, 9)]
+    cases = [
+        # name, [(model config, availability table or None = the model env has no get_available_actions)], s0, planner config, seed
+        ("large_pair_b100", [(large1, av_l1), (large2, av_l2)], 0, dict(budget=100, gamma=0.8), 0),
+        ("large_pair_b500", [(large1, av_l1), (large2, av_l2)], 7, dict(budget=500, gamma=0.8), 1),
+        ("large_same_mask", [(large1, av_l1), (large2, av_l1)], 42, dict(budget=300, gamma=0.9), 2),
+        ("highway_pair", [(hw, av_hw), (hw2, av_hw)], 0, dict(budget=300, gamma=0.8), 0),
+        ("highway_corner_tr05", [(hw, av_hw), (hw2, av_hw)], 119 - 9, dict(budget=300, gamma=0.9, terminal_reward=0.5), 3),
+        ("garnet_triple", [(g1, av_g[0]), (g2, av_g[1]), (g3, av_g[2])], 5, dict(budget=240, gamma=0.85, terminal_reward=0.25), 2),
+        ("garnet_one_unrestricted", [(g1, av_g[0]), (g2, None)], 9, dict(budget=200, gamma=0.85), 4),   # union = all actions
+        ("single_model", [(large1, av_l2)], 3, dict(budget=200, gamma=0.8), 4),
+    ]
+    for name, models, s0, pcfg, seed in cases:
+        envs = [mg.make_env(c, state=s0) if av is None else make_masked_env(c, av, state=s0) for c, av in models]
+        joint = mgr.JointEnv5(envs)
+        planner = DiscreteRobustPlanner(joint, dict(dict(terminal_reward=0), **pcfg))
+        planner.seed(seed)
+        st0 = mg.rng_state(planner.np_random)
+        planner.step_by_reset()
+        plan = planner.plan(joint, s0)
+        root = planner.root
+        m = len(models)
+        p = "robust_masked/" + name
+        s_, a_ = np.asarray(models[0][0]["reward"]).shape
+        avail = np.stack([np.ones((s_, a_), bool) if av is None else np.asarray(av, bool) for _, av in models])
+        for i, (c, _) in enumerate(models):
+            mg.put_mdp(store, "{}/mdp{}".format(p, i), c)
+        mg.put(store, p, dict(n_models=m, s0=s0, seed=seed, budget=planner.config["budget"], gamma=planner.config["gamma"],
+                              terminal_reward=planner.config.get("terminal_reward", 0), available=avail,
+                              has_mask=np.asarray([av is not None for _, av in models]),
+                              plan=np.asarray(plan, np.int32), root_lower=float(np.min(root.value_lower)),
+                              root_upper=float(np.min(root.value_upper)), root_count=root.count,
+                              env_steps=len(planner.observations), rng_before=st0,
+                              rng_after=mg.rng_state(planner.np_random)))
+        mg.put(store, p + "/tree", robust_keyed_tree(root, m))
+        names.append(name)
+    store["robust_masked/names"] = np.asarray(names)
+
+
+def main():
+    store = {}
+    golden_rvi_v(store)
+    golden_robust_masked(store)
+    for extra in ("golden_env_side", "golden_state_aware_masked", "golden_uct_stochastic"):
+        fn = globals().get(extra)
+        if fn is not None:
+            fn(store)
+    path = os.path.join(mg.REPO, "tests", "golden", "round3.npz")
+    np.savez_compressed(path, **store)
+    print("{}: {} arrays, {:.1f} KB".format(path, len(store), os.path.getsize(path) / 1024))
+
+
+if __name__ == "__main__":
+    main()
