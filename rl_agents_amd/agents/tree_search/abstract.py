@@ -202,11 +202,50 @@ class AbstractPlanner(Configurable):
         mdp = device_model.finite_mdp_of(state)
         if mdp.mode != "deterministic":
             raise TypeError("tree search on the device needs a deterministic finite MDP, got mode '{}'".format(mdp.mode))
-        available = device_model.available_actions_of(state, mdp)
+        available, order = device_model.availability_of(state, mdp)
         if available is not None and not self.supports_restricted_actions:
             raise NotImplementedError("this planner does not handle environments that restrict the available actions")
         return self.models.get(device_model.spec_from_mdp(mdp, max_steps=device_model.env_max_steps(state),
-                                                          available=available))
+                                                          available=available, action_order=order))
+
+    # An environment that lists its actions in a non-ascending order is planned on in the permuted action space (see
+    # device_model.TableSpec.action_order): labels are mapped back here, at the planner's boundary.
+    @staticmethod
+    def action_order(model):
+        return getattr(model, "action_order", None)
+
+    @classmethod
+    def relabel(cls, out, model):
+        """Device labels -> the environment's action ids in a batch result (plans, per-action root statistics)."""
+        order = cls.action_order(model)
+        if order is None:
+            return out
+        plans = out["plans"]
+        out["plans"] = np.where(plans >= 0, order[np.maximum(plans, 0)], -1).astype(plans.dtype)
+        for k in ("root_child_count", "root_child_value"):
+            if k in out:
+                back = np.empty_like(out[k])
+                back[:, order] = out[k]
+                out[k] = back
+        return out
+
+    @classmethod
+    def device_actions(cls, actions, model):
+        """Environment action ids -> device labels (for re-rooting kept trees)."""
+        order = cls.action_order(model)
+        if order is None:
+            return actions
+        inv = np.empty_like(order)
+        inv[order] = np.arange(len(order))
+        return inv[np.asarray(actions, dtype=np.int64)]
+
+    @classmethod
+    def relabel_tree(cls, arrays, model):
+        order = cls.action_order(model)
+        if order is not None:
+            act = arrays["action"]
+            arrays["action"] = np.where(act >= 0, order[np.maximum(act, 0)], act).astype(act.dtype)
+        return arrays
 
     def plan(self, state, observation):
         """Plan from the current state of the environment object ``state`` (never stepped, never copied)."""

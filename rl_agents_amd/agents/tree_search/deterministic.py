@@ -30,7 +30,8 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
         if (out["status"] == native.ERR_REWARD_RANGE).any():
             raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
         out["rng_states"] = rng_states
-        self.last, self._root, self._last_actions = out, None, model.A
+        self.relabel(out, model)
+        self.last, self._root, self._last_actions, self._last_model = out, None, model.A, model
         self.claim_device_tree()
         self.env_steps += int(out["env_steps"].sum())
         return out
@@ -39,7 +40,7 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
         self.require_device_tree()
         a = self._last_actions
         cap = 1 + (int(self.config["budget"]) // a) * a
-        arrays = self.models.ctx.opd_tree(root, cap)
+        arrays = self.relabel_tree(self.models.ctx.opd_tree(root, cap), getattr(self, "_last_model", None))
         arrays["value_lower"], arrays["value_upper"] = arrays["lower"], arrays["upper"]
         return build_tree(arrays, "lower", extra=("value_lower", "value_upper", "reward", "done", "state"))
 

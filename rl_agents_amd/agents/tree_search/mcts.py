@@ -122,7 +122,7 @@ class MCTS(AbstractPlanner):
         if not live or not self.owns_device_tree() or self._tree_roots != 1:
             self.step_by_reset()
             return
-        self.models.ctx.uct_step_tree([int(action)])
+        self.models.ctx.uct_step_tree(self.device_actions([int(action)], getattr(self, "_last_model", None)))
         self.last, self._root = None, None
         self._armed = True
 
@@ -135,20 +135,25 @@ class MCTS(AbstractPlanner):
         ctx = self.models.ctx
         armed, self._armed = self._armed and n == 1, False
         if keep_actions is not None and self.owns_device_tree():
-            ctx.uct_step_tree(keep_actions)             # batched callers hand the executed actions over here
+            ctx.uct_step_tree(self.device_actions(keep_actions, model))   # batched callers hand the executed actions over here
         elif not (armed and self.owns_device_tree()):
             ctx.uct_reset_tree()
         available = getattr(model, "available", None)
         if self.policy_source is not None or available is not None:
             if self.policy_source is not None:
-                prior, rollout = self.policy_source(state, model)      # (restricted to the available actions there)
-                listed = available
+                prior, rollout = self.policy_source(state, model)      # (restricted to the available actions there;
+                listed = available                                     #  columns in the model's listing order)
             else:
                 prior, rollout, listed = self.restricted_policy_tables(model, available)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
                                None, None, rng_states, root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1),
                                policy=self.device_policy(model, prior, rollout, listed))
-            self._last_tables = (np.asarray(device_model.finite_mdp_of(state).transition), prior,
+            order = self.action_order(model)
+            prior_ids = prior
+            if order is not None:                       # export works in the environment's action ids
+                prior_ids = np.empty_like(prior)
+                prior_ids[:, order] = prior
+            self._last_tables = (np.asarray(device_model.finite_mdp_of(state).transition), prior_ids,
                                  np.asarray(root_states, dtype=np.int64))
         else:
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
@@ -157,6 +162,8 @@ class MCTS(AbstractPlanner):
                                root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1))
             self._last_tables = None
         out["rng_states"] = rng_states
+        self.relabel(out, model)
+        self._last_model = model
         self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
         self._tree_roots = n
         self.claim_device_tree()
@@ -167,8 +174,14 @@ class MCTS(AbstractPlanner):
         """(prior, rollout, listed) tables of this planner's policy configs on a restricted-action model, kept per model."""
         hit = self._restricted.get(id(model))
         if hit is None or hit[0] is not model:
-            prior, listed = policy_tables(self.prior_policy, available)
-            rollout, _ = policy_tables(self.rollout_policy, available)
+            order = self.action_order(model)
+
+            def on_device(cfg):     # a preference policy names an environment action id: its column on the device
+                if order is not None and cfg.get("type") == "preference" and 0 <= cfg["action"] < len(order):
+                    return dict(cfg, action=int(np.flatnonzero(order == cfg["action"])[0]))
+                return cfg
+            prior, listed = policy_tables(on_device(self.prior_policy), available)
+            rollout, _ = policy_tables(on_device(self.rollout_policy), available)
             if len(self._restricted) >= 4:
                 self._restricted.clear()
             hit = self._restricted[id(model)] = (model, prior, rollout, listed)
@@ -206,7 +219,7 @@ class MCTS(AbstractPlanner):
         if not actions:
             return []
         self.require_device_tree()
-        tree = self.models.ctx.uct_tree(0)
+        tree = self.relabel_tree(self.models.ctx.uct_tree(0), getattr(self, "_last_model", None))
         node = 0
         for a in actions:       # creation-order arrays: children of `node` are contiguous from first_child
             fc, k = int(tree["first_child"][node]), int(tree["n_children"][node])
@@ -251,7 +264,7 @@ class MCTS(AbstractPlanner):
 
     def _export_open_loop(self, root=0):
         self.require_device_tree()
-        arrays = self.models.ctx.uct_tree(root)
+        arrays = self.relabel_tree(self.models.ctx.uct_tree(root), getattr(self, "_last_model", None))
         if self._last_tables is None:
             return build_tree(arrays, "value", prior=policy_probabilities(self.prior_policy, self._last_actions))
         # per-state priors: a child's prior is the prior agent's probability of its action in the state of its

@@ -63,6 +63,9 @@ class MCTSWithPriorPolicyAgent(MCTSAgent):
         """(prior, rollout) tables for the model behind ``state``: one distribution serves both (:31-32)."""
         self.prior_agent.env = state                    # "reset prior agent environment" (:49)
         table = tabulate_prior_agent(self.prior_agent, model.S, model.A)
+        order = getattr(model, "action_order", None)
+        if order is not None:           # the model's columns are in the environment's listing order (device_model)
+            table = np.ascontiguousarray(table[:, order])
         available = getattr(model, "available", None)
         if available is not None:
             # agent_policy_available (:56-62): the distribution over the available actions, renormalised by numpy's sum

@@ -107,6 +107,96 @@ def golden_robust_masked(store):
     store["robust_masked/names"] = np.asarray(names)
 
 
+def golden_env_side(store):
+    """The reference's agents planning DIRECTLY on an environment with highway-env's surface (HighwayLikeEnv: restriction
+    on the env, listed IDLE-first, to_finite_mdp() without an availability table): what a device planner has to
+    reproduce when it derives the table and the listing order from the env (device_model.availability_of)."""
+    import prior_agents  # noqa: F401
+    from make_golden_variants import OPD_FIELDS, UCT_FIELDS, keyed_tree, store_uct_case
+    from rl_agents_amd.envs import HighwayLikeEnv
+    small = generators.highway_shaped(3, 4, 10, seed=3)
+    mid = generators.highway_shaped(5, 5, 20, seed=4)
+    pref3 = {"type": "preference", "action": 3, "ratio": 2.5}
+    rnd = {"type": "random"}
+    unames = []
+    ucases = [
+        ("small_s0", small, 0, dict(budget=1000, horizon=30, episodes=33), [0, 1]),
+        ("small_corner", small, 119 - 9, dict(budget=400), [2]),
+        ("small_pref", small, 41, dict(budget=300, prior_policy=pref3, rollout_policy=pref3), [5]),
+        ("small_rollout_random", small, 13, dict(budget=300, rollout_policy=rnd), [3]),
+        ("mid_s22", mid, 22, dict(budget=1000, horizon=30, episodes=33), [0]),
+        ("mid_closed", mid, 3, dict(budget=600, closed_loop=True), [1]),
+    ]
+    for name, table, s0, acfg, seeds in ucases:
+        for seed in seeds:
+            env = HighwayLikeEnv(table=table, state=s0)
+            agent = agent_factory(env, dict(acfg, __class__=mg.UCT))
+            p = "env_side/uct/{}_seed{}".format(name, seed)
+            store_uct_case(store, p, table, env, agent, seed, s0, 0,
+                           dict(shape=np.asarray(table["original_shape"]), listing=np.asarray(env.get_available_actions())))
+            store[p + "/prior_policy_json"] = np.asarray(json.dumps(agent.config["prior_policy"]))
+            store[p + "/rollout_policy_json"] = np.asarray(json.dumps(agent.config["rollout_policy"]))
+            assert env.state_index == s0 and env.steps == 0
+            unames.append("{}_seed{}".format(name, seed))
+    store["env_side/uct/names"] = np.asarray(unames)
+    # receding horizon with tree re-use
+    env = HighwayLikeEnv(table=small, state=5)
+    agent = agent_factory(env, dict(__class__=mg.UCT, budget=300, horizon=12, episodes=25, step_strategy="subtree"))
+    agent.seed(11)
+    p = "env_side/uct_subtree"
+    mg.put_mdp(store, p + "/mdp", small)
+    states = []
+    for step in range(5):
+        states.append(env.state_index)
+        plan = agent.plan(env.state_index)
+        root = agent.planner.root
+        mg.put(store, "{}/step{}".format(p, step), dict(plan=np.asarray(plan, np.int32), root_count=root.count,
+                                                        root_value=float(root.value),
+                                                        rng_after=mg.rng_state(agent.planner.np_random)))
+        mg.put(store, "{}/step{}/tree".format(p, step), keyed_tree(root, UCT_FIELDS))
+        _, _, term, trunc, _ = env.step(plan[0])
+        if term or trunc:
+            break
+    mg.put(store, p, dict(states=np.asarray(states, np.int32), n_steps=len(states), shape=np.asarray(small["original_shape"])))
+    # MCTSWithPriorPolicyAgent: the prior agent's distribution renormalised over the LISTED actions, in listing order
+    pnames = []
+    for name, table, s0, acfg, pcfg, seeds in [
+            ("small", small, 0, dict(budget=1000, horizon=30, episodes=33), dict(gamma=0.95, temperature=0.3), [0]),
+            ("mid", mid, 31, dict(budget=300), dict(gamma=0.9, temperature=0.5), [1])]:
+        for seed in seeds:
+            env = HighwayLikeEnv(table=table, state=s0)
+            agent = agent_factory(env, dict(acfg, __class__=mg.UCTP, prior_agent=dict(pcfg, __class__=mg.PRIOR)))
+            p = "env_side/uct_prior/{}_seed{}".format(name, seed)
+            store_uct_case(store, p, table, env, agent, seed, s0, 0,
+                           dict(shape=np.asarray(table["original_shape"]), prior_table=np.array(agent.prior_agent.table),
+                                prior_gamma=pcfg["gamma"], prior_temperature=pcfg["temperature"]))
+            pnames.append("{}_seed{}".format(name, seed))
+    store["env_side/uct_prior/names"] = np.asarray(pnames)
+    onames = []
+    for name, table, s0, acfg, seed in [
+            ("small_s0", small, 0, dict(budget=300, gamma=0.8), 0),
+            ("small_s41_tr05", small, 41, dict(budget=300, gamma=0.9, terminal_reward=0.5), 3),
+            ("small_corner", small, 119 - 9, dict(budget=200, gamma=0.8), 1),
+            ("mid_s22_b1000", mid, 22, dict(budget=1000, gamma=0.85), 2)]:
+        env = HighwayLikeEnv(table=table, state=s0)
+        agent = agent_factory(env, dict(acfg, __class__=mg.OPD))
+        agent.seed(seed)
+        st0 = mg.rng_state(agent.planner.np_random)
+        plan = agent.plan(s0)
+        root = agent.planner.root
+        p = "env_side/opd/" + name
+        mg.put_mdp(store, p + "/mdp", table)
+        mg.put(store, p, dict(s0=s0, seed=seed, budget=agent.config["budget"], gamma=agent.config["gamma"],
+                              terminal_reward=agent.config["terminal_reward"], shape=np.asarray(table["original_shape"]),
+                              plan=np.asarray(plan, np.int32), root_lower=float(root.value_lower),
+                              root_upper=float(root.value_upper), root_count=root.count,
+                              env_steps=len(agent.planner.observations), rng_before=st0,
+                              rng_after=mg.rng_state(agent.planner.np_random)))
+        mg.put(store, p + "/tree", keyed_tree(root, OPD_FIELDS))
+        onames.append(name)
+    store["env_side/opd/names"] = np.asarray(onames)
+
+
 def main():
     store = {}
     golden_rvi_v(store)

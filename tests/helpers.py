@@ -107,15 +107,16 @@ def assert_keyed_tree_equal(z, prefix, tree, fields):
         assert np.array_equal(got.astype(want.dtype), want), "tree field {} differs".format(gold_name)
 
 
-def reference_policy_lists(policy_config, available):
+def reference_policy_lists(policy_config, available, order=None):
     """What the reference's policy functions return, state by state, on an environment whose
-    get_available_actions() lists flatnonzero(available[s]) (mcts.py:46-97): dict(actions=[...], p=[...]).
+    get_available_actions() lists flatnonzero(available[s]) (mcts.py:46-97) -- or, with ``order`` (a permutation of the
+    action ids), lists the available actions in that order: dict(actions=[...], p=[...]).
     Restated here for the tests only (the oracle consumes the lists; the product builds [S, A] tables of its own)."""
     available = np.asarray(available).astype(bool)
     n_states, n_actions = available.shape
     actions, probs = [], []
     for s in range(n_states):
-        av = np.flatnonzero(available[s])
+        av = np.flatnonzero(available[s]) if order is None else np.asarray([a for a in order if available[s, a]])
         kind = policy_config["type"]
         if kind == "random":                                  # mcts.py:46-57: ignores availability
             a, p = np.arange(n_actions), np.ones(n_actions) / n_actions
@@ -135,13 +136,13 @@ def reference_policy_lists(policy_config, available):
     return dict(actions=actions, p=probs)
 
 
-def restricted_agent_policy_lists(table, available):
+def restricted_agent_policy_lists(table, available, order=None):
     """MCTSWithPriorPolicyAgent.agent_policy_available (mcts_with_prior.py:56-62): the prior agent's distribution
-    restricted to the available actions and renormalised with numpy's sum."""
+    restricted to the available actions (in the env's listing order) and renormalised with numpy's sum."""
     available = np.asarray(available).astype(bool)
     actions, probs = [], []
     for s in range(available.shape[0]):
-        av = np.flatnonzero(available[s])
+        av = np.flatnonzero(available[s]) if order is None else np.asarray([a for a in order if available[s, a]])
         p = np.array([table[s, a] for a in av])
         p /= np.sum(p)
         actions.append([int(x) for x in av])

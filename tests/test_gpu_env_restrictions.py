@@ -1,9 +1,8 @@
 """Action restrictions that live ON THE ENV OBJECT (missing 2 / task 4): an environment with highway-env's
-surface -- get_available_actions() on the env, to_finite_mdp() WITHOUT an `available` table but with `original_shape` --
-is planned on by deriving the [S, A] table (device_model.available_actions_of).  The expected results are the
-reference's own: its MCTSAgent / MCTSWithPriorPolicyAgent / DeterministicPlannerAgent planning on the finite-MDP env
-built from the same tables and the same restriction (tests/golden/variants.npz, uct_masked/highway_*, opd_masked/highway_*,
-uct_prior_masked/highway_*)."""
+surface -- get_available_actions() on the env (listing IDLE first), to_finite_mdp() WITHOUT an `available` table but with
+`original_shape` -- is planned on by deriving the [S, A] table and the listing order (device_model.availability_of).
+The expected results are the reference's own: its MCTSAgent / MCTSWithPriorPolicyAgent / DeterministicPlannerAgent run
+DIRECTLY on that environment (tests/golden/round3.npz, env_side/*: make_golden_round3.py)."""
 import json
 import os
 
@@ -11,39 +10,38 @@ import numpy as np
 import pytest
 
 from tests.helpers import mdp_from_golden
-from tests.test_gpu_variants import OPD, UCT, UCTP, VI, _assert_agent_tree, _uct_cfg, names
+from tests.test_gpu_variants import OPD, UCT, UCTP, VI, _assert_agent_tree, _uct_cfg
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SHAPES = {"highway_small": (3, 4, 10), "highway_mid": (5, 5, 20)}
 
 
 @pytest.fixture(scope="module")
 def z():
-    return np.load(os.path.join(REPO, "tests", "golden", "variants.npz"))
+    return np.load(os.path.join(REPO, "tests", "golden", "round3.npz"))
 
 
-def _highway_env(z, p, name, state):
-    from rl_agents_amd.envs import HighwayLikeEnv, generators
-    shape = next(v for k, v in SHAPES.items() if name.startswith(k))
+def names(z, group):
+    return [str(n) for n in z[group + "/names"]]
+
+
+def _highway_env(z, p, state):
+    from rl_agents_amd.envs import HighwayLikeEnv
     cfg = mdp_from_golden(z, p + "/mdp")
-    table = dict(transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"], original_shape=shape)
-    assert np.array_equal(z[p + "/available"], generators.highway_available(table))   # the golden's restriction IS the rule
+    table = dict(transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"],
+                 original_shape=tuple(int(x) for x in z[p + "/shape"]))
     env = HighwayLikeEnv(table=table, state=state)
     mdp = env.to_finite_mdp()
-    assert not hasattr(mdp, "available") and mdp.original_shape == shape
+    assert not hasattr(mdp, "available") and env.get_available_actions()[0] == 1      # restriction on the env, IDLE first
     return env
 
 
 def test_mcts_agents_on_env_side_restrictions_match_reference(z):
     from rl_agents_amd import native
     from rl_agents_amd.agents.common.factory import agent_factory
-    done = 0
-    for name in names(z, "uct_masked"):
-        if not name.startswith("highway"):
-            continue
-        p = "uct_masked/" + name
-        env = _highway_env(z, p, name, int(z[p + "/s0"]))
+    for name in names(z, "env_side/uct"):
+        p = "env_side/uct/" + name
+        env = _highway_env(z, p, int(z[p + "/s0"]))
         agent = agent_factory(env, _uct_cfg(z, p, closed_loop=bool(z[p + "/closed_loop"]),
                                             prior_policy=json.loads(str(z[p + "/prior_policy_json"])),
                                             rollout_policy=json.loads(str(z[p + "/rollout_policy_json"]))))
@@ -52,13 +50,12 @@ def test_mcts_agents_on_env_side_restrictions_match_reference(z):
         np.testing.assert_array_equal([int(x) for x in plan], z[p + "/plan"], err_msg=name)
         assert [isinstance(x, str) for x in plan] == list(z[p + "/plan_is_obs"]), name
         np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        assert agent.planner.env_steps == int(z[p + "/env_steps"]), name
         _assert_agent_tree(z, p + "/tree", agent.planner.root)
         assert env.state_index == int(z[p + "/s0"]) and env.steps == 0, "the live environment is never stepped"
-        done += 1
-    assert done >= 4
     # receding horizon with tree re-use: the env moves, the derived table is cross-checked at every plan
-    p = "uct_masked/subtree_highway"
-    env = _highway_env(z, p, "highway_small", int(z[p + "/states"][0]))
+    p = "env_side/uct_subtree"
+    env = _highway_env(z, p, int(z[p + "/states"][0]))
     agent = agent_factory(env, dict(__class__=UCT, budget=300, horizon=12, episodes=25, step_strategy="subtree"))
     agent.seed(11)
     for step in range(int(z[p + "/n_steps"])):
@@ -67,30 +64,30 @@ def test_mcts_agents_on_env_side_restrictions_match_reference(z):
         q = "{}/step{}".format(p, step)
         np.testing.assert_array_equal(plan, z[q + "/plan"], err_msg=q)
         _assert_agent_tree(z, q + "/tree", agent.planner.root, fields=("count", "value"))
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[q + "/rng_after"])
         env.step(plan[0])
-    # MCTSWithPriorPolicyAgent: the VI prior agent's distribution renormalised over the env's available actions
-    for name in names(z, "uct_prior_masked"):
-        if not name.startswith("highway"):
-            continue
-        p = "uct_prior_masked/" + name
-        env = _highway_env(z, p, name, int(z[p + "/s0"]))
+    # MCTSWithPriorPolicyAgent: the VI prior agent's distribution renormalised over the LISTED actions, in listing order
+    for name in names(z, "env_side/uct_prior"):
+        p = "env_side/uct_prior/" + name
+        env = _highway_env(z, p, int(z[p + "/s0"]))
         agent = agent_factory(env, _uct_cfg(z, p, __class__=UCTP,
                                             prior_agent=dict(__class__=VI, gamma=float(z[p + "/prior_gamma"]),
                                                              temperature=float(z[p + "/prior_temperature"]))))
+        assert np.array_equal(agent.prior_agent.policy_table(), z[p + "/prior_table"]), name
         agent.seed(int(z[p + "/seed"]))
         plan = agent.plan(int(z[p + "/s0"]))
         np.testing.assert_array_equal(plan, z[p + "/plan"], err_msg=name)
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
         _assert_agent_tree(z, p + "/tree", agent.planner.root, fields=("count", "value", "prior"))
 
 
 def test_opd_agent_on_env_side_restrictions_matches_reference(z):
+    from rl_agents_amd import native
     from rl_agents_amd.agents.common.factory import agent_factory
-    done = 0
-    for name in names(z, "opd_masked"):
-        if not name.startswith("highway"):
-            continue
-        p = "opd_masked/" + name
-        env = _highway_env(z, p, name, int(z[p + "/s0"]))
+    from tests.test_gpu_variants import _agent_tree
+    for name in names(z, "env_side/opd"):
+        p = "env_side/opd/" + name
+        env = _highway_env(z, p, int(z[p + "/s0"]))
         agent = agent_factory(env, dict(__class__=OPD, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
                                         terminal_reward=float(z[p + "/terminal_reward"])))
         agent.seed(int(z[p + "/seed"]))
@@ -98,8 +95,20 @@ def test_opd_agent_on_env_side_restrictions_matches_reference(z):
         root = agent.planner.root
         assert root.value_lower == float(z[p + "/root_lower"]) and root.value_upper == float(z[p + "/root_upper"])
         assert root.count == int(z[p + "/root_count"]) and agent.planner.env_steps == int(z[p + "/env_steps"])
-        done += 1
-    assert done == 2
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        # the whole tree, children in the env's listing order
+        nodes, parents, keys = [root], [-1], [-1]
+        i = 0
+        while i < len(nodes):
+            for k, c in nodes[i].children.items():
+                nodes.append(c)
+                parents.append(i)
+                keys.append(int(k))
+            i += 1
+        np.testing.assert_array_equal(parents, z[p + "/tree/parent"], err_msg=name)
+        np.testing.assert_array_equal(keys, z[p + "/tree/action"], err_msg=name)
+        assert np.array_equal([n.value_lower for n in nodes], z[p + "/tree/lower"]), name
+        assert np.array_equal([n.count for n in nodes], z[p + "/tree/count"]), name
 
 
 def test_value_iteration_agent_on_the_highway_like_env():

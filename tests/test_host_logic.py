@@ -278,9 +278,16 @@ def test_availability_of_env_side_restrictions():
     assert not hasattr(mdp, "available")
     table = device_model.available_actions_of(env, mdp)
     assert table.shape == (120, 5) and table.dtype == bool
-    for s in range(120):                # the rule reproduces the env's own restriction in every state
+    _, order = device_model.availability_of(env, mdp)
+    assert list(order) == [1, 0, 2, 3, 4]          # IDLE first: the order the env lists its actions in
+    for s in range(120):                # the rule reproduces the env's own LIST (actions and order) in every state
         e = HighwayLikeEnv(table=env.table, state=s)
-        assert sorted(e.get_available_actions()) == list(np.flatnonzero(table[s]))
+        assert e.get_available_actions() == [a for a in order if table[s, a]]
+    # the spec a planner uploads is in listing order: column j of every table = action order[j]
+    spec = device_model.spec_from_mdp(mdp, available=table, action_order=order)
+    assert np.array_equal(spec.transition, np.asarray(mdp.transition)[:, order])
+    assert np.array_equal(spec.available.astype(bool), table[:, order]) and list(spec.action_order) == [1, 0, 2, 3, 4]
+    assert spec.key() != device_model.spec_from_mdp(mdp, available=table).key()
     # hook: an env may state its restriction as a table itself
 
     class Hooked(HighwayLikeEnv):
@@ -290,9 +297,16 @@ def test_availability_of_env_side_restrictions():
             return m
 
         def available_table(self, mdp):
-            return generators.highway_available(self.table)
+            return generators.highway_available(self.table), [1, 0, 2, 3, 4]
     h = Hooked(3, 4, 10, seed=3, state=7)
     assert np.array_equal(device_model.available_actions_of(h, h.to_finite_mdp()), table)
+    assert list(device_model.availability_of(h, h.to_finite_mdp())[1]) == [1, 0, 2, 3, 4]
+
+    class WrongOrder(Hooked):           # right actions, wrong listing order: refused as well
+        def available_table(self, mdp):
+            return generators.highway_available(self.table)
+    with pytest.raises(ValueError):
+        device_model.available_actions_of(WrongOrder(3, 4, 10, seed=3, state=10), WrongOrder(3, 4, 10, seed=3, state=10).to_finite_mdp())
     # a derived table that contradicts the env is refused
 
     class Liar(Hooked):

@@ -61,3 +61,63 @@ def test_robust_planner_restricted_actions_goldens(z):
         assert_keyed_tree_equal(z, p + "/tree", tree, dict(count="count", depth="depth", lower_min="lower_min",
                                                           upper_min="upper_min", reward="reward", done="done", obs="obs",
                                                           n_children="n_children"))
+
+
+# ------------------------------------------------------------------ restrictions on the env object, listed IDLE first
+ORDER = [1, 0, 2, 3, 4]     # highway-env's listing order (device_model.GRID_LISTING_ORDER)
+
+
+def _grid_available(shape):
+    from rl_agents_amd.device_model import grid_available
+    return grid_available(tuple(int(x) for x in shape))
+
+
+def test_env_side_uct_goldens_oracle_literal(z):
+    """The reference MCTSAgent / MCTSWithPriorPolicyAgent planning directly on HighwayLikeEnv (restriction on the env,
+    listed IDLE first): the oracle, fed the policies as the literal per-state lists in listing order, reproduces plans
+    (with observation keys), env steps, generator state and whole trees."""
+    import json
+    from oracle import oracle
+    from tests.helpers import reference_policy_lists, restricted_agent_policy_lists
+    for group in ("env_side/uct", "env_side/uct_prior"):
+        for name in names(z, group):
+            p = "{}/{}".format(group, name)
+            cfg = mdp_from_golden(z, p + "/mdp")
+            avail = _grid_available(z[p + "/shape"])
+            if group.endswith("prior"):
+                prior_l = roll_l = restricted_agent_policy_lists(z[p + "/prior_table"], avail, ORDER)
+            else:
+                prior_l = reference_policy_lists(json.loads(str(z[p + "/prior_policy_json"])), avail, ORDER)
+                roll_l = reference_policy_lists(json.loads(str(z[p + "/rollout_policy_json"])), avail, ORDER)
+            out = oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], int(z[p + "/s0"]), int(z[p + "/episodes"]),
+                                  int(z[p + "/horizon"]), float(z[p + "/gamma"]), float(z[p + "/temperature"]), prior_l, roll_l,
+                                  z[p + "/rng_before"], max_plan_len=2 * int(z[p + "/horizon"]),
+                                  closed_loop=bool(z[p + "/closed_loop"]))
+            np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+            assert out["env_steps"] == int(z[p + "/env_steps"]), name
+            np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+            assert_keyed_tree_equal(z, p + "/tree", out["tree"], dict(count="count", value="value", prior="prior"))
+
+
+def test_env_side_opd_goldens_oracle_in_listing_order(z):
+    """DeterministicPlannerAgent on HighwayLikeEnv: children are created in listing order (deterministic.py:32-43), which
+    fixes the leaves order and so every tie of the leaf argmax.  Planning in the permuted action space (column j =
+    action ORDER[j]) and mapping the labels back reproduces the reference -- the claim the device path rests on."""
+    from oracle import oracle
+    order = np.asarray(ORDER)
+    for name in names(z, "env_side/opd"):
+        p = "env_side/opd/" + name
+        cfg = mdp_from_golden(z, p + "/mdp")
+        avail = _grid_available(z[p + "/shape"])
+        out = oracle.opd_plan(cfg["transition"][:, order], cfg["reward"][:, order], cfg["terminal"], int(z[p + "/s0"]),
+                              int(z[p + "/budget"]), float(z[p + "/gamma"]), float(z[p + "/terminal_reward"]),
+                              rng_state=z[p + "/rng_before"], available=avail[:, order])
+        np.testing.assert_array_equal(order[out["plan"]], z[p + "/plan"], err_msg=name)
+        assert out["root_lower"] == float(z[p + "/root_lower"]) and out["root_upper"] == float(z[p + "/root_upper"]), name
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+        tree = dict(out["tree"])
+        tree["action"] = np.where(tree["action"] >= 0, order[np.maximum(tree["action"], 0)], -1)
+        tree["obs"] = np.where(np.arange(len(tree["state"])) == 0, -1, tree["state"])
+        assert_keyed_tree_equal(z, p + "/tree", tree, dict(count="count", lower="lower", upper="upper", reward="reward",
+                                                          done="done", depth="depth", obs="obs"))
