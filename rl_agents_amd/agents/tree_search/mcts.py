@@ -144,6 +144,12 @@ class MCTS(AbstractPlanner):
                 prior, rollout = self.policy_source(state, model)      # (restricted to the available actions there;
                 listed = available                                     #  columns in the model's listing order)
             else:
+                if self.action_order(model) is not None and "random" in (self.prior_policy["type"], self.rollout_policy["type"]):
+                    # `random` lists np.arange(n) whatever the env lists (mcts.py:46-57): its sampling / child order is
+                    # ascending while the other policy and the env follow the listing order -- two orders in one tree
+                    raise NotImplementedError("policy type 'random' on an environment that lists its available actions "
+                                              "in a non-ascending order is not supported on the device; use "
+                                              "'random_available' (the reference's default) or 'preference'")
                 prior, rollout, listed = self.restricted_policy_tables(model, available)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
                                None, None, rng_states, root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1),
