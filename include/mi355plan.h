@@ -269,6 +269,33 @@ int mp_uct_tree_capacity(mp_ctx *ctx, int32_t *cap);
 int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                        int64_t *count, double *value, int32_t *first_child, int32_t *n_children);
 
+/*
+ * MCTS on STOCHASTIC finite MDPs (the `stochastic` [S,A,S] and `sparse` [S,A,B] modes of a finite-MDP env: models from
+ * mp_model_load_dense / mp_model_load_sparse; deterministic table models are accepted too), open or closed loop.
+ * The reference's planner steps deep copies of the env (mcts.py:183, tree_search/abstract.py:158-161) and the env
+ * samples its next state with its OWN numpy generator, next = rng.choice(n, p=transition[s, a]); a copy carries a copy
+ * of that generator (common/factory.py:119-134), so every episode of a plan starts from the same env generator state:
+ *   env_rng_state uint64 [n_roots,6]: the env generator's record at plan time, read-only (NULL for deterministic models).
+ * closed_loop != 0 (mcts.py:147, MCTSNode.get_child :267-273): an action node has one child per distinct observation
+ * (= next state index) seen after it, created on first visit; `plans` then alternates action, observation key, action ...
+ * as AbstractPlanner.get_plan walks such a tree (abstract.py:143-156); max_plan_len counts both.
+ * prior_p / rollout_p: one distribution over the |A| actions for every state.  Restricted action sets, per-state
+ * policies and tree re-use (mp_uct_step_tree) are not available on this path.  mp_model_set_episode_rules sets what a
+ * table model gets at load time: done_on_next (terminated = terminal[s'] instead of terminal[s]) and the TimeLimit.
+ * mp_uct_stoch_tree_export: the tree of `root` in creation order -- parent, key (action id or observed state), is_obs,
+ * count, value -- a node's children in dict order are its children by ascending index; capacity from
+ * mp_uct_stoch_tree_capacity.
+ */
+int mp_model_set_episode_rules(mp_model *model, int32_t done_on_next, int32_t max_steps);
+int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, const int32_t *root_steps,
+                           int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
+                           const double *rollout_p, int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state,
+                           int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
+                           int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem);
+int mp_uct_stoch_tree_capacity(mp_ctx *ctx, int32_t *cap);
+int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *key,
+                             uint8_t *is_obs, int64_t *count, double *value);
+
 /* ---------------------------------------------------------------- OPD ----------------------- */
 /*
  * OptimisticDeterministicPlanner.plan (tree_search/deterministic.py:116-122) for n_roots

@@ -262,6 +262,72 @@ def uct_plan(transition, reward, terminal, s0, episodes, horizon, gamma, tempera
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, tree=tree)
 
 
+def uct_plan_stoch(mode, transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                   rng_state, env_rng_state, next_states=None, closed_loop=False, steps0=0, max_steps=0, done_rule="source",
+                   max_plan_len=128):
+    """MCTS.plan on a finite MDP whose env samples the next state with its OWN generator (`stochastic` [S,A,S] / `sparse`
+    [S,A,B] + next; `deterministic` accepted too), open or closed loop.  env_rng_state: the env generator's record at
+    plan time (every episode's clone starts from it).  -> plan (observation keys included when closed_loop), env_steps,
+    rng_after, root_value, tree (creation order: parent, action = key, is_obs, count, value, prior)."""
+    mode_i = _MODES[mode]
+    r = _f64(reward)
+    s, a = r.shape
+    t_i = _i64(transition) if mode_i == 0 else None
+    t_f = _f64(transition) if mode_i != 0 else None
+    nxt = _i64(next_states) if mode_i == 2 else None
+    b = t_f.shape[-1] if mode_i == 2 else 0
+    term = None if terminal is None else _u8(np.asarray(terminal).reshape(s))
+    rng = np.array(rng_state, dtype=np.uint64)
+    erng = np.array(env_rng_state, dtype=np.uint64)
+    prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
+    cap = 1 + episodes * (a + horizon)
+    plan = np.full(max_plan_len, -1, dtype=np.int32)
+    plan_len, steps, nn, rv = C.c_int32(), C.c_int64(), C.c_int32(), C.c_double()
+    tree = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), is_obs=np.zeros(cap, np.uint8),
+                count=np.zeros(cap, np.int64), value=np.zeros(cap, np.float64), prior=np.zeros(cap, np.float64))
+    rc = lib().orc_uct_plan_stoch(mode_i, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
+                                  _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"), int(max_steps), int(s0),
+                                  int(steps0), int(episodes), int(horizon), C.c_double(gamma), C.c_double(temperature),
+                                  _p(prior, C.c_double), _p(cdf, C.c_double), int(bool(closed_loop)), _p(rng, C.c_uint64),
+                                  _p(erng, C.c_uint64), max_plan_len, _p(plan, C.c_int32), C.byref(plan_len), C.byref(steps),
+                                  C.byref(rv), cap, _p(tree["parent"], C.c_int32), _p(tree["action"], C.c_int32),
+                                  _p(tree["is_obs"], C.c_uint8), _p(tree["count"], C.c_int64), _p(tree["value"], C.c_double),
+                                  _p(tree["prior"], C.c_double), C.byref(nn))
+    assert rc == 0, rc
+    tree = {k: v[:nn.value].copy() for k, v in tree.items()}
+    return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, root_value=rv.value, tree=tree)
+
+
+def uct_plan_stoch_batch(mode, transition, reward, terminal, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                         rng_states, env_rng_states, next_states=None, closed_loop=False, steps0=None, max_steps=0,
+                         done_rule="source", max_plan_len=16, n_threads=1):
+    mode_i = _MODES[mode]
+    r = _f64(reward)
+    s, a = r.shape
+    t_i = _i64(transition) if mode_i == 0 else None
+    t_f = _f64(transition) if mode_i != 0 else None
+    nxt = _i64(next_states) if mode_i == 2 else None
+    b = t_f.shape[-1] if mode_i == 2 else 0
+    term = None if terminal is None else _u8(np.asarray(terminal).reshape(s))
+    s0 = np.ascontiguousarray(s0, dtype=np.int32)
+    n = len(s0)
+    st0 = None if steps0 is None else np.ascontiguousarray(steps0, dtype=np.int32)
+    rng = np.array(rng_states, dtype=np.uint64).reshape(n, 6)
+    erng = np.ascontiguousarray(np.array(env_rng_states, dtype=np.uint64).reshape(n, 6))
+    prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
+    plans = np.full((n, max_plan_len), -1, dtype=np.int32)
+    plan_len, steps, rv = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.float64)
+    rc = lib().orc_uct_plan_stoch_batch(mode_i, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
+                                        _p(r, C.c_double), _p(term, C.c_uint8), int(done_rule == "next"), int(max_steps), n,
+                                        _p(s0, C.c_int32), _p(st0, C.c_int32), int(episodes), int(horizon), C.c_double(gamma),
+                                        C.c_double(temperature), _p(prior, C.c_double), _p(cdf, C.c_double),
+                                        int(bool(closed_loop)), _p(rng, C.c_uint64), _p(erng, C.c_uint64), max_plan_len,
+                                        _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(steps, C.c_int64),
+                                        _p(rv, C.c_double), int(n_threads))
+    assert rc == 0, rc
+    return dict(plans=plans, plan_len=plan_len, env_steps=steps, root_value=rv, rng_after=rng)
+
+
 def uct_reroot(tree, action, n_actions):
     """AbstractPlanner.step_by_subtree on an exported tree dict -> re-rooted tree dict, or None for a fresh tree."""
     n = len(tree["count"])

@@ -822,6 +822,160 @@ int orc_uct_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
 }
 
 /*
+ * MCTS on a STOCHASTIC finite MDP (mcts.py:132-184 over a FiniteMDPEnv in `stochastic` / `sparse` mode, restated in
+ * rl_agents_amd/envs/finite_mdp.py: next state = rng.choice(n, p=row) with the ENV's generator), open or closed loop.
+ * What differs from orc_uct_plan:
+ *   - every episode steps a deep copy of the env (mcts.py:183 safe_deepcopy_env), and the copy includes the env's own
+ *     numpy generator: each episode starts from the SAME env generator state env_rng6 (never advanced for the caller);
+ *   - closed loop (mcts.py:147, get_child :267-273): an action node has one child per DISTINCT observation seen after it
+ *     (key = the next state index, prior 0), created on first visit, in first-visit order.
+ * mode: 0 deterministic T [S,A]; 1 dense P [S,A,S]; 2 sparse P [S,A,B] + NXT [S,A,B].  Policies: one distribution over
+ * actions 0..A-1 for every state (prior [A], rollout_cdf [A]).
+ * Tree arrays in creation order, capacity `cap` >= 1 + episodes * (A + horizon): parent, key (action or observation),
+ * is_obs, count, value, prior.  A node's children in dict order = its children by ascending id.
+ */
+int orc_uct_plan_stoch(int mode, int S, int A, int B, const int64_t *T, const double *P, const int64_t *NXT,
+                       const double *R, const uint8_t *term, int done_on_next, int max_steps, int32_t s0, int32_t steps0,
+                       int episodes, int horizon, double gamma, double temperature, const double *prior,
+                       const double *rollout_cdf, int closed_loop, uint64_t *rng6, const uint64_t *env_rng6,
+                       int max_plan_len, int32_t *plan, int32_t *plan_len, int64_t *env_steps, double *root_value,
+                       int cap, int32_t *t_parent, int32_t *t_key, uint8_t *t_is_obs, int64_t *t_count, double *t_value,
+                       double *t_prior, int32_t *n_nodes_out)
+{
+    if (cap < 1 + episodes * (A + horizon)) return ORC_ERR_ARG;
+    const int W = mode == 1 ? S : B;
+    int32_t *parent = malloc(cap * sizeof(int32_t)), *key = malloc(cap * sizeof(int32_t));
+    int32_t *first = malloc(cap * sizeof(int32_t)), *last = malloc(cap * sizeof(int32_t)), *next = malloc(cap * sizeof(int32_t));
+    int32_t *n_ch = malloc(cap * sizeof(int32_t));
+    uint8_t *is_obs = malloc(cap);
+    int64_t *count = malloc(cap * sizeof(int64_t));
+    double *value = malloc(cap * sizeof(double)), *nprior = malloc(cap * sizeof(double));
+    double *gpow = malloc((horizon + 1) * sizeof(double)), *cdf = malloc(((W > 0 ? W : 1) + 1) * sizeof(double));
+    double *score = malloc((A > 0 ? A : 1) * sizeof(double));
+    int *ties = malloc((A > 0 ? A : 1) * sizeof(int)), *kids = malloc((A > 0 ? A : 1) * sizeof(int));
+    if (!parent || !key || !first || !last || !next || !n_ch || !is_obs || !count || !value || !nprior || !gpow || !cdf || !score ||
+        !ties || !kids)
+        return ORC_ERR_ALLOC;
+    for (int h = 0; h <= horizon; ++h) gpow[h] = pow(gamma, h);
+    orc_pcg64 g = {rng6[0], rng6[1], rng6[2], rng6[3], rng6[4], rng6[5]};
+    int n_nodes = 0;
+#define NEW_NODE(par_, key_, obs_, prior_) ({ const int c_ = n_nodes++; parent[c_] = (par_); key[c_] = (key_); is_obs[c_] = (obs_); \
+        count[c_] = 0; value[c_] = 0; nprior[c_] = (prior_); first[c_] = last[c_] = next[c_] = -1; n_ch[c_] = 0; \
+        if ((par_) >= 0) { if (last[par_] < 0) first[par_] = c_; else next[last[par_]] = c_; last[par_] = c_; n_ch[par_] += 1; } c_; })
+    NEW_NODE(-1, -1, 0, 1.0); /* mcts.py:129-130 reset() */
+    int64_t steps_taken = 0;
+    for (int ep = 0; ep < episodes; ++ep) {
+        int32_t s = s0, st = steps0; /* safe_deepcopy_env(state): state, step counter AND the env's generator */
+        orc_pcg64 eg = {env_rng6[0], env_rng6[1], env_rng6[2], env_rng6[3], env_rng6[4], env_rng6[5]};
+        int node = 0, depth = 0, terminal = 0;
+        double total_reward = 0;
+#define ENV_STEP(a_, r_out, term_out, trunc_out) do { \
+            const long sa_ = (long)s * A + (a_); int32_t sn_; \
+            if (mode == 0) sn_ = (int32_t)T[sa_]; \
+            else { /* Generator.choice(n, p=row): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(cdf, random(), 'right') */ \
+                double acc_ = 0; for (int j_ = 0; j_ < W; ++j_) { acc_ += P[sa_ * W + j_]; cdf[j_] = acc_; } \
+                for (int j_ = 0; j_ < W; ++j_) cdf[j_] /= acc_; \
+                const int idx_ = orc_cdf_pick(cdf, W, orc_pcg64_double(&eg)); \
+                sn_ = mode == 1 ? idx_ : (int32_t)NXT[sa_ * W + idx_]; } \
+            (r_out) = R[sa_]; (term_out) = term ? (done_on_next ? term[sn_] : term[s]) : 0; \
+            s = sn_; st += 1; (trunc_out) = max_steps > 0 && st >= max_steps; ++steps_taken; } while (0)
+        while (depth < horizon && n_ch[node] > 0 && !terminal) { /* mcts.py:143-149; node: the root or an observation node
+                                                                   * (closed loop) / an action node (open loop) */
+            const int k = n_ch[node];
+            int j = 0;
+            double m = 0;
+            for (int c = first[node]; c >= 0; c = next[c], ++j) {
+                kids[j] = c;
+                score[j] = value[c] + temperature * k * nprior[c] / (double)(count[c] + 1); /* mcts.py:275-286 */
+                if (j == 0 || score[j] > m) m = score[j];
+            }
+            int nt = 0;
+            for (j = 0; j < k; ++j) if (score[j] == m) ties[nt++] = j;
+            const int child = kids[ties[orc_pcg64_below(&g, (uint32_t)nt)]];
+            double r; int trunc;
+            ENV_STEP(key[child], r, terminal, trunc);
+            (void)trunc;
+            total_reward += gpow[depth] * r;
+            node = child;
+            if (closed_loop) { /* get_child(action, observation): the child keyed by str(observation), made on first visit */
+                int o = -1;
+                for (int c = first[node]; c >= 0; c = next[c]) if (key[c] == s) { o = c; break; }
+                if (o < 0) o = NEW_NODE(node, s, 1, 0.0);
+                node = o;
+            }
+            ++depth;
+        }
+        if (n_ch[node] == 0 && depth < horizon && (!terminal || node == 0)) /* mcts.py:151-154 */
+            for (int a = 0; a < A; ++a) NEW_NODE(node, a, 0, prior[a]);
+        if (!terminal)
+            for (int h = depth; h < horizon; ++h) { /* mcts.py:160-177 */
+                const int a = orc_cdf_pick(rollout_cdf, A, orc_pcg64_double(&g));
+                double r; int term_h, trunc_h;
+                ENV_STEP(a, r, term_h, trunc_h);
+                total_reward += gpow[h] * r;
+                if (term_h || trunc_h) break;
+            }
+        for (int n = node; n >= 0; n = parent[n]) { /* mcts.py:248-265 */
+            count[n] += 1;
+            value[n] += 1.0 / (double)count[n] * (total_reward - value[n]);
+        }
+        if (n_nodes + A + horizon > cap && ep + 1 < episodes) { /* cannot happen with the documented capacity */ }
+    }
+#undef ENV_STEP
+    /* abstract.py:143-156 get_plan, mcts.py:212-218 selection_rule at every level (action nodes AND observation nodes) */
+    int n = 0, len = 0;
+    while (n_ch[n] > 0) {
+        int64_t mc = -1;
+        for (int c = first[n]; c >= 0; c = next[c]) if (count[c] > mc) mc = count[c];
+        int best = -1;
+        for (int c = first[n]; c >= 0; c = next[c])
+            if (count[c] == mc && (best < 0 || value[c] > value[best])) best = c;
+        if (plan && len < max_plan_len) plan[len] = key[best];
+        ++len;
+        n = best;
+    }
+    if (plan) for (int i = len; i < max_plan_len; ++i) plan[i] = -1;
+    if (plan_len) *plan_len = len;
+    if (env_steps) *env_steps = steps_taken;
+    if (root_value) *root_value = value[0];
+    rng6[0] = g.s_hi; rng6[1] = g.s_lo; rng6[2] = g.inc_hi; rng6[3] = g.inc_lo; rng6[4] = g.has_uint32; rng6[5] = g.uinteger;
+    for (int i = 0; i < n_nodes; ++i) {
+        if (t_parent) t_parent[i] = parent[i];
+        if (t_key) t_key[i] = key[i];
+        if (t_is_obs) t_is_obs[i] = is_obs[i];
+        if (t_count) t_count[i] = count[i];
+        if (t_value) t_value[i] = value[i];
+        if (t_prior) t_prior[i] = nprior[i];
+    }
+    if (n_nodes_out) *n_nodes_out = n_nodes;
+#undef NEW_NODE
+    free(parent); free(key); free(first); free(last); free(next); free(n_ch); free(is_obs); free(count); free(value);
+    free(nprior); free(gpow); free(cdf); free(score); free(ties); free(kids);
+    return ORC_OK;
+}
+
+int orc_uct_plan_stoch_batch(int mode, int S, int A, int B, const int64_t *T, const double *P, const int64_t *NXT,
+                             const double *R, const uint8_t *term, int done_on_next, int max_steps, int n_roots,
+                             const int32_t *s0, const int32_t *steps0, int episodes, int horizon, double gamma,
+                             double temperature, const double *prior, const double *rollout_cdf, int closed_loop,
+                             uint64_t *rng6, const uint64_t *env_rng6, int max_plan_len, int32_t *plans, int32_t *plan_len,
+                             int64_t *env_steps, double *root_value, int n_threads)
+{
+    const int cap = 1 + episodes * (A + horizon);
+    int bad = 0;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
+    for (int i = 0; i < n_roots; ++i) {
+        int rc = orc_uct_plan_stoch(mode, S, A, B, T, P, NXT, R, term, done_on_next, max_steps, s0[i], steps0 ? steps0[i] : 0,
+                                    episodes, horizon, gamma, temperature, prior, rollout_cdf, closed_loop, rng6 + (long)i * 6,
+                                    env_rng6 + (long)i * 6, max_plan_len, plans ? plans + (long)i * max_plan_len : NULL,
+                                    plan_len ? plan_len + i : NULL, env_steps ? env_steps + i : NULL,
+                                    root_value ? root_value + i : NULL, cap, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+        if (rc != ORC_OK) bad = rc;
+    }
+    return bad;
+}
+
+/*
  * AbstractPlanner.step_by_subtree (abstract.py:195-206): the tree is replaced by the subtree of the root's child
  * `action`; an unexpanded root or child-less choice starts a new tree (n_out = 0 -> caller plans from a fresh root).
  * Nodes are re-numbered breadth-first so that children stay contiguous.  Arrays of capacity n_in.

@@ -23,6 +23,7 @@ import logging
 import numpy as np
 
 from rl_agents_amd import device_model
+from rl_agents_amd import native as native_modes
 from rl_agents_amd.agents.tree_search.abstract import AbstractPlanner, AbstractTreeSearchAgent, build_tree
 from rl_agents_amd.agents.tree_search.olop import OLOP
 
@@ -114,6 +115,8 @@ class MCTS(AbstractPlanner):
             # the reference re-roots at the ACTION node, whose children are keyed by observation strings: its next
             # run() would step the environment with such a key (abstract.py:195-206 + mcts.py:143-146)
             raise NotImplementedError("step_strategy 'subtree' does not work on closed-loop trees (in the reference either)")
+        if getattr(self, "_stochastic", False):
+            raise NotImplementedError("step_strategy 'subtree' is not available on stochastic models on the device")
         # every act() steps the tree (abstract.py:70-82), also between two plans when receding_horizon > 1: the device
         # descends one level per call (a pending re-rooting is applied when the next one is armed)
         live = self.last is not None or self._armed
@@ -126,11 +129,52 @@ class MCTS(AbstractPlanner):
         self.last, self._root = None, None
         self._armed = True
 
-    def plan_batch(self, state, root_states, root_steps=None, rng_states=None, keep_actions=None):
+    def model_for(self, state):
+        """Deterministic tables / CartPole as every planner; MCTS also plans on STOCHASTIC finite MDPs (`stochastic`,
+        `sparse` modes: the reference's planner steps any env, tree_search/abstract.py:158-161)."""
+        if not device_model.is_cartpole(state):
+            mdp = device_model.finite_mdp_of(state)
+            if mdp.mode in ("stochastic", "sparse"):
+                if device_model.availability_of(state, mdp)[0] is not None:
+                    raise NotImplementedError("restricted action sets on a stochastic model are not supported on the device")
+                model = self.models.get(device_model.spec_from_mdp(mdp))
+                model.set_episode_rules(getattr(mdp, "done_rule", "source"), device_model.env_max_steps(state))
+                return model
+        return super(MCTS, self).model_for(state)
+
+    def plan_batch_stochastic(self, state, model, root_states, root_steps, rng_states, env_rng_states=None):
+        """The stochastic-model path (uct_stoch.hip): every root's episodes replay the noise of the ENV's generator as it
+        is at plan time (clones copy it, common/factory.py:119-134); closed loop keys the tree by observed next states."""
+        from rl_agents_amd import native
+        n, cfg = len(root_states), self.config
+        if self.policy_source is not None:
+            raise NotImplementedError("per-state prior policies on a stochastic model are not supported on the device")
+        if env_rng_states is None:
+            gen = getattr(getattr(state, "unwrapped", state), "np_random", None)
+            if gen is None:
+                raise TypeError("a stochastic environment must expose its numpy generator as `np_random`")
+            env_rng_states = np.tile(native.rng_state_from_generator(gen), (n, 1))
+        out = self.models.ctx.uct_plan_stochastic(
+            model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
+            policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A), rng_states,
+            env_rng_state=env_rng_states, closed_loop=cfg["closed_loop"], root_steps=root_steps)
+        out["rng_states"] = rng_states
+        self._last_tables, self._last_model, self._stochastic = None, model, True
+        self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
+        self._tree_roots = n
+        self.claim_device_tree()
+        self.env_steps += int(out["env_steps"].sum())
+        return out
+
+    def plan_batch(self, state, root_states, root_steps=None, rng_states=None, keep_actions=None, env_rng_states=None):
         model = self.model_for(state)
         n = len(root_states)
         if rng_states is None:
             rng_states = self.batch_rng_states(n)
+        if model.mode in (native_modes.MODE_STOCHASTIC, native_modes.MODE_SPARSE):
+            self._armed = False
+            return self.plan_batch_stochastic(state, model, root_states, root_steps, rng_states, env_rng_states)
+        self._stochastic = False
         cfg = self.config
         ctx = self.models.ctx
         armed, self._armed = self._armed and n == 1, False
@@ -208,6 +252,11 @@ class MCTS(AbstractPlanner):
     def plan(self, state, observation):
         actions = super(MCTS, self).plan(state, observation)
         self._closed_plan = None
+        if getattr(self, "_stochastic", False):
+            if self.config["closed_loop"]:      # the device returns action, observation key, action, ...: keys are strings
+                self._closed_plan = [a if i % 2 == 0 else str(a) for i, a in enumerate(actions)]
+                return list(self._closed_plan)
+            return actions
         if self.config["closed_loop"]:
             self._closed_plan = self._with_observation_keys(state, actions)
             return list(self._closed_plan)
@@ -240,10 +289,31 @@ class MCTS(AbstractPlanner):
         return out
 
     def export_tree(self, root=0):
+        if getattr(self, "_stochastic", False):
+            return self._export_stochastic(root)
         tree = self._export_open_loop(root)
         if self.config["closed_loop"]:
             self._insert_observation_nodes(tree, root)
         return tree
+
+    def _export_stochastic(self, root=0):
+        """Tree of a stochastic-model plan: action nodes keyed by action id (prior = the prior policy's probability),
+        observation nodes keyed by str(next state) with prior 0 (mcts.py:267-273), children in dict order."""
+        from rl_agents_amd.agents.tree_search.abstract import Node
+        self.require_device_tree()
+        t = self.models.ctx.uct_stoch_tree(root)
+        prior = policy_probabilities(self.prior_policy, self._last_actions)
+        nodes = []
+        for i in range(len(t["parent"])):
+            par = nodes[t["parent"][i]] if t["parent"][i] >= 0 else None
+            obs = bool(t["is_obs"][i])
+            key = None if par is None else (str(int(t["action"][i])) if obs else int(t["action"][i]))
+            node = Node(par, key, int(t["count"][i]), float(t["value"][i]), 0 if par is None else par.depth + (0 if obs else 1))
+            node.prior = 1.0 if par is None else (0 if obs else float(prior[int(t["action"][i])]))
+            if par is not None:
+                par.children[key] = node
+            nodes.append(node)
+        return nodes[0]
 
     def _insert_observation_nodes(self, tree, root):
         """Closed loop: every visited action node gets its single observation child (key str(observation), prior 0,

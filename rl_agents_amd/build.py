@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmi355plan.so")
-SOURCES = ["api.hip", "vi.hip", "uct.hip", "opd.hip", "ropd.hip", "saopd.hip"]
+SOURCES = ["api.hip", "vi.hip", "uct.hip", "uct_stoch.hip", "opd.hip", "ropd.hip", "saopd.hip"]
 HEADERS = ["common.hpp", "pcg64.hpp", "wave.hpp"]
 # -ffp-contract=off: the reference evaluates a*b+c with two roundings (Python floats); a fused
 # multiply-add would change the last bit of bounds and Q values and break bit-exact parity.

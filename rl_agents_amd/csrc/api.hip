@@ -609,6 +609,7 @@ int mp_model_free(mp_model *m)
     if (m->rec_all) hipFree(m->rec_all);
     if (m->term_all) hipFree(m->term_all);
     if (m->NXT) hipFree(m->NXT);
+    if (m->thr) hipFree(m->thr);
     delete m;
     return MP_OK;
 }

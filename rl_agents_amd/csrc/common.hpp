@@ -133,6 +133,7 @@ struct mp_model {
     const double *P = nullptr;
     bool borrowed = false;
     int32_t *NXT = nullptr;
+    uint64_t *thr = nullptr; // dense / sparse models: sampling thresholds ceil(cdf * 2^53) of every row (uct_stoch.hip), lazily built
     mp_cartpole_params cp;
 };
 

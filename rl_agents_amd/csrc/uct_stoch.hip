@@ -1,0 +1,391 @@
+// uct_stoch.hip -- MCTS / UCT on STOCHASTIC finite MDPs, open and closed loop (reference rl_agents/agents/tree_search/
+// mcts.py:132-184, MCTSNode.get_child :267-273; the env side -- next state = rng.choice(n, p=row) with the ENV's own numpy
+// generator -- is rl_agents_amd/envs/finite_mdp.py's restatement of the absent `finite_mdp` package).
+//
+// What is different from uct.hip (deterministic tables):
+//   * a transition SAMPLES the next state: one double of the env's PCG64 stream, inverse CDF over the row.  The rows are
+//     kept as integer thresholds ceil(cdf * 2^53) (built on the device from the model's probabilities with numpy's
+//     arithmetic: sequential cumsum, one IEEE division by the last element), so a step is a binary search on uint64;
+//   * every episode steps a deep copy of the env (mcts.py:183), and the copy includes the env's generator: each episode
+//     of a plan starts from the SAME env generator record (a second 48-byte record per root, read-only);
+//   * closed loop: an action node has one child per DISTINCT next state observed after it, created on first visit, in
+//     first-visit order (a linked list: `first` / `next`); the statistics of an observation node are its own.  Nodes are
+//     therefore created at data-dependent moments, ids no longer advance in lock-step across the lanes of a wave: the
+//     trees are root-major, 32-byte nodes with parent links (the export and the oracle walk them literally).
+// One root per lane; all randomness of the planner from its numpy-PCG64 record (pcg64.hpp), bit for bit.
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.hpp"
+#include "pcg64.hpp"
+
+namespace mp {
+
+struct alignas(16) SNode {
+    double value;
+    int32_t count;
+    int32_t first;  // root / observation node (open loop: any node): first of its |A| contiguous action children, -1 = leaf;
+                    // action node in closed loop: head of its observation children (linked by `next`)
+    int32_t key;    // action id, or the observed next state
+    int32_t next;   // next observation sibling (closed loop), -1
+    int32_t parent;
+    int32_t is_obs;
+};
+static_assert(sizeof(SNode) == 32, "SNode is two dwordx4");
+
+struct StochArgs {
+    int n_roots, mode, S, A, W, episodes, horizon, cap, closed_loop, done_on_next, max_steps, max_plan_len;
+    const int32_t *T;       // deterministic: [S*A]
+    const uint64_t *thr;    // dense [S*A][S] / sparse [S*A][B]: ceil(cdf * 2^53)
+    const int32_t *nxt;     // sparse: [S*A][B]
+    const double *R;        // [S*A]
+    const uint8_t *term;    // [S] or nullptr
+    const int32_t *root_state, *root_steps;
+    const double *tab;      // gpow[H+1] | rollout thresholds [A] (uint64 bits) | tp[A] = (temperature * |A|) * prior[a]
+    uint64_t *rng;
+    const uint64_t *env_rng;
+    SNode *tree;
+    int32_t *n_nodes_out;
+    int32_t *plans, *plan_len;
+    double *root_value, *root_child_value;
+    int64_t *root_child_count, *env_steps;
+};
+
+// numpy: cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, u, 'right') with u = k * 2^-53:
+// #{j : cdf[j] <= u} = #{j : ceil(cdf[j] * 2^53) <= k}.  One thread per (s, a) row.
+__global__ void build_thresholds(long rows, int W, const double *__restrict__ P, uint64_t *__restrict__ thr)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const double *p = P + i * W;
+    double acc = 0.0;
+    for (int j = 0; j < W; ++j) acc += p[j]; // (the running sums below repeat these additions in the same order)
+    const double last = acc;
+    acc = 0.0;
+    for (int j = 0; j < W; ++j) {
+        acc += p[j];
+        const double scaled = ceil(ldexp(acc / last, 53));
+        thr[i * W + j] = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
+    }
+}
+
+__global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_s[];
+    const int lane = threadIdx.x, A = p.A, H = p.horizon, E = p.episodes;
+    double *gpow = lds_s;
+    const uint64_t *rthr = reinterpret_cast<const uint64_t *>(gpow + (H + 1));
+    const double *tp = gpow + (H + 1) + A;
+    const int ntab = (H + 1) + 2 * A;
+    int32_t *path = reinterpret_cast<int32_t *>(lds_s + ntab) + lane; // entry i of this lane: path[i * 64]
+    for (int i = lane; i < ntab; i += 64) lds_s[i] = p.tab[i];
+    __syncthreads();
+    const int r = blockIdx.x * 64 + lane;
+    if (r >= p.n_roots) return;
+    SNode *tree = p.tree + (long)r * p.cap;
+    Pcg64 g;
+    g.load(p.rng + (long)r * 6);
+    const int32_t s0 = p.root_state[r], st0 = p.root_steps ? p.root_steps[r] : 0;
+    const bool closed = p.closed_loop != 0;
+    auto make = [&](int id, int parent, int key, int obs) {
+        SNode n;
+        n.value = 0.0; n.count = 0; n.first = -1; n.key = key; n.next = -1; n.parent = parent; n.is_obs = obs;
+        tree[id] = n;
+    };
+    make(0, -1, -1, 0); // mcts.py:129-130 reset()
+    int n_nodes = 1;
+    long steps_taken = 0;
+    for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
+        int32_t s = s0, st = st0;    // safe_deepcopy_env(state): the clone's state, step counter ...
+        Pcg64 eg;                    // ... and a COPY of the env's generator: every episode replays the same noise
+        eg.load(p.env_rng + (long)r * 6);
+        // one env.step(a): -> reward, terminated, truncated; advances (s, st) and, for a stochastic model, eg
+        auto env_step = [&](int a, double &reward, bool &terminated, bool &truncated) {
+            const long sa = (long)s * A + a;
+            int32_t sn;
+            if (p.mode == MP_MODE_DETERMINISTIC) {
+                sn = p.T[sa];
+            } else {
+                const uint64_t k = eg.next64() >> 11; // Generator.random()
+                const uint64_t *row = p.thr + sa * p.W;
+                int lo = 0, hi = p.W;                 // searchsorted(cdf, u, 'right')
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (row[mid] <= k) lo = mid + 1; else hi = mid;
+                }
+                if (lo >= p.W) lo = p.W - 1;          // (u < 1 = cdf[-1]: not reached)
+                sn = p.mode == MP_MODE_SPARSE ? p.nxt[sa * p.W + lo] : lo;
+            }
+            reward = p.R[sa];
+            terminated = p.term ? (p.done_on_next ? p.term[sn] != 0 : p.term[s] != 0) : false;
+            s = sn;
+            st += 1;
+            truncated = p.max_steps > 0 && st >= p.max_steps;
+            ++steps_taken;
+        };
+        int node = 0, depth = 0, plen = 0;
+        bool terminal = false;
+        double total = 0.0;
+        path[(plen++) * 64] = 0;
+        int fc = tree[0].first;
+        // ---- selection, mcts.py:143-149
+        while (depth < H && fc >= 0 && !terminal) {
+            // MCTSNode.selection_strategy (:275-286): value + temperature * len(children) * prior / (count + 1);
+            // Node.random_argmax (abstract.py:296-311): exact-equality argmax set, one bounded draw among >= 2 ties
+            double m = 0.0;
+            int nt = 0;
+            for (int a = 0; a < A; ++a) {
+                const SNode c = tree[fc + a];
+                const double sc = c.value + tp[a] / (double)(c.count + 1);
+                if (a == 0 || sc > m) { m = sc; nt = 1; } else if (sc == m) ++nt;
+            }
+            int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
+            int act = 0;
+            for (int a = 0; a < A; ++a) {
+                const SNode c = tree[fc + a];
+                const double sc = c.value + tp[a] / (double)(c.count + 1);
+                if (sc == m) {
+                    if (pick == 0) { act = a; break; }
+                    --pick;
+                }
+            }
+            double reward;
+            bool trunc;
+            env_step(act, reward, terminal, trunc);
+            total += gpow[depth] * reward;
+            node = fc + act;
+            path[(plen++) * 64] = node;
+            if (closed) { // get_child(action, observation): the child keyed by str(observation), made on first visit
+                int o = tree[node].first, prev = -1;
+                while (o >= 0 && tree[o].key != s) { prev = o; o = tree[o].next; }
+                if (o < 0) {
+                    o = n_nodes++;
+                    make(o, node, s, 1);
+                    if (prev < 0) tree[node].first = o; else tree[prev].next = o;
+                }
+                node = o;
+                path[(plen++) * 64] = node;
+            }
+            fc = tree[node].first;
+            ++depth;
+        }
+        // ---- expansion, mcts.py:151-154 (a child per action, prior = the state-independent prior policy's)
+        if (fc < 0 && depth < H && (!terminal || node == 0)) {
+            const int c0 = n_nodes;
+            for (int a = 0; a < A; ++a) make(c0 + a, node, a, 0);
+            tree[node].first = c0;
+            n_nodes += A;
+        }
+        // ---- rollout, mcts.py:160-177
+        if (!terminal) {
+            for (int h = depth; h < H; ++h) {
+                const uint64_t k = g.next64() >> 11; // np_random.choice(actions, 1, p=p): one double, inverse cdf
+                int a = 0;
+                for (int j = 0; j < A - 1; ++j) a += rthr[j] <= k ? 1 : 0;
+                double reward;
+                bool term_h, trunc_h;
+                env_step(a, reward, term_h, trunc_h);
+                total += gpow[h] * reward;
+                if (term_h || trunc_h) break;
+            }
+        }
+        // ---- update_branch, mcts.py:248-265: the same total on every node of the path
+        for (int i = 0; i < plen; ++i) {
+            SNode *nd = tree + path[i * 64];
+            const int c = nd->count + 1;
+            const double v = nd->value;
+            nd->count = c;
+            nd->value = v + 1.0 / (double)c * (total - v);
+        }
+    }
+    g.store(p.rng + (long)r * 6);
+    if (p.n_nodes_out) p.n_nodes_out[r] = n_nodes;
+    if (p.env_steps) p.env_steps[r] = steps_taken;
+    if (p.root_value) p.root_value[r] = tree[0].value;
+    {
+        const int fc = tree[0].first;
+        for (int a = 0; a < A; ++a) {
+            if (p.root_child_count) p.root_child_count[(long)r * A + a] = fc >= 0 ? tree[fc + a].count : 0;
+            if (p.root_child_value) p.root_child_value[(long)r * A + a] = fc >= 0 ? tree[fc + a].value : 0.0;
+        }
+    }
+    // ---- get_plan (abstract.py:143-156) with MCTSNode.selection_rule (mcts.py:212-218) at every level: most visited
+    // child, ties to the first largest value; under an action node of a closed-loop tree the "action" is the observation key
+    int len = 0, node = 0;
+    bool at_action_node = false;
+    for (;;) {
+        int best = -1, bc = 0;
+        double bv = 0.0;
+        if (closed && at_action_node) {
+            for (int o = tree[node].first; o >= 0; o = tree[o].next) {
+                const int c = tree[o].count;
+                const double v = tree[o].value;
+                if (best < 0 || c > bc || (c == bc && v > bv)) { best = o; bc = c; bv = v; }
+            }
+        } else {
+            const int fc = tree[node].first;
+            if (fc >= 0)
+                for (int a = 0; a < A; ++a) {
+                    const int c = tree[fc + a].count;
+                    const double v = tree[fc + a].value;
+                    if (best < 0 || c > bc || (c == bc && v > bv)) { best = fc + a; bc = c; bv = v; }
+                }
+        }
+        if (best < 0) break;
+        if (p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = tree[best].key;
+        ++len;
+        node = best;
+        at_action_node = !at_action_node;
+    }
+    if (p.plans)
+        for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+    if (p.plan_len) p.plan_len[r] = len;
+}
+
+} // namespace mp
+
+using namespace mp;
+
+extern "C" {
+
+int mp_model_set_episode_rules(mp_model *model, int32_t done_on_next, int32_t max_steps)
+{
+    if (!model) return fail(MP_ERR_ARG, "mp_model_set_episode_rules: model is NULL");
+    model->done_on_next = done_on_next ? 1 : 0;
+    model->max_steps = max_steps > 0 ? max_steps : 0;
+    return MP_OK;
+}
+
+int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, const int32_t *root_steps,
+                           int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
+                           const double *rollout_p, int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state,
+                           int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
+                           int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem)
+{
+    if (!ctx || !model || !root_state || !rng_state || !prior_p || !rollout_p)
+        return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: NULL argument");
+    if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: unknown mem flags %d", mem);
+    const int mode = model->mode;
+    if (mode != MP_MODE_DETERMINISTIC && mode != MP_MODE_STOCHASTIC && mode != MP_MODE_SPARSE)
+        return fail(MP_ERR_MODE, "mp_uct_plan_stochastic: model mode %d is not a finite MDP", mode);
+    if (mode != MP_MODE_DETERMINISTIC && !env_rng_state)
+        return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: a stochastic model needs the env's generator records");
+    if (mode == MP_MODE_STOCHASTIC && (model->M != 1 || model->Sc != model->S))
+        return fail(MP_ERR_MODE, "mp_uct_plan_stochastic: one full dense model [S,A,S] expected");
+    if (model->masked) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: restricted action sets are not supported here");
+    if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
+        return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: bad sizes (n_roots=%d episodes=%d horizon=%d)", n_roots, episodes, horizon);
+    const int A = model->A, S = model->S, H = horizon, E = episodes;
+    const int W = mode == MP_MODE_STOCHASTIC ? S : (mode == MP_MODE_SPARSE ? model->B : 0);
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int amem = mem_arrays(mem), rmem = mem_rng(mem);
+
+    // sampling thresholds of the model's rows, built once per model on the device (numpy's cumsum / division order)
+    if (mode != MP_MODE_DETERMINISTIC && !model->thr) {
+        const long rows = (long)S * A;
+        if (hipMalloc(&model->thr, (size_t)rows * W * sizeof(uint64_t)) != hipSuccess)
+            return fail(MP_ERR_ALLOC, "mp_uct_plan_stochastic: %zu B for the sampling thresholds", (size_t)rows * W * 8);
+        hipLaunchKernelGGL(build_thresholds, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, W, model->P, model->thr);
+        MP_HIP(hipGetLastError());
+    }
+
+    // per-call tables, computed on the host exactly as Python computes them (see uct_plan_impl)
+    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A;
+    std::vector<double> tab(ntab);
+    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A;
+    for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);
+    double acc = 0.0;
+    for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }
+    for (int a = 0; a < A; ++a) {
+        const double scaled = ceil(ldexp(cdf[a] / acc, 53));
+        const uint64_t t = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
+        memcpy(&cdf[a], &t, sizeof(t));
+    }
+    for (int a = 0; a < A; ++a) tpv[a] = temperature * (double)A * prior_p[a]; // mcts.py:286, left to right
+    double *d_tab = nullptr;
+    MP_TRY(upload_tables(ctx, 7, tab, &d_tab));
+
+    const long cap = 1 + (long)E * ((long)A + (closed_loop ? H : 0));
+    const size_t lds = ntab * sizeof(double) + (size_t)(2 * H + 2) * 64 * sizeof(int32_t);
+    if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
+
+    StochArgs a;
+    memset(&a, 0, sizeof(a));
+    a.n_roots = n_roots; a.mode = mode; a.S = S; a.A = A; a.W = W; a.episodes = E; a.horizon = H; a.cap = (int)cap;
+    a.closed_loop = closed_loop ? 1 : 0; a.done_on_next = model->done_on_next; a.max_steps = model->max_steps;
+    a.max_plan_len = max_plan_len;
+    a.T = model->T; a.thr = model->thr; a.nxt = model->NXT; a.R = model->R; a.term = model->term; a.tab = d_tab;
+    MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.tree));
+    MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out));
+    ctx->tree.kind = 4; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.armed = false;
+    ctx->tree.K = closed_loop ? 1 : 0;
+
+    int32_t *d_rs = nullptr, *d_st = nullptr;
+    MP_TRY(stage_in(ctx, WS_IO0, root_state, (size_t)n_roots, amem, &d_rs));
+    if (root_steps) MP_TRY(stage_in(ctx, WS_IO1, root_steps, (size_t)n_roots, amem, &d_st));
+    MP_TRY(stage_in(ctx, WS_IO2, (const uint64_t *)rng_state, (size_t)n_roots * 6, rmem, &a.rng));
+    uint64_t *d_erng = nullptr;
+    if (env_rng_state) MP_TRY(stage_in(ctx, WS_IO9, env_rng_state, (size_t)n_roots * 6, amem, &d_erng));
+    a.env_rng = d_erng;
+    a.root_state = d_rs; a.root_steps = d_st;
+    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, amem, &a.plans));
+    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, amem, &a.plan_len));
+    MP_TRY(stage_out_alloc(ctx, WS_IO5, root_value, (size_t)n_roots, amem, &a.root_value));
+    MP_TRY(stage_out_alloc(ctx, WS_IO6, root_child_count, (size_t)n_roots * A, amem, &a.root_child_count));
+    MP_TRY(stage_out_alloc(ctx, WS_IO7, root_child_value, (size_t)n_roots * A, amem, &a.root_child_value));
+    MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, amem, &a.env_steps));
+
+    MP_TRY(kernels_begin(ctx));
+    hipLaunchKernelGGL(uct_stoch_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+    MP_TRY(kernels_end(ctx, 1));
+    MP_HIP(hipGetLastError());
+
+    MP_TRY(stage_out_copy(ctx, rng_state, a.rng, (size_t)n_roots * 6, rmem));
+    MP_TRY(stage_out_copy(ctx, plans, a.plans, (size_t)n_roots * max_plan_len, amem));
+    MP_TRY(stage_out_copy(ctx, plan_len, a.plan_len, (size_t)n_roots, amem));
+    MP_TRY(stage_out_copy(ctx, root_value, a.root_value, (size_t)n_roots, amem));
+    MP_TRY(stage_out_copy(ctx, root_child_count, a.root_child_count, (size_t)n_roots * A, amem));
+    MP_TRY(stage_out_copy(ctx, root_child_value, a.root_child_value, (size_t)n_roots * A, amem));
+    MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, amem));
+    if (amem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+int mp_uct_stoch_tree_capacity(mp_ctx *ctx, int32_t *cap)
+{
+    if (!ctx || !cap) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_capacity: NULL argument");
+    if (ctx->tree.kind != 4) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_capacity: no such tree on this ctx");
+    *cap = ctx->tree.cap;
+    return MP_OK;
+}
+
+int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *key,
+                             uint8_t *is_obs, int64_t *count, double *value)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
+    if (ctx->tree.kind != 4) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_export: no tree of mp_uct_plan_stochastic on this ctx");
+    if (root < 0 || root >= ctx->tree.n_roots) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_export: root %d out of range", root);
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipStreamSynchronize(ctx->stream));
+    int32_t n = 0;
+    MP_HIP(hipMemcpy(&n, (const int32_t *)ctx->ws[WS_TREE1].p + root, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (n > cap) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_export: capacity %d < %d nodes", cap, n);
+    std::vector<SNode> h((size_t)n);
+    MP_HIP(hipMemcpy(h.data(), (const SNode *)ctx->ws[WS_TREE0].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SNode),
+                     hipMemcpyDeviceToHost));
+    for (int i = 0; i < n; ++i) {
+        if (parent) parent[i] = h[i].parent;
+        if (key) key[i] = h[i].key;
+        if (is_obs) is_obs[i] = (uint8_t)h[i].is_obs;
+        if (count) count[i] = h[i].count;
+        if (value) value[i] = h[i].value;
+    }
+    if (n_nodes) *n_nodes = n;
+    return MP_OK;
+}
+
+} // extern "C"

@@ -55,6 +55,11 @@ SIGNATURES = {
     "mp_uct_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
     "mp_uct_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_model_set_available": (C.c_int, [_vp, _vp]),
+    "mp_model_set_episode_rules": (C.c_int, [_vp, c_i32, c_i32]),
+    "mp_uct_plan_stochastic": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, c_i32, _vp, _vp,
+                                         c_i32, _vp, _vp, _vp, _vp, _vp, _vp, c_i32]),
+    "mp_uct_stoch_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
+    "mp_uct_stoch_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp]),
     "mp_policy_load_listed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, P(_vp)]),
     "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               c_i32]),
@@ -491,6 +496,44 @@ class Context(object):
                                      _ptr(root_value), _ptr(root_child_count), _ptr(root_child_value),
                                      _ptr(env_steps), MP_MEM_DEVICE))
 
+    def uct_plan_stochastic(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
+                            env_rng_state=None, closed_loop=False, root_steps=None, max_plan_len=None):
+        """MCTS.plan on a stochastic (dense / sparse) finite-MDP model, open or closed loop (mp_uct_plan_stochastic).
+        env_rng_state uint64 [n,6]: the env generator's record per root at plan time (every episode's clone starts from
+        it; not advanced).  closed_loop: plans alternate action, observation key (next state index), action, ..."""
+        rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
+        n = rs.shape[0]
+        st = None if root_steps is None else np.ascontiguousarray(root_steps, dtype=np.int32).reshape(n)
+        mem, rng_ptr = self._rng_arg(rng_state, n)
+        erng = None if env_rng_state is None else np.ascontiguousarray(env_rng_state, dtype=np.uint64).reshape(n, 6)
+        mpl = int((2 if closed_loop else 1) * horizon if max_plan_len is None else max_plan_len)
+        pp = np.ascontiguousarray(prior_p, dtype=np.float64)
+        rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
+        if pp.shape != (model.A,) or rp.shape != (model.A,):
+            raise ValueError("prior_p / rollout_p must have one entry per action")
+        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
+                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        _check(self._lib.mp_uct_plan_stochastic(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
+                                                float(gamma), float(temperature), _ptr(pp), _ptr(rp), int(bool(closed_loop)),
+                                                rng_ptr, _ptr(erng), mpl, _ptr(out["plans"]), _ptr(out["plan_len"]),
+                                                _ptr(out["root_value"]), _ptr(out["root_child_count"]),
+                                                _ptr(out["root_child_value"]), _ptr(out["env_steps"]), mem))
+        return out
+
+    def uct_stoch_tree(self, root):
+        """Tree of `root` after the last uct_plan_stochastic, creation order: parent, action (= key: action id or observed
+        state), is_obs, count, value."""
+        c = c_i32()
+        _check(self._lib.mp_uct_stoch_tree_capacity(self._h, C.byref(c)))
+        cap = c.value
+        t = dict(parent=np.zeros(cap, np.int32), action=np.zeros(cap, np.int32), is_obs=np.zeros(cap, np.uint8),
+                 count=np.zeros(cap, np.int64), value=np.zeros(cap, np.float64))
+        n = c_i32()
+        _check(self._lib.mp_uct_stoch_tree_export(self._h, int(root), cap, C.byref(n), _ptr(t["parent"]), _ptr(t["action"]),
+                                                  _ptr(t["is_obs"]), _ptr(t["count"]), _ptr(t["value"])))
+        return {k: v[:n.value].copy() for k, v in t.items()}
+
     def uct_step_tree(self, actions):
         """step_strategy 'subtree': keep, for the next uct_plan, the subtree under each root's child actions[i]."""
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)
@@ -670,6 +713,11 @@ class Model(object):
     def __init__(self, ctx, handle, mode, m, s, a, b):
         self.ctx, self._h, self.mode, self.M, self.S, self.A, self.B = ctx, handle, mode, m, s, a, b
         self._keep = None
+
+    def set_episode_rules(self, done_rule="source", max_steps=0):
+        """Terminal convention and TimeLimit of the env stepping this model (dense / sparse models: table models get them
+        at load time)."""
+        _check(self.ctx._lib.mp_model_set_episode_rules(self._h, int(done_rule == "next"), int(max_steps or 0)))
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):

@@ -197,6 +197,58 @@ def golden_env_side(store):
     store["env_side/opd/names"] = np.asarray(onames)
 
 
+def golden_uct_stochastic(store):
+    """MCTSAgent on STOCHASTIC finite MDPs (dense `stochastic` and `sparse` modes), open and closed loop: the planner
+    steps deep copies of the env, each copy carrying a copy of the env's own generator (common/factory.py:119-134), so
+    every episode of a plan replays the same noise; closed loop keys the tree by the observed next states
+    (mcts.py:147,267-273)."""
+    from make_golden_variants import UCT_FIELDS, keyed_tree
+    dense = generators.random_stochastic(30, 3, seed=5, terminal_rate=0.1)
+    dense_b = generators.random_stochastic(50, 5, seed=6, concentration=0.05)       # few likely next states per (s, a)
+    sparse = generators.random_sparse(60, 3, 2, seed=7, terminal_rate=0.1)
+    sparse_b = generators.random_sparse(200, 5, 4, seed=8)
+    sparse_ms = dict(sparse_b, max_steps=9)
+    pref = {"type": "preference", "action": 1, "ratio": 3}
+    cases = [
+        ("dense_open", dense, 0, 0, dict(budget=300), [0, 1]),
+        ("dense_closed", dense, 0, 0, dict(budget=300, closed_loop=True), [0, 1]),
+        ("dense_b_closed_h30", dense_b, 7, 0, dict(budget=1000, horizon=30, episodes=33, closed_loop=True), [2]),
+        ("dense_b_open_pref", dense_b, 11, 0, dict(budget=400, prior_policy=pref, rollout_policy=pref), [3]),
+        ("sparse_open", sparse, 5, 0, dict(budget=400, gamma=0.9), [0]),
+        ("sparse_closed", sparse, 5, 0, dict(budget=400, gamma=0.9, closed_loop=True), [0, 4]),
+        ("sparse_b_closed", sparse_b, 17, 0, dict(budget=1000, horizon=30, episodes=33, closed_loop=True), [1]),
+        ("sparse_maxsteps_closed", sparse_ms, 3, 4, dict(budget=300, closed_loop=True, temperature=3.0), [6]),
+    ]
+    names = []
+    for name, cfg, s0, steps0, acfg, seeds in cases:
+        for seed in seeds:
+            env = mg.make_env(cfg, state=s0, steps=steps0)
+            env.seed(1000 + seed)                                   # the env's own generator (copied with every clone)
+            env_rng = mg.rng_state(env.np_random)
+            agent = agent_factory(env, dict(acfg, __class__=mg.UCT))
+            agent.seed(seed)
+            st0 = mg.rng_state(agent.planner.np_random)
+            plan = agent.plan(s0)
+            root = agent.planner.root
+            pc = agent.planner.config
+            p = "uct_stoch/{}_seed{}".format(name, seed)
+            mg.put_mdp(store, p + "/mdp", cfg)
+            prior_a, prior_p = agent.planner.prior_policy(env, None)
+            roll_a, roll_p = agent.planner.rollout_policy(env, None)
+            mg.put(store, p, dict(s0=s0, steps0=steps0, seed=seed, budget=pc["budget"], gamma=pc["gamma"], episodes=pc["episodes"],
+                                  horizon=pc["horizon"], temperature=pc["temperature"], closed_loop=bool(pc["closed_loop"]),
+                                  plan=np.asarray([int(x) for x in plan], np.int32),
+                                  plan_is_obs=np.asarray([isinstance(x, str) for x in plan], bool),
+                                  root_count=root.count, root_value=float(root.value), env_steps=len(agent.planner.observations),
+                                  rng_before=st0, rng_after=mg.rng_state(agent.planner.np_random), env_rng=env_rng,
+                                  env_rng_after=mg.rng_state(env.np_random),
+                                  prior_p=np.asarray(prior_p, np.float64), rollout_p=np.asarray(roll_p, np.float64)))
+            mg.put(store, p + "/tree", keyed_tree(root, UCT_FIELDS))
+            assert env.mdp.state == s0 and np.array_equal(mg.rng_state(env.np_random), env_rng)   # the live env is untouched
+            names.append("{}_seed{}".format(name, seed))
+    store["uct_stoch/names"] = np.asarray(names)
+
+
 def main():
     store = {}
     golden_rvi_v(store)

@@ -148,3 +148,33 @@ def restricted_agent_policy_lists(table, available, order=None):
         actions.append([int(x) for x in av])
         probs.append(p)
     return dict(actions=actions, p=probs)
+
+
+def bfs_by_parent(parent):
+    """Creation-order parent array -> BFS permutation in which a node's children come in ascending id = the order in
+    which the reference inserted them into its `children` dict (expansion order for action nodes, first-visit order for
+    observation nodes).  -> (order, bfs_parent)."""
+    kids = [[] for _ in parent]
+    for i, p in enumerate(parent):
+        if p >= 0:
+            kids[int(p)].append(i)
+    order, bpar = [0], [-1]
+    i = 0
+    while i < len(order):
+        for c in kids[order[i]]:
+            order.append(c)
+            bpar.append(i)
+        i += 1
+    return np.asarray(order), np.asarray(bpar, np.int32)
+
+
+def assert_parent_tree_equal(z, prefix, tree, fields):
+    """Compare a creation-order tree given by `parent` / `action` (= key) arrays with a golden keyed BFS tree."""
+    order, bpar = bfs_by_parent(tree["parent"])
+    assert len(order) == len(z[prefix + "/parent"]), (len(order), len(z[prefix + "/parent"]))
+    np.testing.assert_array_equal(bpar, z[prefix + "/parent"])
+    np.testing.assert_array_equal(np.asarray(tree["action"])[order], z[prefix + "/action"])
+    for gold_name, mine in fields.items():
+        got = np.asarray(tree[mine])[order]
+        want = z[prefix + "/" + gold_name]
+        assert np.array_equal(got.astype(want.dtype), want), "tree field {} differs".format(gold_name)

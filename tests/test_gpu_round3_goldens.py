@@ -153,3 +153,159 @@ def test_robust_planner_restricted_actions_batch_vs_oracle(ctx, n_models, n_acti
     assert np.array_equal(out["root_lower"], ref["root_lower"]) and np.array_equal(out["root_upper"], ref["root_upper"])
     np.testing.assert_array_equal(rng, ref["rng_after"])
     model.close()
+
+
+# ------------------------------------------------------------------ MCTS on stochastic finite MDPs (uct_stoch.hip)
+UCT = "<class 'rl_agents_amd.agents.tree_search.mcts.MCTSAgent'>"
+
+
+def _stoch_model(ctx, cfg):
+    if cfg["mode"] == "stochastic":
+        model = ctx.load_dense(cfg["transition"], cfg["reward"], cfg["terminal"])
+    elif cfg["mode"] == "sparse":
+        model = ctx.load_sparse(cfg["transition"], cfg["next"], cfg["reward"], cfg["terminal"])
+    else:
+        return ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"], max_steps=cfg["max_steps"])
+    model.set_episode_rules("source", cfg["max_steps"])
+    return model
+
+
+def test_uct_on_stochastic_models_goldens_c_abi(ctx, z):
+    """mp_uct_plan_stochastic against the reference MCTSAgent on `stochastic` / `sparse` finite MDPs, open and closed
+    loop: plans with observation keys, values, env steps, the planner's generator, whole trees (observation layer)."""
+    from tests.helpers import assert_parent_tree_equal
+    from tests.test_oracle_round3 import stoch_case
+    for name in names(z, "uct_stoch"):
+        p = "uct_stoch/" + name
+        cfg, _, _ = stoch_case(z, p)
+        model = _stoch_model(ctx, cfg)
+        rng = np.array(z[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        closed = bool(z[p + "/closed_loop"])
+        out = ctx.uct_plan_stochastic(model, [int(z[p + "/s0"])], int(z[p + "/episodes"]), int(z[p + "/horizon"]),
+                                      float(z[p + "/gamma"]), float(z[p + "/temperature"]), z[p + "/prior_p"], z[p + "/rollout_p"],
+                                      rng, env_rng_state=z[p + "/env_rng"].reshape(1, 6), closed_loop=closed,
+                                      root_steps=[int(z[p + "/steps0"])])
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], z[p + "/plan"], err_msg=name)
+        assert out["root_value"][0] == float(z[p + "/root_value"]), name
+        assert int(out["env_steps"][0]) == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(rng[0], z[p + "/rng_after"], err_msg=name)
+        tree = ctx.uct_stoch_tree(0)
+        assert_parent_tree_equal(z, p + "/tree", tree, dict(count="count", value="value", is_obs="is_obs"))
+        model.close()
+
+
+def test_uct_on_stochastic_models_agent(z):
+    """MCTSAgent through agent_factory on a stochastic FiniteMDPEnv: plan() with string observation keys, planner.root
+    with the observation layer, the env's generator left untouched."""
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv
+    from tests.test_gpu_variants import _agent_tree
+    from tests.test_oracle_round3 import stoch_case
+    for name in names(z, "uct_stoch"):
+        p = "uct_stoch/" + name
+        cfg, _, _ = stoch_case(z, p)
+        c = dict(mode=cfg["mode"], transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"],
+                 max_steps=cfg["max_steps"], state=int(z[p + "/s0"]))
+        if "next" in cfg:
+            c["next"] = cfg["next"]
+        env = FiniteMDPEnv(c)
+        env.reset()
+        env.steps = int(z[p + "/steps0"])
+        env.seed(1000 + int(z[p + "/seed"]))
+        assert np.array_equal(native.rng_state_from_generator(env.np_random), z[p + "/env_rng"])
+        acfg = dict(__class__=UCT, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]), temperature=float(z[p + "/temperature"]),
+                    horizon=int(z[p + "/horizon"]), episodes=int(z[p + "/episodes"]), closed_loop=bool(z[p + "/closed_loop"]))
+        if "pref" in name:
+            acfg.update(prior_policy={"type": "preference", "action": 1, "ratio": 3},
+                        rollout_policy={"type": "preference", "action": 1, "ratio": 3})
+        agent = agent_factory(env, acfg)
+        agent.seed(int(z[p + "/seed"]))
+        plan = agent.plan(int(z[p + "/s0"]))
+        np.testing.assert_array_equal([int(x) for x in plan], z[p + "/plan"], err_msg=name)
+        assert [isinstance(x, str) for x in plan] == list(z[p + "/plan_is_obs"]), name
+        assert plan == agent.planner.get_plan()
+        assert agent.planner.env_steps == int(z[p + "/env_steps"]), name
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"])
+        np.testing.assert_array_equal(native.rng_state_from_generator(env.np_random), z[p + "/env_rng"])    # never stepped
+        t = _agent_tree(agent.planner.root)
+        np.testing.assert_array_equal(t["parent"], z[p + "/tree/parent"])
+        np.testing.assert_array_equal(t["action"], z[p + "/tree/action"])
+        for f in ("count", "value", "prior", "is_obs"):
+            assert np.array_equal(t[f].astype(z[p + "/tree/" + f].dtype), z[p + "/tree/" + f]), (name, f)
+
+
+@pytest.mark.parametrize("mode,closed", [("stochastic", False), ("stochastic", True), ("sparse", False), ("sparse", True),
+                                         ("deterministic", True)])
+def test_uct_on_stochastic_models_batch_vs_oracle(ctx, mode, closed):
+    """Seeded batches of 300 roots (ragged last wave), distinct planner AND env generator records per root, a TimeLimit
+    and both terminal conventions: plans, values, env steps and generator records equal the oracle's."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    if mode == "stochastic":
+        cfg = generators.random_stochastic(90, 4, seed=21, terminal_rate=0.05, concentration=0.1)
+    elif mode == "sparse":
+        cfg = generators.random_sparse(400, 5, 3, seed=22, terminal_rate=0.05)
+    else:
+        cfg = generators.random_deterministic(200, 4, seed=23, terminal_rate=0.05)
+    a = cfg["reward"].shape[1]
+    n = 300
+    g = np.random.Generator(np.random.PCG64(77))
+    s0 = g.integers(0, cfg["reward"].shape[0], size=n).astype(np.int32)
+    steps0 = g.integers(0, 6, size=n).astype(np.int32)
+
+    def records():
+        r = g.integers(0, 2 ** 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+        r[:, 3] |= np.uint64(1)
+        r[:, 4:] = 0
+        return r
+    rng, erng = records(), records()
+    rng_ref = rng.copy()
+    prior = g.random(a) + 0.1
+    prior /= prior.sum()
+    roll = g.random(a) + 0.1
+    roll /= roll.sum()
+    for rule in ("source", "next"):
+        if mode == "stochastic":
+            model = ctx.load_dense(cfg["transition"], cfg["reward"], cfg["terminal"])
+        elif mode == "sparse":
+            model = ctx.load_sparse(cfg["transition"], cfg["next"], cfg["reward"], cfg["terminal"])
+        else:
+            model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+        model.set_episode_rules(rule, 25)
+        out = ctx.uct_plan_stochastic(model, s0, 24, 9, 0.9, 4.5, prior, roll, rng, env_rng_state=erng, closed_loop=closed,
+                                      root_steps=steps0, max_plan_len=18)
+        ref = oracle.uct_plan_stoch_batch(mode, cfg["transition"], cfg["reward"], cfg["terminal"], s0, 24, 9, 0.9, 4.5, prior,
+                                          roll, rng_ref, erng, next_states=cfg.get("next"), closed_loop=closed, steps0=steps0,
+                                          max_steps=25, done_rule=rule, max_plan_len=18, n_threads=8)
+        for k in ("plans", "plan_len", "env_steps"):
+            np.testing.assert_array_equal(out[k], ref[k], err_msg="{} {}".format(rule, k))
+        assert np.array_equal(out["root_value"], ref["root_value"])
+        np.testing.assert_array_equal(rng, ref["rng_after"])
+        rng_ref = ref["rng_after"].copy()
+        model.close()
+
+
+def test_closed_loop_on_a_deterministic_model_through_the_literal_kernel(ctx):
+    """Cross-check of round 2's argument (closed loop on a deterministic model = the open-loop statistics + a host-side
+    observation layer): the literal kernel -- real observation nodes -- reproduces the reference's closed-loop goldens of
+    variants.npz on deterministic tables."""
+    zv = np.load(os.path.join(REPO, "tests", "golden", "variants.npz"))
+    from tests.helpers import assert_parent_tree_equal
+    done = 0
+    for name in [str(n) for n in zv["closed/names"]]:
+        p = "closed/" + name
+        cfg = mdp_from_golden(zv, p + "/mdp")
+        model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"], max_steps=cfg["max_steps"])
+        rng = np.array(zv[p + "/rng_before"], dtype=np.uint64).reshape(1, 6)
+        out = ctx.uct_plan_stochastic(model, [int(zv[p + "/s0"])], int(zv[p + "/episodes"]), int(zv[p + "/horizon"]),
+                                      float(zv[p + "/gamma"]), float(zv[p + "/temperature"]), zv[p + "/prior_p"],
+                                      zv[p + "/rollout_p"], rng, closed_loop=True, root_steps=[int(zv[p + "/steps0"])])
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], zv[p + "/plan"], err_msg=name)
+        np.testing.assert_array_equal(rng[0], zv[p + "/rng_after"], err_msg=name)
+        assert_parent_tree_equal(zv, p + "/tree", ctx.uct_stoch_tree(0), dict(count="count", value="value", is_obs="is_obs"))
+        model.close()
+        done += 1
+    assert done >= 10

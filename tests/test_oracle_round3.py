@@ -121,3 +121,30 @@ def test_env_side_opd_goldens_oracle_in_listing_order(z):
         tree["obs"] = np.where(np.arange(len(tree["state"])) == 0, -1, tree["state"])
         assert_keyed_tree_equal(z, p + "/tree", tree, dict(count="count", lower="lower", upper="upper", reward="reward",
                                                           done="done", depth="depth", obs="obs"))
+
+
+# ------------------------------------------------------------------ MCTS on stochastic finite MDPs
+def stoch_case(z, p):
+    cfg = mdp_from_golden(z, p + "/mdp")
+    kw = dict(next_states=cfg.get("next"), closed_loop=bool(z[p + "/closed_loop"]), steps0=int(z[p + "/steps0"]),
+              max_steps=cfg["max_steps"])
+    args = (cfg["mode"], cfg["transition"], cfg["reward"], cfg["terminal"], int(z[p + "/s0"]), int(z[p + "/episodes"]),
+            int(z[p + "/horizon"]), float(z[p + "/gamma"]), float(z[p + "/temperature"]), z[p + "/prior_p"], z[p + "/rollout_p"])
+    return cfg, args, kw
+
+
+def test_uct_on_stochastic_models_goldens(z):
+    """The reference MCTSAgent on `stochastic` / `sparse` finite MDPs, open and closed loop: plans (observation keys
+    included), env steps, both generators, whole trees with the observation layer."""
+    from oracle import oracle
+    from tests.helpers import assert_parent_tree_equal
+    for name in names(z, "uct_stoch"):
+        p = "uct_stoch/" + name
+        cfg, args, kw = stoch_case(z, p)
+        out = oracle.uct_plan_stoch(*args, z[p + "/rng_before"], z[p + "/env_rng"], max_plan_len=4 * int(z[p + "/horizon"]), **kw)
+        np.testing.assert_array_equal(out["plan"], z[p + "/plan"], err_msg=name)
+        assert out["env_steps"] == int(z[p + "/env_steps"]), name
+        assert out["root_value"] == float(z[p + "/root_value"]), name
+        np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
+        assert_parent_tree_equal(z, p + "/tree", out["tree"], dict(count="count", value="value", prior="prior", is_obs="is_obs"))
+        assert int(out["tree"]["count"][0]) == int(z[p + "/root_count"])
