@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
         int32_t s = s0, st = st0;    // safe_deepcopy_env(state): the clone's state, step counter ...
         Pcg64 eg;                    // ... and a COPY of the env's generator: every episode replays the same noise
-        eg.load(p.env_rng + (long)r * 6);
+        eg.s_hi = eg.s_lo = eg.inc_hi = 0; eg.inc_lo = 1; eg.has_uint32 = eg.uinteger = 0;
+        if (p.env_rng) eg.load(p.env_rng + (long)r * 6); // (a deterministic model draws nothing from it)
         // one env.step(a): -> reward, terminated, truncated; advances (s, st) and, for a stochastic model, eg
         auto env_step = [&](int a, double &reward, bool &terminated, bool &truncated) {
             const long sa = (long)s * A + a;
