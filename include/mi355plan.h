@@ -390,6 +390,25 @@ int mp_saopd_export(mp_saopd *planners, int32_t planner, int32_t cap, int32_t *p
                     int32_t *depth, double *reward, double *lower, uint8_t *done, int64_t *count, int32_t *first_child,
                     uint8_t *alive, double *state_values);
 
+/* ---------------------------------------------------------------- batched evaluation -------- */
+/*
+ * The env side of Evaluation.step (trainer/evaluation.py:164-190) for n lock-step episodes of ONE deterministic table
+ * model, on the device: for every episode i still alive, act = plans[i * plan_stride] (an empty plan, -1, acts 0),
+ *   reward = R[s, act];  done = terminal[s] (or terminal[s'] with done_on_next);  s <- T[s, act];  steps += 1;
+ *   returns[i] += reward;  discounted[i] += reward * gpow[steps before];  actions_log[i * log_stride + steps before] = act;
+ *   alive[i] = !(done || steps >= max_steps).
+ * state / steps int32 [n], alive uint8 [n], returns / discounted double [n] (all in / out); gpow double [max_steps]
+ * (gamma ** t as the host computes it); n_alive int32 [1] = episodes still alive after the step.  Episodes that are not
+ * alive are left untouched.  The planners' root-state buffers ARE `state` / `steps`: no host round trip per step.
+ * mp_greedy_actions: plans[i * plan_stride] = argmax_a Q[state[i], a] (first maximum: ValueIterationAgent.act,
+ * value_iteration.py:35) -- the "plan" of a value-iteration agent for the same loop.
+ */
+int mp_env_step(mp_ctx *ctx, mp_model *model, int32_t n, int32_t *state, int32_t *steps, uint8_t *alive,
+                const int32_t *plans, int32_t plan_stride, int32_t max_steps, const double *gpow, double *returns,
+                double *discounted, int32_t *actions_log, int32_t log_stride, int32_t *n_alive, int32_t mem);
+int mp_greedy_actions(mp_ctx *ctx, int32_t n, int32_t S, int32_t A, const double *Q, const int32_t *state, int32_t *plans,
+                      int32_t plan_stride, int32_t mem);
+
 /* ---------------------------------------------------------------- helpers ------------------- */
 /* OLOP.allocation (tree_search/olop.py:50-62) with OLOP.horizon (:42-44); host arithmetic. */
 int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t *horizon);

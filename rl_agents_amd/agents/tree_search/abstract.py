@@ -193,6 +193,15 @@ class AbstractPlanner(Configurable):
     # -------------------------------------------------------------------------------------------------
     supports_cartpole = False
     supports_restricted_actions = True
+    # device-resident evaluation loop (trainer/batched_evaluation.py): planners that can plan a batch whose roots,
+    # generator records and results all live in device buffers provide plan_batch_device(...)
+    plan_batch_device = None
+
+    def supports_device_loop(self):
+        return False
+
+    def raise_for_device_status(self, d_status, live):
+        pass
 
     def model_for(self, state):
         if device_model.is_cartpole(state):

@@ -36,6 +36,29 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
         self.env_steps += int(out["env_steps"].sum())
         return out
 
+    # -- device-resident evaluation loop (BatchedEvaluation) ----------------------------------------------------------------
+    def supports_device_loop(self):
+        return type(self).plan_batch is OptimisticDeterministicPlanner.plan_batch     # (not the state-aware / robust planners)
+
+    def device_plan_len(self, model):
+        return 1
+
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status):
+        """One asynchronous batched plan (mp_opd_plan, MP_MEM_DEVICE): only enqueues; reward-range errors land in d_status."""
+        cfg = self.config
+        budget = int(cfg["budget"])
+        if cfg["gamma"] == 1 and budget >= model.A:
+            raise ZeroDivisionError("float division by zero")
+        self.models.ctx.opd_plan_device(model, n, d_state, budget, cfg["gamma"], cfg.get("terminal_reward", 0), d_rng,
+                                        int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, env_steps=d_env_steps,
+                                        status=d_status)
+        self.claim_device_tree()
+        self.last, self._root = None, None
+
+    def raise_for_device_status(self, d_status, live):
+        if bool(((d_status == native.ERR_REWARD_RANGE) & live).any().item()):
+            raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")  # deterministic.py:46-47
+
     def export_tree(self, root=0):
         self.require_device_tree()
         a = self._last_actions

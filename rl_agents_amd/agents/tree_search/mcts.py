@@ -220,6 +220,40 @@ class MCTS(AbstractPlanner):
         self.env_steps += int(out["env_steps"].sum())
         return out
 
+    # -- device-resident evaluation loop (BatchedEvaluation): roots, generator records and results are device buffers ----
+    def supports_device_loop(self):
+        """Plain receding-horizon MCTS on a deterministic table: no kept trees, no host-side observation layer."""
+        return self.config.get("step_strategy", "reset") != "subtree" and not self.config["closed_loop"]
+
+    def device_plan_len(self, model):
+        return 1
+
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status):
+        """One asynchronous batched plan (mp_uct_plan / mp_uct_plan_policy, MP_MEM_DEVICE): only enqueues."""
+        if model.mode != native_modes.MODE_DETERMINISTIC:
+            raise NotImplementedError("the device-resident loop steps deterministic table models")
+        cfg, ctx = self.config, self.models.ctx
+        ctx.uct_reset_tree()
+        available = getattr(model, "available", None)
+        policy, pp, rp = None, None, None
+        if self.policy_source is not None or available is not None:
+            if self.policy_source is not None:
+                prior, rollout = self.policy_source(state, model)
+                listed = available
+            else:
+                if self.action_order(model) is not None and "random" in (self.prior_policy["type"], self.rollout_policy["type"]):
+                    raise NotImplementedError("policy type 'random' on a non-ascending listing order (see plan_batch)")
+                prior, rollout, listed = self.restricted_policy_tables(model, available)
+            policy = self.device_policy(model, prior, rollout, listed)
+        else:
+            pp = policy_probabilities(self.prior_policy, model.A)
+            rp = policy_probabilities(self.rollout_policy, model.A)
+        ctx.uct_plan_device(model, n, d_state, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp, rp, d_rng,
+                            int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, env_steps=d_env_steps, root_steps=d_steps,
+                            policy=policy)
+        self.claim_device_tree()
+        self.last, self._root = None, None
+
     def restricted_policy_tables(self, model, available):
         """(prior, rollout, listed) tables of this planner's policy configs on a restricted-action model, kept per model."""
         hit = self._restricted.get(id(model))

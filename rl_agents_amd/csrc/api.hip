@@ -189,6 +189,46 @@ __global__ void pack_t16(int S, int A, const int32_t *__restrict__ T, const uint
     t16[i] = (uint16_t)((uint32_t)nx | (term && term[nx] ? 0x8000u : 0u));
 }
 
+// trainer/evaluation.py:164-190 for a batch of episodes of one table model (see mi355plan.h)
+__global__ void env_step_kernel(int n, int A, const Rec *__restrict__ rec, int done_on_next, int32_t *__restrict__ state,
+                                int32_t *__restrict__ steps, uint8_t *__restrict__ alive, const int32_t *__restrict__ plans,
+                                int plan_stride, int max_steps, const double *__restrict__ gpow, double *__restrict__ returns,
+                                double *__restrict__ discounted, int32_t *__restrict__ actions_log, int log_stride,
+                                int32_t *__restrict__ n_alive)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (i < n && alive[i]) {
+        int act = plans[(long)i * plan_stride];
+        if (act < 0) act = 0;
+        const int s = state[i], t = steps[i];
+        const Rec rc = rec[(long)s * A + act];
+        const bool done = (rc.flags & (done_on_next ? 2u : 1u)) != 0;
+        returns[i] += rc.reward;
+        discounted[i] += rc.reward * gpow[t];
+        if (actions_log && t < log_stride) actions_log[(long)i * log_stride + t] = act;
+        state[i] = rc.next;
+        steps[i] = t + 1;
+        live = !(done || t + 1 >= max_steps);
+        alive[i] = live ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_alive, (int)__popcll(b));
+}
+
+__global__ void greedy_actions_kernel(int n, int A, const double *__restrict__ Q, const int32_t *__restrict__ state,
+                                      int32_t *__restrict__ plans, int plan_stride)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double *q = Q + (long)state[i] * A;
+    int best = 0;
+    double m = q[0];
+    for (int a = 1; a < A; ++a)
+        if (q[a] > m) { m = q[a]; best = a; } // np.argmax: first maximum
+    plans[(long)i * plan_stride] = best;
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -225,6 +265,37 @@ int mp_ctx_create(int device, void *stream, mp_ctx **out)
         return fail(MP_ERR_HIP, "hipEventCreate failed");
     }
     *out = ctx;
+    return MP_OK;
+}
+
+int mp_env_step(mp_ctx *ctx, mp_model *model, int32_t n, int32_t *state, int32_t *steps, uint8_t *alive,
+                const int32_t *plans, int32_t plan_stride, int32_t max_steps, const double *gpow, double *returns,
+                double *discounted, int32_t *actions_log, int32_t log_stride, int32_t *n_alive, int32_t mem)
+{
+    if (!ctx || !model || !state || !steps || !alive || !plans || !gpow || !returns || !discounted || !n_alive)
+        return fail(MP_ERR_ARG, "mp_env_step: NULL argument");
+    if (mem != MP_MEM_DEVICE) return fail(MP_ERR_ARG, "mp_env_step: device arrays only (the loop it serves has no host side)");
+    if (model->mode != MP_MODE_DETERMINISTIC || !model->rec) return fail(MP_ERR_MODE, "mp_env_step: deterministic table models only");
+    if (n < 1 || plan_stride < 1 || max_steps < 1) return fail(MP_ERR_ARG, "mp_env_step: bad sizes");
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_HIP(hipMemsetAsync(n_alive, 0, sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(env_step_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, model->A, model->rec,
+                       model->done_on_next, state, steps, alive, plans, plan_stride, max_steps, gpow, returns, discounted,
+                       actions_log, log_stride, n_alive);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_greedy_actions(mp_ctx *ctx, int32_t n, int32_t S, int32_t A, const double *Q, const int32_t *state, int32_t *plans,
+                      int32_t plan_stride, int32_t mem)
+{
+    if (!ctx || !Q || !state || !plans) return fail(MP_ERR_ARG, "mp_greedy_actions: NULL argument");
+    if (mem != MP_MEM_DEVICE) return fail(MP_ERR_ARG, "mp_greedy_actions: device arrays only");
+    if (n < 1 || S < 1 || A < 1 || plan_stride < 1) return fail(MP_ERR_ARG, "mp_greedy_actions: bad sizes");
+    MP_HIP(hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(greedy_actions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, A, Q, state, plans,
+                       plan_stride);
+    MP_HIP(hipGetLastError());
     return MP_OK;
 }
 

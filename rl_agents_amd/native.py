@@ -76,6 +76,8 @@ SIGNATURES = {
     "mp_saopd_export": (C.c_int, [_vp, c_i32, c_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_olop_allocation": (C.c_int, [c_i32, c_f64, P(c_i32), P(c_i32)]),
     "mp_last_kernel_ms": (C.c_int, [_vp, P(c_f64), P(c_i32)]),
+    "mp_env_step": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, _vp, c_i32, c_i32, _vp, _vp, _vp, _vp, c_i32, _vp, c_i32]),
+    "mp_greedy_actions": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32]),
     "mp_host_alloc": (C.c_int, [_vp, c_i64, P(_vp)]),
     "mp_host_free": (C.c_int, [_vp, _vp]),
     "mp_rng_create": (C.c_int, [_vp, c_i32, P(_vp)]),
@@ -257,6 +259,20 @@ class Context(object):
         rng = DeviceRng(self, st.shape[0])
         rng.set(st)
         return rng
+
+    # ---- batched evaluation on the device ------------------------------------------------------------------------
+    def env_step_device(self, model, state, steps, alive, plans, max_steps, gpow, returns, discounted, actions_log, n_alive):
+        """One lock-step env.step of every live episode (mp_env_step): all arguments are device tensors; only enqueues."""
+        n = int(state.shape[0])
+        _check(self._lib.mp_env_step(self._h, model._h, n, _ptr(state), _ptr(steps), _ptr(alive), _ptr(plans),
+                                     int(plans.shape[1]), int(max_steps), _ptr(gpow), _ptr(returns), _ptr(discounted),
+                                     _ptr(actions_log), 0 if actions_log is None else int(actions_log.shape[1]),
+                                     _ptr(n_alive), MP_MEM_DEVICE))
+
+    def greedy_actions_device(self, q, state, plans):
+        """plans[:, 0] = argmax_a q[state, a] (first maximum), device tensors."""
+        _check(self._lib.mp_greedy_actions(self._h, int(state.shape[0]), int(q.shape[0]), int(q.shape[1]), _ptr(q),
+                                           _ptr(state), _ptr(plans), int(plans.shape[1]), MP_MEM_DEVICE))
 
     # ---- models ------------------------------------------------------------------------------
     def load_table(self, transition, reward, terminal=None, done_rule="source", max_steps=0, available=None):

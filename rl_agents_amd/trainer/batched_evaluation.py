@@ -28,12 +28,24 @@ from rl_agents_amd.agents.tree_search.abstract import np_random
 
 
 class BatchedEvaluation(object):
-    def __init__(self, env, agent, num_episodes=64, sim_seed=0, max_steps=None):
-        """``env``: a finite-MDP environment (template of every episode); ``agent``: a tree-search agent of this
-        package built on it.  ``max_steps``: episode length cap (defaults to the env's ``max_steps``, else 100)."""
+    def __init__(self, env, agent, num_episodes=64, sim_seed=0, max_steps=None, device_resident="auto", sharded=False,
+                 check_every=8):
+        """``env``: a finite-MDP environment (template of every episode); ``agent``: a tree-search or value-iteration
+        agent of this package built on it.  ``max_steps``: episode length cap (defaults to the env's ``max_steps``, else
+        100).
+
+        ``device_resident``: keep the whole loop on the GPU -- root states, step counters, generator records, returns and
+        the action log live in device buffers, the planner runs in its asynchronous device mode and the environments are
+        stepped by ``mp_env_step`` on the planner's own root-state buffer: NO host round trip per step (the host looks at
+        one 4-byte counter every ``check_every`` steps to leave the loop).  ``"auto"``: when the planner supports it
+        (MCTS without tree re-use / closed loop, OPD, value-iteration agents), else the host-stepped loop; ``True``
+        raises if it does not.  ``sharded``: the episodes are split over the ranks of the process group
+        (:func:`rl_agents_amd.distributed.shard_bounds`; episode i keeps seed ``sim_seed + i`` whatever the number of
+        ranks) and the per-episode results are gathered with ONE collective at the end."""
         self.env, self.agent = env, agent
         self.num_episodes = int(num_episodes)
         self.sim_seed = sim_seed
+        self.device_resident, self.sharded, self.check_every = device_resident, bool(sharded), int(check_every)
         mdp = device_model.finite_mdp_of(env)
         if mdp.mode != "deterministic":
             raise TypeError("batched evaluation steps a deterministic finite MDP")
@@ -45,17 +57,126 @@ class BatchedEvaluation(object):
         self.max_steps = int(max_steps or device_model.env_max_steps(env) or 100)
 
     def run(self, initial_states=None):
-        """Run all episodes to termination / truncation. Returns dict(returns, lengths, actions, fps, plan_seconds)."""
-        n = self.num_episodes
-        planner = self.agent.planner
-        states = (np.full(n, self.initial_state, dtype=np.int32) if initial_states is None
+        """Run all episodes to termination / truncation. Returns dict(returns, discounted_returns, lengths, actions, fps,
+        plan_seconds, planner_env_steps) -- with ``sharded`` the per-episode arrays cover ALL episodes on every rank."""
+        first, n = 0, self.num_episodes
+        starts = (np.full(n, self.initial_state, dtype=np.int32) if initial_states is None
                   else np.asarray(initial_states, dtype=np.int32).copy())
+        if self.sharded:
+            from rl_agents_amd.distributed import rank_world, shard_bounds
+            rank, world = rank_world()
+            if n < world:
+                raise RuntimeError("fewer episodes ({}) than ranks ({})".format(n, world))
+            first, hi = shard_bounds(n, rank, world)
+            out = self._run_local(starts[first:hi], first)
+            return self._gather(out, n)
+        return self._run_local(starts, 0)
+
+    def _gather(self, out, n_total):
+        """One packed all_gather of the per-episode results; rates are summed over the ranks' own clocks."""
+        from rl_agents_amd.distributed import all_gather_packed, rank_world
+        keys = ("returns", "discounted_returns", "lengths", "actions")
+        full = all_gather_packed({k: out[k] for k in keys}, n_total)
+        rank, world = rank_world()
+        scal = np.array([[out["fps"], out["plan_seconds"], float(out["planner_env_steps"])]])
+        scal = all_gather_packed({"s": scal}, world)["s"] if world > 1 else scal
+        return dict(full, fps=float(scal[:, 0].sum()), plan_seconds=float(scal[:, 1].max()),
+                    planner_env_steps=int(scal[:, 2].sum()), device_resident=out.get("device_resident", False))
+
+    def _device_capable(self):
+        agent = self.agent
+        if hasattr(agent, "get_state_action_value") and not hasattr(agent, "planner"):
+            return True
+        planner = getattr(agent, "planner", None)
+        return planner is not None and getattr(planner, "plan_batch_device", None) is not None and \
+            planner.supports_device_loop()
+
+    def _run_local(self, starts, first):
+        use_device = self.device_resident is True or (self.device_resident == "auto" and self._device_capable())
+        if use_device:
+            if not self._device_capable():
+                raise NotImplementedError("this agent's planner has no device-resident evaluation loop")
+            return self._run_device(starts, first)
+        return self._run_host(starts, first)
+
+    # ---------------------------------------------------------------------------------------- device-resident loop
+    def _run_device(self, starts, first):
+        import torch
+        agent = self.agent
+        vi = not hasattr(agent, "planner")
+        n, T = len(starts), self.max_steps
+        env = agent.planning_env() if hasattr(agent, "planning_env") else self.env
+        if vi:
+            models = device_model.ModelCache()
+            model = models.get(device_model.spec_from_mdp(device_model.finite_mdp_of(self.env),
+                                                          max_steps=device_model.env_max_steps(self.env)))
+            ctx = models.ctx
+        else:
+            planner = agent.planner
+            model = planner.model_for(env)
+            ctx = planner.models.ctx
+        dev = torch.device("cuda", ctx.device)
+        order = getattr(model, "action_order", None)
+        mpl = 1 if vi else planner.device_plan_len(model)
+        d_state = torch.from_numpy(np.ascontiguousarray(starts, dtype=np.int32)).to(dev)
+        d_steps = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_alive = torch.ones(n, dtype=torch.uint8, device=dev)
+        d_ret = torch.zeros(n, dtype=torch.float64, device=dev)
+        d_disc = torch.zeros(n, dtype=torch.float64, device=dev)
+        d_log = torch.full((n, T), -1, dtype=torch.int32, device=dev)
+        d_plans = torch.full((n, mpl), -1, dtype=torch.int32, device=dev)
+        d_len = torch.zeros(n, dtype=torch.int32, device=dev)
+        d_es = torch.zeros((T, n), dtype=torch.int64, device=dev)          # planner env steps, per step and episode
+        d_status = torch.zeros((T, n), dtype=torch.int32, device=dev)
+        d_nalive = torch.zeros(1, dtype=torch.int32, device=dev)
+        gamma = float(agent.config.get("gamma", 1))
+        d_gpow = torch.from_numpy(gamma ** np.arange(T, dtype=np.float64) if T else np.zeros(0)).to(dev)
+        # the stream a sequential Evaluation gives agent i: np_random(sim_seed + i) (evaluation.py:375)
+        d_rng = torch.from_numpy(native.seed_sequence_states((), self.sim_seed + first, n).view(np.int64)).to(dev)
+        d_q = None
+        if vi:
+            d_q = torch.from_numpy(np.ascontiguousarray(agent.get_state_action_value(), dtype=np.float64)).to(dev)
+        torch.cuda.synchronize(dev)                            # the buffers exist before the ctx stream touches them
+        t0 = time.perf_counter()
+        t = 0
+        while t < T:
+            if vi:
+                ctx.greedy_actions_device(d_q, d_state, d_plans)
+            else:
+                planner.plan_batch_device(env, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_es[t], d_status[t])
+            ctx.env_step_device(model, d_state, d_steps, d_alive, d_plans, T, d_gpow, d_ret, d_disc, d_log, d_nalive)
+            t += 1
+            if t % self.check_every == 0 or t == T:
+                ctx.synchronize()
+                if int(d_nalive.item()) == 0:
+                    break
+        ctx.synchronize()
+        wall = time.perf_counter() - t0
+        lengths = d_steps.cpu().numpy()
+        live = torch.arange(T, device=dev)[:, None] < d_steps[None, :].to(torch.int64)      # step t of episode i was played
+        if not vi:
+            planner.raise_for_device_status(d_status, live)
+            planner.env_steps += int((d_es * live).sum().item())
+        actions = d_log.cpu().numpy()
+        if order is not None:                                  # the device planned in the env's listing order
+            actions = np.where(actions >= 0, np.asarray(order)[np.maximum(actions, 0)], -1).astype(np.int32)
+        return dict(returns=d_ret.cpu().numpy(), discounted_returns=d_disc.cpu().numpy(), lengths=lengths, actions=actions,
+                    fps=float(lengths.sum()) / wall, plan_seconds=wall,
+                    planner_env_steps=0 if vi else int(planner.env_steps), device_resident=True)
+
+    # ---------------------------------------------------------------------------------------- host-stepped loop
+    def _run_host(self, starts, first):
+        n = len(starts)
+        if not hasattr(self.agent, "planner"):
+            return self._run_host_vi(starts)
+        planner = self.agent.planner
+        states = np.asarray(starts, dtype=np.int32).copy()
         steps = np.zeros(n, dtype=np.int32)
         alive = np.ones(n, dtype=bool)
         returns = np.zeros(n)
         gamma_returns = np.zeros(n)
         gamma = float(self.agent.config.get("gamma", 1))
-        rng = np.stack([native.rng_state_from_generator(np_random(self.sim_seed + i)[0]) for i in range(n)])
+        rng = native.seed_sequence_states((), self.sim_seed + first, n)    # np_random(sim_seed + i), evaluation.py:375
         actions_log = np.full((n, self.max_steps), -1, dtype=np.int32)
         env = preprocess_env(self.env, self.agent.config["env_preprocessors"])
         subtree = planner.config.get("step_strategy") == "subtree" and hasattr(planner, "step_by_subtree")
@@ -107,7 +228,35 @@ class BatchedEvaluation(object):
             alive[idx] = ~(done | (steps[idx] >= self.max_steps))
         wall = time.perf_counter() - t0
         return dict(returns=returns, discounted_returns=gamma_returns, lengths=steps.copy(), actions=actions_log,
-                    fps=env_steps / wall, plan_seconds=plan_seconds, planner_env_steps=planner.env_steps)
+                    fps=env_steps / wall, plan_seconds=plan_seconds, planner_env_steps=planner.env_steps,
+                    device_resident=False)
+
+    def _run_host_vi(self, starts):
+        """Value-iteration agents on the host-stepped loop: act = argmax Q[state] (value_iteration.py:35), vectorised."""
+        q = np.asarray(self.agent.get_state_action_value())
+        n, T = len(starts), self.max_steps
+        states, steps, alive = np.asarray(starts, dtype=np.int32).copy(), np.zeros(n, np.int32), np.ones(n, bool)
+        returns, gamma_returns = np.zeros(n), np.zeros(n)
+        gamma = float(self.agent.config.get("gamma", 1))
+        actions_log = np.full((n, T), -1, dtype=np.int32)
+        t0, env_steps = time.perf_counter(), 0
+        while alive.any():
+            idx = np.flatnonzero(alive)
+            s = states[idx]
+            act = np.argmax(q[s], axis=1)
+            r = self.reward[s, act]
+            s_next = self.transition[s, act].astype(np.int32)
+            done = self.terminal[s] if self.done_rule == "source" else self.terminal[s_next]
+            actions_log[idx, steps[idx]] = act
+            gamma_returns[idx] += r * gamma ** steps[idx]
+            returns[idx] += r
+            states[idx] = s_next
+            steps[idx] += 1
+            env_steps += len(idx)
+            alive[idx] = ~(done | (steps[idx] >= T))
+        wall = time.perf_counter() - t0
+        return dict(returns=returns, discounted_returns=gamma_returns, lengths=steps.copy(), actions=actions_log,
+                    fps=env_steps / wall, plan_seconds=0.0, planner_env_steps=0, device_resident=False)
 
 
 # --------------------------------------------------------------------------------------------- benchmark mode

@@ -1,0 +1,131 @@
+"""Batched evaluation that STAYS ON THE DEVICE (task 9): root states, step counters, generator records,
+returns and the action log are device buffers, the planner runs in its asynchronous device mode and `mp_env_step` steps the
+environments on the planner's own root-state buffer.  The device-resident loop must reproduce the host-stepped loop --
+which tests/test_gpu_agents.py pins to N sequential agent / env loops -- action for action, and value-iteration agents
+are accepted."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+UCT = "<class 'rl_agents_amd.agents.tree_search.mcts.MCTSAgent'>"
+OPD = "<class 'rl_agents_amd.agents.tree_search.deterministic.DeterministicPlannerAgent'>"
+VI = "<class 'rl_agents_amd.agents.dynamic_programming.value_iteration.ValueIterationAgent'>"
+RVI = "<class 'rl_agents_amd.agents.dynamic_programming.robust_value_iteration.RobustValueIterationAgent'>"
+
+
+def _table_env(masked=False, max_steps=9, state=2):
+    from rl_agents_amd.envs import FiniteMDPEnv, MaskedFiniteMDPEnv, generators
+    cfg = dict(generators.highway_shaped(3, 4, 10, seed=3), state=state, max_steps=max_steps)
+    if masked:
+        cfg["available"] = generators.highway_available(cfg)
+    env = (MaskedFiniteMDPEnv if masked else FiniteMDPEnv)(cfg)
+    env.reset()
+    return env
+
+
+def _compare(a, b):
+    for k in ("lengths", "actions"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    assert np.array_equal(a["returns"], b["returns"]) and np.array_equal(a["discounted_returns"], b["discounted_returns"])
+    assert a["planner_env_steps"] == b["planner_env_steps"]
+
+
+@pytest.mark.parametrize("kind", ["uct", "uct_masked", "uct_highway_like", "opd", "opd_masked"])
+def test_device_resident_loop_equals_host_stepped_loop(kind):
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import HighwayLikeEnv
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    if kind == "uct_highway_like":
+        def make_env():
+            return HighwayLikeEnv(3, 4, 10, seed=3, state=12)
+        cfg = dict(__class__=UCT, budget=150, gamma=0.9)
+    else:
+        def make_env():
+            return _table_env(masked=kind.endswith("masked"))
+        cfg = dict(__class__=UCT, budget=150, gamma=0.9) if kind.startswith("uct") else dict(__class__=OPD, budget=120, gamma=0.85)
+    n = 70                                              # more than a wavefront, ragged
+    starts = (np.arange(n) * 7 % 100).astype(np.int32)
+    runs = []
+    for resident in (False, True):
+        env = make_env()
+        agent = agent_factory(env, dict(cfg))
+        ev = BatchedEvaluation(env, agent, num_episodes=n, sim_seed=40, max_steps=9, device_resident=resident, check_every=4)
+        runs.append(ev.run(initial_states=starts))
+        assert runs[-1]["device_resident"] is resident
+    _compare(runs[0], runs[1])
+    assert runs[0]["lengths"].min() < runs[0]["lengths"].max(), "episodes of different lengths are part of the case"
+
+
+def test_device_resident_loop_equals_sequential_agents():
+    """The anchor itself: N device-resident lock-step episodes = N sequential agent / env loops (evaluation.py:164-190)."""
+    from rl_agents_amd.agents.tree_search.mcts import MCTSAgent
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    cfg = dict(generators.highway_shaped(3, 4, 10, seed=3), state=2, max_steps=9)
+    env = FiniteMDPEnv(cfg)
+    env.reset()
+    agent_cfg = dict(budget=120, gamma=0.9)
+    out = BatchedEvaluation(env, MCTSAgent(env, dict(agent_cfg)), num_episodes=6, sim_seed=40, device_resident=True).run()
+    for i in range(6):
+        e = FiniteMDPEnv(cfg)
+        e.reset()
+        agent = MCTSAgent(e, dict(agent_cfg))
+        agent.seed(40 + i)
+        actions, total, done = [], 0.0, False
+        while not done:
+            a = agent.act(e.mdp.state)
+            _, r, term, trunc, _ = e.step(a)
+            actions.append(a)
+            total += r
+            done = term or trunc
+        assert out["lengths"][i] == len(actions)
+        np.testing.assert_array_equal(out["actions"][i, :len(actions)], actions)
+        assert out["returns"][i] == pytest.approx(total, abs=1e-12)
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_value_iteration_agents_in_the_batched_loop(robust):
+    """VI / robust-VI agents ("tree-search only"): act = argmax Q[state] on the device (mp_greedy_actions),
+    equal to the host loop and to agent.act() step by step."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    env = _table_env(max_steps=12, state=5)
+    if robust:
+        cfg2 = generators.rewire(generators.highway_shaped(3, 4, 10, seed=3), 0.2, seed=9)
+        models = [dict(mode="deterministic", transition=np.asarray(env.mdp.transition).tolist(), reward=env.mdp.reward.tolist()),
+                  dict(mode="deterministic", transition=cfg2["transition"].tolist(), reward=(cfg2["reward"] * 0.9).tolist())]
+        acfg = dict(__class__=RVI, gamma=0.9, iterations=100, models=models)
+    else:
+        acfg = dict(__class__=VI, gamma=0.9, iterations=100)
+    n = 130
+    starts = (np.arange(n) * 11 % 120).astype(np.int32)
+    runs = [BatchedEvaluation(env, agent_factory(env, dict(acfg)), num_episodes=n, max_steps=12, device_resident=r)
+            .run(initial_states=starts) for r in (False, True)]
+    assert runs[1]["device_resident"] and not runs[0]["device_resident"]
+    _compare(runs[0], runs[1])
+    agent = agent_factory(env, dict(acfg))
+    t, term = np.asarray(env.mdp.transition), np.asarray(env.mdp.terminal)
+    for i in (0, 7, 129):
+        s, acts = int(starts[i]), []
+        for _ in range(12):
+            a = int(agent.act(s))
+            acts.append(a)
+            done = bool(term[s])
+            s = int(t[s, a])
+            if done:
+                break
+        np.testing.assert_array_equal(runs[1]["actions"][i, :len(acts)], acts)
+        assert runs[1]["lengths"][i] == len(acts)
+
+
+def test_stateful_planners_keep_the_host_stepped_loop():
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    env = _table_env()
+    agent = agent_factory(env, dict(__class__=UCT, budget=100, step_strategy="subtree"))
+    out = BatchedEvaluation(env, agent, num_episodes=5, sim_seed=3).run()
+    assert out["device_resident"] is False
+    with pytest.raises(NotImplementedError):
+        BatchedEvaluation(env, agent, num_episodes=5, sim_seed=3, device_resident=True).run()

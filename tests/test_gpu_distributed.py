@@ -99,6 +99,21 @@ def _vi_sharded(robust, force_collective=False):
     return q, sweeps
 
 
+def _evaluate(sharded):
+    """BatchedEvaluation of 150 episodes (device-resident loop), optionally sharded over the process group."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    cfg = dict(generators.highway_shaped(3, 4, 10, seed=3), state=2, max_steps=8)
+    env = FiniteMDPEnv(cfg)
+    env.reset()
+    agent = agent_factory(env, dict(__class__=UCT, budget=100, gamma=0.9))
+    starts = (np.arange(150) * 7 % 100).astype(np.int32)
+    out = BatchedEvaluation(env, agent, num_episodes=150, sim_seed=9, max_steps=8, device_resident=True, sharded=sharded).run(
+        initial_states=starts)
+    return {k: out[k] for k in ("returns", "discounted_returns", "lengths", "actions", "planner_env_steps")}
+
+
 def _worker(rank, world, port, backend, queue):
     sys.path.insert(0, REPO)
     import torch
@@ -109,7 +124,7 @@ def _worker(rank, world, port, backend, queue):
     try:
         force = world == 1
         res = dict(plans=_plan_all(force_collective=force), vi=_vi_sharded(False, force), rvi=_vi_sharded(True, force),
-                   backend=dist.get_backend(), world=dist.get_world_size())
+                   evaluation=_evaluate(sharded=True), backend=dist.get_backend(), world=dist.get_world_size())
         from rl_agents_amd import native
         res["lib"] = native.lib_path()
         if rank == 0:
@@ -136,7 +151,7 @@ def _run_group(world, backend):
 @pytest.fixture(scope="module")
 def single():
     """World size 1, no process group: the reference result of every comparison below."""
-    return dict(plans=_plan_all(), vi=_vi_sharded(False), rvi=_vi_sharded(True))
+    return dict(plans=_plan_all(), vi=_vi_sharded(False), rvi=_vi_sharded(True), evaluation=_evaluate(sharded=False))
 
 
 def _assert_same(res, single):
@@ -146,6 +161,9 @@ def _assert_same(res, single):
         for k in a:
             assert a[k].shape[0] == N_ROOTS
             np.testing.assert_array_equal(a[k], b[k], err_msg="{}/{}".format(name, k))
+    for k in ("returns", "discounted_returns", "lengths", "actions"):     # sharded device-resident evaluation
+        np.testing.assert_array_equal(res["evaluation"][k], single["evaluation"][k], err_msg="evaluation/" + k)
+    assert res["evaluation"]["planner_env_steps"] == single["evaluation"]["planner_env_steps"]
     for k in ("vi", "rvi"):
         assert res[k][1] == single[k][1], k                       # same sweep count
         np.testing.assert_array_equal(res[k][0], single[k][0], err_msg=k)
