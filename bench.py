@@ -102,7 +102,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -491,6 +491,103 @@ def bench_uct_cartpole(args, rank, world, local):
         res["cpu_baseline"] = dict(value=done / cdt, unit="env-steps/s", cores=cores, kind="port",
                                    sample="oracle/planning_oracle.c uct_plan_batch (CartPole), OpenMP over {} roots "
                                           "per batch for {:.1f} s".format(n_cpu, cdt))
+    return res
+
+
+def bench_uct_stoch(args, rank, world, local):
+    """MCTS on a STOCHASTIC finite MDP, closed loop (uct_stoch.hip; VERDICT r2 task 7): the highway-shaped table made
+    `sparse` -- every (s, a) reaches its intended next state with probability 0.8 and the IDLE successor with 0.2 -- budget
+    1000 as 33 episodes x horizon 30, observation nodes keyed by the sampled next state.  A step = one batched plan()."""
+    import torch
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    n_roots = args.roots or 65536
+    episodes, horizon, gamma, temperature = 33, 30, 0.8, 2 / (1 - 0.8)
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    s_, a_ = r.shape
+    nxt = np.stack([t, np.repeat(t[:, 1:2], a_, axis=1)], axis=-1).astype(np.int64)        # [S, A, 2]: intended, IDLE's
+    pr = np.broadcast_to(np.array([0.8, 0.2]), (s_, a_, 2)).copy()
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_sparse(pr, nxt, r, term)
+    gids = np.arange(rank * n_roots, (rank + 1) * n_roots)
+    non_term = np.flatnonzero(~np.asarray(term))
+    all_roots = np.random.Generator(np.random.PCG64(12345)).choice(non_term, size=world * n_roots).astype(np.int32)
+    s0 = all_roots[gids]
+    rng0 = seed_states(gids)
+    erng0 = seed_states(gids, base_seed=10 ** 6)
+    dev = torch.device("cuda", local)
+    d_s0 = torch.from_numpy(s0).to(dev)
+    d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)
+    d_erng = torch.from_numpy(erng0.view(np.int64)).to(dev)
+    mpl = 8
+    d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
+    d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
+    d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
+    d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    p = np.ones(a_) / a_
+    lib = ctx._lib
+
+    def step():
+        native._check(lib.mp_uct_plan_stochastic(ctx._h, model._h, n_roots, native._ptr(d_s0), None, episodes, horizon, gamma,
+                                                 temperature, native._ptr(p), native._ptr(p), 1, native._ptr(d_rng),
+                                                 native._ptr(d_erng), mpl, native._ptr(d_plans), native._ptr(d_len),
+                                                 native._ptr(d_val), None, None, native._ptr(d_steps), native.MP_MEM_DEVICE))
+        d_total.add_(d_steps.sum())
+
+    for _ in range(args.warmup):
+        step()
+    d_total.zero_()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    timed = int(d_total.item())
+    step()
+    k_ms = ctx.last_kernel_ms()[0]
+    env_steps = int(d_steps.sum().item())
+    total = sum_over_ranks(float(timed), world) / args.steps
+    # algorithmic bytes, measured quantities: per env step the sampled row's thresholds (2 x 8 B) + next (4) + R (8) + term
+    # (1); per scored level |A| 32-byte nodes; per path node a 32-byte read-modify-write; per created node 32 B
+    sample = np.unique(np.linspace(0, n_roots - 1, 65).astype(np.int64))
+    nodes = sel = 0
+    for root in sample:
+        tr = ctx.uct_stoch_tree(int(root))
+        nodes += len(tr["parent"])
+        sel += int(tr["count"][(tr["is_obs"] == 0) & (tr["parent"] >= 0)].sum())        # visits of action nodes = selection steps
+    smp_env = float(d_steps[torch.from_numpy(sample).to(dev)].sum().item())
+    bytes_per_step = (29.0 * smp_env + 32.0 * a_ * sel + 2 * 32.0 * (2 * sel + len(sample) * episodes) + 32.0 * nodes) / smp_env
+    res = dict(
+        metric="rollout env-steps/sec (UCT plan() on a stochastic model, closed loop, budget=1000)", unit="env-steps/s",
+        value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
+        config=dict(workload="uct_stochastic_sparse_highway_shaped_S{}_A{}_B2_closed_loop_budget1000_e{}xh{}_roots{}_per_gpu".format(
+            s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, episodes=episodes,
+            horizon=horizon, gamma=gamma, env_steps_per_step=total, measured_nodes_per_tree=nodes / float(len(sample)),
+            algorithmic_bytes_per_env_step=bytes_per_step, parallelism="roots sharded over {} GPU(s)".format(world)),
+        roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      kernel="uct_stoch_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps,
+                      traffic=None, traffic_frac=None,
+                      note="generic kernel (one root per lane, root-major 32-byte nodes, parent links): written for parity, "
+                           "not tuned"),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        cores = host_cores()
+        n_cpu = 64 * cores
+        done, t1 = 0, time.perf_counter()
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            o = oracle.uct_plan_stoch_batch("sparse", pr, r, term, np.resize(all_roots, n_cpu), episodes, horizon, gamma,
+                                            temperature, p, p, seed_states(np.arange(n_cpu)), seed_states(np.arange(n_cpu), 10 ** 6),
+                                            next_states=nxt, closed_loop=True, n_threads=cores)
+            done += int(o["env_steps"].sum())
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=done / cdt, unit="env-steps/s", cores=cores, kind="port",
+                                   sample="oracle/planning_oracle.c orc_uct_plan_stoch_batch, OpenMP over {} roots per batch for "
+                                          "{:.1f} s".format(n_cpu, cdt))
     return res
 
 
@@ -1003,6 +1100,8 @@ def main():
             res = bench_uct(args, rank, world, local)
         elif args.workload == "uct_cartpole":
             res = bench_uct_cartpole(args, rank, world, local)
+        elif args.workload == "uct_stoch":
+            res = bench_uct_stoch(args, rank, world, local)
         elif args.workload == "opd":
             res = bench_opd(args, rank, world, local)
         elif args.workload == "ropd":

@@ -50,7 +50,7 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "uct_prior", "uct_cartpole", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
+    for wl in ("uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
@@ -69,7 +69,7 @@ def main():
                     name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
             lines.append("")
     traffic = {}
-    for wl in ("uct", "uct_prior", "vi_dense", "rvi_dense_shard", "opd", "opd8192", "ropd", "saopd"):
+    for wl in ("uct", "uct_prior", "uct_stoch", "vi_dense", "rvi_dense_shard", "opd", "opd8192", "ropd", "saopd"):
         entry = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             f = os.path.join(src, "pmc_{}_{}".format(wl, ctr), wl + "_counter_collection.csv")
