@@ -377,6 +377,10 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
  * The model must outlive the planners (they read its transition records).
  * mp_saopd_export: arena of one planner in creation order (node rows [root, n_nodes) are the current tree; `alive` =
  * "in planner.leaves"), arrays of capacity >= n_nodes (mp_saopd_info), and state_values double [S].
+ * Restricted action sets (mp_model_set_available on the model; deterministic.py:32-35): an expansion still takes |A|
+ * consecutive rows, the rows of unlisted actions are PHANTOMS -- lower = -inf, never alive, in no state's list, count 0 --
+ * that a caller drops (rl_agents_amd/native.py StateAwarePlanners.export does, and renumbers); env_steps counts the
+ * listed actions only.
  */
 typedef struct mp_saopd mp_saopd;
 int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd **out);

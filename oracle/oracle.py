@@ -419,7 +419,7 @@ class StateAwarePlannerState(object):
 
     FIELDS = (("parent", np.int32), ("action", np.int32), ("state", np.int32), ("depth", np.int32),
               ("reward", np.float64), ("lower", np.float64), ("done", np.uint8), ("count", np.int64),
-              ("first_child", np.int32), ("alive", np.uint8), ("next_same", np.int32))
+              ("first_child", np.int32), ("alive", np.uint8), ("next_same", np.int32), ("n_children", np.int32))
 
     def __init__(self, n_states):
         self.n_nodes, self.root, self.cap = 0, -1, 0
@@ -439,11 +439,13 @@ class StateAwarePlannerState(object):
 
 def saopd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_state=None, planner=None,
                accuracy=0.0, backup_aggregated_nodes=True, prune_suboptimal_leaves=True, done_rule="source",
-               max_plan_len=64):
+               max_plan_len=64, available=None):
     """StateAwarePlanner.plan for one root (tree_search/state_aware.py).  planner: the StateAwarePlannerState of the
-    planner object this plan() is called on (None = a new planner); returned in the result for the next call."""
+    planner object this plan() is called on (None = a new planner); returned in the result for the next call.
+    available: bool [S, A] = state.get_available_actions() per state (deterministic.py:32-35), None = all."""
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
+    av = None if available is None else _u8(np.asarray(available).reshape(s, a))
     fresh = planner is None
     if fresh:
         planner = StateAwarePlannerState(s)
@@ -462,7 +464,8 @@ def saopd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=
                               _p(nd["depth"], C.c_int32), _p(nd["reward"], C.c_double), _p(nd["lower"], C.c_double),
                               _p(nd["done"], C.c_uint8), _p(nd["count"], C.c_int64), _p(nd["first_child"], C.c_int32),
                               _p(nd["alive"], C.c_uint8), _p(nd["next_same"], C.c_int32), _p(planner.sv, C.c_double),
-                              _p(planner.head, C.c_int32), _p(planner.tail, C.c_int32))
+                              _p(planner.head, C.c_int32), _p(planner.tail, C.c_int32), _p(av, C.c_uint8),
+                              _p(nd["n_children"], C.c_int32))
     if rc == -2:
         raise ValueError("This planner assumes that all rewards are normalized in [0, 1]")
     if rc == -4:
@@ -480,10 +483,11 @@ def saopd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=
 
 def saopd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
                      accuracy=0.0, backup_aggregated_nodes=True, prune_suboptimal_leaves=True, done_rule="source",
-                     max_plan_len=8, n_threads=1):
+                     max_plan_len=8, n_threads=1, available=None):
     """First plan() of len(s0) fresh planners (no planner state returned): per-planner plans, env steps, status."""
     t, r, term = _i64(transition), _f64(reward), _u8(terminal)
     s, a = r.shape
+    av = None if available is None else _u8(np.asarray(available).reshape(s, a))
     s0 = np.ascontiguousarray(s0, dtype=np.int32)
     n = len(s0)
     rng = (np.tile(np.array([0, 1, 0, 1, 0, 0], np.uint64), (n, 1)) if rng_states is None
@@ -496,7 +500,7 @@ def saopd_plan_batch(transition, reward, terminal, s0, budget, gamma, terminal_r
                                     C.c_double(accuracy), int(bool(backup_aggregated_nodes)),
                                     int(bool(prune_suboptimal_leaves)), _p(rng, C.c_uint64), max_plan_len,
                                     _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(steps, C.c_int64),
-                                    _p(updates, C.c_int64), _p(status, C.c_int32), int(n_threads))
+                                    _p(updates, C.c_int64), _p(status, C.c_int32), int(n_threads), _p(av, C.c_uint8))
     assert rc == 0
     return dict(plans=plans, plan_len=plan_len, env_steps=steps, updates=updates, status=status, rng_after=rng)
 

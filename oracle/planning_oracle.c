@@ -1110,7 +1110,11 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
                    /* planner state: arena of capacity cap nodes, n_nodes in/out, root out */
                    int fresh, int cap, int32_t *n_nodes_io, int32_t *root_out, int32_t *parent, int32_t *action,
                    int32_t *state, int32_t *depth, double *reward, double *lower, uint8_t *done, int64_t *count,
-                   int32_t *first_child, uint8_t *alive, int32_t *next_same, double *sv, int32_t *head, int32_t *tail)
+                   int32_t *first_child, uint8_t *alive, int32_t *next_same, double *sv, int32_t *head, int32_t *tail,
+                   /* restricted action sets (deterministic.py:32-35): avail [S,A] flags = state.get_available_actions(),
+                    * NULL = all; n_children [cap] (in / out with the arena): children are contiguous from first_child,
+                    * keyed by `action` */
+                   const uint8_t *avail, int32_t *n_children)
 {
     orc_env env = {S, A, T, R, term, done_on_next, 0, NULL};
     const int K = budget / A; /* deterministic.py:118 */
@@ -1129,7 +1133,7 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
     for (int i = 0; i < n_nodes; ++i) alive[i] = 0;
     const int root = n_nodes++;
     parent[root] = -1; action[root] = -1; state[root] = s0; depth[root] = 0; reward[root] = 0; lower[root] = 0;
-    done[root] = 0; count[root] = 1; first_child[root] = -1; alive[root] = 1; next_same[root] = -1;
+    done[root] = 0; count[root] = 1; first_child[root] = -1; alive[root] = 1; next_same[root] = -1; n_children[root] = 0;
     /* plan(), state_aware.py:117-121 */
     head[s0] = tail[s0] = root;
     sv[s0] = vmax;
@@ -1148,8 +1152,12 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
         /* deterministic.py:28-43 expand */
         alive[leaf] = 0;
         first_child[leaf] = n_nodes;
+        n_children[leaf] = 0;
         for (int a = 0; a < A; ++a) {
+            if (avail && !avail[(long)state[leaf] * A + a]) continue;
             const int c = n_nodes++;
+            n_children[leaf] += 1;
+            n_children[c] = 0;
             parent[c] = leaf; action[c] = a; depth[c] = depth[leaf] + 1; first_child[c] = -1;
             int32_t s = state[leaf], st = 0;
             double r; int terminated, truncated;
@@ -1182,7 +1190,7 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
             if (first_child[node] >= 0) {
                 int bc = first_child[node];
                 double bcu = SA_U(bc);
-                for (int a = 1; a < A; ++a) {
+                for (int a = 1; a < n_children[node]; ++a) {
                     const double u = SA_U(first_child[node] + a);
                     if (u > bcu) { bc = first_child[node] + a; bcu = u; }
                 }
@@ -1232,11 +1240,11 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
             while (first_child[n] >= 0) {
                 const int fc = first_child[n];
                 double m = lower[fc];
-                for (int a = 1; a < A; ++a) if (lower[fc + a] > m) m = lower[fc + a];
+                for (int a = 1; a < n_children[n]; ++a) if (lower[fc + a] > m) m = lower[fc + a];
                 int ties[64], nt = 0;
-                for (int a = 0; a < A && nt < 64; ++a) if (lower[fc + a] == m) ties[nt++] = a;
+                for (int a = 0; a < n_children[n] && nt < 64; ++a) if (lower[fc + a] == m) ties[nt++] = a;
                 const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
-                if (plan && len < max_plan_len) plan[len] = a;
+                if (plan && len < max_plan_len) plan[len] = action[fc + a];
                 ++len;
                 n = fc + a;
             }
@@ -1259,12 +1267,12 @@ int orc_saopd_plan_batch(int S, int A, const int64_t *T, const double *R, const 
                          int n, const int32_t *s0, int budget, double gamma, double terminal_reward, double accuracy,
                          int backup_aggregated_nodes, int prune_suboptimal_leaves, uint64_t *rng6 /* [n,6] */,
                          int max_plan_len, int32_t *plans, int32_t *plan_len, int64_t *env_steps, int64_t *updates,
-                         int32_t *status, int n_threads)
+                         int32_t *status, int n_threads, const uint8_t *avail)
 {
     const int cap = 1 + (budget / A) * A;
 #pragma omp parallel for schedule(dynamic, 4) num_threads(n_threads > 0 ? n_threads : 1)
     for (int i = 0; i < n; ++i) {
-        int32_t *i32 = malloc((size_t)cap * 6 * sizeof(int32_t) + (size_t)S * 2 * sizeof(int32_t));
+        int32_t *i32 = malloc((size_t)cap * 7 * sizeof(int32_t) + (size_t)S * 2 * sizeof(int32_t));
         double *f64 = malloc((size_t)cap * 2 * sizeof(double) + (size_t)S * sizeof(double));
         int64_t *cnt = malloc((size_t)cap * sizeof(int64_t));
         uint8_t *u8 = malloc((size_t)cap * 2);
@@ -1276,7 +1284,7 @@ int orc_saopd_plan_batch(int S, int A, const int64_t *T, const double *R, const 
                                 plans ? plans + (long)i * max_plan_len : NULL, plan_len ? plan_len + i : NULL,
                                 env_steps ? env_steps + i : NULL, updates ? updates + i : NULL, 1, cap, &nn, &root,
                                 i32, i32 + cap, i32 + 2 * cap, i32 + 3 * cap, f64, f64 + cap, u8, cnt, i32 + 4 * cap,
-                                u8 + cap, i32 + 5 * cap, f64 + 2 * cap, i32 + 6 * cap, i32 + 6 * cap + S);
+                                u8 + cap, i32 + 5 * cap, f64 + 2 * cap, i32 + 7 * cap, i32 + 7 * cap + S, avail, i32 + 6 * cap);
         if (status) status[i] = rc;
         free(i32); free(f64); free(cnt); free(u8);
     }

@@ -21,7 +21,6 @@ logger = logging.getLogger(__name__)
 class StateAwarePlanner(OptimisticDeterministicPlanner):
     """State-aware planner (state_aware.py:70-127) for one or many independent planners of one finite MDP."""
     carries_state = True    # per-slot state on the device: callers keep the batch composition fixed
-    supports_restricted_actions = False
 
     def __init__(self, env, config=None):
         super(StateAwarePlanner, self).__init__(env, config)
@@ -65,7 +64,8 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
         if not getattr(self, "defer_errors", False):               # (a batched caller checks its live slots only)
             self.raise_for_status(out["status"])
         out["rng_states"] = rng_states
-        self.last, self._root, self._last_actions = out, None, model.A
+        self.relabel(out, model)
+        self.last, self._root, self._last_actions, self._last_model = out, None, model.A, model
         self.env_steps += int(out["env_steps"].sum())
         return out
 
@@ -82,6 +82,7 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
 
     def export_tree(self, root=0):
         arrays, state_values = self._device[2].export(root)
+        arrays = self.relabel_tree(arrays, getattr(self, "_last_model", None))
         arrays["value_lower"] = arrays["lower"]
         # get_value_upper_bound (state_aware.py:65-67): value_lower + gamma**depth * state_values[observation]
         gamma = self.config["gamma"]

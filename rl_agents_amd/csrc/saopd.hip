@@ -251,6 +251,18 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
         for (int a = 0; a < A; ++a) {
             const int c = n_nodes + a;
             const Rec rc = p.rec[(long)sl * A + a];
+            if (!(rc.flags & 4u)) {
+                // deterministic.py:32-35: an action state.get_available_actions() does not list gets no child.  Its slot
+                // stays in the id space (ids advance by |A| per expansion) as a PHANTOM row: lower = -inf (never the best
+                // child of a Bellman backup), not alive (never a leaf), in no state's list (never a neighbour, never a
+                // dominator), dead for the prune scan; the export drops it.
+                SaNode ph;
+                ph.lower = -INFINITY; ph.next_same = -1; ph.meta = (uint32_t)(dl + 1);
+                ND(c) = ph;
+                ST(c) = rc.next; PA(c) = leaf; FC(c) = -1; RW(c) = 0.0;
+                p.done[(long)c * n + r] = 2;
+                continue;
+            }
             const bool terminated = (rc.flags & done_bit) != 0;
             ++steps_taken;
             if (!(0.0 <= rc.reward) || !(rc.reward <= 1.0)) { status = MP_ERR_REWARD_RANGE; break; }
@@ -645,28 +657,33 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
         const int dl = (int)(lf.meta & SA_DEPTH);
         const int32_t sl = ST(leaf);
         const int g = n_nodes;
-        bool bad = false, term_c = false;
+        bool bad = false, term_c = false, real_c = false;
         int32_t s_c = 0;
         if (lane < A) {
             const Rec rc = p.rec[(long)sl * A + lane];
-            term_c = (rc.flags & done_bit) != 0;
-            bad = !(0.0 <= rc.reward) || !(rc.reward <= 1.0);
+            // deterministic.py:32-35: the slot of an action state.get_available_actions() does not list is a PHANTOM row
+            // (see saopd_kernel): lower = -inf, not alive, in no state's list, dead for the prune scan
+            real_c = (rc.flags & 4u) != 0;
+            term_c = real_c && (rc.flags & done_bit) != 0;
+            bad = real_c && (!(0.0 <= rc.reward) || !(rc.reward <= 1.0));
             const int d = dl + 1;
             double lower = lf.lower + gpow[d - 1] * rc.reward;
             if (term_c) lower = lower + trg[d];
+            if (!real_c) lower = -INFINITY;
             s_c = rc.next;
             const int c = g + lane;
             SaNode nd;
-            nd.lower = lower; nd.next_same = -1; nd.meta = SA_ALIVE | ((uint32_t)lane << SA_ACT_SHIFT) | (uint32_t)d;
+            nd.lower = lower; nd.next_same = -1; nd.meta = (real_c ? SA_ALIVE : 0u) | ((uint32_t)lane << SA_ACT_SHIFT) | (uint32_t)d;
             ND(c) = nd;
-            ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = rc.reward;
-            p.done[nb + c] = term_c ? 1 : 0;
+            ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = real_c ? rc.reward : 0.0;
+            p.done[nb + c] = real_c ? (term_c ? 1 : 0) : 2;
         }
+        const unsigned long long real_mask = __ballot(real_c);
         if (l0) {
             ND(leaf).meta = (lf.meta & ~SA_ALIVE) | SA_CHILDREN;
             FC(leaf) = g;
         }
-        steps_taken += A;
+        steps_taken += __popcll(real_mask); // planner.step calls: one per listed action
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         __syncthreads();
         // state_nodes[str(observation)].append(child), update_value(observation, 0), child by child in action order.  What an
@@ -683,6 +700,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                 if (par_backup) my_ls = ls_b[s_c];
             }
             for (int a = 0; a < A; ++a) {
+                if (!((real_mask >> a) & 1ULL)) continue; // a phantom slot joins no list and moves no state value (uniform)
                 const int32_t s = __builtin_amdgcn_readlane(s_c, a);
                 const bool term = __builtin_amdgcn_readlane((int)term_c, a) != 0;
                 const int c = g + a;
@@ -1628,7 +1646,8 @@ int mp_saopd_export(mp_saopd *pl, int32_t planner, int32_t cap, int32_t *parent,
     if (count) {
         // DeterministicNode starts at count 1 and update() adds 1 along the whole root->child sequence
         // (deterministic.py:17,64-65): count = 1 + subtree size, the root of a tree (no update of its own) one less
-        for (size_t i = 0; i < nn; ++i) count[i] = 1;
+        // (phantom rows -- slots of actions the env does not list, lower = -inf -- are not nodes: they count for nothing)
+        for (size_t i = 0; i < nn; ++i) count[i] = hn[i].lower == -INFINITY ? 0 : 1;
         for (size_t i = nn; i-- > 0;)
             if (hpar[i] >= 0) count[hpar[i]] += count[i];
         for (size_t i = 0; i < nn; ++i) count[i] = hpar[i] >= 0 ? count[i] + 1 : count[i];

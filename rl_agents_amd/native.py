@@ -805,12 +805,28 @@ class StateAwarePlanners(object):
                                              _ptr(t["state"]), _ptr(t["depth"]), _ptr(t["reward"]), _ptr(t["lower"]),
                                              _ptr(t["done"]), _ptr(t["count"]), _ptr(t["first_child"]), _ptr(t["alive"]),
                                              _ptr(sv)))
-        if current_tree_only:
-            lo = inf["root"]
-            t = {k: v[lo:].copy() for k, v in t.items()}
-            for k in ("parent", "first_child"):
-                t[k] = np.where(t[k] >= 0, t[k] - lo, -1).astype(np.int32)
-        return t, sv
+        # Rows of actions the environment does not list (restricted action sets, deterministic.py:32-35) are PHANTOMS in
+        # the arena -- lower = -inf, never alive -- that only keep the ids of an expansion's |A| slots contiguous: they
+        # are not nodes of the tree.  Drop them and renumber; a node's children are then contiguous from first_child,
+        # n_children of them.
+        lo = inf["root"] if current_tree_only else 0
+        keep = ~np.isneginf(t["lower"])
+        new_id = np.cumsum(keep) - 1
+        fc_old = t["first_child"]
+        n_children = np.zeros(cap, np.int32)
+        has = fc_old >= 0
+        for i in np.flatnonzero(has):                      # an expansion's |A| slots: fc .. fc + |A| - 1
+            grp = keep[fc_old[i]:fc_old[i] + self.model.A]
+            n_children[i] = int(grp.sum())
+            fc_old[i] = fc_old[i] + int(np.argmax(grp))
+        t["n_children"] = n_children
+        sel = keep.copy()
+        sel[:lo] = False
+        base = int(new_id[lo]) if lo < cap else 0
+        out = {k: v[sel].copy() for k, v in t.items()}
+        for k in ("parent", "first_child"):
+            out[k] = np.where(out[k] >= lo, new_id[np.maximum(out[k], 0)] - base, -1).astype(np.int32)
+        return out, sv
 
     def close(self):
         if getattr(self, "_h", None) and getattr(self.ctx, "_h", None):

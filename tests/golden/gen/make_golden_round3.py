@@ -197,6 +197,86 @@ def golden_env_side(store):
     store["env_side/opd/names"] = np.asarray(onames)
 
 
+def golden_state_aware_masked(store):
+    """StateAwarePlannerAgent multi-plan episodes on environments that restrict their actions: table envs listing in
+    ascending order (MaskedFiniteMDPEnv) and the highway-like env listing IDLE first (children in listing order)."""
+    from rl_agents_amd.envs import HighwayLikeEnv
+    large1 = mg.load_env_config("large/env_1.json")
+    hw = generators.highway_shaped(3, 4, 10, seed=3)
+    grid = generators.gridworld()
+    garnet = generators.random_deterministic(60, 4, seed=31, terminal_rate=0.05)
+    cases = [
+        # name, env factory, mdp cfg, availability (None: derived from the highway-like env), start, agent cfg, seed, plans
+        ("grid_walls_b500", grid, generators.random_available(100, 4, seed=3, rate=0.3), 0, dict(budget=500, gamma=0.8), 0, 4),
+        ("grid_accuracy", grid, generators.random_available(100, 4, seed=4, rate=0.4), 12, dict(budget=300, gamma=0.8, accuracy=0.05), 1, 3),
+        ("large1_b500", large1, generators.random_available(100, 5, seed=1, rate=0.35), 0, dict(budget=500, gamma=0.8), 0, 3),
+        ("large1_no_aggregation", large1, generators.random_available(100, 5, seed=1, rate=0.35), 7,
+         dict(budget=300, gamma=0.8, backup_aggregated_nodes=False), 2, 3),
+        ("highway_table", hw, generators.highway_available(hw), 0, dict(budget=300, gamma=0.8), 0, 4),
+        ("garnet_half_tr05", garnet, generators.random_available(60, 4, seed=2, rate=0.5), 5,
+         dict(budget=240, gamma=0.85, terminal_reward=0.5), 2, 3),
+        ("highway_like_env", hw, None, 12, dict(budget=300, gamma=0.8), 0, 4),          # restriction on the env, IDLE first
+        ("highway_like_env_corner", hw, None, 119 - 9, dict(budget=200, gamma=0.9), 3, 3),
+    ]
+    names = []
+    for name, cfg, avail, s_start, agent_cfg, seed, n_plans in cases:
+        if avail is None:
+            env = HighwayLikeEnv(table=cfg, state=s_start)
+            avail_store = generators.highway_available(cfg)
+
+            def current(e=env):
+                return e.state_index
+        else:
+            env = make_masked_env(cfg, avail, state=s_start)
+            avail_store = np.asarray(avail, bool)
+
+            def current(e=env):
+                return e.mdp.state
+        agent = agent_factory(env, dict(agent_cfg, __class__=mg.SAOPD))
+        agent.seed(seed)
+        p = "sa_masked/" + name
+        mg.put_mdp(store, p + "/mdp", cfg)
+        pc = agent.planner.config
+        n_states = np.asarray(cfg["reward"]).shape[0]
+        store[p + "/rng_before"] = mg.rng_state(agent.planner.np_random)
+        store[p + "/available"] = avail_store
+        store[p + "/listing_idle_first"] = np.asarray(avail is None)
+        states = []
+        for step in range(n_plans):
+            states.append(current())
+            try:
+                plan = agent.plan(current())
+            except ValueError as e:
+                assert "empty" in str(e)
+                store[p + "/raises_at_step"] = np.asarray(step)
+                break
+            planner = agent.planner
+            leaves = set(id(n) for n in planner.leaves)
+            tree = keyed_tree_sa(planner.root, leaves)
+            sv = np.array([planner.state_values[str(s)] if str(s) in planner.state_values else np.nan for s in range(n_states)])
+            q = "{}/step{}".format(p, step)
+            mg.put(store, q, dict(plan=np.asarray(plan, np.int32), state_values=sv, n_leaves=len(planner.leaves),
+                                  env_steps=len(planner.observations), rng_after=mg.rng_state(planner.np_random)))
+            mg.put(store, q + "/tree", tree)
+            _, _, term, trunc, _ = env.step(plan[0])
+            if term or trunc:
+                break
+        mg.put(store, p, dict(states=np.asarray(states, np.int32), n_steps=len(states), seed=seed, budget=pc["budget"],
+                              gamma=pc["gamma"], terminal_reward=agent.config["terminal_reward"], accuracy=pc["accuracy"],
+                              backup_aggregated_nodes=pc["backup_aggregated_nodes"],
+                              prune_suboptimal_leaves=pc["prune_suboptimal_leaves"]))
+        names.append(name)
+    store["sa_masked/names"] = np.asarray(names)
+
+
+def keyed_tree_sa(root, leaves):
+    from make_golden_variants import keyed_tree
+    return keyed_tree(root, [("count", lambda n: n.count, np.int64), ("lower", lambda n: float(n.value_lower), np.float64),
+                             ("reward", lambda n: float(n.reward), np.float64), ("done", lambda n: bool(n.done), bool),
+                             ("depth", lambda n: n.depth, np.int32), ("obs", lambda n: int(n.observation), np.int64),
+                             ("is_leaf", lambda n: id(n) in leaves, bool)])
+
+
 def golden_uct_stochastic(store):
     """MCTSAgent on STOCHASTIC finite MDPs (dense `stochastic` and `sparse` modes), open and closed loop: the planner
     steps deep copies of the env, each copy carrying a copy of the env's own generator (common/factory.py:119-134), so

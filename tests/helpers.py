@@ -178,3 +178,45 @@ def assert_parent_tree_equal(z, prefix, tree, fields):
         got = np.asarray(tree[mine])[order]
         want = z[prefix + "/" + gold_name]
         assert np.array_equal(got.astype(want.dtype), want), "tree field {} differs".format(gold_name)
+
+
+def replay_state_aware_masked_episode(z, name, plan_fn):
+    """Replay one golden StateAwarePlannerAgent episode on an environment that restricts its actions
+    (tests/golden/round3.npz, sa_masked/*): every plan, keyed tree, leaves set, state-value table, env-step count and
+    generator state.  plan_fn(cfg, available, order, s0, params, rng, planner_state) -> dict(plan, env_steps, rng_after,
+    tree, state_values, planner) in the ENVIRONMENT's action ids; `order` = the env's listing order (None = ascending);
+    tree: creation-order arrays re-based at the root with `action`, `n_children`, `alive`.  Raises where the reference does."""
+    import pytest
+    p = "sa_masked/" + name
+    cfg = mdp_from_golden(z, p + "/mdp")
+    params = dict(budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
+                  terminal_reward=float(z[p + "/terminal_reward"]), accuracy=float(z[p + "/accuracy"]),
+                  backup_aggregated_nodes=bool(z[p + "/backup_aggregated_nodes"]),
+                  prune_suboptimal_leaves=bool(z[p + "/prune_suboptimal_leaves"]))
+    order = [1, 0, 2, 3, 4] if bool(z[p + "/listing_idle_first"]) else None
+    rng = np.array(z[p + "/rng_before"], dtype=np.uint64)
+    raises_at = int(z[p + "/raises_at_step"]) if p + "/raises_at_step" in z.files else -1
+    planner, env_steps = None, 0
+    n_steps = int(z[p + "/n_steps"])
+    for step in range(n_steps):
+        s0 = int(z[p + "/states"][step])
+        if step == raises_at:
+            with pytest.raises(ValueError):
+                plan_fn(cfg, z[p + "/available"], order, s0, params, rng, planner)
+            break
+        out = plan_fn(cfg, z[p + "/available"], order, s0, params, rng, planner)
+        q = "{}/step{}".format(p, step)
+        np.testing.assert_array_equal(out["plan"], z[q + "/plan"], err_msg=q)
+        np.testing.assert_array_equal(out["rng_after"], z[q + "/rng_after"], err_msg=q)
+        env_steps += int(out["env_steps"])
+        assert env_steps == int(z[q + "/env_steps"]), q
+        tree = out["tree"]
+        assert int(np.asarray(tree["alive"]).sum()) == int(z[q + "/n_leaves"]), q
+        assert_keyed_tree_equal(z, q + "/tree", tree, dict(count="count", lower="lower", reward="reward", done="done",
+                                                          depth="depth", obs="state", is_leaf="alive"))
+        want = z[q + "/state_values"]
+        seen = ~np.isnan(want)
+        assert np.array_equal(out["state_values"][seen], want[seen]), q
+        assert np.all(out["state_values"][~seen] == 1 / (1 - params["gamma"])), q
+        planner, rng = out["planner"], out["rng_after"]
+    assert raises_at >= 0 or n_steps > 0

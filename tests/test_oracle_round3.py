@@ -148,3 +148,30 @@ def test_uct_on_stochastic_models_goldens(z):
         np.testing.assert_array_equal(out["rng_after"], z[p + "/rng_after"], err_msg=name)
         assert_parent_tree_equal(z, p + "/tree", out["tree"], dict(count="count", value="value", prior="prior", is_obs="is_obs"))
         assert int(out["tree"]["count"][0]) == int(z[p + "/root_count"])
+
+
+# ------------------------------------------------------------------ state-aware OPD on restricted action sets
+def oracle_sa_masked_plan(cfg, available, order, s0, params, rng, planner):
+    """One plan() of the oracle's state-aware planner on a restricted-action model; with a listing order the oracle plans
+    in the permuted action space and the labels are mapped back (see test_env_side_opd_goldens_oracle_in_listing_order)."""
+    from oracle import oracle
+    t, r, av = cfg["transition"], cfg["reward"], np.asarray(available)
+    if order is not None:
+        o = np.asarray(order)
+        t, r, av = t[:, o], r[:, o], av[:, o]
+    out = oracle.saopd_plan(t, r, cfg["terminal"], s0, params["budget"], params["gamma"], params["terminal_reward"],
+                            rng_state=rng, planner=planner, accuracy=params["accuracy"],
+                            backup_aggregated_nodes=params["backup_aggregated_nodes"],
+                            prune_suboptimal_leaves=params["prune_suboptimal_leaves"], max_plan_len=params["budget"] + 1,
+                            available=av)
+    if order is not None:
+        o = np.asarray(order)
+        out["plan"] = o[out["plan"]]
+        out["tree"]["action"] = np.where(out["tree"]["action"] >= 0, o[np.maximum(out["tree"]["action"], 0)], -1)
+    return out
+
+
+def test_state_aware_restricted_actions_goldens(z):
+    from tests.helpers import replay_state_aware_masked_episode
+    for name in names(z, "sa_masked"):
+        replay_state_aware_masked_episode(z, name, oracle_sa_masked_plan)
