@@ -14,4 +14,13 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def test_random_cases_match_the_oracle(seed):
     import fuzz_parity
     kinds = fuzz_parity.run(200, seed)
-    assert sum(kinds.values()) == 200 and len(kinds) == 9
+    assert sum(kinds.values()) == 200 and len(kinds) == 12        # every kind, the three of round 3 included
+
+
+def test_random_cases_of_the_round3_kinds(monkeypatch):
+    """Only the kinds added in round 3: robust OPD and state-aware OPD on restricted action sets (all kernel mappings),
+    MCTS on stochastic / sparse / deterministic models through the literal kernel (open and closed loop, whole trees)."""
+    import fuzz_parity
+    monkeypatch.setenv("FUZZ_KINDS", "ropd_masked,saopd_masked,uct_stoch")
+    kinds = fuzz_parity.run(150, 31)
+    assert sum(kinds.values()) == 150 and set(kinds) == {"ropd_masked", "saopd_masked", "uct_stoch"}

@@ -60,11 +60,16 @@ def one_case(ctx, g, case):
     s0 = g.integers(0, s, size=n).astype(np.int32)
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
-    kind = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree", "uct_listed", "opd_masked", "ropd"][int(g.integers(0, 9))]
+    kinds = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree", "uct_listed", "opd_masked", "ropd",
+             "ropd_masked", "saopd_masked", "uct_stoch"]                    # (the last three: round 3)
+    only = os.environ.get("FUZZ_KINDS")
+    if only:
+        kinds = [k for k in kinds if k in only.split(",")]
+    kind = kinds[int(g.integers(0, len(kinds)))]
     # OPD kernels: let the host choose the variant, or force one ("ldsx": parent map in HBM; "global": bounds in HBM)
     variant = str(g.choice(["", "lds", "ldsx", "global"]))
     os.environ.pop("MP_OPD_MODEL", None)
-    if variant and kind in ("opd", "opd_masked", "ropd"):
+    if variant and kind in ("opd", "opd_masked", "ropd", "ropd_masked"):
         os.environ["MP_OPD_MODEL"] = variant
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant)
     if kind == "vi":
@@ -218,6 +223,96 @@ def one_case(ctx, g, case):
         for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
             eq(out[k], ref[k], k, desc)
         eq(rng_dev, ref["rng_after"], "rng", desc)
+    elif kind == "uct_stoch":       # MCTS on stochastic / sparse finite MDPs, open and closed loop (uct_stoch.hip)
+        mode = str(g.choice(["stochastic", "sparse", "deterministic"]))
+        closed = bool(g.random() < 0.6)
+        model.close()
+        nxt = None
+        if mode == "stochastic":
+            s = min(s, 257)                                           # [S, A, S] thresholds
+            t, r, term, s0 = t[:s] % s, r[:s], term[:s], s0 % s
+            p_ = g.random((s, a, s)) ** float(g.choice([1.0, 4.0, 12.0]))      # from flat to a few likely next states
+            if g.random() < 0.3:
+                p_[g.random((s, a, s)) < 0.5] = 0.0                   # exact zeros inside the rows
+                p_[:, :, 0] += 1e-3
+            p_ /= p_.sum(axis=-1, keepdims=True)
+            model = ctx.load_dense(p_, r, term)
+            trans = p_
+        elif mode == "sparse":
+            b = int(g.choice([1, 2, 3, 5]))
+            nxt = g.integers(0, s, size=(s, a, b), dtype=np.int64)
+            p_ = g.random((s, a, b)) + 0.05
+            p_ /= p_.sum(axis=-1, keepdims=True)
+            model = ctx.load_sparse(p_, nxt, r, term)
+            trans = p_
+        else:
+            model = ctx.load_table(t, r, term)
+            trans = t
+        model.set_episode_rules(done_rule, max_steps)
+        episodes = int(g.choice([0, 1, 7, 33, 90]))
+        horizon = int(g.choice([1, 2, 6, 11, 30]))
+        temperature = float(g.choice([0.0, 1.0, 10.0, 200.0]))
+        prior = g.random(a) + 0.05
+        prior /= prior.sum()
+        roll = g.random(a) ** 2 + 1e-3
+        roll /= roll.sum()
+        steps0 = g.integers(0, 3, size=n).astype(np.int32)
+        erng = rng_states(g, n)
+        erng[:, 4:] = 0
+        desc.update(mode=mode, closed=closed, episodes=episodes, horizon=horizon, temperature=temperature, S=s)
+        rng_dev = rng.copy()
+        mpl = 2 * horizon + 2
+        out = ctx.uct_plan_stochastic(model, s0, episodes, horizon, gamma, temperature, prior, roll, rng_dev, env_rng_state=erng,
+                                      closed_loop=closed, root_steps=steps0, max_plan_len=mpl)
+        ref = oracle.uct_plan_stoch_batch(mode, trans, r, term, s0, episodes, horizon, gamma, temperature, prior, roll, rng.copy(),
+                                          erng, next_states=nxt, closed_loop=closed, steps0=steps0, max_steps=max_steps,
+                                          done_rule=done_rule, max_plan_len=mpl, n_threads=8)
+        for k in ("plans", "plan_len", "env_steps", "root_value"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+        root = int(g.integers(0, n))                                  # one whole tree, node for node
+        tree = ctx.uct_stoch_tree(root)
+        one = oracle.uct_plan_stoch(mode, trans, r, term, int(s0[root]), episodes, horizon, gamma, temperature, prior, roll,
+                                    rng[root].copy(), erng[root], next_states=nxt, closed_loop=closed, steps0=int(steps0[root]),
+                                    max_steps=max_steps, done_rule=done_rule, max_plan_len=mpl)["tree"]
+        for k in ("parent", "action", "is_obs", "count", "value"):
+            eq(tree[k], one[k], "tree " + k, desc)
+    elif kind == "ropd_masked":     # robust OPD on models that restrict their actions: union over the models (robust.py:22-25)
+        m = int(g.choice([1, 2, 3, 5]))
+        tm = np.stack([t] + [g.integers(0, s, size=(s, a), dtype=np.int64) for _ in range(m - 1)])
+        rm = np.stack([r] + [np.clip(r * float(g.uniform(0.5, 1.0)), 0.0, 1.0) for _ in range(m - 1)])
+        termm = np.stack([term] + [g.random(s) < 0.1 for _ in range(m - 1)])
+        avail = g.random((m, s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
+        for k in range(m):
+            avail[k, np.arange(s), g.integers(0, a, size=s)] = True
+        if m > 1 and g.random() < 0.3:
+            avail[m - 1] = True                                        # a model whose env has no get_available_actions
+        model.close()
+        model = ctx.load_joint(tm, rm, termm, done_rule=done_rule, available=avail)
+        budget = int(g.choice([0, 1, a, 3 * a + 1, 100, 400]))
+        tr = float(g.choice([0.0, 0.25, 1.0]))
+        if gamma >= 0.999:
+            gamma = 0.95
+        n = min(n, 200)
+        joint = g.integers(0, s, size=(n, m)).astype(np.int32)
+        if g.random() < 0.5:
+            joint[:] = joint[:, :1]
+        desc.update(budget=budget, terminal_reward=tr, gamma=gamma, M=m, n=n)
+        rng_dev = rng[:n].copy()
+        out = ctx.ropd_plan(model, joint, budget, gamma, tr, rng_dev, max_plan_len=budget // a + 1)
+        ref = oracle.ropd_plan_batch(tm, rm, termm, joint, budget, gamma, tr, rng[:n].copy(), done_rule=done_rule,
+                                     max_plan_len=budget // a + 1, n_threads=8, available=avail)
+        for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
+            eq(out[k], ref[k], k, desc)
+        eq(rng_dev, ref["rng_after"], "rng", desc)
+        root = int(g.integers(0, n))
+        if out["status"][root] == 0 and budget >= a:                  # one whole tree
+            tree = ctx.ropd_tree(root, 1 + (budget // a) * a, m)
+            one = oracle.ropd_plan(tm, rm, termm, joint[root], budget, gamma, tr, rng_state=rng[root].copy(), done_rule=done_rule,
+                                   max_plan_len=budget // a + 1, available=avail)["tree"]
+            for k in ("parent", "action", "depth", "count", "first_child", "n_children", "state", "reward"):
+                eq(tree[k], one[k], "tree " + k, desc)
+            eq(tree["lower"].min(axis=1), one["lower"].min(axis=1), "tree min lower", desc)
     elif kind == "ropd":            # discrete robust OPD (agents/robust/robust.py:28-50): M models, joint states
         m = int(g.choice([1, 2, 3, 7]))
         tm = np.stack([t] + [g.integers(0, s, size=(s, a), dtype=np.int64) for _ in range(m - 1)])
@@ -261,7 +356,21 @@ def one_case(ctx, g, case):
                                   max_plan_len=budget // a + 1)["tree"]
             for k in one:
                 eq(tree[k], one[k], "tree " + k, desc)
-    else:
+    else:                           # "saopd" / "saopd_masked": state-aware OPD, two consecutive plans per planner
+        avail = None
+        os.environ.pop("MP_SAOPD_MODEL", None)
+        os.environ.pop("MP_SAOPD_LDS", None)
+        if kind == "saopd_masked":  # deterministic.py:32-35 under the state-aware planner: phantom rows (round 3)
+            avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
+            avail[np.arange(s), g.integers(0, a, size=s)] = True
+            model.close()
+            model = ctx.load_table(t, r, term, done_rule=done_rule, available=avail)
+            mapping = str(g.choice(["wave", "lane", "lds"]))
+            if mapping == "lane":
+                os.environ["MP_SAOPD_MODEL"] = "lane"
+            elif mapping == "lds":
+                os.environ["MP_SAOPD_LDS"] = "1"
+            desc.update(mapping=mapping)
         budget = int(g.choice([0, a, 5 * a, 120, 300] + ([1000] if HEAVY else [])))
         tr = float(g.choice([0.0, 0.5]))
         if gamma >= 0.999:
@@ -280,7 +389,7 @@ def one_case(ctx, g, case):
                     continue
                 try:
                     o = oracle.saopd_plan(t, r, term, int(states[i]), budget, gamma, terminal_reward=tr, rng_state=ref_rng[i],
-                                          planner=ref_pl[i], done_rule=done_rule, max_plan_len=budget + 1, **cfgs)
+                                          planner=ref_pl[i], done_rule=done_rule, max_plan_len=budget + 1, available=avail, **cfgs)
                 except ValueError:
                     if out["status"][i] != native.MP_ERR_ARG:
                         raise AssertionError("status {} where the reference raises, case {}".format(out["status"][i], desc))
@@ -292,15 +401,20 @@ def one_case(ctx, g, case):
                     raise AssertionError("status {} in case {}".format(out["status"][i], desc))
                 eq(out["plans"][i, :out["plan_len"][i]], o["plan"], "plan", desc)
                 eq(out["updates"][i], o["updates"], "updates", desc)
+                eq(out["env_steps"][i], o["env_steps"], "env steps", desc)
                 eq(rng[i], o["rng_after"], "rng", desc)
                 ref_pl[i], ref_rng[i] = o["planner"], o["rng_after"]
                 if i % 16 == 0:
                     tree, sv = planners.export(i)
                     eq(sv, o["state_values"], "state values", desc)
                     eq(tree["alive"], o["tree"]["alive"], "leaves", desc)
+                    for k in ("parent", "action", "lower", "first_child", "n_children", "count"):
+                        eq(tree[k], o["tree"][k], "tree " + k, desc)
             nxt = np.where(out["plan_len"] > 0, t[states, np.maximum(out["plans"][:, 0], 0)], states)
             states = nxt.astype(np.int32)
         planners.close()
+        os.environ.pop("MP_SAOPD_MODEL", None)
+        os.environ.pop("MP_SAOPD_LDS", None)
     model.close()
     return desc
 
