@@ -329,7 +329,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
         latency["kernel_ms_batch_of_{}".format(nl)] = ctx.last_kernel_ms()[0]
         latency["env_steps_batch_of_{}".format(nl)] = int(d_steps[:nl].sum().item())
 
-    pageable_ms = {}
+    pageable_ms, host_kernel_ms = {}, {}
 
     def host_inclusive(nr, reps):
         """SURVEY.md 8(d) as written: wall time of the batched plan() handing over HOST arrays (MP_MEM_HOST: root
@@ -344,11 +344,13 @@ def bench_uct(args, rank, world, local, with_prior=False):
         rngd = ctx.device_rng(rng0[:nr])
         pp = None if with_prior else p
         ctx.uct_plan(model, bufs["root_state"], episodes, horizon, gamma, temperature, pp, pp, rngd, policy=policy, out=bufs)
-        steps, t1 = 0, time.perf_counter()
+        steps, w = 0, 0.0
         for _ in range(reps):
+            t1 = time.perf_counter()
             o = ctx.uct_plan(model, bufs["root_state"], episodes, horizon, gamma, temperature, pp, pp, rngd, policy=policy, out=bufs)
-            steps += int(o["env_steps"].sum())
-        w = time.perf_counter() - t1
+            w += time.perf_counter() - t1
+            steps += int(o["env_steps"].sum())        # (the metric's counter, read while the clock is stopped: not part of plan())
+        host_kernel_ms[nr] = ctx.last_kernel_ms()[0]
         # the round-2 form of the same call for comparison: pageable numpy arrays, all six outputs, records in and out
         s0h, rngh = np.ascontiguousarray(s0[:nr]), rng0[:nr].copy()
         ctx.uct_plan(model, s0h, episodes, horizon, gamma, temperature, pp, pp, rngh, max_plan_len=mpl, policy=policy)
@@ -378,6 +380,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
                                    single_root_device=latency.get("plan_wall_ms_batch_of_1"),
                                    single_root_host_inclusive=hi1_ms),
         host_inclusive_pageable_all_outputs_ms={str(k): v for k, v in pageable_ms.items()},
+        host_inclusive_kernel_ms={str(k): v for k, v in host_kernel_ms.items()},
         dtype="f64",
         config=dict(workload="{}_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(
             "uct_with_vi_boltzmann_prior" if with_prior else "uct", s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
