@@ -386,6 +386,9 @@ def bench_uct(args, rank, world, local, with_prior=False):
             "uct_with_vi_boltzmann_prior" if with_prior else "uct", s_, a_, episodes, horizon, n_roots), n_roots_per_gpu=n_roots, n_roots_total=n_roots * world,
             states=s_, actions=a_, episodes=episodes, horizon=horizon, gamma=gamma,
             env_steps_per_step=total_env_steps, plan_ms_per_root=1e3 * dt / args.steps / n_roots, latency=latency,
+            value_definition="`value` = device-resident: roots, generator records and results stay in HBM (this tier's "
+                             "bench contract); SURVEY 8(d)'s host-inclusive form of the same metric (host arrays in and out, the "
+                             "transfers inside the call) is `value_host_inclusive` in this line",
             measured_mean_selection_depth=mean_depth, measured_expansions_per_episode=expansions / float(n_smp * episodes),
             algorithmic_bytes_per_env_step=bytes_per_step,
             parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
