@@ -74,7 +74,10 @@ int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *
  *     space (hipHostMalloc, portable | mapped).  When every array of a MP_MEM_HOST call lies in such memory, the kernels
  *     read the root states from and write the results to the caller's arrays directly over the bus: the call is one
  *     launch and one synchronisation, no copy is issued (every plan entry point; MP_NO_ZERO_COPY=1 disables).
- *     Any other host pointer is still accepted everywhere and goes through staging copies.
+ *     mp_uct_plan does so up to 65 536 roots (MP_ZERO_COPY_MAX); larger batches in such memory run as two chunks on two
+ *     streams with asynchronous copies (the first chunk's results travel under the second chunk's kernel: faster than
+ *     13 MB of kernel stores over the bus).  Any other host pointer is still accepted everywhere and goes through
+ *     staging copies.
  *   - mp_uct_plan with mem = MP_MEM_HOST and ordinary (pageable) arrays splits batches of more than 65 536 roots into
  *     chunks and pipelines H2D(roots) -> kernel -> D2H(results) of different chunks over several HIP streams owned by
  *     the ctx (same kernels, same trees, same results: a root's plan depends on its own state and stream only).

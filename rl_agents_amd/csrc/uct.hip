@@ -895,6 +895,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // per chunk, below).  The generator records follow their own flag (MP_MEM_RNG_DEVICE: an mp_rng).
     int amem = mem_arrays(mem), rmem = mem_rng(mem);
     const bool host_call = amem == MP_MEM_HOST;       // the call synchronises before it returns
+    bool all_pinned = false;                          // every host array lies in mp_host_alloc memory
     // Zero-copy: when EVERY array the caller hands over lives in mp_host_alloc memory (pinned and mapped into the
     // device's address space) the kernel reads the root states from and writes the results to the caller's arrays over
     // the bus, and the whole call is one launch + one synchronisation: no copy is issued at all.
@@ -916,7 +917,14 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         alias(root_child_count, (size_t)n_roots * A * 8, &z_cc);
         alias(root_child_value, (size_t)n_roots * A * 8, &z_cv);
         alias(env_steps, (size_t)n_roots * 8, &z_es);
-        if (all && !getenv("MP_NO_ZERO_COPY")) {
+        all_pinned = all;
+        // Measured (262 144 roots, 13 MB of results): the kernel writing over the bus 1.52 ms; one launch + asynchronous
+        // copies into the same pinned arrays 1.48 ms; two saturating chunks back to back on two streams, the first
+        // chunk's results travelling under the second chunk's kernel, 1.35-1.37 ms (device-resident: 1.12).  Small batches
+        // (4 096 roots: 0.349 ms zero-copy against 0.346 ms device-resident) are dominated by the calls a copy costs.
+        long zc_max = 65536;
+        if (const char *e = getenv("MP_ZERO_COPY_MAX")) zc_max = atol(e);
+        if (all && !getenv("MP_NO_ZERO_COPY") && n_roots <= zc_max) {
             root_state = z_rs; root_steps = z_st; rng_state = z_rng; plans = z_plans; plan_len = z_len; root_value = z_val;
             root_child_count = z_cc; root_child_value = z_cv; env_steps = z_es;
             amem = MP_MEM_DEVICE; rmem = MP_MEM_DEVICE;     // from here on: device arrays (their aliases)
@@ -934,12 +942,19 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     if (rmem == MP_MEM_DEVICE) a.rng = rng_state; else MP_TRY(ws_get(ctx, WS_IO2, (size_t)n_roots * 6, &a.rng));
     a.root_x = d_rx; a.root_state = d_rs; a.root_steps = d_st;
-    MP_TRY(stage_out_alloc(ctx, WS_IO3, plans, (size_t)n_roots * max_plan_len, amem, &a.plans));
-    MP_TRY(stage_out_alloc(ctx, WS_IO4, plan_len, (size_t)n_roots, amem, &a.plan_len));
-    MP_TRY(stage_out_alloc(ctx, WS_IO5, root_value, (size_t)n_roots, amem, &a.root_value));
-    MP_TRY(stage_out_alloc(ctx, WS_IO6, root_child_count, (size_t)n_roots * A, amem, &a.root_child_count));
-    MP_TRY(stage_out_alloc(ctx, WS_IO7, root_child_value, (size_t)n_roots * A, amem, &a.root_child_value));
-    MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, amem, &a.env_steps));
+    // (device twins from the workspaces, NOT stage_out_alloc: that helper would hand back the device alias of a pinned
+    // array -- the zero-copy form, decided above for the whole call -- and the chunk copies below would copy it onto itself)
+    auto twin = [&](int slot, auto *dst, size_t count, auto **dev) -> int {
+        if (!host) { *dev = dst; return MP_OK; }
+        if (!dst) { *dev = nullptr; return MP_OK; }
+        return ws_get(ctx, slot, count, dev);
+    };
+    MP_TRY(twin(WS_IO3, plans, (size_t)n_roots * max_plan_len, &a.plans));
+    MP_TRY(twin(WS_IO4, plan_len, (size_t)n_roots, &a.plan_len));
+    MP_TRY(twin(WS_IO5, root_value, (size_t)n_roots, &a.root_value));
+    MP_TRY(twin(WS_IO6, root_child_count, (size_t)n_roots * A, &a.root_child_count));
+    MP_TRY(twin(WS_IO7, root_child_value, (size_t)n_roots * A, &a.root_child_value));
+    MP_TRY(twin(WS_IO8, env_steps, (size_t)n_roots, &a.env_steps));
 
     // ---- one chunk of roots [r0, r1): copies in, the kernel, copies out, all on stream `s`.  A chunk is the same launch
     // on shifted pointers (r0 is a multiple of 1024: whole wavefront blocks of the interleaved tree layouts and whole
@@ -999,7 +1014,10 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // ---- host arrays and a big batch: chunks pipelined over side streams (H2D of chunk i+1 and D2H of chunk i-1 run
     // under the kernel of chunk i, and kernels of different chunks share the chip).  Everything else: one chunk on the
     // ctx stream, as ever.
-    int chunk = 65536, n_streams = 4; // measured at 262 144 roots: 65 536 x 4 streams 4.1 ms, 32 768 x 4 7.3 ms, 8 192 x 8 12.6 ms
+    // pageable arrays, measured at 262 144 roots: 65 536 x 4 streams 4.1 ms, 32 768 x 4 7.3 ms, 8 192 x 8 12.6 ms (the
+    // runtime stages every pageable copy); pinned arrays: two chunks that each fill the chip, see above
+    int chunk = 65536, n_streams = 4;
+    if (all_pinned) { chunk = (((n_roots + 1) / 2) + 1023) & ~1023; n_streams = 2; }
     if (const char *e = getenv("MP_PIPE_CHUNK")) chunk = atoi(e) > 0 ? ((atoi(e) + 1023) & ~1023) : 0;
     if (const char *e = getenv("MP_PIPE_STREAMS")) { const int v = atoi(e); if (v >= 1 && v <= 8) n_streams = v; }
     const bool piped = host && chunk > 0 && n_roots > chunk;

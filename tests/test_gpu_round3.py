@@ -102,7 +102,9 @@ def test_pipelined_host_plan_equals_the_single_launch(ctx, n, chunk, streams, mo
     bufs["root_state"][:] = roots
     dev_rng = ctx.device_rng(rng0)
     out2 = ctx.uct_plan(model, bufs["root_state"], *args, dev_rng, out=bufs)
-    assert ctx.last_kernel_ms()[1] == 1, "mp_host_alloc arrays are read / written in place: one launch, no copies"
+    # mp_host_alloc arrays: read / written in place up to 65 536 roots (one launch, no copies), two pipelined chunks beyond
+    want = 1 if n <= 65536 else (2 if chunk is None else -(-n // chunk))
+    assert ctx.last_kernel_ms()[1] == want, "launches for pinned arrays"
     assert set(out2) == {"root_state", "plans", "plan_len", "env_steps"}
     for k in ("plans", "plan_len", "env_steps"):
         np.testing.assert_array_equal(out2[k], ref[k], err_msg=k)
@@ -123,7 +125,6 @@ def test_pipelined_host_plan_equals_the_single_launch(ctx, n, chunk, streams, mo
     pin["rng"][:] = rng0
     out5 = ctx.uct_plan(model, bufs["root_state"], *args, pin["rng"], out=dict(root_value=pin["root_value"],
                                                                               root_child_count=pin["counts"]))
-    assert ctx.last_kernel_ms()[1] == 1
     np.testing.assert_array_equal(out5["root_value"], ref["root_value"])
     np.testing.assert_array_equal(out5["root_child_count"], ref["root_child_count"])
     np.testing.assert_array_equal(pin["rng"], rng_a)
