@@ -13,6 +13,7 @@ for wl in uct uct_prior uct_cartpole uct_stoch opd ropd saopd vi rvi vi_dense rv
 done
 timeout 400 python bench.py --workload opd --roots 8192 --no-cpu-baseline 2>/dev/null | grep "^{" >> gpurun_out/r03_bench_lines.jsonl
 timeout 300 python tools/eval_fps.py 4096 > gpurun_out/r03_batched_eval_fps.txt 2>&1
+MI355PLAN_NO_TORCH=1 timeout 300 python tools/micro_host_path.py > gpurun_out/r03_host_path.txt 2>&1
 BENCH_RCCL_STANDIN=1 timeout 300 python bench.py --workload rvi_dense_shard --steps 10 --warmup 2 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/r03_shard_rccl_standin.json
 BENCH_SAME_DEVICE=1 BENCH_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 bench.py --gpus 2 --steps 5 --warmup 1 --roots 65536 --no-cpu-baseline 2>/dev/null | grep "^{" > gpurun_out/r03_bench_2rank_same_device.json
 wc -l gpurun_out/r03_bench_lines.jsonl; cat gpurun_out/r03_batched_eval_fps.txt
