@@ -122,7 +122,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 
 #ifdef MP_PROFILE
     long long t_scan = 0, t_exp = 0, t_all0 = clock64(), t_f[5] = {0, 0, 0, 0, 0};
+    long long t_p[6] = {0, 0, 0, 0, 0, 0};
 #define PROF_T(x) const long long x = clock64()
+#define ANCHOR(v) { int t__; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(t__) : "v"(v) : "memory"); }
 #else
 #define PROF_T(x)
 #endif
@@ -133,6 +135,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         int leaf = cbid;
         wave_argmax(bu, leaf);
         const int cls = leaf & 63;
+#ifdef MP_PROFILE2
+        ANCHOR(leaf); const long long pa = clock64();
+#endif
         // the leaf's record is needed by the expansion only: fetch it now, under the class re-scan
         const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
         // the selected leaf stops being one; re-derive the best leaf of its class from LDS
@@ -152,9 +157,16 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
                 if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
+#ifdef MP_PROFILE2
+            ANCHOR(__double2hiint(ru)); const long long pb = clock64();
+            t_p[0] += pa - c0; t_p[1] += pb - pa;
+#endif
             wave_argmax(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
+#ifdef MP_PROFILE2
+        ANCHOR(cbid);
+#endif
         PROF_T(c1);
         // ---- DeterministicNode.expand, deterministic.py:28-43
         OpdNode pn; // (one dwordx4: the compiler splits the struct load when a field is read first)
@@ -165,6 +177,10 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
                      tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
         const int g = n_nodes; // first child
+#ifdef MP_PROFILE2
+        ANCHOR((int)leaf_raw.w); const long long pd = clock64();
+        t_p[2] += pd - c1;
+#endif
         bool bad = false, avail = false;
         double Uc_mine = 0.0;
         if (lane < A) {
@@ -193,6 +209,10 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             LU(c) = Uc;
             Uc_mine = Uc;
         }
+#ifdef MP_PROFILE2
+        ANCHOR(__double2hiint(Uc_mine)); const long long pe = clock64();
+        t_p[3] += pe - pd;
+#endif
         if (lane == 0) {
             exp_lds[k] = leaf;
         }
@@ -212,7 +232,11 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             }
         }
 #ifdef MP_PROFILE
-        { const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1; }
+        { ANCHOR(__double2hiint(cbu)); const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1;
+#ifdef MP_PROFILE2
+          t_p[4] += c2 - pe;
+#endif
+        }
 #endif
     }
     PROF_T(cf0);
@@ -236,21 +260,29 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
         __syncthreads();
         PROF_T(cf2);
-        int ek = 0; // EXPG: 64 entries of the parent map per coalesced read
-        for (int k = k_done - 1; k >= 0; --k) {
+        // The reference's backups, as a fixed point: L[parent of expansion k] = max over the children group k.  Children are
+        // expanded after their parents, so the 64-expansion chunks are taken from the last one down and each chunk is
+        // repeated until none of its lanes computed a new maximum (a parent and its child's expansion inside one chunk: one
+        // more repeat per such link).  One expansion per LANE -- |A| LDS reads and a compare -- instead of one per trip of
+        // a K-long chain of LDS read -> DPP max -> LDS write (436 cycles per expansion, 18 % of the kernel at budget 5000).
+        for (int kb = (k_done - 1) & ~63; kb >= 0; kb -= 64) {
+            const int k = kb + lane;
+            const bool on = k < k_done;
+            const int parent = on ? exp_lds[k] : 0;
             const int g = 1 + k * A;
-            // the |A| children in one read, lane a its child a; the maximum on DPP (a wave is one instruction stream and
-            // this loop is a K-long dependent chain: |A| reads one after the other were 900 cycles per step)
-            const double mine = lane < A ? LU(g + lane) : ninf;
-            const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
-            int parent_k;
-            if (EXPG) {
-                if (k == k_done - 1 || (k & 63) == 63) ek = (k & ~63) + lane < k_done ? exp_lds[(k & ~63) + lane] : 0;
-                parent_k = __builtin_amdgcn_readlane(ek, k & 63);
-            } else {
-                parent_k = exp_lds[k];
+            double last = __hiloint2double((int)0x7FF80000, 0); // NaN: the first repeat always writes
+            for (;;) {
+                double m = ninf;
+                if (on)
+                    for (int a = 0; a < A; ++a) {
+                        const double l = LU(g + a);
+                        m = l > m ? l : m;
+                    }
+                const bool changed = on && !(m == last);
+                if (changed) { LU(parent) = m; last = m; }
+                __builtin_amdgcn_wave_barrier(); // (one wavefront: LDS operations execute in program order)
+                if (!__any(changed)) break;
             }
-            if (lane == 0) LU(parent_k) = m;
         }
         __syncthreads();
         PROF_T(cf3);
@@ -263,16 +295,24 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
 #endif
         // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
-        // (deterministic.py:21-26): random_argmax over the children's lower bounds (in LDS).
-        // A node's children are group 1 + k*A where k is its expansion index; a chosen child's own
-        // index is found by searching the parent map forward (children are expanded after parents).
+        // (deterministic.py:21-26): random_argmax over the children's lower bounds.
+        // A node's children are group 1 + k*A where k is its expansion index.  The bounds array now becomes the node -> expansion-index map (a negative quiet NaN with payload k in the slot of
+        // every expanded node), so that a level of the descent is ONE round trip -- the children's final lower bounds from
+        // their records, their slots from LDS -- instead of a search of the parent map (16 dependent reads per level when
+        // the map lives in HBM).
+        __syncthreads(); // the final lower bounds are in the records (s_waitcnt vmcnt(0))
+        const double root_lower = LU(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < k_done; k += 64) LU(exp_lds[k]) = __hiloint2double((int)0xFFF80000, k);
+        __syncthreads();
         Pcg64 gen;
         gen.load(p.rng + (long)root * 6);
         int len = 0;
         int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
-            const double l = lane < A ? LU(fc + lane) : ninf;
+            const double l = lane < A ? NA[fc + lane].L : ninf;
+            const double slot = lane < A ? LU(fc + lane) : 0.0;
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -282,14 +322,8 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             const int a = __ffsll((long long)t) - 1;
             if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
             ++len;
-            const int child = fc + a;
-            int knext = -1;
-            for (int b = kcur + 1; b < k_done; b += 64) {
-                const int idx = b + lane;
-                const unsigned long long hit = __ballot(idx < k_done && exp_lds[idx] == child);
-                if (hit) { knext = b + __ffsll((long long)hit) - 1; break; }
-            }
-            kcur = knext;
+            const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
+            kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
         }
 #ifdef MP_PROFILE
         t_f[4] = clock64() - t_f[4];
@@ -299,7 +333,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             if (p.plans)
                 for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[root] = len;
-            if (p.root_lower) p.root_lower[root] = LU(0);
+            if (p.root_lower) p.root_lower[root] = root_lower;
             if (p.root_upper) p.root_upper[root] = root_upper;
         }
     } else if (lane == 0) {
@@ -312,6 +346,11 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         printf("opd prof root0: K=%d total=%lld scan=%lld expand=%lld final=%lld [U %lld  Lload %lld  backward %lld  Lstore %lld  "
                "descent %lld] (clock64 ticks)\n", p.K, (long long)(clock64() - t_all0), t_scan, t_exp, (long long)(clock64() - cf0),
                t_f[0], t_f[1], t_f[2], t_f[3], t_f[4]);
+#ifdef MP_PROFILE2
+    if (root == 0 && lane == 0)
+        printf("opd prof2 root0: argmax %lld  rescan-reads %lld  rescan-argmax %lld  leaf-wait+tables %lld  model+children %lld  tail %lld\n",
+               t_p[0], t_p[1], t_scan - t_p[0] - t_p[1], t_p[2], t_p[3], t_p[4]);
+#endif
 #endif
     int n_real = real_mine;
     for (int off = 32; off > 0; off >>= 1) n_real += __shfl_xor(n_real, off);

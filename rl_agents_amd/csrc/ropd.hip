@@ -181,19 +181,26 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
         __syncthreads();
         for (int i = lane; i < n_nodes; i += 64) LU(i) = Lmin[i];
         __syncthreads();
-        int ek = 0; // EXPG: 64 entries of the parent map per coalesced read
-        for (int k = k_done - 1; k >= 0; --k) {
+        // chunks of 64 expansions from the last one down, one expansion per lane, each chunk repeated until no lane
+        // computed a new maximum (opd.hip: the backups as a fixed point)
+        for (int kb = (k_done - 1) & ~63; kb >= 0; kb -= 64) {
+            const int k = kb + lane;
+            const bool on = k < k_done;
+            const int parent = on ? exp_lds[k] : 0;
             const int g = 1 + k * A;
-            const double mine = lane < A ? LU(g + lane) : ninf; // the |A| children in one read, maximum on DPP (opd.hip)
-            const double m = A <= 16 ? row0_max(mine) : wave_max(mine);
-            int parent_k;
-            if (EXPG) {
-                if (k == k_done - 1 || (k & 63) == 63) ek = (k & ~63) + lane < k_done ? exp_lds[(k & ~63) + lane] : 0;
-                parent_k = __builtin_amdgcn_readlane(ek, k & 63);
-            } else {
-                parent_k = exp_lds[k];
+            double last = __hiloint2double((int)0x7FF80000, 0); // NaN: the first repeat always writes
+            for (;;) {
+                double m = ninf;
+                if (on)
+                    for (int a = 0; a < A; ++a) {
+                        const double l = LU(g + a);
+                        m = l > m ? l : m;
+                    }
+                const bool changed = on && !(m == last);
+                if (changed) { LU(parent) = m; last = m; }
+                __builtin_amdgcn_wave_barrier();
+                if (!__any(changed)) break;
             }
-            if (lane == 0) LU(parent_k) = m;
         }
         __syncthreads();
         for (int k = lane; k < k_done; k += 64) {
@@ -201,13 +208,22 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
             Lmin[n] = LU(n);
         }
         // ---- get_plan with DeterministicNode.selection_rule over get_value_lower_bound = np.min
+        // the bounds array becomes the node -> expansion-index map (NaN-boxed k in the slot of every expanded node): a
+        // level of the descent is one round trip (the children's final min L from Lmin[], their slots from LDS), not a
+        // search of the parent map (opd.hip)
+        __syncthreads();
+        const double root_lower = LU(0);
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < k_done; k += 64) LU(exp_lds[k]) = __hiloint2double((int)0xFFF80000, k);
+        __syncthreads();
         Pcg64 gen;
         gen.load(p.rng + (long)root * 6);
         int len = 0;
         int kcur = k_done > 0 ? 0 : -1;
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
-            const double l = lane < A ? LU(fc + lane) : ninf;
+            const double l = lane < A ? Lmin[fc + lane] : ninf;
+            const double slot = lane < A ? LU(fc + lane) : 0.0;
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -217,21 +233,15 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
             const int a = __ffsll((long long)t) - 1;
             if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
             ++len;
-            const int child = fc + a;
-            int knext = -1;
-            for (int b = kcur + 1; b < k_done; b += 64) {
-                const int idx = b + lane;
-                const unsigned long long hit = __ballot(idx < k_done && exp_lds[idx] == child);
-                if (hit) { knext = b + __ffsll((long long)hit) - 1; break; }
-            }
-            kcur = knext;
+            const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
+            kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
         }
         if (lane == 0) {
             gen.store(p.rng + (long)root * 6);
             if (p.plans)
                 for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[root] = len;
-            if (p.root_lower) p.root_lower[root] = LU(0);
+            if (p.root_lower) p.root_lower[root] = root_lower;
             if (p.root_upper) p.root_upper[root] = root_upper;
         }
     } else if (lane == 0) {
