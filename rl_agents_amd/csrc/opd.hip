@@ -37,6 +37,7 @@
 #include "common.hpp"
 #include "pcg64.hpp"
 #include "wave.hpp"
+#include "opd_closing.hpp"
 
 namespace mp {
 
@@ -44,6 +45,7 @@ struct OpdArgs {
     int n_roots, S, A, K, cap, done_on_next, max_plan_len;
     int T; // row length of a residue class: odd, >= ceil(cap / 64)
     int chunk; // opd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
+    int closing_chain; // opd_kernel: 1 = the node-array closing passes even where opd_closing.hpp fits (MP_OPD_CLOSING=chain: test hook)
     const Rec *rec;
     const int32_t *root_state;
     const double *g1;   // g1[d]   = gamma ** (d - 1), d >= 1
@@ -123,6 +125,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 #ifdef MP_PROFILE
     long long t_scan = 0, t_exp = 0, t_all0 = clock64(), t_f[5] = {0, 0, 0, 0, 0};
     long long t_p[6] = {0, 0, 0, 0, 0, 0};
+    int n_follow = 0, n_recent = 0, n_tie_top = 0;
 #define PROF_T(x) const long long x = clock64()
 #define ANCHOR(v) { int t__; asm volatile("v_readfirstlane_b32 %0, %1" : "=s"(t__) : "v"(v) : "memory"); }
 #else
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         const int cls = leaf & 63;
 #ifdef MP_PROFILE2
         ANCHOR(leaf); const long long pa = clock64();
+        if (leaf >= n_nodes - A) ++n_follow;
+        if (leaf >= n_nodes - 8 * A) ++n_recent;
+        if (__popcll(__ballot(cbu == bu)) > 1) ++n_tie_top;
 #endif
         // the leaf's record is needed by the expansion only: fetch it now, under the class re-scan
         const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
@@ -146,6 +152,11 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         // other lanes' later reads without a barrier.  Only the compiler is ordered here -- a full __syncthreads() would
         // also wait for the record fetch above.
         __builtin_amdgcn_wave_barrier();
+        OpdNode pn; // (one dwordx4: the compiler splits the struct load when a field is read first)
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        u32x4 rc_raw;
+        unsigned long long g1_bits, gdiv_bits, tdiv_bits;
+        int d;
         {
             const double *row = leafU + cls * T;
             const int cnt = (n_nodes - cls + 63) >> 6; // ids cls, cls + 64, ... < n_nodes
@@ -156,6 +167,24 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
                 if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
                 if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+            }
+            // The leaf's record has had the scan's LDS round trip to arrive: request the model records of its |A| actions
+            // NOW, so that they fly under the reduction below (every lane loads -- lanes >= |A| the last action's record,
+            // unused: a load under a divergent branch would be waited for where the branch closes).
+            pn.L = __hiloint2double((int)leaf_raw.y, (int)leaf_raw.x); pn.state = (int32_t)leaf_raw.z; pn.depth = (int32_t)leaf_raw.w;
+            // The loads are inline assembly: the compiler sinks a plain load to its first use, below the reduction, and its
+            // s_waitcnt bookkeeping does not see these -- they are waited for by hand where the children are computed.
+            {
+                const Rec *src = p.rec + ((long)pn.state * A + (lane < A ? lane : A - 1));
+                // (ru passes through: the reduction below cannot be scheduled above the request)
+                asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(rc_raw), "+v"(ru) : "v"(src) : "memory");
+            }
+            // wave-uniform depth in an SGPR: the three gamma tables come through the scalar cache, not the TA
+            d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
+            {
+                const double *s0 = p.g1 + d, *s1 = p.gdiv + d, *s2 = p.tdiv + d;
+                asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx2 %2, %6, 0x0"
+                             : "=&s"(g1_bits), "=&s"(gdiv_bits), "=&s"(tdiv_bits), "+v"(rid) : "s"(s0), "s"(s1), "s"(s2) : "memory");
             }
 #ifdef MP_PROFILE2
             ANCHOR(__double2hiint(ru)); const long long pb = clock64();
@@ -169,22 +198,20 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 #endif
         PROF_T(c1);
         // ---- DeterministicNode.expand, deterministic.py:28-43
-        OpdNode pn; // (one dwordx4: the compiler splits the struct load when a field is read first)
-        pn.L = __hiloint2double((int)leaf_raw.y, (int)leaf_raw.x); pn.state = (int32_t)leaf_raw.z; pn.depth = (int32_t)leaf_raw.w;
-        // wave-uniform depth in an SGPR: the three gamma tables come through the scalar cache, not the TA
-        const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
-        typedef const double __attribute__((address_space(4))) *scalar_f64; // constant address space: s_load
-        const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
-                     tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
         const int g = n_nodes; // first child
 #ifdef MP_PROFILE2
         ANCHOR((int)leaf_raw.w); const long long pd = clock64();
         t_p[2] += pd - c1;
 #endif
+        // (cbid passes through: the wait cannot be scheduled above the reduction)
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(rc_raw), "+s"(g1_bits), "+s"(gdiv_bits), "+s"(tdiv_bits), "+v"(cbid) : : "memory");
+        const double g1d = __longlong_as_double((long long)g1_bits), gdivd = __longlong_as_double((long long)gdiv_bits),
+                     tdivd = __longlong_as_double((long long)tdiv_bits);
+        Rec rc;
+        rc.next = (int32_t)rc_raw.x; rc.flags = rc_raw.y; rc.reward = __hiloint2double((int)rc_raw.w, (int)rc_raw.z);
         bool bad = false, avail = false;
         double Uc_mine = 0.0;
         if (lane < A) {
-            const Rec rc = p.rec[(long)pn.state * A + lane];
             const double r = rc.reward;
             // deterministic.py:32-35: only the actions state.get_available_actions() lists get a child.  The slot of
             // an unavailable action stays in the id space (ids advance by |A| per expansion in every root) as a
@@ -256,74 +283,85 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         root_upper = wave_max(root_upper);
         __syncthreads();
         PROF_T(cf1);
-        // lower bounds: same pass over the creation-time L values
-        for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
-        __syncthreads();
-        PROF_T(cf2);
-        // The reference's backups, as a fixed point: L[parent of expansion k] = max over the children group k.  Children are
-        // expanded after their parents, so the 64-expansion chunks are taken from the last one down and each chunk is
-        // repeated until none of its lanes computed a new maximum (a parent and its child's expansion inside one chunk: one
-        // more repeat per such link).  One expansion per LANE -- |A| LDS reads and a compare -- instead of one per trip of
-        // a K-long chain of LDS read -> DPP max -> LDS write (436 cycles per expansion, 18 % of the kernel at budget 5000).
-        for (int kb = (k_done - 1) & ~63; kb >= 0; kb -= 64) {
-            const int k = kb + lane;
-            const bool on = k < k_done;
-            const int parent = on ? exp_lds[k] : 0;
-            const int g = 1 + k * A;
-            double last = __hiloint2double((int)0x7FF80000, 0); // NaN: the first repeat always writes
-            for (;;) {
-                double m = ninf;
-                if (on)
-                    for (int a = 0; a < A; ++a) {
-                        const double l = LU(g + a);
-                        m = l > m ? l : m;
-                    }
-                const bool changed = on && !(m == last);
-                if (changed) { LU(parent) = m; last = m; }
-                __builtin_amdgcn_wave_barrier(); // (one wavefront: LDS operations execute in program order)
-                if (!__any(changed)) break;
-            }
-        }
-        __syncthreads();
-        PROF_T(cf3);
-        for (int k = lane; k < k_done; k += 64) {
-            const int n = exp_lds[k];
-            NA[n].L = LU(n);
-        }
-        PROF_T(cf4);
-#ifdef MP_PROFILE
-        t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
-#endif
-        // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
-        // (deterministic.py:21-26): random_argmax over the children's lower bounds.
-        // A node's children are group 1 + k*A where k is its expansion index.  The bounds array now becomes the node -> expansion-index map (a negative quiet NaN with payload k in the slot of
-        // every expanded node), so that a level of the descent is ONE round trip -- the children's final lower bounds from
-        // their records, their slots from LDS -- instead of a search of the parent map (16 dependent reads per level when
-        // the map lives in HBM).
-        __syncthreads(); // the final lower bounds are in the records (s_waitcnt vmcnt(0))
-        const double root_lower = LU(0);
-        __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < k_done; k += 64) LU(exp_lds[k]) = __hiloint2double((int)0xFFF80000, k);
-        __syncthreads();
         Pcg64 gen;
         gen.load(p.rng + (long)root * 6);
         int len = 0;
-        int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
-        while (kcur >= 0) {
-            const int fc = 1 + kcur * A;
-            const double l = lane < A ? NA[fc + lane].L : ninf;
-            const double slot = lane < A ? LU(fc + lane) : 0.0;
-            const double m = A <= 16 ? row0_max(l) : wave_max(l);
-            const unsigned long long ties = __ballot(lane < A && l == m);
-            const int nt = __popcll(ties);
-            int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
-            unsigned long long t = ties;
-            while (pick-- > 0) t &= t - 1;
-            const int a = __ffsll((long long)t) - 1;
-            if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
-            ++len;
-            const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
-            kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
+        double root_lower;
+        if (!p.closing_chain && closing_compact_fits(p.K, A, p.cap, 64L * T * 8)) {
+            // pointer jumping over the expansion tree + a prepared plan walk (opd_closing.hpp)
+            len = closing_compact(lds, p.K, k_done, n_nodes, A, exp_lds, [&](int id) { return NA[id].L; },
+                                  [&](int id, double v) { NA[id].L = v; }, gen,
+                                  p.plans ? p.plans + (long)root * p.max_plan_len : nullptr, p.max_plan_len, root_lower);
+            PROF_T(cf2); PROF_T(cf3); PROF_T(cf4);
+#ifdef MP_PROFILE
+            t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
+#endif
+        } else {
+            // lower bounds: same pass over the creation-time L values
+            for (int i = lane; i < n_nodes; i += 64) LU(i) = NA[i].L;
+            __syncthreads();
+            PROF_T(cf2);
+            // (|A| < 4: the tables of opd_closing.hpp do not fit beside each other.)  The backups as a fixed point on the
+            // node array: L[parent of expansion k] = max over the children group k; children are expanded after their
+            // parents, so the 64-expansion chunks are taken from the last one down, one expansion per lane, and each
+            // chunk is repeated until none of its lanes computed a new maximum.
+            for (int kb = (k_done - 1) & ~63; kb >= 0; kb -= 64) {
+                const int k = kb + lane;
+                const bool on = k < k_done;
+                const int parent = on ? exp_lds[k] : 0;
+                const int g = 1 + k * A;
+                double last = __hiloint2double((int)0x7FF80000, 0); // NaN: the first repeat always writes
+                for (;;) {
+                    double m = ninf;
+                    if (on)
+                        for (int a = 0; a < A; ++a) {
+                            const double l = LU(g + a);
+                            m = l > m ? l : m;
+                        }
+                    const bool changed = on && !(m == last);
+                    if (changed) { LU(parent) = m; last = m; }
+                    __builtin_amdgcn_wave_barrier(); // (one wavefront: LDS operations execute in program order)
+                    if (!__any(changed)) break;
+                }
+            }
+            __syncthreads();
+            PROF_T(cf3);
+            for (int k = lane; k < k_done; k += 64) {
+                const int n = exp_lds[k];
+                NA[n].L = LU(n);
+            }
+            PROF_T(cf4);
+#ifdef MP_PROFILE
+            t_f[0] = cf1 - cf0; t_f[1] = cf2 - cf1; t_f[2] = cf3 - cf2; t_f[3] = cf4 - cf3; t_f[4] = cf4;
+#endif
+            // ---- get_plan (abstract.py:143-156) with DeterministicNode.selection_rule
+            // (deterministic.py:21-26): random_argmax over the children's lower bounds.
+            // A node's children are group 1 + k*A where k is its expansion index.  The bounds array now becomes the
+            // node -> expansion-index map (a negative quiet NaN with payload k in the slot of every expanded node), so
+            // that a level of the descent is ONE round trip -- the children's final lower bounds from their records,
+            // their slots from LDS -- instead of a search of the parent map.
+            __syncthreads(); // the final lower bounds are in the records (s_waitcnt vmcnt(0))
+            root_lower = LU(0);
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < k_done; k += 64) LU(exp_lds[k]) = __hiloint2double((int)0xFFF80000, k);
+            __syncthreads();
+            int kcur = k_done > 0 ? 0 : -1; // the first expansion is always the root
+            while (kcur >= 0) {
+                const int fc = 1 + kcur * A;
+                const double l = lane < A ? NA[fc + lane].L : ninf;
+                const double slot = lane < A ? LU(fc + lane) : 0.0;
+                const double m = A <= 16 ? row0_max(l) : wave_max(l);
+                const unsigned long long ties = __ballot(lane < A && l == m);
+                const int nt = __popcll(ties);
+                int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
+                unsigned long long t = ties;
+                while (pick-- > 0) t &= t - 1;
+                const int a = __ffsll((long long)t) - 1;
+                if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
+                ++len;
+                const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
+                kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
+            }
         }
 #ifdef MP_PROFILE
         t_f[4] = clock64() - t_f[4];
@@ -350,6 +388,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
     if (root == 0 && lane == 0)
         printf("opd prof2 root0: argmax %lld  rescan-reads %lld  rescan-argmax %lld  leaf-wait+tables %lld  model+children %lld  tail %lld\n",
                t_p[0], t_p[1], t_scan - t_p[0] - t_p[1], t_p[2], t_p[3], t_p[4]);
+    if (root < 4 && lane == 0) printf("opd prof2 root%d: leaf among the previous expansion's children %d, among the last 8 expansions' %d, ties at the top argmax %d of %d\n", root, n_follow, n_recent, n_tie_top, k_done);
 #endif
 #endif
     int n_real = real_mine;
@@ -641,6 +680,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
 
     OpdArgs a;
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk;
+    { const char *cl = getenv("MP_OPD_CLOSING"); a.closing_chain = cl && cl[0] == 'c'; }
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec;
     a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;

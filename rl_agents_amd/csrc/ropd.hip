@@ -26,6 +26,7 @@
 #include "common.hpp"
 #include "pcg64.hpp"
 #include "wave.hpp"
+#include "opd_closing.hpp"
 
 namespace mp {
 
@@ -35,6 +36,7 @@ struct ROpdArgs {
     int n_roots, M, S, A, K, cap, done_on_next, max_plan_len;
     int T; // row length of a residue class in the upper-bound array: odd, >= ceil(cap / 64)
     int chunk; // ropd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
+    int closing_chain; // ropd_kernel: 1 = the node-array closing passes even where opd_closing.hpp fits (MP_OPD_CLOSING=chain)
     const Rec *rec;            // [M][S*A] packed records of every model
     const int32_t *root_state; // [n_roots][M]
     const double *g1, *gdiv, *tdiv;
@@ -179,62 +181,70 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
         }
         root_upper = wave_max(root_upper);
         __syncthreads();
-        for (int i = lane; i < n_nodes; i += 64) LU(i) = Lmin[i];
-        __syncthreads();
-        // chunks of 64 expansions from the last one down, one expansion per lane, each chunk repeated until no lane
-        // computed a new maximum (opd.hip: the backups as a fixed point)
-        for (int kb = (k_done - 1) & ~63; kb >= 0; kb -= 64) {
-            const int k = kb + lane;
-            const bool on = k < k_done;
-            const int parent = on ? exp_lds[k] : 0;
-            const int g = 1 + k * A;
-            double last = __hiloint2double((int)0x7FF80000, 0); // NaN: the first repeat always writes
-            for (;;) {
-                double m = ninf;
-                if (on)
-                    for (int a = 0; a < A; ++a) {
-                        const double l = LU(g + a);
-                        m = l > m ? l : m;
-                    }
-                const bool changed = on && !(m == last);
-                if (changed) { LU(parent) = m; last = m; }
-                __builtin_amdgcn_wave_barrier();
-                if (!__any(changed)) break;
-            }
-        }
-        __syncthreads();
-        for (int k = lane; k < k_done; k += 64) {
-            const int n = exp_lds[k];
-            Lmin[n] = LU(n);
-        }
-        // ---- get_plan with DeterministicNode.selection_rule over get_value_lower_bound = np.min
-        // the bounds array becomes the node -> expansion-index map (NaN-boxed k in the slot of every expanded node): a
-        // level of the descent is one round trip (the children's final min L from Lmin[], their slots from LDS), not a
-        // search of the parent map (opd.hip)
-        __syncthreads();
-        const double root_lower = LU(0);
-        __builtin_amdgcn_wave_barrier();
-        for (int k = lane; k < k_done; k += 64) LU(exp_lds[k]) = __hiloint2double((int)0xFFF80000, k);
-        __syncthreads();
         Pcg64 gen;
         gen.load(p.rng + (long)root * 6);
         int len = 0;
-        int kcur = k_done > 0 ? 0 : -1;
-        while (kcur >= 0) {
-            const int fc = 1 + kcur * A;
-            const double l = lane < A ? Lmin[fc + lane] : ninf;
-            const double slot = lane < A ? LU(fc + lane) : 0.0;
-            const double m = A <= 16 ? row0_max(l) : wave_max(l);
-            const unsigned long long ties = __ballot(lane < A && l == m);
-            const int nt = __popcll(ties);
-            int pick = (int)gen.below((uint32_t)nt);
-            unsigned long long t = ties;
-            while (pick-- > 0) t &= t - 1;
-            const int a = __ffsll((long long)t) - 1;
-            if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
-            ++len;
-            const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
-            kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
+        double root_lower;
+        if (!p.closing_chain && closing_compact_fits(p.K, A, p.cap, 64L * T * 8)) {
+            // pointer jumping over the expansion tree + a prepared plan walk, on the scalars min_m L (opd_closing.hpp)
+            len = closing_compact(lds, p.K, k_done, n_nodes, A, exp_lds, [&](int id) { return Lmin[id]; },
+                                  [&](int id, double v) { Lmin[id] = v; }, gen,
+                                  p.plans ? p.plans + (long)root * p.max_plan_len : nullptr, p.max_plan_len, root_lower);
+        } else {
+            for (int i = lane; i < n_nodes; i += 64) LU(i) = Lmin[i];
+            __syncthreads();
+            // chunks of 64 expansions from the last one down, one expansion per lane, each chunk repeated until no lane
+            // computed a new maximum (opd.hip: the backups as a fixed point)
+            for (int kb = (k_done - 1) & ~63; kb >= 0; kb -= 64) {
+                const int k = kb + lane;
+                const bool on = k < k_done;
+                const int parent = on ? exp_lds[k] : 0;
+                const int g = 1 + k * A;
+                double last = __hiloint2double((int)0x7FF80000, 0); // NaN: the first repeat always writes
+                for (;;) {
+                    double m = ninf;
+                    if (on)
+                        for (int a = 0; a < A; ++a) {
+                            const double l = LU(g + a);
+                            m = l > m ? l : m;
+                        }
+                    const bool changed = on && !(m == last);
+                    if (changed) { LU(parent) = m; last = m; }
+                    __builtin_amdgcn_wave_barrier();
+                    if (!__any(changed)) break;
+                }
+            }
+            __syncthreads();
+            for (int k = lane; k < k_done; k += 64) {
+                const int n = exp_lds[k];
+                Lmin[n] = LU(n);
+            }
+            // ---- get_plan with DeterministicNode.selection_rule over get_value_lower_bound = np.min
+            // the bounds array becomes the node -> expansion-index map (NaN-boxed k in the slot of every expanded node): a
+            // level of the descent is one round trip (the children's final min L from Lmin[], their slots from LDS), not a
+            // search of the parent map (opd.hip)
+            __syncthreads();
+            root_lower = LU(0);
+            __builtin_amdgcn_wave_barrier();
+            for (int k = lane; k < k_done; k += 64) LU(exp_lds[k]) = __hiloint2double((int)0xFFF80000, k);
+            __syncthreads();
+            int kcur = k_done > 0 ? 0 : -1;
+            while (kcur >= 0) {
+                const int fc = 1 + kcur * A;
+                const double l = lane < A ? Lmin[fc + lane] : ninf;
+                const double slot = lane < A ? LU(fc + lane) : 0.0;
+                const double m = A <= 16 ? row0_max(l) : wave_max(l);
+                const unsigned long long ties = __ballot(lane < A && l == m);
+                const int nt = __popcll(ties);
+                int pick = (int)gen.below((uint32_t)nt);
+                unsigned long long t = ties;
+                while (pick-- > 0) t &= t - 1;
+                const int a = __ffsll((long long)t) - 1;
+                if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = a;
+                ++len;
+                const int shi = __builtin_amdgcn_readlane(__double2hiint(slot), a), slo = __builtin_amdgcn_readlane(__double2loint(slot), a);
+                kcur = ((unsigned)shi == 0xFFF80000u) ? slo : -1; // expanded: its k; a leaf: the plan ends
+            }
         }
         if (lane == 0) {
             gen.store(p.rng + (long)root * 6);
@@ -515,6 +525,7 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
 
     ROpdArgs a;
     a.n_roots = n_roots; a.M = M; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk;
+    { const char *cl = getenv("MP_OPD_CLOSING"); a.closing_chain = cl && cl[0] == 'c'; }
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec_all;
     a.g1 = d_tab; a.gdiv = d_tab + D; a.tdiv = d_tab + 2 * D;

@@ -164,6 +164,30 @@ def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
 
 
+@pytest.mark.parametrize("variant", ["lds", "ldsx"])
+@pytest.mark.parametrize("n_actions,budget", [(4, 100), (5, 2500), (13, 1300), (64, 640)])
+def test_opd_closing_passes_on_the_node_array(ctx, n_actions, budget, variant, monkeypatch):
+    """MP_OPD_CLOSING=chain: the closing passes the kernel falls back to when the tables of opd_closing.hpp do not fit
+    (|A| < 4), forced where they do -- both forms must give the oracle's trees and plans."""
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_CLOSING", "chain")
+    cfg = generators.random_deterministic(300, n_actions, seed=140 + n_actions, terminal_rate=0.05)
+    _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
+    cfg = generators.highway_shaped(6, 8, 40, seed=2)
+    if n_actions == 5:
+        _cmp_opd(ctx, cfg, 70, budget, 0.95, seed=3)
+
+
+def test_opd_negative_terminal_reward_lowers_an_expanded_node(ctx):
+    """terminal_reward < 0: a done child's bound lies BELOW its parent's creation-time bound, so an expanded node's final
+    lower bound can be smaller than the value it had as a leaf -- the backups must not keep the old value."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(60, 4, seed=9, terminal_rate=0.4)
+    _cmp_opd(ctx, cfg, 70, 400, 0.9, terminal_reward=-2.0, seed=4)
+    _cmp_opd(ctx, cfg, 70, 400, 0.9, terminal_reward=-2.0, seed=4, done_rule="next")
+
+
 def test_opd_ties_draw_from_the_generator(ctx):
     """Constant rewards make every lower bound tie: the plan is drawn through the PCG64 tie-break."""
     cfg = dict(transition=np.tile(np.arange(6).reshape(6, 1), (1, 3)), reward=np.full((6, 3), 0.5),

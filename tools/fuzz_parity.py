@@ -71,6 +71,10 @@ def one_case(ctx, g, case):
     os.environ.pop("MP_OPD_MODEL", None)
     if variant and kind in ("opd", "opd_masked", "ropd", "ropd_masked"):
         os.environ["MP_OPD_MODEL"] = variant
+    # closing passes: opd_closing.hpp where it fits (default) or the node-array form everywhere
+    os.environ.pop("MP_OPD_CLOSING", None)
+    if int(g.integers(0, 3)) == 0:
+        os.environ["MP_OPD_CLOSING"] = "chain"
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant)
     if kind == "vi":
         model.close()
@@ -438,6 +442,7 @@ def run(n_cases, seed, ctx=None, verbose=False):
                 print(d)
     finally:
         os.environ.pop("MP_OPD_MODEL", None)
+        os.environ.pop("MP_OPD_CLOSING", None)
         if forced is not None:
             os.environ["MP_OPD_MODEL"] = forced
     if own:
