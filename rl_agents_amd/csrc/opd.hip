@@ -85,7 +85,7 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 //              and LDS only holds the window of the closing pass: 8 waves per SIMD instead of 3-4 per CU.  A wave of this
 //              planner is a chain of dependent round trips (argmax -> leaf record -> model record): ten times more
 //              resident roots hide that latency and multiply the batch throughput.
-template <bool EXPG>
+template <bool EXPG, bool NONNEG>
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         // ---- deterministic.py:110: first maximal upper bound among the leaves
         double bu = cbu;
         int leaf = cbid;
-        wave_argmax(bu, leaf);
+        if (NONNEG) wave_argmax_nonneg(bu, leaf); else wave_argmax(bu, leaf);
         const int cls = leaf & 63;
 #ifdef MP_PROFILE2
         ANCHOR(leaf); const long long pa = clock64();
@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             ANCHOR(__double2hiint(ru)); const long long pb = clock64();
             t_p[0] += pa - c0; t_p[1] += pb - pa;
 #endif
-            wave_argmax(ru, rid);
+            if (NONNEG) wave_argmax_nonneg(ru, rid); else wave_argmax(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
 #ifdef MP_PROFILE2
@@ -705,13 +705,18 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(stage_out_alloc(ctx, WS_IO7, status, (size_t)n_roots, mem, &a.status));
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
-    if (lds > 64 * 1024)
-        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(expg ? opd_kernel<true> : opd_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // every finite bound is >= +0.0 (rewards are range-checked): the cheaper cross-lane maximum (wave.hpp); MP_OPD_NONNEG=0: test hook
+    const char *nn_env = getenv("MP_OPD_NONNEG");
+    const bool nonneg = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(nn_env && nn_env[0] == '0');
+    const void *kfn = expg ? (nonneg ? (const void *)opd_kernel<true, true> : (const void *)opd_kernel<true, false>)
+                           : (nonneg ? (const void *)opd_kernel<false, true> : (const void *)opd_kernel<false, false>);
+    if (lds > 64 * 1024) MP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
     if (glb) hipLaunchKernelGGL(opd_wide_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else if (expg) hipLaunchKernelGGL((opd_kernel<true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((opd_kernel<false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (expg && nonneg) hipLaunchKernelGGL((opd_kernel<true, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (expg) hipLaunchKernelGGL((opd_kernel<true, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (nonneg) hipLaunchKernelGGL((opd_kernel<false, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL((opd_kernel<false, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 

@@ -77,6 +77,55 @@ __device__ __forceinline__ int row0_min(int v)
     return __builtin_amdgcn_readlane(v, 15);
 }
 
+// ---- the same for values known to be >= +0.0 or -inf (the planners' bounds when gamma is in [0, 1) and the terminal
+// reward is not negative): a lane without a DPP source reads 0 instead of its own value (bound_ctrl), so a step needs no
+// copy of the value for the "old" operand -- four issue slots per row step instead of seven, and an instruction is five
+// cycles of a planner wave's chain.  max(u, 0) = u for every real value; the maximum of lanes that are ALL -inf comes
+// out as 0, which the callers detect by the id reduction finding no lane (wave_argmax_nonneg).
+template <int CTRL>
+__device__ __forceinline__ double max_step_zero(double u)
+{
+    const int lo = __double2loint(u), hi = __double2hiint(u);
+    const int olo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+    const int ohi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+    const double ou = __hiloint2double(ohi, olo);
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(u), "v"(ou));
+    return r;
+}
+
+// maximum of non-negative 32-bit integers, same idea: the DPP combiner folds each step into one v_max_i32_dpp
+template <int CTRL>
+__device__ __forceinline__ int imax_step_zero(int v)
+{
+    const int o = __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+    return o > v ? o : v;
+}
+
+// (row_bcast with every row enabled: row r also receives lane 15 of row r - 1 where the classic masks skip it -- one
+// more operand of an idempotent maximum; row 0 / rows 0-1 read 0)
+__device__ __forceinline__ void wave_argmax_nonneg(double &u, int &id)
+{
+    double m = max_step_zero<0x111>(u);
+    m = max_step_zero<0x112>(m);
+    m = max_step_zero<0x114>(m);
+    m = max_step_zero<0x118>(m);
+    m = max_step_zero<0x142>(m);
+    m = max_step_zero<0x143>(m);
+    m = bcast_lane(m, 63);
+    // lowest id among the lanes that hold the maximum = largest (INT_MAX - id); 0 = this lane does not hold it
+    int key = u == m ? 0x7fffffff - id : 0;
+    key = imax_step_zero<0x111>(key);
+    key = imax_step_zero<0x112>(key);
+    key = imax_step_zero<0x114>(key);
+    key = imax_step_zero<0x118>(key);
+    key = imax_step_zero<0x142>(key);
+    key = imax_step_zero<0x143>(key);
+    key = __builtin_amdgcn_readlane(key, 63);
+    id = 0x7fffffff - key;
+    u = key == 0 ? -INFINITY : m; // no lane holds the "maximum": every lane was -inf
+}
+
 // ---- cross-lane argmax on (U, id): maximal U first, lowest id among equal U; every lane returns the pair.
 // U is mapped to an order-preserving (signed high word, unsigned low word) key -- flip the magnitude bits of negative
 // values -- and the argmax is three separable 32-bit reductions: the maximal high word, the maximal low word among the
