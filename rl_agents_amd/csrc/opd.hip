@@ -705,8 +705,9 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(stage_out_alloc(ctx, WS_IO7, status, (size_t)n_roots, mem, &a.status));
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
-    // every finite bound is >= +0.0 (rewards are range-checked): the cheaper cross-lane maximum (wave.hpp); MP_OPD_NONNEG=0: test hook
-    const char *nn_env = getenv("MP_OPD_NONNEG");
+    // every finite bound is >= +0.0 (rewards are range-checked, gamma in [0, 1), terminal reward >= 0): the cheaper cross-lane
+    // maxima (wave.hpp); MP_OPD_LOOP=0: the general ones always -- test hook, shared with mp_ropd_plan
+    const char *nn_env = getenv("MP_OPD_LOOP");
     const bool nonneg = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(nn_env && nn_env[0] == '0');
     const void *kfn = expg ? (nonneg ? (const void *)opd_kernel<true, true> : (const void *)opd_kernel<true, false>)
                            : (nonneg ? (const void *)opd_kernel<false, true> : (const void *)opd_kernel<false, false>);

@@ -58,7 +58,7 @@ struct ROpdArgs {
 // ropd_kernel<EXPG = false>: upper-bound array and parent map in LDS (44 KB per root at budget 5000: 3 roots per CU);
 // ropd_kernel<EXPG = true>: the parent map in HBM (40 448 B: 4 roots per CU, so a 1024-root batch stays on this
 // low-latency form); ropd_wide_kernel below: the bounds array in HBM/L2, 8 waves per SIMD (see opd.hip for all three).
-template <bool EXPG>
+template <bool EXPG, int MB>
 __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -85,6 +85,131 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
     double cbu = lane == 0 ? 0.0 : ninf; // best leaf of this lane's class (ids == lane mod 64)
     int cbid = lane == 0 ? 0 : 0x7fffffff;
 
+    if constexpr (MB > 0) {
+    // ---- MB > 0: at most MB models, every finite bound >= +0.0 (gamma in [0, 1), terminal reward >= 0).  An expansion of
+    // the generic loop below is a chain of 2 M dependent round trips (model m's state of the leaf, then its record, one
+    // model after the other).  Here the leaf's M states and bounds are requested right after the selection (they arrive
+    // under the class re-scan's LDS reads), the M x |A| model records right after that (they arrive under the re-scan's
+    // reduction), and the reductions take the zero-fill DPP steps (wave.hpp).
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    for (int k = 0; k < p.K; ++k) {
+        // ---- robust.py:37: first maximal min_m U among the leaves
+        double bu = cbu;
+        int leaf = cbid;
+        wave_argmax_nonneg(bu, leaf);
+        const int cls = leaf & 63;
+        int sv[MB];
+        double lv[MB];
+        {
+            const double *Lp = Lv + (long)leaf * M;
+            const int32_t *Sp = Sv + (long)leaf * M;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) { // (uniform addresses: broadcast loads; m >= M re-reads model 0, unused)
+                sv[m] = Sp[m < M ? m : 0];
+                lv[m] = Lp[m < M ? m : 0];
+            }
+        }
+        const int dleaf = meta[2 * leaf];
+        if (lane == 0) LU(leaf) = ninf;
+        __builtin_amdgcn_wave_barrier();
+        u32x4 rr[MB];
+        unsigned long long g1_bits, gdiv_bits, tdiv_bits;
+        int d;
+        {
+            const double *row = leafU + cls * T;
+            const int cnt = (n_nodes - cls + 63) >> 6;
+            double ru = ninf;
+            int rid = 0x7fffffff;
+            for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip (budget 5000: 79 entries per class)
+                const double u0 = row[t];
+                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+            }
+            // (the leaf's states and bounds are first touched HERE: left alone, the compiler reads a state into an SGPR
+            // right behind its load -- a wait for the round trip before the re-scan -- and meets the last bound among the
+            // children's stores, where a wait is a wait for those stores)
+            int dl = dleaf;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) asm volatile("" : "+v"(sv[m]), "+v"(lv[m]), "+v"(dl));
+            // the model records (every lane loads -- lanes >= |A| the last action's record, unused) and the gamma-table
+            // entries.  Inline assembly: the compiler sinks a plain load to its first use, below the reduction; `ru` / `rid`
+            // pass through so that the reduction cannot be scheduled above the requests.  Waited for by hand below.
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const Rec *src = p.rec + ((long)(m < M ? m : 0) * SA + (long)sv[m] * A + (lane < A ? lane : A - 1));
+                asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(rr[m]), "+v"(ru) : "v"(src) : "memory");
+            }
+            d = __builtin_amdgcn_readfirstlane(dl) + 1;
+            {
+                const double *s0 = p.g1 + d, *s1 = p.gdiv + d, *s2 = p.tdiv + d;
+                asm volatile("s_load_dwordx2 %0, %4, 0x0\n\ts_load_dwordx2 %1, %5, 0x0\n\ts_load_dwordx2 %2, %6, 0x0"
+                             : "=&s"(g1_bits), "=&s"(gdiv_bits), "=&s"(tdiv_bits), "+v"(rid) : "s"(s0), "s"(s1), "s"(s2) : "memory");
+            }
+            wave_argmax_nonneg(ru, rid);
+            if (lane == cls) { cbu = ru; cbid = rid; }
+        }
+        // ---- DeterministicNode.expand (deterministic.py:28-43), update() with ndarray reward / done (:45-65)
+        // (`cbid` passes through: the wait stays below the reduction)
+        if (MB == 2)
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[MB > 1 ? 1 : 0]), "+s"(g1_bits), "+s"(gdiv_bits), "+s"(tdiv_bits), "+v"(cbid) : : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" : "+v"(rr[0]), "+v"(rr[MB > 1 ? 1 : 0]), "+v"(rr[MB > 2 ? 2 : 0]), "+v"(rr[MB > 3 ? 3 : 0]),
+                         "+s"(g1_bits), "+s"(gdiv_bits), "+s"(tdiv_bits), "+v"(cbid) : : "memory");
+        const double g1d = __longlong_as_double((long long)g1_bits), gdivd = __longlong_as_double((long long)gdiv_bits),
+                     tdivd = __longlong_as_double((long long)tdiv_bits);
+        const int g = n_nodes;
+        bool bad = false, avail = false;
+        double Uc_mine = 0.0;
+        if (lane < A) {
+            const int c = g + lane;
+            double lmin = 0.0, umin = 0.0;
+            uint32_t dbits = 0;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) // JointEnv.step: every model steps its own state (robust.py:13-16)
+                if (m < M) {
+                    const int32_t nxt = (int32_t)rr[m].x;
+                    const uint32_t flags = rr[m].y;
+                    const double r = __hiloint2double((int)rr[m].w, (int)rr[m].z);
+                    avail |= (flags & 4u) != 0;         // robust.py:22-25: the union of the models' listed actions
+                    bad |= !(0.0 <= r) || !(r <= 1.0);  // np.all(0 <= reward), np.all(reward <= 1)
+                    const bool dn = (flags & done_bit) != 0;
+                    double Lc = lv[m] + g1d * r;
+                    double Uc = Lc + gdivd;
+                    if (dn) {
+                        const double nv = Lc + tdivd;
+                        Lc = nv; Uc = nv;
+                    }
+                    Lv[(long)c * M + m] = Lc;
+                    Sv[(long)c * M + m] = nxt;
+                    Rv[(long)c * M + m] = r;
+                    dbits |= (dn ? 1u : 0u) << m;
+                    if (m == 0 || Lc < lmin) lmin = Lc; // np.min
+                    if (m == 0 || Uc < umin) umin = Uc;
+                }
+            bad = bad && avail;                          // (phantom slots: see the generic loop)
+            if (!avail) { lmin = ninf; umin = ninf; }
+            Lmin[c] = lmin;
+            meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
+            LU(c) = umin;
+            Uc_mine = umin;
+        }
+        real_steps += __popcll(__ballot(avail));
+        if (lane == 0) exp_lds[k] = leaf;
+        n_nodes += A;
+        k_done = k + 1;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads(); // the next expansion may read these children's vectors (global memory, other lanes)
+        {
+            const int j = (lane - g) & 63;
+            const double u = __shfl(Uc_mine, j & 63);
+            if (j < A) {
+                const int id = g + j;
+                if (u > cbu) { cbu = u; cbid = id; }
+            }
+        }
+    }
+    } else {
     for (int k = 0; k < p.K; ++k) {
         // ---- robust.py:37: first maximal min_m U among the leaves
         double bu = cbu;
@@ -166,6 +291,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                 if (u > cbu) { cbu = u; cbid = id; }
             }
         }
+    }
     }
     __syncthreads();
 
@@ -554,13 +680,18 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(stage_out_alloc(ctx, WS_IO7, status, (size_t)n_roots, mem, &a.status));
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, mem, &a.env_steps));
 
+    // main loop: the batched-load form for <= 2 / <= 4 models when every finite bound is >= +0.0, else the generic one
+    // (MP_OPD_LOOP=0: the generic one always -- test hook, shared with mp_opd_plan)
+    const char *mode_env = getenv("MP_OPD_LOOP");
+    int mb = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(mode_env && mode_env[0] == '0') ? (M <= 2 ? 2 : M <= 4 ? 4 : 0) : 0;
+    typedef void (*kernel_t)(ROpdArgs);
+    const kernel_t kfn = expg ? (mb == 2 ? ropd_kernel<true, 2> : mb == 4 ? ropd_kernel<true, 4> : ropd_kernel<true, 0>)
+                              : (mb == 2 ? ropd_kernel<false, 2> : mb == 4 ? ropd_kernel<false, 4> : ropd_kernel<false, 0>);
     if (lds > 64 * 1024)
-        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(expg ? ropd_kernel<true> : ropd_kernel<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
     if (glb) hipLaunchKernelGGL(ropd_wide_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else if (expg) hipLaunchKernelGGL((ropd_kernel<true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else hipLaunchKernelGGL((ropd_kernel<false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else hipLaunchKernelGGL(kfn, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 

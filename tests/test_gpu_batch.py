@@ -179,6 +179,17 @@ def test_opd_closing_passes_on_the_node_array(ctx, n_actions, budget, variant, m
         _cmp_opd(ctx, cfg, 70, budget, 0.95, seed=3)
 
 
+@pytest.mark.parametrize("variant", ["lds", "ldsx"])
+def test_opd_general_main_loop_where_the_fast_one_applies(ctx, variant, monkeypatch):
+    """MP_OPD_LOOP=0: the main loop for arbitrary bounds (taken by itself when the terminal reward is negative or gamma is
+    outside [0, 1)), forced where the loop for bounds >= 0 applies."""
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_LOOP", "0")
+    _cmp_opd(ctx, generators.highway_shaped(6, 8, 40, seed=2), 70, 2500, 0.95, seed=3)
+    _cmp_opd(ctx, generators.random_deterministic(300, 7, seed=11, terminal_rate=0.05), 70, 700, 0.9, terminal_reward=0.25, seed=5)
+
+
 def test_opd_negative_terminal_reward_lowers_an_expanded_node(ctx):
     """terminal_reward < 0: a done child's bound lies BELOW its parent's creation-time bound, so an expanded node's final
     lower bound can be smaller than the value it had as a leaf -- the backups must not keep the old value."""

@@ -75,6 +75,10 @@ def one_case(ctx, g, case):
     os.environ.pop("MP_OPD_CLOSING", None)
     if int(g.integers(0, 3)) == 0:
         os.environ["MP_OPD_CLOSING"] = "chain"
+    # main loop: the forms for bounds >= 0 where they apply (default) or the general one everywhere
+    os.environ.pop("MP_OPD_LOOP", None)
+    if int(g.integers(0, 3)) == 0:
+        os.environ["MP_OPD_LOOP"] = "0"
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant)
     if kind == "vi":
         model.close()
@@ -443,6 +447,7 @@ def run(n_cases, seed, ctx=None, verbose=False):
     finally:
         os.environ.pop("MP_OPD_MODEL", None)
         os.environ.pop("MP_OPD_CLOSING", None)
+        os.environ.pop("MP_OPD_LOOP", None)
         if forced is not None:
             os.environ["MP_OPD_MODEL"] = forced
     if own:
