@@ -421,6 +421,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 // skips the leaf in registers -- five vector-memory instructions per expansion instead of nine, but ten more VALU
 // instructions for the lane roles: 3.66 ms against 3.49 at 8192 roots.  TA_BUSY did not move (74 %): it counts a unit
 // with requests in flight, not a unit out of issue slots.
+template <bool NONNEG>
 __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -451,7 +452,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         // ---- deterministic.py:110: first maximal upper bound among the leaves
         double bu = cbu;
         int leaf = cbid;
-        wave_argmax_keys(bu, leaf);
+        if (NONNEG) wave_argmax_keys_nonneg(bu, leaf); else wave_argmax_keys(bu, leaf);
         const int cls = leaf & 63;
         const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
         // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry
@@ -468,7 +469,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
                 if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
                 if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
-            wave_argmax_keys(ru, rid);
+            if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         // ---- DeterministicNode.expand, deterministic.py:28-43
@@ -713,7 +714,8 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
                            : (nonneg ? (const void *)opd_kernel<false, true> : (const void *)opd_kernel<false, false>);
     if (lds > 64 * 1024) MP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    if (glb) hipLaunchKernelGGL(opd_wide_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (glb && nonneg) hipLaunchKernelGGL(opd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (glb) hipLaunchKernelGGL(opd_wide_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (expg && nonneg) hipLaunchKernelGGL((opd_kernel<true, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (expg) hipLaunchKernelGGL((opd_kernel<true, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (nonneg) hipLaunchKernelGGL((opd_kernel<false, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);

@@ -402,6 +402,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
 // selected leaf's slot NaN-boxed with its expansion index (node -> k map; the k -> node map is scattered by the closing
 // pass; the plan descent needs no search), the closing lower-bound sweep through a sliding LDS window over Lmin[], and
 // the arguments only the closing passes need loaded after the main loop (SGPR budget of 8 waves per SIMD).
+template <bool NONNEG>
 __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         // ---- robust.py:37: first maximal min_m U among the leaves
         double bu = cbu;
         int leaf = cbid;
-        wave_argmax_keys(bu, leaf);
+        if (NONNEG) wave_argmax_keys_nonneg(bu, leaf); else wave_argmax_keys(bu, leaf);
         const int cls = leaf & 63;
         const int dleaf = meta[2 * leaf];
         if (lane == 0) LU(leaf) = __hiloint2double((int)0xFFF80000, k); // dead to every selection; carries k
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
                 if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
                 if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
             }
-            wave_argmax_keys(ru, rid);
+            if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         // ---- DeterministicNode.expand (deterministic.py:28-43), update() with ndarray reward / done (:45-65)
@@ -690,7 +691,9 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     if (lds > 64 * 1024)
         MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    if (glb) hipLaunchKernelGGL(ropd_wide_kernel, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    const bool nonneg = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(mode_env && mode_env[0] == '0');
+    if (glb && nonneg) hipLaunchKernelGGL(ropd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (glb) hipLaunchKernelGGL(ropd_wide_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(kfn, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());

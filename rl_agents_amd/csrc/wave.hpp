@@ -126,6 +126,39 @@ __device__ __forceinline__ void wave_argmax_nonneg(double &u, int &id)
     u = key == 0 ? -INFINITY : m; // no lane holds the "maximum": every lane was -inf
 }
 
+// unsigned maximum, zero-fill (see imax_step_zero)
+template <int CTRL>
+__device__ __forceinline__ unsigned umax_step_zero(unsigned v)
+{
+    const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+    return o > v ? o : v;
+}
+
+// The key form of the argmax (argmax_keys below: three separable 32-bit reductions, the fewest instructions -- the choice of
+// the kernels that run 8 waves per SIMD) for bounds >= +0.0 or -inf: the bit pattern of such a double IS an order-preserving
+// (signed high word, unsigned low word) key -- -inf has a negative high word -- so no transform, and every reduction step
+// is one zero-fill DPP instruction.
+__device__ __forceinline__ void wave_argmax_keys_nonneg(double &u, int &id)
+{
+    const int hi = __double2hiint(u);
+    const unsigned lo = (unsigned)__double2loint(u);
+    int kh = hi < 0 ? 0 : hi; // (-inf: below every real high word or equal to that of +0.0 -- then the low words / ids decide)
+    kh = imax_step_zero<0x111>(kh); kh = imax_step_zero<0x112>(kh); kh = imax_step_zero<0x114>(kh);
+    kh = imax_step_zero<0x118>(kh); kh = imax_step_zero<0x142>(kh); kh = imax_step_zero<0x143>(kh);
+    const int mh = __builtin_amdgcn_readlane(kh, 63);
+    const bool c1 = hi == mh;
+    unsigned l1 = c1 ? lo : 0u;
+    l1 = umax_step_zero<0x111>(l1); l1 = umax_step_zero<0x112>(l1); l1 = umax_step_zero<0x114>(l1);
+    l1 = umax_step_zero<0x118>(l1); l1 = umax_step_zero<0x142>(l1); l1 = umax_step_zero<0x143>(l1);
+    const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+    int key = (c1 && lo == ml) ? 0x7fffffff - id : 0;
+    key = imax_step_zero<0x111>(key); key = imax_step_zero<0x112>(key); key = imax_step_zero<0x114>(key);
+    key = imax_step_zero<0x118>(key); key = imax_step_zero<0x142>(key); key = imax_step_zero<0x143>(key);
+    key = __builtin_amdgcn_readlane(key, 63);
+    id = 0x7fffffff - key;
+    u = key == 0 ? -INFINITY : __hiloint2double(mh, (int)ml); // no lane holds the "maximum": every lane was -inf
+}
+
 // ---- cross-lane argmax on (U, id): maximal U first, lowest id among equal U; every lane returns the pair.
 // U is mapped to an order-preserving (signed high word, unsigned low word) key -- flip the magnitude bits of negative
 // values -- and the argmax is three separable 32-bit reductions: the maximal high word, the maximal low word among the
