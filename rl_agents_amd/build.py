@@ -16,7 +16,7 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libmi355plan.so")
 SOURCES = ["api.hip", "vi.hip", "uct.hip", "uct_stoch.hip", "opd.hip", "ropd.hip", "saopd.hip"]
-HEADERS = ["common.hpp", "pcg64.hpp", "wave.hpp"]
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith(".hpp"))   # every header: a stale library is a wrong library
 # -ffp-contract=off: the reference evaluates a*b+c with two roundings (Python floats); a fused
 # multiply-add would change the last bit of bounds and Q values and break bit-exact parity.
 # MP_PROFILE=1 in the environment builds the phase-instrumented kernels (device printf of clock64 ticks)
