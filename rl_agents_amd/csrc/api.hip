@@ -681,6 +681,7 @@ int mp_model_free(mp_model *m)
     if (m->term_all) hipFree(m->term_all);
     if (m->NXT) hipFree(m->NXT);
     if (m->thr) hipFree(m->thr);
+    if (m->srec) hipFree(m->srec);
     delete m;
     return MP_OK;
 }

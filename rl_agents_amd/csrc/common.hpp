@@ -134,6 +134,8 @@ struct mp_model {
     bool borrowed = false;
     int32_t *NXT = nullptr;
     uint64_t *thr = nullptr; // dense / sparse models: sampling thresholds ceil(cdf * 2^53) of every row (uct_stoch.hip), lazily built
+    uint4 *srec = nullptr;   // sparse models with B <= 4: one fused record per (s, a) -- thresholds, next states, reward, terminal
+                             // flags (uct_stoch.hip: an env step is ONE gather), lazily built; 2 (B <= 2) or 4 uint4 each
     mp_cartpole_params cp;
 };
 

@@ -24,30 +24,38 @@
 
 namespace mp {
 
-struct alignas(16) SNode {
+// A node is two 16-byte halves in two arrays: what the descent and the backup touch (every episode, for all |A| children of
+// every level) and what only the observation lists, the plan and the export read.  The |A| children of a node are 16 |A|
+// contiguous bytes of the first array -- one or two cache lines where 32-byte nodes took two or three -- and the halves a
+// plan really visits (~200 nodes x 16 B per root) are what has to stay cached.
+struct alignas(16) SHot {
     double value;
     int32_t count;
     int32_t first;  // root / observation node (open loop: any node): first of its |A| contiguous action children, -1 = leaf;
                     // action node in closed loop: head of its observation children (linked by `next`)
+};
+struct alignas(16) SCold {
     int32_t key;    // action id, or the observed next state
     int32_t next;   // next observation sibling (closed loop), -1
     int32_t parent;
     int32_t is_obs;
 };
-static_assert(sizeof(SNode) == 32, "SNode is two dwordx4");
+static_assert(sizeof(SHot) == 16 && sizeof(SCold) == 16, "node halves are one dwordx4 each");
 
 struct StochArgs {
     int n_roots, mode, S, A, W, episodes, horizon, cap, closed_loop, done_on_next, max_steps, max_plan_len;
     const int32_t *T;       // deterministic: [S*A]
     const uint64_t *thr;    // dense [S*A][S] / sparse [S*A][B]: ceil(cdf * 2^53)
     const int32_t *nxt;     // sparse: [S*A][B]
+    const uint4 *srec;      // sparse, B <= 4: fused records (WB = 2: 2 uint4 per (s, a), WB = 4: 4), else nullptr
     const double *R;        // [S*A]
     const uint8_t *term;    // [S] or nullptr
     const int32_t *root_state, *root_steps;
     const double *tab;      // gpow[H+1] | rollout thresholds [A] (uint64 bits) | tp[A] = (temperature * |A|) * prior[a]
     uint64_t *rng;
     const uint64_t *env_rng;
-    SNode *tree;
+    SHot *hot;              // [n_roots][cap]
+    SCold *cold;            // [n_roots][cap]
     int32_t *n_nodes_out;
     int32_t *plans, *plan_len;
     double *root_value, *root_child_value;
@@ -72,33 +80,96 @@ __global__ void build_thresholds(long rows, int W, const double *__restrict__ P,
     }
 }
 
+// Sparse models with B <= 4 successors: everything an env step reads, in one record per (s, a), so that a step is ONE gather
+// instead of the chain threshold(s) -> next state -> terminal flag of the next state (three to four dependent round trips
+// of a lone wave).  Only the first B - 1 thresholds can decide a draw (the last one is ceil(1.0 * 2^53) > every k).
+//   WB = 2:  q0 = {thr0.lo, thr0.hi, nxt0, nxt1}   q1 = {reward.lo, reward.hi, flags, 0}
+//   WB = 4:  q0 = {thr0, thr1}   q1 = {thr2, reward}   q2 = {nxt0..nxt3}   q3 = {flags, 0, 0, 0}
+// flags: bit 0 = terminal[s], bit 1 + j = terminal[nxt_j].  Unused slots: threshold 2^64 - 1 (never <= k), last successor.
+template <int WB>
+__global__ void pack_sparse_records(long rows, int A, int B, const uint64_t *__restrict__ thr, const int32_t *__restrict__ nxt,
+                                    const double *__restrict__ R, const uint8_t *__restrict__ term, uint4 *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    uint64_t t[3] = {~0ULL, ~0ULL, ~0ULL};
+    int32_t n[4];
+    for (int j = 0; j < 4; ++j) n[j] = nxt[i * B + (j < B ? j : B - 1)];
+    for (int j = 0; j < B - 1 && j < 3; ++j) t[j] = thr[i * B + j];
+    uint32_t flags = term && term[i / A] ? 1u : 0u;
+    for (int j = 0; j < 4; ++j) flags |= (term && term[n[j]] ? 1u : 0u) << (1 + j);
+    const unsigned long long rb = (unsigned long long)__double_as_longlong(R[i]);
+    if (WB == 2) {
+        out[i * 2] = make_uint4((uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)n[0], (uint32_t)n[1]);
+        out[i * 2 + 1] = make_uint4((uint32_t)rb, (uint32_t)(rb >> 32), flags, 0u);
+    } else {
+        out[i * 4] = make_uint4((uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)t[1], (uint32_t)(t[1] >> 32));
+        out[i * 4 + 1] = make_uint4((uint32_t)t[2], (uint32_t)(t[2] >> 32), (uint32_t)rb, (uint32_t)(rb >> 32));
+        out[i * 4 + 2] = make_uint4((uint32_t)n[0], (uint32_t)n[1], (uint32_t)n[2], (uint32_t)n[3]);
+        out[i * 4 + 3] = make_uint4(flags, 0u, 0u, 0u);
+    }
+}
+
+// WB: 0 = any model (deterministic table, dense rows by binary search, sparse rows of any width); 2 / 4 = sparse model through
+// the fused records above.  AT: |A| at compile time (2..8: the children of a node in registers -- one batch of loads, scores
+// computed once, no loop-carried branches), 0 = any |A|.
+template <int WB, int AT>
 __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_s[];
-    const int lane = threadIdx.x, A = p.A, H = p.horizon, E = p.episodes;
-    double *gpow = lds_s;
-    const uint64_t *rthr = reinterpret_cast<const uint64_t *>(gpow + (H + 1));
-    const double *tp = gpow + (H + 1) + A;
-    const int ntab = (H + 1) + 2 * A;
+    const int lane = threadIdx.x, A = AT > 0 ? AT : p.A, H = p.horizon, E = p.episodes;
+    constexpr int AR = AT > 0 ? AT : 1;
+    double *gpow = lds_s;                                   // [H + 1]  gamma ** h
+    const uint64_t *rthr = reinterpret_cast<const uint64_t *>(gpow + (H + 1)); // [A] rollout thresholds
+    const double *tp = gpow + (H + 1) + A;                  // [A]      temperature * |A| * prior[a]
+    const double *rcp = tp + A;                             // [E + 1]  1.0 / n
+    const double *tpdiv = rcp + (E + 1);                    // [A][E+2] temperature * |A| * prior[a] / n
+    const int ntab = (H + 1) + 2 * A + (E + 1) + A * (E + 2);
+    // host tables instead of f64 divisions (the same correctly rounded quotients; a division is ~40 instructions of a lone
+    // wave's chain); counts beyond the tables cannot occur here (a tree lives for one plan), the division is kept anyway
+    auto explore = [&](int a, int cnt1) { return cnt1 <= E + 1 ? tpdiv[a * (E + 2) + cnt1] : tp[a] / (double)cnt1; };
+    auto inv = [&](int c) { return c <= E ? rcp[c] : 1.0 / (double)c; };
     int32_t *path = reinterpret_cast<int32_t *>(lds_s + ntab) + lane; // entry i of this lane: path[i * 64]
+    // statistics of the first NS path nodes as the descent read them (nobody writes them in between): the backup of those
+    // nodes needs no load -- a load per path node was a dependent round trip each
+    constexpr int NS = 12;
+    double *pv = reinterpret_cast<double *>(reinterpret_cast<int32_t *>(lds_s + ntab) + (2 * H + 2) * 64) + lane; // pv[i * 64]
+    int32_t *pc = reinterpret_cast<int32_t *>(pv - lane + NS * 64) + lane;                                          // pc[i * 64]
     for (int i = lane; i < ntab; i += 64) lds_s[i] = p.tab[i];
     __syncthreads();
     const int r = blockIdx.x * 64 + lane;
     if (r >= p.n_roots) return;
-    SNode *tree = p.tree + (long)r * p.cap;
+    SHot *hot = p.hot + (long)r * p.cap;
+    SCold *cold = p.cold + (long)r * p.cap;
     Pcg64 g;
     g.load(p.rng + (long)r * 6);
     const int32_t s0 = p.root_state[r], st0 = p.root_steps ? p.root_steps[r] : 0;
     const bool closed = p.closed_loop != 0;
     auto make = [&](int id, int parent, int key, int obs) {
-        SNode n;
-        n.value = 0.0; n.count = 0; n.first = -1; n.key = key; n.next = -1; n.parent = parent; n.is_obs = obs;
-        tree[id] = n;
+        SHot h;
+        h.value = 0.0; h.count = 0; h.first = -1;
+        SCold c;
+        c.key = key; c.next = -1; c.parent = parent; c.is_obs = obs;
+        hot[id] = h;
+        cold[id] = c;
     };
+    uint64_t rt[AR]; // the rollout policy's thresholds (wave-uniform)
+#pragma unroll
+    for (int j = 0; j < AR; ++j) rt[j] = AT > 0 ? rthr[j] : 0ULL;
     make(0, -1, -1, 0); // mcts.py:129-130 reset()
     int n_nodes = 1;
     long steps_taken = 0;
+    double root_v = 0.0; // the root's statistics live in registers for the plan (every episode reads and updates them)
+    int root_c = 0, root_first = -1;
+#ifdef MP_PROFILE
+    long long t_sel = 0, t_exp = 0, t_roll = 0, t_bak = 0, n_sel = 0, n_roll = 0;
+    const long long t_all0 = clock64();
+#define SPROF(x) const long long x = clock64()
+#else
+#define SPROF(x)
+#endif
     for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
+        SPROF(c0);
         int32_t s = s0, st = st0;    // safe_deepcopy_env(state): the clone's state, step counter ...
         Pcg64 eg;                    // ... and a COPY of the env's generator: every episode replays the same noise
         eg.s_hi = eg.s_lo = eg.inc_hi = 0; eg.inc_lo = 1; eg.has_uint32 = eg.uinteger = 0;
@@ -107,6 +178,34 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         auto env_step = [&](int a, double &reward, bool &terminated, bool &truncated) {
             const long sa = (long)s * A + a;
             int32_t sn;
+            if (WB > 0) {
+                // the draw does not depend on the record: its 128-bit multiply runs while the gather is in flight
+                const uint4 *rp = p.srec + sa * WB;
+                const uint4 q0 = rp[0], q1 = rp[1];
+                uint4 q2 = make_uint4(0u, 0u, 0u, 0u), q3 = q2;
+                if (WB == 4) { q2 = rp[2]; q3 = rp[3]; }
+                const uint64_t k = eg.next64() >> 11; // Generator.random()
+                int lo;                               // searchsorted(cdf, u, 'right') = #{j : thr_j <= k}
+                uint32_t flags;
+                if (WB == 2) {
+                    lo = (((uint64_t)q0.y << 32) | q0.x) <= k ? 1 : 0;
+                    sn = (int32_t)(lo ? q0.w : q0.z);
+                    reward = __hiloint2double((int)q1.y, (int)q1.x);
+                    flags = q1.z;
+                } else {
+                    lo = ((((uint64_t)q0.y << 32) | q0.x) <= k ? 1 : 0) + ((((uint64_t)q0.w << 32) | q0.z) <= k ? 1 : 0) +
+                         ((((uint64_t)q1.y << 32) | q1.x) <= k ? 1 : 0);
+                    sn = (int32_t)(lo == 0 ? q2.x : lo == 1 ? q2.y : lo == 2 ? q2.z : q2.w);
+                    reward = __hiloint2double((int)q1.w, (int)q1.z);
+                    flags = q3.x;
+                }
+                terminated = p.done_on_next ? ((flags >> (1 + lo)) & 1u) != 0 : (flags & 1u) != 0;
+                s = sn;
+                st += 1;
+                truncated = p.max_steps > 0 && st >= p.max_steps;
+                ++steps_taken;
+                return;
+            }
             if (p.mode == MP_MODE_DETERMINISTIC) {
                 sn = p.T[sa];
             } else {
@@ -131,86 +230,163 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         bool terminal = false;
         double total = 0.0;
         path[(plen++) * 64] = 0;
-        int fc = tree[0].first;
+        int fc = root_first;
         // ---- selection, mcts.py:143-149
         while (depth < H && fc >= 0 && !terminal) {
             // MCTSNode.selection_strategy (:275-286): value + temperature * len(children) * prior / (count + 1);
             // Node.random_argmax (abstract.py:296-311): exact-equality argmax set, one bounded draw among >= 2 ties
-            double m = 0.0;
-            int nt = 0;
-            for (int a = 0; a < A; ++a) {
-                const SNode c = tree[fc + a];
-                const double sc = c.value + tp[a] / (double)(c.count + 1);
-                if (a == 0 || sc > m) { m = sc; nt = 1; } else if (sc == m) ++nt;
-            }
-            int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
-            int act = 0;
-            for (int a = 0; a < A; ++a) {
-                const SNode c = tree[fc + a];
-                const double sc = c.value + tp[a] / (double)(c.count + 1);
-                if (sc == m) {
-                    if (pick == 0) { act = a; break; }
-                    --pick;
+            int act = 0, act_first = -1, act_c = 0;
+            double act_v = 0.0;
+            if (AT > 0) {
+                SHot c[AR];
+#pragma unroll
+                for (int a = 0; a < AR; ++a) c[a] = hot[fc + a];
+                double sc[AR];
+#pragma unroll
+                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
+                double m = sc[0];
+#pragma unroll
+                for (int a = 1; a < AR; ++a) m = sc[a] > m ? sc[a] : m;
+                int nt = 0;
+#pragma unroll
+                for (int a = 0; a < AR; ++a) nt += sc[a] == m ? 1 : 0;
+                int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
+                bool found = false;
+#pragma unroll
+                for (int a = 0; a < AR; ++a) {
+                    const bool eq = sc[a] == m;
+                    if (eq && !found && pick == 0) {
+                        act = a; found = true;
+                        act_first = c[a].first; act_c = c[a].count; act_v = c[a].value;
+                    }
+                    if (eq && !found) --pick;
+                }
+            } else {
+                double m = 0.0;
+                int nt = 0;
+                for (int a = 0; a < A; ++a) {
+                    const SHot c = hot[fc + a];
+                    const double sc = c.value + explore(a, c.count + 1);
+                    if (a == 0 || sc > m) { m = sc; nt = 1; } else if (sc == m) ++nt;
+                }
+                int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
+                for (int a = 0; a < A; ++a) {
+                    const SHot c = hot[fc + a];
+                    const double sc = c.value + explore(a, c.count + 1);
+                    if (sc == m) {
+                        if (pick == 0) { act = a; act_first = c.first; act_c = c.count; act_v = c.value; break; }
+                        --pick;
+                    }
                 }
             }
+            // closed loop: both halves of the head of the action node's observation list are requested together with the env
+            // step's record (all three only need the action)
+            SHot oh;
+            oh.value = 0.0; oh.count = 0; oh.first = -1;
+            SCold oc;
+            oc.key = -1; oc.next = -1; oc.parent = -1; oc.is_obs = 1;
+            if (closed && act_first >= 0) { oc = cold[act_first]; oh = hot[act_first]; }
             double reward;
             bool trunc;
             env_step(act, reward, terminal, trunc);
             total += gpow[depth] * reward;
             node = fc + act;
+            if (plen < NS) { pv[plen * 64] = act_v; pc[plen * 64] = act_c; }
             path[(plen++) * 64] = node;
+            fc = act_first;
             if (closed) { // get_child(action, observation): the child keyed by str(observation), made on first visit
-                int o = tree[node].first, prev = -1;
-                while (o >= 0 && tree[o].key != s) { prev = o; o = tree[o].next; }
+                int o = act_first, prev = -1;
+                while (o >= 0) {
+                    if (oc.key == s) break;
+                    prev = o; o = oc.next;
+                    if (o >= 0) { oc = cold[o]; oh = hot[o]; }
+                }
                 if (o < 0) {
                     o = n_nodes++;
                     make(o, node, s, 1);
-                    if (prev < 0) tree[node].first = o; else tree[prev].next = o;
+                    if (prev < 0) hot[node].first = o; else cold[prev].next = o;
+                    oh.value = 0.0; oh.count = 0; oh.first = -1;
                 }
                 node = o;
+                if (plen < NS) { pv[plen * 64] = oh.value; pc[plen * 64] = oh.count; }
                 path[(plen++) * 64] = node;
+                fc = oh.first;
             }
-            fc = tree[node].first;
             ++depth;
         }
+        SPROF(c1);
+#ifdef MP_PROFILE
+        n_sel += depth;
+#endif
         // ---- expansion, mcts.py:151-154 (a child per action, prior = the state-independent prior policy's)
         if (fc < 0 && depth < H && (!terminal || node == 0)) {
             const int c0 = n_nodes;
             for (int a = 0; a < A; ++a) make(c0 + a, node, a, 0);
-            tree[node].first = c0;
+            if (node == 0) root_first = c0;
+            hot[node].first = c0;
             n_nodes += A;
         }
         // ---- rollout, mcts.py:160-177
-        if (!terminal) {
+        SPROF(c2);
+        if (!terminal && depth < H) {
+            // The draw of step h + 1 is computed while step h's lookup is in flight -- on a copy of the generator that is
+            // committed only if the rollout goes on, so a rollout that stops leaves the stream where the reference's is.
+            Pcg64 gn = g;
+            uint64_t k = gn.next64() >> 11;          // np_random.choice(actions, 1, p=p): one double, inverse cdf
             for (int h = depth; h < H; ++h) {
-                const uint64_t k = g.next64() >> 11; // np_random.choice(actions, 1, p=p): one double, inverse cdf
                 int a = 0;
-                for (int j = 0; j < A - 1; ++j) a += rthr[j] <= k ? 1 : 0;
+                if (AT > 0) {
+#pragma unroll
+                    for (int j = 0; j < AR - 1; ++j) a += rt[j] <= k ? 1 : 0;
+                } else {
+                    for (int j = 0; j < A - 1; ++j) a += rthr[j] <= k ? 1 : 0;
+                }
+                g = gn;                              // this step's draw is consumed
+                Pcg64 gs = gn;
+                const uint64_t k_next = gs.next64() >> 11;
                 double reward;
                 bool term_h, trunc_h;
                 env_step(a, reward, term_h, trunc_h);
                 total += gpow[h] * reward;
                 if (term_h || trunc_h) break;
+                gn = gs;
+                k = k_next;
             }
         }
+        SPROF(c3);
         // ---- update_branch, mcts.py:248-265: the same total on every node of the path
-        for (int i = 0; i < plen; ++i) {
-            SNode *nd = tree + path[i * 64];
-            const int c = nd->count + 1;
-            const double v = nd->value;
-            nd->count = c;
-            nd->value = v + 1.0 / (double)c * (total - v);
+        {
+            const int c = root_c + 1;
+            root_c = c;
+            root_v = root_v + inv(c) * (total - root_v);
         }
+        for (int i = 1; i < plen; ++i) {
+            SHot *nd = hot + path[i * 64];
+            const int c = (i < NS ? pc[i * 64] : nd->count) + 1;
+            const double v = i < NS ? pv[i * 64] : nd->value;
+            nd->count = c;
+            nd->value = v + inv(c) * (total - v);
+        }
+#ifdef MP_PROFILE
+        { const long long c4 = clock64(); t_sel += c1 - c0; t_exp += c2 - c1; t_roll += c3 - c2; t_bak += c4 - c3; }
+#endif
     }
+#ifdef MP_PROFILE
+    if (r == 0)
+        printf("uct_stoch prof root0: total=%lld selection=%lld (%lld levels) expansion=%lld rollout=%lld (%lld env steps in all) backup=%lld (clock64 ticks)\n",
+               (long long)(clock64() - t_all0), t_sel, n_sel, t_exp, t_roll, (long long)steps_taken, t_bak);
+#endif
+    hot[0].value = root_v;
+    hot[0].count = root_c;
     g.store(p.rng + (long)r * 6);
     if (p.n_nodes_out) p.n_nodes_out[r] = n_nodes;
     if (p.env_steps) p.env_steps[r] = steps_taken;
-    if (p.root_value) p.root_value[r] = tree[0].value;
+    if (p.root_value) p.root_value[r] = root_v;
     {
-        const int fc = tree[0].first;
+        const int fc = root_first;
         for (int a = 0; a < A; ++a) {
-            if (p.root_child_count) p.root_child_count[(long)r * A + a] = fc >= 0 ? tree[fc + a].count : 0;
-            if (p.root_child_value) p.root_child_value[(long)r * A + a] = fc >= 0 ? tree[fc + a].value : 0.0;
+            if (p.root_child_count) p.root_child_count[(long)r * A + a] = fc >= 0 ? hot[fc + a].count : 0;
+            if (p.root_child_value) p.root_child_value[(long)r * A + a] = fc >= 0 ? hot[fc + a].value : 0.0;
         }
     }
     // ---- get_plan (abstract.py:143-156) with MCTSNode.selection_rule (mcts.py:212-218) at every level: most visited
@@ -218,25 +394,25 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     int len = 0, node = 0;
     bool at_action_node = false;
     for (;;) {
-        int best = -1, bc = 0;
+        int best = -1, bc = 0, bkey = -1;
         double bv = 0.0;
         if (closed && at_action_node) {
-            for (int o = tree[node].first; o >= 0; o = tree[o].next) {
-                const int c = tree[o].count;
-                const double v = tree[o].value;
-                if (best < 0 || c > bc || (c == bc && v > bv)) { best = o; bc = c; bv = v; }
+            for (int o = hot[node].first; o >= 0;) {
+                const SHot on = hot[o];
+                const SCold oc = cold[o];
+                if (best < 0 || on.count > bc || (on.count == bc && on.value > bv)) { best = o; bc = on.count; bv = on.value; bkey = oc.key; }
+                o = oc.next;
             }
         } else {
-            const int fc = tree[node].first;
+            const int fc = hot[node].first;
             if (fc >= 0)
                 for (int a = 0; a < A; ++a) {
-                    const int c = tree[fc + a].count;
-                    const double v = tree[fc + a].value;
-                    if (best < 0 || c > bc || (c == bc && v > bv)) { best = fc + a; bc = c; bv = v; }
+                    const SHot cn = hot[fc + a];
+                    if (best < 0 || cn.count > bc || (cn.count == bc && cn.value > bv)) { best = fc + a; bc = cn.count; bv = cn.value; bkey = a; }
                 }
         }
         if (best < 0) break;
-        if (p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = tree[best].key;
+        if (p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = bkey;
         ++len;
         node = best;
         at_action_node = !at_action_node;
@@ -294,10 +470,26 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
         MP_HIP(hipGetLastError());
     }
 
+    // sparse rows of at most four successors: the fused records (one gather per env step); MP_UCT_STOCH_FUSED=0: test hook
+    const char *fz = getenv("MP_UCT_STOCH_FUSED");
+    const int wb = mode == MP_MODE_SPARSE && W <= 4 && !(fz && fz[0] == '0') ? (W <= 2 ? 2 : 4) : 0;
+    if (wb && !model->srec) {
+        const long rows = (long)S * A;
+        if (hipMalloc(&model->srec, (size_t)rows * wb * sizeof(uint4)) != hipSuccess)
+            return fail(MP_ERR_ALLOC, "mp_uct_plan_stochastic: %zu B for the fused records", (size_t)rows * wb * sizeof(uint4));
+        if (wb == 2)
+            hipLaunchKernelGGL(pack_sparse_records<2>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, A, W, model->thr,
+                               model->NXT, model->R, model->term, model->srec);
+        else
+            hipLaunchKernelGGL(pack_sparse_records<4>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, A, W, model->thr,
+                               model->NXT, model->R, model->term, model->srec);
+        MP_HIP(hipGetLastError());
+    }
+
     // per-call tables, computed on the host exactly as Python computes them (see uct_plan_impl)
-    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A;
+    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (size_t)(E + 1) + (size_t)A * (E + 2);
     std::vector<double> tab(ntab);
-    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A;
+    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (E + 1);
     for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);
     double acc = 0.0;
     for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }
@@ -307,11 +499,17 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
         memcpy(&cdf[a], &t, sizeof(t));
     }
     for (int a = 0; a < A; ++a) tpv[a] = temperature * (double)A * prior_p[a]; // mcts.py:286, left to right
+    rcp[0] = 0.0;
+    for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                     // mcts.py:257: 1 / count
+    for (int a = 0; a < A; ++a) {
+        tpdiv[(size_t)a * (E + 2)] = 0.0;
+        for (int n = 1; n <= E + 1; ++n) tpdiv[(size_t)a * (E + 2) + n] = tpv[a] / (double)n; // mcts.py:286: / (count + 1)
+    }
     double *d_tab = nullptr;
     MP_TRY(upload_tables(ctx, 7, tab, &d_tab));
 
     const long cap = 1 + (long)E * ((long)A + (closed_loop ? H : 0));
-    const size_t lds = ntab * sizeof(double) + (size_t)(2 * H + 2) * 64 * sizeof(int32_t);
+    const size_t lds = ntab * sizeof(double) + (size_t)(2 * H + 2) * 64 * sizeof(int32_t) + (size_t)12 * 64 * (sizeof(double) + sizeof(int32_t));
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
 
     StochArgs a;
@@ -320,7 +518,9 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     a.closed_loop = closed_loop ? 1 : 0; a.done_on_next = model->done_on_next; a.max_steps = model->max_steps;
     a.max_plan_len = max_plan_len;
     a.T = model->T; a.thr = model->thr; a.nxt = model->NXT; a.R = model->R; a.term = model->term; a.tab = d_tab;
-    MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.tree));
+    a.srec = wb ? model->srec : nullptr;
+    MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.hot));
+    MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap, &a.cold));
     MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out));
     ctx->tree.kind = 4; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.armed = false;
     ctx->tree.K = closed_loop ? 1 : 0;
@@ -341,7 +541,17 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, amem, &a.env_steps));
 
     MP_TRY(kernels_begin(ctx));
-    hipLaunchKernelGGL(uct_stoch_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+    {
+        typedef void (*kernel_t)(StochArgs);
+#define MP_ROW(WBV) {uct_stoch_kernel<WBV, 0>, uct_stoch_kernel<WBV, 0>, uct_stoch_kernel<WBV, 2>, uct_stoch_kernel<WBV, 3>, \
+                     uct_stoch_kernel<WBV, 4>, uct_stoch_kernel<WBV, 5>, uct_stoch_kernel<WBV, 6>, uct_stoch_kernel<WBV, 7>, \
+                     uct_stoch_kernel<WBV, 8>}
+        static const kernel_t table[3][9] = {MP_ROW(0), MP_ROW(2), MP_ROW(4)};
+#undef MP_ROW
+        const char *ag = getenv("MP_UCT_STOCH_GENERIC_A"); // "1": the loop form of the selection for any |A| -- test hook
+        const int at = A >= 2 && A <= 8 && !(ag && ag[0] == '1') ? A : 0;
+        hipLaunchKernelGGL(table[wb == 2 ? 1 : wb == 4 ? 2 : 0][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+    }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
 
@@ -375,13 +585,16 @@ int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_
     int32_t n = 0;
     MP_HIP(hipMemcpy(&n, (const int32_t *)ctx->ws[WS_TREE1].p + root, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (n > cap) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_export: capacity %d < %d nodes", cap, n);
-    std::vector<SNode> h((size_t)n);
-    MP_HIP(hipMemcpy(h.data(), (const SNode *)ctx->ws[WS_TREE0].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SNode),
+    std::vector<SHot> h((size_t)n);
+    std::vector<SCold> c((size_t)n);
+    MP_HIP(hipMemcpy(h.data(), (const SHot *)ctx->ws[WS_TREE0].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SHot),
+                     hipMemcpyDeviceToHost));
+    MP_HIP(hipMemcpy(c.data(), (const SCold *)ctx->ws[WS_TREE2].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SCold),
                      hipMemcpyDeviceToHost));
     for (int i = 0; i < n; ++i) {
-        if (parent) parent[i] = h[i].parent;
-        if (key) key[i] = h[i].key;
-        if (is_obs) is_obs[i] = (uint8_t)h[i].is_obs;
+        if (parent) parent[i] = c[i].parent;
+        if (key) key[i] = c[i].key;
+        if (is_obs) is_obs[i] = (uint8_t)c[i].is_obs;
         if (count) count[i] = h[i].count;
         if (value) value[i] = h[i].value;
     }

@@ -237,16 +237,26 @@ def test_uct_on_stochastic_models_agent(z):
 
 
 @pytest.mark.parametrize("mode,closed", [("stochastic", False), ("stochastic", True), ("sparse", False), ("sparse", True),
-                                         ("deterministic", True)])
-def test_uct_on_stochastic_models_batch_vs_oracle(ctx, mode, closed):
+                                         ("deterministic", True), ("sparse2", True), ("sparse2", False), ("sparse6", True),
+                                         ("sparse-unfused", True), ("sparse-many-actions", True), ("sparse-generic-a", True)])
+def test_uct_on_stochastic_models_batch_vs_oracle(ctx, mode, closed, monkeypatch):
     """Seeded batches of 300 roots (ragged last wave), distinct planner AND env generator records per root, a TimeLimit
     and both terminal conventions: plans, values, env steps and generator records equal the oracle's."""
     from oracle import oracle
     from rl_agents_amd.envs import generators
     if mode == "stochastic":
         cfg = generators.random_stochastic(90, 4, seed=21, terminal_rate=0.05, concentration=0.1)
-    elif mode == "sparse":
-        cfg = generators.random_sparse(400, 5, 3, seed=22, terminal_rate=0.05)
+    elif mode.startswith("sparse"):
+        # 3 / 2 successors: the fused 64- / 32-byte records; 6: rows by binary search; "unfused": MP_UCT_STOCH_FUSED=0;
+        # 11 actions: the generic selection (more than eight children)
+        b = {"sparse": 3, "sparse2": 2, "sparse6": 6, "sparse-unfused": 3, "sparse-many-actions": 2, "sparse-generic-a": 2}[mode]
+        n_act = 11 if mode == "sparse-many-actions" else 5
+        cfg = generators.random_sparse(400, n_act, b, seed=22 + b, terminal_rate=0.05)
+        if mode == "sparse-unfused":
+            monkeypatch.setenv("MP_UCT_STOCH_FUSED", "0")
+        if mode == "sparse-generic-a":                       # the loop form of the selection where |A| <= 8
+            monkeypatch.setenv("MP_UCT_STOCH_GENERIC_A", "1")
+        mode = "sparse"
     else:
         cfg = generators.random_deterministic(200, 4, seed=23, terminal_rate=0.05)
     a = cfg["reward"].shape[1]
