@@ -113,7 +113,9 @@ __global__ void pack_sparse_records(long rows, int A, int B, const uint64_t *__r
 // WB: 0 = any model (deterministic table, dense rows by binary search, sparse rows of any width); 2 / 4 = sparse model through
 // the fused records above.  AT: |A| at compile time (2..8: the children of a node in registers -- one batch of loads, scores
 // computed once, no loop-carried branches), 0 = any |A|.
-template <int WB, int AT>
+// PT: the type of a path-stack entry (uint16_t while every node id fits: the stack is the kernel's LDS footprint, and LDS is
+// what limits the waves per SIMD here -- 27 KB per wave held a 262 144-root batch at ONE wave per SIMD).
+template <int WB, int AT, typename PT>
 __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_s[];
@@ -129,12 +131,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     // wave's chain); counts beyond the tables cannot occur here (a tree lives for one plan), the division is kept anyway
     auto explore = [&](int a, int cnt1) { return cnt1 <= E + 1 ? tpdiv[a * (E + 2) + cnt1] : tp[a] / (double)cnt1; };
     auto inv = [&](int c) { return c <= E ? rcp[c] : 1.0 / (double)c; };
-    int32_t *path = reinterpret_cast<int32_t *>(lds_s + ntab) + lane; // entry i of this lane: path[i * 64]
-    // statistics of the first NS path nodes as the descent read them (nobody writes them in between): the backup of those
-    // nodes needs no load -- a load per path node was a dependent round trip each
-    constexpr int NS = 12;
-    double *pv = reinterpret_cast<double *>(reinterpret_cast<int32_t *>(lds_s + ntab) + (2 * H + 2) * 64) + lane; // pv[i * 64]
-    int32_t *pc = reinterpret_cast<int32_t *>(pv - lane + NS * 64) + lane;                                          // pc[i * 64]
+    PT *path = reinterpret_cast<PT *>(lds_s + ntab) + lane; // entry i of this lane: path[i * 64]
     for (int i = lane; i < ntab; i += 64) lds_s[i] = p.tab[i];
     __syncthreads();
     const int r = blockIdx.x * 64 + lane;
@@ -229,7 +226,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         int node = 0, depth = 0, plen = 0;
         bool terminal = false;
         double total = 0.0;
-        path[(plen++) * 64] = 0;
+        path[(plen++) * 64] = (PT)0;
         int fc = root_first;
         // ---- selection, mcts.py:143-149
         while (depth < H && fc >= 0 && !terminal) {
@@ -291,8 +288,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             env_step(act, reward, terminal, trunc);
             total += gpow[depth] * reward;
             node = fc + act;
-            if (plen < NS) { pv[plen * 64] = act_v; pc[plen * 64] = act_c; }
-            path[(plen++) * 64] = node;
+            path[(plen++) * 64] = (PT)node;
             fc = act_first;
             if (closed) { // get_child(action, observation): the child keyed by str(observation), made on first visit
                 int o = act_first, prev = -1;
@@ -308,8 +304,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     oh.value = 0.0; oh.count = 0; oh.first = -1;
                 }
                 node = o;
-                if (plen < NS) { pv[plen * 64] = oh.value; pc[plen * 64] = oh.count; }
-                path[(plen++) * 64] = node;
+                path[(plen++) * 64] = (PT)node;
                 fc = oh.first;
             }
             ++depth;
@@ -361,9 +356,9 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             root_v = root_v + inv(c) * (total - root_v);
         }
         for (int i = 1; i < plen; ++i) {
-            SHot *nd = hot + path[i * 64];
-            const int c = (i < NS ? pc[i * 64] : nd->count) + 1;
-            const double v = i < NS ? pv[i * 64] : nd->value;
+            SHot *nd = hot + (int)path[i * 64];
+            const int c = nd->count + 1;
+            const double v = nd->value;
             nd->count = c;
             nd->value = v + inv(c) * (total - v);
         }
@@ -509,7 +504,8 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     MP_TRY(upload_tables(ctx, 7, tab, &d_tab));
 
     const long cap = 1 + (long)E * ((long)A + (closed_loop ? H : 0));
-    const size_t lds = ntab * sizeof(double) + (size_t)(2 * H + 2) * 64 * sizeof(int32_t) + (size_t)12 * 64 * (sizeof(double) + sizeof(int32_t));
+    const bool p16 = cap <= 65535;
+    const size_t lds = ntab * sizeof(double) + (size_t)(2 * H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
 
     StochArgs a;
@@ -543,14 +539,15 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     MP_TRY(kernels_begin(ctx));
     {
         typedef void (*kernel_t)(StochArgs);
-#define MP_ROW(WBV) {uct_stoch_kernel<WBV, 0>, uct_stoch_kernel<WBV, 0>, uct_stoch_kernel<WBV, 2>, uct_stoch_kernel<WBV, 3>, \
-                     uct_stoch_kernel<WBV, 4>, uct_stoch_kernel<WBV, 5>, uct_stoch_kernel<WBV, 6>, uct_stoch_kernel<WBV, 7>, \
-                     uct_stoch_kernel<WBV, 8>}
-        static const kernel_t table[3][9] = {MP_ROW(0), MP_ROW(2), MP_ROW(4)};
+#define MP_ROW(WBV, PTV) {uct_stoch_kernel<WBV, 0, PTV>, uct_stoch_kernel<WBV, 0, PTV>, uct_stoch_kernel<WBV, 2, PTV>, \
+                          uct_stoch_kernel<WBV, 3, PTV>, uct_stoch_kernel<WBV, 4, PTV>, uct_stoch_kernel<WBV, 5, PTV>, \
+                          uct_stoch_kernel<WBV, 6, PTV>, uct_stoch_kernel<WBV, 7, PTV>, uct_stoch_kernel<WBV, 8, PTV>}
+        static const kernel_t table16[3][9] = {MP_ROW(0, uint16_t), MP_ROW(2, uint16_t), MP_ROW(4, uint16_t)};
+        static const kernel_t table32[3][9] = {MP_ROW(0, int32_t), MP_ROW(2, int32_t), MP_ROW(4, int32_t)};
 #undef MP_ROW
         const char *ag = getenv("MP_UCT_STOCH_GENERIC_A"); // "1": the loop form of the selection for any |A| -- test hook
         const int at = A >= 2 && A <= 8 && !(ag && ag[0] == '1') ? A : 0;
-        hipLaunchKernelGGL(table[wb == 2 ? 1 : wb == 4 ? 2 : 0][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((p16 ? table16 : table32)[wb == 2 ? 1 : wb == 4 ? 2 : 0][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
     }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
