@@ -136,6 +136,7 @@ struct mp_model {
     uint64_t *thr = nullptr; // dense / sparse models: sampling thresholds ceil(cdf * 2^53) of every row (uct_stoch.hip), lazily built
     uint4 *srec = nullptr;   // sparse models with B <= 4: one fused record per (s, a) -- thresholds, next states, reward, terminal
                              // flags (uct_stoch.hip: an env step is ONE gather), lazily built; 2 (B <= 2) or 4 uint4 each
+    int srec_wb = 0;         // 0 = not looked at yet, 2 / 4 = uint4 per record, -1 = rows too wide (dense rows by binary search)
     mp_cartpole_params cp;
 };
 

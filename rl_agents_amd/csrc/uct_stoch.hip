@@ -110,6 +110,59 @@ __global__ void pack_sparse_records(long rows, int A, int B, const uint64_t *__r
     }
 }
 
+// Dense models ([S, A, S] probabilities, the reference's finite-MDP form) whose rows hold at most four non-zero entries take
+// the same records: numpy samples a row by cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(cdf, u, 'right'), an entry of
+// probability 0 adds exactly 0.0 to the running sum and can never be the first index with cdf > u, so the draw is decided
+// by the thresholds of the non-zero entries alone -- the same numbers, computed here in the same order over the full row.
+__global__ void dense_row_width(long rows, int W, const double *__restrict__ P, int *__restrict__ max_nnz)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    int n = 0;
+    if (i < rows)
+        for (int j = 0; j < W; ++j) n += P[i * W + j] != 0.0 ? 1 : 0;
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(n, off); n = o > n ? o : n; }
+    if ((threadIdx.x & 63) == 0) atomicMax(max_nnz, n);
+}
+
+template <int WB>
+__global__ void pack_dense_records(long rows, int A, int W, const double *__restrict__ P, const double *__restrict__ R,
+                                   const uint8_t *__restrict__ term, uint4 *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const double *p = P + i * W;
+    double acc = 0.0;
+    for (int j = 0; j < W; ++j) acc += p[j]; // (build_thresholds' additions, in its order)
+    const double last = acc;
+    uint64_t t[4] = {~0ULL, ~0ULL, ~0ULL, ~0ULL};
+    int32_t n[4] = {0, 0, 0, 0};
+    int cnt = 0;
+    acc = 0.0;
+    for (int j = 0; j < W; ++j) {
+        acc += p[j];
+        if (p[j] != 0.0 && cnt < 4) {
+            const double scaled = ceil(ldexp(acc / last, 53));
+            t[cnt] = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
+            n[cnt] = j;
+            ++cnt;
+        }
+    }
+    for (int j = cnt; j < 4; ++j) { t[j] = ~0ULL; n[j] = cnt ? n[cnt - 1] : 0; }
+    if (cnt) t[cnt - 1] = ~0ULL; // the last non-zero entry's threshold (2^53, or whatever rounding left) is never "<= k": it takes the rest
+    uint32_t flags = term && term[i / A] ? 1u : 0u;
+    for (int j = 0; j < 4; ++j) flags |= (term && term[n[j]] ? 1u : 0u) << (1 + j);
+    const unsigned long long rb = (unsigned long long)__double_as_longlong(R[i]);
+    if (WB == 2) {
+        out[i * 2] = make_uint4((uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)n[0], (uint32_t)n[1]);
+        out[i * 2 + 1] = make_uint4((uint32_t)rb, (uint32_t)(rb >> 32), flags, 0u);
+    } else {
+        out[i * 4] = make_uint4((uint32_t)t[0], (uint32_t)(t[0] >> 32), (uint32_t)t[1], (uint32_t)(t[1] >> 32));
+        out[i * 4 + 1] = make_uint4((uint32_t)t[2], (uint32_t)(t[2] >> 32), (uint32_t)rb, (uint32_t)(rb >> 32));
+        out[i * 4 + 2] = make_uint4((uint32_t)n[0], (uint32_t)n[1], (uint32_t)n[2], (uint32_t)n[3]);
+        out[i * 4 + 3] = make_uint4(flags, 0u, 0u, 0u);
+    }
+}
+
 // WB: 0 = any model (deterministic table, dense rows by binary search, sparse rows of any width); 2 / 4 = sparse model through
 // the fused records above.  AT: |A| at compile time (2..8: the children of a node in registers -- one batch of loads, scores
 // computed once, no loop-carried branches), 0 = any |A|.
@@ -456,28 +509,42 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     hipStream_t st = ctx->stream;
     const int amem = mem_arrays(mem), rmem = mem_rng(mem);
 
-    // sampling thresholds of the model's rows, built once per model on the device (numpy's cumsum / division order)
-    if (mode != MP_MODE_DETERMINISTIC && !model->thr) {
-        const long rows = (long)S * A;
+    // Fused records (one gather per env step) for sparse rows of at most four successors and for dense rows with at most
+    // four non-zero entries; MP_UCT_STOCH_FUSED=0: never -- test hook.
+    const char *fz = getenv("MP_UCT_STOCH_FUSED");
+    const bool fuse_ok = !(fz && fz[0] == '0');
+    const long rows = (long)S * A;
+    if (model->srec_wb == 0 && mode == MP_MODE_SPARSE) model->srec_wb = W <= 2 ? 2 : (W <= 4 ? 4 : -1);
+    if (model->srec_wb == 0 && mode == MP_MODE_STOCHASTIC && fuse_ok) {
+        int *d_max = nullptr, h_max = 0;
+        MP_TRY(ws_get(ctx, WS_IO9, 1, &d_max));
+        MP_HIP(hipMemsetAsync(d_max, 0, sizeof(int), st));
+        hipLaunchKernelGGL(dense_row_width, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, W, model->P, d_max);
+        MP_HIP(hipMemcpyAsync(&h_max, d_max, sizeof(int), hipMemcpyDeviceToHost, st));
+        MP_HIP(hipStreamSynchronize(st));
+        model->srec_wb = h_max <= 2 ? 2 : (h_max <= 4 ? 4 : -1);
+    }
+    const int wb = fuse_ok && model->srec_wb > 0 ? model->srec_wb : 0;
+    // sampling thresholds of the model's rows (rows that are not fused), built once per model on the device (numpy's cumsum /
+    // division order)
+    if (mode != MP_MODE_DETERMINISTIC && !model->thr && (!wb || mode == MP_MODE_SPARSE)) {
         if (hipMalloc(&model->thr, (size_t)rows * W * sizeof(uint64_t)) != hipSuccess)
             return fail(MP_ERR_ALLOC, "mp_uct_plan_stochastic: %zu B for the sampling thresholds", (size_t)rows * W * 8);
         hipLaunchKernelGGL(build_thresholds, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, W, model->P, model->thr);
         MP_HIP(hipGetLastError());
     }
-
-    // sparse rows of at most four successors: the fused records (one gather per env step); MP_UCT_STOCH_FUSED=0: test hook
-    const char *fz = getenv("MP_UCT_STOCH_FUSED");
-    const int wb = mode == MP_MODE_SPARSE && W <= 4 && !(fz && fz[0] == '0') ? (W <= 2 ? 2 : 4) : 0;
     if (wb && !model->srec) {
-        const long rows = (long)S * A;
         if (hipMalloc(&model->srec, (size_t)rows * wb * sizeof(uint4)) != hipSuccess)
             return fail(MP_ERR_ALLOC, "mp_uct_plan_stochastic: %zu B for the fused records", (size_t)rows * wb * sizeof(uint4));
-        if (wb == 2)
-            hipLaunchKernelGGL(pack_sparse_records<2>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, A, W, model->thr,
-                               model->NXT, model->R, model->term, model->srec);
+        const dim3 grid((unsigned)((rows + 127) / 128)), block(128);
+        if (mode == MP_MODE_SPARSE && wb == 2)
+            hipLaunchKernelGGL(pack_sparse_records<2>, grid, block, 0, st, rows, A, W, model->thr, model->NXT, model->R, model->term, model->srec);
+        else if (mode == MP_MODE_SPARSE)
+            hipLaunchKernelGGL(pack_sparse_records<4>, grid, block, 0, st, rows, A, W, model->thr, model->NXT, model->R, model->term, model->srec);
+        else if (wb == 2)
+            hipLaunchKernelGGL(pack_dense_records<2>, grid, block, 0, st, rows, A, W, model->P, model->R, model->term, model->srec);
         else
-            hipLaunchKernelGGL(pack_sparse_records<4>, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, st, rows, A, W, model->thr,
-                               model->NXT, model->R, model->term, model->srec);
+            hipLaunchKernelGGL(pack_dense_records<4>, grid, block, 0, st, rows, A, W, model->P, model->R, model->term, model->srec);
         MP_HIP(hipGetLastError());
     }
 
