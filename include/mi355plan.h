@@ -271,6 +271,11 @@ int mp_uct_tree_capacity(mp_ctx *ctx, int32_t *cap);
  * listed policy lists in the node's state).  Host arrays of capacity `cap` nodes. */
 int mp_uct_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,
                        int64_t *count, double *value, int32_t *first_child, int32_t *n_children);
+/* Visit count of the node reached from root `root` by the action sequence `actions[0..n)` (host array) in the trees of the
+ * last mp_uct_plan on this ctx -- what `AbstractPlanner.get_plan` (abstract.py:143-156) needs to know about the LAST
+ * node of a closed-loop plan (an unvisited action node has no observation child yet) without exporting the tree.
+ * *count = -1 when the path leaves the tree (a node on it is not expanded, or the action is not listed there). */
+int mp_uct_path_count(mp_ctx *ctx, int32_t root, const int32_t *actions, int32_t n, int64_t *count);
 
 /*
  * MCTS on STOCHASTIC finite MDPs (the `stochastic` [S,A,S] and `sparse` [S,A,B] modes of a finite-MDP env: models from

@@ -308,12 +308,9 @@ class MCTS(AbstractPlanner):
         if not actions:
             return []
         self.require_device_tree()
-        tree = self.relabel_tree(self.models.ctx.uct_tree(0), getattr(self, "_last_model", None))
-        node = 0
-        for a in actions:       # creation-order arrays: children of `node` are contiguous from first_child
-            fc, k = int(tree["first_child"][node]), int(tree["n_children"][node])
-            node = next(fc + j for j in range(k) if int(tree["action"][fc + j]) == a)
-        last_visited = int(tree["count"][node]) > 0
+        # (one four-byte read-back of the last node's visit count: mp_uct_path_count -- not an export of the whole tree)
+        model = getattr(self, "_last_model", None)
+        last_visited = self.models.ctx.uct_path_count(0, self.device_actions(actions, model)) > 0
         env = copy.deepcopy(getattr(state, "unwrapped", state))     # never the live environment
         out = []
         for i, a in enumerate(actions):

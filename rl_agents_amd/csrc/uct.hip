@@ -651,6 +651,22 @@ void uct_kernel(UctArgs p)
 // AbstractPlanner.step_by_subtree (abstract.py:195-206), one root per lane: the subtree of the root's child
 // `action` is re-numbered breadth-first into the other tree buffer (children stay contiguous).  While a node
 // waits in the BFS queue its first_child field holds its OLD id.  A never-expanded root gives size 0 (fresh tree).
+// one thread: the visit count at the end of an action path (mp_uct_path_count)
+template <int IL>
+__global__ void uct_path_count_kernel(UctNode *trees, int root, int cap, int A, const int32_t *actions, int n, int64_t *out)
+{
+    const TreeRef<IL, 0> tree = tree_of<IL, 0>(trees, root, cap, A);
+    int node = 0;
+    for (int i = 0; i < n; ++i) {
+        const int fc = tree[node].first_child;
+        const int a = actions[i];
+        if (fc < 0 || a < 0 || a >= A) { out[0] = -1; return; }
+        node = fc + a;
+    }
+    const int c = tree[node].count;
+    out[0] = c < 0 ? -1 : c; // (count < 0: the phantom slot of an action a listed policy does not list)
+}
+
 template <int IL>
 __global__ __launch_bounds__(64) void uct_reroot_kernel(int n_roots, int A, int cap_old, int cap_new,
                                                         const UctNode *__restrict__ old_trees, UctNode *__restrict__ new_trees,
@@ -1201,6 +1217,29 @@ int mp_uct_reset_tree(mp_ctx *ctx)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
     ctx->tree.armed = false;
+    return MP_OK;
+}
+
+int mp_uct_path_count(mp_ctx *ctx, int32_t root, const int32_t *actions, int32_t n, int64_t *count)
+{
+    if (!ctx || !count || (n > 0 && !actions)) return fail(MP_ERR_ARG, "mp_uct_path_count: NULL argument");
+    if (ctx->tree.kind != 1) return fail(MP_ERR_ARG, "mp_uct_path_count: no UCT tree on this ctx");
+    if (root < 0 || root >= ctx->tree.n_roots || n < 0) return fail(MP_ERR_ARG, "mp_uct_path_count: root %d / length %d out of range", root, n);
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    UctNode *trees = (UctNode *)ctx->ws[ctx->tree.buf ? WS_TREE2 : WS_TREE0].p;
+    int32_t *d_act = nullptr;
+    int64_t *d_out = nullptr;
+    MP_TRY(ws_get(ctx, WS_IO1, (size_t)(n > 0 ? n : 1), &d_act));
+    MP_TRY(ws_get(ctx, WS_IO8, 1, &d_out));
+    if (n > 0) MP_HIP(hipMemcpyAsync(d_act, actions, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    const int tcap = ctx->tree.cap, A = ctx->tree.A;
+    if (ctx->tree.il == 2) hipLaunchKernelGGL(uct_path_count_kernel<2>, dim3(1), dim3(1), 0, st, trees, root, tcap, A, d_act, n, d_out);
+    else if (ctx->tree.il == 1) hipLaunchKernelGGL(uct_path_count_kernel<1>, dim3(1), dim3(1), 0, st, trees, root, tcap, A, d_act, n, d_out);
+    else hipLaunchKernelGGL(uct_path_count_kernel<0>, dim3(1), dim3(1), 0, st, trees, root, tcap, A, d_act, n, d_out);
+    MP_HIP(hipGetLastError());
+    MP_HIP(hipMemcpyAsync(count, d_out, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    MP_HIP(hipStreamSynchronize(st));
     return MP_OK;
 }
 

@@ -54,6 +54,7 @@ SIGNATURES = {
     "mp_uct_reset_tree": (C.c_int, [_vp]),
     "mp_uct_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
     "mp_uct_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mp_uct_path_count": (C.c_int, [_vp, c_i32, _vp, c_i32, P(C.c_int64)]),
     "mp_model_set_available": (C.c_int, [_vp, _vp]),
     "mp_model_set_episode_rules": (C.c_int, [_vp, c_i32, c_i32]),
     "mp_uct_plan_stochastic": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, c_i32, _vp, _vp,
@@ -570,6 +571,13 @@ class Context(object):
                                             _ptr(t["action"]), _ptr(t["count"]), _ptr(t["value"]),
                                             _ptr(t["first_child"]), _ptr(t["n_children"])))
         return {k: v[:n.value].copy() for k, v in t.items()}
+
+    def uct_path_count(self, root, actions):
+        """Visit count of the node the action sequence reaches in the last plan's tree of `root` (-1: it leaves the tree)."""
+        a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)
+        c = C.c_int64()
+        _check(self._lib.mp_uct_path_count(self._h, int(root), _ptr(a) if a.size else None, int(a.size), C.byref(c)))
+        return int(c.value)
 
     def opd_plan(self, model, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len=64):
         rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
