@@ -507,7 +507,7 @@ def bench_uct_stoch(args, rank, world, local):
     import torch
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
-    n_roots = args.roots or 65536
+    n_roots = args.roots or 262144      # (as the headline workload; 65 536 roots are one wave per SIMD: 0.85 ms)
     episodes, horizon, gamma, temperature = 33, 30, 0.8, 2 / (1 - 0.8)
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
@@ -556,8 +556,8 @@ def bench_uct_stoch(args, rank, world, local):
     k_ms = ctx.last_kernel_ms()[0]
     env_steps = int(d_steps.sum().item())
     total = sum_over_ranks(float(timed), world) / args.steps
-    # algorithmic bytes, measured quantities: per env step the fused 32-byte record of (s, a) (threshold, two successors,
-    # reward, terminal flags); per scored level the |A| children's 16-byte halves {value, count, first}; per path node a
+    # algorithmic bytes, measured quantities: per env step the fused 16-byte record of (s, a) (threshold, two successors,
+    # reward index, terminal flags: this model has 136 distinct rewards); per scored level the |A| children's 16-byte halves {value, count, first}; per path node a
     # 16-byte read-modify-write of that half; per created node both halves (32 B)
     sample = np.unique(np.linspace(0, n_roots - 1, 65).astype(np.int64))
     nodes = sel = 0
@@ -566,7 +566,7 @@ def bench_uct_stoch(args, rank, world, local):
         nodes += len(tr["parent"])
         sel += int(tr["count"][(tr["is_obs"] == 0) & (tr["parent"] >= 0)].sum())        # visits of action nodes = selection steps
     smp_env = float(d_steps[torch.from_numpy(sample).to(dev)].sum().item())
-    bytes_per_step = (32.0 * smp_env + 16.0 * a_ * sel + 2 * 16.0 * (2 * sel + len(sample) * episodes) + 32.0 * nodes) / smp_env
+    bytes_per_step = (16.0 * smp_env + 16.0 * a_ * sel + 2 * 16.0 * (2 * sel + len(sample) * episodes) + 32.0 * nodes) / smp_env
     res = dict(
         metric="rollout env-steps/sec (UCT plan() on a stochastic model, closed loop, budget=1000)", unit="env-steps/s",
         value=total * args.steps / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64",
@@ -577,9 +577,9 @@ def bench_uct_stoch(args, rank, world, local):
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel="uct_stoch_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps,
                       traffic=None, traffic_frac=None,
-                      note="one root per lane, root-major trees (closed-loop node ids do not advance in lock-step); at this "
-                           "batch the texture-address units are 47 % busy and 83 % at 262 144 roots (profiles/"
-                           "r03_uct_stoch_units.txt): the remaining bound is the count of scattered vector-memory instructions"),
+                      note="one root per lane, root-major trees (closed-loop node ids do not advance in lock-step); the texture-"
+                           "address units are 47 % busy at 65 536 roots and 83 % at 262 144 (profiles/r03_uct_stoch_units.txt, "
+                           "before the 16-byte records): the bound is the count of scattered vector-memory instructions"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -682,6 +682,7 @@ int mp_model_free(mp_model *m)
     if (m->NXT) hipFree(m->NXT);
     if (m->thr) hipFree(m->thr);
     if (m->srec) hipFree(m->srec);
+    if (m->srec_rtab) hipFree(m->srec_rtab);
     delete m;
     return MP_OK;
 }

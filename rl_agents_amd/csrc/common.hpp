@@ -136,7 +136,9 @@ struct mp_model {
     uint64_t *thr = nullptr; // dense / sparse models: sampling thresholds ceil(cdf * 2^53) of every row (uct_stoch.hip), lazily built
     uint4 *srec = nullptr;   // sparse models with B <= 4: one fused record per (s, a) -- thresholds, next states, reward, terminal
                              // flags (uct_stoch.hip: an env step is ONE gather), lazily built; 2 (B <= 2) or 4 uint4 each
-    int srec_wb = 0;         // 0 = not looked at yet, 2 / 4 = uint4 per record, -1 = rows too wide (dense rows by binary search)
+    int srec_wb = 0;         // 0 = not looked at yet, 2 / 4 = uint4 per record, -1 = rows too wide (dense rows by binary search),
+                             // 1 = ONE uint4 per record: two successors at most and at most 256 distinct rewards (srec_rtab)
+    double *srec_rtab = nullptr; // srec_wb == 1: the distinct reward values [256] a record's 8-bit index points into
     mp_cartpole_params cp;
 };
 

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -47,7 +48,8 @@ struct StochArgs {
     const int32_t *T;       // deterministic: [S*A]
     const uint64_t *thr;    // dense [S*A][S] / sparse [S*A][B]: ceil(cdf * 2^53)
     const int32_t *nxt;     // sparse: [S*A][B]
-    const uint4 *srec;      // sparse, B <= 4: fused records (WB = 2: 2 uint4 per (s, a), WB = 4: 4), else nullptr
+    const uint4 *srec;      // sparse, B <= 4: fused records (WB = 2: 2 uint4 per (s, a), WB = 4: 4, WB = 1: 1), else nullptr
+    const double *rtab;     // WB = 1: the distinct rewards [256]
     const double *R;        // [S*A]
     const uint8_t *term;    // [S] or nullptr
     const int32_t *root_state, *root_steps;
@@ -163,6 +165,23 @@ __global__ void pack_dense_records(long rows, int A, int W, const double *__rest
     }
 }
 
+// Two successors at most AND at most 256 distinct reward values in the model (grid- and highway-like models have a
+// handful): the record shrinks to ONE uint4, the reward becomes an 8-bit index into a table staged in LDS -- an env step
+// is one 16-byte gather, as in the deterministic kernel, and the count of scattered vector-memory instructions is what
+// bounds this kernel at scale (profiles/r03_uct_stoch_units.txt).
+//   {thr0.lo, thr0.hi (22 bits) | reward index << 22 | terminal[s] << 30, nxt0 | terminal[nxt0] << 31, nxt1 | terminal[nxt1] << 31}
+__global__ void compact_records16(long rows, const uint4 *__restrict__ rec32, const uint8_t *__restrict__ ridx, uint4 *__restrict__ out)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows) return;
+    const uint4 q0 = rec32[i * 2], q1 = rec32[i * 2 + 1];
+    const uint32_t flags = q1.z;
+    // thr0 <= 2^53 (22 bits of high word) or the "never" mark 2^64 - 1, which becomes 2^54 - 1 (still > every k)
+    const uint32_t hi = q0.y > 0x3fffffu ? 0x3fffffu : q0.y;
+    out[i] = make_uint4(q0.x, hi | ((uint32_t)ridx[i] << 22) | ((flags & 1u) << 30), q0.z | (((flags >> 1) & 1u) << 31),
+                        q0.w | (((flags >> 2) & 1u) << 31));
+}
+
 // WB: 0 = any model (deterministic table, dense rows by binary search, sparse rows of any width); 2 / 4 = sparse model through
 // the fused records above.  AT: |A| at compile time (2..8: the children of a node in registers -- one batch of loads, scores
 // computed once, no loop-carried branches), 0 = any |A|.
@@ -184,8 +203,11 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     // wave's chain); counts beyond the tables cannot occur here (a tree lives for one plan), the division is kept anyway
     auto explore = [&](int a, int cnt1) { return cnt1 <= E + 1 ? tpdiv[a * (E + 2) + cnt1] : tp[a] / (double)cnt1; };
     auto inv = [&](int c) { return c <= E ? rcp[c] : 1.0 / (double)c; };
-    PT *path = reinterpret_cast<PT *>(lds_s + ntab) + lane; // entry i of this lane: path[i * 64]
+    constexpr int NRT = WB == 1 ? 256 : 0;
+    double *rtab = lds_s + ntab;                            // [256] WB = 1: the model's distinct rewards
+    PT *path = reinterpret_cast<PT *>(lds_s + ntab + NRT) + lane; // entry i of this lane: path[i * 64]
     for (int i = lane; i < ntab; i += 64) lds_s[i] = p.tab[i];
+    for (int i = lane; i < NRT; i += 64) rtab[i] = p.rtab[i];
     __syncthreads();
     const int r = blockIdx.x * 64 + lane;
     if (r >= p.n_roots) return;
@@ -228,6 +250,19 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         auto env_step = [&](int a, double &reward, bool &terminated, bool &truncated) {
             const long sa = (long)s * A + a;
             int32_t sn;
+            if (WB == 1) {
+                const uint4 q = p.srec[sa];
+                const uint64_t k = eg.next64() >> 11; // Generator.random(): runs while the gather is in flight
+                const bool up = ((((uint64_t)(q.y & 0x3fffffu)) << 32) | q.x) <= k; // searchsorted(cdf, u, 'right')
+                const uint32_t nw = up ? q.w : q.z;
+                reward = rtab[(q.y >> 22) & 0xffu];
+                terminated = p.done_on_next ? (nw >> 31) != 0 : ((q.y >> 30) & 1u) != 0;
+                s = (int32_t)(nw & 0x7fffffffu);
+                st += 1;
+                truncated = p.max_steps > 0 && st >= p.max_steps;
+                ++steps_taken;
+                return;
+            }
             if (WB > 0) {
                 // the draw does not depend on the record: its 128-bit multiply runs while the gather is in flight
                 const uint4 *rp = p.srec + sa * WB;
@@ -546,7 +581,48 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
         else
             hipLaunchKernelGGL(pack_dense_records<4>, grid, block, 0, st, rows, A, W, model->P, model->R, model->term, model->srec);
         MP_HIP(hipGetLastError());
+        // two successors at most: one uint4 per record when the model has at most 256 distinct rewards (MP_UCT_STOCH_FUSED=2:
+        // keep the 32-byte records -- test hook)
+        if (wb == 2 && !(fz && fz[0] == '2')) {
+            std::vector<double> hr((size_t)rows);
+            MP_HIP(hipMemcpyAsync(hr.data(), model->R, (size_t)rows * sizeof(double), hipMemcpyDeviceToHost, st));
+            MP_HIP(hipStreamSynchronize(st));
+            std::vector<uint64_t> vals;  // distinct bit patterns, in order of first appearance
+            std::unordered_map<uint64_t, int> index_of;
+            std::vector<uint8_t> ridx((size_t)rows);
+            bool few = true;
+            for (long i = 0; i < rows && few; ++i) {
+                uint64_t b;
+                memcpy(&b, &hr[(size_t)i], sizeof(b));
+                auto it = index_of.find(b);
+                if (it == index_of.end()) {
+                    if (vals.size() == 256) { few = false; break; }
+                    it = index_of.emplace(b, (int)vals.size()).first;
+                    vals.push_back(b);
+                }
+                ridx[(size_t)i] = (uint8_t)it->second;
+            }
+            if (few) {
+                std::vector<double> tabv(256, 0.0);
+                for (size_t j = 0; j < vals.size(); ++j) memcpy(&tabv[j], &vals[j], sizeof(double));
+                uint4 *rec16 = nullptr;
+                uint8_t *d_ridx = nullptr;
+                if (hipMalloc(&rec16, (size_t)rows * sizeof(uint4)) != hipSuccess || hipMalloc(&d_ridx, (size_t)rows) != hipSuccess ||
+                    hipMalloc(&model->srec_rtab, 256 * sizeof(double)) != hipSuccess)
+                    return fail(MP_ERR_ALLOC, "mp_uct_plan_stochastic: the compact records");
+                MP_HIP(hipMemcpyAsync(d_ridx, ridx.data(), (size_t)rows, hipMemcpyHostToDevice, st));
+                MP_HIP(hipMemcpyAsync(model->srec_rtab, tabv.data(), 256 * sizeof(double), hipMemcpyHostToDevice, st));
+                hipLaunchKernelGGL(compact_records16, grid, block, 0, st, rows, model->srec, d_ridx, rec16);
+                MP_HIP(hipGetLastError());
+                MP_HIP(hipStreamSynchronize(st)); // (the host vectors and the 32-byte records go away)
+                hipFree(d_ridx);
+                hipFree(model->srec);
+                model->srec = rec16;
+                model->srec_wb = 1;
+            }
+        }
     }
+    const int wbk = wb ? model->srec_wb : 0; // the form the records really have (1: compact)
 
     // per-call tables, computed on the host exactly as Python computes them (see uct_plan_impl)
     const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (size_t)(E + 1) + (size_t)A * (E + 2);
@@ -572,7 +648,7 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
 
     const long cap = 1 + (long)E * ((long)A + (closed_loop ? H : 0));
     const bool p16 = cap <= 65535;
-    const size_t lds = ntab * sizeof(double) + (size_t)(2 * H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
+    const size_t lds = (ntab + (wbk == 1 ? 256 : 0)) * sizeof(double) + (size_t)(2 * H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
 
     StochArgs a;
@@ -582,6 +658,7 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     a.max_plan_len = max_plan_len;
     a.T = model->T; a.thr = model->thr; a.nxt = model->NXT; a.R = model->R; a.term = model->term; a.tab = d_tab;
     a.srec = wb ? model->srec : nullptr;
+    a.rtab = model->srec_rtab;
     MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.hot));
     MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap, &a.cold));
     MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out));
@@ -609,12 +686,12 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
 #define MP_ROW(WBV, PTV) {uct_stoch_kernel<WBV, 0, PTV>, uct_stoch_kernel<WBV, 0, PTV>, uct_stoch_kernel<WBV, 2, PTV>, \
                           uct_stoch_kernel<WBV, 3, PTV>, uct_stoch_kernel<WBV, 4, PTV>, uct_stoch_kernel<WBV, 5, PTV>, \
                           uct_stoch_kernel<WBV, 6, PTV>, uct_stoch_kernel<WBV, 7, PTV>, uct_stoch_kernel<WBV, 8, PTV>}
-        static const kernel_t table16[3][9] = {MP_ROW(0, uint16_t), MP_ROW(2, uint16_t), MP_ROW(4, uint16_t)};
-        static const kernel_t table32[3][9] = {MP_ROW(0, int32_t), MP_ROW(2, int32_t), MP_ROW(4, int32_t)};
+        static const kernel_t table16[4][9] = {MP_ROW(0, uint16_t), MP_ROW(2, uint16_t), MP_ROW(4, uint16_t), MP_ROW(1, uint16_t)};
+        static const kernel_t table32[4][9] = {MP_ROW(0, int32_t), MP_ROW(2, int32_t), MP_ROW(4, int32_t), MP_ROW(1, int32_t)};
 #undef MP_ROW
         const char *ag = getenv("MP_UCT_STOCH_GENERIC_A"); // "1": the loop form of the selection for any |A| -- test hook
         const int at = A >= 2 && A <= 8 && !(ag && ag[0] == '1') ? A : 0;
-        hipLaunchKernelGGL((p16 ? table16 : table32)[wb == 2 ? 1 : wb == 4 ? 2 : 0][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+        hipLaunchKernelGGL((p16 ? table16 : table32)[wbk == 2 ? 1 : wbk == 4 ? 2 : wbk == 1 ? 3 : 0][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
     }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());

@@ -239,12 +239,19 @@ def test_uct_on_stochastic_models_agent(z):
 @pytest.mark.parametrize("mode,closed", [("stochastic", False), ("stochastic", True), ("sparse", False), ("sparse", True),
                                          ("deterministic", True), ("sparse2", True), ("sparse2", False), ("sparse6", True),
                                          ("sparse-unfused", True), ("sparse-many-actions", True), ("sparse-generic-a", True),
-                                         ("dense-few2", True), ("dense-few4", False), ("dense-few4", True)])
+                                         ("dense-few2", True), ("dense-few4", False), ("dense-few4", True),
+                                         ("sparse2-few-rewards", True), ("sparse2-few-rewards", False), ("dense-few2-few-rewards", True),
+                                         ("sparse2-few-rewards-32", True)])
 def test_uct_on_stochastic_models_batch_vs_oracle(ctx, mode, closed, monkeypatch):
     """Seeded batches of 300 roots (ragged last wave), distinct planner AND env generator records per root, a TimeLimit
     and both terminal conventions: plans, values, env steps and generator records equal the oracle's."""
     from oracle import oracle
     from rl_agents_amd.envs import generators
+    few_rewards = "few-rewards" in mode     # at most 256 distinct rewards + two successors: the 16-byte records
+    if mode.endswith("-32"):
+        monkeypatch.setenv("MP_UCT_STOCH_FUSED", "2")       # ... kept at 32 bytes
+        mode = mode[:-3]
+    mode = mode.replace("-few-rewards", "")
     if mode == "stochastic":
         cfg = generators.random_stochastic(90, 4, seed=21, terminal_rate=0.05, concentration=0.1)
     elif mode.startswith("dense-few"):
@@ -270,6 +277,8 @@ def test_uct_on_stochastic_models_batch_vs_oracle(ctx, mode, closed, monkeypatch
         mode = "sparse"
     else:
         cfg = generators.random_deterministic(200, 4, seed=23, terminal_rate=0.05)
+    if few_rewards:
+        cfg = dict(cfg, reward=np.round(cfg["reward"] * 37) / 37)      # 38 values, most of them not exact in binary
     a = cfg["reward"].shape[1]
     n = 300
     g = np.random.Generator(np.random.PCG64(77))
