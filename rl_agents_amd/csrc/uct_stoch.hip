@@ -45,6 +45,7 @@ static_assert(sizeof(SHot) == 16 && sizeof(SCold) == 16, "node halves are one dw
 
 struct StochArgs {
     int n_roots, mode, S, A, W, episodes, horizon, cap, closed_loop, done_on_next, max_steps, max_plan_len;
+    int table_n;            // counts 1..table_n (+1) have entries in the quotient tables of `tab`
     const int32_t *T;       // deterministic: [S*A]
     const uint64_t *thr;    // dense [S*A][S] / sparse [S*A][B]: ceil(cdf * 2^53)
     const int32_t *nxt;     // sparse: [S*A][B]
@@ -196,13 +197,14 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     double *gpow = lds_s;                                   // [H + 1]  gamma ** h
     const uint64_t *rthr = reinterpret_cast<const uint64_t *>(gpow + (H + 1)); // [A] rollout thresholds
     const double *tp = gpow + (H + 1) + A;                  // [A]      temperature * |A| * prior[a]
-    const double *rcp = tp + A;                             // [E + 1]  1.0 / n
-    const double *tpdiv = rcp + (E + 1);                    // [A][E+2] temperature * |A| * prior[a] / n
-    const int ntab = (H + 1) + 2 * A + (E + 1) + A * (E + 2);
+    const int TE = p.table_n;                               // min(E, 512): counts covered by the quotient tables
+    const double *rcp = tp + A;                             // [TE + 1]  1.0 / n
+    const double *tpdiv = rcp + (TE + 1);                   // [A][TE+2] temperature * |A| * prior[a] / n
+    const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
     // host tables instead of f64 divisions (the same correctly rounded quotients; a division is ~40 instructions of a lone
-    // wave's chain); counts beyond the tables cannot occur here (a tree lives for one plan), the division is kept anyway
-    auto explore = [&](int a, int cnt1) { return cnt1 <= E + 1 ? tpdiv[a * (E + 2) + cnt1] : tp[a] / (double)cnt1; };
-    auto inv = [&](int c) { return c <= E ? rcp[c] : 1.0 / (double)c; };
+    // wave's chain); counts beyond the tables (plans of more than 512 episodes) take the IEEE division itself
+    auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
+    auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
     constexpr int NRT = WB == 1 ? 256 : 0;
     double *rtab = lds_s + ntab;                            // [256] WB = 1: the model's distinct rewards
     PT *path = reinterpret_cast<PT *>(lds_s + ntab + NRT) + lane; // entry i of this lane: path[i * 64]
@@ -625,9 +627,10 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     const int wbk = wb ? model->srec_wb : 0; // the form the records really have (1: compact)
 
     // per-call tables, computed on the host exactly as Python computes them (see uct_plan_impl)
-    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (size_t)(E + 1) + (size_t)A * (E + 2);
+    const int TE = E < 512 ? E : 512; // the quotient tables live in LDS: longer plans divide beyond them
+    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (size_t)(TE + 1) + (size_t)A * (TE + 2);
     std::vector<double> tab(ntab);
-    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (E + 1);
+    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (TE + 1);
     for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);
     double acc = 0.0;
     for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }
@@ -638,10 +641,10 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     }
     for (int a = 0; a < A; ++a) tpv[a] = temperature * (double)A * prior_p[a]; // mcts.py:286, left to right
     rcp[0] = 0.0;
-    for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                     // mcts.py:257: 1 / count
+    for (int n = 1; n <= TE; ++n) rcp[n] = 1.0 / (double)n;                    // mcts.py:257: 1 / count
     for (int a = 0; a < A; ++a) {
-        tpdiv[(size_t)a * (E + 2)] = 0.0;
-        for (int n = 1; n <= E + 1; ++n) tpdiv[(size_t)a * (E + 2) + n] = tpv[a] / (double)n; // mcts.py:286: / (count + 1)
+        tpdiv[(size_t)a * (TE + 2)] = 0.0;
+        for (int n = 1; n <= TE + 1; ++n) tpdiv[(size_t)a * (TE + 2) + n] = tpv[a] / (double)n; // mcts.py:286: / (count + 1)
     }
     double *d_tab = nullptr;
     MP_TRY(upload_tables(ctx, 7, tab, &d_tab));
@@ -655,6 +658,7 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     memset(&a, 0, sizeof(a));
     a.n_roots = n_roots; a.mode = mode; a.S = S; a.A = A; a.W = W; a.episodes = E; a.horizon = H; a.cap = (int)cap;
     a.closed_loop = closed_loop ? 1 : 0; a.done_on_next = model->done_on_next; a.max_steps = model->max_steps;
+    a.table_n = TE;
     a.max_plan_len = max_plan_len;
     a.T = model->T; a.thr = model->thr; a.nxt = model->NXT; a.R = model->R; a.term = model->term; a.tab = d_tab;
     a.srec = wb ? model->srec : nullptr;

@@ -317,6 +317,38 @@ def test_uct_on_stochastic_models_batch_vs_oracle(ctx, mode, closed, monkeypatch
         model.close()
 
 
+@pytest.mark.parametrize("closed", [False, True])
+def test_uct_on_stochastic_models_long_plans(ctx, closed):
+    """2 300 episodes: more nodes than a 16-bit path entry can name (the int32 path stack) and visit counts beyond the
+    quotient tables (the kernel's own IEEE divisions) -- against the oracle."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_sparse(120, 4, 2, seed=5, terminal_rate=0.03)
+    n, episodes, horizon = 70, 2300, 25
+    g = np.random.Generator(np.random.PCG64(5))
+    s0 = g.integers(0, 120, size=n).astype(np.int32)
+
+    def records():
+        r = g.integers(0, 2 ** 63, size=(n, 6), dtype=np.int64).astype(np.uint64)
+        r[:, 3] |= np.uint64(1)
+        r[:, 4:] = 0
+        return r
+    rng, erng = records(), records()
+    rng_ref = rng.copy()
+    p = np.ones(4) / 4
+    model = ctx.load_sparse(cfg["transition"], cfg["next"], cfg["reward"], cfg["terminal"])
+    out = ctx.uct_plan_stochastic(model, s0, episodes, horizon, 0.9, 3.0, p, p, rng, env_rng_state=erng, closed_loop=closed,
+                                  max_plan_len=2 * horizon)
+    ref = oracle.uct_plan_stoch_batch("sparse", cfg["transition"], cfg["reward"], cfg["terminal"], s0, episodes, horizon, 0.9, 3.0,
+                                      p, p, rng_ref, erng, next_states=cfg["next"], closed_loop=closed, max_plan_len=2 * horizon,
+                                      n_threads=8)
+    for k in ("plans", "plan_len", "env_steps"):
+        np.testing.assert_array_equal(out[k], ref[k], err_msg=k)
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    model.close()
+
+
 def test_closed_loop_on_a_deterministic_model_through_the_literal_kernel(ctx):
     """Cross-check of round 2's argument (closed loop on a deterministic model = the open-loop statistics + a host-side
     observation layer): the literal kernel -- real observation nodes -- reproduces the reference's closed-loop goldens of
