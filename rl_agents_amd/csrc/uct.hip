@@ -90,6 +90,7 @@ static inline size_t tree_stride_alloc(int lay, long cap, int A) { return (size_
 
 struct UctArgs {
     int n_roots, S, A, episodes, horizon, cap;
+    int table_n; // counts with entries in the quotient tables of `tab` (TE below): min(episodes, what 16 KB of LDS hold)
     int tree_il; // tree layout (TreeRef): 0 root-major, 1 interleaved, 2 group-interleaved
     int done_on_next, max_steps, max_plan_len;
     int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
@@ -99,7 +100,7 @@ struct UctArgs {
     const int32_t *root_state, *root_steps;
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
-    const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[E+1] | tpdiv[A][E+2]
+    const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[TE+1] | tpdiv[A][TE+2]
     uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8): kernel arguments live in SGPRs
     // per-state policies (mp_policy): nullptr / 0 for the state-independent ones
     const double *pol_prior; // [S][pol_stride]
@@ -184,13 +185,14 @@ void uct_kernel(UctArgs p)
     // searchsorted(cdf, u, 'right') = #{a : cdf[a] <= u} = #{a : ceil(cdf[a] * 2^53) <= k}
     const uint64_t *thr = reinterpret_cast<const uint64_t *>(gpow + (H + 1)); // [A]
     double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
-    double *rcp = tp + A;                   // [E + 1]  1.0 / n
-    double *tpdiv = rcp + (E + 1);          // [A][E+2] temperature * |A| * prior[a] / n
-    const int ntab = (H + 1) + 2 * A + (E + 1) + A * (E + 2);
-    // visit counts beyond the tables (trees kept across plans, step_strategy "subtree") take the IEEE division
-    // itself -- the same correctly rounded quotient the host put in the tables
-    auto explore = [&](int a, int cnt1) { return cnt1 <= E + 1 ? tpdiv[a * (E + 2) + cnt1] : tp[a] / (double)cnt1; };
-    auto inv = [&](int c) { return c <= E ? rcp[c] : 1.0 / (double)c; };
+    const int TE = p.table_n;               // counts the quotient tables cover
+    double *rcp = tp + A;                   // [TE + 1]  1.0 / n
+    double *tpdiv = rcp + (TE + 1);         // [A][TE+2] temperature * |A| * prior[a] / n
+    const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
+    // visit counts beyond the tables (trees kept across plans, step_strategy "subtree"; plans of more episodes than the
+    // tables hold) take the IEEE division itself -- the same correctly rounded quotient the host put in the tables
+    auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
+    auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
     int32_t *path_all = reinterpret_cast<int32_t *>(lds_d + ntab); // [H + 1][waves * 64]
     uint16_t *t16 = reinterpret_cast<uint16_t *>(path_all + (H + 1) * nthreads);
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
@@ -804,9 +806,12 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     const long cap = 1 + (long)episodes * A;
 
     // small per-call tables, computed on the host exactly as Python computes them
-    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (E + 1) + (size_t)A * (E + 2);
+    // (the quotient tables live in LDS: 16 KB of them at most; counts beyond take the division in the kernel)
+    const int te_max = (int)(16384 / (sizeof(double) * (size_t)(A + 1)));
+    const int TE = E < te_max ? E : te_max;
+    const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (TE + 1) + (size_t)A * (TE + 2);
     std::vector<double> tab(ntab);
-    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (E + 1);
+    double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (TE + 1);
     for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);                 // gamma ** h
     double acc = 0.0;
     for (int a = 0; a < A; ++a) { acc += pol ? 1.0 : rollout_p[a]; cdf[a] = acc; } // numpy cumsum
@@ -819,18 +824,19 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         memcpy(&cdf[a], &t, sizeof(t));
     }
     rcp[0] = 0.0;
-    for (int n = 1; n <= E; ++n) rcp[n] = 1.0 / (double)n;                         // mcts.py:255  K / count, K = 1
+    for (int n = 1; n <= TE; ++n) rcp[n] = 1.0 / (double)n;                        // mcts.py:255  K / count, K = 1
     for (int a = 0; a < A; ++a) {
         const double tp = temperature * (double)A * (pol ? 0.0 : prior_p[a]);     // mcts.py:286, left to right
         tpv[a] = tp;
-        tpdiv[(size_t)a * (E + 2)] = 0.0;
-        for (int n = 1; n <= E + 1; ++n) tpdiv[(size_t)a * (E + 2) + n] = tp / (double)n; // ... / (count + 1)
+        tpdiv[(size_t)a * (TE + 2)] = 0.0;
+        for (int n = 1; n <= TE + 1; ++n) tpdiv[(size_t)a * (TE + 2) + n] = tp / (double)n; // ... / (count + 1)
     }
     double *d_tab = nullptr;
     MP_TRY(upload_tables(ctx, 1, tab, &d_tab));
 
     UctArgs a;
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.episodes = episodes; a.horizon = horizon; a.cap = (int)cap;
+    a.table_n = TE;
     a.done_on_next = model->done_on_next; a.max_steps = model->max_steps; a.max_plan_len = max_plan_len;
     a.rec = model->rec; a.t16 = model->t16; a.tab = d_tab;
     for (int i = 0; i < 8; ++i) {

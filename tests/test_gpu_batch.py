@@ -77,6 +77,19 @@ def test_uct_batch_preference_policy_truncation_and_next_rule(ctx):
     _cmp_uct(ctx, cfg, 300, 40, 12, 0.95, 3.0, pref, np.ones(4) / 4, seed=4, done_rule="next")
 
 
+@pytest.mark.parametrize("n_actions,episodes", [(5, 5000), (20, 1200)])
+def test_uct_more_episodes_than_the_quotient_tables_hold(ctx, n_actions, episodes):
+    """budget 50 000 at horizon 10: 5 000 episodes -- visit counts far beyond the 16 KB of 1/n and prior/n tables in LDS
+    (the kernel's own IEEE divisions from there on; before round 3's second half such a plan was refused)."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(150, n_actions, seed=3 + n_actions, terminal_rate=0.02)
+    g = np.random.Generator(np.random.PCG64(n_actions))
+    prior = g.random(n_actions) + 0.2
+    prior /= prior.sum()
+    p = np.ones(n_actions) / n_actions
+    _cmp_uct(ctx, cfg, 70, episodes, 10, 0.9, 3.0, prior, p, seed=2)
+
+
 def test_uct_zero_episodes_and_single_root(ctx):
     from rl_agents_amd.envs import generators
     cfg = generators.random_deterministic(50, 3, seed=2)
