@@ -5,13 +5,14 @@
 // What is different from uct.hip (deterministic tables):
 //   * a transition SAMPLES the next state: one double of the env's PCG64 stream, inverse CDF over the row.  The rows are
 //     kept as integer thresholds ceil(cdf * 2^53) (built on the device from the model's probabilities with numpy's
-//     arithmetic: sequential cumsum, one IEEE division by the last element), so a step is a binary search on uint64;
+//     arithmetic: sequential cumsum, one IEEE division by the last element): a step is a binary search on uint64 -- or,
+//     for rows of at most four successors / non-zero entries, ONE gather of a fused record (below);
 //   * every episode steps a deep copy of the env (mcts.py:183), and the copy includes the env's generator: each episode
 //     of a plan starts from the SAME env generator record (a second 48-byte record per root, read-only);
 //   * closed loop: an action node has one child per DISTINCT next state observed after it, created on first visit, in
 //     first-visit order (a linked list: `first` / `next`); the statistics of an observation node are its own.  Nodes are
 //     therefore created at data-dependent moments, ids no longer advance in lock-step across the lanes of a wave: the
-//     trees are root-major, 32-byte nodes with parent links (the export and the oracle walk them literally).
+//     trees are root-major, two 16-byte halves per node with parent links (the export and the oracle walk them literally).
 // One root per lane; all randomness of the planner from its numpy-PCG64 record (pcg64.hpp), bit for bit.
 #include <math.h>
 #include <stdlib.h>
@@ -322,8 +323,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         while (depth < H && fc >= 0 && !terminal) {
             // MCTSNode.selection_strategy (:275-286): value + temperature * len(children) * prior / (count + 1);
             // Node.random_argmax (abstract.py:296-311): exact-equality argmax set, one bounded draw among >= 2 ties
-            int act = 0, act_first = -1, act_c = 0;
-            double act_v = 0.0;
+            int act = 0, act_first = -1;
             if (AT > 0) {
                 SHot c[AR];
 #pragma unroll
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     const bool eq = sc[a] == m;
                     if (eq && !found && pick == 0) {
                         act = a; found = true;
-                        act_first = c[a].first; act_c = c[a].count; act_v = c[a].value;
+                        act_first = c[a].first;
                     }
                     if (eq && !found) --pick;
                 }
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     const SHot c = hot[fc + a];
                     const double sc = c.value + explore(a, c.count + 1);
                     if (sc == m) {
-                        if (pick == 0) { act = a; act_first = c.first; act_c = c.count; act_v = c.value; break; }
+                        if (pick == 0) { act = a; act_first = c.first; break; }
                         --pick;
                     }
                 }
