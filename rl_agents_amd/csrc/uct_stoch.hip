@@ -220,13 +220,17 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     g.load(p.rng + (long)r * 6);
     const int32_t s0 = p.root_state[r], st0 = p.root_steps ? p.root_steps[r] : 0;
     const bool closed = p.closed_loop != 0;
+    // (the cold half of an ACTION node is never written: its key is its position in the sibling group, its parent the node
+    // whose `first` names the group -- the export derives both; only the root and observation nodes carry one)
     auto make = [&](int id, int parent, int key, int obs) {
         SHot h;
         h.value = 0.0; h.count = 0; h.first = -1;
-        SCold c;
-        c.key = key; c.next = -1; c.parent = parent; c.is_obs = obs;
         hot[id] = h;
-        cold[id] = c;
+        if (obs || parent < 0) {
+            SCold c;
+            c.key = key; c.next = -1; c.parent = parent; c.is_obs = obs;
+            cold[id] = c;
+        }
     };
     uint64_t rt[AR]; // the rollout policy's thresholds (wave-uniform)
 #pragma unroll
@@ -449,8 +453,11 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             SHot *nd = hot + (int)path[i * 64];
             const int c = nd->count + 1;
             const double v = nd->value;
-            nd->count = c;
-            nd->value = v + inv(c) * (total - v);
+            const double nv = v + inv(c) * (total - v);
+            // {value, count} as ONE 12-byte store (two stores were two scattered vector-memory instructions)
+            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+            u32x3 w = {(uint32_t)__double2loint(nv), (uint32_t)__double2hiint(nv), (uint32_t)c};
+            *reinterpret_cast<u32x3 *>(nd) = w;
         }
 #ifdef MP_PROFILE
         { const long long c4 = clock64(); t_sel += c1 - c0; t_exp += c2 - c1; t_roll += c3 - c2; t_bak += c4 - c3; }
@@ -736,10 +743,25 @@ int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_
                      hipMemcpyDeviceToHost));
     MP_HIP(hipMemcpy(c.data(), (const SCold *)ctx->ws[WS_TREE2].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SCold),
                      hipMemcpyDeviceToHost));
+    // node types by one pass in creation order (a parent is older than its children): the root and the observation nodes
+    // carry a cold half; an action node's key / parent follow from the sibling group it sits in
+    const int A = ctx->tree.A;
+    const bool closed = ctx->tree.K != 0;
+    std::vector<int32_t> par((size_t)n, -1), ky((size_t)n, -1);
+    std::vector<uint8_t> obs((size_t)n, 0), act((size_t)n, 0);
     for (int i = 0; i < n; ++i) {
-        if (parent) parent[i] = c[i].parent;
-        if (key) key[i] = c[i].key;
-        if (is_obs) is_obs[i] = (uint8_t)c[i].is_obs;
+        const int f = h[i].first;
+        if (f < 0) continue;
+        if (act[i] && closed) { // an action node of a closed-loop tree: its observation children, linked by `next`
+            for (int o = f; o >= 0 && o < n; o = c[o].next) { obs[o] = 1; par[o] = i; ky[o] = c[o].key; }
+        } else {                // root / observation node (open loop: any node): |A| contiguous action children
+            for (int a = 0; a < A && f + a < n; ++a) { act[f + a] = 1; par[f + a] = i; ky[f + a] = a; }
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        if (parent) parent[i] = par[i];
+        if (key) key[i] = ky[i];
+        if (is_obs) is_obs[i] = obs[i];
         if (count) count[i] = h[i].count;
         if (value) value[i] = h[i].value;
     }
