@@ -83,8 +83,12 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 //              low-latency variant.
 // opd_wide_kernel (below): the bounds array lives in HBM/L2 (class-contiguous, so a class re-scan is one coalesced read)
 //              and LDS only holds the window of the closing pass: 8 waves per SIMD instead of 3-4 per CU.  A wave of this
-//              planner is a chain of dependent round trips (argmax -> leaf record -> model record): ten times more
-//              resident roots hide that latency and multiply the batch throughput.
+//              planner is ONE chain of ~300 dependent instructions per expansion (two cross-lane argmaxes of ~345 cycles,
+//              an LDS re-scan, two round trips that hide under them): ten times more resident roots fill the stalls and
+//              multiply the batch throughput.
+// NONNEG: every finite bound is >= +0.0 (gamma in [0, 1), terminal reward >= 0; rewards are range-checked): the reductions
+//              take the zero-fill DPP steps of wave.hpp.  What a lone wave's expansion costs, phase by phase, and what was
+//              tried on it: profiles/r03_opd_pipelining.md.
 template <bool EXPG, bool NONNEG>
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
