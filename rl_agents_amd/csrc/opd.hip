@@ -166,11 +166,17 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             const int cnt = (n_nodes - cls + 63) >> 6; // ids cls, cls + 64, ... < n_nodes
             double ru = ninf;
             int rid = 0x7fffffff;
-            for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip (budget 5000: 79 entries per class)
-                const double u0 = row[t];
-                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
-                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
-                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+            if (T <= 128) { // at most two entries per lane (budget 5000: 79 per class): no loop, both reads unconditional
+                const double u0 = row[lane < cnt ? lane : 0], u1 = row[lane + 64 < cnt ? lane + 64 : 0];
+                if (lane < cnt && u0 > ru) { ru = u0; rid = cls + (lane << 6); }
+                if (lane + 64 < cnt && u1 > ru) { ru = u1; rid = cls + ((lane + 64) << 6); }
+            } else {
+                for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip
+                    const double u0 = row[t];
+                    const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                    if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                    if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+                }
             }
             // The leaf's record has had the scan's LDS round trip to arrive: request the model records of its |A| actions
             // NOW, so that they fly under the reduction below (every lane loads -- lanes >= |A| the last action's record,
@@ -467,11 +473,17 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
             const int cnt = (n_nodes - cls + 63) >> 6;
             double ru = ninf;
             int rid = 0x7fffffff;
-            for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip (budget 5000: 79 entries per class)
-                const double u0 = row[t];
-                const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
-                if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
-                if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+            if (T <= 128) { // at most two entries per lane (budget 5000: 79 per class): no loop, both reads unconditional
+                const double u0 = row[lane < cnt ? lane : 0], u1 = row[lane + 64 < cnt ? lane + 64 : 0];
+                if (lane < cnt && u0 > ru) { ru = u0; rid = cls + (lane << 6); }
+                if (lane + 64 < cnt && u1 > ru) { ru = u1; rid = cls + ((lane + 64) << 6); }
+            } else {
+                for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip
+                    const double u0 = row[t];
+                    const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
+                    if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
+                    if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+                }
             }
             if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }

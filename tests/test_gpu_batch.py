@@ -169,7 +169,7 @@ def test_opd_budget_beyond_lds(ctx):
 
 @pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
 @pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (13, 1300), (20, 2000),
-                                              (64, 640)])
+                                              (64, 640), (5, 10000)])     # (the last: more than 128 entries per class)
 def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     from rl_agents_amd.envs import generators
     monkeypatch.setenv("MP_OPD_MODEL", variant)
