@@ -4,6 +4,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "common.hpp"
@@ -238,6 +240,19 @@ extern "C" {
 const char *mp_last_error(void) { return g_err.c_str(); }
 int mp_abi_version(void) { return MP_ABI_VERSION; }
 
+extern "C++" {
+namespace {
+std::mutex g_ctx_mutex;
+std::set<const mp_ctx *> g_live_ctx;
+} // namespace
+
+bool mp_ctx_alive(const mp_ctx *ctx)
+{
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    return g_live_ctx.count(ctx) != 0;
+}
+} // extern "C++"
+
 int mp_ctx_create(int device, void *stream, mp_ctx **out)
 {
     if (!out) return fail(MP_ERR_ARG, "mp_ctx_create: out is NULL");
@@ -264,6 +279,7 @@ int mp_ctx_create(int device, void *stream, mp_ctx **out)
         delete ctx;
         return fail(MP_ERR_HIP, "hipEventCreate failed");
     }
+    { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_live_ctx.insert(ctx); }
     *out = ctx;
     return MP_OK;
 }
@@ -402,6 +418,7 @@ uint64_t *mp_rng_device_ptr(mp_rng *rng, int32_t first)
 int mp_ctx_destroy(mp_ctx *ctx)
 {
     if (!ctx) return MP_OK;
+    { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_live_ctx.erase(ctx); }
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (int i = 0; i < 8; ++i) {
@@ -412,6 +429,7 @@ int mp_ctx_destroy(mp_ctx *ctx)
     if (ctx->vi_graph_exec) hipGraphExecDestroy((hipGraphExec_t)ctx->vi_graph_exec);
     for (auto &b : ctx->ws)
         if (b.p) hipFree(b.p);
+    for (auto &b : ctx->block_cache) hipFree(b.p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);

@@ -96,7 +96,47 @@ struct mp_ctx {
     // root states from / write results to them directly (zero-copy: no hipMemcpy call at all on the host-array path)
     struct Pinned { const char *host; char *dev; size_t bytes; };
     std::vector<Pinned> pinned;
+    // Device blocks of planner objects that come and go on this ctx (mp_saopd_create / _free): a freed block is kept -- at
+    // most kBlockCacheBytes of them -- and handed to the next allocation of the same size.  hipFree synchronises the device
+    // and costs ~0.2 ms a call; a batch of state-aware planners is twenty blocks.  Every user of the blocks works on the
+    // ctx's stream, so a block that is handed out again is reused in stream order.
+    struct Block { void *p; size_t bytes; };
+    std::vector<Block> block_cache;
+    size_t block_cache_bytes = 0;
 };
+
+constexpr size_t kBlockCacheBytes = (size_t)8 << 30;
+
+// hipMalloc through the ctx's block cache (exact size match)
+inline hipError_t ctx_block_alloc(mp_ctx *ctx, void **out, size_t bytes)
+{
+    for (size_t i = 0; i < ctx->block_cache.size(); ++i)
+        if (ctx->block_cache[i].bytes == bytes) {
+            *out = ctx->block_cache[i].p;
+            ctx->block_cache_bytes -= bytes;
+            ctx->block_cache[i] = ctx->block_cache.back();
+            ctx->block_cache.pop_back();
+            return hipSuccess;
+        }
+    return hipMalloc(out, bytes);
+}
+template <typename T>
+inline hipError_t ctx_block_alloc(mp_ctx *ctx, T **out, size_t bytes) { return ctx_block_alloc(ctx, reinterpret_cast<void **>(out), bytes); }
+
+// is this ctx still alive?  (api.hip keeps the set of live contexts: an object may outlive the ctx it was made on)
+bool mp_ctx_alive(const mp_ctx *ctx);
+
+// back into the cache, or hipFree when the cache is full or the ctx is gone
+inline void ctx_block_release(mp_ctx *ctx, void *p, size_t bytes)
+{
+    if (!p) return;
+    if (ctx && bytes && mp_ctx_alive(ctx) && ctx->block_cache_bytes + bytes <= kBlockCacheBytes && ctx->block_cache.size() < 256) {
+        ctx->block_cache.push_back({p, bytes});
+        ctx->block_cache_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
 
 // device-resident numpy-PCG64 generator records of a batch of roots
 struct mp_rng {

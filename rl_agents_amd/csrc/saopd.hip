@@ -107,6 +107,7 @@ struct mp_saopd {
     double *snap_sv = nullptr;
     int32_t *snap_head = nullptr, *snap_tail = nullptr, *snap_stamp = nullptr, *overflow = nullptr;
     uint64_t *snap_rng = nullptr;
+    std::vector<mp_ctx::Block> blocks; // every device block of this batch, with its size: they go back to the ctx's block cache
     int wave = 0;       // 1: one planner per wavefront, planner-major arrays ([planner][node], [planner][state],
                         //    [planner][slot]); 0: one planner per lane, node-major arrays
     // element (row i, planner r) of a node array = i * node_si + r * node_sr, likewise states and queue slots
@@ -1293,11 +1294,35 @@ __global__ __launch_bounds__(64) void saopd_fix_tails_kernel(int n, int S, long 
     if (t >= 0) node[(long)t * node_si + r * node_sr].next_same = -1;
 }
 
+// device blocks of a planner batch: through the ctx's block cache (common.hpp), remembered with their sizes
 template <typename T>
-static int grow_rows(T **buf, size_t used_rows, size_t old_cap, size_t new_cap, size_t n, bool planner_major, hipStream_t st)
+static hipError_t sa_alloc(mp_saopd *pl, T **out, size_t bytes)
+{
+    void *p = nullptr;
+    const hipError_t e = ctx_block_alloc(pl->ctx, &p, bytes);
+    if (e != hipSuccess) return e;
+    pl->blocks.push_back({p, bytes});
+    *out = static_cast<T *>(p);
+    return hipSuccess;
+}
+static void sa_release(mp_saopd *pl, void *p)
+{
+    if (!p) return;
+    for (size_t i = 0; i < pl->blocks.size(); ++i)
+        if (pl->blocks[i].p == p) {
+            ctx_block_release(pl->ctx, p, pl->blocks[i].bytes);
+            pl->blocks[i] = pl->blocks.back();
+            pl->blocks.pop_back();
+            return;
+        }
+    (void)hipFree(p);
+}
+
+template <typename T>
+static int grow_rows(mp_saopd *pl, T **buf, size_t used_rows, size_t old_cap, size_t new_cap, size_t n, bool planner_major, hipStream_t st)
 {
     T *nw = nullptr;
-    MP_HIP(hipMalloc(&nw, new_cap * n * sizeof(T)));
+    MP_HIP(sa_alloc(pl, &nw, new_cap * n * sizeof(T)));
     if (*buf) {
         if (planner_major) { // [planner][row]: every planner's prefix moves to its new pitch
             if (used_rows)
@@ -1307,7 +1332,7 @@ static int grow_rows(T **buf, size_t used_rows, size_t old_cap, size_t new_cap, 
             MP_HIP(hipMemcpyAsync(nw, *buf, used_rows * n * sizeof(T), hipMemcpyDeviceToDevice, st));
         }
         MP_HIP(hipStreamSynchronize(st));
-        MP_HIP(hipFree(*buf));
+        sa_release(pl, *buf);
     }
     *buf = nw;
     return MP_OK;
@@ -1334,16 +1359,16 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
     pl->wave = !(force && force[0] == 'l');
     if (pl->wave && model->A > 64) pl->wave = 0;
     const size_t sn = (size_t)pl->S * pl->n;
-    if (hipMalloc(&pl->sv, sn * 8) != hipSuccess || hipMalloc(&pl->head, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->tail, sn * 4) != hipSuccess || hipMalloc(&pl->stamp, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->snap_sv, sn * 8) != hipSuccess || hipMalloc(&pl->snap_head, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->snap_tail, sn * 4) != hipSuccess || hipMalloc(&pl->snap_stamp, sn * 4) != hipSuccess ||
-        hipMalloc(&pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || hipMalloc(&pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess ||
-        hipMalloc(&pl->lstate, sn * 16) != hipSuccess) {
+    if (sa_alloc(pl, &pl->sv, sn * 8) != hipSuccess || sa_alloc(pl, &pl->head, sn * 4) != hipSuccess ||
+        sa_alloc(pl, &pl->tail, sn * 4) != hipSuccess || sa_alloc(pl, &pl->stamp, sn * 4) != hipSuccess ||
+        sa_alloc(pl, &pl->snap_sv, sn * 8) != hipSuccess || sa_alloc(pl, &pl->snap_head, sn * 4) != hipSuccess ||
+        sa_alloc(pl, &pl->snap_tail, sn * 4) != hipSuccess || sa_alloc(pl, &pl->snap_stamp, sn * 4) != hipSuccess ||
+        sa_alloc(pl, &pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || sa_alloc(pl, &pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess ||
+        sa_alloc(pl, &pl->lstate, sn * 16) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
     }
-    if (hipMemset(pl->overflow, 0, 4 * (size_t)(1 + pl->n)) != hipSuccess) {
+    if (hipMemsetAsync(pl->overflow, 0, 4 * (size_t)(1 + pl->n), ctx->stream) != hipSuccess) { // (stream order: the block may be a recycled one)
         mp_saopd_free(pl);
         return fail(MP_ERR_HIP, "mp_saopd_create: hipMemset failed");
     }
@@ -1354,10 +1379,9 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
 int mp_saopd_free(mp_saopd *pl)
 {
     if (!pl) return MP_OK;
-    void *bufs[] = {pl->node, pl->state, pl->parent, pl->first_child, pl->reward, pl->done, pl->oldlive, pl->lstate, pl->lpool, pl->sv, pl->head, pl->tail, pl->queue,
-                    pl->stamp, pl->snap_sv, pl->snap_head, pl->snap_tail, pl->snap_stamp, pl->snap_rng, pl->overflow};
-    for (void *b : bufs)
-        if (b) (void)hipFree(b);
+    // (a batch whose ctx is gone cannot recycle: the ctx destroys its cache; planners are freed before their ctx)
+    for (const auto &b : pl->blocks) ctx_block_release(pl->ctx, b.p, b.bytes);
+    pl->blocks.clear();
     delete pl;
     return MP_OK;
 }
@@ -1392,8 +1416,8 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         if (const char *e = getenv("MP_SAOPD_QUEUE")) { want = atol(e); q = 2; }
         while (q < want && q < (1 << 28)) q <<= 1;
         if (q > pl->qcap) {
-            if (pl->queue) { MP_HIP(hipStreamSynchronize(ctx->stream)); MP_HIP(hipFree(pl->queue)); pl->queue = nullptr; }
-            if (hipMalloc(&pl->queue, (size_t)pl->n * q * 4) != hipSuccess)
+            if (pl->queue) { MP_HIP(hipStreamSynchronize(ctx->stream)); sa_release(pl, pl->queue); pl->queue = nullptr; }
+            if (sa_alloc(pl, &pl->queue, (size_t)pl->n * q * 4) != hipSuccess)
                 return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", (size_t)pl->n * q * 4);
             pl->qcap = q;
         }
@@ -1405,21 +1429,21 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         const int new_cap = need + (need - pl->cap < 4096 ? need / 2 : 0); // some slack for the following plans
         const size_t o = (size_t)pl->n_nodes, oc = (size_t)pl->cap;
         const bool pm = pl->wave != 0;
-        MP_TRY(grow_rows(&pl->node, o, oc, new_cap, n, pm, st));
-        MP_TRY(grow_rows(&pl->state, o, oc, new_cap, n, pm, st));
-        MP_TRY(grow_rows(&pl->parent, o, oc, new_cap, n, pm, st));
-        MP_TRY(grow_rows(&pl->first_child, o, oc, new_cap, n, pm, st));
-        MP_TRY(grow_rows(&pl->reward, o, oc, new_cap, n, pm, st));
-        MP_TRY(grow_rows(&pl->done, o, oc, new_cap, n, pm, st));
-        MP_TRY(grow_rows(&pl->oldlive, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->node, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->state, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->parent, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->first_child, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->reward, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->done, o, oc, new_cap, n, pm, st));
+        MP_TRY(grow_rows(pl, &pl->oldlive, o, oc, new_cap, n, pm, st));
         pl->cap = new_cap;
     }
     {   // chunk pool: at most one partly filled chunk per non-empty state, contents rebuilt by every plan (nothing to keep)
         const long states = pl->S < pl->cap ? pl->S : pl->cap;
         const long want = 16L * (states + pl->cap / 15 + 2);
         if (want > pl->pool_ints) {
-            if (pl->lpool) { MP_HIP(hipStreamSynchronize(st)); MP_HIP(hipFree(pl->lpool)); pl->lpool = nullptr; }
-            if (hipMalloc(&pl->lpool, (size_t)n * want * 4) != hipSuccess)
+            if (pl->lpool) { MP_HIP(hipStreamSynchronize(st)); sa_release(pl, pl->lpool); pl->lpool = nullptr; }
+            if (sa_alloc(pl, &pl->lpool, (size_t)n * want * 4) != hipSuccess)
                 return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the state-list chunks", (size_t)n * want * 4);
             pl->pool_ints = want;
         }
@@ -1554,9 +1578,9 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
                 break;
             }
             // roll back and run again with a queue four times as large
-            MP_HIP(hipFree(pl->queue));
+            sa_release(pl, pl->queue);
             pl->queue = nullptr;
-            if (hipMalloc(&pl->queue, bigger) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", bigger);
+            if (sa_alloc(pl, &pl->queue, bigger) != hipSuccess) return fail(MP_ERR_ALLOC, "mp_saopd_plan: %zu B for the backup queues", bigger);
             pl->qcap *= 4;
             a.queue = pl->queue; a.qcap = pl->qcap;
             a.scap = lane_scratch();
