@@ -209,3 +209,39 @@ def test_device_rng_with_the_other_planners(ctx):
     pin.close()
     dev.close()
     model.close()
+
+
+def test_planner_blocks_are_recycled_and_survive_their_context():
+    """The device blocks of a planner batch go back to the ctx's block cache at close() and serve the next batch of the same
+    shape (same results, whatever the recycled memory holds); a batch that outlives its context is still freed cleanly."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    cfg = generators.gridworld()
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    n = 130
+    s0 = (np.arange(n) * 7 % r.shape[0]).astype(np.int32)
+    rng0 = np.zeros((n, 6), np.uint64)
+    rng0[:, 0] = np.arange(n) + 11
+    rng0[:, 1] = 999
+    rng0[:, 3] = 1
+    c = native.Context(0)
+    model = c.load_table(t, r, term)
+    outs = []
+    for _ in range(3):                                  # the second and third batch run on recycled blocks
+        pl = native.StateAwarePlanners(c, model, n)
+        rng = rng0.copy()
+        outs.append((pl.plan(s0, 200, 0.8, 0.0, rng, max_plan_len=12), rng))
+        pl.close()
+    for out, rng in outs[1:]:
+        for k in ("plans", "plan_len", "env_steps", "updates", "status"):
+            np.testing.assert_array_equal(out[k], outs[0][0][k], err_msg=k)
+        np.testing.assert_array_equal(rng, outs[0][1])
+    rng = rng0.copy()
+    ref = oracle.saopd_plan_batch(t, r, term, s0, 200, 0.8, 0.0, rng, max_plan_len=12)
+    np.testing.assert_array_equal(outs[0][0]["plans"], ref["plans"])
+    np.testing.assert_array_equal(outs[0][0]["updates"], ref["updates"])
+    late = native.StateAwarePlanners(c, model, n)       # outlives the context
+    model.close()
+    c.close()
+    late.close()
