@@ -238,6 +238,13 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     make(0, -1, -1, 0); // mcts.py:129-130 reset()
     int n_nodes = 1;
     long steps_taken = 0;
+    // statistics of the first NK path nodes below the root as the descent read them (nobody writes them in between): their
+    // backup needs no load (registers, statically indexed -- a load per path node is a scattered vector-memory instruction)
+    constexpr int NK = 6;
+    double kv[NK];
+    int kc[NK];
+#pragma unroll
+    for (int q = 0; q < NK; ++q) { kv[q] = 0.0; kc[q] = 0; }
     double root_v = 0.0; // the root's statistics live in registers for the plan (every episode reads and updates them)
     int root_c = 0, root_first = -1;
 #ifdef MP_PROFILE
@@ -327,7 +334,8 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         while (depth < H && fc >= 0 && !terminal) {
             // MCTSNode.selection_strategy (:275-286): value + temperature * len(children) * prior / (count + 1);
             // Node.random_argmax (abstract.py:296-311): exact-equality argmax set, one bounded draw among >= 2 ties
-            int act = 0, act_first = -1;
+            int act = 0, act_first = -1, act_c = 0;
+            double act_v = 0.0;
             if (AT > 0) {
                 SHot c[AR];
 #pragma unroll
@@ -348,7 +356,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     const bool eq = sc[a] == m;
                     if (eq && !found && pick == 0) {
                         act = a; found = true;
-                        act_first = c[a].first;
+                        act_first = c[a].first; act_c = c[a].count; act_v = c[a].value;
                     }
                     if (eq && !found) --pick;
                 }
@@ -365,7 +373,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     const SHot c = hot[fc + a];
                     const double sc = c.value + explore(a, c.count + 1);
                     if (sc == m) {
-                        if (pick == 0) { act = a; act_first = c.first; break; }
+                        if (pick == 0) { act = a; act_first = c.first; act_c = c.count; act_v = c.value; break; }
                         --pick;
                     }
                 }
@@ -382,6 +390,9 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             env_step(act, reward, terminal, trunc);
             total += gpow[depth] * reward;
             node = fc + act;
+#pragma unroll
+            for (int q = 0; q < NK; ++q)
+                if (plen == q + 1) { kv[q] = act_v; kc[q] = act_c; }
             path[(plen++) * 64] = (PT)node;
             fc = act_first;
             if (closed) { // get_child(action, observation): the child keyed by str(observation), made on first visit
@@ -398,6 +409,9 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     oh.value = 0.0; oh.count = 0; oh.first = -1;
                 }
                 node = o;
+#pragma unroll
+                for (int q = 0; q < NK; ++q)
+                    if (plen == q + 1) { kv[q] = oh.value; kc[q] = oh.count; }
                 path[(plen++) * 64] = (PT)node;
                 fc = oh.first;
             }
@@ -449,13 +463,22 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             root_c = c;
             root_v = root_v + inv(c) * (total - root_v);
         }
-        for (int i = 1; i < plen; ++i) {
+        typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+#pragma unroll
+        for (int q = 0; q < NK; ++q)
+            if (q + 1 < plen) {
+                SHot *nd = hot + (int)path[(q + 1) * 64];
+                const int c = kc[q] + 1;
+                const double nv = kv[q] + inv(c) * (total - kv[q]);
+                u32x3 w = {(uint32_t)__double2loint(nv), (uint32_t)__double2hiint(nv), (uint32_t)c};
+                *reinterpret_cast<u32x3 *>(nd) = w;
+            }
+        for (int i = NK + 1; i < plen; ++i) {
             SHot *nd = hot + (int)path[i * 64];
             const int c = nd->count + 1;
             const double v = nd->value;
             const double nv = v + inv(c) * (total - v);
             // {value, count} as ONE 12-byte store (two stores were two scattered vector-memory instructions)
-            typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
             u32x3 w = {(uint32_t)__double2loint(nv), (uint32_t)__double2hiint(nv), (uint32_t)c};
             *reinterpret_cast<u32x3 *>(nd) = w;
         }
