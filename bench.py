@@ -8,9 +8,18 @@ Default workload = the BASELINE.json headline: MCTS/UCT on a highway-shaped fini
 A "step" is one batched plan() call over all roots of this rank (inputs already in HBM).
 `value` = environment transitions executed inside plan() by ALL ranks / wall time (max over ranks).
 
-Multi-GPU (driver launches `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
-roots are sharded over ranks with no data-path collective (weak scaling: 4096 roots per GPU); the
-only exchange is one RCCL all_gather of the per-root results (first action, root value) per step.
+Multi-GPU: `python bench.py --gpus N` launches its own N ranks (one per GPU, `python -m torch.distributed.run` on
+127.0.0.1) when it is not already running under a launcher; the driver's own `torch.distributed.run ... bench.py --gpus N`
+form works unchanged.  A run whose process group does not have exactly --gpus ranks exits non-zero.  Roots are sharded
+over ranks with no data-path collective (weak scaling: the same roots per GPU); the only exchange is ONE RCCL
+all_gather_into_tensor of the packed per-root results per step -- the PRODUCT's sharded path
+(rl_agents_amd.distributed.ShardedDevicePlan: agent -> planner -> mp_uct_plan -> mp_pack_rows -> all_gather ->
+mp_unpack_rows, nothing through the host), cross-checked inside the run: rank 0 re-plans a sample of ANOTHER rank's roots
+and compares it with what the gather delivered (`ranks.cross_check`).
+
+The default run (headline workload, one GPU) also runs every other workload of the path for a bounded slice and attaches
+`workloads: {name: {value, kernel_ms, frac, traffic_frac, parity_sample}}` to the one JSON line; `parity_sample` replays a
+sample of the timed launch's own roots (or three sweeps) through the CPU oracle.
 """
 import argparse
 import json
@@ -107,6 +116,8 @@ def parse():
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
+    ap.add_argument("--headline-only", action="store_true", help="skip the bounded slices of the other workloads")
+    ap.add_argument("--no-parity-sample", action="store_true", help="skip the oracle replay of a sample of the timed launch")
     return ap.parse_args()
 
 
@@ -123,18 +134,57 @@ def host_cores():
     return n
 
 
+def visible_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` outside a launcher: become the launcher -- N ranks of this very command line under
+    torch.distributed.run on 127.0.0.1 (one process per GPU, RCCL) -- and return its exit code.  On a box with fewer
+    than N GPUs the ranks share device 0 over a gloo group (RCCL refuses two ranks per device): a DRY RUN of the N > 1
+    code path, flagged in the JSON line (`ranks.dry_run_same_device`), never a scaling measurement."""
+    import socket
+    import subprocess
+    n_dev = visible_devices()
+    env = dict(os.environ)
+    if n_dev < args.gpus:
+        print("bench.py: --gpus {} but {} device(s) visible: DRY RUN with all ranks on device 0 (gloo group); not a "
+              "scaling measurement".format(args.gpus, n_dev), file=sys.stderr)
+        env["BENCH_SAME_DEVICE"] = "1"
+        env.setdefault("BENCH_BACKEND", "gloo")
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def dist_setup(n_gpus):
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != n_gpus:
+        # a SCALE line must be what it says: refuse rather than print a 1-rank number labelled N
+        print("bench.py: --gpus {} but the process group has WORLD_SIZE {}: refusing to run".format(n_gpus, world),
+              file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        # BENCH_SAME_DEVICE=1 BENCH_BACKEND=gloo: dry run of the N > 1 code path on a box with a single GPU
+        # BENCH_SAME_DEVICE=1 (set by self_launch on a box with fewer GPUs than ranks): dry run on device 0, gloo
         if os.environ.get("BENCH_SAME_DEVICE"):
             local = 0
+            os.environ["BENCH_LAUNCH_LOCAL_RANK"] = os.environ.get("LOCAL_RANK", "0")
+            os.environ["LOCAL_RANK"] = "0"      # the package's process-wide context follows LOCAL_RANK
+            os.environ.setdefault("BENCH_BACKEND", "gloo")
+        elif local >= visible_devices():
+            print("bench.py: rank {} has no device {} ({} visible)".format(rank, local, visible_devices()), file=sys.stderr)
+            sys.exit(2)
         torch.cuda.set_device(local)
         backend = os.environ.get("BENCH_BACKEND", "nccl")       # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -144,8 +194,6 @@ def dist_setup(n_gpus):
     else:
         torch.cuda.set_device(0)
         local = 0
-    if world != n_gpus and rank == 0:
-        print("warning: --gpus {} but WORLD_SIZE {}".format(n_gpus, world), file=sys.stderr)
     return rank, world, local
 
 
@@ -155,7 +203,7 @@ def ranks_record(rank, world, local):
     ranks all sat on one GPU (BENCH_SAME_DEVICE dry runs) is visible as such."""
     import torch
     prop = torch.cuda.get_device_properties(local)
-    mine = dict(rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), device_index=local, device_name=prop.name,
+    mine = dict(rank=rank, local_rank=int(os.environ.get("BENCH_LAUNCH_LOCAL_RANK", os.environ.get("LOCAL_RANK", "0"))), device_index=local, device_name=prop.name,
                 pci_bus_id=getattr(prop, "pci_bus_id", None), uuid=str(getattr(prop, "uuid", "")) or None,
                 pid=os.getpid())
     if world == 1:
@@ -164,7 +212,10 @@ def ranks_record(rank, world, local):
     everyone = [None] * world
     dist.all_gather_object(everyone, mine)
     distinct = len({(d["device_index"], d["pci_bus_id"], d["uuid"]) for d in everyone})
-    return dict(ranks_seen=dist.get_world_size(), backend=dist.get_backend(), devices=everyone, distinct_devices=distinct)
+    rec = dict(ranks_seen=dist.get_world_size(), backend=dist.get_backend(), devices=everyone, distinct_devices=distinct)
+    if distinct < world:
+        rec["dry_run_same_device"] = True
+    return rec
 
 
 def barrier(world):
@@ -208,11 +259,26 @@ def seed_states(global_ids, base_seed=0):
 
 
 # ---------------------------------------------------------------------------------------------
+PARITY_ROOTS = 64
+
+
+def sample_rows(n, k=PARITY_ROOTS):
+    """k indices spread over a batch of n (first and last wavefront included)."""
+    return np.unique(np.linspace(0, n - 1, min(k, n)).astype(np.int64))
+
+
+def parity_record(ok, what, **extra):
+    return dict(extra, result="ok" if ok else "MISMATCH", sample=what)
+
+
 def bench_uct(args, rank, world, local, with_prior=False):
-    """with_prior: MCTSWithPriorPolicyAgent's path -- value iteration on the device, its Boltzmann
+    """Headline.  The N-GPU form times the PRODUCT's sharded path: an MCTSAgent built by agent_factory on a FiniteMDPEnv
+    of the table, rl_agents_amd.distributed.ShardedDevicePlan (roots sharded by global index, the planner's asynchronous
+    batched launch, mp_pack_rows -> one all_gather_into_tensor -> mp_unpack_rows on a side stream).
+    with_prior: MCTSWithPriorPolicyAgent's path -- value iteration on the device, its Boltzmann
     distribution as per-state prior and rollout policy (tables built and uploaded outside the timed region)."""
     import torch
-    from rl_agents_amd import native
+    from rl_agents_amd import native, runtime
     from rl_agents_amd.envs import generators
     n_roots = args.roots or 262144
     episodes, horizon, gamma = 33, 30, 0.8
@@ -220,60 +286,78 @@ def bench_uct(args, rank, world, local, with_prior=False):
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
     s_, a_ = r.shape
-    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
-    model = ctx.load_table(t, r, term)
     gids = np.arange(rank * n_roots, (rank + 1) * n_roots)
     roots_rng = np.random.Generator(np.random.PCG64(12345))
     non_term = np.flatnonzero(~np.asarray(term))
     all_roots = roots_rng.choice(non_term, size=world * n_roots).astype(np.int32)
     s0 = all_roots[gids]
-    rng0 = seed_states(gids)
     dev = torch.device("cuda", local)
     d_s0 = torch.from_numpy(s0).to(dev)
-    d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)   # raw 64-bit words
     mpl = 8
-    d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
-    d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
-    d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
-    d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
     p = np.ones(a_) / a_
-    policy, tables = None, None
+    policy, tables, sp, cross = None, None, None, None
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
     if with_prior:
+        ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+        model = ctx.load_table(t, r, term)
+        rng0 = seed_states(gids)
+        d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)   # raw 64-bit words
+        d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
+        d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
+        d_val = torch.empty(n_roots, dtype=torch.float64, device=dev)
+        d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
         q, _ = ctx.vi_solve(model, 0.95, 200)
         z = np.exp((q - q.max(axis=1, keepdims=True)) / 0.3)
         tables = z / z.sum(axis=1, keepdims=True)
         policy = ctx.load_policy(model, tables, tables)
         p = tables                                           # the oracle takes the [S, A] tables in p's place
-    # N > 1: the path's only exchange is the all_gather of the per-root results.  Nothing in the next plan depends
-    # on it, so it runs on its own stream, double-buffered, behind the next launch (the closing barrier of the timed
-    # region waits for the last one).
-    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
-    if world > 1:
-        import torch.distributed as dist
-        comm = torch.cuda.Stream(device=dev)
-        d_vals = [d_val, torch.empty_like(d_val)]
-        gathered = [torch.empty(world * n_roots, dtype=torch.float64, device=dev) for _ in range(2)]
-        kernel_done = [torch.cuda.Event(), torch.cuda.Event()]
-        gather_done = [None, None]
-    turn = [0]
 
-    def step():
-        b = turn[0] & 1
-        turn[0] += 1
-        main = torch.cuda.current_stream()
-        if world > 1 and gather_done[b] is not None:
-            main.wait_event(gather_done[b])              # buffer b is free again
-        ctx.uct_plan_device(model, n_roots, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
-                            plans=d_plans, plan_len=d_len, root_value=d_vals[b] if world > 1 else d_val, env_steps=d_steps,
-                            policy=policy)
-        d_total.add_(d_steps.sum())
-        if world > 1:
-            kernel_done[b].record(main)
-            with torch.cuda.stream(comm):
-                comm.wait_event(kernel_done[b])
-                dist.all_gather_into_tensor(gathered[b], d_vals[b])   # per-root results to every rank
-                gather_done[b] = torch.cuda.Event()
-                gather_done[b].record(comm)
+        def step():
+            ctx.uct_plan_device(model, n_roots, d_s0, episodes, horizon, gamma, temperature, p, p, d_rng, mpl,
+                                plans=d_plans, plan_len=d_len, root_value=d_val, env_steps=d_steps, policy=policy)
+            d_total.add_(d_steps.sum())
+    else:
+        from rl_agents_amd.agents.common.factory import agent_factory
+        from rl_agents_amd.distributed import ShardedDevicePlan
+        from rl_agents_amd.envs import FiniteMDPEnv
+        # the package's process-wide context enqueues on this bench's stream (torch ops, RCCL and kernels: one order)
+        ctx = runtime.get_context(local)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        env = FiniteMDPEnv(dict(mode="deterministic", transition=t, reward=r, terminal=np.asarray(term).astype(int)))
+        env.reset()
+        agent = agent_factory(env, {"__class__": "<class 'rl_agents_amd.agents.tree_search.mcts.MCTSAgent'>",
+                                    "budget": 1000, "gamma": gamma, "horizon": horizon, "episodes": episodes})
+        agent.seed(0)
+        assert agent.planner.config["temperature"] == temperature
+        sp = ShardedDevicePlan(agent, world * n_roots, max_plan_len=mpl)
+        assert (sp.lo, sp.hi) == (rank * n_roots, (rank + 1) * n_roots)
+        model = sp.model
+        rng0 = agent.planner.batch_rng_states(n_roots, first_root=sp.lo)
+        d_rng = sp.d_rng
+        # ---- cross-check inside the run: what the gather delivered for ANOTHER rank's roots == rank 0's own re-plan
+        first = sp.wait(sp.plan(d_s0))
+        if rank == 0:
+            other = 1 % world
+            k = min(256, n_roots)
+            lo_o = other * n_roots + (n_roots - k) // 2            # a block from the middle of that rank's shard
+            take = np.arange(lo_o, lo_o + k)
+            got = {key: first[key][lo_o:lo_o + k].cpu().numpy() for key in ("plans", "plan_len", "value", "env_steps")}
+            chk = ctx.uct_plan(model, all_roots[take], episodes, horizon, gamma, temperature, p, p,
+                               agent.planner.batch_rng_states(k, first_root=lo_o), max_plan_len=mpl)
+            same = (np.array_equal(got["plans"], chk["plans"]) and np.array_equal(got["plan_len"], chk["plan_len"])
+                    and np.array_equal(got["value"], chk["root_value"]) and np.array_equal(got["env_steps"], chk["env_steps"]))
+            cross = dict(cross_check="ok" if same else "MISMATCH", cross_check_roots=int(k), cross_check_of_rank=int(other),
+                         cross_check_what="rank 0 re-planned global roots [{}, {}) through the host-array API and compared "
+                                          "plans / plan_len / root value / env_steps with the gathered rows".format(lo_o, lo_o + k))
+            if not same:
+                print("bench.py: gathered results of rank {} differ from rank 0's re-plan".format(other), file=sys.stderr)
+                os._exit(3)
+        loc = sp.local[0]
+        d_plans, d_len, d_val, d_steps = loc["plans"], loc["plan_len"], loc["value"], loc["env_steps"]
+
+        def step():
+            sp.plan(d_s0)
+            d_total.add_(sp.local[(sp.turn - 1) % len(sp.local)]["env_steps"].sum())
 
     for _ in range(args.warmup):
         step()
@@ -290,9 +374,16 @@ def bench_uct(args, rank, world, local, with_prior=False):
     timed_env_steps = int(d_total.item())
     # per-launch kernel time from HIP events on the kernel's stream (separate short pass so that the
     # event synchronisation does not sit inside the timed region above)
+    def last_buffers():
+        """The result buffers of the last step (the sharded path alternates between two sets)."""
+        if sp is not None:
+            return sp.local[(sp.turn - 1) % len(sp.local)]
+        return dict(plans=d_plans, plan_len=d_len, value=d_val, env_steps=d_steps)
+
     for _ in range(min(args.steps, 10)):
         step()
         kernel_ms.append(ctx.last_kernel_ms()[0])
+        d_steps = last_buffers()["env_steps"]
         env_steps = int(d_steps.sum().item())
     dt = max_over_ranks(dt, world)
     total_env_steps = sum_over_ranks(float(timed_env_steps), world) / args.steps   # per step, all ranks
@@ -391,7 +482,10 @@ def bench_uct(args, rank, world, local, with_prior=False):
                              "transfers inside the call) is `value_host_inclusive` in this line",
             measured_mean_selection_depth=mean_depth, measured_expansions_per_episode=expansions / float(n_smp * episodes),
             algorithmic_bytes_per_env_step=bytes_per_step,
-            parallelism="roots sharded over {} GPU(s), all_gather of per-root values".format(world)),
+            parallelism="roots sharded over {} GPU(s); per step ONE all_gather_into_tensor of the packed per-root rows "
+                        "{{plans[{}], plan_len, root value, env_steps, status}} ({} B per root), product path "
+                        "rl_agents_amd.distributed.ShardedDevicePlan".format(world, mpl, 4 * mpl + 24) if sp is not None else
+                        "single GPU"),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel="uct_kernel<5, ENV_TABLE, {}>".format("true" if with_prior else "false"),
@@ -401,6 +495,25 @@ def bench_uct(args, rank, world, local, with_prior=False):
                                       "are not charged" if with_prior else "")),
     )
     add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)
+    if cross is not None:
+        res["_cross"] = cross
+    if not args.no_parity_sample:
+        # the timed launch itself, replayed: generator records back to their initial values, one more step at the
+        # benchmarked geometry, a sample of its roots through the CPU oracle (every rank steps: the exchange is collective)
+        d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
+        step()
+        if rank == 0:
+            from oracle import oracle
+            buf = last_buffers()
+            idx = sample_rows(n_roots)
+            ti = torch.from_numpy(idx).to(dev)
+            got = {k: buf[k][ti].cpu().numpy() for k in ("plans", "plan_len", "value", "env_steps")}
+            ref = oracle.uct_plan_batch(t, r, term, s0[idx], episodes, horizon, gamma, temperature, p, p, rng0[idx],
+                                        max_plan_len=mpl, n_threads=host_cores())
+            ok = (np.array_equal(got["plans"], ref["plans"]) and np.array_equal(got["plan_len"], ref["plan_len"])
+                  and np.array_equal(got["value"], ref["root_value"]) and np.array_equal(got["env_steps"], ref["env_steps"]))
+            res["parity_sample"] = parity_record(ok, "{} roots of a {}-root launch vs oracle.uct_plan_batch: plans, plan_len, root "
+                                                 "value, env_steps bit for bit".format(len(idx), n_roots))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -440,7 +553,8 @@ def bench_uct_cartpole(args, rank, world, local):
     x0 = np.random.Generator(np.random.PCG64(0)).uniform(-0.05, 0.05, size=(world * n_roots, 4))[gids]
     dev = torch.device("cuda", local)
     d_x0 = torch.from_numpy(np.ascontiguousarray(x0)).to(dev)
-    d_rng = torch.from_numpy(seed_states(gids).view(np.int64)).to(dev)
+    rng0 = seed_states(gids)
+    d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)
     mpl = 8
     d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
     d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
@@ -482,6 +596,20 @@ def bench_uct_cartpole(args, rank, world, local):
                       note="state lives in registers: compute/latency bound by construction"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
+        step()
+        idx = sample_rows(n_roots)
+        ti = torch.from_numpy(idx).to(dev)
+        ref = oracle.uct_plan_batch(None, None, None, x0[idx], episodes, horizon, gamma, temperature, p, p, rng0[idx],
+                                    max_plan_len=mpl, n_threads=host_cores(), cartpole=params)
+        same = ((d_plans[ti].cpu().numpy() == ref["plans"]).all(axis=1) & (d_steps[ti].cpu().numpy() == ref["env_steps"])
+                & (d_val[ti].cpu().numpy() == ref["root_value"]))
+        # sin / cos come from the device math library: the stated tolerance is >= 99.5 % of roots identical (observed 100 %)
+        res["parity_sample"] = parity_record(bool(same.mean() >= 0.98), "{} roots of a {}-root launch vs oracle.uct_plan_batch "
+                                             "(CartPole): plans, env_steps, root value; tolerance >= 98 % of the sample "
+                                             "identical (device sincos)".format(len(idx), n_roots), identical_fraction=float(same.mean()))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -582,6 +710,19 @@ def bench_uct_stoch(args, rank, world, local):
                            "before the 16-byte records): the bound is the count of scattered vector-memory instructions"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
+        step()
+        idx = sample_rows(n_roots)
+        ti = torch.from_numpy(idx).to(dev)
+        ref = oracle.uct_plan_stoch_batch("sparse", pr, r, term, s0[idx], episodes, horizon, gamma, temperature, p, p, rng0[idx],
+                                          erng0[idx], next_states=nxt, closed_loop=True, max_plan_len=mpl, n_threads=host_cores())
+        ok = (np.array_equal(d_plans[ti].cpu().numpy(), ref["plans"]) and np.array_equal(d_len[ti].cpu().numpy(), ref["plan_len"])
+              and np.array_equal(d_val[ti].cpu().numpy(), ref["root_value"])
+              and np.array_equal(d_steps[ti].cpu().numpy(), ref["env_steps"]))
+        res["parity_sample"] = parity_record(ok, "{} roots of a {}-root launch vs oracle.uct_plan_stoch_batch (closed loop): plans "
+                                             "with observation keys, plan_len, root value, env_steps bit for bit".format(len(idx), n_roots))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         cores = host_cores()
@@ -616,7 +757,8 @@ def bench_opd(args, rank, world, local):
     s0 = all_roots[rank * n_roots:(rank + 1) * n_roots]
     dev = torch.device("cuda", local)
     d_s0 = torch.from_numpy(s0).to(dev)
-    d_rng = torch.from_numpy(seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots)).view(np.int64)).to(dev)
+    rng0 = seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots))
+    d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)
     mpl = 32
     d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
     d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
@@ -682,6 +824,18 @@ def bench_opd(args, rank, world, local):
                            "reported separately and not charged"),
     )
     add_traffic(res["roofline"], "opd", "opd_", n_roots * 64)
+    if not args.no_parity_sample and world == 1:
+        from oracle import oracle
+        d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
+        step()
+        idx = sample_rows(n_roots)
+        ti = torch.from_numpy(idx).to(dev)
+        ref = oracle.opd_plan_batch(t, r, term, s0[idx], budget, gamma, 0.0, rng0[idx], max_plan_len=mpl, n_threads=host_cores())
+        ok = (np.array_equal(d_plans[ti].cpu().numpy(), ref["plans"]) and np.array_equal(d_len[ti].cpu().numpy(), ref["plan_len"])
+              and np.array_equal(d_lo[ti].cpu().numpy(), ref["root_lower"]) and np.array_equal(d_up[ti].cpu().numpy(), ref["root_upper"])
+              and np.array_equal(d_steps[ti].cpu().numpy(), ref["env_steps"]))
+        res["parity_sample"] = parity_record(ok, "{} roots of a {}-root launch vs oracle.opd_plan_batch: plans, plan_len, root "
+                                             "bounds, env_steps bit for bit".format(len(idx), n_roots))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()
@@ -716,7 +870,8 @@ def bench_ropd(args, rank, world, local):
     s0 = np.repeat(all_roots[rank * n_roots:(rank + 1) * n_roots, None], m_, axis=1)
     dev = torch.device("cuda", local)
     d_s0 = torch.from_numpy(np.ascontiguousarray(s0)).to(dev)
-    d_rng = torch.from_numpy(seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots)).view(np.int64)).to(dev)
+    rng0 = seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots))
+    d_rng = torch.from_numpy(rng0.view(np.int64)).to(dev)
     mpl = 32
     d_plans = torch.empty((n_roots, mpl), dtype=torch.int32, device=dev)
     d_len = torch.empty(n_roots, dtype=torch.int32, device=dev)
@@ -771,6 +926,17 @@ def bench_ropd(args, rank, world, local):
                       note="executed terms only (one deferred bottom-up backup), expansions / depth measured on exported trees"),
     )
     add_traffic(res["roofline"], "ropd", "ropd_", n_roots * 64)
+    if not args.no_parity_sample and world == 1:
+        from oracle import oracle
+        d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
+        step()
+        idx = sample_rows(n_roots)
+        ti = torch.from_numpy(idx).to(dev)
+        ref = oracle.ropd_plan_batch(t, r, term, s0[idx], budget, gamma, 0.0, rng0[idx], max_plan_len=mpl, n_threads=host_cores())
+        ok = (np.array_equal(d_plans[ti].cpu().numpy(), ref["plans"]) and np.array_equal(d_len[ti].cpu().numpy(), ref["plan_len"])
+              and np.array_equal(d_lo[ti].cpu().numpy(), ref["root_lower"]) and np.array_equal(d_steps[ti].cpu().numpy(), ref["env_steps"]))
+        res["parity_sample"] = parity_record(ok, "{} roots of a {}-root launch vs oracle.ropd_plan_batch: plans, plan_len, root "
+                                             "lower bound, joint env_steps bit for bit".format(len(idx), n_roots))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         cores = host_cores()
@@ -839,6 +1005,14 @@ def bench_saopd(args, rank, world, local):
                       kernel="saopd_wave_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
     add_traffic(res["roofline"], "saopd", "saopd_wave_kernel", n_roots * 64)
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        idx = sample_rows(n_roots)
+        ref = oracle.saopd_plan_batch(t, r, term, s0[idx], budget, gamma, rng_states=rng0[idx], max_plan_len=8, n_threads=host_cores())
+        ok = all(np.array_equal(out[k][idx], ref[k]) for k in ("plans", "plan_len", "env_steps", "updates", "status"))
+        res["parity_sample"] = parity_record(ok, "{} planners of the timed {}-planner batch (first plan of fresh planners) vs "
+                                             "oracle.saopd_plan_batch: plans, plan_len, env_steps, Bellman-backup counts, status "
+                                             "bit for bit".format(len(idx), n_roots))
     if rank == 0:   # outside the timed region: what the FOLLOWING plans of the same planners cost (receding horizon)
         planners = native.StateAwarePlanners(ctx, model, n_roots)
         states, rng, follow = s0.copy(), rng0.copy(), []
@@ -941,6 +1115,31 @@ def bench_vi(args, rank, world, local, dense, robust=False):
     if dense:
         res["roofline"]["mfma_tflops"] = flops / (per_sweep_ms * 1e-3) / 1e12
         res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        if dense:
+            # three sweeps of the reference's iteration (value_iteration.py:65-73) on the device; a backup is independent
+            # per source row, so the oracle replays a SAMPLE of rows of every sweep from the device's previous value vector
+            idx = sample_rows(s_)
+            ti = torch.from_numpy(idx).to(dev)
+            rows_t, rows_r = tt[ti].cpu().numpy(), rr[ti].cpu().numpy()
+            v = torch.zeros(s_, dtype=torch.float64, device=dev)
+            q = torch.empty((s_, a_), dtype=torch.float64, device=dev)
+            worst = 0.0
+            for _ in range(3):
+                ctx.vi_backup(model, gamma, v, q_out=q)
+                ref = oracle.dense_backup_rows(rows_t, rows_r, None, v.cpu().numpy(), gamma)
+                got = q[ti].cpu().numpy()
+                worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))))
+                v = q.max(dim=-1).values
+            res["parity_sample"] = parity_record(worst <= 1e-12, "3 sweeps, {} sampled source rows per sweep vs "
+                                                 "oracle.dense_backup_rows (numpy's pairwise order); tolerance 1e-12 relative "
+                                                 "(matrix-core accumulation order)".format(len(idx)), max_rel_err=worst)
+        else:
+            q, sw = ctx.vi_solve(model, gamma, 3, robust=robust)
+            q_ref, sw_ref = oracle.vi_solve("deterministic", t, r, term, gamma=gamma, iterations=3, robust=robust)
+            res["parity_sample"] = parity_record(bool(sw == sw_ref and np.array_equal(q, q_ref)),
+                                                 "3 sweeps vs oracle.vi_solve: Q [{} x {}] and the sweep count bit for bit".format(s_, a_))
     if rank == 0 and world == 1 and not args.no_cpu_baseline and dense:
         # bounded sample: the oracle's dense sweep (numpy's pairwise add.reduce restated, one thread) costs
         # O(S^2 |A|); time it at S = 2000 (160 MB of transitions) and scale by (2000 / S)^2
@@ -1072,6 +1271,23 @@ def bench_rvi_dense_shard(args, rank, world, local):
     )
     res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
     add_traffic(res["roofline"], "rvi_dense_shard", "vi_dense_q", None, pattern="stream")
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        idx = sample_rows(rows)
+        ti = torch.from_numpy(idx).to(dev)
+        rows_t, rows_r = tt[:, ti].cpu().numpy(), rr[:, ti].cpu().numpy()
+        vv = torch.zeros(s_, dtype=torch.float64, device=dev)
+        qq = torch.empty((rows, a_), dtype=torch.float64, device=dev)
+        worst = 0.0
+        for _ in range(3):
+            ctx.vi_backup(model, gamma, vv, q_out=qq, robust=True)
+            ref = oracle.dense_backup_rows(rows_t, rows_r, None, vv.cpu().numpy(), gamma, robust=True)
+            got = qq[ti].cpu().numpy()
+            worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))))
+            vv[lo:lo + rows] = qq.max(dim=-1).values
+        res["parity_sample"] = parity_record(worst <= 1e-12, "3 sweeps, {} sampled rows of this rank's block per sweep vs "
+                                             "oracle.dense_backup_rows (robust, M = 2); tolerance 1e-12 relative".format(len(idx)),
+                                             max_rel_err=worst)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         s_cpu = 1000
@@ -1093,36 +1309,89 @@ def bench_rvi_dense_shard(args, rank, world, local):
     return res
 
 
+def run_workload(args, rank, world, local):
+    if args.workload == "uct_prior":
+        return bench_uct(args, rank, world, local, with_prior=True)
+    if args.workload == "uct":
+        return bench_uct(args, rank, world, local)
+    if args.workload == "uct_cartpole":
+        return bench_uct_cartpole(args, rank, world, local)
+    if args.workload == "uct_stoch":
+        return bench_uct_stoch(args, rank, world, local)
+    if args.workload == "opd":
+        return bench_opd(args, rank, world, local)
+    if args.workload == "ropd":
+        return bench_ropd(args, rank, world, local)
+    if args.workload == "saopd":
+        return bench_saopd(args, rank, world, local)
+    if args.workload == "rvi_dense_shard":
+        return bench_rvi_dense_shard(args, rank, world, local)
+    return bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
+
+
+# the other workloads of the path, each run for a bounded slice after the headline in the default run: (name, workload,
+# steps, roots override).  Sized so that a slice (setup, warm-up, timed steps, oracle replay of a sample) stays in seconds.
+SLICES = [("uct_prior", "uct_prior", 5, None), ("uct_cartpole", "uct_cartpole", 10, None), ("uct_stoch", "uct_stoch", 5, None),
+          ("opd", "opd", 10, None), ("opd8192", "opd", 3, 8192), ("ropd", "ropd", 10, None), ("saopd", "saopd", 3, None),
+          ("vi", "vi", 10, None), ("rvi", "rvi", 10, None), ("vi_dense", "vi_dense", 3, None),
+          ("rvi_dense_shard", "rvi_dense_shard", 10, None)]
+
+
+def run_slices(args, rank, world, local):
+    """Every other workload for a bounded slice (no CPU baseline) -> {name: {value, unit, ms_per_step, kernel, kernel_ms,
+    frac, traffic_frac, parity_sample, workload}}: the numbers of README / DESIGN, driver-timed in the one line."""
+    import copy
+    import gc
+    import torch
+    out = {}
+    for name, workload, steps, roots in SLICES:
+        sub = copy.copy(args)
+        sub.workload, sub.steps, sub.warmup, sub.roots, sub.no_cpu_baseline = workload, steps, 1, roots, True
+        t0 = time.perf_counter()
+        try:
+            res = run_workload(sub, rank, world, local)
+            roof = res.get("roofline", {})
+            out[name] = dict(workload=res["config"]["workload"], value=res["value"], unit=res["unit"],
+                             ms_per_step=res["ms_per_step"], steps=steps, kernel=roof.get("kernel"), kernel_ms=roof.get("kernel_ms"),
+                             frac=roof.get("frac"), traffic_frac=roof.get("traffic_frac"),
+                             parity_sample=(res.get("parity_sample") or {}).get("result"),
+                             parity_detail=(res.get("parity_sample") or {}).get("sample"))
+            for k in ("mfma_frac_of_f64_peak",):
+                if k in roof:
+                    out[name][k] = roof[k]
+            extra = res["config"].get("kernel_ms_first_and_following_plans")
+            if extra is not None:
+                out[name]["kernel_ms_first_and_following_plans"] = extra
+        except Exception as e:                                    # a slice must not cost the headline its line
+            out[name] = dict(error="{}: {}".format(type(e).__name__, e))
+        out[name]["slice_seconds"] = round(time.perf_counter() - t0, 2)
+        del sub
+        gc.collect()
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     if os.environ.get("BENCH_WATCHDOG"):          # debugging aid: dump every thread's stack and exit after N seconds
         import faulthandler
         faulthandler.dump_traceback_later(float(os.environ["BENCH_WATCHDOG"]), exit=True)
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))                # plain `python bench.py --gpus N`: launch the N ranks ourselves
     rank, world, local = dist_setup(args.gpus)
     import torch
     side = torch.cuda.Stream(device=local)          # one stream for torch ops, RCCL and the HIP kernels
     with torch.cuda.stream(side):
-        if args.workload == "uct_prior":
-            res = bench_uct(args, rank, world, local, with_prior=True)
-        elif args.workload == "uct":
-            res = bench_uct(args, rank, world, local)
-        elif args.workload == "uct_cartpole":
-            res = bench_uct_cartpole(args, rank, world, local)
-        elif args.workload == "uct_stoch":
-            res = bench_uct_stoch(args, rank, world, local)
-        elif args.workload == "opd":
-            res = bench_opd(args, rank, world, local)
-        elif args.workload == "ropd":
-            res = bench_ropd(args, rank, world, local)
-        elif args.workload == "saopd":
-            res = bench_saopd(args, rank, world, local)
-        elif args.workload == "rvi_dense_shard":
-            res = bench_rvi_dense_shard(args, rank, world, local)
-        else:
-            res = bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
-    res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
-               vs_baseline=None, data="synthetic (highway-shaped finite MDP; real highway_env absent)")
-    res["ranks"] = ranks_record(rank, world, local)
+        res = run_workload(args, rank, world, local)
+        res.update(n_gpus=world, steps=args.steps, warmup=args.warmup, higher_is_better=True, scaling="weak",
+                   vs_baseline=None, data="synthetic (highway-shaped finite MDP; real highway_env absent)")
+        res["ranks"] = ranks_record(rank, world, local)
+        res["ranks"].update(res.pop("_cross", None) or {})
+        if res["ranks"].get("dry_run_same_device"):
+            res["scaling"] = "weak (DRY RUN: all ranks on one device, not a scaling measurement)"
+        if args.workload == "uct" and world == 1 and not args.headline_only:
+            res["workloads"] = run_slices(args, rank, world, local)
     res.setdefault("cpu_baseline", None)
     if isinstance(res["cpu_baseline"], dict):
         # the reference's own (pure Python) CPU path on the same tables: it cannot travel to the GPU box, so its timing is
@@ -1136,6 +1405,7 @@ def main():
                  "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
         order += [k for k in res if k not in order]
         print(json.dumps({k: res[k] for k in order}))
+        sys.stdout.flush()
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

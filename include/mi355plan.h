@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 3
+#define MP_ABI_VERSION 4
 
 #define MP_OK 0
 #define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
@@ -62,6 +62,8 @@ int mp_ctx_create(int device, void *stream, mp_ctx **out);
 int mp_ctx_destroy(mp_ctx *ctx);
 int mp_ctx_set_stream(mp_ctx *ctx, void *stream);
 int mp_ctx_synchronize(mp_ctx *ctx);
+/* the hipStream_t the ctx enqueues on (its own or the caller's): lets the caller order events / collectives after its work */
+int mp_ctx_get_stream(mp_ctx *ctx, void **stream);
 /* device facts for reports: compute units, wavefront size, LDS bytes per workgroup, HBM bytes */
 int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *lds_bytes, int64_t *hbm_bytes,
                        char *name, int32_t name_cap);
@@ -420,6 +422,25 @@ int mp_env_step(mp_ctx *ctx, mp_model *model, int32_t n, int32_t *state, int32_t
                 double *discounted, int32_t *actions_log, int32_t log_stride, int32_t *n_alive, int32_t mem);
 int mp_greedy_actions(mp_ctx *ctx, int32_t n, int32_t S, int32_t A, const double *Q, const int32_t *state, int32_t *plans,
                       int32_t plan_stride, int32_t mem);
+
+/* ---------------------------------------------------------------- result exchange ------------ */
+/*
+ * The one exchange of the sharded planning path (per-root {plan, value, env_steps} to every rank; the
+ * reference has no counterpart -- one process per experiment, scripts/experiments.py:102-106).  Both calls work on DEVICE
+ * buffers only and only enqueue (on `stream`, a hipStream_t, or on the ctx stream when NULL): the caller runs ONE
+ * all_gather_into_tensor (RCCL) on `packed` between them, no host hop.
+ *   mp_pack_rows:   n_arrays (<= 8) per-root arrays src[k] with row widths width[k] bytes (multiples of 4) of this
+ *                   rank's n_local roots -> packed uint8 [per][row_bytes], row_bytes = sum(width); rows n_local..per-1
+ *                   (the padding that makes every rank's block the same size) are zero-filled.
+ *   mp_unpack_rows: gathered uint8 [world][per][row_bytes] -> dst[k] [n_total][width[k]]; global row i comes from
+ *                   rank r's block where [lo_r, hi_r) is the balanced contiguous split of n_total over world ranks
+ *                   (the first n_total % world ranks hold one row more), i.e. rl_agents_amd.distributed.shard_bounds.
+ * src / dst / width are HOST arrays of device pointers / ints.
+ */
+int mp_pack_rows(mp_ctx *ctx, void *stream, int32_t n_local, int32_t per, int32_t n_arrays, const void *const *src,
+                 const int32_t *width, void *packed);
+int mp_unpack_rows(mp_ctx *ctx, void *stream, int32_t n_total, int32_t world, int32_t per, int32_t n_arrays,
+                   const void *packed, const int32_t *width, void *const *dst);
 
 /* ---------------------------------------------------------------- helpers ------------------- */
 /* OLOP.allocation (tree_search/olop.py:50-62) with OLOP.horizon (:42-44); host arithmetic. */

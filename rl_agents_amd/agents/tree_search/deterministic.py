@@ -43,15 +43,16 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
     def device_plan_len(self, model):
         return 1
 
-    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status):
-        """One asynchronous batched plan (mp_opd_plan, MP_MEM_DEVICE): only enqueues; reward-range errors land in d_status."""
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None):
+        """One asynchronous batched plan (mp_opd_plan, MP_MEM_DEVICE): only enqueues; reward-range errors land in d_status.
+        ``d_value``: optional float64 [n] buffer for the roots' lower bounds."""
         cfg = self.config
         budget = int(cfg["budget"])
         if cfg["gamma"] == 1 and budget >= model.A:
             raise ZeroDivisionError("float division by zero")
         self.models.ctx.opd_plan_device(model, n, d_state, budget, cfg["gamma"], cfg.get("terminal_reward", 0), d_rng,
-                                        int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, env_steps=d_env_steps,
-                                        status=d_status)
+                                        int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, root_lower=d_value,
+                                        env_steps=d_env_steps, status=d_status)
         self.claim_device_tree()
         self.last, self._root = None, None
 

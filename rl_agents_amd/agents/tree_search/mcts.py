@@ -228,8 +228,9 @@ class MCTS(AbstractPlanner):
     def device_plan_len(self, model):
         return 1
 
-    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status):
-        """One asynchronous batched plan (mp_uct_plan / mp_uct_plan_policy, MP_MEM_DEVICE): only enqueues."""
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None):
+        """One asynchronous batched plan (mp_uct_plan / mp_uct_plan_policy, MP_MEM_DEVICE): only enqueues.
+        ``d_value``: optional float64 [n] buffer for the root values."""
         if model.mode != native_modes.MODE_DETERMINISTIC:
             raise NotImplementedError("the device-resident loop steps deterministic table models")
         cfg, ctx = self.config, self.models.ctx
@@ -249,8 +250,8 @@ class MCTS(AbstractPlanner):
             pp = policy_probabilities(self.prior_policy, model.A)
             rp = policy_probabilities(self.rollout_policy, model.A)
         ctx.uct_plan_device(model, n, d_state, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp, rp, d_rng,
-                            int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, env_steps=d_env_steps, root_steps=d_steps,
-                            policy=policy)
+                            int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, root_value=d_value, env_steps=d_env_steps,
+                            root_steps=d_steps, policy=policy)
         self.claim_device_tree()
         self.last, self._root = None, None
 

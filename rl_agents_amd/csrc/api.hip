@@ -231,6 +231,48 @@ __global__ void greedy_actions_kernel(int n, int A, const double *__restrict__ Q
     plans[(long)i * plan_stride] = best;
 }
 
+// mp_pack_rows / mp_unpack_rows (mi355plan.h): the per-root results of a sharded plan <-> ONE byte matrix for the collective.
+// One thread per 4-byte word of the packed matrix: the packed side is a coalesced stream, the array side runs of
+// width / 4 words.
+struct RowCols {
+    const void *ptr[8];
+    int off[9]; // word offset of array k inside a packed row; off[n] = words per row
+    int n;
+};
+
+__global__ void pack_rows_kernel(RowCols c, int n_local, int per, uint32_t *__restrict__ packed)
+{
+    const int wpr = c.off[c.n];
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)per * wpr) return;
+    const int row = (int)(t / wpr), col = (int)(t - (long)row * wpr);
+    uint32_t v = 0;
+    if (row < n_local) {
+        int k = 0;
+        while (k + 1 < c.n && col >= c.off[k + 1]) ++k;
+        const int w = c.off[k + 1] - c.off[k];
+        v = static_cast<const uint32_t *>(c.ptr[k])[(long)row * w + (col - c.off[k])];
+    }
+    packed[t] = v;
+}
+
+__global__ void unpack_rows_kernel(RowCols c, int n_total, int world, int per, const uint32_t *__restrict__ packed)
+{
+    const int wpr = c.off[c.n];
+    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (long)n_total * wpr) return;
+    const int row = (int)(t / wpr), col = (int)(t - (long)row * wpr);
+    // rank and local row of global row `row` under the balanced contiguous split (distributed.shard_bounds)
+    const int base = n_total / world, extra = n_total - base * world;
+    int r, j;
+    if (row < extra * (base + 1)) { r = row / (base + 1); j = row - r * (base + 1); }
+    else { r = extra + (row - extra * (base + 1)) / base; j = (row - extra * (base + 1)) - (r - extra) * base; }
+    int k = 0;
+    while (k + 1 < c.n && col >= c.off[k + 1]) ++k;
+    const int w = c.off[k + 1] - c.off[k];
+    static_cast<uint32_t *>(const_cast<void *>(c.ptr[k]))[(long)row * w + (col - c.off[k])] = packed[((long)r * per + j) * wpr + col];
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -311,6 +353,51 @@ int mp_greedy_actions(mp_ctx *ctx, int32_t n, int32_t S, int32_t A, const double
     MP_HIP(hipSetDevice(ctx->device));
     hipLaunchKernelGGL(greedy_actions_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, A, Q, state, plans,
                        plan_stride);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+static int row_cols(const char *who, int32_t n_arrays, const void *const *ptr, const int32_t *width, RowCols *c)
+{
+    if (n_arrays < 1 || n_arrays > 8 || !ptr || !width) return fail(MP_ERR_ARG, "%s: 1..8 arrays", who);
+    c->n = n_arrays;
+    c->off[0] = 0;
+    for (int k = 0; k < n_arrays; ++k) {
+        if (!ptr[k] || width[k] < 4 || (width[k] & 3)) return fail(MP_ERR_ARG, "%s: array %d: NULL or row width %d not a positive multiple of 4", who, k, width[k]);
+        c->ptr[k] = ptr[k];
+        c->off[k + 1] = c->off[k] + width[k] / 4;
+    }
+    for (int k = n_arrays; k < 8; ++k) c->ptr[k] = nullptr;
+    return MP_OK;
+}
+
+int mp_pack_rows(mp_ctx *ctx, void *stream, int32_t n_local, int32_t per, int32_t n_arrays, const void *const *src,
+                 const int32_t *width, void *packed)
+{
+    if (!ctx || !packed) return fail(MP_ERR_ARG, "mp_pack_rows: NULL argument");
+    if (n_local < 0 || per < 1 || n_local > per) return fail(MP_ERR_ARG, "mp_pack_rows: bad sizes (n_local=%d per=%d)", n_local, per);
+    RowCols c;
+    MP_TRY(row_cols("mp_pack_rows", n_arrays, src, width, &c));
+    MP_HIP(hipSetDevice(ctx->device));
+    const long words = (long)per * c.off[c.n];
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
+                       c, n_local, per, static_cast<uint32_t *>(packed));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_unpack_rows(mp_ctx *ctx, void *stream, int32_t n_total, int32_t world, int32_t per, int32_t n_arrays,
+                   const void *packed, const int32_t *width, void *const *dst)
+{
+    if (!ctx || !packed) return fail(MP_ERR_ARG, "mp_unpack_rows: NULL argument");
+    if (world < 1 || n_total < world || (long)per * world < n_total || per < (n_total + world - 1) / world)
+        return fail(MP_ERR_ARG, "mp_unpack_rows: bad sizes (n_total=%d world=%d per=%d)", n_total, world, per);
+    RowCols c;
+    MP_TRY(row_cols("mp_unpack_rows", n_arrays, dst, width, &c));
+    MP_HIP(hipSetDevice(ctx->device));
+    const long words = (long)n_total * c.off[c.n];
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, stream ? (hipStream_t)stream : ctx->stream,
+                       c, n_total, world, per, static_cast<const uint32_t *>(packed));
     MP_HIP(hipGetLastError());
     return MP_OK;
 }
@@ -451,6 +538,13 @@ int mp_ctx_set_stream(mp_ctx *ctx, void *stream)
         MP_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
         ctx->own_stream = true;
     }
+    return MP_OK;
+}
+
+int mp_ctx_get_stream(mp_ctx *ctx, void **stream)
+{
+    if (!ctx || !stream) return fail(MP_ERR_ARG, "mp_ctx_get_stream: NULL argument");
+    *stream = (void *)ctx->stream;
     return MP_OK;
 }
 

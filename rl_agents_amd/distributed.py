@@ -223,3 +223,150 @@ def vi_solve_row_sharded_device(ctx, transition_rows, reward_rows, terminal_rows
         dist.all_gather_into_tensor(q_all, q_pad)
         return (q_all if even else q_all[order]), sweeps
     return q_local, sweeps
+
+
+class ShardedDevicePlan(object):
+    """Device-resident form of :func:`plan_batch_sharded`: the same sharding and the same random streams (keyed by the
+    GLOBAL root index), but roots, generator records and results are device buffers and the exchange never touches the
+    host -- per ``plan()``: the planner's asynchronous batched launch on this rank's shard, ``mp_pack_rows`` (the shard's
+    {plans, plan_len, value, env_steps, status} rows into ONE byte matrix), ONE ``all_gather_into_tensor`` (RCCL over xGMI)
+    and ``mp_unpack_rows`` (back into full per-root arrays on every rank).  The collective and the unpack run on a side
+    stream, double-buffered, so a caller that plans again straight away overlaps them with its next launch; the returned
+    ``ready`` event orders any consumer after them.  A ``gloo`` group (CPU tests, same-device dry runs) exchanges the same
+    packed bytes through host memory.  The generator records stay resident and continue from call to call, as
+    ``planner.np_random`` does for a single root (tree_search/abstract.py:124-131).
+
+    ``agent``: a tree-search agent whose planner has a device loop (``plan_batch_device``: MCTS, OPD)."""
+
+    def __init__(self, agent, n_total, max_plan_len=None, force_collective=False, overlap=True):
+        import torch
+        planner = agent.planner
+        if getattr(planner, "plan_batch_device", None) is None or not planner.supports_device_loop():
+            raise NotImplementedError("this agent's planner has no device-resident batched plan")
+        self.agent, self.planner = agent, planner
+        self.rank, self.world = rank_world()
+        self.n = int(n_total)
+        if self.n < self.world:
+            raise RuntimeError("fewer roots ({}) than ranks ({}): give every rank at least one root".format(self.n, self.world))
+        self.lo, self.hi = shard_bounds(self.n, self.rank, self.world)
+        self.env = agent.planning_env()
+        self.model = planner.model_for(self.env)
+        self.ctx = ctx = planner.models.ctx
+        self.dev = dev = torch.device("cuda", ctx.device)
+        self.grouped = _group_active(force_collective)
+        self.on_device = self.grouped and collective_device() is not None          # RCCL: tensors stay on the GPU
+        self.mpl = mpl = int(max_plan_len or planner.device_plan_len(self.model))
+        nl = self.hi - self.lo
+        self.per = per = -(-self.n // self.world)
+        with torch.cuda.device(dev):
+            self.ctx_stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
+            self.comm = torch.cuda.Stream(device=dev) if (overlap and self.grouped) else self.ctx_stream
+            self.d_rng = torch.from_numpy(planner.batch_rng_states(nl, first_root=self.lo).view(np.int64)).to(dev)
+
+            def local():
+                return dict(plans=torch.full((nl, mpl), -1, dtype=torch.int32, device=dev),
+                            plan_len=torch.zeros(nl, dtype=torch.int32, device=dev),
+                            value=torch.zeros(nl, dtype=torch.float64, device=dev),
+                            env_steps=torch.zeros(nl, dtype=torch.int64, device=dev),
+                            status=torch.zeros(nl, dtype=torch.int32, device=dev))
+
+            def full():
+                return dict(plans=torch.empty((self.n, mpl), dtype=torch.int32, device=dev),
+                            plan_len=torch.empty(self.n, dtype=torch.int32, device=dev),
+                            value=torch.empty(self.n, dtype=torch.float64, device=dev),
+                            env_steps=torch.empty(self.n, dtype=torch.int64, device=dev),
+                            status=torch.empty(self.n, dtype=torch.int32, device=dev))
+            self.keys = ("plans", "plan_len", "value", "env_steps", "status")
+            nbuf = 2 if self.grouped else 1
+            self.local = [local() for _ in range(nbuf)]
+            self.row_bytes = 4 * mpl + 4 + 8 + 8 + 4
+            if self.grouped:
+                self.full = [full() for _ in range(nbuf)]
+                self.packed = [torch.empty((per, self.row_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+                self.gathered = [torch.empty((self.world * per, self.row_bytes), dtype=torch.uint8, device=dev)
+                                 for _ in range(nbuf)]
+            self.kernel_done = [torch.cuda.Event() for _ in range(nbuf)]
+            self.gather_done = [None] * nbuf
+            order = getattr(self.model, "action_order", None)
+            self.order = None if order is None else torch.from_numpy(np.asarray(order, dtype=np.int32)).to(dev)
+            torch.cuda.synchronize(dev)                   # the buffers exist before the ctx stream touches them
+        self.turn = 0
+
+    def shard(self, d_roots_all):
+        """This rank's block of a global per-root device tensor."""
+        return d_roots_all[self.lo:self.hi]
+
+    def plan(self, d_root_states, d_root_steps=None):
+        """``d_root_states``: int32 device tensor, either the GLOBAL root list [n_total] (this rank plans its block) or
+        already this rank's block [hi - lo].  Only enqueues.  Returns the full per-root device tensors (identical on every
+        rank) ``plans [n, max_plan_len]`` (environment action ids), ``plan_len``, ``value`` (root value / lower bound),
+        ``env_steps``, ``status`` and ``ready``, the event after which they hold this call's results (``None`` when they are
+        ready in ctx-stream order); they are overwritten by the call after the next one."""
+        import torch
+        import torch.distributed as dist
+        nl = self.hi - self.lo
+        if d_root_states.shape[0] == self.n and self.n != nl:
+            d_root_states = d_root_states[self.lo:self.hi]
+            if d_root_steps is not None:
+                d_root_steps = d_root_steps[self.lo:self.hi]
+        if d_root_states.shape[0] != nl:
+            raise ValueError("expected {} (global) or {} (this rank's) root states, got {}".format(self.n, nl, d_root_states.shape[0]))
+        b = self.turn % len(self.local)
+        self.turn += 1
+        loc = self.local[b]
+        if self.gather_done[b] is not None and self.comm is not self.ctx_stream:
+            self.ctx_stream.wait_event(self.gather_done[b])        # buffer set b is free again
+        self.planner.plan_batch_device(self.env, self.model, nl, d_root_states, d_root_steps, self.d_rng, loc["plans"],
+                                       loc["plan_len"], loc["env_steps"], loc["status"], d_value=loc["value"])
+        if not self.grouped:
+            out = dict(loc)
+            if self.order is not None:
+                with torch.cuda.stream(self.ctx_stream):
+                    out["plans"] = torch.where(loc["plans"] >= 0, self.order[loc["plans"].clamp(min=0).long()], loc["plans"])
+            out["ready"] = None
+            return out
+        arrays = [loc[k] for k in self.keys]
+        self.ctx.pack_rows(arrays, nl, self.packed[b])
+        full = self.full[b]
+        outs = [full[k] for k in self.keys]
+        if self.on_device:
+            if self.comm is not self.ctx_stream:
+                self.kernel_done[b].record(self.ctx_stream)
+                self.comm.wait_event(self.kernel_done[b])
+            with torch.cuda.stream(self.comm):
+                dist.all_gather_into_tensor(self.gathered[b], self.packed[b])
+            self.ctx.unpack_rows(self.gathered[b], self.n, self.world, outs, stream=self.comm.cuda_stream)
+        else:                                                   # gloo: the same packed bytes, through host memory
+            self.ctx.synchronize()
+            host = self.packed[b].cpu()
+            got = torch.empty((self.world * self.per, self.row_bytes), dtype=torch.uint8)
+            dist.all_gather_into_tensor(got, host)
+            with torch.cuda.stream(self.comm):
+                self.gathered[b].copy_(got)
+            self.ctx.unpack_rows(self.gathered[b], self.n, self.world, outs, stream=self.comm.cuda_stream)
+        out = dict(full)
+        with torch.cuda.stream(self.comm):
+            if self.order is not None:
+                out["plans"] = torch.where(full["plans"] >= 0, self.order[full["plans"].clamp(min=0).long()], full["plans"])
+            ev = torch.cuda.Event()
+            ev.record(self.comm)
+        self.gather_done[b] = ev
+        out["ready"] = ev
+        return out
+
+    def wait(self, out):
+        """Block the host until ``out`` (a result of :meth:`plan`) is complete."""
+        if out.get("ready") is not None:
+            out["ready"].synchronize()
+        else:
+            self.ctx.synchronize()
+        return out
+
+
+def plan_batch_sharded_device(agent, d_root_states, d_root_steps=None, max_plan_len=None, force_collective=False):
+    """One-shot form of :class:`ShardedDevicePlan` (fresh generator records keyed by global root index, as
+    :func:`plan_batch_sharded`): plans the global device root list sharded over the group and returns the gathered
+    device tensors after the exchange completed."""
+    sp = ShardedDevicePlan(agent, int(d_root_states.shape[0]), max_plan_len=max_plan_len, force_collective=force_collective,
+                           overlap=False)
+    return sp.wait(sp.plan(d_root_states, d_root_steps))

@@ -31,6 +31,7 @@ SIGNATURES = {
     "mp_ctx_destroy": (C.c_int, [_vp]),
     "mp_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "mp_ctx_synchronize": (C.c_int, [_vp]),
+    "mp_ctx_get_stream": (C.c_int, [_vp, P(_vp)]),
     "mp_ctx_device_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i64), P(c_i64), C.c_char_p, c_i32]),
     "mp_model_load_table": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32, P(_vp)]),
     "mp_model_load_dense": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "mp_rng_seed_sequence": (C.c_int, [_vp, c_i32, c_i32, _vp, c_i32, c_i64]),
     "mp_rng_device_ptr": (_vp, [_vp, c_i32]),
     "mp_seed_sequence_states": (C.c_int, [_vp, c_i32, c_i64, c_i32, _vp]),
+    "mp_pack_rows": (C.c_int, [_vp, _vp, c_i32, c_i32, c_i32, _vp, _vp, _vp]),
+    "mp_unpack_rows": (C.c_int, [_vp, _vp, c_i32, c_i32, c_i32, c_i32, _vp, _vp, _vp]),
 }
 
 
@@ -127,7 +130,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 3:
+    if lib.mp_abi_version() != 4:
         raise RuntimeError("libmi355plan ABI version mismatch")
     _LIB = lib
     return lib
@@ -221,6 +224,16 @@ class Context(object):
     def synchronize(self):
         _check(self._lib.mp_ctx_synchronize(self._h))
 
+    def set_stream(self, stream):
+        """Enqueue on another hipStream_t from now on (raw pointer, e.g. ``torch.cuda.current_stream().cuda_stream``)."""
+        _check(self._lib.mp_ctx_set_stream(self._h, _vp(stream) if stream else None))
+
+    def stream_ptr(self):
+        """The raw hipStream_t this context enqueues on (``torch.cuda.ExternalStream(ptr)`` wraps it)."""
+        st = _vp()
+        _check(self._lib.mp_ctx_get_stream(self._h, C.byref(st)))
+        return st.value or 0
+
     def device_info(self):
         cu, wave, lds, hbm = c_i32(), c_i32(), c_i64(), c_i64()
         name = C.create_string_buffer(256)
@@ -274,6 +287,26 @@ class Context(object):
         """plans[:, 0] = argmax_a q[state, a] (first maximum), device tensors."""
         _check(self._lib.mp_greedy_actions(self._h, int(state.shape[0]), int(q.shape[0]), int(q.shape[1]), _ptr(q),
                                            _ptr(state), _ptr(plans), int(plans.shape[1]), MP_MEM_DEVICE))
+
+    # ---- result exchange of the sharded path (mp_pack_rows / mp_unpack_rows): device tensors, only enqueues ------------
+    @staticmethod
+    def _row_args(arrays):
+        ptrs = (_vp * len(arrays))(*[_ptr(a) for a in arrays])
+        widths = (c_i32 * len(arrays))(*[int(a.element_size()) * int(np.prod(tuple(a.shape[1:]), dtype=np.int64))
+                                         for a in arrays])
+        return ptrs, widths
+
+    def pack_rows(self, arrays, n_local, packed, stream=None):
+        """Per-root device arrays [n_local, ...] -> rows of ``packed`` (uint8 [per, row_bytes]); padding rows zeroed."""
+        ptrs, widths = self._row_args(arrays)
+        _check(self._lib.mp_pack_rows(self._h, _vp(stream) if stream else None, int(n_local), int(packed.shape[0]),
+                                      len(arrays), ptrs, widths, _ptr(packed)))
+
+    def unpack_rows(self, gathered, n_total, world, arrays, stream=None):
+        """``gathered`` (uint8 [world * per, row_bytes], rank-major) -> the full per-root arrays [n_total, ...]."""
+        ptrs, widths = self._row_args(arrays)
+        _check(self._lib.mp_unpack_rows(self._h, _vp(stream) if stream else None, int(n_total), int(world),
+                                        int(gathered.shape[0]) // int(world), len(arrays), _ptr(gathered), widths, ptrs))
 
     # ---- models ------------------------------------------------------------------------------
     def load_table(self, transition, reward, terminal=None, done_rule="source", max_steps=0, available=None):

@@ -65,6 +65,15 @@ def _plan_all(force_collective=False):
     res = {}
     for name, agent in agents:
         res[name] = plan_batch_sharded(agent, roots, force_collective=force_collective)
+    # the device-resident form of the same exchange (mp_pack_rows -> one all_gather_into_tensor -> mp_unpack_rows, no host
+    # hop under RCCL): fresh agents (same seeds), global roots as a device tensor
+    import torch
+    from rl_agents_amd.distributed import plan_batch_sharded_device
+    agents, _ = _agents()
+    d_roots = torch.from_numpy(roots).cuda()
+    for name, agent in agents[:2]:
+        out = plan_batch_sharded_device(agent, d_roots, max_plan_len=res[name]["plans"].shape[1], force_collective=force_collective)
+        res[name + "_device"] = {k: out[k].cpu().numpy() for k in ("plans", "plan_len", "value", "env_steps", "status")}
     return res
 
 
@@ -161,6 +170,15 @@ def _assert_same(res, single):
         for k in a:
             assert a[k].shape[0] == N_ROOTS
             np.testing.assert_array_equal(a[k], b[k], err_msg="{}/{}".format(name, k))
+    for name, vkey in (("uct", "root_value"), ("opd", "root_lower")):      # device-resident exchange == host-packed exchange
+        for r in (res, single):
+            d, h = r["plans"][name + "_device"], r["plans"][name]
+            assert d["plans"].shape == (N_ROOTS, h["plans"].shape[1])
+            np.testing.assert_array_equal(d["plans"], h["plans"], err_msg=name + "_device/plans")
+            np.testing.assert_array_equal(d["plan_len"], h["plan_len"], err_msg=name + "_device/plan_len")
+            np.testing.assert_array_equal(d["env_steps"], h["env_steps"], err_msg=name + "_device/env_steps")
+            np.testing.assert_array_equal(d["value"], h[vkey], err_msg=name + "_device/value")
+            assert not d["status"].any()
     for k in ("returns", "discounted_returns", "lengths", "actions"):     # sharded device-resident evaluation
         np.testing.assert_array_equal(res["evaluation"][k], single["evaluation"][k], err_msg="evaluation/" + k)
     assert res["evaluation"]["planner_env_steps"] == single["evaluation"]["planner_env_steps"]
