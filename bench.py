@@ -385,6 +385,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
         kernel_ms.append(ctx.last_kernel_ms()[0])
         d_steps = last_buffers()["env_steps"]
         env_steps = int(d_steps.sum().item())
+    variant = ctx.last_kernel_variant()
     dt = max_over_ranks(dt, world)
     total_env_steps = sum_over_ranks(float(timed_env_steps), world) / args.steps   # per step, all ranks
     # Algorithmic bytes of THIS run, SURVEY.md 8(d): per env step 13 B of model (T 4 + R 8 + term 1); per selection
@@ -401,7 +402,19 @@ def bench_uct(args, rank, world, local, with_prior=False):
         sample_env += int(smp_steps[i])
     n_smp = len(sample)
     mean_depth = sel_steps / float(n_smp * episodes)
-    bytes_per_step = (13.0 * sample_env + 16.0 * a_ * sel_steps + 24.0 * (sel_steps + n_smp * episodes)
+    # model term: 13 B per env step gathered from the 16-byte records -- or, when the kernel keeps the whole model in LDS
+    # (uct_ldsr: the default from 65 536 roots), only what every workgroup stages once per launch: 3 B per (s, a) + tables
+    model_bytes_per_step = 13.0
+    staged = None
+    if variant == "uct_ldsr":
+        cus = ctx.device_info()["n_cu"]
+        waves = 1
+        while waves < -(-(n_roots // 64) // cus) and waves < 16:
+            waves *= 2
+        n_wg = -(-n_roots // (64 * waves))
+        staged = n_wg * (3.0 * s_ * a_ + 8.0 * len(np.unique(r)) + 8.0 * (horizon + 1 + 2 * a_ + (episodes + 1) + a_ * (episodes + 2)))
+        model_bytes_per_step = staged / float(env_steps)
+    bytes_per_step = (model_bytes_per_step * sample_env + 16.0 * a_ * sel_steps + 24.0 * (sel_steps + n_smp * episodes)
                       + 24.0 * a_ * expansions) / sample_env
     # metric half (ii) and the 8(d) definition: small batches and the host-inclusive call, rank 0's GPU
     latency = {}
@@ -488,10 +501,14 @@ def bench_uct(args, rank, world, local, with_prior=False):
                         "single GPU"),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      kernel="uct_kernel<5, ENV_TABLE, {}>".format("true" if with_prior else "false"),
+                      kernel="uct_kernel<5, {}>".format("ENV_TABLE, per-state policies" if with_prior else
+                                                        ("ENV_TABLE_LDSR (model resident in LDS)" if variant == "uct_ldsr" else "ENV_TABLE")),
+                      kernel_variant=variant, model_bytes_staged_per_launch=staged,
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps,
                       note="algorithmic bytes = SURVEY 8(d) terms with the depth / expansions measured on this launch's "
-                           "trees" + ("; the per-state policy tables (L2-resident by construction, like the 800 KB model) "
+                           "trees" + ("; the model term is what the workgroups stage into LDS once per launch (an env step "
+                                      "makes no global request), so the fraction prices the tree traffic only: this kernel is "
+                                      "bound by vector-ALU issue, not by HBM" if variant == "uct_ldsr" else "") + ("; the per-state policy tables (L2-resident by construction, like the 800 KB model) "
                                       "are not charged" if with_prior else "")),
     )
     add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)

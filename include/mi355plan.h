@@ -448,6 +448,9 @@ int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t 
 /* Timing of the last kernel batch enqueued by a plan / solve call, from HIP events recorded on
  * the ctx stream around the kernel launches only (no copies).  Synchronises the stream. */
 int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches);
+/* Name of the kernel variant the last mp_uct_plan* call launched ("uct_global", "uct_ldsr" = model resident in LDS,
+ * "uct_lds", "uct_policy", "uct_cartpole"): the host picks by model and batch size; reports and tests name what ran. */
+const char *mp_last_kernel_variant(mp_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,7 @@
 
 #include <mutex>
 #include <set>
+#include <unordered_map>
 #include <vector>
 
 #include "common.hpp"
@@ -569,6 +570,8 @@ int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *
     return MP_OK;
 }
 
+const char *mp_last_kernel_variant(mp_ctx *ctx) { return ctx ? ctx->last_variant : ""; }
+
 int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
@@ -616,6 +619,31 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
             return bail(fail(MP_ERR_ALLOC, "mp_model_load_table: hipMalloc failed"));
         hipLaunchKernelGGL(pack_t16, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, ctx->stream, S, A, m->T, m->term,
                            m->t16);
+        // the LDS-resident form of model 0 (uct.hip ENV_TABLE_LDSR): rewards as 8-bit indices into the table of their
+        // distinct values (by bit pattern: -0.0 and 0.0, or two NaNs, stay what they are) -- when there are at most 256
+        std::unordered_map<uint64_t, int> seen;
+        std::vector<uint8_t> idx(((size_t)sa + 15) & ~(size_t)15, 0);
+        std::vector<double> dict(256, 0.0);
+        bool fits = true;
+        for (long i = 0; i < sa && fits; ++i) {
+            uint64_t bits;
+            memcpy(&bits, &reward[i], sizeof(bits));
+            auto it = seen.find(bits);
+            if (it == seen.end()) {
+                if (seen.size() == 256) { fits = false; break; }
+                it = seen.emplace(bits, (int)seen.size()).first;
+                dict[it->second] = reward[i];
+            }
+            idx[i] = (uint8_t)it->second;
+        }
+        if (fits) {
+            if (hipMalloc(&m->r8, idx.size()) != hipSuccess || hipMalloc(&m->rdict, 256 * sizeof(double)) != hipSuccess)
+                return bail(fail(MP_ERR_ALLOC, "mp_model_load_table: hipMalloc failed"));
+            if (hipMemcpy(m->r8, idx.data(), idx.size(), hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(m->rdict, dict.data(), 256 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail(MP_ERR_HIP, "mp_model_load_table: upload failed"));
+            m->n_rdict = (int)seen.size();
+        }
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(MP_ERR_HIP, "pack_records failed"));
     *out = m;
@@ -788,6 +816,8 @@ int mp_model_free(mp_model *m)
     if (m->T) hipFree(m->T);
     if (m->rec) hipFree(m->rec);
     if (m->t16) hipFree(m->t16);
+    if (m->r8) hipFree(m->r8);
+    if (m->rdict) hipFree(m->rdict);
     if (m->avail) hipFree(m->avail);
     if (m->rec_all) hipFree(m->rec_all);
     if (m->term_all) hipFree(m->term_all);

@@ -78,6 +78,7 @@ struct mp_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool timed = false;
     int n_launches = 0;
+    char last_variant[48] = ""; // which kernel variant the last tree-search call launched (mp_last_kernel_variant)
     hipDeviceProp_t prop;
     mp::DevBuf ws[mp::WS_COUNT];
     mp::TreeMeta tree;
@@ -169,6 +170,9 @@ struct mp_model {
     mp::Rec *rec_all = nullptr;  // joint models (mp_model_load_joint): packed records of every model, [M][S*A]; rec = rec_all
     uint8_t *term_all = nullptr; // joint models: terminal flags per model, [M][S]
     uint16_t *t16 = nullptr; // model 0 as {bit15 = terminal[next], next}, [S*A]; only when S < 32768
+    uint8_t *r8 = nullptr;   // model 0's rewards as indices into rdict, [S*A] (padded to 16 B); only with t16 and <= 256 distinct rewards
+    double *rdict = nullptr; // the distinct reward values (bit patterns), [256]
+    int n_rdict = 0;
     // dense [M,S,A,S] / sparse [S,A,B]
     const double *P = nullptr;
     bool borrowed = false;

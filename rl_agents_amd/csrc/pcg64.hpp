@@ -32,30 +32,54 @@ struct Pcg64 {
         p[0] = s_hi; p[1] = s_lo; p[2] = inc_hi; p[3] = inc_lo;
         p[4] = has_uint32; p[5] = uinteger;
     }
-    __device__ __forceinline__ uint64_t next64()
+    // d = a * m + c as one v_mad_u64_u32 (32 x 32 + 64 -> 64); the instruction's carry-out lane mask goes to a dead SGPR pair.
+    // The multiplier limb sits in an SGPR (one constant-bus operand); written as inline assembly because the compiler
+    // otherwise expands the schoolbook product into twice as many instructions (zero-extending moves, multiplies by a
+    // literal 0 used as 64-bit adds: 60 VALU instructions per step against the 27 of this form).
+    __device__ __forceinline__ static uint64_t mad64(uint32_t a, uint32_t m, uint64_t c)
     {
-        // state * 0x2360ED051FC65DA44385DF649FCCF645 + inc  (mod 2^128), schoolbook on 32-bit limbs:
-        // the 6 partial products that feed carries as 32x32+64 multiply-adds, the 4 of the top limb as
-        // low-half multiplies -- 10 multiplies (the generic 64-bit formulation compiles to 18).
+        uint64_t d, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "s"(m), "v"(c));
+        return d;
+    }
+    // state <- state * 0x2360ED051FC65DA44385DF649FCCF645 + inc (mod 2^128), by columns of 32-bit limbs: column k sums the
+    // products a_i * m_j with i + j = k on top of the carry of column k - 1, each product one multiply-add into a 64-bit
+    // accumulator (14 instructions; checked against Python integers, tests/test_host_logic.py restates it on the host).
+    __device__ __forceinline__ void advance()
+    {
         const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
         const uint32_t a0 = (uint32_t)s_lo, a1 = (uint32_t)(s_lo >> 32), a2 = (uint32_t)s_hi, a3 = (uint32_t)(s_hi >> 32);
-        const uint64_t c0 = (uint64_t)a0 * m0;
-        const uint64_t t1 = (uint64_t)a0 * m1 + (c0 >> 32);
-        const uint64_t u1 = (uint64_t)a1 * m0 + (uint32_t)t1;
-        const uint64_t k2 = (t1 >> 32) + (u1 >> 32);
-        const uint64_t v2 = (uint64_t)a0 * m2 + k2;
-        const uint64_t w2 = (uint64_t)a1 * m1 + (uint32_t)v2;
-        const uint64_t x2 = (uint64_t)a2 * m0 + (uint32_t)w2;
-        const uint32_t k3 = (uint32_t)(v2 >> 32) + (uint32_t)(w2 >> 32) + (uint32_t)(x2 >> 32);
-        const uint32_t r3 = a0 * m3 + a1 * m2 + a2 * m1 + a3 * m0 + k3;
-        const uint64_t lo = (uint64_t)(uint32_t)c0 | ((uint64_t)(uint32_t)u1 << 32);
-        uint64_t hi = (uint64_t)(uint32_t)x2 | ((uint64_t)r3 << 32);
+        const uint64_t A0 = mad64(a0, m0, 0);                        // column 0
+        const uint64_t B = mad64(a0, m1, A0 >> 32);                  // column 1: a0 m1 + carry (no overflow)
+        const uint64_t A1 = mad64(a1, m0, B);                        //           + a1 m0 (65 bits: the carry is c1)
+        // (c1 as a compare the compiler sees, not the instruction's own carry-out: on gfx950 a VALU that reads an SGPR
+        // another VALU wrote needs two wait states in between, which only the compiler's hazard pass inserts)
+        const uint32_t c1 = A1 < B ? 1u : 0u;
+        const uint64_t C = mad64(a0, m2, (A1 >> 32) | ((uint64_t)c1 << 32)); // column 2 (carries beyond bit 127 are dropped)
+        const uint64_t D = mad64(a1, m1, C);
+        const uint64_t A2 = mad64(a2, m0, D);
+        uint64_t Q = mad64(a0, m3, 0);                               // column 3: the low 32 bits only
+        Q = mad64(a1, m2, Q);
+        Q = mad64(a2, m1, Q);
+        Q = mad64(a3, m0, Q);
+        const uint32_t r3 = (uint32_t)Q + (uint32_t)(A2 >> 32);
+        const uint64_t lo = (uint64_t)(uint32_t)A0 | ((uint64_t)(uint32_t)A1 << 32);
+        uint64_t hi = (uint64_t)(uint32_t)A2 | ((uint64_t)r3 << 32);
         const uint64_t lo2 = lo + inc_lo;
         hi += inc_hi + (lo2 < lo ? 1ULL : 0ULL);
         s_hi = hi; s_lo = lo2;
-        const uint64_t x = hi ^ lo2;
-        const unsigned rot = (unsigned)(hi >> 58);
-        return (x >> rot) | (x << ((64u - rot) & 63u));
+    }
+    __device__ __forceinline__ uint64_t next64()
+    {
+        advance();
+        // XSL-RR: rotr64(hi ^ lo, hi >> 58) as two 32-bit funnel shifts (v_alignbit_b32 takes the shift modulo 32; a
+        // rotation by 32 or more swaps the halves first)
+        const uint32_t xl = (uint32_t)s_lo ^ (uint32_t)s_hi, xh = (uint32_t)(s_lo >> 32) ^ (uint32_t)(s_hi >> 32);
+        const uint32_t rot = (uint32_t)(s_hi >> 58);
+        const bool sw = rot >= 32u;
+        const uint32_t a = sw ? xh : xl, b = sw ? xl : xh;           // rotating {b, a} by rot & 31
+        const uint32_t lo = __builtin_amdgcn_alignbit(b, a, rot), hi = __builtin_amdgcn_alignbit(a, b, rot);
+        return ((uint64_t)hi << 32) | lo;
     }
     __device__ __forceinline__ uint32_t next32()
     {

@@ -11,6 +11,11 @@
 //           staged once per workgroup into LDS as uint16 {bit15 = terminal[next], next state} and the
 //           step's reward is fetched off the chain, added one step later in the reference's order.
 //           Measured slower (0.376 vs 0.338 ms at 4096 roots): the chain is instruction-bound.
+//           ENV_TABLE_LDSR (round 4, the default wherever the model fits): the WHOLE model lives in LDS -- uint16
+//           transitions, a uint8 index per (s,a) into the table of the model's distinct rewards (<= 256 of them) and that
+//           table -- 3 B per (s,a): the headline's S*A = 50 000 takes 150 of the CU's 160 KB.  An env step then makes
+//           no global-memory request at all; the path stack moves from LDS to registers (depths 1..5) with a global
+//           spill beyond.  One workgroup of up to 16 waves per CU shares the tables.
 //           ENV_CARTPOLE: closed-form dynamics, state in registers.
 //   rng     numpy PCG64 stepped per lane (pcg64.hpp, 128-bit multiply on 32-bit limbs); the draw for
 //           step h+1 is computed on a second generator copy while step h's lookup is in flight and
@@ -68,6 +73,9 @@ struct TreeRef {
     __device__ __forceinline__ int root_handle() const { return LAY == 2 ? AT - 1 : 0; }
     __device__ __forceinline__ UctNode &at(int h) const { return base[LAY == 2 ? (unsigned)h : idx01(h)]; }
     __device__ __forceinline__ UctNode &child(int fc, int a) const { return at(handle(fc, a)); }
+    // sibling a of a group whose first node is *first (= &child(fc, 0)): one address computation per group, the siblings
+    // at constant offsets (the compiler cannot derive that from 32-bit handles: it re-materialises a 64-bit address each)
+    __device__ __forceinline__ static UctNode &sibling(UctNode *first, int a) { return first[LAY == 1 ? a << 6 : a]; }
     __device__ __forceinline__ UctNode &operator[](int n) const
     {
         if (LAY != 2) return base[idx01(n)];
@@ -96,12 +104,18 @@ struct UctArgs {
     int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
     int waves; // wavefronts per workgroup
     const Rec *rec;
-    const uint16_t *t16; // compact transitions (LDS variant), [S*A]
+    const uint16_t *t16; // compact transitions (LDS variants), [S*A]
+    const uint8_t *r8;   // LDS-resident variant: index of reward[s, a] in rdict, [S*A]
+    const double *rdict; //                       the model's distinct reward values, [n_rdict] (<= 256)
+    int n_rdict;
+    int32_t *path_spill; // LDS-resident variant: path handles of depths the registers do not hold, [H + 1][spill_stride]
+    long spill_stride;
     const int32_t *root_state, *root_steps;
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
     const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[TE+1] | tpdiv[A][TE+2]
-    uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8): kernel arguments live in SGPRs
+    uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8), SHIFTED UP by 11 bits (compared with the raw 64-bit draw; 2^53 -> ~0): kernel arguments live in SGPRs
+    int thr_valid;       // how many of the first |A| - 1 thresholds are below 2^53 (the others can never be reached)
     // per-state policies (mp_policy): nullptr / 0 for the state-independent ones
     const double *pol_prior; // [S][pol_stride]
     const uint64_t *pol_thr; // [S][pol_stride]
@@ -143,7 +157,7 @@ __device__ __forceinline__ bool cartpole_step(const mp_cartpole_params &c, doubl
     return x < -c.x_threshold || x > c.x_threshold || theta < -c.theta_threshold || theta > c.theta_threshold;
 }
 
-enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
+enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3 };
 
 // AT > 0: |A| known at compile time (children scored from registers in one pass);
 // AT == 0: any |A| (three passes over the children).  ENV: where an env step comes from.
@@ -165,8 +179,8 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2 };
 template <int AT, int ENV, bool SP = false, bool MK = false, int IL = 0>
 // Per-state-policy kernels with |A| <= 5 are held to the registers of 4 waves per SIMD (they would take 134-140 VGPRs = 3
 // waves; TA 52 %, VALU 45 %, L1 28 % busy: latency-bound -- 2.14 -> 1.91 ms at 262 144 roots with the fourth wave).
-__global__ __launch_bounds__(ENV == ENV_TABLE_LDS ? 1024 : 64,
-                             ENV == ENV_TABLE_LDS ? 1 : (SP && AT > 0 && AT <= 5 && MP_UCT_MIN_WAVES < 4 ? 4 : MP_UCT_MIN_WAVES))
+__global__ __launch_bounds__((ENV == ENV_TABLE_LDS || ENV == ENV_TABLE_LDSR) ? 1024 : 64,
+                             (ENV == ENV_TABLE_LDS || ENV == ENV_TABLE_LDSR) ? 1 : (SP && AT > 0 && AT <= 5 && MP_UCT_MIN_WAVES < 4 ? 4 : MP_UCT_MIN_WAVES))
 void uct_kernel(UctArgs p)
 {
     static_assert(!SP || (AT > 0 && ENV == ENV_TABLE), "per-state policies: table env, |A| known at compile time");
@@ -174,8 +188,14 @@ void uct_kernel(UctArgs p)
     constexpr int NTH = AT > 1 ? AT - 1 : 1; // thresholds that can be reached (the last one is 2^53: never)
     constexpr int NQ = (NTH + 1) / 2;        // 16-byte chunks of a row of exact (uint64) thresholds
     constexpr int NQ32 = (NTH + 3) / 4;      // 16-byte chunks of the fused record's 32-bit thresholds
-    constexpr bool LDSM = ENV == ENV_TABLE_LDS;
+    constexpr bool LDSR = ENV == ENV_TABLE_LDSR;             // transitions AND rewards in LDS, path stack in registers
+    constexpr bool LDSM = ENV == ENV_TABLE_LDS || LDSR;      // transitions in LDS (reward one step behind the state chain)
+    static_assert(!LDSR || (AT > 0 && !SP), "the LDS-resident variant: |A| at compile time, state-independent policies");
     constexpr bool CART = ENV == ENV_CARTPOLE;
+    // RAWU: the rollout compares the generator's raw 64-bit output with thresholds shifted up by 11 bits (thr <= out >> 11
+    // <=> thr << 11 <= out) instead of shifting every draw down to its 53 random bits
+    constexpr bool RAWU = AT > 0 && !SP;
+    constexpr int USH = RAWU ? 0 : 11;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int A = AT > 0 ? AT : p.A, H = p.horizon, E = p.episodes;
@@ -193,9 +213,20 @@ void uct_kernel(UctArgs p)
     // tables hold) take the IEEE division itself -- the same correctly rounded quotient the host put in the tables
     auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
     auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
-    int32_t *path_all = reinterpret_cast<int32_t *>(lds_d + ntab); // [H + 1][waves * 64]
-    uint16_t *t16 = reinterpret_cast<uint16_t *>(path_all + (H + 1) * nthreads);
+    int32_t *path_all = reinterpret_cast<int32_t *>(lds_d + ntab); // [H + 1][waves * 64]  (not in the LDS-resident variant)
+    const int ntab2 = (ntab + 1) & ~1;                             // (16-byte alignment of what follows)
+    const double *rdict = lds_d + ntab2;                           // LDSR: [n_rdict] distinct rewards
+    uint16_t *t16 = LDSR ? reinterpret_cast<uint16_t *>(lds_d + ntab2 + ((p.n_rdict + 1) & ~1))
+                         : reinterpret_cast<uint16_t *>(path_all + (H + 1) * nthreads);
+    uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((p.S * A + 7) & ~7)); // LDSR: [S*A]
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
+    if (LDSR) {
+        for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
+        const int n16 = (p.S * A + 15) >> 4; // (the device array is padded to whole 16-byte chunks)
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.r8);
+        uint4 *dst = reinterpret_cast<uint4 *>(r8);
+        for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+    }
     if (LDSM) {
         // S*A uint16 entries, staged with 16-byte loads where the tail allows
         const int n = p.S * A;
@@ -267,6 +298,35 @@ void uct_kernel(UctArgs p)
     int kc[KEEP];
 #pragma unroll
     for (int i = 0; i < KEEP; ++i) { kv[i] = 0.0; kc[i] = 0; }
+    // where the handles of the path nodes live: a per-lane stack in LDS ([depth][lane]) -- or, when the model fills the
+    // LDS (LDSR), registers for depths 1 .. 1 + KEEP and a global spill array beyond (rarely reached: mean depth ~2)
+    int ph1 = 0, ph[KEEP];
+#pragma unroll
+    for (int i = 0; i < KEEP; ++i) ph[i] = 0;
+    // (macros, not lambdas: a closure over `ph` keeps a dead copy of the array in scratch memory)
+#define PATH_PUT(d_, h_)                                                                        \
+    do {                                                                                        \
+        const int pd_ = (d_), phv_ = (h_);                                                      \
+        if constexpr (!LDSR) {                                                                  \
+            path[pd_ * nthreads + lane] = phv_;                                                 \
+        } else {                                                                                \
+            if (pd_ == 1) ph1 = phv_;                                                           \
+            _Pragma("unroll") for (int i_ = 0; i_ < KEEP; ++i_) ph[i_] = pd_ == 2 + i_ ? phv_ : ph[i_]; \
+            if (pd_ >= 2 + KEEP) p.path_spill[(size_t)pd_ * p.spill_stride + r] = phv_;        \
+        }                                                                                       \
+    } while (0)
+#define PATH_GET(out_, d_)                                                                      \
+    do {                                                                                        \
+        const int pd_ = (d_);                                                                   \
+        if constexpr (!LDSR) {                                                                  \
+            out_ = path[pd_ * nthreads + lane];                                                 \
+        } else {                                                                                \
+            int hh_ = ph1;                                                                      \
+            _Pragma("unroll") for (int i_ = 0; i_ < KEEP; ++i_) hh_ = pd_ == 2 + i_ ? ph[i_] : hh_; \
+            if (pd_ >= 2 + KEEP) hh_ = p.path_spill[(size_t)pd_ * p.spill_stride + r];          \
+            out_ = hh_;                                                                         \
+        }                                                                                       \
+    } while (0)
 
 #ifdef MP_PROFILE
     long long t_sel = 0, t_expd = 0, t_roll = 0, t_bak = 0, n_sel = 0, n_roll = 0;
@@ -284,7 +344,7 @@ void uct_kernel(UctArgs p)
         bool cur_term = root_term; // terminal[s] of the state the next action is taken from
         double total = 0.0;
         uint32_t cur_mask = mask0; // MK: listed actions of the state the descent is in
-        path[lane] = tree.root_handle();
+        if (!RC) PATH_PUT(0, tree.root_handle());
         int hnode = tree.root_handle(); // where `node` lives (TreeRef handle)
         int fc = RC ? tf0 : tree[0].first_child;
         // ---- selection, mcts.py:143-149
@@ -299,8 +359,9 @@ void uct_kernel(UctArgs p)
 #pragma unroll
                     for (int a = 0; a < AR; ++a) { c[a].value = tv[a]; c[a].count = tc[a]; c[a].first_child = tf[a]; }
                 } else {
+                    UctNode *grp = &tree.child(fc, 0);
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) c[a] = tree.child(fc, a);
+                    for (int a = 0; a < AR; ++a) c[a] = tree.sibling(grp, a);
                 }
                 double sc[AR];
                 if (SP) {
@@ -373,7 +434,7 @@ void uct_kernel(UctArgs p)
                 reward = 1.0;
             } else if (LDSM) {
                 const uint32_t e = t16[idx];
-                reward = rec[idx].reward;
+                reward = LDSR ? rdict[r8[idx]] : rec[idx].reward;
                 const bool next_term = (e & 0x8000u) != 0;
                 terminal = p.done_on_next ? next_term : cur_term;
                 cur_term = next_term;
@@ -396,7 +457,7 @@ void uct_kernel(UctArgs p)
             node = fc + act;
             hnode = tree.handle(fc, act);
             ++depth;
-            path[depth * nthreads + lane] = hnode;
+            PATH_PUT(depth, hnode);
             fc = nfc;
 #ifdef MP_PROFILE
             ++n_sel;
@@ -419,13 +480,21 @@ void uct_kernel(UctArgs p)
 #pragma unroll
                     for (int a = 0; a < AR; ++a) tc[a] = (cur_mask >> a) & 1u ? 0 : -1;
                 } else {
+                    UctNode *grp = &tree.child(n_nodes, 0);
                     for (int a = 0; a < A; ++a) {
                         n.count = (cur_mask >> a) & 1u ? 0 : -1;
-                        tree.child(n_nodes, a) = n;
+                        tree.sibling(grp, a) = n;
                     }
                 }
-            } else if (!(RC && node == 0)) // the root's children were zero-initialised in registers
-                for (int a = 0; a < A; ++a) tree.child(n_nodes, a) = n;
+            } else if (!(RC && node == 0)) { // the root's children were zero-initialised in registers
+                UctNode *grp = &tree.child(n_nodes, 0);
+                if (AT > 0) {
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) tree.sibling(grp, a) = n;
+                } else {
+                    for (int a = 0; a < A; ++a) tree.sibling(grp, a) = n;
+                }
+            }
             n_nodes += A;
         }
         PROF_T(c2);
@@ -437,7 +506,7 @@ void uct_kernel(UctArgs p)
         if (!terminal && depth < H) {
             int h = depth;
             Pcg64 ga = g, gb = g;
-            uint64_t u = ga.next64() >> 11; // the 53 random bits of Generator.random()
+            uint64_t u = ga.next64() >> USH; // the 53 random bits of Generator.random() (RAWU: all 64, see thr_arg)
             bool stopped_in_a = true;
             double r_a = 0.0, r_b = 0.0, g_a = 0.0, g_b = 0.0;
             bool have_b = false;
@@ -479,8 +548,12 @@ void uct_kernel(UctArgs p)
                         for (int a = 0; a < NTH; ++a) act += tx[a] <= u ? 1 : 0;
                     }
                 } else if (AT > 0) {
+                    // (the last threshold, 2^53, is never reached; thresholds of 2^53 before it -- trailing zero
+                    // probabilities -- are ~0 here and form a suffix: thr_valid caps the count so that even the draw
+                    // 2^64 - 1 selects what searchsorted selects)
 #pragma unroll
-                    for (int a = 0; a < AR; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands
+                    for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands
+                    act = min(act, p.thr_valid);
                 } else {
                     for (int a = 0; a < A; ++a) act += thr[a] <= u ? 1 : 0;
                 }
@@ -490,15 +563,15 @@ void uct_kernel(UctArgs p)
                 bool term_h;
                 if (CART) {
                     gspec = gcur;
-                    unext = gspec.next64() >> 11;
+                    unext = gspec.next64() >> USH;
                     term_h = cartpole_step(p.cp, x4, act);
                     total += g_mine * 1.0;
                 } else if (LDSM) {
                     const unsigned idx = ridx;
                     const uint32_t e = t16[idx];
-                    r_mine = rec[idx].reward;
+                    r_mine = LDSR ? rdict[r8[idx]] : rec[idx].reward;
                     gspec = gcur;
-                    unext = gspec.next64() >> 11;
+                    unext = gspec.next64() >> USH;
                     if (add_prev) total += g_prev * r_prev;
                     const bool next_term = (e & 0x8000u) != 0;
                     term_h = p.done_on_next ? next_term : cur_term;
@@ -509,7 +582,7 @@ void uct_kernel(UctArgs p)
                     // (an ambiguous draw -- ~0.4 % of the steps -- fetches the exact row, as above)
                     const uint4 q0 = p.pol_frec[ridx];
                     gspec = gcur;
-                    unext = gspec.next64() >> 11; // overlaps the gather
+                    unext = gspec.next64() >> USH; // overlaps the gather
                     term_h = (q0.y & done_bit) != 0;
                     s = (int32_t)(q0.x & 0xfffffu);
                     total += g_mine * __hiloint2double((int)q0.w, (int)q0.z);
@@ -524,7 +597,7 @@ void uct_kernel(UctArgs p)
 #pragma unroll
                     for (int q = 0; q < NQ32; ++q) qt[q] = fr[1 + q];
                     gspec = gcur;
-                    unext = gspec.next64() >> 11; // overlaps the gather
+                    unext = gspec.next64() >> USH; // overlaps the gather
                     term_h = (q0.y & done_bit) != 0;
                     s = (int32_t)q0.x;
                     total += g_mine * __hiloint2double((int)q0.w, (int)q0.z);
@@ -538,7 +611,7 @@ void uct_kernel(UctArgs p)
                 } else {
                     const Rec rc = rec[ridx];
                     gspec = gcur;
-                    unext = gspec.next64() >> 11; // overlaps the gather
+                    unext = gspec.next64() >> USH; // overlaps the gather
                     term_h = (rc.flags & done_bit) != 0;
                     s = rc.next;
                     total += g_mine * rc.reward;
@@ -563,7 +636,8 @@ void uct_kernel(UctArgs p)
         PROF_T(c3);
         // ---- backup, mcts.py:248-265: the same return for every node on the path
         for (int d = depth; d >= (RC ? 2 : 0); --d) {
-            const int n = path[d * nthreads + lane];
+            int n;
+            PATH_GET(n, d);
             if (RC && d < 2 + KEEP) {
                 double v = kv[0];
                 int cnt = kc[0];
@@ -583,7 +657,9 @@ void uct_kernel(UctArgs p)
         }
         if (RC) {
             if (depth >= 1) {
-                const int n = path[nthreads + lane] - tree.handle(1, 0); // level-1 node: which child of the root
+                int n;
+                PATH_GET(n, 1);
+                n -= tree.handle(1, 0); // level-1 node: which child of the root
                 double v = tv[0];
                 int cnt = tc[0];
 #pragma unroll
@@ -720,12 +796,30 @@ static int uct_lanes_per_wave()
     return 64;
 }
 
+// whether the LDS-resident model is used when nothing is forced (MP_UCT_MODEL unset)
+// Measured on MI355X (headline table, 33 x 30; profiles/r04_uct_ldsr.md): kernel ms global / LDS-resident at 8 192 roots
+// 0.342 / 0.357, 32 768 0.376 / 0.383, 65 536 0.412 / 0.369, 131 072 0.564 / 0.473, 262 144 1.049 / 0.781, 524 288
+// 2.050 / 1.545 -- staging 150 KB per workgroup costs ~25 us and a lone wave per SIMD hides the gather anyway, so the
+// variant is the default from one wave per SIMD (four per CU) upwards.
+static bool uct_ldsr_default(bool forced, long n_roots, int cus)
+{
+    if (forced) return true;
+    return (n_roots + 63) / 64 >= 4L * (cus > 0 ? cus : 256);
+}
+
 template <int AT>
-static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed)
+static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed, bool ldsr = false)
 {
     const int roots_per_block = a.waves * a.lanes;
     const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
-    if (sp && listed) {
+    if (ldsr) {
+        if constexpr (AT > 0) {
+            if (lds > 64 * 1024)
+                MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<AT, ENV_TABLE_LDSR, false, false, 2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_LDSR, false, false, 2>), grid, block, lds, st, a);
+        }
+    } else if (sp && listed) {
         if constexpr (AT > 0) {
             if (a.tree_il == 2) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true, 2>), grid, block, lds, st, a);
             else if (a.tree_il == 1) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE, true, true, 1>), grid, block, lds, st, a);
@@ -839,9 +933,17 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.table_n = TE;
     a.done_on_next = model->done_on_next; a.max_steps = model->max_steps; a.max_plan_len = max_plan_len;
     a.rec = model->rec; a.t16 = model->t16; a.tab = d_tab;
+    a.thr_valid = 0;
     for (int i = 0; i < 8; ++i) {
         a.thr_arg[i] = ~0ULL;
-        if (i < A) memcpy(&a.thr_arg[i], &cdf[i], sizeof(uint64_t));
+        if (i < A) {
+            uint64_t t;
+            memcpy(&t, &cdf[i], sizeof(uint64_t));
+            if (t < (1ULL << 53)) {
+                a.thr_arg[i] = t << 11;
+                if (i < A - 1) a.thr_valid = i + 1;     // (thresholds are non-decreasing: the valid ones are a prefix)
+            }
+        }
     }
     a.cp = model->cp; a.root_x = nullptr;
     a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_frec = pol ? pol->frec : nullptr;
@@ -868,19 +970,42 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // default: group-interleaved wherever |A| has a compile-time specialisation (262 144 roots: 1.05-1.07 ms against
     // 1.16 ms root-major and 1.09 ms interleaved; 4 096 roots and single roots: no difference)
     const int want_il = !lay ? (at_known ? 2 : 0) : (lay[0] == 'i' ? 1 : (lay[0] == 'g' && at_known ? 2 : 0));
-    bool ldsm = !cart && !pol && model->t16 != nullptr && force && force[0] == 'l'; // (the LDS variant keeps root-major trees)
-    a.lanes = ldsm ? 64 : uct_lanes_per_wave();
+    bool ldsm = !cart && !pol && model->t16 != nullptr && force && !strcmp(force, "lds"); // (the LDS variant keeps root-major trees)
+    // LDS-RESIDENT model (transitions + reward indices + reward table in LDS, nothing of an env step in global memory):
+    // table models with S < 32768, at most 256 distinct rewards, |A| with a specialisation, whose 3 B per (s,a) fit the
+    // CU's LDS next to the per-call tables.  MP_UCT_MODEL=ldsr forces it on, =global off.
+    bool ldsr = !cart && !pol && at_known && model->t16 != nullptr && model->r8 != nullptr && want_il == 2 &&
+                !(force && strcmp(force, "ldsr") != 0) && uct_ldsr_default(force != nullptr, n_roots, ctx->prop.multiProcessorCount);
+    const size_t sa16 = ((size_t)model->S * A + 15) & ~(size_t)15;
+    const size_t lds_ldsr = (((ntab + 1) & ~(size_t)1) + (((size_t)model->n_rdict + 1) & ~(size_t)1)) * sizeof(double) +
+                            (((size_t)model->S * A + 7) & ~(size_t)7) * 2 + sa16;
+    if (ldsr && lds_ldsr > kLdsBytes) {
+        if (force && !strcmp(force, "ldsr")) return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds_ldsr);
+        ldsr = false;
+    }
+    if (ldsr) ldsm = false;
+    a.r8 = model->r8; a.rdict = model->rdict; a.n_rdict = model->n_rdict; a.path_spill = nullptr; a.spill_stride = 0;
+    a.lanes = (ldsm || ldsr) ? 64 : uct_lanes_per_wave();
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
+    if (ldsr) {
+        // one workgroup per CU shares the tables: as many waves per workgroup as it takes to put the batch on the chip's
+        // CUs (a power of two <= 16, so that chunk boundaries -- multiples of 1024 roots -- are workgroup boundaries)
+        const long total_waves = ((long)n_roots + 63) / 64, cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        long w = (total_waves + cus - 1) / cus;
+        if (const char *e = getenv("MP_UCT_LDSR_WAVES")) w = atol(e);
+        a.waves = 1;
+        while (a.waves < w && a.waves < 16) a.waves <<= 1;
+    }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
-    size_t lds = lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0);
+    size_t lds = ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0);
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
         ldsm = false;
         a.lanes = uct_lanes_per_wave(); a.waves = 1;
         lds = ntab * sizeof(double) + (size_t)(H + 1) * 64 * sizeof(int32_t);
     }
-    if (!ldsm && lds > 64 * 1024)
+    if (!ldsm && !ldsr && lds > 64 * 1024)
         return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
 
     // trees: fresh ones, or (step_strategy "subtree") the kept ones re-rooted into the other buffer with room
@@ -906,11 +1031,17 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         ctx->tree.armed = false;
         ctx->tree.buf = 0;
         ctx->tree.kept_bound = 1 + (long)horizon * episodes * A;
-        ctx->tree.il = (!cart && !ldsm) ? want_il : 0;
+        ctx->tree.il = (!cart && !ldsm) ? want_il : 0;   // (ldsr implies want_il == 2)
         MP_TRY(ws_get(ctx, WS_TREE0, (size_t)((n_roots + 63) & ~63) * tree_stride_alloc(ctx->tree.il, cap_use, A), &a.tree));
     }
     a.cap = (int)cap_use;
     a.tree_il = ctx->tree.il;
+    if (ldsr && ctx->tree.il != 2) ldsr = false, ldsm = false; // (a kept tree in another layout: the default kernel)
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : "uct_global"))));
+    if (ldsr) {
+        a.spill_stride = ((long)n_roots + 63) & ~63L;
+        MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
+    }
     ctx->tree.kind = 1; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap_use;
 
     // ---- staging.  Device arrays are used in place; host arrays get device twins (no copy yet: the copies are issued
@@ -997,6 +1128,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (c.root_steps) c.root_steps += r0;
         c.rng += (size_t)r0 * 6;
         c.tree += (long)(r0 >> 6) * tree_off_per_block;
+        if (c.path_spill) c.path_spill += r0;
         if (c.n_nodes_in) c.n_nodes_in += r0;
         c.n_nodes_out += r0;
         if (c.plans) c.plans += (size_t)r0 * max_plan_len;
@@ -1010,12 +1142,12 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
         } else
         switch (A) {
-        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed)); break;
-        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed)); break;
-        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed)); break;
-        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed)); break;
-        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed)); break;
-        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed)); break;
+        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
+        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
+        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
+        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
+        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
+        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
         default:
             if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
             MP_TRY(uct_launch<0>(c, ldsm, lds, s, false, false));

@@ -78,6 +78,7 @@ SIGNATURES = {
     "mp_saopd_export": (C.c_int, [_vp, c_i32, c_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mp_olop_allocation": (C.c_int, [c_i32, c_f64, P(c_i32), P(c_i32)]),
     "mp_last_kernel_ms": (C.c_int, [_vp, P(c_f64), P(c_i32)]),
+    "mp_last_kernel_variant": (C.c_char_p, [_vp]),
     "mp_env_step": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, _vp, c_i32, c_i32, _vp, _vp, _vp, _vp, c_i32, _vp, c_i32]),
     "mp_greedy_actions": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32]),
     "mp_host_alloc": (C.c_int, [_vp, c_i64, P(_vp)]),
@@ -245,6 +246,10 @@ class Context(object):
         ms, n = c_f64(), c_i32()
         _check(self._lib.mp_last_kernel_ms(self._h, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def last_kernel_variant(self):
+        """Which kernel variant the last UCT plan launched ("uct_global", "uct_ldsr", ...)."""
+        return self._lib.mp_last_kernel_variant(self._h).decode()
 
     # ---- host-inclusive fast path: pinned arrays, device-resident generator records -------------------------
     def pinned(self, spec):

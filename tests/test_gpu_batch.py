@@ -44,16 +44,78 @@ def _cmp_uct(ctx, cfg, n_roots, episodes, horizon, gamma, temperature, prior, ro
     return out
 
 
-@pytest.mark.parametrize("variant", ["global", "lds"])
+@pytest.mark.parametrize("variant", ["global", "lds", "ldsr"])
 def test_uct_batch_highway_headline_shape(ctx, variant, monkeypatch):
     """Headline configuration (highway-shaped S=10 000, A=5, 33 episodes x horizon 30), 1536 ragged roots,
-    with the model gathered from HBM/L2 records (default) and with the transition table staged in LDS."""
+    with the model gathered from HBM/L2 records (default at this size), with the transition table staged in LDS, and with
+    the whole model resident in LDS (round 4: the default from 65 536 roots upwards)."""
     from rl_agents_amd.envs import generators
     monkeypatch.setenv("MP_UCT_MODEL", variant)
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     p = np.ones(5) / 5
     out = _cmp_uct(ctx, cfg, 1536 + 17, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=1)
     assert out["env_steps"].max() <= 33 * 30
+    assert ctx.last_kernel_variant() == "uct_" + variant
+
+
+def _coarse(cfg, levels=16):
+    """The same model with rewards on a grid of `levels` + 1 values: at most 256 distinct rewards, what the LDS-resident
+    variant needs (its reward table is indexed by a byte)."""
+    return dict(cfg, reward=np.round(np.asarray(cfg["reward"]) * levels) / levels)
+
+
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 8])
+def test_uct_lds_resident_model_action_counts(ctx, n_actions, monkeypatch):
+    """ENV_TABLE_LDSR for every |A| it is compiled for: preference policies, TimeLimit truncation with steps already
+    taken, both terminal conventions, ragged batch sizes around the workgroup size."""
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_MODEL", "ldsr")
+    cfg = _coarse(generators.random_deterministic(257, n_actions, seed=n_actions, terminal_rate=0.05))
+    p = np.ones(n_actions) / n_actions
+    _cmp_uct(ctx, cfg, 200, 25, 9, 0.9, 7.5, p, p, seed=n_actions)
+    assert ctx.last_kernel_variant() == "uct_ldsr"
+    pref = np.ones(n_actions) / (n_actions - 1 + 3.0)
+    pref[1] *= 3.0
+    steps0 = np.random.Generator(np.random.PCG64(5)).integers(0, 6, size=1100).astype(np.int32)
+    monkeypatch.setenv("MP_UCT_LDSR_WAVES", "16")          # whole 1024-thread workgroups and a ragged last one
+    _cmp_uct(ctx, cfg, 1100, 40, 12, 0.95, 3.0, pref, pref, seed=3, max_steps=10, steps0=steps0)
+    _cmp_uct(ctx, cfg, 1100, 40, 12, 0.95, 3.0, pref, p, seed=4, done_rule="next")
+    assert ctx.last_kernel_variant() == "uct_ldsr"
+
+
+def test_uct_lds_resident_model_deep_trees_spill_the_path(ctx, monkeypatch):
+    """Paths deeper than the register-held levels (depths 1..5) go through the global spill array: 600 episodes at a
+    small exploration constant on a two-action chain drive the tree to depth > 12."""
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_MODEL", "ldsr")
+    cfg = _coarse(generators.random_deterministic(97, 2, seed=5, terminal_rate=0.0), levels=4)
+    p = np.ones(2) / 2
+    out = _cmp_uct(ctx, cfg, 130, 600, 25, 0.97, 0.05, p, p, seed=6)
+    assert ctx.last_kernel_variant() == "uct_ldsr" and out["plan_len"].max() > 8
+    cfg3 = _coarse(generators.random_deterministic(64, 3, seed=8, terminal_rate=0.02), levels=8)
+    p3 = np.ones(3) / 3
+    out = _cmp_uct(ctx, cfg3, 70, 900, 30, 0.99, 0.02, p3, p3, seed=7)
+    assert out["plan_len"].max() > 8
+
+
+def test_uct_lds_resident_model_falls_back(ctx, monkeypatch):
+    """More than 256 distinct rewards: no byte-indexed reward table exists and the record-gather kernel runs, also when
+    the variant is asked for; a model that does not fit the LDS is refused when forced."""
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_MODEL", "ldsr")
+    cfg = generators.random_deterministic(257, 4, seed=4, terminal_rate=0.05)     # 1028 distinct rewards
+    p = np.ones(4) / 4
+    _cmp_uct(ctx, cfg, 100, 20, 8, 0.9, 5.0, p, p, seed=1)
+    assert ctx.last_kernel_variant() == "uct_global"
+    big = _coarse(generators.random_deterministic(20000, 4, seed=4, terminal_rate=0.05))   # 240 KB of tables
+    model = ctx.load_table(big["transition"], big["reward"], big["terminal"])
+    with pytest.raises(native.NativeError):
+        ctx.uct_plan(model, np.zeros(4, np.int32), 5, 5, 0.9, 5.0, p, p, _rng_states(4), max_plan_len=5)
+    monkeypatch.delenv("MP_UCT_MODEL")
+    ctx.uct_plan(model, np.zeros(4, np.int32), 5, 5, 0.9, 5.0, p, p, _rng_states(4), max_plan_len=5)
+    assert ctx.last_kernel_variant() == "uct_global"
+    model.close()
 
 
 @pytest.mark.parametrize("variant", ["global", "lds"])

@@ -134,10 +134,14 @@ def test_uct_golden(ctx, golden):
         model.close()
 
 
+@pytest.mark.parametrize("variant", ["default", "ldsr"])
 @pytest.mark.parametrize("tag", ["subtree_large1", "subtree_highway"])
-def test_uct_subtree_strategy_golden(ctx, golden, tag):
+def test_uct_subtree_strategy_golden(ctx, golden, tag, variant, monkeypatch):
     """step_strategy 'subtree': mp_uct_step_tree re-roots the kept tree, the next mp_uct_plan continues on it;
-    plans, trees and generator state equal the reference's over a 5-step episode."""
+    plans, trees and generator state equal the reference's over a 5-step episode -- with the record-gather kernel and with
+    the LDS-resident model (the highway table has few distinct rewards; large1 has 500 and falls back)."""
+    if variant != "default":
+        monkeypatch.setenv("MP_UCT_MODEL", variant)
     z = golden["uct"]
     p = "uct/" + tag
     cfg = mdp_from_golden(z, p + "/mdp")

@@ -1,0 +1,21 @@
+#!/bin/bash
+# round-4 call 5: LDS-resident variant as the default for large batches: whole suite + default bench + 2-rank dry run
+cd /root/repo
+mkdir -p gpurun_out/r04
+python -m pytest tests -m gpu -x -q > gpurun_out/r04/pytest_gpu5.log 2>&1
+echo "pytest rc=$?" >> gpurun_out/r04/pytest_gpu5.log
+tail -8 gpurun_out/r04/pytest_gpu5.log
+timeout 600 python bench.py > gpurun_out/r04/bench_default5.json 2> gpurun_out/r04/bench_default5.err
+tail -3 gpurun_out/r04/bench_default5.err
+timeout 400 python bench.py --gpus 2 --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/r04/bench_2rank_dry5.json 2> gpurun_out/r04/bench_2rank_dry5.err
+python - <<'PY'
+import json
+for f in ('gpurun_out/r04/bench_default5.json','gpurun_out/r04/bench_2rank_dry5.json'):
+    try:
+        d=json.loads([l for l in open(f) if l.startswith('{')][-1])
+        print(f, 'value %.4g'%d['value'], 'ms %.3f'%d['ms_per_step'], 'frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'), d['roofline'].get('kernel_variant'), 'parity', d.get('parity_sample',{}).get('result'), 'v4096 %.4g'%d['value_roots4096'], 'host incl %.4g'%d['value_host_inclusive'])
+        print('  ranks', {k:v for k,v in d['ranks'].items() if k not in ('devices','cross_check_what')})
+        for k,v in (d.get('workloads') or {}).items():
+            print('  ', k, {kk:(round(vv,4) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk in ('value','kernel_ms','frac','parity_sample','error')})
+    except Exception as e: print(f,'ERR',e)
+PY
