@@ -252,6 +252,14 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
  */
 int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout,
                           const uint8_t *listed, mp_policy **out);
+/* mp_policy_load_listed + the order in which the ROLLOUT policy lists the actions of each state: rollout_slot uint8 [S, A],
+ * slot k of state s is column rollout_slot[s, k] (a permutation per state, zero-probability columns last; NULL = the
+ * column order).  The columns -- the order of a node's children and of every tie-break -- follow the PRIOR policy's
+ * listing; the rollout's inverse CDF (mcts.py:172, np_random.choice(actions, p=...)) runs over ITS listing.  The two
+ * differ when one of them is the `random` policy, which lists np.arange(n) whatever the environment lists (mcts.py:46-57),
+ * on an environment whose get_available_actions() is not ascending (highway-env: IDLE first). */
+int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout,
+                           const uint8_t *listed, const uint8_t *rollout_slot, mp_policy **out);
 int mp_policy_free(mp_policy *policy);
 int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const void *root_state,
                        const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,

@@ -112,6 +112,7 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
         budget = int(cfg["budget"])
         if cfg["gamma"] == 1 and budget >= model.A:
             raise ZeroDivisionError("float division by zero")       # gamma ** depth / (1 - gamma), deterministic.py:53
+        self.about_to_plan()
         out = self.models.ctx.ropd_plan(model, rs, budget, cfg["gamma"], cfg.get("terminal_reward", 0), rng_states,
                                         max_plan_len=budget // model.A + 1)
         if (out["status"] == native.ERR_REWARD_RANGE).any():
@@ -128,7 +129,7 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
         arrays = self.models.ctx.ropd_tree(root, 1 + (int(self.config["budget"]) // a) * a, m)
         lower, upper = arrays["lower"], arrays["upper"]
         arrays["value_lower_min"], arrays["value_upper_min"] = lower.min(axis=1), upper.min(axis=1)
-        tree = build_tree(arrays, "value_upper_min", extra=("value_lower_min", "value_upper_min"))
+        tree = build_tree(arrays, "value_upper_min", extra=("value_lower_min", "value_upper_min"), planner=self)
         # per-model vectors as the reference's nodes hold them: ndarrays on leaves, the backed-up scalars once expanded
         by_id = [tree] + [None] * (len(arrays["parent"]) - 1)
         for i in range(1, len(by_id)):       # creation order: parents come first

@@ -52,8 +52,16 @@ class AbstractTreeSearchAgent(AbstractAgent):
             actions = self.planner.plan(state=self.planning_env(), observation=observation)
         else:
             actions = self.previous_actions[1:]
+        self.write_tree()
         self.previous_actions = actions
         return actions
+
+    def write_tree(self):
+        """With ``display_tree`` and a summary writer set (``set_writer``): the expanded tree of the last plan as an
+        image (abstract.py:104-106; the plot is tree_search/graphics.py:115-166 restated in this package's graphics)."""
+        if self.config["display_tree"] and self.writer:
+            from rl_agents_amd.agents.tree_search.graphics import TreePlot
+            TreePlot(self.planner, max_depth=6).plot_to_writer(self.writer, epoch=self.steps, show=True)
 
     def step(self, actions):
         """Receding-horizon bookkeeping; True when a new plan is required (abstract.py:70-82)."""
@@ -97,17 +105,19 @@ class AbstractTreeSearchAgent(AbstractAgent):
 
 
 class Node(object):
-    """Read-only view of one node of an exported device tree, with the attributes the reference's
-    tree consumers read (tree_search/graphics.py:19-37, abstract.py:246-265): children, parent, count,
-    get_value(), depth."""
+    """One node of an exported device tree, with what the reference's tree consumers use (tree_search/graphics.py:19-37,
+    115-166; abstract.py:212-358): ``children`` (dict keyed by action label, creation order), ``parent``, ``count``,
+    ``get_value()``, ``depth``, ``planner``, ``path()`` / ``sequence()``, ``breadth_first_search``, ``get_trajectories``,
+    ``get_obs_visits``.  Read-only: the tree itself lives on the device; this is its picture after a plan."""
 
-    def __init__(self, parent, action, count, value, depth):
+    def __init__(self, parent, action, count, value, depth, planner=None):
         self.parent = parent
         self.action = action
         self.children = {}
         self.count = count
         self.value = value
         self.depth = depth
+        self.planner = planner
 
     def get_value(self):
         return self.value
@@ -134,22 +144,127 @@ class Node(object):
         return self.get_value() + temperature * len(self.parent.children) * getattr(self, "prior", 1.0) / (self.count + 1)
 
     def path(self):
+        """Action labels from the root to this node (abstract.py:269-281; a list -- the reference returns an iterator)."""
         node, actions = self, []
         while node.parent is not None:
             actions.append(node.action)
             node = node.parent
         return actions[::-1]
 
+    def sequence(self):
+        """Nodes from the root to this node (abstract.py:283-293)."""
+        node, nodes = self, [self]
+        while node.parent is not None:
+            node = node.parent
+            nodes.append(node)
+        return nodes[::-1]
 
-def build_tree(arrays, value_key, extra=(), prior=None):
+    @staticmethod
+    def all_argmax(x):
+        x = np.asarray(x)
+        return np.flatnonzero(x == x.max())
+
+    @staticmethod
+    def breadth_first_search(root, operator=None, condition=None, condition_blocking=True):
+        """Level-order traversal (abstract.py:246-265): yields ``operator(node, path)`` -- or ``(node, path)`` -- for every
+        node that meets ``condition`` (all of them without one); with ``condition_blocking`` the subtree below a node that
+        met the condition is not explored.  ``path`` = the action labels from ``root``."""
+        from collections import deque
+        todo = deque([(root, [])])
+        while todo:
+            node, path = todo.popleft()
+            met = condition is None or bool(condition(node))
+            if met:
+                yield operator(node, path) if operator else (node, path)
+            if condition is None or not condition_blocking or not met:
+                for key, child in node.children.items():
+                    todo.append((child, path + [key]))
+
+    def get_trajectories(self, full_trajectories=True, include_leaves=True):
+        """The nodes of this subtree as the reference lists them (abstract.py:319-339): with ``full_trajectories`` one node
+        sequence per root-to-leaf path (this node first); otherwise the single nodes, every child's subtree before the
+        node itself; leaves only with ``include_leaves``."""
+        if full_trajectories:
+            out = []
+            stack = [(self, [self])]
+            while stack:                                    # depth first, children in dict order
+                node, seq = stack.pop()
+                if node.children:
+                    for child in reversed(list(node.children.values())):
+                        stack.append((child, seq + [child]))
+                elif include_leaves:                        # (without leaves every path ends in nothing: [])
+                    out.append(seq)
+            return out
+        out = []
+
+        def visit(node):                                    # post-order: children first, then the node
+            if node.children:
+                for child in node.children.values():
+                    visit(child)
+                out.append(node)
+            elif include_leaves:
+                out.append(node)
+        import sys
+        limit = sys.getrecursionlimit()
+        sys.setrecursionlimit(max(limit, 10000))
+        try:
+            visit(self)
+        finally:
+            sys.setrecursionlimit(limit)
+        return out
+
+    def get_obs_visits(self, state=None):
+        """How often each observation is the one of an EXPANDED node of this subtree (abstract.py:341-358) ->
+        (visits, updates), dicts keyed by ``str(observation)``.  Nodes that carry their ``observation`` (the optimistic
+        planners' nodes: the state reached) are counted directly.  Otherwise the reference replays every node's action
+        path on a copy of the environment ``state``; here the state a node is reached in is known from the device model
+        (``node.state``: root state + transition table, no stepping), and only trees exported without it (CartPole) replay
+        on copies of ``state``.  As in the reference a node with an EMPTY path -- the root -- is booked under the
+        observation of the node listed before it (its loop variable is simply not reassigned)."""
+        from collections import defaultdict
+        visits, updates = defaultdict(int), defaultdict(int)
+        nodes = self.get_trajectories(full_trajectories=False, include_leaves=False)
+        if hasattr(self, "observation"):
+            for node in nodes:
+                if hasattr(node, "observation"):
+                    visits[str(node.observation)] += 1
+                    if hasattr(node, "updates_count"):
+                        updates[str(node.observation)] += node.updates_count
+            return visits, updates
+        observation, bound = None, False
+        for node in nodes:
+            path = node.path()
+            if path:
+                if hasattr(node, "state"):
+                    observation = node.state
+                else:
+                    import copy
+                    env = copy.deepcopy(getattr(state, "unwrapped", state))
+                    for action in path:
+                        observation = env.step(action)[0]
+                bound = True
+            if not bound:
+                raise NameError("the root is the only expanded node: the reference's replay has no observation to book it under")
+            visits[str(observation)] += 1
+        return visits, updates
+
+    def __str__(self):
+        return "{} (n:{}, v:{:.2f})".format(self.path(), self.count, self.get_value())
+
+
+def build_tree(arrays, value_key, extra=(), prior=None, planner=None, transition=None, root_state=None):
     """Creation-order arrays (parent, action, count, <value_key>, ...) -> linked :class:`Node` objects.
-    ``prior``: per-action prior probabilities, attached to the nodes as ``node.prior`` (mcts.py:237-246)."""
+    ``prior``: per-action prior probabilities, attached to the nodes as ``node.prior`` (mcts.py:237-246).
+    ``transition`` [S, A] (environment action ids) + ``root_state``: every node also gets ``node.state``, the state its
+    action sequence reaches (the observation a replay of ``node.path()`` would end on)."""
     parent, action = arrays["parent"], arrays["action"]
     nodes = []
     for i in range(len(parent)):
         par = nodes[parent[i]] if parent[i] >= 0 else None
         node = Node(par, int(action[i]), int(arrays["count"][i]), float(arrays[value_key][i]),
-                    0 if par is None else par.depth + 1)
+                    0 if par is None else par.depth + 1, planner)
+        if transition is not None and root_state is not None:
+            node.state = int(root_state) if par is None else int(transition[par.state, int(action[i])])
         for name in extra:
             setattr(node, name, arrays[name][i].item())
         if prior is not None:
@@ -273,15 +388,43 @@ class AbstractPlanner(Configurable):
 
     @property
     def root(self):
-        """Root :class:`Node` of the last plan's tree (root 0 of the batch), exported on demand."""
+        """Root :class:`Node` of the last plan's tree (root 0 of the batch), exported on demand -- or already, when
+        another planner of the process was about to reuse the device workspaces (:meth:`claim_device_tree`)."""
         if self._root is None and self.last is not None:
             self._root = self.export_tree(0)
         return self._root
 
+    def get_visits(self):
+        """Observations the planner stepped through (abstract.py:163-167).  The device logs no observations; planners whose
+        tree holds every state they stepped into (the optimistic planners) derive it from the last plan's tree."""
+        raise NotImplementedError("this planner's rollout steps leave no trace on the device: get_visits is not available "
+                                  "(use planner.root.get_obs_visits for the states of the expanded nodes)")
+
+    def get_updates(self):
+        from collections import defaultdict
+        return defaultdict(int)
+
     # The trees of the last plan live in workspaces of the process-wide device context, shared by every planner of the
     # process: a planner claims them when it plans and may only read them back while the claim still stands.
+    def about_to_plan(self):
+        """Called before a device plan overwrites the context's tree workspaces: the planner that owns them exports the
+        tree of its last plan first (root 0, once), so its ``planner.root`` keeps answering after another agent of the
+        process has planned -- e.g. benchmark mode with ``display_tree``."""
+        ctx = self.models.ctx
+        prev = getattr(ctx, "_tree_owner", None)
+        if prev is not None and prev is not self:
+            prev.preserve_tree()
+            ctx._tree_owner = None
+
     def claim_device_tree(self):
         self.models.ctx._tree_owner = self
+
+    def preserve_tree(self):
+        if self.last is not None and self._root is None:
+            try:
+                self._root = self.export_tree(0)
+            except Exception as e:          # an export must never break the planner that is about to plan
+                logger.warning("could not keep the tree of the previous planner: %s", e)
 
     def owns_device_tree(self):
         return getattr(self.models.ctx, "_tree_owner", None) is self

@@ -17,6 +17,7 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
         self.env = env
 
     def plan_batch(self, state, root_states, root_steps=None, rng_states=None):
+        self.about_to_plan()
         model = self.model_for(state)
         n = len(root_states)
         if rng_states is None:
@@ -50,6 +51,7 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
         budget = int(cfg["budget"])
         if cfg["gamma"] == 1 and budget >= model.A:
             raise ZeroDivisionError("float division by zero")
+        self.about_to_plan()
         self.models.ctx.opd_plan_device(model, n, d_state, budget, cfg["gamma"], cfg.get("terminal_reward", 0), d_rng,
                                         int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, root_lower=d_value,
                                         env_steps=d_env_steps, status=d_status)
@@ -66,7 +68,31 @@ class OptimisticDeterministicPlanner(AbstractPlanner):
         cap = 1 + (int(self.config["budget"]) // a) * a
         arrays = self.relabel_tree(self.models.ctx.opd_tree(root, cap), getattr(self, "_last_model", None))
         arrays["value_lower"], arrays["value_upper"] = arrays["lower"], arrays["upper"]
-        return build_tree(arrays, "lower", extra=("value_lower", "value_upper", "reward", "done", "state"))
+        tree = build_tree(arrays, "lower", extra=("value_lower", "value_upper", "reward", "done", "state"), planner=self)
+        return with_observations(tree)
+
+    def get_visits(self):
+        """Observations stepped through (abstract.py:163-167): every node but the root was created by ONE env step, into
+        its ``observation``.  Covers the last plan (the reference's log grows over the planner's lifetime)."""
+        from collections import defaultdict
+        visits = defaultdict(int)
+        if self.root is not None:
+            for node, _ in self.root.breadth_first_search(self.root):
+                if node.parent is not None:
+                    visits[str(node.observation)] += 1
+        return visits
+
+
+def with_observations(tree):
+    """DeterministicNode.observation (deterministic.py:13,41-43): None at the root, the observation of the step that
+    created the node elsewhere -- for a finite-MDP environment the state reached."""
+    tree.observation = None
+    stack = list(tree.children.values())
+    while stack:
+        node = stack.pop()
+        node.observation = node.state
+        stack.extend(node.children.values())
+    return tree
 
 
 class DeterministicPlannerAgent(AbstractTreeSearchAgent):

@@ -48,31 +48,53 @@ def policy_probabilities(policy_config, n_actions):
     raise ValueError("Unknown policy type")
 
 
-def policy_tables(policy_config, available):
-    """A prior / rollout policy config on an environment that restricts the available actions (bool ``available``
-    [S, A]) -> (probabilities [S, A], listed bool [S, A]): row s is what the reference's policy function returns in
-    state s (mcts.py:46-97), zero on the actions it does not list.  Arithmetic as there: ``ones(k) / k``,
-    ``ones(k) / (k - 1 + ratio)`` then ``*= ratio`` on the preferred action."""
+def policy_tables(policy_config, available, col_ids=None, env_rank=None):
+    """A prior / rollout policy config on an environment that restricts (or orders) its available actions -> (probabilities
+    [S, A], listed bool [S, A], slots uint8 [S, A] or None).  ``available``: bool [S, A] in the DEVICE's column order;
+    ``col_ids[j]``: the environment action id of column j (None: ascending); ``env_rank[e]``: the position of action e in
+    the environment's own listing (None: ascending).
+
+    Row s of the table is what the reference's policy function returns in state s (mcts.py:46-97), zero on the actions
+    it does not list.  Arithmetic as there: ``ones(k) / k``, ``ones(k) / (k - 1 + ratio)`` then ``*= ratio`` on the
+    preferred action.  ``slots[s]`` is the order in which the policy LISTS the columns -- ``random`` lists
+    ``np.arange(n)`` whatever the environment lists, the other two list ``get_available_actions()`` -- and is None when
+    that is the column order anyway (then the inverse CDF over columns is the reference's)."""
     available = np.asarray(available).astype(bool)
     n_states, n_actions = available.shape
+    col_ids = np.arange(n_actions) if col_ids is None else np.asarray(col_ids, dtype=np.int64)
+    env_rank = np.arange(n_actions) if env_rank is None else np.asarray(env_rank, dtype=np.int64)
     kind = policy_config["type"]
     if kind == "random":                                          # ignores availability (mcts.py:46-57)
-        return np.ones((n_states, n_actions)) / n_actions, np.ones((n_states, n_actions), dtype=bool)
-    k = available.sum(axis=1)
-    uniform = np.where(available, (np.ones(n_states) / k)[:, None], 0.0)
-    if kind == "random_available":
-        return uniform, available
-    if kind == "preference":
-        action, ratio = policy_config["action"], policy_config.get("ratio", 2)
-        table = uniform
-        if 0 <= action < n_actions:
-            has = available[:, action]
-            base = np.ones(n_states) / (k - 1 + ratio)
-            pref = np.where(available, base[:, None], 0.0)
-            pref[:, action] = np.where(has, base * ratio, 0.0)
-            table = np.where(has[:, None], pref, uniform)
-        return table, available
-    raise ValueError("Unknown policy type")
+        table, listed = np.ones((n_states, n_actions)) / n_actions, np.ones((n_states, n_actions), dtype=bool)
+        key = np.broadcast_to(col_ids, (n_states, n_actions))                         # listed by ascending action id
+    else:
+        k = available.sum(axis=1)
+        uniform = np.where(available, (np.ones(n_states) / k)[:, None], 0.0)
+        listed = available
+        if kind == "random_available":
+            table = uniform
+        elif kind == "preference":
+            action, ratio = policy_config["action"], policy_config.get("ratio", 2)
+            table = uniform
+            if 0 <= action < n_actions:
+                has = available[:, action]
+                base = np.ones(n_states) / (k - 1 + ratio)
+                pref = np.where(available, base[:, None], 0.0)
+                pref[:, action] = np.where(has, base * ratio, 0.0)
+                table = np.where(has[:, None], pref, uniform)
+        else:
+            raise ValueError("Unknown policy type")
+        # listed in the environment's order, the unlisted columns after them
+        key = np.where(available, env_rank[col_ids][None, :], n_actions + np.arange(n_actions)[None, :])
+    slots = np.argsort(key, axis=1, kind="stable").astype(np.uint8)
+    # the order only matters among the columns with a positive probability
+    ascending = True
+    for s_row, t_row in zip(slots, table > 0):
+        cols = s_row[t_row[s_row]]
+        if np.any(np.diff(cols.astype(np.int64)) < 0):
+            ascending = False
+            break
+    return table, listed, (None if ascending else slots)
 
 
 class MCTS(AbstractPlanner):
@@ -140,6 +162,15 @@ class MCTS(AbstractPlanner):
                 model = self.models.get(device_model.spec_from_mdp(mdp))
                 model.set_episode_rules(getattr(mdp, "done_rule", "source"), device_model.env_max_steps(state))
                 return model
+            if mdp.mode == "deterministic":
+                # The columns of the device tables -- the order of a node's children and of every tie-break -- follow
+                # the order in which the PRIOR policy lists the actions (mcts.py:237-246): the environment's listing
+                # order, or np.arange(n) for policy type `random` (mcts.py:46-57), whatever the environment lists.
+                available, order = device_model.availability_of(state, mdp)
+                self._env_order = order
+                tree_order = None if self.prior_policy["type"] == "random" and self.policy_source is None else order
+                return self.models.get(device_model.spec_from_mdp(mdp, max_steps=device_model.env_max_steps(state),
+                                                                  available=available, action_order=tree_order))
         return super(MCTS, self).model_for(state)
 
     def plan_batch_stochastic(self, state, model, root_states, root_steps, rng_states, env_rng_states=None):
@@ -167,6 +198,7 @@ class MCTS(AbstractPlanner):
         return out
 
     def plan_batch(self, state, root_states, root_steps=None, rng_states=None, keep_actions=None, env_rng_states=None):
+        self.about_to_plan()
         model = self.model_for(state)
         n = len(root_states)
         if rng_states is None:
@@ -187,17 +219,12 @@ class MCTS(AbstractPlanner):
             if self.policy_source is not None:
                 prior, rollout = self.policy_source(state, model)      # (restricted to the available actions there;
                 listed = available                                     #  columns in the model's listing order)
+                slots = None
             else:
-                if self.action_order(model) is not None and "random" in (self.prior_policy["type"], self.rollout_policy["type"]):
-                    # `random` lists np.arange(n) whatever the env lists (mcts.py:46-57): its sampling / child order is
-                    # ascending while the other policy and the env follow the listing order -- two orders in one tree
-                    raise NotImplementedError("policy type 'random' on an environment that lists its available actions "
-                                              "in a non-ascending order is not supported on the device; use "
-                                              "'random_available' (the reference's default) or 'preference'")
-                prior, rollout, listed = self.restricted_policy_tables(model, available)
+                prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
                                None, None, rng_states, root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1),
-                               policy=self.device_policy(model, prior, rollout, listed))
+                               policy=self.device_policy(model, prior, rollout, listed, slots))
             order = self.action_order(model)
             prior_ids = prior
             if order is not None:                       # export works in the environment's action ids
@@ -215,6 +242,7 @@ class MCTS(AbstractPlanner):
         self.relabel(out, model)
         self._last_model = model
         self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
+        self._last_roots = np.asarray(root_states, dtype=np.int64) if model.mode == native_modes.MODE_DETERMINISTIC else None
         self._tree_roots = n
         self.claim_device_tree()
         self.env_steps += int(out["env_steps"].sum())
@@ -234,6 +262,7 @@ class MCTS(AbstractPlanner):
         if model.mode != native_modes.MODE_DETERMINISTIC:
             raise NotImplementedError("the device-resident loop steps deterministic table models")
         cfg, ctx = self.config, self.models.ctx
+        self.about_to_plan()
         ctx.uct_reset_tree()
         available = getattr(model, "available", None)
         policy, pp, rp = None, None, None
@@ -241,11 +270,10 @@ class MCTS(AbstractPlanner):
             if self.policy_source is not None:
                 prior, rollout = self.policy_source(state, model)
                 listed = available
+                slots = None
             else:
-                if self.action_order(model) is not None and "random" in (self.prior_policy["type"], self.rollout_policy["type"]):
-                    raise NotImplementedError("policy type 'random' on a non-ascending listing order (see plan_batch)")
-                prior, rollout, listed = self.restricted_policy_tables(model, available)
-            policy = self.device_policy(model, prior, rollout, listed)
+                prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
+            policy = self.device_policy(model, prior, rollout, listed, slots)
         else:
             pp = policy_probabilities(self.prior_policy, model.A)
             rp = policy_probabilities(self.rollout_policy, model.A)
@@ -256,30 +284,40 @@ class MCTS(AbstractPlanner):
         self.last, self._root = None, None
 
     def restricted_policy_tables(self, model, available):
-        """(prior, rollout, listed) tables of this planner's policy configs on a restricted-action model, kept per model."""
+        """(prior, rollout, listed, rollout slots) of this planner's policy configs on a model whose environment restricts
+        or orders its actions, kept per model.  Columns are in the PRIOR policy's order (:meth:`model_for`); the rollout
+        policy's own listing order comes back as ``slots`` when it differs (mp_policy_load_ordered)."""
         hit = self._restricted.get(id(model))
         if hit is None or hit[0] is not model:
+            n = model.A
             order = self.action_order(model)
+            col_ids = np.arange(n) if order is None else np.asarray(order, dtype=np.int64)
+            env_order = getattr(self, "_env_order", None)
+            env_rank = np.arange(n)
+            if env_order is not None:
+                env_rank = np.empty(n, dtype=np.int64)
+                env_rank[np.asarray(env_order, dtype=np.int64)] = np.arange(n)
 
             def on_device(cfg):     # a preference policy names an environment action id: its column on the device
-                if order is not None and cfg.get("type") == "preference" and 0 <= cfg["action"] < len(order):
-                    return dict(cfg, action=int(np.flatnonzero(order == cfg["action"])[0]))
+                if cfg.get("type") == "preference" and 0 <= cfg["action"] < n:
+                    return dict(cfg, action=int(np.flatnonzero(col_ids == cfg["action"])[0]))
                 return cfg
-            prior, listed = policy_tables(on_device(self.prior_policy), available)
-            rollout, _ = policy_tables(on_device(self.rollout_policy), available)
+            prior, listed, prior_slots = policy_tables(on_device(self.prior_policy), available, col_ids, env_rank)
+            assert prior_slots is None, "the device columns follow the prior policy's listing order"
+            rollout, _, slots = policy_tables(on_device(self.rollout_policy), available, col_ids, env_rank)
             if len(self._restricted) >= 4:
                 self._restricted.clear()
-            hit = self._restricted[id(model)] = (model, prior, rollout, listed)
-        return hit[1], hit[2], hit[3]
+            hit = self._restricted[id(model)] = (model, prior, rollout, listed, slots)
+        return hit[1], hit[2], hit[3], hit[4]
 
-    def device_policy(self, model, prior, rollout, listed=None):
+    def device_policy(self, model, prior, rollout, listed=None, slots=None):
         """Upload (once per model and table contents) the per-state policy tables."""
         key = (id(model), id(prior), id(rollout))
         hit = self._policies.get(key)
         if hit is None or hit[0] is not model or hit[1] is not prior or hit[2] is not rollout:
             if len(self._policies) >= 4:
                 self._policies.clear()
-            hit = (model, prior, rollout, self.models.ctx.load_policy(model, prior, rollout, listed=listed))
+            hit = (model, prior, rollout, self.models.ctx.load_policy(model, prior, rollout, listed=listed, rollout_slots=slots))
             self._policies[key] = hit
         return hit[3]
 
@@ -374,11 +412,16 @@ class MCTS(AbstractPlanner):
         self.require_device_tree()
         arrays = self.relabel_tree(self.models.ctx.uct_tree(root), getattr(self, "_last_model", None))
         if self._last_tables is None:
-            return build_tree(arrays, "value", prior=policy_probabilities(self.prior_policy, self._last_actions))
+            # finite-MDP models: every node also learns the state its action sequence reaches (Node.get_obs_visits)
+            transition, roots = None, getattr(self, "_last_roots", None)
+            if roots is not None and not device_model.is_cartpole(self._last_env):
+                transition = np.asarray(device_model.finite_mdp_of(self._last_env).transition)
+            return build_tree(arrays, "value", prior=policy_probabilities(self.prior_policy, self._last_actions), planner=self,
+                              transition=transition, root_state=None if transition is None else int(roots[root]))
         # per-state priors: a child's prior is the prior agent's probability of its action in the state of its
         # parent (mcts.py:237-246); states follow from the root state and the deterministic transitions
         transition, prior, roots = self._last_tables
-        tree = build_tree(arrays, "value")
+        tree = build_tree(arrays, "value", planner=self)
         tree.prior, tree.state = 1.0, int(roots[root])
         stack = [tree]
         while stack:

@@ -90,7 +90,7 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
                                           zip(arrays["lower"], arrays["depth"], arrays["state"])])
         arrays["observation"] = arrays["state"]
         tree = build_tree(arrays, "value_upper", extra=("value_lower", "value_upper", "reward", "done", "state",
-                                                        "observation", "alive"))
+                                                        "observation", "alive"), planner=self)
         tree.state_values = state_values
         return tree
 

@@ -201,6 +201,7 @@ struct mp_policy {
     double *prior = nullptr;    // [S][stride]  prior[s][a]
     uint64_t *thr = nullptr;    // [S][stride]  ceil(cdf[s][a] * 2^53), a < A-1 (the last threshold is never reached)
     uint4 *frec = nullptr;      // [S*A][frq]   {Rec of (s,a); top 32 bits of the thr row of the state it leads to}
+    uint4 *frec_roll = nullptr; // the same records by ROLLOUT slot (mp_policy_load_ordered), nullptr when the orders agree
 };
 
 namespace mp {

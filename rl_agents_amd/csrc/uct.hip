@@ -120,6 +120,7 @@ struct UctArgs {
     const double *pol_prior; // [S][pol_stride]
     const uint64_t *pol_thr; // [S][pol_stride]
     const uint4 *pol_frec;   // [S*A][1 + ceil((A-1)/4)]
+    const uint4 *pol_frec_roll; // the same records laid out by ROLLOUT slot (= pol_frec unless the rollout policy lists the actions in another order)
     int pol_stride;
     int pol_shift;           // fused thresholds = min(thr >> pol_shift, pol_sat); 21 = the top 32 of 53 bits
     uint32_t pol_sat;        // 2^32 - 1, or 1023 for the packed 16-byte records
@@ -591,7 +592,7 @@ void uct_kernel(UctArgs p)
                     if (NTH > 2) tcur[NTH > 2 ? 2 : 0] = (q0.y >> 12) & 1023u;
                     if (NTH > 3) tcur[NTH > 3 ? 3 : 0] = (q0.y >> 22) & 1023u;
                 } else if (SP) {
-                    const uint4 *fr = p.pol_frec + (size_t)ridx * (1 + NQ32);
+                    const uint4 *fr = p.pol_frec_roll + (size_t)ridx * (1 + NQ32);
                     const uint4 q0 = fr[0];
                     uint4 qt[NQ32];
 #pragma unroll
@@ -947,6 +948,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     a.cp = model->cp; a.root_x = nullptr;
     a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_frec = pol ? pol->frec : nullptr;
+    a.pol_frec_roll = pol ? (pol->frec_roll ? pol->frec_roll : pol->frec) : nullptr;
     a.pol_stride = pol ? pol->stride : 0;
     // 16-byte records for saturated batches (see mp_policy_load)
     bool use16 = pol && pol->packed && n_roots > 16384;
@@ -1230,6 +1232,18 @@ int mp_policy_load(mp_ctx *ctx, mp_model *model, const double *prior, const doub
 int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, const uint8_t *listed,
                           mp_policy **out)
 {
+    return mp_policy_load_ordered(ctx, model, prior, rollout, listed, nullptr, out);
+}
+
+// rollout_slot (uint8 [S][A], nullptr = identity): the order in which the ROLLOUT policy lists the actions of a state --
+// slot k of state s is column rollout_slot[s][k] (a permutation of the columns; zero-probability columns last).  The
+// rollout's inverse CDF runs over slots, so the tree (columns: the PRIOR policy's listing order, which decides child
+// order and tie-breaks) and the rollout may list the actions differently: policy type `random` lists np.arange(n)
+// whatever the environment lists (mcts.py:46-57).  A rollout step never touches the tree -- it needs the next state,
+// the reward, the flags and the next state's thresholds -- so its fused records are simply laid out by slot.
+int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, const uint8_t *listed,
+                           const uint8_t *rollout_slot, mp_policy **out)
+{
     if (!ctx || !model || !prior || !rollout || !out) return fail(MP_ERR_ARG, "mp_policy_load: NULL argument");
     if (model->mode != MP_MODE_DETERMINISTIC || !model->rec)
         return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a deterministic table model");
@@ -1240,13 +1254,24 @@ int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, con
     const int stride = (A + 1) & ~1, frq = 1 + (A - 1 + 3) / 4;
     std::vector<double> hp((size_t)S * stride, 0.0);
     std::vector<uint64_t> ht((size_t)S * stride, ~0ULL);
+    // column of slot k in state s
+    auto col = [&](int s, int k) { return rollout_slot ? (int)rollout_slot[(size_t)s * A + k] : k; };
+    if (rollout_slot)
+        for (int s = 0; s < S; ++s) {
+            uint32_t seen = 0;
+            for (int k = 0; k < A; ++k) {
+                const int c = rollout_slot[(size_t)s * A + k];
+                if (c >= A || (seen >> c) & 1u) return fail(MP_ERR_ARG, "mp_policy_load_ordered: rollout_slot of state %d is not a permutation", s);
+                seen |= 1u << c;
+            }
+        }
     for (int s = 0; s < S; ++s) {
         double cdf[8], acc = 0.0;
         for (int a = 0; a < A; ++a) {
-            const double q = rollout[(size_t)s * A + a], pr = prior[(size_t)s * A + a];
+            const double q = rollout[(size_t)s * A + col(s, a)], pr = prior[(size_t)s * A + a];
             if (!(q >= 0.0) || !(pr >= 0.0)) return fail(MP_ERR_ARG, "mp_policy_load: negative or NaN probability in state %d", s);
             hp[(size_t)s * stride + a] = pr;
-            acc += q; cdf[a] = acc;                                                // numpy cumsum
+            acc += q; cdf[a] = acc;                                                // numpy cumsum, in the rollout policy's order
         }
         if (!(acc > 0.0)) return fail(MP_ERR_ARG, "mp_policy_load: rollout distribution of state %d sums to 0", s);
         for (int a = 0; a < A; ++a) {
@@ -1267,7 +1292,7 @@ int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, con
     // record formats: always 32 / 48 bytes with 32 coarse bits per threshold; when |A| <= 5 and S <= 2^20 also 16 bytes
     // (10 coarse bits per threshold in the spare bits of next and flags), which saturated batches use (one gather per
     // rollout step instead of two: +5-9 % there, -5 % on a lone wave).  MP_UCT_POLICY_RECORD=fused / packed forces one.
-    const bool can_pack = A <= 5 && S <= (1 << 20) && !getenv("MP_UCT_COARSE_BITS") && !listed;
+    const bool can_pack = A <= 5 && S <= (1 << 20) && !getenv("MP_UCT_COARSE_BITS") && !listed && !rollout_slot;
     std::vector<uint32_t> lmask((size_t)S, (1u << A) - 1u); // actions the prior policy lists per state
     if (listed)
         for (int s = 0; s < S; ++s) {
@@ -1297,11 +1322,20 @@ int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, con
             g[1] = (hrec[i].flags & 3u) | (th[1] << 2) | (th[2] << 12) | (th[3] << 22);
         }
     }
+    // records of the rollout, by slot: entry (s, k) = the record of (s, column of slot k) + the next state's thresholds
+    std::vector<uint32_t> hfr;
+    if (rollout_slot) {
+        hfr.resize(hf.size());
+        for (int s = 0; s < S; ++s)
+            for (int k = 0; k < A; ++k)
+                memcpy(hfr.data() + ((size_t)s * A + k) * frq * 4, hf.data() + ((size_t)s * A + col(s, k)) * frq * 4, (size_t)frq * 16);
+    }
     mp_policy *pol = new (std::nothrow) mp_policy;
     if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
     pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift; pol->packed = can_pack ? 1 : 0; pol->listed = listed ? 1 : 0;
     if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
         hipMalloc(&pol->frec, hf.size() * 4) != hipSuccess ||
+        (rollout_slot && hipMalloc(&pol->frec_roll, hfr.size() * 4) != hipSuccess) ||
         (can_pack && hipMalloc(&pol->frec16, hp16.size() * 4) != hipSuccess)) {
         mp_policy_free(pol);
         return fail(MP_ERR_ALLOC, "mp_policy_load: device allocation failed");
@@ -1310,6 +1344,7 @@ int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, con
     MP_HIP(hipMemcpy(pol->thr, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
     MP_HIP(hipMemcpy(pol->frec, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
     if (can_pack) MP_HIP(hipMemcpy(pol->frec16, hp16.data(), hp16.size() * 4, hipMemcpyHostToDevice));
+    if (rollout_slot) MP_HIP(hipMemcpy(pol->frec_roll, hfr.data(), hfr.size() * 4, hipMemcpyHostToDevice));
     *out = pol;
     return MP_OK;
 }
@@ -1321,6 +1356,7 @@ int mp_policy_free(mp_policy *policy)
     if (policy->thr) (void)hipFree(policy->thr);
     if (policy->frec) (void)hipFree(policy->frec);
     if (policy->frec16) (void)hipFree(policy->frec16);
+    if (policy->frec_roll) (void)hipFree(policy->frec_roll);
     delete policy;
     return MP_OK;
 }

@@ -417,8 +417,9 @@ def test_mcts_subtree_with_receding_horizon_descends_every_step():
 
 
 def test_tree_export_checks_ownership():
-    """planner.root reads the shared device context: after another planner has planned it raises instead of silently
-    returning that planner's tree."""
+    """planner.root after another planner of the process has planned: never that planner's tree -- the first planner's own
+    last tree, handed over to the host just before the shared device workspaces were reused (round 4: it used to raise);
+    a fresh export of a tree that is no longer on the device still raises."""
     from rl_agents_amd.agents.common.factory import agent_factory
     from rl_agents_amd.envs import FiniteMDPEnv, generators
     cfg = generators.gridworld()
@@ -430,12 +431,17 @@ def test_tree_export_checks_ownership():
     a.plan(0)
     assert a.planner.root.count > 0
     a.plan(0)
+    count_a = a.planner.root.count
+    a.planner._root = None                         # not exported yet when the second agent plans
     b.plan(0)
     assert b.planner.root.count == 101
+    root_a = a.planner.root                        # a's OWN tree (kept when b took the workspaces over), not b's
+    assert root_a.count == count_a and not hasattr(root_a, "value_lower")
     with pytest.raises(RuntimeError):
-        a.planner.root
+        a.planner.export_tree(0)                   # ... but it is not on the device any more
     a.plan(0)
     assert a.planner.root.count > 0
+    assert b.planner.root.count == 101 and hasattr(b.planner.root, "value_lower")
     with pytest.raises(RuntimeError):
         b.planner.export_tree(0)
 
@@ -469,3 +475,69 @@ def test_batched_benchmark_equals_individual_evaluations(tmp_path):
     np.testing.assert_array_equal(r["actions"], alone["actions"])
     assert np.array_equal(r["returns"], alone["returns"]) and r["episodes"] == 9
     assert results[0]["agent"]["__class__"] == OPD and results[1]["agent"]["budget"] == 60
+
+
+def _tree_agents(z, name):
+    from rl_agents_amd.agents.common.factory import agent_factory
+    p = "trees/" + name
+    cfg = mdp_from_golden(z, p + "/mdp")
+    env = _env(cfg, state=int(z[p + "/s0"]))
+    if bool(z[p + "/is_uct"]):
+        agent_cfg = dict(__class__=UCT, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]),
+                         temperature=float(z[p + "/temperature"]), horizon=int(z[p + "/horizon"]), episodes=int(z[p + "/episodes"]))
+    else:
+        agent_cfg = dict(__class__=OPD, budget=int(z[p + "/budget"]), gamma=float(z[p + "/gamma"]))
+    agent = agent_factory(env, agent_cfg)
+    agent.seed(int(z[p + "/seed"]))
+    return agent, env, p
+
+
+def test_exported_tree_consumers_match_the_reference(golden):
+    """f-3 end to end on the device: plan() on the GPU, then planner.root feeds get_obs_visits / get_trajectories /
+    breadth_first_search / planner.get_visits with the reference's answers for the same plans (tree_tools.npz)."""
+    from rl_agents_amd.agents.tree_search.abstract import Node
+    z = golden["tree_tools"]
+    for name in [str(n) for n in z["trees/names"]]:
+        agent, env, p = _tree_agents(z, name)
+        plan = agent.plan(int(z[p + "/s0"]))
+        np.testing.assert_array_equal(plan, z[p + "/plan"], err_msg=name)
+        root = agent.planner.root
+        assert root.planner is agent.planner
+        visits, _ = root.get_obs_visits(state=env)
+        ref = dict(zip([str(k) for k in z[p + "/visit_keys"]], [int(c) for c in z[p + "/visit_counts"]]))
+        assert dict(visits) == ref, name
+        assert [n.count for n in root.get_trajectories(False, False)] == [int(c) for c in z[p + "/flat_counts"]]
+        counts = list(Node.breadth_first_search(root, operator=lambda n, path: n.count))
+        assert counts == [int(c) for c in z[p + "/bfs_counts"]]
+        if not bool(z[p + "/is_uct"]):
+            ref = dict(zip([str(k) for k in z[p + "/planner_visit_keys"]], [int(c) for c in z[p + "/planner_visit_counts"]]))
+            assert dict(agent.planner.get_visits()) == ref
+        else:
+            with pytest.raises(NotImplementedError):
+                agent.planner.get_visits()
+
+
+def test_a_second_agent_does_not_take_the_first_agents_tree(golden):
+    """Tree ownership per planner: the planner about to lose the shared device workspaces exports its last tree first,
+    so planner.root keeps answering (benchmark mode + display_tree); write_tree sends the plot to the writer."""
+    import types
+    import matplotlib
+    matplotlib.use("Agg")
+    z = golden["tree_tools"]
+    first, env1, p1 = _tree_agents(z, "uct_highway_small")
+    second, env2, p2 = _tree_agents(z, "opd_grid_c1")
+    first.config["display_tree"] = True
+    writer = types.SimpleNamespace(images=[])
+    writer.add_image = lambda title, image, epoch: writer.images.append((title, image.shape, epoch))
+    first.set_writer(writer)
+    first.plan(int(z[p1 + "/s0"]))
+    assert writer.images and writer.images[0][0] == "Expanded_tree" and writer.images[0][2] == 1
+    first.planner._root = None                     # (write_tree exported it: drop the cache to exercise the hand-over)
+    second.plan(int(z[p2 + "/s0"]))                # the second agent plans on the same context ...
+    assert not first.planner.owns_device_tree()
+    root = first.planner.root                      # ... and the first agent's tree is still there
+    counts = [n.count for n in root.get_trajectories(False, False)]
+    assert counts == [int(c) for c in z[p1 + "/flat_counts"]]
+    third, _, p3 = _tree_agents(z, "uct_large1_b100")
+    third.plan(int(z[p3 + "/s0"]))
+    assert [n.count for n in second.planner.root.get_trajectories(False, False)] == [int(c) for c in z[p2 + "/flat_counts"]]

@@ -46,12 +46,6 @@ def test_mcts_agents_on_env_side_restrictions_match_reference(z):
                                             prior_policy=json.loads(str(z[p + "/prior_policy_json"])),
                                             rollout_policy=json.loads(str(z[p + "/rollout_policy_json"]))))
         agent.seed(int(z[p + "/seed"]))
-        if "random" in (agent.config["prior_policy"]["type"], agent.config["rollout_policy"]["type"]):
-            # `random` samples np.arange(n) in ascending order while the tree follows the env's listing order: documented
-            # refusal (the oracle reproduces this golden from the literal lists: tests/test_oracle_round3.py)
-            with pytest.raises(NotImplementedError):
-                agent.plan(int(z[p + "/s0"]))
-            continue
         plan = agent.plan(int(z[p + "/s0"]))
         np.testing.assert_array_equal([int(x) for x in plan], z[p + "/plan"], err_msg=name)
         assert [isinstance(x, str) for x in plan] == list(z[p + "/plan_is_obs"]), name
@@ -130,3 +124,39 @@ def test_value_iteration_agent_on_the_highway_like_env():
         a = agent.act(env.state_index)
         assert a == int(np.argmax(q[env.state_index]))
         env.step(a)
+
+
+def test_policy_type_random_on_a_non_ascending_listing_order():
+    """policy type `random` lists np.arange(n) whatever the environment lists (mcts.py:46-57), so on
+    HighwayLikeEnv (IDLE first) the prior's order (children, tie-breaks) and the rollout's order (inverse CDF) differ --
+    every combination of `random` with a listing-order policy, open and closed loop, and a subtree episode, against the
+    unmodified reference (tests/golden/random_policy.npz, tests/golden/gen/make_golden_random_policy.py)."""
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    z = np.load(os.path.join(REPO, "tests", "golden", "random_policy.npz"))
+    for name in names(z, "random_policy"):
+        p = "random_policy/" + name
+        env = _highway_env(z, p, int(z[p + "/s0"]))
+        agent = agent_factory(env, _uct_cfg(z, p, closed_loop=bool(z[p + "/closed_loop"]),
+                                            prior_policy=json.loads(str(z[p + "/prior_policy_json"])),
+                                            rollout_policy=json.loads(str(z[p + "/rollout_policy_json"]))))
+        agent.seed(int(z[p + "/seed"]))
+        plan = agent.plan(int(z[p + "/s0"]))
+        np.testing.assert_array_equal([int(x) for x in plan], z[p + "/plan"], err_msg=name)
+        assert [isinstance(x, str) for x in plan] == list(z[p + "/plan_is_obs"]), name
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[p + "/rng_after"], err_msg=name)
+        assert agent.planner.env_steps == int(z[p + "/env_steps"]), name
+        _assert_agent_tree(z, p + "/tree", agent.planner.root)
+    p = "random_policy_subtree"
+    env = _highway_env(z, p, int(z[p + "/states"][0]))
+    agent = agent_factory(env, dict(__class__=UCT, budget=300, horizon=12, episodes=25, step_strategy="subtree",
+                                    prior_policy={"type": "random"}, rollout_policy={"type": "random_available"}))
+    agent.seed(11)
+    for step in range(int(z[p + "/n_steps"])):
+        assert env.state_index == int(z[p + "/states"][step])
+        plan = agent.plan(env.state_index)
+        q = "{}/step{}".format(p, step)
+        np.testing.assert_array_equal(plan, z[q + "/plan"], err_msg=q)
+        _assert_agent_tree(z, q + "/tree", agent.planner.root, fields=("count", "value"))
+        np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), z[q + "/rng_after"])
+        env.step(plan[0])

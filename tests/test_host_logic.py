@@ -98,12 +98,29 @@ def test_mcts_defaults_and_policies():
     avail = generators.random_available(23, 5, seed=3, rate=0.5)
     for pol in ({"type": "random"}, {"type": "random_available"}, {"type": "preference", "action": 2, "ratio": 3},
                 {"type": "preference", "action": 4, "ratio": 2.5}, {"type": "preference", "action": 7, "ratio": 2}):
-        table, listed = mcts_mod.policy_tables(pol, avail)
+        table, listed, slots = mcts_mod.policy_tables(pol, avail)
+        assert slots is None                                   # ascending listing = the column order
         ref = reference_policy_lists(pol, avail)
         for s in range(23):
             assert list(np.flatnonzero(listed[s])) == ref["actions"][s]
             assert np.array_equal(table[s, ref["actions"][s]], ref["p"][s]) and table[s].sum() == pytest.approx(1.0)
             assert (table[s, ~listed[s]] == 0).all()
+    # ... and on an environment that lists in a non-ascending order (IDLE first): columns in the PRIOR policy's order, the
+    # other policy's listing as slots -- state by state the reference's lists again
+    order = np.array([1, 0, 2, 3, 4])
+    rank = np.empty(5, dtype=np.int64)
+    rank[order] = np.arange(5)
+    for col_ids in (order, np.arange(5)):                      # prior lists like the env / prior is `random`
+        cols = avail[:, col_ids]
+        for pol in ({"type": "random"}, {"type": "random_available"}, {"type": "preference", "action": 2, "ratio": 3}):
+            dev = dict(pol, action=int(np.flatnonzero(col_ids == pol["action"])[0])) if pol["type"] == "preference" else pol
+            table, listed, slots = mcts_mod.policy_tables(dev, cols, col_ids, rank)
+            ref = reference_policy_lists(pol, avail, order)
+            for s in range(23):
+                seq = np.arange(5) if slots is None else slots[s]
+                mine = [int(col_ids[c]) for c in seq if table[s, c] > 0]
+                assert mine == ref["actions"][s], (pol, s)
+                assert np.array_equal([table[s, c] for c in seq if table[s, c] > 0], ref["p"][s])
 
 
 def test_receding_horizon_bookkeeping():

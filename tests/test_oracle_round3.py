@@ -175,3 +175,28 @@ def test_state_aware_restricted_actions_goldens(z):
     from tests.helpers import replay_state_aware_masked_episode
     for name in names(z, "sa_masked"):
         replay_state_aware_masked_episode(z, name, oracle_sa_masked_plan)
+
+
+def test_random_policy_goldens_oracle_literal():
+    """Policy type `random` on the IDLE-first environment (tests/golden/random_policy.npz): the oracle, fed each policy as
+    the literal per-state list the reference's function returns -- np.arange(n) for `random`, the env's listing for the
+    others -- reproduces plans, env steps, generator state and whole trees."""
+    import json
+    import os
+    from oracle import oracle
+    from tests.helpers import reference_policy_lists
+    zz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "random_policy.npz"))
+    for name in [str(n) for n in zz["random_policy/names"]]:
+        p = "random_policy/" + name
+        cfg = mdp_from_golden(zz, p + "/mdp")
+        avail = _grid_available(zz[p + "/shape"])
+        prior_l = reference_policy_lists(json.loads(str(zz[p + "/prior_policy_json"])), avail, ORDER)
+        roll_l = reference_policy_lists(json.loads(str(zz[p + "/rollout_policy_json"])), avail, ORDER)
+        out = oracle.uct_plan(cfg["transition"], cfg["reward"], cfg["terminal"], int(zz[p + "/s0"]), int(zz[p + "/episodes"]),
+                              int(zz[p + "/horizon"]), float(zz[p + "/gamma"]), float(zz[p + "/temperature"]), prior_l, roll_l,
+                              zz[p + "/rng_before"], max_plan_len=2 * int(zz[p + "/horizon"]),
+                              closed_loop=bool(zz[p + "/closed_loop"]))
+        np.testing.assert_array_equal(out["plan"], zz[p + "/plan"], err_msg=name)
+        assert out["env_steps"] == int(zz[p + "/env_steps"]), name
+        np.testing.assert_array_equal(out["rng_after"], zz[p + "/rng_after"], err_msg=name)
+        assert_keyed_tree_equal(zz, p + "/tree", out["tree"], dict(count="count", value="value", prior="prior"))
