@@ -415,7 +415,9 @@ int mp_saopd_export(mp_saopd *planners, int32_t planner, int32_t cap, int32_t *p
 /* ---------------------------------------------------------------- batched evaluation -------- */
 /*
  * The env side of Evaluation.step (trainer/evaluation.py:164-190) for n lock-step episodes of ONE deterministic table
- * model, on the device: for every episode i still alive, act = plans[i * plan_stride] (an empty plan, -1, acts 0),
+ * model, on the device: for every episode i still alive, act = plans[i * plan_stride] (an empty plan, -1, steps label 0
+ * and is LOGGED as -1: Evaluation.step raises "The agent did not plan any action" there, evaluation.py:168-170, and so
+ * does the caller of this loop),
  *   reward = R[s, act];  done = terminal[s] (or terminal[s'] with done_on_next);  s <- T[s, act];  steps += 1;
  *   returns[i] += reward;  discounted[i] += reward * gpow[steps before];  actions_log[i * log_stride + steps before] = act;
  *   alive[i] = !(done || steps >= max_steps).

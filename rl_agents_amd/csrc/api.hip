@@ -39,6 +39,11 @@ int ws_reserve(mp_ctx *ctx, int slot, size_t bytes, void **out)
         }
         size_t want = bytes + bytes / 4 + 256;
         hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess && !ctx->block_cache.empty()) { // dead planner blocks may be what is in the way
+            (void)hipGetLastError();
+            ctx_block_cache_flush(ctx);
+            e = hipMalloc(&b.p, want);
+        }
         if (e != hipSuccess) {
             b.p = nullptr;
             return fail(MP_ERR_ALLOC, "hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -202,14 +207,14 @@ __global__ void env_step_kernel(int n, int A, const Rec *__restrict__ rec, int d
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     bool live = false;
     if (i < n && alive[i]) {
-        int act = plans[(long)i * plan_stride];
-        if (act < 0) act = 0;
+        const int planned = plans[(long)i * plan_stride];
+        const int act = planned < 0 ? 0 : planned; // an empty plan: logged as -1 (the caller raises, as Evaluation.step does)
         const int s = state[i], t = steps[i];
         const Rec rc = rec[(long)s * A + act];
         const bool done = (rc.flags & (done_on_next ? 2u : 1u)) != 0;
         returns[i] += rc.reward;
         discounted[i] += rc.reward * gpow[t];
-        if (actions_log && t < log_stride) actions_log[(long)i * log_stride + t] = act;
+        if (actions_log && t < log_stride) actions_log[(long)i * log_stride + t] = planned < 0 ? -1 : act;
         state[i] = rc.next;
         steps[i] = t + 1;
         live = !(done || t + 1 >= max_steps);

@@ -106,23 +106,45 @@ struct mp_ctx {
     size_t block_cache_bytes = 0;
 };
 
-constexpr size_t kBlockCacheBytes = (size_t)8 << 30;
+constexpr size_t kBlockCacheBytes = (size_t)2 << 30;
 
-// hipMalloc through the ctx's block cache (exact size match)
-inline hipError_t ctx_block_alloc(mp_ctx *ctx, void **out, size_t bytes)
+// give every cached block back to the runtime (an allocation failed: dead blocks of other sizes may be what is in the way)
+inline void ctx_block_cache_flush(mp_ctx *ctx)
 {
-    for (size_t i = 0; i < ctx->block_cache.size(); ++i)
-        if (ctx->block_cache[i].bytes == bytes) {
-            *out = ctx->block_cache[i].p;
-            ctx->block_cache_bytes -= bytes;
-            ctx->block_cache[i] = ctx->block_cache.back();
-            ctx->block_cache.pop_back();
-            return hipSuccess;
-        }
-    return hipMalloc(out, bytes);
+    for (auto &b : ctx->block_cache) (void)hipFree(b.p);
+    ctx->block_cache.clear();
+    ctx->block_cache_bytes = 0;
+}
+
+// hipMalloc through the ctx's block cache: the smallest cached block that holds `bytes` and wastes at most a quarter of
+// itself (a batch of planners re-created with slightly different sizes reuses blocks instead of piling up dead ones);
+// when the runtime is out of memory the cache is flushed and the allocation tried once more
+inline hipError_t ctx_block_alloc(mp_ctx *ctx, void **out, size_t bytes, size_t *got = nullptr)
+{
+    if (got) *got = bytes;
+    size_t best = ctx->block_cache.size();
+    for (size_t i = 0; i < ctx->block_cache.size(); ++i) {
+        const size_t have = ctx->block_cache[i].bytes;
+        if (have >= bytes && have - bytes <= have / 4 && (best == ctx->block_cache.size() || have < ctx->block_cache[best].bytes)) best = i;
+    }
+    if (best != ctx->block_cache.size()) {
+        *out = ctx->block_cache[best].p;
+        if (got) *got = ctx->block_cache[best].bytes;    // (the block's real size: what goes back into the cache later)
+        ctx->block_cache_bytes -= ctx->block_cache[best].bytes;
+        ctx->block_cache[best] = ctx->block_cache.back();
+        ctx->block_cache.pop_back();
+        return hipSuccess;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->block_cache.empty()) {
+        (void)hipGetLastError();
+        ctx_block_cache_flush(ctx);
+        e = hipMalloc(out, bytes);
+    }
+    return e;
 }
 template <typename T>
-inline hipError_t ctx_block_alloc(mp_ctx *ctx, T **out, size_t bytes) { return ctx_block_alloc(ctx, reinterpret_cast<void **>(out), bytes); }
+inline hipError_t ctx_block_alloc(mp_ctx *ctx, T **out, size_t bytes, size_t *got = nullptr) { return ctx_block_alloc(ctx, reinterpret_cast<void **>(out), bytes, got); }
 
 // is this ctx still alive?  (api.hip keeps the set of live contexts: an object may outlive the ctx it was made on)
 bool mp_ctx_alive(const mp_ctx *ctx);

@@ -1299,9 +1299,10 @@ template <typename T>
 static hipError_t sa_alloc(mp_saopd *pl, T **out, size_t bytes)
 {
     void *p = nullptr;
-    const hipError_t e = ctx_block_alloc(pl->ctx, &p, bytes);
+    size_t got = bytes;
+    const hipError_t e = ctx_block_alloc(pl->ctx, &p, bytes, &got);
     if (e != hipSuccess) return e;
-    pl->blocks.push_back({p, bytes});
+    pl->blocks.push_back({p, got});
     *out = static_cast<T *>(p);
     return hipSuccess;
 }

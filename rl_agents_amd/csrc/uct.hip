@@ -158,7 +158,9 @@ __device__ __forceinline__ bool cartpole_step(const mp_cartpole_params &c, doubl
     return x < -c.x_threshold || x > c.x_threshold || theta < -c.theta_threshold || theta > c.theta_threshold;
 }
 
-enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3 };
+enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3, ENV_TABLE_SPILL = 4 };
+// ENV_TABLE_SPILL: ENV_TABLE with the path stack in registers + a global spill array instead of LDS -- for horizons whose
+// [H + 1][64] stack would not fit (the reference has no horizon limit: tree_search/mcts.py:116-118)
 
 // AT > 0: |A| known at compile time (children scored from registers in one pass);
 // AT == 0: any |A| (three passes over the children).  ENV: where an env step comes from.
@@ -192,6 +194,7 @@ void uct_kernel(UctArgs p)
     constexpr bool LDSR = ENV == ENV_TABLE_LDSR;             // transitions AND rewards in LDS, path stack in registers
     constexpr bool LDSM = ENV == ENV_TABLE_LDS || LDSR;      // transitions in LDS (reward one step behind the state chain)
     static_assert(!LDSR || (AT > 0 && !SP), "the LDS-resident variant: |A| at compile time, state-independent policies");
+    constexpr bool PREG = LDSR || ENV == ENV_TABLE_SPILL;    // path stack in registers + global spill, not in LDS
     constexpr bool CART = ENV == ENV_CARTPOLE;
     // RAWU: the rollout compares the generator's raw 64-bit output with thresholds shifted up by 11 bits (thr <= out >> 11
     // <=> thr << 11 <= out) instead of shifting every draw down to its 53 random bits
@@ -308,7 +311,7 @@ void uct_kernel(UctArgs p)
 #define PATH_PUT(d_, h_)                                                                        \
     do {                                                                                        \
         const int pd_ = (d_), phv_ = (h_);                                                      \
-        if constexpr (!LDSR) {                                                                  \
+        if constexpr (!PREG) {                                                                  \
             path[pd_ * nthreads + lane] = phv_;                                                 \
         } else {                                                                                \
             if (pd_ == 1) ph1 = phv_;                                                           \
@@ -319,10 +322,10 @@ void uct_kernel(UctArgs p)
 #define PATH_GET(out_, d_)                                                                      \
     do {                                                                                        \
         const int pd_ = (d_);                                                                   \
-        if constexpr (!LDSR) {                                                                  \
+        if constexpr (!PREG) {                                                                  \
             out_ = path[pd_ * nthreads + lane];                                                 \
         } else {                                                                                \
-            int hh_ = ph1;                                                                      \
+            int hh_ = pd_ == 0 ? tree.root_handle() : ph1;                                      \
             _Pragma("unroll") for (int i_ = 0; i_ < KEEP; ++i_) hh_ = pd_ == 2 + i_ ? ph[i_] : hh_; \
             if (pd_ >= 2 + KEEP) hh_ = p.path_spill[(size_t)pd_ * p.spill_stride + r];          \
             out_ = hh_;                                                                         \
@@ -809,11 +812,17 @@ static bool uct_ldsr_default(bool forced, long n_roots, int cus)
 }
 
 template <int AT>
-static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed, bool ldsr = false)
+static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed, bool ldsr = false, bool spill = false)
 {
     const int roots_per_block = a.waves * a.lanes;
     const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
-    if (ldsr) {
+    if (spill) {
+        if (a.tree_il == 2) {
+            if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_SPILL, false, false, 2>), grid, block, lds, st, a);
+        } else {
+            hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_SPILL, false, false, 0>), grid, block, lds, st, a);
+        }
+    } else if (ldsr) {
         if constexpr (AT > 0) {
             if (lds > 64 * 1024)
                 MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<AT, ENV_TABLE_LDSR, false, false, 2>),
@@ -1007,8 +1016,17 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         a.lanes = uct_lanes_per_wave(); a.waves = 1;
         lds = ntab * sizeof(double) + (size_t)(H + 1) * 64 * sizeof(int32_t);
     }
-    if (!ldsm && !ldsr && lds > 64 * 1024)
-        return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
+    // a path stack that does not fit 64 KB of LDS (horizon >~ 180): registers + the global spill array instead
+    bool spill = false;
+    if (!ldsm && !ldsr && lds > 64 * 1024) {
+        const char *lay_now = getenv("MP_UCT_TREE");
+        if (cart || pol || (lay_now && lay_now[0] == 'i') || ntab * sizeof(double) > 64 * 1024)
+            return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
+        spill = true;
+        lds = ntab * sizeof(double);
+    }
+    if (const char *e = getenv("MP_UCT_PATH")) // "spill": force the register / global path stack (test hook)
+        if (e[0] == 's' && !ldsm && !ldsr && !cart && !pol && want_il != 1) { spill = true; lds = ntab * sizeof(double); }
 
     // trees: fresh ones, or (step_strategy "subtree") the kept ones re-rooted into the other buffer with room
     // for this plan's expansions
@@ -1038,9 +1056,15 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     a.cap = (int)cap_use;
     a.tree_il = ctx->tree.il;
-    if (ldsr && ctx->tree.il != 2) ldsr = false, ldsm = false; // (a kept tree in another layout: the default kernel)
-    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : "uct_global"))));
-    if (ldsr) {
+    if (ldsr && ctx->tree.il != 2) { // (a kept tree in another layout: the default kernel and its LDS budget)
+        ldsr = false; ldsm = false;
+        a.waves = 1;
+        lds = ntab * sizeof(double) + (size_t)(H + 1) * 64 * sizeof(int32_t);
+        if (lds > 64 * 1024) { spill = true; lds = ntab * sizeof(double); }
+    }
+    if (spill && ctx->tree.il == 1) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d needs the spilled path stack, which the interleaved tree layout does not have", H);
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
+    if (ldsr || spill) {
         a.spill_stride = ((long)n_roots + 63) & ~63L;
         MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
     }
@@ -1144,15 +1168,15 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
         } else
         switch (A) {
-        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
-        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
-        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
-        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
-        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
-        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr)); break;
+        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         default:
             if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
-            MP_TRY(uct_launch<0>(c, ldsm, lds, s, false, false));
+            MP_TRY(uct_launch<0>(c, ldsm, lds, s, false, false, false, spill));
             break;
         }
         if (rmem == MP_MEM_HOST) MP_HIP(hipMemcpyAsync(rng_state + (size_t)r0 * 6, c.rng, cnt * 48, hipMemcpyDeviceToHost, s));

@@ -637,19 +637,30 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
             if (few) {
                 std::vector<double> tabv(256, 0.0);
                 for (size_t j = 0; j < vals.size(); ++j) memcpy(&tabv[j], &vals[j], sizeof(double));
+                // (the model is touched only after every step has succeeded: a failure leaves the 32-byte records in use)
                 uint4 *rec16 = nullptr;
                 uint8_t *d_ridx = nullptr;
+                double *d_rtab = nullptr;
+                auto drop = [&]() { if (rec16) hipFree(rec16); if (d_ridx) hipFree(d_ridx); if (d_rtab) hipFree(d_rtab); };
                 if (hipMalloc(&rec16, (size_t)rows * sizeof(uint4)) != hipSuccess || hipMalloc(&d_ridx, (size_t)rows) != hipSuccess ||
-                    hipMalloc(&model->srec_rtab, 256 * sizeof(double)) != hipSuccess)
+                    hipMalloc(&d_rtab, 256 * sizeof(double)) != hipSuccess) {
+                    drop();
                     return fail(MP_ERR_ALLOC, "mp_uct_plan_stochastic: the compact records");
-                MP_HIP(hipMemcpyAsync(d_ridx, ridx.data(), (size_t)rows, hipMemcpyHostToDevice, st));
-                MP_HIP(hipMemcpyAsync(model->srec_rtab, tabv.data(), 256 * sizeof(double), hipMemcpyHostToDevice, st));
+                }
+                if (hipMemcpyAsync(d_ridx, ridx.data(), (size_t)rows, hipMemcpyHostToDevice, st) != hipSuccess ||
+                    hipMemcpyAsync(d_rtab, tabv.data(), 256 * sizeof(double), hipMemcpyHostToDevice, st) != hipSuccess) {
+                    drop();
+                    return fail(MP_ERR_HIP, "mp_uct_plan_stochastic: upload of the compact records failed");
+                }
                 hipLaunchKernelGGL(compact_records16, grid, block, 0, st, rows, model->srec, d_ridx, rec16);
-                MP_HIP(hipGetLastError());
-                MP_HIP(hipStreamSynchronize(st)); // (the host vectors and the 32-byte records go away)
+                if (hipGetLastError() != hipSuccess || hipStreamSynchronize(st) != hipSuccess) { // (the host vectors go away)
+                    drop();
+                    return fail(MP_ERR_HIP, "mp_uct_plan_stochastic: compact_records16 failed");
+                }
                 hipFree(d_ridx);
                 hipFree(model->srec);
                 model->srec = rec16;
+                model->srec_rtab = d_rtab;
                 model->srec_wb = 1;
             }
         }
@@ -681,7 +692,8 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
 
     const long cap = 1 + (long)E * ((long)A + (closed_loop ? H : 0));
     const bool p16 = cap <= 65535;
-    const size_t lds = (ntab + (wbk == 1 ? 256 : 0)) * sizeof(double) + (size_t)(2 * H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
+    // path stack entries: the root + one per level, two per level in closed loop (action node, observation node)
+    const size_t lds = (ntab + (wbk == 1 ? 256 : 0)) * sizeof(double) + (size_t)(closed_loop ? 2 * H + 2 : H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
 
     StochArgs a;

@@ -863,13 +863,17 @@ class StateAwarePlanners(object):
         lo = inf["root"] if current_tree_only else 0
         keep = ~np.isneginf(t["lower"])
         new_id = np.cumsum(keep) - 1
-        fc_old = t["first_child"]
-        n_children = np.zeros(cap, np.int32)
+        a = self.model.A
+        fc_old = t["first_child"].copy()
         has = fc_old >= 0
-        for i in np.flatnonzero(has):                      # an expansion's |A| slots: fc .. fc + |A| - 1
-            grp = keep[fc_old[i]:fc_old[i] + self.model.A]
-            n_children[i] = int(grp.sum())
-            fc_old[i] = fc_old[i] + int(np.argmax(grp))
+        # an expansion's |A| slots fc .. fc + |A| - 1: how many are real nodes, and the first of them
+        csum = np.concatenate([[0], np.cumsum(keep)])
+        fc0 = np.where(has, fc_old, 0)
+        n_children = np.where(has, csum[np.minimum(fc0 + a, cap)] - csum[fc0], 0).astype(np.int32)
+        next_kept = np.where(keep, np.arange(cap), cap)
+        next_kept = np.minimum.accumulate(next_kept[::-1])[::-1] if cap else next_kept      # first kept row at or after i
+        first_kept = np.where(n_children > 0, next_kept[fc0], -1)      # (every slot a phantom: no children, no first child)
+        t["first_child"] = first_kept.astype(np.int32)
         t["n_children"] = n_children
         sel = keep.copy()
         sel[:lo] = False

@@ -158,6 +158,8 @@ class BatchedEvaluation(object):
             planner.raise_for_device_status(d_status, live)
             planner.env_steps += int((d_es * live).sum().item())
         actions = d_log.cpu().numpy()
+        if (actions[live.cpu().numpy().T] < 0).any():          # a live episode was handed an empty plan (budget < |A|, no
+            raise Exception("The agent did not plan any action")   # episodes): Evaluation.step raises (evaluation.py:168-170)
         if order is not None:                                  # the device planned in the env's listing order
             actions = np.where(actions >= 0, np.asarray(order)[np.maximum(actions, 0)], -1).astype(np.int32)
         return dict(returns=d_ret.cpu().numpy(), discounted_returns=d_disc.cpu().numpy(), lengths=lengths, actions=actions,
@@ -208,7 +210,9 @@ class BatchedEvaluation(object):
             plan_seconds += time.perf_counter() - t1
             rng[idx] = sub_rng
             act = out["plans"][:, 0].astype(np.int64)
-            act[act < 0] = 0                                   # an empty plan (budget < |A|) falls back to action 0
+            if (act[alive[idx]] < 0).any():                    # Evaluation.step (evaluation.py:168-170) raises on an empty plan
+                raise Exception("The agent did not plan any action")
+            act[act < 0] = 0                                   # (episodes that are over: their plans are ignored)
             if stateful:
                 previous = act.astype(np.int32)
                 live = alive[idx]

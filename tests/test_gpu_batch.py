@@ -98,6 +98,21 @@ def test_uct_lds_resident_model_deep_trees_spill_the_path(ctx, monkeypatch):
     assert out["plan_len"].max() > 8
 
 
+@pytest.mark.parametrize("n_actions", [3, 5, 7])
+def test_uct_long_horizons_spill_the_path_stack(ctx, n_actions, monkeypatch):
+    """The reference has no horizon limit (mcts.py:116-118); a [H + 1][64] path stack stops fitting 64 KB of LDS near
+    H = 180 (round 3 refused there).  Beyond, the stack lives in registers (depths 1..5) + a global spill array; also forced
+    at a small horizon (MP_UCT_PATH=spill), for compile-time and generic |A|."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(300, n_actions, seed=40 + n_actions, terminal_rate=0.0)
+    p = np.ones(n_actions) / n_actions
+    _cmp_uct(ctx, cfg, 70, 30, 400, 0.995, 0.01, p, p, seed=2)                # horizon 400: deep, narrow trees
+    assert ctx.last_kernel_variant() == "uct_global_spill"
+    monkeypatch.setenv("MP_UCT_PATH", "spill")
+    _cmp_uct(ctx, cfg, 130, 200, 20, 0.97, 0.05, p, p, seed=3)
+    assert ctx.last_kernel_variant() == "uct_global_spill"
+
+
 def test_uct_lds_resident_model_falls_back(ctx, monkeypatch):
     """More than 256 distinct rewards: no byte-indexed reward table exists and the record-gather kernel runs, also when
     the variant is asked for; a model that does not fit the LDS is refused when forced."""
@@ -385,8 +400,10 @@ def test_limits_and_error_codes(ctx):
     model = ctx.load_table(small["transition"], small["reward"], small["terminal"])
     rng = _rng_states(2)
     p = np.ones(3) / 3
-    with pytest.raises(native.NativeError) as e:                      # horizon too deep for the LDS path stack
-        ctx.uct_plan(model, [0, 1], 4, 5000, 0.9, 1.0, p, p, rng, max_plan_len=4)
+    ctx.uct_plan(model, [0, 1], 4, 5000, 0.9, 1.0, p, p, rng, max_plan_len=4)   # (round 4: a deep horizon spills the path stack)
+    assert ctx.last_kernel_variant() == "uct_global_spill"
+    with pytest.raises(native.NativeError) as e:                      # ... until the gamma ** h table itself outgrows the LDS
+        ctx.uct_plan(model, [0, 1], 4, 20000, 0.9, 1.0, p, p, rng, max_plan_len=4)
     assert e.value.code == native.ERR_ARG
     with pytest.raises(native.NativeError) as e:                      # gamma = 1: the reference divides by 1 - gamma
         ctx.opd_plan(model, [0, 1], 30, 1.0, 0.0, rng)
