@@ -137,8 +137,6 @@ class MCTS(AbstractPlanner):
             # the reference re-roots at the ACTION node, whose children are keyed by observation strings: its next
             # run() would step the environment with such a key (abstract.py:195-206 + mcts.py:143-146)
             raise NotImplementedError("step_strategy 'subtree' does not work on closed-loop trees (in the reference either)")
-        if getattr(self, "_stochastic", False):
-            raise NotImplementedError("step_strategy 'subtree' is not available on stochastic models on the device")
         # every act() steps the tree (abstract.py:70-82), also between two plans when receding_horizon > 1: the device
         # descends one level per call (a pending re-rooting is applied when the next one is armed)
         live = self.last is not None or self._armed
@@ -204,7 +202,10 @@ class MCTS(AbstractPlanner):
         if rng_states is None:
             rng_states = self.batch_rng_states(n)
         if model.mode in (native_modes.MODE_STOCHASTIC, native_modes.MODE_SPARSE):
-            self._armed = False
+            # (open-loop trees are re-used like the deterministic ones: mp_uct_step_tree armed the re-rooting)
+            armed, self._armed = self._armed and n == 1 and not self.config["closed_loop"], False
+            if not (armed and self.owns_device_tree()):
+                self.models.ctx.uct_reset_tree()
             return self.plan_batch_stochastic(state, model, root_states, root_steps, rng_states, env_rng_states)
         self._stochastic = False
         cfg = self.config

@@ -252,6 +252,11 @@ inline int mem_arrays(int mem) { return mem & 1; }
 inline int mem_rng(int mem) { return (mem & (MP_MEM_DEVICE | MP_MEM_RNG_DEVICE)) ? MP_MEM_DEVICE : MP_MEM_HOST; }
 inline bool mem_valid(int mem) { return mem >= 0 && mem <= 3; }
 
+// uct_stoch.hip: apply a pending re-rooting of the open-loop stochastic trees (mp_uct_step_tree arms it)
+} // namespace mp
+int uct_stoch_reroot_now(mp_ctx *ctx, long cap_new);
+namespace mp {
+
 // side streams for the pipelined host-mode plan: `n` streams forked off the ctx stream / joined back into it
 int pipe_fork(mp_ctx *ctx, int n);
 int pipe_join(mp_ctx *ctx, int n);

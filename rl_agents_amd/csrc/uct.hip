@@ -1388,12 +1388,13 @@ int mp_policy_free(mp_policy *policy)
 int mp_uct_step_tree(mp_ctx *ctx, int32_t n_roots, const int32_t *actions, int32_t mem)
 {
     if (!ctx || !actions) return fail(MP_ERR_ARG, "mp_uct_step_tree: NULL argument");
-    if (ctx->tree.kind != 1 || ctx->tree.n_roots != n_roots)
-        return fail(MP_ERR_ARG, "mp_uct_step_tree: no UCT trees of %d roots on this ctx", n_roots);
+    const bool stoch = ctx->tree.kind == 4 && ctx->tree.K == 0; // open-loop trees of mp_uct_plan_stochastic
+    if ((ctx->tree.kind != 1 && !stoch) || ctx->tree.n_roots != n_roots)
+        return fail(MP_ERR_ARG, "mp_uct_step_tree: no UCT trees of %d roots on this ctx (closed-loop trees cannot be re-used)", n_roots);
     MP_HIP(hipSetDevice(ctx->device));
     // a second step before the next plan (receding_horizon > 1: abstract.py:70-82 steps the tree on every act) descends
     // one more level: apply the pending re-rooting now, then arm the new one
-    if (ctx->tree.armed) MP_TRY(uct_reroot_now(ctx, ctx->tree.cap));
+    if (ctx->tree.armed) MP_TRY(stoch ? uct_stoch_reroot_now(ctx, ctx->tree.cap) : uct_reroot_now(ctx, ctx->tree.cap));
     int32_t *d = nullptr;
     MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots, &d));
     MP_HIP(hipMemcpyAsync(d, actions, (size_t)n_roots * sizeof(int32_t),

@@ -60,6 +60,7 @@ struct StochArgs {
     const uint64_t *env_rng;
     SHot *hot;              // [n_roots][cap]
     SCold *cold;            // [n_roots][cap]
+    const int32_t *n_nodes_in; // kept (re-rooted) tree sizes, nullptr = every root starts fresh (step_strategy "subtree", open loop)
     int32_t *n_nodes_out;
     int32_t *plans, *plan_len;
     double *root_value, *root_child_value;
@@ -235,8 +236,11 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     uint64_t rt[AR]; // the rollout policy's thresholds (wave-uniform)
 #pragma unroll
     for (int j = 0; j < AR; ++j) rt[j] = AT > 0 ? rthr[j] : 0ULL;
-    make(0, -1, -1, 0); // mcts.py:129-130 reset()
-    int n_nodes = 1;
+    int n_nodes = p.n_nodes_in ? p.n_nodes_in[r] : 0; // > 0: a tree kept by step_strategy "subtree" (open loop only)
+    if (n_nodes < 1) {
+        make(0, -1, -1, 0); // mcts.py:129-130 reset()
+        n_nodes = 1;
+    }
     long steps_taken = 0;
     // statistics of the first NK path nodes below the root as the descent read them (nobody writes them in between): their
     // backup needs no load (registers, statically indexed -- a load per path node is a scattered vector-memory instruction)
@@ -247,6 +251,10 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     for (int q = 0; q < NK; ++q) { kv[q] = 0.0; kc[q] = 0; }
     double root_v = 0.0; // the root's statistics live in registers for the plan (every episode reads and updates them)
     int root_c = 0, root_first = -1;
+    if (p.n_nodes_in && p.n_nodes_in[r] > 0) { // (a kept root continues from its statistics)
+        const SHot h0 = hot[0];
+        root_v = h0.value; root_c = h0.count; root_first = h0.first;
+    }
 #ifdef MP_PROFILE
     long long t_sel = 0, t_exp = 0, t_roll = 0, t_bak = 0, n_sel = 0, n_roll = 0;
     const long long t_all0 = clock64();
@@ -537,9 +545,73 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     if (p.plan_len) p.plan_len[r] = len;
 }
 
+// AbstractPlanner.step_by_subtree (abstract.py:195-206) on OPEN-LOOP trees of this kernel, one root per lane: the subtree of
+// the root's child `action` is re-numbered breadth-first into the other buffer (every expanded node's |A| children stay
+// contiguous).  While a node waits in the queue its `first` holds its OLD id.  A never-expanded root gives size 0.
+__global__ __launch_bounds__(64) void uct_stoch_reroot_kernel(int n_roots, int A, int cap_old, int cap_new,
+                                                              const SHot *__restrict__ old_hot, SHot *__restrict__ new_hot,
+                                                              SCold *__restrict__ cold, const int32_t *n_old,
+                                                              const int32_t *__restrict__ actions, int32_t *n_new)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_roots) return;
+    const SHot *o = old_hot + (long)r * cap_old;
+    SHot *n = new_hot + (long)r * cap_new;
+    const int a = actions[r];
+    if (n_old[r] < 1 || o[0].first < 0 || a < 0 || a >= A) {
+        n_new[r] = 0;
+        return;
+    }
+    int head = 0, tail = 1;
+    SHot first;
+    first.value = 0.0; first.count = 0; first.first = o[0].first + a;
+    n[0] = first;
+    while (head < tail) {
+        const SHot src = o[n[head].first];
+        SHot out;
+        out.value = src.value; out.count = src.count; out.first = -1;
+        if (src.first >= 0) {
+            out.first = tail;
+            for (int c = 0; c < A; ++c) {
+                SHot q;
+                q.value = 0.0; q.count = 0; q.first = src.first + c;
+                n[tail + c] = q;
+            }
+            tail += A;
+        }
+        n[head] = out;
+        ++head;
+    }
+    SCold c0;
+    c0.key = -1; c0.next = -1; c0.parent = -1; c0.is_obs = 0;
+    cold[(long)r * cap_new] = c0; // (the root is the only node of an open-loop tree with a cold half)
+    n_new[r] = tail;
+}
+
 } // namespace mp
 
 using namespace mp;
+
+// Apply the re-rooting armed by mp_uct_step_tree to the open-loop trees of the last mp_uct_plan_stochastic: every kept tree
+// -> the subtree under its root's child actions[i], into the other hot buffer with node stride cap_new.
+int uct_stoch_reroot_now(mp_ctx *ctx, long cap_new)
+{
+    const int n_roots = ctx->tree.n_roots, A = ctx->tree.A;
+    const int old_slot = ctx->tree.buf ? WS_TREE5 : WS_TREE0, new_slot = ctx->tree.buf ? WS_TREE0 : WS_TREE5;
+    SHot *nw = nullptr;
+    SCold *cold = nullptr;
+    MP_TRY(ws_get(ctx, new_slot, (size_t)n_roots * cap_new, &nw));
+    MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap_new, &cold));
+    int32_t *sizes = (int32_t *)ctx->ws[WS_TREE1].p;
+    const int32_t *acts = (const int32_t *)ctx->ws[WS_TREE3].p;
+    hipLaunchKernelGGL(uct_stoch_reroot_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), 0, ctx->stream, n_roots, A,
+                       ctx->tree.cap, (int)cap_new, (const SHot *)ctx->ws[old_slot].p, nw, cold, sizes, acts, sizes);
+    MP_HIP(hipGetLastError());
+    ctx->tree.buf ^= 1;
+    ctx->tree.cap = (int)cap_new;
+    ctx->tree.armed = false;
+    return MP_OK;
+}
 
 extern "C" {
 
@@ -690,25 +762,46 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     double *d_tab = nullptr;
     MP_TRY(upload_tables(ctx, 7, tab, &d_tab));
 
-    const long cap = 1 + (long)E * ((long)A + (closed_loop ? H : 0));
-    const bool p16 = cap <= 65535;
+    // nodes per tree: an episode expands at most one node (|A| action children) and, in closed loop, creates at most ONE
+    // observation node -- the descent stops at a new node, which has no children yet (mcts.py:143-149)
+    const long cap = 1 + (long)E * ((long)A + (closed_loop ? 1 : 0));
+    // step_strategy "subtree" (open loop): the trees kept by mp_uct_step_tree are re-rooted into the other buffer with room
+    // for this plan's expansions; a kept subtree only holds nodes of the last `horizon` plans (see uct_plan_impl)
+    const bool cont = ctx->tree.armed && ctx->tree.kind == 4 && ctx->tree.K == 0 && !closed_loop && ctx->tree.n_roots == n_roots &&
+                      ctx->tree.A == A;
+    long cap_use = cap;
+    if (cont) {
+        const long now = 1 + (long)H * E * A;
+        if (now > ctx->tree.kept_bound) ctx->tree.kept_bound = now;
+        cap_use = (ctx->tree.cap < ctx->tree.kept_bound ? (long)ctx->tree.cap : ctx->tree.kept_bound) + (long)E * A;
+    }
+    const bool p16 = cap_use <= 65535;
     // path stack entries: the root + one per level, two per level in closed loop (action node, observation node)
     const size_t lds = (ntab + (wbk == 1 ? 256 : 0)) * sizeof(double) + (size_t)(closed_loop ? 2 * H + 2 : H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
 
     StochArgs a;
     memset(&a, 0, sizeof(a));
-    a.n_roots = n_roots; a.mode = mode; a.S = S; a.A = A; a.W = W; a.episodes = E; a.horizon = H; a.cap = (int)cap;
+    a.n_roots = n_roots; a.mode = mode; a.S = S; a.A = A; a.W = W; a.episodes = E; a.horizon = H; a.cap = (int)cap_use;
     a.closed_loop = closed_loop ? 1 : 0; a.done_on_next = model->done_on_next; a.max_steps = model->max_steps;
     a.table_n = TE;
     a.max_plan_len = max_plan_len;
     a.T = model->T; a.thr = model->thr; a.nxt = model->NXT; a.R = model->R; a.term = model->term; a.tab = d_tab;
     a.srec = wb ? model->srec : nullptr;
     a.rtab = model->srec_rtab;
-    MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap, &a.hot));
-    MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap, &a.cold));
-    MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out));
-    ctx->tree.kind = 4; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.armed = false;
+    MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out)); // per-root tree sizes (updated in place by re-rooting and planning)
+    if (cont) {
+        MP_TRY(uct_stoch_reroot_now(ctx, cap_use));
+        a.hot = (SHot *)ctx->ws[ctx->tree.buf ? WS_TREE5 : WS_TREE0].p;
+        a.cold = (SCold *)ctx->ws[WS_TREE2].p;
+        a.n_nodes_in = a.n_nodes_out;
+    } else {
+        ctx->tree.buf = 0;
+        ctx->tree.kept_bound = 1 + (long)H * E * A;
+        MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap_use, &a.hot));
+        MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap_use, &a.cold));
+    }
+    ctx->tree.kind = 4; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap_use; ctx->tree.armed = false;
     ctx->tree.K = closed_loop ? 1 : 0;
 
     int32_t *d_rs = nullptr, *d_st = nullptr;
@@ -774,7 +867,7 @@ int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_
     if (n > cap) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_export: capacity %d < %d nodes", cap, n);
     std::vector<SHot> h((size_t)n);
     std::vector<SCold> c((size_t)n);
-    MP_HIP(hipMemcpy(h.data(), (const SHot *)ctx->ws[WS_TREE0].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SHot),
+    MP_HIP(hipMemcpy(h.data(), (const SHot *)ctx->ws[ctx->tree.buf ? WS_TREE5 : WS_TREE0].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SHot),
                      hipMemcpyDeviceToHost));
     MP_HIP(hipMemcpy(c.data(), (const SCold *)ctx->ws[WS_TREE2].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SCold),
                      hipMemcpyDeviceToHost));

@@ -515,3 +515,50 @@ def test_state_aware_restricted_actions_batch_vs_oracle(ctx, shape, mapping, mon
             break
     planners.close()
     model.close()
+
+
+def test_mcts_subtree_strategy_on_stochastic_models_matches_reference():
+    """step_strategy "subtree" on STOCHASTIC finite MDPs, open loop (round 4: the device refused before; the reference's
+    step_by_subtree, tree_search/abstract.py:195-206, works on any env): multi-step episodes -- the live env is stepped,
+    its generator advances, the device re-roots the kept tree (mp_uct_step_tree on the trees of mp_uct_plan_stochastic,
+    also twice between two plans with receding_horizon = 2) -- plans, whole trees, generator states equal the unmodified
+    reference's (tests/golden/stoch_subtree.npz, tests/golden/gen/make_golden_stoch_subtree.py)."""
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv
+    from tests.test_gpu_variants import _agent_tree
+    zz = np.load(os.path.join(REPO, "tests", "golden", "stoch_subtree.npz"))
+    for name in [str(n) for n in zz["stoch_subtree/names"]]:
+        p = "stoch_subtree/" + name
+        cfg = mdp_from_golden(zz, p + "/mdp")
+        c = dict(mode=cfg["mode"], transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"],
+                 max_steps=cfg["max_steps"], state=int(zz[p + "/s0"]))
+        if "next" in cfg:
+            c["next"] = cfg["next"]
+        env = FiniteMDPEnv(c)
+        env.reset()
+        env.seed(1000 + int(zz[p + "/seed"]))
+        acfg = dict(__class__=UCT, budget=int(zz[p + "/budget"]), gamma=float(zz[p + "/gamma"]), temperature=float(zz[p + "/temperature"]),
+                    horizon=int(zz[p + "/horizon"]), episodes=int(zz[p + "/episodes"]), step_strategy="subtree",
+                    receding_horizon=int(zz[p + "/receding_horizon"]))
+        if "pref" in name:
+            acfg.update(prior_policy={"type": "preference", "action": 1, "ratio": 3},
+                        rollout_policy={"type": "preference", "action": 1, "ratio": 3})
+        agent = agent_factory(env, acfg)
+        agent.seed(int(zz[p + "/seed"]))
+        for step in range(int(zz[p + "/n_steps"])):
+            q = "{}/step{}".format(p, step)
+            assert env.mdp.state == int(zz[p + "/states"][step]), (name, step)
+            np.testing.assert_array_equal(native.rng_state_from_generator(env.np_random), zz[q + "/env_rng"])
+            plan = agent.plan(env.mdp.state)
+            np.testing.assert_array_equal(plan, zz[q + "/plan"], err_msg=q)
+            np.testing.assert_array_equal(native.rng_state_from_generator(agent.planner.np_random), zz[q + "/rng_after"], err_msg=q)
+            if agent.planner.last is not None:                   # (a step that re-used the previous plan exports nothing new)
+                root = agent.planner.root
+                assert root.count == int(zz[q + "/root_count"]) and root.get_value() == float(zz[q + "/root_value"]), q
+                t = _agent_tree(root)
+                np.testing.assert_array_equal(t["parent"], zz[q + "/tree/parent"], err_msg=q)
+                np.testing.assert_array_equal(t["action"], zz[q + "/tree/action"], err_msg=q)
+                for f in ("count", "value"):
+                    assert np.array_equal(t[f].astype(zz[q + "/tree/" + f].dtype), zz[q + "/tree/" + f]), (q, f)
+            env.step(plan[0])

@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /root/repo
+python -m pytest tests -m gpu -x -q -k "stoch or round3 or subtree" 2>&1 | tail -25
