@@ -310,6 +310,17 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
                            const double *rollout_p, int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state,
                            int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
                            int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem);
+/* The same plan with PER-STATE policies (restricted action sets, mcts.py:59-97; prior agents, mcts_with_prior.py:47-62) from
+ * mp_policy_load / _listed / _ordered on this (stochastic or sparse) model.  A node is expanded with the listed actions and
+ * priors of the state the env clone is in at that moment (mcts.py:151-154,237-246) and keeps them -- in open loop later
+ * episodes reach it in other states.  mp_uct_step_tree re-uses open-loop trees of either form. */
+int mp_uct_plan_stochastic_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const int32_t *root_state,
+                                  const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                                  int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state, int32_t max_plan_len,
+                                  int32_t *plans, int32_t *plan_len, double *root_value, int64_t *root_child_count,
+                                  double *root_child_value, int64_t *env_steps, int32_t mem);
+/* stored child priors (0 for the root and observation nodes) of the tree LAST exported by mp_uct_stoch_tree_export, same order */
+int mp_uct_stoch_tree_priors(mp_ctx *ctx, int32_t cap, double *prior);
 int mp_uct_stoch_tree_capacity(mp_ctx *ctx, int32_t *cap);
 int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *key,
                              uint8_t *is_obs, int64_t *count, double *value);

@@ -279,7 +279,7 @@ def uct_plan_stoch(mode, transition, reward, terminal, s0, episodes, horizon, ga
     term = None if terminal is None else _u8(np.asarray(terminal).reshape(s))
     rng = np.array(rng_state, dtype=np.uint64)
     erng = np.array(env_rng_state, dtype=np.uint64)
-    prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
+    prior, cdf, state_policy, pol_n, pol_act = _policy_args(prior_p, rollout_p, s, a)
     cap = 1 + episodes * (a + horizon)
     plan = np.full(max_plan_len, -1, dtype=np.int32)
     plan_len, steps, nn, rv = C.c_int32(), C.c_int64(), C.c_int32(), C.c_double()
@@ -292,7 +292,8 @@ def uct_plan_stoch(mode, transition, reward, terminal, s0, episodes, horizon, ga
                                   _p(erng, C.c_uint64), max_plan_len, _p(plan, C.c_int32), C.byref(plan_len), C.byref(steps),
                                   C.byref(rv), cap, _p(tree["parent"], C.c_int32), _p(tree["action"], C.c_int32),
                                   _p(tree["is_obs"], C.c_uint8), _p(tree["count"], C.c_int64), _p(tree["value"], C.c_double),
-                                  _p(tree["prior"], C.c_double), C.byref(nn))
+                                  _p(tree["prior"], C.c_double), C.byref(nn), state_policy, _p(pol_n, C.c_int32),
+                                  _p(pol_act, C.c_int32))
     assert rc == 0, rc
     tree = {k: v[:nn.value].copy() for k, v in tree.items()}
     return dict(plan=plan[:plan_len.value].copy(), env_steps=steps.value, rng_after=rng, root_value=rv.value, tree=tree)
@@ -314,7 +315,7 @@ def uct_plan_stoch_batch(mode, transition, reward, terminal, s0, episodes, horiz
     st0 = None if steps0 is None else np.ascontiguousarray(steps0, dtype=np.int32)
     rng = np.array(rng_states, dtype=np.uint64).reshape(n, 6)
     erng = np.ascontiguousarray(np.array(env_rng_states, dtype=np.uint64).reshape(n, 6))
-    prior, cdf = _f64(prior_p), policy_cdf(rollout_p)
+    prior, cdf, state_policy, pol_n, pol_act = _policy_args(prior_p, rollout_p, s, a)
     plans = np.full((n, max_plan_len), -1, dtype=np.int32)
     plan_len, steps, rv = np.zeros(n, np.int32), np.zeros(n, np.int64), np.zeros(n, np.float64)
     rc = lib().orc_uct_plan_stoch_batch(mode_i, s, a, b, _p(t_i, C.c_int64), _p(t_f, C.c_double), _p(nxt, C.c_int64),
@@ -323,7 +324,8 @@ def uct_plan_stoch_batch(mode, transition, reward, terminal, s0, episodes, horiz
                                         C.c_double(temperature), _p(prior, C.c_double), _p(cdf, C.c_double),
                                         int(bool(closed_loop)), _p(rng, C.c_uint64), _p(erng, C.c_uint64), max_plan_len,
                                         _p(plans, C.c_int32), _p(plan_len, C.c_int32), _p(steps, C.c_int64),
-                                        _p(rv, C.c_double), int(n_threads))
+                                        _p(rv, C.c_double), int(n_threads), state_policy, _p(pol_n, C.c_int32),
+                                        _p(pol_act, C.c_int32))
     assert rc == 0, rc
     return dict(plans=plans, plan_len=plan_len, env_steps=steps, root_value=rv, rng_after=rng)
 

@@ -840,9 +840,15 @@ int orc_uct_plan_stoch(int mode, int S, int A, int B, const int64_t *T, const do
                        const double *rollout_cdf, int closed_loop, uint64_t *rng6, const uint64_t *env_rng6,
                        int max_plan_len, int32_t *plan, int32_t *plan_len, int64_t *env_steps, double *root_value,
                        int cap, int32_t *t_parent, int32_t *t_key, uint8_t *t_is_obs, int64_t *t_count, double *t_value,
-                       double *t_prior, int32_t *n_nodes_out)
+                       double *t_prior, int32_t *n_nodes_out,
+                       /* per-state policies as in orc_uct_plan: 0 = prior [A] / rollout cdf [A]; 1 = tables [S, A]; 2 = listed
+                        * (pol_n [2 S]: listed actions per state of the prior, then of the rollout policy; pol_act [2 S A]: their
+                        * ids; prior / rollout_cdf [S, A] by list position).  A node is expanded with the list of the state the
+                        * env is in AT THAT MOMENT (mcts.py:151-154,237-246) and keeps it. */
+                       int state_policy, const int32_t *pol_n, const int32_t *pol_act)
 {
     if (cap < 1 + episodes * (A + horizon)) return ORC_ERR_ARG;
+    if (state_policy == 2 && (!pol_n || !pol_act)) return ORC_ERR_ARG;
     const int W = mode == 1 ? S : B;
     int32_t *parent = malloc(cap * sizeof(int32_t)), *key = malloc(cap * sizeof(int32_t));
     int32_t *first = malloc(cap * sizeof(int32_t)), *last = malloc(cap * sizeof(int32_t)), *next = malloc(cap * sizeof(int32_t));
@@ -905,11 +911,19 @@ int orc_uct_plan_stoch(int mode, int S, int A, int B, const int64_t *T, const do
             }
             ++depth;
         }
-        if (n_ch[node] == 0 && depth < horizon && (!terminal || node == 0)) /* mcts.py:151-154 */
-            for (int a = 0; a < A; ++a) NEW_NODE(node, a, 0, prior[a]);
+        if (n_ch[node] == 0 && depth < horizon && (!terminal || node == 0)) { /* mcts.py:151-154 */
+            const int k = state_policy == 2 ? pol_n[s] : A;
+            for (int j = 0; j < k; ++j)
+                NEW_NODE(node, state_policy == 2 ? pol_act[(long)s * A + j] : j, 0, state_policy ? prior[(long)s * A + j] : prior[j]);
+        }
         if (!terminal)
             for (int h = depth; h < horizon; ++h) { /* mcts.py:160-177 */
-                const int a = orc_cdf_pick(rollout_cdf, A, orc_pcg64_double(&g));
+                const double u = orc_pcg64_double(&g);
+                int a;
+                if (state_policy == 2)
+                    a = pol_act[(long)S * A + (long)s * A + orc_cdf_pick(rollout_cdf + (long)s * A, pol_n[S + s], u)];
+                else
+                    a = orc_cdf_pick(state_policy ? rollout_cdf + (long)s * A : rollout_cdf, A, u);
                 double r; int term_h, trunc_h;
                 ENV_STEP(a, r, term_h, trunc_h);
                 total_reward += gpow[h] * r;
@@ -959,7 +973,8 @@ int orc_uct_plan_stoch_batch(int mode, int S, int A, int B, const int64_t *T, co
                              const int32_t *s0, const int32_t *steps0, int episodes, int horizon, double gamma,
                              double temperature, const double *prior, const double *rollout_cdf, int closed_loop,
                              uint64_t *rng6, const uint64_t *env_rng6, int max_plan_len, int32_t *plans, int32_t *plan_len,
-                             int64_t *env_steps, double *root_value, int n_threads)
+                             int64_t *env_steps, double *root_value, int n_threads, int state_policy, const int32_t *pol_n,
+                             const int32_t *pol_act)
 {
     const int cap = 1 + episodes * (A + horizon);
     int bad = 0;
@@ -969,7 +984,8 @@ int orc_uct_plan_stoch_batch(int mode, int S, int A, int B, const int64_t *T, co
                                     episodes, horizon, gamma, temperature, prior, rollout_cdf, closed_loop, rng6 + (long)i * 6,
                                     env_rng6 + (long)i * 6, max_plan_len, plans ? plans + (long)i * max_plan_len : NULL,
                                     plan_len ? plan_len + i : NULL, env_steps ? env_steps + i : NULL,
-                                    root_value ? root_value + i : NULL, cap, NULL, NULL, NULL, NULL, NULL, NULL, NULL);
+                                    root_value ? root_value + i : NULL, cap, NULL, NULL, NULL, NULL, NULL, NULL, NULL, state_policy,
+                                    pol_n, pol_act);
         if (rc != ORC_OK) bad = rc;
     }
     return bad;

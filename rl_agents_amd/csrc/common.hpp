@@ -56,6 +56,7 @@ struct TreeMeta {
     bool armed = false; // UCT: mp_uct_step_tree was called; the next plan re-roots and continues
     int il = 0;          // UCT: 1 = wave-interleaved tree layout (see uct.hip TreeRef)
     long kept_bound = 0; // UCT: upper bound on the nodes a kept (re-rooted) tree can hold, see uct_plan_impl
+    bool sp = false;     // stochastic UCT: the last plan used per-state policies (stored priors in the cold halves, phantom slots)
 };
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,
@@ -103,6 +104,7 @@ struct mp_ctx {
     // ctx's stream, so a block that is handed out again is reused in stream order.
     struct Block { void *p; size_t bytes; };
     std::vector<Block> block_cache;
+    std::vector<double> stoch_priors; // stored child priors of the tree last exported by mp_uct_stoch_tree_export (per-state policies)
     size_t block_cache_bytes = 0;
 };
 
@@ -224,6 +226,8 @@ struct mp_policy {
     uint64_t *thr = nullptr;    // [S][stride]  ceil(cdf[s][a] * 2^53), a < A-1 (the last threshold is never reached)
     uint4 *frec = nullptr;      // [S*A][frq]   {Rec of (s,a); top 32 bits of the thr row of the state it leads to}
     uint4 *frec_roll = nullptr; // the same records by ROLLOUT slot (mp_policy_load_ordered), nullptr when the orders agree
+    uint32_t *lmask = nullptr;  // policies of STOCHASTIC models (uct_stoch.hip): actions the prior policy lists per state, [S]
+    uint8_t *rslot = nullptr;   // ... and the column of every rollout slot, [S][A], nullptr when slots are the columns
 };
 
 namespace mp {

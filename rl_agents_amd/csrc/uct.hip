@@ -894,7 +894,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     if (!ctx || !model || !root_state || !rng_state || (!pol && (!prior_p || !rollout_p)))
         return fail(MP_ERR_ARG, "mp_uct_plan: NULL argument");
     const bool cart = model->mode == MP_MODE_CARTPOLE;
-    if (pol && (cart || pol->model != model || pol->model_serial != model->serial || pol->ctx != ctx))
+    if (pol && (cart || pol->model != model || pol->model_serial != model->serial || pol->ctx != ctx || !pol->frec))
         return fail(MP_ERR_ARG, "mp_uct_plan_policy: the policy was not loaded for this model");
     if (model->mode != MP_MODE_DETERMINISTIC && !cart)
         return fail(MP_ERR_MODE, "mp_uct_plan: model mode %d is neither a deterministic table nor CartPole", model->mode);
@@ -1269,11 +1269,12 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
                            const uint8_t *rollout_slot, mp_policy **out)
 {
     if (!ctx || !model || !prior || !rollout || !out) return fail(MP_ERR_ARG, "mp_policy_load: NULL argument");
-    if (model->mode != MP_MODE_DETERMINISTIC || !model->rec)
-        return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a deterministic table model");
+    const bool stoch = model->mode == MP_MODE_STOCHASTIC || model->mode == MP_MODE_SPARSE; // policies for uct_stoch.hip
+    if (!stoch && (model->mode != MP_MODE_DETERMINISTIC || !model->rec))
+        return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a finite-MDP model");
     const int S = model->S, A = model->A;
-    if (!(A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8))
-        return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not one of 2,3,4,5,6,8", A);
+    if (stoch ? (A < 2 || A > 8) : !(A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8))
+        return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not one of %s", A, stoch ? "2..8" : "2,3,4,5,6,8");
     MP_HIP(hipSetDevice(ctx->device));
     const int stride = (A + 1) & ~1, frq = 1 + (A - 1 + 3) / 4;
     std::vector<double> hp((size_t)S * stride, 0.0);
@@ -1302,6 +1303,34 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
             const double scaled = ceil(ldexp(cdf[a] / acc, 53));                   // cdf /= cdf[-1]; see mp_uct_plan
             ht[(size_t)s * stride + a] = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
         }
+    }
+    if (stoch) {
+        // a stochastic model's kernel stores priors in the tree and reads thresholds by state: prior / thresholds / listed
+        // masks (+ the rollout slots' columns) are all it needs -- no fused records
+        std::vector<uint32_t> lm((size_t)S, (1u << A) - 1u);
+        if (listed)
+            for (int s = 0; s < S; ++s) {
+                uint32_t m = 0;
+                for (int a = 0; a < A; ++a) m |= (listed[(size_t)s * A + a] ? 1u : 0u) << a;
+                if (!m) return fail(MP_ERR_ARG, "mp_policy_load_listed: the prior policy lists no action in state %d", s);
+                lm[(size_t)s] = m;
+            }
+        mp_policy *pol = new (std::nothrow) mp_policy;
+        if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
+        pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride;
+        pol->listed = listed ? 1 : 0;
+        if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
+            hipMalloc(&pol->lmask, lm.size() * 4) != hipSuccess ||
+            (rollout_slot && hipMalloc(&pol->rslot, (size_t)S * A) != hipSuccess)) {
+            mp_policy_free(pol);
+            return fail(MP_ERR_ALLOC, "mp_policy_load: device allocation failed");
+        }
+        MP_HIP(hipMemcpy(pol->prior, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
+        MP_HIP(hipMemcpy(pol->thr, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
+        MP_HIP(hipMemcpy(pol->lmask, lm.data(), lm.size() * 4, hipMemcpyHostToDevice));
+        if (rollout_slot) MP_HIP(hipMemcpy(pol->rslot, rollout_slot, (size_t)S * A, hipMemcpyHostToDevice));
+        *out = pol;
+        return MP_OK;
     }
     std::vector<Rec> hrec((size_t)S * A);
     MP_HIP(hipStreamSynchronize(ctx->stream));
@@ -1381,6 +1410,8 @@ int mp_policy_free(mp_policy *policy)
     if (policy->frec) (void)hipFree(policy->frec);
     if (policy->frec16) (void)hipFree(policy->frec16);
     if (policy->frec_roll) (void)hipFree(policy->frec_roll);
+    if (policy->lmask) (void)hipFree(policy->lmask);
+    if (policy->rslot) (void)hipFree(policy->rslot);
     delete policy;
     return MP_OK;
 }

@@ -56,6 +56,13 @@ struct StochArgs {
     const uint8_t *term;    // [S] or nullptr
     const int32_t *root_state, *root_steps;
     const double *tab;      // gpow[H+1] | rollout thresholds [A] (uint64 bits) | tp[A] = (temperature * |A|) * prior[a]
+    // per-state policies (mp_policy of a stochastic model): nullptr for the state-independent ones
+    const double *pol_prior;   // [S][pol_stride]  prior[s][a], 0 for the actions the prior policy does not list
+    const uint64_t *pol_thr;   // [S][pol_stride]  ceil(cdf * 2^53) of the rollout policy, by rollout slot
+    const uint32_t *pol_mask;  // [S]  actions the prior policy lists
+    const uint8_t *pol_rslot;  // [S][A] column of rollout slot k, or nullptr (slots are the columns)
+    int pol_stride;
+    double temperature;
     uint64_t *rng;
     const uint64_t *env_rng;
     SHot *hot;              // [n_roots][cap]
@@ -190,9 +197,15 @@ __global__ void compact_records16(long rows, const uint4 *__restrict__ rec32, co
 // computed once, no loop-carried branches), 0 = any |A|.
 // PT: the type of a path-stack entry (uint16_t while every node id fits: the stack is the kernel's LDS footprint, and LDS is
 // what limits the waves per SIMD here -- 27 KB per wave held a 262 144-root batch at ONE wave per SIMD).
-template <int WB, int AT, typename PT>
+// SP: per-state prior / rollout policies (restricted action sets, mcts.py:59-97; prior agents, mcts_with_prior.py:47-62).
+// A node is expanded with the actions and priors of the state the env is in AT THAT MOMENT (mcts.py:151-154,237-246) and
+// keeps them whatever state later episodes reach it in: the prior of a child is STORED (the first 8 bytes of the action
+// node's otherwise unused cold half), an unlisted action's slot is a PHANTOM (count = -1: never scored, never visited,
+// dropped by the export) and len(children) is the number of real slots of the scored group.
+template <int WB, int AT, typename PT, bool SP = false>
 __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
 {
+    static_assert(!SP || AT > 0, "per-state policies: |A| at compile time");
     extern __shared__ __attribute__((aligned(16))) double lds_s[];
     const int lane = threadIdx.x, A = AT > 0 ? AT : p.A, H = p.horizon, E = p.episodes;
     constexpr int AR = AT > 0 ? AT : 1;
@@ -349,8 +362,22 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
 #pragma unroll
                 for (int a = 0; a < AR; ++a) c[a] = hot[fc + a];
                 double sc[AR];
+                if (SP) {
+                    double pr[AR];
+                    int nl = 0;
 #pragma unroll
-                for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
+                    for (int a = 0; a < AR; ++a) {
+                        pr[a] = *reinterpret_cast<const double *>(&cold[fc + a]);
+                        nl += c[a].count >= 0 ? 1 : 0;
+                    }
+                    const double TAk = p.temperature * (double)nl; // mcts.py:286, left to right
+#pragma unroll
+                    for (int a = 0; a < AR; ++a)
+                        sc[a] = c[a].count < 0 ? -INFINITY : c[a].value + (TAk * pr[a]) / (double)(c[a].count + 1);
+                } else {
+#pragma unroll
+                    for (int a = 0; a < AR; ++a) sc[a] = c[a].value + explore(a, c[a].count + 1);
+                }
                 double m = sc[0];
 #pragma unroll
                 for (int a = 1; a < AR; ++a) m = sc[a] > m ? sc[a] : m;
@@ -432,7 +459,18 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
         // ---- expansion, mcts.py:151-154 (a child per action, prior = the state-independent prior policy's)
         if (fc < 0 && depth < H && (!terminal || node == 0)) {
             const int c0 = n_nodes;
-            for (int a = 0; a < A; ++a) make(c0 + a, node, a, 0);
+            if (SP) { // prior_policy(state, observation) of the state the clone is in now
+                const uint32_t mask = p.pol_mask[s];
+                const double *row = p.pol_prior + (long)s * p.pol_stride;
+                for (int a = 0; a < A; ++a) {
+                    SHot h;
+                    h.value = 0.0; h.count = (mask >> a) & 1u ? 0 : -1; h.first = -1;
+                    hot[c0 + a] = h;
+                    *reinterpret_cast<double *>(&cold[c0 + a]) = row[a];
+                }
+            } else {
+                for (int a = 0; a < A; ++a) make(c0 + a, node, a, 0);
+            }
             if (node == 0) root_first = c0;
             hot[node].first = c0;
             n_nodes += A;
@@ -446,7 +484,12 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             uint64_t k = gn.next64() >> 11;          // np_random.choice(actions, 1, p=p): one double, inverse cdf
             for (int h = depth; h < H; ++h) {
                 int a = 0;
-                if (AT > 0) {
+                if (SP) { // rollout_policy(state, observation): the thresholds of the state the clone is in
+                    const uint64_t *tr = p.pol_thr + (long)s * p.pol_stride;
+#pragma unroll
+                    for (int j = 0; j < AR - 1; ++j) a += tr[j] <= k ? 1 : 0;
+                    if (p.pol_rslot) a = p.pol_rslot[(long)s * A + a];
+                } else if (AT > 0) {
 #pragma unroll
                     for (int j = 0; j < AR - 1; ++j) a += rt[j] <= k ? 1 : 0;
                 } else {
@@ -508,7 +551,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
     {
         const int fc = root_first;
         for (int a = 0; a < A; ++a) {
-            if (p.root_child_count) p.root_child_count[(long)r * A + a] = fc >= 0 ? hot[fc + a].count : 0;
+            if (p.root_child_count) p.root_child_count[(long)r * A + a] = fc >= 0 ? max(hot[fc + a].count, 0) : 0;
             if (p.root_child_value) p.root_child_value[(long)r * A + a] = fc >= 0 ? hot[fc + a].value : 0.0;
         }
     }
@@ -531,6 +574,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             if (fc >= 0)
                 for (int a = 0; a < A; ++a) {
                     const SHot cn = hot[fc + a];
+                    if (cn.count < 0) continue; // (the phantom slot of an unlisted action)
                     if (best < 0 || cn.count > bc || (cn.count == bc && cn.value > bv)) { best = fc + a; bc = cn.count; bv = cn.value; bkey = a; }
                 }
         }
@@ -548,17 +592,21 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
 // AbstractPlanner.step_by_subtree (abstract.py:195-206) on OPEN-LOOP trees of this kernel, one root per lane: the subtree of
 // the root's child `action` is re-numbered breadth-first into the other buffer (every expanded node's |A| children stay
 // contiguous).  While a node waits in the queue its `first` holds its OLD id.  A never-expanded root gives size 0.
+// old_cold != nullptr (per-state policies): the action nodes' cold halves hold their stored priors and travel with them.
 __global__ __launch_bounds__(64) void uct_stoch_reroot_kernel(int n_roots, int A, int cap_old, int cap_new,
                                                               const SHot *__restrict__ old_hot, SHot *__restrict__ new_hot,
-                                                              SCold *__restrict__ cold, const int32_t *n_old,
-                                                              const int32_t *__restrict__ actions, int32_t *n_new)
+                                                              const SCold *__restrict__ old_cold, SCold *__restrict__ cold,
+                                                              const int32_t *n_old, const int32_t *__restrict__ actions, int32_t *n_new)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_roots) return;
     const SHot *o = old_hot + (long)r * cap_old;
     SHot *n = new_hot + (long)r * cap_new;
+    const SCold *oc = old_cold ? old_cold + (long)r * cap_old : nullptr;
+    SCold *nc = cold + (long)r * cap_new;
     const int a = actions[r];
-    if (n_old[r] < 1 || o[0].first < 0 || a < 0 || a >= A) {
+    // `if action in self.root.children` (abstract.py:201): an unlisted action has a phantom slot, not a child
+    if (n_old[r] < 1 || o[0].first < 0 || a < 0 || a >= A || o[o[0].first + a].count < 0) {
         n_new[r] = 0;
         return;
     }
@@ -576,6 +624,7 @@ __global__ __launch_bounds__(64) void uct_stoch_reroot_kernel(int n_roots, int A
                 SHot q;
                 q.value = 0.0; q.count = 0; q.first = src.first + c;
                 n[tail + c] = q;
+                if (oc) nc[tail + c] = oc[src.first + c];
             }
             tail += A;
         }
@@ -584,7 +633,7 @@ __global__ __launch_bounds__(64) void uct_stoch_reroot_kernel(int n_roots, int A
     }
     SCold c0;
     c0.key = -1; c0.next = -1; c0.parent = -1; c0.is_obs = 0;
-    cold[(long)r * cap_new] = c0; // (the root is the only node of an open-loop tree with a cold half)
+    nc[0] = c0; // (the root is the only node of an open-loop tree whose cold half is a record)
     n_new[r] = tail;
 }
 
@@ -598,14 +647,18 @@ int uct_stoch_reroot_now(mp_ctx *ctx, long cap_new)
 {
     const int n_roots = ctx->tree.n_roots, A = ctx->tree.A;
     const int old_slot = ctx->tree.buf ? WS_TREE5 : WS_TREE0, new_slot = ctx->tree.buf ? WS_TREE0 : WS_TREE5;
+    // (per-state policies keep stored priors in the cold halves: those alternate between two buffers like the hot ones)
+    const bool sp = ctx->tree.sp;
+    const int old_cold = sp && ctx->tree.buf ? WS_TREE6 : WS_TREE2, new_cold = sp && !ctx->tree.buf ? WS_TREE6 : WS_TREE2;
     SHot *nw = nullptr;
     SCold *cold = nullptr;
     MP_TRY(ws_get(ctx, new_slot, (size_t)n_roots * cap_new, &nw));
-    MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap_new, &cold));
+    MP_TRY(ws_get(ctx, new_cold, (size_t)n_roots * cap_new, &cold));
     int32_t *sizes = (int32_t *)ctx->ws[WS_TREE1].p;
     const int32_t *acts = (const int32_t *)ctx->ws[WS_TREE3].p;
     hipLaunchKernelGGL(uct_stoch_reroot_kernel, dim3((unsigned)((n_roots + 63) / 64)), dim3(64), 0, ctx->stream, n_roots, A,
-                       ctx->tree.cap, (int)cap_new, (const SHot *)ctx->ws[old_slot].p, nw, cold, sizes, acts, sizes);
+                       ctx->tree.cap, (int)cap_new, (const SHot *)ctx->ws[old_slot].p, nw,
+                       sp ? (const SCold *)ctx->ws[old_cold].p : (const SCold *)nullptr, cold, sizes, acts, sizes);
     MP_HIP(hipGetLastError());
     ctx->tree.buf ^= 1;
     ctx->tree.cap = (int)cap_new;
@@ -623,14 +676,19 @@ int mp_model_set_episode_rules(mp_model *model, int32_t done_on_next, int32_t ma
     return MP_OK;
 }
 
-int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, const int32_t *root_steps,
-                           int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
-                           const double *rollout_p, int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state,
-                           int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
-                           int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem)
+} // extern "C"
+
+static int uct_stoch_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int32_t n_roots, const int32_t *root_state,
+                               const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                               const double *prior_p, const double *rollout_p, int32_t closed_loop, uint64_t *rng_state,
+                               const uint64_t *env_rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len,
+                               double *root_value, int64_t *root_child_count, double *root_child_value, int64_t *env_steps,
+                               int32_t mem)
 {
-    if (!ctx || !model || !root_state || !rng_state || !prior_p || !rollout_p)
+    if (!ctx || !model || !root_state || !rng_state || (!pol && (!prior_p || !rollout_p)))
         return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: NULL argument");
+    if (pol && (pol->model != model || pol->model_serial != model->serial || pol->ctx != ctx || !pol->lmask))
+        return fail(MP_ERR_ARG, "mp_uct_plan_stochastic_policy: the policy was not loaded for this (stochastic) model");
     if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: unknown mem flags %d", mem);
     const int mode = model->mode;
     if (mode != MP_MODE_DETERMINISTIC && mode != MP_MODE_STOCHASTIC && mode != MP_MODE_SPARSE)
@@ -639,7 +697,8 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
         return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: a stochastic model needs the env's generator records");
     if (mode == MP_MODE_STOCHASTIC && (model->M != 1 || model->Sc != model->S))
         return fail(MP_ERR_MODE, "mp_uct_plan_stochastic: one full dense model [S,A,S] expected");
-    if (model->masked) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: restricted action sets are not supported here");
+    if (model->masked && !pol)
+        return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: the model restricts its action sets: plan with a policy (mp_uct_plan_stochastic_policy)");
     if (n_roots < 1 || episodes < 0 || horizon < 0 || max_plan_len < 0)
         return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: bad sizes (n_roots=%d episodes=%d horizon=%d)", n_roots, episodes, horizon);
     const int A = model->A, S = model->S, H = horizon, E = episodes;
@@ -746,13 +805,13 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (TE + 1);
     for (int h = 0; h <= H; ++h) gpow[h] = pow(gamma, (double)h);
     double acc = 0.0;
-    for (int a = 0; a < A; ++a) { acc += rollout_p[a]; cdf[a] = acc; }
+    for (int a = 0; a < A; ++a) { acc += pol ? 1.0 : rollout_p[a]; cdf[a] = acc; }
     for (int a = 0; a < A; ++a) {
         const double scaled = ceil(ldexp(cdf[a] / acc, 53));
         const uint64_t t = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
         memcpy(&cdf[a], &t, sizeof(t));
     }
-    for (int a = 0; a < A; ++a) tpv[a] = temperature * (double)A * prior_p[a]; // mcts.py:286, left to right
+    for (int a = 0; a < A; ++a) tpv[a] = temperature * (double)A * (pol ? 0.0 : prior_p[a]); // mcts.py:286, left to right
     rcp[0] = 0.0;
     for (int n = 1; n <= TE; ++n) rcp[n] = 1.0 / (double)n;                    // mcts.py:257: 1 / count
     for (int a = 0; a < A; ++a) {
@@ -768,14 +827,14 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     // step_strategy "subtree" (open loop): the trees kept by mp_uct_step_tree are re-rooted into the other buffer with room
     // for this plan's expansions; a kept subtree only holds nodes of the last `horizon` plans (see uct_plan_impl)
     const bool cont = ctx->tree.armed && ctx->tree.kind == 4 && ctx->tree.K == 0 && !closed_loop && ctx->tree.n_roots == n_roots &&
-                      ctx->tree.A == A;
+                      ctx->tree.A == A && ctx->tree.sp == (pol != nullptr);
     long cap_use = cap;
     if (cont) {
         const long now = 1 + (long)H * E * A;
         if (now > ctx->tree.kept_bound) ctx->tree.kept_bound = now;
         cap_use = (ctx->tree.cap < ctx->tree.kept_bound ? (long)ctx->tree.cap : ctx->tree.kept_bound) + (long)E * A;
     }
-    const bool p16 = cap_use <= 65535;
+    const bool p16 = cap_use <= 65535 && !pol; // (the per-state-policy kernels are built with 32-bit path entries only)
     // path stack entries: the root + one per level, two per level in closed loop (action node, observation node)
     const size_t lds = (ntab + (wbk == 1 ? 256 : 0)) * sizeof(double) + (size_t)(closed_loop ? 2 * H + 2 : H + 2) * 64 * (p16 ? sizeof(uint16_t) : sizeof(int32_t));
     if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic: horizon %d needs %zu B of LDS (> 64 KiB)", H, lds);
@@ -789,14 +848,17 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     a.T = model->T; a.thr = model->thr; a.nxt = model->NXT; a.R = model->R; a.term = model->term; a.tab = d_tab;
     a.srec = wb ? model->srec : nullptr;
     a.rtab = model->srec_rtab;
+    a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_mask = pol ? pol->lmask : nullptr;
+    a.pol_rslot = pol ? pol->rslot : nullptr; a.pol_stride = pol ? pol->stride : 0; a.temperature = temperature;
     MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out)); // per-root tree sizes (updated in place by re-rooting and planning)
     if (cont) {
         MP_TRY(uct_stoch_reroot_now(ctx, cap_use));
         a.hot = (SHot *)ctx->ws[ctx->tree.buf ? WS_TREE5 : WS_TREE0].p;
-        a.cold = (SCold *)ctx->ws[WS_TREE2].p;
+        a.cold = (SCold *)ctx->ws[ctx->tree.sp && ctx->tree.buf ? WS_TREE6 : WS_TREE2].p;
         a.n_nodes_in = a.n_nodes_out;
     } else {
         ctx->tree.buf = 0;
+        ctx->tree.sp = pol != nullptr;
         ctx->tree.kept_bound = 1 + (long)H * E * A;
         MP_TRY(ws_get(ctx, WS_TREE0, (size_t)n_roots * cap_use, &a.hot));
         MP_TRY(ws_get(ctx, WS_TREE2, (size_t)n_roots * cap_use, &a.cold));
@@ -828,9 +890,20 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
         static const kernel_t table16[4][9] = {MP_ROW(0, uint16_t), MP_ROW(2, uint16_t), MP_ROW(4, uint16_t), MP_ROW(1, uint16_t)};
         static const kernel_t table32[4][9] = {MP_ROW(0, int32_t), MP_ROW(2, int32_t), MP_ROW(4, int32_t), MP_ROW(1, int32_t)};
 #undef MP_ROW
+#define MP_ROWP(WBV) {uct_stoch_kernel<WBV, 2, int32_t, true>, uct_stoch_kernel<WBV, 3, int32_t, true>, uct_stoch_kernel<WBV, 4, int32_t, true>, \
+                      uct_stoch_kernel<WBV, 5, int32_t, true>, uct_stoch_kernel<WBV, 6, int32_t, true>, uct_stoch_kernel<WBV, 7, int32_t, true>, \
+                      uct_stoch_kernel<WBV, 8, int32_t, true>}
+        static const kernel_t table_sp[4][7] = {MP_ROWP(0), MP_ROWP(2), MP_ROWP(4), MP_ROWP(1)};
+#undef MP_ROWP
         const char *ag = getenv("MP_UCT_STOCH_GENERIC_A"); // "1": the loop form of the selection for any |A| -- test hook
         const int at = A >= 2 && A <= 8 && !(ag && ag[0] == '1') ? A : 0;
-        hipLaunchKernelGGL((p16 ? table16 : table32)[wbk == 2 ? 1 : wbk == 4 ? 2 : wbk == 1 ? 3 : 0][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+        const int wrow = wbk == 2 ? 1 : wbk == 4 ? 2 : wbk == 1 ? 3 : 0;
+        if (pol) {
+            if (A < 2 || A > 8) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic_policy: |A| = %d is not in 2..8", A);
+            hipLaunchKernelGGL(table_sp[wrow][A - 2], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+        } else {
+            hipLaunchKernelGGL((p16 ? table16 : table32)[wrow][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+        }
     }
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());
@@ -843,6 +916,39 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
     MP_TRY(stage_out_copy(ctx, root_child_value, a.root_child_value, (size_t)n_roots * A, amem));
     MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, amem));
     if (amem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
+extern "C" {
+
+int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, const int32_t *root_steps,
+                           int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,
+                           const double *rollout_p, int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state,
+                           int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
+                           int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem)
+{
+    return uct_stoch_plan_impl(ctx, model, nullptr, n_roots, root_state, root_steps, episodes, horizon, gamma, temperature, prior_p,
+                               rollout_p, closed_loop, rng_state, env_rng_state, max_plan_len, plans, plan_len, root_value,
+                               root_child_count, root_child_value, env_steps, mem);
+}
+
+int mp_uct_plan_stochastic_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const int32_t *root_state,
+                                  const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                                  int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state, int32_t max_plan_len,
+                                  int32_t *plans, int32_t *plan_len, double *root_value, int64_t *root_child_count,
+                                  double *root_child_value, int64_t *env_steps, int32_t mem)
+{
+    if (!policy) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic_policy: policy is NULL");
+    return uct_stoch_plan_impl(ctx, model, policy, n_roots, root_state, root_steps, episodes, horizon, gamma, temperature, nullptr,
+                               nullptr, closed_loop, rng_state, env_rng_state, max_plan_len, plans, plan_len, root_value,
+                               root_child_count, root_child_value, env_steps, mem);
+}
+
+int mp_uct_stoch_tree_priors(mp_ctx *ctx, int32_t cap, double *prior)
+{
+    if (!ctx || !prior) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_priors: NULL argument");
+    if ((size_t)cap < ctx->stoch_priors.size()) return fail(MP_ERR_ARG, "mp_uct_stoch_tree_priors: capacity %d < %zu nodes", cap, ctx->stoch_priors.size());
+    for (size_t i = 0; i < ctx->stoch_priors.size(); ++i) prior[i] = ctx->stoch_priors[i];
     return MP_OK;
 }
 
@@ -869,8 +975,8 @@ int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_
     std::vector<SCold> c((size_t)n);
     MP_HIP(hipMemcpy(h.data(), (const SHot *)ctx->ws[ctx->tree.buf ? WS_TREE5 : WS_TREE0].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SHot),
                      hipMemcpyDeviceToHost));
-    MP_HIP(hipMemcpy(c.data(), (const SCold *)ctx->ws[WS_TREE2].p + (long)root * ctx->tree.cap, (size_t)n * sizeof(SCold),
-                     hipMemcpyDeviceToHost));
+    MP_HIP(hipMemcpy(c.data(), (const SCold *)ctx->ws[ctx->tree.sp && ctx->tree.buf ? WS_TREE6 : WS_TREE2].p + (long)root * ctx->tree.cap,
+                     (size_t)n * sizeof(SCold), hipMemcpyDeviceToHost));
     // node types by one pass in creation order (a parent is older than its children): the root and the observation nodes
     // carry a cold half; an action node's key / parent follow from the sibling group it sits in
     const int A = ctx->tree.A;
@@ -886,14 +992,26 @@ int mp_uct_stoch_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_
             for (int a = 0; a < A && f + a < n; ++a) { act[f + a] = 1; par[f + a] = i; ky[f + a] = a; }
         }
     }
+    // per-state policies: the slots of unlisted actions are phantoms (count = -1), not nodes: dropped and the ids closed up
+    std::vector<int32_t> new_id((size_t)n, -1);
+    int m = 0;
+    for (int i = 0; i < n; ++i)
+        if (!(act[i] && h[i].count < 0)) new_id[i] = m++;
     for (int i = 0; i < n; ++i) {
-        if (parent) parent[i] = par[i];
-        if (key) key[i] = ky[i];
-        if (is_obs) is_obs[i] = obs[i];
-        if (count) count[i] = h[i].count;
-        if (value) value[i] = h[i].value;
+        const int j = new_id[i];
+        if (j < 0) continue;
+        if (parent) parent[j] = par[i] >= 0 ? new_id[par[i]] : -1;
+        if (key) key[j] = ky[i];
+        if (is_obs) is_obs[j] = obs[i];
+        if (count) count[j] = h[i].count;
+        if (value) value[j] = h[i].value;
     }
-    if (n_nodes) *n_nodes = n;
+    // stored priors of the action nodes (per-state policies), for the agent-level tree: kept for mp_uct_stoch_tree_priors
+    ctx->stoch_priors.assign((size_t)m, 0.0);
+    if (ctx->tree.sp)
+        for (int i = 0; i < n; ++i)
+            if (new_id[i] >= 0 && act[i]) memcpy(&ctx->stoch_priors[(size_t)new_id[i]], &c[i], sizeof(double));
+    if (n_nodes) *n_nodes = m;
     return MP_OK;
 }
 

@@ -60,6 +60,9 @@ SIGNATURES = {
     "mp_model_set_episode_rules": (C.c_int, [_vp, c_i32, c_i32]),
     "mp_uct_plan_stochastic": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, c_i32, _vp, _vp,
                                          c_i32, _vp, _vp, _vp, _vp, _vp, _vp, c_i32]),
+    "mp_uct_plan_stochastic_policy": (C.c_int, [_vp, _vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, c_i32, _vp, _vp,
+                                                c_i32, _vp, _vp, _vp, _vp, _vp, _vp, c_i32]),
+    "mp_uct_stoch_tree_priors": (C.c_int, [_vp, c_i32, _vp]),
     "mp_uct_stoch_tree_capacity": (C.c_int, [_vp, P(c_i32)]),
     "mp_uct_stoch_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp]),
     "mp_policy_load_listed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, P(_vp)]),
@@ -557,7 +560,7 @@ class Context(object):
                                      _ptr(env_steps), MP_MEM_DEVICE))
 
     def uct_plan_stochastic(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
-                            env_rng_state=None, closed_loop=False, root_steps=None, max_plan_len=None):
+                            env_rng_state=None, closed_loop=False, root_steps=None, max_plan_len=None, policy=None):
         """MCTS.plan on a stochastic (dense / sparse) finite-MDP model, open or closed loop (mp_uct_plan_stochastic).
         env_rng_state uint64 [n,6]: the env generator's record per root at plan time (every episode's clone starts from
         it; not advanced).  closed_loop: plans alternate action, observation key (next state index), action, ..."""
@@ -567,13 +570,20 @@ class Context(object):
         mem, rng_ptr = self._rng_arg(rng_state, n)
         erng = None if env_rng_state is None else np.ascontiguousarray(env_rng_state, dtype=np.uint64).reshape(n, 6)
         mpl = int((2 if closed_loop else 1) * horizon if max_plan_len is None else max_plan_len)
+        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
+                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
+                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        if policy is not None:          # per-state policies (load_policy on this stochastic model)
+            _check(self._lib.mp_uct_plan_stochastic_policy(self._h, model._h, policy._h, n, _ptr(rs), _ptr(st), int(episodes),
+                                                           int(horizon), float(gamma), float(temperature), int(bool(closed_loop)),
+                                                           rng_ptr, _ptr(erng), mpl, _ptr(out["plans"]), _ptr(out["plan_len"]),
+                                                           _ptr(out["root_value"]), _ptr(out["root_child_count"]),
+                                                           _ptr(out["root_child_value"]), _ptr(out["env_steps"]), mem))
+            return out
         pp = np.ascontiguousarray(prior_p, dtype=np.float64)
         rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
         if pp.shape != (model.A,) or rp.shape != (model.A,):
             raise ValueError("prior_p / rollout_p must have one entry per action")
-        out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
-                   root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
-                   root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
         _check(self._lib.mp_uct_plan_stochastic(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
                                                 float(gamma), float(temperature), _ptr(pp), _ptr(rp), int(bool(closed_loop)),
                                                 rng_ptr, _ptr(erng), mpl, _ptr(out["plans"]), _ptr(out["plan_len"]),
@@ -592,6 +602,8 @@ class Context(object):
         n = c_i32()
         _check(self._lib.mp_uct_stoch_tree_export(self._h, int(root), cap, C.byref(n), _ptr(t["parent"]), _ptr(t["action"]),
                                                   _ptr(t["is_obs"]), _ptr(t["count"]), _ptr(t["value"])))
+        t["prior"] = np.zeros(cap, np.float64)      # stored child priors (per-state policies; zeros otherwise)
+        _check(self._lib.mp_uct_stoch_tree_priors(self._h, cap, _ptr(t["prior"])))
         return {k: v[:n.value].copy() for k, v in t.items()}
 
     def uct_step_tree(self, actions):

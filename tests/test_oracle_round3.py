@@ -200,3 +200,47 @@ def test_random_policy_goldens_oracle_literal():
         assert out["env_steps"] == int(zz[p + "/env_steps"]), name
         np.testing.assert_array_equal(out["rng_after"], zz[p + "/rng_after"], err_msg=name)
         assert_keyed_tree_equal(zz, p + "/tree", out["tree"], dict(count="count", value="value", prior="prior"))
+
+
+def stoch_policy_lists(zz, p):
+    """The per-state lists the reference's policy functions return for a stoch_policies.npz case (ascending listing:
+    MaskedFiniteMDPEnv / FiniteMDPEnv): (prior, rollout) dicts for the oracle."""
+    import json
+    from tests.helpers import reference_policy_lists, restricted_agent_policy_lists
+    cfg = mdp_from_golden(zz, p + "/mdp")
+    n_states, n_actions = cfg["reward"].shape
+    restricted = (p + "/available") in zz.files
+    avail = zz[p + "/available"] if restricted else np.ones((n_states, n_actions), bool)
+    if bool(zz[p + "/with_prior_agent"]):
+        if restricted:                  # agent_policy_available renormalises over the listed actions ...
+            lists = restricted_agent_policy_lists(zz[p + "/prior_table"], avail)
+        else:                           # ... and hands the agent's distribution through as it is otherwise (:56-62)
+            table = zz[p + "/prior_table"]
+            lists = dict(actions=[list(range(n_actions))] * n_states, p=[table[s].copy() for s in range(n_states)])
+        return lists, lists
+    return (reference_policy_lists(json.loads(str(zz[p + "/prior_policy_json"])), avail),
+            reference_policy_lists(json.loads(str(zz[p + "/rollout_policy_json"])), avail))
+
+
+def test_stochastic_models_with_per_state_policies_goldens():
+    """Round 4: restricted action sets and prior agents on STOCHASTIC models (tests/golden/stoch_policies.npz, the unmodified
+    reference's MCTSAgent / MCTSWithPriorPolicyAgent): the oracle, fed the literal per-state lists, reproduces plans (with
+    observation keys), env steps, root values, generator states and whole trees, open and closed loop."""
+    import os
+    from oracle import oracle
+    from tests.helpers import assert_parent_tree_equal
+    zz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stoch_policies.npz"))
+    for name in [str(n) for n in zz["stoch_policies/names"]]:
+        p = "stoch_policies/" + name
+        cfg = mdp_from_golden(zz, p + "/mdp")
+        prior_l, roll_l = stoch_policy_lists(zz, p)
+        out = oracle.uct_plan_stoch(cfg["mode"], cfg["transition"], cfg["reward"], cfg["terminal"], int(zz[p + "/s0"]),
+                                    int(zz[p + "/episodes"]), int(zz[p + "/horizon"]), float(zz[p + "/gamma"]),
+                                    float(zz[p + "/temperature"]), prior_l, roll_l, zz[p + "/rng_before"], zz[p + "/env_rng"],
+                                    next_states=cfg.get("next"), closed_loop=bool(zz[p + "/closed_loop"]), max_steps=cfg["max_steps"],
+                                    max_plan_len=4 * int(zz[p + "/horizon"]))
+        np.testing.assert_array_equal(out["plan"], zz[p + "/plan"], err_msg=name)
+        assert out["env_steps"] == int(zz[p + "/env_steps"]), name
+        assert out["root_value"] == float(zz[p + "/root_value"]), name
+        np.testing.assert_array_equal(out["rng_after"], zz[p + "/rng_after"], err_msg=name)
+        assert_parent_tree_equal(zz, p + "/tree", out["tree"], dict(count="count", value="value", prior="prior", is_obs="is_obs"))
