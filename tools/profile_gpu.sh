@@ -4,7 +4,7 @@
 # into the tracked profiles/$TAG_*.md summaries.
 #   usage: tools/profile_gpu.sh r01
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=/root/repo/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
@@ -13,14 +13,14 @@ cd /tmp
 args_of() { if [ "$1" = opd8192 ]; then echo "--workload opd --roots 8192"; else echo "--workload $1"; fi; }
 for wl in uct uct_prior uct_cartpole uct_stoch opd opd8192 ropd saopd vi rvi vi_dense rvi_dense_shard; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- \
-      python /root/repo/bench.py $(args_of $wl) --steps 5 --warmup 1 --no-cpu-baseline > $OUT/trace_$wl.log 2>&1
+      python /root/repo/bench.py $(args_of $wl) --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample > $OUT/trace_$wl.log 2>&1
 done
 # HBM traffic: FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots) -> two runs each; counters only,
 # no tracing domains besides the kernel trace
 for wl in uct uct_prior uct_stoch vi_dense rvi_dense_shard opd opd8192 ropd saopd; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o $wl -- \
-        python /root/repo/bench.py $(args_of $wl) --steps 3 --warmup 1 --no-cpu-baseline > $OUT/pmc_${wl}_$ctr.log 2>&1
+        python /root/repo/bench.py $(args_of $wl) --steps 3 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample > $OUT/pmc_${wl}_$ctr.log 2>&1
   done
 done
 find $OUT -name "*.csv" | head -50

@@ -49,7 +49,7 @@ def main():
     os.makedirs(dst, exist_ok=True)
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
-             "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline` on one MI355X (tools/profile_gpu.sh).", ""]
+             "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample` on one MI355X (tools/profile_gpu.sh).", ""]
     for wl in ("uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
