@@ -402,7 +402,9 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
  *   mem = MP_MEM_DEVICE: ASYNCHRONOUS, one launch and nothing read back; a planner whose queue fills up then reports
  *   MP_ERR_ALLOC in `status`, cannot be rolled back, and stays failed: every later call reports MP_ERR_ALLOC for it again
  *   (the other planners of the batch are unaffected).  The same holds for the planners left full when a host-mode call
- *   runs out of room to grow the queue.
+ *   runs out of room to grow the queue.  A planner whose leaves were ALL pruned (the reference raises ValueError from
+ *   max() there, state_aware.py:95) reports MP_ERR_ARG and, in the asynchronous mode -- where the caller goes on stepping
+ *   the batch -- stays failed the same way.
  * The model must outlive the planners (they read its transition records).
  * mp_saopd_export: arena of one planner in creation order (node rows [root, n_nodes) are the current tree; `alive` =
  * "in planner.leaves"), arrays of capacity >= n_nodes (mp_saopd_info), and state_values double [S].

@@ -266,20 +266,28 @@ class MCTS(AbstractPlanner):
 
     # -- device-resident evaluation loop (BatchedEvaluation): roots, generator records and results are device buffers ----
     def supports_device_loop(self):
-        """Plain receding-horizon MCTS on a deterministic table: no kept trees, no host-side observation layer."""
-        return self.config.get("step_strategy", "reset") != "subtree" and not self.config["closed_loop"]
+        """MCTS on deterministic tables: plain, with tree re-use (``step_strategy="subtree"``: the kept trees are re-rooted
+        on the device from the action buffer) and closed loop (on a deterministic model the first action of a
+        closed-loop plan is the open-loop plan's, see the module docstring)."""
+        return True
 
     def device_plan_len(self, model):
         return 1
 
-    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None):
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None,
+                          keep_actions=None):
         """One asynchronous batched plan (mp_uct_plan / mp_uct_plan_policy, MP_MEM_DEVICE): only enqueues.
-        ``d_value``: optional float64 [n] buffer for the root values."""
+        ``d_value``: optional float64 [n] buffer for the root values.  ``keep_actions``: contiguous int32 device tensor of
+        the (device-label) actions executed since the last plan -- ``step_strategy="subtree"``: the trees of the last plan
+        are re-rooted under them (abstract.py:195-206) instead of being reset."""
         if model.mode != native_modes.MODE_DETERMINISTIC:
             raise NotImplementedError("the device-resident loop steps deterministic table models")
         cfg, ctx = self.config, self.models.ctx
         self.about_to_plan()
-        ctx.uct_reset_tree()
+        if keep_actions is not None and self.owns_device_tree() and self._tree_roots == n:
+            ctx.uct_step_tree(keep_actions)
+        else:
+            ctx.uct_reset_tree()
         available = getattr(model, "available", None)
         policy, pp, rp = None, None, None
         if self.policy_source is not None or available is not None:
@@ -297,7 +305,7 @@ class MCTS(AbstractPlanner):
                             int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, root_value=d_value, env_steps=d_env_steps,
                             root_steps=d_steps, policy=policy)
         self.claim_device_tree()
-        self.last, self._root = None, None
+        self.last, self._root, self._tree_roots = None, None, n
 
     def restricted_policy_tables(self, model, available):
         """(prior, rollout, listed, rollout slots) of this planner's policy configs on a model whose environment restricts

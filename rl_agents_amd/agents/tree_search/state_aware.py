@@ -69,6 +69,32 @@ class StateAwarePlanner(OptimisticDeterministicPlanner):
         self.env_steps += int(out["env_steps"].sum())
         return out
 
+    # -- device-resident evaluation loop (BatchedEvaluation): the planners' arenas, state values and lists already live on
+    # the device between plans; only the call form changes (mp_saopd_plan with MP_MEM_DEVICE: asynchronous, a planner whose
+    # backup queue fills up reports MP_ERR_ALLOC and stays failed instead of being rolled back)
+    def supports_device_loop(self):
+        return True
+
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None,
+                          keep_actions=None):
+        import torch
+        cfg = self.config
+        if cfg["gamma"] == 1:
+            raise ZeroDivisionError("division by zero")
+        planners = self.device_planners(model, n)
+        if getattr(self, "_d_updates", None) is None or self._d_updates.shape[0] != n:
+            self._d_updates = torch.zeros(n, dtype=torch.int64, device=d_state.device)
+        planners.plan_device(d_state, int(cfg["budget"]), cfg["gamma"], cfg.get("terminal_reward", 0), d_rng,
+                             int(d_plans.shape[1]), accuracy=cfg["accuracy"], backup_aggregated_nodes=cfg["backup_aggregated_nodes"],
+                             prune_suboptimal_leaves=cfg["prune_suboptimal_leaves"], plans=d_plans, plan_len=d_len,
+                             env_steps=d_env_steps, updates=self._d_updates, status=d_status)
+        self.last, self._root = None, None
+
+    def raise_for_device_status(self, d_status, live):
+        bad = d_status[live]
+        if bad.numel():
+            self.raise_for_status(bad.cpu().numpy())
+
     @staticmethod
     def raise_for_status(status):
         """The reference's exceptions for the per-planner status codes."""

@@ -242,7 +242,11 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
                     if (leaf < 0 || u > bu) { leaf = i0 + j; bu = u; }
                 }
         }
-        if (leaf < 0) { status = MP_ERR_ARG; break; } // the reference raises: max() of an empty sequence
+        if (leaf < 0) { // the reference raises: max() of an empty sequence.  Asynchronous mode: the caller goes on stepping the
+            status = MP_ERR_ARG; // batch, so the planner stays failed (its tree has no leaf to plan from)
+            if (p.sticky) p.overflow[1 + r] = MP_ERR_ARG;
+            break;
+        }
         // ---- expand (deterministic.py:28-43) + update (:45-65, state_aware.py:15-26)
         const SaNode lf = ND(leaf);
         const int dl = (int)(lf.meta & SA_DEPTH);
@@ -339,7 +343,7 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
                             SV(sn) = backup; SM(sn) = cur;
                             if (qt - qh >= dcap) {
                                 status = MP_ERR_ALLOC; *p.overflow = 1; active = false;
-                                if (p.sticky) p.overflow[1 + r] = 1;
+                                if (p.sticky) p.overflow[1 + r] = MP_ERR_ALLOC;
                                 continue;
                             }
                             QD(qt, 0) = sn; QD(qt, 1) = target;
@@ -481,7 +485,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             if (p.plans)
                 for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
             if (p.plan_len) p.plan_len[r] = 0;
-            if (p.status) p.status[r] = MP_ERR_ALLOC;
+            if (p.status) p.status[r] = p.overflow[1 + r]; // the code it failed with (MP_ERR_ALLOC: queue full; MP_ERR_ARG: every leaf pruned)
             if (p.env_steps) p.env_steps[r] = 0;
             if (p.updates) p.updates[r] = 0;
         }
@@ -651,7 +655,11 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             }
         }
         wave_argmax(bu, leaf);
-        if (leaf == 0x7fffffff) { status = MP_ERR_ARG; break; } // max() of an empty leaves list
+        if (leaf == 0x7fffffff) { // max() of an empty leaves list (see saopd_kernel: sticky in asynchronous mode)
+            status = MP_ERR_ARG;
+            if (p.sticky && lane == 0) p.overflow[1 + r] = MP_ERR_ARG;
+            break;
+        }
         SA_PROF(0);
         // ---- expand + update: one child per lane, then the list appends in action order
         const SaNode lf = load_node(&ND(leaf));
@@ -800,7 +808,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         if (delta > 0.0) {
                             if (qt - qh >= dcap) {
                                 status = MP_ERR_ALLOC;
-                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = 1; }
+                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = MP_ERR_ALLOC; }
                                 break;
                             }
                             if (l0) {
@@ -884,7 +892,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         if (delta > 0.0) {
                             if (qt - qh >= dcap) {
                                 status = MP_ERR_ALLOC;
-                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = 1; }
+                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = MP_ERR_ALLOC; }
                                 break;
                             }
                             if (l0) {
@@ -1281,7 +1289,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
 __global__ __launch_bounds__(64) void saopd_mark_failed_kernel(int n, const int32_t *status, int32_t *overflow)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n && status[r] == MP_ERR_ALLOC) overflow[1 + r] = 1;
+    if (r < n && status[r] == MP_ERR_ALLOC) overflow[1 + r] = MP_ERR_ALLOC;
 }
 
 __global__ __launch_bounds__(64) void saopd_fix_tails_kernel(int n, int S, long node_si, long node_sr, long state_si, long state_sr,

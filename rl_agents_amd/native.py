@@ -607,7 +607,11 @@ class Context(object):
         return {k: v[:n.value].copy() for k, v in t.items()}
 
     def uct_step_tree(self, actions):
-        """step_strategy 'subtree': keep, for the next uct_plan, the subtree under each root's child actions[i]."""
+        """step_strategy 'subtree': keep, for the next uct_plan, the subtree under each root's child actions[i] (a host
+        array, or a contiguous int32 device tensor: only enqueues then)."""
+        if hasattr(actions, "data_ptr"):
+            _check(self._lib.mp_uct_step_tree(self._h, int(actions.shape[0]), _ptr(actions), MP_MEM_DEVICE))
+            return
         a = np.ascontiguousarray(actions, dtype=np.int32).reshape(-1)
         _check(self._lib.mp_uct_step_tree(self._h, a.shape[0], _ptr(a), MP_MEM_HOST))
 

@@ -136,15 +136,28 @@ class BatchedEvaluation(object):
         d_q = None
         if vi:
             d_q = torch.from_numpy(np.ascontiguousarray(agent.get_state_action_value(), dtype=np.float64)).to(dev)
+        # planners that carry state from plan to plan (kept UCT trees, the state-aware planner's values and lists): every
+        # episode starts with a new planner object, every step plans the FULL batch (finished slots are ignored)
+        subtree = (not vi) and planner.config.get("step_strategy") == "subtree" and hasattr(planner, "step_by_subtree")
+        if not vi and (subtree or getattr(planner, "carries_state", False)):
+            planner.step_by_reset()
+            if hasattr(planner, "forget"):
+                planner.forget()
+        d_prev = torch.zeros(n, dtype=torch.int32, device=dev)
         torch.cuda.synchronize(dev)                            # the buffers exist before the ctx stream touches them
         t0 = time.perf_counter()
         t = 0
         while t < T:
             if vi:
                 ctx.greedy_actions_device(d_q, d_state, d_plans)
+            elif subtree:                                      # AbstractPlanner.step_tree -> step_by_subtree(actions[0])
+                planner.plan_batch_device(env, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_es[t], d_status[t],
+                                          keep_actions=d_prev if t else None)
             else:
                 planner.plan_batch_device(env, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_es[t], d_status[t])
             ctx.env_step_device(model, d_state, d_steps, d_alive, d_plans, T, d_gpow, d_ret, d_disc, d_log, d_nalive)
+            if subtree:
+                self._copy_first_actions(ctx, d_plans, d_prev)
             t += 1
             if t % self.check_every == 0 or t == T:
                 ctx.synchronize()
@@ -156,15 +169,26 @@ class BatchedEvaluation(object):
         live = torch.arange(T, device=dev)[:, None] < d_steps[None, :].to(torch.int64)      # step t of episode i was played
         if not vi:
             planner.raise_for_device_status(d_status, live)
-            planner.env_steps += int((d_es * live).sum().item())
+        if (d_log.cpu().numpy()[live.cpu().numpy().T] < 0).any():   # a live episode was handed an empty plan (budget < |A|, no
+            raise Exception("The agent did not plan any action")     # episodes): Evaluation.step raises (evaluation.py:168-170)
+        if not vi:
+            if subtree or getattr(planner, "carries_state", False):
+                planner.env_steps += int(d_es[:t].sum().item())   # (stateful planners plan every slot at every step, as the
+            else:                                                #  host-stepped loop does: finished slots count there too)
+                planner.env_steps += int((d_es * live).sum().item())
         actions = d_log.cpu().numpy()
-        if (actions[live.cpu().numpy().T] < 0).any():          # a live episode was handed an empty plan (budget < |A|, no
-            raise Exception("The agent did not plan any action")   # episodes): Evaluation.step raises (evaluation.py:168-170)
         if order is not None:                                  # the device planned in the env's listing order
             actions = np.where(actions >= 0, np.asarray(order)[np.maximum(actions, 0)], -1).astype(np.int32)
         return dict(returns=d_ret.cpu().numpy(), discounted_returns=d_disc.cpu().numpy(), lengths=lengths, actions=actions,
                     fps=float(lengths.sum()) / wall, plan_seconds=wall,
                     planner_env_steps=0 if vi else int(planner.env_steps), device_resident=True)
+
+    @staticmethod
+    def _copy_first_actions(ctx, d_plans, d_prev):
+        """d_prev <- d_plans[:, 0] on the planner's stream (the actions the kept trees are re-rooted under next step)."""
+        import torch
+        with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_ptr(), device=d_plans.device)):
+            d_prev.copy_(d_plans[:, 0])
 
     # ---------------------------------------------------------------------------------------- host-stepped loop
     def _run_host(self, starts, first):
@@ -210,14 +234,14 @@ class BatchedEvaluation(object):
             plan_seconds += time.perf_counter() - t1
             rng[idx] = sub_rng
             act = out["plans"][:, 0].astype(np.int64)
+            if stateful and "status" in out and hasattr(planner, "raise_for_status"):
+                planner.raise_for_status(np.asarray(out["status"])[alive[idx]])   # what a sequential agent would raise
             if (act[alive[idx]] < 0).any():                    # Evaluation.step (evaluation.py:168-170) raises on an empty plan
                 raise Exception("The agent did not plan any action")
             act[act < 0] = 0                                   # (episodes that are over: their plans are ignored)
             if stateful:
                 previous = act.astype(np.int32)
                 live = alive[idx]
-                if "status" in out and hasattr(planner, "raise_for_status"):
-                    planner.raise_for_status(np.asarray(out["status"])[live])   # what a sequential agent would raise
                 idx, act = idx[live], act[live]
             s = states[idx]
             r = self.reward[s, act]

@@ -120,12 +120,41 @@ def test_value_iteration_agents_in_the_batched_loop(robust):
         assert runs[1]["lengths"][i] == len(acts)
 
 
-def test_stateful_planners_keep_the_host_stepped_loop():
+SAOPD = "<class 'rl_agents_amd.agents.tree_search.state_aware.StateAwarePlannerAgent'>"
+
+
+@pytest.mark.parametrize("kind", ["uct_subtree", "uct_subtree_masked", "uct_closed_loop", "state_aware", "state_aware_masked"])
+def test_stateful_planners_in_the_device_resident_loop(kind):
+    """Round 4: planners that carry state from plan to plan run in the device-resident loop too -- MCTS with
+    step_strategy="subtree" (the kept trees are re-rooted on the device from the action buffer), closed-loop MCTS on a
+    deterministic table, the state-aware planner (its arenas, state values and lists live on the device anyway) -- and
+    equal the host-stepped loop (which tests/test_gpu_agents.py pins to N sequential agents) action for action."""
     from rl_agents_amd.agents.common.factory import agent_factory
     from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
-    env = _table_env()
-    agent = agent_factory(env, dict(__class__=UCT, budget=100, step_strategy="subtree"))
-    out = BatchedEvaluation(env, agent, num_episodes=5, sim_seed=3).run()
-    assert out["device_resident"] is False
-    with pytest.raises(NotImplementedError):
-        BatchedEvaluation(env, agent, num_episodes=5, sim_seed=3, device_resident=True).run()
+    if kind.startswith("uct_subtree"):
+        cfg = dict(__class__=UCT, budget=150, gamma=0.9, step_strategy="subtree")
+    elif kind == "uct_closed_loop":
+        cfg = dict(__class__=UCT, budget=150, gamma=0.9, closed_loop=True)
+    else:
+        # (with pruning one of these 70 episodes ends in the reference's own ValueError -- every leaf pruned,
+        # state_aware.py:95 -- which both loops raise: checked at the end)
+        cfg = dict(__class__=SAOPD, budget=120, gamma=0.85, prune_suboptimal_leaves=False)
+    n = 70
+    starts = (np.arange(n) * 7 % 100).astype(np.int32)
+    runs = []
+    for resident in (False, True):
+        env = _table_env(masked=kind.endswith("masked"))
+        agent = agent_factory(env, dict(cfg))
+        ev = BatchedEvaluation(env, agent, num_episodes=n, sim_seed=40, max_steps=9, device_resident=resident, check_every=4)
+        runs.append(ev.run(initial_states=starts))
+        assert runs[-1]["device_resident"] is resident
+    _compare(runs[0], runs[1])
+    auto = BatchedEvaluation(_table_env(masked=kind.endswith("masked")), agent_factory(_table_env(masked=kind.endswith("masked")), dict(cfg)),
+                             num_episodes=5, sim_seed=3).run()
+    assert auto["device_resident"] is True
+    if kind == "state_aware":
+        for resident in (False, True):
+            env = _table_env()
+            agent = agent_factory(env, dict(cfg, prune_suboptimal_leaves=True))
+            with pytest.raises(ValueError, match="empty sequence"):
+                BatchedEvaluation(env, agent, num_episodes=n, sim_seed=40, max_steps=9, device_resident=resident).run(initial_states=starts)
