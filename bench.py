@@ -84,6 +84,50 @@ def pmc_traffic(workload, kernel_substr, grid_threads, pattern="scattered"):
     return None, None
 
 
+def live_pmc_traffic(kernel_substr, grid_threads, pattern, extra_args):
+    """HBM bytes per launch of the headline kernel MEASURED IN THIS RUN: this very script is run twice more for a few steps
+    under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, counters only, as the guide
+    prescribes), and the kernel's launches at the benchmarked grid are averaged.  -> (bytes, raw dict) or (None, reason).
+    BENCH_NO_LIVE_PMC=1 skips it (and so does running under it)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if os.environ.get("BENCH_NO_LIVE_PMC") or os.environ.get("BENCH_UNDER_PMC"):
+        return None, "skipped"
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, "rocprofv3 not found"
+    cal = calibration()
+    vals = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = [prof, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", out, "-o", "pmc", "--",
+               sys.executable, os.path.abspath(__file__), "--headline-only", "--no-cpu-baseline", "--no-parity-sample", "--steps", "3",
+               "--warmup", "1"] + extra_args
+        try:
+            subprocess.run(cmd, env=dict(os.environ, BENCH_UNDER_PMC="1", TMPDIR="/tmp"), cwd="/tmp", stdout=subprocess.DEVNULL,
+                           stderr=subprocess.DEVNULL, timeout=240, check=False)
+            got = []
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr and kernel_substr in row["Kernel_Name"] and int(row["Grid_Size"]) == grid_threads:
+                        got.append(float(row["Counter_Value"]))
+            if not got:
+                return None, "no {} rows for the kernel".format(ctr)
+            vals[ctr] = (sum(got) / len(got), len(got))
+        except (OSError, subprocess.SubprocessError, ValueError, KeyError) as e:
+            return None, "{}: {}".format(type(e).__name__, e)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    ff, fw = cal["fetch_" + pattern], cal["write_" + pattern]
+    raw = dict(FETCH_SIZE_bytes=vals["FETCH_SIZE"][0] * 1024.0, WRITE_SIZE_bytes=vals["WRITE_SIZE"][0] * 1024.0, fetch_factor=ff,
+               write_factor=fw, calibration=cal["source"], launches=[vals["FETCH_SIZE"][1], vals["WRITE_SIZE"][1]],
+               source="measured in this run: two rocprofv3 --pmc passes of `bench.py --headline-only --steps 3`")
+    return ff * raw["FETCH_SIZE_bytes"] + fw * raw["WRITE_SIZE_bytes"], raw
+
+
 def add_traffic(roofline, workload, kernel_substr, grid_threads, pattern="scattered"):
     """roofline.traffic (+ traffic_frac = traffic / kernel time / peak, the MEASURED HBM fraction, next to the contract's
     algorithmic one) from the committed PMC passes."""
@@ -512,6 +556,17 @@ def bench_uct(args, rank, world, local, with_prior=False):
                                       "are not charged" if with_prior else "")),
     )
     add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)
+    if not with_prior and rank == 0 and world == 1 and not args.headline_only:
+        # the default run measures the headline kernel's HBM traffic itself (it used to be read from a committed
+        # summary); the committed figure stays beside it as `traffic_committed`
+        live, raw = live_pmc_traffic("uct_kernel", n_roots, "scattered", ["--roots", str(n_roots)])
+        roof = res["roofline"]
+        roof["traffic_committed"] = roof["traffic"]
+        if live is not None:
+            roof["traffic"], roof["traffic_counters"] = live, raw
+            roof["traffic_frac"] = live / (roof["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        else:
+            roof["traffic_live"] = raw              # (why not: the committed summary is what `traffic` holds then)
     if cross is not None:
         res["_cross"] = cross
     if not args.no_parity_sample:
