@@ -448,18 +448,19 @@ def bench_uct(args, rank, world, local, with_prior=False):
     mean_depth = sel_steps / float(n_smp * episodes)
     # model term: 13 B per env step gathered from the 16-byte records -- or, when the kernel keeps the whole model in LDS
     # (uct_ldsr: the default from 65 536 roots), only what every workgroup stages once per launch: 3 B per (s, a) + tables
-    model_bytes_per_step = 13.0
-    staged = None
+    staged, bytes_per_step_hbm = None, None
+    tree_bytes = 16.0 * a_ * sel_steps + 24.0 * (sel_steps + n_smp * episodes) + 24.0 * a_ * expansions
+    bytes_per_step = (13.0 * sample_env + tree_bytes) / sample_env          # the ALGORITHM's bytes, whatever serves them
     if variant == "uct_ldsr":
+        # ... of which the 13 B per env step of the model are served from LDS by this kernel: what it must move through HBM is
+        # the tree terms + what every workgroup stages once per launch (3 B per (s, a) + tables) -- reported beside `frac`
         cus = ctx.device_info()["n_cu"]
         waves = 1
         while waves < -(-(n_roots // 64) // cus) and waves < 16:
             waves *= 2
         n_wg = -(-n_roots // (64 * waves))
         staged = n_wg * (3.0 * s_ * a_ + 8.0 * len(np.unique(r)) + 8.0 * (horizon + 1 + 2 * a_ + (episodes + 1) + a_ * (episodes + 2)))
-        model_bytes_per_step = staged / float(env_steps)
-    bytes_per_step = (model_bytes_per_step * sample_env + 16.0 * a_ * sel_steps + 24.0 * (sel_steps + n_smp * episodes)
-                      + 24.0 * a_ * expansions) / sample_env
+        bytes_per_step_hbm = (staged / float(env_steps) * sample_env + tree_bytes) / sample_env
     # metric half (ii) and the 8(d) definition: small batches and the host-inclusive call, rank 0's GPU
     latency = {}
     for nl in (1, 4096):
@@ -548,11 +549,14 @@ def bench_uct(args, rank, world, local, with_prior=False):
                       kernel="uct_kernel<5, {}>".format("ENV_TABLE, per-state policies" if with_prior else
                                                         ("ENV_TABLE_LDSR (model resident in LDS)" if variant == "uct_ldsr" else "ENV_TABLE")),
                       kernel_variant=variant, model_bytes_staged_per_launch=staged,
+                      hbm_side_bytes_per_launch=None if bytes_per_step_hbm is None else bytes_per_step_hbm * env_steps,
+                      frac_hbm_side=None if bytes_per_step_hbm is None else bytes_per_step_hbm * env_steps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                       kernel_ms=k_ms, algorithmic_bytes_per_launch=bytes_per_step * env_steps,
                       note="algorithmic bytes = SURVEY 8(d) terms with the depth / expansions measured on this launch's "
-                           "trees" + ("; the model term is what the workgroups stage into LDS once per launch (an env step "
-                                      "makes no global request), so the fraction prices the tree traffic only: this kernel is "
-                                      "bound by vector-ALU issue, not by HBM" if variant == "uct_ldsr" else "") + ("; the per-state policy tables (L2-resident by construction, like the 800 KB model) "
+                           "trees" + ("; this kernel serves the model term (13 B per env step) from LDS -- staged once per workgroup -- so "
+                                      "`frac` is the rate at which the ALGORITHM's bytes are consumed, not HBM traffic: "
+                                      "`frac_hbm_side` prices what must cross HBM (tree terms + staging) and `traffic` is what "
+                                      "the counters saw; the kernel is bound by vector-ALU issue" if variant == "uct_ldsr" else "") + ("; the per-state policy tables (L2-resident by construction, like the 800 KB model) "
                                       "are not charged" if with_prior else "")),
     )
     add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)
