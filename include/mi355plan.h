@@ -445,6 +445,14 @@ int mp_env_step(mp_ctx *ctx, mp_model *model, int32_t n, int32_t *state, int32_t
                 double *discounted, int32_t *actions_log, int32_t log_stride, int32_t *n_alive, int32_t mem);
 int mp_greedy_actions(mp_ctx *ctx, int32_t n, int32_t S, int32_t A, const double *Q, const int32_t *state, int32_t *plans,
                       int32_t plan_stride, int32_t mem);
+/* mp_env_step for STOCHASTIC / sparse models: the next state is sampled from the episode's own env generator record
+ * (env_rng uint64 [n, 6], numpy PCG64, advanced in place) exactly as FiniteMDPEnv.step does -- one Generator.random()
+ * double, inverse CDF over the row.  The planner reads the same records (mp_uct_plan_stochastic's env_rng_state): every
+ * plan's clones start from the env generator as it is at that step. */
+int mp_env_step_stochastic(mp_ctx *ctx, mp_model *model, int32_t n, int32_t *state, int32_t *steps, uint8_t *alive,
+                           const int32_t *plans, int32_t plan_stride, int32_t max_steps, const double *gpow, double *returns,
+                           double *discounted, int32_t *actions_log, int32_t log_stride, int32_t *n_alive, uint64_t *env_rng,
+                           int32_t mem);
 
 /* ---------------------------------------------------------------- result exchange ------------ */
 /*

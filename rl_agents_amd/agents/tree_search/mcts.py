@@ -219,7 +219,9 @@ class MCTS(AbstractPlanner):
         if model.mode in (native_modes.MODE_STOCHASTIC, native_modes.MODE_SPARSE):
             # (open-loop trees are re-used like the deterministic ones: mp_uct_step_tree armed the re-rooting)
             armed, self._armed = self._armed and n == 1 and not self.config["closed_loop"], False
-            if not (armed and self.owns_device_tree()):
+            if keep_actions is not None and self.owns_device_tree() and not self.config["closed_loop"] and self._tree_roots == n:
+                self.models.ctx.uct_step_tree(np.asarray(keep_actions, dtype=np.int32))   # (batched callers: the executed actions)
+            elif not (armed and self.owns_device_tree()):
                 self.models.ctx.uct_reset_tree()
             return self.plan_batch_stochastic(state, model, root_states, root_steps, rng_states, env_rng_states)
         self._stochastic = False
@@ -275,15 +277,41 @@ class MCTS(AbstractPlanner):
         return 1
 
     def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None,
-                          keep_actions=None):
+                          keep_actions=None, d_env_rng=None):
         """One asynchronous batched plan (mp_uct_plan / mp_uct_plan_policy, MP_MEM_DEVICE): only enqueues.
         ``d_value``: optional float64 [n] buffer for the root values.  ``keep_actions``: contiguous int32 device tensor of
         the (device-label) actions executed since the last plan -- ``step_strategy="subtree"``: the trees of the last plan
         are re-rooted under them (abstract.py:195-206) instead of being reset."""
-        if model.mode != native_modes.MODE_DETERMINISTIC:
-            raise NotImplementedError("the device-resident loop steps deterministic table models")
         cfg, ctx = self.config, self.models.ctx
         self.about_to_plan()
+        if model.mode != native_modes.MODE_DETERMINISTIC:
+            # stochastic / sparse models: the episodes' env generator records are a device buffer too (d_env_rng: every
+            # plan's clones start from the env generator as it is at that step; mp_env_step_stochastic advances it)
+            if d_env_rng is None:
+                raise ValueError("a stochastic model needs the episodes' env generator records (d_env_rng)")
+            armed = keep_actions is not None and self.owns_device_tree() and self._tree_roots == n and not cfg["closed_loop"]
+            if armed:
+                ctx.uct_step_tree(keep_actions)
+            else:
+                ctx.uct_reset_tree()
+            available = getattr(model, "available", None)
+            policy, pp, rp = None, None, None
+            if self.policy_source is not None or available is not None:
+                if self.policy_source is not None:
+                    prior, rollout = self.policy_source(state, model)
+                    listed, slots = available, None
+                else:
+                    prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
+                policy = self.device_policy(model, prior, rollout, listed, slots)
+            else:
+                pp, rp = policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A)
+            ctx.uct_plan_stochastic_device(model, n, d_state, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp,
+                                           rp, d_rng, d_env_rng, int(d_plans.shape[1]), closed_loop=cfg["closed_loop"],
+                                           plans=d_plans, plan_len=d_len, root_value=d_value, env_steps=d_env_steps,
+                                           root_steps=d_steps, policy=policy)
+            self.claim_device_tree()
+            self.last, self._root, self._tree_roots, self._stochastic = None, None, n, True
+            return
         if keep_actions is not None and self.owns_device_tree() and self._tree_roots == n:
             ctx.uct_step_tree(keep_actions)
         else:

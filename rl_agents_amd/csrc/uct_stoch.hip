@@ -637,9 +637,65 @@ __global__ __launch_bounds__(64) void uct_stoch_reroot_kernel(int n_roots, int A
     n_new[r] = tail;
 }
 
+// The env side of Evaluation.step (trainer/evaluation.py:164-190) for n lock-step episodes of a STOCHASTIC model: as
+// env_step_kernel (api.hip), with the next state sampled from the episode's OWN env generator (advanced in place), exactly
+// as FiniteMDPEnv.step does: one Generator.random() double, inverse CDF over the row's integer thresholds.
+__global__ void env_step_stoch_kernel(int n, int A, int sparse, int W, const uint64_t *__restrict__ thr, const int32_t *__restrict__ nxt,
+                                      const double *__restrict__ R, const uint8_t *__restrict__ term, int done_on_next,
+                                      int32_t *__restrict__ state, int32_t *__restrict__ steps, uint8_t *__restrict__ alive,
+                                      const int32_t *__restrict__ plans, int plan_stride, int max_steps, const double *__restrict__ gpow,
+                                      double *__restrict__ returns, double *__restrict__ discounted, int32_t *__restrict__ actions_log,
+                                      int log_stride, int32_t *__restrict__ n_alive, uint64_t *__restrict__ env_rng)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool live = false;
+    if (i < n && alive[i]) {
+        const int planned = plans[(long)i * plan_stride];
+        const int act = planned < 0 ? 0 : planned;
+        const int s = state[i], t = steps[i];
+        const long sa = (long)s * A + act;
+        Pcg64 eg;
+        eg.load(env_rng + (long)i * 6);
+        const uint64_t k = eg.next64() >> 11; // Generator.random()
+        eg.store(env_rng + (long)i * 6);
+        const uint64_t *row = thr + sa * W;
+        int lo = 0, hi = W;                   // searchsorted(cdf, u, 'right')
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (row[mid] <= k) lo = mid + 1; else hi = mid;
+        }
+        if (lo >= W) lo = W - 1;
+        const int sn = sparse ? nxt[sa * W + lo] : lo;
+        const double reward = R[sa];
+        const bool done = term ? (done_on_next ? term[sn] != 0 : term[s] != 0) : false;
+        returns[i] += reward;
+        discounted[i] += reward * gpow[t];
+        if (actions_log && t < log_stride) actions_log[(long)i * log_stride + t] = planned < 0 ? -1 : act;
+        state[i] = sn;
+        steps[i] = t + 1;
+        live = !(done || t + 1 >= max_steps);
+        alive[i] = live ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(live);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(n_alive, (int)__popcll(b));
+}
+
 } // namespace mp
 
 using namespace mp;
+
+// sampling thresholds of a stochastic / sparse model's rows, built once per model on the device (numpy's cumsum / division order)
+static int ensure_thresholds(mp_ctx *ctx, mp_model *model)
+{
+    if (model->thr) return MP_OK;
+    const long rows = (long)model->S * model->A;
+    const int W = model->mode == MP_MODE_STOCHASTIC ? model->S : model->B;
+    if (hipMalloc(&model->thr, (size_t)rows * W * sizeof(uint64_t)) != hipSuccess)
+        return fail(MP_ERR_ALLOC, "%zu B for the sampling thresholds", (size_t)rows * W * 8);
+    hipLaunchKernelGGL(build_thresholds, dim3((unsigned)((rows + 127) / 128)), dim3(128), 0, ctx->stream, rows, W, model->P, model->thr);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
 
 // Apply the re-rooting armed by mp_uct_step_tree to the open-loop trees of the last mp_uct_plan_stochastic: every kept tree
 // -> the subtree under its root's child actions[i], into the other hot buffer with node stride cap_new.
@@ -942,6 +998,31 @@ int mp_uct_plan_stochastic_policy(mp_ctx *ctx, mp_model *model, mp_policy *polic
     return uct_stoch_plan_impl(ctx, model, policy, n_roots, root_state, root_steps, episodes, horizon, gamma, temperature, nullptr,
                                nullptr, closed_loop, rng_state, env_rng_state, max_plan_len, plans, plan_len, root_value,
                                root_child_count, root_child_value, env_steps, mem);
+}
+
+int mp_env_step_stochastic(mp_ctx *ctx, mp_model *model, int32_t n, int32_t *state, int32_t *steps, uint8_t *alive,
+                           const int32_t *plans, int32_t plan_stride, int32_t max_steps, const double *gpow, double *returns,
+                           double *discounted, int32_t *actions_log, int32_t log_stride, int32_t *n_alive, uint64_t *env_rng,
+                           int32_t mem)
+{
+    if (!ctx || !model || !state || !steps || !alive || !plans || !gpow || !returns || !discounted || !n_alive || !env_rng)
+        return fail(MP_ERR_ARG, "mp_env_step_stochastic: NULL argument");
+    if (mem != MP_MEM_DEVICE) return fail(MP_ERR_ARG, "mp_env_step_stochastic: device arrays only");
+    if (model->mode != MP_MODE_STOCHASTIC && model->mode != MP_MODE_SPARSE)
+        return fail(MP_ERR_MODE, "mp_env_step_stochastic: stochastic / sparse models only (mp_env_step steps table models)");
+    if (model->mode == MP_MODE_STOCHASTIC && (model->M != 1 || model->Sc != model->S))
+        return fail(MP_ERR_MODE, "mp_env_step_stochastic: one full dense model [S,A,S] expected");
+    if (n < 1 || plan_stride < 1 || max_steps < 1) return fail(MP_ERR_ARG, "mp_env_step_stochastic: bad sizes");
+    MP_HIP(hipSetDevice(ctx->device));
+    MP_TRY(ensure_thresholds(ctx, model));
+    MP_HIP(hipMemsetAsync(n_alive, 0, sizeof(int32_t), ctx->stream));
+    const int W = model->mode == MP_MODE_STOCHASTIC ? model->S : model->B;
+    hipLaunchKernelGGL(env_step_stoch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, model->A,
+                       model->mode == MP_MODE_SPARSE ? 1 : 0, W, model->thr, model->NXT, model->R, model->term, model->done_on_next,
+                       state, steps, alive, plans, plan_stride, max_steps, gpow, returns, discounted, actions_log, log_stride, n_alive,
+                       env_rng);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
 }
 
 int mp_uct_stoch_tree_priors(mp_ctx *ctx, int32_t cap, double *prior)

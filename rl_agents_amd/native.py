@@ -85,6 +85,8 @@ SIGNATURES = {
     "mp_last_kernel_variant": (C.c_char_p, [_vp]),
     "mp_env_step": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, _vp, c_i32, c_i32, _vp, _vp, _vp, _vp, c_i32, _vp, c_i32]),
     "mp_greedy_actions": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32]),
+    "mp_env_step_stochastic": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, _vp, c_i32, c_i32, _vp, _vp, _vp, _vp, c_i32, _vp, _vp,
+                                         c_i32]),
     "mp_host_alloc": (C.c_int, [_vp, c_i64, P(_vp)]),
     "mp_host_free": (C.c_int, [_vp, _vp]),
     "mp_rng_create": (C.c_int, [_vp, c_i32, P(_vp)]),
@@ -291,6 +293,35 @@ class Context(object):
                                      int(plans.shape[1]), int(max_steps), _ptr(gpow), _ptr(returns), _ptr(discounted),
                                      _ptr(actions_log), 0 if actions_log is None else int(actions_log.shape[1]),
                                      _ptr(n_alive), MP_MEM_DEVICE))
+
+    def env_step_stochastic_device(self, model, state, steps, alive, plans, max_steps, gpow, returns, discounted, actions_log,
+                                   n_alive, env_rng):
+        """mp_env_step_stochastic: env_step_device for stochastic / sparse models; env_rng int64 [n, 6] device records of the
+        episodes' own env generators, advanced in place."""
+        n = int(state.shape[0])
+        _check(self._lib.mp_env_step_stochastic(self._h, model._h, n, _ptr(state), _ptr(steps), _ptr(alive), _ptr(plans),
+                                                int(plans.shape[1]), int(max_steps), _ptr(gpow), _ptr(returns), _ptr(discounted),
+                                                _ptr(actions_log), 0 if actions_log is None else int(actions_log.shape[1]),
+                                                _ptr(n_alive), _ptr(env_rng), MP_MEM_DEVICE))
+
+    def uct_plan_stochastic_device(self, model, n_roots, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                                   rng_state, env_rng_state, max_plan_len, closed_loop=False, plans=None, plan_len=None,
+                                   root_value=None, env_steps=None, root_steps=None, policy=None):
+        """mp_uct_plan_stochastic / _policy on device tensors; only enqueues."""
+        if policy is not None:
+            _check(self._lib.mp_uct_plan_stochastic_policy(self._h, model._h, policy._h, int(n_roots), _ptr(root_state),
+                                                           _ptr(root_steps), int(episodes), int(horizon), float(gamma),
+                                                           float(temperature), int(bool(closed_loop)), _ptr(rng_state),
+                                                           _ptr(env_rng_state), int(max_plan_len), _ptr(plans), _ptr(plan_len),
+                                                           _ptr(root_value), None, None, _ptr(env_steps), MP_MEM_DEVICE))
+            return
+        pp = np.ascontiguousarray(prior_p, dtype=np.float64)
+        rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
+        _check(self._lib.mp_uct_plan_stochastic(self._h, model._h, int(n_roots), _ptr(root_state), _ptr(root_steps), int(episodes),
+                                                int(horizon), float(gamma), float(temperature), _ptr(pp), _ptr(rp),
+                                                int(bool(closed_loop)), _ptr(rng_state), _ptr(env_rng_state), int(max_plan_len),
+                                                _ptr(plans), _ptr(plan_len), _ptr(root_value), None, None, _ptr(env_steps),
+                                                MP_MEM_DEVICE))
 
     def greedy_actions_device(self, q, state, plans):
         """plans[:, 0] = argmax_a q[state, a] (first maximum), device tensors."""

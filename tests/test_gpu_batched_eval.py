@@ -158,3 +158,57 @@ def test_stateful_planners_in_the_device_resident_loop(kind):
             agent = agent_factory(env, dict(cfg, prune_suboptimal_leaves=True))
             with pytest.raises(ValueError, match="empty sequence"):
                 BatchedEvaluation(env, agent, num_episodes=n, sim_seed=40, max_steps=9, device_resident=resident).run(initial_states=starts)
+
+
+def _stoch_env(kind, max_steps=9, state=2):
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    if kind == "sparse":
+        cfg = generators.random_sparse(60, 3, 2, seed=7, terminal_rate=0.1)
+    else:
+        cfg = generators.random_stochastic(30, 3, seed=5, terminal_rate=0.1)
+    env = FiniteMDPEnv(dict(cfg, state=state, max_steps=max_steps))
+    env.reset()
+    return env
+
+
+@pytest.mark.parametrize("kind,agent_kind", [("sparse", "uct"), ("sparse", "uct_closed"), ("sparse", "uct_subtree"), ("dense", "uct"),
+                                             ("dense", "vi"), ("sparse", "vi")])
+def test_batched_evaluation_on_stochastic_models(kind, agent_kind):
+    """Round 4: BatchedEvaluation steps STOCHASTIC finite MDPs (it refused them): episode i samples with its own env
+    generator Generator(PCG64(SeedSequence([env_seed, i]))), exactly as FiniteMDPEnv.step does, and every plan's clones start
+    from that generator as it is at that step.  Device-resident loop (mp_env_step_stochastic, generator records in a device
+    buffer) == host-stepped loop == N sequential agent / env loops."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    cfg = dict(uct=dict(__class__=UCT, budget=120, gamma=0.9), uct_closed=dict(__class__=UCT, budget=120, gamma=0.9, closed_loop=True),
+               uct_subtree=dict(__class__=UCT, budget=120, gamma=0.9, step_strategy="subtree"),
+               vi=dict(__class__=VI, gamma=0.9, iterations=100))[agent_kind]
+    n = 70
+    n_states = 60 if kind == "sparse" else 30
+    starts = (np.arange(n) * 7 % n_states).astype(np.int32)
+    runs = []
+    for resident in (False, True):
+        env = _stoch_env(kind)
+        ev = BatchedEvaluation(env, agent_factory(env, dict(cfg)), num_episodes=n, sim_seed=40, max_steps=9, device_resident=resident,
+                               check_every=4, env_seed=17)
+        runs.append(ev.run(initial_states=starts))
+        assert runs[-1]["device_resident"] is resident
+    _compare(runs[0], runs[1])
+    assert runs[0]["lengths"].min() < runs[0]["lengths"].max()
+    # the anchor: sequential agents on envs seeded the documented way
+    for i in (0, 13, 69):
+        e = _stoch_env(kind, state=int(starts[i]))
+        e.np_random = np.random.Generator(np.random.PCG64(np.random.SeedSequence([17, i])))
+        agent = agent_factory(e, dict(cfg))
+        if agent_kind != "vi":
+            agent.seed(40 + i)
+        actions, total, done = [], 0.0, False
+        while not done:
+            a = int(agent.act(e.mdp.state))
+            _, r, term, trunc, _ = e.step(a)
+            actions.append(a)
+            total += r
+            done = term or trunc
+        assert runs[1]["lengths"][i] == len(actions), (i, actions, runs[1]["actions"][i])
+        np.testing.assert_array_equal(runs[1]["actions"][i, :len(actions)], actions)
+        assert runs[1]["returns"][i] == pytest.approx(total, abs=1e-12)
