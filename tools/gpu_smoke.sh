@@ -1,0 +1,3 @@
+#!/bin/bash
+cd /root/repo
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -5
