@@ -44,6 +44,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <vector>
 
@@ -129,6 +130,7 @@ struct SaArgs {
     int prune_rows; // wave kernel: rows the prune pass takes through its register sets (256; MP_SAOPD_PRUNE_ROWS: test knob)
     int par_backup; // wave kernel: 1 = grouped parallel backup over chunked state lists (host: the first plan of fresh planners)
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
+    int tab_lds;            // wave kernel with the dictionaries in LDS: depth-table entries held in LDS
     double gamma, vmax;
     const Rec *rec;
     const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
@@ -456,6 +458,9 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 // planners per CU).  The kernel is a chain of dependent accesses (queue front -> list element -> parent -> children ->
 // state values), ~15 000 per plan: from LDS each costs ~100 cycles instead of a ~600-2 000-cycle L2 / HBM round trip.
 // The host selects it while the arena fits (first plans of a planner; later plans fall back to the global-memory form).
+#ifndef MP_SAOPD_DICT_WAVES
+#define MP_SAOPD_DICT_WAVES 8 // the same for the variant with the dictionaries in LDS (5 KB of LDS per planner)
+#endif
 #ifndef MP_SAOPD_MIN_WAVES
 #define MP_SAOPD_MIN_WAVES 8 // waves per SIMD the register allocation must admit (106 SGPRs would cap the kernel at 6)
 #endif
@@ -468,15 +473,30 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 #else
 #define SA_ORDER() __builtin_amdgcn_wave_barrier()
 #endif
-template <bool LDSR>
-__global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_kernel(SaArgs p)
+// LDSD (round 4): only the per-state DICTIONARIES live in LDS for the plan -- state values, list heads / tails, stamps and the
+// chunked lists' records, 36 B per state (3.6 KB at S = 100, which leaves five waves per SIMD) -- staged in at the start and
+// written back at the end.  Every dependent chain of the plan ends in one of them (a child's or a parent's state value, a
+// popped state's list, a scanned row's stamp): those hops become LDS reads, off the texture path the kernel is bound by.
+template <bool LDSR, bool LDSD = false>
+__global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAOPD_MIN_WAVES)) void saopd_wave_kernel(SaArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
-    const int ntab = 3 * (p.K + 3);
+    // the depth tables in LDS; LDSD keeps only their first tab_lds entries there (deeper nodes read the global copy), so that
+    // tables + dictionaries stay within the 5 KB per planner that eight waves per SIMD leave
+    const int TLD = LDSD ? p.tab_lds : p.K + 3;
+    const int ntab = 3 * TLD;
     const int lane = threadIdx.x;
-    for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
-    const double *gpow = lds_d, *trg = lds_d + (p.K + 3), *acc = lds_d + 2 * (p.K + 3);
-    constexpr int DCAP = 128; // (512 B of LDS after the tables, reserved by the host's size computation; unused since the
+    for (int i = lane; i < ntab; i += 64) {
+        const int t = i / TLD;
+        lds_d[i] = p.tab[t * (p.K + 3) + (i - t * TLD)];
+    }
+    struct DepthTab {
+        const double *l, *g;
+        int nl;
+        __device__ __forceinline__ double operator[](int d) const { return (!LDSD || d < nl) ? l[d] : g[d]; }
+    };
+    const DepthTab gpow{lds_d, p.tab, TLD}, trg{lds_d + TLD, p.tab + (p.K + 3), TLD}, acc{lds_d + 2 * TLD, p.tab + 2 * (p.K + 3), TLD};
+    constexpr int DCAP = LDSD ? 4 : 128; // (512 B of LDS after the tables, reserved by the host's size computation; unused since the
                               // prune pass finds the rows of changed states by their stamps)
     const int r = blockIdx.x;
     const int A = p.A;
@@ -502,15 +522,20 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     int32_t *l_parent = l_state + LR, *l_fc = l_parent + LR;
     int32_t *l_head = l_fc + LR, *l_tail = l_head + p.S, *l_stamp = l_tail + p.S;
     int32_t *l_queue = l_stamp + p.S;
+    // LDS carve (LDSD): [tables | 4 i32 | sv f64 [S] | list records int4 [S] | head, tail, stamp, mark i32 [S]]
+    double *d_sv = lds_d + ((ntab + DCAP / 2 + 1) & ~1);
+    int4 *d_ls = reinterpret_cast<int4 *>(d_sv + p.S);
+    int32_t *d_head = reinterpret_cast<int32_t *>(d_ls + p.S), *d_tail = d_head + p.S, *d_stamp = d_tail + p.S;
+    uint32_t *d_mark = reinterpret_cast<uint32_t *>(d_stamp + p.S); // backup: the first group of the pass that may write a state
     SaNode *const node_b = LDSR ? l_node : p.node + nb;
     int32_t *const state_b = LDSR ? l_state : p.state + nb;
     int32_t *const parent_b = LDSR ? l_parent : p.parent + nb;
     int32_t *const fc_b = LDSR ? l_fc : p.first_child + nb;
     double *const reward_b = LDSR ? l_reward : p.reward + nb;
-    double *const sv_b = LDSR ? l_sv : p.sv + sb;
-    int32_t *const head_b = LDSR ? l_head : p.head + sb;
-    int32_t *const tail_b = LDSR ? l_tail : p.tail + sb;
-    int32_t *const stamp_b = LDSR ? l_stamp : p.stamp + sb;
+    double *const sv_b = LDSR ? l_sv : (LDSD ? d_sv : p.sv + sb);
+    int32_t *const head_b = LDSR ? l_head : (LDSD ? d_head : p.head + sb);
+    int32_t *const tail_b = LDSR ? l_tail : (LDSD ? d_tail : p.tail + sb);
+    int32_t *const stamp_b = LDSR ? l_stamp : (LDSD ? d_stamp : p.stamp + sb);
     int32_t *const queue_b = LDSR ? l_queue : p.queue + qb;
     const int qcap = LDSR ? p.lds_qcap : p.qcap;
     if (LDSR) { // stage in: the rows of earlier plans and the dictionaries (a fresh planner starts from the defaults)
@@ -526,6 +551,14 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             l_stamp[s] = p.fresh ? -1 : p.stamp[sb + s];
         }
     }
+    if (LDSD)
+        for (int s = lane; s < p.S; s += 64) {
+            d_sv[s] = p.fresh ? p.vmax : p.sv[sb + s];
+            d_head[s] = p.fresh ? -1 : p.head[sb + s];
+            d_tail[s] = p.fresh ? -1 : p.tail[sb + s];
+            d_stamp[s] = p.fresh ? -1 : p.stamp[sb + s];
+            d_mark[s] = 0xffffffffu;
+        }
     __syncthreads();
     auto ND = [&](int i) -> SaNode & { return node_b[i]; };
     auto ST = [&](int i) -> int32_t & { return state_b[i]; };
@@ -586,7 +619,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
     // and kept up to date by this plan's appends.
     constexpr int CH = 15;
     const bool par_backup = p.par_backup != 0 && A <= 32; // a group of |A| lanes per list element, at least two groups per pass
-    int4 *ls_b = p.lstate + sb; // one 16-byte record per state: one load / one store where three arrays took three
+    int4 *const ls_b = LDSD ? d_ls : p.lstate + sb; // one 16-byte record per state: one load / one store where three arrays took three
     int32_t *pool_b = p.lpool + (long)r * p.pool_ints;
     auto PL = [&](int chunk, int f) -> int32_t & { return pool_b[(chunk << 4) + f]; };
     int pool_top = 0;
@@ -910,6 +943,64 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         }
                     }
                 };
+                // The same sequential half for ALL groups of a pass at once (LDSD: the dictionaries are in LDS).  What orders
+                // the groups is (i) a later group whose parent is in a state an earlier group wrote -- its `old` is the
+                // running minimum of that state's value -- and (ii) a later group with a CHILD in such a state (its backup is
+                // stale).  (i): LDS atomics of one wave instruction apply in lane order (tools/lds_atomic_order.hip, and
+                // tests/test_gpu_batch.py checks it on the box), so ONE ds_min_rtn_f64 of the group leaders onto sv[] hands
+                // every leader the value the turn-by-turn loop would have read, and leaves the minimum.  (ii): the groups that
+                // may write (old > backup with the unpatched old: a superset of the writers) mark their parent's state with
+                // their group index; every lane looks its child's state up; the first group that finds an earlier mark ends the
+                // batch: the groups before it are applied together (queue slots by rank among the writers), the marked ones
+                // are re-evaluated, and the rest goes through the next round.
+                auto apply_vec = [&](bool valid, int src_, double src_delta_, int my_nbr, int my_given) {
+                    bool in_r = valid; // lanes of the groups not yet applied
+                    const unsigned long long gmask = (A == 64 ? ~0ULL : ((1ULL << A) - 1ULL));
+                    const unsigned long long ltm = (1ULL << lane) - 1ULL;
+                    while (__any(in_r) && status == MP_OK) {
+                        const bool leader = in_r && my_a == 0;
+                        const bool cand = leader && v_old > v_backup;
+                        if (cand) atomicMin(&d_mark[v_sn], (uint32_t)my_g);
+                        SA_ORDER();
+                        const uint32_t m = in_r ? d_mark[v_sc] : 0xffffffffu;
+                        const unsigned long long stale = __ballot(m < (uint32_t)my_g);
+                        const int c_g = stale ? (__ffsll((long long)stale) - 1) / A : 64; // the first group with a stale child value
+                        const bool now = in_r && my_g < c_g;
+                        double ret = 0.0;
+                        bool w = false;
+                        if (now && cand) {
+                            ret = __hip_atomic_fetch_min(&sv_b[v_sn], v_backup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            w = v_backup < ret;
+                        }
+                        const unsigned long long wm = __ballot(w);
+                        const int n_w = __popcll(wm);
+                        updates += __popcll(__ballot(now && leader));
+                        if (n_w) {
+                            if (qt - qh + (unsigned)n_w > dcap) {
+                                status = MP_ERR_ALLOC;
+                                if (l0) { *p.overflow = 1; if (p.sticky) p.overflow[1 + r] = MP_ERR_ALLOC; }
+                            } else if (w) {
+                                const double delta = ret - v_backup;
+                                SM(v_sn) = cur;
+                                QD4(qt + (unsigned)__popcll(wm & ltm)) = make_int4(v_sn, v_node, __double2loint(delta), __double2hiint(delta));
+                            }
+                            qt += (unsigned)n_w;
+                        }
+                        if (cand) d_mark[v_sn] = 0xffffffffu;
+                        SA_ORDER();
+                        in_r = in_r && my_g >= c_g;
+                        if (!stale) break;
+                        // the remaining groups: re-evaluate those with a child in a state a group applied above may have
+                        // written; the others re-read their parent state's value (it may have moved)
+                        const unsigned long long nm = __ballot(in_r && m < (uint32_t)c_g);
+                        const bool redo = in_r && ((nm >> g_lead) & gmask) != 0ULL;
+#ifdef MP_PROFILE
+                        pf_reval += __popcll(__ballot(redo && my_a == 0));
+#endif
+                        eval(redo, my_nbr, my_given, src_, src_delta_);
+                        if (in_r && !redo) v_old = SV(v_sn);
+                    }
+                };
                 const int nq_max = npp < 16 ? npp : 16;
                 while (qh != qt && status == MP_OK) {
                     // ---- several pending descriptors per pass.  Early in a plan a state's list holds a handful of nodes, so
@@ -951,7 +1042,8 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                         ++pf_pass;
 #endif
                         eval(mine, my_nbr, my_given, ds_o < 0 ? -1 : src_o, delta_o);
-                        apply(__ballot(mine && v_cond && my_a == 0), ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
+                        if constexpr (LDSD) apply_vec(mine && v_cond, ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
+                        else apply(__ballot(mine && v_cond && my_a == 0), ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
                         continue;
                     }
                     // the first pending descriptor alone is longer than a pass: chunk by chunk
@@ -977,7 +1069,8 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
                             ++pf_pass;
 #endif
                             eval(my_nbr >= 0, my_nbr, -1, src_, src_delta_);
-                            apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr, -1);
+                            if constexpr (LDSD) apply_vec(my_nbr >= 0 && v_cond, src_, src_delta_, my_nbr, -1);
+                            else apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr, -1);
                         }
                     }
                 }
@@ -1281,6 +1374,12 @@ __global__ __launch_bounds__(64, LDSR ? 1 : MP_SAOPD_MIN_WAVES) void saopd_wave_
             p.sv[sb + s] = l_sv[s]; p.head[sb + s] = l_head[s]; p.tail[sb + s] = l_tail[s]; p.stamp[sb + s] = l_stamp[s];
         }
     }
+    if (LDSD) {
+        __syncthreads();
+        for (int s = lane; s < p.S; s += 64) {
+            p.sv[sb + s] = d_sv[s]; p.head[sb + s] = d_head[s]; p.tail[sb + s] = d_tail[s]; p.stamp[sb + s] = d_stamp[s];
+        }
+    }
 }
 
 // grow a node array from old_cap to new_cap rows per planner, keeping the used_rows rows in use
@@ -1528,6 +1627,13 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     // rolled back and retried then: it reports MP_ERR_ALLOC and stays failed (every later call reports it again), the
     // other planners of the batch are unaffected.  With host arrays the call synchronises anyway, reads the overflow
     // word and retries with a larger queue.
+    // dictionaries in LDS (LDSD): while they leave five planners per SIMD
+    // (5 KB per planner = 32 per CU = eight waves per SIMD; the depth tables take what the dictionaries leave, at least 16 entries)
+    const long dict_room = 5 * 1024 - 32 - (long)pl->S * (8 + 16 + 16);
+    a.tab_lds = (int)std::min<long>(K + 3, dict_room / 24);
+    const size_t lds_dict = (size_t)a.tab_lds * 24 + 32 + (size_t)pl->S * (8 + 16 + 16);
+    bool use_dict = pl->wave && a.tab_lds >= 16;
+    if (const char *e = getenv("MP_SAOPD_DICT")) use_dict = use_dict && e[0] == '1';
     const bool async = mem == MP_MEM_DEVICE;
     a.sticky = async ? 1 : 0;
     if (async) use_lds = false; // (its small queue relies on the retry)
@@ -1564,7 +1670,8 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
                 MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(saopd_wave_kernel<true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res));
             hipLaunchKernelGGL(saopd_wave_kernel<true>, dim3((unsigned)n), dim3(64), lds_res, st, a);
-        } else if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel<false>, dim3((unsigned)n), dim3(64), lds, st, a);
+        } else if (pl->wave && use_dict) hipLaunchKernelGGL((saopd_wave_kernel<false, true>), dim3((unsigned)n), dim3(64), lds_dict, st, a);
+        else if (pl->wave) hipLaunchKernelGGL(saopd_wave_kernel<false>, dim3((unsigned)n), dim3(64), lds, st, a);
         else hipLaunchKernelGGL(saopd_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), lds, st, a);
         ++launches;
         if (async) break;

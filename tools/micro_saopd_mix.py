@@ -1,0 +1,45 @@
+"""State-aware OPD, first plan of fresh planners: how the batch time depends on the MIX of planners.
+A planner's work is fixed by its root state (1 741 .. 12 956 Bellman backups on the 10x10 grid); the bench batch draws the
+roots uniformly.  Kernel time for: the bench mix, the mix sorted heavy-first / light-first (workgroups are dispatched in
+index order), only light roots, only heavy roots, and small batches of heavy roots (a lone planner's latency)."""
+import sys
+import numpy as np
+import torch
+from rl_agents_amd import native
+from rl_agents_amd.envs import generators
+from oracle import oracle
+
+cfg = generators.gridworld()
+t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+S = r.shape[0]
+ctx = native.Context(0, torch.cuda.current_stream().cuda_stream)
+model = ctx.load_table(t, r, term)
+cost = oracle.saopd_plan_batch(t, r, term, np.arange(S, dtype=np.int32), 500, 0.8, max_plan_len=8, n_threads=8)["updates"]
+print("updates per root state: min %d  mean %.0f  max %d" % (cost.min(), cost.mean(), cost.max()))
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+mix = np.random.Generator(np.random.PCG64(12345)).integers(0, S, size=n).astype(np.int32)
+light, heavy = int(np.argmin(cost)), int(np.argmax(cost))
+
+
+def run(name, roots, reps=3):
+    ms = []
+    for _ in range(reps):
+        pl = native.StateAwarePlanners(ctx, model, len(roots))
+        rng = native.seed_sequence_states((), 7, len(roots))
+        o = pl.plan(roots, 500, 0.8, 0.0, rng, max_plan_len=8)
+        ms.append(ctx.last_kernel_ms()[0])
+        pl.close()
+    print("%-34s n %6d  mean updates %7.0f  kernel ms %s" % (name, len(roots), o["updates"].mean(), " ".join("%.2f" % m for m in ms)))
+
+
+run("bench mix", mix)
+run("mix, heavy first", mix[np.argsort(-cost[mix], kind="stable")])
+run("mix, light first", mix[np.argsort(cost[mix], kind="stable")])
+run("all light (state %d)" % light, np.full(n, light, np.int32))
+run("all heavy (state %d)" % heavy, np.full(n, heavy, np.int32))
+med = int(np.argsort(cost)[S // 2])
+run("all median (state %d)" % med, np.full(n, med, np.int32))
+for k in (1, 64, 1024, 4096):
+    run("heavy only", np.full(k, heavy, np.int32))
+for k in (1, 64, 1024):
+    run("light only", np.full(k, light, np.int32))
