@@ -477,6 +477,9 @@ __global__ __launch_bounds__(64) void saopd_kernel(SaArgs p)
 // chunked lists' records, 36 B per state (3.6 KB at S = 100, which leaves five waves per SIMD) -- staged in at the start and
 // written back at the end.  Every dependent chain of the plan ends in one of them (a child's or a parent's state value, a
 // popped state's list, a scanned row's stamp): those hops become LDS reads, off the texture path the kernel is bound by.
+// SA_SYNC: a wave's stores followed by its own (other lanes') loads.  From global memory the texture path's order is enough
+// (see SA_ORDER); the LDS-resident form keeps the barrier it was validated with.
+#define SA_SYNC() do { if constexpr (LDSR) __syncthreads(); else SA_ORDER(); } while (0)
 template <bool LDSR, bool LDSD = false>
 __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAOPD_MIN_WAVES)) void saopd_wave_kernel(SaArgs p)
 {
@@ -663,7 +666,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         const int cur = p.iter_base + k;
         SA_PROF(4);
         // ---- max(leaves, key=U): 64 rows per trip, then (max U, lowest id) across the lanes
-        double bu = ninf;
+        double bu = ninf, b_lower = 0.0;
+        uint32_t b_meta = 0;
+        int32_t b_state = 0; // the lane's best leaf's record: the expansion takes the winner's from its lane, not from memory
         int leaf = 0x7fffffff;
         constexpr int WU = 4; // 4 x 64 rows per trip: the three levels of loads (node, state, state value) each in flight together
         for (int i0 = root + lane; i0 < n_nodes; i0 += 64 * WU) {
@@ -683,7 +688,10 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                 const int i = i0 + 64 * j;
                 if (i < n_nodes && (nd[j].meta & SA_ALIVE)) {
                     const double u = nd[j].lower + gpow[nd[j].meta & SA_DEPTH] * sv[j];
-                    if (u > bu || leaf == 0x7fffffff) { bu = u; leaf = i; } // ascending ids within a lane: first maximum
+                    if (u > bu || leaf == 0x7fffffff) { // ascending ids within a lane: first maximum
+                        bu = u; leaf = i;
+                        b_lower = nd[j].lower; b_meta = nd[j].meta; b_state = st[j];
+                    }
                 }
             }
         }
@@ -695,9 +703,11 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         }
         SA_PROF(0);
         // ---- expand + update: one child per lane, then the list appends in action order
-        const SaNode lf = load_node(&ND(leaf));
+        const int owner = (leaf - root) & 63; // rows are dealt to the lanes round-robin from the root
+        SaNode lf;
+        lf.lower = bcast_lane(b_lower, owner); lf.next_same = -1; lf.meta = (uint32_t)__builtin_amdgcn_readlane((int)b_meta, owner);
         const int dl = (int)(lf.meta & SA_DEPTH);
-        const int32_t sl = ST(leaf);
+        const int32_t sl = __builtin_amdgcn_readlane(b_state, owner);
         const int g = n_nodes;
         bool bad = false, term_c = false, real_c = false;
         int32_t s_c = 0;
@@ -727,7 +737,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         }
         steps_taken += __popcll(real_mask); // planner.step calls: one per listed action
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads();
+        SA_SYNC();
         // state_nodes[str(observation)].append(child), update_value(observation, 0), child by child in action order.  What an
         // append reads -- its state's list tail, value (and chunk record) -- is fetched for ALL children at once, lane a
         // for child a (one round trip instead of |A|); the appends then run in order over registers, and a later sibling
@@ -871,6 +881,23 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                 int v_node = -1, v_sn = -1, v_sc = -1;
                 double v_old = 0.0, v_backup = 0.0;
                 bool v_cond = false;
+                // the lane's child as fetched: a re-evaluation (a state value moved) needs no memory access beyond sv[]
+                double c_lower = 0.0, c_rew = 0.0;
+                int c_depth = 0;
+                // the group's Bellman backup from the state values as they are NOW (sv[] only)
+                auto score = [&](bool mine) {
+                    if (!mine) return;
+                    v_old = SV(v_sn);
+                    const double svc = SV(v_sc);
+                    const double u = c_lower + gpow[c_depth] * svc;
+                    const double bk = c_rew + p.gamma * svc;
+                    double bu = ninf, bkb = 0.0; // first maximal U in action order, over the lanes of the group
+                    for (int q = 0; q < A; ++q) {
+                        const double uq = __shfl(u, g_lead + q), bq = __shfl(bk, g_lead + q);
+                        if (q == 0 || uq > bu) { bu = uq; bkb = bq; }
+                    }
+                    v_backup = bkb;
+                };
                 // node_given >= 0: the descriptor names the node itself (the expanded leaf); otherwise the node is the parent
                 // of list element `nbr`.  Every lane of a taking group runs this with the same nbr.
                 auto eval = [&](bool mine, int nbr, int node_given, int src_, double src_delta_) {
@@ -880,30 +907,22 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                     if (node_given >= 0) {
                         fc = FC(node_given);
                     } else {
-                        const SaNode nd = load_node(&ND(nbr));
+                        const uint32_t nmeta = ND(nbr).meta; // (depth and action: four of the record's sixteen bytes)
                         const int par = PA(nbr);
-                        if (par >= 0 && (nbr == src_ || p.backup_aggregated) && src_delta_ > acc[nd.meta & SA_DEPTH]) {
+                        if (par >= 0 && (nbr == src_ || p.backup_aggregated) && src_delta_ > acc[nmeta & SA_DEPTH]) {
                             node_ = par;
-                            fc = nbr - (int)((nd.meta & SA_ACT) >> SA_ACT_SHIFT); // the siblings of nbr = the children of par
+                            fc = nbr - (int)((nmeta & SA_ACT) >> SA_ACT_SHIFT); // the siblings of nbr = the children of par
                         }
                     }
                     if (node_ < 0 || fc < 0) return;
                     v_cond = true;
                     v_node = node_;
                     v_sn = ST(node_);
-                    v_old = SV(v_sn);
                     const int c = fc + my_a;
                     const SaNode cd = load_node(&ND(c));
                     v_sc = ST(c);
-                    const double svc = SV(v_sc);
-                    const double u = cd.lower + gpow[cd.meta & SA_DEPTH] * svc;
-                    const double bk = RW(c) + p.gamma * svc;
-                    double bu = ninf, bkb = 0.0; // first maximal U in action order, over the lanes of the group
-                    for (int q = 0; q < A; ++q) {
-                        const double uq = __shfl(u, g_lead + q), bq = __shfl(bk, g_lead + q);
-                        if (q == 0 || uq > bu) { bu = uq; bkb = bq; }
-                    }
-                    v_backup = bkb;
+                    c_lower = cd.lower; c_depth = (int)(cd.meta & SA_DEPTH); c_rew = RW(c);
+                    score(true);
                 };
                 // the sequential half over the group leaders in `todo` (ascending = list order)
                 auto apply = [&](unsigned long long todo, int src_, double src_delta_, int my_nbr, int my_given) {
@@ -913,7 +932,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                         const int j = __ffsll((long long)todo) - 1; // the group's first lane
                         todo &= todo - 1;
                         if (dirty & (gmask << j)) {
-                            eval(lane >= j && lane < j + A, my_nbr, my_given, src_, src_delta_); // a child's state value moved
+                            score(lane >= j && lane < j + A); // a child's state value moved
 #ifdef MP_PROFILE
                             ++pf_reval;
 #endif
@@ -997,7 +1016,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #ifdef MP_PROFILE
                         pf_reval += __popcll(__ballot(redo && my_a == 0));
 #endif
-                        eval(redo, my_nbr, my_given, src_, src_delta_);
+                        score(redo);
                         if (in_r && !redo) v_old = SV(v_sn);
                     }
                 };
@@ -1135,26 +1154,29 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             pf_nd += n_d; pf_fallback += n_d > 64 * NS ? 1 : 0; pf_ndmax = n_d > pf_ndmax ? n_d : pf_ndmax;
 #endif
             if (n_d <= pcap) {
-                __syncthreads(); // the pairs are read back by other lanes
+                SA_SYNC(); // the pairs are read back by other lanes
                 // One group of rows (record j: row id_at(j), state st_at(j), j < cnt <= 64 NS, ascending id) through NS
                 // register sets: record lane + 64 q = {state, meta, value}; a record is identified by (set, lane).
                 auto process = [&](int cnt, auto id_at, auto st_at) {
-                    int rst[NS];
+                    int rst[NS], key[NS]; // key: the row's depth while it can dominate (alive or with children), -1 otherwise
                     uint32_t rmeta[NS];
                     double rval[NS];
                     uint32_t changed = 0;
 #pragma unroll
                     for (int q = 0; q < NS; ++q) {
                         const int j = lane + 64 * q;
-                        rst[q] = -1; rmeta[q] = 0; rval[q] = ninf;
+                        rst[q] = -1; rmeta[q] = 0; rval[q] = ninf; key[q] = -1;
+                        if (64 * q >= cnt) continue; // (uniform: an empty set costs nothing)
                         if (j < cnt) {
                             rst[q] = st_at(j);
                             const SaNode nd = load_node(&ND(id_at(j)));
                             rmeta[q] = nd.meta;
                             rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
+                            key[q] = (nd.meta & (SA_CHILDREN | SA_ALIVE)) ? (int)(nd.meta & SA_DEPTH) : -1;
                         }
                     }
-                    // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it
+                    // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it.
+                    // One candidate against one set = three compares (state, value, depth-or-dead).
 #pragma unroll
                     for (int q = NS - 1; q >= 0; --q) {
                         if (64 * q >= cnt) continue;
@@ -1165,12 +1187,15 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                             const int cs = __builtin_amdgcn_readlane(rst[q], l);
                             const int cd = (int)(__builtin_amdgcn_readlane((int)rmeta[q], l) & SA_DEPTH);
                             const double cv = bcast_lane(rval[q], l);
-                            bool dom = false;
+                            unsigned long long dom = 0ULL;
 #pragma unroll
-                            for (int t = 0; t < NS; ++t)
-                                dom |= rst[t] == cs && (t != q || lane != l) && rval[t] >= cv && (int)(rmeta[t] & SA_DEPTH) >= cd &&
-                                       (rmeta[t] & (SA_CHILDREN | SA_ALIVE)) != 0;
-                            if (__any(dom) && lane == l) { rmeta[q] &= ~SA_ALIVE; changed |= 1u << q; }
+                            for (int t = 0; t < NS; ++t) {
+                                if (64 * t >= cnt) continue;
+                                unsigned long long m = __ballot(rst[t] == cs && rval[t] >= cv && key[t] >= cd);
+                                if (t == q) m &= ~(1ULL << l);
+                                dom |= m;
+                            }
+                            if (dom && lane == l) { rmeta[q] &= ~SA_ALIVE; key[q] = -1; changed |= 1u << q; }
                         }
                     }
 #pragma unroll
@@ -1272,7 +1297,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                     serial_prune = too_long;
                 }
             }
-            __syncthreads();
+            SA_SYNC();
         }
         if (serial_prune)
             for (int ib = n_nodes - 1; ib >= root; ib -= 64 * WU) {

@@ -3,7 +3,7 @@
 cd /root/repo
 mkdir -p gpurun_out/r04
 i=0
-IFS=';' read -ra LIST <<< "${FLAGS_LIST:- }"
+IFS=";" read -ra LIST <<< "${FLAGS_LIST:- }"
 for f in "${LIST[@]}"; do
   export MP_EXTRA_FLAGS="$f"
   echo "=== build flags: [$f]"

@@ -32,14 +32,24 @@ def run(name, roots, reps=3):
     print("%-34s n %6d  mean updates %7.0f  kernel ms %s" % (name, len(roots), o["updates"].mean(), " ".join("%.2f" % m for m in ms)))
 
 
+short = len(sys.argv) > 2 and sys.argv[2] == "short"
 run("bench mix", mix)
 run("mix, heavy first", mix[np.argsort(-cost[mix], kind="stable")])
-run("mix, light first", mix[np.argsort(cost[mix], kind="stable")])
+if not short:
+    run("mix, light first", mix[np.argsort(cost[mix], kind="stable")])
 run("all light (state %d)" % light, np.full(n, light, np.int32))
 run("all heavy (state %d)" % heavy, np.full(n, heavy, np.int32))
+if short:
+    run("heavy only", np.full(1024, heavy, np.int32))
+    sys.exit(0)
 med = int(np.argsort(cost)[S // 2])
 run("all median (state %d)" % med, np.full(n, med, np.int32))
 for k in (1, 64, 1024, 4096):
     run("heavy only", np.full(k, heavy, np.int32))
 for k in (1, 64, 1024):
     run("light only", np.full(k, light, np.int32))
+import os
+os.environ["MP_SAOPD_LDS"] = "0"   # small batches without the all-in-LDS latency mode
+for k in (1, 64, 256):
+    run("heavy only, MP_SAOPD_LDS=0", np.full(k, heavy, np.int32))
+run("light only, MP_SAOPD_LDS=0", np.full(1, light, np.int32))
