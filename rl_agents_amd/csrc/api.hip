@@ -823,6 +823,7 @@ int mp_model_free(mp_model *m)
     if (m->t16) hipFree(m->t16);
     if (m->r8) hipFree(m->r8);
     if (m->rdict) hipFree(m->rdict);
+    if (m->sa_cost) hipFree(m->sa_cost);
     if (m->avail) hipFree(m->avail);
     if (m->rec_all) hipFree(m->rec_all);
     if (m->term_all) hipFree(m->term_all);

@@ -197,6 +197,9 @@ struct mp_model {
     uint8_t *r8 = nullptr;   // model 0's rewards as indices into rdict, [S*A] (padded to 16 B); only with t16 and <= 256 distinct rewards
     double *rdict = nullptr; // the distinct reward values (bit patterns), [256]
     int n_rdict = 0;
+    // state-aware OPD (saopd.hip): Bellman backups a fresh planner's first plan ran, by root state -- learned from the
+    // batches planned on this model so far and used ONLY to dispatch the planners of the next fresh batch longest first
+    int32_t *sa_cost = nullptr; // device [S], lazily allocated, 0 = nothing seen yet
     // dense [M,S,A,S] / sparse [S,A,B]
     const double *P = nullptr;
     bool borrowed = false;

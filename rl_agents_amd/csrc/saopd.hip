@@ -109,6 +109,8 @@ struct mp_saopd {
     int32_t *snap_head = nullptr, *snap_tail = nullptr, *snap_stamp = nullptr, *overflow = nullptr;
     uint64_t *snap_rng = nullptr;
     std::vector<mp_ctx::Block> blocks; // every device block of this batch, with its size: they go back to the ctx's block cache
+    int32_t *cost = nullptr, *order = nullptr; // wave kernel: Bellman backups of the last plan per planner / this plan's dispatch order
+    bool cost_valid = false;
     int wave = 0;       // 1: one planner per wavefront, planner-major arrays ([planner][node], [planner][state],
                         //    [planner][slot]); 0: one planner per lane, node-major arrays
     // element (row i, planner r) of a node array = i * node_si + r * node_sr, likewise states and queue slots
@@ -131,6 +133,8 @@ struct SaArgs {
     int par_backup; // wave kernel: 1 = grouped parallel backup over chunked state lists (host: the first plan of fresh planners)
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
     int tab_lds;            // wave kernel with the dictionaries in LDS: depth-table entries held in LDS
+    const int32_t *order;   // wave kernel: workgroup b plans planner order[b] (longest expected plan first), or nullptr
+    int32_t *cost;          // wave kernel: Bellman backups this plan ran, per planner (the next plan's dispatch order)
     double gamma, vmax;
     const Rec *rec;
     const double *tab; // gpow[K+3] | trg[K+3] | acc[K+3]
@@ -501,7 +505,10 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     const DepthTab gpow{lds_d, p.tab, TLD}, trg{lds_d + TLD, p.tab + (p.K + 3), TLD}, acc{lds_d + 2 * TLD, p.tab + 2 * (p.K + 3), TLD};
     constexpr int DCAP = LDSD ? 4 : 128; // (512 B of LDS after the tables, reserved by the host's size computation; unused since the
                               // prune pass finds the rows of changed states by their stamps)
-    const int r = blockIdx.x;
+    // Workgroups start in index order and a planner is one sequential chain whose length varies 7x with its root state
+    // (1 700 .. 13 000 Bellman backups on the reference's grid): a long planner that starts in the last round IS the
+    // kernel's tail.  The host passes the planners sorted by their expected cost, longest first.
+    const int r = p.order ? p.order[blockIdx.x] : (int)blockIdx.x;
     const int A = p.A;
     if (p.overflow[1 + r]) { // failed for good in an earlier asynchronous call (see saopd_kernel)
         if (lane == 0) {
@@ -1386,6 +1393,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         if (p.status) p.status[r] = status;
         if (p.env_steps) p.env_steps[r] = steps_taken;
         if (p.updates) p.updates[r] = updates;
+        if (p.cost) p.cost[r] = (int32_t)(updates < 0x7fffffffL ? updates : 0x7fffffffL) + p.K; // (>= 1 once planned)
     }
     if (LDSR) { // write back: every node record (flags and list links of older rows change too), this plan's rows, the dictionaries
         __syncthreads();
@@ -1405,6 +1413,47 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             p.sv[sb + s] = d_sv[s]; p.head[sb + s] = d_head[s]; p.tail[sb + s] = d_tail[s]; p.stamp[sb + s] = d_stamp[s];
         }
     }
+}
+
+// ---- dispatch order of the wave kernel: planners by expected cost, longest first (a counting sort over 1 024 cost
+// buckets by ONE workgroup; the order inside a bucket is whatever the atomics make it -- the plans do not depend on it).
+// key[r] = by_state ? model_cost[root_state[r]] : cost[r]
+__global__ __launch_bounds__(1024) void saopd_order_kernel(int n, const int32_t *cost, const int32_t *by_state, const int32_t *root_state,
+                                                           int32_t *order)
+{
+    __shared__ int hist[1024];
+    __shared__ int kmax;
+    const int t = threadIdx.x;
+    hist[t] = 0;
+    if (t == 0) kmax = 0;
+    __syncthreads();
+    auto key = [&](int r) { return by_state ? by_state[root_state[r]] : cost[r]; };
+    int m = 0;
+    for (int r = t; r < n; r += 1024) m = max(m, key(r));
+    atomicMax(&kmax, m);
+    __syncthreads();
+    const long km = kmax;
+    if (km <= 0) { // nothing known: index order
+        for (int r = t; r < n; r += 1024) order[r] = r;
+        return;
+    }
+    auto bucket = [&](int r) { const long k = key(r); return 1023 - (int)((k < 0 ? 0 : k) * 1023 / km); }; // bucket 0 = the longest
+    for (int r = t; r < n; r += 1024) atomicAdd(&hist[bucket(r)], 1);
+    __syncthreads();
+    if (t == 0) {
+        int acc = 0;
+        for (int b = 0; b < 1024; ++b) { const int c = hist[b]; hist[b] = acc; acc += c; }
+    }
+    __syncthreads();
+    for (int r = t; r < n; r += 1024) order[atomicAdd(&hist[bucket(r)], 1)] = r;
+}
+
+// what the first plan of a fresh planner cost, remembered by root state with the model
+__global__ __launch_bounds__(256) void saopd_learn_kernel(int n, const int32_t *root_state, const int32_t *cost, const int32_t *status,
+                                                          int32_t *model_cost)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n && (!status || status[r] == MP_OK)) model_cost[root_state[r]] = cost[r];
 }
 
 // grow a node array from old_cap to new_cap rows per planner, keeping the used_rows rows in use
@@ -1497,7 +1546,8 @@ int mp_saopd_create(mp_ctx *ctx, mp_model *model, int32_t n_planners, mp_saopd *
         sa_alloc(pl, &pl->snap_sv, sn * 8) != hipSuccess || sa_alloc(pl, &pl->snap_head, sn * 4) != hipSuccess ||
         sa_alloc(pl, &pl->snap_tail, sn * 4) != hipSuccess || sa_alloc(pl, &pl->snap_stamp, sn * 4) != hipSuccess ||
         sa_alloc(pl, &pl->snap_rng, (size_t)pl->n * 6 * 8) != hipSuccess || sa_alloc(pl, &pl->overflow, 4 * (size_t)(1 + pl->n)) != hipSuccess ||
-        sa_alloc(pl, &pl->lstate, sn * 16) != hipSuccess) {
+        sa_alloc(pl, &pl->lstate, sn * 16) != hipSuccess || sa_alloc(pl, &pl->cost, 4 * (size_t)pl->n) != hipSuccess ||
+        sa_alloc(pl, &pl->order, 4 * (size_t)pl->n) != hipSuccess) {
         mp_saopd_free(pl);
         return fail(MP_ERR_ALLOC, "mp_saopd_create: device allocation failed (%zu states x planners)", sn);
     }
@@ -1681,7 +1731,21 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     size_t max_queue_bytes = (size_t)8 << 30; // per batch; MP_SAOPD_QUEUE_LIMIT_MB overrides
     if (const char *e = getenv("MP_SAOPD_QUEUE_LIMIT_MB")) max_queue_bytes = (size_t)atol(e) << 20;
     int launches = 0;
+    // Dispatch order (wave kernel, batches beyond one residency round = 32 planners per CU): by the cost of the planner's
+    // previous plan, or -- fresh planners -- by what first plans from the same root state cost on this model so far.
+    // Only the ORDER in which workgroups start depends on it; MP_SAOPD_ORDER=0 keeps the index order.
+    a.order = nullptr; a.cost = pl->wave ? pl->cost : nullptr;
+    bool ordered = pl->wave && n > 32 * ctx->prop.multiProcessorCount;
+    if (const char *e = getenv("MP_SAOPD_ORDER")) ordered = pl->wave && e[0] == '1';
+    const bool have_cost = fresh ? pl->model->sa_cost != nullptr : pl->cost_valid;
+    if (pl->wave && fresh && !pl->model->sa_cost && hipMalloc(&pl->model->sa_cost, 4 * (size_t)pl->S) == hipSuccess)
+        MP_HIP(hipMemsetAsync(pl->model->sa_cost, 0, 4 * (size_t)pl->S, st));
     MP_TRY(kernels_begin(ctx));
+    if (ordered && have_cost) { // (inside the timed region: the sort is part of what a plan costs)
+        hipLaunchKernelGGL(saopd_order_kernel, dim3(1), dim3(1024), 0, st, n, pl->cost, fresh ? pl->model->sa_cost : nullptr, d_rs, pl->order);
+        a.order = pl->order;
+        ++launches;
+    }
     for (;;) {
         MP_HIP(hipMemsetAsync(pl->overflow, 0, 4, st));
         if (fresh) {
@@ -1736,6 +1800,14 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
             ++launches;
         }
         MP_HIP(hipMemcpyAsync(a.rng, pl->snap_rng, (size_t)n * 48, hipMemcpyDeviceToDevice, st));
+    }
+    if (pl->wave) {
+        pl->cost_valid = true;
+        if (fresh && pl->model->sa_cost) { // remember the first plans' costs by root state
+            hipLaunchKernelGGL(saopd_learn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, d_rs, pl->cost, a.status,
+                               pl->model->sa_cost);
+            ++launches;
+        }
     }
     MP_TRY(kernels_end(ctx, launches));
     MP_HIP(hipGetLastError());

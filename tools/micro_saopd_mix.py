@@ -33,7 +33,12 @@ def run(name, roots, reps=3):
 
 
 short = len(sys.argv) > 2 and sys.argv[2] == "short"
-run("bench mix", mix)
+import os
+os.environ["MP_SAOPD_ORDER"] = "0"
+run("bench mix, index order", mix)
+del os.environ["MP_SAOPD_ORDER"]
+run("bench mix (cost order from rep 2)", mix)
+os.environ["MP_SAOPD_ORDER"] = "0"
 run("mix, heavy first", mix[np.argsort(-cost[mix], kind="stable")])
 if not short:
     run("mix, light first", mix[np.argsort(cost[mix], kind="stable")])
