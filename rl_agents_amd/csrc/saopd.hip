@@ -718,6 +718,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         const int g = n_nodes;
         bool bad = false, term_c = false, real_c = false;
         int32_t s_c = 0;
+        double c0_lower = ninf, c0_rew = 0.0; // the lane's child as stored (its parent's Bellman backup below needs no read-back)
         if (lane < A) {
             const Rec rc = p.rec[(long)sl * A + lane];
             // deterministic.py:32-35: the slot of an action state.get_available_actions() does not list is a PHANTOM row
@@ -734,7 +735,8 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             SaNode nd;
             nd.lower = lower; nd.next_same = -1; nd.meta = (real_c ? SA_ALIVE : 0u) | ((uint32_t)lane << SA_ACT_SHIFT) | (uint32_t)d;
             ND(c) = nd;
-            ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = real_c ? rc.reward : 0.0;
+            c0_lower = lower; c0_rew = real_c ? rc.reward : 0.0;
+            ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = c0_rew;
             p.done[nb + c] = real_c ? (term_c ? 1 : 0) : 2;
         }
         const unsigned long long real_mask = __ballot(real_c);
@@ -799,9 +801,31 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         // (lazy queue of {state, node, delta} descriptors: see saopd_kernel)
         {
             unsigned qh = 0, qt = 0;
-            if (l0) QD4(qt) = make_int4(-1, leaf, 0, 0);
-            ++qt;
-            SA_ORDER();
+            {   // The first pop of backup_to_root is the expanded leaf itself: its children are still in this wave's registers
+                // (lower bound, depth dl + 1, state, reward as stored above), so its Bellman backup reads the state values only
+                // -- no trip through the queue, no read-back of the rows just written.
+                double u = ninf, bk = 0.0;
+                int a_id = 0x7fffffff;
+                if (lane < A) {
+                    const double svc = SV(s_c);
+                    u = c0_lower + gpow[dl + 1] * svc;
+                    bk = c0_rew + p.gamma * svc;
+                    a_id = lane;
+                }
+                const double old = SV(sl);
+                if (A <= 16) row0_argmax(u, a_id); else wave_argmax(u, a_id); // first maximal U in action order
+                const double backup = __shfl(bk, a_id);
+                const double delta = old - backup;
+                ++updates;
+                if (delta > 0.0) { // (an empty queue cannot be full)
+                    if (l0) {
+                        SV(sl) = backup; SM(sl) = cur;
+                        QD4(qt) = make_int4(sl, leaf, __double2loint(delta), __double2hiint(delta));
+                    }
+                    ++qt;
+                    SA_ORDER();
+                }
+            }
             if (!par_backup) {
                 int src = -1, nbr = -1;
                 double src_delta = 0.0;
