@@ -482,6 +482,12 @@ int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches);
 /* Name of the kernel variant the last mp_uct_plan* call launched ("uct_global", "uct_ldsr" = model resident in LDS,
  * "uct_lds", "uct_policy", "uct_cartpole"): the host picks by model and batch size; reports and tests name what ran. */
 const char *mp_last_kernel_variant(mp_ctx *ctx);
+/* Hardware self-test (no reference counterpart): LDS atomics of ONE wavefront instruction that hit the same address apply
+ * in LANE ORDER on this device -- the state-aware OPD kernel's grouped backup relies on it (one ds_min_rtn_f64 of the group
+ * leaders hands every leader the running minimum the reference's turn-by-turn loop would have read).  Runs `waves` wave
+ * instructions with random lane masks / addresses / values; *violations = returned values that are not the lane-order
+ * prefix minimum + wrong final cells (0 on a conforming device). */
+int mp_selftest_lds_atomic_order(mp_ctx *ctx, int32_t waves, int64_t *violations);
 
 #ifdef __cplusplus
 }

@@ -577,6 +577,67 @@ int mp_ctx_device_info(mp_ctx *ctx, int32_t *n_cu, int32_t *wave_size, int64_t *
 
 const char *mp_last_kernel_variant(mp_ctx *ctx) { return ctx ? ctx->last_variant : ""; }
 
+// ---- self-test: lane order of same-address LDS atomics within one wave instruction (see mi355plan.h) ----------------------
+namespace mp {
+__device__ __forceinline__ uint32_t st_hash(uint32_t x)
+{
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(64) void selftest_lds_order_kernel(int waves, unsigned long long *violations)
+{
+    __shared__ double cell[8];
+    const int lane = threadIdx.x;
+    unsigned long long bad = 0;
+    for (int w = blockIdx.x; w < waves; w += gridDim.x) {
+        if (lane < 8) cell[lane] = 5.0;
+        __syncthreads();
+        const uint32_t h = st_hash((uint32_t)w * 64u + (uint32_t)lane);
+        const int n_addr = (w & 7) + 1;
+        const int a = (int)((h >> 8) % (uint32_t)n_addr);
+        const double v = (double)(h & 63u) / 8.0;
+        const bool on = (w & 3) == 0 || ((h >> 20) & 1u);
+        double got = -1.0;
+        if (on) got = __hip_atomic_fetch_min(&cell[a], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __syncthreads();
+        // what lane order prescribes: the minimum of 5.0 and the values of the LOWER active lanes on the same cell
+        double want = 5.0, fin = 5.0;
+        for (int l = 0; l < 64; ++l) {
+            const uint32_t hl = st_hash((uint32_t)w * 64u + (uint32_t)l);
+            const bool on_l = (w & 3) == 0 || ((hl >> 20) & 1u);
+            const int a_l = (int)((hl >> 8) % (uint32_t)n_addr);
+            const double v_l = (double)(hl & 63u) / 8.0;
+            if (on_l && a_l == a) {
+                if (l < lane) want = v_l < want ? v_l : want;
+                fin = v_l < fin ? v_l : fin;
+            }
+        }
+        if (on && got != want) ++bad;
+        if (on && cell[a] != fin) ++bad;
+        __syncthreads();
+    }
+    if (bad) atomicAdd(violations, bad);
+}
+} // namespace mp
+
+int mp_selftest_lds_atomic_order(mp_ctx *ctx, int32_t waves, int64_t *violations)
+{
+    if (!ctx || !violations || waves < 1) return fail(MP_ERR_ARG, "mp_selftest_lds_atomic_order: bad argument");
+    MP_HIP(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    MP_HIP(hipMalloc(&d, 8));
+    MP_HIP(hipMemsetAsync(d, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(mp::selftest_lds_order_kernel, dim3((unsigned)(waves < 4096 ? waves : 4096)), dim3(64), 0, ctx->stream, waves, d);
+    unsigned long long h = 0;
+    const hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    MP_HIP(e);
+    MP_HIP(e2);
+    *violations = (int64_t)h;
+    return MP_OK;
+}
+
 int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");

@@ -1733,6 +1733,9 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     const size_t lds_dict = (size_t)a.tab_lds * 24 + 32 + (size_t)pl->S * (8 + 16 + 16);
     bool use_dict = pl->wave && a.tab_lds >= 16;
     if (const char *e = getenv("MP_SAOPD_DICT")) use_dict = use_dict && e[0] == '1';
+    // with the dictionaries in LDS and the grouped backup the global-memory arena is as fast for ONE planner as the all-in-LDS
+    // latency mode (first plan, light / heavy root: 1.4 / 3.3 ms against 1.4 / 4.6 ms): MP_SAOPD_LDS=1 still forces that one
+    if (use_dict && !getenv("MP_SAOPD_LDS")) use_lds = false;
     const bool async = mem == MP_MEM_DEVICE;
     a.sticky = async ? 1 : 0;
     if (async) use_lds = false; // (its small queue relies on the retry)

@@ -83,6 +83,7 @@ SIGNATURES = {
     "mp_olop_allocation": (C.c_int, [c_i32, c_f64, P(c_i32), P(c_i32)]),
     "mp_last_kernel_ms": (C.c_int, [_vp, P(c_f64), P(c_i32)]),
     "mp_last_kernel_variant": (C.c_char_p, [_vp]),
+    "mp_selftest_lds_atomic_order": (C.c_int, [_vp, C.c_int32, C.POINTER(C.c_int64)]),
     "mp_env_step": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, _vp, c_i32, c_i32, _vp, _vp, _vp, _vp, c_i32, _vp, c_i32]),
     "mp_greedy_actions": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32]),
     "mp_env_step_stochastic": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, _vp, c_i32, c_i32, _vp, _vp, _vp, _vp, c_i32, _vp, _vp,
@@ -256,6 +257,12 @@ class Context(object):
     def last_kernel_variant(self):
         """Which kernel variant the last UCT plan launched ("uct_global", "uct_ldsr", ...)."""
         return self._lib.mp_last_kernel_variant(self._h).decode()
+
+    def selftest_lds_atomic_order(self, waves=65536):
+        """Violations of "same-address LDS atomics of one wave instruction apply in lane order" (0 on a conforming device)."""
+        v = C.c_int64(-1)
+        _check(self._lib.mp_selftest_lds_atomic_order(self._h, int(waves), C.byref(v)))
+        return int(v.value)
 
     # ---- host-inclusive fast path: pinned arrays, device-resident generator records -------------------------
     def pinned(self, spec):

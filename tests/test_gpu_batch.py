@@ -563,7 +563,14 @@ def test_policy_load_errors(ctx):
     model.close()
 
 
-@pytest.mark.parametrize("mapping", ["wave", "wave-serial-prune", "wave-par-backup", "wave-seq-backup", "lane"])
+def test_lds_atomics_apply_in_lane_order(ctx):
+    """What the state-aware kernel's grouped backup relies on (csrc/saopd.hip apply_vec): same-address LDS atomics of one
+    wave instruction apply in lane order -- checked on THIS device over 131 072 wave instructions with random masks."""
+    assert ctx.selftest_lds_atomic_order(131072) == 0
+
+
+@pytest.mark.parametrize("mapping", ["wave", "wave-serial-prune", "wave-par-backup", "wave-seq-backup", "wave-global", "wave-ordered",
+                                     "lane"])
 @pytest.mark.parametrize("shape", ["grid", "garnet", "highway"])
 def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     """200 planners per launch, three consecutive plans each (planner state kept on the device), vs the oracle run
@@ -578,15 +585,23 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
         monkeypatch.setenv("MP_SAOPD_PAR_BACKUP", "1")   # chunked lists are rebuilt from the linked ones by the later plans
     if mapping == "wave-seq-backup":        # ... and in none: the element-by-element loop
         monkeypatch.setenv("MP_SAOPD_PAR_BACKUP", "0")
+    if mapping == "wave-global":            # round 4: the dictionaries stay in global memory (default: LDS where they fit)
+        monkeypatch.setenv("MP_SAOPD_DICT", "0")
+    if mapping == "wave-ordered":           # round 4: dispatch by expected cost also for this small batch (default: > 32 per CU)
+        monkeypatch.setenv("MP_SAOPD_ORDER", "1")
     cfg, budget, gamma = {"grid": (generators.gridworld(), 120, 0.8),
                           "garnet": (generators.random_deterministic(40, 3, seed=5, terminal_rate=0.1), 90, 0.7),
                           "highway": (generators.highway_shaped(3, 4, 10, seed=3), 150, 0.9)}[shape]
     t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
     n = 200
     model = ctx.load_table(t, r, term)
-    planners = native.StateAwarePlanners(ctx, model, n)
     g = np.random.Generator(np.random.PCG64(17))
     states = g.integers(0, r.shape[0], size=n).astype(np.int32)
+    if mapping == "wave-ordered":           # an earlier batch on the model: the first plans below start longest first
+        warm = native.StateAwarePlanners(ctx, model, n)
+        warm.plan(states[::-1].copy(), budget, gamma, 0.0, _rng_states(n, base=1))
+        warm.close()
+    planners = native.StateAwarePlanners(ctx, model, n)
     rng = _rng_states(n, base=4242)
     ref_rng = rng.copy()
     ref_planner = [None] * n

@@ -222,14 +222,16 @@ def test_uct_state_policies_subtree_golden(ctx, golden):
     model.close()
 
 
-@pytest.mark.parametrize("mapping", ["wave", "lane"])
+@pytest.mark.parametrize("mapping", ["wave", "wave-global", "lane"])
 def test_state_aware_planner_golden_episodes(ctx, golden, mapping, monkeypatch):
     """(one planner per wavefront / per lane) mp_saopd_plan vs the unmodified StateAwarePlannerAgent over multi-plan episodes: plans, trees, leaves sets,
     state-value tables, env-step counts and generator state, with the planner state carried across plans; where
     the reference raises (every leaf pruned) the planner reports MP_ERR_ARG."""
     from rl_agents_amd import native
     from tests.helpers import replay_state_aware_episode
-    monkeypatch.setenv("MP_SAOPD_MODEL", mapping)
+    monkeypatch.setenv("MP_SAOPD_MODEL", mapping.split("-")[0])
+    if mapping == "wave-global":    # (round 4: the default wave kernel keeps the per-state dictionaries in LDS; this one does not)
+        monkeypatch.setenv("MP_SAOPD_DICT", "0")
     z = golden["state_aware"]
     for name in [str(n) for n in z["sa/names"]]:
         cfg = mdp_from_golden(z, "sa/{}/mdp".format(name))

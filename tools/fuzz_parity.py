@@ -368,6 +368,15 @@ def one_case(ctx, g, case):
         avail = None
         os.environ.pop("MP_SAOPD_MODEL", None)
         os.environ.pop("MP_SAOPD_LDS", None)
+        os.environ.pop("MP_SAOPD_DICT", None)
+        os.environ.pop("MP_SAOPD_ORDER", None)
+        # round 4: the wave kernel with the dictionaries in LDS is the default where they fit; "0" keeps them in global memory.
+        # Dispatch by expected cost (only the order in which planners start) is forced on for half of the cases.
+        if g.random() < 0.4:
+            os.environ["MP_SAOPD_DICT"] = "0"
+        if g.random() < 0.5:
+            os.environ["MP_SAOPD_ORDER"] = "1"
+        desc.update(dict_lds=os.environ.get("MP_SAOPD_DICT", "auto"), order=os.environ.get("MP_SAOPD_ORDER", "auto"))
         if kind == "saopd_masked":  # deterministic.py:32-35 under the state-aware planner: phantom rows (round 3)
             avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
             avail[np.arange(s), g.integers(0, a, size=s)] = True
@@ -423,6 +432,8 @@ def one_case(ctx, g, case):
         planners.close()
         os.environ.pop("MP_SAOPD_MODEL", None)
         os.environ.pop("MP_SAOPD_LDS", None)
+        os.environ.pop("MP_SAOPD_DICT", None)
+        os.environ.pop("MP_SAOPD_ORDER", None)
     model.close()
     return desc
 
