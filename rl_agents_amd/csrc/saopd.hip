@@ -94,7 +94,7 @@ struct mp_saopd {
     int32_t *state = nullptr, *parent = nullptr, *first_child = nullptr;
     double *reward = nullptr;
     uint8_t *done = nullptr;
-    int32_t *oldlive = nullptr; // wave kernel: ids of the rows of earlier plans that have children (rebuilt by every plan)
+    int2 *oldlive = nullptr; // wave kernel: {row, state} of the rows of earlier plans that have children (rebuilt by every plan)
     // wave kernel: every state's node list again as chunks of 15 ids + link (16 ints), rebuilt from the linked lists by every
     // plan and kept up to date by its appends: the backup reads a popped state's list 15 neighbours per load
     int4 *lstate = nullptr;     // [n][S] {count, head chunk, tail chunk, -}
@@ -144,7 +144,7 @@ struct SaArgs {
     int32_t *state, *parent, *first_child;
     double *reward;
     uint8_t *done;
-    int32_t *oldlive; // [planner][cap] scratch of the wave kernel's prune scan
+    int2 *oldlive;    // [planner][cap] {row, state}: scratch of the wave kernel's prune scan
     int4 *lstate;     // chunked per-state lists (wave kernel): {count, head chunk, tail chunk, -} per state
     int32_t *lpool;
     long pool_ints;
@@ -609,7 +609,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     // the rows of EARLIER plans that can still matter to a prune test: those with children (their leaves were dropped by
     // reset()).  Listed once per plan, in id order, so that the per-iteration scan below reads a quarter of the old arena
     // and nothing of its dead rows -- the scan's cost would otherwise grow with every plan of an episode.
-    int32_t *old_b = p.oldlive + nb;
+    int2 *old_b = p.oldlive + nb;
     int n_old = 0;
     if (p.prune) {
         const unsigned long long lt0 = (1ULL << lane) - 1ULL;
@@ -617,7 +617,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             const int i = i0 + lane;
             const bool live = i < root && (ND(i).meta & SA_CHILDREN) != 0;
             const unsigned long long bm = __ballot(live);
-            if (live) old_b[n_old + __popcll(bm & lt0)] = i;
+            if (live) old_b[n_old + __popcll(bm & lt0)] = make_int2(i, ST(i)); // (a row with children is never dead: no flag byte)
             n_old += __popcll(bm);
         }
         __syncthreads();
@@ -1152,19 +1152,73 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             const unsigned long long lt = (1ULL << lane) - 1ULL;
             // scan positions: the listed old rows, then the rows of this plan (root .. n_nodes - 1)
             const int n_pos = n_old + (n_nodes - root);
+            // The register sets: rst[q] = the row's state (-1: none), ids[q] = its row, rows in ascending id over (set, lane).
+            // key = the row's depth while it can dominate (alive or with children), -1 otherwise.
+            auto process_sets = [&](const int (&ids)[NS], int (&rst)[NS]) {
+                int key[NS];
+                uint32_t rmeta[NS];
+                double rval[NS];
+                uint32_t changed = 0, nonempty = 0;
+#pragma unroll
+                for (int q = 0; q < NS; ++q) {
+                    rmeta[q] = 0; rval[q] = ninf; key[q] = -1;
+                    if (!__any(rst[q] >= 0)) continue; // (uniform: an empty set costs nothing)
+                    nonempty |= 1u << q;
+                    if (rst[q] >= 0) {
+                        const SaNode nd = load_node(&ND(ids[q]));
+                        rmeta[q] = nd.meta;
+                        rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
+                        key[q] = (nd.meta & (SA_CHILDREN | SA_ALIVE)) ? (int)(nd.meta & SA_DEPTH) : -1;
+                    }
+                }
+                // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it.
+                // One candidate against one set = three compares (state, value, depth-or-dead).
+#pragma unroll
+                for (int q = NS - 1; q >= 0; --q) {
+                    if (!(nonempty & (1u << q))) continue;
+                    unsigned long long todo = __ballot(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
+                    while (todo) {
+                        const int l = 63 - __clzll((long long)todo);
+                        todo &= ~(1ULL << l);
+                        const int cs = __builtin_amdgcn_readlane(rst[q], l);
+                        const int cd = (int)(__builtin_amdgcn_readlane((int)rmeta[q], l) & SA_DEPTH);
+                        const double cv = bcast_lane(rval[q], l);
+                        unsigned long long dom = 0ULL;
+#pragma unroll
+                        for (int t = 0; t < NS; ++t) {
+                            if (!(nonempty & (1u << t))) continue;
+                            unsigned long long m = __ballot(rst[t] == cs && rval[t] >= cv && key[t] >= cd);
+                            if (t == q) m &= ~(1ULL << l);
+                            dom |= m;
+                        }
+                        if (dom && lane == l) { rmeta[q] &= ~SA_ALIVE; key[q] = -1; changed |= 1u << q; }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < NS; ++q)
+                    if (changed & (1u << q)) { // a pruned leaf: not alive, no children -- dead from now on
+                        const int i = ids[q];
+                        ND(i).meta = rmeta[q];
+                        p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2);
+                    }
+            };
+            // (Tried: hits left where a single-trip scan found them, no compaction through memory -- slower, 6.05 -> 6.45 ms for
+            // light planners: uncompacted, the ~30 rows occupy all four register sets and every candidate pays four compares.)
             for (int i0 = 0; i0 < n_pos; i0 += 64 * WU) {
                 int32_t rows[WU], sts[WU], stamps[WU], heads[WU];
                 uint8_t dead[WU];
 #pragma unroll
                 for (int j = 0; j < WU; ++j) {
                     const int q = min(i0 + 64 * j + lane, n_pos - 1);
-                    rows[j] = q < n_old ? old_b[q] : root + (q - n_old);
+                    rows[j] = root + (q - n_old); sts[j] = 0; dead[j] = 0;
+                    if (q < n_old) { const int2 o = old_b[q]; rows[j] = o.x; sts[j] = o.y; }
                 }
 #pragma unroll
-                for (int j = 0; j < WU; ++j) {
-                    sts[j] = ST(rows[j]);
-                    dead[j] = p.done[nb + rows[j]];
-                }
+                for (int j = 0; j < WU; ++j)
+                    if (min(i0 + 64 * j + lane, n_pos - 1) >= n_old) {
+                        sts[j] = ST(rows[j]);
+                        dead[j] = p.done[nb + rows[j]];
+                    }
 #pragma unroll
                 for (int j = 0; j < WU; ++j) { stamps[j] = SM(sts[j]); heads[j] = HD(sts[j]); }
 #pragma unroll
@@ -1186,56 +1240,17 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #endif
             if (n_d <= pcap) {
                 SA_SYNC(); // the pairs are read back by other lanes
-                // One group of rows (record j: row id_at(j), state st_at(j), j < cnt <= 64 NS, ascending id) through NS
-                // register sets: record lane + 64 q = {state, meta, value}; a record is identified by (set, lane).
+                // One group of rows (record j: row id_at(j), state st_at(j), j < cnt <= 64 NS, ascending id) through the NS
+                // register sets: record lane + 64 q; a record is identified by (set, lane).
                 auto process = [&](int cnt, auto id_at, auto st_at) {
-                    int rst[NS], key[NS]; // key: the row's depth while it can dominate (alive or with children), -1 otherwise
-                    uint32_t rmeta[NS];
-                    double rval[NS];
-                    uint32_t changed = 0;
+                    int ids[NS], rst[NS];
 #pragma unroll
                     for (int q = 0; q < NS; ++q) {
                         const int j = lane + 64 * q;
-                        rst[q] = -1; rmeta[q] = 0; rval[q] = ninf; key[q] = -1;
-                        if (64 * q >= cnt) continue; // (uniform: an empty set costs nothing)
-                        if (j < cnt) {
-                            rst[q] = st_at(j);
-                            const SaNode nd = load_node(&ND(id_at(j)));
-                            rmeta[q] = nd.meta;
-                            rval[q] = nd.lower + gpow[nd.meta & SA_DEPTH] * SV(rst[q]);
-                            key[q] = (nd.meta & (SA_CHILDREN | SA_ALIVE)) ? (int)(nd.meta & SA_DEPTH) : -1;
-                        }
+                        ids[q] = 0; rst[q] = -1;
+                        if (j < cnt) { ids[q] = id_at(j); rst[q] = st_at(j); }
                     }
-                    // candidates: alive rows, descending id = the last set from its last lane down, then the sets before it.
-                    // One candidate against one set = three compares (state, value, depth-or-dead).
-#pragma unroll
-                    for (int q = NS - 1; q >= 0; --q) {
-                        if (64 * q >= cnt) continue;
-                        unsigned long long todo = __ballot(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
-                        while (todo) {
-                            const int l = 63 - __clzll((long long)todo);
-                            todo &= ~(1ULL << l);
-                            const int cs = __builtin_amdgcn_readlane(rst[q], l);
-                            const int cd = (int)(__builtin_amdgcn_readlane((int)rmeta[q], l) & SA_DEPTH);
-                            const double cv = bcast_lane(rval[q], l);
-                            unsigned long long dom = 0ULL;
-#pragma unroll
-                            for (int t = 0; t < NS; ++t) {
-                                if (64 * t >= cnt) continue;
-                                unsigned long long m = __ballot(rst[t] == cs && rval[t] >= cv && key[t] >= cd);
-                                if (t == q) m &= ~(1ULL << l);
-                                dom |= m;
-                            }
-                            if (dom && lane == l) { rmeta[q] &= ~SA_ALIVE; key[q] = -1; changed |= 1u << q; }
-                        }
-                    }
-#pragma unroll
-                    for (int q = 0; q < NS; ++q)
-                        if (changed & (1u << q)) { // a pruned leaf: not alive, no children -- dead from now on
-                            const int i = id_at(lane + 64 * q);
-                            ND(i).meta = rmeta[q];
-                            p.done[nb + i] = (uint8_t)(p.done[nb + i] | 2);
-                        }
+                    process_sets(ids, rst);
                 };
                 if (n_d <= p.prune_rows) { // the usual case: every changed state at once
                     process(n_d, [&](int j) { return recs[2 * j]; }, [&](int j) { return recs[2 * j + 1]; });
