@@ -30,7 +30,7 @@
 
 namespace mp {
 
-constexpr int kMaxModels = 16;
+constexpr int kMaxModels = 32; // (one terminal flag per model in a 32-bit word of the node)
 
 struct ROpdArgs {
     int n_roots, M, S, A, K, cap, done_on_next, max_plan_len;

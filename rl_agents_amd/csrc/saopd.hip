@@ -133,6 +133,7 @@ struct SaArgs {
     int par_backup; // wave kernel: 1 = grouped parallel backup over chunked state lists (host: the first plan of fresh planners)
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
     int tab_lds;            // wave kernel with the dictionaries in LDS: depth-table entries held in LDS
+    int tab_plain;          // the other wave kernels: depth-table entries held in LDS (all K + 3 unless the budget is huge)
     const int32_t *order;   // wave kernel: workgroup b plans planner order[b] (longest expected plan first), or nullptr
     int32_t *cost;          // wave kernel: Bellman backups this plan ran, per planner (the next plan's dispatch order)
     double gamma, vmax;
@@ -490,7 +491,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
     // the depth tables in LDS; LDSD keeps only their first tab_lds entries there (deeper nodes read the global copy), so that
     // tables + dictionaries stay within the 5 KB per planner that eight waves per SIMD leave
-    const int TLD = LDSD ? p.tab_lds : p.K + 3;
+    const int TLD = LDSD ? p.tab_lds : p.tab_plain;
     const int ntab = 3 * TLD;
     const int lane = threadIdx.x;
     for (int i = lane; i < ntab; i += 64) {
@@ -500,7 +501,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     struct DepthTab {
         const double *l, *g;
         int nl;
-        __device__ __forceinline__ double operator[](int d) const { return (!LDSD || d < nl) ? l[d] : g[d]; }
+        __device__ __forceinline__ double operator[](int d) const { return d < nl ? l[d] : g[d]; }
     };
     const DepthTab gpow{lds_d, p.tab, TLD}, trg{lds_d + TLD, p.tab + (p.K + 3), TLD}, acc{lds_d + 2 * TLD, p.tab + 2 * (p.K + 3), TLD};
     constexpr int DCAP = LDSD ? 4 : 128; // (512 B of LDS after the tables, reserved by the host's size computation; unused since the
@@ -1721,8 +1722,12 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     MP_TRY(stage_out_alloc(ctx, WS_IO6, env_steps, (size_t)n, mem, &a.env_steps));
     MP_TRY(stage_out_alloc(ctx, WS_IO7, updates, (size_t)n, mem, &a.updates));
 
-    const size_t lds = tab.size() * sizeof(double) + 128 * sizeof(int32_t); // tables + the wave kernel's changed-state list
-    if (lds > 64 * 1024) return fail(MP_ERR_ARG, "mp_saopd_plan: budget %d needs %zu B of LDS tables (> 64 KiB)", budget, lds);
+    // tables (+ 512 B the wave kernel uses as a counter).  The wave kernels keep at most 2 560 depth entries (60 KB) in LDS and
+    // read deeper nodes' entries from the global copy, so the budget is not bounded by LDS (round 4); the lane kernel holds them all
+    a.tab_plain = pl->wave ? std::min(K + 3, 2560) : K + 3;
+    const size_t lds = (size_t)3 * a.tab_plain * sizeof(double) + 128 * sizeof(int32_t);
+    if (lds > 64 * 1024)
+        return fail(MP_ERR_ARG, "mp_saopd_plan: budget %d needs %zu B of LDS tables (> 64 KiB) in the one-planner-per-lane kernel", budget, lds);
     // LDS-resident variant of the wave kernel: the arena after this plan, the dictionaries and a (smaller) queue in LDS.
     // A queue overflow there rolls the plan back like any other and the retry runs on the global-memory form.
     a.lds_rows = need;

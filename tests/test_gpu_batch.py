@@ -679,6 +679,44 @@ def test_state_aware_many_actions_vs_oracle(ctx, n_actions):
     model.close()
 
 
+@pytest.mark.parametrize("dict_lds", ["1", "0"])
+@pytest.mark.parametrize("shape", ["grid-12400", "ring-2700"])
+def test_state_aware_large_budgets_vs_oracle(ctx, shape, dict_lds, monkeypatch):
+    """Round 4: the budget is no longer bounded by LDS.  The wave kernels keep the first depth-table entries in LDS (37 with
+    the dictionaries there, 2 560 without) and read deeper nodes' entries from the global copy: the 10x10 grid at budget 12 400
+    reaches depth 223, a one-action ring at budget 2 700 depth 2 700.  Plans, Bellman-backup counts, trees vs the oracle."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_SAOPD_DICT", dict_lds)
+    if shape == "grid-12400":
+        cfg = generators.gridworld()
+        t, r, term, budget = cfg["transition"], cfg["reward"], cfg["terminal"], 12400
+    else:
+        g = np.random.Generator(np.random.PCG64(8))
+        t, r, term, budget = ((np.arange(30) + 1) % 30).reshape(30, 1), np.round(g.random((30, 1)), 2), np.zeros(30, bool), 2700
+    states = np.array([5, 17, 29], dtype=np.int32)
+    n = len(states)
+    model = ctx.load_table(t, r, term)
+    planners = native.StateAwarePlanners(ctx, model, n)
+    rng = _rng_states(n, base=77)
+    ref_rng = rng.copy()
+    out = planners.plan(states, budget, 0.8, 0.0, rng, max_plan_len=budget + 1)
+    for i in range(n):
+        o = oracle.saopd_plan(t, r, term, int(states[i]), budget, 0.8, rng_state=ref_rng[i], max_plan_len=budget + 1)
+        assert out["status"][i] == 0
+        np.testing.assert_array_equal(out["plans"][i, :out["plan_len"][i]], o["plan"])
+        assert out["env_steps"][i] == o["env_steps"] and out["updates"][i] == o["updates"]
+        np.testing.assert_array_equal(rng[i], o["rng_after"])
+        tree, sv = planners.export(i)
+        assert np.array_equal(sv, o["state_values"])
+        for k in ("parent", "depth", "lower", "alive"):
+            assert np.array_equal(tree[k], o["tree"][k]), k
+        assert tree["depth"].max() == o["tree"]["depth"].max() and tree["depth"].max() > (200 if shape == "grid-12400" else 2600)
+    planners.close()
+    model.close()
+
+
 @pytest.mark.parametrize("prune_rows", [None, 64, 0])
 @pytest.mark.parametrize("n_states,n_actions,budget", [(2, 3, 420), (3, 2, 500), (6, 4, 480)])
 def test_state_aware_long_lists_vs_oracle(ctx, n_states, n_actions, budget, prune_rows, monkeypatch):
