@@ -68,8 +68,11 @@ constexpr uint32_t SA_ALIVE = 0x80000000u, SA_CHILDREN = 0x40000000u, SA_DEPTH =
 // instructions it issues.
 __device__ __forceinline__ SaNode load_node(const SaNode *p)
 {
-    uint4 r = *reinterpret_cast<const uint4 *>(p);
-    asm volatile("" : "+v"(r.x), "+v"(r.y), "+v"(r.z), "+v"(r.w)); // (all four words live here)
+    // (round 4: no barrier behind the load any more.  An `asm volatile` that made all four words live kept the load one
+    // dwordx4, but it also made the compiler WAIT for it where it stood: the leaf scan requested its four rows one after the
+    // other with a full round trip each.  Plain: 5.92 against 6.08 ms for light planners, 5.4 / 6.35 against 5.6 / 6.6 ms for
+    // the following plans.)
+    const uint4 r = *reinterpret_cast<const uint4 *>(p);
     SaNode n;
     n.lower = __hiloint2double((int)r.y, (int)r.x); n.next_same = (int32_t)r.z; n.meta = r.w;
     return n;
@@ -501,7 +504,17 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     struct DepthTab {
         const double *l, *g;
         int nl;
-        __device__ __forceinline__ double operator[](int d) const { return d < nl ? l[d] : g[d]; }
+        // The LDS read is unconditional and the global one a branch no lane of a shallow tree takes.  (Written as
+        // `d < nl ? l[d] : g[d]` the compiler selects between the two POINTERS and issues one flat_load through the texture path
+        // for every table access -- the path this kernel is short of; explicit address spaces keep it from forming the select.)
+        __device__ __forceinline__ double operator[](int d) const
+        {
+            typedef const __attribute__((address_space(3))) double *lds_cdp;
+            typedef const __attribute__((address_space(1))) double *glb_cdp;
+            double v = ((lds_cdp)l)[d < nl ? d : nl - 1];
+            if (d >= nl) v = ((glb_cdp)g)[d];
+            return v;
+        }
     };
     const DepthTab gpow{lds_d, p.tab, TLD}, trg{lds_d + TLD, p.tab + (p.K + 3), TLD}, acc{lds_d + 2 * TLD, p.tab + 2 * (p.K + 3), TLD};
     constexpr int DCAP = LDSD ? 4 : 128; // (512 B of LDS after the tables, reserved by the host's size computation; unused since the
