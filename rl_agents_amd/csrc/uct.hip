@@ -977,7 +977,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // single-gather variant is the default; MP_UCT_MODEL=lds selects the LDS-resident transition table.
     const char *force = getenv("MP_UCT_MODEL"); // "global" (default) / "lds"
     const char *lay = getenv("MP_UCT_TREE"); // "rootmajor" / "interleaved" / "group": tree layout (TreeRef)
-    const bool at_known = A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8;
+    const bool at_known = A >= 2 && A <= 8;
     // default: group-interleaved wherever |A| has a compile-time specialisation (262 144 roots: 1.05-1.07 ms against
     // 1.16 ms root-major and 1.09 ms interleaved; 4 096 roots and single roots: no difference)
     const int want_il = !lay ? (at_known ? 2 : 0) : (lay[0] == 'i' ? 1 : (lay[0] == 'g' && at_known ? 2 : 0));
@@ -1173,9 +1173,10 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 7: MP_TRY(uct_launch<7>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         default:
-            if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not one of 2,3,4,5,6,8", A);
+            if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not in 2..8", A);
             MP_TRY(uct_launch<0>(c, ldsm, lds, s, false, false, false, spill));
             break;
         }
@@ -1273,8 +1274,7 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
     if (!stoch && (model->mode != MP_MODE_DETERMINISTIC || !model->rec))
         return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a finite-MDP model");
     const int S = model->S, A = model->A;
-    if (stoch ? (A < 2 || A > 8) : !(A == 2 || A == 3 || A == 4 || A == 5 || A == 6 || A == 8))
-        return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not one of %s", A, stoch ? "2..8" : "2,3,4,5,6,8");
+    if (A < 2 || A > 8) return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not in 2..8", A);
     MP_HIP(hipSetDevice(ctx->device));
     const int stride = (A + 1) & ~1, frq = 1 + (A - 1 + 3) / 4;
     std::vector<double> hp((size_t)S * stride, 0.0);

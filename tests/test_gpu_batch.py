@@ -64,7 +64,7 @@ def _coarse(cfg, levels=16):
     return dict(cfg, reward=np.round(np.asarray(cfg["reward"]) * levels) / levels)
 
 
-@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 7, 8])
 def test_uct_lds_resident_model_action_counts(ctx, n_actions, monkeypatch):
     """ENV_TABLE_LDSR for every |A| it is compiled for: preference policies, TimeLimit truncation with steps already
     taken, both terminal conventions, ragged batch sizes around the workgroup size."""
@@ -471,7 +471,7 @@ def _random_policy_tables(s, a, seed, zero_rate=0.15):
 
 
 @pytest.mark.parametrize("coarse_bits", [None, 5, "packed"])
-@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 7, 8])
 def test_uct_state_policies_batch_action_counts(ctx, n_actions, coarse_bits, monkeypatch):
     """Per-state prior / rollout tables (mcts_with_prior.py:47-62), every |A| specialisation, 300 roots vs the oracle.
     coarse_bits = 5 keeps only 5 bits of each threshold in the fused records, so that the exact-row fallback (taken

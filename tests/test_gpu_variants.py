@@ -204,7 +204,7 @@ def test_uct_restricted_actions_agents_match_reference(z):
         _assert_agent_tree(z, p + "/tree", agent.planner.root, fields=("count", "value", "prior"))
 
 
-@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 8])
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 5, 6, 7, 8])
 def test_uct_restricted_actions_batch_vs_oracle(ctx, n_actions):
     """300 roots per |A| specialisation: listed policies (random restrictions, preference policy that falls back where
     its action is unavailable, a rollout policy that ignores availability) against the oracle's literal lists."""

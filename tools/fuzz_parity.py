@@ -159,7 +159,7 @@ def one_case(ctx, g, case):
         temperature = float(g.choice([0.0, 1.0, 10.0, 3000.0]))
         steps0 = g.integers(0, 3, size=n).astype(np.int32) if max_steps else None
         desc.update(episodes=episodes, horizon=horizon, temperature=temperature)
-        if kind == "uct_policy" and a in (2, 3, 4, 5, 6, 8):
+        if kind == "uct_policy" and a in (2, 3, 4, 5, 6, 7, 8):
             w = g.random((2, s, a)) ** 2
             w[g.random((2, s, a)) < 0.2] = 0.0
             w[:, np.arange(s), g.integers(0, a, size=s)] += 0.1
@@ -187,7 +187,7 @@ def one_case(ctx, g, case):
         eq(rng_dev, ref["rng_after"], "rng", desc)
     elif kind == "uct_listed":      # policies over restricted action sets (mcts.py:59-97): listed-policy kernel variant
         from tests.helpers import reference_policy_lists
-        if a not in (2, 3, 4, 5, 6, 8):
+        if a not in (2, 3, 4, 5, 6, 7, 8):
             model.close()
             return desc
         avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
