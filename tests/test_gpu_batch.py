@@ -539,10 +539,10 @@ def test_uct_state_policies_headline_shape_and_uniform_equivalence(ctx):
 def test_policy_load_errors(ctx):
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
-    cfg = generators.random_deterministic(50, 7, seed=1)
+    cfg = generators.random_deterministic(50, 9, seed=1)
     model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
-    with pytest.raises(native.NativeError):   # |A| = 7 has no compile-time specialisation
-        ctx.load_policy(model, np.full((50, 7), 1 / 7), np.full((50, 7), 1 / 7))
+    with pytest.raises(native.NativeError):   # |A| = 9 has no compile-time specialisation (2..8 have)
+        ctx.load_policy(model, np.full((50, 9), 1 / 9), np.full((50, 9), 1 / 9))
     model.close()
     cfg = generators.random_deterministic(50, 4, seed=1)
     model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
