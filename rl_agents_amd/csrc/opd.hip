@@ -638,6 +638,148 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
 #undef LU
 }
 
+// ---- any number of actions (|A| > 64): the plain form.  One root per wavefront, bounds / records / parent map in global
+// memory, the |A| children of an expansion 64 at a time, the leaf argmax a scan of the whole bounds array (the reference's
+// own max(leaves, key=U), deterministic.py:110), backups and plan descent as in the other kernels -- same results, none of
+// their machinery: environments with that many actions have small K = budget // |A|.
+__global__ __launch_bounds__(64) void opd_any_kernel(OpdArgs p)
+{
+    const int lane = threadIdx.x, root = blockIdx.x, A = p.A;
+    const long base = (long)root * p.cap;
+    OpdNode *NA = reinterpret_cast<OpdNode *>(p.L) + base;
+    double *U = p.U + base, *RW = p.reward + base;
+    int32_t *EXP = p.expanded + (long)root * (p.K > 0 ? p.K : 1);
+    constexpr int32_t DONE_FLAG = 1 << 30;
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+    if (lane == 0) {
+        OpdNode n0;
+        n0.L = 0.0; n0.state = p.root_state[root]; n0.depth = 0;
+        NA[0] = n0;
+        RW[0] = 0.0;
+        U[0] = 0.0;
+    }
+    __syncthreads();
+    int n_nodes = 1, real_mine = 0, status = MP_OK, k_done = 0;
+    for (int k = 0; k < p.K; ++k) {
+        // deterministic.py:110: first maximal upper bound among the leaves (an expanded node's slot holds -inf)
+        double bu = ninf;
+        int leaf = 0x7fffffff;
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = U[i];
+            if (u > bu) { bu = u; leaf = i; }
+        }
+        wave_argmax(bu, leaf);
+        if (leaf == 0x7fffffff) { status = MP_ERR_ARG; break; } // (no leaf with a finite bound: cannot happen with >= 1 action per state)
+        const OpdNode pn = NA[leaf];
+        const int d = (pn.depth & (DONE_FLAG - 1)) + 1;
+        const double g1d = p.g1[d], gdivd = p.gdiv[d], tdivd = p.tdiv[d];
+        const int g = n_nodes;
+        bool bad = false;
+        for (int a = lane; a < A; a += 64) { // DeterministicNode.expand / update, deterministic.py:28-65
+            const Rec rc = p.rec[(long)pn.state * A + a];
+            const double r = rc.reward;
+            const bool avail = (rc.flags & 4u) != 0;      // deterministic.py:32-35 (phantom slots: see opd_kernel)
+            bad |= avail && (!(0.0 <= r) || !(r <= 1.0)); // deterministic.py:46-47
+            const bool dn = (rc.flags & done_bit) != 0;
+            double Lc = pn.L + g1d * r;
+            double Uc = Lc + gdivd;
+            if (dn) {
+                const double nv = Lc + tdivd;
+                Lc = nv; Uc = nv;
+            }
+            if (!avail) { Lc = ninf; Uc = ninf; }
+            OpdNode cn;
+            cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
+            NA[g + a] = cn;
+            RW[g + a] = r;
+            U[g + a] = Uc;
+            real_mine += avail ? 1 : 0;
+        }
+        if (lane == 0) { U[leaf] = ninf; EXP[k] = leaf; }
+        n_nodes += A;
+        k_done = k + 1;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads();
+    }
+    __syncthreads();
+    double root_upper = ninf;
+    for (int i = lane; i < n_nodes; i += 64) {
+        const double u = U[i];
+        if (u > root_upper) root_upper = u;
+    }
+    root_upper = wave_max(root_upper);
+    if (status == MP_OK) {
+        // lower bounds: L[parent of expansion k] = max over its children, children before parents (reverse expansion order)
+        for (int k = k_done - 1; k >= 0; --k) {
+            const int fc = 1 + k * A;
+            double m = ninf;
+            for (int a = lane; a < A; a += 64) {
+                const double l = NA[fc + a].L;
+                m = l > m ? l : m;
+            }
+            m = wave_max(m);
+            if (lane == 0) NA[EXP[k]].L = m;
+            __syncthreads();
+        }
+        // get_plan (abstract.py:143-156) with DeterministicNode.selection_rule (deterministic.py:21-26)
+        Pcg64 gen;
+        gen.load(p.rng + (long)root * 6);
+        int len = 0, node = 0;
+        for (;;) {
+            int kcur = -1; // the expansion that made `node`'s children, if any
+            for (int k0 = 0; k0 < k_done && kcur < 0; k0 += 64) {
+                const unsigned long long hit = __ballot(k0 + lane < k_done && EXP[k0 + lane] == node);
+                if (hit) kcur = k0 + __ffsll((long long)hit) - 1;
+            }
+            if (kcur < 0) break;
+            const int fc = 1 + kcur * A;
+            double m = ninf;
+            for (int a = lane; a < A; a += 64) {
+                const double l = NA[fc + a].L;
+                m = l > m ? l : m;
+            }
+            m = wave_max(m);
+            int nt = 0;
+            for (int a0 = 0; a0 < A; a0 += 64) nt += __popcll(__ballot(a0 + lane < A && NA[fc + a0 + lane].L == m));
+            int pick = (int)gen.below((uint32_t)nt), act = 0;
+            for (int a0 = 0; a0 < A; a0 += 64) {
+                unsigned long long t = __ballot(a0 + lane < A && NA[fc + a0 + lane].L == m);
+                const int c = __popcll(t);
+                if (pick < c) {
+                    while (pick-- > 0) t &= t - 1;
+                    act = a0 + __ffsll((long long)t) - 1;
+                    break;
+                }
+                pick -= c;
+            }
+            if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = act;
+            ++len;
+            node = fc + act;
+        }
+        if (lane == 0) {
+            gen.store(p.rng + (long)root * 6);
+            if (p.plans)
+                for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+            if (p.plan_len) p.plan_len[root] = len;
+            if (p.root_lower) p.root_lower[root] = NA[0].L;
+            if (p.root_upper) p.root_upper[root] = root_upper;
+        }
+    } else if (lane == 0) {
+        if (p.plans)
+            for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[root] = 0;
+    }
+    int n_real = real_mine;
+    for (int off = 32; off > 0; off >>= 1) n_real += __shfl_xor(n_real, off);
+    if (lane == 0) {
+        if (p.status) p.status[root] = status;
+        if (p.env_steps) p.env_steps[root] = (int64_t)n_real;
+        p.n_nodes_out[root] = n_nodes;
+    }
+    for (int k = k_done + lane; k < p.K; k += 64) EXP[k] = -1;
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -656,7 +798,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     if (model->mode != MP_MODE_DETERMINISTIC)
         return fail(MP_ERR_MODE, "mp_opd_plan: model mode %d is not a deterministic table", model->mode);
     const int A = model->A;
-    if (A > 64) return fail(MP_ERR_ARG, "mp_opd_plan: |A| = %d > 64 actions not supported", A);
+    const bool any_a = A > 64; // more actions than lanes: the plain kernel (opd_any_kernel)
     if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_opd_plan: bad sizes");
     const int K = budget / A; // deterministic.py:118
     if (K > 0 && !(gamma != 1.0))
@@ -706,7 +848,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(ws_get(ctx, WS_TREE1, nn, &a.U));
     MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.reward));
     a.leaf_global = nullptr;
-    if (glb) MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots * 64 * T, &a.leaf_global));
+    if (glb && !any_a) MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots * 64 * T, &a.leaf_global));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
     a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
     ctx->tree.kind = 2; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
@@ -728,9 +870,10 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     const bool nonneg = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(nn_env && nn_env[0] == '0');
     const void *kfn = expg ? (nonneg ? (const void *)opd_kernel<true, true> : (const void *)opd_kernel<true, false>)
                            : (nonneg ? (const void *)opd_kernel<false, true> : (const void *)opd_kernel<false, false>);
-    if (lds > 64 * 1024) MP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (!any_a && lds > 64 * 1024) MP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
-    if (glb && nonneg) hipLaunchKernelGGL(opd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (any_a) hipLaunchKernelGGL(opd_any_kernel, dim3((unsigned)n_roots), dim3(64), 0, st, a);
+    else if (glb && nonneg) hipLaunchKernelGGL(opd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (glb) hipLaunchKernelGGL(opd_wide_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (expg && nonneg) hipLaunchKernelGGL((opd_kernel<true, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (expg) hipLaunchKernelGGL((opd_kernel<true, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);

@@ -254,6 +254,17 @@ def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
 
 
+@pytest.mark.parametrize("n_actions,budget", [(65, 650), (100, 1999), (130, 1300), (257, 2000)])
+def test_opd_more_actions_than_lanes(ctx, n_actions, budget):
+    """Round 4: |A| > 64 (the reference has no bound) runs on the plain kernel -- children 64 at a time, leaf argmax as a scan;
+    rewards with many ties (one decimal), a terminal reward, negative terminal reward, plans / bounds / trees vs the oracle."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(120, n_actions, seed=90 + n_actions, terminal_rate=0.05)
+    cfg = dict(cfg, reward=np.round(cfg["reward"], 1))
+    _cmp_opd(ctx, cfg, 40, budget, 0.9, terminal_reward=0.25, seed=n_actions)
+    _cmp_opd(ctx, cfg, 5, budget, 0.7, terminal_reward=-0.5, seed=n_actions + 1, done_rule="next")
+
+
 @pytest.mark.parametrize("variant", ["lds", "ldsx"])
 @pytest.mark.parametrize("n_actions,budget", [(4, 100), (5, 2500), (13, 1300), (64, 640)])
 def test_opd_closing_passes_on_the_node_array(ctx, n_actions, budget, variant, monkeypatch):
