@@ -615,6 +615,154 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
 #undef LU
 }
 
+// ---- any number of actions (|A| > 64): the plain form (opd.hip's opd_any_kernel on the minima over the models) -- one root
+// per wavefront, everything in global memory, children 64 at a time, the leaf argmax a scan of min_m U.
+__global__ __launch_bounds__(64) void ropd_any_kernel(ROpdArgs p)
+{
+    const int lane = threadIdx.x, root = blockIdx.x, A = p.A, M = p.M;
+    const long base = (long)root * p.cap, SA = (long)p.S * A;
+    double *Lv = p.Lv + base * M, *Rv = p.Rv + base * M, *Lmin = p.Lmin + base, *Umin = p.Umin + base;
+    int32_t *Sv = p.Sv + base * M, *meta = p.meta + base * 2;
+    int32_t *EXP = p.expanded + (long)root * (p.K > 0 ? p.K : 1);
+    const uint32_t done_bit = p.done_on_next ? 2u : 1u;
+    const double ninf = -INFINITY;
+    if (lane == 0) {
+        for (int m = 0; m < M; ++m) { Lv[m] = 0.0; Sv[m] = p.root_state[(long)root * M + m]; Rv[m] = 0.0; }
+        Lmin[0] = 0.0; meta[0] = 0; meta[1] = 0;
+        Umin[0] = 0.0;
+    }
+    __syncthreads();
+    int n_nodes = 1, status = MP_OK, k_done = 0, real_steps = 0;
+    for (int k = 0; k < p.K; ++k) {
+        double bu = ninf; // robust.py:37: first maximal min_m U among the leaves (an expanded node's slot holds -inf)
+        int leaf = 0x7fffffff;
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = Umin[i];
+            if (u > bu) { bu = u; leaf = i; }
+        }
+        wave_argmax(bu, leaf);
+        if (leaf == 0x7fffffff) { status = MP_ERR_ARG; break; }
+        const int d = meta[2 * leaf] + 1;
+        const double g1d = p.g1[d], gdivd = p.gdiv[d], tdivd = p.tdiv[d];
+        const int g = n_nodes;
+        bool bad_any = false;
+        const double *Lp = Lv + (long)leaf * M;
+        const int32_t *Sp = Sv + (long)leaf * M;
+        for (int a0 = 0; a0 < A; a0 += 64) {
+            const int a = a0 + lane;
+            bool bad = false, avail = false;
+            if (a < A) {
+                const int c = g + a;
+                double lmin = 0.0, umin = 0.0;
+                uint32_t dbits = 0;
+                for (int m = 0; m < M; ++m) { // JointEnv.step: every model steps its own state (robust.py:13-16)
+                    const Rec rc = p.rec[(long)m * SA + (long)Sp[m] * A + a];
+                    const double r = rc.reward;
+                    avail |= (rc.flags & 4u) != 0;     // robust.py:22-25: the union of what the models list
+                    bad |= !(0.0 <= r) || !(r <= 1.0); // np.all(0 <= reward), np.all(reward <= 1)
+                    const bool dn = (rc.flags & done_bit) != 0;
+                    double Lc = Lp[m] + g1d * r;
+                    double Uc = Lc + gdivd;
+                    if (dn) {
+                        const double nv = Lc + tdivd;
+                        Lc = nv; Uc = nv;
+                    }
+                    Lv[(long)c * M + m] = Lc;
+                    Sv[(long)c * M + m] = rc.next;
+                    Rv[(long)c * M + m] = r;
+                    dbits |= (dn ? 1u : 0u) << m;
+                    if (m == 0 || Lc < lmin) lmin = Lc; // np.min
+                    if (m == 0 || Uc < umin) umin = Uc;
+                }
+                bad = bad && avail;
+                if (!avail) { lmin = ninf; umin = ninf; } // a phantom slot (see ropd_kernel)
+                Lmin[c] = lmin;
+                meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
+                Umin[c] = umin;
+            }
+            real_steps += __popcll(__ballot(avail));
+            bad_any |= __any(bad);
+        }
+        if (lane == 0) { Umin[leaf] = ninf; EXP[k] = leaf; }
+        n_nodes += A;
+        k_done = k + 1;
+        if (bad_any) { status = MP_ERR_REWARD_RANGE; break; }
+        __syncthreads();
+    }
+    __syncthreads();
+    if (status == MP_OK) {
+        double root_upper = ninf;
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = Umin[i];
+            if (u > root_upper) root_upper = u;
+        }
+        root_upper = wave_max(root_upper);
+        for (int k = k_done - 1; k >= 0; --k) { // the backups on the scalars min_m L, children before parents
+            const int fc = 1 + k * A;
+            double m = ninf;
+            for (int a = lane; a < A; a += 64) {
+                const double l = Lmin[fc + a];
+                m = l > m ? l : m;
+            }
+            m = wave_max(m);
+            if (lane == 0) Lmin[EXP[k]] = m;
+            __syncthreads();
+        }
+        Pcg64 gen;
+        gen.load(p.rng + (long)root * 6);
+        int len = 0, node = 0;
+        for (;;) { // get_plan with DeterministicNode.selection_rule over get_value_lower_bound = np.min
+            int kcur = -1;
+            for (int k0 = 0; k0 < k_done && kcur < 0; k0 += 64) {
+                const unsigned long long hit = __ballot(k0 + lane < k_done && EXP[k0 + lane] == node);
+                if (hit) kcur = k0 + __ffsll((long long)hit) - 1;
+            }
+            if (kcur < 0) break;
+            const int fc = 1 + kcur * A;
+            double m = ninf;
+            for (int a = lane; a < A; a += 64) {
+                const double l = Lmin[fc + a];
+                m = l > m ? l : m;
+            }
+            m = wave_max(m);
+            int nt = 0;
+            for (int a0 = 0; a0 < A; a0 += 64) nt += __popcll(__ballot(a0 + lane < A && Lmin[fc + a0 + lane] == m));
+            int pick = (int)gen.below((uint32_t)nt), act = 0;
+            for (int a0 = 0; a0 < A; a0 += 64) {
+                unsigned long long t = __ballot(a0 + lane < A && Lmin[fc + a0 + lane] == m);
+                const int c = __popcll(t);
+                if (pick < c) {
+                    while (pick-- > 0) t &= t - 1;
+                    act = a0 + __ffsll((long long)t) - 1;
+                    break;
+                }
+                pick -= c;
+            }
+            if (lane == 0 && p.plans && len < p.max_plan_len) p.plans[(long)root * p.max_plan_len + len] = act;
+            ++len;
+            node = fc + act;
+        }
+        if (lane == 0) {
+            gen.store(p.rng + (long)root * 6);
+            if (p.plans)
+                for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+            if (p.plan_len) p.plan_len[root] = len;
+            if (p.root_lower) p.root_lower[root] = Lmin[0];
+            if (p.root_upper) p.root_upper[root] = root_upper;
+        }
+    } else if (lane == 0) {
+        if (p.plans)
+            for (int i = 0; i < p.max_plan_len; ++i) p.plans[(long)root * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[root] = 0;
+    }
+    if (lane == 0) {
+        if (p.status) p.status[root] = status;
+        if (p.env_steps) p.env_steps[root] = (int64_t)real_steps;
+        p.n_nodes_out[root] = n_nodes;
+    }
+    for (int k = k_done + lane; k < p.K; k += 64) EXP[k] = -1;
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -632,7 +780,7 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     if (model->mode != MP_MODE_DETERMINISTIC || !model->rec_all)
         return fail(MP_ERR_MODE, "mp_ropd_plan: needs a joint model (mp_model_load_joint)");
     const int A = model->A, M = model->M;
-    if (A > 64) return fail(MP_ERR_ARG, "mp_ropd_plan: |A| = %d > 64 actions not supported", A);
+    const bool any_a = A > 64; // more actions than lanes: the plain kernel (ropd_any_kernel)
     if (M > kMaxModels) return fail(MP_ERR_ARG, "mp_ropd_plan: %d models > %d not supported", M, kMaxModels);
     if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_ropd_plan: bad sizes");
     const int K = budget / A; // deterministic.py:118
@@ -682,7 +830,7 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(ws_get(ctx, WS_TREE4, nn * M, &a.Rv));
     MP_TRY(ws_get(ctx, WS_TREE5, nn * 2, &a.meta));
     a.leaf_global = nullptr;
-    if (glb) MP_TRY(ws_get(ctx, WS_TREE6, (size_t)n_roots * 64 * T, &a.leaf_global));
+    if (glb && !any_a) MP_TRY(ws_get(ctx, WS_TREE6, (size_t)n_roots * 64 * T, &a.leaf_global));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
     a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
     ctx->tree.kind = 3; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
@@ -706,11 +854,12 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     typedef void (*kernel_t)(ROpdArgs);
     const kernel_t kfn = expg ? (mb == 2 ? ropd_kernel<true, 2> : mb == 4 ? ropd_kernel<true, 4> : ropd_kernel<true, 0>)
                               : (mb == 2 ? ropd_kernel<false, 2> : mb == 4 ? ropd_kernel<false, 4> : ropd_kernel<false, 0>);
-    if (lds > 64 * 1024)
+    if (!any_a && lds > 64 * 1024)
         MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
     const bool nonneg = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(mode_env && mode_env[0] == '0');
-    if (glb && nonneg) hipLaunchKernelGGL(ropd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    if (any_a) hipLaunchKernelGGL(ropd_any_kernel, dim3((unsigned)n_roots), dim3(64), 0, st, a);
+    else if (glb && nonneg) hipLaunchKernelGGL(ropd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (glb) hipLaunchKernelGGL(ropd_wide_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else hipLaunchKernelGGL(kfn, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));

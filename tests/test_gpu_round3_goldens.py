@@ -128,7 +128,7 @@ def test_robust_planner_agent_on_restricted_models(z):
 
 @pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
 @pytest.mark.parametrize("n_models,n_actions,budget", [(1, 3, 150), (2, 5, 500), (3, 4, 300), (5, 7, 280), (16, 2, 100), (24, 3, 150),
-                                                        (32, 2, 100)])
+                                                        (32, 2, 100), (2, 65, 700), (3, 130, 1400)])   # (|A| > 64: the plain kernel)
 def test_robust_planner_restricted_actions_batch_vs_oracle(ctx, n_models, n_actions, budget, variant, monkeypatch):
     from oracle import oracle
     from rl_agents_amd.envs import generators
