@@ -137,6 +137,7 @@ struct SaArgs {
     int lds_rows, lds_qcap; // LDS-resident wave kernel: node rows held in LDS (>= rows after this plan), queue ints in LDS
     int tab_lds;            // wave kernel with the dictionaries in LDS: depth-table entries held in LDS
     int tab_plain;          // the other wave kernels: depth-table entries held in LDS (all K + 3 unless the budget is huge)
+    int csr_old;            // wave kernel, dictionaries in LDS: the earlier plans' rows bucketed by state: 0 never, 1 from the fourth plan, 2 always
     const int32_t *order;   // wave kernel: workgroup b plans planner order[b] (longest expected plan first), or nullptr
     int32_t *cost;          // wave kernel: Bellman backups this plan ran, per planner (the next plan's dispatch order)
     double gamma, vmax;
@@ -625,7 +626,51 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     // and nothing of its dead rows -- the scan's cost would otherwise grow with every plan of an episode.
     int2 *old_b = p.oldlive + nb;
     int n_old = 0;
-    if (p.prune) {
+    // LDSD, later plans (no chunked lists in use): the same rows BUCKETED BY STATE -- a counting sort through LDS counters
+    // (lane-ordered atomics keep the ids ascending inside a state), {count, offset} per state in the idle list records -- so that
+    // an iteration touches the old rows of its few changed states only, not all of them: the prune pass of the sixteenth
+    // plan of an episode costs what the second one's does.
+    auto wave_incl_scan = [&](int v) {
+        for (int d = 1; d < 64; d <<= 1) {
+            const int o = __shfl_up(v, d);
+            if (lane >= d) v += o;
+        }
+        return v;
+    };
+    // (building the buckets costs two passes over the old rows: it pays from the fourth plan of an episode on -- measured 5.7 against
+    // 5.25 ms for a second plan, 4.8 against 5.2 ms for an eighth; MP_SAOPD_CSR=1 buckets from the second plan on, =0 never)
+    const bool csr = LDSD && p.prune && !(p.par_backup != 0 && A <= 32) && p.S <= 128 && root > 0 &&
+                     (p.csr_old == 2 || (p.csr_old == 1 && root >= 3 * (1 + p.K * A)));
+    if (csr) {
+        for (int s = lane; s < p.S; s += 64) d_mark[s] = 0u;
+        __syncthreads();
+        for (int i0 = 0; i0 < root; i0 += 64) {
+            const int i = i0 + lane;
+            // (the state is range-checked: a planner whose earlier plan broke off -- every leaf pruned -- has rows nobody wrote)
+            bool live = i < root && (ND(i).meta & SA_CHILDREN) != 0;
+            const int st = live ? ST(i) : 0;
+            live = live && (unsigned)st < (unsigned)p.S;
+            if (live && i >= HD(st)) atomicAdd(&d_mark[st], 1u); // (rows in front of the list head were dropped by a root restart)
+        }
+        __syncthreads();
+        const int c0 = lane < p.S ? (int)d_mark[lane] : 0, c1 = lane + 64 < p.S ? (int)d_mark[lane + 64] : 0;
+        const int i0s = wave_incl_scan(c0);
+        const int tot0 = __builtin_amdgcn_readlane(i0s, 63);
+        const int i1s = wave_incl_scan(c1) + tot0;
+        if (lane < p.S) { d_ls[lane] = make_int4(c0, i0s - c0, 0, 0); d_mark[lane] = 0u; }
+        if (lane + 64 < p.S) { d_ls[lane + 64] = make_int4(c1, i1s - c1, 0, 0); d_mark[lane + 64] = 0u; }
+        __syncthreads();
+        for (int i0 = 0; i0 < root; i0 += 64) {
+            const int i = i0 + lane;
+            bool live = i < root && (ND(i).meta & SA_CHILDREN) != 0;
+            const int st = live ? ST(i) : 0;
+            live = live && (unsigned)st < (unsigned)p.S;
+            if (live && i >= HD(st)) old_b[d_ls[st].y + (int)atomicAdd(&d_mark[st], 1u)] = make_int2(i, st);
+        }
+        __syncthreads();
+        for (int s = lane; s < p.S; s += 64) d_mark[s] = 0xffffffffu;
+        __syncthreads();
+    } else if (p.prune) {
         const unsigned long long lt0 = (1ULL << lane) - 1ULL;
         for (int i0 = 0; i0 < root; i0 += 64) {
             const int i = i0 + lane;
@@ -1164,6 +1209,23 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             const int pcap = (qcap - 64 * NS) >> 1; // pairs that fit in front of the per-state selection area
             int n_d = 0;
             const unsigned long long lt = (1ULL << lane) - 1ULL;
+            if (csr) { // the old rows of the CHANGED states: straight from their buckets into the pairs, state by state
+                const int4 b0 = lane < p.S ? d_ls[lane] : make_int4(0, 0, 0, 0), b1 = lane + 64 < p.S ? d_ls[lane + 64] : make_int4(0, 0, 0, 0);
+                const bool h0 = lane < p.S && b0.x > 0 && SM(lane) == cur, h1 = lane + 64 < p.S && b1.x > 0 && SM(lane + 64) == cur;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    unsigned long long todo = __ballot(half ? h1 : h0);
+                    while (todo) {
+                        const int l = __ffsll((long long)todo) - 1;
+                        todo &= todo - 1;
+                        const int cnt = __builtin_amdgcn_readlane(half ? b1.x : b0.x, l), off = __builtin_amdgcn_readlane(half ? b1.y : b0.y, l);
+                        const int st = l + 64 * half;
+                        for (int k = lane; k < cnt; k += 64)
+                            if (n_d + k < pcap) { recs[2 * (n_d + k)] = old_b[off + k].x; recs[2 * (n_d + k) + 1] = st; }
+                        n_d += cnt;
+                    }
+                }
+            }
             // scan positions: the listed old rows, then the rows of this plan (root .. n_nodes - 1)
             const int n_pos = n_old + (n_nodes - root);
             // The register sets: rst[q] = the row's state (-1: none), ids[q] = its row, rows in ascending id over (set, lane).
@@ -1413,6 +1475,18 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     if (r == 0 && l0) printf("saopd prof planner0: backup passes %ld, re-evaluated groups %ld, updates %ld\n", pf_pass, pf_reval, updates);
     if (r == 0 && l0) printf("saopd prof planner0: rows of dirty states %ld over %d iterations (max %d), serial fallbacks %d\n", pf_nd, p.K, pf_ndmax, pf_fallback);
 #endif
+    if (status != MP_OK) {
+        // A plan that broke off (every leaf pruned, a reward out of range, a full queue) leaves the rest of its row range
+        // unwritten, and the host counts the whole range as used: later plans of the batch scan it.  Make those rows what a
+        // phantom is -- no children, not alive, dead for the prune scan, state 0.
+        for (int i = n_nodes + lane; i < root + 1 + p.K * A; i += 64) {
+            SaNode nd;
+            nd.lower = ninf; nd.next_same = -1; nd.meta = 0;
+            ND(i) = nd;
+            ST(i) = 0; PA(i) = -1; FC(i) = -1; RW(i) = 0.0;
+            p.done[nb + i] = 2;
+        }
+    }
     // ---- get_plan, twice (see saopd_kernel), uniform
     int len = 0;
     if (status == MP_OK) {
@@ -1450,8 +1524,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
     }
     if (LDSR) { // write back: every node record (flags and list links of older rows change too), this plan's rows, the dictionaries
         __syncthreads();
-        for (int i = lane; i < n_nodes; i += 64) p.node[nb + i] = l_node[i];
-        for (int i = root + lane; i < n_nodes; i += 64) {
+        const int n_wb = status == MP_OK ? n_nodes : root + 1 + p.K * A; // (a broken-off plan: with the rows made harmless above)
+        for (int i = lane; i < n_wb; i += 64) p.node[nb + i] = l_node[i];
+        for (int i = root + lane; i < n_wb; i += 64) {
             p.state[nb + i] = l_state[i]; p.parent[nb + i] = l_parent[i]; p.first_child[nb + i] = l_fc[i];
             p.reward[nb + i] = l_reward[i];
         }
@@ -1720,6 +1795,8 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     // costs more than it saves (16 384 planners: 7.8 / 9.0 ms against 6.9 / 7.9).  MP_SAOPD_PAR_BACKUP=0|1 forces it.
     a.par_backup = fresh ? 1 : 0;
     if (const char *e = getenv("MP_SAOPD_PAR_BACKUP")) a.par_backup = e[0] == '1';
+    a.csr_old = 1;
+    if (const char *e = getenv("MP_SAOPD_CSR")) a.csr_old = e[0] == '0' ? 0 : 2;
     a.prune_rows = 256;
     if (const char *e = getenv("MP_SAOPD_PRUNE_ROWS")) { // test knob: 0 = every changed state through the streamed form
         const int v = atoi(e);

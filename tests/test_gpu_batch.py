@@ -581,7 +581,7 @@ def test_lds_atomics_apply_in_lane_order(ctx):
 
 
 @pytest.mark.parametrize("mapping", ["wave", "wave-serial-prune", "wave-par-backup", "wave-seq-backup", "wave-global", "wave-ordered",
-                                     "lane"])
+                                     "wave-flat", "wave-buckets", "lane"])
 @pytest.mark.parametrize("shape", ["grid", "garnet", "highway"])
 def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     """200 planners per launch, three consecutive plans each (planner state kept on the device), vs the oracle run
@@ -600,6 +600,10 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
         monkeypatch.setenv("MP_SAOPD_DICT", "0")
     if mapping == "wave-ordered":           # round 4: dispatch by expected cost also for this small batch (default: > 32 per CU)
         monkeypatch.setenv("MP_SAOPD_ORDER", "1")
+    if mapping == "wave-flat":              # round 4: the earlier plans' rows as one flat list in every plan ...
+        monkeypatch.setenv("MP_SAOPD_CSR", "0")
+    if mapping == "wave-buckets":           # ... and bucketed by state from the second plan on (default: from the fourth)
+        monkeypatch.setenv("MP_SAOPD_CSR", "1")
     cfg, budget, gamma = {"grid": (generators.gridworld(), 120, 0.8),
                           "garnet": (generators.random_deterministic(40, 3, seed=5, terminal_rate=0.1), 90, 0.7),
                           "highway": (generators.highway_shaped(3, 4, 10, seed=3), 150, 0.9)}[shape]

@@ -376,6 +376,9 @@ def one_case(ctx, g, case):
             os.environ["MP_SAOPD_DICT"] = "0"
         if g.random() < 0.5:
             os.environ["MP_SAOPD_ORDER"] = "1"
+        os.environ.pop("MP_SAOPD_CSR", None)
+        if g.random() < 0.6:
+            os.environ["MP_SAOPD_CSR"] = str(int(g.integers(0, 2)))   # never / from the second plan on (default: from the fourth)
         desc.update(dict_lds=os.environ.get("MP_SAOPD_DICT", "auto"), order=os.environ.get("MP_SAOPD_ORDER", "auto"))
         if kind == "saopd_masked":  # deterministic.py:32-35 under the state-aware planner: phantom rows (round 3)
             avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
