@@ -440,9 +440,11 @@ int orc_opd_plan(int S, int A, const int64_t *T, const double *R, const uint8_t 
             const int fc = first_child[n], kc = n_children[n];
             double m = lower[fc];
             for (int j = 1; j < kc; ++j) if (lower[fc + j] > m) m = lower[fc + j];
-            int ties[64], nt = 0;
-            for (int j = 0; j < kc && nt < 64; ++j) if (lower[fc + j] == m) ties[nt++] = j;
-            const int j = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            /* Node.random_argmax (abstract.py:304-311): choice over ALL maximal children (any number of them: |A| > 64) */
+            int nt = 0, j = 0;
+            for (int q = 0; q < kc; ++q) nt += lower[fc + q] == m;
+            int pick = (int)orc_pcg64_below(&g, (uint32_t)nt);
+            for (int q = 0; q < kc; ++q) if (lower[fc + q] == m && pick-- == 0) { j = q; break; }
             if (plan && len < max_plan_len) plan[len] = action[fc + j];
             ++len;
             n = fc + j;
@@ -583,9 +585,10 @@ int orc_ropd_plan(int M, int S, int A, const int64_t *T, const double *R, const 
             const int fc = first_child[n];
             double m = VMIN(lower, fc);
             for (int a = 1; a < n_children[n]; ++a) { const double l = VMIN(lower, fc + a); if (l > m) m = l; }
-            int ties[64], nt = 0;
-            for (int a = 0; a < n_children[n] && nt < 64; ++a) if (VMIN(lower, fc + a) == m) ties[nt++] = a;
-            const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+            int nt = 0, a = 0; /* choice over all maximal children, however many */
+            for (int q = 0; q < n_children[n]; ++q) nt += VMIN(lower, fc + q) == m;
+            int pick = (int)orc_pcg64_below(&g, (uint32_t)nt);
+            for (int q = 0; q < n_children[n]; ++q) if (VMIN(lower, fc + q) == m && pick-- == 0) { a = q; break; }
             if (plan && len < max_plan_len) plan[len] = action[fc + a];
             ++len;
             n = fc + a;
@@ -1257,9 +1260,10 @@ int orc_saopd_plan(int S, int A, const int64_t *T, const double *R, const uint8_
                 const int fc = first_child[n];
                 double m = lower[fc];
                 for (int a = 1; a < n_children[n]; ++a) if (lower[fc + a] > m) m = lower[fc + a];
-                int ties[64], nt = 0;
-                for (int a = 0; a < n_children[n] && nt < 64; ++a) if (lower[fc + a] == m) ties[nt++] = a;
-                const int a = ties[orc_pcg64_below(&g, (uint32_t)nt)];
+                int nt = 0, a = 0; /* choice over all maximal children, however many */
+                for (int q = 0; q < n_children[n]; ++q) nt += lower[fc + q] == m;
+                int pick = (int)orc_pcg64_below(&g, (uint32_t)nt);
+                for (int q = 0; q < n_children[n]; ++q) if (lower[fc + q] == m && pick-- == 0) { a = q; break; }
                 if (plan && len < max_plan_len) plan[len] = action[fc + a];
                 ++len;
                 n = fc + a;

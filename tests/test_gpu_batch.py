@@ -263,6 +263,11 @@ def test_opd_more_actions_than_lanes(ctx, n_actions, budget):
     cfg = dict(cfg, reward=np.round(cfg["reward"], 1))
     _cmp_opd(ctx, cfg, 40, budget, 0.9, terminal_reward=0.25, seed=n_actions)
     _cmp_opd(ctx, cfg, 5, budget, 0.7, terminal_reward=-0.5, seed=n_actions + 1, done_rule="next")
+    # more than 64 children tie for the plan's choice (constant rewards; gamma = 0 makes whole levels tie): the fuzz sweep found
+    # the ORACLE capping its tie list at 64 entries there -- random_argmax draws among all of them (abstract.py:304-311)
+    flat = dict(cfg, reward=np.full_like(cfg["reward"], 0.5))
+    _cmp_opd(ctx, flat, 6, budget, 0.9, seed=n_actions + 2)
+    _cmp_opd(ctx, cfg, 6, budget, 0.0, seed=n_actions + 3)
 
 
 @pytest.mark.parametrize("variant", ["lds", "ldsx"])

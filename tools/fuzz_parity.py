@@ -19,7 +19,7 @@ from rl_agents_amd import native  # noqa: E402
 
 def random_mdp(g):
     s = int(g.choice([1, 2, 3, 7, 40, 257, 1500]))
-    a = int(g.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 13]))
+    a = int(g.choice([1, 2, 3, 4, 5, 6, 7, 8, 9, 13, 70]))   # (70: more actions than lanes -- the plain OPD kernels, round 4)
     t = g.integers(0, s, size=(s, a), dtype=np.int64)
     kind = g.integers(0, 4)
     if kind == 0:
