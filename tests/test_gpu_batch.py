@@ -655,7 +655,7 @@ def test_state_aware_batch_vs_oracle(ctx, shape, mapping, monkeypatch):
     model.close()
 
 
-@pytest.mark.parametrize("n_actions", [9, 16, 33, 40])
+@pytest.mark.parametrize("n_actions", [9, 16, 33, 40, 70])   # (70: more actions than lanes -- the one-planner-per-lane kernel)
 def test_state_aware_many_actions_vs_oracle(ctx, n_actions):
     """|A| from 9 to 40: the grouped parallel backup runs 7, 4 and (|A| > 32) no groups per pass -- the last is the
     element-by-element loop."""
