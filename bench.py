@@ -1029,7 +1029,8 @@ def bench_ropd(args, rank, world, local):
 def bench_saopd(args, rank, world, local):
     """State-aware OPD (tree_search/state_aware.py) at the reference's own GridWorld configuration
     (scripts/configs/GridWorld/agents/state-aware.json: budget 500, gamma 0.8; 10x10 grid).  A step = the first plan()
-    of a fresh batch of planners (the costly one: ~4 200 Bellman backups per planner), planner creation included."""
+    of a fresh batch of planners (the costly one: ~4 200 Bellman backups per planner on average, 1 700 .. 13 000 by root state),
+    planner creation included."""
     import torch
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
@@ -1076,6 +1077,9 @@ def bench_saopd(args, rank, world, local):
                     n_roots_per_gpu=n_roots, n_roots_total=n_roots * world, budget=budget, gamma=gamma,
                     plan_ms_per_root=1e3 * dt / args.steps / n_roots,
                     bellman_backups_per_planner=float(out["updates"].mean()),
+                    dispatch="planners start longest first: the cost of a fresh planner's first plan by root state is learned with "
+                             "the model from the warm-up batch on (saopd_order_kernel, inside the timed launch batch; "
+                             "MP_SAOPD_ORDER=0 keeps the index order: +1.6 ms at 16 384 planners).  Results do not depend on it",
                     parallelism="planners sharded over {} GPU(s)".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel="saopd_wave_kernel", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),

@@ -626,12 +626,14 @@ int mp_selftest_lds_atomic_order(mp_ctx *ctx, int32_t waves, int64_t *violations
     MP_HIP(hipSetDevice(ctx->device));
     unsigned long long *d = nullptr;
     MP_HIP(hipMalloc(&d, 8));
-    MP_HIP(hipMemsetAsync(d, 0, 8, ctx->stream));
-    hipLaunchKernelGGL(mp::selftest_lds_order_kernel, dim3((unsigned)(waves < 4096 ? waves : 4096)), dim3(64), 0, ctx->stream, waves, d);
     unsigned long long h = 0;
-    const hipError_t e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+    hipError_t e = hipMemsetAsync(d, 0, 8, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mp::selftest_lds_order_kernel, dim3((unsigned)(waves < 4096 ? waves : 4096)), dim3(64), 0, ctx->stream, waves, d);
+        e = hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
     const hipError_t e2 = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
+    (void)hipFree(d); // (freed on every path)
     MP_HIP(e);
     MP_HIP(e2);
     *violations = (int64_t)h;
