@@ -123,6 +123,35 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
         self.env_steps += int(out["env_steps"].sum())
         return out
 
+    # -- device-resident evaluation loop (BatchedEvaluation): the planner plans on the JOINT model, the loop steps the TRUE env
+    plans_on_joint_env = True
+
+    def supports_device_loop(self):
+        return type(self).plan_batch is DiscreteRobustPlanner.plan_batch
+
+    def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None):
+        """One asynchronous batched plan (mp_ropd_plan, MP_MEM_DEVICE): every model starts in the episode's state (the agent
+        rebuilds its JointEnv from the true env before every plan, robust.py:67-70).  ``model`` (the true env's, which the loop
+        steps) is not used; ``state`` is the JointEnv."""
+        import torch
+        cfg = self.config
+        jm, _ = self.joint_model(state)
+        budget = int(cfg["budget"])
+        if cfg["gamma"] == 1 and budget >= jm.A:
+            raise ZeroDivisionError("float division by zero")
+        ctx = self.models.ctx
+        if getattr(self, "_d_joint", None) is None or self._d_joint.shape != (n, jm.M) or self._d_joint.device != d_state.device:
+            self._d_joint = torch.empty((n, jm.M), dtype=torch.int32, device=d_state.device)
+        with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_ptr(), device=d_state.device)):
+            self._d_joint.copy_(d_state[:, None].expand(n, jm.M))          # (on the planner's stream, after the env step)
+        self.about_to_plan()
+        ctx.ropd_plan_device(jm, n, self._d_joint, budget, cfg["gamma"], cfg.get("terminal_reward", 0), d_rng,
+                             int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, root_lower=d_value, env_steps=d_env_steps,
+                             status=d_status)
+        self._last_actions, self._last_models = jm.A, jm.M
+        self.claim_device_tree()
+        self.last, self._root = None, None
+
     def export_tree(self, root=0):
         self.require_device_tree()
         a, m = self._last_actions, self._last_models

@@ -136,7 +136,9 @@ class BatchedEvaluation(object):
             ctx = models.ctx
         else:
             planner = agent.planner
-            model = planner.model_for(env)
+            # (a planner of the discrete robust agent plans on its JointEnv of candidate models; what the loop steps is the true env)
+            joint = getattr(planner, "plans_on_joint_env", False)
+            model = planner.model_for(preprocess_env(self.env, agent.config["env_preprocessors"]) if joint else env)
             ctx = planner.models.ctx
         dev = torch.device("cuda", ctx.device)
         order = getattr(model, "action_order", None)
@@ -237,6 +239,8 @@ class BatchedEvaluation(object):
         rng = native.seed_sequence_states((), self.sim_seed + first, n)    # np_random(sim_seed + i), evaluation.py:375
         actions_log = np.full((n, self.max_steps), -1, dtype=np.int32)
         env = preprocess_env(self.env, self.agent.config["env_preprocessors"])
+        if getattr(planner, "plans_on_joint_env", False):      # the discrete robust agent: plans on its candidate models
+            env = self.agent.planning_env()
         self._gens = self._env_generators(first, n) if self.stochastic else None
         subtree = planner.config.get("step_strategy") == "subtree" and hasattr(planner, "step_by_subtree")
         stateful = subtree or getattr(planner, "carries_state", False)

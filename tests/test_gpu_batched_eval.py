@@ -212,3 +212,50 @@ def test_batched_evaluation_on_stochastic_models(kind, agent_kind):
         assert runs[1]["lengths"][i] == len(actions), (i, actions, runs[1]["actions"][i])
         np.testing.assert_array_equal(runs[1]["actions"][i, :len(actions)], actions)
         assert runs[1]["returns"][i] == pytest.approx(total, abs=1e-12)
+
+
+def test_discrete_robust_planner_in_the_batched_loop():
+    """Round 4: the discrete robust planner agent (robust.py:52-71) in BatchedEvaluation -- it plans on the joint model of
+    its candidate models, every model starting in the episode's state, while the loop steps the TRUE environment.  Host loop
+    == device-resident loop == N sequential agent / env loops."""
+    from rl_agents_amd.agents.common.factory import agent_factory
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.batched_evaluation import BatchedEvaluation
+    DRP = "<class 'rl_agents_amd.agents.robust.robust.DiscreteRobustPlannerAgent'>"
+    base = generators.highway_shaped(3, 4, 10, seed=3)
+    other = generators.rewire(base, 0.2, seed=9)
+
+    def table(c, scale=1.0):
+        return dict(mode="deterministic", transition=np.asarray(c["transition"]).tolist(),
+                    reward=(np.asarray(c["reward"]) * scale).tolist(), terminal=np.asarray(c["terminal"]).astype(int).tolist())
+    models = [[{"method": "copy_with_config", "args": table(base)}], [{"method": "copy_with_config", "args": table(other, 0.9)}]]
+    acfg = dict(__class__=DRP, budget=100, gamma=0.85, models=models)
+
+    def make_env(state=2):
+        env = FiniteMDPEnv(dict(base, state=state, max_steps=8))
+        env.reset()
+        return env
+    n = 70
+    starts = (np.arange(n) * 7 % 100).astype(np.int32)
+    runs = []
+    for resident in (False, True):
+        env = make_env()
+        ev = BatchedEvaluation(env, agent_factory(env, dict(acfg)), num_episodes=n, sim_seed=40, max_steps=8,
+                               device_resident=resident, check_every=3)
+        runs.append(ev.run(initial_states=starts))
+        assert runs[-1]["device_resident"] is resident
+    _compare(runs[0], runs[1])
+    for i in (0, 13, 69):
+        e = make_env(int(starts[i]))
+        agent = agent_factory(e, dict(acfg))
+        agent.seed(40 + i)
+        actions, total, done = [], 0.0, False
+        while not done:
+            a = agent.act(e.mdp.state)
+            _, r, term, trunc, _ = e.step(a)
+            actions.append(a)
+            total += r
+            done = term or trunc
+        assert runs[1]["lengths"][i] == len(actions)
+        np.testing.assert_array_equal(runs[1]["actions"][i, :len(actions)], actions)
+        assert runs[1]["returns"][i] == pytest.approx(total, abs=1e-12)
