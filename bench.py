@@ -34,6 +34,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+DENSE_SHARD_MODE = "mfma"       # --workload rvi_dense_shard without --dense-mode
 MFMA_F64_PEAK_TFLOPS = 78.6    # MI355X FP64 matrix peak (vendor figure; the guide lists no f64 row)
 # algorithmic HBM bytes per unit of work, SURVEY.md §8(d) / DESIGN.md §Kernels
 
@@ -155,9 +156,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "vi_dense_exact", "rvi_dense_shard"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
+    ap.add_argument("--dense-mode", default=None, choices=["mfma", "exact"],
+                    help="dense VI workloads: contraction on the f64 matrix cores or in numpy's order of additions (bit-exact)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--headline-only", action="store_true", help="skip the bounded slices of the other workloads")
@@ -1120,11 +1123,14 @@ def bench_saopd(args, rank, world, local):
     return res
 
 
-def bench_vi(args, rank, world, local, dense, robust=False):
+def bench_vi(args, rank, world, local, dense, robust=False, exact=False):
     import torch
     from rl_agents_amd import native
     from rl_agents_amd.envs import generators
     ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    if dense:   # the contraction on the f64 matrix cores (tolerance parity) or in numpy's order of additions (bit-exact)
+        exact = exact or args.dense_mode == "exact"
+        ctx.vi_dense_mode("exact" if exact else "mfma")
     gamma, sweeps = 0.95, 200
     dev = torch.device("cuda", local)
     n_models = 1
@@ -1152,7 +1158,7 @@ def bench_vi(args, rank, world, local, dense, robust=False):
         sweeps = 20
         alg = 8.0 * s_ * s_ * a_
         flops = 2.0 * s_ * s_ * a_
-        name = "vi_dense_q"
+        name = "vi_dense_exact_q" if exact else "vi_dense_q"
     else:
         cfg = generators.highway_shaped(10, 10, 100, seed=0)
         t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
@@ -1182,17 +1188,17 @@ def bench_vi(args, rank, world, local, dense, robust=False):
         metric="value-iteration Bellman sweeps/sec", unit="sweeps/s", value=world * sweeps * args.steps / dt,
         ms_per_step=1e3 * dt / args.steps, dtype="f64",
         config=dict(workload="{}_S{}_A{}_{}sweeps".format("robust_vi_intersection_shaped_M2" if robust else
-                                                       ("vi_dense" if dense else "vi_highway_shaped"), s_, a_, sweeps),
+                                                       (("vi_dense_numpy_order" if exact else "vi_dense") if dense else "vi_highway_shaped"), s_, a_, sweeps),
                     states=s_, actions=a_, gamma=gamma, ms_per_sweep=1e3 * dt / args.steps / sweeps,
                     parallelism="replicas only ({} GPU(s))".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (per_sweep_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel=name, kernel_ms=per_sweep_ms, algorithmic_bytes_per_launch=alg),
     )
     if dense:
-        add_traffic(res["roofline"], "vi_dense", "vi_dense_q", None, pattern="stream")
+        add_traffic(res["roofline"], "vi_dense_exact" if exact else "vi_dense", name, None, pattern="stream")
     else:
         res["roofline"].update(traffic=None, traffic_frac=None, frac=res["roofline"]["achieved"] / HBM_PEAK_GBS)
-    if dense:
+    if dense and not exact:
         res["roofline"]["mfma_tflops"] = flops / (per_sweep_ms * 1e-3) / 1e12
         res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
     if not args.no_parity_sample and rank == 0:
@@ -1205,16 +1211,21 @@ def bench_vi(args, rank, world, local, dense, robust=False):
             rows_t, rows_r = tt[ti].cpu().numpy(), rr[ti].cpu().numpy()
             v = torch.zeros(s_, dtype=torch.float64, device=dev)
             q = torch.empty((s_, a_), dtype=torch.float64, device=dev)
-            worst = 0.0
+            worst, equal = 0.0, True
             for _ in range(3):
                 ctx.vi_backup(model, gamma, v, q_out=q)
                 ref = oracle.dense_backup_rows(rows_t, rows_r, None, v.cpu().numpy(), gamma)
                 got = q[ti].cpu().numpy()
                 worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))))
+                equal = equal and bool(np.array_equal(got, ref))
                 v = q.max(dim=-1).values
-            res["parity_sample"] = parity_record(worst <= 1e-12, "3 sweeps, {} sampled source rows per sweep vs "
-                                                 "oracle.dense_backup_rows (numpy's pairwise order); tolerance 1e-12 relative "
-                                                 "(matrix-core accumulation order)".format(len(idx)), max_rel_err=worst)
+            if exact:
+                res["parity_sample"] = parity_record(equal, "3 sweeps, {} sampled source rows per sweep vs oracle.dense_backup_rows "
+                                                     "(numpy's add.reduce order): bit for bit".format(len(idx)), max_rel_err=worst)
+            else:
+                res["parity_sample"] = parity_record(worst <= 1e-12, "3 sweeps, {} sampled source rows per sweep vs "
+                                                     "oracle.dense_backup_rows (numpy's pairwise order); tolerance 1e-12 relative "
+                                                     "(matrix-core accumulation order)".format(len(idx)), max_rel_err=worst)
         else:
             q, sw = ctx.vi_solve(model, gamma, 3, robust=robust)
             q_ref, sw_ref = oracle.vi_solve("deterministic", t, r, term, gamma=gamma, iterations=3, robust=robust)
@@ -1268,6 +1279,9 @@ def bench_rvi_dense_shard(args, rank, world, local):
     gamma = 0.95
     dev = torch.device("cuda", local)
     ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    exact = (args.dense_mode or DENSE_SHARD_MODE) == "exact"
+    ctx.vi_dense_mode("exact" if exact else "mfma")
+    kname = "vi_dense_exact_q (robust, row block)" if exact else "vi_dense_q (robust, row block)"
     g = torch.Generator(device=dev)
     g.manual_seed(1000 + rank)
     tt = torch.empty((m_, rows, a_, s_), dtype=torch.float64, device=dev)
@@ -1346,11 +1360,15 @@ def bench_rvi_dense_shard(args, rank, world, local):
                         ms_per_sweep=ms_sweep, sweeps_per_s=args.steps / dt,
                         full_model_bytes_per_sweep=8.0 * alg, aggregate_tb_per_s=8.0 * alg / (ms_sweep * 1e-3) / 1e12),
                     parallelism="rows sharded over {} GPU(s) ({} of 8 C5 ranks), all_gather of V + 4-byte all_reduce per sweep".format(world, world)),
-        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel="vi_dense_q (robust, row block)",
-                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg, mfma_tflops=flops / (k_ms * 1e-3) / 1e12),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel=kname,
+                      kernel_ms=k_ms, algorithmic_bytes_per_launch=alg),
     )
-    res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
-    add_traffic(res["roofline"], "rvi_dense_shard", "vi_dense_q", None, pattern="stream")
+    if not exact:
+        res["roofline"]["mfma_tflops"] = flops / (k_ms * 1e-3) / 1e12
+        res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS
+    res["config"]["dense_mode"] = "exact" if exact else "mfma"
+    add_traffic(res["roofline"], "rvi_dense_shard_exact" if exact else "rvi_dense_shard", "vi_dense_exact_q" if exact else "vi_dense_q", None,
+                pattern="stream")
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         idx = sample_rows(rows)
@@ -1358,15 +1376,17 @@ def bench_rvi_dense_shard(args, rank, world, local):
         rows_t, rows_r = tt[:, ti].cpu().numpy(), rr[:, ti].cpu().numpy()
         vv = torch.zeros(s_, dtype=torch.float64, device=dev)
         qq = torch.empty((rows, a_), dtype=torch.float64, device=dev)
-        worst = 0.0
+        worst, equal = 0.0, True
         for _ in range(3):
             ctx.vi_backup(model, gamma, vv, q_out=qq, robust=True)
             ref = oracle.dense_backup_rows(rows_t, rows_r, None, vv.cpu().numpy(), gamma, robust=True)
             got = qq[ti].cpu().numpy()
             worst = max(worst, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1.0))))
+            equal = equal and bool(np.array_equal(got, ref))
             vv[lo:lo + rows] = qq.max(dim=-1).values
-        res["parity_sample"] = parity_record(worst <= 1e-12, "3 sweeps, {} sampled rows of this rank's block per sweep vs "
-                                             "oracle.dense_backup_rows (robust, M = 2); tolerance 1e-12 relative".format(len(idx)),
+        res["parity_sample"] = parity_record(equal if exact else worst <= 1e-12,
+                                             "3 sweeps, {} sampled rows of this rank's block per sweep vs oracle.dense_backup_rows "
+                                             "(robust, M = 2); {}".format(len(idx), "bit for bit" if exact else "tolerance 1e-12 relative"),
                                              max_rel_err=worst)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
@@ -1406,7 +1426,8 @@ def run_workload(args, rank, world, local):
         return bench_saopd(args, rank, world, local)
     if args.workload == "rvi_dense_shard":
         return bench_rvi_dense_shard(args, rank, world, local)
-    return bench_vi(args, rank, world, local, dense=args.workload == "vi_dense", robust=args.workload == "rvi")
+    return bench_vi(args, rank, world, local, dense=args.workload in ("vi_dense", "vi_dense_exact"), robust=args.workload == "rvi",
+                    exact=args.workload == "vi_dense_exact")
 
 
 # the other workloads of the path, each run for a bounded slice after the headline in the default run: (name, workload,
@@ -1414,7 +1435,8 @@ def run_workload(args, rank, world, local):
 SLICES = [("uct_prior", "uct_prior", 5, None), ("uct_cartpole", "uct_cartpole", 10, None), ("uct_stoch", "uct_stoch", 5, None),
           ("opd", "opd", 10, None), ("opd8192", "opd", 3, 8192), ("ropd", "ropd", 10, None), ("saopd", "saopd", 3, None),
           ("vi", "vi", 10, None), ("rvi", "rvi", 10, None), ("vi_dense", "vi_dense", 3, None),
-          ("rvi_dense_shard", "rvi_dense_shard", 10, None)]
+          ("vi_dense_exact", "vi_dense_exact", 3, None), ("rvi_dense_shard", "rvi_dense_shard", 10, None),
+          ("rvi_dense_shard_exact", "rvi_dense_shard", 10, None, "exact")]
 
 
 def run_slices(args, rank, world, local):
@@ -1424,9 +1446,10 @@ def run_slices(args, rank, world, local):
     import gc
     import torch
     out = {}
-    for name, workload, steps, roots in SLICES:
+    for name, workload, steps, roots, *mode in SLICES:
         sub = copy.copy(args)
         sub.workload, sub.steps, sub.warmup, sub.roots, sub.no_cpu_baseline = workload, steps, 1, roots, True
+        sub.dense_mode = mode[0] if mode else ("mfma" if workload == "rvi_dense_shard" else None)
         t0 = time.perf_counter()
         try:
             res = run_workload(sub, rank, world, local)

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 4
+#define MP_ABI_VERSION 5
 
 #define MP_OK 0
 #define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
@@ -176,9 +176,10 @@ int mp_model_info(const mp_model *model, int32_t *mode, int32_t *M, int32_t *S, 
  * robust = 1, RobustValueIterationAgent.get_state_action_value (robust_value_iteration.py:39-58):
  * min over the M models, no terminal masking.
  *   Q_out double [S,A]; sweeps_out int32 [1] = Bellman sweeps actually executed.
- * Deterministic and sparse (B < 8) modes are bit-exact with the reference; the dense mode
- * accumulates on the f64 matrix cores in a different order than numpy's pairwise sum
- * (relative error ~1e-15 per sweep).
+ * Deterministic and sparse modes are bit-exact with the reference.  The dense mode has two forms (mp_vi_dense_mode):
+ * in numpy's own order of roundings and additions -- bit-exact Q, V and sweep counts (the default) -- or on the f64
+ * matrix cores, which accumulate in another order than numpy's pairwise sum (relative error ~1e-15 per sweep: Q within
+ * 1e-12, greedy actions equal, sweep count within 1).
  * Deterministic models with |S| <= 16 384 are solved by ONE persistent launch whose workgroups hand V to each other and
  * therefore must all be resident at once.  On a GPU shared with other work that can fail (bounded spins, no hang):
  *   mem = MP_MEM_HOST  : the call notices and transparently solves again on the chained launches;
@@ -200,6 +201,28 @@ int mp_vi_solve_v_robust(mp_ctx *ctx, mp_model *model, double gamma, int32_t ite
  * Q double [S_rows,A] out.  The row-sharded driver (rl_agents_amd/distributed.py) all_gathers V between backups.
  */
 int mp_vi_backup(mp_ctx *ctx, mp_model *model, double gamma, int32_t robust, const double *V, double *Q, int32_t mem);
+/*
+ * How dense models (MP_MODE_STOCHASTIC) are contracted with V by every VI entry point of this ctx
+ * (value_iteration.py:54-55: (T * v).sum(axis=-1) -- products rounded one by one, numpy's pairwise add.reduce):
+ *   MP_VI_DENSE_MFMA   v_mfma_f64_16x16x4_f64 (fused, reordered accumulation): tolerance parity, see mp_vi_solve
+ *   MP_VI_DENSE_EXACT  the reference's order restated (eight strided accumulators per block of <= 128 elements, the
+ *                      halving recursion above it): bit-exact; both stream T once and are bound by HBM
+ * Without a call the environment decides (MP_VI_DENSE=mfma|exact), else MP_VI_DENSE_EXACT: parity first, and at
+ * 0.25 flop per byte the contraction is bound by HBM in both forms (measured: DESIGN.md 4.5).
+ */
+#define MP_VI_DENSE_MFMA 0
+#define MP_VI_DENSE_EXACT 1
+int mp_vi_dense_mode(mp_ctx *ctx, int32_t mode);
+/* Host only (no GPU needed): the tables MP_VI_DENSE_EXACT sums a row of n elements by -- numpy's add.reduce: the
+ * running sum, from the identity 0., of the pairwise sums (DOUBLE_pairwise_sum: blocks of at most 128, halves rounded
+ * down to a multiple of 8) of the row's pieces of numpy.getbufsize() = 8192 elements.
+ * leaves int32 [cap_leaves,2] {offset, length} left to right, leaf 0 = {0, 0} is the identity; nodes int32 [cap_nodes,2] {left, right} result
+ * slots of the recursion's additions ordered by height (leaf l = slot l, addition k = slot n_leaves + k, the last one
+ * is the row's sum); hoff int32 [cap_heights + 1]: additions of height h + 1 are [hoff[h], hoff[h+1]);
+ * counts int32 [4] = {n_leaves, n_nodes, n_heights, most 8-element steps in a leaf}.  Arrays too small (or NULL) are
+ * left alone: call once for the counts.  tests/test_host_logic.py replays the tables against numpy.add.reduce. */
+int mp_vi_exact_plan(int32_t n, int32_t cap_leaves, int32_t *leaves, int32_t cap_nodes, int32_t *nodes, int32_t cap_heights,
+                     int32_t *hoff, int32_t *counts);
 /* Timing hook: run exactly `sweeps` Bellman sweeps (no early exit), Q left on the device. */
 int mp_vi_sweeps(mp_ctx *ctx, mp_model *model, double gamma, int32_t sweeps, int32_t robust);
 

@@ -164,6 +164,23 @@ static double orc_pairwise_sum(const double *a, long n)
     }
 }
 
+/*
+ * numpy add.reduce of a contiguous double vector as the ufunc machinery runs it: the reduction's iterator hands the inner
+ * loop at most `bufsize` = 8192 elements at a time (numpy.getbufsize(), the default the reference runs with) even when
+ * nothing needs buffering, so a row longer than 8192 is NOT one pairwise sum: it is the running sum, from the identity
+ * 0., of the pairwise sums of its 8192-element pieces.  (Found in round 4 while restating the order on the device:
+ * tests/test_oracle_vi_long_rows.py pins this function on numpy itself for rows of 8193 .. 50 000 elements; up to 8192
+ * elements -- every golden of the reference -- it is 0. + orc_pairwise_sum, as before.)
+ */
+#define ORC_NPY_BUFSIZE 8192
+static double orc_add_reduce(const double *a, long n)
+{
+    double res = 0.0;
+    for (long off = 0; off < n; off += ORC_NPY_BUFSIZE)
+        res += orc_pairwise_sum(a + off, n - off < ORC_NPY_BUFSIZE ? n - off : ORC_NPY_BUFSIZE);
+    return res;
+}
+
 /* numpy.isclose for one pair (a = old value, b = new value) */
 static inline int orc_isclose(double a, double b, double rtol, double atol)
 {
@@ -194,10 +211,10 @@ static void orc_bellman(int mode, int M, int S, int A, int B, const int64_t *T, 
                 } else if (mode == 1) {
                     const double *row = P + sa * (long)S;
                     for (int k = 0; k < S; ++k) scratch[k] = row[k] * v[k];
-                    next_v = 0.0 + orc_pairwise_sum(scratch, S);
+                    next_v = orc_add_reduce(scratch, S);
                 } else {
                     for (int b = 0; b < B; ++b) scratch[b] = P[sa * B + b] * v[NXT[sa * B + b]];
-                    next_v = 0.0 + orc_pairwise_sum(scratch, B);
+                    next_v = orc_add_reduce(scratch, B);
                 }
                 if (!robust && term && term[s]) next_v = 0.0; /* value_iteration.py:62 */
                 const double qm = R[sa] + gamma * next_v;
@@ -227,7 +244,7 @@ int orc_dense_backup_rows(int M, int rows, int A, int S_cols, const double *P, c
                 const long sa = ((long)m * rows + s) * A + a;
                 const double *row = P + sa * (long)S_cols;
                 for (int k = 0; k < S_cols; ++k) scratch[k] = row[k] * v[k];
-                double next_v = 0.0 + orc_pairwise_sum(scratch, S_cols);
+                double next_v = orc_add_reduce(scratch, S_cols);
                 if (!robust && term && term[s]) next_v = 0.0;
                 const double qm = R[sa] + gamma * next_v;
                 if (m == 0 || qm < best) best = qm;

@@ -61,7 +61,7 @@ struct TreeMeta {
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,
        WS_IO5, WS_IO6, WS_IO7, WS_IO8, WS_IO9, WS_TAB0, WS_TAB1, WS_TAB2, WS_TAB3, WS_VI0, WS_VI1, WS_VI2, WS_VI3,
-       WS_VI4, WS_COUNT };
+       WS_VI4, WS_VI5, WS_COUNT };
 
 // everything a captured chain of deterministic VI sweeps bakes into its kernel arguments
 struct ViGraphKey {
@@ -90,6 +90,11 @@ struct mp_ctx {
     // cached hipGraphExec of the last deterministic VI sweep chain
     void *vi_graph_exec = nullptr;
     mp::ViGraphKey vi_graph_key;
+    // dense value iteration: 1 = contract in numpy's summation order (vi_dense_exact_q, bit-exact with the reference),
+    // 0 = on the f64 matrix cores (vi_dense_q); -1 = not set yet (MP_VI_DENSE in the environment, else the default)
+    int vi_dense_exact = -1;
+    int vi_exact_cols = 0; // the row length whose summation plan sits in WS_VI5 (0 = none)
+    int vi_exact_nleaf = 0, vi_exact_nnode = 0, vi_exact_nh = 0, vi_exact_nb = 0, vi_exact_npiece = 0;
     // side streams of the pipelined host-mode plan (created on first use), one completion event each, one fork event
     hipStream_t pipe[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pipe_done[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};

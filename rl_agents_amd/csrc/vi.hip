@@ -20,6 +20,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <utility>
+#include <vector>
+
 #include "common.hpp"
 
 namespace mp {
@@ -514,6 +517,10 @@ struct ViGenArgs {
     int32_t *notclose;
 };
 
+#ifndef MP_VI_DENSE_DEFAULT_EXACT
+#define MP_VI_DENSE_DEFAULT_EXACT 1 // dense backups without MP_VI_DENSE / mp_vi_dense_mode: 1 = numpy's order (bit-exact, and measured
+                                    // as fast as the matrix cores: HBM bounds both), 0 = matrix cores
+#endif
 #ifndef MP_DENSE_CHUNK
 #define MP_DENSE_CHUNK 4096
 #endif
@@ -629,9 +636,313 @@ __global__ __launch_bounds__(256) void vi_dense_combine(ViGenArgs p)
     p.Qnext[row] = best;
 }
 
+// ---- the dense backup in NUMPY'S summation order: bit-exact with value_iteration.py:54-55 --------------------------------
+// The reference computes (T * v.reshape(1, 1, S)).sum(axis=-1): every product rounded, then numpy's add.reduce over the
+// contiguous axis -- pairwise summation: a row longer than 128 is halved (the left half rounded down to a multiple of 8)
+// until the pieces ("leaves") hold at most 128 elements; a leaf is summed by eight strided accumulators r[j] += a[8 i + j],
+// combined ((r0 + r1) + (r2 + r3)) + ((r4 + r5) + (r6 + r7)), its last len % 8 elements added one by one.  The matrix cores
+// fuse and reorder (vi_dense_q: 1e-12); this kernel restates the order itself: ONE ROW PER WAVEFRONT, eight lanes per leaf
+// (lane j of a group IS accumulator j: its loads are 8 elements apart, the eight lanes of a group read one 64-byte piece,
+// and every byte of a line is used by two consecutive steps), eight leaves per pass, all loads of a pass in flight
+// together; the group's three-level sum is a butterfly (IEEE addition commutes, so every lane ends with the reference's
+// value); leaf results go to LDS and the recursion's additions are done level by level from a table the host derives
+// from the row length -- including what the ufunc machinery adds: the reduction's iterator hands the inner loop at most
+// numpy.getbufsize() = 8192 elements at a time, so a longer row is the running sum, from the identity 0., of the pairwise
+// sums of its 8192-element pieces.  V is staged in LDS when it fits beside the tables (S <= ~14 000), else read through
+// L2.  The kernel streams T once, as the matrix-core kernel does: it is bound by HBM, not by the order of its additions.
+struct ViExactPlan {
+    const int2 *leaves; // {offset, length} of the leaves of the recursion over Sc elements, left to right; leaf 0 = the identity
+    const int2 *nodes;  // its additions by height: {left, right} result slots (leaf l = slot l, addition k = slot nleaf + k)
+    const int *hoff;    // additions of height h + 1: [hoff[h], hoff[h + 1])
+    const int *piece;   // leaves of the 8192-element piece c: [piece[c], piece[c + 1])
+    int nleaf, nnode, nh, npiece;
+};
+
+enum { VI_V_GLOBAL = 0, VI_V_LDS = 1, VI_V_PIECES = 2 };
+constexpr int kViPiece = 8192; // numpy.getbufsize(): what add.reduce hands its inner loop at a time (and the V window of VI_V_PIECES)
+
+// VM: where the lanes read V from.  VI_V_LDS: all of it staged once per workgroup (it fits beside the tables up to ~14 000
+// states).  VI_V_PIECES: longer rows -- the 8192-element piece the workgroup's waves are summing, staged between two
+// barriers (the waves of a workgroup then walk their rows in step; read through L2 instead, every wave-load of T is
+// matched by one of V that misses the 32 KB L1: 5.45 against 4.0 ms per sweep on a 25 GB row block).  VI_V_GLOBAL: no staging.
+template <int NBT, int VM>
+__global__ __launch_bounds__(512) void vi_dense_exact_q(ViGenArgs p, ViExactPlan pl)
+{
+    if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
+    extern __shared__ __attribute__((aligned(16))) double xs[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nw = (int)(blockDim.x >> 6);
+    const int nslot = pl.nleaf + pl.nnode;
+    // LDS: [leaves int2][nodes int2][hoff, piece int, padded to a double][result slots of every wave][V or its window]
+    int2 *l_leaves = reinterpret_cast<int2 *>(xs);
+    int2 *l_nodes = l_leaves + pl.nleaf;
+    int *l_hoff = reinterpret_cast<int *>(l_nodes + pl.nnode);
+    int *l_piece = l_hoff + pl.nh + 1;
+    const int tab = nslot + (pl.nh + pl.npiece + 3) / 2;
+    double *slots = xs + tab + (long)wave * nslot;
+    double *vs = xs + tab + (long)nw * nslot;
+    for (int t = threadIdx.x; t < pl.nleaf; t += blockDim.x) l_leaves[t] = pl.leaves[t];
+    for (int t = threadIdx.x; t < pl.nnode; t += blockDim.x) l_nodes[t] = pl.nodes[t];
+    for (int t = threadIdx.x; t <= pl.nh; t += blockDim.x) l_hoff[t] = pl.hoff[t];
+    for (int t = threadIdx.x; t <= pl.npiece; t += blockDim.x) l_piece[t] = pl.piece[t];
+    if (VM == VI_V_LDS)
+        for (int t = threadIdx.x; t < p.Sc; t += blockDim.x) vs[t] = p.Vcur[t];
+    __syncthreads();
+    const long SA = (long)p.S * p.A;
+    const int g = lane >> 3, j = lane & 7;
+    constexpr int VPRE = VM == VI_V_PIECES ? kViPiece / 512 : 1; // window elements a thread prefetches (all of them from 512 threads on)
+    double vpre[VPRE];
+    if (VM == VI_V_PIECES) {
+        const int nn = min(kViPiece, p.Sc);
+#pragma unroll
+        for (int i = 0; i < VPRE; ++i) {
+            const int t = (int)threadIdx.x + i * (int)blockDim.x;
+            vpre[i] = p.Vcur[t < nn ? t : 0];
+        }
+    }
+    // (VI_V_PIECES: every wave of the workgroup makes the same number of trips -- the barriers -- so a wave past the last
+    // row sums the last row again and does not store)
+    for (long row0 = (long)blockIdx.x * nw; row0 < SA; row0 += (long)gridDim.x * nw) {
+        long row = row0 + wave;
+        const bool mine = row < SA;
+        if (!mine) {
+            if (VM != VI_V_PIECES) break;
+            row = SA - 1;
+        }
+        double best = 0.0;
+        for (int m = 0; m < p.M; ++m) {
+            const double *prow = p.P + ((long)m * SA + row) * p.Sc;
+            if (lane == 0) slots[0] = 0.0;                      // leaf 0: the identity the reduction starts from
+            for (int c = 0; c < pl.npiece; ++c) {
+                const int vbase = VM == VI_V_PIECES ? c * kViPiece : 0;
+                if (VM == VI_V_PIECES) {
+                    // the window was requested one piece ago (vpre, below): its round trip to L2 hides behind the passes of
+                    // the previous piece instead of standing between two barriers
+                    __syncthreads();                            // the previous window's readers are done
+                    const int cn = min(kViPiece, p.Sc - vbase);
+#pragma unroll
+                    for (int i = 0; i < VPRE; ++i) {
+                        const int t = (int)threadIdx.x + i * (int)blockDim.x;
+                        if (t < cn) vs[t] = vpre[i];
+                    }
+                    for (int t = threadIdx.x + VPRE * blockDim.x; t < cn; t += blockDim.x) vs[t] = p.Vcur[vbase + t]; // (< 512 threads)
+                    __syncthreads();
+                    const int nbase = (c + 1 < pl.npiece ? c + 1 : 0) * kViPiece; // every (rows, model) walks the pieces in order
+                    const int nn = min(kViPiece, p.Sc - nbase);
+#pragma unroll
+                    for (int i = 0; i < VPRE; ++i) {
+                        const int t = (int)threadIdx.x + i * (int)blockDim.x;
+                        vpre[i] = p.Vcur[nbase + (t < nn ? t : 0)];
+                    }
+                }
+                const int l_end = l_piece[c + 1];
+                for (int l0 = l_piece[c]; l0 < l_end; l0 += 8) {
+                    const int l = l0 + g;
+                    const bool valid = l < l_end;
+                    const int2 lf = l_leaves[valid ? l : l_end - 1];
+                    const int off = lf.x, len = valid ? lf.y : 0;
+                    const int nb = len >> 3;                    // full steps of the eight accumulators
+                    const int base = nb > 0 ? off + j : vbase;  // (a lane without a step re-reads an element that is there)
+                    double x[NBT], v[NBT];
+#pragma unroll
+                    for (int i = 0; i < NBT; ++i) {
+                        const int idx = base + (i < nb ? 8 * i : 0);
+                        x[i] = prow[idx];
+                        v[i] = VM == VI_V_GLOBAL ? p.Vcur[idx] : vs[idx - vbase];
+                    }
+                    double r = nb > 0 ? x[0] * v[0] : 0.0;      // r[j] = a[j] (n < 8: res = 0.)
+#pragma unroll
+                    for (int i = 1; i < NBT; ++i) {
+                        const double t = x[i] * v[i];
+                        r = i < nb ? r + t : r;
+                    }
+                    r += __shfl_xor(r, 1);                      // r0 + r1 | r2 + r3 | r4 + r5 | r6 + r7
+                    r += __shfl_xor(r, 2);                      // (r0 + r1) + (r2 + r3) | (r4 + r5) + (r6 + r7)
+                    r += __shfl_xor(r, 4);
+                    const int rem = len & 7;
+                    if (__any(rem != 0)) {                      // only the last leaf of a row can have a remainder
+                        const int tail = off + 8 * nb;
+#pragma unroll
+                        for (int t = 0; t < 7; ++t) {
+                            const int idx = t < rem ? tail + t : vbase;
+                            const double pv = prow[idx] * (VM == VI_V_GLOBAL ? p.Vcur[idx] : vs[idx - vbase]);
+                            r = t < rem ? r + pv : r;
+                        }
+                    }
+                    if (j == 0 && valid) slots[l] = r;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int h = 0; h < pl.nh; ++h) {
+                for (int k = l_hoff[h] + lane; k < l_hoff[h + 1]; k += 64) {
+                    const int2 nd = l_nodes[k];
+                    slots[pl.nleaf + k] = slots[nd.x] + slots[nd.y];
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            double nv = slots[nslot - 1];
+            __builtin_amdgcn_wave_barrier();
+            const int s = (int)(row / p.A);
+            if (!p.robust && p.term && p.term[s]) nv = 0.0;
+            const double qm = p.R[(long)m * SA + row] + p.gamma * nv;
+            if (m == 0 || qm < best) best = qm;
+        }
+        if (lane == 0 && mine) p.Qnext[row] = best;
+    }
+}
+
+// the recursion of numpy's pairwise sum over n elements as tables (see vi_dense_exact_q)
+static void vi_exact_plan_host(int n, std::vector<int> &leaves, std::vector<int> &nodes, std::vector<int> &hoff, std::vector<int> &piece,
+                               int *nb_max)
+{
+    struct Add { int l, r, h; };
+    std::vector<Add> adds;
+    leaves.clear();
+    // returns {slot, height}; leaves take slots 0.., additions are renumbered by height below
+    struct Rec {
+        std::vector<int> &lv; std::vector<Add> &ad;
+        std::pair<int, int> go(int off, int len)
+        {
+            if (len <= 128) { lv.push_back(off); lv.push_back(len); return {(int)lv.size() / 2 - 1, 0}; }
+            int n2 = len / 2;
+            n2 -= n2 % 8;
+            const auto a = go(off, n2), b = go(off + n2, len - n2);
+            const int h = 1 + (a.second > b.second ? a.second : b.second);
+            ad.push_back({a.first, b.first, h});
+            return {-(int)ad.size(), h}; // additions as negative provisional ids
+        }
+    } rec{leaves, adds};
+    // add.reduce hands its inner loop at most numpy.getbufsize() = 8192 elements at a time: a longer row is the running
+    // sum, from the identity 0., of the pairwise sums of its 8192-element pieces.  The identity is leaf 0 (no elements).
+    leaves.push_back(0); leaves.push_back(0);
+    piece.clear();
+    int acc = 0, acc_h = 0;
+    for (int off = 0; off < n; off += kViPiece) {
+        piece.push_back((int)leaves.size() / 2);
+        const auto sum = rec.go(off, n - off < kViPiece ? n - off : kViPiece);
+        acc_h = 1 + (acc_h > sum.second ? acc_h : sum.second);
+        adds.push_back({acc, sum.first, acc_h});
+        acc = -(int)adds.size();
+    }
+    piece.push_back((int)leaves.size() / 2);
+    const int nleaf = (int)leaves.size() / 2, nnode = (int)adds.size();
+    int nh = 0, nbm = 1;
+    for (const Add &a : adds) nh = a.h > nh ? a.h : nh;
+    for (int l = 0; l < nleaf; ++l) nbm = leaves[2 * l + 1] / 8 > nbm ? leaves[2 * l + 1] / 8 : nbm;
+    // stable counting sort of the additions by height (1..nh); the slot of the addition at position k is nleaf + k, the
+    // root -- the only addition of the greatest height -- comes last
+    std::vector<int> start(nh + 2, 0);
+    for (const Add &a : adds) ++start[a.h + 1];
+    for (int h = 1; h <= nh + 1; ++h) start[h] += start[h - 1]; // start[h] = additions of height < h
+    std::vector<int> cur(start), order(nnode), newid(nnode);
+    for (int k = 0; k < nnode; ++k) { const int pos = cur[adds[k].h]++; order[pos] = k; newid[k] = pos; }
+    auto slot = [&](int id) { return id >= 0 ? id : nleaf + newid[-id - 1]; };
+    nodes.assign(2 * (size_t)nnode, 0);
+    for (int pos = 0; pos < nnode; ++pos) {
+        nodes[2 * pos] = slot(adds[order[pos]].l);
+        nodes[2 * pos + 1] = slot(adds[order[pos]].r);
+    }
+    hoff.assign(nh + 1, 0);
+    for (int h = 0; h <= nh; ++h) hoff[h] = start[h + 1]; // heights 1..nh -> [hoff[h - 1], hoff[h])
+    *nb_max = nbm;
+}
+
+static bool vi_dense_exact_on(mp_ctx *ctx)
+{
+    if (ctx->vi_dense_exact < 0) {
+        const char *e = getenv("MP_VI_DENSE");
+        ctx->vi_dense_exact = (e && !strcmp(e, "exact")) ? 1 : ((e && !strcmp(e, "mfma")) ? 0 : MP_VI_DENSE_DEFAULT_EXACT);
+    }
+    return ctx->vi_dense_exact == 1;
+}
+
+template <int NBT, int VM>
+static int vi_dense_exact_launch_vm(const ViGenArgs &a, const ViExactPlan &pl, unsigned grid, unsigned block, size_t lds, hipStream_t st)
+{
+    MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vi_dense_exact_q<NBT, VM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((vi_dense_exact_q<NBT, VM>), dim3(grid), dim3(block), lds, st, a, pl);
+    return MP_OK;
+}
+
+template <int NBT>
+static int vi_dense_exact_launch_nb(const ViGenArgs &a, const ViExactPlan &pl, int vm, unsigned grid, unsigned block, size_t lds,
+                                    hipStream_t st)
+{
+    if (vm == VI_V_LDS) return vi_dense_exact_launch_vm<NBT, VI_V_LDS>(a, pl, grid, block, lds, st);
+    if (vm == VI_V_PIECES) return vi_dense_exact_launch_vm<NBT, VI_V_PIECES>(a, pl, grid, block, lds, st);
+    return vi_dense_exact_launch_vm<NBT, VI_V_GLOBAL>(a, pl, grid, block, lds, st);
+}
+
+static int vi_dense_exact_launch(mp_ctx *ctx, ViGenArgs &a, hipStream_t st, int *launches)
+{
+    if (ctx->vi_exact_cols != a.Sc) { // the summation tables of this row length (a few KB, uploaded once)
+        std::vector<int> leaves, nodes, hoff, piece;
+        int nbm = 1;
+        vi_exact_plan_host(a.Sc, leaves, nodes, hoff, piece, &nbm);
+        std::vector<int> all(leaves);
+        all.insert(all.end(), nodes.begin(), nodes.end());
+        all.insert(all.end(), hoff.begin(), hoff.end());
+        all.insert(all.end(), piece.begin(), piece.end());
+        int *d = nullptr;
+        ctx->vi_exact_cols = 0;
+        MP_TRY(ws_get(ctx, WS_VI5, all.size(), &d));
+        MP_HIP(hipMemcpyAsync(d, all.data(), all.size() * sizeof(int), hipMemcpyHostToDevice, st));
+        MP_HIP(hipStreamSynchronize(st)); // (`all` is a local)
+        ctx->vi_exact_cols = a.Sc;
+        ctx->vi_exact_nleaf = (int)leaves.size() / 2; ctx->vi_exact_nnode = (int)nodes.size() / 2;
+        ctx->vi_exact_nh = (int)hoff.size() - 1; ctx->vi_exact_nb = nbm; ctx->vi_exact_npiece = (int)piece.size() - 1;
+    }
+    ViExactPlan pl;
+    int *d = static_cast<int *>(ctx->ws[WS_VI5].p);
+    pl.nleaf = ctx->vi_exact_nleaf; pl.nnode = ctx->vi_exact_nnode; pl.nh = ctx->vi_exact_nh; pl.npiece = ctx->vi_exact_npiece;
+    pl.leaves = reinterpret_cast<const int2 *>(d);
+    pl.nodes = reinterpret_cast<const int2 *>(d + 2 * pl.nleaf);
+    pl.hoff = d + 2 * pl.nleaf + 2 * pl.nnode;
+    pl.piece = pl.hoff + pl.nh + 1;
+    const long SA = (long)a.S * a.A;
+    const int nslot = pl.nleaf + pl.nnode;
+    // Eight waves per workgroup: measured 0.669 ms per sweep at S = 10 000 against 0.700 with sixteen (50 000 rows over 2 048
+    // waves leave a shorter tail than over 4 096) -- each wave keeps up to sixteen 512-byte loads in flight.
+    int nw = 8;
+    if (const char *e = getenv("MP_VI_EXACT_WAVES")) { const int v = atoi(e); if (v >= 1 && v <= 8) nw = v; } // (launch bounds: 512 threads)
+    const size_t tab = (size_t)nslot + (size_t)(pl.nh + pl.npiece + 3) / 2;
+    while (nw > 1 && (tab + (size_t)nw * nslot) * sizeof(double) > kLdsBytes / 2) nw >>= 1;
+    const size_t fixed = (tab + (size_t)nw * nslot) * sizeof(double);
+    if (fixed > kLdsBytes - 1024) return fail(MP_ERR_ARG, "vi: rows of %d columns need %zu bytes of LDS for the summation tables", a.Sc, fixed);
+    int vm = VI_V_GLOBAL;
+    if (fixed + (size_t)a.Sc * sizeof(double) <= kLdsBytes - 1024) vm = VI_V_LDS;
+    else if (fixed + (size_t)kViPiece * sizeof(double) <= kLdsBytes - 1024) vm = VI_V_PIECES;
+    if (const char *e = getenv("MP_VI_EXACT_V")) { // test / measurement knob: global | pieces (whole-V staging only where it fits)
+        if (!strcmp(e, "global")) vm = VI_V_GLOBAL;
+        else if (!strcmp(e, "pieces") && fixed + (size_t)kViPiece * sizeof(double) <= kLdsBytes - 1024) vm = VI_V_PIECES;
+    }
+    if (getenv("MP_VI_EXACT_NO_VLDS")) vm = VI_V_GLOBAL;
+    const size_t vbytes = vm == VI_V_LDS ? (size_t)a.Sc * sizeof(double) : (vm == VI_V_PIECES ? (size_t)kViPiece * sizeof(double) : 0);
+    const size_t lds = fixed + vbytes;
+    const long groups = (SA + nw - 1) / nw;
+    int wg_per_cu = (int)((kLdsBytes - 1024) / (lds > 0 ? lds : 1));
+    if (wg_per_cu > 2048 / (64 * nw)) wg_per_cu = 2048 / (64 * nw);
+    if (vm != VI_V_GLOBAL) wg_per_cu = 1; // one staged copy of V per CU
+    if (wg_per_cu < 1) wg_per_cu = 1;
+    const long cap = (long)ctx->prop.multiProcessorCount * wg_per_cu;
+    const unsigned grid = (unsigned)(groups < cap ? groups : cap);
+    const unsigned block = 64u * (unsigned)nw;
+    const int nb = ctx->vi_exact_nb;
+    int rc;
+    if (nb <= 8) rc = vi_dense_exact_launch_nb<8>(a, pl, vm, grid, block, lds, st);
+    else if (nb <= 10) rc = vi_dense_exact_launch_nb<10>(a, pl, vm, grid, block, lds, st);
+    else if (nb <= 12) rc = vi_dense_exact_launch_nb<12>(a, pl, vm, grid, block, lds, st);
+    else if (nb <= 14) rc = vi_dense_exact_launch_nb<14>(a, pl, vm, grid, block, lds, st);
+    else rc = vi_dense_exact_launch_nb<16>(a, pl, vm, grid, block, lds, st);
+    if (rc != MP_OK) return rc;
+    if (launches) ++*launches;
+    return MP_OK;
+}
+
 // launch the dense backup (split by column segments when the rows are long)
 static int vi_dense_launch(mp_ctx *ctx, ViGenArgs &a, hipStream_t st, int *launches)
 {
+    if (vi_dense_exact_on(ctx)) return vi_dense_exact_launch(ctx, a, st, launches);
     const long SA = (long)a.S * a.A;
     a.seg_cols = kDenseSegCols;
     a.nseg = a.Sc > kDenseSegCols && !getenv("MP_DENSE_NO_SPLIT") ? (a.Sc + kDenseSegCols - 1) / kDenseSegCols : 1;
@@ -1000,6 +1311,28 @@ int mp_vi_solve_v_robust(mp_ctx *ctx, mp_model *model, double gamma, int32_t ite
                          double *V_out, int32_t mem)
 {
     return mp::vi_run(ctx, model, gamma, iterations, rtol, atol, 1, 1, nullptr, V_out, nullptr, mem);
+}
+
+int mp_vi_dense_mode(mp_ctx *ctx, int32_t mode)
+{
+    if (!ctx) return mp::fail(MP_ERR_ARG, "mp_vi_dense_mode: NULL ctx");
+    if (mode != MP_VI_DENSE_MFMA && mode != MP_VI_DENSE_EXACT) return mp::fail(MP_ERR_ARG, "mp_vi_dense_mode: mode %d", (int)mode);
+    ctx->vi_dense_exact = mode == MP_VI_DENSE_EXACT ? 1 : 0;
+    return MP_OK;
+}
+
+int mp_vi_exact_plan(int32_t n, int32_t cap_leaves, int32_t *leaves, int32_t cap_nodes, int32_t *nodes, int32_t cap_heights,
+                     int32_t *hoff, int32_t *counts)
+{
+    if (n < 1 || !counts) return mp::fail(MP_ERR_ARG, "mp_vi_exact_plan: n = %d", (int)n);
+    std::vector<int> lv, nd, ho, pc;
+    int nbm = 1;
+    mp::vi_exact_plan_host(n, lv, nd, ho, pc, &nbm);
+    counts[0] = (int32_t)lv.size() / 2; counts[1] = (int32_t)nd.size() / 2; counts[2] = (int32_t)ho.size() - 1; counts[3] = nbm;
+    if (leaves && (size_t)cap_leaves * 2 >= lv.size()) memcpy(leaves, lv.data(), lv.size() * sizeof(int));
+    if (nodes && (size_t)cap_nodes * 2 >= nd.size()) memcpy(nodes, nd.data(), nd.size() * sizeof(int));
+    if (hoff && (size_t)cap_heights + 1 >= ho.size()) memcpy(hoff, ho.data(), ho.size() * sizeof(int));
+    return MP_OK;
 }
 
 int mp_vi_sweeps(mp_ctx *ctx, mp_model *model, double gamma, int32_t sweeps, int32_t robust)

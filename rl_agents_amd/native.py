@@ -45,6 +45,8 @@ SIGNATURES = {
     "mp_vi_solve_v": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, c_i32]),
     "mp_vi_solve_v_robust": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, c_i32]),
     "mp_vi_sweeps": (C.c_int, [_vp, _vp, c_f64, c_i32, c_i32]),
+    "mp_vi_dense_mode": (C.c_int, [_vp, c_i32]),
+    "mp_vi_exact_plan": (C.c_int, [c_i32, c_i32, _vp, c_i32, _vp, c_i32, _vp, _vp]),
     "mp_uct_plan": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, c_i32]),
     "mp_policy_load": (C.c_int, [_vp, _vp, _vp, _vp, P(_vp)]),
@@ -138,7 +140,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 4:
+    if lib.mp_abi_version() != 5:
         raise RuntimeError("libmi355plan ABI version mismatch")
     _LIB = lib
     return lib
@@ -195,6 +197,21 @@ def olop_allocation(budget, gamma):
     if rc != 0:
         raise ValueError("Could not split budget {} with gamma {}".format(budget, gamma))
     return e.value, h.value
+
+
+def vi_exact_plan(n):
+    """The tables the bit-exact dense backup sums a row of ``n`` elements by (numpy's pairwise recursion; host only):
+    -> (leaves int32 [L,2] {offset, length}, nodes int32 [K,2] {left slot, right slot} by height, hoff int32 [H+1],
+    most 8-element steps in a leaf).  Leaf l is slot l, addition k slot L + k; the last slot holds the sum."""
+    lib = load()
+    counts = np.zeros(4, dtype=np.int32)
+    _check(lib.mp_vi_exact_plan(int(n), 0, None, 0, None, 0, None, _ptr(counts)))
+    leaves = np.zeros((int(counts[0]), 2), dtype=np.int32)
+    nodes = np.zeros((int(counts[1]), 2), dtype=np.int32)
+    hoff = np.zeros(int(counts[2]) + 1, dtype=np.int32)
+    _check(lib.mp_vi_exact_plan(int(n), len(leaves), _ptr(leaves), len(nodes), _ptr(nodes) if len(nodes) else None,
+                                len(hoff) - 1, _ptr(hoff), _ptr(counts)))
+    return leaves, nodes, hoff, int(counts[3])
 
 
 class Context(object):
@@ -505,6 +522,11 @@ class Context(object):
 
     def vi_sweeps(self, model, gamma, sweeps, robust=False):
         _check(self._lib.mp_vi_sweeps(self._h, model._h, float(gamma), int(sweeps), int(bool(robust))))
+
+    def vi_dense_mode(self, mode):
+        """How dense models are contracted with V: ``"mfma"`` (f64 matrix cores, tolerance parity) or ``"exact"``
+        (numpy's own order of roundings and additions: Q, V and sweep counts bit-equal to the reference's)."""
+        _check(self._lib.mp_vi_dense_mode(self._h, {"mfma": 0, "exact": 1}[mode]))
 
     # ---- tree search -------------------------------------------------------------------------
     def load_policy(self, model, prior, rollout, listed=None, rollout_slots=None):

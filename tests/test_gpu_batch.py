@@ -362,6 +362,12 @@ def test_vi_sparse_and_dense_vs_oracle(ctx):
         q, sweeps = ctx.vi_solve(model, 0.9, 40)
         q_ref, sweeps_ref = oracle.vi_solve("stochastic", cfg["transition"], cfg["reward"], cfg["terminal"], gamma=0.9,
                                             iterations=40)
+        assert sweeps == sweeps_ref and np.array_equal(q, q_ref)     # default: numpy's order of additions
+        ctx.vi_dense_mode("mfma")
+        try:
+            q, sweeps = ctx.vi_solve(model, 0.9, 40)
+        finally:
+            ctx.vi_dense_mode("exact")
         # matrix-core accumulation order differs from numpy's pairwise sum: 1e-12 relative
         np.testing.assert_allclose(q, q_ref, rtol=1e-12, atol=1e-12)
         assert abs(sweeps - sweeps_ref) <= 1
@@ -380,11 +386,14 @@ def test_vi_properties_at_scale(ctx):
     np.testing.assert_allclose(q2 - q, 0.1 / (1 - 0.9), rtol=1e-9)   # constant reward shift -> shift / (1 - gamma)
 
 
-def test_row_block_backup_and_sharded_driver_world1(ctx):
+@pytest.mark.parametrize("dense_mode", ["exact", "mfma"])
+def test_row_block_backup_and_sharded_driver_world1(ctx, dense_mode, request):
     """mp_vi_backup on row blocks reassembles the full backup; the sharded driver at world size 1 returns
-    exactly what mp_vi_solve returns (same kernel, same order)."""
+    exactly what mp_vi_solve returns (same kernel, same order) -- in both forms of the dense contraction."""
     from rl_agents_amd.distributed import vi_solve_row_sharded
     from rl_agents_amd.envs import generators
+    ctx.vi_dense_mode(dense_mode)
+    request.addfinalizer(lambda: ctx.vi_dense_mode("exact"))
     cfg = generators.random_stochastic(301, 3, seed=5, terminal_rate=0.1)
     t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
     full = ctx.load_dense(t, r, term)

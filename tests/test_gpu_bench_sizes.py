@@ -158,8 +158,8 @@ def test_vi_dense_S10000_three_sweeps_vs_oracle(ctx):
     """C2-dense (bench.py --workload vi_dense): S = 10 000, |A| = 5 ALWAYS (4.0 GB of transitions, three V chunks of
     4096 columns per row; VERDICT r2: no fallback to |A| = 2).  The model is built on the device and borrowed by the
     library; the oracle -- numpy's pairwise order -- never needs the whole array: a dense backup is independent per
-    source row, so it replays the three sweeps one 500-row block (200 MB) at a time.  Q within 1e-12, identical greedy
-    actions, same sweep count."""
+    source row, so it replays the three sweeps one 500-row block (200 MB) at a time.  Matrix-core form: Q within 1e-12,
+    identical greedy actions, same sweep count; default form (numpy's order): bit for bit."""
     import torch
     from oracle import oracle
     s, a, gamma, block = 10000, 5, 0.95, 500
@@ -175,7 +175,11 @@ def test_vi_dense_S10000_three_sweeps_vs_oracle(ctx):
     d_term = torch.from_numpy(term.astype(np.uint8)).to(dev)
     torch.cuda.synchronize()
     model = ctx.load_dense(t, d_r, d_term)
-    q, sweeps = ctx.vi_solve(model, gamma, 3)
+    ctx.vi_dense_mode("mfma")
+    try:
+        q, sweeps = ctx.vi_solve(model, gamma, 3)
+    finally:
+        ctx.vi_dense_mode("exact")
     assert (model.S, model.A) == (s, a) and sweeps == 3
     # the reference's fixed_point_iteration (value_iteration.py:65-73) on the same numbers, block by block
     q_ref = np.zeros((s, a))
@@ -189,4 +193,8 @@ def test_vi_dense_S10000_three_sweeps_vs_oracle(ctx):
         q_ref = q_next
     np.testing.assert_allclose(q, q_ref, rtol=1e-12, atol=1e-12)
     assert np.array_equal(q.argmax(axis=1), q_ref.argmax(axis=1))
+    # the same three sweeps in numpy's own order of additions (vi_dense_exact_q; rows of 10 000 = a piece of 8192 and one
+    # of 1808 elements, see tests/test_oracle_vi_long_rows.py): bit for bit
+    q_x, sweeps_x = ctx.vi_solve(model, gamma, 3)          # (the default form)
+    assert sweeps_x == 3 and np.array_equal(q_x, q_ref)
     model.close()

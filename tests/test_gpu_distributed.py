@@ -211,7 +211,7 @@ def test_single_process_results_match_the_oracle(single):
     tt, rr, tm, _ = _vi_problem(False)
     q_ref, sweeps_ref = oracle.vi_solve("stochastic", tt, rr, tm, gamma=0.9, iterations=120)
     assert single["vi"][1] == sweeps_ref
-    np.testing.assert_allclose(single["vi"][0], q_ref, rtol=1e-12, atol=1e-12)
+    assert np.array_equal(single["vi"][0], q_ref)       # dense VI: numpy's order of additions on the device
 
 
 def test_world2_real_kernels_equal_world1(single):

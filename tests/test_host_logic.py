@@ -27,7 +27,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
-    assert native.load().mp_abi_version() == 4
+    assert native.load().mp_abi_version() == 5
 
 
 def test_context_fails_loudly_without_gpu_or_library(monkeypatch):
@@ -351,3 +351,44 @@ def test_availability_of_env_side_restrictions():
     from rl_agents_amd.envs import FiniteMDPEnv
     f = FiniteMDPEnv(dict(mode="deterministic", transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"]))
     assert device_model.available_actions_of(f, f.mdp) is None
+
+
+def test_vi_exact_plan_replays_numpy_add_reduce():
+    """mp_vi_exact_plan (host only): the leaves and additions the bit-exact dense backup follows, replayed here the way
+    the kernel does it -- eight strided accumulators per leaf, the three-level combine, the remainder one by one, the
+    recursion's additions height by height -- equal numpy.add.reduce bit for bit on every row length shape."""
+    from rl_agents_amd import native
+    g = np.random.Generator(np.random.PCG64(7))
+    for n in [1, 5, 7, 8, 9, 15, 16, 100, 127, 128, 129, 130, 255, 256, 257, 1000, 1029, 2500, 4099, 8191, 8192, 8193, 8200, 10000,
+              16384, 16385, 24576, 31250, 50000]:
+        leaves, nodes, hoff, nb_max = native.vi_exact_plan(n)
+        assert tuple(leaves[0]) == (0, 0) and leaves[-1].sum() == n and np.all(leaves[1:, 0] == leaves[:-1].sum(axis=1))
+        assert np.all(leaves[:, 1] <= 128) and nb_max == max(1, int(leaves[:, 1].max()) // 8) and len(nodes) == len(leaves) - 1
+        assert np.all(leaves[:-1, 1] % 8 == 0)                  # only the last leaf can have a remainder
+        assert len(hoff) - 1 >= -(-n // 8192)                   # one running-sum addition per 8192-element piece
+        for trial in range(3):
+            a = g.standard_normal(n) * np.exp(g.standard_normal(n) * 3)
+            slots = np.zeros(len(leaves) + len(nodes))
+            for l, (off, ln) in enumerate(leaves):
+                nb = ln // 8
+                if nb > 0:
+                    r = a[off:off + 8].copy()
+                    for i in range(1, nb):
+                        r = r + a[off + 8 * i:off + 8 * i + 8]
+                    res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]))
+                else:
+                    res = 0.0
+                for i in range(off + 8 * nb, off + ln):
+                    res = res + a[i]
+                slots[l] = res
+            written = np.zeros(len(slots), dtype=bool)
+            written[:len(leaves)] = True
+            for h in range(len(hoff) - 1):
+                ks = range(hoff[h], hoff[h + 1])
+                assert all(written[nodes[k, 0]] and written[nodes[k, 1]] for k in ks)   # operands come from lower heights
+                for k in ks:
+                    slots[len(leaves) + k] = slots[nodes[k, 0]] + slots[nodes[k, 1]]
+                for k in ks:
+                    written[len(leaves) + k] = True
+            assert hoff[-1] == len(nodes) and written.all()
+            assert slots[-1].tobytes() == np.add.reduce(a).tobytes(), (n, trial)

@@ -1,0 +1,49 @@
+"""The oracle's dense Bellman backup against NUMPY ITSELF on rows longer than numpy's reduction buffer.
+
+value_iteration.py:54-55 is `(T * v.reshape((1, 1, S))).sum(axis=-1)`.  numpy's add.reduce is a pairwise sum only
+within what the ufunc machinery hands the inner loop at a time: at most numpy.getbufsize() = 8192 elements, even for a
+contiguous aligned array.  A row of more than 8192 next states -- BASELINE's C2-dense (S = 10 000) and C5-dense
+(S = 50 000) -- is therefore the running sum, from 0., of the pairwise sums of its 8192-element pieces.  Every golden
+of the reference has S <= 130, so this is pinned here, on the expression the reference evaluates (numpy is importable;
+no reference code is needed for it).  Found in round 4: the oracle used one pairwise sum for the whole row, which
+differs in the last bits for S > 8192 (the tolerance test of the matrix-core kernel could not see it).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle
+
+
+@pytest.mark.parametrize("s", [8191, 8192, 8193, 8200, 10000, 16385, 24576, 50000])
+def test_dense_backup_rows_equals_numpy_expression(s):
+    assert np.getbufsize() == 8192
+    g = np.random.Generator(np.random.PCG64(s))
+    rows, a = 3, 2
+    t = g.random((rows, a, s))
+    t /= t.sum(-1, keepdims=True)
+    r = g.random((rows, a))
+    v = g.standard_normal(s) * 5
+    term = np.array([False, True, False])
+    next_v = (t * v.reshape((1, 1, v.size))).sum(axis=-1)   # value_iteration.py:54-55
+    next_v[term] = 0                                        # :62
+    ref = r + 0.95 * next_v                                 # :63
+    assert np.array_equal(oracle.dense_backup_rows(t, r, term, v, 0.95), ref)
+    # robust: min over two models, no terminal mask (robust_value_iteration.py:46-58)
+    t2 = np.stack([t, t[::-1]])
+    r2 = np.stack([r, r[::-1] * 0.9])
+    ref2 = np.min(r2 + 0.95 * (t2 * v.reshape((1, 1, 1, v.size))).sum(axis=-1), axis=0)
+    assert np.array_equal(oracle.dense_backup_rows(t2, r2, None, v, 0.95, robust=True), ref2)
+
+
+def test_vi_solve_long_rows_equals_numpy_loop():
+    """fixed_point_iteration (value_iteration.py:65-73) on a 9 000-state dense model, three sweeps, numpy against the oracle."""
+    s, a = 9000, 2
+    g = np.random.Generator(np.random.PCG64(1))
+    t = g.random((s, a, s))
+    t /= t.sum(-1, keepdims=True)
+    r = g.random((s, a))
+    q = np.zeros((s, a))
+    for _ in range(3):
+        q = r + 0.9 * (t * q.max(axis=-1).reshape((1, 1, s))).sum(axis=-1)
+    q_orc, sweeps = oracle.vi_solve("stochastic", t, r, None, gamma=0.9, iterations=3)
+    assert sweeps == 3 and np.array_equal(q_orc, q)
