@@ -835,7 +835,6 @@ int mp_model_load_sparse(mp_ctx *ctx, int32_t S, int32_t A, int32_t B, const dou
 {
     if (!ctx || !out || !transition || !reward || !next) return fail(MP_ERR_ARG, "mp_model_load_sparse: NULL argument");
     if (S < 1 || A < 1 || B < 1) return fail(MP_ERR_ARG, "mp_model_load_sparse: bad shape");
-    if (B > 128) return fail(MP_ERR_ARG, "mp_model_load_sparse: B=%d > 128 next-states per (s,a) not supported", B);
     const size_t n = (size_t)S * A * B;
     std::vector<int32_t> n32(n);
     for (size_t i = 0; i < n; ++i) {

@@ -27,6 +27,8 @@
 
 namespace mp {
 
+constexpr int kViPiece = 8192; // numpy.getbufsize(): what add.reduce hands its inner loop at a time (and the V window of VI_V_PIECES)
+
 typedef double double4_t __attribute__((ext_vector_type(4)));
 typedef double double4_u __attribute__((ext_vector_type(4), aligned(8)));
 
@@ -659,7 +661,6 @@ struct ViExactPlan {
 };
 
 enum { VI_V_GLOBAL = 0, VI_V_LDS = 1, VI_V_PIECES = 2 };
-constexpr int kViPiece = 8192; // numpy.getbufsize(): what add.reduce hands its inner loop at a time (and the V window of VI_V_PIECES)
 
 // VM: where the lanes read V from.  VI_V_LDS: all of it staged once per workgroup (it fits beside the tables up to ~14 000
 // states).  VI_V_PIECES: longer rows -- the 8192-element piece the workgroup's waves are summing, staged between two
@@ -980,7 +981,20 @@ __device__ __forceinline__ double np_sum_le128(int n, F elem)
     return res;
 }
 
+// numpy's pairwise recursion above the 128-element blocks (a thread's own row: B next states), and add.reduce's running sum
+// over the 8192-element pieces its iterator cuts a long row into (see vi_dense_exact_q)
+template <typename F>
+__device__ double np_pairwise(int off, int n, const F &elem)
+{
+    if (n <= 128) return np_sum_le128(n, [&](int i) { return elem(off + i); });
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    const double a = np_pairwise(off, n2, elem);
+    return a + np_pairwise(off + n2, n - n2, elem);
+}
+
 // value_iteration.py:56-59: (P * np.take(v, next)).sum(axis=-1)
+template <bool BIG>
 __global__ __launch_bounds__(256) void vi_sparse_q(ViGenArgs p)
 {
     if (p.k > 0 && p.notclose[p.k - 1] == 0) return;
@@ -990,7 +1004,13 @@ __global__ __launch_bounds__(256) void vi_sparse_q(ViGenArgs p)
     const double *pp = p.P + sa * p.B;
     const int32_t *nn = p.NXT + sa * p.B;
     const double *V = p.Vcur;
-    double nv = 0.0 + np_sum_le128(p.B, [&](int b) { return pp[b] * V[nn[b]]; });
+    auto elem = [&](int b) { return pp[b] * V[nn[b]]; };
+    double nv = 0.0;
+    if (BIG) { // more than 128 next states per (s, a): the recursion (device stack), piece by piece
+        for (int off = 0; off < p.B; off += kViPiece) nv += np_pairwise(off, min(kViPiece, p.B - off), elem);
+    } else {
+        nv += np_sum_le128(p.B, elem);
+    }
     if (p.term && p.term[s]) nv = 0.0;
     p.Qnext[sa] = p.R[sa] + p.gamma * nv;
 }
@@ -1215,7 +1235,8 @@ static int vi_run_impl(mp_ctx *ctx, mp_model *m, double gamma, int iterations, d
             if (m->mode == MP_MODE_STOCHASTIC) {
                 MP_TRY(vi_dense_launch(ctx, a, st, &launches));
             } else {
-                hipLaunchKernelGGL(vi_sparse_q, dim3(gq_sparse), dim3(256), 0, st, a);
+                if (a.B > 128) hipLaunchKernelGGL(vi_sparse_q<true>, dim3(gq_sparse), dim3(256), 0, st, a);
+                else hipLaunchKernelGGL(vi_sparse_q<false>, dim3(gq_sparse), dim3(256), 0, st, a);
                 ++launches;
             }
             hipLaunchKernelGGL(vi_finish, dim3(gs), dim3(256), 0, st, a);

@@ -47,3 +47,18 @@ def test_vi_solve_long_rows_equals_numpy_loop():
         q = r + 0.9 * (t * q.max(axis=-1).reshape((1, 1, s))).sum(axis=-1)
     q_orc, sweeps = oracle.vi_solve("stochastic", t, r, None, gamma=0.9, iterations=3)
     assert sweeps == 3 and np.array_equal(q_orc, q)
+
+
+@pytest.mark.parametrize("b", [129, 1000, 8200])
+def test_sparse_rows_beyond_one_block_equal_numpy_loop(b):
+    """Sparse mode (value_iteration.py:56-59) with more next states per (s, a) than a pairwise block / than the buffer."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_sparse(23, 2, b, seed=b, terminal_rate=0.1)
+    q = np.zeros((23, 2))
+    for _ in range(3):
+        next_v = (cfg["transition"] * np.take(q.max(axis=-1), cfg["next"])).sum(axis=-1)
+        next_v[cfg["terminal"]] = 0
+        q = cfg["reward"] + 0.9 * next_v
+    q_orc, sweeps = oracle.vi_solve("sparse", cfg["transition"], cfg["reward"], cfg["terminal"], gamma=0.9, iterations=3,
+                                    next_states=cfg["next"])
+    assert sweeps == 3 and np.array_equal(q_orc, q)
