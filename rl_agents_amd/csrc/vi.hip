@@ -301,19 +301,26 @@ __global__ __launch_bounds__(1024) void vi_det_persist(ViPersistArgs q)
 #pragma unroll
             for (int a = 0; a < AT; ++a) vc[a] = 0.0;
             if (k > 0 && own) {
-                const gu64_t *slot = ring + (long)(k % kRing) * S * 2;
+                // Both granules of a successor with ONE 16-byte L1-bypassing (sc1) load -- half the requests in the CU's
+                // memory queue, where a hand-off's latency sits: 2.45-2.5 against 2.7 us per sweep at C2 (each half is
+                // validated by its own tag, so a load torn between the two 8-byte stores is simply not ready yet).
+                // Measured and dropped (round 4, profiles/r04_vi_persist_ab.txt): several probes in flight a fraction of a
+                // round trip apart (3.4-4.9 us: the extra requests queue in front of the ones that matter), and the same solve
+                // with single-wave workgroups and the arrival word sharded 64 ways (2.9 us at C2, 19 us at S = 50 000).
+                const __amdgpu_buffer_rsrc_t rsrc =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)(q.Vring + (long)(k % kRing) * S * 2), 0, S * 16, 0x00020000);
                 unsigned spins = 0;
                 while (true) {
                     bool all = true;
 #pragma unroll
                     for (int a = 0; a < AT; ++a) {
-                        const unsigned long long lo = __hip_atomic_load(slot + 2L * t[m][a], MP_RLX_AGENT);
-                        const unsigned long long hi = __hip_atomic_load(slot + 2L * t[m][a] + 1, MP_RLX_AGENT);
-                        all &= (unsigned)(lo >> 32) == (unsigned)k && (unsigned)(hi >> 32) == (unsigned)k;
-                        vc[a] = __hiloint2double((int)(unsigned)hi, (int)(unsigned)lo);
+                        const uint4 g = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, t[m][a] * 16, 0, 16));
+                        all &= g.y == (unsigned)k && g.w == (unsigned)k;
+                        vc[a] = __hiloint2double((int)g.z, (int)g.x);
                     }
                     if (all) break;
                     if (++spins > kSpinLimit || __hip_atomic_load(tmo, MP_RLX_AGENT)) { ok = false; break; }
+                    asm volatile("" ::: "memory"); // (the next probe reads memory again)
                 }
             }
 #pragma unroll
