@@ -30,7 +30,8 @@
 
 namespace mp {
 
-constexpr int kMaxModels = 32; // (one terminal flag per model in a 32-bit word of the node)
+// (one terminal flag per model in a 32-bit word of the node; from the 33rd model on the flag rides in the sign bit of the
+// stored reward -- rewards are range-checked to [0, 1], and 0. with the flag is -0. -- so the number of models is not bounded)
 
 struct ROpdArgs {
     int n_roots, M, S, A, K, cap, done_on_next, max_plan_len;
@@ -188,8 +189,8 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                     }
                     Lv[(long)c * M + m] = Lc;
                     Sv[(long)c * M + m] = nxt;
-                    Rv[(long)c * M + m] = r;
-                    dbits |= (dn ? 1u : 0u) << m;
+                    Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                    if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                     if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                     if (m == 0 || Uc < umin) umin = Uc;
                 }
@@ -274,8 +275,8 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                 }
                 Lv[(long)c * M + m] = Lc;
                 Sv[(long)c * M + m] = rc.next;
-                Rv[(long)c * M + m] = r;
-                dbits |= (dn ? 1u : 0u) << m;
+                Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                 if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                 if (m == 0 || Uc < umin) umin = Uc;
             }
@@ -497,8 +498,8 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
                 }
                 Lv[(long)c * M + m] = Lc;
                 Sv[(long)c * M + m] = rc.next;
-                Rv[(long)c * M + m] = r;
-                dbits |= (dn ? 1u : 0u) << m;
+                Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                 if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                 if (m == 0 || Uc < umin) umin = Uc;
             }
@@ -669,8 +670,8 @@ __global__ __launch_bounds__(64) void ropd_any_kernel(ROpdArgs p)
                     }
                     Lv[(long)c * M + m] = Lc;
                     Sv[(long)c * M + m] = rc.next;
-                    Rv[(long)c * M + m] = r;
-                    dbits |= (dn ? 1u : 0u) << m;
+                    Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                    if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                     if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                     if (m == 0 || Uc < umin) umin = Uc;
                 }
@@ -781,7 +782,6 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
         return fail(MP_ERR_MODE, "mp_ropd_plan: needs a joint model (mp_model_load_joint)");
     const int A = model->A, M = model->M;
     const bool any_a = A > 64; // more actions than lanes: the plain kernel (ropd_any_kernel)
-    if (M > kMaxModels) return fail(MP_ERR_ARG, "mp_ropd_plan: %d models > %d not supported", M, kMaxModels);
     if (n_roots < 1 || budget < 0 || max_plan_len < 0) return fail(MP_ERR_ARG, "mp_ropd_plan: bad sizes");
     const int K = budget / A; // deterministic.py:118
     if (K > 0 && !(gamma != 1.0))
@@ -948,10 +948,10 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
         if (first_child) first_child[o] = first;
         if (n_children) n_children[o] = nc;
         for (int m = 0; m < M; ++m) {
-            const bool dn = ((uint32_t)meta[2 * i + 1] >> m) & 1u;
             const size_t j = (size_t)i * M + m, jo = (size_t)o * M + m;
+            const bool dn = m < 32 ? (((uint32_t)meta[2 * i + 1] >> m) & 1u) != 0 : std::signbit(rv[j]);
             if (state) state[jo] = sv[j];
-            if (reward) reward[jo] = rv[j];
+            if (reward) reward[jo] = m < 32 ? rv[j] : fabs(rv[j]);
             if (done) done[jo] = (uint8_t)dn;
             // a leaf keeps its vectors (U recomputed as update() computed it, deterministic.py:51-59: same host
             // operations as the planning tables); an expanded node holds the backed-up scalars

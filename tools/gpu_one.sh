@@ -1,3 +1,3 @@
 #!/bin/bash
 cd /root/repo
-python -X faulthandler -m pytest tests -m gpu -x -q -k "sparse or dense or vi" 2>&1 | grep -v "Extension modules" | tail -6 | cut -c1-220
+python -X faulthandler -m pytest tests -m gpu -x -q -k "robust" 2>&1 | grep -v "Extension modules" | tail -15 | cut -c1-220
