@@ -391,7 +391,7 @@ int mp_model_set_available_joint(mp_model *model, const uint8_t *available);
  * update (:45-65): per-model lower / upper bounds; backup_to_root (:74-79) on the minima over the models }, then get_plan
  * with selection_rule (:21-26) on min_m L.  Rewards outside [0,1] in ANY model: status MP_ERR_REWARD_RANGE.
  *   root_state int32 [n_roots,M] (usually the same state M times); root_lower / root_upper = min over the models of
- *   the root's bounds; everything else as mp_opd_plan.  At most 32 models (one terminal flag per model in a 32-bit word).
+ *   the root's bounds; everything else as mp_opd_plan.  Any number of models (the reference steps a list, robust.py:9-16).
  */
 int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget, double gamma,
                  double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len,

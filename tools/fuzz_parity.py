@@ -102,7 +102,7 @@ def one_case(ctx, g, case):
             q_ref, sweeps_ref = oracle.vi_solve("deterministic", tm, rm, None, gamma=gamma, iterations=iterations, robust=True)
             eq(q, q_ref, "robust Q", desc)
         elif which == 2:
-            b = int(g.choice([1, 2, 5]))
+            b = int(g.choice([1, 2, 5, 8, 9, 127, 128, 129, 300]))
             nxt = g.integers(0, s, size=(s, a, b), dtype=np.int64)
             pr = g.random((s, a, b)) + 0.01
             pr /= pr.sum(-1, keepdims=True)
@@ -111,18 +111,48 @@ def one_case(ctx, g, case):
             q_ref, sweeps_ref = oracle.vi_solve("sparse", pr, rewards, term, gamma=gamma, iterations=iterations, next_states=nxt)
             eq(q, q_ref, "sparse Q", desc)
         else:
-            sd = min(s, 300)
-            pr = g.random((sd, a, sd)) ** 3 + 1e-3
+            # dense: any row length (every shape of numpy's pairwise recursion); a few cases beyond its 8192-element buffer
+            sd = int(g.choice([1, 2, 5, 7, 8, 9, 17, 64, 100, 127, 128, 129, 130, 200, 257, 300, 500, 1029])) if g.random() < 0.85 \
+                else int(g.choice([8193, 9000]))
+            ad = a if sd <= 1029 else 1
+            sparse_rows = g.random() < 0.3                              # exact zeros in the rows
+            pr = g.random((sd, ad, sd)) ** 3 + 1e-3
+            if sparse_rows:
+                pr[g.random((sd, ad, sd)) < 0.5] = 0.0
+                pr[..., 0] += 1e-3
             pr /= pr.sum(-1, keepdims=True)
-            rd, td = rewards[:sd], term[:sd]
+            rd = (g.random((sd, ad)) if sd > s else np.resize(rewards, (sd, a))[:, :ad]) * 1.0
+            td = g.random(sd) < 0.1
+            if sd > 1029:
+                iterations = min(iterations, 7)
+            desc.update(dense_states=sd, dense_actions=ad)
             model = ctx.load_dense(pr, rd, td)
-            q, sweeps = ctx.vi_solve(model, gamma, iterations)
             q_ref, sweeps_ref = oracle.vi_solve("stochastic", pr, rd, td, gamma=gamma, iterations=iterations)
-            if not np.allclose(q, q_ref, rtol=1e-12, atol=1e-12 * max(1.0, float(np.abs(q_ref).max()))):
-                raise AssertionError("dense Q differs beyond 1e-12 in case {}".format(desc))
-            if abs(sweeps - sweeps_ref) > 1:
-                raise AssertionError("dense sweeps {} vs {} in case {}".format(sweeps, sweeps_ref, desc))
-            sweeps = sweeps_ref
+            forms = [("exact", None)]
+            if sd <= 1029:
+                forms += [("exact", "global"), ("exact", "pieces"), ("mfma", None)]
+            form, vmode = forms[int(g.integers(0, len(forms)))]
+            desc.update(dense_form=form, dense_v=vmode)
+            os.environ.pop("MP_VI_EXACT_V", None)
+            if vmode:
+                os.environ["MP_VI_EXACT_V"] = vmode
+            ctx.vi_dense_mode(form)
+            try:
+                q, sweeps = ctx.vi_solve(model, gamma, iterations)
+                if form == "exact" and sd <= 1029:
+                    eq(ctx.vi_solve_v(model, gamma, iterations),
+                       oracle.vi_solve("stochastic", pr, rd, td, gamma=gamma, iterations=iterations, state_value=True), "dense V", desc)
+            finally:
+                ctx.vi_dense_mode("exact")
+                os.environ.pop("MP_VI_EXACT_V", None)
+            if form == "exact":
+                eq(q, q_ref, "dense Q (numpy's order)", desc)
+            else:
+                if not np.allclose(q, q_ref, rtol=1e-12, atol=1e-12 * max(1.0, float(np.abs(q_ref).max()))):
+                    raise AssertionError("dense Q differs beyond 1e-12 in case {}".format(desc))
+                if abs(sweeps - sweeps_ref) > 1:
+                    raise AssertionError("dense sweeps {} vs {} in case {}".format(sweeps, sweeps_ref, desc))
+                sweeps = sweeps_ref
         if sweeps != sweeps_ref:
             raise AssertionError("sweeps {} vs {} in case {}".format(sweeps, sweeps_ref, desc))
     elif kind == "uct_subtree":     # step_strategy "subtree": plan, re-root at the executed action, plan again
@@ -322,7 +352,7 @@ def one_case(ctx, g, case):
                 eq(tree[k], one[k], "tree " + k, desc)
             eq(tree["lower"].min(axis=1), one["lower"].min(axis=1), "tree min lower", desc)
     elif kind == "ropd":            # discrete robust OPD (agents/robust/robust.py:28-50): M models, joint states
-        m = int(g.choice([1, 2, 3, 7]))
+        m = int(g.choice([1, 2, 3, 7, 33, 40]))   # (more than 32 models: round 4)
         tm = np.stack([t] + [g.integers(0, s, size=(s, a), dtype=np.int64) for _ in range(m - 1)])
         rm = np.stack([r] + [np.clip(r * float(g.uniform(0.5, 1.0)), 0.0, 1.0) for _ in range(m - 1)])
         termm = np.stack([term] + [g.random(s) < 0.1 for _ in range(m - 1)])
