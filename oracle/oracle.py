@@ -150,7 +150,9 @@ def opd_plan(transition, reward, terminal, s0, budget, gamma, terminal_reward=0.
     s, a = r.shape
     av = None if available is None else _u8(np.asarray(available).reshape(s, a))
     cap = 1 + (budget // a) * a
-    rng = np.array(rng_state if rng_state is not None else np.zeros(6), dtype=np.uint64)
+    # (default: a valid PCG64 record -- an all-zero one has an even increment and the bounded-draw rejection loop of a tie-break
+    # never ends on it)
+    rng = np.array(rng_state if rng_state is not None else [0, 1, 0, 1, 0, 0], dtype=np.uint64)
     plan = np.full(max_plan_len, -1, dtype=np.int32)
     plan_len, steps = C.c_int32(), C.c_int64()
     lo, up = C.c_double(), C.c_double()
