@@ -1,17 +1,14 @@
 #!/bin/bash
 cd /root/repo
-mkdir -p gpurun_out/r04z
-( time python bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/r04z/bench_2rank.json 2> gpurun_out/r04z/bench_2rank.err ) 2>&1 | tail -3
-echo "rc=$?"
-tail -c 1500 gpurun_out/r04z/bench_2rank.json
-tail -5 gpurun_out/r04z/bench_2rank.err
-( time python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 5 --warmup 2 > gpurun_out/r04z/bench_2rank_tr.json 2> gpurun_out/r04z/bench_2rank_tr.err ) 2>&1 | tail -3
-python - <<'PY'
-import json
-for f in ('gpurun_out/r04z/bench_2rank.json', 'gpurun_out/r04z/bench_2rank_tr.json'):
-    try:
-        d = json.loads([l for l in open(f) if l.startswith('{')][-1])
-        print(f, d['n_gpus'], d['value'], d['ranks'], d['scaling'])
-    except Exception as e:
-        print(f, 'ERR', e)
-PY
+for L in 64 32 16 8 4 2 1; do
+  echo "== cartpole lanes $L"
+  MP_UCT_LANES=$L python bench.py --workload uct_cartpole --steps 10 --warmup 2 --no-cpu-baseline --headline-only 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']; print('  value %.4g kernel_ms %.4f parity %s' % (d['value'], r['kernel_ms'], (d.get('parity_sample') or {}).get('result')))"
+done
+for L in 64 16 8 4; do
+  echo "== uct 4096 roots lanes $L"
+  MP_UCT_LANES=$L python bench.py --workload uct --roots 4096 --steps 10 --warmup 2 --no-cpu-baseline --headline-only --no-parity-sample 2>/dev/null | python -c "
+import json,sys
+d=json.loads([l for l in sys.stdin if l.startswith('{')][-1]); r=d['roofline']; print('  value %.4g kernel_ms %.4f' % (d['value'], r['kernel_ms']))"
+done
