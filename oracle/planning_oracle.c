@@ -19,8 +19,11 @@
  *     (next64 >> 11) * 2^-53, next_uint32 buffering of the high half, and the bounded-integer
  *     draw used by Generator.integers/choice (Lemire multiply-shift with rejection on the
  *     buffered 32-bit stream).  Pinned against numpy 2.2.6 draws in tests/golden/misc.npz.
- *   - numpy add.reduce over a contiguous axis (pairwise summation, blocks of 128, 8 lanes),
- *     needed for (T * v).sum(-1) in dense/sparse value iteration.
+ *   - numpy add.reduce over a contiguous axis (pairwise summation, blocks of 128, 8 lanes, and -- rows longer than
+ *     numpy.getbufsize() = 8192 elements -- the running sum over the 8192-element pieces the reduction's iterator cuts
+ *     them into), needed for (T * v).sum(-1) in dense/sparse value iteration.  Pinned against numpy 2.2.6 ITSELF (the
+ *     expression the reference evaluates) for rows of 8191 .. 50 000 elements in tests/test_oracle_vi_long_rows.py: the
+ *     reference's goldens stop at 130 states.
  *   - numpy.allclose (rtol 1e-5, atol 1e-8) early exit.
  */
 #include <math.h>
