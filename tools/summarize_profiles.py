@@ -50,11 +50,14 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "rvi_dense_shard"):
+    for wl in ("uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "vi_dense_exact",
+               "rvi_dense_shard", "rvi_dense_shard_exact"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
-        lines += ["## " + wl + (" (= --workload opd --roots 8192)" if wl == "opd8192" else ""), "",
+        lines += ["## " + wl + (" (= --workload opd --roots 8192)" if wl == "opd8192" else
+                                " (= --workload rvi_dense_shard --dense-mode exact)" if wl == "rvi_dense_shard_exact" else
+                                " (--dense-mode mfma)" if wl == "rvi_dense_shard" else ""), "",
                   "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
         for name, calls, avg, pct in kernel_stats(f):
             lines.append("| `{}` | {} | {:.2f} | {:.2f} |".format(name.replace("|", "/"), calls, avg, pct))
@@ -69,7 +72,8 @@ def main():
                     name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
             lines.append("")
     traffic = {}
-    for wl in ("uct", "uct_prior", "uct_stoch", "vi_dense", "rvi_dense_shard", "opd", "opd8192", "ropd", "saopd"):
+    for wl in ("uct", "uct_prior", "uct_stoch", "vi_dense", "vi_dense_exact", "rvi_dense_shard", "rvi_dense_shard_exact", "opd", "opd8192",
+               "ropd", "saopd"):
         entry = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             f = os.path.join(src, "pmc_{}_{}".format(wl, ctr), wl + "_counter_collection.csv")
