@@ -1,3 +1,4 @@
 #!/bin/bash
+# one short, bounded GPU command (always under `timeout`)
 cd /root/repo
-MI355PLAN_LIB=build_variants/prof/libmi355plan.so timeout 300 python bench.py --workload saopd --no-cpu-baseline --no-parity-sample --steps 1 --warmup 0 2>/dev/null | grep "saopd prof" | tail -8
+timeout 120 python -X faulthandler -m pytest tests -m gpu -x -q -k "stoch" 2>&1 | grep -v "Extension modules" | tail -6 | cut -c1-220
