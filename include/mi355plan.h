@@ -255,7 +255,9 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
  * the policy is asked about.  On a finite MDP that is a table:
  *   prior   double [S,A]  prior[s,a]   = probability handed to MCTSNode.expand when a node reached in state s is expanded
  *   rollout double [S,A]  rollout[s,:] = distribution MCTS.evaluate samples from in state s (Generator.choice(p=...))
- * Host pointers (policy upload is outside every timed region, like model upload).  |A| must be in 2..8.
+ * Host pointers (policy upload is outside every timed region, like model upload).  Any |A| >= 2: mp_uct_plan_policy
+ * (nodes' policy rows in registers) plans with 2..8 actions; beyond that mp_uct_plan_stochastic_policy does -- its loop
+ * forms take any number of actions and deterministic tables as well as stochastic / sparse models.
  * A policy is tied to the model it was loaded for (its records are fused into the policy tables): use it with that
  * model only (checked) and free it before the model.
  * mp_uct_plan_policy = mp_uct_plan with (prior_p, rollout_p) looked up per state; everything else is identical,

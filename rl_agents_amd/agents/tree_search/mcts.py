@@ -175,12 +175,26 @@ class MCTS(AbstractPlanner):
                                                                   available=available, action_order=tree_order))
         return super(MCTS, self).model_for(state)
 
+    def loop_form(self, model):
+        """Per-state policies (restricted action sets, prior agents) over MORE THAN 8 ACTIONS on a deterministic table: the
+        kernel of the stochastic models plans on deterministic ones too and has loop forms for any number of actions
+        (uct.hip keeps a node's policy rows in registers: 2..8 actions).  Same planner, same results: the reference does
+        not distinguish the two kinds of environment."""
+        if model.mode != native_modes.MODE_DETERMINISTIC or model.A <= 8:
+            return False
+        if self.policy_source is None and getattr(model, "available", None) is None:
+            return False
+        if self.action_order(model) is not None:
+            raise NotImplementedError("per-state policies over more than 8 actions on an environment that lists them in a "
+                                      "non-ascending order are not supported on the device")
+        return True
+
     def plan_batch_stochastic(self, state, model, root_states, root_steps, rng_states, env_rng_states=None):
         """The stochastic-model path (uct_stoch.hip): every root's episodes replay the noise of the ENV's generator as it
         is at plan time (clones copy it, common/factory.py:119-134); closed loop keys the tree by observed next states."""
         from rl_agents_amd import native
         n, cfg = len(root_states), self.config
-        if env_rng_states is None:
+        if env_rng_states is None and model.mode != native_modes.MODE_DETERMINISTIC:   # (a deterministic table draws nothing)
             gen = getattr(getattr(state, "unwrapped", state), "np_random", None)
             if gen is None:
                 raise TypeError("a stochastic environment must expose its numpy generator as `np_random`")
@@ -216,7 +230,7 @@ class MCTS(AbstractPlanner):
         n = len(root_states)
         if rng_states is None:
             rng_states = self.batch_rng_states(n)
-        if model.mode in (native_modes.MODE_STOCHASTIC, native_modes.MODE_SPARSE):
+        if model.mode in (native_modes.MODE_STOCHASTIC, native_modes.MODE_SPARSE) or self.loop_form(model):
             # (open-loop trees are re-used like the deterministic ones: mp_uct_step_tree armed the re-rooting)
             armed, self._armed = self._armed and n == 1 and not self.config["closed_loop"], False
             if keep_actions is not None and self.owns_device_tree() and not self.config["closed_loop"] and self._tree_roots == n:
@@ -284,10 +298,10 @@ class MCTS(AbstractPlanner):
         are re-rooted under them (abstract.py:195-206) instead of being reset."""
         cfg, ctx = self.config, self.models.ctx
         self.about_to_plan()
-        if model.mode != native_modes.MODE_DETERMINISTIC:
+        if model.mode != native_modes.MODE_DETERMINISTIC or self.loop_form(model):
             # stochastic / sparse models: the episodes' env generator records are a device buffer too (d_env_rng: every
             # plan's clones start from the env generator as it is at that step; mp_env_step_stochastic advances it)
-            if d_env_rng is None:
+            if d_env_rng is None and model.mode != native_modes.MODE_DETERMINISTIC:
                 raise ValueError("a stochastic model needs the episodes' env generator records (d_env_rng)")
             armed = keep_actions is not None and self.owns_device_tree() and self._tree_roots == n and not cfg["closed_loop"]
             if armed:

@@ -236,6 +236,7 @@ struct mp_policy {
     uint4 *frec_roll = nullptr; // the same records by ROLLOUT slot (mp_policy_load_ordered), nullptr when the orders agree
     uint32_t *lmask = nullptr;  // policies of STOCHASTIC models (uct_stoch.hip): actions the prior policy lists per state, [S]
     uint8_t *rslot = nullptr;   // ... and the column of every rollout slot, [S][A], nullptr when slots are the columns
+    uint8_t *listed8 = nullptr; // ... the listed actions as a byte per action, [S][A], when |A| > 32 (lmask is 32 bits wide)
 };
 
 namespace mp {

@@ -894,6 +894,9 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     if (!ctx || !model || !root_state || !rng_state || (!pol && (!prior_p || !rollout_p)))
         return fail(MP_ERR_ARG, "mp_uct_plan: NULL argument");
     const bool cart = model->mode == MP_MODE_CARTPOLE;
+    if (pol && !cart && pol->model == model && pol->model_serial == model->serial && pol->ctx == ctx && !pol->frec && pol->A > 8)
+        return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not in 2..8: per-state policies over more actions plan through "
+                                "mp_uct_plan_stochastic_policy (it takes deterministic tables too)", pol->A);
     if (pol && (cart || pol->model != model || pol->model_serial != model->serial || pol->ctx != ctx || !pol->frec))
         return fail(MP_ERR_ARG, "mp_uct_plan_policy: the policy was not loaded for this model");
     if (model->mode != MP_MODE_DETERMINISTIC && !cart)
@@ -1176,7 +1179,8 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         case 7: MP_TRY(uct_launch<7>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
         default:
-            if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not in 2..8", A);
+            if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not in 2..8: per-state policies over more actions plan through "
+                                             "mp_uct_plan_stochastic_policy (it takes deterministic tables too)", A);
             MP_TRY(uct_launch<0>(c, ldsm, lds, s, false, false, false, spill));
             break;
         }
@@ -1274,7 +1278,11 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
     if (!stoch && (model->mode != MP_MODE_DETERMINISTIC || !model->rec))
         return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a finite-MDP model");
     const int S = model->S, A = model->A;
-    if (A < 2 || A > 8) return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d is not in 2..8", A);
+    if (A < 2) return fail(MP_ERR_ARG, "mp_policy_load: |A| = %d", A);
+    if (rollout_slot && A > 256) return fail(MP_ERR_ARG, "mp_policy_load_ordered: rollout slots hold a byte per column (|A| = %d > 256)", A);
+    // More than 8 actions (round 4): the policy of the loop-form kernel (uct_stoch.hip plans on deterministic tables too): priors,
+    // thresholds, listed actions -- no fused records, whatever the model's mode
+    const bool loop_form = stoch || A > 8;
     MP_HIP(hipSetDevice(ctx->device));
     const int stride = (A + 1) & ~1, frq = 1 + (A - 1 + 3) / 4;
     std::vector<double> hp((size_t)S * stride, 0.0);
@@ -1283,15 +1291,16 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
     auto col = [&](int s, int k) { return rollout_slot ? (int)rollout_slot[(size_t)s * A + k] : k; };
     if (rollout_slot)
         for (int s = 0; s < S; ++s) {
-            uint32_t seen = 0;
+            std::vector<uint8_t> seen((size_t)A, 0);
             for (int k = 0; k < A; ++k) {
                 const int c = rollout_slot[(size_t)s * A + k];
-                if (c >= A || (seen >> c) & 1u) return fail(MP_ERR_ARG, "mp_policy_load_ordered: rollout_slot of state %d is not a permutation", s);
-                seen |= 1u << c;
+                if (c >= A || seen[(size_t)c]) return fail(MP_ERR_ARG, "mp_policy_load_ordered: rollout_slot of state %d is not a permutation", s);
+                seen[(size_t)c] = 1;
             }
         }
     for (int s = 0; s < S; ++s) {
-        double cdf[8], acc = 0.0;
+        std::vector<double> cdf((size_t)A);
+        double acc = 0.0;
         for (int a = 0; a < A; ++a) {
             const double q = rollout[(size_t)s * A + col(s, a)], pr = prior[(size_t)s * A + a];
             if (!(q >= 0.0) || !(pr >= 0.0)) return fail(MP_ERR_ARG, "mp_policy_load: negative or NaN probability in state %d", s);
@@ -1304,15 +1313,22 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
             ht[(size_t)s * stride + a] = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
         }
     }
-    if (stoch) {
+    if (loop_form) {
         // a stochastic model's kernel stores priors in the tree and reads thresholds by state: prior / thresholds / listed
         // masks (+ the rollout slots' columns) are all it needs -- no fused records
-        std::vector<uint32_t> lm((size_t)S, (1u << A) - 1u);
+        std::vector<uint32_t> lm((size_t)S, A >= 32 ? 0xffffffffu : (1u << A) - 1u);
+        std::vector<uint8_t> l8(A > 32 ? (size_t)S * A : 0, 1); // more than 32 actions: a byte per action
         if (listed)
             for (int s = 0; s < S; ++s) {
                 uint32_t m = 0;
-                for (int a = 0; a < A; ++a) m |= (listed[(size_t)s * A + a] ? 1u : 0u) << a;
-                if (!m) return fail(MP_ERR_ARG, "mp_policy_load_listed: the prior policy lists no action in state %d", s);
+                bool any = false;
+                for (int a = 0; a < A; ++a) {
+                    const bool on = listed[(size_t)s * A + a] != 0;
+                    any |= on;
+                    if (a < 32) m |= (on ? 1u : 0u) << a;
+                    if (A > 32) l8[(size_t)s * A + a] = on ? 1 : 0;
+                }
+                if (!any) return fail(MP_ERR_ARG, "mp_policy_load_listed: the prior policy lists no action in state %d", s);
                 lm[(size_t)s] = m;
             }
         mp_policy *pol = new (std::nothrow) mp_policy;
@@ -1321,6 +1337,7 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
         pol->listed = listed ? 1 : 0;
         if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
             hipMalloc(&pol->lmask, lm.size() * 4) != hipSuccess ||
+            (!l8.empty() && hipMalloc(&pol->listed8, l8.size()) != hipSuccess) ||
             (rollout_slot && hipMalloc(&pol->rslot, (size_t)S * A) != hipSuccess)) {
             mp_policy_free(pol);
             return fail(MP_ERR_ALLOC, "mp_policy_load: device allocation failed");
@@ -1328,6 +1345,7 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
         MP_HIP(hipMemcpy(pol->prior, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
         MP_HIP(hipMemcpy(pol->thr, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
         MP_HIP(hipMemcpy(pol->lmask, lm.data(), lm.size() * 4, hipMemcpyHostToDevice));
+        if (!l8.empty()) MP_HIP(hipMemcpy(pol->listed8, l8.data(), l8.size(), hipMemcpyHostToDevice));
         if (rollout_slot) MP_HIP(hipMemcpy(pol->rslot, rollout_slot, (size_t)S * A, hipMemcpyHostToDevice));
         *out = pol;
         return MP_OK;
@@ -1412,6 +1430,7 @@ int mp_policy_free(mp_policy *policy)
     if (policy->frec_roll) (void)hipFree(policy->frec_roll);
     if (policy->lmask) (void)hipFree(policy->lmask);
     if (policy->rslot) (void)hipFree(policy->rslot);
+    if (policy->listed8) (void)hipFree(policy->listed8);
     delete policy;
     return MP_OK;
 }

@@ -59,7 +59,8 @@ struct StochArgs {
     // per-state policies (mp_policy of a stochastic model): nullptr for the state-independent ones
     const double *pol_prior;   // [S][pol_stride]  prior[s][a], 0 for the actions the prior policy does not list
     const uint64_t *pol_thr;   // [S][pol_stride]  ceil(cdf * 2^53) of the rollout policy, by rollout slot
-    const uint32_t *pol_mask;  // [S]  actions the prior policy lists
+    const uint32_t *pol_mask;  // [S]  actions the prior policy lists (|A| <= 32)
+    const uint8_t *pol_listed; // [S][A] the same as a byte per action (more than 32 actions), else nullptr
     const uint8_t *pol_rslot;  // [S][A] column of rollout slot k, or nullptr (slots are the columns)
     int pol_stride;
     double temperature;
@@ -205,7 +206,7 @@ __global__ void compact_records16(long rows, const uint4 *__restrict__ rec32, co
 template <int WB, int AT, typename PT, bool SP = false>
 __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
 {
-    static_assert(!SP || AT > 0, "per-state policies: |A| at compile time");
+    // (SP with AT == 0: per-state policies over any number of actions -- the loop forms below, round 4)
     extern __shared__ __attribute__((aligned(16))) double lds_s[];
     const int lane = threadIdx.x, A = AT > 0 ? AT : p.A, H = p.horizon, E = p.episodes;
     constexpr int AR = AT > 0 ? AT : 1;
@@ -396,17 +397,31 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                     if (eq && !found) --pick;
                 }
             } else {
+                double TAk = 0.0;
+                if (SP) { // len(children) = the listed slots of this group (a phantom slot has count < 0)
+                    int nl = 0;
+                    for (int a = 0; a < A; ++a) nl += hot[fc + a].count >= 0 ? 1 : 0;
+                    TAk = p.temperature * (double)nl; // mcts.py:286, left to right
+                }
+                auto score = [&](const SHot &c, int a) -> double {
+                    if (SP) {
+                        if (c.count < 0) return -INFINITY;
+                        const double pr = *reinterpret_cast<const double *>(&cold[fc + a]); // the prior stored at expansion
+                        return c.value + (TAk * pr) / (double)(c.count + 1);
+                    }
+                    return c.value + explore(a, c.count + 1);
+                };
                 double m = 0.0;
                 int nt = 0;
                 for (int a = 0; a < A; ++a) {
                     const SHot c = hot[fc + a];
-                    const double sc = c.value + explore(a, c.count + 1);
+                    const double sc = score(c, a);
                     if (a == 0 || sc > m) { m = sc; nt = 1; } else if (sc == m) ++nt;
                 }
                 int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
                 for (int a = 0; a < A; ++a) {
                     const SHot c = hot[fc + a];
-                    const double sc = c.value + explore(a, c.count + 1);
+                    const double sc = score(c, a);
                     if (sc == m) {
                         if (pick == 0) { act = a; act_first = c.first; act_c = c.count; act_v = c.value; break; }
                         --pick;
@@ -461,10 +476,12 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             const int c0 = n_nodes;
             if (SP) { // prior_policy(state, observation) of the state the clone is in now
                 const uint32_t mask = p.pol_mask[s];
+                const uint8_t *lrow = p.pol_listed ? p.pol_listed + (long)s * A : nullptr; // more than 32 actions: a byte per action
                 const double *row = p.pol_prior + (long)s * p.pol_stride;
                 for (int a = 0; a < A; ++a) {
                     SHot h;
-                    h.value = 0.0; h.count = (mask >> a) & 1u ? 0 : -1; h.first = -1;
+                    const bool is_listed = lrow ? lrow[a] != 0 : ((mask >> (a & 31)) & 1u) != 0;
+                    h.value = 0.0; h.count = is_listed ? 0 : -1; h.first = -1;
                     hot[c0 + a] = h;
                     *reinterpret_cast<double *>(&cold[c0 + a]) = row[a];
                 }
@@ -486,8 +503,12 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                 int a = 0;
                 if (SP) { // rollout_policy(state, observation): the thresholds of the state the clone is in
                     const uint64_t *tr = p.pol_thr + (long)s * p.pol_stride;
+                    if (AT > 0) {
 #pragma unroll
-                    for (int j = 0; j < AR - 1; ++j) a += tr[j] <= k ? 1 : 0;
+                        for (int j = 0; j < AR - 1; ++j) a += tr[j] <= k ? 1 : 0;
+                    } else {
+                        for (int j = 0; j < A - 1; ++j) a += tr[j] <= k ? 1 : 0;
+                    }
                     if (p.pol_rslot) a = p.pol_rslot[(long)s * A + a];
                 } else if (AT > 0) {
 #pragma unroll
@@ -855,7 +876,10 @@ static int uct_stoch_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *po
     const int wbk = wb ? model->srec_wb : 0; // the form the records really have (1: compact)
 
     // per-call tables, computed on the host exactly as Python computes them (see uct_plan_impl)
-    const int TE = E < 512 ? E : 512; // the quotient tables live in LDS: longer plans divide beyond them
+    int TE = E < 512 ? E : 512; // the quotient tables live in LDS: longer plans divide beyond them
+    // (any number of actions: the [A][TE + 2] table of the state-independent prior must leave room for the path stack; counts
+    // beyond the tables take the IEEE division itself -- the same quotients)
+    while (TE > 1 && (size_t)A * (TE + 2) * sizeof(double) > 24 * 1024) TE >>= 1;
     const size_t ntab = (size_t)(H + 1) + 2 * (size_t)A + (size_t)(TE + 1) + (size_t)A * (TE + 2);
     std::vector<double> tab(ntab);
     double *gpow = tab.data(), *cdf = gpow + (H + 1), *tpv = cdf + A, *rcp = tpv + A, *tpdiv = rcp + (TE + 1);
@@ -905,6 +929,7 @@ static int uct_stoch_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *po
     a.srec = wb ? model->srec : nullptr;
     a.rtab = model->srec_rtab;
     a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_mask = pol ? pol->lmask : nullptr;
+    a.pol_listed = pol ? pol->listed8 : nullptr;
     a.pol_rslot = pol ? pol->rslot : nullptr; a.pol_stride = pol ? pol->stride : 0; a.temperature = temperature;
     MP_TRY(ws_get(ctx, WS_TREE1, (size_t)n_roots, &a.n_nodes_out)); // per-root tree sizes (updated in place by re-rooting and planning)
     if (cont) {
@@ -955,8 +980,11 @@ static int uct_stoch_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *po
         const int at = A >= 2 && A <= 8 && !(ag && ag[0] == '1') ? A : 0;
         const int wrow = wbk == 2 ? 1 : wbk == 4 ? 2 : wbk == 1 ? 3 : 0;
         if (pol) {
-            if (A < 2 || A > 8) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic_policy: |A| = %d is not in 2..8", A);
-            hipLaunchKernelGGL(table_sp[wrow][A - 2], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
+            static const kernel_t any_sp[4] = {uct_stoch_kernel<0, 0, int32_t, true>, uct_stoch_kernel<2, 0, int32_t, true>,
+                                               uct_stoch_kernel<4, 0, int32_t, true>, uct_stoch_kernel<1, 0, int32_t, true>};
+            if (A < 2) return fail(MP_ERR_ARG, "mp_uct_plan_stochastic_policy: |A| = %d", A);
+            // |A| in 2..8: the unrolled forms; beyond (round 4): the loop forms -- any number of actions
+            hipLaunchKernelGGL(at ? table_sp[wrow][A - 2] : any_sp[wrow], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
         } else {
             hipLaunchKernelGGL((p16 ? table16 : table32)[wrow][at], dim3((unsigned)((n_roots + 63) / 64)), dim3(64), lds, st, a);
         }

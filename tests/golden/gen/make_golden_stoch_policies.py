@@ -23,33 +23,8 @@ import prior_agents  # noqa: E402,F401
 OUT = os.path.abspath(os.path.join(HERE, "..", "stoch_policies.npz"))
 
 
-def main():
-    store, names = {}, []
-    dense = generators.random_stochastic(30, 3, seed=5, terminal_rate=0.1)
-    dense_b = generators.random_stochastic(50, 5, seed=6, concentration=0.05)
-    sparse = generators.random_sparse(60, 3, 2, seed=7, terminal_rate=0.1)
-    sparse_b = generators.random_sparse(200, 5, 4, seed=8)
-    pref = {"type": "preference", "action": 1, "ratio": 3}
-    rnd = {"type": "random"}
-    prior_cfg = dict(__class__=mg.PRIOR, gamma=0.9, temperature=0.5)
-    prior_masked = dict(__class__=mg.PRIOR, gamma=0.9, temperature=0.5, mask=3)
-    cases = [
-        # name, cfg, available (seed, rate) or None, s0, agent class, agent cfg, seeds
-        ("masked_sparse_open", sparse, (1, 0.4), 5, mg.UCT, dict(budget=400, gamma=0.9), [0, 1]),
-        ("masked_sparse_closed", sparse, (1, 0.4), 5, mg.UCT, dict(budget=400, gamma=0.9, closed_loop=True), [0, 4]),
-        ("masked_dense_open_pref", dense, (2, 0.3), 0, mg.UCT, dict(budget=300, prior_policy=pref, rollout_policy=pref), [2]),
-        ("masked_dense_closed", dense, (2, 0.3), 0, mg.UCT, dict(budget=300, closed_loop=True), [1]),
-        ("masked_sparse_b_h30_closed", sparse_b, (3, 0.35), 17, mg.UCT,
-         dict(budget=1000, horizon=30, episodes=33, closed_loop=True), [1]),
-        ("masked_sparse_b_rollout_random", sparse_b, (3, 0.35), 17, mg.UCT, dict(budget=400, rollout_policy=rnd), [5]),
-        ("prior_sparse_open", sparse, None, 5, mg.UCTP, dict(budget=400, gamma=0.9, prior_agent=prior_cfg), [0]),
-        ("prior_sparse_closed", sparse, None, 5, mg.UCTP, dict(budget=400, gamma=0.9, closed_loop=True, prior_agent=prior_cfg), [3]),
-        ("prior_dense_b_open", dense_b, None, 7, mg.UCTP, dict(budget=1000, horizon=30, episodes=33, prior_agent=prior_cfg), [2]),
-        ("prior_dense_b_closed_masked_table", dense_b, None, 11, mg.UCTP,
-         dict(budget=400, closed_loop=True, prior_agent=prior_masked), [6]),
-        ("prior_masked_env_sparse_b_open", sparse_b, (4, 0.3), 3, mg.UCTP, dict(budget=400, prior_agent=prior_cfg), [7]),
-        ("prior_masked_env_sparse_closed", sparse, (1, 0.4), 9, mg.UCTP, dict(budget=300, closed_loop=True, prior_agent=prior_cfg), [8]),
-    ]
+def build(cases, store, names):
+    """cases: (name, mdp config, (availability seed, rate) or None, root state, agent class, agent config, seeds)."""
     for name, cfg, av, s0, klass, acfg, seeds in cases:
         r = np.asarray(cfg["reward"])
         avail = None if av is None else generators.random_available(r.shape[0], r.shape[1], seed=av[0], rate=av[1])
@@ -83,6 +58,36 @@ def main():
             mg.put(store, p + "/tree", keyed_tree(root, UCT_FIELDS))
             assert env.mdp.state == s0 and np.array_equal(mg.rng_state(env.np_random), env_rng)
             names.append("{}_seed{}".format(name, seed))
+
+
+def main():
+    store, names = {}, []
+    dense = generators.random_stochastic(30, 3, seed=5, terminal_rate=0.1)
+    dense_b = generators.random_stochastic(50, 5, seed=6, concentration=0.05)
+    sparse = generators.random_sparse(60, 3, 2, seed=7, terminal_rate=0.1)
+    sparse_b = generators.random_sparse(200, 5, 4, seed=8)
+    pref = {"type": "preference", "action": 1, "ratio": 3}
+    rnd = {"type": "random"}
+    prior_cfg = dict(__class__=mg.PRIOR, gamma=0.9, temperature=0.5)
+    prior_masked = dict(__class__=mg.PRIOR, gamma=0.9, temperature=0.5, mask=3)
+    cases = [
+        # name, cfg, available (seed, rate) or None, s0, agent class, agent cfg, seeds
+        ("masked_sparse_open", sparse, (1, 0.4), 5, mg.UCT, dict(budget=400, gamma=0.9), [0, 1]),
+        ("masked_sparse_closed", sparse, (1, 0.4), 5, mg.UCT, dict(budget=400, gamma=0.9, closed_loop=True), [0, 4]),
+        ("masked_dense_open_pref", dense, (2, 0.3), 0, mg.UCT, dict(budget=300, prior_policy=pref, rollout_policy=pref), [2]),
+        ("masked_dense_closed", dense, (2, 0.3), 0, mg.UCT, dict(budget=300, closed_loop=True), [1]),
+        ("masked_sparse_b_h30_closed", sparse_b, (3, 0.35), 17, mg.UCT,
+         dict(budget=1000, horizon=30, episodes=33, closed_loop=True), [1]),
+        ("masked_sparse_b_rollout_random", sparse_b, (3, 0.35), 17, mg.UCT, dict(budget=400, rollout_policy=rnd), [5]),
+        ("prior_sparse_open", sparse, None, 5, mg.UCTP, dict(budget=400, gamma=0.9, prior_agent=prior_cfg), [0]),
+        ("prior_sparse_closed", sparse, None, 5, mg.UCTP, dict(budget=400, gamma=0.9, closed_loop=True, prior_agent=prior_cfg), [3]),
+        ("prior_dense_b_open", dense_b, None, 7, mg.UCTP, dict(budget=1000, horizon=30, episodes=33, prior_agent=prior_cfg), [2]),
+        ("prior_dense_b_closed_masked_table", dense_b, None, 11, mg.UCTP,
+         dict(budget=400, closed_loop=True, prior_agent=prior_masked), [6]),
+        ("prior_masked_env_sparse_b_open", sparse_b, (4, 0.3), 3, mg.UCTP, dict(budget=400, prior_agent=prior_cfg), [7]),
+        ("prior_masked_env_sparse_closed", sparse, (1, 0.4), 9, mg.UCTP, dict(budget=300, closed_loop=True, prior_agent=prior_cfg), [8]),
+    ]
+    build(cases, store, names)
     store["stoch_policies/names"] = np.asarray(names)
     np.savez_compressed(OUT, **store)
     print("wrote", OUT, len(store), "arrays,", len(names), "cases")

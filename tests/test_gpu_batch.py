@@ -566,8 +566,14 @@ def test_policy_load_errors(ctx):
     from rl_agents_amd.envs import generators
     cfg = generators.random_deterministic(50, 9, seed=1)
     model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
-    with pytest.raises(native.NativeError):   # |A| = 9 has no compile-time specialisation (2..8 have)
-        ctx.load_policy(model, np.full((50, 9), 1 / 9), np.full((50, 9), 1 / 9))
+    # |A| = 9: no register-resident specialisation in uct.hip (2..8 have one) -- the policy loads (round 4) and plans through
+    # the loop forms of the other kernel, on this deterministic table too; mp_uct_plan_policy itself says where to go
+    pol9 = ctx.load_policy(model, np.full((50, 9), 1 / 9), np.full((50, 9), 1 / 9))
+    with pytest.raises(native.NativeError, match="mp_uct_plan_stochastic_policy"):
+        ctx.uct_plan(model, [0], 5, 5, 0.8, 10.0, None, None, _rng_states(1), policy=pol9)
+    out = ctx.uct_plan_stochastic(model, [0, 3], 5, 5, 0.8, 10.0, None, None, _rng_states(2), policy=pol9)
+    assert (out["plan_len"] >= 1).all()
+    pol9.close()
     model.close()
     cfg = generators.random_deterministic(50, 4, seed=1)
     model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])

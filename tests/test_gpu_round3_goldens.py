@@ -594,11 +594,14 @@ def test_mcts_subtree_strategy_on_stochastic_models_matches_reference():
             env.step(plan[0])
 
 
-def test_per_state_policies_on_stochastic_models_match_reference():
+@pytest.mark.parametrize("golden_file", ["stoch_policies.npz", "many_actions.npz"])
+def test_per_state_policies_on_stochastic_models_match_reference(golden_file):
     """Round 4: restricted action sets (policies over get_available_actions(), mcts.py:59-97) and prior agents
     (mcts_with_prior.py:47-62) on STOCHASTIC finite MDPs, open and closed loop -- both refused before.  A node keeps the
     actions and priors of the state it was expanded in; plans, trees (stored priors included), env steps and generator
-    states equal the unmodified reference's (tests/golden/stoch_policies.npz, make_golden_stoch_policies.py)."""
+    states equal the unmodified reference's (tests/golden/stoch_policies.npz, make_golden_stoch_policies.py).
+    many_actions.npz: 9 .. 40 actions -- the loop forms of the kernel (any number of actions) -- on deterministic tables too,
+    which the planner routes there when their policies are per-state (make_golden_many_actions.py)."""
     import json
     from rl_agents_amd import native
     from rl_agents_amd.agents.common.factory import agent_factory
@@ -607,7 +610,7 @@ def test_per_state_policies_on_stochastic_models_match_reference():
     from tests.test_gpu_variants import _agent_tree
     UCTP = "<class 'rl_agents_amd.agents.tree_search.mcts_with_prior.MCTSWithPriorPolicyAgent'>"
     VI = "<class 'rl_agents_amd.agents.dynamic_programming.value_iteration.ValueIterationAgent'>"
-    zz = np.load(os.path.join(REPO, "tests", "golden", "stoch_policies.npz"))
+    zz = np.load(os.path.join(REPO, "tests", "golden", golden_file))
     for name in [str(n) for n in zz["stoch_policies/names"]]:
         p = "stoch_policies/" + name
         cfg = mdp_from_golden(zz, p + "/mdp")
@@ -660,7 +663,8 @@ def test_per_state_policies_on_stochastic_models_match_reference():
 
 @pytest.mark.parametrize("closed", [False, True], ids=["open", "closed"])
 @pytest.mark.parametrize("mode,n_actions", [("sparse2", 3), ("sparse2", 5), ("sparse4", 7), ("sparse6", 4), ("stochastic", 2),
-                                            ("stochastic", 8)])
+                                            ("stochastic", 8), ("sparse2", 12), ("stochastic", 9), ("sparse4", 40),
+                                            ("deterministic", 12), ("deterministic", 33)])   # (> 8 actions: the loop forms)
 def test_per_state_policies_on_stochastic_models_batch_vs_oracle(ctx, mode, n_actions, closed):
     """mp_uct_plan_stochastic_policy, seeded batches of 300 roots (ragged last wave), every |A| specialisation and record
     form: random availability tables, random per-state prior / rollout distributions over the listed actions, a TimeLimit,
@@ -671,12 +675,17 @@ def test_per_state_policies_on_stochastic_models_batch_vs_oracle(ctx, mode, n_ac
     if mode == "stochastic":
         cfg = generators.random_stochastic(s_, n_actions, seed=21 + n_actions, terminal_rate=0.05, concentration=0.1)
         kw, load = dict(), lambda: ctx.load_dense(cfg["transition"], cfg["reward"], cfg["terminal"])
+    elif mode == "deterministic":   # a deterministic table through the same kernel (per-state policies over > 8 actions)
+        cfg = generators.random_deterministic(s_, n_actions, seed=40 + n_actions, terminal_rate=0.05)
+        kw, load = dict(), lambda: ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"],
+                                                  done_rule="next" if n_actions % 2 else "source", max_steps=9)
     else:
         cfg = generators.random_sparse(s_, n_actions, int(mode[-1]), seed=30 + n_actions, terminal_rate=0.05)
         kw = dict(next_states=cfg["next"])
         load = lambda: ctx.load_sparse(cfg["transition"], cfg["next"], cfg["reward"], cfg["terminal"])
     model = load()
-    model.set_episode_rules("next" if n_actions % 2 else "source", 9)
+    if mode != "deterministic":     # (table models get their episode rules at load time)
+        model.set_episode_rules("next" if n_actions % 2 else "source", 9)
     g = np.random.Generator(np.random.PCG64(100 + n_actions))
     avail = generators.random_available(s_, n_actions, seed=n_actions, rate=0.4)
     prior = np.where(avail, g.random((s_, n_actions)) + 0.1, 0.0)

@@ -222,14 +222,16 @@ def stoch_policy_lists(zz, p):
             reference_policy_lists(json.loads(str(zz[p + "/rollout_policy_json"])), avail))
 
 
-def test_stochastic_models_with_per_state_policies_goldens():
+@pytest.mark.parametrize("golden_file", ["stoch_policies.npz", "many_actions.npz"])
+def test_stochastic_models_with_per_state_policies_goldens(golden_file):
     """Round 4: restricted action sets and prior agents on STOCHASTIC models (tests/golden/stoch_policies.npz, the unmodified
     reference's MCTSAgent / MCTSWithPriorPolicyAgent): the oracle, fed the literal per-state lists, reproduces plans (with
-    observation keys), env steps, root values, generator states and whole trees, open and closed loop."""
+    observation keys), env steps, root values, generator states and whole trees, open and closed loop.
+    many_actions.npz: the same with 9 .. 40 actions, deterministic tables included (make_golden_many_actions.py)."""
     import os
     from oracle import oracle
     from tests.helpers import assert_parent_tree_equal
-    zz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stoch_policies.npz"))
+    zz = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", golden_file))
     for name in [str(n) for n in zz["stoch_policies/names"]]:
         p = "stoch_policies/" + name
         cfg = mdp_from_golden(zz, p + "/mdp")

@@ -217,7 +217,7 @@ def one_case(ctx, g, case):
         eq(rng_dev, ref["rng_after"], "rng", desc)
     elif kind == "uct_listed":      # policies over restricted action sets (mcts.py:59-97): listed-policy kernel variant
         from tests.helpers import reference_policy_lists
-        if a not in (2, 3, 4, 5, 6, 7, 8):
+        if a < 2:
             model.close()
             return desc
         avail = g.random((s, a)) >= float(g.choice([0.2, 0.5, 0.8]))
@@ -236,6 +236,22 @@ def one_case(ctx, g, case):
         desc.update(episodes=episodes, horizon=horizon, temperature=temperature)
         policy = ctx.load_policy(model, prior, rollout, listed=listed)
         rng_dev = rng.copy()
+        if a > 8:   # more than 8 actions (round 4): the loop forms of the other kernel, on this deterministic table; open / closed loop
+            closed = bool(g.integers(0, 2))
+            mpl = 2 * horizon + 2
+            desc.update(loop_form=True, closed=closed)
+            out = ctx.uct_plan_stochastic(model, s0, episodes, horizon, gamma, temperature, None, None, rng_dev, closed_loop=closed,
+                                          root_steps=steps0, max_plan_len=mpl, policy=policy)
+            policy.close()
+            ref = oracle.uct_plan_stoch_batch("deterministic", t, r, term, s0, episodes, horizon, gamma, temperature, pl, rl,
+                                              rng.copy(), np.tile(np.array([0, 1, 0, 1, 0, 0], np.uint64), (n, 1)),
+                                              closed_loop=closed, steps0=steps0, max_steps=max_steps, done_rule=done_rule,
+                                              max_plan_len=mpl, n_threads=8)
+            for k in ("plans", "plan_len", "root_value", "env_steps"):
+                eq(out[k], ref[k], k, desc)
+            eq(rng_dev, ref["rng_after"], "rng", desc)
+            model.close()
+            return desc
         out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, None, None, rng_dev, root_steps=steps0,
                            max_plan_len=horizon, policy=policy)
         policy.close()
