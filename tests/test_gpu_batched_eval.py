@@ -31,7 +31,7 @@ def _compare(a, b):
     assert a["planner_env_steps"] == b["planner_env_steps"]
 
 
-@pytest.mark.parametrize("kind", ["uct", "uct_masked", "uct_highway_like", "opd", "opd_masked"])
+@pytest.mark.parametrize("kind", ["uct", "uct_masked", "uct_highway_like", "uct_masked_12_actions", "opd", "opd_masked"])
 def test_device_resident_loop_equals_host_stepped_loop(kind):
     from rl_agents_amd.agents.common.factory import agent_factory
     from rl_agents_amd.envs import HighwayLikeEnv
@@ -40,6 +40,15 @@ def test_device_resident_loop_equals_host_stepped_loop(kind):
         def make_env():
             return HighwayLikeEnv(3, 4, 10, seed=3, state=12)
         cfg = dict(__class__=UCT, budget=150, gamma=0.9)
+    elif kind == "uct_masked_12_actions":   # restricted action sets over more than 8 actions: the loop-form kernel, both loops
+        def make_env():
+            from rl_agents_amd.envs import MaskedFiniteMDPEnv, generators
+            c = dict(generators.random_deterministic(120, 12, seed=21, terminal_rate=0.05), state=2, max_steps=9)
+            c["available"] = generators.random_available(120, 12, seed=4, rate=0.4)
+            env = MaskedFiniteMDPEnv(c)
+            env.reset()
+            return env
+        cfg = dict(__class__=UCT, budget=200, gamma=0.9)
     else:
         def make_env():
             return _table_env(masked=kind.endswith("masked"))
