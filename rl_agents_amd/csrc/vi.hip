@@ -657,8 +657,9 @@ __global__ __launch_bounds__(256) void vi_dense_combine(ViGenArgs p)
 // value); leaf results go to LDS and the recursion's additions are done level by level from a table the host derives
 // from the row length -- including what the ufunc machinery adds: the reduction's iterator hands the inner loop at most
 // numpy.getbufsize() = 8192 elements at a time, so a longer row is the running sum, from the identity 0., of the pairwise
-// sums of its 8192-element pieces.  V is staged in LDS when it fits beside the tables (S <= ~14 000), else read through
-// L2.  The kernel streams T once, as the matrix-core kernel does: it is bound by HBM, not by the order of its additions.
+// sums of its 8192-element pieces.  V is staged in LDS: all of it where it fits beside the tables (S <= ~14 000), else the
+// piece being summed (VM below).  The kernel streams T once, as the matrix-core kernel does: it is bound by HBM, not by the
+// order of its additions.
 struct ViExactPlan {
     const int2 *leaves; // {offset, length} of the leaves of the recursion over Sc elements, left to right; leaf 0 = the identity
     const int2 *nodes;  // its additions by height: {left, right} result slots (leaf l = slot l, addition k = slot nleaf + k)
