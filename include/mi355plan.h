@@ -322,8 +322,8 @@ int mp_uct_path_count(mp_ctx *ctx, int32_t root, const int32_t *actions, int32_t
  * closed_loop != 0 (mcts.py:147, MCTSNode.get_child :267-273): an action node has one child per distinct observation
  * (= next state index) seen after it, created on first visit; `plans` then alternates action, observation key, action ...
  * as AbstractPlanner.get_plan walks such a tree (abstract.py:143-156); max_plan_len counts both.
- * prior_p / rollout_p: one distribution over the |A| actions for every state.  Restricted action sets, per-state
- * policies and tree re-use (mp_uct_step_tree) are not available on this path.  mp_model_set_episode_rules sets what a
+ * prior_p / rollout_p: one distribution over the |A| actions for every state (restricted action sets and per-state
+ * policies: mp_uct_plan_stochastic_policy below).  mp_model_set_episode_rules sets what a
  * table model gets at load time: done_on_next (terminated = terminal[s'] instead of terminal[s]) and the TimeLimit.
  * mp_uct_stoch_tree_export: the tree of `root` in creation order -- parent, key (action id or observed state), is_obs,
  * count, value -- a node's children in dict order are its children by ascending index; capacity from
@@ -336,7 +336,8 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
                            int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,
                            int64_t *root_child_count, double *root_child_value, int64_t *env_steps, int32_t mem);
 /* The same plan with PER-STATE policies (restricted action sets, mcts.py:59-97; prior agents, mcts_with_prior.py:47-62) from
- * mp_policy_load / _listed / _ordered on this (stochastic or sparse) model.  A node is expanded with the listed actions and
+ * mp_policy_load / _listed / _ordered on this model -- stochastic, sparse, or a deterministic table (whose per-state policies
+ * over more than 8 actions plan here: the loop forms take any number of actions).  A node is expanded with the listed actions and
  * priors of the state the env clone is in at that moment (mcts.py:151-154,237-246) and keeps them -- in open loop later
  * episodes reach it in other states.  mp_uct_step_tree re-uses open-loop trees of either form. */
 int mp_uct_plan_stochastic_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const int32_t *root_state,
