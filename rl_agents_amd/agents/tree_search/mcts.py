@@ -155,14 +155,15 @@ class MCTS(AbstractPlanner):
         if not device_model.is_cartpole(state):
             mdp = device_model.finite_mdp_of(state)
             if mdp.mode in ("stochastic", "sparse"):
+                # (columns in the PRIOR policy's listing order, as for the deterministic tables below)
                 available, order = device_model.availability_of(state, mdp)
-                if order is not None:
-                    raise NotImplementedError("a stochastic environment that lists its available actions in a non-ascending "
-                                              "order is not supported on the device")
-                model = self.models.get(device_model.spec_from_mdp(mdp))
+                self._env_order = order
+                tree_order = None if self.prior_policy["type"] == "random" and self.policy_source is None else order
+                spec = device_model.spec_from_mdp(mdp, available=available, action_order=tree_order)
+                model = self.models.get(spec)
                 model.set_episode_rules(getattr(mdp, "done_rule", "source"), device_model.env_max_steps(state))
                 # (restrictions reach the kernel through the per-state policy tables, not through the model)
-                model.available, model.action_order, self._env_order = available, None, None
+                model.available = None if spec.available is None else spec.available.astype(bool)
                 return model
             if mdp.mode == "deterministic":
                 # The columns of the device tables -- the order of a node's children and of every tie-break -- follow
@@ -184,9 +185,6 @@ class MCTS(AbstractPlanner):
             return False
         if self.policy_source is None and getattr(model, "available", None) is None:
             return False
-        if self.action_order(model) is not None:
-            raise NotImplementedError("per-state policies over more than 8 actions on an environment that lists them in a "
-                                      "non-ascending order are not supported on the device")
         return True
 
     def plan_batch_stochastic(self, state, model, root_states, root_steps, rng_states, env_rng_states=None):
@@ -216,6 +214,17 @@ class MCTS(AbstractPlanner):
             model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp, rp, rng_states,
             env_rng_state=env_rng_states, closed_loop=cfg["closed_loop"], root_steps=root_steps, policy=policy)
         out["rng_states"] = rng_states
+        order = self.action_order(model)
+        if order is not None:           # device labels -> the environment's action ids (closed loop: every other entry is
+            plans = out["plans"]        # an observation key)
+            is_action = np.ones(plans.shape[1], dtype=bool)
+            if cfg["closed_loop"]:
+                is_action[1::2] = False
+            out["plans"] = np.where((plans >= 0) & is_action[None, :], order[np.maximum(plans, 0) % len(order)], plans).astype(plans.dtype)
+            for k in ("root_child_count", "root_child_value"):
+                back = np.empty_like(out[k])
+                back[:, order] = out[k]
+                out[k] = back
         self._last_tables, self._last_model, self._stochastic = None, model, True
         self._stored_priors = policy is not None
         self.last, self._root, self._last_actions, self._last_env = out, None, model.A, state
@@ -234,7 +243,8 @@ class MCTS(AbstractPlanner):
             # (open-loop trees are re-used like the deterministic ones: mp_uct_step_tree armed the re-rooting)
             armed, self._armed = self._armed and n == 1 and not self.config["closed_loop"], False
             if keep_actions is not None and self.owns_device_tree() and not self.config["closed_loop"] and self._tree_roots == n:
-                self.models.ctx.uct_step_tree(np.asarray(keep_actions, dtype=np.int32))   # (batched callers: the executed actions)
+                # (batched callers: the executed actions, as device labels)
+                self.models.ctx.uct_step_tree(np.asarray(self.device_actions(keep_actions, model), dtype=np.int32))
             elif not (armed and self.owns_device_tree()):
                 self.models.ctx.uct_reset_tree()
             return self.plan_batch_stochastic(state, model, root_states, root_steps, rng_states, env_rng_states)
@@ -438,6 +448,10 @@ class MCTS(AbstractPlanner):
         from rl_agents_amd.agents.tree_search.abstract import Node
         self.require_device_tree()
         t = self.models.ctx.uct_stoch_tree(root)
+        order = self.action_order(getattr(self, "_last_model", None))
+        if order is not None:           # action nodes' keys: device labels -> the environment's action ids
+            act = t["action"]
+            t["action"] = np.where((act >= 0) & (t["is_obs"] == 0), order[np.maximum(act, 0) % len(order)], act).astype(act.dtype)
         stored = getattr(self, "_stored_priors", False)     # per-state policies: the priors the device kept in the tree
         prior = None if stored else policy_probabilities(self.prior_policy, self._last_actions)
         nodes = []

@@ -57,10 +57,13 @@ class TableSpec(object):
             if sorted(order.tolist()) != list(range(self.reward.shape[-1])):
                 raise ValueError("action_order must be a permutation of the action ids")
             if not np.array_equal(order, np.arange(len(order))):
-                if mode != "deterministic":
-                    raise ValueError("a listing order needs a deterministic table")
                 self.action_order = order
-                self.transition = np.ascontiguousarray(self.transition[..., order])
+                if mode == "deterministic":
+                    self.transition = np.ascontiguousarray(self.transition[..., order])                 # [.., S, A]
+                else:                                                                                   # [S, A, S] / [S, A, B]
+                    self.transition = np.ascontiguousarray(self.transition[:, order])
+                    if self.next is not None:
+                        self.next = np.ascontiguousarray(self.next[:, order])
                 self.reward = np.ascontiguousarray(self.reward[..., order])
                 if self.available is not None:
                     self.available = np.ascontiguousarray(self.available[:, order])
@@ -245,5 +248,8 @@ class ModelCache(object):
             model.action_order = spec.action_order      # None, or: column j of the device tables = action order[j]
             return model
         if spec.mode == "stochastic":
-            return self.ctx.load_dense(spec.transition, spec.reward, spec.terminal)
-        return self.ctx.load_sparse(spec.transition, spec.next, spec.reward, spec.terminal)
+            model = self.ctx.load_dense(spec.transition, spec.reward, spec.terminal)
+        else:
+            model = self.ctx.load_sparse(spec.transition, spec.next, spec.reward, spec.terminal)
+        model.action_order = spec.action_order          # (as above: the planners map labels back at the boundary)
+        return model

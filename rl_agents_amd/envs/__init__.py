@@ -1,4 +1,4 @@
-from .finite_mdp import FiniteMDPEnv, MaskedFiniteMDPEnv, MDP, DeterministicMDP, StochasticMDP, SparseMDP, Discrete  # noqa: F401
+from .finite_mdp import FiniteMDPEnv, MaskedFiniteMDPEnv, OrderedMaskedFiniteMDPEnv, MDP, DeterministicMDP, StochasticMDP, SparseMDP, Discrete  # noqa: F401
 from . import generators  # noqa: F401
 from .cartpole import CartPoleEnv  # noqa: F401
 from .highway_like import HighwayLikeEnv  # noqa: F401

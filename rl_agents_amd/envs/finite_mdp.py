@@ -230,3 +230,26 @@ class MaskedFiniteMDPEnv(FiniteMDPEnv):
     def get_available_actions(self):
         """Sorted list of the actions available in the current state."""
         return [int(a) for a in np.flatnonzero(self.mdp.available[self.mdp.state])]
+
+
+class OrderedMaskedFiniteMDPEnv(MaskedFiniteMDPEnv):
+    """A :class:`MaskedFiniteMDPEnv` that LISTS its available actions in a fixed non-ascending order
+    (``config["listing_order"]``: a permutation of the action ids; highway-env lists IDLE first) and keeps the restriction
+    on the env object, not in the MDP: the planners see it through ``get_available_actions()`` (reference) or through the
+    ``available_table(mdp)`` hook (device: :func:`rl_agents_amd.device_model.availability_of`).  Any MDP mode."""
+
+    def configure(self, config):
+        super().configure(config)
+        n = self.mdp.reward.shape[-1]
+        order = [int(a) for a in self.config.get("listing_order", range(n))]
+        if sorted(order) != list(range(n)):
+            raise ValueError("listing_order must be a permutation of the action ids")
+        self._order = order
+        self._available = self.mdp.available
+        del self.mdp.available                      # the restriction lives on the env object
+
+    def get_available_actions(self):
+        return [a for a in self._order if self._available[self.mdp.state, a]]
+
+    def available_table(self, mdp):
+        return np.asarray(self._available, dtype=bool), list(self._order)

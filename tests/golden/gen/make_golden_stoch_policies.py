@@ -28,8 +28,16 @@ def build(cases, store, names):
     for name, cfg, av, s0, klass, acfg, seeds in cases:
         r = np.asarray(cfg["reward"])
         avail = None if av is None else generators.random_available(r.shape[0], r.shape[1], seed=av[0], rate=av[1])
+        order = av[2] if av is not None and len(av) > 2 else None    # the env LISTS its actions in this (non-ascending) order
         for seed in seeds:
-            env = mg.make_env(cfg, state=s0) if avail is None else make_masked_env(cfg, avail, state=s0)
+            if order is not None:
+                from rl_agents_amd.envs import OrderedMaskedFiniteMDPEnv
+                c = {k: v for k, v in cfg.items() if k != "original_shape"}
+                c.update(state=int(s0), available=np.asarray(avail), listing_order=list(order))
+                env = OrderedMaskedFiniteMDPEnv(c)
+                env.reset()
+            else:
+                env = mg.make_env(cfg, state=s0) if avail is None else make_masked_env(cfg, avail, state=s0)
             env.seed(1000 + seed)
             env_rng = mg.rng_state(env.np_random)
             agent = agent_factory(env, dict(acfg, __class__=klass))
@@ -43,6 +51,8 @@ def build(cases, store, names):
             extra = {}
             if avail is not None:
                 extra["available"] = np.asarray(avail, bool)
+            if order is not None:
+                extra["listing_order"] = np.asarray(order, np.int32)
             if klass == mg.UCTP:
                 extra.update(prior_table=np.array(agent.prior_agent.table), prior_gamma=acfg["prior_agent"]["gamma"],
                              prior_temperature=acfg["prior_agent"]["temperature"], prior_mask=acfg["prior_agent"].get("mask", 0))

@@ -211,23 +211,26 @@ def stoch_policy_lists(zz, p):
     n_states, n_actions = cfg["reward"].shape
     restricted = (p + "/available") in zz.files
     avail = zz[p + "/available"] if restricted else np.ones((n_states, n_actions), bool)
+    # (listing_order.npz: the env lists its available actions in this order -- children and tie-breaks follow it)
+    order = [int(a) for a in zz[p + "/listing_order"]] if (p + "/listing_order") in zz.files else None
     if bool(zz[p + "/with_prior_agent"]):
         if restricted:                  # agent_policy_available renormalises over the listed actions ...
-            lists = restricted_agent_policy_lists(zz[p + "/prior_table"], avail)
+            lists = restricted_agent_policy_lists(zz[p + "/prior_table"], avail, order)
         else:                           # ... and hands the agent's distribution through as it is otherwise (:56-62)
             table = zz[p + "/prior_table"]
             lists = dict(actions=[list(range(n_actions))] * n_states, p=[table[s].copy() for s in range(n_states)])
         return lists, lists
-    return (reference_policy_lists(json.loads(str(zz[p + "/prior_policy_json"])), avail),
-            reference_policy_lists(json.loads(str(zz[p + "/rollout_policy_json"])), avail))
+    return (reference_policy_lists(json.loads(str(zz[p + "/prior_policy_json"])), avail, order),
+            reference_policy_lists(json.loads(str(zz[p + "/rollout_policy_json"])), avail, order))
 
 
-@pytest.mark.parametrize("golden_file", ["stoch_policies.npz", "many_actions.npz"])
+@pytest.mark.parametrize("golden_file", ["stoch_policies.npz", "many_actions.npz", "listing_order.npz"])
 def test_stochastic_models_with_per_state_policies_goldens(golden_file):
     """Round 4: restricted action sets and prior agents on STOCHASTIC models (tests/golden/stoch_policies.npz, the unmodified
     reference's MCTSAgent / MCTSWithPriorPolicyAgent): the oracle, fed the literal per-state lists, reproduces plans (with
     observation keys), env steps, root values, generator states and whole trees, open and closed loop.
-    many_actions.npz: the same with 9 .. 40 actions, deterministic tables included (make_golden_many_actions.py)."""
+    many_actions.npz: the same with 9 .. 40 actions, deterministic tables included (make_golden_many_actions.py);
+    listing_order.npz: environments that list their actions in a non-ascending order (make_golden_listing_order.py)."""
     import os
     from oracle import oracle
     from tests.helpers import assert_parent_tree_equal
