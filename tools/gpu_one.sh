@@ -1,4 +1,5 @@
 #!/bin/bash
 # one short, bounded GPU command (always under `timeout`)
 cd /root/repo
-timeout 300 python -X faulthandler -m pytest tests -m gpu -q -k "per_state_policies or stoch or policy or policies or restrict or agents or batched" 2>&1 | grep -v "Extension modules" | tail -40 | cut -c1-260
+timeout 400 python -m pytest tests -m gpu -q 2>&1 | tail -3 | cut -c1-250
+timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | cut -c1-120
