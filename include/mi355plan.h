@@ -340,6 +340,15 @@ int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const 
  * over more than 8 actions plan here: the loop forms take any number of actions).  A node is expanded with the listed actions and
  * priors of the state the env clone is in at that moment (mcts.py:151-154,237-246) and keeps them -- in open loop later
  * episodes reach it in other states.  mp_uct_step_tree re-uses open-loop trees of either form. */
+/*
+ * AbstractPlanner.get_visits (abstract.py:163-167): the planner appends the observation of EVERY env step of a plan --
+ * descent and rollouts -- to planner.observations (:158-161) and get_visits counts them.  Arms the NEXT
+ * mp_uct_plan_stochastic / _policy call of this ctx (host arrays): visits int32 [n_roots, S] receives, per root, how often
+ * the plan's env steps landed in each state (= observation of a finite MDP).  Rollouts leave no trace in the tree, so a
+ * binding that wants get_visits replays the plan with its saved generator records through this pair
+ * (rl_agents_amd/agents/tree_search/mcts.py: a private ctx, so the trees of the real plans stay untouched).
+ */
+int mp_uct_record_visits(mp_ctx *ctx, int32_t *visits);
 int mp_uct_plan_stochastic_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const int32_t *root_state,
                                   const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
                                   int32_t closed_loop, uint64_t *rng_state, const uint64_t *env_rng_state, int32_t max_plan_len,

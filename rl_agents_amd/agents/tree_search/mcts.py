@@ -145,9 +145,85 @@ class MCTS(AbstractPlanner):
         if not live or not self.owns_device_tree() or self._tree_roots != 1:
             self.step_by_reset()
             return
-        self.models.ctx.uct_step_tree(self.device_actions([int(action)], getattr(self, "_last_model", None)))
+        labels = self.device_actions([int(action)], getattr(self, "_last_model", None))
+        self.models.ctx.uct_step_tree(labels)
+        self._visit_events().append(("step", np.asarray(labels, dtype=np.int32).copy()))
         self.last, self._root = None, None
         self._armed = True
+
+    # -- get_visits (abstract.py:163-167): rollouts leave no trace in the tree, so the single-root plans are logged (root
+    # state, generator records, policies: a few hundred bytes each) and REPLAYED on demand with the visit counter armed
+    # (mp_uct_record_visits) -- on a private context, so the trees of the real plans stay where they are.
+    def _visit_events(self):
+        if not hasattr(self, "_visit_log"):
+            self._visit_log, self._visit_done, self._visit_counts = [], 0, {}
+            self._visit_gap = None
+        return self._visit_log
+
+    def _log_plan(self, model, root_states, root_steps, rng_states, env_rng_states, policy, continued):
+        """Called right BEFORE a plan: everything a replay needs (``policy``: ("tables", prior, rollout, listed, slots)
+        or ("flat", prior_p, rollout_p))."""
+        events = self._visit_events()
+        if len(root_states) != 1:
+            self._visit_gap = "a batched plan ({} roots) is not replayed".format(len(root_states))
+            return
+        if getattr(model, "spec", None) is None:
+            self._visit_gap = "observations of this environment are not states of a finite MDP"
+            return
+        rules = getattr(model, "episode_rules", None)    # stochastic / sparse models: set after the upload (model_for)
+        cfg = self.config
+        events.append(("plan", dict(
+            spec=model.spec, rules=rules, s0=np.array(root_states, dtype=np.int32).reshape(1),
+            steps0=None if root_steps is None else np.array(root_steps, dtype=np.int32).reshape(1),
+            rng=np.array(rng_states, dtype=np.uint64).reshape(1, 6).copy(),
+            erng=None if env_rng_states is None else np.array(env_rng_states, dtype=np.uint64).reshape(1, 6).copy(),
+            episodes=cfg["episodes"], horizon=cfg["horizon"], gamma=cfg["gamma"], temperature=cfg["temperature"],
+            closed=bool(cfg["closed_loop"]), policy=policy, continued=bool(continued))))
+
+    def get_visits(self):
+        """How often the planner's env steps -- descents and rollouts of every plan so far -- observed each state
+        (``str(observation)`` -> count), as the reference's ever-growing ``planner.observations`` gives it."""
+        from collections import defaultdict
+        from rl_agents_amd import native
+        events = self._visit_events()
+        if self._visit_gap:
+            raise NotImplementedError("get_visits: " + self._visit_gap)
+        if self._visit_done < len(events):
+            if not hasattr(self, "_replay_models"):
+                self._replay_models = device_model.ModelCache(ctx=native.Context(self.models.ctx.device))
+                self._replay_policies = {}
+            cache, ctx = self._replay_models, self._replay_models.ctx
+            for kind, e in events[self._visit_done:]:
+                if kind == "step":
+                    ctx.uct_step_tree(e)
+                    continue
+                model = cache.get(e["spec"])
+                if e["rules"] is not None:
+                    model.set_episode_rules(*e["rules"])
+                if not e["continued"]:
+                    ctx.uct_reset_tree()
+                policy, pp, rp = None, None, None
+                if e["policy"][0] == "tables":
+                    _, prior, rollout, listed, slots = e["policy"]
+                    key = (id(model), id(prior), id(rollout))
+                    hit = self._replay_policies.get(key)
+                    if hit is None:
+                        hit = (prior, rollout, ctx.load_policy(model, prior, rollout, listed=listed, rollout_slots=slots))
+                        self._replay_policies = {key: hit}         # (one at a time: a policy is tied to its model)
+                    policy = hit[2]
+                else:
+                    _, pp, rp = e["policy"]
+                visits = np.zeros((1, model.S), dtype=np.int32)
+                ctx.uct_plan_stochastic(model, e["s0"], e["episodes"], e["horizon"], e["gamma"], e["temperature"], pp, rp,
+                                        e["rng"].copy(), env_rng_state=e["erng"], closed_loop=e["closed"], root_steps=e["steps0"],
+                                        policy=policy, visits=visits)
+                for s in np.flatnonzero(visits[0]):
+                    self._visit_counts[int(s)] = self._visit_counts.get(int(s), 0) + int(visits[0, s])
+            self._visit_done = len(events)
+        out = defaultdict(int)
+        for s, c in self._visit_counts.items():
+            out[str(s)] = c
+        return out
 
     def model_for(self, state):
         """Deterministic tables / CartPole as every planner; MCTS also plans on STOCHASTIC finite MDPs (`stochastic`,
@@ -161,7 +237,8 @@ class MCTS(AbstractPlanner):
                 tree_order = None if self.prior_policy["type"] == "random" and self.policy_source is None else order
                 spec = device_model.spec_from_mdp(mdp, available=available, action_order=tree_order)
                 model = self.models.get(spec)
-                model.set_episode_rules(getattr(mdp, "done_rule", "source"), device_model.env_max_steps(state))
+                model.episode_rules = (getattr(mdp, "done_rule", "source"), device_model.env_max_steps(state))
+                model.set_episode_rules(*model.episode_rules)
                 # (restrictions reach the kernel through the per-state policy tables, not through the model)
                 model.available = None if spec.available is None else spec.available.astype(bool)
                 return model
@@ -208,8 +285,11 @@ class MCTS(AbstractPlanner):
             else:
                 prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
             policy = self.device_policy(model, prior, rollout, listed, slots)
+            logged = ("tables", prior, rollout, listed, slots)
         else:
             pp, rp = policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A)
+            logged = ("flat", pp, rp)
+        self._log_plan(model, root_states, root_steps, rng_states, env_rng_states, logged, getattr(self, "_continued", False))
         out = self.models.ctx.uct_plan_stochastic(
             model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp, rp, rng_states,
             env_rng_state=env_rng_states, closed_loop=cfg["closed_loop"], root_steps=root_steps, policy=policy)
@@ -242,20 +322,26 @@ class MCTS(AbstractPlanner):
         if model.mode in (native_modes.MODE_STOCHASTIC, native_modes.MODE_SPARSE) or self.loop_form(model):
             # (open-loop trees are re-used like the deterministic ones: mp_uct_step_tree armed the re-rooting)
             armed, self._armed = self._armed and n == 1 and not self.config["closed_loop"], False
+            self._continued = False
             if keep_actions is not None and self.owns_device_tree() and not self.config["closed_loop"] and self._tree_roots == n:
                 # (batched callers: the executed actions, as device labels)
                 self.models.ctx.uct_step_tree(np.asarray(self.device_actions(keep_actions, model), dtype=np.int32))
             elif not (armed and self.owns_device_tree()):
                 self.models.ctx.uct_reset_tree()
+            else:
+                self._continued = True      # the plan goes on in the tree step_by_subtree kept (logged for get_visits)
             return self.plan_batch_stochastic(state, model, root_states, root_steps, rng_states, env_rng_states)
         self._stochastic = False
         cfg = self.config
         ctx = self.models.ctx
         armed, self._armed = self._armed and n == 1, False
+        continued = False
         if keep_actions is not None and self.owns_device_tree():
             ctx.uct_step_tree(self.device_actions(keep_actions, model))   # batched callers hand the executed actions over here
         elif not (armed and self.owns_device_tree()):
             ctx.uct_reset_tree()
+        else:
+            continued = True
         available = getattr(model, "available", None)
         if self.policy_source is not None or available is not None:
             if self.policy_source is not None:
@@ -264,6 +350,7 @@ class MCTS(AbstractPlanner):
                 slots = None
             else:
                 prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
+            self._log_plan(model, root_states, root_steps, rng_states, None, ("tables", prior, rollout, listed, slots), continued)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
                                None, None, rng_states, root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1),
                                policy=self.device_policy(model, prior, rollout, listed, slots))
@@ -275,6 +362,9 @@ class MCTS(AbstractPlanner):
             self._last_tables = (np.asarray(device_model.finite_mdp_of(state).transition), prior_ids,
                                  np.asarray(root_states, dtype=np.int64))
         else:
+            self._log_plan(model, root_states, root_steps, rng_states, None,
+                           ("flat", policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A)),
+                           continued)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
                                policy_probabilities(self.prior_policy, model.A),
                                policy_probabilities(self.rollout_policy, model.A), rng_states,
@@ -308,6 +398,8 @@ class MCTS(AbstractPlanner):
         are re-rooted under them (abstract.py:195-206) instead of being reset."""
         cfg, ctx = self.config, self.models.ctx
         self.about_to_plan()
+        self._visit_events()
+        self._visit_gap = "the plans of a device-resident evaluation loop are not replayed"
         if model.mode != native_modes.MODE_DETERMINISTIC or self.loop_form(model):
             # stochastic / sparse models: the episodes' env generator records are a device buffer too (d_env_rng: every
             # plan's clones start from the env generator as it is at that step; mp_env_step_stochastic advances it)

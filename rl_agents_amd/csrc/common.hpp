@@ -109,6 +109,7 @@ struct mp_ctx {
     // ctx's stream, so a block that is handed out again is reused in stream order.
     struct Block { void *p; size_t bytes; };
     std::vector<Block> block_cache;
+    int32_t *visits_host = nullptr;   // mp_uct_record_visits: where the next stochastic-kernel plan writes its visit counts
     std::vector<double> stoch_priors; // stored child priors of the tree last exported by mp_uct_stoch_tree_export (per-state policies)
     size_t block_cache_bytes = 0;
 };

@@ -1405,7 +1405,8 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
     if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
     pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq; pol->shift = shift; pol->packed = can_pack ? 1 : 0; pol->listed = listed ? 1 : 0;
     if (hipMalloc(&pol->prior, hp.size() * 8) != hipSuccess || hipMalloc(&pol->thr, ht.size() * 8) != hipSuccess ||
-        hipMalloc(&pol->frec, hf.size() * 4) != hipSuccess ||
+        hipMalloc(&pol->frec, hf.size() * 4) != hipSuccess || hipMalloc(&pol->lmask, lmask.size() * 4) != hipSuccess ||
+        (rollout_slot && hipMalloc(&pol->rslot, (size_t)S * A) != hipSuccess) ||
         (rollout_slot && hipMalloc(&pol->frec_roll, hfr.size() * 4) != hipSuccess) ||
         (can_pack && hipMalloc(&pol->frec16, hp16.size() * 4) != hipSuccess)) {
         mp_policy_free(pol);
@@ -1414,6 +1415,10 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
     MP_HIP(hipMemcpy(pol->prior, hp.data(), hp.size() * 8, hipMemcpyHostToDevice));
     MP_HIP(hipMemcpy(pol->thr, ht.data(), ht.size() * 8, hipMemcpyHostToDevice));
     MP_HIP(hipMemcpy(pol->frec, hf.data(), hf.size() * 4, hipMemcpyHostToDevice));
+    // (the same policy also plans through mp_uct_plan_stochastic_policy -- which takes deterministic tables -- e.g. when a
+    // binding replays a plan with the visit counter armed: that kernel reads the listed masks and the rollout slots' columns)
+    MP_HIP(hipMemcpy(pol->lmask, lmask.data(), lmask.size() * 4, hipMemcpyHostToDevice));
+    if (rollout_slot) MP_HIP(hipMemcpy(pol->rslot, rollout_slot, (size_t)S * A, hipMemcpyHostToDevice));
     if (can_pack) MP_HIP(hipMemcpy(pol->frec16, hp16.data(), hp16.size() * 4, hipMemcpyHostToDevice));
     if (rollout_slot) MP_HIP(hipMemcpy(pol->frec_roll, hfr.data(), hfr.size() * 4, hipMemcpyHostToDevice));
     *out = pol;

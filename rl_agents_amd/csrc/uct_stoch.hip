@@ -68,6 +68,7 @@ struct StochArgs {
     const uint64_t *env_rng;
     SHot *hot;              // [n_roots][cap]
     SCold *cold;            // [n_roots][cap]
+    int32_t *visits;           // [n_roots][S] or nullptr: += 1 for the state every env step of the plan lands in (planner.observations)
     const int32_t *n_nodes_in; // kept (re-rooted) tree sizes, nullptr = every root starts fresh (step_strategy "subtree", open loop)
     int32_t *n_nodes_out;
     int32_t *plans, *plan_len;
@@ -438,6 +439,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
             double reward;
             bool trunc;
             env_step(act, reward, terminal, trunc);
+            if (p.visits) atomicAdd(p.visits + (long)r * p.S + s, 1); // AbstractPlanner.step: observations.append (abstract.py:158-161)
             total += gpow[depth] * reward;
             node = fc + act;
 #pragma unroll
@@ -522,6 +524,7 @@ __global__ __launch_bounds__(64) void uct_stoch_kernel(StochArgs p)
                 double reward;
                 bool term_h, trunc_h;
                 env_step(a, reward, term_h, trunc_h);
+                if (p.visits) atomicAdd(p.visits + (long)r * p.S + s, 1);
                 total += gpow[h] * reward;
                 if (term_h || trunc_h) break;
                 gn = gs;
@@ -962,6 +965,14 @@ static int uct_stoch_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *po
     MP_TRY(stage_out_alloc(ctx, WS_IO7, root_child_value, (size_t)n_roots * A, amem, &a.root_child_value));
     MP_TRY(stage_out_alloc(ctx, WS_IO8, env_steps, (size_t)n_roots, amem, &a.env_steps));
 
+    // mp_uct_record_visits armed this call: every env step of the plan is counted by the state it lands in
+    int32_t *visits_host = ctx->visits_host;
+    ctx->visits_host = nullptr;
+    if (visits_host) {
+        if (amem != MP_MEM_HOST) return fail(MP_ERR_ARG, "mp_uct_record_visits: the recording call takes host arrays");
+        MP_TRY(ws_get(ctx, WS_VI4, (size_t)n_roots * S, &a.visits)); // (a value-iteration slot: idle during a plan)
+        MP_HIP(hipMemsetAsync(a.visits, 0, (size_t)n_roots * S * sizeof(int32_t), st));
+    }
     MP_TRY(kernels_begin(ctx));
     {
         typedef void (*kernel_t)(StochArgs);
@@ -999,11 +1010,19 @@ static int uct_stoch_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *po
     MP_TRY(stage_out_copy(ctx, root_child_count, a.root_child_count, (size_t)n_roots * A, amem));
     MP_TRY(stage_out_copy(ctx, root_child_value, a.root_child_value, (size_t)n_roots * A, amem));
     MP_TRY(stage_out_copy(ctx, env_steps, a.env_steps, (size_t)n_roots, amem));
+    if (visits_host) MP_HIP(hipMemcpyAsync(visits_host, a.visits, (size_t)n_roots * S * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     if (amem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
     return MP_OK;
 }
 
 extern "C" {
+
+int mp_uct_record_visits(mp_ctx *ctx, int32_t *visits)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "mp_uct_record_visits: NULL ctx");
+    ctx->visits_host = visits; // consumed (and cleared) by the next mp_uct_plan_stochastic / _policy call of this ctx
+    return MP_OK;
+}
 
 int mp_uct_plan_stochastic(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, const int32_t *root_steps,
                            int32_t episodes, int32_t horizon, double gamma, double temperature, const double *prior_p,

@@ -221,6 +221,7 @@ class ModelCache(object):
         model = self._models.get(key)
         if model is None:
             model = self._upload(spec)
+            model.spec = spec                       # (what it was uploaded from: MCTS.get_visits replays plans on a private context)
             self.uploads += 1
             self._models[key] = model
             if len(self._order) >= self.capacity:

@@ -46,6 +46,7 @@ SIGNATURES = {
     "mp_vi_solve_v_robust": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, c_i32]),
     "mp_vi_sweeps": (C.c_int, [_vp, _vp, c_f64, c_i32, c_i32]),
     "mp_vi_dense_mode": (C.c_int, [_vp, c_i32]),
+    "mp_uct_record_visits": (C.c_int, [_vp, _vp]),
     "mp_vi_exact_plan": (C.c_int, [c_i32, c_i32, _vp, c_i32, _vp, c_i32, _vp, _vp]),
     "mp_uct_plan": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
                               _vp, _vp, _vp, _vp, c_i32]),
@@ -620,7 +621,7 @@ class Context(object):
                                      _ptr(env_steps), MP_MEM_DEVICE))
 
     def uct_plan_stochastic(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
-                            env_rng_state=None, closed_loop=False, root_steps=None, max_plan_len=None, policy=None):
+                            env_rng_state=None, closed_loop=False, root_steps=None, max_plan_len=None, policy=None, visits=None):
         """MCTS.plan on a stochastic (dense / sparse) finite-MDP model, open or closed loop (mp_uct_plan_stochastic).
         env_rng_state uint64 [n,6]: the env generator's record per root at plan time (every episode's clone starts from
         it; not advanced).  closed_loop: plans alternate action, observation key (next state index), action, ..."""
@@ -633,6 +634,10 @@ class Context(object):
         out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
                    root_value=np.zeros(n, np.float64), root_child_count=np.zeros((n, model.A), np.int64),
                    root_child_value=np.zeros((n, model.A), np.float64), env_steps=np.zeros(n, np.int64))
+        if visits is not None:          # int32 [n, S]: how often the plan's env steps land in each state (mp_uct_record_visits)
+            if visits.dtype != np.int32 or visits.shape != (n, model.S) or not visits.flags.c_contiguous:
+                raise ValueError("visits must be a C-contiguous int32 [n_roots, S] array")
+            _check(self._lib.mp_uct_record_visits(self._h, _ptr(visits)))
         if policy is not None:          # per-state policies (load_policy on this stochastic model)
             _check(self._lib.mp_uct_plan_stochastic_policy(self._h, model._h, policy._h, n, _ptr(rs), _ptr(st), int(episodes),
                                                            int(horizon), float(gamma), float(temperature), int(bool(closed_loop)),
