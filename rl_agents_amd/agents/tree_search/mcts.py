@@ -147,7 +147,8 @@ class MCTS(AbstractPlanner):
             return
         labels = self.device_actions([int(action)], getattr(self, "_last_model", None))
         self.models.ctx.uct_step_tree(labels)
-        self._visit_events().append(("step", np.asarray(labels, dtype=np.int32).copy()))
+        if not getattr(self, "_visit_gap", None):
+            self._visit_events().append(("step", np.asarray(labels, dtype=np.int32).copy()))
         self.last, self._root = None, None
         self._armed = True
 
@@ -164,6 +165,11 @@ class MCTS(AbstractPlanner):
         """Called right BEFORE a plan: everything a replay needs (``policy``: ("tables", prior, rollout, listed, slots)
         or ("flat", prior_p, rollout_p))."""
         events = self._visit_events()
+        if len(events) > 20000:     # nobody asked for visits in 20 000 plans: stop logging (a few MB), say so when asked
+            del events[:]
+            self._visit_gap = "more than 20 000 plans since get_visits was last asked: the log was dropped"
+        if self._visit_gap:
+            return
         if len(root_states) != 1:
             self._visit_gap = "a batched plan ({} roots) is not replayed".format(len(root_states))
             return
@@ -219,7 +225,8 @@ class MCTS(AbstractPlanner):
                                         policy=policy, visits=visits)
                 for s in np.flatnonzero(visits[0]):
                     self._visit_counts[int(s)] = self._visit_counts.get(int(s), 0) + int(visits[0, s])
-            self._visit_done = len(events)
+            del events[:]                                  # replayed: only the counts are kept
+            self._visit_done = 0
         out = defaultdict(int)
         for s, c in self._visit_counts.items():
             out[str(s)] = c

@@ -1,4 +1,4 @@
 #!/bin/bash
 # one short, bounded GPU command (always under `timeout`)
 cd /root/repo
-timeout 300 python -X faulthandler -m pytest tests/test_gpu_visits.py tests/test_gpu_batch.py -m gpu -q -k "visits or policy" 2>&1 | grep -v "Extension modules" | tail -40 | cut -c1-300
+timeout 300 python -m pytest tests/test_gpu_agents.py tests/test_gpu_visits.py tests/test_tree_tools.py -m gpu -q 2>&1 | tail -8 | cut -c1-250
