@@ -709,78 +709,108 @@ __global__ __launch_bounds__(512) void vi_dense_exact_q(ViGenArgs p, ViExactPlan
             vpre[i] = p.Vcur[t < nn ? t : 0];
         }
     }
-    // (VI_V_PIECES: every wave of the workgroup makes the same number of trips -- the barriers -- so a wave past the last
-    // row sums the last row again and does not store)
-    for (long row0 = (long)blockIdx.x * nw; row0 < SA; row0 += (long)gridDim.x * nw) {
-        long row = row0 + wave;
-        const bool mine = row < SA;
-        if (!mine) {
-            if (VM != VI_V_PIECES) break;
-            row = SA - 1;
+    // A PASS = eight leaves of one (row, model): the unit of the loop below.  Passes are software-pipelined: the loads of pass
+    // n + 1 -- of the same row, of its next model, or of the wave's next row -- are issued BEFORE pass n is summed, so a wave
+    // keeps up to 2 x 16 loads of 512 bytes in flight and the reduction / combine phases hide under them (one pass at a time
+    // left the memory system idle while a wave added: 0.74 of the HBM peak against the matrix-core kernel's 0.74-0.78).
+    // (VI_V_PIECES: every wave of the workgroup walks the same sequence of passes -- the barriers of the window staging --
+    // so a wave past the last row sums the last row again and does not store.)
+    struct Pass {
+        long row0;      // first row of the workgroup's row group (row = row0 + wave)
+        int m, c, l0;   // model, 8192-element piece, first leaf of the pass
+        int nb, base, off, len, l;
+        bool valid, lvalid;
+    };
+    const long stride = (long)gridDim.x * nw;
+    auto row_of = [&](const Pass &q) -> long {
+        const long r = q.row0 + wave;
+        return r < SA ? r : SA - 1;
+    };
+    auto alive = [&](long row0) -> bool { return VM == VI_V_PIECES ? row0 < SA : row0 + wave < SA; };
+    auto issue = [&](Pass &q, double (&x)[NBT]) { // leaf of this lane's group + the loads of its eight accumulators' steps
+        const int l_end = l_piece[q.c + 1];
+        q.l = q.l0 + g;
+        q.lvalid = q.l < l_end;
+        const int2 lf = l_leaves[q.lvalid ? q.l : l_end - 1];
+        q.off = lf.x;
+        q.len = q.lvalid ? lf.y : 0;
+        q.nb = q.len >> 3;                                      // full steps of the eight accumulators
+        const int vbase = VM == VI_V_PIECES ? q.c * kViPiece : 0;
+        q.base = q.nb > 0 ? q.off + j : vbase;                  // (a lane without a step re-reads an element that is there)
+        const double *prow = p.P + ((long)q.m * SA + row_of(q)) * p.Sc;
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) x[i] = prow[q.base + (i < q.nb ? 8 * i : 0)];
+    };
+    auto advance = [&](const Pass &q) -> Pass {
+        Pass n = q;
+        n.l0 = q.l0 + 8;
+        if (n.l0 >= l_piece[q.c + 1]) {
+            n.c = q.c + 1;
+            if (n.c >= pl.npiece) {
+                n.c = 0;
+                n.m = q.m + 1;
+                if (n.m >= p.M) { n.m = 0; n.row0 = q.row0 + stride; }
+            }
+            n.l0 = l_piece[n.c];
         }
-        double best = 0.0;
-        for (int m = 0; m < p.M; ++m) {
-            const double *prow = p.P + ((long)m * SA + row) * p.Sc;
-            if (lane == 0) slots[0] = 0.0;                      // leaf 0: the identity the reduction starts from
-            for (int c = 0; c < pl.npiece; ++c) {
-                const int vbase = VM == VI_V_PIECES ? c * kViPiece : 0;
-                if (VM == VI_V_PIECES) {
-                    // the window was requested one piece ago (vpre, below): its round trip to L2 hides behind the passes of
-                    // the previous piece instead of standing between two barriers
-                    __syncthreads();                            // the previous window's readers are done
-                    const int cn = min(kViPiece, p.Sc - vbase);
+        n.valid = alive(n.row0);
+        return n;
+    };
+    double best = 0.0;
+    auto compute = [&](const Pass &q, const double (&x)[NBT]) {
+        const long row = row_of(q);
+        const double *prow = p.P + ((long)q.m * SA + row) * p.Sc;
+        const int vbase = VM == VI_V_PIECES ? q.c * kViPiece : 0;
+        if (q.l0 == l_piece[q.c]) {                             // first pass of a piece
+            if (q.c == 0 && lane == 0) slots[0] = 0.0;          // leaf 0: the identity the reduction starts from
+            if (VM == VI_V_PIECES) {
+                // the window was requested one piece ago (vpre, below): its round trip to L2 hides behind the passes of
+                // the previous piece instead of standing between two barriers
+                __syncthreads();                                // the previous window's readers are done
+                const int cn = min(kViPiece, p.Sc - vbase);
 #pragma unroll
-                    for (int i = 0; i < VPRE; ++i) {
-                        const int t = (int)threadIdx.x + i * (int)blockDim.x;
-                        if (t < cn) vs[t] = vpre[i];
-                    }
-                    for (int t = threadIdx.x + VPRE * blockDim.x; t < cn; t += blockDim.x) vs[t] = p.Vcur[vbase + t]; // (< 512 threads)
-                    __syncthreads();
-                    const int nbase = (c + 1 < pl.npiece ? c + 1 : 0) * kViPiece; // every (rows, model) walks the pieces in order
-                    const int nn = min(kViPiece, p.Sc - nbase);
-#pragma unroll
-                    for (int i = 0; i < VPRE; ++i) {
-                        const int t = (int)threadIdx.x + i * (int)blockDim.x;
-                        vpre[i] = p.Vcur[nbase + (t < nn ? t : 0)];
-                    }
+                for (int i = 0; i < VPRE; ++i) {
+                    const int t = (int)threadIdx.x + i * (int)blockDim.x;
+                    if (t < cn) vs[t] = vpre[i];
                 }
-                const int l_end = l_piece[c + 1];
-                for (int l0 = l_piece[c]; l0 < l_end; l0 += 8) {
-                    const int l = l0 + g;
-                    const bool valid = l < l_end;
-                    const int2 lf = l_leaves[valid ? l : l_end - 1];
-                    const int off = lf.x, len = valid ? lf.y : 0;
-                    const int nb = len >> 3;                    // full steps of the eight accumulators
-                    const int base = nb > 0 ? off + j : vbase;  // (a lane without a step re-reads an element that is there)
-                    double x[NBT], v[NBT];
+                for (int t = threadIdx.x + VPRE * blockDim.x; t < cn; t += blockDim.x) vs[t] = p.Vcur[vbase + t]; // (< 512 threads)
+                __syncthreads();
+                const int nbase = (q.c + 1 < pl.npiece ? q.c + 1 : 0) * kViPiece; // every (rows, model) walks the pieces in order
+                const int nn = min(kViPiece, p.Sc - nbase);
 #pragma unroll
-                    for (int i = 0; i < NBT; ++i) {
-                        const int idx = base + (i < nb ? 8 * i : 0);
-                        x[i] = prow[idx];
-                        v[i] = VM == VI_V_GLOBAL ? p.Vcur[idx] : vs[idx - vbase];
-                    }
-                    double r = nb > 0 ? x[0] * v[0] : 0.0;      // r[j] = a[j] (n < 8: res = 0.)
-#pragma unroll
-                    for (int i = 1; i < NBT; ++i) {
-                        const double t = x[i] * v[i];
-                        r = i < nb ? r + t : r;
-                    }
-                    r += __shfl_xor(r, 1);                      // r0 + r1 | r2 + r3 | r4 + r5 | r6 + r7
-                    r += __shfl_xor(r, 2);                      // (r0 + r1) + (r2 + r3) | (r4 + r5) + (r6 + r7)
-                    r += __shfl_xor(r, 4);
-                    const int rem = len & 7;
-                    if (__any(rem != 0)) {                      // only the last leaf of a row can have a remainder
-                        const int tail = off + 8 * nb;
-#pragma unroll
-                        for (int t = 0; t < 7; ++t) {
-                            const int idx = t < rem ? tail + t : vbase;
-                            const double pv = prow[idx] * (VM == VI_V_GLOBAL ? p.Vcur[idx] : vs[idx - vbase]);
-                            r = t < rem ? r + pv : r;
-                        }
-                    }
-                    if (j == 0 && valid) slots[l] = r;
+                for (int i = 0; i < VPRE; ++i) {
+                    const int t = (int)threadIdx.x + i * (int)blockDim.x;
+                    vpre[i] = p.Vcur[nbase + (t < nn ? t : 0)];
                 }
             }
+        }
+        double v[NBT];
+#pragma unroll
+        for (int i = 0; i < NBT; ++i) {
+            const int idx = q.base + (i < q.nb ? 8 * i : 0);
+            v[i] = VM == VI_V_GLOBAL ? p.Vcur[idx] : vs[idx - vbase];
+        }
+        double r = q.nb > 0 ? x[0] * v[0] : 0.0;                // r[j] = a[j] (n < 8: res = 0.)
+#pragma unroll
+        for (int i = 1; i < NBT; ++i) {
+            const double t = x[i] * v[i];
+            r = i < q.nb ? r + t : r;
+        }
+        r += __shfl_xor(r, 1);                                  // r0 + r1 | r2 + r3 | r4 + r5 | r6 + r7
+        r += __shfl_xor(r, 2);                                  // (r0 + r1) + (r2 + r3) | (r4 + r5) + (r6 + r7)
+        r += __shfl_xor(r, 4);
+        const int rem = q.len & 7;
+        if (__any(rem != 0)) {                                  // only the last leaf of a row can have a remainder
+            const int tail = q.off + 8 * q.nb;
+#pragma unroll
+            for (int t = 0; t < 7; ++t) {
+                const int idx = t < rem ? tail + t : vbase;
+                const double pv = prow[idx] * (VM == VI_V_GLOBAL ? p.Vcur[idx] : vs[idx - vbase]);
+                r = t < rem ? r + pv : r;
+            }
+        }
+        if (j == 0 && q.lvalid) slots[q.l] = r;
+        if (q.c == pl.npiece - 1 && q.l0 + 8 >= l_piece[pl.npiece]) { // last pass of this (row, model): the recursion's additions
             __builtin_amdgcn_wave_barrier();
             for (int h = 0; h < pl.nh; ++h) {
                 for (int k = l_hoff[h] + lane; k < l_hoff[h + 1]; k += 64) {
@@ -793,10 +823,25 @@ __global__ __launch_bounds__(512) void vi_dense_exact_q(ViGenArgs p, ViExactPlan
             __builtin_amdgcn_wave_barrier();
             const int s = (int)(row / p.A);
             if (!p.robust && p.term && p.term[s]) nv = 0.0;
-            const double qm = p.R[(long)m * SA + row] + p.gamma * nv;
-            if (m == 0 || qm < best) best = qm;
+            const double qm = p.R[(long)q.m * SA + row] + p.gamma * nv;
+            if (q.m == 0 || qm < best) best = qm;
+            if (q.m == p.M - 1 && lane == 0 && q.row0 + wave < SA) p.Qnext[row] = best;
         }
-        if (lane == 0 && mine) p.Qnext[row] = best;
+    };
+    Pass pa, pb;
+    double xa[NBT], xb[NBT];
+    pa.row0 = (long)blockIdx.x * nw; pa.m = 0; pa.c = 0; pa.l0 = l_piece[0];
+    pa.valid = alive(pa.row0);
+    pb = pa; pb.valid = false;
+    if (pa.valid) issue(pa, xa);
+    while (pa.valid) {
+        pb = advance(pa);
+        if (pb.valid) issue(pb, xb);
+        compute(pa, xa);
+        if (!pb.valid) break;
+        pa = advance(pb);
+        if (pa.valid) issue(pa, xa);
+        compute(pb, xb);
     }
 }
 
