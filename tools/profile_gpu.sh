@@ -15,13 +15,14 @@ args_of() {
   elif [ "$1" = rvi_dense_shard ]; then echo "--workload rvi_dense_shard --dense-mode mfma";
   elif [ "$1" = rvi_dense_shard_exact ]; then echo "--workload rvi_dense_shard --dense-mode exact";
   else echo "--workload $1"; fi; }
-for wl in uct uct_prior uct_cartpole uct_stoch opd opd8192 ropd saopd vi rvi vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact; do
+# (TRACE_WLS / PMC_WLS: re-collect a subset after a kernel changed; summarize_profiles.py reads whatever is there)
+for wl in ${TRACE_WLS:-uct uct_prior uct_cartpole uct_stoch opd opd8192 ropd saopd vi rvi vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- \
       python /root/repo/bench.py $(args_of $wl) --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample > $OUT/trace_$wl.log 2>&1
 done
 # HBM traffic: FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots) -> two runs each; counters only,
 # no tracing domains besides the kernel trace
-for wl in uct uct_prior uct_stoch vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact opd opd8192 ropd saopd; do
+for wl in ${PMC_WLS:-uct uct_prior uct_stoch vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact opd opd8192 ropd saopd}; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o $wl -- \
         python /root/repo/bench.py $(args_of $wl) --steps 3 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample > $OUT/pmc_${wl}_$ctr.log 2>&1
