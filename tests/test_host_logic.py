@@ -392,3 +392,35 @@ def test_vi_exact_plan_replays_numpy_add_reduce():
                     written[len(leaves) + k] = True
             assert hoff[-1] == len(nodes) and written.all()
             assert slots[-1].tobytes() == np.add.reduce(a).tobytes(), (n, trial)
+
+
+def test_listing_order_permutes_every_model_kind():
+    """A non-ascending listing order (round 4: also on stochastic / sparse models): the spec's columns follow the order
+    -- transition, next states, rewards, availability -- and availability_of reads table and order off the env's hook,
+    cross-checked against get_available_actions()."""
+    from rl_agents_amd.envs import OrderedMaskedFiniteMDPEnv
+    order = [1, 0, 2, 3, 4]
+    for cfg in (generators.random_sparse(20, 5, 2, seed=1), generators.random_stochastic(12, 5, seed=2),
+                generators.random_deterministic(15, 5, seed=3)):
+        avail = generators.random_available(cfg["reward"].shape[0], 5, seed=7, rate=0.4)
+        env = OrderedMaskedFiniteMDPEnv(dict({k: v for k, v in cfg.items() if k != "original_shape"}, state=3,
+                                             available=avail, listing_order=order))
+        env.reset()
+        listed = env.get_available_actions()
+        assert listed == [a for a in order if avail[3, a]] and not hasattr(env.mdp, "available")
+        table, got = device_model.availability_of(env, env.mdp)
+        assert np.array_equal(table, avail) and list(got) == order
+        spec = device_model.spec_from_mdp(env.mdp, available=table, action_order=got)
+        assert list(spec.action_order) == order
+        assert np.array_equal(spec.reward, np.asarray(cfg["reward"])[:, order])
+        assert np.array_equal(spec.available.astype(bool), avail[:, order])
+        if cfg["mode"] == "deterministic":
+            assert np.array_equal(spec.transition, np.asarray(cfg["transition"])[:, order])
+        else:
+            assert np.array_equal(spec.transition, np.asarray(cfg["transition"])[:, order, :])
+        if cfg["mode"] == "sparse":
+            assert np.array_equal(spec.next, np.asarray(cfg["next"])[:, order, :])
+        assert device_model.spec_from_mdp(env.mdp, available=table, action_order=got).key() == spec.key()
+        assert device_model.spec_from_mdp(env.mdp, available=table).key() != spec.key()
+    with pytest.raises(ValueError):
+        OrderedMaskedFiniteMDPEnv(dict(generators.random_sparse(5, 3, 2, seed=1), listing_order=[0, 0, 1]))
