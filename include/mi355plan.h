@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 5
+#define MP_ABI_VERSION 6
 
 #define MP_OK 0
 #define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
@@ -128,6 +128,48 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
                         const double *reward, const uint8_t *terminal, int32_t done_on_next, int32_t max_steps,
                         mp_model **out);
 /*
+ * A BATCH of N independent deterministic finite MDPs of one shape (S states, A actions each), one per episode of a
+ * benchmark batch.  The reference evaluates one environment per process (trainer/evaluation.py:139-194,
+ * scripts/experiments.py:102-106) and, for an environment that is not a FiniteMDPEnv (highway-v0), re-extracts its own
+ * table with to_finite_mdp() at EVERY step (dynamic_programming/value_iteration.py:29-35, tree_search/abstract.py:59-62
+ * through env_preprocessors): a batch of such episodes is N distinct tables, all of which change between two steps.
+ *   transition int64 [N,S,A] (state indices LOCAL to each MDP, 0 <= t < S), reward double [N,S,A],
+ *   terminal uint8 [N,S] or NULL; done_on_next / max_steps as mp_model_load_table.  N * S * A < 2^31.
+ * The result is ONE table model over the disjoint union of the N state spaces -- GLOBAL state b * S + s, records packed
+ * exactly as mp_model_load_table packs them -- so that every entry point that takes a deterministic table model works
+ * on it unchanged and a root's plan depends on its own MDP only: mp_uct_plan*, mp_opd_plan, mp_ropd_plan,
+ * mp_saopd_*, mp_policy_load* (per-state policies over the N * S global states), mp_env_step, mp_greedy_actions take
+ * GLOBAL states; mp_uct_plan_models / mp_opd_plan_models below take (model_index, local state) pairs instead.
+ * Tree exports report global states.  mp_vi_solve on it would test convergence over all N MDPs at once, which is not what
+ * N agents do: use mp_vi_solve_batch (mp_vi_solve refuses a batch model).
+ * mp_model_batch_info: *N = number of MDPs (1 for any other model), *S_each = states per MDP.
+ */
+int mp_model_load_table_batch(mp_ctx *ctx, int32_t N, int32_t S, int32_t A, const int64_t *transition, const double *reward,
+                              const uint8_t *terminal, int32_t done_on_next, int32_t max_steps, mp_model **out);
+int mp_model_batch_info(const mp_model *model, int32_t *N, int32_t *S_each);
+/*
+ * Replace the tables of MDPs [first, first + count) of a batch model (or, with first = 0 and count = 1, the whole of a
+ * single-MDP table model from mp_model_load_table with M = 1): the per-step delta of a batch of highway episodes is each
+ * episode's own table.  Arrays as mp_model_load_table_batch with N = count (host pointers; terminal must be given iff the
+ * model was loaded with terminal flags).  Stream-ordered on the ctx stream through a pinned staging block owned by the
+ * model: work enqueued earlier still reads the old tables, work enqueued later the new ones; nothing is synchronised
+ * unless the previous update's copies are still in flight.  Only the touched records are re-packed.  Policies loaded for
+ * the model become invalid (their fused records hold the old transitions).
+ */
+int mp_model_update_tables(mp_model *model, int32_t first, int32_t count, const int64_t *transition, const double *reward,
+                           const uint8_t *terminal);
+/*
+ * Delta upload of a changed model (value_iteration.py:12-21,29-35 re-converts the env on every act):
+ * replace n_rows rows of a deterministic table model (single, M = 1, or batch).
+ *   rows int32 [n_rows]: GLOBAL state ids, distinct;  transition int64 [n_rows,A] (LOCAL next-state indices of the row's
+ *   MDP), reward double [n_rows,A], terminal uint8 [n_rows] or NULL = the rows' terminal flags do not change.
+ * With terminal == NULL only the records of the listed rows are re-packed; otherwise every record of the MDPs that own a
+ * listed row is (a record carries terminal[next]: predecessors of a row whose flag changed must follow).  Stream-ordered
+ * like mp_model_update_tables.
+ */
+int mp_model_update_rows(mp_model *model, int32_t n_rows, const int32_t *rows, const int64_t *transition, const double *reward,
+                         const uint8_t *terminal);
+/*
  * Environments that restrict the actions available in a state -- state.get_available_actions(), read by
  * DeterministicNode.expand (deterministic.py:32-35) -- as a table:
  *   available uint8 [S,A], non-zero = action a is listed in state s; every state needs at least one (else MP_ERR_ARG).
@@ -188,6 +230,17 @@ int mp_model_info(const mp_model *model, int32_t *mode, int32_t *M, int32_t *S, 
  */
 int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
                 int32_t robust, double *Q_out, int32_t *sweeps_out, int32_t mem);
+/*
+ * N value-iteration agents at once: mp_vi_solve of every MDP of a batch model (mp_model_load_table_batch) in ONE launch,
+ * one workgroup per MDP -- the fixed-point iteration of each MDP runs to ITS OWN allclose exit, exactly as N
+ * ValueIterationAgent objects would (value_iteration.py:42-45,65-73 per agent; trainer/evaluation.py:139-194 runs one
+ * agent per process).  Bit-exact with N mp_vi_solve calls on the N tables.
+ *   Q_out double [N,S,A] (= [N*S, A] over global states: what mp_greedy_actions takes), sweeps_out int32 [N].
+ * mem = MP_MEM_DEVICE only enqueues.  Rows of an MDP live in registers and its value vector in LDS when
+ * S <= 4096 (any such S), else the value vector is double-buffered in LDS (S <= 10 200) or kept in global memory.
+ */
+int mp_vi_solve_batch(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                      double *Q_out, int32_t *sweeps_out, int32_t mem);
 /* get_state_value (value_iteration.py:37-40): the V-form iteration.  V_out double [S]. */
 int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
                   double *V_out, int32_t mem);
@@ -249,6 +302,16 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
                 const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
                 int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
                 int64_t *env_steps, int32_t mem);
+/*
+ * mp_uct_plan on a batch model (mp_model_load_table_batch) with one MDP per root: root i plans on MDP model_index[i]
+ * from its LOCAL state root_state[i] (model_index int32 [n_roots], values in [0, N); several roots may share an MDP).
+ * Everything else as mp_uct_plan; equal to mp_uct_plan with root_state = model_index * S + root_state.
+ */
+int mp_uct_plan_models(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *model_index, const int32_t *root_state,
+                       const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                       const double *prior_p, const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                       int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
+                       int64_t *env_steps, int32_t mem);
 /*
  * Per-state prior / rollout policies: MCTSWithPriorPolicyAgent (tree_search/mcts_with_prior.py:8-71) replaces the
  * planner's two policies by agent_policy_available (:47-62), the action distribution a prior agent gives for the state
@@ -373,6 +436,11 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
                 double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
                 int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status,
                 int32_t mem);
+/* mp_opd_plan on a batch model with one MDP per root (see mp_uct_plan_models): model_index int32 [n_roots], root_state LOCAL. */
+int mp_opd_plan_models(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *model_index, const int32_t *root_state,
+                       int32_t budget, double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len,
+                       int32_t *plans, int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps,
+                       int32_t *status, int32_t mem);
 /* Tree of root `root` after the last mp_opd_plan, creation order (the n_children children of an expanded node are
  * contiguous from first_child: |A|, or the available actions of its state); host arrays, capacity `cap`. */
 int mp_opd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes, int32_t *parent, int32_t *action,

@@ -564,3 +564,48 @@ def ropd_plan_batch(transitions, rewards, terminals, s0, budget, gamma, terminal
                               _p(lo, C.c_double), _p(up, C.c_double), _p(steps, C.c_int64), _p(status, C.c_int32),
                               int(n_threads), _p(av, C.c_uint8))
     return dict(plans=plans, plan_len=plan_len, root_lower=lo, root_upper=up, env_steps=steps, status=status, rng_after=rng)
+
+
+# ---- N independent agents, each with its own table (a batch of episodes: trainer/evaluation.py:139-194 runs one per process) --
+def vi_solve_each(transitions, rewards, terminals, gamma=1.0, iterations=100, rtol=1e-5, atol=1e-8):
+    """N ValueIterationAgent objects, one per deterministic table (value_iteration.py:42-45,65-73 each): transitions int
+    [N,S,A] (local states), rewards [N,S,A], terminals [N,S] -> (Q [N,S,A], sweeps [N]); N sequential vi_solve calls."""
+    t, r = _i64(transitions), _f64(rewards)
+    n = t.shape[0]
+    q = np.zeros(r.shape, np.float64)
+    sweeps = np.zeros(n, np.int32)
+    for b in range(n):
+        q[b], sweeps[b] = vi_solve("deterministic", t[b], r[b], None if terminals is None else terminals[b], gamma=gamma,
+                                   iterations=iterations, rtol=rtol, atol=atol)
+    return q, sweeps
+
+
+def uct_plan_each(transitions, rewards, terminals, model_index, s0, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                  rng_states, max_plan_len=16, **kw):
+    """Root i plans with MCTS (tree_search/mcts.py:132-184) on table model_index[i] from local state s0[i]: one
+    uct_plan_batch call per root, results stacked like uct_plan_batch's."""
+    n = len(s0)
+    rng = np.array(rng_states, dtype=np.uint64).reshape(n, 6)
+    outs = []
+    for i in range(n):
+        b = int(model_index[i])
+        steps0 = None if kw.get("steps0") is None else [kw["steps0"][i]]
+        outs.append(uct_plan_batch(transitions[b], rewards[b], None if terminals is None else terminals[b], [int(s0[i])],
+                                   episodes, horizon, gamma, temperature, prior_p, rollout_p, rng[i:i + 1],
+                                   steps0=steps0, max_steps=kw.get("max_steps", 0), done_rule=kw.get("done_rule", "source"),
+                                   max_plan_len=max_plan_len))
+    return {k: np.concatenate([o[k] for o in outs]) for k in outs[0]}
+
+
+def opd_plan_each(transitions, rewards, terminals, model_index, s0, budget, gamma, terminal_reward=0.0, rng_states=None,
+                  max_plan_len=32, done_rule="source"):
+    """Root i plans with OPD (tree_search/deterministic.py:106-122) on table model_index[i] from local state s0[i]."""
+    n = len(s0)
+    rng = None if rng_states is None else np.array(rng_states, dtype=np.uint64).reshape(n, 6)
+    outs = []
+    for i in range(n):
+        b = int(model_index[i])
+        outs.append(opd_plan_batch(transitions[b], rewards[b], None if terminals is None else terminals[b], [int(s0[i])], budget,
+                                   gamma, terminal_reward, None if rng is None else rng[i:i + 1], done_rule=done_rule,
+                                   max_plan_len=max_plan_len))
+    return {k: np.concatenate([o[k] for o in outs]) for k in outs[0]}

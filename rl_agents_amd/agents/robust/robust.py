@@ -129,13 +129,23 @@ class DiscreteRobustPlanner(OptimisticDeterministicPlanner):
     def supports_device_loop(self):
         return type(self).plan_batch is DiscreteRobustPlanner.plan_batch
 
+    def begin_device_loop(self):
+        """A new device-resident evaluation run: forget the joint model held for the previous one."""
+        self._device_joint = None
+
     def plan_batch_device(self, state, model, n, d_state, d_steps, d_rng, d_plans, d_len, d_env_steps, d_status, d_value=None):
         """One asynchronous batched plan (mp_ropd_plan, MP_MEM_DEVICE): every model starts in the episode's state (the agent
         rebuilds its JointEnv from the true env before every plan, robust.py:67-70).  ``model`` (the true env's, which the loop
         steps) is not used; ``state`` is the JointEnv."""
         import torch
         cfg = self.config
-        jm, _ = self.joint_model(state)
+        # the joint model of this loop's JointEnv, resolved ONCE: joint_model() stacks and hashes every candidate model's
+        # tables on the host, O(M S A) work that would make every step of an asynchronous loop host-bound (ADVICE r4);
+        # the evaluation loop announces itself with begin_device_loop()
+        held = getattr(self, "_device_joint", None)
+        if held is None or held[0] is not state:
+            held = self._device_joint = (state, self.joint_model(state)[0])
+        jm = held[1]
         budget = int(cfg["budget"])
         if cfg["gamma"] == 1 and budget >= jm.A:
             raise ZeroDivisionError("float division by zero")

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <mutex>
 #include <set>
 #include <unordered_map>
@@ -187,6 +188,67 @@ __global__ void pack_records(int S, int A, const int32_t *__restrict__ T, const 
     rec[i] = r;
 }
 
+// the same for the records of states [s0, s0 + ns) only (mp_model_update_tables / _rows: T, term, avail, rec are the
+// model's whole arrays)
+__global__ void pack_records_range(int s0, int ns, int A, const int32_t *__restrict__ T, const double *__restrict__ R,
+                                   const uint8_t *__restrict__ term, const uint8_t *__restrict__ avail, Rec *__restrict__ rec,
+                                   uint16_t *__restrict__ t16)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (long)ns * A) return;
+    const long i = (long)s0 * A + j;
+    const int s = (int)(i / A);
+    Rec r;
+    r.next = T[i];
+    r.flags = (term && term[s] ? 1u : 0u) | (term && term[r.next] ? 2u : 0u) | (!avail || avail[i] ? 4u : 0u);
+    r.reward = R[i];
+    rec[i] = r;
+    if (t16) t16[i] = (uint16_t)((uint32_t)r.next | (term && term[r.next] ? 0x8000u : 0u));
+}
+
+// mp_model_update_rows: rows[k] = global state id; its |A| transitions / rewards (+ terminal flag, + reward indices) from the
+// staged arrays into the model's tables
+__global__ void scatter_rows(int n_rows, int A, const int32_t *__restrict__ rows, const int32_t *__restrict__ t_new,
+                             const double *__restrict__ r_new, const uint8_t *__restrict__ term_new,
+                             const uint8_t *__restrict__ r8_new, int32_t *__restrict__ T, double *__restrict__ R,
+                             uint8_t *__restrict__ term, uint8_t *__restrict__ r8)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (long)n_rows * A) return;
+    const int k = (int)(j / A), a = (int)(j - (long)k * A);
+    const long i = (long)rows[k] * A + a;
+    T[i] = t_new[j];
+    R[i] = r_new[j];
+    if (r8 && r8_new) r8[i] = r8_new[j];
+    if (a == 0 && term && term_new) term[rows[k]] = term_new[k];
+}
+
+// ... and the records of exactly those rows (terminal flags unchanged)
+__global__ void pack_records_rows(int n_rows, int A, const int32_t *__restrict__ rows, const int32_t *__restrict__ T,
+                                  const double *__restrict__ R, const uint8_t *__restrict__ term, const uint8_t *__restrict__ avail,
+                                  Rec *__restrict__ rec, uint16_t *__restrict__ t16)
+{
+    const long j = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= (long)n_rows * A) return;
+    const int k = (int)(j / A), a = (int)(j - (long)k * A);
+    const int s = rows[k];
+    const long i = (long)s * A + a;
+    Rec r;
+    r.next = T[i];
+    r.flags = (term && term[s] ? 1u : 0u) | (term && term[r.next] ? 2u : 0u) | (!avail || avail[i] ? 4u : 0u);
+    r.reward = R[i];
+    rec[i] = r;
+    if (t16) t16[i] = (uint16_t)((uint32_t)r.next | (term && term[r.next] ? 0x8000u : 0u));
+}
+
+// root i of a batch model: global state = model_index[i] * Sb + local state (mp_uct_plan_models / mp_opd_plan_models)
+__global__ void globalize_roots(int n, int Sb, const int32_t *__restrict__ model_index, const int32_t *__restrict__ local,
+                                int32_t *__restrict__ global)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) global[i] = model_index[i] * Sb + local[i];
+}
+
 // compact transitions for the LDS variant of the UCT kernel (S < 32768)
 __global__ void pack_t16(int S, int A, const int32_t *__restrict__ T, const uint8_t *__restrict__ term,
                          uint16_t *__restrict__ t16)
@@ -277,6 +339,35 @@ __global__ void unpack_rows_kernel(RowCols c, int n_total, int world, int per, c
     while (k + 1 < c.n && col >= c.off[k + 1]) ++k;
     const int w = c.off[k + 1] - c.off[k];
     static_cast<uint32_t *>(const_cast<void *>(c.ptr[k]))[(long)row * w + (col - c.off[k])] = packed[((long)r * per + j) * wpr + col];
+}
+
+int globalize_roots_arg(mp_ctx *ctx, const mp_model *model, int n_roots, const int32_t *model_index, const int32_t *root_state,
+                        int mem, std::vector<int32_t> &host_tmp, const int32_t **out)
+{
+    if (!ctx || !model || !model_index || !root_state) return fail(MP_ERR_ARG, "plan on a batch model: NULL argument");
+    if (model->mode != MP_MODE_DETERMINISTIC || !model->rec) return fail(MP_ERR_MODE, "plan on a batch model: deterministic table models only");
+    if (n_roots < 1) return fail(MP_ERR_ARG, "plan on a batch model: n_roots = %d", n_roots);
+    const int Sb = model->Sb > 0 ? model->Sb : model->S;
+    if (mem_arrays(mem) == MP_MEM_DEVICE) {
+        int32_t *d = nullptr;
+        MP_HIP(hipSetDevice(ctx->device));
+        MP_TRY(ws_get(ctx, WS_GROOT, (size_t)n_roots, &d));
+        hipLaunchKernelGGL(globalize_roots, dim3((unsigned)((n_roots + 255) / 256)), dim3(256), 0, ctx->stream, n_roots, Sb, model_index,
+                           root_state, d);
+        MP_HIP(hipGetLastError());
+        *out = d;
+        return MP_OK;
+    }
+    host_tmp.resize((size_t)n_roots);
+    for (int i = 0; i < n_roots; ++i) {
+        if (model_index[i] < 0 || model_index[i] >= model->NB)
+            return fail(MP_ERR_ARG, "plan on a batch model: model_index[%d] = %d outside [0, %d)", i, model_index[i], model->NB);
+        if (root_state[i] < 0 || root_state[i] >= Sb)
+            return fail(MP_ERR_ARG, "plan on a batch model: root_state[%d] = %d outside [0, %d)", i, root_state[i], Sb);
+        host_tmp[i] = model_index[i] * Sb + root_state[i];
+    }
+    *out = host_tmp.data();
+    return MP_OK;
 }
 
 } // namespace mp
@@ -653,22 +744,16 @@ int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches)
 }
 
 // ------------------------------------------------------------------ models --------------------
-int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition,
-                        const double *reward, const uint8_t *terminal, int32_t done_on_next, int32_t max_steps,
-                        mp_model **out)
+extern "C++" {
+namespace {
+// t32: the [M,S,A] transitions, range-checked and narrowed by the caller
+int load_table_common(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const std::vector<int32_t> &t32, const double *reward,
+                      const uint8_t *terminal, int32_t done_on_next, int32_t max_steps, mp_model **out)
 {
-    if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_table: NULL argument");
-    if (M < 1 || S < 1 || A < 1) return fail(MP_ERR_ARG, "mp_model_load_table: bad shape M=%d S=%d A=%d", M, S, A);
     const size_t n = (size_t)M * S * A;
-    std::vector<int32_t> t32(n);
-    for (size_t i = 0; i < n; ++i) {
-        const int64_t v = transition[i];
-        if (v < 0 || v >= S) return fail(MP_ERR_ARG, "mp_model_load_table: transition[%zu] = %lld outside [0, %d)", i, (long long)v, S);
-        t32[i] = (int32_t)v;
-    }
     MP_HIP(hipSetDevice(ctx->device));
     mp_model *m = new mp_model();
-    m->ctx = ctx; m->mode = MP_MODE_DETERMINISTIC; m->M = M; m->S = S; m->A = A; m->Sc = S;
+    m->ctx = ctx; m->mode = MP_MODE_DETERMINISTIC; m->M = M; m->S = S; m->A = A; m->Sc = S; m->NB = 1; m->Sb = S;
     m->done_on_next = done_on_next ? 1 : 0; m->max_steps = max_steps > 0 ? max_steps : 0;
     auto bail = [&](int rc) { mp_model_free(m); return rc; };
     if (hipMalloc(&m->T, n * sizeof(int32_t)) != hipSuccess || hipMalloc(&m->R, n * sizeof(double)) != hipSuccess ||
@@ -689,7 +774,8 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
                            m->t16);
         // the LDS-resident form of model 0 (uct.hip ENV_TABLE_LDSR): rewards as 8-bit indices into the table of their
         // distinct values (by bit pattern: -0.0 and 0.0, or two NaNs, stay what they are) -- when there are at most 256
-        std::unordered_map<uint64_t, int> seen;
+        m->rmap = new std::unordered_map<uint64_t, int>();
+        std::unordered_map<uint64_t, int> &seen = *m->rmap;
         std::vector<uint8_t> idx(((size_t)sa + 15) & ~(size_t)15, 0);
         std::vector<double> dict(256, 0.0);
         bool fits = true;
@@ -711,10 +797,264 @@ int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int6
                 hipMemcpy(m->rdict, dict.data(), 256 * sizeof(double), hipMemcpyHostToDevice) != hipSuccess)
                 return bail(fail(MP_ERR_HIP, "mp_model_load_table: upload failed"));
             m->n_rdict = (int)seen.size();
+        } else {
+            delete m->rmap;
+            m->rmap = nullptr;
         }
     }
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) return bail(fail(MP_ERR_HIP, "pack_records failed"));
     *out = m;
+    return MP_OK;
+}
+
+// pinned staging block / device scratch block of a model's table updates, grown on demand
+int update_blocks(mp_model *m, size_t stage_bytes, size_t dev_bytes)
+{
+    mp_ctx *ctx = m->ctx;
+    if (!m->upd_done) MP_HIP(hipEventCreateWithFlags(&m->upd_done, hipEventDisableTiming));
+    if (m->upd_pending) { // the previous update's copies still read the staging block
+        MP_HIP(hipEventSynchronize(m->upd_done));
+        m->upd_pending = false;
+    }
+    if (stage_bytes > m->upd_stage_cap) {
+        if (m->upd_stage) MP_HIP(hipHostFree(m->upd_stage));
+        m->upd_stage = nullptr; m->upd_stage_cap = 0;
+        const size_t want = stage_bytes + stage_bytes / 4 + 4096;
+        if (hipHostMalloc(&m->upd_stage, want, hipHostMallocDefault) != hipSuccess)
+            return fail(MP_ERR_ALLOC, "model update: hipHostMalloc(%zu) failed", want);
+        m->upd_stage_cap = want;
+    }
+    if (dev_bytes > m->upd_dev_cap) {
+        if (m->upd_dev) {
+            MP_HIP(hipStreamSynchronize(ctx->stream)); // (enqueued kernels of the previous update may still read it)
+            MP_HIP(hipFree(m->upd_dev));
+        }
+        m->upd_dev = nullptr; m->upd_dev_cap = 0;
+        const size_t want = dev_bytes + dev_bytes / 4 + 4096;
+        if (hipMalloc(&m->upd_dev, want) != hipSuccess) return fail(MP_ERR_ALLOC, "model update: hipMalloc(%zu) failed", want);
+        m->upd_dev_cap = want;
+    }
+    return MP_OK;
+}
+
+// index of reward r in the model's table of distinct rewards, extending it (host mirror + device copy, stream-ordered);
+// -1: the table is full -- the model loses its LDS-resident form (the record-gather kernels serve it)
+int reward_index(mp_model *m, double r, bool *grew)
+{
+    uint64_t bits;
+    memcpy(&bits, &r, sizeof(bits));
+    auto it = m->rmap->find(bits);
+    if (it != m->rmap->end()) return it->second;
+    if (m->rmap->size() >= 256) return -1;
+    const int k = (int)m->rmap->size();
+    m->rmap->emplace(bits, k);
+    *grew = true;
+    return k;
+}
+
+void drop_compact_rewards(mp_model *m)
+{
+    // (r8 / rdict stay allocated -- enqueued kernels may still read them -- but no later launch uses them)
+    m->n_rdict = 0;
+    delete m->rmap;
+    m->rmap = nullptr;
+}
+} // namespace
+} // extern "C++"
+
+int mp_model_load_table(mp_ctx *ctx, int32_t M, int32_t S, int32_t A, const int64_t *transition,
+                        const double *reward, const uint8_t *terminal, int32_t done_on_next, int32_t max_steps,
+                        mp_model **out)
+{
+    if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_table: NULL argument");
+    if (M < 1 || S < 1 || A < 1) return fail(MP_ERR_ARG, "mp_model_load_table: bad shape M=%d S=%d A=%d", M, S, A);
+    const size_t n = (size_t)M * S * A;
+    std::vector<int32_t> t32(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t v = transition[i];
+        if (v < 0 || v >= S) return fail(MP_ERR_ARG, "mp_model_load_table: transition[%zu] = %lld outside [0, %d)", i, (long long)v, S);
+        t32[i] = (int32_t)v;
+    }
+    return load_table_common(ctx, M, S, A, t32, reward, terminal, done_on_next, max_steps, out);
+}
+
+int mp_model_load_table_batch(mp_ctx *ctx, int32_t N, int32_t S, int32_t A, const int64_t *transition, const double *reward,
+                              const uint8_t *terminal, int32_t done_on_next, int32_t max_steps, mp_model **out)
+{
+    if (!ctx || !out || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_load_table_batch: NULL argument");
+    if (N < 1 || S < 1 || A < 1) return fail(MP_ERR_ARG, "mp_model_load_table_batch: bad shape N=%d S=%d A=%d", N, S, A);
+    if ((int64_t)N * S * A >= ((int64_t)1 << 31))
+        return fail(MP_ERR_ARG, "mp_model_load_table_batch: N * S * A = %lld does not fit 31 bits", (long long)N * S * A);
+    const size_t n = (size_t)N * S * A, sa = (size_t)S * A;
+    std::vector<int32_t> t32(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t v = transition[i];
+        if (v < 0 || v >= S)
+            return fail(MP_ERR_ARG, "mp_model_load_table_batch: transition[%zu] = %lld outside [0, %d)", i, (long long)v, S);
+        t32[i] = (int32_t)(i / sa) * S + (int32_t)v; // global state of the MDP's own block
+    }
+    MP_TRY(load_table_common(ctx, 1, N * S, A, t32, reward, terminal, done_on_next, max_steps, out));
+    (*out)->NB = N;
+    (*out)->Sb = S;
+    return MP_OK;
+}
+
+int mp_model_batch_info(const mp_model *m, int32_t *N, int32_t *S_each)
+{
+    if (!m) return fail(MP_ERR_ARG, "model is NULL");
+    if (N) *N = m->NB;
+    if (S_each) *S_each = m->NB > 1 || m->Sb > 0 ? m->Sb : m->S;
+    return MP_OK;
+}
+
+int mp_model_update_tables(mp_model *m, int32_t first, int32_t count, const int64_t *transition, const double *reward,
+                           const uint8_t *terminal)
+{
+    if (!m || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_update_tables: NULL argument");
+    if (m->mode != MP_MODE_DETERMINISTIC || !m->rec || m->M != 1 || m->rec_all)
+        return fail(MP_ERR_MODE, "mp_model_update_tables: deterministic table models (M = 1) only");
+    const int Sb = m->Sb > 0 ? m->Sb : m->S, A = m->A;
+    if (first < 0 || count < 1 || first + count > m->NB)
+        return fail(MP_ERR_ARG, "mp_model_update_tables: MDPs [%d, %d) of %d", first, first + count, m->NB);
+    if ((terminal != nullptr) != (m->term != nullptr))
+        return fail(MP_ERR_ARG, "mp_model_update_tables: terminal flags must be given iff the model was loaded with them");
+    mp_ctx *ctx = m->ctx;
+    MP_HIP(hipSetDevice(ctx->device));
+    const size_t ns = (size_t)count * Sb, n = ns * A;
+    const bool compact = m->r8 && m->rmap && m->n_rdict > 0;
+    // staging layout: T int32 [n] | R double [n] | term uint8 [ns] | r8 uint8 [n] | rdict double [256]
+    const size_t off_r = (n * 4 + 15) & ~(size_t)15, off_term = off_r + n * 8, off_r8 = (off_term + ns + 15) & ~(size_t)15,
+                 off_dict = (off_r8 + n + 15) & ~(size_t)15, total = off_dict + 256 * 8;
+    MP_TRY(update_blocks(m, total, 0));
+    char *st = static_cast<char *>(m->upd_stage);
+    int32_t *t32 = reinterpret_cast<int32_t *>(st);
+    const size_t sa = (size_t)Sb * A;
+    for (size_t i = 0; i < n; ++i) {
+        const int64_t v = transition[i];
+        if (v < 0 || v >= Sb)
+            return fail(MP_ERR_ARG, "mp_model_update_tables: transition[%zu] = %lld outside [0, %d)", i, (long long)v, Sb);
+        t32[i] = (first + (int32_t)(i / sa)) * Sb + (int32_t)v;
+    }
+    memcpy(st + off_r, reward, n * 8);
+    if (terminal) memcpy(st + off_term, terminal, ns);
+    bool keep_compact = compact, grew = false;
+    if (compact) {
+        uint8_t *idx = reinterpret_cast<uint8_t *>(st + off_r8);
+        for (size_t i = 0; i < n && keep_compact; ++i) {
+            const int k = reward_index(m, reward[i], &grew);
+            if (k < 0) keep_compact = false;
+            else idx[i] = (uint8_t)k;
+        }
+    }
+    hipStream_t s = ctx->stream;
+    const size_t g0 = (size_t)first * Sb; // first global state
+    MP_HIP(hipMemcpyAsync(m->T + g0 * A, t32, n * 4, hipMemcpyHostToDevice, s));
+    MP_HIP(hipMemcpyAsync(m->R + g0 * A, st + off_r, n * 8, hipMemcpyHostToDevice, s));
+    if (terminal) MP_HIP(hipMemcpyAsync(m->term + g0, st + off_term, ns, hipMemcpyHostToDevice, s));
+    if (compact && keep_compact) {
+        MP_HIP(hipMemcpyAsync(m->r8 + g0 * A, st + off_r8, n, hipMemcpyHostToDevice, s));
+        if (grew) {
+            double *dict = reinterpret_cast<double *>(st + off_dict);
+            for (const auto &kv : *m->rmap) memcpy(&dict[kv.second], &kv.first, 8);
+            MP_HIP(hipMemcpyAsync(m->rdict, dict, m->rmap->size() * 8, hipMemcpyHostToDevice, s));
+            m->n_rdict = (int)m->rmap->size();
+        }
+    } else if (compact) {
+        drop_compact_rewards(m);
+    }
+    hipLaunchKernelGGL(pack_records_range, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, (int)g0, (int)ns, A, m->T, m->R,
+                       m->term, (const uint8_t *)m->avail, m->rec, m->t16);
+    MP_HIP(hipGetLastError());
+    MP_HIP(hipEventRecord(m->upd_done, s));
+    m->upd_pending = true;
+    m->serial = mp::next_model_serial(); // policies fused from the old records no longer belong to this model
+    return MP_OK;
+}
+
+int mp_model_update_rows(mp_model *m, int32_t n_rows, const int32_t *rows, const int64_t *transition, const double *reward,
+                         const uint8_t *terminal)
+{
+    if (!m || !rows || !transition || !reward) return fail(MP_ERR_ARG, "mp_model_update_rows: NULL argument");
+    if (m->mode != MP_MODE_DETERMINISTIC || !m->rec || m->M != 1 || m->rec_all)
+        return fail(MP_ERR_MODE, "mp_model_update_rows: deterministic table models (M = 1) only");
+    if (n_rows < 1) return fail(MP_ERR_ARG, "mp_model_update_rows: n_rows = %d", n_rows);
+    if (terminal && !m->term) return fail(MP_ERR_ARG, "mp_model_update_rows: the model was loaded without terminal flags");
+    const int Sb = m->Sb > 0 ? m->Sb : m->S, A = m->A;
+    mp_ctx *ctx = m->ctx;
+    MP_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)n_rows * A;
+    const bool compact = m->r8 && m->rmap && m->n_rdict > 0;
+    // staging = device scratch layout: rows int32 [n_rows] | T int32 [n] | R double [n] | term uint8 [n_rows] | r8 uint8 [n] | rdict [256]
+    const size_t off_t = ((size_t)n_rows * 4 + 15) & ~(size_t)15, off_r = (off_t + n * 4 + 15) & ~(size_t)15, off_term = off_r + n * 8,
+                 off_r8 = (off_term + n_rows + 15) & ~(size_t)15, off_dict = (off_r8 + n + 15) & ~(size_t)15, total = off_dict + 256 * 8;
+    MP_TRY(update_blocks(m, total, total));
+    char *st = static_cast<char *>(m->upd_stage);
+    int32_t *hrows = reinterpret_cast<int32_t *>(st), *t32 = reinterpret_cast<int32_t *>(st + off_t);
+    std::vector<int32_t> owners; // MDPs that own a listed row
+    for (int k = 0; k < n_rows; ++k) {
+        const int32_t g = rows[k];
+        if (g < 0 || g >= m->S) return fail(MP_ERR_ARG, "mp_model_update_rows: rows[%d] = %d outside [0, %d)", k, g, m->S);
+        hrows[k] = g;
+        const int32_t b = g / Sb;
+        if (owners.empty() || owners.back() != b) owners.push_back(b);
+        for (int a = 0; a < A; ++a) {
+            const int64_t v = transition[(size_t)k * A + a];
+            if (v < 0 || v >= Sb)
+                return fail(MP_ERR_ARG, "mp_model_update_rows: transition[%d, %d] = %lld outside [0, %d)", k, a, (long long)v, Sb);
+            t32[(size_t)k * A + a] = b * Sb + (int32_t)v;
+        }
+    }
+    memcpy(st + off_r, reward, n * 8);
+    if (terminal) memcpy(st + off_term, terminal, (size_t)n_rows);
+    bool keep_compact = compact, grew = false;
+    if (compact) {
+        uint8_t *idx = reinterpret_cast<uint8_t *>(st + off_r8);
+        for (size_t i = 0; i < n && keep_compact; ++i) {
+            const int k = reward_index(m, reward[i], &grew);
+            if (k < 0) keep_compact = false;
+            else idx[i] = (uint8_t)k;
+        }
+    }
+    if (compact && keep_compact && grew) {
+        double *dict = reinterpret_cast<double *>(st + off_dict);
+        for (const auto &kv : *m->rmap) memcpy(&dict[kv.second], &kv.first, 8);
+    }
+    hipStream_t s = ctx->stream;
+    char *dv = static_cast<char *>(m->upd_dev);
+    MP_HIP(hipMemcpyAsync(dv, st, total, hipMemcpyHostToDevice, s));
+    if (compact && keep_compact && grew) {
+        MP_HIP(hipMemcpyAsync(m->rdict, dv + off_dict, m->rmap->size() * 8, hipMemcpyDeviceToDevice, s));
+        m->n_rdict = (int)m->rmap->size();
+    }
+    if (compact && !keep_compact) drop_compact_rewards(m);
+    const int32_t *drows = reinterpret_cast<const int32_t *>(dv);
+    hipLaunchKernelGGL(scatter_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_rows, A, drows,
+                       reinterpret_cast<const int32_t *>(dv + off_t), reinterpret_cast<const double *>(dv + off_r),
+                       terminal ? reinterpret_cast<const uint8_t *>(dv + off_term) : (const uint8_t *)nullptr,
+                       compact && keep_compact ? reinterpret_cast<const uint8_t *>(dv + off_r8) : (const uint8_t *)nullptr, m->T, m->R,
+                       m->term, compact && keep_compact ? m->r8 : (uint8_t *)nullptr);
+    if (!terminal) {
+        hipLaunchKernelGGL(pack_records_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, n_rows, A, drows, m->T, m->R, m->term,
+                           (const uint8_t *)m->avail, m->rec, m->t16);
+    } else {
+        // a record carries terminal[next]: every record of the owning MDPs follows (one launch per MDP; many owners: all)
+        std::sort(owners.begin(), owners.end());
+        owners.erase(std::unique(owners.begin(), owners.end()), owners.end());
+        if (owners.size() > 64) {
+            const long sa = (long)m->S * A;
+            hipLaunchKernelGGL(pack_records_range, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, s, 0, m->S, A, m->T, m->R, m->term,
+                               (const uint8_t *)m->avail, m->rec, m->t16);
+        } else {
+            const long sa = (long)Sb * A;
+            for (int32_t b : owners)
+                hipLaunchKernelGGL(pack_records_range, dim3((unsigned)((sa + 255) / 256)), dim3(256), 0, s, b * Sb, Sb, A, m->T, m->R,
+                                   m->term, (const uint8_t *)m->avail, m->rec, m->t16);
+        }
+    }
+    MP_HIP(hipGetLastError());
+    MP_HIP(hipEventRecord(m->upd_done, s));
+    m->upd_pending = true;
+    m->serial = mp::next_model_serial();
     return MP_OK;
 }
 
@@ -893,6 +1233,11 @@ int mp_model_free(mp_model *m)
     if (m->thr) hipFree(m->thr);
     if (m->srec) hipFree(m->srec);
     if (m->srec_rtab) hipFree(m->srec_rtab);
+    if (m->upd_pending && m->upd_done) (void)hipEventSynchronize(m->upd_done);
+    if (m->upd_stage) (void)hipHostFree(m->upd_stage);
+    if (m->upd_dev) hipFree(m->upd_dev);
+    if (m->upd_done) (void)hipEventDestroy(m->upd_done);
+    delete m->rmap;
     delete m;
     return MP_OK;
 }

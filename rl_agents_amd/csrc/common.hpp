@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/mi355plan.h"
@@ -61,7 +62,7 @@ struct TreeMeta {
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,
        WS_IO5, WS_IO6, WS_IO7, WS_IO8, WS_IO9, WS_TAB0, WS_TAB1, WS_TAB2, WS_TAB3, WS_VI0, WS_VI1, WS_VI2, WS_VI3,
-       WS_VI4, WS_VI5, WS_COUNT };
+       WS_VI4, WS_VI5, WS_GROOT, WS_COUNT };
 
 // everything a captured chain of deterministic VI sweeps bakes into its kernel arguments
 struct ViGraphKey {
@@ -189,6 +190,18 @@ struct mp_model {
     uint64_t serial = mp::next_model_serial(); // distinguishes a model from a later one at the same address
     int mode = 0, M = 1, S = 0, A = 0, B = 0;
     int Sc = 0; // dense models: number of next-state columns (= S, or the full |S| for a block of rows)
+    // batch models (mp_model_load_table_batch): NB independent MDPs of Sb states each, S = NB * Sb GLOBAL states
+    // (b * Sb + s); every table below is the disjoint union.  NB = 1, Sb = S for any other model.
+    int NB = 1, Sb = 0;
+    // table updates (mp_model_update_tables / _rows): a pinned staging block + a device scratch block owned by the model,
+    // and the event that says the last update's copies out of the staging block are done
+    void *upd_stage = nullptr;
+    size_t upd_stage_cap = 0;
+    void *upd_dev = nullptr;
+    size_t upd_dev_cap = 0;
+    hipEvent_t upd_done = nullptr;
+    bool upd_pending = false;
+    std::unordered_map<uint64_t, int> *rmap = nullptr; // host mirror of rdict (bit pattern -> index): updates extend it
     int done_on_next = 0, max_steps = 0;
     bool masked = false;     // mp_model_set_available restricted the action sets (state.get_available_actions())
     uint8_t *avail = nullptr; // device [S*A] flags, only when masked
@@ -270,6 +283,11 @@ inline bool mem_valid(int mem) { return mem >= 0 && mem <= 3; }
 } // namespace mp
 int uct_stoch_reroot_now(mp_ctx *ctx, long cap_new);
 namespace mp {
+
+// (model_index, local root state) pairs of a batch model -> global root states for the planners: `host_tmp` backs *out for
+// host arrays (validated), WS_GROOT for device arrays (one small launch on the ctx stream)
+int globalize_roots_arg(mp_ctx *ctx, const mp_model *model, int n_roots, const int32_t *model_index, const int32_t *root_state,
+                        int mem, std::vector<int32_t> &host_tmp, const int32_t **out);
 
 // side streams for the pipelined host-mode plan: `n` streams forked off the ctx stream / joined back into it
 int pipe_fork(mp_ctx *ctx, int n);

@@ -789,6 +789,24 @@ extern "C" {
 int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget,
                 double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
                 int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status,
+                int32_t mem);
+
+int mp_opd_plan_models(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *model_index, const int32_t *root_state,
+                       int32_t budget, double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len,
+                       int32_t *plans, int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps,
+                       int32_t *status, int32_t mem)
+{
+    if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_opd_plan_models: unknown mem flags %d", mem);
+    std::vector<int32_t> tmp;
+    const int32_t *global = nullptr;
+    MP_TRY(globalize_roots_arg(ctx, model, n_roots, model_index, root_state, mem, tmp, &global));
+    return mp_opd_plan(ctx, model, n_roots, global, budget, gamma, terminal_reward, rng_state, max_plan_len, plans, plan_len,
+                       root_lower, root_upper, env_steps, status, mem);
+}
+
+int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *root_state, int32_t budget,
+                double gamma, double terminal_reward, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                int32_t *plan_len, double *root_lower, double *root_upper, int64_t *env_steps, int32_t *status,
                 int32_t mem)
 {
     if (!ctx || !model || !root_state || !rng_state) return fail(MP_ERR_ARG, "mp_opd_plan: NULL argument");

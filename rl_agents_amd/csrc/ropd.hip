@@ -30,6 +30,34 @@
 
 namespace mp {
 
+// done flags of the models beyond a node's 32 flag bits ride in the stored reward: BIT 62 of its pattern.  A reward the
+// planner accepts lies in [0, 1] (deterministic.py:46-47; anything else ends the plan with MP_ERR_REWARD_RANGE): its
+// exponent field is at most 0x3ff, so bit 62 is free -- and the sign bit stays the reward's own (-0.0 passes the range check
+// and must neither read as "done" nor lose its sign in the export: ADVICE r4).
+__host__ __device__ __forceinline__ double reward_with_done(double r)
+{
+    unsigned long long b;
+    memcpy(&b, &r, 8);
+    b |= 1ull << 62;
+    memcpy(&r, &b, 8);
+    return r;
+}
+__host__ __device__ __forceinline__ bool reward_done(double r)
+{
+    unsigned long long b;
+    memcpy(&b, &r, 8);
+    return (b >> 62) & 1ull;
+}
+__host__ __device__ __forceinline__ double reward_plain(double r)
+{
+    unsigned long long b;
+    memcpy(&b, &r, 8);
+    b &= ~(1ull << 62);
+    memcpy(&r, &b, 8);
+    return r;
+}
+
+
 // (one terminal flag per model in a 32-bit word of the node; from the 33rd model on the flag rides in the sign bit of the
 // stored reward -- rewards are range-checked to [0, 1], and 0. with the flag is -0. -- so the number of models is not bounded)
 
@@ -189,7 +217,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                     }
                     Lv[(long)c * M + m] = Lc;
                     Sv[(long)c * M + m] = nxt;
-                    Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                    Rv[(long)c * M + m] = (m >= 32 && dn) ? reward_with_done(r) : r; // (models beyond the 32 done bits of the node: the flag rides in bit 62 of the reward)
                     if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                     if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                     if (m == 0 || Uc < umin) umin = Uc;
@@ -275,7 +303,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                 }
                 Lv[(long)c * M + m] = Lc;
                 Sv[(long)c * M + m] = rc.next;
-                Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                Rv[(long)c * M + m] = (m >= 32 && dn) ? reward_with_done(r) : r; // (models beyond the 32 done bits of the node: the flag rides in bit 62 of the reward)
                 if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                 if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                 if (m == 0 || Uc < umin) umin = Uc;
@@ -498,7 +526,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
                 }
                 Lv[(long)c * M + m] = Lc;
                 Sv[(long)c * M + m] = rc.next;
-                Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                Rv[(long)c * M + m] = (m >= 32 && dn) ? reward_with_done(r) : r; // (models beyond the 32 done bits of the node: the flag rides in bit 62 of the reward)
                 if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                 if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                 if (m == 0 || Uc < umin) umin = Uc;
@@ -670,7 +698,7 @@ __global__ __launch_bounds__(64) void ropd_any_kernel(ROpdArgs p)
                     }
                     Lv[(long)c * M + m] = Lc;
                     Sv[(long)c * M + m] = rc.next;
-                    Rv[(long)c * M + m] = (m >= 32 && dn) ? -r : r; // (models beyond the 32 done bits of the node: the flag rides in the reward's sign)
+                    Rv[(long)c * M + m] = (m >= 32 && dn) ? reward_with_done(r) : r; // (models beyond the 32 done bits of the node: the flag rides in bit 62 of the reward)
                     if (m < 32) dbits |= (dn ? 1u : 0u) << m;
                     if (m == 0 || Lc < lmin) lmin = Lc; // np.min
                     if (m == 0 || Uc < umin) umin = Uc;
@@ -949,9 +977,9 @@ int mp_ropd_tree_export(mp_ctx *ctx, int32_t root, int32_t cap, int32_t *n_nodes
         if (n_children) n_children[o] = nc;
         for (int m = 0; m < M; ++m) {
             const size_t j = (size_t)i * M + m, jo = (size_t)o * M + m;
-            const bool dn = m < 32 ? (((uint32_t)meta[2 * i + 1] >> m) & 1u) != 0 : std::signbit(rv[j]);
+            const bool dn = m < 32 ? (((uint32_t)meta[2 * i + 1] >> m) & 1u) != 0 : reward_done(rv[j]);
             if (state) state[jo] = sv[j];
-            if (reward) reward[jo] = m < 32 ? rv[j] : fabs(rv[j]);
+            if (reward) reward[jo] = m < 32 ? rv[j] : reward_plain(rv[j]);
             if (done) done[jo] = (uint8_t)dn;
             // a leaf keeps its vectors (U recomputed as update() computed it, deterministic.py:51-59: same host
             // operations as the planning tables); an expanded node holds the backed-up scalars

@@ -1546,7 +1546,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 // ---- dispatch order of the wave kernel: planners by expected cost, longest first (a counting sort over 1 024 cost
 // buckets by ONE workgroup; the order inside a bucket is whatever the atomics make it -- the plans do not depend on it).
 // key[r] = by_state ? model_cost[root_state[r]] : cost[r]
-__global__ __launch_bounds__(1024) void saopd_order_kernel(int n, const int32_t *cost, const int32_t *by_state, const int32_t *root_state,
+__global__ __launch_bounds__(1024) void saopd_order_kernel(int n, int S, const int32_t *cost, const int32_t *by_state, const int32_t *root_state,
                                                            int32_t *order)
 {
     __shared__ int hist[1024];
@@ -1555,7 +1555,13 @@ __global__ __launch_bounds__(1024) void saopd_order_kernel(int n, const int32_t 
     hist[t] = 0;
     if (t == 0) kmax = 0;
     __syncthreads();
-    auto key = [&](int r) { return by_state ? by_state[root_state[r]] : cost[r]; };
+    // (root states of device arrays cannot be checked on the host: a state outside [0, S) -- which the plan kernel reports in
+    // `status` -- sorts as "nothing known" instead of reading beyond the [S] table)
+    auto key = [&](int r) {
+        if (!by_state) return cost[r];
+        const int rs = root_state[r];
+        return (unsigned)rs < (unsigned)S ? by_state[rs] : 0;
+    };
     int m = 0;
     for (int r = t; r < n; r += 1024) m = max(m, key(r));
     atomicMax(&kmax, m);
@@ -1577,11 +1583,13 @@ __global__ __launch_bounds__(1024) void saopd_order_kernel(int n, const int32_t 
 }
 
 // what the first plan of a fresh planner cost, remembered by root state with the model
-__global__ __launch_bounds__(256) void saopd_learn_kernel(int n, const int32_t *root_state, const int32_t *cost, const int32_t *status,
+__global__ __launch_bounds__(256) void saopd_learn_kernel(int n, int S, const int32_t *root_state, const int32_t *cost, const int32_t *status,
                                                           int32_t *model_cost)
 {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n && (!status || status[r] == MP_OK)) model_cost[root_state[r]] = cost[r];
+    if (r >= n || (status && status[r] != MP_OK)) return;
+    const int rs = root_state[r];
+    if ((unsigned)rs < (unsigned)S) model_cost[rs] = cost[r]; // (never a store beyond the [S] table, whatever the status says)
 }
 
 // grow a node array from old_cap to new_cap rows per planner, keeping the used_rows rows in use
@@ -1879,7 +1887,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
         MP_HIP(hipMemsetAsync(pl->model->sa_cost, 0, 4 * (size_t)pl->S, st));
     MP_TRY(kernels_begin(ctx));
     if (ordered && have_cost) { // (inside the timed region: the sort is part of what a plan costs)
-        hipLaunchKernelGGL(saopd_order_kernel, dim3(1), dim3(1024), 0, st, n, pl->cost, fresh ? pl->model->sa_cost : nullptr, d_rs, pl->order);
+        hipLaunchKernelGGL(saopd_order_kernel, dim3(1), dim3(1024), 0, st, n, pl->model->S, pl->cost, fresh ? pl->model->sa_cost : nullptr, d_rs, pl->order);
         a.order = pl->order;
         ++launches;
     }
@@ -1941,7 +1949,7 @@ int mp_saopd_plan(mp_ctx *ctx, mp_saopd *pl, const int32_t *root_state, int32_t 
     if (pl->wave) {
         pl->cost_valid = true;
         if (fresh && pl->model->sa_cost) { // remember the first plans' costs by root state
-            hipLaunchKernelGGL(saopd_learn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, d_rs, pl->cost, a.status,
+            hipLaunchKernelGGL(saopd_learn_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, n, pl->model->S, d_rs, pl->cost, a.status,
                                pl->model->sa_cost);
             ++launches;
         }

@@ -1240,6 +1240,20 @@ int mp_uct_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const void *root_
                          root_child_value, env_steps, mem);
 }
 
+int mp_uct_plan_models(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *model_index, const int32_t *root_state,
+                       const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
+                       const double *prior_p, const double *rollout_p, uint64_t *rng_state, int32_t max_plan_len, int32_t *plans,
+                       int32_t *plan_len, double *root_value, int64_t *root_child_count, double *root_child_value,
+                       int64_t *env_steps, int32_t mem)
+{
+    if (!mem_valid(mem)) return fail(MP_ERR_ARG, "mp_uct_plan_models: unknown mem flags %d", mem);
+    std::vector<int32_t> tmp;
+    const int32_t *global = nullptr;
+    MP_TRY(globalize_roots_arg(ctx, model, n_roots, model_index, root_state, mem, tmp, &global));
+    return uct_plan_impl(ctx, model, nullptr, n_roots, global, root_steps, episodes, horizon, gamma, temperature, prior_p, rollout_p,
+                         rng_state, max_plan_len, plans, plan_len, root_value, root_child_count, root_child_value, env_steps, mem);
+}
+
 int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const void *root_state,
                        const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,
                        uint64_t *rng_state, int32_t max_plan_len, int32_t *plans, int32_t *plan_len, double *root_value,

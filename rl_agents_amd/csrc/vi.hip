@@ -39,6 +39,15 @@ __device__ __forceinline__ bool isclose_np(double a, double b, double rtol, doub
     return a == b;
 }
 
+// the same predicate without a branch (both sides evaluated, selected): keeps fully unrolled loops straight-line code
+__device__ __forceinline__ bool isclose_np_sel(double a, double b, double rtol, double atol)
+{
+    const bool fin = isfinite(a) & isfinite(b);
+    const bool close = fabs(a - b) <= atol + rtol * fabs(b);
+    const bool same = a == b;
+    return fin ? close : same;
+}
+
 struct ViDetArgs {
     int M, S, A, robust, vform, k;
     const int32_t *T;
@@ -1144,6 +1153,8 @@ static int vi_run_impl(mp_ctx *ctx, mp_model *m, double gamma, int iterations, d
     if (m->mode == MP_MODE_CARTPOLE) return fail(MP_ERR_MODE, "vi: the environment must be of type finite_mdp");
     if (robust && m->mode == MP_MODE_SPARSE) return fail(MP_ERR_MODE, "Unknown mode"); // robust_value_iteration.py:57-58
     if (m->Sc != m->S) return fail(MP_ERR_MODE, "vi: a row-block model can only be used with mp_vi_backup");
+    if (m->NB > 1)
+        return fail(MP_ERR_MODE, "vi: a batch model holds %d independent MDPs, each with its own convergence test: use mp_vi_solve_batch", m->NB);
     MP_HIP(hipSetDevice(ctx->device));
     const int S = m->S, A = m->A, M = robust ? m->M : 1;
     const long SA = (long)S * A;
@@ -1333,6 +1344,390 @@ static int vi_run(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double
     return MP_OK;
 }
 
+// ------------------------------------------------------------------ batched deterministic VI ---
+// N independent MDPs (a batch model: mp_model_load_table_batch), ONE WORKGROUP PER MDP, one launch: what N
+// ValueIterationAgent objects compute (value_iteration.py:42-73 each, one agent per process in trainer/evaluation.py:139-194).
+// Every MDP runs to its own allclose exit -- a uniform branch of its workgroup -- and returns its own iterate.  The tables of
+// the batch hold GLOBAL next states (b * Sb + s'); a workgroup subtracts its base.
+struct ViBatchArgs {
+    int N, Sb, A, iterations;
+    const int32_t *T;     // [N*Sb*A] global next states
+    const double *R;      // [N*Sb*A]
+    const uint8_t *term;  // [N*Sb] or nullptr
+    double gamma, rtol, atol;
+    double *Q_out;        // [N*Sb*A]
+    int32_t *sweeps_out;  // [N]
+    double *Vglobal;      // VGLOBAL form: [N][3][Sb]
+};
+
+// REGISTER form (Sb <= OWN * BLOCK): a thread keeps the rows of its OWN states -- transitions, rewards and the last Q row,
+// which is what the allclose test compares with -- in registers for the whole solve; V is double-buffered in LDS; one
+// barrier per sweep (it also carries the "did anything move" vote).
+template <int AT, int OWN, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void vi_det_batch_reg(ViBatchArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_v[];
+    const int b = blockIdx.x, tid = threadIdx.x, S = p.Sb;
+    const long base = (long)b * S;
+    double *V0 = lds_v, *V1 = lds_v + S;
+    int32_t t[OWN][AT];
+    double r[OWN][AT], qp[OWN][AT];
+    bool term_s[OWN], own[OWN];
+#pragma unroll
+    for (int i = 0; i < OWN; ++i) {
+        const int s = tid + i * BLOCK;
+        own[i] = s < S;
+        const long sa0 = (base + (own[i] ? s : 0)) * AT;
+        term_s[i] = (p.term && own[i]) ? p.term[base + s] != 0 : false;
+#pragma unroll
+        for (int a = 0; a < AT; ++a) {
+            t[i][a] = p.T[sa0 + a] - (int32_t)base;
+            r[i][a] = p.R[sa0 + a];
+            qp[i][a] = 0.0;                                  // Q_0 = 0 (value_iteration.py:43)
+        }
+        if (own[i]) V0[s] = 0.0;
+    }
+    __syncthreads();
+    int sweeps = p.iterations;
+    for (int k = 0; k < p.iterations; ++k) {
+        const double *Vcur = (k & 1) ? V1 : V0;
+        double *Vnext = (k & 1) ? V0 : V1;
+        bool nc = false;
+        double qn[OWN][AT];
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+            double vc[AT];
+#pragma unroll
+            for (int a = 0; a < AT; ++a) vc[a] = Vcur[t[i][a]];
+            double vmax = 0.0;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) {
+                qn[i][a] = r[i][a] + p.gamma * (term_s[i] ? 0.0 : vc[a]);
+                nc |= own[i] && !isclose_np(qp[i][a], qn[i][a], p.rtol, p.atol);
+                if (a == 0 || qn[i][a] > vmax) vmax = qn[i][a];
+            }
+            if (own[i]) Vnext[tid + i * BLOCK] = vmax;
+        }
+        // every thread has read V_k and written its part of V_{k+1}; the vote decides the sweep for the whole MDP
+        // (a single-wave workgroup votes by ballot: its LDS accesses are issued in order, no barrier is needed)
+        const bool moved = BLOCK == 64 ? __any(nc ? 1 : 0) != 0 : __syncthreads_or(nc ? 1 : 0) != 0;
+        if (!moved) { sweeps = k + 1; break; } // allclose(Q_k, Q_{k+1}): return Q_k = qp
+#pragma unroll
+        for (int i = 0; i < OWN; ++i)
+#pragma unroll
+            for (int a = 0; a < AT; ++a) qp[i][a] = qn[i][a];
+    }
+    if (tid == 0 && p.sweeps_out) p.sweeps_out[b] = sweeps;
+    if (p.Q_out)
+#pragma unroll
+        for (int i = 0; i < OWN; ++i)
+            if (own[i])
+#pragma unroll
+                for (int a = 0; a < AT; ++a) p.Q_out[(base + tid + i * BLOCK) * AT + a] = qp[i][a];
+}
+
+// WORKGROUP form (any |A|, Sb beyond the register form): 1024 threads walk the states of their MDP; the tables stream from
+// global memory (L2 / MALL resident across sweeps: 12 B per (s, a)); Q_k for the allclose test is recomputed from V_{k-1}, as
+// the chained single-MDP sweeps do.  VLDS: V_{k-1} and V_k live in LDS and a thread holds its V_{k+1} values in registers
+// until every gather of the sweep is done (two barriers per sweep, 16 * Sb bytes of LDS: Sb <= 10 200); otherwise three
+// buffers per MDP in global memory (a workgroup's own writes are visible to it after a barrier).
+constexpr int kViBatchOwn = 10; // states per thread the VLDS form holds V_{k+1} for: Sb <= 10 * 1024
+template <int AT, bool VLDS>
+__global__ __launch_bounds__(1024) void vi_det_batch_wg(ViBatchArgs p)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_v[];
+    const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, S = p.Sb, A = AT > 0 ? AT : p.A;
+    const long base = (long)b * S;
+    double *Vb = VLDS ? lds_v : p.Vglobal + (long)b * 3 * S; // VLDS: [2][S]; global: [3][S]
+    constexpr int NB = VLDS ? 2 : 3;
+    for (int i = tid; i < NB * S; i += nt) Vb[i] = 0.0;
+    __syncthreads();
+    constexpr int AR = AT > 0 ? AT : 64;
+    auto qrow = [&](const double *V, int s, bool term_s, double *out) {
+        const long sa0 = (base + s) * A;
+        if (AT > 0) {
+            int32_t tt[AR];
+            double rr[AR];
+#pragma unroll
+            for (int a = 0; a < AR; ++a) { tt[a] = p.T[sa0 + a] - (int32_t)base; rr[a] = p.R[sa0 + a]; }
+#pragma unroll
+            for (int a = 0; a < AR; ++a) out[a] = rr[a] + p.gamma * (term_s ? 0.0 : V[tt[a]]);
+        } else {
+            for (int a = 0; a < A; ++a) out[a] = p.R[sa0 + a] + p.gamma * (term_s ? 0.0 : V[p.T[sa0 + a] - (int32_t)base]);
+        }
+    };
+    int j = p.iterations, sweeps = p.iterations;
+    for (int k = 0; k < p.iterations; ++k) {
+        // VLDS: V_k in buffer k & 1, V_{k-1} in the other, V_{k+1} replaces V_{k-1} after the gathers; global: ring of three
+        const double *Vcur = Vb + (long)(VLDS ? (k & 1) : (k % 3)) * S;
+        const double *Vprev = Vb + (long)(VLDS ? ((k + 1) & 1) : ((k + 2) % 3)) * S;
+        double *Vnext = Vb + (long)(VLDS ? ((k + 1) & 1) : ((k + 1) % 3)) * S;
+        bool nc = false;
+        double vown[kViBatchOwn];
+        int o = 0;
+        for (int s = tid; s < S; s += nt, ++o) {
+            const bool term_s = p.term ? p.term[base + s] != 0 : false;
+            double qn[AR], qo[AR];
+            qrow(Vcur, s, term_s, qn);
+            if (k > 0) qrow(Vprev, s, term_s, qo);
+            double vmax = qn[0];
+#pragma unroll
+            for (int a = 0; a < AR; ++a)
+                if (a < A) {
+                    nc |= !isclose_np(k == 0 ? 0.0 : qo[a], qn[a], p.rtol, p.atol);
+                    if (a > 0 && qn[a] > vmax) vmax = qn[a];
+                }
+            if (VLDS) {
+#pragma unroll
+                for (int i = 0; i < kViBatchOwn; ++i) vown[i] = o == i ? vmax : vown[i];
+            } else {
+                Vnext[s] = vmax;
+            }
+        }
+        if (__syncthreads_or(nc ? 1 : 0) == 0) { j = k; sweeps = k + 1; break; } // (V_{k-1} is still in place: Q_k below)
+        if (VLDS) {
+            o = 0;
+            for (int s = tid; s < S; s += nt, ++o) {
+                double v = vown[0];
+#pragma unroll
+                for (int i = 1; i < kViBatchOwn; ++i) v = o == i ? vown[i] : v;
+                Vnext[s] = v;
+            }
+            __syncthreads();
+        }
+    }
+    if (tid == 0 && p.sweeps_out) p.sweeps_out[b] = sweeps;
+    if (p.Q_out) {
+        // the returned iterate Q_j = Bellman(V_{j-1}) (0 for j = 0): V_{j-1} is where sweep j - 1 read V_cur from
+        const double *Vjm1 = Vb + (long)(VLDS ? ((j + 1) & 1) : ((j + 2) % 3)) * S;
+        for (int s = tid; s < S; s += nt) {
+            const bool term_s = p.term ? p.term[base + s] != 0 : false;
+            double qj[AR];
+            if (j > 0) qrow(Vjm1, s, term_s, qj);
+            for (int a = 0; a < A; ++a) p.Q_out[(base + s) * A + a] = j == 0 ? 0.0 : qj[a];
+        }
+    }
+}
+
+// LANE-MAJOR copies of a batch model's tables for the streaming form below: Tt uint16 [N][A][Sb] (LOCAL next state), Rt double
+// [N][A][Sb] -- thread t of an MDP's workgroup owns states t, t + 1024, ...: with the state index innermost every load of a
+// wavefront is one contiguous 128- / 512-byte run (state-major rows of |A| = 5 doubles are 40 bytes apart per lane: every
+// load instruction would touch twenty cache lines for one line's worth of data).
+__global__ __launch_bounds__(256) void vi_batch_transpose(int N, int Sb, int A, const int32_t *__restrict__ T, const double *__restrict__ R,
+                                                          uint16_t *__restrict__ Tt, double *__restrict__ Rt)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // over [N][A][Sb]
+    if (i >= (long)N * A * Sb) return;
+    const int s = (int)(i % Sb);
+    const long ba = i / Sb;
+    const int a = (int)(ba % A), b = (int)(ba / A);
+    const long src = ((long)b * Sb + s) * A + a;
+    Tt[i] = (uint16_t)(T[src] - b * Sb);
+    Rt[i] = R[src];
+}
+
+// STREAMING workgroup form (|A| at compile time, 4096 < Sb and 16 * Sb bytes of LDS: Sb <= 10 200 -- the C2 shape, S = 10 000).
+// Thread t owns states t, t + 1024, ...; a sweep streams the lane-major tables once (10 B per (s, a): every wave-load one
+// contiguous run), the rows of the NEXT state requested before the gathers of the current one, so that the only
+// dependent chain of a state is its LDS gathers.  V_k and V_{k+1} are double-buffered in LDS -- V_{k+1} is written where it
+// belongs as soon as it is known, one barrier per sweep -- and every V is also written to a ring of three in global memory
+// (L2-resident, 8 B per state and sweep): V_{k-1}, which only the allclose test and the returned iterate need, is read
+// from there.  allclose(Q_k, Q_{k+1}) is an OR over all (s, a): the sweep first tests only the pairs of each thread's FIRST
+// state (exactly, Q_k recomputed from V_{k-1}); any pair that moved settles the sweep for the whole MDP -- every sweep but
+// the last few -- and only when none of them moved does a second pass test the rest.  Same decisions, same returned
+// iterate as the chained sweeps, half the gathers.
+template <int AT>
+__global__ __launch_bounds__(1024) void vi_det_batch_wgr(ViBatchArgs p, const uint16_t *__restrict__ Tt, const double *__restrict__ Rt)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_v[];
+    constexpr int NT = 1024;
+    const int b = blockIdx.x, tid = threadIdx.x, S = p.Sb;
+    const long base = (long)b * S;
+    const int n_own = (S + NT - 1) / NT;
+    // tables through buffer resources: a 32-bit per-lane offset (the state) and a scalar offset (the action's row) per load
+    const __amdgpu_buffer_rsrc_t rres = __builtin_amdgcn_make_buffer_rsrc((void *)(Rt + (long)b * AT * S), 0, AT * S * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t tres = __builtin_amdgcn_make_buffer_rsrc((void *)(Tt + (long)b * AT * S), 0, AT * S * 2, 0x00020000);
+    auto rload = [&](int a, int s) -> double {
+        const uint2 w = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rres, s * 8, a * S * 8, 0));
+        return __hiloint2double((int)w.y, (int)w.x);
+    };
+    auto tload = [&](int a, int s) -> int { return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(tres, s * 2, a * S * 2, 0); };
+    double *Vb = lds_v;                                  // [2][S]: V_k in buffer k & 1
+    double *Vg = p.Vglobal + (long)b * 3 * S;            // [3][S]: V_k in slot k % 3
+    for (int i = tid; i < 2 * S; i += NT) Vb[i] = 0.0;
+    for (int i = tid; i < 3 * S; i += NT) Vg[i] = 0.0;
+    __syncthreads();
+    int j = p.iterations, sweeps = p.iterations;
+    for (int k = 0; k < p.iterations; ++k) {
+        const double *Vcur = Vb + (long)(k & 1) * S;
+        double *Vnext = Vb + (long)((k + 1) & 1) * S;
+        const double *Vprev = Vg + (long)((k + 2) % 3) * S;
+        double *Vnext_g = Vg + (long)((k + 1) % 3) * S;
+        bool nc = false;
+        int tn[AT];
+        double rn[AT];
+        {
+            const int sc = tid < S ? tid : 0;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) { tn[a] = tload(a, sc); rn[a] = rload(a, sc); }
+        }
+        for (int i = 0; i < n_own; ++i) {
+            const int s = tid + i * NT;
+            int t[AT];
+            double r[AT];
+#pragma unroll
+            for (int a = 0; a < AT; ++a) { t[a] = tn[a]; r[a] = rn[a]; }
+            {   // the next state's rows: requested before this state's gathers (the last trip re-reads its own)
+                const int sn = s + NT < S ? s + NT : (s < S ? s : 0);
+#pragma unroll
+                for (int a = 0; a < AT; ++a) { tn[a] = tload(a, sn); rn[a] = rload(a, sn); }
+            }
+            const bool term_s = (p.term && s < S) ? p.term[base + s] != 0 : false;
+            double vc[AT], vp[AT];
+#pragma unroll
+            for (int a = 0; a < AT; ++a) vc[a] = Vcur[t[a]];
+            const bool test = i == 0 && k > 0;
+            if (test) {
+#pragma unroll
+                for (int a = 0; a < AT; ++a) vp[a] = Vprev[t[a]];
+            }
+            double vmax = 0.0;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) {
+                const double qn = r[a] + p.gamma * (term_s ? 0.0 : vc[a]);
+                if (i == 0) {
+                    const double qo = k == 0 ? 0.0 : r[a] + p.gamma * (term_s ? 0.0 : vp[a]);
+                    nc |= s < S && !isclose_np_sel(qo, qn, p.rtol, p.atol);
+                }
+                if (a == 0 || qn > vmax) vmax = qn;
+            }
+            if (s < S) { Vnext[s] = vmax; Vnext_g[s] = vmax; }
+        }
+        bool moved = __syncthreads_or(nc ? 1 : 0) != 0;
+        if (!moved) { // none of the first states' pairs moved: test the others (the last few sweeps only)
+            bool nc2 = false;
+            for (int s = tid + NT; s < S; s += NT) {
+                const bool term_s = p.term ? p.term[base + s] != 0 : false;
+#pragma unroll
+                for (int a = 0; a < AT; ++a) {
+                    const int t = tload(a, s);
+                    const double r = rload(a, s);
+                    const double qn = r + p.gamma * (term_s ? 0.0 : Vcur[t]);
+                    const double qo = k == 0 ? 0.0 : r + p.gamma * (term_s ? 0.0 : Vprev[t]);
+                    nc2 |= !isclose_np_sel(qo, qn, p.rtol, p.atol);
+                }
+            }
+            moved = __syncthreads_or(nc2 ? 1 : 0) != 0;
+        }
+        if (!moved) { j = k; sweeps = k + 1; break; }
+    }
+    if (tid == 0 && p.sweeps_out) p.sweeps_out[b] = sweeps;
+    if (p.Q_out) {
+        const double *Vjm1 = Vg + (long)((j + 2) % 3) * S; // V_{j-1}
+        for (int s = tid; s < S; s += NT) {
+            const bool term_s = p.term ? p.term[base + s] != 0 : false;
+#pragma unroll
+            for (int a = 0; a < AT; ++a)
+                p.Q_out[(base + s) * AT + a] = j == 0 ? 0.0 : rload(a, s) + p.gamma * (term_s ? 0.0 : Vjm1[tload(a, s)]);
+        }
+    }
+}
+
+template <int AT>
+static int vi_batch_launch(mp_ctx *ctx, ViBatchArgs &q, hipStream_t st, const char **variant)
+{
+    const int S = q.Sb;
+    const unsigned grid = (unsigned)q.N;
+    if constexpr (AT > 0) {
+        const size_t lds = (size_t)2 * S * sizeof(double);
+#define MP_VB(own, block)                                                                                              \
+    if (S <= (own) * (block)) {                                                                                        \
+        hipLaunchKernelGGL((vi_det_batch_reg<AT, own, block>), dim3(grid), dim3(block), lds, st, q);                   \
+        *variant = "vi_batch_reg<" #own "," #block ">";                                                                \
+        return MP_OK;                                                                                                  \
+    }
+        if (!getenv("MP_VI_BATCH_NO_REG")) {
+            MP_VB(1, 64) MP_VB(2, 64) MP_VB(2, 128) MP_VB(2, 256) MP_VB(4, 256) MP_VB(4, 512)
+            if constexpr (AT <= 4) { MP_VB(4, 1024) }
+        }
+#undef MP_VB
+    }
+    if constexpr (AT > 0) {
+        if (S <= kViBatchOwn * 1024 && (size_t)2 * S * sizeof(double) <= kLdsBytes - 512 && !getenv("MP_VI_BATCH_NO_VLDS") &&
+            !getenv("MP_VI_BATCH_NO_WGR")) {
+            // lane-major copies of the tables (a few microseconds; rebuilt on every call: the tables of a batch change
+            // between two steps of its episodes)
+            const size_t npairs = (size_t)q.N * S * AT;
+            uint16_t *Tt = nullptr;
+            double *Rt = nullptr;
+            MP_TRY(ws_get(ctx, WS_VI2, npairs, &Rt));
+            MP_TRY(ws_get(ctx, WS_VI4, npairs, &Tt));
+            MP_TRY(ws_get(ctx, WS_VI1, (size_t)q.N * 3 * S, &q.Vglobal));
+            hipLaunchKernelGGL(vi_batch_transpose, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, q.N, S, AT, q.T, q.R, Tt, Rt);
+            const size_t lds = (size_t)2 * S * sizeof(double);
+            MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vi_det_batch_wgr<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+            hipLaunchKernelGGL((vi_det_batch_wgr<AT>), dim3(grid), dim3(1024), lds, st, q, (const uint16_t *)Tt, (const double *)Rt);
+            *variant = "vi_batch_wg_stream";
+            return MP_OK;
+        }
+    }
+    if (S <= kViBatchOwn * 1024 && (size_t)2 * S * sizeof(double) <= kLdsBytes - 512 && !getenv("MP_VI_BATCH_NO_VLDS")) {
+        const size_t lds = (size_t)2 * S * sizeof(double);
+        if (lds > 64 * 1024)
+            MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vi_det_batch_wg<AT, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds));
+        hipLaunchKernelGGL((vi_det_batch_wg<AT, true>), dim3(grid), dim3(1024), lds, st, q);
+        *variant = "vi_batch_wg_lds";
+        return MP_OK;
+    }
+    MP_TRY(ws_get(ctx, WS_VI1, (size_t)q.N * 3 * S, &q.Vglobal));
+    hipLaunchKernelGGL((vi_det_batch_wg<AT, false>), dim3(grid), dim3(1024), 0, st, q);
+    *variant = "vi_batch_wg_global";
+    return MP_OK;
+}
+
+static int vi_solve_batch(mp_ctx *ctx, mp_model *m, double gamma, int iterations, double rtol, double atol, double *Q_out,
+                          int32_t *sweeps_out, int mem)
+{
+    if (!ctx || !m) return fail(MP_ERR_ARG, "mp_vi_solve_batch: NULL ctx/model");
+    if (iterations < 0) return fail(MP_ERR_ARG, "mp_vi_solve_batch: iterations < 0");
+    if (m->mode != MP_MODE_DETERMINISTIC || !m->T || m->M != 1)
+        return fail(MP_ERR_MODE, "mp_vi_solve_batch: deterministic table models (mp_model_load_table_batch, or one MDP with M = 1) only");
+    if (mem != MP_MEM_HOST && mem != MP_MEM_DEVICE) return fail(MP_ERR_ARG, "mp_vi_solve_batch: unknown mem flags %d", mem);
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const int N = m->NB, Sb = m->Sb > 0 ? m->Sb : m->S, A = m->A;
+    if (A > 64) return fail(MP_ERR_ARG, "mp_vi_solve_batch: |A| = %d > 64", A);
+    const size_t nq = (size_t)N * Sb * A;
+    double *dQ = nullptr;
+    int32_t *dSw = nullptr;
+    MP_TRY(stage_out_alloc(ctx, WS_IO0, Q_out, nq, mem, &dQ));
+    MP_TRY(stage_out_alloc(ctx, WS_IO2, sweeps_out, (size_t)N, mem, &dSw));
+    ViBatchArgs q;
+    memset(&q, 0, sizeof(q));
+    q.N = N; q.Sb = Sb; q.A = A; q.iterations = iterations; q.T = m->T; q.R = m->R; q.term = m->term;
+    q.gamma = gamma; q.rtol = rtol; q.atol = atol; q.Q_out = dQ; q.sweeps_out = dSw;
+    const char *variant = "";
+    MP_TRY(kernels_begin(ctx));
+    switch (A) {
+    case 2: MP_TRY(vi_batch_launch<2>(ctx, q, st, &variant)); break;
+    case 3: MP_TRY(vi_batch_launch<3>(ctx, q, st, &variant)); break;
+    case 4: MP_TRY(vi_batch_launch<4>(ctx, q, st, &variant)); break;
+    case 5: MP_TRY(vi_batch_launch<5>(ctx, q, st, &variant)); break;
+    case 6: MP_TRY(vi_batch_launch<6>(ctx, q, st, &variant)); break;
+    case 8: MP_TRY(vi_batch_launch<8>(ctx, q, st, &variant)); break;
+    default: MP_TRY(vi_batch_launch<0>(ctx, q, st, &variant)); break;
+    }
+    MP_TRY(kernels_end(ctx, 1));
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", variant);
+    MP_HIP(hipGetLastError());
+    MP_TRY(stage_out_copy(ctx, Q_out, dQ, nq, mem));
+    MP_TRY(stage_out_copy(ctx, sweeps_out, dSw, (size_t)N, mem));
+    if (mem == MP_MEM_HOST) MP_HIP(hipStreamSynchronize(st));
+    return MP_OK;
+}
+
 // One Bellman backup Q = min_m (R_m + gamma * mask(T_m . V)) of a dense (possibly row-block) model.
 static int vi_backup(mp_ctx *ctx, mp_model *m, double gamma, int robust, const double *V, double *Q, int mem)
 {
@@ -1373,6 +1768,12 @@ int mp_vi_solve(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, 
                 int32_t robust, double *Q_out, int32_t *sweeps_out, int32_t mem)
 {
     return mp::vi_run(ctx, model, gamma, iterations, rtol, atol, robust ? 1 : 0, 0, Q_out, nullptr, sweeps_out, mem);
+}
+
+int mp_vi_solve_batch(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,
+                      double *Q_out, int32_t *sweeps_out, int32_t mem)
+{
+    return mp::vi_solve_batch(ctx, model, gamma, iterations, rtol, atol, Q_out, sweeps_out, mem);
 }
 
 int mp_vi_solve_v(mp_ctx *ctx, mp_model *model, double gamma, int32_t iterations, double rtol, double atol,

@@ -34,6 +34,15 @@ SIGNATURES = {
     "mp_ctx_get_stream": (C.c_int, [_vp, P(_vp)]),
     "mp_ctx_device_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i64), P(c_i64), C.c_char_p, c_i32]),
     "mp_model_load_table": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32, P(_vp)]),
+    "mp_model_load_table_batch": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32, P(_vp)]),
+    "mp_model_batch_info": (C.c_int, [_vp, P(c_i32), P(c_i32)]),
+    "mp_model_update_tables": (C.c_int, [_vp, c_i32, c_i32, _vp, _vp, _vp]),
+    "mp_model_update_rows": (C.c_int, [_vp, c_i32, _vp, _vp, _vp, _vp]),
+    "mp_vi_solve_batch": (C.c_int, [_vp, _vp, c_f64, c_i32, c_f64, c_f64, _vp, _vp, c_i32]),
+    "mp_uct_plan_models": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, _vp, c_i32, c_i32, c_f64, c_f64, _vp, _vp, _vp, c_i32, _vp, _vp,
+                                     _vp, _vp, _vp, _vp, c_i32]),
+    "mp_opd_plan_models": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     c_i32]),
     "mp_model_load_dense": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
     "mp_model_load_dense_rows": (C.c_int, [_vp, c_i32, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
     "mp_vi_backup": (C.c_int, [_vp, _vp, c_f64, c_i32, _vp, _vp, c_i32]),
@@ -141,7 +150,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 5:
+    if lib.mp_abi_version() != 6:
         raise RuntimeError("libmi355plan ABI version mismatch")
     _LIB = lib
     return lib
@@ -394,6 +403,39 @@ class Context(object):
             model.available = av.astype(bool)
         return model
 
+    def load_table_batch(self, transition, reward, terminal=None, done_rule="source", max_steps=0):
+        """A batch of N independent deterministic MDPs of one shape (mp_model_load_table_batch): transition int [N,S,A]
+        (states LOCAL to each MDP), reward [N,S,A], terminal [N,S] or None -> one :class:`Model` over the N * S GLOBAL
+        states ``b * S + s`` (``model.n_models``, ``model.S_each``); every deterministic-table entry point takes it, the
+        planners with ``model_index=`` (one MDP per root) or with global root states."""
+        t = np.ascontiguousarray(transition, dtype=np.int64)
+        r = np.ascontiguousarray(reward, dtype=np.float64)
+        if t.shape != r.shape or t.ndim != 3:
+            raise ValueError("transition and reward must both be [N, S, A]")
+        n, s, a = t.shape
+        term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).reshape(n, s).astype(np.uint8))
+        h = _vp()
+        _check(self._lib.mp_model_load_table_batch(self._h, n, s, a, _ptr(t), _ptr(r), _ptr(term), int(done_rule == "next"),
+                                                   int(max_steps or 0), C.byref(h)))
+        model = Model(self, h, MODE_DETERMINISTIC, 1, n * s, a, 0)
+        model.n_models, model.S_each = n, s
+        return model
+
+    def vi_solve_batch(self, model, gamma, iterations, rtol=1e-5, atol=1e-8):
+        """N value-iteration agents in one launch (mp_vi_solve_batch) -> (Q float64 [N,S,A], sweeps int32 [N]): each MDP of
+        the batch model runs to its own allclose exit, bit-equal to N :meth:`vi_solve` calls on the N tables."""
+        q = np.zeros((model.n_models, model.S_each, model.A), dtype=np.float64)
+        sweeps = np.zeros(model.n_models, dtype=np.int32)
+        _check(self._lib.mp_vi_solve_batch(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
+                                           _ptr(q), _ptr(sweeps), MP_MEM_HOST))
+        return q, sweeps
+
+    def vi_solve_batch_device(self, model, gamma, iterations, q_out, sweeps_out, rtol=1e-5, atol=1e-8):
+        """Asynchronous form on device tensors: q_out float64 [N*S, A] (what ``greedy_actions_device`` takes with global
+        states), sweeps_out int32 [N]; only enqueues."""
+        _check(self._lib.mp_vi_solve_batch(self._h, model._h, float(gamma), int(iterations), float(rtol), float(atol),
+                                           _ptr(q_out), _ptr(sweeps_out), MP_MEM_DEVICE))
+
     def load_joint(self, transitions, rewards, terminals=None, done_rule="source", available=None):
         """A joint environment of M models (agents/robust/robust.py:9-26): transitions int [M,S,A], rewards [M,S,A],
         terminals [M,S] (each model's own flags) or None.  available: bool [M,S,A], what each model's env lists in
@@ -551,7 +593,7 @@ class Context(object):
         return Policy(self, h, model)
 
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,
-                 root_steps=None, max_plan_len=None, policy=None, out=None):
+                 root_steps=None, max_plan_len=None, policy=None, out=None, model_index=None):
         """MCTS.plan for a batch of roots (host arrays). rng_state uint64 [n,6] is advanced in place (or a
         :class:`DeviceRng`, advanced on the device).  policy (load_policy): per-state policies instead of prior_p /
         rollout_p.  out (plan_buffers): caller-owned pinned result arrays; only the outputs they hold are produced."""
@@ -562,6 +604,12 @@ class Context(object):
         n = rs.shape[0]
         st = None if root_steps is None else np.ascontiguousarray(root_steps, dtype=np.int32).reshape(n)
         mem, rng_ptr = self._rng_arg(rng_state, n)
+        mi = None
+        if model_index is not None:             # batch model: root i plans on MDP model_index[i] from its LOCAL state
+            mi = np.ascontiguousarray(model_index, dtype=np.int32).reshape(n)
+            if policy is not None:              # (policies are tables over the global states: no second index needed)
+                rs = (mi * np.int32(model.S_each) + rs).astype(np.int32)
+                mi = None
         if out is not None:                     # caller-owned (pinned) buffers: only the outputs they hold are produced
             mpl = out["plans"].shape[1] if "plans" in out else 0
             for k in out:
@@ -583,6 +631,11 @@ class Context(object):
         rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
         if pp.shape != (model.A,) or rp.shape != (model.A,):
             raise ValueError("prior_p / rollout_p must have one entry per action")
+        if mi is not None:
+            _check(self._lib.mp_uct_plan_models(self._h, model._h, n, _ptr(mi), _ptr(rs), _ptr(st), int(episodes), int(horizon),
+                                                float(gamma), float(temperature), _ptr(pp), _ptr(rp), rng_ptr, mpl,
+                                                o[0], o[1], o[2], o[3], o[4], o[5], mem))
+            return out
         _check(self._lib.mp_uct_plan(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
                                      float(gamma), float(temperature), _ptr(pp), _ptr(rp), rng_ptr, mpl,
                                      o[0], o[1], o[2], o[3], o[4], o[5], mem))
@@ -603,8 +656,20 @@ class Context(object):
 
     def uct_plan_device(self, model, n_roots, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p,
                         rng_state, max_plan_len, plans=None, plan_len=None, root_value=None, root_child_count=None,
-                        root_child_value=None, env_steps=None, root_steps=None, policy=None):
-        """Same, on device tensors (torch); only enqueues on the ctx stream."""
+                        root_child_value=None, env_steps=None, root_steps=None, policy=None, model_index=None):
+        """Same, on device tensors (torch); only enqueues on the ctx stream.  model_index (int32 device tensor): batch
+        model, one MDP per root, root_state LOCAL."""
+        if model_index is not None and policy is None:
+            pp = np.ascontiguousarray(prior_p, dtype=np.float64)
+            rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
+            _check(self._lib.mp_uct_plan_models(self._h, model._h, int(n_roots), _ptr(model_index), _ptr(root_state),
+                                                _ptr(root_steps), int(episodes), int(horizon), float(gamma), float(temperature),
+                                                _ptr(pp), _ptr(rp), _ptr(rng_state), int(max_plan_len), _ptr(plans),
+                                                _ptr(plan_len), _ptr(root_value), _ptr(root_child_count),
+                                                _ptr(root_child_value), _ptr(env_steps), MP_MEM_DEVICE))
+            return
+        if model_index is not None:
+            raise ValueError("per-state policies on a batch model are indexed by global state: pass global root states")
         if policy is not None:
             _check(self._lib.mp_uct_plan_policy(self._h, model._h, policy._h, int(n_roots), _ptr(root_state),
                                                 _ptr(root_steps), int(episodes), int(horizon), float(gamma),
@@ -703,7 +768,9 @@ class Context(object):
         _check(self._lib.mp_uct_path_count(self._h, int(root), _ptr(a) if a.size else None, int(a.size), C.byref(c)))
         return int(c.value)
 
-    def opd_plan(self, model, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len=64):
+    def opd_plan(self, model, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len=64, model_index=None):
+        """OptimisticDeterministicPlanner.plan for a batch of roots (host arrays).  model_index: batch model, root i plans
+        on MDP model_index[i] from its LOCAL state."""
         rs = np.ascontiguousarray(root_state, dtype=np.int32).reshape(-1)
         n = rs.shape[0]
         if not (isinstance(rng_state, np.ndarray) and rng_state.dtype == np.uint64 and rng_state.flags.c_contiguous
@@ -713,6 +780,13 @@ class Context(object):
         out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
                    root_lower=np.zeros(n, np.float64), root_upper=np.zeros(n, np.float64),
                    env_steps=np.zeros(n, np.int64), status=np.zeros(n, np.int32))
+        if model_index is not None:
+            mi = np.ascontiguousarray(model_index, dtype=np.int32).reshape(n)
+            _check(self._lib.mp_opd_plan_models(self._h, model._h, n, _ptr(mi), _ptr(rs), int(budget), float(gamma),
+                                                float(terminal_reward), _ptr(rng_state), mpl, _ptr(out["plans"]),
+                                                _ptr(out["plan_len"]), _ptr(out["root_lower"]), _ptr(out["root_upper"]),
+                                                _ptr(out["env_steps"]), _ptr(out["status"]), MP_MEM_HOST))
+            return out
         _check(self._lib.mp_opd_plan(self._h, model._h, n, _ptr(rs), int(budget), float(gamma),
                                      float(terminal_reward), _ptr(rng_state), mpl, _ptr(out["plans"]),
                                      _ptr(out["plan_len"]), _ptr(out["root_lower"]), _ptr(out["root_upper"]),
@@ -720,7 +794,13 @@ class Context(object):
         return out
 
     def opd_plan_device(self, model, n_roots, root_state, budget, gamma, terminal_reward, rng_state, max_plan_len,
-                        plans=None, plan_len=None, root_lower=None, root_upper=None, env_steps=None, status=None):
+                        plans=None, plan_len=None, root_lower=None, root_upper=None, env_steps=None, status=None, model_index=None):
+        if model_index is not None:
+            _check(self._lib.mp_opd_plan_models(self._h, model._h, int(n_roots), _ptr(model_index), _ptr(root_state), int(budget),
+                                                float(gamma), float(terminal_reward), _ptr(rng_state), int(max_plan_len), _ptr(plans),
+                                                _ptr(plan_len), _ptr(root_lower), _ptr(root_upper), _ptr(env_steps),
+                                                _ptr(status), MP_MEM_DEVICE))
+            return
         _check(self._lib.mp_opd_plan(self._h, model._h, int(n_roots), _ptr(root_state), int(budget), float(gamma),
                                      float(terminal_reward), _ptr(rng_state), int(max_plan_len), _ptr(plans),
                                      _ptr(plan_len), _ptr(root_lower), _ptr(root_upper), _ptr(env_steps),
@@ -861,6 +941,28 @@ class Model(object):
     def __init__(self, ctx, handle, mode, m, s, a, b):
         self.ctx, self._h, self.mode, self.M, self.S, self.A, self.B = ctx, handle, mode, m, s, a, b
         self._keep = None
+        self.n_models, self.S_each = 1, s       # batch models (Context.load_table_batch): N MDPs of S_each states
+
+    def update_tables(self, first, transition, reward, terminal=None):
+        """Replace the tables of MDPs [first, first + count) of a batch model -- or the whole of a single table model with
+        first = 0 -- (mp_model_update_tables): transition int [count,S,A] LOCAL states, reward [count,S,A], terminal
+        [count,S] iff the model has terminal flags.  Stream-ordered, no synchronisation; policies loaded for the model
+        become invalid."""
+        t = np.ascontiguousarray(transition, dtype=np.int64).reshape(-1, self.S_each, self.A)
+        r = np.ascontiguousarray(reward, dtype=np.float64).reshape(t.shape)
+        term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).reshape(t.shape[0], self.S_each).astype(np.uint8))
+        _check(self.ctx._lib.mp_model_update_tables(self._h, int(first), int(t.shape[0]), _ptr(t), _ptr(r), _ptr(term)))
+
+    def update_rows(self, rows, transition, reward, terminal=None):
+        """Delta upload (mp_model_update_rows): rows int [k] GLOBAL state ids (distinct), transition int [k,A] LOCAL next
+        states of each row's MDP, reward [k,A], terminal [k] or None = the rows' flags do not change."""
+        rw = np.ascontiguousarray(rows, dtype=np.int32).reshape(-1)
+        t = np.ascontiguousarray(transition, dtype=np.int64).reshape(rw.shape[0], self.A)
+        r = np.ascontiguousarray(reward, dtype=np.float64).reshape(t.shape)
+        term = None if terminal is None else np.ascontiguousarray(np.asarray(terminal).reshape(rw.shape[0]).astype(np.uint8))
+        if len(np.unique(rw)) != len(rw):
+            raise ValueError("update_rows: row ids must be distinct")
+        _check(self.ctx._lib.mp_model_update_rows(self._h, int(rw.shape[0]), _ptr(rw), _ptr(t), _ptr(r), _ptr(term)))
 
     def set_episode_rules(self, done_rule="source", max_steps=0):
         """Terminal convention and TimeLimit of the env stepping this model (dense / sparse models: table models get them

@@ -140,6 +140,13 @@ class BatchedEvaluation(object):
             joint = getattr(planner, "plans_on_joint_env", False)
             model = planner.model_for(preprocess_env(self.env, agent.config["env_preprocessors"]) if joint else env)
             ctx = planner.models.ctx
+            if hasattr(planner, "begin_device_loop"):
+                planner.begin_device_loop()
+            if joint and getattr(model, "action_order", None) is not None:
+                # the plans come from the JOINT model in the env's action ids; re-labelling them through the stepped
+                # model's listing order would map ids that are already ids
+                raise NotImplementedError("the device-resident loop of the discrete robust planner steps a true environment "
+                                          "that lists its actions in ascending order; use device_resident=False")
         dev = torch.device("cuda", ctx.device)
         order = getattr(model, "action_order", None)
         mpl = 1 if vi else planner.device_plan_len(model)

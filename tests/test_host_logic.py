@@ -27,7 +27,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
-    assert native.load().mp_abi_version() == 5
+    assert native.load().mp_abi_version() == 6
 
 
 def test_context_fails_loudly_without_gpu_or_library(monkeypatch):
