@@ -4,7 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload uct|opd|vi|vi_dense] [--roots R]
 
 Default workload = the BASELINE.json headline: MCTS/UCT on a highway-shaped finite MDP
-(S = 10 000, |A| = 5), budget 1000 as 33 episodes x horizon 30, 4096 independent roots per GPU.
+(S = 10 000, |A| = 5), budget 1000 as 33 episodes x horizon 30, 262 144 independent roots per GPU (the saturated batch;
+SURVEY 8(d)'s own batch sizes -- 4096 roots and a single root -- are measured in the same run and printed beside it:
+`value_roots4096`, `plan_wall_ms_per_root`).
 A "step" is one batched plan() call over all roots of this rank (inputs already in HBM).
 `value` = environment transitions executed inside plan() by ALL ranks / wall time (max over ranks).
 
@@ -12,11 +14,14 @@ Multi-GPU: `python bench.py --gpus N` launches its own N ranks (one per GPU, `py
 127.0.0.1) when it is not already running under a launcher; the driver's own `torch.distributed.run ... bench.py --gpus N`
 form works unchanged.  A run whose process group does not have exactly --gpus ranks exits non-zero.  Roots are sharded
 over ranks with no data-path collective (weak scaling: the same roots per GPU); the only exchange is ONE RCCL
-all_gather_into_tensor of the packed per-root results per step -- the PRODUCT's sharded path
+all_gather_into_tensor of the packed per-root rows per step ({plan[0], root value, env_steps}: 20 B per root; `exchange`
+in the line prices it: pack + collective + unpack in ms, and whether it ran under the next launch) -- the PRODUCT's sharded path
 (rl_agents_amd.distributed.ShardedDevicePlan: agent -> planner -> mp_uct_plan -> mp_pack_rows -> all_gather ->
 mp_unpack_rows, nothing through the host), cross-checked inside the run: rank 0 re-plans a sample of ANOTHER rank's roots
 and compares it with what the gather delivered (`ranks.cross_check`).
 
+With N > 1 the default run also shards BASELINE configs C4 (OPD, 1024 roots per GPU) and C5 (dense robust VI, one 25 GB row
+block per GPU with the per-sweep all_gather of V) and attaches them under `workloads`.
 The default run (headline workload, one GPU) also runs every other workload of the path for a bounded slice and attaches
 `workloads: {name: {value, kernel_ms, frac, traffic_frac, parity_sample}}` to the one JSON line; `parity_sample` replays a
 sample of the timed launch's own roots (or three sweeps) through the CPU oracle.
@@ -156,7 +161,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "vi_dense_exact", "rvi_dense_shard"])
+    ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "vi_dense_exact", "rvi_dense_shard", "vi_batch",
+                                                         "uct_per_root_model"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--dense-mode", default=None, choices=["mfma", "exact"],
@@ -306,7 +312,8 @@ def seed_states(global_ids, base_seed=0):
 
 
 # ---------------------------------------------------------------------------------------------
-PARITY_ROOTS = 64
+PARITY_ROOTS = 512       # roots / planners of a timed launch replayed through the CPU oracle (each replay stays under ~1 s)
+PARITY_DENSE_ROWS = 64   # dense VI: sampled (s, a) rows per sweep (a row is |S| doubles: the sample is copied to the host)
 
 
 def sample_rows(n, k=PARITY_ROOTS):
@@ -376,7 +383,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
                                     "budget": 1000, "gamma": gamma, "horizon": horizon, "episodes": episodes})
         agent.seed(0)
         assert agent.planner.config["temperature"] == temperature
-        sp = ShardedDevicePlan(agent, world * n_roots, max_plan_len=mpl)
+        sp = ShardedDevicePlan(agent, world * n_roots, max_plan_len=mpl, time_exchange=world > 1)
         assert (sp.lo, sp.hi) == (rank * n_roots, (rank + 1) * n_roots)
         model = sp.model
         rng0 = agent.planner.batch_rng_states(n_roots, first_root=sp.lo)
@@ -388,14 +395,16 @@ def bench_uct(args, rank, world, local, with_prior=False):
             k = min(256, n_roots)
             lo_o = other * n_roots + (n_roots - k) // 2            # a block from the middle of that rank's shard
             take = np.arange(lo_o, lo_o + k)
-            got = {key: first[key][lo_o:lo_o + k].cpu().numpy() for key in ("plans", "plan_len", "value", "env_steps")}
+            got = {key: first[key][lo_o:lo_o + k].cpu().numpy() for key in ("plans", "plan_len", "value", "env_steps", "status")}
             chk = ctx.uct_plan(model, all_roots[take], episodes, horizon, gamma, temperature, p, p,
                                agent.planner.batch_rng_states(k, first_root=lo_o), max_plan_len=mpl)
-            same = (np.array_equal(got["plans"], chk["plans"]) and np.array_equal(got["plan_len"], chk["plan_len"])
-                    and np.array_equal(got["value"], chk["root_value"]) and np.array_equal(got["env_steps"], chk["env_steps"]))
+            w = got["plans"].shape[1]                  # plan entries a row carries (1: the compact payload)
+            same = (np.array_equal(got["plans"], chk["plans"][:, :w]) and np.array_equal(got["plan_len"], np.minimum(chk["plan_len"], w))
+                    and np.array_equal(got["value"], chk["root_value"]) and np.array_equal(got["env_steps"], chk["env_steps"])
+                    and not got["status"].any())
             cross = dict(cross_check="ok" if same else "MISMATCH", cross_check_roots=int(k), cross_check_of_rank=int(other),
                          cross_check_what="rank 0 re-planned global roots [{}, {}) through the host-array API and compared "
-                                          "plans / plan_len / root value / env_steps with the gathered rows".format(lo_o, lo_o + k))
+                                          "first action / root value / env_steps / status with the gathered rows".format(lo_o, lo_o + k))
             if not same:
                 print("bench.py: gathered results of rank {} differ from rank 0's re-plan".format(other), file=sys.stderr)
                 os._exit(3)
@@ -427,12 +436,33 @@ def bench_uct(args, rank, world, local, with_prior=False):
             return sp.local[(sp.turn - 1) % len(sp.local)]
         return dict(plans=d_plans, plan_len=d_len, value=d_val, env_steps=d_steps)
 
+    exchange_ms = []
     for _ in range(min(args.steps, 10)):
         step()
         kernel_ms.append(ctx.last_kernel_ms()[0])
+        if sp is not None and sp.last_exchange_ms() is not None:
+            exchange_ms.append(sp.last_exchange_ms())
         d_steps = last_buffers()["env_steps"]
         env_steps = int(d_steps.sum().item())
     variant = ctx.last_kernel_variant()
+    # the GENERAL-model kernel on the same batch: a model that does not fit LDS, has more than 256 distinct rewards
+    # or 32 768+ states gathers 16-byte records from L2 / HBM instead (`uct_global`); printed beside the LDS-resident headline
+    general = None
+    if variant == "uct_ldsr" and not with_prior and not os.environ.get("MP_UCT_MODEL"):
+        os.environ["MP_UCT_MODEL"] = "global"
+        try:
+            gk = []
+            step()
+            for _ in range(3):
+                step()
+                gk.append(ctx.last_kernel_ms()[0])
+            g_steps = int(last_buffers()["env_steps"].sum().item())
+            general = dict(kernel_variant=ctx.last_kernel_variant(), kernel_ms=float(np.mean(gk)),
+                           value=sum_over_ranks(g_steps / (float(np.mean(gk)) * 1e-3), world), unit="env-steps/s",
+                           note="same roots, same plans (bit-identical results), the record-gather kernel: what a model that "
+                                "cannot live in LDS gets; rate = env steps / kernel time")
+        finally:
+            os.environ.pop("MP_UCT_MODEL", None)
     dt = max_over_ranks(dt, world)
     total_env_steps = sum_over_ranks(float(timed_env_steps), world) / args.steps   # per step, all ranks
     # Algorithmic bytes of THIS run, SURVEY.md 8(d): per env step 13 B of model (T 4 + R 8 + term 1); per selection
@@ -544,8 +574,8 @@ def bench_uct(args, rank, world, local, with_prior=False):
             measured_mean_selection_depth=mean_depth, measured_expansions_per_episode=expansions / float(n_smp * episodes),
             algorithmic_bytes_per_env_step=bytes_per_step,
             parallelism="roots sharded over {} GPU(s); per step ONE all_gather_into_tensor of the packed per-root rows "
-                        "{{plans[{}], plan_len, root value, env_steps, status}} ({} B per root), product path "
-                        "rl_agents_amd.distributed.ShardedDevicePlan".format(world, mpl, 4 * mpl + 24) if sp is not None else
+                        "{{plan[0], root value, env_steps (status in its top byte)}} ({} B per root), product path "
+                        "rl_agents_amd.distributed.ShardedDevicePlan".format(world, sp.row_bytes) if sp is not None else
                         "single GPU"),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
@@ -562,6 +592,22 @@ def bench_uct(args, rank, world, local, with_prior=False):
                                       "the counters saw; the kernel is bound by vector-ALU issue" if variant == "uct_ldsr" else "") + ("; the per-state policy tables (L2-resident by construction, like the 800 KB model) "
                                       "are not charged" if with_prior else "")),
     )
+    if general is not None:
+        res["general_model_kernel"] = general
+    if sp is not None:
+        # the price of the one exchange of the sharded path: HIP events from the end of the planner's kernel to the end
+        # of the unpack (pack + all_gather_into_tensor + unpack), on the side stream the next launch overlaps
+        ex = float(np.mean(exchange_ms)) if exchange_ms else None
+        step_ms = 1e3 * dt / args.steps
+        res["exchange"] = dict(
+            payload=sp.payload, row_bytes=int(sp.row_bytes), bytes_sent_per_rank_per_step=int(sp.row_bytes) * int(sp.per),
+            bytes_received_per_rank_per_step=int(sp.row_bytes) * int(sp.per) * world, exchange_ms=ex,
+            on_side_stream=bool(sp.overlapped), backend="rccl" if sp.on_device else ("gloo via host" if sp.grouped else None),
+            kernel_ms=k_ms, step_ms=step_ms,
+            hidden_ms=None if ex is None else max(0.0, min(ex, k_ms + ex - step_ms)),
+            note="exchange_ms = pack + all_gather_into_tensor + unpack (HIP events around them); hidden_ms = how much of it the "
+                 "timed loop did not pay (kernel_ms + exchange_ms - step_ms, clamped to [0, exchange_ms]): the side stream runs "
+                 "it under the next step's kernel" if world > 1 else "single rank: no process group, no exchange")
     add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)
     if not with_prior and rank == 0 and world == 1 and not args.headline_only:
         # the default run measures the headline kernel's HBM traffic itself (it used to be read from a committed
@@ -845,14 +891,48 @@ def bench_opd(args, rank, world, local):
     d_up = torch.empty(n_roots, dtype=torch.float64, device=dev)
     d_steps = torch.empty(n_roots, dtype=torch.int64, device=dev)
     d_status = torch.empty(n_roots, dtype=torch.int32, device=dev)
-    gathered = torch.empty(world * n_roots, dtype=torch.float64, device=dev) if world > 1 else None
+    sp, cross = None, None
+    if world > 1:
+        # N > 1 (BASELINE config C4: 8192 roots over 8 GPUs): the PRODUCT's sharded path, as the headline -- a
+        # DeterministicPlannerAgent from agent_factory, ShardedDevicePlan (roots by global index, asynchronous launch,
+        # mp_pack_rows -> ONE all_gather_into_tensor -> mp_unpack_rows on a side stream), cross-checked inside the run
+        from rl_agents_amd import runtime
+        from rl_agents_amd.agents.common.factory import agent_factory
+        from rl_agents_amd.distributed import ShardedDevicePlan
+        from rl_agents_amd.envs import FiniteMDPEnv
+        model.close()
+        ctx.close()
+        ctx = runtime.get_context(local)
+        ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+        env = FiniteMDPEnv(dict(mode="deterministic", transition=t, reward=r, terminal=np.asarray(term).astype(int)))
+        env.reset()
+        agent = agent_factory(env, {"__class__": "<class 'rl_agents_amd.agents.tree_search.deterministic.DeterministicPlannerAgent'>",
+                                    "budget": budget, "gamma": gamma})
+        agent.seed(0)
+        sp = ShardedDevicePlan(agent, world * n_roots, max_plan_len=mpl, time_exchange=True)
+        assert (sp.lo, sp.hi) == (rank * n_roots, (rank + 1) * n_roots)
+        model = sp.model
+        rng0 = agent.planner.batch_rng_states(n_roots, first_root=sp.lo)
+        first = sp.wait(sp.plan(d_s0))
+        if rank == 0:
+            other, k = 1 % world, min(64, n_roots)
+            lo_o = other * n_roots + (n_roots - k) // 2
+            got = {key: first[key][lo_o:lo_o + k].cpu().numpy() for key in ("plans", "value", "env_steps", "status")}
+            chk = ctx.opd_plan(model, all_roots[lo_o:lo_o + k], budget, gamma, 0.0, agent.planner.batch_rng_states(k, first_root=lo_o),
+                               max_plan_len=mpl)
+            same = (np.array_equal(got["plans"][:, 0], chk["plans"][:, 0]) and np.array_equal(got["value"], chk["root_lower"])
+                    and np.array_equal(got["env_steps"], chk["env_steps"]) and not got["status"].any())
+            cross = dict(cross_check="ok" if same else "MISMATCH", cross_check_roots=int(k), cross_check_of_rank=int(other))
+            if not same:
+                print("bench.py: gathered OPD results of rank {} differ from rank 0's re-plan".format(other), file=sys.stderr)
+                os._exit(3)
 
     def step():
+        if sp is not None:
+            sp.plan(d_s0)
+            return
         ctx.opd_plan_device(model, n_roots, d_s0, budget, gamma, 0.0, d_rng, mpl, plans=d_plans, plan_len=d_len,
                             root_lower=d_lo, root_upper=d_up, env_steps=d_steps, status=d_status)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_gather_into_tensor(gathered, d_lo)
 
     for _ in range(args.warmup):
         step()
@@ -864,6 +944,10 @@ def bench_opd(args, rank, world, local):
     dt = max_over_ranks(time.perf_counter() - t0, world)
     step()
     k_ms = ctx.last_kernel_ms()[0]
+    exchange_ms = None if sp is None else sp.last_exchange_ms()
+    if sp is not None:
+        loc = sp.local[(sp.turn - 1) % len(sp.local)]
+        d_steps, d_status = loc["env_steps"], loc["status"]
     env_steps = int(d_steps.sum().item())
     assert int(d_status.abs().sum().item()) == 0
     total = sum_over_ranks(float(env_steps), world)
@@ -903,6 +987,15 @@ def bench_opd(args, rank, world, local):
                            "reported separately and not charged"),
     )
     add_traffic(res["roofline"], "opd", "opd_", n_roots * 64)
+    if sp is not None:
+        res["exchange"] = dict(payload=sp.payload, row_bytes=int(sp.row_bytes), exchange_ms=exchange_ms, kernel_ms=k_ms,
+                               step_ms=1e3 * dt / args.steps, on_side_stream=bool(sp.overlapped),
+                               backend="rccl" if sp.on_device else "gloo via host")
+        res["config"]["parallelism"] = ("{} roots sharded over {} GPU(s) (BASELINE C4: 8192 over 8), product path "
+                                        "rl_agents_amd.distributed.ShardedDevicePlan, ONE all_gather_into_tensor of {} B rows per step"
+                                        .format(world * n_roots, world, sp.row_bytes))
+    if cross is not None:
+        res["_cross"] = cross
     if not args.no_parity_sample and world == 1:
         from oracle import oracle
         d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
@@ -1206,7 +1299,7 @@ def bench_vi(args, rank, world, local, dense, robust=False, exact=False):
         if dense:
             # three sweeps of the reference's iteration (value_iteration.py:65-73) on the device; a backup is independent
             # per source row, so the oracle replays a SAMPLE of rows of every sweep from the device's previous value vector
-            idx = sample_rows(s_)
+            idx = sample_rows(s_, PARITY_DENSE_ROWS)
             ti = torch.from_numpy(idx).to(dev)
             rows_t, rows_r = tt[ti].cpu().numpy(), rr[ti].cpu().numpy()
             v = torch.zeros(s_, dtype=torch.float64, device=dev)
@@ -1371,7 +1464,7 @@ def bench_rvi_dense_shard(args, rank, world, local):
                 pattern="stream")
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
-        idx = sample_rows(rows)
+        idx = sample_rows(rows, PARITY_DENSE_ROWS)
         ti = torch.from_numpy(idx).to(dev)
         rows_t, rows_r = tt[:, ti].cpu().numpy(), rr[:, ti].cpu().numpy()
         vv = torch.zeros(s_, dtype=torch.float64, device=dev)
@@ -1409,7 +1502,235 @@ def bench_rvi_dense_shard(args, rank, world, local):
     return res
 
 
+def _episode_tables(n, shape, seed0=0, distinct=None):
+    """n highway-shaped tables of one (V, L, T) grid -- the finite MDPs of n episodes -- of which `distinct` are generated (the
+    rest repeat them: every episode still owns its copy on the device)."""
+    from rl_agents_amd.envs import generators
+    distinct = n if distinct is None else min(n, distinct)
+    cfgs = [generators.highway_shaped(*shape, collision_rate=0.03 + 0.02 * (i % 5), seed=seed0 + i) for i in range(distinct)]
+    idx = np.arange(n) % distinct
+    return (np.stack([c["transition"] for c in cfgs])[idx], np.stack([c["reward"] for c in cfgs])[idx],
+            np.stack([c["terminal"] for c in cfgs])[idx])
+
+
+def bench_vi_batch(args, rank, world, local):
+    """N value-iteration agents in ONE launch (round 5): a batch of episodes each owns its finite MDP (highway-v0's
+    to_finite_mdp() table, re-extracted at every step: value_iteration.py:29-35) -- mp_vi_solve_batch solves all of them, each to
+    its own allclose exit, as N ValueIterationAgent objects would (gamma 0.95, at most 200 sweeps).  --roots = MDPs per GPU
+    (default 4096), --states 120 (grid 3 x 4 x 10, highway-env's default shape) or 10 000 (10 x 10 x 100, BASELINE C2's shape).
+    A step = the solve of all MDPs of this rank (their tables resident on the device).  Independent MDPs shard over ranks with no
+    collective."""
+    import torch
+    from rl_agents_amd import native
+    s_req = args.states or 120
+    shape = (3, 4, 10) if s_req <= 120 else (10, 10, 100)
+    n = args.roots or (4096 if s_req <= 120 else 64)
+    gamma, iters = 0.95, 200
+    tr, rw, tm = _episode_tables(n, shape, seed0=1000 * rank, distinct=n if s_req <= 120 else 64)
+    s_, a_ = tr.shape[1:]
+    dev = torch.device("cuda", local)
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    model = ctx.load_table_batch(tr, rw, tm)
+    d_q = torch.zeros((n * s_, a_), dtype=torch.float64, device=dev)
+    d_sw = torch.zeros(n, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.vi_solve_batch_device(model, gamma, iters, d_q, d_sw)
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    k_ms = []
+    for _ in range(5):
+        step()
+        k_ms.append(ctx.last_kernel_ms()[0])
+    k_ms = float(np.mean(k_ms))
+    variant = ctx.last_kernel_variant()
+    sweeps = d_sw.cpu().numpy().astype(np.int64)
+    total_sweeps = sum_over_ranks(float(sweeps.sum()), world)
+    # the single-solve path on ONE of these MDPs (what an agent that owns one environment calls): sweeps per second
+    single = ctx.load_table(tr[0], rw[0], tm[0])
+    q1 = torch.zeros((s_, a_), dtype=torch.float64, device=dev)
+    sw1 = torch.zeros(1, dtype=torch.int32, device=dev)
+    ctx.vi_solve_device(single, gamma, iters, q1, sw1)
+    one_ms = []
+    for _ in range(5):
+        ctx.vi_solve_device(single, gamma, iters, q1, sw1)
+        one_ms.append(ctx.last_kernel_ms()[0])
+    one_sweeps = int(sw1.cpu().numpy()[0])
+    single_rate = one_sweeps / (float(np.mean(one_ms)) * 1e-3)
+    single.close()
+    per_sweep = 12.0 * s_ * a_ + 17.0 * s_                      # SURVEY 8(d): T 4 + R 8 per (s, a); V read + write + flag per state
+    alg = per_sweep * float(sweeps.sum())
+    rate = total_sweeps * args.steps / dt
+    res = dict(
+        metric="value-iteration Bellman sweeps/sec (N independent MDPs per launch, each to its own allclose exit)", unit="sweeps/s",
+        value=rate, ms_per_step=1e3 * dt / args.steps, dtype="f64", variant=variant,
+        speedup_vs_single_solve=dict(batch_sweeps_per_s=float(sweeps.sum()) / (k_ms * 1e-3), single_solve_sweeps_per_s=single_rate,
+                                     ratio=float(sweeps.sum()) / (k_ms * 1e-3) / single_rate, single_solve_kernel_ms=float(np.mean(one_ms)),
+                                     note="kernel time of ONE mp_vi_solve_batch launch over all MDPs against mp_vi_solve on one of them"),
+        config=dict(workload="vi_batch_{}_mdps_highway_shaped_S{}_A{}_gamma{}_max{}sweeps".format(n, s_, a_, gamma, iters),
+                    mdps_per_gpu=n, states=s_, actions=a_, gamma=gamma, iterations=iters, sweeps_run_mean=float(sweeps.mean()),
+                    sweeps_run_min=int(sweeps.min()), sweeps_run_max=int(sweeps.max()), solves_per_s=n * args.steps / dt * world,
+                    parallelism="independent MDPs sharded over {} GPU(s), no collective".format(world)),
+        roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel=variant, kernel_ms=k_ms,
+                      algorithmic_bytes_per_launch=alg, traffic=None,
+                      note="algorithmic bytes = SURVEY 8(d) (12 S A + 17 S per sweep) x the sweeps every MDP really ran; the "
+                           "register form (S <= 4096) keeps an MDP's rows in registers and V in LDS -- it touches HBM once per solve, "
+                           "so `frac` is the rate at which the algorithm's bytes are consumed, not HBM traffic; the streaming form "
+                           "(S = 10 000) re-reads 10 B per (s, a) per sweep from L2 / MALL"),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        idx = sample_rows(n, 512 if s_ <= 120 else 8)
+        q_ref, sw_ref = oracle.vi_solve_each(tr[idx], rw[idx], tm[idx], gamma=gamma, iterations=iters)
+        q = d_q.cpu().numpy().reshape(n, s_, a_)
+        ok = np.array_equal(q[idx], q_ref) and np.array_equal(sweeps[idx], sw_ref)
+        res["parity_sample"] = parity_record(ok, "{} MDPs of the timed {}-MDP launch vs {} sequential oracle solves: Q and sweep "
+                                             "counts bit for bit".format(len(idx), n, len(idx)))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        t1, done, i = time.perf_counter(), 0, 0
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            _, k = oracle.vi_solve("deterministic", tr[i % n], rw[i % n], tm[i % n], gamma=gamma, iterations=iters)
+            done += k
+            i += 1
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=done / cdt, unit="sweeps/s", cores=1, kind="port",
+                                   sample="oracle/planning_oracle.c orc_vi_solve on {} of these MDPs one after the other ({:.1f} s)".format(i, cdt))
+    model.close()
+    return res
+
+
+def bench_uct_per_root_model(args, rank, world, local):
+    """UCT with ONE MDP PER ROOT (round 5): every root of the batch plans on its own highway-shaped (3, 4, 10) table -- the batch
+    of highway episodes of trainer/evaluation.py:139-194, one environment each -- through mp_uct_plan_models on a batch model;
+    budget 1000 as 33 x 30.  Beside it: the same roots on ONE shared table (the kernel the other UCT rows measure)."""
+    import torch
+    from rl_agents_amd import native
+    n_roots = args.roots or 4096
+    episodes, horizon, gamma, temperature = 33, 30, 0.8, 2 / (1 - 0.8)
+    tr, rw, tm = _episode_tables(n_roots, (3, 4, 10), seed0=7 + 100000 * rank, distinct=4096)
+    s_, a_ = tr.shape[1:]
+    dev = torch.device("cuda", local)
+    ctx = native.Context(local, torch.cuda.current_stream().cuda_stream)
+    t_load = time.perf_counter()
+    model = ctx.load_table_batch(tr, rw, tm)
+    load_ms = 1e3 * (time.perf_counter() - t_load)
+    t_upd = time.perf_counter()
+    model.update_tables(0, tr, rw, tm)              # what a step of the episodes costs on the upload side: every table replaced
+    ctx.synchronize()
+    upd_ms = 1e3 * (time.perf_counter() - t_upd)
+    g = np.random.Generator(np.random.PCG64(1 + rank))
+    s0 = g.integers(0, s_, n_roots).astype(np.int32)
+    rng0 = seed_states(np.arange(rank * n_roots, (rank + 1) * n_roots))
+    mpl = 8
+    p = np.ones(a_) / a_
+    d = dict(mi=torch.arange(n_roots, dtype=torch.int32, device=dev), s0=torch.from_numpy(s0).to(dev),
+             rng=torch.from_numpy(rng0.view(np.int64)).to(dev), plans=torch.full((n_roots, mpl), -1, dtype=torch.int32, device=dev),
+             plan_len=torch.zeros(n_roots, dtype=torch.int32, device=dev), value=torch.zeros(n_roots, dtype=torch.float64, device=dev),
+             steps=torch.zeros(n_roots, dtype=torch.int64, device=dev))
+    d_total = torch.zeros(1, dtype=torch.int64, device=dev)
+    torch.cuda.synchronize()
+
+    def step(m=None, mi=True):
+        ctx.uct_plan_device(m or model, n_roots, d["s0"], episodes, horizon, gamma, temperature, p, p, d["rng"], mpl, plans=d["plans"],
+                            plan_len=d["plan_len"], root_value=d["value"], env_steps=d["steps"], model_index=d["mi"] if mi else None)
+        d_total.add_(d["steps"].sum())
+
+    for _ in range(args.warmup):
+        step()
+    barrier(world)
+    d_total.zero_()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    timed = sum_over_ranks(float(d_total.item()), world)
+    k_ms = []
+    for _ in range(5):
+        step()
+        k_ms.append(ctx.last_kernel_ms()[0])
+    k_ms = float(np.mean(k_ms))
+    variant = ctx.last_kernel_variant()
+    env_steps = int(d["steps"].sum().item())
+    sample = np.unique(np.linspace(0, n_roots - 1, 129).astype(np.int64))
+    sel_steps = expansions = 0
+    smp_steps = int(d["steps"][torch.from_numpy(sample).to(dev)].sum().item())
+    for root in sample:
+        tree = ctx.uct_tree(int(root))
+        sel_steps += int(tree["count"][1:].sum())
+        expansions += int((tree["first_child"] >= 0).sum())
+    bytes_per_step = (13.0 * smp_steps + 16.0 * a_ * sel_steps + 24.0 * (sel_steps + len(sample) * episodes) + 24.0 * a_ * expansions) / smp_steps
+    # the same roots on ONE shared table: the kernel every other UCT row of this file measures
+    shared = ctx.load_table(tr[0], rw[0], tm[0])
+    sh_ms = []
+    step(shared, mi=False)
+    for _ in range(5):
+        step(shared, mi=False)
+        sh_ms.append(ctx.last_kernel_ms()[0])
+    sh_ms, sh_variant, sh_steps = float(np.mean(sh_ms)), ctx.last_kernel_variant(), int(d["steps"].sum().item())
+    shared.close()
+    res = dict(
+        metric="rollout env-steps/sec (UCT plan(), budget=1000, one MDP per root)", unit="env-steps/s",
+        value=timed / dt, ms_per_step=1e3 * dt / args.steps, dtype="f64", variant=variant,
+        vs_shared_model_kernel=dict(per_root_model_kernel_ms=k_ms, shared_model_kernel_ms=sh_ms, shared_model_variant=sh_variant,
+                                    ratio=k_ms / sh_ms, per_root_env_steps_per_s=env_steps / (k_ms * 1e-3),
+                                    shared_env_steps_per_s=sh_steps / (sh_ms * 1e-3),
+                                    note="same roots, budget and policies; `shared` plans every root on table 0"),
+        config=dict(workload="uct_per_root_model_highway_shaped_S{}_A{}_budget1000_e{}xh{}_roots{}_per_gpu".format(s_, a_, episodes, horizon, n_roots),
+                    n_roots_per_gpu=n_roots, states_per_mdp=s_, actions=a_, episodes=episodes, horizon=horizon, gamma=gamma,
+                    model_bytes=int(n_roots) * s_ * a_ * 16, model_load_ms=load_ms, replace_every_table_ms=upd_ms,
+                    algorithmic_bytes_per_env_step=bytes_per_step,
+                    parallelism="roots (episodes) sharded over {} GPU(s), no collective".format(world)),
+        roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                      kernel="uct_kernel<5, ENV_TABLE> on the union model ({})".format(variant), kernel_ms=k_ms,
+                      algorithmic_bytes_per_launch=bytes_per_step * env_steps, traffic=None,
+                      note="algorithmic bytes = SURVEY 8(d) terms with depth / expansions measured on this launch's trees; every root "
+                           "gathers the 16-byte records of ITS OWN {} B table".format(s_ * a_ * 16)),
+    )
+    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    if not args.no_parity_sample and rank == 0:
+        from oracle import oracle
+        d["rng"].copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
+        step()
+        idx = sample_rows(n_roots)
+        ti = torch.from_numpy(idx).to(dev)
+        ref = oracle.uct_plan_each(tr, rw, tm, idx, s0[idx], episodes, horizon, gamma, temperature, p, p, rng0[idx], max_plan_len=mpl)
+        ok = (np.array_equal(d["plans"][ti].cpu().numpy(), ref["plans"]) and np.array_equal(d["value"][ti].cpu().numpy(), ref["root_value"])
+              and np.array_equal(d["steps"][ti].cpu().numpy(), ref["env_steps"])
+              and np.array_equal(d["rng"][ti].cpu().numpy().view(np.uint64), ref["rng_after"]))
+        res["parity_sample"] = parity_record(ok, "{} roots of the timed {}-root launch vs per-root oracle plans on each root's own table: "
+                                             "plans, root value, env_steps, generator state bit for bit".format(len(idx), n_roots))
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle
+        t1, done, i = time.perf_counter(), 0, 0
+        cpu_rng = seed_states(np.arange(256))
+        while time.perf_counter() - t1 < args.cpu_seconds:
+            o = oracle.uct_plan_batch(tr[i % n_roots], rw[i % n_roots], tm[i % n_roots], np.resize(s0, 256), episodes, horizon, gamma,
+                                      temperature, p, p, cpu_rng, n_threads=host_cores())
+            done += int(o["env_steps"].sum())
+            i += 1
+        cdt = time.perf_counter() - t1
+        res["cpu_baseline"] = dict(value=done / cdt, unit="env-steps/s", cores=host_cores(), kind="port",
+                                   sample="oracle/planning_oracle.c uct_plan_batch, 256 roots per table, {} tables in {:.1f} s".format(i, cdt))
+    model.close()
+    return res
+
+
 def run_workload(args, rank, world, local):
+    if args.workload == "vi_batch":
+        return bench_vi_batch(args, rank, world, local)
+    if args.workload == "uct_per_root_model":
+        return bench_uct_per_root_model(args, rank, world, local)
     if args.workload == "uct_prior":
         return bench_uct(args, rank, world, local, with_prior=True)
     if args.workload == "uct":
@@ -1436,20 +1757,31 @@ SLICES = [("uct_prior", "uct_prior", 5, None), ("uct_cartpole", "uct_cartpole", 
           ("opd", "opd", 10, None), ("opd8192", "opd", 3, 8192), ("ropd", "ropd", 10, None), ("saopd", "saopd", 3, None),
           ("vi", "vi", 10, None), ("rvi", "rvi", 10, None), ("vi_dense", "vi_dense", 3, None),
           ("vi_dense_exact", "vi_dense_exact", 3, None), ("rvi_dense_shard", "rvi_dense_shard", 10, None),
-          ("rvi_dense_shard_exact", "rvi_dense_shard", 10, None, "exact")]
+          ("rvi_dense_shard_exact", "rvi_dense_shard", 10, None, "exact"),
+          # round 5: one finite MDP per episode -- N value-iteration agents in one launch, UCT with one MDP per root
+          ("vi_batch", "vi_batch", 10, 4096, None, 120), ("vi_batch_s10000", "vi_batch", 5, 64, None, 10000),
+          ("uct_per_root_model", "uct_per_root_model", 10, 4096)]
 
 
-def run_slices(args, rank, world, local):
+SLICES_MULTI_GPU = [("opd", "opd", 10, None), ("rvi_dense_shard_exact", "rvi_dense_shard", 10, None, "exact")]
+
+
+def run_slices(args, rank, world, local, slices=None):
     """Every other workload for a bounded slice (no CPU baseline) -> {name: {value, unit, ms_per_step, kernel, kernel_ms,
     frac, traffic_frac, parity_sample, workload}}: the numbers of README / DESIGN, driver-timed in the one line."""
     import copy
     import gc
     import torch
     out = {}
-    for name, workload, steps, roots, *mode in SLICES:
+    for name, workload, steps, roots, *mode in (slices or SLICES):
         sub = copy.copy(args)
-        sub.workload, sub.steps, sub.warmup, sub.roots, sub.no_cpu_baseline = workload, steps, 1, roots, True
-        sub.dense_mode = mode[0] if mode else ("mfma" if workload == "rvi_dense_shard" else None)
+        # (every slice carries its own bounded CPU baseline -- the C port on this host's cores for about a second -- and the
+        # unmodified Python reference's committed timing of the same workload beside it: VERDICT r4)
+        sub.workload, sub.steps, sub.warmup, sub.roots = workload, steps, 1, roots
+        sub.no_cpu_baseline, sub.cpu_seconds = args.no_cpu_baseline or world > 1, 1.0
+        sub.dense_mode = mode[0] if mode and mode[0] else ("mfma" if workload == "rvi_dense_shard" else None)
+        if len(mode) > 1:
+            sub.states = mode[1]
         t0 = time.perf_counter()
         try:
             res = run_workload(sub, rank, world, local)
@@ -1465,6 +1797,20 @@ def run_slices(args, rank, world, local):
             extra = res["config"].get("kernel_ms_first_and_following_plans")
             if extra is not None:
                 out[name]["kernel_ms_first_and_following_plans"] = extra
+            for k in ("exchange", "cpu_baseline", "variant", "speedup_vs_single_solve", "vs_shared_model_kernel"):
+                if res.get(k) is not None:
+                    out[name][k] = res[k]
+            if isinstance(out[name].get("cpu_baseline"), dict):
+                ref = reference_python(workload)
+                if ref is not None:
+                    out[name]["cpu_baseline"]["reference_python"] = ref
+            if world > 1:
+                rec = ranks_record(rank, world, local)
+                out[name]["ranks_seen"] = rec["ranks_seen"]
+                out[name]["cross_check"] = (res.get("_cross") or {}).get("cross_check")
+                out[name]["parallelism"] = res["config"].get("parallelism")
+                if workload == "rvi_dense_shard":
+                    out[name]["all_gather_ms"] = res["config"].get("all_gather_ms")
         except Exception as e:                                    # a slice must not cost the headline its line
             out[name] = dict(error="{}: {}".format(type(e).__name__, e))
         out[name]["slice_seconds"] = round(time.perf_counter() - t0, 2)
@@ -1495,6 +1841,10 @@ def main():
             res["scaling"] = "weak (DRY RUN: all ranks on one device, not a scaling measurement)"
         if args.workload == "uct" and world == 1 and not args.headline_only:
             res["workloads"] = run_slices(args, rank, world, local)
+        elif args.workload == "uct" and world > 1 and not args.headline_only:
+            # the other two BASELINE configurations that are sharded over the GPUs of a node, in the same launch the driver
+            # times: C4 (OPD, 1024 roots per GPU) and C5 (dense robust VI, one row block per GPU, all_gather of V per sweep)
+            res["workloads"] = run_slices(args, rank, world, local, slices=SLICES_MULTI_GPU)
     res.setdefault("cpu_baseline", None)
     if isinstance(res["cpu_baseline"], dict):
         # the reference's own (pure Python) CPU path on the same tables: it cannot travel to the GPU box, so its timing is

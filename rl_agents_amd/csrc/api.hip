@@ -854,7 +854,10 @@ int reward_index(mp_model *m, double r, bool *grew)
 
 void drop_compact_rewards(mp_model *m)
 {
-    // (r8 / rdict stay allocated -- enqueued kernels may still read them -- but no later launch uses them)
+    // (the arrays stay allocated -- enqueued kernels may still read them -- but no later launch sees them: the planners
+    // pick the LDS-resident form by model->r8)
+    if (m->r8) m->dead_blocks.push_back(m->r8);
+    m->r8 = nullptr;
     m->n_rdict = 0;
     delete m->rmap;
     m->rmap = nullptr;
@@ -1237,6 +1240,7 @@ int mp_model_free(mp_model *m)
     if (m->upd_stage) (void)hipHostFree(m->upd_stage);
     if (m->upd_dev) hipFree(m->upd_dev);
     if (m->upd_done) (void)hipEventDestroy(m->upd_done);
+    for (void *p : m->dead_blocks) (void)hipFree(p);
     delete m->rmap;
     delete m;
     return MP_OK;

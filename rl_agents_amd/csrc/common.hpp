@@ -202,6 +202,7 @@ struct mp_model {
     hipEvent_t upd_done = nullptr;
     bool upd_pending = false;
     std::unordered_map<uint64_t, int> *rmap = nullptr; // host mirror of rdict (bit pattern -> index): updates extend it
+    std::vector<void *> dead_blocks;                   // device arrays an update retired (freed with the model)
     int done_on_next = 0, max_steps = 0;
     bool masked = false;     // mp_model_set_available restricted the action sets (state.get_available_actions())
     uint8_t *avail = nullptr; // device [S*A] flags, only when masked

@@ -1514,7 +1514,8 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wg(ViBatchArgs p)
 // wavefront is one contiguous 128- / 512-byte run (state-major rows of |A| = 5 doubles are 40 bytes apart per lane: every
 // load instruction would touch twenty cache lines for one line's worth of data).
 __global__ __launch_bounds__(256) void vi_batch_transpose(int N, int Sb, int A, const int32_t *__restrict__ T, const double *__restrict__ R,
-                                                          uint16_t *__restrict__ Tt, double *__restrict__ Rt)
+                                                          const uint8_t *__restrict__ term, uint16_t *__restrict__ Tt,
+                                                          double *__restrict__ Rt)
 {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x; // over [N][A][Sb]
     if (i >= (long)N * A * Sb) return;
@@ -1522,7 +1523,9 @@ __global__ __launch_bounds__(256) void vi_batch_transpose(int N, int Sb, int A, 
     const long ba = i / Sb;
     const int a = (int)(ba % A), b = (int)(ba / A);
     const long src = ((long)b * Sb + s) * A + a;
-    Tt[i] = (uint16_t)(T[src] - b * Sb);
+    // bit 15: terminal[s] of the SOURCE state (Sb <= 10 240 here) -- the flag arrives with the row it masks instead of
+    // costing the sweep a dependent byte load per state
+    Tt[i] = (uint16_t)((T[src] - b * Sb) | (term && term[(long)b * Sb + s] ? 0x8000 : 0));
     Rt[i] = R[src];
 }
 
@@ -1564,53 +1567,60 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wgr(ViBatchArgs p, const ui
         const double *Vprev = Vg + (long)((k + 2) % 3) * S;
         double *Vnext_g = Vg + (long)((k + 1) % 3) * S;
         bool nc = false;
-        int tn[AT];
-        double rn[AT];
-        {
-            const int sc = tid < S ? tid : 0;
+        // rows requested THREE states ahead (three register stages, rotated by a 3x unrolled loop): with one MDP per CU the
+        // tables of a batch (32 MB at 64 x S = 10 000) stream from the infinity cache, ~0.6 us away -- one state of work per wave
+        // (x 4 waves per SIMD) does not cover that
+        int t0[AT], t1[AT], t2[AT];
+        double r0[AT], r1[AT], r2[AT];
+        auto request = [&](int (&tt)[AT], double (&rr)[AT], int s) {
+            const int sc = s < S ? s : (tid < S ? tid : 0);     // (beyond the last state: re-read a row that is there)
 #pragma unroll
-            for (int a = 0; a < AT; ++a) { tn[a] = tload(a, sc); rn[a] = rload(a, sc); }
-        }
-        for (int i = 0; i < n_own; ++i) {
-            const int s = tid + i * NT;
-            int t[AT];
-            double r[AT];
+            for (int a = 0; a < AT; ++a) { tt[a] = tload(a, sc); rr[a] = rload(a, sc); }
+        };
+        auto state = [&](int (&tt)[AT], const double (&rr)[AT], int s, bool first) {
+            const bool term_s = (tt[0] & 0x8000) != 0;          // (rides in the row: vi_batch_transpose)
 #pragma unroll
-            for (int a = 0; a < AT; ++a) { t[a] = tn[a]; r[a] = rn[a]; }
-            {   // the next state's rows: requested before this state's gathers (the last trip re-reads its own)
-                const int sn = s + NT < S ? s + NT : (s < S ? s : 0);
-#pragma unroll
-                for (int a = 0; a < AT; ++a) { tn[a] = tload(a, sn); rn[a] = rload(a, sn); }
-            }
-            const bool term_s = (p.term && s < S) ? p.term[base + s] != 0 : false;
+            for (int a = 0; a < AT; ++a) tt[a] &= 0x7fff;
             double vc[AT], vp[AT];
 #pragma unroll
-            for (int a = 0; a < AT; ++a) vc[a] = Vcur[t[a]];
-            const bool test = i == 0 && k > 0;
-            if (test) {
+            for (int a = 0; a < AT; ++a) vc[a] = Vcur[tt[a]];
+            if (first && k > 0) {
 #pragma unroll
-                for (int a = 0; a < AT; ++a) vp[a] = Vprev[t[a]];
+                for (int a = 0; a < AT; ++a) vp[a] = Vprev[tt[a]];
             }
             double vmax = 0.0;
 #pragma unroll
             for (int a = 0; a < AT; ++a) {
-                const double qn = r[a] + p.gamma * (term_s ? 0.0 : vc[a]);
-                if (i == 0) {
-                    const double qo = k == 0 ? 0.0 : r[a] + p.gamma * (term_s ? 0.0 : vp[a]);
+                const double qn = rr[a] + p.gamma * (term_s ? 0.0 : vc[a]);
+                if (first) {
+                    const double qo = k == 0 ? 0.0 : rr[a] + p.gamma * (term_s ? 0.0 : vp[a]);
                     nc |= s < S && !isclose_np_sel(qo, qn, p.rtol, p.atol);
                 }
                 if (a == 0 || qn > vmax) vmax = qn;
             }
             if (s < S) { Vnext[s] = vmax; Vnext_g[s] = vmax; }
+        };
+        request(t0, r0, tid);
+        request(t1, r1, tid + NT);
+        request(t2, r2, tid + 2 * NT);
+        for (int i = 0; i < n_own; i += 3) {
+            const int s = tid + i * NT;
+            state(t0, r0, s, i == 0);
+            request(t0, r0, s + 3 * NT);
+            if (i + 1 < n_own) state(t1, r1, s + NT, false);
+            request(t1, r1, s + 4 * NT);
+            if (i + 2 < n_own) state(t2, r2, s + 2 * NT, false);
+            request(t2, r2, s + 5 * NT);
         }
         bool moved = __syncthreads_or(nc ? 1 : 0) != 0;
         if (!moved) { // none of the first states' pairs moved: test the others (the last few sweeps only)
             bool nc2 = false;
             for (int s = tid + NT; s < S; s += NT) {
-                const bool term_s = p.term ? p.term[base + s] != 0 : false;
 #pragma unroll
                 for (int a = 0; a < AT; ++a) {
-                    const int t = tload(a, s);
+                    const int tw = tload(a, s);
+                    const bool term_s = (tw & 0x8000) != 0;
+                    const int t = tw & 0x7fff;
                     const double r = rload(a, s);
                     const double qn = r + p.gamma * (term_s ? 0.0 : Vcur[t]);
                     const double qo = k == 0 ? 0.0 : r + p.gamma * (term_s ? 0.0 : Vprev[t]);
@@ -1625,10 +1635,11 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wgr(ViBatchArgs p, const ui
     if (p.Q_out) {
         const double *Vjm1 = Vg + (long)((j + 2) % 3) * S; // V_{j-1}
         for (int s = tid; s < S; s += NT) {
-            const bool term_s = p.term ? p.term[base + s] != 0 : false;
 #pragma unroll
-            for (int a = 0; a < AT; ++a)
-                p.Q_out[(base + s) * AT + a] = j == 0 ? 0.0 : rload(a, s) + p.gamma * (term_s ? 0.0 : Vjm1[tload(a, s)]);
+            for (int a = 0; a < AT; ++a) {
+                const int tw = tload(a, s);
+                p.Q_out[(base + s) * AT + a] = j == 0 ? 0.0 : rload(a, s) + p.gamma * ((tw & 0x8000) ? 0.0 : Vjm1[tw & 0x7fff]);
+            }
         }
     }
 }
@@ -1663,7 +1674,7 @@ static int vi_batch_launch(mp_ctx *ctx, ViBatchArgs &q, hipStream_t st, const ch
             MP_TRY(ws_get(ctx, WS_VI2, npairs, &Rt));
             MP_TRY(ws_get(ctx, WS_VI4, npairs, &Tt));
             MP_TRY(ws_get(ctx, WS_VI1, (size_t)q.N * 3 * S, &q.Vglobal));
-            hipLaunchKernelGGL(vi_batch_transpose, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, q.N, S, AT, q.T, q.R, Tt, Rt);
+            hipLaunchKernelGGL(vi_batch_transpose, dim3((unsigned)((npairs + 255) / 256)), dim3(256), 0, st, q.N, S, AT, q.T, q.R, q.term, Tt, Rt);
             const size_t lds = (size_t)2 * S * sizeof(double);
             MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vi_det_batch_wgr<AT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)lds));

@@ -229,20 +229,31 @@ class ShardedDevicePlan(object):
     """Device-resident form of :func:`plan_batch_sharded`: the same sharding and the same random streams (keyed by the
     GLOBAL root index), but roots, generator records and results are device buffers and the exchange never touches the
     host -- per ``plan()``: the planner's asynchronous batched launch on this rank's shard, ``mp_pack_rows`` (the shard's
-    {plans, plan_len, value, env_steps, status} rows into ONE byte matrix), ONE ``all_gather_into_tensor`` (RCCL over xGMI)
-    and ``mp_unpack_rows`` (back into full per-root arrays on every rank).  The collective and the unpack run on a side
-    stream, double-buffered, so a caller that plans again straight away overlaps them with its next launch; the returned
-    ``ready`` event orders any consumer after them.  A ``gloo`` group (CPU tests, same-device dry runs) exchanges the same
-    packed bytes through host memory.  The generator records stay resident and continue from call to call, as
-    ``planner.np_random`` does for a single root (tree_search/abstract.py:124-131).
+    per-root rows into ONE byte matrix), ONE ``all_gather_into_tensor`` (RCCL over xGMI) and ``mp_unpack_rows`` (back into
+    full per-root arrays on every rank).  The collective and the unpack run on a side stream, double-buffered, so a
+    caller that plans again straight away overlaps them with its next launch; the returned ``ready`` event orders any
+    consumer after them.  A ``gloo`` group (CPU tests, same-device dry runs) exchanges the same packed bytes through host
+    memory.  The generator records stay resident and continue from call to call, as ``planner.np_random`` does for a
+    single root (tree_search/abstract.py:124-131).
+
+    ``payload``: what a root's row carries (per-root {plan[0..k], value, env_steps}).
+      ``"compact"`` (default): ``{plans[:plan_entries] int32, value f64, env_steps i64}`` -- 20 B per root with
+      ``plan_entries = 1`` (the action every caller of ``plan()`` executes, trainer/evaluation.py:168-180); the planner's
+      per-root status rides in the top byte of the env-step word (env steps stay far below 2^56), so no row is spent on it;
+      ``plan_len`` is not exchanged (the gathered ``plan_len`` is ``min(plan_len, plan_entries)`` of what was sent: 1 or 0);
+      ``"full"``: ``{plans[max_plan_len], plan_len, value, env_steps, status}`` (56 B at ``max_plan_len`` 8).
+    At 8 x 262 144 roots a step's exchange is 42 MB instead of 117 MB per rank.
 
     ``agent``: a tree-search agent whose planner has a device loop (``plan_batch_device``: MCTS, OPD)."""
 
-    def __init__(self, agent, n_total, max_plan_len=None, force_collective=False, overlap=True):
+    def __init__(self, agent, n_total, max_plan_len=None, force_collective=False, overlap=True, payload="compact", plan_entries=1,
+                 time_exchange=False):
         import torch
         planner = agent.planner
         if getattr(planner, "plan_batch_device", None) is None or not planner.supports_device_loop():
             raise NotImplementedError("this agent's planner has no device-resident batched plan")
+        if payload not in ("compact", "full"):
+            raise ValueError("payload must be 'compact' or 'full'")
         self.agent, self.planner = agent, planner
         self.rank, self.world = rank_world()
         self.n = int(n_total)
@@ -256,11 +267,15 @@ class ShardedDevicePlan(object):
         self.grouped = _group_active(force_collective)
         self.on_device = self.grouped and collective_device() is not None          # RCCL: tensors stay on the GPU
         self.mpl = mpl = int(max_plan_len or planner.device_plan_len(self.model))
+        self.payload = payload
+        self.sent = sent = mpl if payload == "full" else max(1, min(int(plan_entries), mpl))   # plan entries per exchanged row
+        self.time_exchange = bool(time_exchange)
         nl = self.hi - self.lo
         self.per = per = -(-self.n // self.world)
         with torch.cuda.device(dev):
             self.ctx_stream = torch.cuda.ExternalStream(ctx.stream_ptr(), device=dev)
             self.comm = torch.cuda.Stream(device=dev) if (overlap and self.grouped) else self.ctx_stream
+            self.overlapped = self.comm is not self.ctx_stream
             self.d_rng = torch.from_numpy(planner.batch_rng_states(nl, first_root=self.lo).view(np.int64)).to(dev)
 
             def local():
@@ -268,29 +283,35 @@ class ShardedDevicePlan(object):
                             plan_len=torch.zeros(nl, dtype=torch.int32, device=dev),
                             value=torch.zeros(nl, dtype=torch.float64, device=dev),
                             env_steps=torch.zeros(nl, dtype=torch.int64, device=dev),
-                            status=torch.zeros(nl, dtype=torch.int32, device=dev))
+                            status=torch.zeros(nl, dtype=torch.int32, device=dev),
+                            head=torch.zeros((nl, sent), dtype=torch.int32, device=dev),       # compact rows: plans[:, :sent]
+                            word=torch.zeros(nl, dtype=torch.int64, device=dev))              # compact rows: env_steps | status << 56
 
             def full():
-                return dict(plans=torch.empty((self.n, mpl), dtype=torch.int32, device=dev),
+                return dict(plans=torch.empty((self.n, sent), dtype=torch.int32, device=dev),
                             plan_len=torch.empty(self.n, dtype=torch.int32, device=dev),
                             value=torch.empty(self.n, dtype=torch.float64, device=dev),
                             env_steps=torch.empty(self.n, dtype=torch.int64, device=dev),
                             status=torch.empty(self.n, dtype=torch.int32, device=dev))
-            self.keys = ("plans", "plan_len", "value", "env_steps", "status")
-            nbuf = 2 if self.grouped else 1
+            self.keys = ("plans", "plan_len", "value", "env_steps", "status") if payload == "full" else ("head", "value", "word")
+            # two buffer sets in every configuration: the buffers a plan() returns stay valid through the NEXT plan() and are
+            # overwritten by the one after it (the ungrouped case used to hold a single set)
+            nbuf = 2
             self.local = [local() for _ in range(nbuf)]
-            self.row_bytes = 4 * mpl + 4 + 8 + 8 + 4
+            self.row_bytes = 4 * mpl + 4 + 8 + 8 + 4 if payload == "full" else 4 * sent + 8 + 8
             if self.grouped:
                 self.full = [full() for _ in range(nbuf)]
                 self.packed = [torch.empty((per, self.row_bytes), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
                 self.gathered = [torch.empty((self.world * per, self.row_bytes), dtype=torch.uint8, device=dev)
                                  for _ in range(nbuf)]
-            self.kernel_done = [torch.cuda.Event() for _ in range(nbuf)]
+            self.kernel_done = [torch.cuda.Event(enable_timing=self.time_exchange) for _ in range(nbuf)]
+            self.exchange_done = [torch.cuda.Event(enable_timing=self.time_exchange) for _ in range(nbuf)]
             self.gather_done = [None] * nbuf
             order = getattr(self.model, "action_order", None)
             self.order = None if order is None else torch.from_numpy(np.asarray(order, dtype=np.int32)).to(dev)
             torch.cuda.synchronize(dev)                   # the buffers exist before the ctx stream touches them
         self.turn = 0
+        self._last_timed = None
 
     def shard(self, d_roots_all):
         """This rank's block of a global per-root device tensor."""
@@ -299,9 +320,10 @@ class ShardedDevicePlan(object):
     def plan(self, d_root_states, d_root_steps=None):
         """``d_root_states``: int32 device tensor, either the GLOBAL root list [n_total] (this rank plans its block) or
         already this rank's block [hi - lo].  Only enqueues.  Returns the full per-root device tensors (identical on every
-        rank) ``plans [n, max_plan_len]`` (environment action ids), ``plan_len``, ``value`` (root value / lower bound),
-        ``env_steps``, ``status`` and ``ready``, the event after which they hold this call's results (``None`` when they are
-        ready in ctx-stream order); they are overwritten by the call after the next one."""
+        rank) ``plans [n, plan entries exchanged]`` (environment action ids), ``plan_len``, ``value`` (root value / lower
+        bound), ``env_steps``, ``status`` and ``ready``, the event after which they hold this call's results (``None`` when
+        they are ready in ctx-stream order); they stay valid through the next ``plan()`` and are overwritten by the one
+        after it.  Without a process group the tensors are this rank's (= all) roots' own result buffers."""
         import torch
         import torch.distributed as dist
         nl = self.hi - self.lo
@@ -319,20 +341,31 @@ class ShardedDevicePlan(object):
         self.planner.plan_batch_device(self.env, self.model, nl, d_root_states, d_root_steps, self.d_rng, loc["plans"],
                                        loc["plan_len"], loc["env_steps"], loc["status"], d_value=loc["value"])
         if not self.grouped:
-            out = dict(loc)
+            out = {k: loc[k] for k in ("plans", "plan_len", "value", "env_steps", "status")}
             if self.order is not None:
                 with torch.cuda.stream(self.ctx_stream):
                     out["plans"] = torch.where(loc["plans"] >= 0, self.order[loc["plans"].clamp(min=0).long()], loc["plans"])
             out["ready"] = None
             return out
+        if self.time_exchange:
+            self.kernel_done[b].record(self.ctx_stream)            # the planner's kernel is done here: the exchange starts
+        if self.payload == "compact":
+            with torch.cuda.stream(self.ctx_stream):               # two small elementwise launches: the row's plan entries and
+                loc["head"].copy_(loc["plans"][:, :self.sent])     # the env-step word with the status in its top byte
+                torch.bitwise_or(loc["env_steps"], (-loc["status"]).to(torch.int64) << 56, out=loc["word"])
         arrays = [loc[k] for k in self.keys]
         self.ctx.pack_rows(arrays, nl, self.packed[b])
         full = self.full[b]
-        outs = [full[k] for k in self.keys]
+        outs = [full[k] for k in (self.keys if self.payload == "full" else ("plans", "value", "env_steps"))]
         if self.on_device:
             if self.comm is not self.ctx_stream:
-                self.kernel_done[b].record(self.ctx_stream)
-                self.comm.wait_event(self.kernel_done[b])
+                if not self.time_exchange:
+                    self.kernel_done[b].record(self.ctx_stream)
+                    self.comm.wait_event(self.kernel_done[b])
+                else:                                           # (kernel_done was recorded BEFORE the pack: order after the pack)
+                    ev = torch.cuda.Event()
+                    ev.record(self.ctx_stream)
+                    self.comm.wait_event(ev)
             with torch.cuda.stream(self.comm):
                 dist.all_gather_into_tensor(self.gathered[b], self.packed[b])
             self.ctx.unpack_rows(self.gathered[b], self.n, self.world, outs, stream=self.comm.cuda_stream)
@@ -346,13 +379,29 @@ class ShardedDevicePlan(object):
             self.ctx.unpack_rows(self.gathered[b], self.n, self.world, outs, stream=self.comm.cuda_stream)
         out = dict(full)
         with torch.cuda.stream(self.comm):
+            if self.payload == "compact":                       # status back out of the env-step word; plan_len of what was sent
+                word = full["env_steps"]
+                full["status"].copy_((-(word >> 56)).to(torch.int32))
+                word.bitwise_and_((1 << 56) - 1)
+                full["plan_len"].copy_((full["plans"] >= 0).sum(dim=1).to(torch.int32))
             if self.order is not None:
                 out["plans"] = torch.where(full["plans"] >= 0, self.order[full["plans"].clamp(min=0).long()], full["plans"])
-            ev = torch.cuda.Event()
+            ev = self.exchange_done[b] if self.time_exchange else torch.cuda.Event()
             ev.record(self.comm)
         self.gather_done[b] = ev
+        if self.time_exchange:
+            self._last_timed = b
         out["ready"] = ev
         return out
+
+    def last_exchange_ms(self):
+        """Milliseconds from the end of the planner's kernel to the end of the unpack of the LAST plan() (pack + collective +
+        unpack, as HIP events saw them; needs ``time_exchange=True``; synchronises).  None without a process group."""
+        if not self.time_exchange or self._last_timed is None:
+            return None
+        b = self._last_timed
+        self.exchange_done[b].synchronize()
+        return float(self.kernel_done[b].elapsed_time(self.exchange_done[b]))
 
     def wait(self, out):
         """Block the host until ``out`` (a result of :meth:`plan`) is complete."""
@@ -368,5 +417,5 @@ def plan_batch_sharded_device(agent, d_root_states, d_root_steps=None, max_plan_
     :func:`plan_batch_sharded`): plans the global device root list sharded over the group and returns the gathered
     device tensors after the exchange completed."""
     sp = ShardedDevicePlan(agent, int(d_root_states.shape[0]), max_plan_len=max_plan_len, force_collective=force_collective,
-                           overlap=False)
+                           overlap=False, payload="full")
     return sp.wait(sp.plan(d_root_states, d_root_steps))

@@ -1,0 +1,59 @@
+"""Environments whose finite MDP CHANGES AT EVERY STEP -- the surface of highway-v0, whose ``to_finite_mdp()`` rebuilds the
+time-to-collision table from the current traffic each time it is asked (real ``highway_env`` is absent from this image).
+Agents of the reference re-read the table at every step (dynamic_programming/value_iteration.py:29-35); a batch of such
+episodes is what ``rl_agents_amd.trainer.per_episode_evaluation`` advances with one launch per step."""
+import numpy as np
+
+from . import generators
+from .finite_mdp import FiniteMDPEnv
+from .highway_like import HighwayLikeEnv
+
+
+class ScheduledTableEnv(FiniteMDPEnv):
+    """A FiniteMDPEnv whose tables are replaced before every step from a schedule ``tables[t]`` (dicts with transition /
+    reward / terminal; the last one stays) -- what a re-extraction does to the env's MDP: new tables, same current state."""
+
+    def __init__(self, tables, state=0, max_steps=0):
+        self.tables = [dict(t) for t in tables]
+        cfg = {k: v for k, v in self.tables[0].items() if k != "original_shape"}
+        cfg.update(state=int(state), max_steps=int(max_steps))
+        super(ScheduledTableEnv, self).__init__(cfg)
+        self.reset()
+
+    def _install(self, t):
+        tab = self.tables[min(int(t), len(self.tables) - 1)]
+        self.mdp.transition = np.ascontiguousarray(tab["transition"], dtype=np.int64)
+        self.mdp.reward = np.ascontiguousarray(tab["reward"], dtype=np.float64)
+        self.mdp.terminal = np.asarray(tab["terminal"]).astype(bool)
+
+    def reset(self, **kw):
+        out = super(ScheduledTableEnv, self).reset(**kw)
+        self._install(0)
+        return out
+
+    def step(self, action):
+        out = super(ScheduledTableEnv, self).step(action)
+        self._install(self.steps)
+        return out
+
+
+class ChangingHighwayEnv(HighwayLikeEnv):
+    """A :class:`HighwayLikeEnv` (restricted action sets listed IDLE first, restriction on the env object) whose table is
+    re-drawn after every step: ``highway_shaped(V, L, T, seed = table_seed + steps)``."""
+
+    def __init__(self, n_speeds=3, n_lanes=4, n_times=10, table_seed=0, state=0, collision_rate=0.05):
+        self.grid, self.table_seed, self.collision_rate = (n_speeds, n_lanes, n_times), int(table_seed), float(collision_rate)
+        super(ChangingHighwayEnv, self).__init__(n_speeds, n_lanes, n_times, state=state, table=self._table(0))
+
+    def _table(self, t):
+        return generators.highway_shaped(*self.grid, collision_rate=self.collision_rate, seed=self.table_seed + int(t))
+
+    def reset(self, **kw):
+        out = super(ChangingHighwayEnv, self).reset(**kw)
+        self.table = self._table(0)
+        return out
+
+    def step(self, action):
+        out = super(ChangingHighwayEnv, self).step(action)
+        self.table = self._table(self.steps)
+        return out

@@ -943,6 +943,12 @@ class Model(object):
         self._keep = None
         self.n_models, self.S_each = 1, s       # batch models (Context.load_table_batch): N MDPs of S_each states
 
+    def set_available(self, available):
+        """Restrict the action sets (mp_model_set_available): bool [S, A] over this model's (global) states."""
+        av = np.ascontiguousarray(np.asarray(available).reshape(self.S, self.A).astype(np.uint8))
+        _check(self.ctx._lib.mp_model_set_available(self._h, _ptr(av)))
+        self.available = av.astype(bool)
+
     def update_tables(self, first, transition, reward, terminal=None):
         """Replace the tables of MDPs [first, first + count) of a batch model -- or the whole of a single table model with
         first = 0 -- (mp_model_update_tables): transition int [count,S,A] LOCAL states, reward [count,S,A], terminal

@@ -77,6 +77,37 @@ def _plan_all(force_collective=False):
     return res
 
 
+def _plan_sequence(force_collective=False):
+    """ShardedDevicePlan with the exchange on its side stream (overlap=True), THREE consecutive plan() calls on changing
+    roots, consumed one call late (call k is read after call k + 1 was enqueued: the double-buffered path), in both
+    payloads.  -> {payload/agent: [per call {plans, plan_len, value, env_steps, status}]}"""
+    import torch
+    from rl_agents_amd.distributed import ShardedDevicePlan
+    _, cfg = _agents()
+    non_term = np.flatnonzero(~np.asarray(cfg["terminal"]))
+    g = np.random.Generator(np.random.PCG64(11))
+    roots = [torch.from_numpy(g.choice(non_term, size=N_ROOTS).astype(np.int32)).cuda() for _ in range(3)]
+    res = {}
+    for payload in ("compact", "full"):
+        agents, _ = _agents()
+        for name, agent in agents[:2]:
+            sp = ShardedDevicePlan(agent, N_ROOTS, max_plan_len=6, force_collective=force_collective, overlap=True,
+                                   payload=payload, time_exchange=True)
+            calls, pending = [], None
+            for k in range(3):
+                out = sp.plan(roots[k])
+                if pending is not None:
+                    sp.wait(pending)
+                    calls.append({key: pending[key].cpu().numpy().copy() for key in ("plans", "plan_len", "value", "env_steps", "status")})
+                pending = out
+            sp.wait(pending)
+            calls.append({key: pending[key].cpu().numpy().copy() for key in ("plans", "plan_len", "value", "env_steps", "status")})
+            ms = sp.last_exchange_ms()
+            assert ms is None or ms >= 0.0
+            res["{}/{}".format(payload, name)] = calls
+    return res
+
+
 def _vi_problem(robust):
     from rl_agents_amd.envs import generators
     s = 301                                         # 151 + 150 rows
@@ -133,7 +164,8 @@ def _worker(rank, world, port, backend, queue):
     try:
         force = world == 1
         res = dict(plans=_plan_all(force_collective=force), vi=_vi_sharded(False, force), rvi=_vi_sharded(True, force),
-                   evaluation=_evaluate(sharded=True), backend=dist.get_backend(), world=dist.get_world_size())
+                   evaluation=_evaluate(sharded=True), sequence=_plan_sequence(force_collective=force),
+                   backend=dist.get_backend(), world=dist.get_world_size())
         from rl_agents_amd import native
         res["lib"] = native.lib_path()
         if rank == 0:
@@ -160,7 +192,8 @@ def _run_group(world, backend):
 @pytest.fixture(scope="module")
 def single():
     """World size 1, no process group: the reference result of every comparison below."""
-    return dict(plans=_plan_all(), vi=_vi_sharded(False), rvi=_vi_sharded(True), evaluation=_evaluate(sharded=False))
+    return dict(plans=_plan_all(), vi=_vi_sharded(False), rvi=_vi_sharded(True), evaluation=_evaluate(sharded=False),
+                sequence=_plan_sequence())
 
 
 def _assert_same(res, single):
@@ -179,6 +212,22 @@ def _assert_same(res, single):
             np.testing.assert_array_equal(d["env_steps"], h["env_steps"], err_msg=name + "_device/env_steps")
             np.testing.assert_array_equal(d["value"], h[vkey], err_msg=name + "_device/value")
             assert not d["status"].any()
+    # three consecutive plans through the side-stream, double-buffered exchange (it had no multi-call test)
+    for key, calls in res["sequence"].items():
+        ref_calls = single["sequence"][key]
+        assert len(calls) == len(ref_calls) == 3
+        compact = key.startswith("compact")
+        for k, (a, b) in enumerate(zip(calls, ref_calls)):
+            tag = "sequence/{}/call{}".format(key, k)
+            assert a["plans"].shape[0] == N_ROOTS
+            width = a["plans"].shape[1]
+            assert width == (1 if compact else 6)
+            np.testing.assert_array_equal(a["plans"], b["plans"][:, :width], err_msg=tag)
+            np.testing.assert_array_equal(a["value"], b["value"], err_msg=tag)
+            np.testing.assert_array_equal(a["env_steps"], b["env_steps"], err_msg=tag)
+            np.testing.assert_array_equal(a["status"], b["status"], err_msg=tag)
+            np.testing.assert_array_equal(a["plan_len"], np.minimum(b["plan_len"], width) if compact else b["plan_len"], err_msg=tag)
+        assert not np.array_equal(calls[0]["value"], calls[1]["value"])      # (the calls do differ: different roots)
     for k in ("returns", "discounted_returns", "lengths", "actions"):     # sharded device-resident evaluation
         np.testing.assert_array_equal(res["evaluation"][k], single["evaluation"][k], err_msg="evaluation/" + k)
     assert res["evaluation"]["planner_env_steps"] == single["evaluation"]["planner_env_steps"]

@@ -323,8 +323,10 @@ def test_update_rows_batch_model(ctx):
 def test_batch_model_argument_errors(ctx):
     from rl_agents_amd import native
     tr, rw, tm = _tables(3)
+    bad = tr.copy()
+    bad[1, 5, 2] = tr.shape[1]
     with pytest.raises(native.NativeError):
-        ctx.load_table_batch(np.where(tr == 0, tr.shape[1], tr), rw, tm)       # a LOCAL index out of range
+        ctx.load_table_batch(bad, rw, tm)                                        # a LOCAL index out of range
     model = ctx.load_table_batch(tr, rw, tm)
     assert (model.n_models, model.S_each, model.S) == (3, tr.shape[1], 3 * tr.shape[1])
     with pytest.raises(native.NativeError):
