@@ -487,7 +487,8 @@ class MCTS(AbstractPlanner):
 
     def device_policy(self, model, prior, rollout, listed=None, slots=None):
         """Upload (once per model and table contents) the per-state policy tables."""
-        key = (id(model), id(prior), id(rollout))
+        # (model.epoch: a delta upload patched the model's tables -- the fused policy records hold the old transitions)
+        key = (id(model), id(prior), id(rollout), getattr(model, "epoch", 0))
         hit = self._policies.get(key)
         if hit is None or hit[0] is not model or hit[1] is not prior or hit[2] is not rollout:
             if len(self._policies) >= 4:

@@ -1557,8 +1557,10 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wgr(ViBatchArgs p, const ui
     auto tload = [&](int a, int s) -> int { return (int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(tres, s * 2, a * S * 2, 0); };
     double *Vb = lds_v;                                  // [2][S]: V_k in buffer k & 1
     double *Vg = p.Vglobal + (long)b * 3 * S;            // [3][S]: V_k in slot k % 3
+    __shared__ int vote[3];
     for (int i = tid; i < 2 * S; i += NT) Vb[i] = 0.0;
     for (int i = tid; i < 3 * S; i += NT) Vg[i] = 0.0;
+    if (tid < 3) vote[tid] = 0;
     __syncthreads();
     int j = p.iterations, sweeps = p.iterations;
     for (int k = 0; k < p.iterations; ++k) {
@@ -1567,52 +1569,52 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wgr(ViBatchArgs p, const ui
         const double *Vprev = Vg + (long)((k + 2) % 3) * S;
         double *Vnext_g = Vg + (long)((k + 1) % 3) * S;
         bool nc = false;
-        // rows requested THREE states ahead (three register stages, rotated by a 3x unrolled loop): with one MDP per CU the
-        // tables of a batch (32 MB at 64 x S = 10 000) stream from the infinity cache, ~0.6 us away -- one state of work per wave
-        // (x 4 waves per SIMD) does not cover that
-        int t0[AT], t1[AT], t2[AT];
-        double r0[AT], r1[AT], r2[AT];
-        auto request = [&](int (&tt)[AT], double (&rr)[AT], int s) {
+        // rows requested ONE state ahead (two register stages): the only dependent chain of a state is its LDS gathers.
+        // (Three stages ahead measured SLOWER -- 1.41 against 1.25 ms for 64 MDPs x 101 sweeps: the sweep is not waiting for
+        // the tables, it is bound by issue + LDS gathers + the barrier.)
+        int tn[AT];
+        double rn[AT];
+        auto request = [&](int s) {
             const int sc = s < S ? s : (tid < S ? tid : 0);     // (beyond the last state: re-read a row that is there)
 #pragma unroll
-            for (int a = 0; a < AT; ++a) { tt[a] = tload(a, sc); rr[a] = rload(a, sc); }
+            for (int a = 0; a < AT; ++a) { tn[a] = tload(a, sc); rn[a] = rload(a, sc); }
         };
-        auto state = [&](int (&tt)[AT], const double (&rr)[AT], int s, bool first) {
-            const bool term_s = (tt[0] & 0x8000) != 0;          // (rides in the row: vi_batch_transpose)
+        request(tid);
+        for (int i = 0; i < n_own; ++i) {
+            const int s = tid + i * NT;
+            int t[AT];
+            double r[AT];
 #pragma unroll
-            for (int a = 0; a < AT; ++a) tt[a] &= 0x7fff;
+            for (int a = 0; a < AT; ++a) { t[a] = tn[a]; r[a] = rn[a]; }
+            request(s + NT);
+            const bool term_s = (t[0] & 0x8000) != 0;           // (rides in the row: vi_batch_transpose)
+#pragma unroll
+            for (int a = 0; a < AT; ++a) t[a] &= 0x7fff;
             double vc[AT], vp[AT];
 #pragma unroll
-            for (int a = 0; a < AT; ++a) vc[a] = Vcur[tt[a]];
-            if (first && k > 0) {
+            for (int a = 0; a < AT; ++a) vc[a] = Vcur[t[a]];
+            if (i == 0 && k > 0) {
 #pragma unroll
-                for (int a = 0; a < AT; ++a) vp[a] = Vprev[tt[a]];
+                for (int a = 0; a < AT; ++a) vp[a] = Vprev[t[a]];
             }
             double vmax = 0.0;
 #pragma unroll
             for (int a = 0; a < AT; ++a) {
-                const double qn = rr[a] + p.gamma * (term_s ? 0.0 : vc[a]);
-                if (first) {
-                    const double qo = k == 0 ? 0.0 : rr[a] + p.gamma * (term_s ? 0.0 : vp[a]);
+                const double qn = r[a] + p.gamma * (term_s ? 0.0 : vc[a]);
+                if (i == 0) {
+                    const double qo = k == 0 ? 0.0 : r[a] + p.gamma * (term_s ? 0.0 : vp[a]);
                     nc |= s < S && !isclose_np_sel(qo, qn, p.rtol, p.atol);
                 }
                 if (a == 0 || qn > vmax) vmax = qn;
             }
             if (s < S) { Vnext[s] = vmax; Vnext_g[s] = vmax; }
-        };
-        request(t0, r0, tid);
-        request(t1, r1, tid + NT);
-        request(t2, r2, tid + 2 * NT);
-        for (int i = 0; i < n_own; i += 3) {
-            const int s = tid + i * NT;
-            state(t0, r0, s, i == 0);
-            request(t0, r0, s + 3 * NT);
-            if (i + 1 < n_own) state(t1, r1, s + NT, false);
-            request(t1, r1, s + 4 * NT);
-            if (i + 2 < n_own) state(t2, r2, s + 2 * NT, false);
-            request(t2, r2, s + 5 * NT);
         }
-        bool moved = __syncthreads_or(nc ? 1 : 0) != 0;
+        // the vote: ONE barrier (a wave that saw movement raises the sweep's flag; three flags rotate so that the reset of a
+        // flag lies a whole sweep away from its last reader and its next writer)
+        if (__any(nc ? 1 : 0) && (tid & 63) == 0) vote[k % 3] = 1;
+        __syncthreads();
+        bool moved = vote[k % 3] != 0;
+        if (tid == 0) vote[(k + 2) % 3] = 0;
         if (!moved) { // none of the first states' pairs moved: test the others (the last few sweeps only)
             bool nc2 = false;
             for (int s = tid + NT; s < S; s += NT) {

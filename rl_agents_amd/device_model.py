@@ -13,6 +13,7 @@ Uploads are cached per context and keyed by a content hash of the tables, so age
 MDP on every ``act`` (value_iteration.py:29-35) only pay for an upload when the tables changed.
 """
 import hashlib
+import os
 
 try:                                    # optional: only the speed of the model-cache key depends on it
     from xxhash import xxh3_128 as _xxh3_128
@@ -28,7 +29,11 @@ class TableSpec(object):
     """Host-side view of a finite MDP in the reference's wire format (mode / transition / reward / terminal)."""
 
     def __init__(self, mode, transition, reward, terminal=None, next_states=None, done_rule="source", max_steps=0,
-                 available=None, action_order=None):
+                 available=None, action_order=None, version=None, dirty_rows_since=None):
+        # version: hashable identity of the table CONTENTS promised by the environment (MDP.tables_version: equal values =
+        # identical tables) -- the cache then keys the model without hashing 16 B per (s, a) on every act();
+        # dirty_rows_since(counter): the rows changed since an earlier version of the same tables, for the delta upload
+        self.version, self.dirty_rows_since = version, dirty_rows_since
         self.mode = mode
         self.reward = np.ascontiguousarray(reward, dtype=np.float64)
         if mode == "deterministic":
@@ -76,6 +81,13 @@ class TableSpec(object):
     def n_actions(self):
         return self.reward.shape[-1]
 
+    def static_key(self):
+        """What a version does not cover: shapes, the episode rules and what the ENVIRONMENT adds to the MDP's tables (the
+        availability table -- a few KB, hashed -- and the listing order)."""
+        av = None if self.available is None else hashlib.blake2b(self.available.view(np.uint8).reshape(-1), digest_size=8).hexdigest()
+        return (self.mode, self.transition.shape, self.done_rule, self.max_steps, av,
+                None if self.action_order is None else tuple(int(a) for a in self.action_order))
+
     def key(self):
         # a 128-bit content digest: a collision would silently serve a stale model.  The key is recomputed on every
         # act() (the tables may have been edited in place), so its speed is most of a single-root act(): XXH3-128
@@ -101,10 +113,14 @@ def finite_mdp_of(env):
 
 
 def spec_from_mdp(mdp, max_steps=0, available=None, action_order=None):
+    version = getattr(mdp, "tables_version", None)
+    if version is not None and (not isinstance(version, tuple) or version[0] is None):
+        version = None
     return TableSpec(mdp.mode, mdp.transition, mdp.reward, getattr(mdp, "terminal", None),
                      next_states=getattr(mdp, "next", None) if mdp.mode == "sparse" else None,
                      done_rule=getattr(mdp, "done_rule", "source"), max_steps=max_steps, available=available,
-                     action_order=action_order)
+                     action_order=action_order, version=version,
+                     dirty_rows_since=getattr(mdp, "dirty_rows_since", None) if version is not None else None)
 
 
 def grid_available(original_shape):
@@ -208,7 +224,9 @@ class ModelCache(object):
         self.capacity = capacity
         self._models = {}
         self._order = []
+        self._by_token = {}         # (tables token, static key) -> (version counter, cache key) of the model that holds them
         self.uploads = 0
+        self.row_updates = 0        # rows patched by delta uploads
 
     @property
     def ctx(self):
@@ -217,7 +235,43 @@ class ModelCache(object):
         return self._ctx
 
     def get(self, spec):
-        key = spec.key()
+        if spec.version is not None and not os.environ.get("MP_NO_TABLE_VERSIONS"):
+            return self._get_versioned(spec)
+        return self._get_keyed(spec.key(), spec)
+
+    def _get_versioned(self, spec):
+        """The environment vouches for its tables' identity (MDP.tables_version): no hashing.  A newer version of tables this
+        cache already holds, with a known set of changed rows, PATCHES the device model (mp_model_update_rows: the delta
+        upload of SURVEY.md 8 f-2) instead of uploading a new one."""
+        token, counter = spec.version
+        static = spec.static_key()
+        key = ("version", token, counter, static)
+        if key in self._models:
+            return self._get_keyed(key, spec)
+        held = self._by_token.get((token, static))
+        if held is not None and held[1] in self._models and spec.mode == "deterministic" and spec.dirty_rows_since is not None \
+                and spec.transition.ndim == 2 and not os.environ.get("MP_NO_DELTA_UPLOAD"):
+            rows = spec.dirty_rows_since(held[0])
+            if rows is not None and len(rows) * 4 <= spec.n_states:
+                model = self._models.pop(held[1])
+                self._order.remove(held[1])
+                if len(rows):
+                    model.update_rows(rows, spec.transition[rows], spec.reward[rows], spec.terminal[rows])
+                    self.row_updates += int(len(rows))
+                    model._vi_cache = None              # (solutions / policies derived from the old tables)
+                    model.epoch = getattr(model, "epoch", 0) + 1
+                model.spec = spec
+                self._models[key] = model
+                self._order.append(key)
+                self._by_token[(token, static)] = (counter, key)
+                return model
+        model = self._get_keyed(key, spec)
+        self._by_token[(token, static)] = (counter, key)
+        if len(self._by_token) > 4 * self.capacity:
+            self._by_token = {k: v for k, v in self._by_token.items() if v[1] in self._models}
+        return model
+
+    def _get_keyed(self, key, spec):
         model = self._models.get(key)
         if model is None:
             model = self._upload(spec)

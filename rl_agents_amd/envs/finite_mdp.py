@@ -36,8 +36,97 @@ class Discrete(object):
         return "Discrete({})".format(self.n)
 
 
+_TABLE_TOKENS = iter(range(1, 1 << 62))       # process-wide identities of table sets (MDP.tables_version)
+_TABLE_FIELDS = ("transition", "reward", "terminal", "next", "available")
+
+
 class MDP(object):
+    """``tables_version`` protocol (read by rl_agents_amd.device_model: SURVEY.md 8 f-2 -- an agent that re-converts its
+    environment on every ``act``, value_iteration.py:29-35, should neither re-hash nor re-upload tables that did not change):
+    ``mdp.tables_version`` is a hashable ``(token, counter)``; EQUAL VALUES PROMISE IDENTICAL TABLES.  The counter advances
+    whenever a table attribute is assigned (``mdp.reward = new_array``) or rows are edited through :meth:`edit_rows`, which also
+    remembers WHICH rows changed so that the device model is patched (mp_model_update_rows) instead of re-uploaded.  The arrays
+    an MDP holds are read-only views: an element assignment through the MDP (``mdp.reward[s, a] = x``) raises instead of silently
+    leaving a stale device model -- use ``edit_rows`` or assign a new array.  An environment that edits, behind the MDP's back,
+    an array it kept its own reference to must call :meth:`touch`.  Objects without ``tables_version`` (any third-party MDP) are
+    keyed by a content hash of their tables, as before."""
     mode = None
+
+    def __setattr__(self, name, value):
+        if name in _TABLE_FIELDS:
+            d = self.__dict__
+            d["_tables_counter"] = d.get("_tables_counter", 0) + 1
+            d.setdefault("_tables_token", next(_TABLE_TOKENS))
+            d["_dirty_log"] = {}                       # a table was replaced: nothing is known about single rows
+            d["_dirty_base"] = d["_tables_counter"]
+            if isinstance(value, np.ndarray):
+                value = value.view()
+                value.setflags(write=False)
+        object.__setattr__(self, name, value)
+
+    @property
+    def tables_version(self):
+        return (self.__dict__.get("_tables_token"), self.__dict__.get("_tables_counter", 0))
+
+    def touch(self):
+        """The tables were changed behind the MDP's back (through another reference to an array): a new version, every row
+        suspect."""
+        d = self.__dict__
+        d["_tables_counter"] = d.get("_tables_counter", 0) + 1
+        d["_dirty_log"], d["_dirty_base"] = {}, d["_tables_counter"]
+
+    def edit_rows(self, rows, transition=None, reward=None, terminal=None, next_states=None):
+        """Replace the rows ``rows`` (state indices) of the given tables in place and remember them as the delta of this
+        version (the device model is then patched row by row: mp_model_update_rows)."""
+        rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        for name, new in (("transition", transition), ("reward", reward), ("terminal", terminal), ("next", next_states)):
+            if new is None:
+                continue
+            arr = self.__dict__[name]
+            base = arr.base if arr.base is not None and not arr.flags.writeable else arr
+            if not base.flags.writeable:
+                base = np.array(arr)                   # (the caller handed a read-only array over: own a copy)
+            base[rows] = new
+            view = base.view()
+            view.setflags(write=False)
+            self.__dict__[name] = view
+        d = self.__dict__
+        d["_tables_counter"] = d.get("_tables_counter", 0) + 1
+        d.setdefault("_dirty_log", {})[d["_tables_counter"]] = rows.copy()
+
+    def dirty_rows_since(self, counter):
+        """Rows edited since version ``counter`` of THIS object's tables (sorted, unique), or None when that is not known
+        (a whole table was assigned since, or the version is older than the log)."""
+        d = self.__dict__
+        if counter < d.get("_dirty_base", 0) or counter > d.get("_tables_counter", 0):
+            return None
+        log = d.get("_dirty_log", {})
+        parts = []
+        for c in range(counter + 1, d.get("_tables_counter", 0) + 1):
+            if c not in log:
+                return None
+            parts.append(log[c])
+        if len(log) > 64:                               # keep the log short: forget what nobody can ask for cheaply any more
+            for c in sorted(log)[:-32]:
+                del log[c]
+            d["_dirty_base"] = min(log) - 1
+        return np.unique(np.concatenate(parts)) if parts else np.zeros(0, dtype=np.int64)
+
+    def __deepcopy__(self, memo):
+        # a copy's tables may be edited independently of the original's: it gets its own identity (and writable arrays of
+        # its own behind the read-only views)
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            if k in _TABLE_FIELDS and isinstance(v, np.ndarray):
+                v = np.array(v)
+                v.setflags(write=False)
+                new.__dict__[k] = v
+            elif k not in ("_tables_token", "_tables_counter", "_dirty_log", "_dirty_base"):
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        new.__dict__["_tables_token"], new.__dict__["_tables_counter"] = next(_TABLE_TOKENS), 0
+        new.__dict__["_dirty_log"], new.__dict__["_dirty_base"] = {}, 0
+        return new
 
     def __init__(self, transition, reward, terminal=None, state=0, done_rule="source"):
         self.transition = transition

@@ -77,6 +77,14 @@ class HighwayLikeEnv(object):
         mdp = DeterministicMDP(self.table["transition"], self.table["reward"], terminal=self.table["terminal"],
                                state=self.state_index)
         mdp.original_shape = self.shape        # no `available`: highway-env's conversion has none
+        # every call returns a NEW object over the SAME table: give it the table's version (MDP.tables_version protocol), so
+        # that an agent re-converting at every step (value_iteration.py:29-35) neither re-hashes nor re-uploads it
+        token = self.table.get("_version_token")
+        if token is None:
+            from .finite_mdp import _TABLE_TOKENS
+            token = self.table["_version_token"] = next(_TABLE_TOKENS)
+        mdp.__dict__["_tables_token"], mdp.__dict__["_tables_counter"] = token, 0
+        mdp.__dict__["_dirty_log"], mdp.__dict__["_dirty_base"] = {}, 0
         return mdp
 
     def render(self, *a, **k):

@@ -340,3 +340,47 @@ def test_batch_model_argument_errors(ctx):
     with pytest.raises(native.NativeError):
         ctx.opd_plan(model, [0, tr.shape[1]], 50, 0.8, 0.0, rng, model_index=[0, 1])
     model.close()
+
+
+def test_agent_delta_upload_through_versioned_tables():
+    """SURVEY 8 f-2 at agent level: an MCTSAgent / ValueIterationAgent on a FiniteMDPEnv whose MDP is edited row by row
+    between two act() calls -- the cached device model is PATCHED (no new upload, no hashing: MDP.tables_version) and the
+    next plan equals a fresh agent's on the edited tables (= the oracle's)."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.agents.dynamic_programming.value_iteration import ValueIterationAgent
+    from rl_agents_amd.agents.tree_search.mcts import MCTSAgent
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    cfg = {k: v for k, v in generators.highway_shaped(10, 10, 100, seed=2).items() if k != "original_shape"}
+    cfg["state"] = 40
+    env = FiniteMDPEnv(cfg)
+    env.reset()
+    agent = MCTSAgent(env, dict(budget=400, gamma=0.8))
+    agent.seed(5)
+    agent.act(40)
+    cache = agent.planner.models
+    assert cache.uploads == 1
+    g = np.random.Generator(np.random.PCG64(0))
+    t, r, term = np.array(env.mdp.transition), np.array(env.mdp.reward), np.array(env.mdp.terminal)
+    rows = g.choice(t.shape[0], size=50, replace=False)
+    t[rows] = g.integers(0, t.shape[0], size=(50, 5))
+    r[rows] = g.random((50, 5))
+    term[rows] = g.random(50) < 0.2
+    env.mdp.edit_rows(rows, transition=t[rows], reward=r[rows], terminal=term[rows])
+    rng_before = native.rng_state_from_generator(agent.planner.np_random)
+    plan = agent.plan(40)
+    assert cache.uploads == 1 and cache.row_updates == 50
+    c = agent.planner.config
+    p = np.ones(5) / 5
+    ref = oracle.uct_plan(t, r, term, 40, c["episodes"], c["horizon"], c["gamma"], c["temperature"], p, p, rng_before,
+                          max_plan_len=c["horizon"])
+    np.testing.assert_array_equal(plan, ref["plan"])
+    # value iteration: same protocol, Q of the edited tables
+    vi = ValueIterationAgent(env, dict(gamma=0.95, iterations=60))
+    up0 = vi.models.uploads
+    rows2 = g.choice(t.shape[0], size=10, replace=False)
+    r[rows2] = g.random((10, 5))
+    env.mdp.edit_rows(rows2, reward=r[rows2])
+    q = vi.get_state_action_value()
+    q_ref, _ = oracle.vi_solve("deterministic", t, r, term, gamma=0.95, iterations=60)
+    assert vi.models.uploads == up0 and vi.models.row_updates == 10 and np.array_equal(q, q_ref)

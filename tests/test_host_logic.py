@@ -424,3 +424,72 @@ def test_listing_order_permutes_every_model_kind():
         assert device_model.spec_from_mdp(env.mdp, available=table).key() != spec.key()
     with pytest.raises(ValueError):
         OrderedMaskedFiniteMDPEnv(dict(generators.random_sparse(5, 3, 2, seed=1), listing_order=[0, 0, 1]))
+
+
+def test_mdp_tables_version_protocol():
+    """MDP.tables_version (rl_agents_amd/envs/finite_mdp.py): equal versions promise identical tables -- assigning a table
+    or editing rows advances it, element assignment through the MDP raises, edit_rows remembers the rows, copies get their
+    own identity, and a HighwayLikeEnv's re-conversion returns the same version while its table stays what it was."""
+    import copy
+    from rl_agents_amd.envs import ChangingHighwayEnv, FiniteMDPEnv, HighwayLikeEnv, generators
+    cfg = {k: v for k, v in generators.highway_shaped(3, 4, 10, seed=1).items() if k != "original_shape"}
+    env = FiniteMDPEnv(cfg)
+    m = env.mdp
+    v0 = m.tables_version
+    assert m.tables_version == v0 and m.dirty_rows_since(v0[1]).size == 0
+    with pytest.raises(ValueError):
+        m.reward[0, 0] = 0.25                         # read-only view: no silent stale device model
+    m.edit_rows([5, 3], reward=np.full((2, 5), 0.5), terminal=[True, False])
+    v1 = m.tables_version
+    assert v1[0] == v0[0] and v1[1] == v0[1] + 1
+    np.testing.assert_array_equal(m.dirty_rows_since(v0[1]), [3, 5])
+    assert m.reward[5, 0] == 0.5 and bool(m.terminal[5]) and not bool(m.terminal[3])
+    m.edit_rows([7], transition=np.zeros((1, 5), np.int64))
+    np.testing.assert_array_equal(m.dirty_rows_since(v0[1]), [3, 5, 7])
+    np.testing.assert_array_equal(m.dirty_rows_since(v1[1]), [7])
+    m.reward = np.array(m.reward)                     # a whole table assigned: rows unknown
+    assert m.tables_version[1] == v1[1] + 2 and m.dirty_rows_since(v1[1]) is None
+    twin = copy.deepcopy(env)
+    assert twin.mdp.tables_version[0] != m.tables_version[0]
+    np.testing.assert_array_equal(twin.mdp.reward, m.reward)
+    twin.mdp.edit_rows([0], reward=np.ones((1, 5)))
+    assert m.reward[0, 0] != 1.0                      # the copy's arrays are its own
+    h = HighwayLikeEnv()
+    assert h.to_finite_mdp().tables_version == h.to_finite_mdp().tables_version
+    c = ChangingHighwayEnv(table_seed=3)
+    before = c.to_finite_mdp().tables_version
+    c.step(1)
+    assert c.to_finite_mdp().tables_version != before
+
+
+def test_model_cache_keys_by_version_without_hashing(monkeypatch):
+    """device_model.ModelCache with a versioned spec: no content hash is computed (TableSpec.key is never called), a changed
+    version with known dirty rows patches the held model (update_rows), an unknown change uploads."""
+    from rl_agents_amd import device_model
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+
+    class FakeModel(object):
+        def __init__(self):
+            self.rows = []
+
+        def update_rows(self, rows, t, r, term):
+            self.rows.append(np.asarray(rows).copy())
+
+        def close(self):
+            pass
+
+    cache = device_model.ModelCache(ctx=object())
+    monkeypatch.setattr(cache, "_upload", lambda spec: FakeModel())
+    monkeypatch.setattr(device_model.TableSpec, "key", lambda self: (_ for _ in ()).throw(AssertionError("hashed")))
+    cfg = {k: v for k, v in generators.highway_shaped(3, 4, 10, seed=1).items() if k != "original_shape"}
+    env = FiniteMDPEnv(cfg)
+    m1 = cache.get(device_model.spec_from_mdp(env.mdp))
+    assert cache.get(device_model.spec_from_mdp(env.mdp)) is m1 and cache.uploads == 1
+    env.mdp.edit_rows([4, 9], reward=np.zeros((2, 5)))
+    m2 = cache.get(device_model.spec_from_mdp(env.mdp))
+    assert m2 is m1 and cache.uploads == 1 and cache.row_updates == 2
+    np.testing.assert_array_equal(m1.rows[0], [4, 9])
+    assert cache.get(device_model.spec_from_mdp(env.mdp)) is m1 and len(m1.rows) == 1
+    env.mdp.reward = np.array(env.mdp.reward)        # unknown change: a new upload
+    m3 = cache.get(device_model.spec_from_mdp(env.mdp))
+    assert m3 is not m1 and cache.uploads == 2

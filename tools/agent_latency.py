@@ -47,6 +47,23 @@ def main():
                 obs = obs[0] if isinstance(obs, tuple) else obs
         print("{:42s} act(): first {:8.2f} ms, then median {:7.2f} ms (min {:.2f})".format(
             name, times[0], float(np.median(times[1:])), min(times[1:])), flush=True)
+    # the same MCTSAgent with the tables keyed by CONTENT HASH (MP_NO_TABLE_VERSIONS=1: what an environment without
+    # MDP.tables_version gets) -- the round-4 path
+    import os
+    os.environ["MP_NO_TABLE_VERSIONS"] = "1"
+    name, cfg, agent_cfg = CASES[0]
+    env = FiniteMDPEnv(dict(mode="deterministic", transition=cfg["transition"], reward=cfg["reward"], terminal=cfg["terminal"]))
+    obs = env.reset()[0]
+    agent = agent_factory(env, agent_cfg)
+    agent.seed(0)
+    times = []
+    for step in range(12):
+        t0 = time.perf_counter()
+        action = agent.act(obs)
+        times.append(1e3 * (time.perf_counter() - t0))
+        obs = env.step(action)[0]
+    print("{:42s} act(): first {:8.2f} ms, then median {:7.2f} ms (min {:.2f})".format(
+        name + " [content hash]", times[0], float(np.median(times[1:])), min(times[1:])), flush=True)
 
 
 if __name__ == "__main__":
