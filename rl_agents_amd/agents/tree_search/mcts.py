@@ -159,7 +159,21 @@ class MCTS(AbstractPlanner):
         if not hasattr(self, "_visit_log"):
             self._visit_log, self._visit_done, self._visit_counts = [], 0, {}
             self._visit_gap = None
+            self._visit_roots = {}          # batch slot -> {state: count}: what N sequential planners would each answer
+            self._visit_bytes = 0
         return self._visit_log
+
+    def _device_clone(self, x):
+        """A copy of a device tensor made on the planner's stream (where the loop that owns the tensor writes it)."""
+        import torch
+        with torch.cuda.stream(torch.cuda.ExternalStream(self.models.ctx.stream_ptr(), device=x.device)):
+            return x.detach().clone()
+
+    def reset_visits(self):
+        """Forget the visit log, the counts and any gap (get_visits then counts the plans made from here on).  The
+        reference's ``planner.observations`` is never cleared (abstract.py:114,160), so nothing calls this implicitly."""
+        self._visit_log, self._visit_done, self._visit_counts = [], 0, {}
+        self._visit_gap, self._visit_roots, self._visit_bytes = None, {}, 0
 
     def _log_plan(self, model, root_states, root_steps, rng_states, env_rng_states, policy, continued):
         """Called right BEFORE a plan: everything a replay needs (``policy``: ("tables", prior, rollout, listed, slots)
@@ -170,67 +184,123 @@ class MCTS(AbstractPlanner):
             self._visit_gap = "more than 20 000 plans since get_visits was last asked: the log was dropped"
         if self._visit_gap:
             return
-        if len(root_states) != 1:
-            self._visit_gap = "a batched plan ({} roots) is not replayed".format(len(root_states))
-            return
+        n = len(root_states)
         if getattr(model, "spec", None) is None:
             self._visit_gap = "observations of this environment are not states of a finite MDP"
             return
+        # a batched plan is logged like a single-root one -- 60 bytes per root (root, step count, generator records) -- up to
+        # 512 MB of log since get_visits was last asked
+        self._visit_bytes += 64 * n
+        if self._visit_bytes > (512 << 20):
+            del events[:]
+            self._visit_gap = "more than 512 MB of batched plans since get_visits was last asked: the log was dropped"
+            return
         rules = getattr(model, "episode_rules", None)    # stochastic / sparse models: set after the upload (model_for)
         cfg = self.config
+
+        def host(x, dtype, shape):
+            if x is None:
+                return None
+            if hasattr(x, "detach"):                     # a device tensor (device-resident loops with record_visits): a device-side
+                import torch                             # copy now, ON THE PLANNER'S STREAM (the loop's env step writes these
+                ctx = self.models.ctx                    # buffers there); brought to the host when replayed
+                with torch.cuda.stream(torch.cuda.ExternalStream(ctx.stream_ptr(), device=x.device)):
+                    return x.detach().clone()
+            return np.array(x, dtype=dtype).reshape(shape).copy()
         events.append(("plan", dict(
-            spec=model.spec, rules=rules, s0=np.array(root_states, dtype=np.int32).reshape(1),
-            steps0=None if root_steps is None else np.array(root_steps, dtype=np.int32).reshape(1),
-            rng=np.array(rng_states, dtype=np.uint64).reshape(1, 6).copy(),
-            erng=None if env_rng_states is None else np.array(env_rng_states, dtype=np.uint64).reshape(1, 6).copy(),
+            spec=model.spec, rules=rules, n=n, s0=host(root_states, np.int32, n), steps0=host(root_steps, np.int32, n),
+            rng=host(rng_states, np.uint64, (n, 6)), erng=host(env_rng_states, np.uint64, (n, 6)),
             episodes=cfg["episodes"], horizon=cfg["horizon"], gamma=cfg["gamma"], temperature=cfg["temperature"],
             closed=bool(cfg["closed_loop"]), policy=policy, continued=bool(continued))))
 
     def get_visits(self):
         """How often the planner's env steps -- descents and rollouts of every plan so far -- observed each state
-        (``str(observation)`` -> count), as the reference's ever-growing ``planner.observations`` gives it."""
+        (``str(observation)`` -> count), as the reference's ever-growing ``planner.observations`` gives it.  Batched plans
+        count for every root of the batch (the sum of what N sequential planners would answer: :meth:`get_visits_per_root`
+        has them one by one)."""
         from collections import defaultdict
-        from rl_agents_amd import native
-        events = self._visit_events()
-        if self._visit_gap:
-            raise NotImplementedError("get_visits: " + self._visit_gap)
-        if self._visit_done < len(events):
-            if not hasattr(self, "_replay_models"):
-                self._replay_models = device_model.ModelCache(ctx=native.Context(self.models.ctx.device))
-                self._replay_policies = {}
-            cache, ctx = self._replay_models, self._replay_models.ctx
-            for kind, e in events[self._visit_done:]:
-                if kind == "step":
-                    ctx.uct_step_tree(e)
-                    continue
-                model = cache.get(e["spec"])
-                if e["rules"] is not None:
-                    model.set_episode_rules(*e["rules"])
-                if not e["continued"]:
-                    ctx.uct_reset_tree()
-                policy, pp, rp = None, None, None
-                if e["policy"][0] == "tables":
-                    _, prior, rollout, listed, slots = e["policy"]
-                    key = (id(model), id(prior), id(rollout))
-                    hit = self._replay_policies.get(key)
-                    if hit is None:
-                        hit = (prior, rollout, ctx.load_policy(model, prior, rollout, listed=listed, rollout_slots=slots))
-                        self._replay_policies = {key: hit}         # (one at a time: a policy is tied to its model)
-                    policy = hit[2]
-                else:
-                    _, pp, rp = e["policy"]
-                visits = np.zeros((1, model.S), dtype=np.int32)
-                ctx.uct_plan_stochastic(model, e["s0"], e["episodes"], e["horizon"], e["gamma"], e["temperature"], pp, rp,
-                                        e["rng"].copy(), env_rng_state=e["erng"], closed_loop=e["closed"], root_steps=e["steps0"],
-                                        policy=policy, visits=visits)
-                for s in np.flatnonzero(visits[0]):
-                    self._visit_counts[int(s)] = self._visit_counts.get(int(s), 0) + int(visits[0, s])
-            del events[:]                                  # replayed: only the counts are kept
-            self._visit_done = 0
+        self._replay_visits()
         out = defaultdict(int)
         for s, c in self._visit_counts.items():
             out[str(s)] = c
         return out
+
+    def get_visits_per_root(self):
+        """Batched plans: ``get_visits()`` of each batch slot -- what the planner of a sequential agent i would answer
+        (abstract.py:163-167 for N planner objects) -- as a list of ``{str(state): count}`` indexed by slot."""
+        from collections import defaultdict
+        self._replay_visits()
+        n = 1 + max(self._visit_roots) if self._visit_roots else 0
+        out = []
+        for i in range(n):
+            d = defaultdict(int)
+            for s, c in self._visit_roots.get(i, {}).items():
+                d[str(s)] = c
+            out.append(d)
+        return out
+
+    def _replay_visits(self):
+        from rl_agents_amd import native
+        events = self._visit_events()
+        if self._visit_gap:
+            raise NotImplementedError("get_visits: " + self._visit_gap)
+        if self._visit_done >= len(events):
+            return
+        if not hasattr(self, "_replay_models"):
+            self._replay_models = device_model.ModelCache(ctx=native.Context(self.models.ctx.device))
+            self._replay_policies = {}
+        cache, ctx = self._replay_models, self._replay_models.ctx
+
+        def to_host(x, dtype):
+            if x is None or isinstance(x, np.ndarray):
+                return x
+            arr = x.cpu().numpy()                         # (device clones of a device-resident loop)
+            return arr.view(np.uint64) if dtype == np.uint64 else arr.astype(dtype)
+        for kind, e in events[self._visit_done:]:
+            if kind == "step":
+                ctx.uct_step_tree(to_host(e, np.int32))
+                continue
+            model = cache.get(e["spec"])
+            if e["rules"] is not None:
+                model.set_episode_rules(*e["rules"])
+            if not e["continued"]:
+                ctx.uct_reset_tree()
+            policy, pp, rp = None, None, None
+            if e["policy"][0] == "tables":
+                _, prior, rollout, listed, slots = e["policy"]
+                key = (id(model), id(prior), id(rollout))
+                hit = self._replay_policies.get(key)
+                if hit is None:
+                    hit = (prior, rollout, ctx.load_policy(model, prior, rollout, listed=listed, rollout_slots=slots))
+                    self._replay_policies = {key: hit}         # (one at a time: a policy is tied to its model)
+                policy = hit[2]
+            else:
+                _, pp, rp = e["policy"]
+            n = e["n"]
+            s0, steps0 = to_host(e["s0"], np.int32), to_host(e["steps0"], np.int32)
+            rng, erng = to_host(e["rng"], np.uint64), to_host(e["erng"], np.uint64)
+            # the whole batch in one launch when its [n, S] visit matrix stays under 256 MB, else chunk by chunk (a plan that
+            # continues kept trees needs the whole batch's trees on the replay context: it is not chunked)
+            chunk = max(1, min(n, (256 << 20) // (4 * model.S)))
+            if e["continued"] and chunk < n:
+                raise NotImplementedError("get_visits: a batched plan on kept subtrees of {} roots x {} states does not fit the "
+                                          "replay buffer".format(n, model.S))
+            for lo in range(0, n, chunk):
+                hi = min(n, lo + chunk)
+                visits = np.zeros((hi - lo, model.S), dtype=np.int32)
+                ctx.uct_plan_stochastic(model, s0[lo:hi], e["episodes"], e["horizon"], e["gamma"], e["temperature"], pp, rp,
+                                        np.ascontiguousarray(rng[lo:hi]).copy(),
+                                        env_rng_state=None if erng is None else np.ascontiguousarray(erng[lo:hi]),
+                                        closed_loop=e["closed"], root_steps=None if steps0 is None else steps0[lo:hi],
+                                        policy=policy, visits=visits)
+                rows, cols = np.nonzero(visits)
+                for r_, c_ in zip(rows.tolist(), cols.tolist()):
+                    k = int(visits[r_, c_])
+                    self._visit_counts[c_] = self._visit_counts.get(c_, 0) + k
+                    per = self._visit_roots.setdefault(lo + r_, {})
+                    per[c_] = per.get(c_, 0) + k
+        del events[:]                                  # replayed: only the counts are kept
+        self._visit_done, self._visit_bytes = 0, 0
 
     def model_for(self, state):
         """Deterministic tables / CartPole as every planner; MCTS also plans on STOCHASTIC finite MDPs (`stochastic`,
@@ -332,7 +402,11 @@ class MCTS(AbstractPlanner):
             self._continued = False
             if keep_actions is not None and self.owns_device_tree() and not self.config["closed_loop"] and self._tree_roots == n:
                 # (batched callers: the executed actions, as device labels)
-                self.models.ctx.uct_step_tree(np.asarray(self.device_actions(keep_actions, model), dtype=np.int32))
+                labels = np.asarray(self.device_actions(keep_actions, model), dtype=np.int32)
+                self.models.ctx.uct_step_tree(labels)
+                if not getattr(self, "_visit_gap", None):
+                    self._visit_events().append(("step", labels.copy()))
+                self._continued = True
             elif not (armed and self.owns_device_tree()):
                 self.models.ctx.uct_reset_tree()
             else:
@@ -344,7 +418,11 @@ class MCTS(AbstractPlanner):
         armed, self._armed = self._armed and n == 1, False
         continued = False
         if keep_actions is not None and self.owns_device_tree():
-            ctx.uct_step_tree(self.device_actions(keep_actions, model))   # batched callers hand the executed actions over here
+            labels = np.asarray(self.device_actions(keep_actions, model), dtype=np.int32)
+            ctx.uct_step_tree(labels)                                     # batched callers hand the executed actions over here
+            if not getattr(self, "_visit_gap", None):
+                self._visit_events().append(("step", labels.copy()))
+            continued = True
         elif not (armed and self.owns_device_tree()):
             ctx.uct_reset_tree()
         else:
@@ -406,7 +484,10 @@ class MCTS(AbstractPlanner):
         cfg, ctx = self.config, self.models.ctx
         self.about_to_plan()
         self._visit_events()
-        self._visit_gap = "the plans of a device-resident evaluation loop are not replayed"
+        record = bool(cfg.get("record_visits"))      # opt-in: device-side copies of the roots / generator records of every step
+        if not record:
+            self._visit_gap = ("the plans of a device-resident evaluation loop are not logged (set the planner's config "
+                               "'record_visits' to log them, or call reset_visits() afterwards)")
         if model.mode != native_modes.MODE_DETERMINISTIC or self.loop_form(model):
             # stochastic / sparse models: the episodes' env generator records are a device buffer too (d_env_rng: every
             # plan's clones start from the env generator as it is at that step; mp_env_step_stochastic advances it)
@@ -415,6 +496,8 @@ class MCTS(AbstractPlanner):
             armed = keep_actions is not None and self.owns_device_tree() and self._tree_roots == n and not cfg["closed_loop"]
             if armed:
                 ctx.uct_step_tree(keep_actions)
+                if record:
+                    self._visit_events().append(("step", self._device_clone(keep_actions)))
             else:
                 ctx.uct_reset_tree()
             available = getattr(model, "available", None)
@@ -426,8 +509,13 @@ class MCTS(AbstractPlanner):
                 else:
                     prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
                 policy = self.device_policy(model, prior, rollout, listed, slots)
+                logged = ("tables", prior, rollout, listed, slots)
             else:
                 pp, rp = policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A)
+                logged = ("flat", pp, rp)
+            if record:
+                self._log_plan(model, d_state[:n], None if d_steps is None else d_steps[:n], d_rng[:n],
+                               None if d_env_rng is None else d_env_rng[:n], logged, armed)
             ctx.uct_plan_stochastic_device(model, n, d_state, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp,
                                            rp, d_rng, d_env_rng, int(d_plans.shape[1]), closed_loop=cfg["closed_loop"],
                                            plans=d_plans, plan_len=d_len, root_value=d_value, env_steps=d_env_steps,
@@ -435,8 +523,11 @@ class MCTS(AbstractPlanner):
             self.claim_device_tree()
             self.last, self._root, self._tree_roots, self._stochastic = None, None, n, True
             return
-        if keep_actions is not None and self.owns_device_tree() and self._tree_roots == n:
+        armed = keep_actions is not None and self.owns_device_tree() and self._tree_roots == n
+        if armed:
             ctx.uct_step_tree(keep_actions)
+            if record:
+                self._visit_events().append(("step", self._device_clone(keep_actions)))
         else:
             ctx.uct_reset_tree()
         available = getattr(model, "available", None)
@@ -449,9 +540,13 @@ class MCTS(AbstractPlanner):
             else:
                 prior, rollout, listed, slots = self.restricted_policy_tables(model, available)
             policy = self.device_policy(model, prior, rollout, listed, slots)
+            logged = ("tables", prior, rollout, listed, slots)
         else:
             pp = policy_probabilities(self.prior_policy, model.A)
             rp = policy_probabilities(self.rollout_policy, model.A)
+            logged = ("flat", pp, rp)
+        if record:
+            self._log_plan(model, d_state[:n], None if d_steps is None else d_steps[:n], d_rng[:n], None, logged, armed)
         ctx.uct_plan_device(model, n, d_state, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"], pp, rp, d_rng,
                             int(d_plans.shape[1]), plans=d_plans, plan_len=d_len, root_value=d_value, env_steps=d_env_steps,
                             root_steps=d_steps, policy=policy)

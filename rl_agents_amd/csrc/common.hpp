@@ -62,7 +62,7 @@ struct TreeMeta {
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,
        WS_IO5, WS_IO6, WS_IO7, WS_IO8, WS_IO9, WS_TAB0, WS_TAB1, WS_TAB2, WS_TAB3, WS_VI0, WS_VI1, WS_VI2, WS_VI3,
-       WS_VI4, WS_VI5, WS_GROOT, WS_COUNT };
+       WS_VI4, WS_VI5, WS_GROOT, WS_JUMP, WS_COUNT };
 
 // everything a captured chain of deterministic VI sweeps bakes into its kernel arguments
 struct ViGraphKey {
@@ -110,6 +110,7 @@ struct mp_ctx {
     // ctx's stream, so a block that is handed out again is reused in stream order.
     struct Block { void *p; size_t bytes; };
     std::vector<Block> block_cache;
+    int jump_entries = 0;             // PCG64 jump-ahead table (limbs of A^n, G_n for n < jump_entries) resident in WS_JUMP
     int32_t *visits_host = nullptr;   // mp_uct_record_visits: where the next stochastic-kernel plan writes its visit counts
     std::vector<double> stoch_priors; // stored child priors of the tree last exported by mp_uct_stoch_tree_export (per-state policies)
     size_t block_cache_bytes = 0;

@@ -47,7 +47,63 @@ struct Pcg64 {
     // accumulator (14 instructions; checked against Python integers, tests/test_host_logic.py restates it on the host).
     __device__ __forceinline__ void advance()
     {
-        const uint32_t m0 = 0x9FCCF645u, m1 = 0x4385DF64u, m2 = 0x1FC65DA4u, m3 = 0x2360ED05u;
+        mul_add<0x9FCCF645u, 0x4385DF64u, 0x1FC65DA4u, 0x2360ED05u>(inc_lo, inc_hi);
+    }
+    // JUMP AHEAD.  k steps of the generator are one affine map: state <- A^k state + inc G_k with G_k = 1 + A + ... + A^(k-1)
+    // (mod 2^128).  For k = 4 both factors are constants of the generator: A^4 = 0xF4DD417327DB7A9B_D194DFBE42D45771,
+    // G_4 = 0x610E11A14B07E063_817FA187ADEFBA1C (checked against stepping in tests/test_host_logic.py and by every rollout of
+    // the four-lanes-per-root kernel, whose generator states are compared with numpy's).
+    // inc_g4(): inc * G_4, the additive term of a 4-step jump (constant per generator: computed once per plan).
+    __device__ __forceinline__ void inc_g4(uint64_t &lo, uint64_t &hi) const
+    {
+        Pcg64 t = *this;
+        t.s_lo = inc_lo; t.s_hi = inc_hi;
+        t.mul_add<0xADEFBA1Cu, 0x817FA187u, 0x4B07E063u, 0x610E11A1u>(0, 0);
+        lo = t.s_lo; hi = t.s_hi;
+    }
+    __device__ __forceinline__ void advance4(uint64_t g4_lo, uint64_t g4_hi)
+    {
+        mul_add<0x42D45771u, 0xD194DFBEu, 0x27DB7A9Bu, 0xF4DD4173u>(g4_lo, g4_hi);
+    }
+    // state <- A^n state + inc G_n for a PER-LANE n: the limbs of A^n and G_n come from a table (VGPR multipliers)
+    __device__ __forceinline__ static uint64_t mad64v(uint32_t a, uint32_t m, uint64_t c)
+    {
+        uint64_t d, cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(cy) : "v"(a), "v"(m), "v"(c));
+        return d;
+    }
+    __device__ __forceinline__ static void mul128v(uint64_t x_lo, uint64_t x_hi, const uint32_t (&m)[4], uint64_t &r_lo, uint64_t &r_hi)
+    {
+        const uint32_t a0 = (uint32_t)x_lo, a1 = (uint32_t)(x_lo >> 32), a2 = (uint32_t)x_hi, a3 = (uint32_t)(x_hi >> 32);
+        const uint64_t A0 = mad64v(a0, m[0], 0);
+        const uint64_t B = mad64v(a0, m[1], A0 >> 32);
+        const uint64_t A1 = mad64v(a1, m[0], B);
+        const uint32_t c1 = A1 < B ? 1u : 0u;
+        const uint64_t C = mad64v(a0, m[2], (A1 >> 32) | ((uint64_t)c1 << 32));
+        const uint64_t D = mad64v(a1, m[1], C);
+        const uint64_t A2 = mad64v(a2, m[0], D);
+        uint64_t Q = mad64v(a0, m[3], 0);
+        Q = mad64v(a1, m[2], Q);
+        Q = mad64v(a2, m[1], Q);
+        Q = mad64v(a3, m[0], Q);
+        const uint32_t r3 = (uint32_t)Q + (uint32_t)(A2 >> 32);
+        r_lo = (uint64_t)(uint32_t)A0 | ((uint64_t)(uint32_t)A1 << 32);
+        r_hi = (uint64_t)(uint32_t)A2 | ((uint64_t)r3 << 32);
+    }
+    __device__ __forceinline__ void jump(const uint32_t (&an)[4], const uint32_t (&gn)[4])
+    {
+        uint64_t p_lo, p_hi, q_lo, q_hi;
+        mul128v(s_lo, s_hi, an, p_lo, p_hi);
+        mul128v(inc_lo, inc_hi, gn, q_lo, q_hi);
+        const uint64_t lo = p_lo + q_lo;
+        s_hi = p_hi + q_hi + (lo < p_lo ? 1ULL : 0ULL);
+        s_lo = lo;
+    }
+    // state <- state * (m3:m2:m1:m0) + (add_hi:add_lo)  (mod 2^128), multiplier limbs as literals / SGPRs
+    template <uint32_t M0, uint32_t M1, uint32_t M2, uint32_t M3>
+    __device__ __forceinline__ void mul_add(uint64_t add_lo, uint64_t add_hi)
+    {
+        const uint32_t m0 = M0, m1 = M1, m2 = M2, m3 = M3;
         const uint32_t a0 = (uint32_t)s_lo, a1 = (uint32_t)(s_lo >> 32), a2 = (uint32_t)s_hi, a3 = (uint32_t)(s_hi >> 32);
         const uint64_t A0 = mad64(a0, m0, 0);                        // column 0
         const uint64_t B = mad64(a0, m1, A0 >> 32);                  // column 1: a0 m1 + carry (no overflow)
@@ -65,13 +121,18 @@ struct Pcg64 {
         const uint32_t r3 = (uint32_t)Q + (uint32_t)(A2 >> 32);
         const uint64_t lo = (uint64_t)(uint32_t)A0 | ((uint64_t)(uint32_t)A1 << 32);
         uint64_t hi = (uint64_t)(uint32_t)A2 | ((uint64_t)r3 << 32);
-        const uint64_t lo2 = lo + inc_lo;
-        hi += inc_hi + (lo2 < lo ? 1ULL : 0ULL);
+        const uint64_t lo2 = lo + add_lo;
+        hi += add_hi + (lo2 < lo ? 1ULL : 0ULL);
         s_hi = hi; s_lo = lo2;
     }
     __device__ __forceinline__ uint64_t next64()
     {
         advance();
+        return output();
+    }
+    // the 64-bit output of the CURRENT state (numpy steps first, then outputs: next64 = advance + output)
+    __device__ __forceinline__ uint64_t output() const
+    {
         // XSL-RR: rotr64(hi ^ lo, hi >> 58) as two 32-bit funnel shifts (v_alignbit_b32 takes the shift modulo 32; a
         // rotation by 32 or more swaps the halves first)
         const uint32_t xl = (uint32_t)s_lo ^ (uint32_t)s_hi, xh = (uint32_t)(s_lo >> 32) ^ (uint32_t)(s_hi >> 32);

@@ -108,6 +108,7 @@ struct UctArgs {
     const uint8_t *r8;   // LDS-resident variant: index of reward[s, a] in rdict, [S*A]
     const double *rdict; //                       the model's distinct reward values, [n_rdict] (<= 256)
     int n_rdict;
+    const uint32_t *jump; // four-lanes-per-root variant: limbs of A^n and G_n, n = 0..H (PCG64 jump-ahead), [H + 1][8]
     int32_t *path_spill; // LDS-resident variant: path handles of depths the registers do not hold, [H + 1][spill_stride]
     long spill_stride;
     const int32_t *root_state, *root_steps;
@@ -179,7 +180,16 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3, E
 // PHANTOMS (count = -1): never scored, never visited, dropped by the tree export.  The listed-action masks of the state
 // reached / acted from ride in bits 8-15 / 16-23 of the fused records' flags word, so the descent always knows the mask
 // of the state it is in without another gather; len(children) in the exploration term is the mask's population count.
-template <int AT, int ENV, bool SP = false, bool MK = false, int IL = 0>
+// QD (with ENV_TABLE_LDSR; round 5): FOUR LANES PER ROOT, for batches too small to fill the chip (SURVEY 8(d)'s own sizes: 4096
+// roots, one root).  A lone wave per SIMD runs at the latency of its dependency chain, and in a rollout step that chain is
+// numpy's PCG64 (27 of the step's 52 vector instructions) + the model lookup.  With state-independent policies the ACTION
+// SEQUENCE of a rollout does not depend on the states it visits: the four lanes of a root draw the rollout's H actions four
+// at a time -- lane j holds the generator j + 1 steps ahead and jumps by four per round (state <- A^4 state + inc G_4: one
+// 128-bit multiply, as a single step) -- and the root's first lane (its OWNER: tree phases are its alone) walks the model in
+// LDS through each round's four actions while the next round's draws are computed beside it: per step one LDS lookup on the
+// state chain and no generator arithmetic.  The walk consumes n draws; the generator then jumps by exactly n (limbs of A^n,
+// G_n from a table), so the stream stays the reference's.  Same trees, plans and generator states as every other variant.
+template <int AT, int ENV, bool SP = false, bool MK = false, int IL = 0, bool QD = false>
 // Per-state-policy kernels with |A| <= 5 are held to the registers of 4 waves per SIMD (they would take 134-140 VGPRs = 3
 // waves; TA 52 %, VALU 45 %, L1 28 % busy: latency-bound -- 2.14 -> 1.91 ms at 262 144 roots with the fourth wave).
 __global__ __launch_bounds__((ENV == ENV_TABLE_LDS || ENV == ENV_TABLE_LDSR) ? 1024 : 64,
@@ -194,6 +204,7 @@ void uct_kernel(UctArgs p)
     constexpr bool LDSR = ENV == ENV_TABLE_LDSR;             // transitions AND rewards in LDS, path stack in registers
     constexpr bool LDSM = ENV == ENV_TABLE_LDS || LDSR;      // transitions in LDS (reward one step behind the state chain)
     static_assert(!LDSR || (AT > 0 && !SP), "the LDS-resident variant: |A| at compile time, state-independent policies");
+    static_assert(!QD || LDSR, "four lanes per root: the LDS-resident model");
     constexpr bool PREG = LDSR || ENV == ENV_TABLE_SPILL;    // path stack in registers + global spill, not in LDS
     constexpr bool CART = ENV == ENV_CARTPOLE;
     // RAWU: the rollout compares the generator's raw 64-bit output with thresholds shifted up by 11 bits (thr <= out >> 11
@@ -223,6 +234,9 @@ void uct_kernel(UctArgs p)
     uint16_t *t16 = LDSR ? reinterpret_cast<uint16_t *>(lds_d + ntab2 + ((p.n_rdict + 1) & ~1))
                          : reinterpret_cast<uint16_t *>(path_all + (H + 1) * nthreads);
     uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((p.S * A + 7) & ~7)); // LDSR: [S*A]
+    uint32_t *jump = reinterpret_cast<uint32_t *>(r8 + ((p.S * A + 15) & ~15)); // QD: [H + 5][8]
+    if (QD)
+        for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
     if (LDSR) {
         for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
@@ -242,13 +256,17 @@ void uct_kernel(UctArgs p)
     }
     __syncthreads();
     int32_t *path = path_all + wave * 64; // slot d of this lane: path[d * nthreads + lane]
-    const int r = (blockIdx.x * p.waves + wave) * p.lanes + lane;
-    if (lane >= p.lanes || r >= p.n_roots) return;
+    const int slot = QD ? lane >> 2 : lane;        // which root of the wave (QD: four lanes per root, the first one owns it)
+    const bool owner = QD ? (lane & 3) == 0 : true;
+    const int r = (blockIdx.x * p.waves + wave) * p.lanes + slot;
+    if (slot >= p.lanes || r >= p.n_roots) return;   // (QD: whole quads leave together)
     static_assert(IL != 2 || AT > 0, "the group-interleaved layout needs |A| at compile time");
     const TreeRef<IL, AT> tree = tree_of<IL, AT>(p.tree, r, p.cap, A);
     const Rec *__restrict__ rec = p.rec;
     Pcg64 g;
     g.load(p.rng + (long)r * 6);
+    uint64_t g4_lo = 0, g4_hi = 0;          // QD: inc * G_4, the additive term of a four-step jump of this root's generator
+    if (QD) g.inc_g4(g4_lo, g4_hi);
     const int32_t s0 = CART ? 0 : p.root_state[r];
     const int32_t st0 = p.root_steps ? p.root_steps[r] : 0;
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
@@ -352,7 +370,7 @@ void uct_kernel(UctArgs p)
         int hnode = tree.root_handle(); // where `node` lives (TreeRef handle)
         int fc = RC ? tf0 : tree[0].first_child;
         // ---- selection, mcts.py:143-149
-        while (depth < H && fc >= 0 && !terminal) {
+        while (owner && depth < H && fc >= 0 && !terminal) {
             // MCTSNode.selection_strategy (mcts.py:275-286): value + temperature*|A|*prior/(count+1);
             // Node.random_argmax (abstract.py:296-311): exact-equality argmax set, uniform draw
             // among >= 2 ties (no draw for a single maximum)
@@ -469,7 +487,7 @@ void uct_kernel(UctArgs p)
         }
         PROF_T(c1);
         // ---- expansion, mcts.py:151-154 / 237-246
-        if (fc < 0 && depth < H && (!terminal || node == 0)) {
+        if (owner && fc < 0 && depth < H && (!terminal || node == 0)) {
             UctNode n;
             n.value = 0.0; n.count = 0; n.first_child = -1;
             if (RC && node <= A) {
@@ -507,6 +525,74 @@ void uct_kernel(UctArgs p)
         // and commits it only if the rollout continues; step "b" mirrors it.  No register copies per step,
         // and a rollout that stops leaves the stream exactly where the reference's would be.  In the LDS
         // variant the reward of a step (HBM/L2, off the state chain) is added one step later, in order.
+        if constexpr (QD) {
+            // ---- rollout, four lanes per root (see the comment on QD above)
+            const bool want = owner && !terminal && depth < H;
+            if (__any(want ? 1 : 0)) {
+                auto bcastq = [](uint32_t v, int q) { // lane q of the quad, to its four lanes (quad_perm q,q,q,q)
+                    return (uint32_t)(q == 0 ? __builtin_amdgcn_mov_dpp((int)v, 0x00, 0xf, 0xf, true)
+                                             : (q == 1 ? __builtin_amdgcn_mov_dpp((int)v, 0x55, 0xf, 0xf, true)
+                                                       : (q == 2 ? __builtin_amdgcn_mov_dpp((int)v, 0xaa, 0xf, 0xf, true)
+                                                                 : __builtin_amdgcn_mov_dpp((int)v, 0xff, 0xf, 0xf, true))));
+                };
+                // the owner's generator state, to the four lanes of its quad; lane j jumps j + 1 steps ahead (draw k of the
+                // rollout is the output of the state after k + 1 steps) -- one table-driven jump, not j + 1 steps
+                Pcg64 q = g;
+                q.s_lo = (uint64_t)bcastq((uint32_t)g.s_lo, 0) | ((uint64_t)bcastq((uint32_t)(g.s_lo >> 32), 0) << 32);
+                q.s_hi = (uint64_t)bcastq((uint32_t)g.s_hi, 0) | ((uint64_t)bcastq((uint32_t)(g.s_hi >> 32), 0) << 32);
+                const uint64_t st_lo = q.s_lo, st_hi = q.s_hi;      // (the state the final jump by n starts from)
+                {
+                    const int j1 = (lane & 3) + 1;
+                    uint32_t an[4], gn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { an[i] = jump[j1 * 8 + i]; gn[i] = jump[j1 * 8 + 4 + i]; }
+                    q.jump(an, gn);
+                }
+                auto draw = [&](const Pcg64 &gen) -> uint32_t {     // searchsorted(cdf, u, 'right') on the raw 64-bit output
+                    const uint64_t u = gen.output();
+                    int act = 0;
+#pragma unroll
+                    for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0;
+                    return (uint32_t)min(act, p.thr_valid);
+                };
+                // ROUNDS of four draws (one per lane) and four steps of the owner's walk, as long as any root of the wave is
+                // still rolling; the draws of round r + 1 are computed beside the walk of round r (independent instruction
+                // streams of one basic block: the walk's LDS round trips hide under the generator's multiplies).  Every step is
+                // unconditional arithmetic with selects -- a finished root re-reads a valid record and keeps its values.
+                bool alive = want;
+                int h = depth, n = 0;
+                uint32_t act_cur = draw(q);
+                q.advance4(g4_lo, g4_hi);
+                while (__any(alive ? 1 : 0)) {
+                    const uint32_t a4[4] = {bcastq(act_cur, 0), bcastq(act_cur, 1), bcastq(act_cur, 2), bcastq(act_cur, 3)};
+                    const uint32_t act_next = draw(q);
+                    q.advance4(g4_lo, g4_hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const unsigned idx = (unsigned)(s * A) + a4[i];
+                        const uint32_t e = t16[idx];
+                        const double rew = rdict[r8[idx]];
+                        const double tnew = total + gpow[h] * rew;
+                        const bool next_term = (e & 0x8000u) != 0;
+                        const bool term_h = p.done_on_next ? next_term : cur_term;
+                        total = alive ? tnew : total;
+                        cur_term = alive ? next_term : cur_term;
+                        s = alive ? (int32_t)(e & 0x7fffu) : s;
+                        const int inc1 = alive ? 1 : 0;
+                        st += inc1; steps_taken += inc1; h += inc1; n += inc1;
+                        alive = alive && !(term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H);
+                    }
+                    act_cur = act_next;
+                }
+                if (want) { // the generator after the n draws the walk consumed: A^n state + inc G_n
+                    uint32_t an[4], gn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { an[i] = jump[n * 8 + i]; gn[i] = jump[n * 8 + 4 + i]; }
+                    g.s_lo = st_lo; g.s_hi = st_hi;
+                    g.jump(an, gn);
+                }
+            }
+        } else
         if (!terminal && depth < H) {
             int h = depth;
             Pcg64 ga = g, gb = g;
@@ -685,6 +771,7 @@ void uct_kernel(UctArgs p)
         printf("uct prof wave0: total=%lld select=%lld expand=%lld rollout=%lld backup=%lld | lane0 select steps=%lld rollout steps=%lld\n",
                (long long)(clock64() - t_all0), t_sel, t_expd, t_roll, t_bak, n_sel, n_roll);
 #endif
+    if (!owner) return;                      // (QD: the helper lanes held no tree)
     if (RC) {
         UctNode w;
         w.value = tv0; w.count = tc0; w.first_child = tf0;
@@ -812,7 +899,8 @@ static bool uct_ldsr_default(bool forced, long n_roots, int cus)
 }
 
 template <int AT>
-static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed, bool ldsr = false, bool spill = false)
+static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, bool sp, bool listed, bool ldsr = false, bool spill = false,
+                      bool quad = false)
 {
     const int roots_per_block = a.waves * a.lanes;
     const dim3 grid((unsigned)((a.n_roots + roots_per_block - 1) / roots_per_block)), block((unsigned)a.waves * 64);
@@ -821,6 +909,13 @@ static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, b
             if constexpr (AT > 0) hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_SPILL, false, false, 2>), grid, block, lds, st, a);
         } else {
             hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_SPILL, false, false, 0>), grid, block, lds, st, a);
+        }
+    } else if (ldsr && quad) {
+        if constexpr (AT > 0) {
+            if (lds > 64 * 1024)
+                MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<AT, ENV_TABLE_LDSR, false, false, 2, true>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((uct_kernel<AT, ENV_TABLE_LDSR, false, false, 2, true>), grid, block, lds, st, a);
         }
     } else if (ldsr) {
         if constexpr (AT > 0) {
@@ -998,21 +1093,57 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         ldsr = false;
     }
     if (ldsr) ldsm = false;
+    // FOUR LANES PER ROOT (uct_kernel<..., QD>): small batches of an LDS-resident model -- at most one wave per SIMD's worth of
+    // roots (16 roots per wave: 16 384 roots on 256 CUs).  MP_UCT_QUAD=1 / 0 forces it on / off.
+    bool quad = false;
+    const size_t lds_quad = lds_ldsr + (size_t)(H + 5) * 32;   // jump table: n = 0 .. H (and the lanes' 1 .. 4)
+    if (!cart && !pol && at_known && model->t16 != nullptr && model->r8 != nullptr && want_il == 2 && H >= 1 && H <= 255 &&
+        lds_quad <= kLdsBytes) {
+        const long cus_q = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        const char *qe = getenv("MP_UCT_QUAD");
+        // measured (profiles/r05_uct_small_batch.md): 64 .. 16 384 roots 1.2-1.25x faster than the one-lane-per-root gather
+        // kernel, a single root level with it (0.186 against 0.183 ms: its chain is selection + backup in global memory)
+        quad = qe ? atoi(qe) != 0 : (!force && n_roots >= 16 && ((long)n_roots + 15) / 16 <= 4 * cus_q);
+    }
+    if (quad) { ldsr = true; ldsm = false; }
+    a.jump = nullptr;
+    if (quad) {
+        // limbs of A^n and G_n = 1 + A + ... + A^(n-1) (mod 2^128), n = 0..H: the generator after n draws is A^n state + inc G_n
+        if (ctx->jump_entries < H + 5) {
+            typedef unsigned __int128 u128;
+            const u128 mult = ((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
+            const int n_e = H + 5 > 64 ? H + 5 : 64;
+            std::vector<uint32_t> tabj((size_t)n_e * 8);
+            u128 an = 1, gn = 0;
+            for (int n = 0; n < n_e; ++n) {
+                for (int i = 0; i < 4; ++i) { tabj[(size_t)n * 8 + i] = (uint32_t)(an >> (32 * i)); tabj[(size_t)n * 8 + 4 + i] = (uint32_t)(gn >> (32 * i)); }
+                gn = gn * mult + 1;
+                an = an * mult;
+            }
+            uint32_t *dj = nullptr;
+            ctx->jump_entries = 0;
+            MP_TRY(ws_get(ctx, WS_JUMP, tabj.size(), &dj));
+            MP_HIP(hipMemcpyAsync(dj, tabj.data(), tabj.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            MP_HIP(hipStreamSynchronize(ctx->stream)); // (`tabj` is a local)
+            ctx->jump_entries = n_e;
+        }
+        a.jump = static_cast<const uint32_t *>(ctx->ws[WS_JUMP].p);
+    }
     a.r8 = model->r8; a.rdict = model->rdict; a.n_rdict = model->n_rdict; a.path_spill = nullptr; a.spill_stride = 0;
-    a.lanes = (ldsm || ldsr) ? 64 : uct_lanes_per_wave();
+    a.lanes = quad ? 16 : ((ldsm || ldsr) ? 64 : uct_lanes_per_wave());
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
     if (ldsr) {
         // one workgroup per CU shares the tables: as many waves per workgroup as it takes to put the batch on the chip's
         // CUs (a power of two <= 16, so that chunk boundaries -- multiples of 1024 roots -- are workgroup boundaries)
-        const long total_waves = ((long)n_roots + 63) / 64, cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        const long total_waves = ((long)n_roots + a.lanes - 1) / a.lanes, cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
         long w = (total_waves + cus - 1) / cus;
         if (const char *e = getenv("MP_UCT_LDSR_WAVES")) w = atol(e);
         a.waves = 1;
         while (a.waves < w && a.waves < 16) a.waves <<= 1;
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
-    size_t lds = ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0);
+    size_t lds = quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
         ldsm = false;
@@ -1060,13 +1191,14 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.cap = (int)cap_use;
     a.tree_il = ctx->tree.il;
     if (ldsr && ctx->tree.il != 2) { // (a kept tree in another layout: the default kernel and its LDS budget)
-        ldsr = false; ldsm = false;
+        ldsr = false; ldsm = false; quad = false;
+        a.lanes = uct_lanes_per_wave();
         a.waves = 1;
         lds = ntab * sizeof(double) + (size_t)(H + 1) * 64 * sizeof(int32_t);
         if (lds > 64 * 1024) { spill = true; lds = ntab * sizeof(double); }
     }
     if (spill && ctx->tree.il == 1) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d needs the spilled path stack, which the interleaved tree layout does not have", H);
-    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
     if (ldsr || spill) {
         a.spill_stride = ((long)n_roots + 63) & ~63L;
         MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
@@ -1171,13 +1303,13 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
         } else
         switch (A) {
-        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
-        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
-        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
-        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
-        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
-        case 7: MP_TRY(uct_launch<7>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
-        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill)); break;
+        case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
+        case 3: MP_TRY(uct_launch<3>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
+        case 4: MP_TRY(uct_launch<4>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
+        case 5: MP_TRY(uct_launch<5>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
+        case 6: MP_TRY(uct_launch<6>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
+        case 7: MP_TRY(uct_launch<7>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
+        case 8: MP_TRY(uct_launch<8>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
         default:
             if (pol) return fail(MP_ERR_ARG, "mp_uct_plan_policy: |A| = %d is not in 2..8: per-state policies over more actions plan through "
                                              "mp_uct_plan_stochastic_policy (it takes deterministic tables too)", A);

@@ -42,7 +42,7 @@ __device__ __forceinline__ bool isclose_np(double a, double b, double rtol, doub
 // the same predicate without a branch (both sides evaluated, selected): keeps fully unrolled loops straight-line code
 __device__ __forceinline__ bool isclose_np_sel(double a, double b, double rtol, double atol)
 {
-    const bool fin = isfinite(a) & isfinite(b);
+    const bool fin = (int)isfinite(a) & (int)isfinite(b);
     const bool close = fabs(a - b) <= atol + rtol * fabs(b);
     const bool same = a == b;
     return fin ? close : same;
