@@ -731,10 +731,15 @@ def bench_uct_cartpole(args, rank, world, local):
                                     max_plan_len=mpl, n_threads=host_cores(), cartpole=params)
         same = ((d_plans[ti].cpu().numpy() == ref["plans"]).all(axis=1) & (d_steps[ti].cpu().numpy() == ref["env_steps"])
                 & (d_val[ti].cpu().numpy() == ref["root_value"]))
-        # sin / cos come from the device math library: the stated tolerance is >= 99.5 % of roots identical (observed 100 %)
-        res["parity_sample"] = parity_record(bool(same.mean() >= 0.98), "{} roots of a {}-root launch vs oracle.uct_plan_batch "
-                                             "(CartPole): plans, env_steps, root value; tolerance >= 98 % of the sample "
-                                             "identical (device sincos)".format(len(idx), n_roots), identical_fraction=float(same.mean()))
+        # sin / cos of the pole angle are the host libm's algorithm restated on the device (csrc/libm_sincos.hpp): bit for bit
+        # when one of the two forms reproduces this host's libm (variant 1 / 2), else the device math library and the old tolerance
+        variant = native.libm_sincos_variant()
+        need = 1.0 if variant in (1, 2) else 0.98
+        res["parity_sample"] = parity_record(bool(same.mean() >= need), "{} roots of a {}-root launch vs oracle.uct_plan_batch "
+                                             "(CartPole): plans, env_steps, root value; {}".format(
+                                                 len(idx), n_roots, "bit for bit (host libm's sin / cos restated on the device, form {})".format(variant)
+                                                 if need == 1.0 else "tolerance >= 98 % of the sample identical (device sincos: no restated form matched this host's libm)"),
+                                             identical_fraction=float(same.mean()), libm_sincos_variant=variant)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:   # the host baseline is an N = 1 figure
         from oracle import oracle
         cores = host_cores()

@@ -207,6 +207,20 @@ typedef struct {
     int32_t euler;           /* 1 = explicit Euler (gymnasium default) */
 } mp_cartpole_params;
 int mp_model_load_cartpole(mp_ctx *ctx, const mp_cartpole_params *params, mp_model **out);
+/*
+ * CartPole's dynamics take math.sin / math.cos of the pole angle (gymnasium's cartpole.py, restated in
+ * rl_agents_amd/envs/cartpole.py), i.e. the host C library's sin / cos -- which are not correctly rounded: "the" value is
+ * what glibc's algorithm yields.  The kernels evaluate glibc's dbl-64 algorithm for |x| < 0.855469 themselves (a pole angle
+ * stays below 0.21 rad), in the form that reproduces THIS host's libm:
+ *   mp_libm_sincos_variant(): 1 = the FMA-contracted form (x86-64 CPUs with FMA + AVX2), 2 = every operation rounded
+ *   (SSE2 / AVX variants), 0 = neither matched the host's sin / cos on the probe sample -- the device then uses its own
+ *   math library and CartPole plans carry the tolerance of rounds 1-4 (>= 99.5 % of roots identical); host only, cached.
+ *   mp_libm_sincos: the restated functions on the HOST, variant 1 / 2 (0 = libm itself): s[i], c[i] = sin, cos of x[i].
+ *   mp_selftest_sincos: the same on the DEVICE (host arrays in / out) -- tests compare 10^7 angles with the host's libm.
+ */
+int mp_libm_sincos_variant(void);
+int mp_libm_sincos(int32_t n, const double *x, int32_t variant, double *s, double *c);
+int mp_selftest_sincos(mp_ctx *ctx, int32_t n, const double *x, int32_t variant, double *s, double *c);
 int mp_model_free(mp_model *model);
 int mp_model_info(const mp_model *model, int32_t *mode, int32_t *M, int32_t *S, int32_t *A, int32_t *B);
 

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "libm_sincos.hpp"
 
 namespace mp {
 
@@ -1203,11 +1204,72 @@ int mp_model_load_sparse(mp_ctx *ctx, int32_t S, int32_t A, int32_t B, const dou
     return MP_OK;
 }
 
+// Which restated form of glibc's small-argument sin / cos reproduces THIS host's libm (the reference's CartPole calls
+// math.sin / math.cos): both forms against sin() / cos() on 40 000 angles over the range a pole can reach and beyond, plus the
+// tiny-argument branches.  1 = the FMA-contracted form, 2 = every operation rounded, 0 = neither (another libm).
+int mp_libm_sincos_variant(void)
+{
+    static int cached = -1;
+    if (cached >= 0) return cached;
+    bool ok[3] = {false, true, true};
+    uint64_t lcg = 0x9E3779B97F4A7C15ULL;
+    for (int i = 0; i < 40000; ++i) {
+        lcg = lcg * 6364136223846793005ULL + 1442695040888963407ULL;
+        const double u = (double)(lcg >> 11) * (1.0 / 9007199254740992.0);            // [0, 1)
+        double x = (i % 4 == 0 ? 0.85 : (i % 4 == 1 ? 0.3 : (i % 4 == 2 ? 0.13 : 1e-6))) * (2.0 * u - 1.0);
+        if (i % 997 == 0) x = ldexp(x, -30);
+        const double s = sin(x), c = cos(x);
+        if (libm_sin_small<true>(x) != s || libm_cos_small<true>(x) != c) ok[1] = false;
+        if (libm_sin_small<false>(x) != s || libm_cos_small<false>(x) != c) ok[2] = false;
+    }
+    cached = ok[1] ? SINCOS_LIBM_FMA : (ok[2] ? SINCOS_LIBM_PLAIN : SINCOS_DEVICE);
+    return cached;
+}
+
+int mp_libm_sincos(int32_t n, const double *x, int32_t variant, double *s, double *c)
+{
+    if (n < 0 || !x || !s || !c || variant < 0 || variant > 2) return fail(MP_ERR_ARG, "mp_libm_sincos: bad argument");
+    for (int i = 0; i < n; ++i) libm_sincos(variant, x[i], &s[i], &c[i]);
+    return MP_OK;
+}
+
+extern "C++" {
+namespace mp {
+__global__ void sincos_selftest_kernel(int n, int variant, const double *__restrict__ x, double *__restrict__ s, double *__restrict__ c)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) libm_sincos(variant, x[i], &s[i], &c[i]);
+}
+} // namespace mp
+}
+
+int mp_selftest_sincos(mp_ctx *ctx, int32_t n, const double *x, int32_t variant, double *s, double *c)
+{
+    if (!ctx || n < 1 || !x || !s || !c || variant < 0 || variant > 2) return fail(MP_ERR_ARG, "mp_selftest_sincos: bad argument");
+    MP_HIP(hipSetDevice(ctx->device));
+    double *d = nullptr;
+    MP_HIP(hipMalloc(&d, (size_t)n * 3 * sizeof(double)));
+    hipError_t e = hipMemcpyAsync(d, x, (size_t)n * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(mp::sincos_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, variant, d, d + n, d + 2 * (size_t)n);
+        e = hipMemcpyAsync(s, d + n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(c, d + 2 * (size_t)n, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
+    const hipError_t e2 = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    MP_HIP(e);
+    MP_HIP(e2);
+    return MP_OK;
+}
+
 int mp_model_load_cartpole(mp_ctx *ctx, const mp_cartpole_params *params, mp_model **out)
 {
     if (!ctx || !out || !params) return fail(MP_ERR_ARG, "mp_model_load_cartpole: NULL argument");
     mp_model *m = new mp_model();
     m->ctx = ctx; m->mode = MP_MODE_CARTPOLE; m->M = 1; m->S = 0; m->A = 2;
+    m->cp_sincos = mp_libm_sincos_variant();
+    if (const char *e = getenv("MP_CARTPOLE_SINCOS")) // "device" / "fma" / "plain": measurement and test knob
+        m->cp_sincos = !strcmp(e, "fma") ? SINCOS_LIBM_FMA : (!strcmp(e, "plain") ? SINCOS_LIBM_PLAIN : SINCOS_DEVICE);
     m->cp = *params;
     m->max_steps = params->max_steps;
     *out = m;

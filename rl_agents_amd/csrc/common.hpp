@@ -232,6 +232,7 @@ struct mp_model {
                              // 1 = ONE uint4 per record: two successors at most and at most 256 distinct rewards (srec_rtab)
     double *srec_rtab = nullptr; // srec_wb == 1: the distinct reward values [256] a record's 8-bit index points into
     mp_cartpole_params cp;
+    int cp_sincos = 0;       // CartPole: which restated form of the host libm's sin / cos the kernel evaluates (libm_sincos.hpp)
 };
 
 // per-state prior / rollout policies of one model (mcts_with_prior.py:47-62), device

@@ -1,0 +1,171 @@
+// libm_sincos.hpp -- sin / cos of SMALL arguments exactly as the host's libm computes them, on the device.
+//
+// gymnasium's CartPole (restated in rl_agents_amd/envs/cartpole.py; the reference's only pinned test drives it,
+// tests/agents/tree_search/test_mcts.py:7-19) evaluates math.sin / math.cos of the pole angle, i.e. the C library's
+// double-precision sin / cos.  glibc's are not correctly rounded (0.55 ULP), so "the" value is whatever its algorithm
+// yields: the device math library's sincos differs in the last bit now and then, which made CartPole the one planner
+// path with a tolerance (rounds 1-4: >= 99.5 % of roots identical).  This header restates the algorithm of glibc's
+// dbl-64 sin / cos for |x| < 0.855469 -- the only range a pole angle can reach (|theta| < 0.21 rad until termination)
+// -- operation for operation:
+//   |x| < 2^-26 (sin) / 2^-27 (cos)   x / 1.0
+//   |x| < 0.126 (sin only)             the odd Taylor polynomial s1 .. s5
+//   else                               x = xk + r with xk = round(|x| * 128) / 128 taken from big + |x|; sin / cos of xk from
+//                                      the double-double table (sincos_table.inc), short polynomials in r, the
+//                                      angle-addition formula with a correction term
+// in the TWO forms the library ships on x86-64 and selects by CPU (ifunc): with fused multiply-adds where the compiler
+// contracted them (`FMA = true`: the instruction sequence of glibc 2.35's FMA variant, decoded from the library; any CPU
+// with FMA + AVX2, i.e. every host an MI355X sits in) and with every operation rounded (`FMA = false`: the SSE2 / AVX
+// variants).  The host side of the library checks at model-load time which of the two reproduces THIS host's sin / cos on
+// a sample of angles and tells the kernel (mp_libm_sincos_variant); if neither does (another libm), the device falls back to
+// its own sincos and the parity claim for CartPole is the old tolerance (reported, never silent).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <string.h>
+
+namespace mp {
+
+#define MP_SINCOS_ENTRIES 440
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ const double kSincosTab[MP_SINCOS_ENTRIES] = {
+#include "sincos_table.inc"
+};
+#else
+static const double kSincosTab[MP_SINCOS_ENTRIES] = {
+#include "sincos_table.inc"
+};
+#endif
+
+struct LibmConst {
+    static constexpr double s1 = -0x1.5555555555555p-3, s2 = 0x1.1111111110ecep-7, s3 = -0x1.a01a019db08b8p-13,
+                            s4 = 0x1.71de27b9a7ed9p-19, s5 = -0x1.addffc2fcdf59p-26;
+    static constexpr double sn3 = -0x1.5555555555515p-3, sn5 = 0x1.11110e829872fp-7;
+    static constexpr double cs2 = 0x1.0p-1, cs4 = -0x1.5555555555535p-5, cs6 = 0x1.6c16bedd9e239p-10;
+    static constexpr double big = 0x1.8p+45;
+};
+
+__host__ __device__ __forceinline__ double libm_fma(double a, double b, double c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fma_rn(a, b, c);
+#else
+    return fma(a, b, c);
+#endif
+}
+__host__ __device__ __forceinline__ uint32_t libm_high_abs(double x)
+{
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    return (uint32_t)(b >> 32) & 0x7fffffffu;
+}
+__host__ __device__ __forceinline__ int libm_low_word(double x)
+{
+    uint64_t b;
+    memcpy(&b, &x, 8);
+    return (int)(uint32_t)b;
+}
+
+// true when |x| is inside the restated range
+__host__ __device__ __forceinline__ bool libm_small(double x) { return libm_high_abs(x) < 0x3feb6000u; }
+
+template <bool FMA>
+__host__ __device__ inline double libm_sin_small(double x)
+{
+    typedef LibmConst K;
+    const uint32_t k = libm_high_abs(x);
+    if (k < 0x3e500000u) return x;
+    const double ax = fabs(x);
+    if (ax < 0.126) { // TAYLOR_SIN (x * x, x, 0)
+        const double xx = x * x;
+        double poly, t;
+        if (FMA) {
+            poly = libm_fma(xx, K::s5, K::s4);
+            poly = libm_fma(xx, poly, K::s3);
+            poly = libm_fma(xx, poly, K::s2);
+            poly = libm_fma(xx, poly, K::s1);
+            t = libm_fma(x, poly, -0.0);
+            t = libm_fma(t, xx, 0.0);
+        } else {
+            poly = ((((K::s5 * xx + K::s4) * xx + K::s3) * xx + K::s2) * xx) + K::s1;
+            t = (poly * x - 0.5 * 0.0) * xx + 0.0;
+        }
+        return x + t;
+    }
+    const double dx = x <= 0 ? -0.0 : 0.0;
+    const double u = K::big + ax;
+    const double r = ax - (u - K::big);
+    const int i4 = libm_low_word(u) << 2;
+    const double sn = kSincosTab[i4], ssn = kSincosTab[i4 + 1], cs = kSincosTab[i4 + 2], ccs = kSincosTab[i4 + 3];
+    const double xx = r * r;
+    double s, c, cor;
+    if (FMA) {
+        const double p = libm_fma(xx, K::sn5, K::sn3);
+        s = r + libm_fma(r * xx, p, dx);
+        double q = libm_fma(xx, K::cs6, K::cs4);
+        q = libm_fma(xx, q, K::cs2);
+        c = libm_fma(r, dx, xx * q);
+        const double e1 = libm_fma(s, ccs, ssn);
+        const double e2 = libm_fma(-c, sn, e1);
+        cor = libm_fma(s, cs, e2);
+    } else {
+        s = r + (dx + r * xx * (K::sn3 + xx * K::sn5));
+        c = r * dx + xx * (K::cs2 + xx * (K::cs4 + xx * K::cs6));
+        cor = (ssn + s * ccs - sn * c) + cs * s;
+    }
+    return copysign(sn + cor, x);
+}
+
+template <bool FMA>
+__host__ __device__ inline double libm_cos_small(double x)
+{
+    typedef LibmConst K;
+    const uint32_t k = libm_high_abs(x);
+    if (k < 0x3e400000u) return 1.0;
+    const double ax = fabs(x);
+    const double dx = x < 0 ? -0.0 : 0.0;
+    const double u = K::big + ax;
+    const double r = ax - (u - K::big) + dx;
+    const int i4 = libm_low_word(u) << 2;
+    const double sn = kSincosTab[i4], ssn = kSincosTab[i4 + 1], cs = kSincosTab[i4 + 2], ccs = kSincosTab[i4 + 3];
+    const double xx = r * r;
+    double s, c, cor;
+    if (FMA) {
+        const double p = libm_fma(xx, K::sn5, K::sn3);
+        s = libm_fma(r * xx, p, r);
+        double q = libm_fma(xx, K::cs6, K::cs4);
+        q = libm_fma(xx, q, K::cs2);
+        c = xx * q;
+        const double e1 = libm_fma(-s, ssn, ccs);
+        const double e2 = libm_fma(-c, cs, e1);
+        cor = libm_fma(-s, sn, e2);
+    } else {
+        s = r + r * xx * (K::sn3 + xx * K::sn5);
+        c = xx * (K::cs2 + xx * (K::cs4 + xx * K::cs6));
+        cor = (ccs - s * ssn - cs * c) - sn * s;
+    }
+    return cs + cor;
+}
+
+enum { SINCOS_DEVICE = 0, SINCOS_LIBM_FMA = 1, SINCOS_LIBM_PLAIN = 2 };
+
+// sin and cos of x in the form `variant` names; outside the restated range (never for a pole angle) the math library's
+__host__ __device__ __forceinline__ void libm_sincos(int variant, double x, double *s, double *c)
+{
+    if (variant == SINCOS_LIBM_FMA && libm_small(x)) {
+        *s = libm_sin_small<true>(x);
+        *c = libm_cos_small<true>(x);
+    } else if (variant == SINCOS_LIBM_PLAIN && libm_small(x)) {
+        *s = libm_sin_small<false>(x);
+        *c = libm_cos_small<false>(x);
+    } else {
+#if defined(__HIP_DEVICE_COMPILE__)
+        sincos(x, s, c);
+#else
+        *s = sin(x);
+        *c = cos(x);
+#endif
+    }
+}
+
+} // namespace mp

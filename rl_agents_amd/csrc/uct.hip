@@ -41,6 +41,7 @@
 #include <type_traits>
 
 #include "common.hpp"
+#include "libm_sincos.hpp"
 #include "pcg64.hpp"
 
 namespace mp {
@@ -114,6 +115,7 @@ struct UctArgs {
     const int32_t *root_state, *root_steps;
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
+    int cp_sincos;       // how CartPole's sin / cos are evaluated (libm_sincos.hpp: 0 device, 1 / 2 the host libm's forms)
     const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[TE+1] | tpdiv[A][TE+2]
     uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8), SHIFTED UP by 11 bits (compared with the raw 64-bit draw; 2^53 -> ~0): kernel arguments live in SGPRs
     int thr_valid;       // how many of the first |A| - 1 thresholds are below 2^53 (the others can never be reached)
@@ -138,15 +140,16 @@ struct UctArgs {
 };
 
 // rl_agents_amd/envs/cartpole.py step(), operation for operation in IEEE double (no contraction).
-// sin/cos come from the device math library, whose last bit may differ from glibc's: CartPole plans are
-// compared with the oracle statistically-exactly (tests/test_gpu_cartpole.py), not by construction.
-__device__ __forceinline__ bool cartpole_step(const mp_cartpole_params &c, double (&x4)[4], int act)
+// sin / cos of the pole angle: the HOST libm's algorithm restated (libm_sincos.hpp; `sincos_mode` = the form that
+// reproduces this host's sin / cos, found at model-load time) -- bit-exact plans by construction since round 5; mode 0 = the
+// device math library (last bit may differ from glibc's: the tolerance of rounds 1-4).
+__device__ __forceinline__ bool cartpole_step(const mp_cartpole_params &c, double (&x4)[4], int act, int sincos_mode)
 {
     const double total_mass = c.masspole + c.masscart, polemass_length = c.masspole * c.length;
     double x = x4[0], x_dot = x4[1], theta = x4[2], theta_dot = x4[3];
     const double force = act == 1 ? c.force_mag : -c.force_mag;
     double sintheta, costheta;
-    sincos(theta, &sintheta, &costheta);
+    libm_sincos(sincos_mode, theta, &sintheta, &costheta);
     const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
     const double thetaacc = (c.gravity * sintheta - costheta * temp) /
                             (c.length * (4.0 / 3.0 - c.masspole * (costheta * costheta) / total_mass));
@@ -452,7 +455,7 @@ void uct_kernel(UctArgs p)
             const long idx = (long)s * A + act;
             double reward;
             if (CART) {
-                terminal = cartpole_step(p.cp, x4, act);
+                terminal = cartpole_step(p.cp, x4, act, p.cp_sincos);
                 reward = 1.0;
             } else if (LDSM) {
                 const uint32_t e = t16[idx];
@@ -654,7 +657,7 @@ void uct_kernel(UctArgs p)
                 if (CART) {
                     gspec = gcur;
                     unext = gspec.next64() >> USH;
-                    term_h = cartpole_step(p.cp, x4, act);
+                    term_h = cartpole_step(p.cp, x4, act, p.cp_sincos);
                     total += g_mine * 1.0;
                 } else if (LDSM) {
                     const unsigned idx = ridx;
@@ -1053,7 +1056,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             }
         }
     }
-    a.cp = model->cp; a.root_x = nullptr;
+    a.cp = model->cp; a.cp_sincos = model->cp_sincos; a.root_x = nullptr;
     a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_frec = pol ? pol->frec : nullptr;
     a.pol_frec_roll = pol ? (pol->frec_roll ? pol->frec_roll : pol->frec) : nullptr;
     a.pol_stride = pol ? pol->stride : 0;

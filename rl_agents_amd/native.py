@@ -43,6 +43,9 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _vp, c_i32]),
     "mp_opd_plan_models": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      c_i32]),
+    "mp_libm_sincos_variant": (C.c_int, []),
+    "mp_libm_sincos": (C.c_int, [c_i32, _vp, c_i32, _vp, _vp]),
+    "mp_selftest_sincos": (C.c_int, [_vp, c_i32, _vp, c_i32, _vp, _vp]),
     "mp_model_load_dense": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
     "mp_model_load_dense_rows": (C.c_int, [_vp, c_i32, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, P(_vp)]),
     "mp_vi_backup": (C.c_int, [_vp, _vp, c_f64, c_i32, _vp, _vp, c_i32]),
@@ -200,6 +203,20 @@ def seed_sequence_states(entropy, first_key, count):
     return out
 
 
+def libm_sincos_variant():
+    """Which restated form of glibc's small-argument sin / cos reproduces this host's libm (mp_libm_sincos_variant):
+    1 = FMA-contracted, 2 = every operation rounded, 0 = neither (CartPole then keeps the device's own sincos)."""
+    return int(load().mp_libm_sincos_variant())
+
+
+def libm_sincos(x, variant):
+    """The restated functions on the host: (sin, cos) arrays of ``x`` in form ``variant`` (0 = libm itself)."""
+    x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+    s, c = np.zeros_like(x), np.zeros_like(x)
+    _check(load().mp_libm_sincos(int(x.size), _ptr(x), int(variant), _ptr(s), _ptr(c)))
+    return s, c
+
+
 def olop_allocation(budget, gamma):
     """OLOP.allocation (tree_search/olop.py:50-62): budget -> (episodes, horizon)."""
     e, h = c_i32(), c_i32()
@@ -284,6 +301,13 @@ class Context(object):
     def last_kernel_variant(self):
         """Which kernel variant the last UCT plan launched ("uct_global", "uct_ldsr", ...)."""
         return self._lib.mp_last_kernel_variant(self._h).decode()
+
+    def selftest_sincos(self, x, variant):
+        """(sin, cos) of ``x`` evaluated by the DEVICE's restated libm functions in form ``variant`` (mp_selftest_sincos)."""
+        x = np.ascontiguousarray(x, dtype=np.float64).reshape(-1)
+        s, c = np.zeros_like(x), np.zeros_like(x)
+        _check(self._lib.mp_selftest_sincos(self._h, int(x.size), _ptr(x), int(variant), _ptr(s), _ptr(c)))
+        return s, c
 
     def selftest_lds_atomic_order(self, waves=65536):
         """Violations of "same-address LDS atomics of one wave instruction apply in lane order" (0 on a conforming device)."""

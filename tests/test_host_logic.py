@@ -493,3 +493,33 @@ def test_model_cache_keys_by_version_without_hashing(monkeypatch):
     env.mdp.reward = np.array(env.mdp.reward)        # unknown change: a new upload
     m3 = cache.get(device_model.spec_from_mdp(env.mdp))
     assert m3 is not m1 and cache.uploads == 2
+
+
+def test_restated_sincos_equals_host_libm():
+    """csrc/libm_sincos.hpp on the HOST: the form mp_libm_sincos_variant picks reproduces this process's libm sin / cos (what
+    math.sin / math.cos -- gymnasium's CartPole -- call) on two million angles of the restated range; a child process whose
+    libm is steered to its other variant (GLIBC_TUNABLES: no FMA) must pick the other form and match it as well."""
+    import math
+    import subprocess
+    import sys
+    from rl_agents_amd import native
+    variant = native.libm_sincos_variant()
+    assert variant in (1, 2), "neither restated form reproduces this host's libm"
+    g = np.random.Generator(np.random.PCG64(3))
+    x = np.concatenate([g.uniform(-0.855468, 0.855468, 1_000_000), g.uniform(-0.25, 0.25, 1_000_000),
+                        g.uniform(-1e-7, 1e-7, 1000), np.arange(-110, 110) / 128.0, [0.0, -0.0, 0.126, -0.126, 2.0 ** -26, 2.0 ** -27]])
+    s, c = native.libm_sincos(x, variant)
+    s0, c0 = native.libm_sincos(x, 0)
+    assert np.array_equal(s, s0) and np.array_equal(c, c0)
+    assert [math.sin(v) for v in x[:20000]] == s[:20000].tolist() and [math.cos(v) for v in x[:20000]] == c[:20000].tolist()
+    code = ("import sys, numpy as np; sys.path.insert(0, %r); from rl_agents_amd import native; v = native.libm_sincos_variant();"
+            "x = np.random.Generator(np.random.PCG64(4)).uniform(-0.855468, 0.855468, 400000);"
+            "s, c = native.libm_sincos(x, v); s0, c0 = native.libm_sincos(x, 0);"
+            "print(v, int(np.array_equal(s, s0) and np.array_equal(c, c0)))") % REPO
+    env = dict(os.environ, GLIBC_TUNABLES="glibc.cpu.hwcaps=-FMA,-AVX2_Usable,-FMA4", MI355PLAN_NO_TORCH="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stderr.decode()[-500:]
+    other, ok = (int(v) for v in out.stdout.decode().split()[-2:])
+    assert ok == 1 and other in (1, 2)
+    if variant == 1:
+        assert other == 2, "with FMA masked off glibc must select (and the probe find) the uncontracted form"
