@@ -72,10 +72,15 @@ def pmc_traffic(workload, kernel_substr, grid_threads, pattern="scattered"):
     files = sorted(glob.glob(os.path.join(REPO, "profiles", "*_pmc.json")))
     if not files:
         return None, None
-    try:
-        entry = json.load(open(files[-1])).get(workload, {})
-    except (OSError, ValueError):
-        return None, None
+    entry = {}
+    for path in reversed(files):                     # the newest summary that holds this workload
+        try:
+            entry = json.load(open(path)).get(workload, {})
+        except (OSError, ValueError):
+            entry = {}
+        if entry:
+            files = [path]
+            break
     cal = calibration()
     for key, v in entry.items():
         # grid_threads None: the kernel is launched on one geometry only in this workload (dense VI: the column split

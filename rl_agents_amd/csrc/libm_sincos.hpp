@@ -70,7 +70,7 @@ __host__ __device__ __forceinline__ int libm_low_word(double x)
 __host__ __device__ __forceinline__ bool libm_small(double x) { return libm_high_abs(x) < 0x3feb6000u; }
 
 template <bool FMA>
-__host__ __device__ inline double libm_sin_small(double x)
+__host__ __device__ inline double libm_sin_small(double x, const double *tab = kSincosTab)
 {
     typedef LibmConst K;
     const uint32_t k = libm_high_abs(x);
@@ -96,7 +96,7 @@ __host__ __device__ inline double libm_sin_small(double x)
     const double u = K::big + ax;
     const double r = ax - (u - K::big);
     const int i4 = libm_low_word(u) << 2;
-    const double sn = kSincosTab[i4], ssn = kSincosTab[i4 + 1], cs = kSincosTab[i4 + 2], ccs = kSincosTab[i4 + 3];
+    const double sn = tab[i4], ssn = tab[i4 + 1], cs = tab[i4 + 2], ccs = tab[i4 + 3];
     const double xx = r * r;
     double s, c, cor;
     if (FMA) {
@@ -117,7 +117,7 @@ __host__ __device__ inline double libm_sin_small(double x)
 }
 
 template <bool FMA>
-__host__ __device__ inline double libm_cos_small(double x)
+__host__ __device__ inline double libm_cos_small(double x, const double *tab = kSincosTab)
 {
     typedef LibmConst K;
     const uint32_t k = libm_high_abs(x);
@@ -127,7 +127,7 @@ __host__ __device__ inline double libm_cos_small(double x)
     const double u = K::big + ax;
     const double r = ax - (u - K::big) + dx;
     const int i4 = libm_low_word(u) << 2;
-    const double sn = kSincosTab[i4], ssn = kSincosTab[i4 + 1], cs = kSincosTab[i4 + 2], ccs = kSincosTab[i4 + 3];
+    const double sn = tab[i4], ssn = tab[i4 + 1], cs = tab[i4 + 2], ccs = tab[i4 + 3];
     const double xx = r * r;
     double s, c, cor;
     if (FMA) {
@@ -150,14 +150,16 @@ __host__ __device__ inline double libm_cos_small(double x)
 enum { SINCOS_DEVICE = 0, SINCOS_LIBM_FMA = 1, SINCOS_LIBM_PLAIN = 2 };
 
 // sin and cos of x in the form `variant` names; outside the restated range (never for a pole angle) the math library's
-__host__ __device__ __forceinline__ void libm_sincos(int variant, double x, double *s, double *c)
+// (tab: the table in whatever memory the caller staged it -- the CartPole kernel keeps a copy in LDS: four lookups per step
+// sit on the dependency chain of a lone wave)
+__host__ __device__ __forceinline__ void libm_sincos(int variant, double x, double *s, double *c, const double *tab = kSincosTab)
 {
     if (variant == SINCOS_LIBM_FMA && libm_small(x)) {
-        *s = libm_sin_small<true>(x);
-        *c = libm_cos_small<true>(x);
+        *s = libm_sin_small<true>(x, tab);
+        *c = libm_cos_small<true>(x, tab);
     } else if (variant == SINCOS_LIBM_PLAIN && libm_small(x)) {
-        *s = libm_sin_small<false>(x);
-        *c = libm_cos_small<false>(x);
+        *s = libm_sin_small<false>(x, tab);
+        *c = libm_cos_small<false>(x, tab);
     } else {
 #if defined(__HIP_DEVICE_COMPILE__)
         sincos(x, s, c);

@@ -143,13 +143,13 @@ struct UctArgs {
 // sin / cos of the pole angle: the HOST libm's algorithm restated (libm_sincos.hpp; `sincos_mode` = the form that
 // reproduces this host's sin / cos, found at model-load time) -- bit-exact plans by construction since round 5; mode 0 = the
 // device math library (last bit may differ from glibc's: the tolerance of rounds 1-4).
-__device__ __forceinline__ bool cartpole_step(const mp_cartpole_params &c, double (&x4)[4], int act, int sincos_mode)
+__device__ __forceinline__ bool cartpole_step(const mp_cartpole_params &c, double (&x4)[4], int act, int sincos_mode, const double *sctab)
 {
     const double total_mass = c.masspole + c.masscart, polemass_length = c.masspole * c.length;
     double x = x4[0], x_dot = x4[1], theta = x4[2], theta_dot = x4[3];
     const double force = act == 1 ? c.force_mag : -c.force_mag;
     double sintheta, costheta;
-    libm_sincos(sincos_mode, theta, &sintheta, &costheta);
+    libm_sincos(sincos_mode, theta, &sintheta, &costheta, sctab);
     const double temp = (force + polemass_length * (theta_dot * theta_dot) * sintheta) / total_mass;
     const double thetaacc = (c.gravity * sintheta - costheta * temp) /
                             (c.length * (4.0 / 3.0 - c.masspole * (costheta * costheta) / total_mass));
@@ -240,6 +240,11 @@ void uct_kernel(UctArgs p)
     uint32_t *jump = reinterpret_cast<uint32_t *>(r8 + ((p.S * A + 15) & ~15)); // QD: [H + 5][8]
     if (QD)
         for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
+    // CartPole: the sin / cos table of libm_sincos.hpp, in LDS behind the path stack (the host sizes the allocation)
+    double *sctab_lds = reinterpret_cast<double *>(path_all + (((H + 1) * nthreads + 1) & ~1));
+    if (CART)
+        for (int i = tid; i < MP_SINCOS_ENTRIES; i += nthreads) sctab_lds[i] = kSincosTab[i];
+    const double *sctab = CART ? sctab_lds : nullptr;
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
     if (LDSR) {
         for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
@@ -455,7 +460,7 @@ void uct_kernel(UctArgs p)
             const long idx = (long)s * A + act;
             double reward;
             if (CART) {
-                terminal = cartpole_step(p.cp, x4, act, p.cp_sincos);
+                terminal = cartpole_step(p.cp, x4, act, p.cp_sincos, sctab);
                 reward = 1.0;
             } else if (LDSM) {
                 const uint32_t e = t16[idx];
@@ -657,7 +662,7 @@ void uct_kernel(UctArgs p)
                 if (CART) {
                     gspec = gcur;
                     unext = gspec.next64() >> USH;
-                    term_h = cartpole_step(p.cp, x4, act, p.cp_sincos);
+                    term_h = cartpole_step(p.cp, x4, act, p.cp_sincos, sctab);
                     total += g_mine * 1.0;
                 } else if (LDSM) {
                     const unsigned idx = ridx;
@@ -1147,6 +1152,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
     size_t lds = quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
+    if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double); // the sin / cos table of libm_sincos.hpp behind the path stack
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
         ldsm = false;

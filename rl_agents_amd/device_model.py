@@ -225,6 +225,7 @@ class ModelCache(object):
         self._models = {}
         self._order = []
         self._by_token = {}         # (tables token, static key) -> (version counter, cache key) of the model that holds them
+        self._version_alias = {}    # version key -> cache key (content hash, or the version key itself for patched models)
         self.uploads = 0
         self.row_updates = 0        # rows patched by delta uploads
 
@@ -246,8 +247,9 @@ class ModelCache(object):
         token, counter = spec.version
         static = spec.static_key()
         key = ("version", token, counter, static)
-        if key in self._models:
-            return self._get_keyed(key, spec)
+        alias = self._version_alias.get(key)
+        if alias is not None and alias in self._models:
+            return self._get_keyed(alias, spec)
         held = self._by_token.get((token, static))
         if held is not None and held[1] in self._models and spec.mode == "deterministic" and spec.dirty_rows_since is not None \
                 and spec.transition.ndim == 2 and not os.environ.get("MP_NO_DELTA_UPLOAD"):
@@ -261,12 +263,21 @@ class ModelCache(object):
                     model._vi_cache = None              # (solutions / policies derived from the old tables)
                     model.epoch = getattr(model, "epoch", 0) + 1
                 model.spec = spec
-                self._models[key] = model
-                self._order.append(key)
+                self._models[key] = model                # (a patched model is known by its version only: its content hash
+                self._order.append(key)                  # would have to be recomputed, which is what the version spares)
+                self._version_alias[key] = key
                 self._by_token[(token, static)] = (counter, key)
                 return model
-        model = self._get_keyed(key, spec)
-        self._by_token[(token, static)] = (counter, key)
+        # tables this cache has not seen under that identity (a NEW MDP object per conversion -- highway-env's to_finite_mdp --
+        # or the first call): their CONTENT decides, once; the version then names the model that holds them
+        alias = self._version_alias.get(key)
+        if alias is None or alias not in self._models:
+            alias = spec.key()
+            if len(self._version_alias) > 64:
+                self._version_alias = {k: v for k, v in self._version_alias.items() if v in self._models}
+            self._version_alias[key] = alias
+        model = self._get_keyed(alias, spec)
+        self._by_token[(token, static)] = (counter, alias)
         if len(self._by_token) > 4 * self.capacity:
             self._by_token = {k: v for k, v in self._by_token.items() if v[1] in self._models}
         return model

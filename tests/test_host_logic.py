@@ -480,19 +480,26 @@ def test_model_cache_keys_by_version_without_hashing(monkeypatch):
 
     cache = device_model.ModelCache(ctx=object())
     monkeypatch.setattr(cache, "_upload", lambda spec: FakeModel())
-    monkeypatch.setattr(device_model.TableSpec, "key", lambda self: (_ for _ in ()).throw(AssertionError("hashed")))
+    hashed = []
+    real_key = device_model.TableSpec.key
+    monkeypatch.setattr(device_model.TableSpec, "key", lambda self: (hashed.append(1), real_key(self))[1])
     cfg = {k: v for k, v in generators.highway_shaped(3, 4, 10, seed=1).items() if k != "original_shape"}
     env = FiniteMDPEnv(cfg)
     m1 = cache.get(device_model.spec_from_mdp(env.mdp))
-    assert cache.get(device_model.spec_from_mdp(env.mdp)) is m1 and cache.uploads == 1
+    assert len(hashed) == 1                           # tables never seen under this identity: their content decides, once
+    assert cache.get(device_model.spec_from_mdp(env.mdp)) is m1 and cache.uploads == 1 and len(hashed) == 1
+    # another MDP OBJECT with the same tables (a re-conversion that builds a new object each time): one more hash, no upload
+    twin = FiniteMDPEnv(cfg)
+    assert cache.get(device_model.spec_from_mdp(twin.mdp)) is m1 and cache.uploads == 1 and len(hashed) == 2
+    assert cache.get(device_model.spec_from_mdp(twin.mdp)) is m1 and len(hashed) == 2
     env.mdp.edit_rows([4, 9], reward=np.zeros((2, 5)))
     m2 = cache.get(device_model.spec_from_mdp(env.mdp))
     assert m2 is m1 and cache.uploads == 1 and cache.row_updates == 2
     np.testing.assert_array_equal(m1.rows[0], [4, 9])
-    assert cache.get(device_model.spec_from_mdp(env.mdp)) is m1 and len(m1.rows) == 1
-    env.mdp.reward = np.array(env.mdp.reward)        # unknown change: a new upload
+    assert cache.get(device_model.spec_from_mdp(env.mdp)) is m1 and len(m1.rows) == 1 and len(hashed) == 2
+    env.mdp.reward = np.array(env.mdp.reward) * 0.5   # unknown change: hashed once, a new upload
     m3 = cache.get(device_model.spec_from_mdp(env.mdp))
-    assert m3 is not m1 and cache.uploads == 2
+    assert m3 is not m1 and cache.uploads == 2 and len(hashed) == 3
 
 
 def test_restated_sincos_equals_host_libm():
