@@ -1590,13 +1590,15 @@ def bench_vi_batch(args, rank, world, local):
                     sweeps_run_min=int(sweeps.min()), sweeps_run_max=int(sweeps.max()), solves_per_s=n * args.steps / dt * world,
                     parallelism="independent MDPs sharded over {} GPU(s), no collective".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel=variant, kernel_ms=k_ms,
-                      algorithmic_bytes_per_launch=alg, traffic=None,
+                      algorithmic_bytes_per_launch=alg,
                       note="algorithmic bytes = SURVEY 8(d) (12 S A + 17 S per sweep) x the sweeps every MDP really ran; the "
                            "register form (S <= 4096) keeps an MDP's rows in registers and V in LDS -- it touches HBM once per solve, "
                            "so `frac` is the rate at which the algorithm's bytes are consumed, not HBM traffic; the streaming form "
                            "(S = 10 000) re-reads 10 B per (s, a) per sweep from L2 / MALL"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    block = 1024 if "wg" in variant else int(variant.split(",")[-1].rstrip(">"))
+    add_traffic(res["roofline"], "vi_batch", "vi_det_batch", n * block, pattern="stream")
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         idx = sample_rows(n, 512 if s_ <= 120 else 8)
@@ -1703,11 +1705,12 @@ def bench_uct_per_root_model(args, rank, world, local):
                     parallelism="roots (episodes) sharded over {} GPU(s), no collective".format(world)),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel="uct_kernel<5, ENV_TABLE> on the union model ({})".format(variant), kernel_ms=k_ms,
-                      algorithmic_bytes_per_launch=bytes_per_step * env_steps, traffic=None,
+                      algorithmic_bytes_per_launch=bytes_per_step * env_steps,
                       note="algorithmic bytes = SURVEY 8(d) terms with depth / expansions measured on this launch's trees; every root "
                            "gathers the 16-byte records of ITS OWN {} B table".format(s_ * a_ * 16)),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    add_traffic(res["roofline"], "uct_per_root_model", "uct_kernel", n_roots)
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         d["rng"].copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))

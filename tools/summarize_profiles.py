@@ -49,13 +49,17 @@ def main():
     os.makedirs(dst, exist_ok=True)
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
-             "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample` on one MI355X (tools/profile_gpu.sh).", ""]
-    for wl in ("uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi", "vi_dense", "vi_dense_exact",
-               "rvi_dense_shard", "rvi_dense_shard_exact"):
+             "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample` on one MI355X (tools/profile_gpu.sh; BENCH_NO_LIVE_PMC unset is harmless: --headline-only skips it).", ""]
+    for wl in ("uct", "uct4096", "uct_per_root_model", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi",
+               "vi_batch", "vi_batch_s10000", "vi_batch_s10000_256", "vi_dense", "vi_dense_exact", "rvi_dense_shard", "rvi_dense_shard_exact"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
         lines += ["## " + wl + (" (= --workload opd --roots 8192)" if wl == "opd8192" else
+                                " (= --workload uct --roots 4096: the four-lanes-per-root kernel)" if wl == "uct4096" else
+                                " (= --workload vi_batch --states 120 --roots 4096)" if wl == "vi_batch" else
+                                " (= --workload vi_batch --states 10000 --roots 64)" if wl == "vi_batch_s10000" else
+                                " (= --workload vi_batch --states 10000 --roots 256)" if wl == "vi_batch_s10000_256" else
                                 " (= --workload rvi_dense_shard --dense-mode exact)" if wl == "rvi_dense_shard_exact" else
                                 " (--dense-mode mfma)" if wl == "rvi_dense_shard" else ""), "",
                   "| kernel | calls | avg us | % of GPU time |", "|---|---|---|---|"]
@@ -72,8 +76,8 @@ def main():
                     name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
             lines.append("")
     traffic = {}
-    for wl in ("uct", "uct_prior", "uct_stoch", "vi_dense", "vi_dense_exact", "rvi_dense_shard", "rvi_dense_shard_exact", "opd", "opd8192",
-               "ropd", "saopd"):
+    for wl in ("uct", "uct_per_root_model", "uct_prior", "uct_stoch", "vi_batch_s10000", "vi_batch_s10000_256", "vi_dense", "vi_dense_exact",
+               "rvi_dense_shard", "rvi_dense_shard_exact", "opd", "opd8192", "ropd", "saopd"):
         entry = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             f = os.path.join(src, "pmc_{}_{}".format(wl, ctr), wl + "_counter_collection.csv")
@@ -82,7 +86,7 @@ def main():
                     entry.setdefault(k, {})[ctr + "_KB_per_launch"] = mean_kb
                     entry[k]["launches_" + ctr] = n
         if entry:  # (bench.py looks a launch up by workload and grid size: the 8192-root pass belongs to "opd")
-            traffic.setdefault("opd" if wl == "opd8192" else wl, {}).update(entry)
+            traffic.setdefault("opd" if wl == "opd8192" else ("vi_batch" if wl.startswith("vi_batch") else wl), {}).update(entry)
     if traffic:
         lines += ["## HBM traffic (PMC, separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`)", "",
                   "Per launch, KB as rocprofv3 reports them.  To bytes: x2 for FETCH_SIZE (streams AND scattered 16-byte gathers: "
