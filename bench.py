@@ -613,11 +613,14 @@ def bench_uct(args, rank, world, local, with_prior=False):
             note="exchange_ms = pack + all_gather_into_tensor + unpack (HIP events around them); hidden_ms = how much of it the "
                  "timed loop did not pay (kernel_ms + exchange_ms - step_ms, clamped to [0, exchange_ms]): the side stream runs "
                  "it under the next step's kernel" if world > 1 else "single rank: no process group, no exchange")
-    add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel", n_roots)
+    # (the same run also launches the record-gather kernel on this grid -- `general_model_kernel` -- so the counters are looked
+    # up by the full template name: ENV 3 = model resident in LDS, 0 = records gathered)
+    kname = "uct_kernel<{}, {},".format(a_, 3 if variant in ("uct_ldsr", "uct_quad") else 0)
+    add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel" if with_prior else kname, n_roots)
     if not with_prior and rank == 0 and world == 1 and not args.headline_only:
         # the default run measures the headline kernel's HBM traffic itself (it used to be read from a committed
         # summary); the committed figure stays beside it as `traffic_committed`
-        live, raw = live_pmc_traffic("uct_kernel", n_roots, "scattered", ["--roots", str(n_roots)])
+        live, raw = live_pmc_traffic(kname, n_roots, "scattered", ["--roots", str(n_roots)])
         roof = res["roofline"]
         roof["traffic_committed"] = roof["traffic"]
         if live is not None:
@@ -1577,7 +1580,17 @@ def bench_vi_batch(args, rank, world, local):
     single_rate = one_sweeps / (float(np.mean(one_ms)) * 1e-3)
     single.close()
     per_sweep = 12.0 * s_ * a_ + 17.0 * s_                      # T 4 + R 8 per (s, a); V read + write + flag per state
-    alg = per_sweep * float(sweeps.sum())
+    alg_survey = per_sweep * float(sweeps.sum())
+    # what a launch must move BEYOND THE CU (the roofline's numerator): the register form reads an MDP's tables once per SOLVE
+    # and writes its Q; the streaming form re-reads 10 B per (s, a) and writes 8 B per state every sweep, after one pass that
+    # re-lays the tables out lane-major (12 S A + S read, 10 S A written)
+    sa = float(s_ * a_)
+    if "reg" in variant:
+        alg = float(n) * (12.0 * sa + s_ + 8.0 * sa + 4.0)
+    elif "stream" in variant:
+        alg = float(sweeps.sum()) * (10.0 * sa + 8.0 * s_) + float(n) * ((12.0 * sa + s_) + 10.0 * sa + 8.0 * sa + 4.0)
+    else:
+        alg = alg_survey + float(n) * 8.0 * sa
     rate = total_sweeps * args.steps / dt
     res = dict(
         metric="value-iteration Bellman sweeps/sec (N independent MDPs per launch, each to its own allclose exit)", unit="sweeps/s",
@@ -1590,11 +1603,14 @@ def bench_vi_batch(args, rank, world, local):
                     sweeps_run_min=int(sweeps.min()), sweeps_run_max=int(sweeps.max()), solves_per_s=n * args.steps / dt * world,
                     parallelism="independent MDPs sharded over {} GPU(s), no collective".format(world)),
         roofline=dict(bound="hbm", achieved=alg / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s", kernel=variant, kernel_ms=k_ms,
-                      algorithmic_bytes_per_launch=alg,
-                      note="algorithmic bytes = SURVEY 8(d) (12 S A + 17 S per sweep) x the sweeps every MDP really ran; the "
-                           "register form (S <= 4096) keeps an MDP's rows in registers and V in LDS -- it touches HBM once per solve, "
-                           "so `frac` is the rate at which the algorithm's bytes are consumed, not HBM traffic; the streaming form "
-                           "(S = 10 000) re-reads 10 B per (s, a) per sweep from L2 / MALL"),
+                      algorithmic_bytes_per_launch=alg, survey_formula_bytes_per_launch=alg_survey,
+                      survey_formula_rate_vs_hbm_peak=alg_survey / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      note="bytes = what the launch moves beyond the CU: the register form (S <= 4096) keeps an MDP's rows in "
+                           "registers and V in LDS and touches memory once per SOLVE (tables in, Q out); the streaming form "
+                           "(S = 10 000) re-reads 10 B per (s, a) and writes 8 B per state per sweep (L2 / infinity cache "
+                           "resident) after one lane-major re-layout pass.  SURVEY 8(d)'s per-sweep formula (12 S A + 17 S) x the "
+                           "sweeps really run is beside it (`survey_formula_*`): for the register form that rate exceeds the HBM peak "
+                           "because those bytes never leave the CU -- it is not HBM traffic"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     block = 1024 if "wg" in variant else int(variant.split(",")[-1].rstrip(">"))
