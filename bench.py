@@ -599,7 +599,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
     )
     if general is not None:
         res["general_model_kernel"] = general
-    if sp is not None:
+    if sp is not None and world > 1:
         # the price of the one exchange of the sharded path: HIP events from the end of the planner's kernel to the end
         # of the unpack (pack + all_gather_into_tensor + unpack), on the side stream the next launch overlaps
         ex = float(np.mean(exchange_ms)) if exchange_ms else None
@@ -1614,7 +1614,8 @@ def bench_vi_batch(args, rank, world, local):
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
     block = 1024 if "wg" in variant else int(variant.split(",")[-1].rstrip(">"))
-    add_traffic(res["roofline"], "vi_batch", "vi_det_batch", n * block, pattern="stream")
+    kernel_name = "vi_det_batch_reg" if "reg" in variant else ("vi_det_batch_wgr" if "stream" in variant else "vi_det_batch_wg<")
+    add_traffic(res["roofline"], "vi_batch", kernel_name, n * block, pattern="stream")
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         idx = sample_rows(n, 512 if s_ <= 120 else 8)

@@ -590,6 +590,26 @@ int mp_pack_rows(mp_ctx *ctx, void *stream, int32_t n_local, int32_t per, int32_
 int mp_unpack_rows(mp_ctx *ctx, void *stream, int32_t n_total, int32_t world, int32_t per, int32_t n_arrays,
                    const void *packed, const int32_t *width, void *const *dst);
 
+/*
+ * The collective itself, for a consumer that has no torch.distributed (mp_comm_init / mp_gather_results): RCCL,
+ * resolved at run time (dlopen of librccl.so.1 -- the copy already in the process if there is one, e.g. PyTorch's -- so the
+ * library has no link-time dependency on it).  One communicator per ctx, one rank per GPU.
+ *   mp_comm_unique_id: rank 0 creates the 128-byte id (ncclGetUniqueId); the caller hands it to the other ranks out of band
+ *                      (a file, a socket, MPI: whatever launched the ranks).
+ *   mp_comm_init:      ncclCommInitRank on the ctx's device; collective over all `world` ranks.
+ *   mp_gather_results: ncclAllGather of this rank's packed block (per * row_bytes bytes, from mp_pack_rows) into
+ *                      gathered [world][per][row_bytes] on `stream` (NULL: the ctx stream); device buffers, only enqueues.
+ *                      mp_unpack_rows then spreads the rows into the per-root arrays.
+ *   mp_comm_destroy:   ncclCommDestroy (also done by mp_ctx_destroy).
+ * rl_agents_amd.distributed.ShardedDevicePlan uses torch.distributed's process group instead (the host side of this
+ * package is PyTorch); tests/test_gpu_distributed.py checks that both deliver the same bytes.
+ */
+#define MP_COMM_UID_BYTES 128
+int mp_comm_unique_id(void *uid);
+int mp_comm_init(mp_ctx *ctx, int32_t rank, int32_t world, const void *uid);
+int mp_gather_results(mp_ctx *ctx, void *stream, int32_t per, int32_t row_bytes, const void *packed, void *gathered);
+int mp_comm_destroy(mp_ctx *ctx);
+
 /* ---------------------------------------------------------------- helpers ------------------- */
 /* OLOP.allocation (tree_search/olop.py:50-62) with OLOP.horizon (:42-44); host arithmetic. */
 int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t *horizon);

@@ -1,4 +1,5 @@
 // api.hip -- context, transition-model upload and host helpers of libmi355plan.so.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -500,6 +501,95 @@ int mp_unpack_rows(mp_ctx *ctx, void *stream, int32_t n_total, int32_t world, in
     return MP_OK;
 }
 
+// ---- RCCL, resolved at run time (mi355plan.h: mp_comm_*) ------------------------------------------------------------------
+extern "C++" {
+namespace {
+struct RcclUid { char b[MP_COMM_UID_BYTES]; };   // ncclUniqueId: 128 bytes, passed BY VALUE to ncclCommInitRank
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(void *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclUid, int) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int rccl_load()
+{
+    if (g_rccl.lib) return MP_OK;
+    void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);          // the copy the process already holds (PyTorch's), if any
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!h) return fail(MP_ERR_HIP, "mp_comm: librccl.so.1 not found (%s)", dlerror());
+    Rccl r;
+    r.lib = h;
+    r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+    r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+    r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(h, "ncclAllGather"));
+    r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllGather || !r.CommDestroy)
+        return fail(MP_ERR_HIP, "mp_comm: librccl.so.1 lacks an expected symbol");
+    g_rccl = r;
+    return MP_OK;
+}
+int rccl_fail(const char *what, int rc)
+{
+    return fail(MP_ERR_HIP, "%s failed: %s (ncclResult %d)", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "?", rc);
+}
+} // namespace
+} // extern "C++"
+
+int mp_comm_unique_id(void *uid)
+{
+    if (!uid) return fail(MP_ERR_ARG, "mp_comm_unique_id: uid is NULL");
+    MP_TRY(rccl_load());
+    const int rc = g_rccl.GetUniqueId(uid);
+    return rc == 0 ? MP_OK : rccl_fail("ncclGetUniqueId", rc);
+}
+
+int mp_comm_destroy(mp_ctx *ctx)
+{
+    if (!ctx) return fail(MP_ERR_ARG, "mp_comm_destroy: ctx is NULL");
+    if (ctx->comm && g_rccl.CommDestroy) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)g_rccl.CommDestroy(ctx->comm);
+    }
+    ctx->comm = nullptr;
+    ctx->comm_world = 0;
+    return MP_OK;
+}
+
+int mp_comm_init(mp_ctx *ctx, int32_t rank, int32_t world, const void *uid)
+{
+    if (!ctx || !uid) return fail(MP_ERR_ARG, "mp_comm_init: NULL argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(MP_ERR_ARG, "mp_comm_init: rank %d of %d", rank, world);
+    MP_TRY(rccl_load());
+    MP_HIP(hipSetDevice(ctx->device));
+    if (ctx->comm) MP_TRY(mp_comm_destroy(ctx));
+    RcclUid id;
+    memcpy(id.b, uid, MP_COMM_UID_BYTES);
+    void *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) return rccl_fail("ncclCommInitRank", rc);
+    ctx->comm = comm;
+    ctx->comm_world = world;
+    return MP_OK;
+}
+
+int mp_gather_results(mp_ctx *ctx, void *stream, int32_t per, int32_t row_bytes, const void *packed, void *gathered)
+{
+    if (!ctx || !packed || !gathered) return fail(MP_ERR_ARG, "mp_gather_results: NULL argument");
+    if (!ctx->comm) return fail(MP_ERR_ARG, "mp_gather_results: no communicator on this ctx (mp_comm_init)");
+    if (per < 1 || row_bytes < 1) return fail(MP_ERR_ARG, "mp_gather_results: per %d, row_bytes %d", per, row_bytes);
+    MP_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    const int rc = g_rccl.AllGather(packed, gathered, (size_t)per * row_bytes, /* ncclInt8 */ 0, ctx->comm, s);
+    return rc == 0 ? MP_OK : rccl_fail("ncclAllGather", rc);
+}
+
 int mp_seed_sequence_states(const uint32_t *entropy, int32_t n_words, int64_t first_key, int32_t count, uint64_t *out)
 {
     if (!out || n_words < 0 || (n_words && !entropy) || count < 0 || first_key < 0)
@@ -602,6 +692,7 @@ uint64_t *mp_rng_device_ptr(mp_rng *rng, int32_t first)
 
 int mp_ctx_destroy(mp_ctx *ctx)
 {
+    if (ctx && ctx->comm) (void)mp_comm_destroy(ctx);
     if (!ctx) return MP_OK;
     { std::lock_guard<std::mutex> lock(g_ctx_mutex); g_live_ctx.erase(ctx); }
     hipSetDevice(ctx->device);

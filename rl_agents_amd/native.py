@@ -43,6 +43,10 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _vp, c_i32]),
     "mp_opd_plan_models": (C.c_int, [_vp, _vp, c_i32, _vp, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      c_i32]),
+    "mp_comm_unique_id": (C.c_int, [_vp]),
+    "mp_comm_init": (C.c_int, [_vp, c_i32, c_i32, _vp]),
+    "mp_gather_results": (C.c_int, [_vp, _vp, c_i32, c_i32, _vp, _vp]),
+    "mp_comm_destroy": (C.c_int, [_vp]),
     "mp_libm_sincos_variant": (C.c_int, []),
     "mp_libm_sincos": (C.c_int, [c_i32, _vp, c_i32, _vp, _vp]),
     "mp_selftest_sincos": (C.c_int, [_vp, c_i32, _vp, c_i32, _vp, _vp]),
@@ -301,6 +305,26 @@ class Context(object):
     def last_kernel_variant(self):
         """Which kernel variant the last UCT plan launched ("uct_global", "uct_ldsr", ...)."""
         return self._lib.mp_last_kernel_variant(self._h).decode()
+
+    # ---- the collective of the C ABI (RCCL resolved at run time): what a consumer without torch.distributed calls ------------
+    @staticmethod
+    def comm_unique_id():
+        """128-byte RCCL unique id (rank 0 creates it, the caller distributes it)."""
+        uid = np.zeros(128, dtype=np.uint8)
+        _check(load().mp_comm_unique_id(_ptr(uid)))
+        return uid
+
+    def comm_init(self, rank, world, uid):
+        uid = np.ascontiguousarray(uid, dtype=np.uint8).reshape(128)
+        _check(self._lib.mp_comm_init(self._h, int(rank), int(world), _ptr(uid)))
+
+    def gather_results(self, packed, gathered, stream=None):
+        """ncclAllGather of this rank's packed rows (uint8 device tensor [per, row_bytes]) into ``gathered`` [world * per, row_bytes]."""
+        _check(self._lib.mp_gather_results(self._h, _vp(stream) if stream else None, int(packed.shape[0]), int(packed.shape[1]),
+                                           _ptr(packed), _ptr(gathered)))
+
+    def comm_destroy(self):
+        _check(self._lib.mp_comm_destroy(self._h))
 
     def selftest_sincos(self, x, variant):
         """(sin, cos) of ``x`` evaluated by the DEVICE's restated libm functions in form ``variant`` (mp_selftest_sincos)."""

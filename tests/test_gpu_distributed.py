@@ -277,3 +277,35 @@ def test_rccl_single_rank_collectives_on_product_tensors(single):
     res = _run_group(1, "nccl")
     assert res["backend"] == "nccl" and res["world"] == 1
     _assert_same(res, single)
+
+
+def test_c_abi_collective_delivers_the_same_bytes():
+    """mp_comm_unique_id / mp_comm_init / mp_gather_results (the collective for a consumer without
+    torch.distributed; RCCL resolved with dlopen) on a single-rank communicator: pack -> gather -> unpack is the identity,
+    i.e. exactly what ShardedDevicePlan's torch.distributed exchange delivers for world 1."""
+    import torch
+    from rl_agents_amd import native
+    ctx = native.Context(0)
+    dev = torch.device("cuda", 0)
+    n, mpl = 1000, 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    plans = torch.randint(-1, 5, (n, mpl), dtype=torch.int32, device=dev, generator=g)
+    value = torch.rand(n, dtype=torch.float64, device=dev, generator=g)
+    steps = torch.randint(0, 10 ** 6, (n,), dtype=torch.int64, device=dev, generator=g)
+    row = 4 * mpl + 8 + 8
+    packed = torch.empty((n, row), dtype=torch.uint8, device=dev)
+    gathered = torch.zeros((n, row), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    ctx.comm_init(0, 1, native.Context.comm_unique_id())
+    ctx.pack_rows([plans, value, steps], n, packed)
+    ctx.gather_results(packed, gathered)
+    out = [torch.empty_like(plans), torch.empty_like(value), torch.empty_like(steps)]
+    ctx.unpack_rows(gathered, n, 1, out)
+    ctx.synchronize()
+    assert torch.equal(gathered, packed)
+    assert torch.equal(out[0], plans) and torch.equal(out[1], value) and torch.equal(out[2], steps)
+    ctx.comm_destroy()
+    with pytest.raises(native.NativeError):
+        ctx.gather_results(packed, gathered)          # no communicator any more
+    ctx.close()

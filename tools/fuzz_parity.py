@@ -34,6 +34,15 @@ def random_mdp(g):
     return t, r, term
 
 
+def random_mdp_rewards(g, s, a):
+    kind = g.integers(0, 3)
+    if kind == 0:
+        return g.random((s, a))
+    if kind == 1:
+        return np.round(g.random((s, a)), 1)
+    return g.integers(0, 2, size=(s, a)).astype(np.float64)
+
+
 def rng_states(g, n):
     out = g.integers(1, 2 ** 62, size=(n, 6)).astype(np.uint64)
     out[:, 3] |= 1
@@ -61,7 +70,8 @@ def one_case(ctx, g, case):
     rng = rng_states(g, n)
     model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
     kinds = ["uct", "uct_policy", "opd", "saopd", "vi", "uct_subtree", "uct_listed", "opd_masked", "ropd",
-             "ropd_masked", "saopd_masked", "uct_stoch"]                    # (the last three: round 3)
+             "ropd_masked", "saopd_masked", "uct_stoch",                    # (the last three: round 3)
+             "vi_batch", "per_root_models", "update_rows"]                  # round 5: one MDP per episode, delta uploads
     only = os.environ.get("FUZZ_KINDS")
     if only:
         kinds = [k for k in kinds if k in only.split(",")]
@@ -79,8 +89,112 @@ def one_case(ctx, g, case):
     os.environ.pop("MP_OPD_LOOP", None)
     if int(g.integers(0, 3)) == 0:
         os.environ["MP_OPD_LOOP"] = "0"
-    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant)
-    if kind == "vi":
+    # UCT on an LDS-resident model: four lanes per root by default for 16 .. 16 384 roots; forced on / off now and then
+    os.environ.pop("MP_UCT_QUAD", None)
+    quad = str(g.choice(["", "", "0", "1"]))
+    if quad and kind in ("uct", "uct_subtree", "per_root_models", "update_rows"):
+        os.environ["MP_UCT_QUAD"] = quad
+    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad)
+    if kind in ("vi_batch", "per_root_models"):
+        # N independent MDPs of this shape (mp_model_load_table_batch): N value-iteration agents in one launch, each to its own
+        # allclose exit, in every kernel form; UCT and OPD with one MDP per root; a second round after mp_model_update_tables
+        model.close()
+        nb = int(g.choice([1, 2, 5, 33]))
+        sb = min(s, int(g.choice([1, 3, 40, 130, 700])))
+        tb = g.integers(0, sb, size=(nb, sb, a), dtype=np.int64)
+        rb = np.stack([random_mdp_rewards(g, sb, a) for _ in range(nb)]) * (10.0 ** -g.integers(0, 4, size=(nb, 1, 1)))
+        termb = g.random((nb, sb)) < g.choice([0.0, 0.1])
+        with_term = bool(g.random() < 0.8)
+        desc.update(n_models=nb, S=sb, with_term=with_term)
+        model = ctx.load_table_batch(tb, rb, termb if with_term else None, done_rule=done_rule, max_steps=max_steps)
+        tz = termb if with_term else None
+        for rnd in range(2):
+            if rnd == 1:                                               # the episodes' tables change: the per-step delta
+                lo = int(g.integers(0, nb))
+                hi = int(g.integers(lo + 1, nb + 1))
+                tb[lo:hi] = g.integers(0, sb, size=(hi - lo, sb, a))
+                rb[lo:hi] = np.stack([random_mdp_rewards(g, sb, a) for _ in range(hi - lo)])
+                if with_term:
+                    termb[lo:hi] = g.random((hi - lo, sb)) < 0.2
+                model.update_tables(lo, tb[lo:hi], rb[lo:hi], termb[lo:hi] if with_term else None)
+            if kind == "vi_batch":
+                for knob in ("MP_VI_BATCH_NO_REG", "MP_VI_BATCH_NO_WGR", "MP_VI_BATCH_NO_VLDS"):
+                    os.environ.pop(knob, None)
+                form = int(g.integers(0, 4))
+                for knob in (["MP_VI_BATCH_NO_REG"] if form >= 1 else []) + (["MP_VI_BATCH_NO_WGR"] if form >= 2 else []) + \
+                        (["MP_VI_BATCH_NO_VLDS"] if form >= 3 else []):
+                    os.environ[knob] = "1"
+                iterations = int(g.choice([0, 1, 7, 100]))
+                rew = rb * float(g.choice([1.0, -1.0, 10.0]))
+                if form or rnd:                                        # (other rewards than the model's: reload)
+                    m2 = ctx.load_table_batch(tb, rew, tz)
+                else:
+                    m2 = ctx.load_table_batch(tb, rew, tz)
+                try:
+                    q, sweeps = ctx.vi_solve_batch(m2, gamma, iterations)
+                finally:
+                    m2.close()
+                    for knob in ("MP_VI_BATCH_NO_REG", "MP_VI_BATCH_NO_WGR", "MP_VI_BATCH_NO_VLDS"):
+                        os.environ.pop(knob, None)
+                q_ref, sw_ref = oracle.vi_solve_each(tb, rew, tz, gamma=gamma, iterations=iterations)
+                desc.update(iterations=iterations, form=form)
+                eq(sweeps, sw_ref, "sweeps per MDP", desc)
+                eq(q, q_ref, "Q per MDP", desc)
+            else:
+                nr = min(n, 70)
+                mi = g.integers(0, nb, size=nr).astype(np.int32)
+                sl = g.integers(0, sb, size=nr).astype(np.int32)
+                st0 = g.integers(0, 4, size=nr).astype(np.int32) if max_steps else None
+                if 2 <= a <= 8 or a in (1, 9, 13):
+                    episodes, horizon = int(g.choice([1, 6, 30])), int(g.choice([1, 5, 12]))
+                    pp = g.random(a) + 0.05
+                    pp /= pp.sum()
+                    rr, rr_ref = rng[:nr].copy(), rng[:nr].copy()
+                    out = ctx.uct_plan(model, sl, episodes, horizon, gamma, 5.0, pp, pp, rr, root_steps=st0, max_plan_len=max(horizon, 1),
+                                       model_index=mi)
+                    ref = oracle.uct_plan_each(tb, rb, tz if tz is not None else np.zeros((nb, sb), bool), mi, sl, episodes, horizon, gamma,
+                                               5.0, pp, pp, rr_ref, max_plan_len=max(horizon, 1), steps0=st0, max_steps=max_steps,
+                                               done_rule=done_rule)
+                    for k in ("plans", "plan_len", "root_value", "root_child_count", "env_steps"):
+                        eq(out[k], ref[k], "per-root-model UCT " + k, desc)
+                    eq(rr, ref["rng_after"], "per-root-model UCT generator", desc)
+                if float(rb.min()) >= 0.0 and float(rb.max()) <= 1.0 and gamma < 1.0:
+                    budget = int(g.choice([a, 3 * a, 40 * a]))
+                    rr, rr_ref = rng[:nr].copy(), rng[:nr].copy()
+                    out = ctx.opd_plan(model, sl, budget, gamma, 0.0, rr, max_plan_len=16, model_index=mi)
+                    ref = oracle.opd_plan_each(tb, rb, tz if tz is not None else np.zeros((nb, sb), bool), mi, sl, budget, gamma, 0.0, rr_ref,
+                                               max_plan_len=16, done_rule=done_rule)
+                    for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status"):
+                        eq(out[k], ref[k], "per-root-model OPD " + k, desc)
+                    eq(rr, ref["rng_after"], "per-root-model OPD generator", desc)
+    elif kind == "update_rows":
+        # delta upload (mp_model_update_rows): rows replaced in place, with and without terminal flags, rewards that stay in /
+        # leave the table of distinct values -- then every planner must see exactly the edited tables
+        t2, r2, term2 = t.copy(), r.copy(), term.copy()
+        for rnd in range(2):
+            k = int(g.integers(1, max(2, s // 3 + 1)))
+            rows = g.choice(s, size=min(k, s), replace=False).astype(np.int32)
+            t2[rows] = g.integers(0, s, size=(len(rows), a))
+            r2[rows] = g.choice(np.unique(r), size=(len(rows), a)) if g.random() < 0.5 else g.random((len(rows), a))
+            flags = bool(g.random() < 0.5)
+            if flags:
+                term2[rows] = g.random(len(rows)) < 0.3
+            model.update_rows(rows, t2[rows], r2[rows], term2[rows] if flags else None)
+            q, sweeps = ctx.vi_solve(model, gamma, 30)
+            q_ref, sw_ref = oracle.vi_solve("deterministic", t2, r2, term2, gamma=gamma, iterations=30)
+            eq(q, q_ref, "Q after update_rows", desc)
+            if sweeps != sw_ref:
+                raise AssertionError("sweeps {} vs {} in case {}".format(sweeps, sw_ref, desc))
+            if 2 <= a <= 8:
+                pp = np.ones(a) / a
+                rr, rr_ref = rng.copy(), rng.copy()
+                out = ctx.uct_plan(model, s0, 12, 6, gamma, 5.0, pp, pp, rr, max_plan_len=6)
+                ref = oracle.uct_plan_batch(t2, r2, term2, s0, 12, 6, gamma, 5.0, pp, pp, rr_ref, max_steps=max_steps, done_rule=done_rule,
+                                            max_plan_len=6)
+                for kk in ("plans", "root_value", "env_steps"):
+                    eq(out[kk], ref[kk], "UCT after update_rows " + kk, desc)
+                eq(rr, ref["rng_after"], "UCT generator after update_rows", desc)
+    elif kind == "vi":
         model.close()
         iterations = int(g.choice([1, 7, 100, 300]))
         rewards = r * float(g.choice([1.0, -1.0, 10.0]))             # VI takes any reward range
@@ -508,6 +622,7 @@ def run(n_cases, seed, ctx=None, verbose=False):
         os.environ.pop("MP_OPD_MODEL", None)
         os.environ.pop("MP_OPD_CLOSING", None)
         os.environ.pop("MP_OPD_LOOP", None)
+        os.environ.pop("MP_UCT_QUAD", None)
         if forced is not None:
             os.environ["MP_OPD_MODEL"] = forced
     if own:
