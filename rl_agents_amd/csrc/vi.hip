@@ -1442,7 +1442,7 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wg(ViBatchArgs p)
     constexpr int NB = VLDS ? 2 : 3;
     for (int i = tid; i < NB * S; i += nt) Vb[i] = 0.0;
     __syncthreads();
-    constexpr int AR = AT > 0 ? AT : 64;
+    constexpr int AR = AT > 0 ? AT : 1;
     auto qrow = [&](const double *V, int s, bool term_s, double *out) {
         const long sa0 = (base + s) * A;
         if (AT > 0) {
@@ -1467,16 +1467,29 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wg(ViBatchArgs p)
         int o = 0;
         for (int s = tid; s < S; s += nt, ++o) {
             const bool term_s = p.term ? p.term[base + s] != 0 : false;
-            double qn[AR], qo[AR];
-            qrow(Vcur, s, term_s, qn);
-            if (k > 0) qrow(Vprev, s, term_s, qo);
-            double vmax = qn[0];
+            double vmax = 0.0;
+            if (AT > 0) {
+                double qn[AR], qo[AR];
+                qrow(Vcur, s, term_s, qn);
+                if (k > 0) qrow(Vprev, s, term_s, qo);
+                vmax = qn[0];
 #pragma unroll
-            for (int a = 0; a < AR; ++a)
-                if (a < A) {
-                    nc |= !isclose_np(k == 0 ? 0.0 : qo[a], qn[a], p.rtol, p.atol);
-                    if (a > 0 && qn[a] > vmax) vmax = qn[a];
+                for (int a = 0; a < AR; ++a)
+                    if (a < A) {
+                        nc |= !isclose_np(k == 0 ? 0.0 : qo[a], qn[a], p.rtol, p.atol);
+                        if (a > 0 && qn[a] > vmax) vmax = qn[a];
+                    }
+            } else { // any number of actions: one (s, a) at a time
+                const long sa0 = (base + s) * A;
+                for (int a = 0; a < A; ++a) {
+                    const int tn = p.T[sa0 + a] - (int32_t)base;
+                    const double r = p.R[sa0 + a];
+                    const double qn = r + p.gamma * (term_s ? 0.0 : Vcur[tn]);
+                    const double qo = k == 0 ? 0.0 : r + p.gamma * (term_s ? 0.0 : Vprev[tn]);
+                    nc |= !isclose_np(qo, qn, p.rtol, p.atol);
+                    if (a == 0 || qn > vmax) vmax = qn;
                 }
+            }
             if (VLDS) {
 #pragma unroll
                 for (int i = 0; i < kViBatchOwn; ++i) vown[i] = o == i ? vmax : vown[i];
@@ -1502,9 +1515,15 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wg(ViBatchArgs p)
         const double *Vjm1 = Vb + (long)(VLDS ? ((j + 1) & 1) : ((j + 2) % 3)) * S;
         for (int s = tid; s < S; s += nt) {
             const bool term_s = p.term ? p.term[base + s] != 0 : false;
-            double qj[AR];
-            if (j > 0) qrow(Vjm1, s, term_s, qj);
-            for (int a = 0; a < A; ++a) p.Q_out[(base + s) * A + a] = j == 0 ? 0.0 : qj[a];
+            if (AT > 0) {
+                double qj[AR];
+                if (j > 0) qrow(Vjm1, s, term_s, qj);
+                for (int a = 0; a < A; ++a) p.Q_out[(base + s) * A + a] = j == 0 ? 0.0 : qj[a];
+            } else {
+                const long sa0 = (base + s) * A;
+                for (int a = 0; a < A; ++a)
+                    p.Q_out[sa0 + a] = j == 0 ? 0.0 : p.R[sa0 + a] + p.gamma * (term_s ? 0.0 : Vjm1[p.T[sa0 + a] - (int32_t)base]);
+            }
         }
     }
 }
@@ -1711,7 +1730,6 @@ static int vi_solve_batch(mp_ctx *ctx, mp_model *m, double gamma, int iterations
     MP_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const int N = m->NB, Sb = m->Sb > 0 ? m->Sb : m->S, A = m->A;
-    if (A > 64) return fail(MP_ERR_ARG, "mp_vi_solve_batch: |A| = %d > 64", A);
     const size_t nq = (size_t)N * Sb * A;
     double *dQ = nullptr;
     int32_t *dSw = nullptr;
