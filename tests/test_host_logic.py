@@ -530,3 +530,19 @@ def test_restated_sincos_equals_host_libm():
     assert ok == 1 and other in (1, 2)
     if variant == 1:
         assert other == 2, "with FMA masked off glibc must select (and the probe find) the uncontracted form"
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is the checker, never the thing shipped: no module of the package (nor its C / HIP sources) imports,
+    includes or loads anything under oracle/ -- only tests/, tools/, __graft_entry__.smoke() and the benchmark may."""
+    import re
+    pkg = os.path.join(REPO, "rl_agents_amd")
+    bad = []
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if not f.endswith((".py", ".hip", ".hpp", ".h", ".c", ".cpp")):
+                continue
+            text = open(os.path.join(root, f), errors="replace").read()
+            if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<][^\">]*oracle|planning_oracle|liboracle", text, re.M):
+                bad.append(os.path.relpath(os.path.join(root, f), REPO))
+    assert not bad, bad
