@@ -44,6 +44,7 @@ namespace mp {
 struct OpdArgs {
     int n_roots, S, A, K, cap, done_on_next, max_plan_len;
     int T; // row length of a residue class: odd, >= ceil(cap / 64)
+    int Tsib, lgP; // opd_wide_kernel<SIB>: row length of the sibling layout, log2 of a sibling group's slots
     int chunk; // opd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
     int closing_chain; // opd_kernel: 1 = the node-array closing passes even where opd_closing.hpp fits (MP_OPD_CLOSING=chain: test hook)
     const Rec *rec;
@@ -431,11 +432,12 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 // skips the leaf in registers -- five vector-memory instructions per expansion instead of nine, but ten more VALU
 // instructions for the lane roles: 3.66 ms against 3.49 at 8192 roots.  TA_BUSY did not move (74 %): it counts a unit
 // with requests in flight, not a unit out of issue slots.
-template <bool NONNEG>
+template <bool NONNEG, bool SMALLT, bool SIB>
 __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int T = p.T;
+    const int T = SIB ? p.Tsib : p.T;
+    const int lgP = p.lgP, P = 1 << lgP; // SIB: a sibling group's slots, a power of two >= |A|
     double *leafU = p.leaf_global + (long)blockIdx.x * 64 * T;
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x, root = blockIdx.x, A = p.A;
@@ -451,87 +453,267 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         n0.L = 0.0; n0.state = p.root_state[root]; n0.depth = 0;
         NA[0] = n0;
         RW[0] = 0.0;
-        LU(0) = 0.0;
+        if (!SIB) LU(0) = 0.0;
     }
+    if (SIB && lane < P) leafU[lane] = lane == 0 ? 0.0 : ninf; // group 0 of row 0: the root and its padding
     __syncthreads();
     int n_nodes = 1, real_mine = 0, status = MP_OK, k_done = 0;
     double cbu = lane == 0 ? 0.0 : ninf;
-    int cbid = lane == 0 ? 0 : 0x7fffffff;
+    int cbid0 = lane == 0 ? 0 : 0x7fffffff; // (SIB: the root's code is 0 as well)
 
+    bool drain_ok = false;
+    int drain_hi = 0, drain_lo = 0;
+    if constexpr (SIB) {
+    // ---- sibling layout.  The bounds array has 64 rows; the |A| children of expansion k sit TOGETHER, in group
+    // e = k + 1 (group 0 holds the root): row e mod 64, slots (e / 64) * P .. + P - 1 (unused slots -inf), so an expansion
+    // writes its children's bounds as ONE aligned 64-byte request (|A| <= 8) where the residue-class layout scattered
+    // them over |A| rows -- this kernel waits on the L1's outstanding requests three quarters of the time, most of them
+    // partial-line writes (profiles/r05_opd_wide.md).  A leaf is named by its code e * P + j, ordered like the ids.
+    // Lane l caches the best leaf of row l; the children of an expansion all belong to ONE row.
+    const int cb0 = (((lane >> lgP) << 6) << lgP) | (lane & (P - 1));          // code of slot t = lane of row 0 ...
+    const int cb1 = ((((lane + 64) >> lgP) << 6) << lgP) | (lane & (P - 1));   // ... and of slot lane + 64
+    int cbid = cbid0;
     for (int k = 0; k < p.K; ++k) {
-        // ---- deterministic.py:110: first maximal upper bound among the leaves
-        double bu = cbu;
-        int leaf = cbid;
-        if (NONNEG) wave_argmax_keys_nonneg(bu, leaf); else wave_argmax_keys(bu, leaf);
-        const int cls = leaf & 63;
-        const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
-        // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry
-        if (lane == 0) LU(leaf) = __hiloint2double((int)0xFFF80000, k);
-        __syncthreads(); // the re-scan reads that slot through memory, from another lane
+        // ---- deterministic.py:110: first maximal upper bound among the leaves (see the residue-class loop below)
+        int leaf;
         {
-            const double *row = leafU + cls * T;
-            const int cnt = (n_nodes - cls + 63) >> 6;
+            unsigned long long cand = drain_ok ? __ballot(__double2hiint(cbu) == drain_hi && __double2loint(cbu) == drain_lo) : 0ull;
+            if (cand == 0ull) { // (wave-uniform) a new maximum: the first two reductions
+                int kh; unsigned kl;
+                if (NONNEG) { kh = __double2hiint(cbu); kl = (unsigned)__double2loint(cbu); if (kh < 0) kh = 0; }
+                else { const double uc = cbu + 0.0; const int hi = __double2hiint(uc), sg = hi >> 31; kh = hi ^ (sg & 0x7fffffff); kl = (unsigned)(__double2loint(uc) ^ sg); }
+                int mh = kh;
+                MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
+                mh = __builtin_amdgcn_readlane(mh, 63);
+                const bool c1 = (NONNEG ? __double2hiint(cbu) : kh) == mh;
+                unsigned l1 = c1 ? kl : 0u;
+                MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
+                const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+                cand = __ballot(c1 && kl == ml);
+                if (NONNEG) { drain_hi = mh; drain_lo = (int)ml; }
+                else { const int ms = mh >> 31; drain_hi = mh ^ (ms & 0x7fffffff); drain_lo = (int)(ml ^ (unsigned)ms); }
+                drain_ok = true;
+            }
+            if (__popcll(cand) == 1) leaf = __builtin_amdgcn_readlane(cbid, __ffsll((long long)cand) - 1);
+            else {
+                int i2 = ((cand >> lane) & 1ull) ? cbid : 0x7fffffff;
+                MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
+                leaf = __builtin_amdgcn_readlane(i2, 63);
+            }
+        }
+        const int leaf_s = __builtin_amdgcn_readfirstlane(leaf);
+        const int el = leaf_s >> lgP, jl = leaf_s & (P - 1);
+        const int cls = el & 63;
+        const int leaf_id = el == 0 ? 0 : 1 + (el - 1) * A + jl;
+        const double *row = leafU + cls * T;
+        // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry (one lane, one request)
+        if (lane == 0) leafU[cls * T + ((el >> 6) << lgP) + jl] = __hiloint2double((int)0xFFF80000, k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (a wavefront's vector-memory operations are performed in order)
+        const int cnt = (((k - cls) >> 6) + 1) << lgP; // groups e <= k of this row
+        double u0 = ninf, u1 = ninf;
+        typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+        u32x4 lr;
+        const OpdNode *lp = NA + leaf_id;
+        if (SMALLT) {
+            u0 = row[lane < cnt ? lane : 0];
+            if (cnt > 64) {
+                u1 = row[lane + 64 < cnt ? lane + 64 : 0];
+                asm volatile("s_waitcnt vmcnt(3)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(1)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+        }
+        OpdNode pn;
+        pn.L = __hiloint2double((int)lr.y, (int)lr.x); pn.state = (int32_t)lr.z; pn.depth = (int32_t)lr.w;
+        const bool mine = lane < A;
+        Rec rc;
+        rc.next = 0; rc.flags = 0; rc.reward = 0.0;
+        if (mine) rc = (p.rec + (long)pn.state * A)[lane];
+        {
             double ru = ninf;
             int rid = 0x7fffffff;
-            if (T <= 128) { // at most two entries per lane (budget 5000: 79 per class): no loop, both reads unconditional
-                const double u0 = row[lane < cnt ? lane : 0], u1 = row[lane + 64 < cnt ? lane + 64 : 0];
-                if (lane < cnt && u0 > ru) { ru = u0; rid = cls + (lane << 6); }
-                if (lane + 64 < cnt && u1 > ru) { ru = u1; rid = cls + ((lane + 64) << 6); }
+            const int cshift = cls << lgP;
+            if (SMALLT) {
+                if (lane < cnt && u0 > ru) { ru = u0; rid = cb0 | cshift; }
+                if (cnt > 64 && lane + 64 < cnt && u1 > ru) { ru = u1; rid = cb1 | cshift; }
             } else {
-                for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip
-                    const double u0 = row[t];
-                    const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
-                    if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
-                    if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+                for (int t = lane; t < cnt; t += 64) {
+                    const double v0 = row[t];
+                    if (v0 > ru) { ru = v0; rid = ((((t >> lgP) << 6) << lgP) | (t & (P - 1))) | cshift; }
                 }
             }
             if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
-        // ---- DeterministicNode.expand, deterministic.py:28-43
-        OpdNode pn;
-        pn.L = __hiloint2double((int)leaf_raw.y, (int)leaf_raw.x); pn.state = (int32_t)leaf_raw.z; pn.depth = (int32_t)leaf_raw.w;
         const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
         typedef const double __attribute__((address_space(4))) *scalar_f64;
         const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
                      tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
-        const int g = n_nodes;
-        bool bad = false, avail = false;
-        double Uc_mine = 0.0;
-        if (lane < A) {
-            const Rec rc = p.rec[(long)pn.state * A + lane];
-            const double r = rc.reward;
-            avail = (rc.flags & 4u) != 0;                 // deterministic.py:32-35 (phantom slots: see opd_kernel)
-            bad = avail && (!(0.0 <= r) || !(r <= 1.0));  // deterministic.py:46-47
-            const bool dn = (rc.flags & done_bit) != 0;
-            double Lc = pn.L + g1d * r;                   // deterministic.py:45-65 update()
-            double Uc = Lc + gdivd;
-            if (dn) {
-                const double nv = Lc + tdivd;
-                Lc = nv; Uc = nv;
-            }
-            if (!avail) { Lc = ninf; Uc = ninf; }
-            const int c = g + lane;
+        double r = rc.reward;
+        asm volatile("" : "+v"(r));
+        const bool avail = mine && (rc.flags & 4u) != 0;    // deterministic.py:32-35 (phantom slots: see opd_kernel)
+        const bool bad = avail && (!(0.0 <= r) || !(r <= 1.0)); // deterministic.py:46-47
+        const bool dn = (rc.flags & done_bit) != 0;
+        double Lc = pn.L + g1d * r;                       // deterministic.py:45-65 update()
+        double Uc = Lc + gdivd;
+        if (dn) {
+            const double nv = Lc + tdivd;
+            Lc = nv; Uc = nv;
+        }
+        if (!avail) { Lc = ninf; Uc = ninf; }
+        const int e = k + 1, re = e & 63;
+        if (mine) {
+            const int c = n_nodes + lane;
             OpdNode cn;
             cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
             NA[c] = cn;
             RW[c] = r;
-            LU(c) = Uc;
-            Uc_mine = Uc;
+        }
+        if (lane < P) leafU[re * T + ((e >> 6) << lgP) + lane] = Uc; // the whole group: children, then -inf
+        n_nodes += A;
+        real_mine += avail ? 1 : 0;
+        k_done = k + 1;
+        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the next re-scan may read these children through memory, from other lanes
+        // the children against the best of THEIR row (lane re)
+        const double cbu_re = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cbu), re), __builtin_amdgcn_readlane(__double2loint(cbu), re));
+        if (__any(mine && Uc > cbu_re)) { // (wave-uniform)
+            const double um = mine ? Uc : ninf;
+            const double m = A <= 16 ? row0_max(um) : wave_max(um);
+            const int jm = __ffsll((long long)__ballot(mine && Uc == m)) - 1; // lowest id among equal bounds
+            if (lane == re) { cbu = m; cbid = (e << lgP) + jm; }
+            // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma)
+            // can land an ulp above gamma^(d-1) / (1 - gamma))
+            if (m > __hiloint2double(drain_hi, drain_lo)) drain_ok = false;
+        }
+    }
+    cbid0 = cbid;
+    } else {
+    int cbid = cbid0;
+    for (int k = 0; k < p.K; ++k) {
+        // ---- deterministic.py:110: first maximal upper bound among the leaves
+        // The maximum M found by a full selection stays THE maximum for as long as some class best still equals it: no
+        // bound above it can appear without being noticed (a re-scan returns a leaf that was already there; children are
+        // compared with M below).  OPD's trees are full of exact ties -- on the benchmark tables nine selections in ten
+        // pick among leaves that share the bound of the previous one -- so the usual selection is only the third of
+        // the three reductions: the lowest id among the lanes that hold M.
+        int leaf;
+        {
+            unsigned long long cand = drain_ok ? __ballot(__double2hiint(cbu) == drain_hi && __double2loint(cbu) == drain_lo) : 0ull;
+            if (cand == 0ull) { // (wave-uniform) a new maximum: the first two reductions
+                int kh; unsigned kl;
+                if (NONNEG) { kh = __double2hiint(cbu); kl = (unsigned)__double2loint(cbu); if (kh < 0) kh = 0; }
+                else { const double uc = cbu + 0.0; const int hi = __double2hiint(uc), sg = hi >> 31; kh = hi ^ (sg & 0x7fffffff); kl = (unsigned)(__double2loint(uc) ^ sg); }
+                int mh = kh;
+                MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
+                mh = __builtin_amdgcn_readlane(mh, 63);
+                const bool c1 = (NONNEG ? __double2hiint(cbu) : kh) == mh;
+                unsigned l1 = c1 ? kl : 0u;
+                MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
+                const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+                cand = __ballot(c1 && kl == ml);
+                if (NONNEG) { drain_hi = mh; drain_lo = (int)ml; }
+                else { const int ms = mh >> 31; drain_hi = mh ^ (ms & 0x7fffffff); drain_lo = (int)(ml ^ (unsigned)ms); }
+                drain_ok = true;
+            }
+            if (__popcll(cand) == 1) leaf = __builtin_amdgcn_readlane(cbid, __ffsll((long long)cand) - 1);
+            else {
+                int i2 = ((cand >> lane) & 1ull) ? cbid : 0x7fffffff;
+                MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
+                leaf = __builtin_amdgcn_readlane(i2, 63);
+            }
+        }
+        const int leaf_s = __builtin_amdgcn_readfirstlane(leaf);
+        const int cls = leaf_s & 63;
+        // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry (one lane, one request)
+        if (lane == 0) LU(leaf_s) = __hiloint2double((int)0xFFF80000, k);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (a wavefront's vector-memory operations are performed in order)
+        const double *row = leafU + cls * T;
+        const int cnt = (n_nodes - cls + 63) >> 6;
+        double u0 = ninf, u1 = ninf;
+        // The leaf's record is wave-uniform: a SCALAR load (no address-coalescer time, results in scalar registers), past the
+        // scalar cache (glc: the record was written by this wave's vector stores, the scalar cache does not see those).  The
+        // stores that wrote it are the previous expansion's at the latest: vmcnt(N), N = the vector-memory operations of THIS
+        // expansion issued so far, waits for exactly those.
+        typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
+        u32x4 lr;
+        const OpdNode *lp = NA + leaf_s;
+        if (SMALLT) {
+            u0 = row[lane < cnt ? lane : 0];
+            if (cnt > 64) {
+                u1 = row[lane + 64 < cnt ? lane + 64 : 0];
+                asm volatile("s_waitcnt vmcnt(3)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(2)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+            }
+        } else {
+            asm volatile("s_waitcnt vmcnt(1)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+        }
+        OpdNode pn;
+        pn.L = __hiloint2double((int)lr.y, (int)lr.x); pn.state = (int32_t)lr.z; pn.depth = (int32_t)lr.w;
+        const int g = n_nodes;
+        const int j = (lane - g) & 63; // child j is computed by lane (g + j) mod 64, the owner of its class
+        const bool mine = j < A;
+        Rec rc;
+        rc.next = 0; rc.flags = 0; rc.reward = 0.0;
+        if (mine) rc = (p.rec + (long)pn.state * A)[j];
+        {
+            double ru = ninf;
+            int rid = 0x7fffffff;
+            if (SMALLT) {
+                if (lane < cnt && u0 > ru) { ru = u0; rid = cls + (lane << 6); }
+                if (cnt > 64 && lane + 64 < cnt && u1 > ru) { ru = u1; rid = cls + ((lane + 64) << 6); }
+            } else {
+                for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip
+                    const double v0 = row[t];
+                    const double v1 = t + 64 < cnt ? row[t + 64] : ninf;
+                    if (v0 > ru) { ru = v0; rid = cls + (t << 6); }
+                    if (v1 > ru) { ru = v1; rid = cls + ((t + 64) << 6); }
+                }
+            }
+            if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
+            if (lane == cls) { cbu = ru; cbid = rid; }
+        }
+        const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
+        typedef const double __attribute__((address_space(4))) *scalar_f64;
+        const double g1d = ((scalar_f64)(unsigned long long)p.g1)[d], gdivd = ((scalar_f64)(unsigned long long)p.gdiv)[d],
+                     tdivd = ((scalar_f64)(unsigned long long)p.tdiv)[d];
+        // (computed by every lane -- lanes >= |A| on a copy of the last record, discarded -- so that the wait for the
+        // records sits in straight-line code and only the three stores are conditional)
+        double r = rc.reward;
+        asm volatile("" : "+v"(r));
+        const bool avail = mine && (rc.flags & 4u) != 0;    // deterministic.py:32-35 (phantom slots: see opd_kernel)
+        const bool bad = avail && (!(0.0 <= r) || !(r <= 1.0)); // deterministic.py:46-47
+        const bool dn = (rc.flags & done_bit) != 0;
+        double Lc = pn.L + g1d * r;                       // deterministic.py:45-65 update()
+        double Uc = Lc + gdivd;
+        if (dn) {
+            const double nv = Lc + tdivd;
+            Lc = nv; Uc = nv;
+        }
+        if (!avail) { Lc = ninf; Uc = ninf; }
+        const double Uc_mine = Uc;
+        const int c = g + j;
+        if (mine) {
+            OpdNode cn;
+            cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
+            NA[c] = cn;
+            RW[c] = r;
+            leafU[__umul24(lane, T) + (c >> 6)] = Uc;     // = LU(c): c mod 64 is this lane
         }
         n_nodes += A;
         real_mine += avail ? 1 : 0;
         k_done = k + 1;
         if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads(); // the next re-scan may read these children through memory, from other lanes
-        {
-            const int j = (lane - g) & 63;
-            const double u = __shfl(Uc_mine, j & 63);
-            if (j < A) {
-                const int id = g + j;
-                if (u > cbu) { cbu = u; cbid = id; }
-            }
-        }
+        // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma) can
+        // land an ulp above gamma^(d-1) / (1 - gamma))
+        if (__any(mine && Uc_mine > __hiloint2double(drain_hi, drain_lo))) drain_ok = false;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the next re-scan may read these children through memory, from other lanes
+        if (mine && Uc_mine > cbu) { cbu = Uc_mine; cbid = c; }
+    }
+    cbid0 = cbid;
     }
     __syncthreads();
 
@@ -552,11 +734,47 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
     // closing pass over the bounds array: leaf upper bounds out, the root's upper bound, and the parent map scattered from
     // the NaN payloads (every expanded node carries its k)
     double root_upper = ninf;
-    for (int i = lane; i < n_nodes; i += 64) {
-        const double u = LU(i);
-        U[i] = u != u ? ninf : u; // (-inf marks an expanded node for the export, as in the other variants)
-        if (u > root_upper) root_upper = u;
-        if (u != u) exp_map[__double2loint(u)] = i;
+    if constexpr (SIB) {
+        // (four rows per trip: up to eight independent reads in flight; the slots of a row that no group has reached yet
+        // are skipped by index, whatever they hold)
+        auto emit = [&](int r, int t, int cnt, double u) {
+            const int e = ((t >> lgP) << 6) | r, jj = t & (P - 1);
+            if (t < cnt && jj < A && (e > 0 || jj == 0)) {
+                const int id = e == 0 ? 0 : 1 + (e - 1) * A + jj;
+                U[id] = u != u ? ninf : u;
+                if (u > root_upper) root_upper = u;
+                if (u != u) exp_map[__double2loint(u)] = id;
+            }
+        };
+        for (int r0 = 0; r0 < 64 && r0 <= k_done; r0 += 4) {
+            int cnt[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) cnt[a] = r0 + a <= k_done ? (((k_done - r0 - a) >> 6) + 1) << lgP : 0;
+            if (SMALLT) {
+                double uu[4][2];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    uu[a][0] = leafU[(r0 + a) * T + lane];
+                    uu[a][1] = leafU[(r0 + a) * T + (lane + 64 < T ? lane + 64 : lane)];
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    emit(r0 + a, lane, cnt[a], uu[a][0]);
+                    emit(r0 + a, lane + 64, cnt[a], uu[a][1]);
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    for (int t = lane; t < cnt[a]; t += 64) emit(r0 + a, t, cnt[a], leafU[(r0 + a) * T + t]);
+            }
+        }
+    } else {
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = LU(i);
+            U[i] = u != u ? ninf : u; // (-inf marks an expanded node for the export, as in the other variants)
+            if (u > root_upper) root_upper = u;
+            if (u != u) exp_map[__double2loint(u)] = i;
+        }
     }
     root_upper = wave_max(root_upper);
     __syncthreads();
@@ -601,7 +819,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
             const double l = lane < A ? NA[fc + lane].L : ninf;
-            const double slot = lane < A ? LU(fc + lane) : 0.0;
+            const double slot = lane >= A ? 0.0 : SIB ? leafU[((kcur + 1) & 63) * T + (((kcur + 1) >> 6) << lgP) + lane] : LU(fc + lane);
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -856,7 +1074,15 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     OpdArgs a;
-    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk;
+    // high-occupancy variant, sibling layout (default; MP_OPD_WIDE=cls: the residue-class layout): groups of P = 2^lgP >= |A| slots,
+    // ceil((K + 1) / 64) groups per row, one cache line of padding so that rows do not all start in the same channels
+    int lgP = 0;
+    while ((1 << lgP) < A) ++lgP;
+    const int groups = (K + 1 + 63) / 64;
+    const int Tsib = (groups << lgP) + ((1 << lgP) > 16 ? (1 << lgP) : 16);
+    const char *wide_env = getenv("MP_OPD_WIDE");
+    const bool sib = !(wide_env && wide_env[0] == 'c');
+    a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk; a.Tsib = Tsib; a.lgP = lgP;
     { const char *cl = getenv("MP_OPD_CLOSING"); a.closing_chain = cl && cl[0] == 'c'; }
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec;
@@ -866,7 +1092,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(ws_get(ctx, WS_TREE1, nn, &a.U));
     MP_TRY(ws_get(ctx, WS_TREE2, nn, &a.reward));
     a.leaf_global = nullptr;
-    if (glb && !any_a) MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots * 64 * T, &a.leaf_global));
+    if (glb && !any_a) MP_TRY(ws_get(ctx, WS_TREE3, (size_t)n_roots * 64 * (sib ? Tsib : T), &a.leaf_global));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
     a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
     ctx->tree.kind = 2; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
@@ -891,8 +1117,15 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     if (!any_a && lds > 64 * 1024) MP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     MP_TRY(kernels_begin(ctx));
     if (any_a) hipLaunchKernelGGL(opd_any_kernel, dim3((unsigned)n_roots), dim3(64), 0, st, a);
-    else if (glb && nonneg) hipLaunchKernelGGL(opd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else if (glb) hipLaunchKernelGGL(opd_wide_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (glb) {
+        const bool small = sib ? (groups << lgP) <= 128 : a.T <= 128; // at most two slots per lane in a re-scan
+        void (*kw)(OpdArgs) =
+            sib ? (nonneg ? (small ? opd_wide_kernel<true, true, true> : opd_wide_kernel<true, false, true>)
+                          : (small ? opd_wide_kernel<false, true, true> : opd_wide_kernel<false, false, true>))
+                : (nonneg ? (small ? opd_wide_kernel<true, true, false> : opd_wide_kernel<true, false, false>)
+                          : (small ? opd_wide_kernel<false, true, false> : opd_wide_kernel<false, false, false>));
+        hipLaunchKernelGGL(kw, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    }
     else if (expg && nonneg) hipLaunchKernelGGL((opd_kernel<true, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (expg) hipLaunchKernelGGL((opd_kernel<true, false>), dim3((unsigned)n_roots), dim3(64), lds, st, a);
     else if (nonneg) hipLaunchKernelGGL((opd_kernel<false, true>), dim3((unsigned)n_roots), dim3(64), lds, st, a);

@@ -147,10 +147,33 @@ __device__ __forceinline__ void wave_argmax_keys_nonneg(double &u, int &id)
     kh = imax_step_zero<0x118>(kh); kh = imax_step_zero<0x142>(kh); kh = imax_step_zero<0x143>(kh);
     const int mh = __builtin_amdgcn_readlane(kh, 63);
     const bool c1 = hi == mh;
+#ifndef MP_ARGMAX_NO_EARLY_EXIT
+    // ONE lane holds the maximal high word (the usual case: 20 mantissa bits rarely tie between leaves): the pair is that
+    // lane's, read with two readlanes instead of twelve more reduction steps.  Wave-uniform branch.
+    {
+        const unsigned long long b1 = __ballot(c1);
+        if (__popcll(b1) == 1) {
+            const int src = __ffsll((long long)b1) - 1;
+            id = __builtin_amdgcn_readlane(id, src);
+            u = __hiloint2double(mh, __builtin_amdgcn_readlane((int)lo, src));
+            return;
+        }
+    }
+#endif
     unsigned l1 = c1 ? lo : 0u;
     l1 = umax_step_zero<0x111>(l1); l1 = umax_step_zero<0x112>(l1); l1 = umax_step_zero<0x114>(l1);
     l1 = umax_step_zero<0x118>(l1); l1 = umax_step_zero<0x142>(l1); l1 = umax_step_zero<0x143>(l1);
     const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+#ifndef MP_ARGMAX_NO_EARLY_EXIT
+    {
+        const unsigned long long b2 = __ballot(c1 && lo == ml);
+        if (__popcll(b2) == 1) {
+            id = __builtin_amdgcn_readlane(id, __ffsll((long long)b2) - 1);
+            u = __hiloint2double(mh, (int)ml);
+            return;
+        }
+    }
+#endif
     int key = (c1 && lo == ml) ? 0x7fffffff - id : 0;
     key = imax_step_zero<0x111>(key); key = imax_step_zero<0x112>(key); key = imax_step_zero<0x114>(key);
     key = imax_step_zero<0x118>(key); key = imax_step_zero<0x142>(key); key = imax_step_zero<0x143>(key);
@@ -177,13 +200,24 @@ __device__ __forceinline__ void argmax_keys(double &u, int &id)
     if (ROW0) { MP_DPP_REDUCE_ROW("v_max_i32_dpp", kh); } else { MP_DPP_REDUCE_WAVE("v_max_i32_dpp", kh); }
     const int mh = __builtin_amdgcn_readlane(kh, ROW0 ? 15 : 63);
     const bool c1 = kh_own == mh;
+    const int ms = mh >> 31;
+#ifndef MP_ARGMAX_NO_EARLY_EXIT
+    if (!ROW0) {          // one lane holds the maximal high word: see wave_argmax_keys_nonneg
+        const unsigned long long b1 = __ballot(c1);
+        if (__popcll(b1) == 1) {
+            const int src = __ffsll((long long)b1) - 1;
+            id = __builtin_amdgcn_readlane(id, src);
+            u = __hiloint2double(mh ^ (ms & 0x7fffffff), __builtin_amdgcn_readlane((int)kl, src) ^ ms);
+            return;
+        }
+    }
+#endif
     unsigned l1 = c1 ? kl : 0u;
     if (ROW0) { MP_DPP_REDUCE_ROW("v_max_u32_dpp", l1); } else { MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1); }
     const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, ROW0 ? 15 : 63);
     int i2 = (c1 && kl == ml) ? id : 0x7fffffff;
     if (ROW0) { MP_DPP_REDUCE_ROW("v_min_i32_dpp", i2); } else { MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2); }
     id = __builtin_amdgcn_readlane(i2, ROW0 ? 15 : 63);
-    const int ms = mh >> 31;
     u = __hiloint2double(mh ^ (ms & 0x7fffffff), (int)(ml ^ (unsigned)ms));
 }
 
