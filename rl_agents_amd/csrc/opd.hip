@@ -90,6 +90,45 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 // NONNEG: every finite bound is >= +0.0 (gamma in [0, 1), terminal reward >= 0; rewards are range-checked): the reductions
 //              take the zero-fill DPP steps of wave.hpp.  What a lone wave's expansion costs, phase by phase, and what was
 //              tried on it: profiles/r03_opd_pipelining.md.
+// ---- the leaf to expand (deterministic.py:110: the first maximal upper bound), from the per-lane class bests.
+// The maximum M found by a full selection stays THE maximum for as long as some class best still equals it: no bound above
+// it can appear without being noticed (a re-scan returns a leaf that was already there; the callers compare new children
+// with M and clear `ok`).  OPD's trees are full of exact ties -- on the benchmark tables nine selections in ten pick among
+// leaves that share the bound of the previous one -- so the usual selection is only the third of the three reductions of
+// wave.hpp's key argmax: the lowest id among the lanes that hold M (and not even that when one lane holds it).
+template <bool NONNEG>
+__device__ __forceinline__ int select_drain(double cbu, int cbid, int lane, bool &ok, int &m_hi, int &m_lo)
+{
+    unsigned long long cand = ok ? __ballot(__double2hiint(cbu) == m_hi && __double2loint(cbu) == m_lo) : 0ull;
+    if (cand == 0ull) { // (wave-uniform) a new maximum: the first two reductions
+        int kh;
+        unsigned kl;
+        if (NONNEG) {
+            kh = __double2hiint(cbu); kl = (unsigned)__double2loint(cbu);
+            if (kh < 0) kh = 0;
+        } else {
+            const double uc = cbu + 0.0;
+            const int hi = __double2hiint(uc), sg = hi >> 31;
+            kh = hi ^ (sg & 0x7fffffff); kl = (unsigned)(__double2loint(uc) ^ sg);
+        }
+        int mh = kh;
+        MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
+        mh = __builtin_amdgcn_readlane(mh, 63);
+        const bool c1 = (NONNEG ? __double2hiint(cbu) : kh) == mh;
+        unsigned l1 = c1 ? kl : 0u;
+        MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
+        const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+        cand = __ballot(c1 && kl == ml);
+        if (NONNEG) { m_hi = mh; m_lo = (int)ml; }
+        else { const int ms = mh >> 31; m_hi = mh ^ (ms & 0x7fffffff); m_lo = (int)(ml ^ (unsigned)ms); }
+        ok = true;
+    }
+    if (__popcll(cand) == 1) return __builtin_amdgcn_readlane(cbid, __ffsll((long long)cand) - 1);
+    int i2 = ((cand >> lane) & 1ull) ? cbid : 0x7fffffff;
+    MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
+    return __builtin_amdgcn_readlane(i2, 63);
+}
+
 template <bool EXPG, bool NONNEG>
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
@@ -136,18 +175,17 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 #else
 #define PROF_T(x)
 #endif
+    bool drain_ok = false; // select_drain's maximum and whether it still stands
+    int drain_hi = 0, drain_lo = 0;
     for (int k = 0; k < p.K; ++k) {
         PROF_T(c0);
         // ---- deterministic.py:110: first maximal upper bound among the leaves
-        double bu = cbu;
-        int leaf = cbid;
-        if (NONNEG) wave_argmax_nonneg(bu, leaf); else wave_argmax(bu, leaf);
+        const int leaf = select_drain<NONNEG>(cbu, cbid, lane, drain_ok, drain_hi, drain_lo);
         const int cls = leaf & 63;
 #ifdef MP_PROFILE2
         ANCHOR(leaf); const long long pa = clock64();
         if (leaf >= n_nodes - A) ++n_follow;
         if (leaf >= n_nodes - 8 * A) ++n_recent;
-        if (__popcll(__ballot(cbu == bu)) > 1) ++n_tie_top;
 #endif
         // the leaf's record is needed by the expansion only: fetch it now, under the class re-scan
         const uint4 leaf_raw = *reinterpret_cast<const uint4 *>(&NA[leaf]);
@@ -186,7 +224,8 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
             // The loads are inline assembly: the compiler sinks a plain load to its first use, below the reduction, and its
             // s_waitcnt bookkeeping does not see these -- they are waited for by hand where the children are computed.
             {
-                const Rec *src = p.rec + ((long)pn.state * A + (lane < A ? lane : A - 1));
+                const int cj = (lane - n_nodes) & 63; // child j is computed by lane (g + j) mod 64, the owner of its class
+                const Rec *src = p.rec + ((long)pn.state * A + (cj < A ? cj : A - 1));
                 // (ru passes through: the reduction below cannot be scheduled above the request)
                 asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(rc_raw), "+v"(ru) : "v"(src) : "memory");
             }
@@ -221,8 +260,9 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         Rec rc;
         rc.next = (int32_t)rc_raw.x; rc.flags = rc_raw.y; rc.reward = __hiloint2double((int)rc_raw.w, (int)rc_raw.z);
         bool bad = false, avail = false;
-        double Uc_mine = 0.0;
-        if (lane < A) {
+        double Uc_mine = ninf;
+        const int cj = (lane - g) & 63;
+        if (cj < A) {
             const double r = rc.reward;
             // deterministic.py:32-35: only the actions state.get_available_actions() lists get a child.  The slot of
             // an unavailable action stays in the id space (ids advance by |A| per expansion in every root) as a
@@ -239,7 +279,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 Lc = nv; Uc = nv;
             }
             if (!avail) { Lc = ninf; Uc = ninf; }
-            const int c = g + lane;
+            const int c = g + cj;
             OpdNode cn;
             cn.L = Lc; cn.state = rc.next; cn.depth = d | (dn ? DONE_FLAG : 0);
             NA[c] = cn;
@@ -261,14 +301,10 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         __builtin_amdgcn_wave_barrier();
         // the (at most one, |A| <= 64) new child that falls in this lane's class may beat its cached
         // best; on equality the older (lower id) leaf stays, as in the reference's list order
-        {
-            const int j = (lane - g) & 63;
-            const double u = __shfl(Uc_mine, j & 63); // child j was made by lane j: no trip through memory
-            if (j < A) {
-                const int id = g + j;
-                if (u > cbu) { cbu = u; cbid = id; }
-            }
-        }
+        // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma) can
+        // land an ulp above gamma^(d-1) / (1 - gamma): then the maximum select_drain holds no longer stands)
+        if (__any(Uc_mine > __hiloint2double(drain_hi, drain_lo))) drain_ok = false;
+        if (Uc_mine > cbu) { cbu = Uc_mine; cbid = g + cj; } // (-inf in the lanes without a child)
 #ifdef MP_PROFILE
         { ANCHOR(__double2hiint(cbu)); const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1;
 #ifdef MP_PROFILE2
@@ -475,32 +511,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
     int cbid = cbid0;
     for (int k = 0; k < p.K; ++k) {
         // ---- deterministic.py:110: first maximal upper bound among the leaves (see the residue-class loop below)
-        int leaf;
-        {
-            unsigned long long cand = drain_ok ? __ballot(__double2hiint(cbu) == drain_hi && __double2loint(cbu) == drain_lo) : 0ull;
-            if (cand == 0ull) { // (wave-uniform) a new maximum: the first two reductions
-                int kh; unsigned kl;
-                if (NONNEG) { kh = __double2hiint(cbu); kl = (unsigned)__double2loint(cbu); if (kh < 0) kh = 0; }
-                else { const double uc = cbu + 0.0; const int hi = __double2hiint(uc), sg = hi >> 31; kh = hi ^ (sg & 0x7fffffff); kl = (unsigned)(__double2loint(uc) ^ sg); }
-                int mh = kh;
-                MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
-                mh = __builtin_amdgcn_readlane(mh, 63);
-                const bool c1 = (NONNEG ? __double2hiint(cbu) : kh) == mh;
-                unsigned l1 = c1 ? kl : 0u;
-                MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
-                const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
-                cand = __ballot(c1 && kl == ml);
-                if (NONNEG) { drain_hi = mh; drain_lo = (int)ml; }
-                else { const int ms = mh >> 31; drain_hi = mh ^ (ms & 0x7fffffff); drain_lo = (int)(ml ^ (unsigned)ms); }
-                drain_ok = true;
-            }
-            if (__popcll(cand) == 1) leaf = __builtin_amdgcn_readlane(cbid, __ffsll((long long)cand) - 1);
-            else {
-                int i2 = ((cand >> lane) & 1ull) ? cbid : 0x7fffffff;
-                MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
-                leaf = __builtin_amdgcn_readlane(i2, 63);
-            }
-        }
+        const int leaf = select_drain<NONNEG>(cbu, cbid, lane, drain_ok, drain_hi, drain_lo);
         const int leaf_s = __builtin_amdgcn_readfirstlane(leaf);
         const int el = leaf_s >> lgP, jl = leaf_s & (P - 1);
         const int cls = el & 63;
@@ -594,37 +605,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
     int cbid = cbid0;
     for (int k = 0; k < p.K; ++k) {
         // ---- deterministic.py:110: first maximal upper bound among the leaves
-        // The maximum M found by a full selection stays THE maximum for as long as some class best still equals it: no
-        // bound above it can appear without being noticed (a re-scan returns a leaf that was already there; children are
-        // compared with M below).  OPD's trees are full of exact ties -- on the benchmark tables nine selections in ten
-        // pick among leaves that share the bound of the previous one -- so the usual selection is only the third of
-        // the three reductions: the lowest id among the lanes that hold M.
-        int leaf;
-        {
-            unsigned long long cand = drain_ok ? __ballot(__double2hiint(cbu) == drain_hi && __double2loint(cbu) == drain_lo) : 0ull;
-            if (cand == 0ull) { // (wave-uniform) a new maximum: the first two reductions
-                int kh; unsigned kl;
-                if (NONNEG) { kh = __double2hiint(cbu); kl = (unsigned)__double2loint(cbu); if (kh < 0) kh = 0; }
-                else { const double uc = cbu + 0.0; const int hi = __double2hiint(uc), sg = hi >> 31; kh = hi ^ (sg & 0x7fffffff); kl = (unsigned)(__double2loint(uc) ^ sg); }
-                int mh = kh;
-                MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
-                mh = __builtin_amdgcn_readlane(mh, 63);
-                const bool c1 = (NONNEG ? __double2hiint(cbu) : kh) == mh;
-                unsigned l1 = c1 ? kl : 0u;
-                MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
-                const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
-                cand = __ballot(c1 && kl == ml);
-                if (NONNEG) { drain_hi = mh; drain_lo = (int)ml; }
-                else { const int ms = mh >> 31; drain_hi = mh ^ (ms & 0x7fffffff); drain_lo = (int)(ml ^ (unsigned)ms); }
-                drain_ok = true;
-            }
-            if (__popcll(cand) == 1) leaf = __builtin_amdgcn_readlane(cbid, __ffsll((long long)cand) - 1);
-            else {
-                int i2 = ((cand >> lane) & 1ull) ? cbid : 0x7fffffff;
-                MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
-                leaf = __builtin_amdgcn_readlane(i2, 63);
-            }
-        }
+        const int leaf = select_drain<NONNEG>(cbu, cbid, lane, drain_ok, drain_hi, drain_lo);
         const int leaf_s = __builtin_amdgcn_readfirstlane(leaf);
         const int cls = leaf_s & 63;
         // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry (one lane, one request)
