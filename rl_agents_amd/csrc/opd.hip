@@ -44,7 +44,7 @@ namespace mp {
 struct OpdArgs {
     int n_roots, S, A, K, cap, done_on_next, max_plan_len;
     int T; // row length of a residue class: odd, >= ceil(cap / 64)
-    int Tsib, lgP; // opd_wide_kernel<SIB>: row length of the sibling layout, log2 of a sibling group's slots
+    int Tsib, lgP; // opd_wide_kernel<SIB>: row length of the sibling layout; a leaf's code is (group << lgP) | child, 2^lgP >= |A|
     int chunk; // opd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
     int closing_chain; // opd_kernel: 1 = the node-array closing passes even where opd_closing.hpp fits (MP_OPD_CLOSING=chain: test hook)
     const Rec *rec;
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int T = SIB ? p.Tsib : p.T;
-    const int lgP = p.lgP, P = 1 << lgP; // SIB: a sibling group's slots, a power of two >= |A|
+    const int lgP = p.lgP, P = 1 << lgP; // SIB: a leaf's code is (group << lgP) | child index
     double *leafU = p.leaf_global + (long)blockIdx.x * 64 * T;
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x, root = blockIdx.x, A = p.A;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         RW[0] = 0.0;
         if (!SIB) LU(0) = 0.0;
     }
-    if (SIB && lane < P) leafU[lane] = lane == 0 ? 0.0 : ninf; // group 0 of row 0: the root and its padding
+    if (SIB && lane < A) leafU[lane] = lane == 0 ? 0.0 : ninf; // group 0 of row 0: the root (its other slots are never leaves)
     __syncthreads();
     int n_nodes = 1, real_mine = 0, status = MP_OK, k_done = 0;
     double cbu = lane == 0 ? 0.0 : ninf;
@@ -501,13 +501,13 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
     int drain_hi = 0, drain_lo = 0;
     if constexpr (SIB) {
     // ---- sibling layout.  The bounds array has 64 rows; the |A| children of expansion k sit TOGETHER, in group
-    // e = k + 1 (group 0 holds the root): row e mod 64, slots (e / 64) * P .. + P - 1 (unused slots -inf), so an expansion
-    // writes its children's bounds as ONE aligned 64-byte request (|A| <= 8) where the residue-class layout scattered
+    // e = k + 1 (group 0 holds the root): row e mod 64, slots (e / 64) * |A| .. + |A| - 1, so an expansion writes its
+    // children's bounds as ONE request of |A| * 8 contiguous bytes where the residue-class layout scattered
     // them over |A| rows -- this kernel waits on the L1's outstanding requests three quarters of the time, most of them
     // partial-line writes (profiles/r05_opd_wide.md).  A leaf is named by its code e * P + j, ordered like the ids.
     // Lane l caches the best leaf of row l; the children of an expansion all belong to ONE row.
-    const int cb0 = (((lane >> lgP) << 6) << lgP) | (lane & (P - 1));          // code of slot t = lane of row 0 ...
-    const int cb1 = ((((lane + 64) >> lgP) << 6) << lgP) | (lane & (P - 1));   // ... and of slot lane + 64
+    const int cb0 = (((lane / A) << 6) << lgP) | (lane % A);                   // code of slot t = lane of row 0 ...
+    const int cb1 = ((((lane + 64) / A) << 6) << lgP) | ((lane + 64) % A);     // ... and of slot lane + 64
     int cbid = cbid0;
     for (int k = 0; k < p.K; ++k) {
         // ---- deterministic.py:110: first maximal upper bound among the leaves (see the residue-class loop below)
@@ -518,9 +518,9 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         const int leaf_id = el == 0 ? 0 : 1 + (el - 1) * A + jl;
         const double *row = leafU + cls * T;
         // the selected leaf stops being one: its slot becomes the node -> expansion-index map entry (one lane, one request)
-        if (lane == 0) leafU[cls * T + ((el >> 6) << lgP) + jl] = __hiloint2double((int)0xFFF80000, k);
+        if (lane == 0) leafU[cls * T + (el >> 6) * A + jl] = __hiloint2double((int)0xFFF80000, k);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // (a wavefront's vector-memory operations are performed in order)
-        const int cnt = (((k - cls) >> 6) + 1) << lgP; // groups e <= k of this row
+        const int cnt = (((k - cls) >> 6) + 1) * A; // groups e <= k of this row
         double u0 = ninf, u1 = ninf;
         typedef unsigned __attribute__((ext_vector_type(4))) u32x4;
         u32x4 lr;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
             } else {
                 for (int t = lane; t < cnt; t += 64) {
                     const double v0 = row[t];
-                    if (v0 > ru) { ru = v0; rid = ((((t >> lgP) << 6) << lgP) | (t & (P - 1))) | cshift; }
+                    if (v0 > ru) { ru = v0; rid = ((((t / A) << 6) << lgP) | (t % A)) | cshift; }
                 }
             }
             if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
             NA[c] = cn;
             RW[c] = r;
         }
-        if (lane < P) leafU[re * T + ((e >> 6) << lgP) + lane] = Uc; // the whole group: children, then -inf
+        if (mine) leafU[re * T + (e >> 6) * A + lane] = Uc; // the whole group in one request
         n_nodes += A;
         real_mine += avail ? 1 : 0;
         k_done = k + 1;
@@ -718,9 +718,10 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
     if constexpr (SIB) {
         // (four rows per trip: up to eight independent reads in flight; the slots of a row that no group has reached yet
         // are skipped by index, whatever they hold)
-        auto emit = [&](int r, int t, int cnt, double u) {
-            const int e = ((t >> lgP) << 6) | r, jj = t & (P - 1);
-            if (t < cnt && jj < A && (e > 0 || jj == 0)) {
+        const int tg0 = lane / A, tj0 = lane % A, tg1 = (lane + 64) / A, tj1 = (lane + 64) % A;
+        auto emit = [&](int r, int t, int cnt, double u, int tg, int jj) { // slot t = group tg of its row, child jj
+            const int e = (tg << 6) | r;
+            if (t < cnt && (e > 0 || jj == 0)) {
                 const int id = e == 0 ? 0 : 1 + (e - 1) * A + jj;
                 U[id] = u != u ? ninf : u;
                 if (u > root_upper) root_upper = u;
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         for (int r0 = 0; r0 < 64 && r0 <= k_done; r0 += 4) {
             int cnt[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) cnt[a] = r0 + a <= k_done ? (((k_done - r0 - a) >> 6) + 1) << lgP : 0;
+            for (int a = 0; a < 4; ++a) cnt[a] = r0 + a <= k_done ? (((k_done - r0 - a) >> 6) + 1) * A : 0;
             if (SMALLT) {
                 double uu[4][2];
 #pragma unroll
@@ -740,13 +741,13 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
                 }
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    emit(r0 + a, lane, cnt[a], uu[a][0]);
-                    emit(r0 + a, lane + 64, cnt[a], uu[a][1]);
+                    emit(r0 + a, lane, cnt[a], uu[a][0], tg0, tj0);
+                    emit(r0 + a, lane + 64, cnt[a], uu[a][1], tg1, tj1);
                 }
             } else {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    for (int t = lane; t < cnt[a]; t += 64) emit(r0 + a, t, cnt[a], leafU[(r0 + a) * T + t]);
+                    for (int t = lane; t < cnt[a]; t += 64) emit(r0 + a, t, cnt[a], leafU[(r0 + a) * T + t], t / A, t % A);
             }
         }
     } else {
@@ -800,7 +801,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
             const double l = lane < A ? NA[fc + lane].L : ninf;
-            const double slot = lane >= A ? 0.0 : SIB ? leafU[((kcur + 1) & 63) * T + (((kcur + 1) >> 6) << lgP) + lane] : LU(fc + lane);
+            const double slot = lane >= A ? 0.0 : SIB ? leafU[((kcur + 1) & 63) * T + ((kcur + 1) >> 6) * A + lane] : LU(fc + lane);
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = __ballot(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -1055,12 +1056,12 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     OpdArgs a;
-    // high-occupancy variant, sibling layout (default; MP_OPD_WIDE=cls: the residue-class layout): groups of P = 2^lgP >= |A| slots,
+    // high-occupancy variant, sibling layout (default; MP_OPD_WIDE=cls: the residue-class layout): groups of |A| slots,
     // ceil((K + 1) / 64) groups per row, one cache line of padding so that rows do not all start in the same channels
     int lgP = 0;
     while ((1 << lgP) < A) ++lgP;
     const int groups = (K + 1 + 63) / 64;
-    const int Tsib = (groups << lgP) + ((1 << lgP) > 16 ? (1 << lgP) : 16);
+    const int Tsib = groups * A + 16;
     const char *wide_env = getenv("MP_OPD_WIDE");
     const bool sib = !(wide_env && wide_env[0] == 'c');
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk; a.Tsib = Tsib; a.lgP = lgP;
@@ -1099,7 +1100,7 @@ int mp_opd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *ro
     MP_TRY(kernels_begin(ctx));
     if (any_a) hipLaunchKernelGGL(opd_any_kernel, dim3((unsigned)n_roots), dim3(64), 0, st, a);
     else if (glb) {
-        const bool small = sib ? (groups << lgP) <= 128 : a.T <= 128; // at most two slots per lane in a re-scan
+        const bool small = sib ? groups * A <= 128 : a.T <= 128; // at most two slots per lane in a re-scan
         void (*kw)(OpdArgs) =
             sib ? (nonneg ? (small ? opd_wide_kernel<true, true, true> : opd_wide_kernel<true, false, true>)
                           : (small ? opd_wide_kernel<false, true, true> : opd_wide_kernel<false, false, true>))
