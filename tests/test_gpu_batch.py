@@ -226,13 +226,21 @@ def _cmp_opd(ctx, cfg, n_roots, budget, gamma, terminal_reward=0.0, seed=0, done
     return out
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+def _opd_variant(monkeypatch, variant):
+    """MP_OPD_MODEL = lds | ldsx | global; "global_cls": the high-occupancy kernel with the residue-class layout of its
+    bounds array (MP_OPD_WIDE=cls; the default is the sibling layout, round 5)."""
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
+
+
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 def test_opd_batch_highway_budget5000(ctx, variant, monkeypatch):
     """C4 shape: highway-shaped S=10 000, A=5, budget 5000 (1000 expansions), with the upper-bound array in LDS
     (40 KB per root; "ldsx": parent map in HBM so that four roots fit a CU) and in HBM/L2 (the high-occupancy
-    variant used for big batches)."""
+    variant used for big batches; both layouts)."""
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    _opd_variant(monkeypatch, variant)
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     _cmp_opd(ctx, cfg, 96, 5000, 0.8, seed=5)
 
@@ -244,12 +252,12 @@ def test_opd_budget_beyond_lds(ctx):
     _cmp_opd(ctx, cfg, 6, 25000, 0.9, seed=6)
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 @pytest.mark.parametrize("n_actions,budget", [(2, 101), (3, 200), (4, 100), (5, 500), (7, 300), (13, 1300), (20, 2000),
                                               (64, 640), (5, 10000)])     # (the last: more than 128 entries per class)
 def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    _opd_variant(monkeypatch, variant)
     cfg = generators.random_deterministic(300, n_actions, seed=40 + n_actions, terminal_rate=0.05)
     _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
 
@@ -285,12 +293,12 @@ def test_opd_closing_passes_on_the_node_array(ctx, n_actions, budget, variant, m
         _cmp_opd(ctx, cfg, 70, budget, 0.95, seed=3)
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 def test_opd_general_main_loop_where_the_fast_one_applies(ctx, variant, monkeypatch):
     """MP_OPD_LOOP=0: the main loop for arbitrary bounds (taken by itself when the terminal reward is negative or gamma is
     outside [0, 1)), forced where the loop for bounds >= 0 applies."""
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    _opd_variant(monkeypatch, variant)
     monkeypatch.setenv("MP_OPD_LOOP", "0")
     _cmp_opd(ctx, generators.highway_shaped(6, 8, 40, seed=2), 70, 2500, 0.95, seed=3)
     _cmp_opd(ctx, generators.random_deterministic(300, 7, seed=11, terminal_rate=0.05), 70, 700, 0.9, terminal_reward=0.25, seed=5)

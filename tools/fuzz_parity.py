@@ -81,6 +81,11 @@ def one_case(ctx, g, case):
     os.environ.pop("MP_OPD_MODEL", None)
     if variant and kind in ("opd", "opd_masked", "ropd", "ropd_masked"):
         os.environ["MP_OPD_MODEL"] = variant
+    # high-occupancy OPD kernel: sibling layout of the bounds array (default) or the residue-class layout
+    os.environ.pop("MP_OPD_WIDE", None)
+    wide = str(g.choice(["", "cls"]))
+    if wide:
+        os.environ["MP_OPD_WIDE"] = wide
     # closing passes: opd_closing.hpp where it fits (default) or the node-array form everywhere
     os.environ.pop("MP_OPD_CLOSING", None)
     if int(g.integers(0, 3)) == 0:
@@ -94,7 +99,7 @@ def one_case(ctx, g, case):
     quad = str(g.choice(["", "", "0", "1"]))
     if quad and kind in ("uct", "uct_subtree", "per_root_models", "update_rows"):
         os.environ["MP_UCT_QUAD"] = quad
-    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad)
+    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad, wide=wide)
     if kind in ("vi_batch", "per_root_models"):
         # N independent MDPs of this shape (mp_model_load_table_batch): N value-iteration agents in one launch, each to its own
         # allclose exit, in every kernel form; UCT and OPD with one MDP per root; a second round after mp_model_update_tables
@@ -622,6 +627,7 @@ def run(n_cases, seed, ctx=None, verbose=False):
         os.environ.pop("MP_OPD_MODEL", None)
         os.environ.pop("MP_OPD_CLOSING", None)
         os.environ.pop("MP_OPD_LOOP", None)
+        os.environ.pop("MP_OPD_WIDE", None)
         os.environ.pop("MP_UCT_QUAD", None)
         if forced is not None:
             os.environ["MP_OPD_MODEL"] = forced
