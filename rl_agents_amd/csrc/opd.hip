@@ -129,6 +129,26 @@ __device__ __forceinline__ int select_drain(double cbu, int cbid, int lane, bool
     return __builtin_amdgcn_readlane(i2, 63);
 }
 
+// ---- the best leaf of a re-scanned row from the per-lane bests (ru, rid).  Nothing exceeds the maximum M that select_drain
+// holds, so if some lane's best EQUALS M the row's best is M and only the lowest id among those lanes is wanted (with the
+// sibling layout: 85 % of the re-scans on the benchmark tables -- siblings tie); else the full key argmax.
+template <bool NONNEG>
+__device__ __forceinline__ void rescan_best(double &ru, int &rid, int lane, int m_hi, int m_lo)
+{
+    const unsigned long long eq = __ballot(__double2hiint(ru) == m_hi && __double2loint(ru) == m_lo);
+    if (eq != 0ull) { // (wave-uniform)
+        if (__popcll(eq) == 1) rid = __builtin_amdgcn_readlane(rid, __ffsll((long long)eq) - 1);
+        else {
+            int i2 = ((eq >> lane) & 1ull) ? rid : 0x7fffffff;
+            MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
+            rid = __builtin_amdgcn_readlane(i2, 63);
+        }
+        ru = __hiloint2double(m_hi, m_lo);
+        return;
+    }
+    if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
+}
+
 template <bool EXPG, bool NONNEG>
 __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 {
@@ -555,7 +575,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
                     if (v0 > ru) { ru = v0; rid = ((((t / A) << 6) << lgP) | (t % A)) | cshift; }
                 }
             }
-            if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
+            rescan_best<NONNEG>(ru, rid, lane, drain_hi, drain_lo);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
@@ -654,7 +674,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
                     if (v1 > ru) { ru = v1; rid = cls + ((t + 64) << 6); }
                 }
             }
-            if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
+            rescan_best<NONNEG>(ru, rid, lane, drain_hi, drain_lo);
             if (lane == cls) { cbu = ru; cbid = rid; }
         }
         const int d = __builtin_amdgcn_readfirstlane((pn.depth & (DONE_FLAG - 1)) + 1);
