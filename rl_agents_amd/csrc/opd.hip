@@ -90,6 +90,15 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 // NONNEG: every finite bound is >= +0.0 (gamma in [0, 1), terminal reward >= 0; rewards are range-checked): the reductions
 //              take the zero-fill DPP steps of wave.hpp.  What a lone wave's expansion costs, phase by phase, and what was
 //              tried on it: profiles/r03_opd_pipelining.md.
+// the lowest id (>= 0) among the lanes of a predicate: the largest INT_MAX - id, zero-fill DPP steps
+__device__ __forceinline__ int lowest_id(bool in, int id)
+{
+    int key = in ? 0x7fffffff - id : 0;
+    key = imax_step_zero<0x111>(key); key = imax_step_zero<0x112>(key); key = imax_step_zero<0x114>(key);
+    key = imax_step_zero<0x118>(key); key = imax_step_zero<0x142>(key); key = imax_step_zero<0x143>(key);
+    return 0x7fffffff - __builtin_amdgcn_readlane(key, 63);
+}
+
 // ---- the leaf to expand (deterministic.py:110: the first maximal upper bound), from the per-lane class bests.
 // The maximum M found by a full selection stays THE maximum for as long as some class best still equals it: no bound above
 // it can appear without being noticed (a re-scan returns a leaf that was already there; the callers compare new children
@@ -99,34 +108,44 @@ static_assert(sizeof(OpdNode) == 16, "OpdNode must be one dwordx4");
 template <bool NONNEG>
 __device__ __forceinline__ int select_drain(double cbu, int cbid, int lane, bool &ok, int &m_hi, int &m_lo)
 {
-    unsigned long long cand = ok ? __ballot(__double2hiint(cbu) == m_hi && __double2loint(cbu) == m_lo) : 0ull;
+    bool in = ok && __double2hiint(cbu) == m_hi && __double2loint(cbu) == m_lo;
+    unsigned long long cand = ballot64(in);
     if (cand == 0ull) { // (wave-uniform) a new maximum: the first two reductions
-        int kh;
-        unsigned kl;
-        if (NONNEG) {
-            kh = __double2hiint(cbu); kl = (unsigned)__double2loint(cbu);
-            if (kh < 0) kh = 0;
+        if (NONNEG) { // (bounds >= +0.0 or -inf: the bit pattern is the key, zero-fill DPP steps -- wave.hpp)
+            const int hi = __double2hiint(cbu);
+            const unsigned lo = (unsigned)__double2loint(cbu);
+            int kh = hi < 0 ? 0 : hi;
+            kh = imax_step_zero<0x111>(kh); kh = imax_step_zero<0x112>(kh); kh = imax_step_zero<0x114>(kh);
+            kh = imax_step_zero<0x118>(kh); kh = imax_step_zero<0x142>(kh); kh = imax_step_zero<0x143>(kh);
+            const int mh = __builtin_amdgcn_readlane(kh, 63);
+            const bool c1 = hi == mh;
+            unsigned l1 = c1 ? lo : 0u;
+            l1 = umax_step_zero<0x111>(l1); l1 = umax_step_zero<0x112>(l1); l1 = umax_step_zero<0x114>(l1);
+            l1 = umax_step_zero<0x118>(l1); l1 = umax_step_zero<0x142>(l1); l1 = umax_step_zero<0x143>(l1);
+            const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+            in = c1 && lo == ml;
+            m_hi = mh; m_lo = (int)ml;
         } else {
             const double uc = cbu + 0.0;
             const int hi = __double2hiint(uc), sg = hi >> 31;
-            kh = hi ^ (sg & 0x7fffffff); kl = (unsigned)(__double2loint(uc) ^ sg);
+            const int kh = hi ^ (sg & 0x7fffffff);
+            const unsigned kl = (unsigned)(__double2loint(uc) ^ sg);
+            int mh = kh;
+            MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
+            mh = __builtin_amdgcn_readlane(mh, 63);
+            const bool c1 = kh == mh;
+            unsigned l1 = c1 ? kl : 0u;
+            MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
+            const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
+            in = c1 && kl == ml;
+            const int ms = mh >> 31;
+            m_hi = mh ^ (ms & 0x7fffffff); m_lo = (int)(ml ^ (unsigned)ms);
         }
-        int mh = kh;
-        MP_DPP_REDUCE_WAVE("v_max_i32_dpp", mh);
-        mh = __builtin_amdgcn_readlane(mh, 63);
-        const bool c1 = (NONNEG ? __double2hiint(cbu) : kh) == mh;
-        unsigned l1 = c1 ? kl : 0u;
-        MP_DPP_REDUCE_WAVE("v_max_u32_dpp", l1);
-        const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
-        cand = __ballot(c1 && kl == ml);
-        if (NONNEG) { m_hi = mh; m_lo = (int)ml; }
-        else { const int ms = mh >> 31; m_hi = mh ^ (ms & 0x7fffffff); m_lo = (int)(ml ^ (unsigned)ms); }
+        cand = ballot64(in);
         ok = true;
     }
     if (__popcll(cand) == 1) return __builtin_amdgcn_readlane(cbid, __ffsll((long long)cand) - 1);
-    int i2 = ((cand >> lane) & 1ull) ? cbid : 0x7fffffff;
-    MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
-    return __builtin_amdgcn_readlane(i2, 63);
+    return lowest_id(in, cbid);
 }
 
 // ---- the best leaf of a re-scanned row from the per-lane bests (ru, rid).  Nothing exceeds the maximum M that select_drain
@@ -135,14 +154,10 @@ __device__ __forceinline__ int select_drain(double cbu, int cbid, int lane, bool
 template <bool NONNEG>
 __device__ __forceinline__ void rescan_best(double &ru, int &rid, int lane, int m_hi, int m_lo)
 {
-    const unsigned long long eq = __ballot(__double2hiint(ru) == m_hi && __double2loint(ru) == m_lo);
+    const bool in = __double2hiint(ru) == m_hi && __double2loint(ru) == m_lo;
+    const unsigned long long eq = ballot64(in);
     if (eq != 0ull) { // (wave-uniform)
-        if (__popcll(eq) == 1) rid = __builtin_amdgcn_readlane(rid, __ffsll((long long)eq) - 1);
-        else {
-            int i2 = ((eq >> lane) & 1ull) ? rid : 0x7fffffff;
-            MP_DPP_REDUCE_WAVE("v_min_i32_dpp", i2);
-            rid = __builtin_amdgcn_readlane(i2, 63);
-        }
+        rid = __popcll(eq) == 1 ? __builtin_amdgcn_readlane(rid, __ffsll((long long)eq) - 1) : lowest_id(in, rid);
         ru = __hiloint2double(m_hi, m_lo);
         return;
     }
@@ -317,13 +332,13 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         n_nodes += A;
         real_mine += avail ? 1 : 0;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (ballot64(bad) != 0ull) { status = MP_ERR_REWARD_RANGE; break; }
         __builtin_amdgcn_wave_barrier();
         // the (at most one, |A| <= 64) new child that falls in this lane's class may beat its cached
         // best; on equality the older (lower id) leaf stays, as in the reference's list order
         // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma) can
         // land an ulp above gamma^(d-1) / (1 - gamma): then the maximum select_drain holds no longer stands)
-        if (__any(Uc_mine > __hiloint2double(drain_hi, drain_lo))) drain_ok = false;
+        if (ballot64(Uc_mine > __hiloint2double(drain_hi, drain_lo)) != 0ull) drain_ok = false;
         if (Uc_mine > cbu) { cbu = Uc_mine; cbid = g + cj; } // (-inf in the lanes without a child)
 #ifdef MP_PROFILE
         { ANCHOR(__double2hiint(cbu)); const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1;
@@ -606,14 +621,14 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         n_nodes += A;
         real_mine += avail ? 1 : 0;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (ballot64(bad) != 0ull) { status = MP_ERR_REWARD_RANGE; break; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the next re-scan may read these children through memory, from other lanes
         // the children against the best of THEIR row (lane re)
         const double cbu_re = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cbu), re), __builtin_amdgcn_readlane(__double2loint(cbu), re));
-        if (__any(mine && Uc > cbu_re)) { // (wave-uniform)
+        if (ballot64(mine && Uc > cbu_re) != 0ull) { // (wave-uniform)
             const double um = mine ? Uc : ninf;
             const double m = A <= 16 ? row0_max(um) : wave_max(um);
-            const int jm = __ffsll((long long)__ballot(mine && Uc == m)) - 1; // lowest id among equal bounds
+            const int jm = __ffsll((long long)ballot64(mine && Uc == m)) - 1; // lowest id among equal bounds
             if (lane == re) { cbu = m; cbid = (e << lgP) + jm; }
             // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma)
             // can land an ulp above gamma^(d-1) / (1 - gamma))
@@ -707,10 +722,10 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
         n_nodes += A;
         real_mine += avail ? 1 : 0;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (ballot64(bad) != 0ull) { status = MP_ERR_REWARD_RANGE; break; }
         // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma) can
         // land an ulp above gamma^(d-1) / (1 - gamma))
-        if (__any(mine && Uc_mine > __hiloint2double(drain_hi, drain_lo))) drain_ok = false;
+        if (ballot64(mine && Uc_mine > __hiloint2double(drain_hi, drain_lo)) != 0ull) drain_ok = false;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); // the next re-scan may read these children through memory, from other lanes
         if (mine && Uc_mine > cbu) { cbu = Uc_mine; cbid = c; }
     }
@@ -919,7 +934,7 @@ __global__ __launch_bounds__(64) void opd_any_kernel(OpdArgs p)
         if (lane == 0) { U[leaf] = ninf; EXP[k] = leaf; }
         n_nodes += A;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (ballot64(bad) != 0ull) { status = MP_ERR_REWARD_RANGE; break; }
         __syncthreads();
     }
     __syncthreads();

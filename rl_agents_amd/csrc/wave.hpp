@@ -4,6 +4,11 @@
 
 namespace mp {
 
+// The lane mask of a predicate as the compare's own SGPR pair.  (HIP's __ballot / __any take an int: the predicate is first
+// materialised with v_cndmask and compared with zero again -- two vector instructions per call in kernels that count them.)
+__device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
+
 // ---- 32-bit DPP reductions written as ONE instruction per step: `v_op_dpp v, v, v` computes op(dpp(v), v) in place and
 // lanes without a valid DPP source keep their value (bound_ctrl off = the lane is disabled for the instruction).  The
 // builtin route (update_dpp, then the operation) costs a register copy, the DPP move and the operation per step -- three
