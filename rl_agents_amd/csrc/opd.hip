@@ -403,7 +403,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                     const bool changed = on && !(m == last);
                     if (changed) { LU(parent) = m; last = m; }
                     __builtin_amdgcn_wave_barrier(); // (one wavefront: LDS operations execute in program order)
-                    if (!__any(changed)) break;
+                    if (!any64(changed)) break;
                 }
             }
             __syncthreads();
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
                 const double l = lane < A ? NA[fc + lane].L : ninf;
                 const double slot = lane < A ? LU(fc + lane) : 0.0;
                 const double m = A <= 16 ? row0_max(l) : wave_max(l);
-                const unsigned long long ties = __ballot(lane < A && l == m);
+                const unsigned long long ties = ballot64(lane < A && l == m);
                 const int nt = __popcll(ties);
                 int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
                 unsigned long long t = ties;
@@ -838,7 +838,7 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
             const double l = lane < A ? NA[fc + lane].L : ninf;
             const double slot = lane >= A ? 0.0 : SIB ? leafU[((kcur + 1) & 63) * T + ((kcur + 1) >> 6) * A + lane] : LU(fc + lane);
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
-            const unsigned long long ties = __ballot(lane < A && l == m);
+            const unsigned long long ties = ballot64(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt);
             unsigned long long t = ties;
@@ -964,7 +964,7 @@ __global__ __launch_bounds__(64) void opd_any_kernel(OpdArgs p)
         for (;;) {
             int kcur = -1; // the expansion that made `node`'s children, if any
             for (int k0 = 0; k0 < k_done && kcur < 0; k0 += 64) {
-                const unsigned long long hit = __ballot(k0 + lane < k_done && EXP[k0 + lane] == node);
+                const unsigned long long hit = ballot64(k0 + lane < k_done && EXP[k0 + lane] == node);
                 if (hit) kcur = k0 + __ffsll((long long)hit) - 1;
             }
             if (kcur < 0) break;
@@ -976,10 +976,10 @@ __global__ __launch_bounds__(64) void opd_any_kernel(OpdArgs p)
             }
             m = wave_max(m);
             int nt = 0;
-            for (int a0 = 0; a0 < A; a0 += 64) nt += __popcll(__ballot(a0 + lane < A && NA[fc + a0 + lane].L == m));
+            for (int a0 = 0; a0 < A; a0 += 64) nt += __popcll(ballot64(a0 + lane < A && NA[fc + a0 + lane].L == m));
             int pick = (int)gen.below((uint32_t)nt), act = 0;
             for (int a0 = 0; a0 < A; a0 += 64) {
-                unsigned long long t = __ballot(a0 + lane < A && NA[fc + a0 + lane].L == m);
+                unsigned long long t = ballot64(a0 + lane < A && NA[fc + a0 + lane].L == m);
                 const int c = __popcll(t);
                 if (pick < c) {
                     while (pick-- > 0) t &= t - 1;

@@ -108,7 +108,7 @@ __device__ __forceinline__ int closing_compact(void *lds, int K, int k_done, int
 #ifdef MP_PROFILE
         ++n_rounds;
 #endif
-        if (!__any(active)) break;
+        if (!any64(active)) break;
     }
     CT(3);
     // the final bounds into the records (the tree export reads them); the root's for the caller
@@ -163,7 +163,7 @@ __device__ __forceinline__ int closing_compact(void *lds, int K, int k_done, int
                 l = kc >= 0 ? val[kc] : loadL(fc + lane);
             }
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
-            const unsigned long long ties = __ballot(lane < A && l == m);
+            const unsigned long long ties = ballot64(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt); // uniform across lanes (same state, same draws)
             unsigned long long t = ties;

@@ -229,11 +229,11 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
             LU(c) = umin;
             Uc_mine = umin;
         }
-        real_steps += __popcll(__ballot(avail));
+        real_steps += __popcll(ballot64(avail));
         if (lane == 0) exp_lds[k] = leaf;
         n_nodes += A;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         __syncthreads(); // the next expansion may read these children's vectors (global memory, other lanes)
         {
             const int j = (lane - g) & 63;
@@ -318,11 +318,11 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
             LU(c) = umin;
             Uc_mine = umin;
         }
-        real_steps += __popcll(__ballot(avail));
+        real_steps += __popcll(ballot64(avail));
         if (lane == 0) exp_lds[k] = leaf;
         n_nodes += A;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         __syncthreads(); // the next expansion may read these children's vectors (global memory, other lanes)
         {
             const int j = (lane - g) & 63;
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                     const bool changed = on && !(m == last);
                     if (changed) { LU(parent) = m; last = m; }
                     __builtin_amdgcn_wave_barrier();
-                    if (!__any(changed)) break;
+                    if (!any64(changed)) break;
                 }
             }
             __syncthreads();
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                 const double l = lane < A ? Lmin[fc + lane] : ninf;
                 const double slot = lane < A ? LU(fc + lane) : 0.0;
                 const double m = A <= 16 ? row0_max(l) : wave_max(l);
-                const unsigned long long ties = __ballot(lane < A && l == m);
+                const unsigned long long ties = ballot64(lane < A && l == m);
                 const int nt = __popcll(ties);
                 int pick = (int)gen.below((uint32_t)nt);
                 unsigned long long t = ties;
@@ -541,10 +541,10 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
             LU(c) = umin;
             Uc_mine = umin;
         }
-        real_steps += __popcll(__ballot(avail));
+        real_steps += __popcll(ballot64(avail));
         n_nodes += A;
         k_done = k + 1;
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         __syncthreads();
         {
             const int j = (lane - g) & 63;
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
             const double l = lane < A ? Lmin[fc + lane] : ninf;
             const double slot = lane < A ? LU(fc + lane) : 0.0;
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
-            const unsigned long long ties = __ballot(lane < A && l == m);
+            const unsigned long long ties = ballot64(lane < A && l == m);
             const int nt = __popcll(ties);
             int pick = (int)gen.below((uint32_t)nt);
             unsigned long long t = ties;
@@ -709,8 +709,8 @@ __global__ __launch_bounds__(64) void ropd_any_kernel(ROpdArgs p)
                 meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
                 Umin[c] = umin;
             }
-            real_steps += __popcll(__ballot(avail));
-            bad_any |= __any(bad);
+            real_steps += __popcll(ballot64(avail));
+            bad_any |= any64(bad);
         }
         if (lane == 0) { Umin[leaf] = ninf; EXP[k] = leaf; }
         n_nodes += A;
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(64) void ropd_any_kernel(ROpdArgs p)
         for (;;) { // get_plan with DeterministicNode.selection_rule over get_value_lower_bound = np.min
             int kcur = -1;
             for (int k0 = 0; k0 < k_done && kcur < 0; k0 += 64) {
-                const unsigned long long hit = __ballot(k0 + lane < k_done && EXP[k0 + lane] == node);
+                const unsigned long long hit = ballot64(k0 + lane < k_done && EXP[k0 + lane] == node);
                 if (hit) kcur = k0 + __ffsll((long long)hit) - 1;
             }
             if (kcur < 0) break;
@@ -755,10 +755,10 @@ __global__ __launch_bounds__(64) void ropd_any_kernel(ROpdArgs p)
             }
             m = wave_max(m);
             int nt = 0;
-            for (int a0 = 0; a0 < A; a0 += 64) nt += __popcll(__ballot(a0 + lane < A && Lmin[fc + a0 + lane] == m));
+            for (int a0 = 0; a0 < A; a0 += 64) nt += __popcll(ballot64(a0 + lane < A && Lmin[fc + a0 + lane] == m));
             int pick = (int)gen.below((uint32_t)nt), act = 0;
             for (int a0 = 0; a0 < A; a0 += 64) {
-                unsigned long long t = __ballot(a0 + lane < A && Lmin[fc + a0 + lane] == m);
+                unsigned long long t = ballot64(a0 + lane < A && Lmin[fc + a0 + lane] == m);
                 const int c = __popcll(t);
                 if (pick < c) {
                     while (pick-- > 0) t &= t - 1;

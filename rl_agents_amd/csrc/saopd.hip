@@ -675,7 +675,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
         for (int i0 = 0; i0 < root; i0 += 64) {
             const int i = i0 + lane;
             const bool live = i < root && (ND(i).meta & SA_CHILDREN) != 0;
-            const unsigned long long bm = __ballot(live);
+            const unsigned long long bm = ballot64(live);
             if (live) old_b[n_old + __popcll(bm & lt0)] = make_int2(i, ST(i)); // (a row with children is never dead: no flag byte)
             n_old += __popcll(bm);
         }
@@ -798,13 +798,13 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             ST(c) = s_c; PA(c) = leaf; FC(c) = -1; RW(c) = c0_rew;
             p.done[nb + c] = real_c ? (term_c ? 1 : 0) : 2;
         }
-        const unsigned long long real_mask = __ballot(real_c);
+        const unsigned long long real_mask = ballot64(real_c);
         if (l0) {
             ND(leaf).meta = (lf.meta & ~SA_ALIVE) | SA_CHILDREN;
             FC(leaf) = g;
         }
         steps_taken += __popcll(real_mask); // planner.step calls: one per listed action
-        if (__any(bad)) { status = MP_ERR_REWARD_RANGE; break; }
+        if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         SA_SYNC();
         // state_nodes[str(observation)].append(child), update_value(observation, 0), child by child in action order.  What an
         // append reads -- its state's list tail, value (and chunk record) -- is fetched for ALL children at once, lane a
@@ -1048,7 +1048,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                                 if (v_sn == sn) v_old = backup;
                                 hit = v_sc == sn;
                             }
-                            dirty |= __ballot(hit);
+                            dirty |= ballot64(hit);
                         }
                     }
                 };
@@ -1066,13 +1066,13 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                     bool in_r = valid; // lanes of the groups not yet applied
                     const unsigned long long gmask = (A == 64 ? ~0ULL : ((1ULL << A) - 1ULL));
                     const unsigned long long ltm = (1ULL << lane) - 1ULL;
-                    while (__any(in_r) && status == MP_OK) {
+                    while (any64(in_r) && status == MP_OK) {
                         const bool leader = in_r && my_a == 0;
                         const bool cand = leader && v_old > v_backup;
                         if (cand) atomicMin(&d_mark[v_sn], (uint32_t)my_g);
                         SA_ORDER();
                         const uint32_t m = in_r ? d_mark[v_sc] : 0xffffffffu;
-                        const unsigned long long stale = __ballot(m < (uint32_t)my_g);
+                        const unsigned long long stale = ballot64(m < (uint32_t)my_g);
                         const int c_g = stale ? (__ffsll((long long)stale) - 1) / A : 64; // the first group with a stale child value
                         const bool now = in_r && my_g < c_g;
                         double ret = 0.0;
@@ -1081,9 +1081,9 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                             ret = __hip_atomic_fetch_min(&sv_b[v_sn], v_backup, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                             w = v_backup < ret;
                         }
-                        const unsigned long long wm = __ballot(w);
+                        const unsigned long long wm = ballot64(w);
                         const int n_w = __popcll(wm);
-                        updates += __popcll(__ballot(now && leader));
+                        updates += __popcll(ballot64(now && leader));
                         if (n_w) {
                             if (qt - qh + (unsigned)n_w > dcap) {
                                 status = MP_ERR_ALLOC;
@@ -1101,10 +1101,10 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                         if (!stale) break;
                         // the remaining groups: re-evaluate those with a child in a state a group applied above may have
                         // written; the others re-read their parent state's value (it may have moved)
-                        const unsigned long long nm = __ballot(in_r && m < (uint32_t)c_g);
+                        const unsigned long long nm = ballot64(in_r && m < (uint32_t)c_g);
                         const bool redo = in_r && ((nm >> g_lead) & gmask) != 0ULL;
 #ifdef MP_PROFILE
-                        pf_reval += __popcll(__ballot(redo && my_a == 0));
+                        pf_reval += __popcll(ballot64(redo && my_a == 0));
 #endif
                         score(redo);
                         if (in_r && !redo) v_old = SV(v_sn);
@@ -1131,7 +1131,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                         const int o = __shfl_up(incl, d);
                         if (lane >= d) incl += o;
                     }
-                    const unsigned long long okm = __ballot(lane < nq && cnt_l <= CH && incl <= npp);
+                    const unsigned long long okm = ballot64(lane < nq && cnt_l <= CH && incl <= npp);
                     const int nb = okm == ~0ULL ? 64 : __ffsll((long long)~okm) - 1; // leading descriptors of the batch
                     if (nb > 0) {
                         const int total = __builtin_amdgcn_readlane(incl, nb - 1);
@@ -1152,7 +1152,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #endif
                         eval(mine, my_nbr, my_given, ds_o < 0 ? -1 : src_o, delta_o);
                         if constexpr (LDSD) apply_vec(mine && v_cond, ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
-                        else apply(__ballot(mine && v_cond && my_a == 0), ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
+                        else apply(ballot64(mine && v_cond && my_a == 0), ds_o < 0 ? -1 : src_o, delta_o, my_nbr, my_given);
                         continue;
                     }
                     // the first pending descriptor alone is longer than a pass: chunk by chunk
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #endif
                             eval(my_nbr >= 0, my_nbr, -1, src_, src_delta_);
                             if constexpr (LDSD) apply_vec(my_nbr >= 0 && v_cond, src_, src_delta_, my_nbr, -1);
-                            else apply(__ballot(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr, -1);
+                            else apply(ballot64(my_nbr >= 0 && v_cond && my_a == 0), src_, src_delta_, my_nbr, -1);
                         }
                     }
                 }
@@ -1214,7 +1214,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                 const bool h0 = lane < p.S && b0.x > 0 && SM(lane) == cur, h1 = lane + 64 < p.S && b1.x > 0 && SM(lane + 64) == cur;
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    unsigned long long todo = __ballot(half ? h1 : h0);
+                    unsigned long long todo = ballot64(half ? h1 : h0);
                     while (todo) {
                         const int l = __ffsll((long long)todo) - 1;
                         todo &= todo - 1;
@@ -1238,7 +1238,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #pragma unroll
                 for (int q = 0; q < NS; ++q) {
                     rmeta[q] = 0; rval[q] = ninf; key[q] = -1;
-                    if (!__any(rst[q] >= 0)) continue; // (uniform: an empty set costs nothing)
+                    if (!any64(rst[q] >= 0)) continue; // (uniform: an empty set costs nothing)
                     nonempty |= 1u << q;
                     if (rst[q] >= 0) {
                         const SaNode nd = load_node(&ND(ids[q]));
@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #pragma unroll
                 for (int q = NS - 1; q >= 0; --q) {
                     if (!(nonempty & (1u << q))) continue;
-                    unsigned long long todo = __ballot(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
+                    unsigned long long todo = ballot64(rst[q] >= 0 && (rmeta[q] & SA_ALIVE));
                     while (todo) {
                         const int l = 63 - __clzll((long long)todo);
                         todo &= ~(1ULL << l);
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
 #pragma unroll
                         for (int t = 0; t < NS; ++t) {
                             if (!(nonempty & (1u << t))) continue;
-                            unsigned long long m = __ballot(rst[t] == cs && rval[t] >= cv && key[t] >= cd);
+                            unsigned long long m = ballot64(rst[t] == cs && rval[t] >= cv && key[t] >= cd);
                             if (t == q) m &= ~(1ULL << l);
                             dom |= m;
                         }
@@ -1303,7 +1303,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                     // a state's list = its rows from the list head on (lists are in id order; plan() starts the root
                     // state's list over, which drops that state's older rows)
                     const bool hit = i0 + 64 * j + lane < n_pos && stamps[j] == cur && i >= heads[j] && !(dead[j] & 2);
-                    const unsigned long long bm = __ballot(hit);
+                    const unsigned long long bm = ballot64(hit);
                     if (hit) {
                         const int pos = n_d + __popcll(bm & lt);
                         if (pos < pcap) { recs[2 * pos] = i; recs[2 * pos + 1] = sts[j]; }
@@ -1354,7 +1354,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                             const int jc = c0 + lane;
                             const uint32_t mc = jc < cnt ? (uint32_t)mt[jc] : 0u;
                             const double vc = jc < cnt ? vl[jc] : ninf;
-                            unsigned long long todo = __ballot(jc < cnt && (mc & SA_ALIVE));
+                            unsigned long long todo = ballot64(jc < cnt && (mc & SA_ALIVE));
                             while (todo) {
                                 const int l = 63 - __clzll((long long)todo);
                                 todo &= ~(1ULL << l);
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                                         dom |= vl[jt] >= cv && (int)(m2 & SA_DEPTH) >= cd && (m2 & (SA_CHILDREN | SA_ALIVE)) != 0;
                                     }
                                 }
-                                if (__any(dom)) {
+                                if (any64(dom)) {
                                     if (lane == l) {
                                         const uint32_t nm = (uint32_t)mt[jc] & ~SA_ALIVE;
                                         mt[jc] = (int32_t)nm;
@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                         for (int j0 = start; j0 < n_d; j0 += 64) {
                             const int j = j0 + lane;
                             const int stj = j < n_d ? recs[2 * j + 1] : -1;
-                            const unsigned long long bm = __ballot(stj >= 0);
+                            const unsigned long long bm = ballot64(stj >= 0);
                             if (bm) {
                                 const int l = __ffsll((long long)bm) - 1;
                                 pj = j0 + l; ps = __builtin_amdgcn_readlane(stj, l);
@@ -1402,7 +1402,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
                             const int j = j0 + lane;
                             const int stj = j < n_d ? recs[2 * j + 1] : -1;
                             const bool hit = stj == ps;
-                            const unsigned long long bm = __ballot(hit);
+                            const unsigned long long bm = ballot64(hit);
                             if (hit) {
                                 const int pos = m + __popcll(bm & lt);
                                 if (pos < selcap) sel[pos] = recs[2 * j];
@@ -1443,7 +1443,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
               for (int jc = 0; jc < WU; ++jc) {
                 const int i0 = ib - 64 * jc;
                 if (i0 < root) break;
-                unsigned long long todo = __ballot(cands[jc]);
+                unsigned long long todo = ballot64(cands[jc]);
                 while (todo) {
                     const int j = __ffsll((long long)todo) - 1; // lane 0 holds the highest row of the chunk
                     todo &= todo - 1;
@@ -1499,7 +1499,7 @@ __global__ __launch_bounds__(64, LDSR ? 1 : (LDSD ? MP_SAOPD_DICT_WAVES : MP_SAO
             while (fc >= 0) {
                 const double l = lane < A ? ND(fc + lane).lower : ninf;
                 const double m = A <= 16 ? row0_max(l) : wave_max(l);
-                const unsigned long long ties = __ballot(lane < A && l == m);
+                const unsigned long long ties = ballot64(lane < A && l == m);
                 const int nt = __popcll(ties);
                 int pick = nt > 1 ? (int)gen.below((uint32_t)nt) : 0;
                 unsigned long long t = ties;

@@ -7,6 +7,7 @@ namespace mp {
 // The lane mask of a predicate as the compare's own SGPR pair.  (HIP's __ballot / __any take an int: the predicate is first
 // materialised with v_cndmask and compared with zero again -- two vector instructions per call in kernels that count them.)
 __device__ __forceinline__ unsigned long long ballot64(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+__device__ __forceinline__ bool any64(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0ull; }
 
 
 // ---- 32-bit DPP reductions written as ONE instruction per step: `v_op_dpp v, v, v` computes op(dpp(v), v) in place and
@@ -156,7 +157,7 @@ __device__ __forceinline__ void wave_argmax_keys_nonneg(double &u, int &id)
     // ONE lane holds the maximal high word (the usual case: 20 mantissa bits rarely tie between leaves): the pair is that
     // lane's, read with two readlanes instead of twelve more reduction steps.  Wave-uniform branch.
     {
-        const unsigned long long b1 = __ballot(c1);
+        const unsigned long long b1 = ballot64(c1);
         if (__popcll(b1) == 1) {
             const int src = __ffsll((long long)b1) - 1;
             id = __builtin_amdgcn_readlane(id, src);
@@ -171,7 +172,7 @@ __device__ __forceinline__ void wave_argmax_keys_nonneg(double &u, int &id)
     const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)l1, 63);
 #ifndef MP_ARGMAX_NO_EARLY_EXIT
     {
-        const unsigned long long b2 = __ballot(c1 && lo == ml);
+        const unsigned long long b2 = ballot64(c1 && lo == ml);
         if (__popcll(b2) == 1) {
             id = __builtin_amdgcn_readlane(id, __ffsll((long long)b2) - 1);
             u = __hiloint2double(mh, (int)ml);
@@ -208,7 +209,7 @@ __device__ __forceinline__ void argmax_keys(double &u, int &id)
     const int ms = mh >> 31;
 #ifndef MP_ARGMAX_NO_EARLY_EXIT
     if (!ROW0) {          // one lane holds the maximal high word: see wave_argmax_keys_nonneg
-        const unsigned long long b1 = __ballot(c1);
+        const unsigned long long b1 = ballot64(c1);
         if (__popcll(b1) == 1) {
             const int src = __ffsll((long long)b1) - 1;
             id = __builtin_amdgcn_readlane(id, src);
