@@ -210,12 +210,14 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
 #else
 #define PROF_T(x)
 #endif
-    bool drain_ok = false; // select_drain's maximum and whether it still stands
-    int drain_hi = 0, drain_lo = 0;
     for (int k = 0; k < p.K; ++k) {
         PROF_T(c0);
         // ---- deterministic.py:110: first maximal upper bound among the leaves
-        const int leaf = select_drain<NONNEG>(cbu, cbid, lane, drain_ok, drain_hi, drain_lo);
+        // (the full reduction every time: select_drain's shortcuts are wave-uniform branches, and a LONE wave pays more for a
+        // readlane -> compare -> branch than for the twelve steps they save -- profiles/r05_opd_wide.md)
+        double bu = cbu;
+        int leaf = cbid;
+        if (NONNEG) wave_argmax_nonneg(bu, leaf); else wave_argmax(bu, leaf);
         const int cls = leaf & 63;
 #ifdef MP_PROFILE2
         ANCHOR(leaf); const long long pa = clock64();
@@ -336,9 +338,6 @@ __global__ __launch_bounds__(64) void opd_kernel(OpdArgs p)
         __builtin_amdgcn_wave_barrier();
         // the (at most one, |A| <= 64) new child that falls in this lane's class may beat its cached
         // best; on equality the older (lower id) leaf stays, as in the reference's list order
-        // (in exact arithmetic a child's bound never exceeds its parent's; rounded, gamma^(d-1) r + gamma^d / (1 - gamma) can
-        // land an ulp above gamma^(d-1) / (1 - gamma): then the maximum select_drain holds no longer stands)
-        if (ballot64(Uc_mine > __hiloint2double(drain_hi, drain_lo)) != 0ull) drain_ok = false;
         if (Uc_mine > cbu) { cbu = Uc_mine; cbid = g + cj; } // (-inf in the lanes without a child)
 #ifdef MP_PROFILE
         { ANCHOR(__double2hiint(cbu)); const long long c2 = clock64(); t_scan += c1 - c0; t_exp += c2 - c1;
