@@ -167,12 +167,13 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
             int dl = dleaf;
 #pragma unroll
             for (int m = 0; m < MB; ++m) asm volatile("" : "+v"(sv[m]), "+v"(lv[m]), "+v"(dl));
-            // the model records (every lane loads -- lanes >= |A| the last action's record, unused) and the gamma-table
+            const int cjl = (lane - n_nodes) & 63; // child j is computed by lane (g + j) mod 64, the owner of its class
+            // the model records (every lane loads -- the lanes without a child the last action's record, unused) and the gamma-table
             // entries.  Inline assembly: the compiler sinks a plain load to its first use, below the reduction; `ru` / `rid`
             // pass through so that the reduction cannot be scheduled above the requests.  Waited for by hand below.
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                const Rec *src = p.rec + ((long)(m < M ? m : 0) * SA + (long)sv[m] * A + (lane < A ? lane : A - 1));
+                const Rec *src = p.rec + ((long)(m < M ? m : 0) * SA + (long)sv[m] * A + (cjl < A ? cjl : A - 1));
                 asm volatile("global_load_dwordx4 %0, %2, off" : "=v"(rr[m]), "+v"(ru) : "v"(src) : "memory");
             }
             d = __builtin_amdgcn_readfirstlane(dl) + 1;
@@ -195,9 +196,10 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
                      tdivd = __longlong_as_double((long long)tdiv_bits);
         const int g = n_nodes;
         bool bad = false, avail = false;
-        double Uc_mine = 0.0;
-        if (lane < A) {
-            const int c = g + lane;
+        double Uc_mine = ninf;
+        const int cj = (lane - g) & 63;
+        if (cj < A) {
+            const int c = g + cj;
             double lmin = 0.0, umin = 0.0;
             uint32_t dbits = 0;
 #pragma unroll
@@ -234,15 +236,12 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
         n_nodes += A;
         k_done = k + 1;
         if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads(); // the next expansion may read these children's vectors (global memory, other lanes)
-        {
-            const int j = (lane - g) & 63;
-            const double u = __shfl(Uc_mine, j & 63);
-            if (j < A) {
-                const int id = g + j;
-                if (u > cbu) { cbu = u; cbid = id; }
-            }
-        }
+        // The next expansion may read these children's vectors through global memory, from other lanes OF THIS WAVEFRONT
+        // (the workgroup is one wave): its vector-memory operations are performed in order, so a wavefront-scope fence is
+        // all the ordering that needs -- __syncthreads() also waited for the stores' acknowledgements, every expansion.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (Uc_mine > cbu) { cbu = Uc_mine; cbid = g + cj; } // (-inf in the lanes without a child; on equality the older leaf stays)
     }
     } else {
     for (int k = 0; k < p.K; ++k) {
