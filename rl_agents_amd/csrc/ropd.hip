@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
         n_nodes += A;
         k_done = k + 1;
         if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads(); // the next expansion may read these children's vectors (global memory, other lanes)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); // (one wave per workgroup: in-order memory operations; no wait for the stores' acknowledgements)
         {
             const int j = (lane - g) & 63;
             const double u = __shfl(Uc_mine, j & 63);
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         const int cls = leaf & 63;
         const int dleaf = meta[2 * leaf];
         if (lane == 0) LU(leaf) = __hiloint2double((int)0xFFF80000, k); // dead to every selection; carries k
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); // (one wave per workgroup: in-order memory operations; no wait for the stores' acknowledgements)
         {
             const double *row = leafU + cls * T;
             const int cnt = (n_nodes - cls + 63) >> 6;
@@ -544,7 +544,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         n_nodes += A;
         k_done = k + 1;
         if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); // (one wave per workgroup: in-order memory operations; no wait for the stores' acknowledgements)
         {
             const int j = (lane - g) & 63;
             const double u = __shfl(Uc_mine, j & 63);
