@@ -64,6 +64,7 @@ __host__ __device__ __forceinline__ double reward_plain(double r)
 struct ROpdArgs {
     int n_roots, M, S, A, K, cap, done_on_next, max_plan_len;
     int T; // row length of a residue class in the upper-bound array: odd, >= ceil(cap / 64)
+    int Tsib, lgP; // ropd_wide_kernel<SIB>: row length of the sibling layout; a leaf's code is (group << lgP) | child (opd.hip)
     int chunk; // ropd_wide_kernel: expansions per LDS window of the closing lower-bound pass (power of two <= 64)
     int closing_chain; // ropd_kernel: 1 = the node-array closing passes even where opd_closing.hpp fits (MP_OPD_CLOSING=chain)
     const Rec *rec;            // [M][S*A] packed records of every model
@@ -442,11 +443,15 @@ __global__ __launch_bounds__(64) void ropd_kernel(ROpdArgs p)
 // selected leaf's slot NaN-boxed with its expansion index (node -> k map; the k -> node map is scattered by the closing
 // pass; the plan descent needs no search), the closing lower-bound sweep through a sliding LDS window over Lmin[], and
 // the arguments only the closing passes need loaded after the main loop (SGPR budget of 8 waves per SIMD).
-template <bool NONNEG>
+template <bool NONNEG, bool SIB>
 __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    const int T = p.T;
+    // SIB: the sibling layout of opd.hip's opd_wide_kernel -- the |A| children of expansion k together, in group k + 1 of
+    // row (k + 1) mod 64 (one write request per expansion instead of |A| scattered ones); a leaf is named by its code
+    // (group << lgP) | child, which orders like the node ids; lane l caches the best of row l.
+    const int T = SIB ? p.Tsib : p.T;
+    const int lgP = p.lgP, P = 1 << lgP;
     double *leafU = p.leaf_global + (long)blockIdx.x * 64 * T;
 #define LU(id) leafU[((id) & 63) * T + ((id) >> 6)]
     const int lane = threadIdx.x, root = blockIdx.x, A = p.A, M = p.M;
@@ -459,9 +464,13 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
     if (lane == 0) {
         for (int m = 0; m < M; ++m) { Lv[m] = 0.0; Sv[m] = p.root_state[(long)root * M + m]; Rv[m] = 0.0; }
         Lmin[0] = 0.0; meta[0] = 0; meta[1] = 0;
-        LU(0) = 0.0;
+        if (!SIB) LU(0) = 0.0;
     }
+    if (SIB && lane < A) leafU[lane] = lane == 0 ? 0.0 : ninf; // group 0 of row 0: the root (its other slots are never leaves)
     __syncthreads();
+    const bool small = (SIB ? T - 16 : T) <= 128; // at most two slots per lane in a re-scan
+    const int cb0 = SIB ? ((((lane / A) << 6) << lgP) | (lane % A)) : 0;               // SIB: code of slot t = lane of row 0 ...
+    const int cb1 = SIB ? (((((lane + 64) / A) << 6) << lgP) | ((lane + 64) % A)) : 0; // ... and of slot lane + 64
     int n_nodes = 1, status = MP_OK, k_done = 0;
     int real_steps = 0; // children of listed actions = planner.step calls of the joint environment
     double cbu = lane == 0 ? 0.0 : ninf;
@@ -472,25 +481,32 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         double bu = cbu;
         int leaf = cbid;
         if (NONNEG) wave_argmax_keys_nonneg(bu, leaf); else wave_argmax_keys(bu, leaf);
-        const int cls = leaf & 63;
+        // (SIB: `leaf` is a code until here)
+        const int el = SIB ? leaf >> lgP : 0, jl = SIB ? leaf & (P - 1) : 0;
+        const int cls = SIB ? el & 63 : leaf & 63;
+        if (SIB) leaf = el == 0 ? 0 : 1 + (el - 1) * A + jl;
         const int dleaf = meta[2 * leaf];
-        if (lane == 0) LU(leaf) = __hiloint2double((int)0xFFF80000, k); // dead to every selection; carries k
+        if (lane == 0) { // dead to every selection; carries k
+            if (SIB) leafU[cls * T + (el >> 6) * A + jl] = __hiloint2double((int)0xFFF80000, k);
+            else LU(leaf) = __hiloint2double((int)0xFFF80000, k);
+        }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); // (one wave per workgroup: in-order memory operations; no wait for the stores' acknowledgements)
         {
             const double *row = leafU + cls * T;
-            const int cnt = (n_nodes - cls + 63) >> 6;
+            const int cnt = SIB ? (((k - cls) >> 6) + 1) * A : (n_nodes - cls + 63) >> 6; // SIB: the groups e <= k of this row
+            const int cshift = cls << lgP;
             double ru = ninf;
             int rid = 0x7fffffff;
-            if (T <= 128) { // at most two entries per lane (budget 5000: 79 per class): no loop, both reads unconditional
+            if (small) { // at most two entries per lane (budget 5000: 79 per class): no loop, both reads unconditional
                 const double u0 = row[lane < cnt ? lane : 0], u1 = row[lane + 64 < cnt ? lane + 64 : 0];
-                if (lane < cnt && u0 > ru) { ru = u0; rid = cls + (lane << 6); }
-                if (lane + 64 < cnt && u1 > ru) { ru = u1; rid = cls + ((lane + 64) << 6); }
+                if (lane < cnt && u0 > ru) { ru = u0; rid = SIB ? cb0 | cshift : cls + (lane << 6); }
+                if (lane + 64 < cnt && u1 > ru) { ru = u1; rid = SIB ? cb1 | cshift : cls + ((lane + 64) << 6); }
             } else {
                 for (int t = lane; t < cnt; t += 128) { // two reads in flight per trip
                     const double u0 = row[t];
                     const double u1 = t + 64 < cnt ? row[t + 64] : ninf;
-                    if (u0 > ru) { ru = u0; rid = cls + (t << 6); }
-                    if (u1 > ru) { ru = u1; rid = cls + ((t + 64) << 6); }
+                    if (u0 > ru) { ru = u0; rid = SIB ? ((((t / A) << 6) << lgP) | (t % A)) | cshift : cls + (t << 6); }
+                    if (u1 > ru) { ru = u1; rid = SIB ? (((((t + 64) / A) << 6) << lgP) | ((t + 64) % A)) | cshift : cls + ((t + 64) << 6); }
                 }
             }
             if (NONNEG) wave_argmax_keys_nonneg(ru, rid); else wave_argmax_keys(ru, rid);
@@ -537,7 +553,8 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
             if (!avail) { lmin = ninf; umin = ninf; }
             Lmin[c] = lmin;
             meta[2 * c] = d; meta[2 * c + 1] = (int32_t)dbits;
-            LU(c) = umin;
+            if (SIB) leafU[((k + 1) & 63) * T + ((k + 1) >> 6) * A + lane] = umin; // the whole group in one request
+            else LU(c) = umin;
             Uc_mine = umin;
         }
         real_steps += __popcll(ballot64(avail));
@@ -545,7 +562,17 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         k_done = k + 1;
         if (any64(bad)) { status = MP_ERR_REWARD_RANGE; break; }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); // (one wave per workgroup: in-order memory operations; no wait for the stores' acknowledgements)
-        {
+        if (SIB) { // the children, all of ONE row, against that row's best (lane re)
+            const int e = k + 1, re = e & 63;
+            const double cbu_re = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cbu), re), __builtin_amdgcn_readlane(__double2loint(cbu), re));
+            const bool mine = lane < A;
+            if (any64(mine && Uc_mine > cbu_re)) { // (wave-uniform)
+                const double um = mine ? Uc_mine : ninf;
+                const double m = A <= 16 ? row0_max(um) : wave_max(um);
+                const int jm = __ffsll((long long)ballot64(mine && Uc_mine == m)) - 1; // lowest id among equal bounds
+                if (lane == re) { cbu = m; cbid = (e << lgP) + jm; }
+            }
+        } else {
             const int j = (lane - g) & 63;
             const double u = __shfl(Uc_mine, j & 63);
             if (j < A) {
@@ -568,11 +595,27 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
     const int max_plan_len = q->max_plan_len;
 
     double root_upper = ninf;
-    for (int i = lane; i < n_nodes; i += 64) {
-        const double u = LU(i);
-        Umin[i] = u != u ? ninf : u;
-        if (u > root_upper) root_upper = u;
-        if (u != u) exp_map[__double2loint(u)] = i;
+    if (SIB) {
+        for (int r = 0; r < 64 && r <= k_done; ++r) {
+            const int cnt = (((k_done - r) >> 6) + 1) * A;
+            for (int t = lane; t < cnt; t += 64) { // slot t = group t / |A| of row r, child t mod |A|
+                const int e = ((t / A) << 6) | r, jj = t % A;
+                if (e > 0 || jj == 0) {
+                    const int id = e == 0 ? 0 : 1 + (e - 1) * A + jj;
+                    const double u = leafU[r * T + t];
+                    Umin[id] = u != u ? ninf : u;
+                    if (u > root_upper) root_upper = u;
+                    if (u != u) exp_map[__double2loint(u)] = id;
+                }
+            }
+        }
+    } else {
+        for (int i = lane; i < n_nodes; i += 64) {
+            const double u = LU(i);
+            Umin[i] = u != u ? ninf : u;
+            if (u > root_upper) root_upper = u;
+            if (u != u) exp_map[__double2loint(u)] = i;
+        }
     }
     root_upper = wave_max(root_upper);
     __syncthreads();
@@ -608,7 +651,7 @@ __global__ __launch_bounds__(64, 8) void ropd_wide_kernel(ROpdArgs p)
         while (kcur >= 0) {
             const int fc = 1 + kcur * A;
             const double l = lane < A ? Lmin[fc + lane] : ninf;
-            const double slot = lane < A ? LU(fc + lane) : 0.0;
+            const double slot = lane >= A ? 0.0 : SIB ? leafU[((kcur + 1) & 63) * T + ((kcur + 1) >> 6) * A + lane] : LU(fc + lane);
             const double m = A <= 16 ? row0_max(l) : wave_max(l);
             const unsigned long long ties = ballot64(lane < A && l == m);
             const int nt = __popcll(ties);
@@ -844,7 +887,13 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(upload_tables(ctx, 2, tab, &d_tab));
 
     ROpdArgs a;
-    a.n_roots = n_roots; a.M = M; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk;
+    // high-occupancy variant: the sibling layout of its bounds array (default; MP_OPD_WIDE=cls: the residue-class layout), see opd.hip
+    int lgP = 0;
+    while ((1 << lgP) < A) ++lgP;
+    const int Tsib = ((K + 1 + 63) / 64) * A + 16;
+    const char *wide_env = getenv("MP_OPD_WIDE");
+    const bool sib = !(wide_env && wide_env[0] == 'c');
+    a.n_roots = n_roots; a.M = M; a.S = model->S; a.A = A; a.K = K; a.cap = (int)cap; a.T = T; a.chunk = chunk; a.Tsib = Tsib; a.lgP = lgP;
     { const char *cl = getenv("MP_OPD_CLOSING"); a.closing_chain = cl && cl[0] == 'c'; }
     a.done_on_next = model->done_on_next; a.max_plan_len = max_plan_len;
     a.rec = model->rec_all;
@@ -857,7 +906,7 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(ws_get(ctx, WS_TREE4, nn * M, &a.Rv));
     MP_TRY(ws_get(ctx, WS_TREE5, nn * 2, &a.meta));
     a.leaf_global = nullptr;
-    if (glb && !any_a) MP_TRY(ws_get(ctx, WS_TREE6, (size_t)n_roots * 64 * T, &a.leaf_global));
+    if (glb && !any_a) MP_TRY(ws_get(ctx, WS_TREE6, (size_t)n_roots * 64 * (sib ? Tsib : T), &a.leaf_global));
     MP_TRY(ws_get(ctx, WS_TREE7, (size_t)n_roots * (K > 0 ? K : 1) + n_roots, &a.expanded));
     a.n_nodes_out = a.expanded + (size_t)n_roots * (K > 0 ? K : 1);
     ctx->tree.kind = 3; ctx->tree.n_roots = n_roots; ctx->tree.A = A; ctx->tree.cap = (int)cap; ctx->tree.K = K;
@@ -886,8 +935,11 @@ int mp_ropd_plan(mp_ctx *ctx, mp_model *model, int32_t n_roots, const int32_t *r
     MP_TRY(kernels_begin(ctx));
     const bool nonneg = gamma >= 0 && gamma < 1 && terminal_reward >= 0 && !(mode_env && mode_env[0] == '0');
     if (any_a) hipLaunchKernelGGL(ropd_any_kernel, dim3((unsigned)n_roots), dim3(64), 0, st, a);
-    else if (glb && nonneg) hipLaunchKernelGGL(ropd_wide_kernel<true>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
-    else if (glb) hipLaunchKernelGGL(ropd_wide_kernel<false>, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    else if (glb) {
+        const kernel_t kw = sib ? (nonneg ? ropd_wide_kernel<true, true> : ropd_wide_kernel<false, true>)
+                                : (nonneg ? ropd_wide_kernel<true, false> : ropd_wide_kernel<false, false>);
+        hipLaunchKernelGGL(kw, dim3((unsigned)n_roots), dim3(64), lds, st, a);
+    }
     else hipLaunchKernelGGL(kfn, dim3((unsigned)n_roots), dim3(64), lds, st, a);
     MP_TRY(kernels_end(ctx, 1));
     MP_HIP(hipGetLastError());

@@ -70,11 +70,13 @@ def test_robust_state_value_all_device_paths_vs_oracle(ctx, n_states, n_models, 
     model.close()
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 def test_robust_planner_restricted_actions_goldens(ctx, z, variant, monkeypatch):
     """mp_ropd_plan on joint models that restrict their actions (union over the models, robust.py:22-25): plans, bounds,
     env steps, generator state and whole trees of the reference's DiscreteRobustPlanner, in every kernel variant."""
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])      # "global_cls": the wide kernels' residue-class layout
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
     for name in names(z, "robust_masked"):
         p = "robust_masked/" + name
         t, r, term = robust_models(z, p)
@@ -123,14 +125,16 @@ def test_robust_planner_agent_on_restricted_models(z):
         assert root.count == int(z[p + "/root_count"]) and root.get_value() == float(z[p + "/root_upper"]), name
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 @pytest.mark.parametrize("n_models,n_actions,budget", [(1, 3, 150), (2, 5, 500), (3, 4, 300), (5, 7, 280), (16, 2, 100), (24, 3, 150),
                                                         (32, 2, 100), (33, 2, 100), (70, 3, 150), (2, 65, 700), (3, 130, 1400)])   # (|A| > 64: the plain kernel;
                                                         # > 32 models: done flags beyond the node's 32 bits ride in the reward's sign)
 def test_robust_planner_restricted_actions_batch_vs_oracle(ctx, n_models, n_actions, budget, variant, monkeypatch):
     from oracle import oracle
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])      # "global_cls": the wide kernels' residue-class layout
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
     s_ = 200
     cfgs = [generators.random_deterministic(s_, n_actions, seed=60 + i, terminal_rate=0.05) for i in range(n_models)]
     t, r = np.stack([c["transition"] for c in cfgs]), np.stack([c["reward"] for c in cfgs])
@@ -154,14 +158,16 @@ def test_robust_planner_restricted_actions_batch_vs_oracle(ctx, n_models, n_acti
     model.close()
 
 
-@pytest.mark.parametrize("variant", ["lds", "global"])
+@pytest.mark.parametrize("variant", ["lds", "global", "global_cls"])
 @pytest.mark.parametrize("n_models", [33, 40, 70])
 def test_robust_planner_more_than_32_models_tree_export(ctx, n_models, variant, monkeypatch):
     """The exported tree of a plan over more than 32 models (the reference has no bound: JointEnv steps a list,
     robust.py:9-16): per-model states, rewards, done flags and bound vectors of every node against the oracle's tree."""
     from oracle import oracle
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])      # "global_cls": the wide kernels' residue-class layout
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
     s_, a_, budget = 120, 3, 90
     cfgs = [generators.random_deterministic(s_, a_, seed=300 + i, terminal_rate=0.15) for i in range(n_models)]
     t, r = np.stack([c["transition"] for c in cfgs]), np.stack([c["reward"] for c in cfgs])

@@ -280,12 +280,14 @@ def test_opd_restricted_actions_goldens(ctx, z):
     assert len(agent_factory(env, dict(__class__=SAOPD, budget=40)).plan(0)) >= 1
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 @pytest.mark.parametrize("n_actions,budget", [(2, 101), (4, 100), (5, 500), (7, 300), (64, 640)])
 def test_opd_restricted_actions_batch_vs_oracle(ctx, n_actions, budget, variant, monkeypatch):
     from oracle import oracle
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])      # "global_cls": the wide kernels' residue-class layout
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
     cfg = generators.random_deterministic(300, n_actions, seed=90 + n_actions, terminal_rate=0.05)
     t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
     avail = generators.random_available(300, n_actions, seed=n_actions, rate=0.45)
@@ -318,12 +320,14 @@ def _robust_models(z, p):
                   np.stack([c["terminal"] for c in cfgs]))
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 def test_discrete_robust_planner_goldens(ctx, z, variant, monkeypatch):
     """mp_ropd_plan against the reference's DiscreteRobustPlanner / RobustNode: plans, min-over-model root bounds, full
     trees with per-model vectors, generator states."""
     from tests.helpers import bfs_children
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])      # "global_cls": the wide kernels' residue-class layout
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
     for name in names(z, "robust"):
         p = "robust/" + name
         cfgs, (t, r, term) = _robust_models(z, p)
@@ -379,13 +383,15 @@ def test_discrete_robust_planner_agent(z):
         agent_factory(trap, dict(__class__=DRP, budget=20, models=[[], []])).plan(0)
 
 
-@pytest.mark.parametrize("variant", ["lds", "ldsx", "global"])
+@pytest.mark.parametrize("variant", ["lds", "ldsx", "global", "global_cls"])
 @pytest.mark.parametrize("n_models,n_actions,budget", [(1, 3, 200), (2, 5, 500), (3, 4, 100), (5, 2, 101), (16, 7, 300)])
 def test_discrete_robust_planner_batch_vs_oracle(ctx, n_models, n_actions, budget, variant, monkeypatch):
     """70 roots with distinct joint states (every model in its own state) per launch vs the oracle."""
     from oracle import oracle
     from rl_agents_amd.envs import generators
-    monkeypatch.setenv("MP_OPD_MODEL", variant)
+    monkeypatch.setenv("MP_OPD_MODEL", variant.split("_")[0])      # "global_cls": the wide kernels' residue-class layout
+    if variant.endswith("_cls"):
+        monkeypatch.setenv("MP_OPD_WIDE", "cls")
     cfgs = [generators.random_deterministic(300, n_actions, seed=100 * n_models + i, terminal_rate=0.05) for i in range(n_models)]
     t = np.stack([c["transition"] for c in cfgs])
     r = np.stack([c["reward"] for c in cfgs])
