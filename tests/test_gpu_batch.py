@@ -262,6 +262,22 @@ def test_opd_batch_action_counts(ctx, n_actions, budget, variant, monkeypatch):
     _cmp_opd(ctx, cfg, 70, budget, 0.9, terminal_reward=0.25, seed=n_actions)
 
 
+@pytest.mark.parametrize("variant", ["lds", "global", "global_cls"])
+@pytest.mark.parametrize("gamma", [0.8, 0.9, 0.95, 0.6])
+def test_opd_children_an_ulp_above_their_parent(ctx, gamma, variant, monkeypatch):
+    """Rewards of exactly 1: in exact arithmetic a child's upper bound EQUALS its parent's (gamma^(d-1) + gamma^d / (1 - gamma) =
+    gamma^(d-1) / (1 - gamma)), so every leaf ties with every other -- and rounded, some children land an ulp ABOVE the
+    maximum the selection holds (6 of 59 depths at gamma = 0.8).  The wide kernel's select_drain / rescan_best keep that
+    maximum across expansions and must notice; plans, bounds, generator states and whole trees vs the oracle."""
+    from rl_agents_amd.envs import generators
+    _opd_variant(monkeypatch, variant)
+    cfg = generators.random_deterministic(200, 5, seed=310, terminal_rate=0.02)
+    ones = dict(cfg, reward=np.ones_like(cfg["reward"]))
+    _cmp_opd(ctx, ones, 40, 1500, gamma, seed=int(gamma * 100))
+    two = dict(cfg, reward=np.where(cfg["reward"] > 0.5, 1.0, 0.5))
+    _cmp_opd(ctx, two, 40, 1500, gamma, terminal_reward=0.5, seed=int(gamma * 100) + 1)
+
+
 @pytest.mark.parametrize("n_actions,budget", [(65, 650), (100, 1999), (130, 1300), (257, 2000)])
 def test_opd_more_actions_than_lanes(ctx, n_actions, budget):
     """Round 4: |A| > 64 (the reference has no bound) runs on the plain kernel -- children 64 at a time, leaf argmax as a scan;
