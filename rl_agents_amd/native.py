@@ -268,6 +268,8 @@ class Context(object):
 
     def close(self):
         if getattr(self, "_h", None):
+            for buf in self.__dict__.pop("_pin_cache", {}).values():
+                buf.close()
             self._lib.mp_ctx_destroy(self._h)
             self._h = None
 
@@ -357,6 +359,21 @@ class Context(object):
             shapes.update(root_child_count=((n, int(n_actions)), np.int64), root_child_value=((n, int(n_actions)), np.float64))
         names = ["root_state"] + [k for k in outputs]
         return PinnedArrays(self, {k: shapes[k] for k in names})
+
+    # Host-array plans of FEW roots (a single agent's act(): one root) are made through pinned scratch arrays the context
+    # keeps: the kernel reads and writes them in place (zero-copy) and the call is one launch + one synchronisation instead of
+    # nine pageable copies, each a driver round trip longer than the data (MCTSAgent.act 0.40 -> ms: tools/agent_latency.py).
+    SMALL_PLAN_ROOTS = 64
+
+    def _scratch(self, kind, n, spec):
+        cache = self.__dict__.setdefault("_pin_cache", {})
+        key = (kind, n) + tuple((k,) + tuple(v[0]) for k, v in spec.items())
+        buf = cache.get(key)
+        if buf is None:
+            if len(cache) >= 8:                                  # a handful of shapes per process: evict the oldest
+                cache.pop(next(iter(cache))).close()
+            buf = cache[key] = PinnedArrays(self, spec)
+        return buf
 
     def device_rng(self, states_or_n):
         """Generator records resident on the device (mp_rng): an int n (uninitialised) or a uint64 [n, 6] array."""
@@ -658,11 +675,28 @@ class Context(object):
             if policy is not None:              # (policies are tables over the global states: no second index needed)
                 rs = (mi * np.int32(model.S_each) + rs).astype(np.int32)
                 mi = None
+        scratch = None
         if out is not None:                     # caller-owned (pinned) buffers: only the outputs they hold are produced
             mpl = out["plans"].shape[1] if "plans" in out else 0
             for k in out:
                 if k != "root_state" and out[k].shape[0] != n:
                     raise ValueError("output buffer '{}' holds {} roots, the batch has {}".format(k, out[k].shape[0], n))
+        elif (n <= self.SMALL_PLAN_ROOTS and mem == MP_MEM_HOST and mi is None and model.mode != MODE_CARTPOLE
+              and not os.environ.get("MP_NO_PINNED_SCRATCH")):
+            mpl = int(horizon if max_plan_len is None else max_plan_len)
+            a_ = int(model.A)
+            scratch = self._scratch("uct", n, dict(
+                root_state=((n,), np.int32), root_steps=((n,), np.int32), rng=((n, 6), np.uint64), plans=((n, mpl), np.int32),
+                plan_len=((n,), np.int32), root_value=((n,), np.float64), root_child_count=((n, a_), np.int64),
+                root_child_value=((n, a_), np.float64), env_steps=((n,), np.int64)))
+            scratch["root_state"][:] = rs
+            scratch["rng"][:] = rng_state.reshape(n, 6)
+            scratch["plans"][:] = -1
+            rs, rng_ptr = scratch["root_state"], scratch["rng"].ctypes.data
+            if st is not None:
+                scratch["root_steps"][:] = st
+                st = scratch["root_steps"]
+            out = {k: scratch[k] for k in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps")}
         else:
             mpl = int(horizon if max_plan_len is None else max_plan_len)
             out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
@@ -674,7 +708,7 @@ class Context(object):
             _check(self._lib.mp_uct_plan_policy(self._h, model._h, policy._h, n, _ptr(rs), _ptr(st), int(episodes),
                                                 int(horizon), float(gamma), float(temperature), rng_ptr, mpl,
                                                 o[0], o[1], o[2], o[3], o[4], o[5], mem))
-            return out
+            return self._from_scratch(scratch, out, rng_state)
         pp = np.ascontiguousarray(prior_p, dtype=np.float64)
         rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
         if pp.shape != (model.A,) or rp.shape != (model.A,):
@@ -687,7 +721,16 @@ class Context(object):
         _check(self._lib.mp_uct_plan(self._h, model._h, n, _ptr(rs), _ptr(st), int(episodes), int(horizon),
                                      float(gamma), float(temperature), _ptr(pp), _ptr(rp), rng_ptr, mpl,
                                      o[0], o[1], o[2], o[3], o[4], o[5], mem))
-        return out
+        return self._from_scratch(scratch, out, rng_state)
+
+    @staticmethod
+    def _from_scratch(scratch, out, rng_state):
+        """Results of a small plan leave the context's pinned scratch arrays as the caller's own copies (the generator records
+        go back into the caller's array, advanced)."""
+        if scratch is None:
+            return out
+        rng_state.reshape(-1, 6)[:] = scratch["rng"]
+        return {k: v.copy() for k, v in out.items()}
 
     @staticmethod
     def _rng_arg(rng_state, n):
@@ -825,6 +868,19 @@ class Context(object):
                 and rng_state.size == n * 6):
             raise ValueError("rng_state must be a C-contiguous uint64 array of shape [n_roots, 6]")
         mpl = int(max_plan_len)
+        if n <= self.SMALL_PLAN_ROOTS and model_index is None and not os.environ.get("MP_NO_PINNED_SCRATCH"):
+            scratch = self._scratch("opd", n, dict(
+                root_state=((n,), np.int32), rng=((n, 6), np.uint64), plans=((n, mpl), np.int32), plan_len=((n,), np.int32),
+                root_lower=((n,), np.float64), root_upper=((n,), np.float64), env_steps=((n,), np.int64), status=((n,), np.int32)))
+            scratch["root_state"][:] = rs
+            scratch["rng"][:] = rng_state.reshape(n, 6)
+            scratch["plans"][:] = -1
+            out = {k: scratch[k] for k in ("plans", "plan_len", "root_lower", "root_upper", "env_steps", "status")}
+            _check(self._lib.mp_opd_plan(self._h, model._h, n, _ptr(scratch["root_state"]), int(budget), float(gamma),
+                                         float(terminal_reward), _ptr(scratch["rng"]), mpl, _ptr(out["plans"]),
+                                         _ptr(out["plan_len"]), _ptr(out["root_lower"]), _ptr(out["root_upper"]),
+                                         _ptr(out["env_steps"]), _ptr(out["status"]), MP_MEM_HOST))
+            return self._from_scratch(scratch, out, rng_state)
         out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
                    root_lower=np.zeros(n, np.float64), root_upper=np.zeros(n, np.float64),
                    env_steps=np.zeros(n, np.int64), status=np.zeros(n, np.int32))
