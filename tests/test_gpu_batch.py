@@ -989,3 +989,36 @@ def test_state_aware_queue_grows_by_rollback(ctx, mapping, monkeypatch):
     assert most > 2000
     planners.close()
     model.close()
+
+
+def test_small_plans_through_pinned_scratch_equal_pageable_ones(ctx, monkeypatch):
+    """Host-array plans of at most 64 roots run through pinned scratch arrays of the context (zero-copy; round 5): same plans,
+    statistics, env steps and advanced generator records as the pageable path (MP_NO_PINNED_SCRATCH=1), results owned by the
+    caller (a second call does not overwrite the first one's arrays)."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(6, 8, 40, seed=2)
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    p = np.ones(5) / 5
+    for n in (1, 7, 64):
+        s0 = np.random.Generator(np.random.PCG64(n)).integers(0, cfg["reward"].shape[0], size=n).astype(np.int32)
+        steps = np.arange(n, dtype=np.int32) % 3
+        rng_a, rng_b = _rng_states(n, base=5), _rng_states(n, base=5)
+        a = ctx.uct_plan(model, s0, 20, 12, 0.9, 1.0, p, p, rng_a, root_steps=steps)
+        a2 = ctx.uct_plan(model, s0, 20, 12, 0.9, 1.0, p, p, rng_a.copy(), root_steps=steps)      # (same scratch arrays again)
+        monkeypatch.setenv("MP_NO_PINNED_SCRATCH", "1")
+        b = ctx.uct_plan(model, s0, 20, 12, 0.9, 1.0, p, p, rng_b, root_steps=steps)
+        monkeypatch.delenv("MP_NO_PINNED_SCRATCH")
+        assert set(a) == set(b)
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+            assert a[k] is not a2[k]
+        np.testing.assert_array_equal(rng_a, rng_b)
+        rng_a, rng_b = _rng_states(n, base=9), _rng_states(n, base=9)
+        a = ctx.opd_plan(model, s0, 300, 0.9, 0.0, rng_a, max_plan_len=70)
+        monkeypatch.setenv("MP_NO_PINNED_SCRATCH", "1")
+        b = ctx.opd_plan(model, s0, 300, 0.9, 0.0, rng_b, max_plan_len=70)
+        monkeypatch.delenv("MP_NO_PINNED_SCRATCH")
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+        np.testing.assert_array_equal(rng_a, rng_b)
+    model.close()
