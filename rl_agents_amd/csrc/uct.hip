@@ -43,6 +43,7 @@
 #include "common.hpp"
 #include "libm_sincos.hpp"
 #include "pcg64.hpp"
+#include "wave.hpp"
 
 namespace mp {
 
@@ -825,6 +826,197 @@ void uct_kernel(UctArgs p)
     }
 }
 
+// ---- ONE ROOT PER WORKGROUP (round 5): the plan of a single agent's act(), and of every batch small enough to give each root
+// a CU of its own.  A lone root is one dependency chain; uct_kernel runs it in one lane of a wave, the tree in global memory
+// (a dependent L2 round trip per scored level and per backed-up node), every rollout step behind numpy's 128-bit generator
+// step.  Here the whole WAVEFRONT works for the root:
+//   * the model (3 B per (s, a)), the per-call tables AND THE TREE live in LDS (a 33-episode tree is 2.7 KB); sixteen waves
+//     stage them, one stays;
+//   * a level's |A| children are scored by |A| lanes, a path's nodes are backed up by as many lanes at once;
+//   * a rollout's actions do not depend on the states it visits (state-independent policy): lane l draws action l from the
+//     generator l + 1 steps ahead (one table-driven jump: A^(l+1) s + inc G_(l+1)), then the walk is H dependent LDS reads
+//     and nothing else -- the rewards are looked up by the lanes in parallel afterwards and added in the reference's order;
+//     the generator then jumps by the n draws the walk consumed, so the stream stays the reference's.
+// Same trees, plans, statistics and generator records as uct_kernel (every single-root golden runs through it when forced:
+// MP_UCT_LONE=1); the tree is written to global memory in the group-interleaved layout at the end (export, re-rooting).
+template <int AT>
+__global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
+{
+    static_assert(AT >= 2 && AT <= 8, "|A| with a compile-time specialisation");
+    constexpr int A = AT, NTH = AT - 1;
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int tid = threadIdx.x, lane = tid & 63, nthreads = blockDim.x;
+    const int H = p.horizon, E = p.episodes, TE = p.table_n;
+    double *gpow = lds_d;                   // [H + 1]  gamma ** h
+    double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
+    double *rcp = tp + A;                   // [TE + 1]  1.0 / n
+    double *tpdiv = rcp + (TE + 1);         // [A][TE+2] temperature * |A| * prior[a] / n
+    const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
+    const int ntab2 = (ntab + 1) & ~1;
+    const double *rdict = lds_d + ntab2;
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(lds_d + ntab2 + ((p.n_rdict + 1) & ~1));
+    uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((p.S * A + 7) & ~7));
+    uint32_t *jump = reinterpret_cast<uint32_t *>(r8 + ((p.S * A + 15) & ~15)); // [H + 5][8]
+    UctNode *tnode = reinterpret_cast<UctNode *>(jump + (H + 5) * 8);            // [cap]
+    int32_t *path = reinterpret_cast<int32_t *>(tnode + p.cap);                  // [H + 1]
+    for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
+    for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
+    for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
+    {
+        const int n16 = (p.S * A + 15) >> 4; // (the device arrays are padded to whole 16-byte chunks)
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.r8);
+        uint4 *dst = reinterpret_cast<uint4 *>(r8);
+        for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+        const int n = p.S * A, n8 = n >> 3;
+        const uint4 *src2 = reinterpret_cast<const uint4 *>(p.t16);
+        uint4 *dst2 = reinterpret_cast<uint4 *>(t16);
+        for (int i = tid; i < n8; i += nthreads) dst2[i] = src2[i];
+        for (int i = (n8 << 3) + tid; i < n; i += nthreads) t16[i] = p.t16[i];
+    }
+    __syncthreads();
+    if (tid >= 64) return; // (the staging waves are done; no barrier below)
+    const int r = blockIdx.x;
+    auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
+    auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
+    Pcg64 g;                                     // (every lane holds the same generator)
+    g.load(p.rng + (long)r * 6);
+    const int32_t s0 = p.root_state[r];
+    const int32_t st0 = p.root_steps ? p.root_steps[r] : 0;
+    const bool root_term = (p.rec[(long)s0 * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
+    int n_nodes = 1, steps_taken = 0;
+    if (lane == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; } // mcts.py:129-130 reset()
+    __builtin_amdgcn_wave_barrier();
+    const int la = lane < A ? lane : 0;
+    for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
+        int32_t s = s0, st = st0;
+        int node = 0, depth = 0;
+        bool terminal = false, cur_term = root_term;
+        double total = 0.0;
+        if (lane == 0) path[0] = 0;
+        int fc = tnode[0].first_child;
+        // ---- selection, mcts.py:143-149: a level's children one per lane
+        while (depth < H && fc >= 0 && !terminal) {
+            const UctNode c = tnode[fc + la];
+            double sc = c.value + explore(la, c.count + 1); // MCTSNode.selection_strategy, mcts.py:275-286
+            if (lane >= A) sc = -INFINITY;
+            const double m = row0_max(sc);
+            const unsigned long long ties = ballot64(lane < A && sc == m); // Node.random_argmax, abstract.py:296-311
+            const int nt = __popcll(ties);
+            int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
+            pick = __builtin_amdgcn_readfirstlane(pick);
+            unsigned long long t = ties;
+            while (pick-- > 0) t &= t - 1;
+            const int act = __ffsll((long long)t) - 1;
+            const int nfc = __builtin_amdgcn_readlane(c.first_child, act);
+            const unsigned idx = (unsigned)(s * A + act);
+            const uint32_t e = t16[idx];
+            const double reward = rdict[r8[idx]];
+            const bool next_term = (e & 0x8000u) != 0;
+            terminal = p.done_on_next ? next_term : cur_term;
+            cur_term = next_term;
+            s = (int32_t)(e & 0x7fffu);
+            ++st; ++steps_taken;
+            total += gpow[depth] * reward;
+            node = fc + act;
+            ++depth;
+            if (lane == 0) path[depth] = node;
+            fc = nfc;
+        }
+        // ---- expansion, mcts.py:151-154 / 237-246
+        if (fc < 0 && depth < H && (!terminal || node == 0)) {
+            if (lane == 0) tnode[node].first_child = n_nodes;
+            if (lane < A) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[n_nodes + lane] = n; }
+            n_nodes += A;
+        }
+        // ---- rollout, mcts.py:156-157 / 160-177
+        if (!terminal && depth < H) {
+            uint32_t act_l;
+            {
+                Pcg64 q = g;
+                const int j1 = lane + 1 < H ? lane + 1 : H; // (draws beyond the horizon are never used)
+                uint32_t an[4], gn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { an[i] = jump[j1 * 8 + i]; gn[i] = jump[j1 * 8 + 4 + i]; }
+                q.jump(an, gn);
+                const uint64_t u = q.output();     // searchsorted(cdf, u, 'right') on the raw 64-bit output
+                int act = 0;
+#pragma unroll
+                for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0;
+                act_l = (uint32_t)min(act, p.thr_valid);
+            }
+            int h = depth, n = 0;
+            unsigned my_idx = 0;                   // lane i: the record of rollout step i
+            bool alive = true;
+            while (alive) {
+                const int a_i = __builtin_amdgcn_readlane((int)act_l, __builtin_amdgcn_readfirstlane(n));
+                const unsigned idx = (unsigned)(s * A + a_i);
+                const uint32_t e = t16[idx];
+                if (lane == n) my_idx = idx;
+                const bool next_term = (e & 0x8000u) != 0;
+                const bool term_h = p.done_on_next ? next_term : cur_term;
+                cur_term = next_term;
+                s = (int32_t)(e & 0x7fffu);
+                ++st; ++steps_taken; ++h; ++n;
+                alive = !(term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H);
+            }
+            // the rewards of the n steps, looked up by n lanes at once and added in the reference's order
+            const double prod = lane < n ? gpow[depth + lane] * rdict[r8[my_idx]] : 0.0;
+            for (int i = 0; i < n; ++i) total += bcast_lane(prod, i);
+            {   // the generator after the n draws the walk consumed: A^n state + inc G_n
+                uint32_t an[4], gn[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { an[i] = jump[n * 8 + i]; gn[i] = jump[n * 8 + 4 + i]; }
+                g.jump(an, gn);
+            }
+        }
+        // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
+        __builtin_amdgcn_wave_barrier();
+        if (lane <= depth) {
+            const int nd = path[lane];
+            UctNode c = tnode[nd];
+            c.count += 1;
+            c.value += inv(c.count) * (total - c.value);
+            tnode[nd].value = c.value;       // (first_child is left alone: the node may just have been expanded)
+            tnode[nd].count = c.count;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    // the tree, to global memory in the group-interleaved layout (export, re-rooting by step_by_subtree)
+    const TreeRef<2, AT> tree = tree_of<2, AT>(p.tree, r, p.cap, A);
+    for (int i = lane; i < n_nodes; i += 64) tree[i] = tnode[i];
+    if (lane == 0) {
+        g.store(p.rng + (long)r * 6);
+        // ---- AbstractPlanner.get_plan (abstract.py:143-156) with MCTSNode.selection_rule (mcts.py:212-218): most visited
+        // child, ties -> first maximal value among them
+        int len = 0;
+        int fc = tnode[0].first_child;
+        while (fc >= 0) {
+            int mc = tnode[fc].count;
+            for (int a = 1; a < A; ++a) mc = max(mc, tnode[fc + a].count);
+            int best = -1;
+            double bv = 0.0;
+            for (int a = 0; a < A; ++a) {
+                const UctNode c = tnode[fc + a];
+                if (c.count == mc && (best < 0 || c.value > bv)) { best = a; bv = c.value; }
+            }
+            if (p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = best;
+            ++len;
+            fc = tnode[fc + best].first_child;
+        }
+        if (p.plans)
+            for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[r] = len;
+        if (p.n_nodes_out) p.n_nodes_out[r] = n_nodes;
+        if (p.root_value) p.root_value[r] = tnode[0].value;
+        if (p.env_steps) p.env_steps[r] = (int64_t)steps_taken;
+        const int rfc = tnode[0].first_child;
+        for (int a = 0; a < A; ++a) {
+            if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? max(tnode[rfc + a].count, 0) : 0;
+            if (p.root_child_value) p.root_child_value[(long)r * A + a] = rfc >= 0 ? tnode[rfc + a].value : 0.0;
+        }
+    }
+}
+
 // AbstractPlanner.step_by_subtree (abstract.py:195-206), one root per lane: the subtree of the root's child
 // `action` is re-numbered breadth-first into the other tree buffer (children stay contiguous).  While a node
 // waits in the BFS queue its first_child field holds its OLD id.  A never-expanded root gives size 0 (fresh tree).
@@ -1114,8 +1306,21 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         quad = qe ? atoi(qe) != 0 : (!force && n_roots >= 16 && ((long)n_roots + 15) / 16 <= 4 * cus_q);
     }
     if (quad) { ldsr = true; ldsm = false; }
+    // ONE ROOT PER WORKGROUP (uct_lone_kernel): batches of fewer than 16 roots -- a single agent's act() -- on fresh trees, model,
+    // tables AND tree in LDS, the whole wavefront working for the root.  MP_UCT_LONE=1 / 0 forces it on (any batch) / off.
+    bool lone = false;
+    const size_t lds_lone = lds_quad + (size_t)cap * sizeof(UctNode) + (size_t)(H + 1) * sizeof(int32_t) + 16;
+    {
+        const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
+        if (!cart && !pol && at_known && model->t16 != nullptr && model->r8 != nullptr && want_il == 2 && H >= 1 && H <= 63 &&
+            lds_lone <= kLdsBytes && !will_continue) {
+            const char *le = getenv("MP_UCT_LONE");
+            lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots < 16);
+        }
+    }
+    if (lone) { quad = false; ldsr = false; ldsm = false; }
     a.jump = nullptr;
-    if (quad) {
+    if (quad || lone) {
         // limbs of A^n and G_n = 1 + A + ... + A^(n-1) (mod 2^128), n = 0..H: the generator after n draws is A^n state + inc G_n
         if (ctx->jump_entries < H + 5) {
             typedef unsigned __int128 u128;
@@ -1151,7 +1356,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         while (a.waves < w && a.waves < 16) a.waves <<= 1;
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
-    size_t lds = quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
+    size_t lds = lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
     if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double); // the sin / cos table of libm_sincos.hpp behind the path stack
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
@@ -1161,7 +1366,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     // a path stack that does not fit 64 KB of LDS (horizon >~ 180): registers + the global spill array instead
     bool spill = false;
-    if (!ldsm && !ldsr && lds > 64 * 1024) {
+    if (!lone && !ldsm && !ldsr && lds > 64 * 1024) {
         const char *lay_now = getenv("MP_UCT_TREE");
         if (cart || pol || (lay_now && lay_now[0] == 'i') || ntab * sizeof(double) > 64 * 1024)
             return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
@@ -1169,7 +1374,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         lds = ntab * sizeof(double);
     }
     if (const char *e = getenv("MP_UCT_PATH")) // "spill": force the register / global path stack (test hook)
-        if (e[0] == 's' && !ldsm && !ldsr && !cart && !pol && want_il != 1) { spill = true; lds = ntab * sizeof(double); }
+        if (e[0] == 's' && !lone && !ldsm && !ldsr && !cart && !pol && want_il != 1) { spill = true; lds = ntab * sizeof(double); }
 
     // trees: fresh ones, or (step_strategy "subtree") the kept ones re-rooted into the other buffer with room
     // for this plan's expansions
@@ -1207,7 +1412,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (lds > 64 * 1024) { spill = true; lds = ntab * sizeof(double); }
     }
     if (spill && ctx->tree.il == 1) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d needs the spilled path stack, which the interleaved tree layout does not have", H);
-    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (lone ? "uct_lone" : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
     if (ldsr || spill) {
         a.spill_stride = ((long)n_roots + 63) & ~63L;
         MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
@@ -1310,6 +1515,15 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (cart) {
             const dim3 grid((unsigned)((c.n_roots + c.lanes - 1) / c.lanes)), block(64);
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
+        } else if (lone) {
+#define MP_LONE(k)                                                                                                                 \
+    case k:                                                                                                                        \
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_lone_kernel<k>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                   (int)lds));                                                                                    \
+        hipLaunchKernelGGL((uct_lone_kernel<k>), dim3((unsigned)c.n_roots), dim3(1024), lds, s, c);                               \
+        break;
+            switch (A) { MP_LONE(2) MP_LONE(3) MP_LONE(4) MP_LONE(5) MP_LONE(6) MP_LONE(7) MP_LONE(8) default: break; }
+#undef MP_LONE
         } else
         switch (A) {
         case 2: MP_TRY(uct_launch<2>(c, ldsm, lds, s, pol != nullptr, listed, ldsr, spill, quad)); break;
