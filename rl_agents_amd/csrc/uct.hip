@@ -858,7 +858,8 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((p.S * A + 7) & ~7));
     uint32_t *jump = reinterpret_cast<uint32_t *>(r8 + ((p.S * A + 15) & ~15)); // [H + 5][8]
     UctNode *tnode = reinterpret_cast<UctNode *>(jump + (H + 5) * 8);            // [cap]
-    int32_t *path = reinterpret_cast<int32_t *>(tnode + p.cap);                  // [H + 1]
+    double *texpl = reinterpret_cast<double *>(tnode + p.cap);                   // [cap] a node's exploration term at its count
+    int32_t *path = reinterpret_cast<int32_t *>(texpl + p.cap);                  // [H + 1]
     for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
     for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
@@ -876,28 +877,40 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     __syncthreads();
     if (tid >= 64) return; // (the staging waves are done; no barrier below)
     const int r = blockIdx.x;
+    // MCTSNode.selection_strategy's exploration term temperature |A| prior[a] / (count + 1) (mcts.py:275-286): from the host's
+    // quotient table, or the same IEEE division beyond it.  Kept PER NODE beside the tree and refreshed by the backup (which
+    // changes the count), so that scoring a level is one LDS round trip, not two
     auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
     auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
     Pcg64 g;                                     // (every lane holds the same generator)
     g.load(p.rng + (long)r * 6);
-    const int32_t s0 = p.root_state[r];
-    const int32_t st0 = p.root_steps ? p.root_steps[r] : 0;
+    const int32_t s0 = __builtin_amdgcn_readfirstlane(p.root_state[r]);
+    const int32_t st0 = p.root_steps ? __builtin_amdgcn_readfirstlane(p.root_steps[r]) : 0;
     const bool root_term = (p.rec[(long)s0 * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
     int n_nodes = 1, steps_taken = 0;
-    if (lane == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; } // mcts.py:129-130 reset()
+    if (lane == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; texpl[0] = 0.0; } // mcts.py:129-130 reset()
     __builtin_amdgcn_wave_barrier();
     const int la = lane < A ? lane : 0;
+    const double expl1 = explore(la, 1);          // a fresh child's term (count 0)
+    // an env step's reward comes through two more LDS reads (reward index, reward): off the state chain, so both the descent
+    // and the rollout add the reward of step i one step later -- in the reference's order
+    auto reward_of = [&](unsigned idx) { return rdict[r8[idx]]; };
     for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
         int32_t s = s0, st = st0;
         int node = 0, depth = 0;
         bool terminal = false, cur_term = root_term;
         double total = 0.0;
         if (lane == 0) path[0] = 0;
-        int fc = tnode[0].first_child;
+        int fc = __builtin_amdgcn_readfirstlane(tnode[0].first_child);
+        unsigned pend_idx = 0;   // the env step whose reward is not added yet
+        bool have_pend = false;
+        int pend_h = 0;
         // ---- selection, mcts.py:143-149: a level's children one per lane
         while (depth < H && fc >= 0 && !terminal) {
             const UctNode c = tnode[fc + la];
-            double sc = c.value + explore(la, c.count + 1); // MCTSNode.selection_strategy, mcts.py:275-286
+            double sc = c.value + texpl[fc + la];
+            double rw = 0.0;
+            if (have_pend) rw = reward_of(pend_idx);
             if (lane >= A) sc = -INFINITY;
             const double m = row0_max(sc);
             const unsigned long long ties = ballot64(lane < A && sc == m); // Node.random_argmax, abstract.py:296-311
@@ -909,14 +922,14 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
             const int act = __ffsll((long long)t) - 1;
             const int nfc = __builtin_amdgcn_readlane(c.first_child, act);
             const unsigned idx = (unsigned)(s * A + act);
-            const uint32_t e = t16[idx];
-            const double reward = rdict[r8[idx]];
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t16[idx]);
+            if (have_pend) total += gpow[pend_h] * rw;
+            pend_idx = idx; pend_h = depth; have_pend = true;
             const bool next_term = (e & 0x8000u) != 0;
             terminal = p.done_on_next ? next_term : cur_term;
             cur_term = next_term;
             s = (int32_t)(e & 0x7fffu);
             ++st; ++steps_taken;
-            total += gpow[depth] * reward;
             node = fc + act;
             ++depth;
             if (lane == 0) path[depth] = node;
@@ -925,7 +938,12 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
         // ---- expansion, mcts.py:151-154 / 237-246
         if (fc < 0 && depth < H && (!terminal || node == 0)) {
             if (lane == 0) tnode[node].first_child = n_nodes;
-            if (lane < A) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[n_nodes + lane] = n; }
+            if (lane < A) {
+                UctNode n;
+                n.value = 0.0; n.count = 0; n.first_child = -1;
+                tnode[n_nodes + lane] = n;
+                texpl[n_nodes + lane] = expl1;
+            }
             n_nodes += A;
         }
         // ---- rollout, mcts.py:156-157 / 160-177
@@ -944,24 +962,28 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
                 for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0;
                 act_l = (uint32_t)min(act, p.thr_valid);
             }
-            int h = depth, n = 0;
-            unsigned my_idx = 0;                   // lane i: the record of rollout step i
-            bool alive = true;
-            while (alive) {
-                const int a_i = __builtin_amdgcn_readlane((int)act_l, __builtin_amdgcn_readfirstlane(n));
+            // the walk: at most n_lim steps (horizon, the env's step limit), one dependent LDS read each; the reward of the
+            // previous step and the sum ride along
+            int n_lim = H - depth;
+            if (p.max_steps > 0 && p.max_steps - st < n_lim) n_lim = p.max_steps - st;
+            if (n_lim < 1) n_lim = 1; // (the first step is unconditional, as in the reference's loop)
+            int n = 0;
+            while (true) {
+                const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
                 const unsigned idx = (unsigned)(s * A + a_i);
-                const uint32_t e = t16[idx];
-                if (lane == n) my_idx = idx;
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t16[idx]);
+                double rw = 0.0;
+                if (have_pend) rw = reward_of(pend_idx);
+                if (have_pend) total += gpow[pend_h] * rw;
+                pend_idx = idx; pend_h = depth + n; have_pend = true;
                 const bool next_term = (e & 0x8000u) != 0;
                 const bool term_h = p.done_on_next ? next_term : cur_term;
                 cur_term = next_term;
                 s = (int32_t)(e & 0x7fffu);
-                ++st; ++steps_taken; ++h; ++n;
-                alive = !(term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H);
+                ++n;
+                if (term_h || n >= n_lim) break;
             }
-            // the rewards of the n steps, looked up by n lanes at once and added in the reference's order
-            const double prod = lane < n ? gpow[depth + lane] * rdict[r8[my_idx]] : 0.0;
-            for (int i = 0; i < n; ++i) total += bcast_lane(prod, i);
+            st += n; steps_taken += n;
             {   // the generator after the n draws the walk consumed: A^n state + inc G_n
                 uint32_t an[4], gn[4];
 #pragma unroll
@@ -969,6 +991,7 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
                 g.jump(an, gn);
             }
         }
+        if (have_pend) total += gpow[pend_h] * reward_of(pend_idx);
         // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
         __builtin_amdgcn_wave_barrier();
         if (lane <= depth) {
@@ -978,6 +1001,7 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
             c.value += inv(c.count) * (total - c.value);
             tnode[nd].value = c.value;       // (first_child is left alone: the node may just have been expanded)
             tnode[nd].count = c.count;
+            if (nd > 0) texpl[nd] = explore((nd - 1) % A, c.count + 1);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1309,7 +1333,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // ONE ROOT PER WORKGROUP (uct_lone_kernel): batches of fewer than 16 roots -- a single agent's act() -- on fresh trees, model,
     // tables AND tree in LDS, the whole wavefront working for the root.  MP_UCT_LONE=1 / 0 forces it on (any batch) / off.
     bool lone = false;
-    const size_t lds_lone = lds_quad + (size_t)cap * sizeof(UctNode) + (size_t)(H + 1) * sizeof(int32_t) + 16;
+    const size_t lds_lone = lds_quad + (size_t)cap * (sizeof(UctNode) + sizeof(double)) + (size_t)(H + 1) * sizeof(int32_t) + 16;
     {
         const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
         if (!cart && !pol && at_known && model->t16 != nullptr && model->r8 != nullptr && want_il == 2 && H >= 1 && H <= 63 &&
