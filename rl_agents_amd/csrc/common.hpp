@@ -113,6 +113,7 @@ struct mp_ctx {
     void *comm = nullptr;             // ncclComm_t of mp_comm_init (RCCL resolved with dlopen: api.hip)
     int comm_world = 0;
     int jump_entries = 0;             // PCG64 jump-ahead table (limbs of A^n, G_n for n < jump_entries) resident in WS_JUMP
+    std::vector<std::vector<uint32_t>> jump_host; // its host copies (one per rebuild): the source of an ASYNCHRONOUS upload has to outlive the call
     int32_t *visits_host = nullptr;   // mp_uct_record_visits: where the next stochastic-kernel plan writes its visit counts
     std::vector<double> stoch_priors; // stored child priors of the tree last exported by mp_uct_stoch_tree_export (per-state policies)
     size_t block_cache_bytes = 0;

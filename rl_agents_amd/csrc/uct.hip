@@ -892,9 +892,10 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     __builtin_amdgcn_wave_barrier();
     const int la = lane < A ? lane : 0;
     const double expl1 = explore(la, 1);          // a fresh child's term (count 0)
-    // an env step's reward comes through two more LDS reads (reward index, reward): off the state chain, so both the descent
-    // and the rollout add the reward of step i one step later -- in the reference's order
-    auto reward_of = [&](unsigned idx) { return rdict[r8[idx]]; };
+    // An env step's reward comes through two more LDS reads (reward index -> reward) that the state chain does not need: a
+    // three-stage pipeline over the steps of an episode (descent and rollout alike).  A step issues its transition read, its
+    // reward-index read and the PREVIOUS step's reward read together, and adds the reward of the step before that from
+    // registers -- one LDS round trip per step on the chain, the sum still in the reference's order.
     for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
         int32_t s = s0, st = st0;
         int node = 0, depth = 0;
@@ -902,17 +903,28 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
         double total = 0.0;
         if (lane == 0) path[0] = 0;
         int fc = __builtin_amdgcn_readfirstlane(tnode[0].first_child);
-        unsigned pend_idx = 0;   // the env step whose reward is not added yet
-        bool have_pend = false;
-        int pend_h = 0;
+        unsigned rb1 = 0; int h1 = 0; bool v1 = false;       // the last step: its reward index, its depth
+        double rd2 = 0.0, gp2 = 0.0; bool v2 = false;        // the step before: its reward, gamma ** depth
+#define MP_LONE_STEP(idx_, h_, e_out_)                                                                  \
+    do {                                                                                                \
+        const uint32_t e_raw_ = t16[idx_];                                                              \
+        const unsigned rbn_ = r8[idx_];                                                                 \
+        const double rdn_ = rdict[rb1], gpn_ = gpow[h1];                                                \
+        if (v2) total += gp2 * rd2;                                                                     \
+        rd2 = rdn_; gp2 = gpn_; v2 = v1;                                                                \
+        rb1 = rbn_; h1 = (h_); v1 = true;                                                               \
+        e_out_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_raw_);                                 \
+    } while (0)
         // ---- selection, mcts.py:143-149: a level's children one per lane
         while (depth < H && fc >= 0 && !terminal) {
             const UctNode c = tnode[fc + la];
             double sc = c.value + texpl[fc + la];
-            double rw = 0.0;
-            if (have_pend) rw = reward_of(pend_idx);
             if (lane >= A) sc = -INFINITY;
-            const double m = row0_max(sc);
+            // (|A| <= 8 scores by readlane into scalar registers and a chain of |A| - 1 maxima: a third of the DPP reduction's
+            // dependent instructions -- a lone wave runs at the latency of its chain)
+            double m = bcast_lane(sc, 0);
+#pragma unroll
+            for (int a = 1; a < A; ++a) { const double o = bcast_lane(sc, a); m = o > m ? o : m; }
             const unsigned long long ties = ballot64(lane < A && sc == m); // Node.random_argmax, abstract.py:296-311
             const int nt = __popcll(ties);
             int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
@@ -922,9 +934,8 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
             const int act = __ffsll((long long)t) - 1;
             const int nfc = __builtin_amdgcn_readlane(c.first_child, act);
             const unsigned idx = (unsigned)(s * A + act);
-            const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t16[idx]);
-            if (have_pend) total += gpow[pend_h] * rw;
-            pend_idx = idx; pend_h = depth; have_pend = true;
+            uint32_t e;
+            MP_LONE_STEP(idx, depth, e);
             const bool next_term = (e & 0x8000u) != 0;
             terminal = p.done_on_next ? next_term : cur_term;
             cur_term = next_term;
@@ -949,8 +960,8 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
         // ---- rollout, mcts.py:156-157 / 160-177
         if (!terminal && depth < H) {
             uint32_t act_l;
+            Pcg64 q = g;
             {
-                Pcg64 q = g;
                 const int j1 = lane + 1 < H ? lane + 1 : H; // (draws beyond the horizon are never used)
                 uint32_t an[4], gn[4];
 #pragma unroll
@@ -971,11 +982,8 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
             while (true) {
                 const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
                 const unsigned idx = (unsigned)(s * A + a_i);
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)t16[idx]);
-                double rw = 0.0;
-                if (have_pend) rw = reward_of(pend_idx);
-                if (have_pend) total += gpow[pend_h] * rw;
-                pend_idx = idx; pend_h = depth + n; have_pend = true;
+                uint32_t e;
+                MP_LONE_STEP(idx, depth + n, e);
                 const bool next_term = (e & 0x8000u) != 0;
                 const bool term_h = p.done_on_next ? next_term : cur_term;
                 cur_term = next_term;
@@ -984,14 +992,17 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
                 if (term_h || n >= n_lim) break;
             }
             st += n; steps_taken += n;
-            {   // the generator after the n draws the walk consumed: A^n state + inc G_n
-                uint32_t an[4], gn[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) { an[i] = jump[n * 8 + i]; gn[i] = jump[n * 8 + 4 + i]; }
-                g.jump(an, gn);
+            {   // the generator after the n draws the walk consumed = the state lane n - 1 jumped to for ITS draw
+                const int src = n - 1;
+                g.s_lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q.s_lo >> 32), src) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q.s_lo, src);
+                g.s_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q.s_hi >> 32), src) << 32) |
+                         (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q.s_hi, src);
             }
         }
-        if (have_pend) total += gpow[pend_h] * reward_of(pend_idx);
+#undef MP_LONE_STEP
+        if (v2) total += gp2 * rd2;                          // drain the pipeline: the last two steps
+        if (v1) total += gpow[h1] * rdict[rb1];
         // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
         __builtin_amdgcn_wave_barrier();
         if (lane <= depth) {
@@ -1330,8 +1341,8 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         quad = qe ? atoi(qe) != 0 : (!force && n_roots >= 16 && ((long)n_roots + 15) / 16 <= 4 * cus_q);
     }
     if (quad) { ldsr = true; ldsm = false; }
-    // ONE ROOT PER WORKGROUP (uct_lone_kernel): batches of fewer than 16 roots -- a single agent's act() -- on fresh trees, model,
-    // tables AND tree in LDS, the whole wavefront working for the root.  MP_UCT_LONE=1 / 0 forces it on (any batch) / off.
+    // ONE ROOT PER WORKGROUP (uct_lone_kernel): batches of at most one root per CU -- a single agent's act() above all -- on fresh
+    // trees: model, tables AND tree in LDS, the whole wavefront working for the root.  MP_UCT_LONE=1 / 0 forces it on (any batch) / off.
     bool lone = false;
     const size_t lds_lone = lds_quad + (size_t)cap * (sizeof(UctNode) + sizeof(double)) + (size_t)(H + 1) * sizeof(int32_t) + 16;
     {
@@ -1339,7 +1350,8 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (!cart && !pol && at_known && model->t16 != nullptr && model->r8 != nullptr && want_il == 2 && H >= 1 && H <= 63 &&
             lds_lone <= kLdsBytes && !will_continue) {
             const char *le = getenv("MP_UCT_LONE");
-            lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots < 16);
+            const long cus_l = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+            lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots <= cus_l); // (one workgroup per CU: 256 roots 0.14 ms, four lanes per root 0.27)
         }
     }
     if (lone) { quad = false; ldsr = false; ldsm = false; }
@@ -1350,7 +1362,10 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             typedef unsigned __int128 u128;
             const u128 mult = ((u128)0x2360ED051FC65DA4ULL << 64) | 0x4385DF649FCCF645ULL;
             const int n_e = H + 5 > 64 ? H + 5 : 64;
-            std::vector<uint32_t> tabj((size_t)n_e * 8);
+            // (kept in the context: the upload is asynchronous on the planner's stream -- a caller that runs the planners
+            // from a stream with pending waits, e.g. ShardedDevicePlan's double-buffered exchange, must not be synchronised here)
+            ctx->jump_host.emplace_back((size_t)n_e * 8, 0u);
+            std::vector<uint32_t> &tabj = ctx->jump_host.back();
             u128 an = 1, gn = 0;
             for (int n = 0; n < n_e; ++n) {
                 for (int i = 0; i < 4; ++i) { tabj[(size_t)n * 8 + i] = (uint32_t)(an >> (32 * i)); tabj[(size_t)n * 8 + 4 + i] = (uint32_t)(gn >> (32 * i)); }
@@ -1361,7 +1376,6 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             ctx->jump_entries = 0;
             MP_TRY(ws_get(ctx, WS_JUMP, tabj.size(), &dj));
             MP_HIP(hipMemcpyAsync(dj, tabj.data(), tabj.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            MP_HIP(hipStreamSynchronize(ctx->stream)); // (`tabj` is a local)
             ctx->jump_entries = n_e;
         }
         a.jump = static_cast<const uint32_t *>(ctx->ws[WS_JUMP].p);

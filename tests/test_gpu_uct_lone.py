@@ -1,0 +1,149 @@
+"""uct_lone_kernel (round 5): ONE ROOT PER WORKGROUP -- the plan of a single agent's act() and of every batch of at most one root
+per CU.  Model, per-call tables and the tree in LDS; a level's children scored one per lane; a rollout's actions drawn by the
+lanes in parallel with PCG64 jump-ahead, the walk one dependent LDS read per step, rewards one step behind.  Same plans,
+statistics, env-step counts, generator states and exported trees as the oracle.  Reference: MCTS.run / evaluate
+(mcts.py:132-184), Node.random_argmax (abstract.py:296-311)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from rl_agents_amd import native
+    c = native.Context(0)
+    yield c
+    c.close()
+
+
+def _cmp(ctx, cfg, n_roots, episodes, horizon, gamma, temperature, prior, rollout, seed=0, max_steps=0, steps0=None,
+         done_rule="source", expect="uct_lone", trees=(0,)):
+    from oracle import oracle
+    from rl_agents_amd import native
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    model = ctx.load_table(t, r, term, done_rule=done_rule, max_steps=max_steps)
+    s0 = np.random.Generator(np.random.PCG64(seed)).integers(0, r.shape[0], size=n_roots).astype(np.int32)
+    rng = native.seed_sequence_states((), 1000 * seed, n_roots)
+    rng_ref = rng.copy()
+    ctx.uct_reset_tree()
+    out = ctx.uct_plan(model, s0, episodes, horizon, gamma, temperature, prior, rollout, rng, root_steps=steps0,
+                       max_plan_len=max(horizon, 1))
+    assert ctx.last_kernel_variant() == expect, ctx.last_kernel_variant()
+    ref = oracle.uct_plan_batch(t, r, term, s0, episodes, horizon, gamma, temperature, prior, rollout, rng_ref, steps0=steps0,
+                                max_steps=max_steps, done_rule=done_rule, max_plan_len=max(horizon, 1), n_threads=8)
+    np.testing.assert_array_equal(out["plans"], ref["plans"])
+    np.testing.assert_array_equal(out["plan_len"], ref["plan_len"])
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(out["root_child_count"], ref["root_child_count"])
+    assert np.array_equal(out["root_child_value"], ref["root_child_value"])
+    np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+    for root in trees:                      # the whole tree (written from LDS to the exported layout), node for node
+        if root >= n_roots:
+            continue
+        tree = ctx.uct_tree(root, 1 + episodes * r.shape[1])
+        one = oracle.uct_plan(t, r, term, int(s0[root]), episodes, horizon, gamma, temperature, prior, rollout,
+                              native.seed_sequence_states((), 1000 * seed, n_roots)[root], max_steps=max_steps,
+                              steps0=0 if steps0 is None else int(steps0[root]), done_rule=done_rule,
+                              max_plan_len=max(horizon, 1))["tree"]
+        for k in ("parent", "action", "count", "value", "first_child"):
+            np.testing.assert_array_equal(tree[k], one[k], err_msg="tree[{}] of root {}".format(k, root))
+    model.close()
+    return out
+
+
+@pytest.mark.parametrize("n_roots", [1, 3, 15, 64, 256])
+def test_lone_headline_geometry(ctx, n_roots):
+    """Headline table (S = 10 000, |A| = 5: 150 of the CU's 160 KB of LDS), budget 1000 as 33 x 30."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    p = np.ones(5) / 5
+    _cmp(ctx, cfg, n_roots, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=n_roots, trees=(0, n_roots - 1))
+
+
+def test_lone_is_for_at_most_one_root_per_cu_and_by_request(ctx, monkeypatch):
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    p = np.ones(5) / 5
+    _cmp(ctx, cfg, 257, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_quad")
+    monkeypatch.setenv("MP_UCT_LONE", "0")
+    _cmp(ctx, cfg, 8, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_global")
+    monkeypatch.setenv("MP_UCT_LONE", "1")
+    _cmp(ctx, cfg, 700, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_lone")     # (three rounds of workgroups)
+
+
+@pytest.mark.parametrize("n_actions", [2, 3, 4, 6, 7, 8])
+def test_lone_every_action_count(ctx, n_actions):
+    g = np.random.Generator(np.random.PCG64(n_actions))
+    s = 300
+    cfg = dict(transition=g.integers(0, s, size=(s, n_actions)), reward=g.choice(np.linspace(0, 1, 17), size=(s, n_actions)),
+               terminal=g.random(s) < 0.05)
+    pr = g.random(n_actions) + 0.1
+    pr /= pr.sum()
+    ro = g.random(n_actions) + 0.1
+    ro /= ro.sum()
+    _cmp(ctx, cfg, 100, 40, 12, 0.9, 5.0, pr, ro, seed=n_actions, trees=(0, 99))
+
+
+@pytest.mark.parametrize("horizon", [1, 2, 4, 5, 39, 62, 63])
+def test_lone_horizons(ctx, horizon):
+    """Rollouts of every length up to the 63 steps one wavefront's lanes draw at once."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(4, 5, 50, collision_rate=0.01, seed=9)
+    p = np.ones(5) / 5
+    _cmp(ctx, cfg, 33, 25, horizon, 0.95, 10.0, p, p, seed=horizon)
+
+
+def test_lone_longer_horizons_and_many_episodes_fall_back(ctx):
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(4, 5, 50, collision_rate=0.01, seed=9)
+    p = np.ones(5) / 5
+    _cmp(ctx, cfg, 33, 10, 64, 0.95, 10.0, p, p, seed=1, expect="uct_quad", trees=())
+    _cmp(ctx, cfg, 5, 10, 64, 0.95, 10.0, p, p, seed=1, expect="uct_global", trees=())
+    big = generators.highway_shaped(10, 10, 100, seed=0)         # a 600-episode tree does not fit LDS beside this model
+    _cmp(ctx, big, 2, 600, 5, 0.8, 10.0, p, p, seed=3, expect="uct_global", trees=())
+
+
+def test_lone_truncation_terminal_conventions_and_zero_probabilities(ctx):
+    """TimeLimit truncation with per-root step counts (also roots already past the limit), both terminal conventions, a rollout
+    policy with zero-probability actions at either end, a preference-like prior."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(3, 4, 10, seed=3)
+    n = 200
+    steps0 = (np.arange(n) % 13).astype(np.int32)
+    prior = np.array([0.1, 0.5, 0.1, 0.2, 0.1])
+    for done_rule in ("source", "next"):
+        for rollout in (np.array([0.0, 0.25, 0.5, 0.25, 0.0]), np.array([0.0, 0.0, 1.0, 0.0, 0.0]), np.ones(5) / 5):
+            _cmp(ctx, cfg, n, 30, 8, 0.8, 10.0, prior, rollout, seed=4, max_steps=10, steps0=steps0, done_rule=done_rule,
+                 trees=(0, 12))
+
+
+def test_lone_hands_kept_subtrees_to_the_other_kernels(ctx):
+    """step_strategy 'subtree': the first plan (fresh tree) runs on the lone kernel, its tree -- written to the exported layout --
+    is re-rooted and CONTINUED by the one-lane kernel; three plans equal the oracle's."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(3, 4, 10, seed=3)
+    t, r, term = cfg["transition"], cfg["reward"], cfg["terminal"]
+    model = ctx.load_table(t, r, term)
+    p = np.ones(5) / 5
+    s, rng = 5, native.seed_sequence_states((), 11, 1)
+    ref_rng = rng.copy()
+    tree = None
+    ctx.uct_reset_tree()
+    for step in range(3):
+        out = ctx.uct_plan(model, [s], 25, 12, 0.8, 10.0, p, p, rng, max_plan_len=12)
+        assert ctx.last_kernel_variant() == ("uct_lone" if step == 0 else "uct_global")
+        ref = oracle.uct_plan(t, r, term, s, 25, 12, 0.8, 10.0, p, p, ref_rng[0], max_plan_len=12, init_tree=tree)
+        ref_rng[0] = ref["rng_after"]
+        n = int(out["plan_len"][0])
+        np.testing.assert_array_equal(out["plans"][0, :n], ref["plan"])
+        np.testing.assert_array_equal(rng, ref_rng)
+        a = int(ref["plan"][0])
+        ctx.uct_step_tree([a])
+        tree = oracle.uct_reroot(ref["tree"], a, 5)
+        s = int(t[s, a])
+    ctx.uct_reset_tree()
+    model.close()

@@ -18,6 +18,13 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _no_lone_kernel(monkeypatch):
+    """(batches of at most one root per CU take uct_lone_kernel by default since it exists -- tests/test_gpu_uct_lone.py; this
+    file is about the kernel that served them before and still serves 257 .. 16 384 roots)"""
+    monkeypatch.setenv("MP_UCT_LONE", "0")
+
+
 def _rng_states(n, base=0):
     from rl_agents_amd import native
     return native.seed_sequence_states((), base, n)
