@@ -220,3 +220,22 @@ def replay_state_aware_masked_episode(z, name, plan_fn):
         assert np.all(out["state_values"][~seen] == 1 / (1 - params["gamma"])), q
         planner, rng = out["planner"], out["rng_after"]
     assert raises_at >= 0 or n_steps > 0
+
+
+def first_result(queue, procs, seconds):
+    """The first item the ranks put on `queue` -- or a test failure, not a hang, when a rank dies or nothing arrives within
+    `seconds` (a crashed rank leaves the others blocked in a collective forever; every process is killed then)."""
+    import time
+    import pytest
+    deadline = time.time() + seconds
+    while time.time() < deadline:
+        if not queue.empty():
+            return queue.get()
+        if any(p.exitcode not in (None, 0) for p in procs):
+            break
+        time.sleep(0.02)
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.kill()
+    pytest.fail("the process group produced no result (exit codes {}; still running ones were killed)".format(codes))

@@ -7,6 +7,7 @@ import sys
 
 import numpy as np
 import pytest
+from tests.helpers import first_result
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -74,7 +75,7 @@ def test_sharded_plans_equal_unsharded(n_roots):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, n_roots, queue)) for r in range(2)]
     for p in procs:
         p.start()
-    sharded = queue.get()
+    sharded = first_result(queue, procs, 240)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
@@ -134,7 +135,7 @@ def test_row_sharded_value_iteration_matches_reference_semantics():
     procs = [ctx.Process(target=_vi_worker, args=(r, 2, port, queue)) for r in range(2)]
     for p in procs:
         p.start()
-    q, sweeps = queue.get()
+    q, sweeps = first_result(queue, procs, 240)
     for p in procs:
         p.join(120)
         assert p.exitcode == 0

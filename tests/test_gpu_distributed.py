@@ -10,6 +10,7 @@ import sys
 
 import numpy as np
 import pytest
+from tests.helpers import first_result
 
 pytestmark = pytest.mark.gpu
 
@@ -182,7 +183,7 @@ def _run_group(world, backend):
     procs = [ctx.Process(target=_worker, args=(r, world, port, backend, queue)) for r in range(world)]
     for p in procs:
         p.start()
-    res = queue.get()
+    res = first_result(queue, procs, 300)
     for p in procs:
         p.join(300)
         assert p.exitcode == 0
