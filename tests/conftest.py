@@ -4,6 +4,9 @@ import sys
 import pytest
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# A hung kernel or a rank blocked in a collective must cost a test, not the whole run: ten minutes per test where the
+# pytest-timeout plugin is installed (it reads this at configure time; --timeout on the command line still wins).
+os.environ.setdefault("PYTEST_TIMEOUT", "600")
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
