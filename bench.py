@@ -251,10 +251,21 @@ def main():
         if ref is not None:
             res["cpu_baseline"]["reference_python"] = ref
     if rank == 0:
-        order = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"]
-        order += [k for k in res if k not in order]
-        print(json.dumps({k: res[k] for k in order}))
+        # the long form first (one JSON object per workload, also written to bench_detail.json), then the ONE compact line the
+        # driver parses: <= 4 KB, strict JSON (benchmarks/report.py; tests/test_bench_line.py)
+        from benchmarks.report import compact_line, detail_lines
+        detail = detail_lines(res)
+        for ln in detail:
+            print(ln)
+        try:
+            side = os.environ.get("BENCH_DETAIL_FILE") or os.path.join(REPO, "gpurun_out", "bench_detail.json")
+            os.makedirs(os.path.dirname(side), exist_ok=True)
+            with open(side, "w") as f:
+                f.write("\n".join(detail) + "\n")
+        except OSError:
+            pass
+        sys.stdout.flush()
+        print(compact_line(res))
         sys.stdout.flush()
     if world > 1:
         import torch.distributed as dist

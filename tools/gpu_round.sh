@@ -22,11 +22,11 @@ for name in ("bench_default", "bench_2rank"):
     except Exception as e:
         print(name, "no JSON line:", e)
         continue
-    print(name, "value %.4g %s, %.3f ms/step, frac %.3f, parity %s" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], (d.get("parity_sample") or {}).get("result")))
+    print(name, "value %.4g %s, %.3f ms/step, frac %.3f, parity %s" % (d["value"], d["unit"], d["ms_per_step"], d["roofline"]["frac"], d.get("parity_sample")), "line bytes", len(json.dumps(d, separators=(",", ":"))))
     if "exchange" in d:
         print("   exchange", {k: v for k, v in d["exchange"].items() if k != "note"}, {k: v for k, v in d["ranks"].items() if k in ("ranks_seen", "cross_check", "backend")})
     for k, v in d.get("workloads", {}).items():
-        print("   %-24s %s" % (k, {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in v.items() if kk in ("value", "kernel_ms", "frac", "traffic_frac", "parity_sample", "error", "ranks_seen", "cross_check")}))
+        print("   %-24s %s" % (k, v))
 PY
 [ -n "$PROFILE" ] && bash tools/profile_gpu.sh $TAG > $O/profile.log 2>&1
 true
