@@ -422,8 +422,9 @@ def bench_uct_cartpole(args, rank, world, local):
         # sin / cos of the pole angle are the host libm's algorithm restated on the device (csrc/libm_sincos.hpp): bit for bit
         # when one of the two forms reproduces this host's libm (variant 1 / 2), else the device math library and the old tolerance
         variant = native.libm_sincos_variant()
-        need = 1.0 if variant in (1, 2) else 0.98
-        res["parity_sample"] = parity_record(bool(same.mean() >= need), "{} roots of a {}-root launch vs oracle.uct_plan_batch "
+        # (no matching form = a FAILING sample: the line must not say "ok" on a host where bit-exactness was not even attempted)
+        need = 1.0
+        res["parity_sample"] = parity_record(bool(same.mean() >= need) and variant in (1, 2), "{} roots of a {}-root launch vs oracle.uct_plan_batch "
                                              "(CartPole): plans, env_steps, root value; {}".format(
                                                  len(idx), n_roots, "bit for bit (host libm's sin / cos restated on the device, form {})".format(variant)
                                                  if need == 1.0 else "tolerance >= 98 % of the sample identical (device sincos: no restated form matched this host's libm)"),

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define MP_ABI_VERSION 6
+#define MP_ABI_VERSION 7
 
 #define MP_OK 0
 #define MP_ERR_HIP (-1)          /* a HIP runtime call failed (message has the hipError string)  */
@@ -61,7 +61,12 @@ int mp_abi_version(void);
 int mp_ctx_create(int device, void *stream, mp_ctx **out);
 int mp_ctx_destroy(mp_ctx *ctx);
 int mp_ctx_set_stream(mp_ctx *ctx, void *stream);
+/* Waits for the ctx's stream.  Returns MP_ERR_ARG -- once, then clears -- when a device-array call since the last
+ * synchronisation had to clamp out-of-range roots (mp_uct_plan_models / mp_opd_plan_models with MP_MEM_DEVICE cannot validate
+ * model_index / root_state on the host; host arrays are validated before the launch, as the reference's IndexError would be). */
 int mp_ctx_synchronize(mp_ctx *ctx);
+/* the sticky count behind that (read without clearing; exact only after the work was waited for) */
+int mp_ctx_device_faults(mp_ctx *ctx, int32_t *count);
 /* the hipStream_t the ctx enqueues on (its own or the caller's): lets the caller order events / collectives after its work */
 int mp_ctx_get_stream(mp_ctx *ctx, void **stream);
 /* device facts for reports: compute units, wavefront size, LDS bytes per workgroup, HBM bytes */

@@ -53,6 +53,19 @@ def needs_build():
         return f.read().strip() != source_digest()
 
 
+def check_generated_code():
+    """The hand-counted `s_waitcnt vmcnt(N)` before opd.hip's scalar leaf-record loads against the code hipcc emitted
+    (tools/check_isa.py): a library whose count is off is refused, not shipped."""
+    if "-DMP_OPD_SAFE_WAITCNT" in FLAGS:
+        return 0
+    import importlib.util
+    path = os.path.join(os.path.dirname(HERE), "tools", "check_isa.py")
+    spec = importlib.util.spec_from_file_location("check_isa", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.check(os.path.join(LIB_DIR, "opd.o"), min_sites=12)
+
+
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link the shared library. Returns its path."""
     if not force and not needs_build():
@@ -74,6 +87,7 @@ def build(force=False, verbose=False):
             raise RuntimeError("hipcc failed on {}:\n{}".format(src, out.decode()))
         if verbose and out:
             print(out.decode())
+    check_generated_code()
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
     subprocess.check_call(cmd)
     with open(STAMP_PATH, "w") as f:

@@ -244,11 +244,17 @@ __global__ void pack_records_rows(int n_rows, int A, const int32_t *__restrict__
 }
 
 // root i of a batch model: global state = model_index[i] * Sb + local state (mp_uct_plan_models / mp_opd_plan_models)
-__global__ void globalize_roots(int n, int Sb, const int32_t *__restrict__ model_index, const int32_t *__restrict__ local,
-                                int32_t *__restrict__ global)
+// Device arrays cannot be validated on the host: a root naming a model outside [0, NB) or a state outside [0, Sb) is CLAMPED to
+// state 0 of model 0 (the planners then read nothing out of bounds) and counted in the ctx's sticky fault word.
+__global__ void globalize_roots(int n, int Sb, int NB, const int32_t *__restrict__ model_index, const int32_t *__restrict__ local,
+                                int32_t *__restrict__ global, int32_t *__restrict__ fault)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) global[i] = model_index[i] * Sb + local[i];
+    if (i >= n) return;
+    const int m = model_index[i], s = local[i];
+    const bool bad = m < 0 || m >= NB || s < 0 || s >= Sb;
+    if (bad && fault) atomicAdd(fault, 1);
+    global[i] = bad ? 0 : m * Sb + s;
 }
 
 // compact transitions for the LDS variant of the UCT kernel (S < 32768)
@@ -354,8 +360,13 @@ int globalize_roots_arg(mp_ctx *ctx, const mp_model *model, int n_roots, const i
         int32_t *d = nullptr;
         MP_HIP(hipSetDevice(ctx->device));
         MP_TRY(ws_get(ctx, WS_GROOT, (size_t)n_roots, &d));
-        hipLaunchKernelGGL(globalize_roots, dim3((unsigned)((n_roots + 255) / 256)), dim3(256), 0, ctx->stream, n_roots, Sb, model_index,
-                           root_state, d);
+        if (!ctx->fault_host) {
+            MP_HIP(hipHostMalloc((void **)&ctx->fault_host, 64, hipHostMallocMapped));
+            *ctx->fault_host = 0;
+            MP_HIP(hipHostGetDevicePointer((void **)&ctx->fault_dev, ctx->fault_host, 0));
+        }
+        hipLaunchKernelGGL(globalize_roots, dim3((unsigned)((n_roots + 255) / 256)), dim3(256), 0, ctx->stream, n_roots, Sb,
+                           model->NB > 0 ? model->NB : 1, model_index, root_state, d, ctx->fault_dev);
         MP_HIP(hipGetLastError());
         *out = d;
         return MP_OK;
@@ -708,6 +719,7 @@ int mp_ctx_destroy(mp_ctx *ctx)
     for (auto &b : ctx->block_cache) hipFree(b.p);
     if (ctx->ev0) hipEventDestroy(ctx->ev0);
     if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->fault_host) hipHostFree(ctx->fault_host);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return MP_OK;
@@ -741,6 +753,19 @@ int mp_ctx_synchronize(mp_ctx *ctx)
 {
     if (!ctx) return fail(MP_ERR_ARG, "ctx is NULL");
     MP_HIP(hipStreamSynchronize(ctx->stream));
+    if (ctx->fault_host && *ctx->fault_host) {
+        const int n = *ctx->fault_host;
+        *ctx->fault_host = 0;
+        return fail(MP_ERR_ARG, "%d root(s) of a device-array plan on a batch model named a model or state out of range "
+                                "(planned from state 0 of model 0 instead): their results are meaningless", n);
+    }
+    return MP_OK;
+}
+
+int mp_ctx_device_faults(mp_ctx *ctx, int32_t *count)
+{
+    if (!ctx || !count) return fail(MP_ERR_ARG, "mp_ctx_device_faults: NULL argument");
+    *count = ctx->fault_host ? *ctx->fault_host : 0;
     return MP_OK;
 }
 

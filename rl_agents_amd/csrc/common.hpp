@@ -117,6 +117,11 @@ struct mp_ctx {
     int32_t *visits_host = nullptr;   // mp_uct_record_visits: where the next stochastic-kernel plan writes its visit counts
     std::vector<double> stoch_priors; // stored child priors of the tree last exported by mp_uct_stoch_tree_export (per-state policies)
     size_t block_cache_bytes = 0;
+    // Sticky fault word for ASYNCHRONOUS device-array calls (pinned host memory mapped into the device: kernels add to it
+    // through fault_dev, the host reads fault_host after a synchronisation).  mp_uct_plan_models / mp_opd_plan_models on
+    // device arrays cannot validate model_index / root_state on the host: the globalize kernel clamps a bad root to state 0
+    // of model 0 and counts it here; mp_ctx_synchronize reports and clears it (mp_ctx_device_faults reads it without clearing).
+    int32_t *fault_host = nullptr, *fault_dev = nullptr;
 };
 
 constexpr size_t kBlockCacheBytes = (size_t)2 << 30;

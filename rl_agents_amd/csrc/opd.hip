@@ -39,6 +39,21 @@
 #include "wave.hpp"
 #include "opd_closing.hpp"
 
+// The selected leaf's 16-byte node record, read by a SCALAR load past the scalar cache (glc).  The record was written by this
+// wave's vector stores of an EARLIER expansion; `s_waitcnt vmcnt(N)` with N = the vector-memory operations THIS expansion has
+// issued so far (the tag store into leafU + the row loads) waits for exactly those older stores without stalling on the row
+// loads just issued.  N is hand-counted against the code hipcc emits: rl_agents_amd/build.py disassembles opd.o after every
+// build and REFUSES the library unless the N vector-memory instructions preceding each of these waits are the expected
+// {N - 1 x global_load_dwordx2, 1 x global_store_dwordx2} (tools/check_isa.py).  -DMP_OPD_SAFE_WAITCNT waits for
+// everything instead (vmcnt(0): correct under any code generation, about one L2 round trip slower per expansion).
+#ifdef MP_OPD_SAFE_WAITCNT
+#define OPD_LEAF_SLOAD(N, lr, lp) \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory")
+#else
+#define OPD_LEAF_SLOAD(N, lr, lp) \
+    asm volatile("s_waitcnt vmcnt(" #N ")\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory")
+#endif
+
 namespace mp {
 
 struct OpdArgs {
@@ -563,12 +578,12 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
             u0 = row[lane < cnt ? lane : 0];
             if (cnt > 64) {
                 u1 = row[lane + 64 < cnt ? lane + 64 : 0];
-                asm volatile("s_waitcnt vmcnt(3)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+                OPD_LEAF_SLOAD(3, lr, lp);
             } else {
-                asm volatile("s_waitcnt vmcnt(2)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+                OPD_LEAF_SLOAD(2, lr, lp);
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(1)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+            OPD_LEAF_SLOAD(1, lr, lp);
         }
         OpdNode pn;
         pn.L = __hiloint2double((int)lr.y, (int)lr.x); pn.state = (int32_t)lr.z; pn.depth = (int32_t)lr.w;
@@ -659,12 +674,12 @@ __global__ __launch_bounds__(64, 8) void opd_wide_kernel(OpdArgs p)
             u0 = row[lane < cnt ? lane : 0];
             if (cnt > 64) {
                 u1 = row[lane + 64 < cnt ? lane + 64 : 0];
-                asm volatile("s_waitcnt vmcnt(3)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+                OPD_LEAF_SLOAD(3, lr, lp);
             } else {
-                asm volatile("s_waitcnt vmcnt(2)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+                OPD_LEAF_SLOAD(2, lr, lp);
             }
         } else {
-            asm volatile("s_waitcnt vmcnt(1)\n\ts_load_dwordx4 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(lr) : "s"(lp) : "memory");
+            OPD_LEAF_SLOAD(1, lr, lp);
         }
         OpdNode pn;
         pn.L = __hiloint2double((int)lr.y, (int)lr.x); pn.state = (int32_t)lr.z; pn.depth = (int32_t)lr.w;

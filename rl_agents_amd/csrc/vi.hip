@@ -1409,7 +1409,14 @@ __global__ __launch_bounds__(BLOCK) void vi_det_batch_reg(ViBatchArgs p)
             if (own[i]) Vnext[tid + i * BLOCK] = vmax;
         }
         // every thread has read V_k and written its part of V_{k+1}; the vote decides the sweep for the whole MDP
-        // (a single-wave workgroup votes by ballot: its LDS accesses are issued in order, no barrier is needed)
+        // (a single-wave workgroup votes by ballot: the hardware issues one wave's LDS accesses in order, so no s_barrier is
+        // needed -- but the COMPILER must not move the V_{k+1} stores below the next sweep's gathers of it: a workgroup-scope
+        // fence + wave barrier pins the order at no run-time cost beyond an s_waitcnt lgkmcnt(0))
+        if (BLOCK == 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
         const bool moved = BLOCK == 64 ? __any(nc ? 1 : 0) != 0 : __syncthreads_or(nc ? 1 : 0) != 0;
         if (!moved) { sweeps = k + 1; break; } // allclose(Q_k, Q_{k+1}): return Q_k = qp
 #pragma unroll

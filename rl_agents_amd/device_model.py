@@ -228,6 +228,9 @@ class ModelCache(object):
         self._version_alias = {}    # version key -> cache key (content hash, or the version key itself for patched models)
         self.uploads = 0
         self.row_updates = 0        # rows patched by delta uploads
+        self._version_hits = {}     # version key -> lookups served without hashing (the sampled content guard below)
+        self._untrusted = set()     # tokens caught changing content under an unchanged version: hashed on every lookup
+        self.version_violations = 0
 
     @property
     def ctx(self):
@@ -245,10 +248,31 @@ class ModelCache(object):
         cache already holds, with a known set of changed rows, PATCHES the device model (mp_model_update_rows: the delta
         upload of SURVEY.md 8 f-2) instead of uploading a new one."""
         token, counter = spec.version
+        if token in self._untrusted:
+            return self._get_keyed(spec.key(), spec)
         static = spec.static_key()
         key = ("version", token, counter, static)
         alias = self._version_alias.get(key)
         if alias is not None and alias in self._models:
+            # SAMPLED GUARD of the promise "equal versions = identical tables": an MDP holds read-only VIEWS of the arrays it
+            # was given, so an in-place edit through the caller's own reference (a config array, say) changes the tables under
+            # an unchanged version.  A model keyed by content (alias != key; patched models own private copies and cannot be
+            # aliased) is re-hashed on its 4th hit and every 64th after (every lookup under MP_VERIFY_TABLE_VERSIONS=1); a
+            # mismatch warns, stops trusting that token for good and serves the model of the tables as they are NOW.
+            hits = self._version_hits[key] = self._version_hits.get(key, 0) + 1
+            if alias != key and (hits == 4 or hits % 64 == 0 or os.environ.get("MP_VERIFY_TABLE_VERSIONS")):
+                now = spec.key()
+                if now != alias:
+                    import warnings
+                    warnings.warn("the tables of a finite MDP changed while its tables_version {} did not (an array edited in "
+                                  "place behind MDP.touch()/edit_rows?): its versions are no longer trusted and every lookup "
+                                  "hashes the tables again".format((token, counter)), RuntimeWarning, stacklevel=3)
+                    self._untrusted.add(token)
+                    self.version_violations += 1
+                    self._version_alias.pop(key, None)
+                    return self._get_keyed(now, spec)
+            if len(self._version_hits) > 256:
+                self._version_hits = {k: v for k, v in self._version_hits.items() if k in self._version_alias}
             return self._get_keyed(alias, spec)
         held = self._by_token.get((token, static))
         if held is not None and held[1] in self._models and spec.mode == "deterministic" and spec.dirty_rows_since is not None \
@@ -258,7 +282,10 @@ class ModelCache(object):
                 model = self._models.pop(held[1])
                 self._order.remove(held[1])
                 if len(rows):
-                    model.update_rows(rows, spec.transition[rows], spec.reward[rows], spec.terminal[rows])
+                    # (terminal flags ride along only when they changed: a flag change re-packs the whole MDP's records)
+                    old = getattr(model.spec, "terminal", None)
+                    same_flags = old is not None and old.shape == spec.terminal.shape and np.array_equal(old[rows], spec.terminal[rows])
+                    model.update_rows(rows, spec.transition[rows], spec.reward[rows], None if same_flags else spec.terminal[rows])
                     self.row_updates += int(len(rows))
                     model._vi_cache = None              # (solutions / policies derived from the old tables)
                     model.epoch = getattr(model, "epoch", 0) + 1

@@ -55,14 +55,25 @@ class MDP(object):
     def __setattr__(self, name, value):
         if name in _TABLE_FIELDS:
             d = self.__dict__
+            self._own_identity()
             d["_tables_counter"] = d.get("_tables_counter", 0) + 1
             d.setdefault("_tables_token", next(_TABLE_TOKENS))
             d["_dirty_log"] = {}                       # a table was replaced: nothing is known about single rows
             d["_dirty_base"] = d["_tables_counter"]
+            d.setdefault("_private", {}).pop(name, None)      # (the MDP does not own the caller's array: see edit_rows)
             if isinstance(value, np.ndarray):
                 value = value.view()
                 value.setflags(write=False)
         object.__setattr__(self, name, value)
+
+    def _own_identity(self):
+        """Copy-on-write identity: an MDP that SHARES its version token with other objects over the same tables (every
+        ``to_finite_mdp()`` of one highway-like table) leaves that family the first time ITS tables change -- otherwise two
+        objects edited differently would both reach (token, 1) and break 'equal versions = identical tables'."""
+        d = self.__dict__
+        if d.pop("_token_shared", False):
+            d["_tables_token"], d["_tables_counter"] = next(_TABLE_TOKENS), 0
+            d["_dirty_log"], d["_dirty_base"] = {}, 0
 
     @property
     def tables_version(self):
@@ -72,25 +83,35 @@ class MDP(object):
         """The tables were changed behind the MDP's back (through another reference to an array): a new version, every row
         suspect."""
         d = self.__dict__
+        self._own_identity()
         d["_tables_counter"] = d.get("_tables_counter", 0) + 1
         d["_dirty_log"], d["_dirty_base"] = {}, d["_tables_counter"]
 
     def edit_rows(self, rows, transition=None, reward=None, terminal=None, next_states=None):
-        """Replace the rows ``rows`` (state indices) of the given tables in place and remember them as the delta of this
-        version (the device model is then patched row by row: mp_model_update_rows)."""
+        """Replace the rows ``rows`` (state indices) of the given tables and remember them as the delta of this version (the
+        device model is then patched row by row: mp_model_update_rows).  The edit never writes into an array the MDP was
+        handed (it may be a slice of a larger array, or shared with other MDP objects): the first edit of a table takes a
+        PRIVATE copy, later edits go into that copy in place."""
         rows = np.asarray(rows, dtype=np.int64).reshape(-1)
+        d = self.__dict__
+        own = d.setdefault("_private", {})
+        shared = d.get("_token_shared", False)
         for name, new in (("transition", transition), ("reward", reward), ("terminal", terminal), ("next", next_states)):
             if new is None:
                 continue
-            arr = self.__dict__[name]
-            base = arr.base if arr.base is not None and not arr.flags.writeable else arr
-            if not base.flags.writeable:
-                base = np.array(arr)                   # (the caller handed a read-only array over: own a copy)
-            base[rows] = new
-            view = base.view()
+            priv = own.get(name)
+            if priv is None:
+                priv = own[name] = np.array(d[name])   # a copy this object owns (never `arr.base`: numpy collapses a view's
+            priv[rows] = new                            # base to the OWNER of the memory, e.g. a whole stack of tables)
+            view = priv.view()
             view.setflags(write=False)
-            self.__dict__[name] = view
-        d = self.__dict__
+            d[name] = view
+        if shared:
+            # the family's device model is not this object's any more: a fresh identity whose first version is whole
+            self._own_identity()
+            d["_tables_counter"] = 1
+            d["_dirty_log"], d["_dirty_base"] = {}, 1
+            return
         d["_tables_counter"] = d.get("_tables_counter", 0) + 1
         d.setdefault("_dirty_log", {})[d["_tables_counter"]] = rows.copy()
 
@@ -122,7 +143,7 @@ class MDP(object):
                 v = np.array(v)
                 v.setflags(write=False)
                 new.__dict__[k] = v
-            elif k not in ("_tables_token", "_tables_counter", "_dirty_log", "_dirty_base"):
+            elif k not in ("_tables_token", "_tables_counter", "_dirty_log", "_dirty_base", "_private", "_token_shared"):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         new.__dict__["_tables_token"], new.__dict__["_tables_counter"] = next(_TABLE_TOKENS), 0
         new.__dict__["_dirty_log"], new.__dict__["_dirty_base"] = {}, 0

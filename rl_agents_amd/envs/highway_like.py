@@ -85,6 +85,8 @@ class HighwayLikeEnv(object):
             token = self.table["_version_token"] = next(_TABLE_TOKENS)
         mdp.__dict__["_tables_token"], mdp.__dict__["_tables_counter"] = token, 0
         mdp.__dict__["_dirty_log"], mdp.__dict__["_dirty_base"] = {}, 0
+        mdp.__dict__["_token_shared"] = True   # (copy-on-write identity: MDP._own_identity)
+        mdp.__dict__.pop("_private", None)
         return mdp
 
     def render(self, *a, **k):

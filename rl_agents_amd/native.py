@@ -31,6 +31,7 @@ SIGNATURES = {
     "mp_ctx_destroy": (C.c_int, [_vp]),
     "mp_ctx_set_stream": (C.c_int, [_vp, _vp]),
     "mp_ctx_synchronize": (C.c_int, [_vp]),
+    "mp_ctx_device_faults": (C.c_int, [_vp, C.POINTER(C.c_int32)]),
     "mp_ctx_get_stream": (C.c_int, [_vp, P(_vp)]),
     "mp_ctx_device_info": (C.c_int, [_vp, P(c_i32), P(c_i32), P(c_i64), P(c_i64), C.c_char_p, c_i32]),
     "mp_model_load_table": (C.c_int, [_vp, c_i32, c_i32, c_i32, _vp, _vp, _vp, c_i32, c_i32, P(_vp)]),
@@ -157,7 +158,7 @@ def load():
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
-    if lib.mp_abi_version() != 6:
+    if lib.mp_abi_version() != 7:
         raise RuntimeError("libmi355plan ABI version mismatch")
     _LIB = lib
     return lib
@@ -280,7 +281,15 @@ class Context(object):
             pass
 
     def synchronize(self):
+        """Wait for the context's stream; raises NativeError(MP_ERR_ARG) if a device-array plan since the last synchronisation
+        had to clamp out-of-range roots (mp_ctx_synchronize)."""
         _check(self._lib.mp_ctx_synchronize(self._h))
+
+    def device_faults(self):
+        """Roots clamped by device-array plans on batch models since the last synchronize() (exact once the work was waited for)."""
+        n = c_i32()
+        _check(self._lib.mp_ctx_device_faults(self._h, C.byref(n)))
+        return int(n.value)
 
     def set_stream(self, stream):
         """Enqueue on another hipStream_t from now on (raw pointer, e.g. ``torch.cuda.current_stream().cuda_stream``)."""
@@ -598,6 +607,13 @@ class Context(object):
     def load_cartpole(self, params):
         """Closed-form CartPole model from ``CartPoleEnv.cartpole_params()`` (dict)."""
         cp = CartPoleParams(**{k: params[k] for k, _ in CartPoleParams._fields_})
+        if libm_sincos_variant() not in (1, 2) and not os.environ.get("MP_CARTPOLE_SINCOS"):
+            # neither restated glibc form reproduces THIS host's libm sin / cos: the device falls back to its own math library
+            # and plans may differ from the reference's in the last bits of a pole angle -- say so, loudly, once per load
+            import warnings
+            warnings.warn("CartPole model: no restated form of sin / cos matches this host's libm (mp_libm_sincos_variant() == 0): "
+                          "the device uses its own sincos and bit-exact parity with the CPU reference is NOT guaranteed",
+                          RuntimeWarning, stacklevel=2)
         h = _vp()
         _check(self._lib.mp_model_load_cartpole(self._h, C.addressof(cp), C.byref(h)))
         return Model(self, h, MODE_CARTPOLE, 1, 0, 2, 0)

@@ -31,7 +31,7 @@ def _load(ctx, cfg):
 def test_library_loaded_is_in_tree():
     from rl_agents_amd import native
     lib = native.load()
-    assert lib.mp_abi_version() == 6
+    assert lib.mp_abi_version() == 7
     assert "rl_agents_amd/lib/libmi355plan.so" in native.lib_path()
 
 

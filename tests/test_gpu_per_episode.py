@@ -246,6 +246,45 @@ def test_per_root_models_device_arrays(ctx):
     model.close()
 
 
+def test_per_root_models_device_arrays_out_of_range_roots_are_reported(ctx):
+    """device arrays cannot be validated on the host -- a root naming a model / state out of range is clamped to
+    state 0 of model 0 (nothing is read out of bounds), counted, and the next synchronize() raises once; the other roots'
+    results are what they would have been."""
+    import torch
+    from oracle import oracle
+    n = 64
+    tr, rw, tm = _tables(n, seed0=70)
+    model = ctx.load_table_batch(tr, rw, tm)
+    g = np.random.Generator(np.random.PCG64(3))
+    s0 = g.integers(0, tr.shape[1], n).astype(np.int32)
+    mi = np.arange(n, dtype=np.int32)
+    bad_s0, bad_mi = s0.copy(), mi.copy()
+    bad_mi[5], bad_mi[9], bad_s0[17], bad_s0[20] = n, -1, tr.shape[1], -3
+    rng = _rng_states(n, base=4)
+    dev = torch.device("cuda", ctx.device)
+    d = dict(mi=torch.from_numpy(bad_mi).to(dev), s0=torch.from_numpy(bad_s0).to(dev),
+             rng=torch.from_numpy(rng.view(np.int64)).to(dev), plans=torch.full((n, 8), -1, dtype=torch.int32, device=dev),
+             plan_len=torch.zeros(n, dtype=torch.int32, device=dev), value=torch.zeros(n, dtype=torch.float64, device=dev),
+             steps=torch.zeros(n, dtype=torch.int64, device=dev))
+    torch.cuda.synchronize()
+    p = np.ones(5) / 5
+    ctx.uct_plan_device(model, n, d["s0"], 25, 8, 0.8, 10.0, p, p, d["rng"], 8, plans=d["plans"], plan_len=d["plan_len"],
+                        root_value=d["value"], env_steps=d["steps"], model_index=d["mi"])
+    torch.cuda.synchronize()
+    assert ctx.device_faults() == 4
+    with pytest.raises(native.NativeError, match="out of range"):
+        ctx.synchronize()
+    ctx.synchronize()                                   # reported once
+    assert ctx.device_faults() == 0
+    fixed_mi, fixed_s0 = mi.copy(), s0.copy()
+    for i in (5, 9, 17, 20):
+        fixed_mi[i], fixed_s0[i] = 0, 0                 # what the clamped roots planned on
+    ref = oracle.uct_plan_each(tr, rw, tm, fixed_mi, fixed_s0, 25, 8, 0.8, 10.0, p, p, rng, max_plan_len=8)
+    np.testing.assert_array_equal(d["plans"].cpu().numpy(), ref["plans"])
+    assert np.array_equal(d["value"].cpu().numpy(), ref["root_value"])
+    model.close()
+
+
 # ---------------------------------------------------------------------------------------------- delta uploads
 def test_update_rows_single_model_matches_reload(ctx):
     """mp_model_update_rows on a single table model: after a delta upload the model plans and solves

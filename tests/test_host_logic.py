@@ -27,7 +27,7 @@ def test_c_abi_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(lib, name), name
     assert declared == set(native.SIGNATURES), declared ^ set(native.SIGNATURES)
-    assert native.load().mp_abi_version() == 6
+    assert native.load().mp_abi_version() == 7
 
 
 def test_context_fails_loudly_without_gpu_or_library(monkeypatch):
@@ -500,6 +500,108 @@ def test_model_cache_keys_by_version_without_hashing(monkeypatch):
     env.mdp.reward = np.array(env.mdp.reward) * 0.5   # unknown change: hashed once, a new upload
     m3 = cache.get(device_model.spec_from_mdp(env.mdp))
     assert m3 is not m1 and cache.uploads == 2 and len(hashed) == 3
+
+
+def test_mdp_edit_rows_never_writes_into_the_callers_arrays():
+    """an MDP built on a SLICE of a larger array (`stack[t]`) must not write through `.base` -- numpy
+    collapses a view's base to the owner of the memory, i.e. the whole stack.  edit_rows takes a private copy."""
+    from rl_agents_amd.envs.finite_mdp import DeterministicMDP
+    from rl_agents_amd.envs import generators
+    cfgs = [generators.highway_shaped(2, 3, 5, seed=i) for i in range(3)]
+    stack_t, stack_r = np.stack([c["transition"] for c in cfgs]), np.stack([c["reward"] for c in cfgs])
+    keep_t, keep_r = stack_t.copy(), stack_r.copy()
+    m = DeterministicMDP(stack_t[1], stack_r[1], terminal=cfgs[1]["terminal"])
+    m.edit_rows([2], reward=np.ones((1, stack_r.shape[2])))
+    assert m.reward.shape == stack_r[1].shape and m.transition.shape == stack_t[1].shape
+    np.testing.assert_array_equal(stack_r, keep_r)            # the caller's stack is untouched ...
+    np.testing.assert_array_equal(stack_t, keep_t)
+    assert (m.reward[2] == 1.0).all() and np.array_equal(m.reward[3], keep_r[1][3])     # ... and the MDP sees its edit
+    m.edit_rows([3], reward=np.zeros((1, stack_r.shape[2])), transition=np.zeros((1, stack_r.shape[2]), np.int64))
+    assert (m.reward[2] == 1.0).all() and (m.reward[3] == 0.0).all() and (m.transition[3] == 0).all()
+    np.testing.assert_array_equal(stack_t, keep_t)
+    np.testing.assert_array_equal(m.dirty_rows_since(m.tables_version[1] - 2), [2, 3])
+    # a read-only array handed over: same thing
+    ro = keep_r[0].copy()
+    ro.setflags(write=False)
+    m2 = DeterministicMDP(keep_t[0], ro)
+    m2.edit_rows([0], reward=np.full((1, ro.shape[1]), 0.25))
+    assert ro[0, 0] == keep_r[0][0, 0] and m2.reward[0, 0] == 0.25
+
+
+def test_mdp_objects_sharing_a_version_token_part_ways_when_edited():
+    """every to_finite_mdp() of one highway-like table shares a (token, 0) version AND the table arrays; two
+    such objects edited differently must not both become (token, 1), and neither edit may reach the shared table."""
+    from rl_agents_amd.envs import HighwayLikeEnv
+    h = HighwayLikeEnv()
+    a, b, c = h.to_finite_mdp(), h.to_finite_mdp(), h.to_finite_mdp()
+    assert a.tables_version == b.tables_version == c.tables_version
+    shared = np.array(h.table["reward"])
+    a.edit_rows([1], reward=np.full((1, 5), 0.125))
+    b.edit_rows([1], reward=np.full((1, 5), 0.875))
+    assert a.tables_version != b.tables_version and a.tables_version[0] != c.tables_version[0] != b.tables_version[0]
+    assert a.reward[1, 0] == 0.125 and b.reward[1, 0] == 0.875
+    np.testing.assert_array_equal(h.table["reward"], shared)
+    np.testing.assert_array_equal(c.reward, shared)
+    assert h.to_finite_mdp().tables_version == c.tables_version      # the family's version still names the unedited table
+    assert a.dirty_rows_since(0) is None                             # (a fresh identity: its first version is a whole table)
+    a.edit_rows([2], reward=np.zeros((1, 5)))
+    np.testing.assert_array_equal(a.dirty_rows_since(1), [2])        # ... deltas from then on
+    d = h.to_finite_mdp()
+    d.reward = shared * 0.5                                          # assigning a table leaves the family too
+    assert d.tables_version[0] != c.tables_version[0]
+
+
+def test_model_cache_catches_tables_edited_behind_an_unchanged_version(monkeypatch):
+    """an MDP holds read-only VIEWS, so the caller's own reference can still change the tables under an
+    unchanged tables_version.  The cache's sampled guard (4th hit, every 64th; every hit under MP_VERIFY_TABLE_VERSIONS)
+    re-hashes, warns, serves the model of the CURRENT tables and stops trusting that token."""
+    from rl_agents_amd import device_model
+    from rl_agents_amd.envs.finite_mdp import DeterministicMDP
+    from rl_agents_amd.envs import generators
+
+    class FakeModel(object):
+        def close(self):
+            pass
+
+    cfg = generators.highway_shaped(3, 4, 10, seed=1)
+    t, r = np.array(cfg["transition"]), np.array(cfg["reward"])
+    mdp = DeterministicMDP(t, r, terminal=cfg["terminal"])
+    cache = device_model.ModelCache(ctx=object())
+    monkeypatch.setattr(cache, "_upload", lambda spec: FakeModel())
+    m1 = cache.get(device_model.spec_from_mdp(mdp))
+    assert cache.get(device_model.spec_from_mdp(mdp)) is m1
+    r[0, 0] += 1.0                                    # behind the MDP's back: same version, other tables
+    assert mdp.reward[0, 0] == r[0, 0]
+    monkeypatch.setenv("MP_VERIFY_TABLE_VERSIONS", "1")
+    with pytest.warns(RuntimeWarning, match="tables_version"):
+        m2 = cache.get(device_model.spec_from_mdp(mdp))
+    assert m2 is not m1 and cache.uploads == 2 and cache.version_violations == 1
+    monkeypatch.delenv("MP_VERIFY_TABLE_VERSIONS")
+    r[0, 0] += 1.0                                    # the token is no longer trusted: every lookup hashes
+    m3 = cache.get(device_model.spec_from_mdp(mdp))
+    assert m3 is not m2 and cache.uploads == 3
+    # without the env knob the guard still fires, on the 4th hit of a version
+    mdp2 = DeterministicMDP(np.array(t), np.array(cfg["reward"]), terminal=cfg["terminal"])
+    r2 = mdp2.reward.base
+    cache2 = device_model.ModelCache(ctx=object())
+    monkeypatch.setattr(cache2, "_upload", lambda spec: FakeModel())
+    first = cache2.get(device_model.spec_from_mdp(mdp2))
+    r2[1, 1] += 1.0
+    got = [cache2.get(device_model.spec_from_mdp(mdp2)) for _ in range(3)]
+    assert all(g is first for g in got)               # (the window the sampling leaves open)
+    with pytest.warns(RuntimeWarning):
+        assert cache2.get(device_model.spec_from_mdp(mdp2)) is not first
+
+
+def test_opd_leaf_load_wait_counts_match_the_generated_code():
+    """the hand-counted `s_waitcnt vmcnt(N)` before opd.hip's scalar leaf-record loads, checked against the
+    disassembly of the object the library was linked from (tools/check_isa.py; rl_agents_amd.build refuses a library that
+    fails it)."""
+    from rl_agents_amd import build
+    obj = os.path.join(build.LIB_DIR, "opd.o")
+    if not os.path.exists(obj):
+        pytest.skip("opd.o not kept (library built elsewhere)")
+    assert build.check_generated_code() >= 12
 
 
 def test_restated_sincos_equals_host_libm():
