@@ -642,13 +642,21 @@ def bench_uct_per_root_model(args, rank, world, local):
                     algorithmic_bytes_per_env_step=bytes_per_step,
                     parallelism="roots (episodes) sharded over {} GPU(s), no collective".format(world)),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
-                      kernel="uct_kernel<5, ENV_TABLE> on the union model ({})".format(variant), kernel_ms=k_ms,
-                      algorithmic_bytes_per_launch=bytes_per_step * env_steps,
-                      note="algorithmic bytes = SURVEY 8(d) terms with depth / expansions measured on this launch's trees; every root "
-                           "gathers the 16-byte records of ITS OWN {} B table".format(s_ * a_ * 16)),
+                      kernel={"uct_row_each": "uct_row_kernel<5> (4 roots per wavefront, each root's MDP + tree in LDS)",
+                              "uct_lone_each": "uct_lone_kernel<5, EACH> (a wavefront per root, its MDP + tree in LDS)"}.get(
+                                  variant, "uct_kernel<5, ENV_TABLE> on the union model ({})".format(variant)), kernel_ms=k_ms,
+                      kernel_variant=variant, algorithmic_bytes_per_launch=bytes_per_step * env_steps,
+                      # what must cross HBM when the MDP and the tree live in LDS: every root's 16-byte records staged once, its
+                      # tree written out once (export / re-rooting), roots / generator records / results
+                      hbm_side_bytes_per_launch=float(n_roots) * (s_ * a_ * 16 + (1 + episodes * a_) * 16 + 4 + 96 + mpl * 4 + 24),
+                      note="algorithmic bytes = SURVEY 8(d) terms with depth / expansions measured on this launch's trees; the "
+                           "LDS-resident kernels serve them from LDS after staging each root's OWN {} B table once: `frac` is the "
+                           "rate at which the algorithm's bytes are consumed, `traffic` what the counters saw; the kernel is bound "
+                           "by the dependency chain of one episode (profiles/r06_uct_row.md)".format(s_ * a_ * 16)),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
-    add_traffic(res["roofline"], "uct_per_root_model", "uct_kernel", n_roots)
+    add_traffic(res["roofline"], "uct_per_root_model", {"uct_row_each": "uct_row_kernel", "uct_lone_each": "uct_lone_kernel"}.get(variant, "uct_kernel"),
+                {"uct_row_each": -(-n_roots // 4) * 64, "uct_lone_each": n_roots * (64 if s_ * a_ <= 4096 else 256)}.get(variant, n_roots))
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         d["rng"].copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))

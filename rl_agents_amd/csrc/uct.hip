@@ -105,6 +105,7 @@ struct UctArgs {
     int done_on_next, max_steps, max_plan_len;
     int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
     int waves; // wavefronts per workgroup
+    int Sb;    // batch models: states per MDP (root r plans on MDP root_state[r] / Sb); = S for any other model
     const Rec *rec;
     const uint16_t *t16; // compact transitions (LDS variants), [S*A]
     const uint8_t *r8;   // LDS-resident variant: index of reward[s, a] in rdict, [S*A]
@@ -839,8 +840,15 @@ void uct_kernel(UctArgs p)
 //     the generator then jumps by the n draws the walk consumed, so the stream stays the reference's.
 // Same trees, plans, statistics and generator records as uct_kernel (every single-root golden runs through it when forced:
 // MP_UCT_LONE=1); the tree is written to global memory in the group-interleaved layout at the end (export, re-rooting).
-template <int AT>
-__global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
+// EACH (round 6): ONE MDP PER ROOT -- a batch model (mp_model_load_table_batch: the finite MDPs of a batch of episodes, each
+// extracted from its own environment) where root r plans on MDP root_state[r] / Sb.  The union model is too large for the compact
+// LDS forms (S = NB * Sb >= 32 768 states), but a root only ever visits ITS MDP: the workgroup stages that MDP's Sb * |A| records
+// from the 16-byte global records into LDS as {uint16 local next state | bit 15 terminal[next]} + the reward itself (f64: no
+// reward dictionary, any number of distinct rewards) -- 10 B per (s, a), 6 KB for a 120-state highway grid -- and everything
+// else is the lone-root kernel: tree in LDS, a level scored across lanes, the rollout's draws by jump-ahead in the lanes.  One
+// wave per workgroup (small MDPs) so that 4096 roots are 4096 wavefronts, four per SIMD.
+template <int AT, bool EACH = false>
+__global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kernel(UctArgs p)
 {
     static_assert(AT >= 2 && AT <= 8, "|A| with a compile-time specialisation");
     constexpr int A = AT, NTH = AT - 1;
@@ -853,17 +861,30 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     double *tpdiv = rcp + (TE + 1);         // [A][TE+2] temperature * |A| * prior[a] / n
     const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
     const int ntab2 = (ntab + 1) & ~1;
-    const double *rdict = lds_d + ntab2;
-    uint16_t *t16 = reinterpret_cast<uint16_t *>(lds_d + ntab2 + ((p.n_rdict + 1) & ~1));
-    uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((p.S * A + 7) & ~7));
-    uint32_t *jump = reinterpret_cast<uint32_t *>(r8 + ((p.S * A + 15) & ~15)); // [H + 5][8]
+    const int SA = (EACH ? p.Sb : p.S) * A;                                       // (s, a) pairs of the model this root plans on
+    const double *rdict = lds_d + ntab2;                                          // shared model: [n_rdict] distinct rewards
+    double *rew = lds_d + ntab2;                                                  // EACH: [SA] the rewards themselves
+    uint16_t *t16 = EACH ? reinterpret_cast<uint16_t *>(rew + ((SA + 1) & ~1))
+                         : reinterpret_cast<uint16_t *>(lds_d + ntab2 + ((p.n_rdict + 1) & ~1));
+    uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((SA + 7) & ~7));             // shared model: [SA] reward indices
+    uint32_t *jump = EACH ? reinterpret_cast<uint32_t *>(r8) : reinterpret_cast<uint32_t *>(r8 + ((SA + 15) & ~15)); // [H + 5][8]
     UctNode *tnode = reinterpret_cast<UctNode *>(jump + (H + 5) * 8);            // [cap]
     double *texpl = reinterpret_cast<double *>(tnode + p.cap);                   // [cap] a node's exploration term at its count
     int32_t *path = reinterpret_cast<int32_t *>(texpl + p.cap);                  // [H + 1]
+    const int r = blockIdx.x;
+    const int32_t s0g = __builtin_amdgcn_readfirstlane(p.root_state[r]);         // (global state of a batch model)
+    const int32_t sbase = EACH ? (s0g / p.Sb) * p.Sb : 0;                         // first global state of this root's MDP
     for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
-    for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
-    {
+    if constexpr (EACH) {
+        const Rec *src = p.rec + (long)sbase * A;
+        for (int i = tid; i < SA; i += nthreads) {
+            const Rec rc = src[i];
+            t16[i] = (uint16_t)((uint32_t)(rc.next - sbase) | ((rc.flags & 2u) ? 0x8000u : 0u));
+            rew[i] = rc.reward;
+        }
+    } else {
+        for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
         const int n16 = (p.S * A + 15) >> 4; // (the device arrays are padded to whole 16-byte chunks)
         const uint4 *src = reinterpret_cast<const uint4 *>(p.r8);
         uint4 *dst = reinterpret_cast<uint4 *>(r8);
@@ -876,7 +897,6 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     }
     __syncthreads();
     if (tid >= 64) return; // (the staging waves are done; no barrier below)
-    const int r = blockIdx.x;
     // MCTSNode.selection_strategy's exploration term temperature |A| prior[a] / (count + 1) (mcts.py:275-286): from the host's
     // quotient table, or the same IEEE division beyond it.  Kept PER NODE beside the tree and refreshed by the backup (which
     // changes the count), so that scoring a level is one LDS round trip, not two
@@ -884,9 +904,9 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
     Pcg64 g;                                     // (every lane holds the same generator)
     g.load(p.rng + (long)r * 6);
-    const int32_t s0 = __builtin_amdgcn_readfirstlane(p.root_state[r]);
+    const int32_t s0 = s0g - sbase;                                    // (local to the staged MDP)
     const int32_t st0 = p.root_steps ? __builtin_amdgcn_readfirstlane(p.root_steps[r]) : 0;
-    const bool root_term = (p.rec[(long)s0 * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
+    const bool root_term = (p.rec[(long)s0g * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
     int n_nodes = 1, steps_taken = 0;
     if (lane == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; texpl[0] = 0.0; } // mcts.py:129-130 reset()
     __builtin_amdgcn_wave_barrier();
@@ -908,11 +928,17 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
 #define MP_LONE_STEP(idx_, h_, e_out_)                                                                  \
     do {                                                                                                \
         const uint32_t e_raw_ = t16[idx_];                                                              \
-        const unsigned rbn_ = r8[idx_];                                                                 \
-        const double rdn_ = rdict[rb1], gpn_ = gpow[h1];                                                \
-        if (v2) total += gp2 * rd2;                                                                     \
-        rd2 = rdn_; gp2 = gpn_; v2 = v1;                                                                \
-        rb1 = rbn_; h1 = (h_); v1 = true;                                                               \
+        if constexpr (EACH) { /* the reward itself is in LDS: a two-stage pipeline (added one step later, in order) */ \
+            const double rdn_ = rew[idx_], gpn_ = gpow[(h_)];                                           \
+            if (v2) total += gp2 * rd2;                                                                 \
+            rd2 = rdn_; gp2 = gpn_; v2 = true;                                                          \
+        } else {                                                                                        \
+            const unsigned rbn_ = r8[idx_];                                                             \
+            const double rdn_ = rdict[rb1], gpn_ = gpow[h1];                                            \
+            if (v2) total += gp2 * rd2;                                                                 \
+            rd2 = rdn_; gp2 = gpn_; v2 = v1;                                                            \
+            rb1 = rbn_; h1 = (h_); v1 = true;                                                           \
+        }                                                                                               \
         e_out_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_raw_);                                 \
     } while (0)
         // ---- selection, mcts.py:143-149: a level's children one per lane
@@ -1001,8 +1027,8 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
             }
         }
 #undef MP_LONE_STEP
-        if (v2) total += gp2 * rd2;                          // drain the pipeline: the last two steps
-        if (v1) total += gpow[h1] * rdict[rb1];
+        if (v2) total += gp2 * rd2;                          // drain the pipeline: the last two steps (EACH: the last one)
+        if (!EACH && v1) total += gpow[h1] * rdict[rb1];
         // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
         __builtin_amdgcn_wave_barrier();
         if (lane <= depth) {
@@ -1020,6 +1046,303 @@ __global__ __launch_bounds__(1024, 1) void uct_lone_kernel(UctArgs p)
     const TreeRef<2, AT> tree = tree_of<2, AT>(p.tree, r, p.cap, A);
     for (int i = lane; i < n_nodes; i += 64) tree[i] = tnode[i];
     if (lane == 0) {
+        g.store(p.rng + (long)r * 6);
+        // ---- AbstractPlanner.get_plan (abstract.py:143-156) with MCTSNode.selection_rule (mcts.py:212-218): most visited
+        // child, ties -> first maximal value among them
+        int len = 0;
+        int fc = tnode[0].first_child;
+        while (fc >= 0) {
+            int mc = tnode[fc].count;
+            for (int a = 1; a < A; ++a) mc = max(mc, tnode[fc + a].count);
+            int best = -1;
+            double bv = 0.0;
+            for (int a = 0; a < A; ++a) {
+                const UctNode c = tnode[fc + a];
+                if (c.count == mc && (best < 0 || c.value > bv)) { best = a; bv = c.value; }
+            }
+            if (p.plans && len < p.max_plan_len) p.plans[(long)r * p.max_plan_len + len] = best;
+            ++len;
+            fc = tnode[fc + best].first_child;
+        }
+        if (p.plans)
+            for (int i = len; i < p.max_plan_len; ++i) p.plans[(long)r * p.max_plan_len + i] = -1;
+        if (p.plan_len) p.plan_len[r] = len;
+        if (p.n_nodes_out) p.n_nodes_out[r] = n_nodes;
+        if (p.root_value) p.root_value[r] = tnode[0].value;
+        if (p.env_steps) p.env_steps[r] = (int64_t)steps_taken;
+        const int rfc = tnode[0].first_child;
+        for (int a = 0; a < A; ++a) {
+            if (p.root_child_count) p.root_child_count[(long)r * A + a] = rfc >= 0 ? max(tnode[rfc + a].count, 0) : 0;
+            if (p.root_child_value) p.root_child_value[(long)r * A + a] = rfc >= 0 ? tnode[rfc + a].value : 0.0;
+        }
+    }
+}
+
+// ---- FOUR ROOTS PER WAVEFRONT, ONE DPP ROW (16 LANES) EACH, ONE MDP PER ROOT (round 6): the batch of highway episodes, each with
+// its own finite MDP (trainer/evaluation.py:139-194 x value_iteration.py:29-35).  uct_lone_kernel<.., EACH> gives such a root a
+// whole wavefront; but a CDNA SIMD is 16 lanes wide -- a wave64 instruction holds it for 4 cycles whatever it computes -- so
+// 4096 lone waves (4 per SIMD) run at a quarter of a lone wave's speed (measured: 0.176 ms, no better than one lane per root).
+// Here a root gets exactly the 16 lanes it can use: |A| children scored by |A| lanes of ITS row, 16 rollout actions drawn at a
+// time by jump-ahead (lane l of the row: the generator 16 k + l + 1 steps ahead), path nodes backed up one per lane; 4096 roots
+// are 1024 wavefronts = one per SIMD, every instruction working for four roots.  Row-uniform values (state, depth, the
+// generator) live in vector registers, identical in the 16 lanes of a row; cross-lane traffic is DPP inside a row
+// (row_newbcast, quad_perm / row_mirror reductions) and one ds_bpermute where the source lane is data-dependent.
+// Per root in LDS: the MDP as {uint16 local next state | bit 15 terminal[next]} + the rewards (f64), the tree, the path.
+// Same trees, plans, statistics and generator records as every other variant.
+template <int CTRL>
+__device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+__device__ __forceinline__ double row16_max(double u) // every lane: the maximum over the 16 lanes of its DPP row
+{
+    u = max_step<0xB1, 0xf>(u);  // quad_perm:[1,0,3,2]
+    u = max_step<0x4E, 0xf>(u);  // quad_perm:[2,3,0,1]
+    u = max_step<0x141, 0xf>(u); // row_half_mirror
+    u = max_step<0x140, 0xf>(u); // row_mirror
+    return u;
+}
+// the maximum over lanes 0 .. |A| - 1 of a row (the lanes that score a level's children; the others hold -inf), in every one of them
+template <int AT>
+__device__ __forceinline__ double row_children_max(double u)
+{
+    u = max_step<0xB1, 0xf>(u);                 // quad_perm:[1,0,3,2]
+    if (AT > 2) u = max_step<0x4E, 0xf>(u);     // quad_perm:[2,3,0,1]
+    if (AT > 4) u = max_step<0x141, 0xf>(u);    // row_half_mirror: lanes 0..7 <-> 7..0
+    return u;
+}
+constexpr int kRowRoots = 4; // roots per wavefront
+template <int AT>
+__global__ __launch_bounds__(64) void uct_row_kernel(UctArgs p)
+{
+    static_assert(AT >= 2 && AT <= 8, "|A| with a compile-time specialisation");
+    constexpr int A = AT, NTH = AT - 1;
+    extern __shared__ __attribute__((aligned(16))) double lds_d[];
+    const int lane = threadIdx.x, row = lane >> 4, l16 = lane & 15;
+    const int H = p.horizon, E = p.episodes, TE = p.table_n;
+    double *gpow = lds_d;                   // [H + 1]  gamma ** h
+    double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
+    double *rcp = tp + A;                   // [TE + 1]  1.0 / n
+    double *tpdiv = rcp + (TE + 1);         // [A][TE+2] temperature * |A| * prior[a] / n
+    const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
+    const int ntab2 = (ntab + 1) & ~1;
+    const int SA = p.Sb * A, SA2 = (SA + 1) & ~1, SA8 = (SA + 7) & ~7, PH = (H + 4) & ~3;
+    double *rew = lds_d + ntab2 + row * SA2;                                                    // [4][SA2] rewards
+    UctNode *tnode = reinterpret_cast<UctNode *>(lds_d + ntab2 + kRowRoots * SA2) + row * p.cap; // [4][cap] trees
+    uint32_t *jump = reinterpret_cast<uint32_t *>(reinterpret_cast<UctNode *>(lds_d + ntab2 + kRowRoots * SA2) + kRowRoots * p.cap); // [H + 5][8]
+    int32_t *path = reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + row * PH;                 // [4][PH] path node ids
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + kRowRoots * PH) + row * SA8; // [4][SA8]
+    const int r = blockIdx.x * kRowRoots + row;
+    const bool live = r < p.n_roots;          // (a last wavefront's spare rows run along on the last root's data and write nothing)
+    const int rr = live ? r : p.n_roots - 1;
+    const int32_t s0g = p.root_state[rr];     // global state of the batch model
+    const int32_t sbase = (s0g / p.Sb) * p.Sb; // first global state of this root's MDP
+    for (int i = lane; i < (H + 5) * 8; i += 64) jump[i] = p.jump[i];
+    for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
+    {
+        const Rec *src = p.rec + (long)sbase * A;
+#pragma unroll 4
+        for (int i = l16; i < SA; i += 16) {
+            const Rec rc = src[i];
+            t16[i] = (uint16_t)((uint32_t)(rc.next - sbase) | ((rc.flags & 2u) ? 0x8000u : 0u));
+            rew[i] = rc.reward;
+        }
+    }
+    __syncthreads();
+    auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
+    auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
+    auto lds_sync = [] { // this wave's LDS writes before its later reads, for the compiler (the hardware keeps a wave's LDS order)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    Pcg64 g;                                  // (the 16 lanes of a row hold the same generator)
+    g.load(p.rng + (long)rr * 6);
+    const int32_t s0 = s0g - sbase;
+    const int32_t st0 = p.root_steps ? p.root_steps[rr] : 0;
+    const bool root_term = (p.rec[(long)s0g * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
+    int n_nodes = 1, steps_taken = 0;
+    if (l16 == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; path[0] = 0; } // mcts.py:129-130 reset()
+    lds_sync();
+    const int la = l16 < A ? l16 : 0;
+    const int row_lane0 = lane & 48;
+    // the first round of a rollout's draws (lane l: the generator l + 1 steps ahead = A^(l+1) state + inc G_(l+1)): the limbs of
+    // A^(l+1) and the product inc G_(l+1) are the same for every rollout of the plan -- registers, one 128-bit multiply per round
+    uint32_t an0[4];
+    uint64_t ig0_lo, ig0_hi;
+    {
+        const int j1 = l16 + 1 < H ? l16 + 1 : H;
+        uint32_t gn0[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { an0[i] = jump[j1 * 8 + i]; gn0[i] = jump[j1 * 8 + 4 + i]; }
+        Pcg64::mul128v(g.inc_lo, g.inc_hi, gn0, ig0_lo, ig0_hi);
+    }
+#ifdef MP_PROFILE
+    long long t_sel = 0, t_exp = 0, t_draw = 0, t_walk = 0, t_cap = 0, t_bak = 0, n_lvl = 0, n_rounds = 0;
+    const long long t_all0 = clock64();
+#endif
+    for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
+        PROF_T(c0);
+        int32_t s = s0, st = st0;
+        int node = 0, depth = 0;
+        bool terminal = false, cur_term = root_term;
+        double total = 0.0;
+        int fc = tnode[0].first_child;
+        // ---- selection, mcts.py:143-149: a level's children one per lane of the row
+        bool sel = live && depth < H && fc >= 0 && !terminal;
+        while (any64(sel)) {
+            const UctNode c = tnode[sel ? fc + la : 0];
+            double sc = c.value + explore(la, c.count + 1);   // MCTSNode.selection_strategy, mcts.py:275-286
+            if (l16 >= A) sc = -INFINITY;
+            const double m = row_children_max<AT>(sc);
+            const unsigned long long ball = ballot64(l16 < A && sc == m); // Node.random_argmax, abstract.py:296-311
+            unsigned t = (unsigned)(ball >> row_lane0) & 0xffffu;
+            const int nt = __popc(t);
+            if (any64(sel && nt > 1)) {   // (no row of this wavefront has a tie: no draw, the first maximum is the only one)
+                int pick = 0;
+                if (sel && nt > 1) pick = (int)g.below((uint32_t)nt);
+#pragma unroll
+                for (int k = 0; k < A - 1; ++k)
+                    if (pick > 0) { t &= t - 1; --pick; }
+            }
+            const int act = t ? __ffs((int)t) - 1 : 0;
+            const unsigned idx = __umul24((unsigned)s, (unsigned)A) + (unsigned)act;
+            // the chosen child's first_child, the transition, the reward and gamma ** depth: ONE LDS round trip
+            const int nfc = tnode[sel ? fc + act : 0].first_child;
+            const uint32_t e = t16[idx];
+            const double rw = rew[idx], gp = gpow[depth];
+            if (sel) {
+                total += gp * rw;
+                const bool next_term = (e & 0x8000u) != 0;
+                terminal = p.done_on_next ? next_term : cur_term;
+                cur_term = next_term;
+                s = (int32_t)(e & 0x7fffu);
+                ++st; ++steps_taken;
+                node = fc + act;
+                ++depth;
+                if (l16 == 0) path[depth] = node;
+                fc = nfc;
+            }
+            sel = sel && depth < H && fc >= 0 && !terminal;
+#ifdef MP_PROFILE
+            ++n_lvl;
+#endif
+        }
+        PROF_T(c1);
+        // ---- expansion, mcts.py:151-154 / 237-246
+        if (live && fc < 0 && depth < H && (!terminal || node == 0)) {
+            if (l16 == 0) tnode[node].first_child = n_nodes;
+            if (l16 < A) {
+                UctNode n;
+                n.value = 0.0; n.count = 0; n.first_child = -1;
+                tnode[n_nodes + l16] = n;
+            }
+            n_nodes += A;
+        }
+        PROF_T(c2);
+        // ---- rollout, mcts.py:156-157 / 160-177: rounds of 16 draws (one per lane of the row, by jump-ahead) and 16 steps of the walk
+        const bool want = live && !terminal && depth < H;
+        if (any64(want)) {
+            int n_lim = H - depth;
+            if (p.max_steps > 0 && p.max_steps - st < n_lim) n_lim = p.max_steps - st;
+            if (n_lim < 1) n_lim = 1; // (the first step is unconditional, as in the reference's loop)
+            bool alive = want, captured = false;
+            int n = 0;
+            for (int k16 = 0; any64(alive); k16 += 16) {
+                PROF_T(d0);
+                Pcg64 q = g;
+                uint32_t act_l;
+                {
+                    if (k16 == 0) {
+                        uint64_t p_lo, p_hi;
+                        Pcg64::mul128v(g.s_lo, g.s_hi, an0, p_lo, p_hi);
+                        const uint64_t lo = p_lo + ig0_lo;
+                        q.s_hi = p_hi + ig0_hi + (lo < p_lo ? 1ULL : 0ULL);
+                        q.s_lo = lo;
+                    } else {
+                        const int j1 = k16 + l16 + 1 < H ? k16 + l16 + 1 : H; // (draws beyond the horizon are never used)
+                        uint32_t an[4], gn[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) { an[i] = jump[j1 * 8 + i]; gn[i] = jump[j1 * 8 + 4 + i]; }
+                        q.jump(an, gn);
+                    }
+                    const uint64_t u = q.output();     // searchsorted(cdf, u, 'right') on the raw 64-bit output
+                    int act = 0;
+#pragma unroll
+                    for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0;
+                    act_l = (uint32_t)min(act, p.thr_valid);
+                }
+                PROF_T(d1);
+#define MP_ROW_WALK(i_)                                                                                 \
+    {                                                                                                   \
+        const int a_i = dpp_mov<0x150 + (i_)>((int)act_l);      /* row_newbcast: lane i_ of the row */   \
+        const unsigned idx = __umul24((unsigned)s, (unsigned)A) + (unsigned)a_i;                        \
+        const uint32_t e = t16[idx];                                                                    \
+        const double rw = rew[idx], gp = gpow[depth + n];                                               \
+        const bool next_term = (e & 0x8000u) != 0;                                                      \
+        const bool term_h = p.done_on_next ? next_term : cur_term;                                      \
+        if (alive) {                                                                                    \
+            total += gp * rw;                                                                           \
+            cur_term = next_term;                                                                       \
+            s = (int32_t)(e & 0x7fffu);                                                                 \
+            ++n;                                                                                        \
+            alive = !(term_h || n >= n_lim);                                                            \
+        }                                                                                               \
+    }
+                MP_ROW_WALK(0) MP_ROW_WALK(1) MP_ROW_WALK(2) MP_ROW_WALK(3)
+                if (any64(alive)) {
+                    MP_ROW_WALK(4) MP_ROW_WALK(5) MP_ROW_WALK(6) MP_ROW_WALK(7)
+                    if (any64(alive)) {
+                        MP_ROW_WALK(8) MP_ROW_WALK(9) MP_ROW_WALK(10) MP_ROW_WALK(11)
+                        if (any64(alive)) { MP_ROW_WALK(12) MP_ROW_WALK(13) MP_ROW_WALK(14) MP_ROW_WALK(15) }
+                    }
+                }
+#undef MP_ROW_WALK
+                PROF_T(d2);
+                // a row whose rollout ended in this round: its generator after the n draws it consumed = the state the lane of
+                // its last draw jumped to
+                const int src = (row_lane0 + ((n - 1) & 15)) << 2;
+                const uint32_t x0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)q.s_lo);
+                const uint32_t x1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(q.s_lo >> 32));
+                const uint32_t x2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)q.s_hi);
+                const uint32_t x3 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)(uint32_t)(q.s_hi >> 32));
+                if (want && !alive && !captured) {
+                    g.s_lo = ((uint64_t)x1 << 32) | x0;
+                    g.s_hi = ((uint64_t)x3 << 32) | x2;
+                    captured = true;
+                }
+#ifdef MP_PROFILE
+                { const long long d3 = clock64(); t_draw += d1 - d0; t_walk += d2 - d1; t_cap += d3 - d2; ++n_rounds; }
+#endif
+            }
+            if (want) { st += n; steps_taken += n; }
+        }
+        PROF_T(c3);
+        // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane of the row
+        lds_sync();
+        for (int d0 = 0; any64(live && d0 <= depth); d0 += 16) {
+            const int d = d0 + l16;
+            if (live && d <= depth) {
+                const int nd = path[d];
+                UctNode c = tnode[nd];
+                c.count += 1;
+                c.value += inv(c.count) * (total - c.value);
+                tnode[nd].value = c.value;       // (first_child is left alone: the node may just have been expanded)
+                tnode[nd].count = c.count;
+            }
+        }
+        lds_sync();
+#ifdef MP_PROFILE
+        { const long long c4 = clock64(); t_sel += c1 - c0; t_exp += c2 - c1; t_bak += c4 - c3; }
+#endif
+    }
+#ifdef MP_PROFILE
+    if (blockIdx.x == 0 && lane == 0)
+        printf("uct_row prof wave0: total=%lld select=%lld (levels %lld) expand=%lld draw=%lld walk=%lld capture=%lld (rounds %lld) backup=%lld\n",
+               (long long)(clock64() - t_all0), t_sel, n_lvl, t_exp, t_draw, t_walk, t_cap, n_rounds, t_bak);
+#endif
+    if (!live) return;
+    // the tree, to global memory in the group-interleaved layout (export, re-rooting by step_by_subtree)
+    const TreeRef<2, AT> tree = tree_of<2, AT>(p.tree, r, p.cap, A);
+    for (int i = l16; i < n_nodes; i += 16) tree[i] = tnode[i];
+    if (l16 == 0) {
         g.store(p.rng + (long)r * 6);
         // ---- AbstractPlanner.get_plan (abstract.py:143-156) with MCTSNode.selection_rule (mcts.py:212-218): most visited
         // child, ties -> first maximal value among them
@@ -1354,7 +1677,42 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots <= cus_l); // (one workgroup per CU: 256 roots 0.14 ms, four lanes per root 0.27)
         }
     }
+    // ONE MDP PER ROOT (uct_lone_kernel<.., EACH>): a batch model -- every root's own MDP staged into its workgroup's LDS from the
+    // 16-byte records (10 B per (s, a)), whatever the batch size.  MP_UCT_EACH=0 keeps the one-lane-per-root gather kernel.
+    bool each = false;
+    const int Sb = model->NB > 1 && model->Sb > 0 ? model->Sb : model->S;
+    const size_t sa_each = (size_t)Sb * A;
+    const size_t lds_each = (((ntab + 1) & ~(size_t)1) + ((sa_each + 1) & ~(size_t)1)) * sizeof(double) + ((sa_each + 7) & ~(size_t)7) * 2 +
+                            (size_t)(H + 5) * 32 + (size_t)cap * (sizeof(UctNode) + sizeof(double)) + (size_t)(H + 1) * sizeof(int32_t) + 16;
+    {
+        const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
+        const char *ee = getenv("MP_UCT_EACH");
+        if (!cart && !pol && at_known && model->NB > 1 && model->Sb > 0 && model->Sb < 32768 && want_il == 2 && H >= 1 && H <= 63 &&
+            lds_each <= kLdsBytes && !will_continue && !force && !(ee && atoi(ee) == 0))
+            each = true;
+    }
+    // ... and FOUR such roots per wavefront, a DPP row each (uct_row_kernel): the default wherever four MDPs + trees fit the LDS of
+    // a workgroup.  MP_UCT_ROW=0 keeps a wavefront per root.
+    bool rowk = false;
+    const size_t lds_row = (((ntab + 1) & ~(size_t)1) + kRowRoots * ((sa_each + 1) & ~(size_t)1)) * sizeof(double) +
+                           kRowRoots * (size_t)cap * sizeof(UctNode) + (size_t)(H + 5) * 32 +
+                           kRowRoots * (size_t)((H + 4) & ~3) * sizeof(int32_t) + kRowRoots * ((sa_each + 7) & ~(size_t)7) * 2;
+    {
+        const char *re = getenv("MP_UCT_ROW");
+        const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
+        if (!cart && !pol && at_known && model->NB > 1 && model->Sb > 0 && model->Sb < 32768 && want_il == 2 && H >= 1 && H <= 255 &&
+            lds_row <= kLdsBytes && !will_continue && !force && !(getenv("MP_UCT_EACH") && atoi(getenv("MP_UCT_EACH")) == 0) &&
+            !(re && atoi(re) == 0)) {
+            // measured (tools/micro_uct_row.py, S = 120, 33 x 30): 4096 roots 0.103 ms against 0.176 (a wavefront per root) and 0.175
+            // (a lane per root); 256 roots 0.090 against 0.081 -- with a CU to itself a root is served best by a whole wavefront
+            const long cus_r = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+            rowk = (re && atoi(re) != 0) || !each || n_roots > cus_r;
+        }
+    }
+    if (rowk) each = false;
+    if (each || rowk) lone = true;
     if (lone) { quad = false; ldsr = false; ldsm = false; }
+    a.Sb = Sb;
     a.jump = nullptr;
     if (quad || lone) {
         // limbs of A^n and G_n = 1 + A + ... + A^(n-1) (mod 2^128), n = 0..H: the generator after n draws is A^n state + inc G_n
@@ -1394,7 +1752,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         while (a.waves < w && a.waves < 16) a.waves <<= 1;
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
-    size_t lds = lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
+    size_t lds = rowk ? lds_row : each ? lds_each : lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
     if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double); // the sin / cos table of libm_sincos.hpp behind the path stack
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
@@ -1450,7 +1808,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (lds > 64 * 1024) { spill = true; lds = ntab * sizeof(double); }
     }
     if (spill && ctx->tree.il == 1) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d needs the spilled path stack, which the interleaved tree layout does not have", H);
-    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (lone ? "uct_lone" : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (rowk ? "uct_row_each" : each ? "uct_lone_each" : lone ? "uct_lone" : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
     if (ldsr || spill) {
         a.spill_stride = ((long)n_roots + 63) & ~63L;
         MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
@@ -1553,6 +1911,28 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (cart) {
             const dim3 grid((unsigned)((c.n_roots + c.lanes - 1) / c.lanes)), block(64);
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
+        } else if (rowk) {
+#define MP_ROWK(k)                                                                                                                 \
+    case k:                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                       \
+            MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_row_kernel<k>),                                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
+        hipLaunchKernelGGL((uct_row_kernel<k>), dim3((unsigned)((c.n_roots + kRowRoots - 1) / kRowRoots)), dim3(64), lds, s, c);   \
+        break;
+            switch (A) { MP_ROWK(2) MP_ROWK(3) MP_ROWK(4) MP_ROWK(5) MP_ROWK(6) MP_ROWK(7) MP_ROWK(8) default: break; }
+#undef MP_ROWK
+        } else if (each) {
+            // one wave per workgroup while a wave stages its MDP in a few trips; four for larger ones
+            const unsigned threads = sa_each <= 4096 ? 64u : 256u;
+#define MP_LONE(k)                                                                                                                 \
+    case k:                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                       \
+            MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_lone_kernel<k, true>),                                  \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
+        hipLaunchKernelGGL((uct_lone_kernel<k, true>), dim3((unsigned)c.n_roots), dim3(threads), lds, s, c);                      \
+        break;
+            switch (A) { MP_LONE(2) MP_LONE(3) MP_LONE(4) MP_LONE(5) MP_LONE(6) MP_LONE(7) MP_LONE(8) default: break; }
+#undef MP_LONE
         } else if (lone) {
 #define MP_LONE(k)                                                                                                                 \
     case k:                                                                                                                        \

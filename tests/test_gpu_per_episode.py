@@ -201,6 +201,62 @@ def test_uct_per_root_models_vs_oracle(ctx, n_models, n_roots):
     model.close()
 
 
+@pytest.mark.parametrize("shape,episodes,horizon,n_roots", [((3, 4, 10), 33, 30, 701), ((2, 3, 5), 9, 7, 130), ((4, 5, 12), 20, 63, 67), ((3, 4, 10), 12, 100, 33)])
+def test_uct_per_root_models_each_kernel_equals_gather_kernel_and_oracle(ctx, monkeypatch, shape, episodes, horizon, n_roots):
+    """Round 6: batch models plan on uct_row_kernel (four roots per wavefront, a DPP row each; MP_UCT_ROW=0: uct_lone_kernel<..,
+    EACH>, a wavefront per root) with the root's own MDP staged in LDS (local uint16 next states + the rewards themselves) --
+    same plans, statistics, env steps, trees and generator records as the one-lane-per-root gather kernel (MP_UCT_EACH=0) and
+    as per-root oracle plans; batch sizes that leave spare rows in the last wavefront; rewards with more than 256 distinct values (no dictionary
+    in this form), terminal root states, `done_rule = next`, a step limit."""
+    from oracle import oracle
+    from rl_agents_amd.envs import generators
+    n_models = 37
+    cfgs = [generators.highway_shaped(*shape, collision_rate=0.03 + 0.02 * (i % 5), seed=500 + i) for i in range(n_models)]
+    tr = np.stack([c["transition"] for c in cfgs])
+    g = np.random.Generator(np.random.PCG64(shape[0] * 1000 + n_roots))
+    rw = np.stack([c["reward"] for c in cfgs]) * g.random((n_models,) + cfgs[0]["reward"].shape)   # S * A distinct values per MDP
+    tm = np.stack([c["terminal"] for c in cfgs])
+    mi = g.integers(0, n_models, n_roots).astype(np.int32)
+    s0 = g.integers(0, tr.shape[1], n_roots).astype(np.int32)
+    term_roots = np.flatnonzero(tm[mi, s0])
+    assert len(term_roots) > 0                      # (terminal root states are part of the sample)
+    p = np.array([0.1, 0.3, 0.2, 0.25, 0.15])
+    for done_rule, max_steps in (("source", 0), ("next", 0), ("source", 11)):
+        model = ctx.load_table_batch(tr, rw, tm, done_rule=done_rule, max_steps=max_steps)
+        steps0 = g.integers(0, 8, n_roots).astype(np.int32) if max_steps else None
+        outs = {}
+        for name, env in (("row", {"MP_UCT_ROW": "1"}), ("lone", {"MP_UCT_ROW": "0"}), ("gather", {"MP_UCT_EACH": "0"})):
+            monkeypatch.delenv("MP_UCT_ROW", raising=False)
+            monkeypatch.delenv("MP_UCT_EACH", raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            rng = _rng_states(n_roots, base=31)
+            out = ctx.uct_plan(model, s0, episodes, horizon, 0.8, 10.0, p, p, rng, max_plan_len=horizon, model_index=mi,
+                               root_steps=steps0)
+            outs[name] = (out, rng, ctx.last_kernel_variant(), ctx.uct_tree(n_roots // 2), ctx.uct_tree(int(term_roots[0])),
+                          ctx.uct_tree(n_roots - 1))
+        monkeypatch.delenv("MP_UCT_EACH", raising=False)
+        monkeypatch.delenv("MP_UCT_ROW", raising=False)
+        # (a wavefront per root draws a rollout's actions one per lane: horizons up to 63; beyond, the gather kernel stands in)
+        assert [outs[k][2] for k in ("row", "lone", "gather")] == ["uct_row_each", "uct_lone_each" if horizon <= 63 else "uct_global", "uct_global"]
+        for name in ("row", "lone"):
+            for key in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps"):
+                np.testing.assert_array_equal(outs[name][0][key], outs["gather"][0][key], err_msg=name + " " + key)
+            np.testing.assert_array_equal(outs[name][1], outs["gather"][1], err_msg=name + " rng")
+            for j in (3, 4, 5):
+                for key in ("count", "value", "first_child"):
+                    np.testing.assert_array_equal(outs[name][j][key], outs["gather"][j][key], err_msg=name + " tree " + key)
+        outs["1"] = outs["row"]
+        rng_ref = _rng_states(n_roots, base=31)
+        ref = oracle.uct_plan_each(tr, rw, tm, mi, s0, episodes, horizon, 0.8, 10.0, p, p, rng_ref, max_plan_len=horizon,
+                                   done_rule=done_rule, max_steps=max_steps, steps0=steps0)
+        np.testing.assert_array_equal(outs["1"][0]["plans"], ref["plans"])
+        assert np.array_equal(outs["1"][0]["root_value"], ref["root_value"])
+        np.testing.assert_array_equal(outs["1"][0]["env_steps"], ref["env_steps"])
+        np.testing.assert_array_equal(outs["1"][1], ref["rng_after"])
+        model.close()
+
+
 def test_opd_per_root_models_vs_oracle(ctx):
     from oracle import oracle
     n = 300
