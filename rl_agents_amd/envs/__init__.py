@@ -2,4 +2,4 @@ from .finite_mdp import FiniteMDPEnv, MaskedFiniteMDPEnv, OrderedMaskedFiniteMDP
 from . import generators  # noqa: F401
 from .cartpole import CartPoleEnv  # noqa: F401
 from .highway_like import HighwayLikeEnv  # noqa: F401
-from .changing import ScheduledTableEnv, ChangingHighwayEnv  # noqa: F401
+from .changing import ScheduledTableEnv, MaskedScheduledTableEnv, ChangingHighwayEnv  # noqa: F401

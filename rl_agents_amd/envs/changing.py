@@ -5,19 +5,19 @@ episodes is what ``rl_agents_amd.trainer.per_episode_evaluation`` advances with 
 import numpy as np
 
 from . import generators
-from .finite_mdp import FiniteMDPEnv
+from .finite_mdp import FiniteMDPEnv, MaskedFiniteMDPEnv
 from .highway_like import HighwayLikeEnv
 
 
-class ScheduledTableEnv(FiniteMDPEnv):
-    """A FiniteMDPEnv whose tables are replaced before every step from a schedule ``tables[t]`` (dicts with transition /
-    reward / terminal; the last one stays) -- what a re-extraction does to the env's MDP: new tables, same current state."""
+class _ScheduledTables(object):
+    """Tables replaced before every step from a schedule ``tables[t]`` (dicts with transition / reward / terminal; the last one
+    stays) -- what a re-extraction does to the env's MDP: new tables, same current state."""
 
     def __init__(self, tables, state=0, max_steps=0):
         self.tables = [dict(t) for t in tables]
         cfg = {k: v for k, v in self.tables[0].items() if k != "original_shape"}
         cfg.update(state=int(state), max_steps=int(max_steps))
-        super(ScheduledTableEnv, self).__init__(cfg)
+        super(_ScheduledTables, self).__init__(cfg)
         self.reset()
 
     def _install(self, t):
@@ -27,14 +27,23 @@ class ScheduledTableEnv(FiniteMDPEnv):
         self.mdp.terminal = np.asarray(tab["terminal"]).astype(bool)
 
     def reset(self, **kw):
-        out = super(ScheduledTableEnv, self).reset(**kw)
+        out = super(_ScheduledTables, self).reset(**kw)
         self._install(0)
         return out
 
     def step(self, action):
-        out = super(ScheduledTableEnv, self).step(action)
+        out = super(_ScheduledTables, self).step(action)
         self._install(self.steps)
         return out
+
+
+class ScheduledTableEnv(_ScheduledTables, FiniteMDPEnv):
+    """A FiniteMDPEnv whose tables follow a schedule (see :class:`_ScheduledTables`)."""
+
+
+class MaskedScheduledTableEnv(_ScheduledTables, MaskedFiniteMDPEnv):
+    """The same over a :class:`MaskedFiniteMDPEnv`: ``tables[0]["available"]`` ([S][A] flags) restricts the action sets of
+    every step (``get_available_actions``), as a grid of one shape does."""
 
 
 class ChangingHighwayEnv(HighwayLikeEnv):

@@ -19,4 +19,4 @@ def pytest_configure(config):
 def golden():
     import numpy as np
     d = os.path.join(REPO, "tests", "golden")
-    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("vi", "opd", "uct", "misc", "uct_cartpole", "uct_prior", "state_aware", "tree_tools", "per_episode")}
+    return {k: np.load(os.path.join(d, k + ".npz")) for k in ("vi", "opd", "uct", "misc", "uct_cartpole", "uct_prior", "state_aware", "tree_tools", "per_episode", "per_episode_prior")}

@@ -43,3 +43,15 @@ class BoltzmannQAgent(object):
 
     def reset(self):
         pass
+
+
+class BoltzmannVIAgent(ValueIterationAgent):
+    """The reference's OWN ValueIterationAgent -- which converts its environment again and re-solves at EVERY act()
+    (value_iteration.py:29-35) -- plus the ``action_distribution`` that mcts_with_prior.py:47-54 asks a prior agent for and that
+    the reference's vi_prior.json assumes it has: a Boltzmann distribution over the Q table the last act() solved.  With it the
+    unmodified MCTSWithPriorPolicyAgent re-solves value iteration on the table of whatever environment copy a policy is asked
+    about: the per-episode, per-step-changing case (tests/golden/per_episode_prior.npz)."""
+
+    def action_distribution(self, observation):
+        table = boltzmann_table(np.array(self.state_action_value), self.config.get("temperature", 1.0))
+        return {a: table[observation, a] for a in range(table.shape[1])}

@@ -116,3 +116,113 @@ def test_unchanged_tables_are_not_sent_again():
     out = ev.run()
     assert out["uploads"] == 8 and out["lengths"].max() >= 2
     ev.close()
+
+
+# ---------------------------------------------------------------------------------------------- MCTS with a VI prior (round 6)
+def _prior_envs(z, name):
+    from rl_agents_amd.envs import MaskedScheduledTableEnv, ScheduledTableEnv
+    envs = []
+    for e in range(4):
+        tables = [dict(mode="deterministic", transition=z[name + "/transition"][e, t], reward=z[name + "/reward"][e, t],
+                       terminal=z[name + "/terminal"][e, t]) for t in range(3)]
+        if name == "masked":
+            for tab in tables:
+                tab["available"] = z["masked/available"].astype(int)
+        envs.append((MaskedScheduledTableEnv if name == "masked" else ScheduledTableEnv)(tables, state=int(z[name + "/s0"][e])))
+    return envs
+
+
+def _prior_agent_config(z, name):
+    return dict(budget=int(z[name + "/budget"]), gamma=float(z[name + "/gamma"]), temperature=float(z[name + "/temperature"]),
+                prior_agent={"__class__": "<class 'rl_agents_amd.agents.dynamic_programming.value_iteration.ValueIterationAgent'>",
+                             "gamma": float(z["prior/gamma"]), "iterations": int(z["prior/iterations"]),
+                             "temperature": float(z["prior/temperature"])})
+
+
+@pytest.mark.parametrize("name", ["plain", "masked"])
+def test_golden_per_episode_mcts_with_vi_prior(golden, name):
+    """tests/golden/per_episode_prior.npz: four episodes of the UNMODIFIED reference MCTSWithPriorPolicyAgent whose prior agent
+    re-solves value iteration on the table of every step (vi_prior.json's chain: value_iteration.py:29-35 ->
+    mcts_with_prior.py:47-62 -> mcts.py:132-184), from one batched launch per step: first actions, planner env steps and the
+    generator of every episode; `masked`: restricted action sets, the distribution renormalised over the listed actions, an
+    episode that terminates after its first step."""
+    from rl_agents_amd.agents.tree_search.mcts_with_prior import MCTSWithPriorPolicyAgent
+    from rl_agents_amd.trainer.per_episode_evaluation import PerEpisodeEvaluation
+    z = golden["per_episode_prior"]
+    envs = _prior_envs(z, name)
+    agent = MCTSWithPriorPolicyAgent(envs[0], _prior_agent_config(z, name))
+    assert agent.planner.config["episodes"] == int(z[name + "/episodes"]) and agent.planner.config["horizon"] == int(z[name + "/horizon"])
+    seed0 = 300 + (10 if name == "masked" else 0)
+    ev = PerEpisodeEvaluation(envs, agent, sim_seed=seed0, max_steps=3)
+    out = ev.run()
+    total = 0
+    for e in range(4):
+        n_steps = int(z["{}/e{}/n_steps".format(name, e)])
+        assert int(out["lengths"][e]) == n_steps
+        for t in range(n_steps):
+            p = "{}/e{}/t{}".format(name, e, t)
+            assert int(out["actions"][e, t]) == int(z[p + "/plan"][0]), p
+        last = "{}/e{}/t{}".format(name, e, n_steps - 1)
+        total += int(z[last + "/env_steps_total"])
+        np.testing.assert_array_equal(ev.rng[e], z[last + "/rng_after"], err_msg=last)
+    assert out["planner_env_steps"] == total
+    ev.close()
+
+
+@pytest.mark.parametrize("restricted", [False, True])
+def test_changing_highway_batch_with_vi_prior_equals_sequential_agents(restricted):
+    """MCTSWithPriorPolicyAgent (prior agent: this package's ValueIterationAgent, re-converting and re-solving at every call
+    like the reference's) on 12 environments whose table is re-drawn after every step: the batch == 12 sequential agent loops."""
+    from rl_agents_amd.agents.tree_search.mcts_with_prior import MCTSWithPriorPolicyAgent
+    from rl_agents_amd.envs import ChangingHighwayEnv, ScheduledTableEnv, generators
+    from rl_agents_amd.trainer.per_episode_evaluation import PerEpisodeEvaluation
+    n, steps = 12, 4
+    cfg = dict(budget=120, gamma=0.8, temperature=6.0,
+               prior_agent={"__class__": "<class 'rl_agents_amd.agents.dynamic_programming.value_iteration.ValueIterationAgent'>",
+                            "gamma": 0.9, "iterations": 100, "temperature": 0.4})
+
+    def envs():
+        if restricted:          # highway-env's surface: the restriction on the env object, IDLE listed first
+            return [ChangingHighwayEnv(3, 4, 10, table_seed=900 + 20 * i, state=((i % 3) * 4 + (i % 4)) * 10,
+                                       collision_rate=0.03 + 0.02 * (i % 4)) for i in range(n)]
+        out = []
+        for i in range(n):
+            tabs = [{k: v for k, v in generators.highway_shaped(3, 4, 10, collision_rate=0.05, seed=4000 + 10 * i + t).items()
+                     if k != "original_shape"} for t in range(steps)]
+            out.append(ScheduledTableEnv(tabs, state=((i % 3) * 4 + (i % 4)) * 10))
+        return out
+    batch_envs = envs()
+    ev = PerEpisodeEvaluation(batch_envs, MCTSWithPriorPolicyAgent(batch_envs[0], dict(cfg)), sim_seed=21, max_steps=steps)
+    out = ev.run()
+    acts, returns = _sequential(envs(), lambda env: MCTSWithPriorPolicyAgent(env, dict(cfg)), 21, steps)
+    np.testing.assert_array_equal(out["actions"], acts)
+    assert np.array_equal(out["returns"], returns)
+    ev.close()
+
+
+def test_static_tables_are_neither_rebuilt_nor_compared():
+    """tables_version in the sync: environments whose MDP keeps its version are not re-extracted into a spec at
+    all after the first step (no TableSpec, no comparison, no upload)."""
+    from rl_agents_amd import device_model
+    from rl_agents_amd.agents.tree_search.deterministic import DeterministicPlannerAgent
+    from rl_agents_amd.envs import FiniteMDPEnv, generators
+    from rl_agents_amd.trainer.per_episode_evaluation import PerEpisodeEvaluation
+    envs = []
+    for i in range(8):
+        cfg = {k: v for k, v in generators.highway_shaped(3, 4, 10, seed=i).items() if k != "original_shape"}
+        cfg["state"] = 10 * i
+        envs.append(FiniteMDPEnv(cfg))
+    ev = PerEpisodeEvaluation(envs, DeterministicPlannerAgent(envs[0], dict(budget=60, gamma=0.8)), sim_seed=1, max_steps=5)
+    built = []
+    real = device_model.spec_from_mdp
+
+    def counting(*a, **k):
+        built.append(1)
+        return real(*a, **k)
+    device_model.spec_from_mdp = counting
+    try:
+        out = ev.run()
+    finally:
+        device_model.spec_from_mdp = real
+    assert out["uploads"] == 8 and len(built) == 8 and out["lengths"].max() >= 2
+    ev.close()

@@ -593,6 +593,28 @@ def test_model_cache_catches_tables_edited_behind_an_unchanged_version(monkeypat
         assert cache2.get(device_model.spec_from_mdp(mdp2)) is not first
 
 
+def test_restrict_and_renormalise_equals_the_per_state_reference_loop():
+    """trainer.per_episode_evaluation.restrict_and_renormalise (every row of a batch at once) == agent_policy_available
+    (mcts_with_prior.py:56-62) state by state -- np.sum over the listed probabilities, including numpy's 8-accumulator form when
+    all of 8 actions are listed -- bit for bit."""
+    from rl_agents_amd.trainer.per_episode_evaluation import restrict_and_renormalise
+    from tests.helpers import restricted_agent_policy_lists
+    g = np.random.Generator(np.random.PCG64(0))
+    for a in (2, 3, 5, 7, 8):
+        t = g.random((6, 40, a))
+        t /= t.sum(axis=-1, keepdims=True)
+        av = g.random((40, a)) < 0.6
+        av[np.arange(40), g.integers(0, a, 40)] = True
+        av[:5] = True                                   # (rows with everything listed)
+        out = restrict_and_renormalise(t, av)
+        for n in range(6):
+            ref = restricted_agent_policy_lists(t[n], av)
+            for st in range(40):
+                want = np.zeros(a)
+                want[ref["actions"][st]] = ref["p"][st]
+                assert np.array_equal(out[n, st], want), (a, n, st)
+
+
 def test_opd_leaf_load_wait_counts_match_the_generated_code():
     """the hand-counted `s_waitcnt vmcnt(N)` before opd.hip's scalar leaf-record loads, checked against the
     disassembly of the object the library was linked from (tools/check_isa.py; rl_agents_amd.build refuses a library that
