@@ -45,6 +45,7 @@ from benchmarks.common import ranks_record, reference_python, visible_devices   
 from benchmarks.uct import bench_uct, bench_uct_cartpole, bench_uct_stoch, bench_uct_per_root_model     # noqa: E402
 from benchmarks.opd import bench_opd, bench_ropd, bench_saopd     # noqa: E402
 from benchmarks.vi import bench_vi, bench_rvi_dense_shard, bench_vi_batch     # noqa: E402
+from benchmarks.eval import bench_per_episode_eval     # noqa: E402
 
 
 def parse():
@@ -53,7 +54,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="uct", choices=["uct", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "ropd", "saopd", "vi", "rvi", "vi_dense", "vi_dense_exact", "rvi_dense_shard", "vi_batch",
-                                                         "uct_per_root_model"])
+                                                         "uct_per_root_model", "per_episode_eval"])
     ap.add_argument("--roots", type=int, default=None, help="roots per GPU (default 262144 uct, 1024 opd)")
     ap.add_argument("--states", type=int, default=None, help="|S| override (vi_dense default 10000)")
     ap.add_argument("--dense-mode", default=None, choices=["mfma", "exact"],
@@ -128,6 +129,8 @@ def run_workload(args, rank, world, local):
         return bench_vi_batch(args, rank, world, local)
     if args.workload == "uct_per_root_model":
         return bench_uct_per_root_model(args, rank, world, local)
+    if args.workload == "per_episode_eval":
+        return bench_per_episode_eval(args, rank, world, local)
     if args.workload == "uct_prior":
         return bench_uct(args, rank, world, local, with_prior=True)
     if args.workload == "uct":
@@ -157,7 +160,9 @@ SLICES = [("uct_prior", "uct_prior", 5, None), ("uct_cartpole", "uct_cartpole", 
           ("rvi_dense_shard_exact", "rvi_dense_shard", 10, None, "exact"),
           # round 5: one finite MDP per episode -- N value-iteration agents in one launch, UCT with one MDP per root
           ("vi_batch", "vi_batch", 10, 4096, None, 120), ("vi_batch_s10000", "vi_batch", 5, 64, None, 10000),
-          ("uct_per_root_model", "uct_per_root_model", 10, 4096)]
+          ("uct_per_root_model", "uct_per_root_model", 10, 4096),
+          # round 6: the per-episode evaluation LOOP end to end (extraction, upload, plan, env.step), 4096 episodes x 2 lock-steps
+          ("per_episode_eval", "per_episode_eval", 2, 4096)]
 
 
 SLICES_MULTI_GPU = [("opd", "opd", 10, None), ("rvi_dense_shard_exact", "rvi_dense_shard", 10, None, "exact")]

@@ -367,6 +367,13 @@ int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, con
  * on an environment whose get_available_actions() is not ascending (highway-env: IDLE first). */
 int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout,
                            const uint8_t *listed, const uint8_t *rollout_slot, mp_policy **out);
+/* mp_policy_load_ordered with `rows` distribution rows: rows = S (one per state of the model), or rows = the states of ONE MDP
+ * of a batch model (mp_model_load_table_batch) -- prior / rollout / listed / rollout_slot are then [rows, A] over LOCAL states
+ * and serve every MDP of the batch: the planner's own policies (mcts.py:46-97) on a batch of environments that restrict their
+ * actions identically (trainer/evaluation.py:139-194 run N at a time).  Deterministic table models with 2..8 actions and at
+ * least 16 384 (s, a) pairs -- and every tiled call -- are fused by kernels on the device (ABI 7); results are identical. */
+int mp_policy_load_rows(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout,
+                        const uint8_t *listed, const uint8_t *rollout_slot, int32_t rows, mp_policy **out);
 int mp_policy_free(mp_policy *policy);
 int mp_uct_plan_policy(mp_ctx *ctx, mp_model *model, mp_policy *policy, int32_t n_roots, const void *root_state,
                        const int32_t *root_steps, int32_t episodes, int32_t horizon, double gamma, double temperature,

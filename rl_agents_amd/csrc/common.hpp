@@ -62,7 +62,7 @@ struct TreeMeta {
 
 enum { WS_TREE0 = 0, WS_TREE1, WS_TREE2, WS_TREE3, WS_TREE4, WS_TREE5, WS_TREE6, WS_TREE7, WS_IO0, WS_IO1, WS_IO2, WS_IO3, WS_IO4,
        WS_IO5, WS_IO6, WS_IO7, WS_IO8, WS_IO9, WS_TAB0, WS_TAB1, WS_TAB2, WS_TAB3, WS_VI0, WS_VI1, WS_VI2, WS_VI3,
-       WS_VI4, WS_VI5, WS_GROOT, WS_JUMP, WS_COUNT };
+       WS_VI4, WS_VI5, WS_GROOT, WS_JUMP, WS_POL0, WS_POL1, WS_POL2, WS_POL3, WS_POL4, WS_COUNT };
 
 // everything a captured chain of deterministic VI sweeps bakes into its kernel arguments
 struct ViGraphKey {
@@ -262,6 +262,10 @@ struct mp_policy {
     uint32_t *lmask = nullptr;  // policies of STOCHASTIC models (uct_stoch.hip): actions the prior policy lists per state, [S]
     uint8_t *rslot = nullptr;   // ... and the column of every rollout slot, [S][A], nullptr when slots are the columns
     uint8_t *listed8 = nullptr; // ... the listed actions as a byte per action, [S][A], when |A| > 32 (lmask is 32 bits wide)
+    // built on the device (policy_build_device): the arrays above are ONE block from the ctx's block cache (hipMalloc / hipFree
+    // synchronise the device; a per-episode evaluation loop re-fuses its policy at every step)
+    void *block = nullptr;
+    size_t block_bytes = 0;
 };
 
 namespace mp {

@@ -1509,6 +1509,98 @@ static int uct_launch(const UctArgs &a, bool ldsm, size_t lds, hipStream_t st, b
     return MP_OK;
 }
 
+// ---- per-state policies fused ON THE DEVICE (round 6).  mp_policy_load's host loops (download the model's records, S * |A|
+// thresholds and fused records in C++, six hipMalloc'ed arrays uploaded) cost 90 ms per call on the batch model of 4096
+// highway episodes (491 520 global states) -- per step of the per-episode evaluation loop, whose tables change at every step.
+// The same arithmetic as kernels: one thread per state for the prior row, the sampling thresholds ceil(cdf * 2^53) (numpy's
+// cumsum order, IEEE division) and the listed-action mask; one thread per (s, a) for the fused record.  `rows` < S: the
+// distributions are given for ONE MDP of a batch model (local states) and apply to every MDP -- the planner's own policies on a
+// batch of environments that restrict their actions identically.
+struct PolBuild {
+    int S, A, stride, frq, rows, shift, can_pack;
+    const double *prior, *rollout;   // [rows][A]
+    const uint8_t *listed, *slot;    // [rows][A] or nullptr
+    const Rec *rec;                  // [S * A]
+    double *hp;                      // [S][stride]
+    uint64_t *ht;                    // [S][stride]
+    uint32_t *lmask;                 // [S]
+    uint32_t *hf, *hfr, *hp16;       // [S * A][frq * 4], the same by rollout slot (or nullptr), [S * A][4] (or nullptr)
+    int32_t *err;                    // {code, state}: 1 negative / NaN probability, 2 rollout row sums to 0, 3 no listed action,
+                                     // 4 rollout slots not a permutation, 5 transition out of range
+};
+__device__ __forceinline__ void pol_err(const PolBuild &b, int code, int s)
+{
+    if (atomicCAS(b.err, 0, code) == 0) b.err[1] = s;
+}
+__global__ void policy_rows_kernel(PolBuild b)
+{
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= b.S) return;
+    const int A = b.A, r = s % b.rows;
+    double cdf[8];
+    double acc = 0.0;
+    unsigned seen = 0;
+    for (int a = 0; a < A; ++a) {
+        const int c = b.slot ? (int)b.slot[(size_t)r * A + a] : a;
+        if (c >= A || ((seen >> c) & 1u)) { pol_err(b, 4, s); return; }
+        seen |= 1u << c;
+        const double q = b.rollout[(size_t)r * A + c], pr = b.prior[(size_t)r * A + a];
+        if (!(q >= 0.0) || !(pr >= 0.0)) pol_err(b, 1, s);
+        b.hp[(size_t)s * b.stride + a] = pr;
+        acc += q; cdf[a] = acc;                                                    // numpy cumsum, in the rollout policy's order
+    }
+    if (!(acc > 0.0)) pol_err(b, 2, s);
+    for (int a = 0; a < A; ++a) {
+        const double scaled = ceil((cdf[a] / acc) * 9007199254740992.0);           // cdf /= cdf[-1]; ceil(ldexp(., 53))
+        b.ht[(size_t)s * b.stride + a] = scaled >= 18446744073709551615.0 ? ~0ULL : (uint64_t)scaled;
+    }
+    for (int a = A; a < b.stride; ++a) { b.hp[(size_t)s * b.stride + a] = 0.0; b.ht[(size_t)s * b.stride + a] = ~0ULL; }
+    uint32_t m = (1u << A) - 1u;
+    if (b.listed) {
+        m = 0;
+        for (int a = 0; a < A; ++a) m |= (b.listed[(size_t)r * A + a] ? 1u : 0u) << a;
+        if (!m) pol_err(b, 3, s);
+    }
+    b.lmask[s] = m;
+}
+__global__ void policy_frec_kernel(PolBuild b)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)b.S * b.A) return;
+    const int A = b.A;
+    uint32_t *f = b.hf + (size_t)i * b.frq * 4;
+    const uint4 rc = reinterpret_cast<const uint4 *>(b.rec)[i];
+    const int nx = (int)rc.x;
+    if (nx < 0 || nx >= b.S) { pol_err(b, 5, (int)(i / A)); return; }
+    f[0] = rc.x; f[2] = rc.z; f[3] = rc.w;
+    f[1] = (rc.y & 0xffu) | (b.lmask[nx] << 8) | (b.lmask[i / A] << 16);
+    for (int k = 4; k < b.frq * 4; ++k) f[k] = 0xffffffffu;
+    uint32_t th[4] = {1023u, 1023u, 1023u, 1023u};
+    for (int a = 0; a + 1 < A; ++a) {
+        const uint64_t t53 = b.ht[(size_t)nx * b.stride + a];
+        const uint64_t hi = t53 >> b.shift;                                        // top bits of the 53, saturated
+        f[4 + a] = hi > 0xffffffffULL ? 0xffffffffu : (uint32_t)hi;
+        if (b.can_pack && a < 4) th[a] = (t53 >> 43) > 1023ULL ? 1023u : (uint32_t)(t53 >> 43);
+    }
+    if (b.can_pack) {
+        uint32_t *g = b.hp16 + (size_t)i * 4;
+        g[0] = (uint32_t)nx | (th[0] << 20);
+        g[1] = (rc.y & 3u) | (th[1] << 2) | (th[2] << 12) | (th[3] << 22);
+        g[2] = rc.z; g[3] = rc.w;
+    }
+}
+__global__ void policy_froll_kernel(PolBuild b) // entry (s, k) = the record of (s, column of slot k)
+{
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)b.S * b.A) return;
+    const int s = (int)(i / b.A), k = (int)(i % b.A), r = s % b.rows;
+    const int c = b.slot[(size_t)r * b.A + k];
+    if (c >= b.A) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(b.hf) + ((size_t)s * b.A + c) * b.frq;
+    uint4 *dst = reinterpret_cast<uint4 *>(b.hfr) + (size_t)i * b.frq;
+    for (int q = 0; q < b.frq; ++q) dst[q] = src[q];
+}
+
 } // namespace mp
 
 using namespace mp;
@@ -2060,7 +2152,119 @@ int mp_policy_load_listed(mp_ctx *ctx, mp_model *model, const double *prior, con
 int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, const uint8_t *listed,
                            const uint8_t *rollout_slot, mp_policy **out)
 {
+    return mp_policy_load_rows(ctx, model, prior, rollout, listed, rollout_slot, model ? model->S : 0, out);
+}
+
+// The fused policy built by kernels (see PolBuild).  One block from the ctx's block cache holds every array.
+static int policy_build_device(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, const uint8_t *listed,
+                               const uint8_t *rollout_slot, int rows, mp_policy **out)
+{
+    const int S = model->S, A = model->A;
+    const int stride = (A + 1) & ~1, frq = 1 + (A - 1 + 3) / 4;
+    int shift = 21;
+    if (const char *e = getenv("MP_UCT_COARSE_BITS")) {
+        const int n = atoi(e);
+        if (n >= 1 && n <= 32) shift = 53 - n;
+    }
+    const bool can_pack = A <= 5 && S <= (1 << 20) && !getenv("MP_UCT_COARSE_BITS") && !listed && !rollout_slot;
+    hipStream_t st = ctx->stream;
+    // inputs -> workspace
+    double *d_prior = nullptr, *d_roll = nullptr;
+    uint8_t *d_listed = nullptr, *d_slot = nullptr;
+    int32_t *d_err = nullptr;
+    const size_t nin = (size_t)rows * A;
+    MP_TRY(ws_get(ctx, WS_POL0, nin, &d_prior));
+    MP_TRY(ws_get(ctx, WS_POL1, nin, &d_roll));
+    MP_TRY(ws_get(ctx, WS_POL4, 2, &d_err));
+    MP_HIP(hipMemcpyAsync(d_prior, prior, nin * 8, hipMemcpyHostToDevice, st));
+    if (rollout == prior) d_roll = d_prior;
+    else MP_HIP(hipMemcpyAsync(d_roll, rollout, nin * 8, hipMemcpyHostToDevice, st));
+    if (listed) {
+        MP_TRY(ws_get(ctx, WS_POL2, nin, &d_listed));
+        MP_HIP(hipMemcpyAsync(d_listed, listed, nin, hipMemcpyHostToDevice, st));
+    }
+    if (rollout_slot) {
+        MP_TRY(ws_get(ctx, WS_POL3, nin, &d_slot));
+        MP_HIP(hipMemcpyAsync(d_slot, rollout_slot, nin, hipMemcpyHostToDevice, st));
+    }
+    MP_HIP(hipMemsetAsync(d_err, 0, 8, st));
+    // outputs: one block
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t b_hp = al((size_t)S * stride * 8), b_ht = b_hp, b_hf = al((size_t)S * A * frq * 16), b_lm = al((size_t)S * 4),
+                 b_hfr = rollout_slot ? b_hf : 0, b_p16 = can_pack ? al((size_t)S * A * 16) : 0, b_rs = rollout_slot ? al((size_t)S * A) : 0;
+    mp_policy *pol = new (std::nothrow) mp_policy;
+    if (!pol) return fail(MP_ERR_ALLOC, "mp_policy_load: out of memory");
+    pol->ctx = ctx; pol->model = model; pol->model_serial = model->serial; pol->S = S; pol->A = A; pol->stride = stride; pol->frq = frq;
+    pol->shift = shift; pol->packed = can_pack ? 1 : 0; pol->listed = listed ? 1 : 0;
+    size_t got = 0;
+    if (ctx_block_alloc(ctx, &pol->block, b_hp + b_ht + b_hf + b_lm + b_hfr + b_p16 + b_rs, &got) != hipSuccess) {
+        (void)hipGetLastError();
+        delete pol;
+        return fail(MP_ERR_ALLOC, "mp_policy_load: device allocation failed");
+    }
+    pol->block_bytes = got;
+    char *base = static_cast<char *>(pol->block);
+    pol->prior = reinterpret_cast<double *>(base); base += b_hp;
+    pol->thr = reinterpret_cast<uint64_t *>(base); base += b_ht;
+    pol->frec = reinterpret_cast<uint4 *>(base); base += b_hf;
+    pol->lmask = reinterpret_cast<uint32_t *>(base); base += b_lm;
+    if (rollout_slot) { pol->frec_roll = reinterpret_cast<uint4 *>(base); base += b_hfr; }
+    if (can_pack) { pol->frec16 = reinterpret_cast<uint4 *>(base); base += b_p16; }
+    if (rollout_slot) { pol->rslot = reinterpret_cast<uint8_t *>(base); base += b_rs; }
+    PolBuild b;
+    b.S = S; b.A = A; b.stride = stride; b.frq = frq; b.rows = rows; b.shift = shift; b.can_pack = can_pack ? 1 : 0;
+    b.prior = d_prior; b.rollout = d_roll; b.listed = d_listed; b.slot = d_slot; b.rec = model->rec;
+    b.hp = pol->prior; b.ht = pol->thr; b.lmask = pol->lmask; b.hf = reinterpret_cast<uint32_t *>(pol->frec);
+    b.hfr = reinterpret_cast<uint32_t *>(pol->frec_roll); b.hp16 = reinterpret_cast<uint32_t *>(pol->frec16); b.err = d_err;
+    hipLaunchKernelGGL(policy_rows_kernel, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(policy_frec_kernel, dim3((unsigned)(((size_t)S * A + 255) / 256)), dim3(256), 0, st, b);
+    if (rollout_slot) {
+        hipLaunchKernelGGL(policy_froll_kernel, dim3((unsigned)(((size_t)S * A + 255) / 256)), dim3(256), 0, st, b);
+        // the slots' columns by GLOBAL state (uct_stoch.hip reads them): tile the rows
+        for (int off = 0; off < S; off += rows)
+            MP_HIP(hipMemcpyAsync(pol->rslot + (size_t)off * A, d_slot, (size_t)(S - off < rows ? S - off : rows) * A, hipMemcpyDeviceToDevice, st));
+    }
+    int32_t err[2] = {0, 0};
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(err, d_err, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) {
+        mp_policy_free(pol);
+        return fail(MP_ERR_HIP, "mp_policy_load: %s", hipGetErrorString(e));
+    }
+    if (err[0]) {
+        mp_policy_free(pol);
+        const int s_bad = err[1];
+        switch (err[0]) {
+        case 1: return fail(MP_ERR_ARG, "mp_policy_load: negative or NaN probability in state %d", s_bad);
+        case 2: return fail(MP_ERR_ARG, "mp_policy_load: rollout distribution of state %d sums to 0", s_bad);
+        case 3: return fail(MP_ERR_ARG, "mp_policy_load_listed: the prior policy lists no action in state %d", s_bad);
+        case 4: return fail(MP_ERR_ARG, "mp_policy_load_ordered: rollout_slot of state %d is not a permutation", s_bad);
+        default: return fail(MP_ERR_ARG, "mp_policy_load: transition out of range");
+        }
+    }
+    *out = pol;
+    return MP_OK;
+}
+
+// `rows` = S: one distribution row per state of the model; `rows` = the states of ONE MDP of a batch model
+// (mp_model_load_table_batch): the rows are given for local states and serve every MDP of the batch.
+int mp_policy_load_rows(mp_ctx *ctx, mp_model *model, const double *prior, const double *rollout, const uint8_t *listed,
+                        const uint8_t *rollout_slot, int32_t rows, mp_policy **out)
+{
     if (!ctx || !model || !prior || !rollout || !out) return fail(MP_ERR_ARG, "mp_policy_load: NULL argument");
+    if (rows != model->S && !(model->NB > 1 && model->Sb > 0 && rows == model->Sb))
+        return fail(MP_ERR_ARG, "mp_policy_load_rows: %d rows for a model of %d states (%d MDPs of %d)", rows, model->S, model->NB, model->Sb);
+    {
+        const bool det = model->mode == MP_MODE_DETERMINISTIC && model->rec && model->A >= 2 && model->A <= 8;
+        const char *how = getenv("MP_POLICY_BUILD"); // "host" / "device": test knob
+        const bool big = (size_t)model->S * model->A >= 16384;
+        if (det && (rows != model->S || (how ? how[0] == 'd' : big))) {
+            MP_HIP(hipSetDevice(ctx->device));
+            return policy_build_device(ctx, model, prior, rollout, listed, rollout_slot, rows, out);
+        }
+        if (rows != model->S) return fail(MP_ERR_ARG, "mp_policy_load_rows: tiled rows need a deterministic table model with 2..8 actions");
+    }
     const bool stoch = model->mode == MP_MODE_STOCHASTIC || model->mode == MP_MODE_SPARSE; // policies for uct_stoch.hip
     if (!stoch && (model->mode != MP_MODE_DETERMINISTIC || !model->rec))
         return fail(MP_ERR_MODE, "mp_policy_load: per-state policies need a finite-MDP model");
@@ -2215,6 +2419,11 @@ int mp_policy_load_ordered(mp_ctx *ctx, mp_model *model, const double *prior, co
 int mp_policy_free(mp_policy *policy)
 {
     if (!policy) return MP_OK;
+    if (policy->block) { // built on the device: one block of the ctx's cache holds every array
+        ctx_block_release(policy->ctx, policy->block, policy->block_bytes);
+        delete policy;
+        return MP_OK;
+    }
     if (policy->prior) (void)hipFree(policy->prior);
     if (policy->thr) (void)hipFree(policy->thr);
     if (policy->frec) (void)hipFree(policy->frec);

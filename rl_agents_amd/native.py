@@ -87,6 +87,7 @@ SIGNATURES = {
     "mp_uct_stoch_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp]),
     "mp_policy_load_listed": (C.c_int, [_vp, _vp, _vp, _vp, _vp, P(_vp)]),
     "mp_policy_load_ordered": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, P(_vp)]),
+    "mp_policy_load_rows": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, c_i32, P(_vp)]),
     "mp_opd_plan": (C.c_int, [_vp, _vp, c_i32, _vp, c_i32, c_f64, c_f64, _vp, c_i32, _vp, _vp, _vp, _vp, _vp, _vp,
                               c_i32]),
     "mp_opd_tree_export": (C.c_int, [_vp, c_i32, c_i32, P(c_i32), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -657,20 +658,20 @@ class Context(object):
         """Per-state prior / rollout policies [S, A] of a table model (mcts_with_prior.py:47-62) -> Policy.
         listed: bool [S, A], the actions the prior policy lists per state (restricted action sets, mcts.py:59-97):
         only those get a child at expansion; None = all.  rollout_slots: uint8 [S, A], the order in which the rollout
-        policy lists the columns of each state when it is not the column order (mp_policy_load_ordered)."""
+        policy lists the columns of each state when it is not the column order (mp_policy_load_ordered).
+        On a batch model the tables may also be [S_each, A]: rows over the LOCAL states of one MDP that serve every MDP of the
+        batch (mp_policy_load_rows)."""
         pr = np.ascontiguousarray(prior, dtype=np.float64)
-        ro = np.ascontiguousarray(rollout, dtype=np.float64)
-        if pr.shape != (model.S, model.A) or ro.shape != (model.S, model.A):
+        ro = pr if rollout is prior else np.ascontiguousarray(rollout, dtype=np.float64)
+        rows = model.S
+        if getattr(model, "n_models", 1) > 1 and pr.shape == (model.S_each, model.A):
+            rows = model.S_each
+        if pr.shape != (rows, model.A) or ro.shape != (rows, model.A):
             raise ValueError("prior / rollout must be [S, A] = [{}, {}]".format(model.S, model.A))
         h = _vp()
-        li = None if listed is None else np.ascontiguousarray(np.asarray(listed).reshape(model.S, model.A).astype(np.uint8))
-        if rollout_slots is not None:
-            sl = np.ascontiguousarray(np.asarray(rollout_slots).reshape(model.S, model.A).astype(np.uint8))
-            _check(self._lib.mp_policy_load_ordered(self._h, model._h, _ptr(pr), _ptr(ro), _ptr(li), _ptr(sl), C.byref(h)))
-        elif listed is None:
-            _check(self._lib.mp_policy_load(self._h, model._h, _ptr(pr), _ptr(ro), C.byref(h)))
-        else:
-            _check(self._lib.mp_policy_load_listed(self._h, model._h, _ptr(pr), _ptr(ro), _ptr(li), C.byref(h)))
+        li = None if listed is None else np.ascontiguousarray(np.asarray(listed).reshape(rows, model.A).astype(np.uint8))
+        sl = None if rollout_slots is None else np.ascontiguousarray(np.asarray(rollout_slots).reshape(rows, model.A).astype(np.uint8))
+        _check(self._lib.mp_policy_load_rows(self._h, model._h, _ptr(pr), _ptr(ro), _ptr(li), _ptr(sl), int(rows), C.byref(h)))
         return Policy(self, h, model)
 
     def uct_plan(self, model, root_state, episodes, horizon, gamma, temperature, prior_p, rollout_p, rng_state,

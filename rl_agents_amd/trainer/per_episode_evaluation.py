@@ -188,9 +188,8 @@ class PerEpisodeEvaluation(object):
         if getattr(self, "_policy", None) is None:
             self.model.available = self._available
             prior, rollout, listed, slots = planner.restricted_policy_tables(self.model, self._available)
-            n = self.n
-            tile = lambda x: None if x is None else np.tile(x, (n, 1))       # noqa: E731
-            self._policy = self.ctx.load_policy(self.model, tile(prior), tile(rollout), listed=tile(listed), rollout_slots=tile(slots))
+            # [S_each, A] rows over LOCAL states: the same for every episode (mp_policy_load_rows tiles them on the device)
+            self._policy = self.ctx.load_policy(self.model, prior, rollout, listed=listed, rollout_slots=slots)
         return self._policy
 
     def _prior_tables(self, live):
@@ -234,7 +233,7 @@ class PerEpisodeEvaluation(object):
         cfg = planner.config
         rng = np.ascontiguousarray(self.rng[idx])
         if self.with_prior:
-            tables = self._prior_tables(live).reshape(self.n * model.S_each, model.A)
+            tables = np.ascontiguousarray(self._prior_tables(live).reshape(self.n * model.S_each, model.A))
             listed = None if self._available is None else np.tile(self._available, (self.n, 1))
             model.available = self._available
             policy = self.ctx.load_policy(model, tables, tables, listed=listed)

@@ -6,6 +6,8 @@ tables.  Reference: value_iteration.py:29-35 (re-extraction on every act), train
 import numpy as np
 import pytest
 
+from rl_agents_amd import native
+
 pytestmark = pytest.mark.gpu
 
 E, T_STEPS = 6, 3
@@ -338,6 +340,66 @@ def test_per_root_models_device_arrays_out_of_range_roots_are_reported(ctx):
     ref = oracle.uct_plan_each(tr, rw, tm, fixed_mi, fixed_s0, 25, 8, 0.8, 10.0, p, p, rng, max_plan_len=8)
     np.testing.assert_array_equal(d["plans"].cpu().numpy(), ref["plans"])
     assert np.array_equal(d["value"].cpu().numpy(), ref["root_value"])
+    model.close()
+
+
+@pytest.mark.parametrize("case", ["plain", "listed", "ordered"])
+def test_policy_fused_on_the_device_equals_the_host_build(ctx, monkeypatch, case):
+    """mp_policy_load_rows (round 6): the per-state policy -- prior rows, sampling thresholds, listed masks, fused records --
+    built by kernels is the policy the host loops build: same plans, statistics and generator records on a single model
+    (S = 3000) and on a batch model, where [S_each, A] rows tiled on the device equal the [N * S_each, A] tables tiled by numpy."""
+    from rl_agents_amd.envs import generators
+    g = np.random.Generator(np.random.PCG64(11))
+
+    def tables(s, a):
+        prior = g.random((s, a)) + 0.05
+        listed, slots = None, None
+        if case != "plain":
+            listed = g.random((s, a)) < 0.7
+            listed[np.arange(s), g.integers(0, a, s)] = True
+            prior = np.where(listed, prior, 0.0)
+        prior /= prior.sum(axis=1, keepdims=True)
+        rollout = prior ** 2 / (prior ** 2).sum(axis=1, keepdims=True)
+        if case == "ordered":       # the rollout policy lists the columns in another order (zero-probability columns last)
+            slots = np.zeros((s, a), np.uint8)
+            for i in range(s):
+                on, off = np.flatnonzero(listed[i]), np.flatnonzero(~listed[i])
+                slots[i] = np.concatenate([g.permutation(on), off])
+        return prior, rollout, listed, slots
+
+    def plan(model, roots, pol_args, mi=None):
+        outs = []
+        for how in ("host", "device"):
+            monkeypatch.setenv("MP_POLICY_BUILD", how)
+            policy = ctx.load_policy(model, *pol_args[how])
+            rng = _rng_states(len(roots), base=3)
+            out = ctx.uct_plan(model, roots, 20, 12, 0.8, 7.0, None, None, rng, max_plan_len=12, policy=policy, model_index=mi)
+            outs.append((out, rng))
+            policy.close()
+        monkeypatch.delenv("MP_POLICY_BUILD")
+        for key in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps"):
+            np.testing.assert_array_equal(outs[0][0][key], outs[1][0][key], err_msg=key)
+        np.testing.assert_array_equal(outs[0][1], outs[1][1])
+
+    cfg = generators.highway_shaped(5, 6, 100, seed=2)                # S = 3000
+    model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
+    pr, ro, li, sl = tables(3000, 5)
+    roots = g.integers(0, 3000, 500).astype(np.int32)
+    plan(model, roots, dict(host=(pr, ro, li, sl), device=(pr, ro, li, sl)))
+    model.close()
+    n = 40
+    tr, rw, tm = _tables(n, seed0=20)
+    s_each = tr.shape[1]
+    model = ctx.load_table_batch(tr, rw, tm)
+    pr, ro, li, sl = tables(s_each, 5)
+    tile = lambda x: None if x is None else np.tile(x, (n, 1))          # noqa: E731
+    roots = g.integers(0, s_each, 300).astype(np.int32)
+    mi = g.integers(0, n, 300).astype(np.int32)
+    plan(model, roots, dict(host=(tile(pr), tile(ro), tile(li), tile(sl)), device=(pr, ro, li, sl)), mi=mi)
+    with pytest.raises(native.NativeError):
+        bad = pr.copy()
+        bad[3, 1] = -0.5
+        ctx.load_policy(model, bad, ro, li, sl)
     model.close()
 
 
