@@ -147,6 +147,88 @@ __host__ __device__ inline double libm_cos_small(double x, const double *tab = k
     return cs + cor;
 }
 
+// The same two functions in ONE basic block (round 6): every regime's value is computed and the regime selects -- operation for
+// operation the arithmetic above, so the results are the same bits.  A branch would end the block, and the CartPole rollout
+// overlaps the sin / cos of step t + 1 with the accelerations of step t by letting the instruction scheduler interleave two
+// independent dependency chains, which it only does inside a block (uct.hip).  `tab` index clamped: a speculative call past the
+// episode's end (the pole already out of range) must not read outside the table.
+template <bool FMA>
+__host__ __device__ __forceinline__ void libm_sincos_small_flat(double x, double *s_out, double *c_out, const double *tab = kSincosTab)
+{
+    typedef LibmConst K;
+    const uint32_t k = libm_high_abs(x);
+    const double ax = fabs(x);
+    // sin, |x| < 0.126: the odd Taylor polynomial
+    double sin_taylor;
+    {
+        const double xx = x * x;
+        double poly, t;
+        if (FMA) {
+            poly = libm_fma(xx, K::s5, K::s4);
+            poly = libm_fma(xx, poly, K::s3);
+            poly = libm_fma(xx, poly, K::s2);
+            poly = libm_fma(xx, poly, K::s1);
+            t = libm_fma(x, poly, -0.0);
+            t = libm_fma(t, xx, 0.0);
+        } else {
+            poly = ((((K::s5 * xx + K::s4) * xx + K::s3) * xx + K::s2) * xx) + K::s1;
+            t = (poly * x - 0.5 * 0.0) * xx + 0.0;
+        }
+        sin_taylor = x + t;
+    }
+    // the table path, shared: x = xk + r
+    const double u = K::big + ax;
+    const double r0 = ax - (u - K::big);
+    int i4 = libm_low_word(u) << 2;
+    i4 = i4 < 0 ? 0 : (i4 > MP_SINCOS_ENTRIES - 4 ? MP_SINCOS_ENTRIES - 4 : i4);
+    const double sn = tab[i4], ssn = tab[i4 + 1], cs = tab[i4 + 2], ccs = tab[i4 + 3];
+    double sin_table, cos_table;
+    {   // sin
+        const double dx = x <= 0 ? -0.0 : 0.0;
+        const double r = r0;
+        const double xx = r * r;
+        double s, c, cor;
+        if (FMA) {
+            const double p = libm_fma(xx, K::sn5, K::sn3);
+            s = r + libm_fma(r * xx, p, dx);
+            double q = libm_fma(xx, K::cs6, K::cs4);
+            q = libm_fma(xx, q, K::cs2);
+            c = libm_fma(r, dx, xx * q);
+            const double e1 = libm_fma(s, ccs, ssn);
+            const double e2 = libm_fma(-c, sn, e1);
+            cor = libm_fma(s, cs, e2);
+        } else {
+            s = r + (dx + r * xx * (K::sn3 + xx * K::sn5));
+            c = r * dx + xx * (K::cs2 + xx * (K::cs4 + xx * K::cs6));
+            cor = (ssn + s * ccs - sn * c) + cs * s;
+        }
+        sin_table = copysign(sn + cor, x);
+    }
+    {   // cos
+        const double dx = x < 0 ? -0.0 : 0.0;
+        const double r = r0 + dx;
+        const double xx = r * r;
+        double s, c, cor;
+        if (FMA) {
+            const double p = libm_fma(xx, K::sn5, K::sn3);
+            s = libm_fma(r * xx, p, r);
+            double q = libm_fma(xx, K::cs6, K::cs4);
+            q = libm_fma(xx, q, K::cs2);
+            c = xx * q;
+            const double e1 = libm_fma(-s, ssn, ccs);
+            const double e2 = libm_fma(-c, cs, e1);
+            cor = libm_fma(-s, sn, e2);
+        } else {
+            s = r + r * xx * (K::sn3 + xx * K::sn5);
+            c = xx * (K::cs2 + xx * (K::cs4 + xx * K::cs6));
+            cor = (ccs - s * ssn - cs * c) - sn * s;
+        }
+        cos_table = cs + cor;
+    }
+    *s_out = k < 0x3e500000u ? x : (ax < 0.126 ? sin_taylor : sin_table);
+    *c_out = k < 0x3e400000u ? 1.0 : cos_table;
+}
+
 enum { SINCOS_DEVICE = 0, SINCOS_LIBM_FMA = 1, SINCOS_LIBM_PLAIN = 2 };
 
 // sin and cos of x in the form `variant` names; outside the restated range (never for a pole angle) the math library's

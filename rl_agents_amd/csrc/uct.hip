@@ -197,7 +197,7 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3, E
 template <int AT, int ENV, bool SP = false, bool MK = false, int IL = 0, bool QD = false>
 // Per-state-policy kernels with |A| <= 5 are held to the registers of 4 waves per SIMD (they would take 134-140 VGPRs = 3
 // waves; TA 52 %, VALU 45 %, L1 28 % busy: latency-bound -- 2.14 -> 1.91 ms at 262 144 roots with the fourth wave).
-__global__ __launch_bounds__((ENV == ENV_TABLE_LDS || ENV == ENV_TABLE_LDSR) ? 1024 : 64,
+__global__ __launch_bounds__((ENV == ENV_TABLE_LDS || ENV == ENV_TABLE_LDSR) ? 1024 : (ENV == ENV_CARTPOLE ? 256 : 64),
                              (ENV == ENV_TABLE_LDS || ENV == ENV_TABLE_LDSR) ? 1 : (SP && AT > 0 && AT <= 5 && MP_UCT_MIN_WAVES < 4 ? 4 : MP_UCT_MIN_WAVES))
 void uct_kernel(UctArgs p)
 {
@@ -601,6 +601,69 @@ void uct_kernel(UctArgs p)
                     g.s_lo = st_lo; g.s_hi = st_hi;
                     g.jump(an, gn);
                 }
+            }
+        } else
+        if (CART && p.cp_sincos != SINCOS_DEVICE) {
+            // ---- CartPole rollout, SOFTWARE-PIPELINED (round 6).  A step's new positions depend on the OLD state only
+            // (x + tau x_dot, theta + tau theta_dot), so the sin / cos of the NEXT angle can be evaluated while this step's
+            // accelerations -- three IEEE divisions on the velocity chain -- are: two independent dependency chains in one basic
+            // block, which the scheduler interleaves (the restated sin / cos is branch-free for that: libm_sincos_small_flat).  A
+            // lone wave runs at the latency of its chain: the chain per step was sin / cos + the accelerations, it is now the
+            // longer of the two.  The next draw is computed beside them as well and kept only if the rollout continues.  The
+            // arithmetic of every value is cartpole_step's, operation for operation (same bits: tests/test_gpu_cartpole.py).
+            bool alive = !terminal && depth < H;
+            if (any64(alive)) {
+                const mp_cartpole_params &c = p.cp;
+                const double total_mass = c.masspole + c.masscart, polemass_length = c.masspole * c.length;
+                // (the form of the host libm's sin / cos is a compile-time parameter of the loop: a run-time test inside it would
+                // split the step into several basic blocks)
+                auto roll = [&](auto fma_tag) {
+                constexpr bool FMA_FORM = decltype(fma_tag)::value;
+                int h = depth;
+                double x = x4[0], x_dot = x4[1], theta = x4[2], theta_dot = x4[3];
+                double sn, cs;
+                libm_sincos_small_flat<FMA_FORM>(theta, &sn, &cs, sctab);
+                Pcg64 gr = g;
+                uint64_t u = gr.next64();
+                while (true) {
+                    int act = 0;
+#pragma unroll
+                    for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands (RAWU: the raw 64-bit draw)
+                    act = min(act, p.thr_valid);
+                    const double force = act == 1 ? c.force_mag : -c.force_mag;
+                    // chain 1: the new positions, then the sin / cos the NEXT step needs
+                    const double x_n = x + c.tau * x_dot;
+                    const double theta_n = theta + c.tau * theta_dot;
+                    double sn_n, cs_n;
+                    libm_sincos_small_flat<FMA_FORM>(theta_n, &sn_n, &cs_n, sctab);
+                    // chain 2: this step's accelerations from sin / cos of the CURRENT angle
+                    const double temp = (force + polemass_length * (theta_dot * theta_dot) * sn) / total_mass;
+                    const double thetaacc = (c.gravity * sn - cs * temp) / (c.length * (4.0 / 3.0 - c.masspole * (cs * cs) / total_mass));
+                    const double xacc = temp - polemass_length * thetaacc * cs / total_mass;
+                    // chain 3: the next draw, kept only if the rollout continues
+                    Pcg64 gs = gr;
+                    const uint64_t un = gs.next64();
+                    const double gp = gpow[h];
+                    const bool fell = x_n < -c.x_threshold || x_n > c.x_threshold || theta_n < -c.theta_threshold || theta_n > c.theta_threshold;
+                    if (alive) {
+                        x = x_n; theta = theta_n;
+                        x_dot = x_dot + c.tau * xacc;
+                        theta_dot = theta_dot + c.tau * thetaacc;
+                        sn = sn_n; cs = cs_n;
+                        total += gp * 1.0;
+                        ++st; ++steps_taken; ++h;
+#ifdef MP_PROFILE
+                        ++n_roll;
+#endif
+                        alive = !(fell || (p.max_steps > 0 && st >= p.max_steps) || h >= H);
+                        if (alive) { gr = gs; u = un; }
+                    }
+                    if (!any64(alive)) break;
+                }
+                if (!terminal && depth < H) g = gr; // the generator whose draw was consumed last
+                };
+                if (p.cp_sincos == SINCOS_LIBM_FMA) roll(std::true_type{});
+                else roll(std::false_type{});
             }
         } else
         if (!terminal && depth < H) {
@@ -1110,12 +1173,16 @@ __device__ __forceinline__ double row_children_max(double u)
 }
 constexpr int kRowRoots = 4; // roots per wavefront
 template <int AT>
-__global__ __launch_bounds__(64) void uct_row_kernel(UctArgs p)
+__global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
 {
     static_assert(AT >= 2 && AT <= 8, "|A| with a compile-time specialisation");
     constexpr int A = AT, NTH = AT - 1;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
-    const int lane = threadIdx.x, row = lane >> 4, l16 = lane & 15;
+    // (a workgroup is blockDim.x / 64 wavefronts sharing one copy of the per-call tables; tools/wave_placement.hip: the dispatcher
+    // spreads single-wave workgroups over the SIMDs just as well -- 1024 of them land one per SIMD -- so 1, 2 or 4 waves per
+    // workgroup run at the same speed)
+    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 4, l16 = tid & 15, nthreads = blockDim.x;
+    const int nrows = nthreads >> 4;         // roots of this workgroup
     const int H = p.horizon, E = p.episodes, TE = p.table_n;
     double *gpow = lds_d;                   // [H + 1]  gamma ** h
     double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
@@ -1124,18 +1191,18 @@ __global__ __launch_bounds__(64) void uct_row_kernel(UctArgs p)
     const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
     const int ntab2 = (ntab + 1) & ~1;
     const int SA = p.Sb * A, SA2 = (SA + 1) & ~1, SA8 = (SA + 7) & ~7, PH = (H + 4) & ~3;
-    double *rew = lds_d + ntab2 + row * SA2;                                                    // [4][SA2] rewards
-    UctNode *tnode = reinterpret_cast<UctNode *>(lds_d + ntab2 + kRowRoots * SA2) + row * p.cap; // [4][cap] trees
-    uint32_t *jump = reinterpret_cast<uint32_t *>(reinterpret_cast<UctNode *>(lds_d + ntab2 + kRowRoots * SA2) + kRowRoots * p.cap); // [H + 5][8]
-    int32_t *path = reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + row * PH;                 // [4][PH] path node ids
-    uint16_t *t16 = reinterpret_cast<uint16_t *>(reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + kRowRoots * PH) + row * SA8; // [4][SA8]
-    const int r = blockIdx.x * kRowRoots + row;
+    double *rew = lds_d + ntab2 + row * SA2;                                                    // [rows][SA2] rewards
+    UctNode *tnode = reinterpret_cast<UctNode *>(lds_d + ntab2 + nrows * SA2) + row * p.cap;    // [rows][cap] trees
+    uint32_t *jump = reinterpret_cast<uint32_t *>(reinterpret_cast<UctNode *>(lds_d + ntab2 + nrows * SA2) + nrows * p.cap); // [H + 5][8]
+    int32_t *path = reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + row * PH;                 // [rows][PH] path node ids
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + nrows * PH) + row * SA8; // [rows][SA8]
+    const int r = blockIdx.x * nrows + row;
     const bool live = r < p.n_roots;          // (a last wavefront's spare rows run along on the last root's data and write nothing)
     const int rr = live ? r : p.n_roots - 1;
     const int32_t s0g = p.root_state[rr];     // global state of the batch model
     const int32_t sbase = (s0g / p.Sb) * p.Sb; // first global state of this root's MDP
-    for (int i = lane; i < (H + 5) * 8; i += 64) jump[i] = p.jump[i];
-    for (int i = lane; i < ntab; i += 64) lds_d[i] = p.tab[i];
+    for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
+    for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
     {
         const Rec *src = p.rec + (long)sbase * A;
 #pragma unroll 4
@@ -1786,9 +1853,15 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // ... and FOUR such roots per wavefront, a DPP row each (uct_row_kernel): the default wherever four MDPs + trees fit the LDS of
     // a workgroup.  MP_UCT_ROW=0 keeps a wavefront per root.
     bool rowk = false;
-    const size_t lds_row = (((ntab + 1) & ~(size_t)1) + kRowRoots * ((sa_each + 1) & ~(size_t)1)) * sizeof(double) +
-                           kRowRoots * (size_t)cap * sizeof(UctNode) + (size_t)(H + 5) * 32 +
-                           kRowRoots * (size_t)((H + 4) & ~3) * sizeof(int32_t) + kRowRoots * ((sa_each + 7) & ~(size_t)7) * 2;
+    // waves per workgroup: four (one per SIMD of the CU) while their MDPs + trees fit the LDS, else two / one
+    auto lds_row_of = [&](int rows_wg) {
+        return (((ntab + 1) & ~(size_t)1) + rows_wg * ((sa_each + 1) & ~(size_t)1)) * sizeof(double) + rows_wg * (size_t)cap * sizeof(UctNode) +
+               (size_t)(H + 5) * 32 + rows_wg * (size_t)((H + 4) & ~3) * sizeof(int32_t) + rows_wg * ((sa_each + 7) & ~(size_t)7) * 2;
+    };
+    int row_waves = 4;
+    if (const char *e = getenv("MP_UCT_ROW_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) row_waves = v; }
+    while (row_waves > 1 && lds_row_of(kRowRoots * row_waves) > kLdsBytes) row_waves >>= 1;
+    const size_t lds_row = lds_row_of(kRowRoots * row_waves);
     {
         const char *re = getenv("MP_UCT_ROW");
         const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
@@ -1834,6 +1907,22 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.lanes = quad ? 16 : ((ldsm || ldsr) ? 64 : uct_lanes_per_wave());
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
+    if (cart) {
+        // CartPole (round 6): a root is one lane, and a wavefront takes as long as its SLOWEST root's episodes -- rollouts end when
+        // the pole falls, at very different lengths -- so a small batch is spread over more wavefronts of FEWER roots: 16 per
+        // wave (4096 roots: 256 waves; 0.564 -> 0.550 ms).  Not fewer: wavefronts with 2 .. 8 active lanes run 1.6 - 3x SLOWER per
+        // instruction when the whole chip is busy with them (tools/exec_rate.hip: an f64 division chain 180 -> 527 cycles at 4 active
+        // lanes x 1024 waves, unchanged at 16 or 64 lanes or on a single wave; the kernel itself 0.56 -> 1.16 ms at 4 roots per
+        // wave although each wave then executes a third fewer instructions: profiles/r06_cartpole.md).
+        const long cus_c = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        if (!getenv("MP_UCT_LANES")) {
+            long per = ((long)n_roots + 4 * cus_c - 1) / (4 * cus_c);
+            a.lanes = 16;
+            while (a.lanes < per && a.lanes < 64) a.lanes <<= 1;
+        }
+        a.waves = 4;
+        if (const char *e = getenv("MP_UCT_CART_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) a.waves = v; }
+    }
     if (ldsr) {
         // one workgroup per CU shares the tables: as many waves per workgroup as it takes to put the batch on the chip's
         // CUs (a power of two <= 16, so that chunk boundaries -- multiples of 1024 roots -- are workgroup boundaries)
@@ -2001,7 +2090,8 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (c.root_child_value) c.root_child_value += (size_t)r0 * A;
         if (c.env_steps) c.env_steps += r0;
         if (cart) {
-            const dim3 grid((unsigned)((c.n_roots + c.lanes - 1) / c.lanes)), block(64);
+            const int per_block = c.lanes * c.waves;
+            const dim3 grid((unsigned)((c.n_roots + per_block - 1) / per_block)), block(64u * c.waves);
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
         } else if (rowk) {
 #define MP_ROWK(k)                                                                                                                 \
@@ -2009,7 +2099,8 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (lds > 64 * 1024)                                                                                                       \
             MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_row_kernel<k>),                                         \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
-        hipLaunchKernelGGL((uct_row_kernel<k>), dim3((unsigned)((c.n_roots + kRowRoots - 1) / kRowRoots)), dim3(64), lds, s, c);   \
+        hipLaunchKernelGGL((uct_row_kernel<k>), dim3((unsigned)((c.n_roots + kRowRoots * row_waves - 1) / (kRowRoots * row_waves))),  \
+                           dim3(64u * row_waves), lds, s, c);                                                                      \
         break;
             switch (A) { MP_ROWK(2) MP_ROWK(3) MP_ROWK(4) MP_ROWK(5) MP_ROWK(6) MP_ROWK(7) MP_ROWK(8) default: break; }
 #undef MP_ROWK
