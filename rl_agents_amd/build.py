@@ -25,6 +25,16 @@ FLAGS = (["-DMP_PROFILE"] if os.environ.get("MP_PROFILE") else []) + \
          "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-Wno-pass-failed"]
 
 
+# Per-file code-generation flags.  The UCT kernels are long straight-line blocks run by few wavefronts per SIMD (a lone wave issues
+# in order: what is not interleaved in the instruction stream is not overlapped at all), so uct.hip is scheduled for instruction-
+# level parallelism instead of occupancy (LLVM's AMDGPU `max-ilp` strategy).  A/B on one box (tools/ab_libs.sh, two rounds each):
+# headline kernel 0.783 -> 0.767 ms, 4096 roots 0.275 -> 0.268, single root 0.0575 -> 0.056; uct_stoch no consistent change (its
+# time is bimodal, 2.38 / 2.65 ms, under either strategy); opd 0.756 -> 0.781 and saopd 8.8 -> 9.25 SLOWER: those keep the default.
+FILE_FLAGS = {"uct.hip": ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]}
+if os.environ.get("MP_NO_FILE_FLAGS"):
+    FILE_FLAGS = {}
+
+
 def hipcc():
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -39,7 +49,7 @@ def source_digest():
     """sha256 over every source, header and flag that goes into the library (mtimes do not survive the
     snapshot to the GPU box, content does)."""
     import hashlib
-    h = hashlib.sha256(" ".join(FLAGS).encode())
+    h = hashlib.sha256((" ".join(FLAGS) + repr(sorted(FILE_FLAGS.items()))).encode())
     for d in [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(INCLUDE, "mi355plan.h")]:
         with open(d, "rb") as f:
             h.update(f.read())
@@ -76,7 +86,7 @@ def build(force=False, verbose=False):
     procs = []
     for src in SOURCES:
         obj = os.path.join(LIB_DIR, src.replace(".hip", ".o"))
-        cmd = [cc] + FLAGS + ["-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [cc] + FLAGS + FILE_FLAGS.get(src, []) + ["-I", INCLUDE, "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

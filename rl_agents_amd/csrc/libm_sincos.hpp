@@ -147,6 +147,23 @@ __host__ __device__ inline double libm_cos_small(double x, const double *tab = k
     return cs + cor;
 }
 
+// c ? a : b as two v_cndmask_b32 on the lane mask of c: an opaque operation, so both operands are computed in the same basic
+// block (a plain ?: lets the compiler branch around the costlier operand: two more blocks, and the instruction scheduler
+// interleaves dependency chains only inside a block)
+__host__ __device__ __forceinline__ double libm_select(bool c, double a, double b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(c);
+    const int a_lo = __double2loint(a), a_hi = __double2hiint(a), b_lo = __double2loint(b), b_hi = __double2hiint(b);
+    int lo, hi;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(lo) : "v"(b_lo), "v"(a_lo), "s"(m));
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(hi) : "v"(b_hi), "v"(a_hi), "s"(m));
+    return __hiloint2double(hi, lo);
+#else
+    return c ? a : b;
+#endif
+}
+
 // The same two functions in ONE basic block (round 6): every regime's value is computed and the regime selects -- operation for
 // operation the arithmetic above, so the results are the same bits.  A branch would end the block, and the CartPole rollout
 // overlaps the sin / cos of step t + 1 with the accelerations of step t by letting the instruction scheduler interleave two
@@ -225,8 +242,9 @@ __host__ __device__ __forceinline__ void libm_sincos_small_flat(double x, double
         }
         cos_table = cs + cor;
     }
-    *s_out = k < 0x3e500000u ? x : (ax < 0.126 ? sin_taylor : sin_table);
-    *c_out = k < 0x3e400000u ? 1.0 : cos_table;
+    // (selects the compiler cannot turn back into branches around the regimes' arithmetic -- it did, with the plain ternaries)
+    *s_out = libm_select(k < 0x3e500000u, x, libm_select(ax < 0.126, sin_taylor, sin_table));
+    *c_out = libm_select(k < 0x3e400000u, 1.0, cos_table);
 }
 
 enum { SINCOS_DEVICE = 0, SINCOS_LIBM_FMA = 1, SINCOS_LIBM_PLAIN = 2 };

@@ -104,6 +104,7 @@ struct UctArgs {
     int tree_il; // tree layout (TreeRef): 0 root-major, 1 interleaved, 2 group-interleaved
     int done_on_next, max_steps, max_plan_len;
     int lanes; // roots per wavefront (64 = dense; fewer spreads a small batch over more SIMDs)
+    int rep_shift; // CartPole: a root is replicated over 2^rep_shift lanes (see the launch code: wavefronts of few ACTIVE lanes run slow)
     int waves; // wavefronts per workgroup
     int Sb;    // batch models: states per MDP (root r plans on MDP root_state[r] / Sb); = S for any other model
     const Rec *rec;
@@ -141,6 +142,14 @@ struct UctArgs {
     int64_t *root_child_count, *env_steps;
 };
 
+
+// lane Q of every quad, to the quad's four lanes (DPP quad_perm Q,Q,Q,Q)
+template <int Q>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, Q * 0x55, 0xf, 0xf, true);
+}
+
 // rl_agents_amd/envs/cartpole.py step(), operation for operation in IEEE double (no contraction).
 // sin / cos of the pole angle: the HOST libm's algorithm restated (libm_sincos.hpp; `sincos_mode` = the form that
 // reproduces this host's sin / cos, found at model-load time) -- bit-exact plans by construction since round 5; mode 0 = the
@@ -170,6 +179,10 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3, E
 
 // AT > 0: |A| known at compile time (children scored from registers in one pass);
 // AT == 0: any |A| (three passes over the children).  ENV: where an env step comes from.
+// CartPole's replicated-root rollout: test for "every root of the wave is done" after every step (1) or every round of four (4)
+#ifndef MP_CART_CHECK_EVERY
+#define MP_CART_CHECK_EVERY 4
+#endif
 #ifndef MP_UCT_MIN_WAVES
 #define MP_UCT_MIN_WAVES 1
 #endif
@@ -246,6 +259,10 @@ void uct_kernel(UctArgs p)
     double *sctab_lds = reinterpret_cast<double *>(path_all + (((H + 1) * nthreads + 1) & ~1));
     if (CART)
         for (int i = tid; i < MP_SINCOS_ENTRIES; i += nthreads) sctab_lds[i] = kSincosTab[i];
+    // CartPole with replicated roots: the generator's jump table behind the sin / cos table
+    uint32_t *cjump = reinterpret_cast<uint32_t *>(sctab_lds + MP_SINCOS_ENTRIES); // [H + 5][8]
+    if (CART && p.rep_shift >= 2)
+        for (int i = tid; i < (H + 5) * 8; i += nthreads) cjump[i] = p.jump[i];
     const double *sctab = CART ? sctab_lds : nullptr;
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
     if (LDSR) {
@@ -266,7 +283,7 @@ void uct_kernel(UctArgs p)
     }
     __syncthreads();
     int32_t *path = path_all + wave * 64; // slot d of this lane: path[d * nthreads + lane]
-    const int slot = QD ? lane >> 2 : lane;        // which root of the wave (QD: four lanes per root, the first one owns it)
+    const int slot = QD ? lane >> 2 : (CART ? lane >> p.rep_shift : lane);   // which root of the wave (QD: four lanes per root, the first one owns it)
     const bool owner = QD ? (lane & 3) == 0 : true;
     const int r = (blockIdx.x * p.waves + wave) * p.lanes + slot;
     if (slot >= p.lanes || r >= p.n_roots) return;   // (QD: whole quads leave together)
@@ -276,7 +293,7 @@ void uct_kernel(UctArgs p)
     Pcg64 g;
     g.load(p.rng + (long)r * 6);
     uint64_t g4_lo = 0, g4_hi = 0;          // QD: inc * G_4, the additive term of a four-step jump of this root's generator
-    if (QD) g.inc_g4(g4_lo, g4_hi);
+    if (QD || (CART && p.rep_shift >= 2)) g.inc_g4(g4_lo, g4_hi);
     const int32_t s0 = CART ? 0 : p.root_state[r];
     const int32_t st0 = p.root_steps ? p.root_steps[r] : 0;
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
@@ -603,6 +620,103 @@ void uct_kernel(UctArgs p)
                 }
             }
         } else
+        if (CART && p.cp_sincos != SINCOS_DEVICE && p.rep_shift >= 2) {
+            // ---- CartPole rollout, REPLICATED ROOTS (round 6).  The launch code gives a root 2^rep_shift >= 4 lanes that all compute
+            // the same plan (why: see there).  What the replicas can do differently is numpy's generator: the action sequence of a
+            // rollout does not depend on the states it visits (uniform policy), so lane j of a quad holds the generator j + 1 steps
+            // ahead and jumps by four per round (as the four-lanes-per-root table kernel, QD above): a step takes its force from a
+            // quad broadcast, and the 128-bit generator step is executed once per FOUR env steps.  The rollout is software-pipelined
+            // as the one-lane form below (sin / cos of the next angle beside this step's accelerations).  The walk consumes n draws; the
+            // generator then jumps by exactly n.  (Tried and dropped: the three divisions by the constant total mass as Markstein's
+            // five multiply-adds on RN(1 / total_mass) -- exact, 8 instructions shorter each, and 7 % SLOWER: the hardware sequence's
+            // reciprocal refinement runs beside the numerator's chain, the short form is one serial chain; profiles/r06_cartpole.md.)  Every value is cartpole_step's, operation for operation (same bits: tests/test_gpu_cartpole.py).
+            bool alive = !terminal && depth < H;
+            if (any64(alive)) {
+                const mp_cartpole_params &c = p.cp;
+                const double total_mass = c.masspole + c.masscart, polemass_length = c.masspole * c.length;
+                auto roll = [&](auto fma_tag) {
+                constexpr bool FMA_FORM = decltype(fma_tag)::value;
+                const bool want = alive;
+                const uint64_t st_lo = g.s_lo, st_hi = g.s_hi;      // (the state the final jump by n starts from)
+                Pcg64 q = g;
+                {
+                    const int j1 = (lane & 3) + 1;
+                    uint32_t an[4], gn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { an[i] = cjump[j1 * 8 + i]; gn[i] = cjump[j1 * 8 + 4 + i]; }
+                    q.jump(an, gn);
+                }
+                // the high word of the force this lane's draw selects (+- force_mag differ in the sign bit only)
+                const int f_lo = __double2loint(c.force_mag);
+                const uint32_t f_pos = (uint32_t)__double2hiint(c.force_mag), f_neg = (uint32_t)__double2hiint(-c.force_mag);
+                auto force_hi = [&](const Pcg64 &gen) -> uint32_t {
+                    const uint64_t u = gen.output();
+                    int act = 0;
+#pragma unroll
+                    for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0; // scalar operands (RAWU: the raw 64-bit draw)
+                    act = min(act, p.thr_valid);
+                    return act == 1 ? f_pos : f_neg;
+                };
+                uint32_t f_cur = force_hi(q);
+                q.advance4(g4_lo, g4_hi);
+                int h = depth;
+                // the step after which the rollout stops at the latest: the horizon, or the environment's step limit
+                const int hmax = p.max_steps > 0 ? min(H, depth + p.max_steps - st) : H;
+                double x = x4[0], x_dot = x4[1], theta = x4[2], theta_dot = x4[3];
+                double sn, cs;
+                libm_sincos_small_flat<FMA_FORM>(theta, &sn, &cs, sctab);
+                // BRANCH-FREE steps: a lane whose rollout ended keeps stepping on values nobody reads (only its return, its step
+                // count and `alive` are frozen), so a round of four steps is one basic block for the scheduler to interleave.
+                double ret = total;
+                while (true) {
+                    const uint32_t f4[4] = {quad_bcast<0>(f_cur), quad_bcast<1>(f_cur), quad_bcast<2>(f_cur), quad_bcast<3>(f_cur)};
+                    const uint32_t f_next = force_hi(q);
+                    q.advance4(g4_lo, g4_hi);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const double force = __hiloint2double((int)f4[i], f_lo);
+                        // chain 1: the new positions, then the sin / cos the NEXT step needs
+                        const double x_n = x + c.tau * x_dot;
+                        const double theta_n = theta + c.tau * theta_dot;
+                        double sn_n, cs_n;
+                        libm_sincos_small_flat<FMA_FORM>(theta_n, &sn_n, &cs_n, sctab);
+                        // chain 2: this step's accelerations from sin / cos of the CURRENT angle
+                        const double a1 = force + polemass_length * (theta_dot * theta_dot) * sn;
+                        const double temp = a1 / total_mass;
+                        const double thetaacc = (c.gravity * sn - cs * temp) / (c.length * (4.0 / 3.0 - c.masspole * (cs * cs) / total_mass));
+                        const double xacc = temp - polemass_length * thetaacc * cs / total_mass;
+                        const double gp = gpow[h];
+                        const bool fell = x_n < -c.x_threshold || x_n > c.x_threshold || theta_n < -c.theta_threshold || theta_n > c.theta_threshold;
+                        x = x_n; theta = theta_n;
+                        x_dot = x_dot + c.tau * xacc;
+                        theta_dot = theta_dot + c.tau * thetaacc;
+                        sn = sn_n; cs = cs_n;
+                        ret = libm_select(alive, ret + gp * 1.0, ret);
+                        h += alive ? 1 : 0;
+#ifdef MP_PROFILE
+                        n_roll += alive ? 1 : 0;
+#endif
+                        alive = alive && !(fell || h >= hmax);
+                        if (MP_CART_CHECK_EVERY == 1 && !any64(alive)) break;
+                    }
+                    f_cur = f_next;
+                    if (!any64(alive)) break;
+                }
+                total = ret;
+                const int n = h - depth;                   // env steps = draws of this rollout
+                st += n; steps_taken += n;
+                if (want) { // the generator after the n draws the walk consumed: A^n state + inc G_n
+                    uint32_t an[4], gn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { an[i] = cjump[n * 8 + i]; gn[i] = cjump[n * 8 + 4 + i]; }
+                    g.s_lo = st_lo; g.s_hi = st_hi;
+                    g.jump(an, gn);
+                }
+                };
+                if (p.cp_sincos == SINCOS_LIBM_FMA) roll(std::true_type{});
+                else roll(std::false_type{});
+            }
+        } else
         if (CART && p.cp_sincos != SINCOS_DEVICE) {
             // ---- CartPole rollout, SOFTWARE-PIPELINED (round 6).  A step's new positions depend on the OLD state only
             // (x + tau x_dot, theta + tau theta_dot), so the sin / cos of the NEXT angle can be evaluated while this step's
@@ -845,6 +959,7 @@ void uct_kernel(UctArgs p)
                (long long)(clock64() - t_all0), t_sel, t_expd, t_roll, t_bak, n_sel, n_roll);
 #endif
     if (!owner) return;                      // (QD: the helper lanes held no tree)
+    if (CART && (lane & ((1 << p.rep_shift) - 1)) != 0) return;   // (replicas of a CartPole root: the first lane reports)
     if (RC) {
         UctNode w;
         w.value = tv0; w.count = tc0; w.first_child = tf0;
@@ -1755,7 +1870,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
 
     UctArgs a;
     a.n_roots = n_roots; a.S = model->S; a.A = A; a.episodes = episodes; a.horizon = horizon; a.cap = (int)cap;
-    a.table_n = TE;
+    a.table_n = TE; a.rep_shift = 0;
     a.done_on_next = model->done_on_next; a.max_steps = model->max_steps; a.max_plan_len = max_plan_len;
     a.rec = model->rec; a.t16 = model->t16; a.tab = d_tab;
     a.thr_valid = 0;
@@ -1879,7 +1994,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     if (lone) { quad = false; ldsr = false; ldsm = false; }
     a.Sb = Sb;
     a.jump = nullptr;
-    if (quad || lone) {
+    if (quad || lone || cart) {
         // limbs of A^n and G_n = 1 + A + ... + A^(n-1) (mod 2^128), n = 0..H: the generator after n draws is A^n state + inc G_n
         if (ctx->jump_entries < H + 5) {
             typedef unsigned __int128 u128;
@@ -1915,12 +2030,20 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         // lanes x 1024 waves, unchanged at 16 or 64 lanes or on a single wave; the kernel itself 0.56 -> 1.16 ms at 4 roots per
         // wave although each wave then executes a third fewer instructions: profiles/r06_cartpole.md).
         const long cus_c = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        // Later in round 6: the slow mode is a matter of how many lanes are ACTIVE, not of how many roots a wave serves (exec_rate.hip
+        // with strides: <= 8 active lanes anywhere in the wave are slow about every other run, >= 16 never).  So a root is REPLICATED
+        // over 2^rep_shift lanes that all compute its plan -- 4 roots x 16 lanes at 4096 roots: 1024 wavefronts, one per SIMD, 669
+        // rollout trips per wave instead of 891 -- and the replicas share the generator work (the rollout block of uct_kernel).
         if (!getenv("MP_UCT_LANES")) {
             long per = ((long)n_roots + 4 * cus_c - 1) / (4 * cus_c);
-            a.lanes = 16;
+            a.lanes = 1;
             while (a.lanes < per && a.lanes < 64) a.lanes <<= 1;
         }
         a.waves = 4;
+        a.rep_shift = 0;
+        while ((a.lanes << (a.rep_shift + 1)) <= 64) ++a.rep_shift;
+        if (const char *e = getenv("MP_UCT_CART_REP")) { a.rep_shift = atoi(e); while (a.rep_shift > 0 && (a.lanes << a.rep_shift) > 64) --a.rep_shift; }
+        if (a.rep_shift < 2) a.rep_shift = 0;      // (the replicated form works on quads)
         if (const char *e = getenv("MP_UCT_CART_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) a.waves = v; }
     }
     if (ldsr) {
@@ -1934,7 +2057,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
     size_t lds = rowk ? lds_row : each ? lds_each : lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
-    if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double); // the sin / cos table of libm_sincos.hpp behind the path stack
+    if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double) + (size_t)(H + 5) * 32; // the sin / cos table of libm_sincos.hpp behind the path stack, then the jump table
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
         ldsm = false;

@@ -63,6 +63,58 @@ def test_cartpole_batch_c3_vs_oracle(ctx):
     np.testing.assert_array_equal(rng, ref["rng_after"])
 
 
+@pytest.mark.parametrize("n", [1, 5, 300, 1100, 4096 + 37, 9000, 20000, 70000])
+def test_cartpole_every_replication_factor_vs_oracle(ctx, n):
+    """Round 6: a CartPole root is replicated over 64 / (roots per wave) lanes (the launch code picks roots per wave by batch
+    size: 1 root x 64 lanes ... 16 x 4, then the one-lane form from 32 roots per wave on); the replicas share the generator's
+    work by jump-ahead.  Every batch size class against the oracle, with skewed policies (a draw decides more than a coin)
+    and step limits inside some horizons."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import CartPoleEnv
+    params = CartPoleEnv().cartpole_params()
+    model = ctx.load_cartpole(params)
+    x0 = np.random.Generator(np.random.PCG64(n)).uniform(-0.08, 0.08, size=(n, 4))
+    steps0 = ((np.arange(n) * 7) % 200).astype(np.int32)
+    rng = native.seed_sequence_states((), 1000 * n, n)            # root i <- Generator(PCG64(SeedSequence(1000 n + i)))
+    rng_ref = rng.copy()
+    prior, roll = np.array([0.5, 0.5]), np.array([0.35, 0.65])
+    out = ctx.uct_plan(model, x0, 12, 40, 0.9, 5.0, prior, roll, rng, root_steps=steps0, max_plan_len=8)
+    assert ctx.last_kernel_variant() == "uct_cartpole"
+    ref = oracle.uct_plan_batch(None, None, None, x0, 12, 40, 0.9, 5.0, prior, roll, rng_ref, steps0=steps0, max_plan_len=8,
+                                n_threads=8, cartpole=params)
+    np.testing.assert_array_equal(out["plans"], ref["plans"])
+    np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(out["root_child_count"], ref["root_child_count"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+
+
+@pytest.mark.parametrize("lanes,rep", [(16, 0), (16, 2), (8, 3), (4, 2), (2, 5), (1, 6), (64, 0)])
+def test_cartpole_forced_layouts_agree(ctx, monkeypatch, lanes, rep):
+    """MP_UCT_LANES x MP_UCT_CART_REP (roots per wave x lanes per root, tools/cart_sweep.sh's knobs): the same plans, statistics
+    and generator records as the default layout."""
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import CartPoleEnv
+    model = ctx.load_cartpole(CartPoleEnv().cartpole_params())
+    n = 777
+    x0 = np.random.Generator(np.random.PCG64(5)).uniform(-0.05, 0.05, size=(n, 4))
+    rng0 = np.stack([native.rng_state_from_generator(np.random.Generator(np.random.PCG64(np.random.SeedSequence(i)))) for i in range(n)])
+    p = np.ones(2) / 2
+
+    def plan():
+        rng = rng0.copy()
+        out = ctx.uct_plan(model, x0, 20, 50, 0.8, 10.0, p, p, rng, max_plan_len=6)
+        return out, rng
+    base, rng_base = plan()
+    monkeypatch.setenv("MP_UCT_LANES", str(lanes))
+    monkeypatch.setenv("MP_UCT_CART_REP", str(rep))
+    got, rng_got = plan()
+    for k in ("plans", "plan_len", "env_steps", "root_value", "root_child_count", "root_child_value"):
+        np.testing.assert_array_equal(got[k], base[k], err_msg=k)
+    np.testing.assert_array_equal(rng_got, rng_base)
+
+
 def test_device_sincos_equals_host_libm_on_ten_million_angles(ctx):
     """The device's restated sin / cos (the form mp_libm_sincos_variant picked for this host) against the host libm's --
     math.sin / math.cos, what gymnasium's CartPole calls -- on 10^7 angles: the pole's range, the whole restated range

@@ -9,7 +9,9 @@ cd /root/repo/rl_agents_amd/csrc
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wno-unused-result -Wno-pass-failed -I /root/repo/include $@"
 pids=()
 for f in api vi uct uct_stoch opd ropd saopd; do
-  /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $OUT/$f.o &
+  # (the per-file flags of rl_agents_amd/build.py FILE_FLAGS; NO_FILE_FLAGS=1 leaves them out)
+  FF=""; if [ -z "$NO_FILE_FLAGS" ] && [ $f = uct ]; then FF="-mllvm -amdgpu-sched-strategy=max-ilp"; fi
+  /opt/rocm/bin/hipcc $FLAGS $FF -c $f.hip -o $OUT/$f.o &
   pids+=($!)
 done
 for p in "${pids[@]}"; do wait $p; done

@@ -18,8 +18,13 @@ rng = np.random.Generator(np.random.PCG64(1)).integers(1, 2 ** 62, size=(n, 6)).
 rng[:, 3] |= 1
 rng[:, 4:] = 0
 p = np.ones(2) / 2
-for rep in range(3):
+best = 1e9
+for rep in range(int(os.environ.get('REPS', 40))):
     out = ctx.uct_plan(model, x0, 20, 50, 0.8, 10.0, p, p, rng, max_plan_len=8)
     ms, _ = ctx.last_kernel_ms()
+    best = min(best, ms)
+    if rep % 13:
+        continue
     print("cartpole uct n={}: kernel {:.3f} ms, env_steps {} -> {:.3e} steps/s".format(n, ms, int(out["env_steps"].sum()),
                                                                                    out["env_steps"].sum() / (ms * 1e-3)), flush=True)
+print('best of reps: {:.4f} ms'.format(best))
