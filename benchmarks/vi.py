@@ -355,7 +355,12 @@ def bench_vi_batch(args, rank, world, local):
     # and writes its Q; the streaming form re-reads 10 B per (s, a) and writes 8 B per state every sweep, after one pass that
     # re-lays the tables out lane-major (12 S A + S read, 10 S A written)
     sa = float(s_ * a_)
-    if "reg" in variant:
+    kc = int(variant[len("vi_batch_cluster"):]) if variant.startswith("vi_batch_cluster") else 0
+    if kc:
+        # the cluster form: tables once per solve (rows in registers), Q out, and per sweep each of the K workgroups of an MDP
+        # publishes its slice of V (8 S in all) and reads the other K - 1 slices (8 S (K - 1) / K each): 8 S K bytes past the CU
+        alg = float(n) * (12.0 * sa + s_ + 8.0 * sa + 4.0) + float(sweeps.sum()) * 8.0 * s_ * kc
+    elif "reg" in variant:
         alg = float(n) * (12.0 * sa + s_ + 8.0 * sa + 4.0)
     elif "stream" in variant:
         alg = float(sweeps.sum()) * (10.0 * sa + 8.0 * s_) + float(n) * ((12.0 * sa + s_) + 10.0 * sa + 8.0 * sa + 4.0)
@@ -378,14 +383,15 @@ def bench_vi_batch(args, rank, world, local):
                       note="bytes = what the launch moves beyond the CU: the register form (S <= 4096) keeps an MDP's rows in "
                            "registers and V in LDS and touches memory once per SOLVE (tables in, Q out); the streaming form "
                            "(S = 10 000) re-reads 10 B per (s, a) and writes 8 B per state per sweep (L2 / infinity cache "
-                           "resident) after one lane-major re-layout pass.  SURVEY 8(d)'s per-sweep formula (12 S A + 17 S) x the "
+                           "resident) after one lane-major re-layout pass; the cluster form (few large MDPs: K workgroups each) is the register "
+                           "form + 8 S K bytes of V exchange per sweep.  SURVEY 8(d)'s per-sweep formula (12 S A + 17 S) x the "
                            "sweeps really run is beside it (`survey_formula_*`): for the register form that rate exceeds the HBM peak "
                            "because those bytes never leave the CU -- it is not HBM traffic"),
     )
     res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
-    block = 1024 if "wg" in variant else int(variant.split(",")[-1].rstrip(">"))
-    kernel_name = "vi_det_batch_reg" if "reg" in variant else ("vi_det_batch_wgr" if "stream" in variant else "vi_det_batch_wg<")
-    add_traffic(res["roofline"], "vi_batch", kernel_name, n * block, pattern="stream")
+    block = 1024 if ("wg" in variant or kc) else int(variant.split(",")[-1].rstrip(">"))
+    kernel_name = "vi_det_batch_cluster" if kc else "vi_det_batch_reg" if "reg" in variant else ("vi_det_batch_wgr" if "stream" in variant else "vi_det_batch_wg<")
+    add_traffic(res["roofline"], "vi_batch", kernel_name, ((n + 7) // 8 * 8 * kc if kc else n) * block, pattern="stream")
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         idx = sample_rows(n, 512 if s_ <= 120 else 8)

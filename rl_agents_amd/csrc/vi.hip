@@ -1358,6 +1358,7 @@ struct ViBatchArgs {
     double *Q_out;        // [N*Sb*A]
     int32_t *sweeps_out;  // [N]
     double *Vglobal;      // VGLOBAL form: [N][3][Sb]
+    int only_failed;      // VGLOBAL form as the cluster form's fallback: solve only the MDPs whose sweeps_out says -1
 };
 
 // REGISTER form (Sb <= OWN * BLOCK): a thread keeps the rows of its OWN states -- transitions, rewards and the last Q row,
@@ -1433,6 +1434,113 @@ __global__ __launch_bounds__(BLOCK) void vi_det_batch_reg(ViBatchArgs p)
                 for (int a = 0; a < AT; ++a) p.Q_out[(base + tid + i * BLOCK) * AT + a] = qp[i][a];
 }
 
+// CLUSTER form (round 6): K WORKGROUPS PER MDP, for batches of FEW LARGE MDPs that would leave most of the chip idle with one
+// workgroup each (64 x S = 10 000: 64 of 256 CUs).  It is the register form -- a thread keeps the rows and the last Q row of its
+// OWN states (those of its workgroup's slice of the MDP) for the whole solve, V double-buffered in LDS, all of it in every
+// workgroup -- plus an exchange per sweep: a workgroup publishes its slice of V_{k+1} with write-through (sc1) stores, the
+// cluster meets at a counter (one word per MDP and sweep: arrivals in the low half, "something moved" votes in the high half
+// -- the barrier IS np.allclose's verdict, so every workgroup takes the same exit), and each workgroup fills the rest of its LDS
+// copy with L1-bypassing (sc1) loads (cdna_hip_programming.md Guideline 16: sc1 stores -> s_waitcnt vmcnt(0) -> barrier ->
+// relaxed agent fetch_add; relaxed polls; sc1 reads).  A cluster's workgroups are block ids 8 apart: the dispatcher places block
+// b on XCD b % 8, so they share an L2 (a speed choice only; any placement is correct).  They must be co-resident: the host
+// launches at most one workgroup per CU, and a spin limit turns a cluster that never met into sweeps_out = -1, which the
+// follow-up launch (the global-memory workgroup form with only_failed) solves again.
+template <int AT, int OWN>
+__global__ __launch_bounds__(1024) void vi_det_batch_cluster(ViBatchArgs p, int K, double *__restrict__ Vx, unsigned *__restrict__ words_all,
+                                                             unsigned need, unsigned spin_limit)
+{
+    extern __shared__ __attribute__((aligned(16))) double lds_v[];
+    constexpr int NT = 1024;
+    const int bid = blockIdx.x, xcd = bid & 7, slot = bid >> 3;
+    const int b = (slot / K) * 8 + xcd, part = slot % K, tid = threadIdx.x, S = p.Sb;
+    if (b >= p.N) return;
+    const int Sp = (S + K - 1) / K, s_lo = part * Sp, s_hi = min(S, s_lo + Sp), n_mine = max(s_hi - s_lo, 0);
+    const long base = (long)b * S;
+    double *V0 = lds_v, *V1 = lds_v + S;
+    unsigned *bc = reinterpret_cast<unsigned *>(lds_v + 2 * (long)S);   // [4]: the verdict, double-buffered
+    double *Vxb = Vx + (long)b * 2 * S;                                 // [2][S]: V_k published in slot k & 1
+    gu32_t *words = (gu32_t *)(words_all + (long)b * p.iterations);
+    int32_t t[OWN][AT];
+    double r[OWN][AT], qp[OWN][AT];
+    bool term_s[OWN], own[OWN];
+#pragma unroll
+    for (int i = 0; i < OWN; ++i) {
+        const int s = s_lo + tid + i * NT;
+        own[i] = s < s_hi;
+        const long sa0 = (base + (own[i] ? s : 0)) * AT;
+        term_s[i] = (p.term && own[i]) ? p.term[base + s] != 0 : false;
+#pragma unroll
+        for (int a = 0; a < AT; ++a) {
+            t[i][a] = p.T[sa0 + a] - (int32_t)base;
+            r[i][a] = p.R[sa0 + a];
+            qp[i][a] = 0.0;                                  // Q_0 = 0 (value_iteration.py:43)
+        }
+    }
+    for (int i = tid; i < S; i += NT) V0[i] = 0.0;
+    __syncthreads();
+    int sweeps = p.iterations;
+    for (int k = 0; k < p.iterations; ++k) {
+        const double *Vcur = (k & 1) ? V1 : V0;
+        double *Vnext = (k & 1) ? V0 : V1;
+        double *Vpub = Vxb + (long)((k + 1) & 1) * S;
+        bool nc = false;
+        double qn[OWN][AT];
+#pragma unroll
+        for (int i = 0; i < OWN; ++i) {
+            double vc[AT];
+#pragma unroll
+            for (int a = 0; a < AT; ++a) vc[a] = Vcur[t[i][a]];
+            double vmax = 0.0;
+#pragma unroll
+            for (int a = 0; a < AT; ++a) {
+                qn[i][a] = r[i][a] + p.gamma * (term_s[i] ? 0.0 : vc[a]);
+                nc |= own[i] && !isclose_np(qp[i][a], qn[i][a], p.rtol, p.atol);
+                if (a == 0 || qn[i][a] > vmax) vmax = qn[i][a];
+            }
+            if (own[i]) {
+                const int s = s_lo + tid + i * NT;
+                Vnext[s] = vmax;
+                __hip_atomic_store((gu64_t *)(Vpub + s), (unsigned long long)__double_as_longlong(vmax), MP_RLX_AGENT); // (8 bytes: an sc1 store)
+            }
+        }
+        // ---- the cluster's barrier and the sweep's verdict in one word
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int agg = __syncthreads_or(nc ? 1 : 0);
+        unsigned *bck = bc + 2 * (k & 1);
+        if (tid == 0) {
+            __hip_atomic_fetch_add(words + k, 1u + (agg ? 0x10000u : 0u), MP_RLX_AGENT);
+            unsigned spins = 0, w, bad = 0;
+            while (((w = __hip_atomic_load(words + k, MP_RLX_AGENT)) & 0xffffu) < need) {   // (need = K)
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > spin_limit) { bad = 1; break; }
+            }
+            bck[0] = bad; bck[1] = w >> 16;
+        }
+        __syncthreads();
+        if (bck[0]) { sweeps = -1; break; }                  // (the cluster never met: not co-resident)
+        if (bck[1] == 0) { sweeps = k + 1; break; }          // allclose(Q_k, Q_{k+1}) over the whole MDP: return Q_k = qp
+#pragma unroll
+        for (int i = 0; i < OWN; ++i)
+#pragma unroll
+            for (int a = 0; a < AT; ++a) qp[i][a] = qn[i][a];
+        // ---- the other workgroups' slices of V_{k+1}, past the L1
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)Vpub, 0, S * 8, 0x00020000);
+        for (int i = tid; i < S - n_mine; i += NT) {
+            const int s = i < s_lo ? i : i + n_mine;
+            const uint2 w = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, s * 8, 0, 16));
+            Vnext[s] = __hiloint2double((int)w.y, (int)w.x);
+        }
+        __syncthreads();
+    }
+    if (tid == 0 && part == 0 && p.sweeps_out) p.sweeps_out[b] = sweeps;
+    if (p.Q_out && sweeps >= 0)
+#pragma unroll
+        for (int i = 0; i < OWN; ++i)
+            if (own[i])
+#pragma unroll
+                for (int a = 0; a < AT; ++a) p.Q_out[(base + s_lo + tid + i * NT) * AT + a] = qp[i][a];
+}
+
 // WORKGROUP form (any |A|, Sb beyond the register form): 1024 threads walk the states of their MDP; the tables stream from
 // global memory (L2 / MALL resident across sweeps: 12 B per (s, a)); Q_k for the allclose test is recomputed from V_{k-1}, as
 // the chained single-MDP sweeps do.  VLDS: V_{k-1} and V_k live in LDS and a thread holds its V_{k+1} values in registers
@@ -1444,6 +1552,7 @@ __global__ __launch_bounds__(1024) void vi_det_batch_wg(ViBatchArgs p)
 {
     extern __shared__ __attribute__((aligned(16))) double lds_v[];
     const int b = blockIdx.x, tid = threadIdx.x, nt = blockDim.x, S = p.Sb, A = AT > 0 ? AT : p.A;
+    if (p.only_failed && p.sweeps_out[b] != -1) return;      // (uniform: before any barrier)
     const long base = (long)b * S;
     double *Vb = VLDS ? lds_v : p.Vglobal + (long)b * 3 * S; // VLDS: [2][S]; global: [3][S]
     constexpr int NB = VLDS ? 2 : 3;
@@ -1690,6 +1799,41 @@ static int vi_batch_launch(mp_ctx *ctx, ViBatchArgs &q, hipStream_t st, const ch
             if constexpr (AT <= 4) { MP_VB(4, 1024) }
         }
 #undef MP_VB
+    }
+    if constexpr (AT > 0 && AT <= 6) {
+        // CLUSTER form: the batch leaves CUs idle with one workgroup per MDP -> K = 2, 4 or 8 workgroups per MDP, at most one per CU
+        // (each takes a CU's LDS: co-resident by construction on an otherwise idle device), each thread owning <= 3 states
+        const long cus = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        int K = 1;
+        while (K < 8 && (long)q.N * (K * 2) <= cus) K *= 2;
+        if (const char *e = getenv("MP_VI_BATCH_CLUSTER")) K = atoi(e);    // 0 / 1: off; 2, 4, 8: forced
+        const int own = K > 1 ? ((S + K - 1) / K + 1023) / 1024 : 99;
+        const size_t lds = (size_t)2 * S * sizeof(double) + 16;
+        if (K > 1 && K <= 8 && own <= 3 && lds <= kLdsBytes && q.iterations > 0) {
+            double *Vx = nullptr;
+            unsigned *words = nullptr;
+            MP_TRY(ws_get(ctx, WS_VI1, (size_t)q.N * 3 * S, &Vx));          // (the cluster uses [N][2][S]; the fallback [N][3][S])
+            MP_TRY(ws_get(ctx, WS_VI3, (size_t)q.N * q.iterations, &words));
+            MP_HIP(hipMemsetAsync(words, 0, (size_t)q.N * q.iterations * sizeof(unsigned), st));
+            const unsigned cgrid = (unsigned)((q.N + 7) / 8) * 8 * K;
+            // (test hook MP_VI_BATCH_CLUSTER_NEVER_MEETS=1: a cluster waits for one arrival too many and gives up after a short spin)
+            const bool hook = getenv("MP_VI_BATCH_CLUSTER_NEVER_MEETS") != nullptr;
+            const unsigned need = (unsigned)K + (hook ? 1u : 0u), spin = hook ? 2000u : kSpinLimit;
+#define MP_VC(o)                                                                                                            \
+    {                                                                                                                       \
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(vi_det_batch_cluster<AT, o>),                             \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                 \
+        hipLaunchKernelGGL((vi_det_batch_cluster<AT, o>), dim3(cgrid), dim3(1024), lds, st, q, K, Vx, words, need, spin);  \
+    }
+            if (own == 1) MP_VC(1) else if (own == 2) MP_VC(2) else MP_VC(3)
+#undef MP_VC
+            // clusters that never met (a busy device): solved again by the global-memory workgroup form (returns at once otherwise)
+            ViBatchArgs f = q;
+            f.only_failed = 1; f.Vglobal = Vx;
+            hipLaunchKernelGGL((vi_det_batch_wg<AT, false>), dim3(grid), dim3(1024), 0, st, f);
+            *variant = K == 2 ? "vi_batch_cluster2" : (K == 4 ? "vi_batch_cluster4" : "vi_batch_cluster8");
+            return MP_OK;
+        }
     }
     if constexpr (AT > 0) {
         if (S <= kViBatchOwn * 1024 && (size_t)2 * S * sizeof(double) <= kLdsBytes - 512 && !getenv("MP_VI_BATCH_NO_VLDS") &&

@@ -126,6 +126,7 @@ def test_vi_batch_workgroup_forms(ctx, monkeypatch, knob, variant):
     V_{k-1}, V_k in LDS; three V buffers in global memory) at the C2 shape S = 10 000 and, forced, on small MDPs -- same Q
     and sweeps as sequential oracle solves."""
     from oracle import oracle
+    monkeypatch.setenv("MP_VI_BATCH_CLUSTER", "0")                 # (few large MDPs would take the cluster form: next test)
     if knob:
         monkeypatch.setenv(knob, "1")
     tr, rw, tm = _tables(3, (10, 10, 100), seed0=50)
@@ -146,6 +147,52 @@ def test_vi_batch_workgroup_forms(ctx, monkeypatch, knob, variant):
         q_ref, sw_ref = oracle.vi_solve_each(tr, rw, tm, gamma=0.95, iterations=iters)
         np.testing.assert_array_equal(sweeps, sw_ref)
         assert np.array_equal(q, q_ref), iters
+    model.close()
+
+
+@pytest.mark.parametrize("n,k", [(3, None), (5, 4), (64, None), (9, 8), (33, 4)])
+def test_vi_batch_cluster_form(ctx, monkeypatch, n, k):
+    """Round 6: K workgroups per MDP for few LARGE MDPs (S = 10 000: 64 MDPs x 4 workgroups fill the chip), V exchanged through
+    write-through stores and a per-sweep counter that also carries the allclose vote -- Q and per-MDP sweep counts of
+    sequential oracle solves, with MDPs of one launch stopping at different sweeps."""
+    from oracle import oracle
+    if k:
+        monkeypatch.setenv("MP_VI_BATCH_CLUSTER", str(k))
+    tr, rw, tm = _tables(n, (10, 10, 100), seed0=300 + n)
+    rw = rw * (10.0 ** -(np.arange(n) % 4))[:, None, None]
+    model = ctx.load_table_batch(tr, rw, tm)
+    for iters in (1, 3, 200):
+        q, sweeps = ctx.vi_solve_batch(model, 0.95, iters)
+        assert ctx.last_kernel_variant() == "vi_batch_cluster{}".format(k or (8 if n <= 32 else 4))
+        q_ref, sw_ref = oracle.vi_solve_each(tr, rw, tm, gamma=0.95, iterations=iters)
+        np.testing.assert_array_equal(sweeps, sw_ref)
+        assert np.array_equal(q, q_ref), iters
+    model.close()
+
+
+def test_vi_batch_cluster_small_mdps_and_fallback(ctx, monkeypatch):
+    """The cluster form forced on small MDPs (K = 2, 4, 8: slices of a few states, an empty slice at K = 8 x S = 30 is not), and
+    clusters that never meet (test hook: one arrival too many is awaited): every MDP is solved again by the follow-up launch."""
+    from oracle import oracle
+    monkeypatch.setenv("MP_VI_BATCH_NO_REG", "1")
+    for shape, n, k in (((3, 4, 10), 21, 2), ((3, 4, 10), 21, 4), ((2, 3, 5), 7, 8), ((5, 5, 20), 11, 4)):
+        monkeypatch.setenv("MP_VI_BATCH_CLUSTER", str(k))
+        tr, rw, tm = _tables(n, shape, seed0=90 + k)
+        model = ctx.load_table_batch(tr, rw, tm)
+        q, sweeps = ctx.vi_solve_batch(model, 0.95, 200)
+        assert ctx.last_kernel_variant() == "vi_batch_cluster{}".format(k)
+        q_ref, sw_ref = oracle.vi_solve_each(tr, rw, tm, gamma=0.95, iterations=200)
+        np.testing.assert_array_equal(sweeps, sw_ref)
+        assert np.array_equal(q, q_ref), (shape, k)
+        model.close()
+    monkeypatch.setenv("MP_VI_BATCH_CLUSTER", "4")
+    monkeypatch.setenv("MP_VI_BATCH_CLUSTER_NEVER_MEETS", "1")
+    tr, rw, tm = _tables(6, (3, 4, 10), seed0=17)
+    model = ctx.load_table_batch(tr, rw, tm)
+    q, sweeps = ctx.vi_solve_batch(model, 0.95, 200)
+    q_ref, sw_ref = oracle.vi_solve_each(tr, rw, tm, gamma=0.95, iterations=200)
+    np.testing.assert_array_equal(sweeps, sw_ref)
+    assert np.array_equal(q, q_ref)
     model.close()
 
 
