@@ -1287,8 +1287,15 @@ __device__ __forceinline__ double row_children_max(double u)
     return u;
 }
 constexpr int kRowRoots = 4; // roots per wavefront
-template <int AT>
-__global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
+// SHARED (later in round 6): the same kernel for ONE model shared by every root -- SURVEY 8(d)'s own batch, 4096 roots of the
+// headline table.  uct_kernel<.., QD> keeps that model's compact tables in LDS (150 of 160 KB) and so has to leave the trees in
+// global memory: a dependent L2 round trip per scored level and per backed-up node, a third of a small plan.  Here the workgroup
+// stages ONE copy of the transitions (uint16 next | terminal bit: 2 B per (s, a), 100 KB for S = 10 000) and the sixteen trees
+// of its four wavefronts take the place of the reward tables; a step's reward comes from the model's 16-byte records in L2 --
+// requested when the state chain reaches the step, added to the return IN ORDER one level later (selection) or after the round
+// of sixteen steps (rollout), so its latency is paid once per round, not per step.
+template <int AT, bool SHARED = false>
+__global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
 {
     static_assert(AT >= 2 && AT <= 8, "|A| with a compile-time specialisation");
     constexpr int A = AT, NTH = AT - 1;
@@ -1296,8 +1303,10 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
     // (a workgroup is blockDim.x / 64 wavefronts sharing one copy of the per-call tables; tools/wave_placement.hip: the dispatcher
     // spreads single-wave workgroups over the SIMDs just as well -- 1024 of them land one per SIMD -- so 1, 2 or 4 waves per
     // workgroup run at the same speed)
-    const int tid = threadIdx.x, lane = tid & 63, row = tid >> 4, l16 = tid & 15, nthreads = blockDim.x;
-    const int nrows = nthreads >> 4;         // roots of this workgroup
+    // SHARED: a workgroup of sixteen wavefronts stages the model; p.waves of them stay to plan (four roots each)
+    const int tid = threadIdx.x, lane = tid & 63, l16 = tid & 15, nthreads = blockDim.x;
+    const int nrows = SHARED ? p.waves * kRowRoots : nthreads >> 4;         // roots of this workgroup
+    const int row = SHARED ? min(tid >> 4, nrows - 1) : tid >> 4;
     const int H = p.horizon, E = p.episodes, TE = p.table_n;
     double *gpow = lds_d;                   // [H + 1]  gamma ** h
     double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
@@ -1305,20 +1314,29 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
     double *tpdiv = rcp + (TE + 1);         // [A][TE+2] temperature * |A| * prior[a] / n
     const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
     const int ntab2 = (ntab + 1) & ~1;
-    const int SA = p.Sb * A, SA2 = (SA + 1) & ~1, SA8 = (SA + 7) & ~7, PH = (H + 4) & ~3;
+    // (SHARED: no reward tables, one transition table for the workgroup)
+    const int SA = (SHARED ? p.S : p.Sb) * A, SA2 = SHARED ? 0 : (SA + 1) & ~1, SA8 = (SA + 7) & ~7, PH = (H + 4) & ~3;
     double *rew = lds_d + ntab2 + row * SA2;                                                    // [rows][SA2] rewards
     UctNode *tnode = reinterpret_cast<UctNode *>(lds_d + ntab2 + nrows * SA2) + row * p.cap;    // [rows][cap] trees
     uint32_t *jump = reinterpret_cast<uint32_t *>(reinterpret_cast<UctNode *>(lds_d + ntab2 + nrows * SA2) + nrows * p.cap); // [H + 5][8]
     int32_t *path = reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + row * PH;                 // [rows][PH] path node ids
-    uint16_t *t16 = reinterpret_cast<uint16_t *>(reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + nrows * PH) + row * SA8; // [rows][SA8]
+    uint16_t *t16 = reinterpret_cast<uint16_t *>(reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + nrows * PH) + (SHARED ? 0 : row * SA8); // [rows][SA8]
     const int r = blockIdx.x * nrows + row;
     const bool live = r < p.n_roots;          // (a last wavefront's spare rows run along on the last root's data and write nothing)
     const int rr = live ? r : p.n_roots - 1;
     const int32_t s0g = p.root_state[rr];     // global state of the batch model
-    const int32_t sbase = (s0g / p.Sb) * p.Sb; // first global state of this root's MDP
+    const int32_t sbase = SHARED ? 0 : (s0g / p.Sb) * p.Sb; // first global state of this root's MDP
     for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
-    {
+    if (SHARED) {
+        // the model's compact transitions (pack_t16: next | terminal[next] << 15), 16 bytes a lane where the tail allows
+        const int n8 = SA >> 3;
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.t16);
+        uint4 *dst = reinterpret_cast<uint4 *>(t16);
+#pragma unroll 4
+        for (int i = tid; i < n8; i += nthreads) dst[i] = src[i];
+        for (int i = (n8 << 3) + tid; i < SA; i += nthreads) t16[i] = p.t16[i];
+    } else {
         const Rec *src = p.rec + (long)sbase * A;
 #pragma unroll 4
         for (int i = l16; i < SA; i += 16) {
@@ -1327,7 +1345,10 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
             rew[i] = rc.reward;
         }
     }
+    // SHARED: reward[s, a] from the 16-byte record in global memory (L2-resident: 16 S |A| bytes)
+    auto reward_of = [&](unsigned idx) -> double { return SHARED ? p.rec[idx].reward : rew[idx]; };
     __syncthreads();
+    if (SHARED && tid >= p.waves * 64) return;          // (the staging wavefronts)
     auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
     auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
     auto lds_sync = [] { // this wave's LDS writes before its later reads, for the compiler (the hardware keeps a wave's LDS order)
@@ -1367,6 +1388,10 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
         bool terminal = false, cur_term = root_term;
         double total = 0.0;
         int fc = tnode[0].first_child;
+        // SHARED: the reward of a scored level arrives from L2 while the next level is scored; it is added before that level's own
+        // (same order of additions).  pend_w = gamma ** depth * [a reward is pending], pend_r = that reward.
+        double pend_r = 0.0, pend_g = 0.0;
+        bool pend = false;
         // ---- selection, mcts.py:143-149: a level's children one per lane of the row
         bool sel = live && depth < H && fc >= 0 && !terminal;
         while (any64(sel)) {
@@ -1389,9 +1414,13 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
             // the chosen child's first_child, the transition, the reward and gamma ** depth: ONE LDS round trip
             const int nfc = tnode[sel ? fc + act : 0].first_child;
             const uint32_t e = t16[idx];
-            const double rw = rew[idx], gp = gpow[depth];
+            const double rw = reward_of(idx), gp = gpow[depth];
+            if (SHARED) {
+                if (pend) total += pend_g * pend_r;       // the previous level's reward (requested a level ago)
+                pend = sel; pend_r = rw; pend_g = gp;
+            }
             if (sel) {
-                total += gp * rw;
+                if (!SHARED) total += gp * rw;
                 const bool next_term = (e & 0x8000u) != 0;
                 terminal = p.done_on_next ? next_term : cur_term;
                 cur_term = next_term;
@@ -1407,6 +1436,7 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
             ++n_lvl;
 #endif
         }
+        if (SHARED && pend) total += pend_g * pend_r;     // the last scored level's reward
         PROF_T(c1);
         // ---- expansion, mcts.py:151-154 / 237-246
         if (live && fc < 0 && depth < H && (!terminal || node == 0)) {
@@ -1452,31 +1482,62 @@ __global__ __launch_bounds__(256) void uct_row_kernel(UctArgs p)
                     act_l = (uint32_t)min(act, p.thr_valid);
                 }
                 PROF_T(d1);
-#define MP_ROW_WALK(i_)                                                                                 \
+                // SHARED: the rewards of the round's steps are requested as the state chain reaches them and summed afterwards, in
+                // step order (a root's live steps are a prefix of the round: n_before .. n - 1)
+                double rwv[16];
+                const int n_before = n;
+                // The walk in GROUPS OF FOUR steps, two passes each.  Pass 1 is the state chain alone -- index -> LDS read -> mask, four
+                // times, SPECULATIVE: sw steps through the model whether or not the row's rollout is still running (a finished row reads
+                // valid records nobody uses) -- with the rewards requested on the way.  Pass 2 is what the four steps mean for the rows
+                // still rolling (terminal flags, step limit, the committed state and return).  A lone wave issues in order: with the
+                // bookkeeping between two steps of the chain (the first form) every step paid for both.
+                int32_t sw = s;
+                uint32_t e4[4];
+                double rw4[4];
+#define MP_ROW_CHAIN(i_, j_)                                                                            \
     {                                                                                                   \
         const int a_i = dpp_mov<0x150 + (i_)>((int)act_l);      /* row_newbcast: lane i_ of the row */   \
-        const unsigned idx = __umul24((unsigned)s, (unsigned)A) + (unsigned)a_i;                        \
-        const uint32_t e = t16[idx];                                                                    \
-        const double rw = rew[idx], gp = gpow[depth + n];                                               \
+        const unsigned idx = __umul24((unsigned)sw, (unsigned)A) + (unsigned)a_i;                       \
+        e4[j_] = t16[idx];                                                                              \
+        if (SHARED) rwv[i_] = reward_of(idx); else rw4[j_] = rew[idx];                                  \
+        sw = (int32_t)(e4[j_] & 0x7fffu);                                                               \
+    }
+#define MP_ROW_BOOK(j_)                                                                                 \
+    {                                                                                                   \
+        const uint32_t e = e4[j_];                                                                      \
         const bool next_term = (e & 0x8000u) != 0;                                                      \
         const bool term_h = p.done_on_next ? next_term : cur_term;                                      \
         if (alive) {                                                                                    \
-            total += gp * rw;                                                                           \
+            if (!SHARED) total += gpow[depth + n] * rw4[j_];                                            \
             cur_term = next_term;                                                                       \
             s = (int32_t)(e & 0x7fffu);                                                                 \
             ++n;                                                                                        \
             alive = !(term_h || n >= n_lim);                                                            \
         }                                                                                               \
     }
-                MP_ROW_WALK(0) MP_ROW_WALK(1) MP_ROW_WALK(2) MP_ROW_WALK(3)
+#define MP_ROW_WALK4(g_)                                                                                \
+    MP_ROW_CHAIN(4 * (g_), 0) MP_ROW_CHAIN(4 * (g_) + 1, 1) MP_ROW_CHAIN(4 * (g_) + 2, 2) MP_ROW_CHAIN(4 * (g_) + 3, 3)     \
+    MP_ROW_BOOK(0) MP_ROW_BOOK(1) MP_ROW_BOOK(2) MP_ROW_BOOK(3)
+                if (SHARED) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) rwv[i] = 0.0;
+                }
+                MP_ROW_WALK4(0)
                 if (any64(alive)) {
-                    MP_ROW_WALK(4) MP_ROW_WALK(5) MP_ROW_WALK(6) MP_ROW_WALK(7)
+                    MP_ROW_WALK4(1)
                     if (any64(alive)) {
-                        MP_ROW_WALK(8) MP_ROW_WALK(9) MP_ROW_WALK(10) MP_ROW_WALK(11)
-                        if (any64(alive)) { MP_ROW_WALK(12) MP_ROW_WALK(13) MP_ROW_WALK(14) MP_ROW_WALK(15) }
+                        MP_ROW_WALK4(2)
+                        if (any64(alive)) { MP_ROW_WALK4(3) }
                     }
                 }
-#undef MP_ROW_WALK
+#undef MP_ROW_WALK4
+#undef MP_ROW_BOOK
+#undef MP_ROW_CHAIN
+                if (SHARED) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        if (n_before + i < n) total += gpow[depth + n_before + i] * rwv[i];
+                }
                 PROF_T(d2);
                 // a row whose rollout ended in this round: its generator after the n draws it consumed = the state the lane of
                 // its last draw jumped to
@@ -1990,7 +2051,30 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         }
     }
     if (rowk) each = false;
-    if (each || rowk) lone = true;
+    // ... and the SHARED-model form of the row kernel (uct_row_kernel<.., true>): batches between one root per CU (uct_lone_kernel)
+    // and sixteen (one round of four-wave workgroups) of a model whose transitions + the workgroup's trees fit the LDS.
+    // MP_UCT_ROWS=1 / 0 forces it on (any batch size) / off.
+    bool rowsh = false;
+    int rowsh_waves = 4;
+    size_t lds_rowsh = 0;
+    {
+        auto lds_rowsh_of = [&](int rows_wg) {
+            return ((ntab + 1) & ~(size_t)1) * sizeof(double) + rows_wg * (size_t)cap * sizeof(UctNode) + (size_t)(H + 5) * 32 +
+                   rows_wg * (size_t)((H + 4) & ~3) * sizeof(int32_t) + (((size_t)model->S * A + 7) & ~(size_t)7) * 2;
+        };
+        const long cus_s = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        // as few waves per workgroup as still put the batch on the chip in one round (fewer roots behind one staged copy)
+        while (rowsh_waves > 1 && ((long)n_roots + kRowRoots * (rowsh_waves / 2) - 1) / (kRowRoots * (rowsh_waves / 2)) <= cus_s) rowsh_waves >>= 1;
+        if (const char *e = getenv("MP_UCT_ROW_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) rowsh_waves = v; }
+        while (rowsh_waves > 1 && lds_rowsh_of(kRowRoots * rowsh_waves) > kLdsBytes) rowsh_waves >>= 1;
+        lds_rowsh = lds_rowsh_of(kRowRoots * rowsh_waves);
+        const char *se = getenv("MP_UCT_ROWS");
+        const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
+        if (!cart && !pol && at_known && model->t16 != nullptr && model->NB <= 1 && want_il == 2 && H >= 1 && H <= 255 &&
+            lds_rowsh <= kLdsBytes && !will_continue && !force && !rowk && !each)
+            rowsh = se ? atoi(se) != 0 : (!lone && !getenv("MP_UCT_QUAD") && !getenv("MP_UCT_PATH") && n_roots >= 16 && n_roots <= 4L * kRowRoots * cus_s);
+    }
+    if (each || rowk || rowsh) lone = true;
     if (lone) { quad = false; ldsr = false; ldsm = false; }
     a.Sb = Sb;
     a.jump = nullptr;
@@ -2022,6 +2106,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.lanes = quad ? 16 : ((ldsm || ldsr) ? 64 : uct_lanes_per_wave());
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
+    if (rowsh) a.waves = rowsh_waves;   // (the wavefronts of a workgroup that plan; the launch adds staging waves)
     if (cart) {
         // CartPole (round 6): a root is one lane, and a wavefront takes as long as its SLOWEST root's episodes -- rollouts end when
         // the pole falls, at very different lengths -- so a small batch is spread over more wavefronts of FEWER roots: 16 per
@@ -2056,7 +2141,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         while (a.waves < w && a.waves < 16) a.waves <<= 1;
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
-    size_t lds = rowk ? lds_row : each ? lds_each : lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
+    size_t lds = rowsh ? lds_rowsh : rowk ? lds_row : each ? lds_each : lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
     if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double) + (size_t)(H + 5) * 32; // the sin / cos table of libm_sincos.hpp behind the path stack, then the jump table
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
@@ -2112,7 +2197,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (lds > 64 * 1024) { spill = true; lds = ntab * sizeof(double); }
     }
     if (spill && ctx->tree.il == 1) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d needs the spilled path stack, which the interleaved tree layout does not have", H);
-    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (rowk ? "uct_row_each" : each ? "uct_lone_each" : lone ? "uct_lone" : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (rowsh ? "uct_row_shared" : rowk ? "uct_row_each" : each ? "uct_lone_each" : lone ? "uct_lone" : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
     if (ldsr || spill) {
         a.spill_stride = ((long)n_roots + 63) & ~63L;
         MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
@@ -2216,6 +2301,17 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             const int per_block = c.lanes * c.waves;
             const dim3 grid((unsigned)((c.n_roots + per_block - 1) / per_block)), block(64u * c.waves);
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
+        } else if (rowsh) {
+#define MP_ROWS(k)                                                                                                                 \
+    case k:                                                                                                                        \
+        if (lds > 64 * 1024)                                                                                                       \
+            MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_row_kernel<k, true>),                                   \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
+        hipLaunchKernelGGL((uct_row_kernel<k, true>), dim3((unsigned)((c.n_roots + kRowRoots * rowsh_waves - 1) / (kRowRoots * rowsh_waves))), \
+                           dim3(1024u), lds, s, c);                                                                                \
+        break;
+            switch (A) { MP_ROWS(2) MP_ROWS(3) MP_ROWS(4) MP_ROWS(5) MP_ROWS(6) MP_ROWS(7) MP_ROWS(8) default: break; }
+#undef MP_ROWS
         } else if (rowk) {
 #define MP_ROWK(k)                                                                                                                 \
     case k:                                                                                                                        \

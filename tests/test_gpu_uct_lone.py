@@ -66,7 +66,7 @@ def test_lone_is_for_at_most_one_root_per_cu_and_by_request(ctx, monkeypatch):
     from rl_agents_amd.envs import generators
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     p = np.ones(5) / 5
-    _cmp(ctx, cfg, 257, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_quad")
+    _cmp(ctx, cfg, 257, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_row_shared")   # (round 6: trees in LDS for 257 .. 4096 roots too)
     monkeypatch.setenv("MP_UCT_LONE", "0")
     _cmp(ctx, cfg, 8, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_global")
     monkeypatch.setenv("MP_UCT_LONE", "1")
@@ -99,7 +99,7 @@ def test_lone_longer_horizons_and_many_episodes_fall_back(ctx):
     from rl_agents_amd.envs import generators
     cfg = generators.highway_shaped(4, 5, 50, collision_rate=0.01, seed=9)
     p = np.ones(5) / 5
-    _cmp(ctx, cfg, 33, 10, 64, 0.95, 10.0, p, p, seed=1, expect="uct_quad", trees=())
+    _cmp(ctx, cfg, 33, 10, 64, 0.95, 10.0, p, p, seed=1, expect="uct_row_shared", trees=())
     _cmp(ctx, cfg, 5, 10, 64, 0.95, 10.0, p, p, seed=1, expect="uct_global", trees=())
     big = generators.highway_shaped(10, 10, 100, seed=0)         # a 600-episode tree does not fit LDS beside this model
     _cmp(ctx, big, 2, 600, 5, 0.8, 10.0, p, p, seed=3, expect="uct_global", trees=())

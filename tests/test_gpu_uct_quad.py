@@ -23,6 +23,7 @@ def _no_lone_kernel(monkeypatch):
     """(batches of at most one root per CU take uct_lone_kernel by default since it exists -- tests/test_gpu_uct_lone.py; this
     file is about the kernel that served them before and still serves 257 .. 16 384 roots)"""
     monkeypatch.setenv("MP_UCT_LONE", "0")
+    monkeypatch.setenv("MP_UCT_ROWS", "0")      # (257 .. 4096 roots take the shared-model row kernel since round 6: test_gpu_uct_rows.py)
 
 
 def _rng_states(n, base=0):
