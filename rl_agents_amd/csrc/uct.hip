@@ -2130,6 +2130,11 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (const char *e = getenv("MP_UCT_CART_REP")) { a.rep_shift = atoi(e); while (a.rep_shift > 0 && (a.lanes << a.rep_shift) > 64) --a.rep_shift; }
         if (a.rep_shift < 2) a.rep_shift = 0;      // (the replicated form works on quads)
         if (const char *e = getenv("MP_UCT_CART_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) a.waves = v; }
+        // (the per-lane path stack is [H + 1][waves * 64] in LDS: fewer waves per workgroup where four would not fit the CU's LDS --
+        // horizons beyond ~150; one wave reaches ~600 steps)
+        while (a.waves > 1 && ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t) + 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double) +
+                                      (size_t)(H + 5) * 32 > kLdsBytes)
+            a.waves >>= 1;
     }
     if (ldsr) {
         // one workgroup per CU shares the tables: as many waves per workgroup as it takes to put the batch on the chip's
@@ -2151,7 +2156,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     }
     // a path stack that does not fit 64 KB of LDS (horizon >~ 180): registers + the global spill array instead
     bool spill = false;
-    if (!lone && !ldsm && !ldsr && lds > 64 * 1024) {
+    if (!lone && !ldsm && !ldsr && lds > 64 * 1024 && !(cart && lds <= kLdsBytes)) {   // (CartPole: the launch raises the kernel's LDS limit)
         const char *lay_now = getenv("MP_UCT_TREE");
         if (cart || pol || (lay_now && lay_now[0] == 'i') || ntab * sizeof(double) > 64 * 1024)
             return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d / episodes %d need %zu B of LDS tables (> 64 KiB)", H, E, lds);
@@ -2300,6 +2305,8 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (cart) {
             const int per_block = c.lanes * c.waves;
             const dim3 grid((unsigned)((c.n_roots + per_block - 1) / per_block)), block(64u * c.waves);
+            if (lds > 64 * 1024)
+                MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_kernel<2, ENV_CARTPOLE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL((uct_kernel<2, ENV_CARTPOLE>), grid, block, lds, s, c);
         } else if (rowsh) {
 #define MP_ROWS(k)                                                                                                                 \

@@ -115,6 +115,28 @@ def test_cartpole_forced_layouts_agree(ctx, monkeypatch, lanes, rep):
     np.testing.assert_array_equal(rng_got, rng_base)
 
 
+@pytest.mark.parametrize("horizon", [60, 120, 220, 400])
+def test_cartpole_long_horizons(ctx, horizon):
+    """Horizons whose per-lane path stack does not fit 64 KB of LDS with four wavefronts per workgroup (round 6's default): the
+    launch raises the kernel's LDS limit and, beyond the CU's 160 KB, takes fewer waves per workgroup instead of refusing."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import CartPoleEnv
+    params = CartPoleEnv().cartpole_params()
+    model = ctx.load_cartpole(params)
+    n = 200
+    x0 = np.random.Generator(np.random.PCG64(horizon)).uniform(-0.02, 0.02, size=(n, 4))
+    rng = native.seed_sequence_states((), 5 * horizon, n)
+    rng_ref = rng.copy()
+    p = np.ones(2) / 2
+    out = ctx.uct_plan(model, x0, 8, horizon, 0.99, 5.0, p, p, rng, max_plan_len=8)
+    ref = oracle.uct_plan_batch(None, None, None, x0, 8, horizon, 0.99, 5.0, p, p, rng_ref, max_plan_len=8, n_threads=8, cartpole=params)
+    np.testing.assert_array_equal(out["plans"], ref["plans"])
+    np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
+    assert np.array_equal(out["root_value"], ref["root_value"])
+    np.testing.assert_array_equal(rng, ref["rng_after"])
+
+
 def test_device_sincos_equals_host_libm_on_ten_million_angles(ctx):
     """The device's restated sin / cos (the form mp_libm_sincos_variant picked for this host) against the host libm's --
     math.sin / math.cos, what gymnasium's CartPole calls -- on 10^7 angles: the pole's range, the whole restated range
