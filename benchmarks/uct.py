@@ -264,8 +264,11 @@ def bench_uct(args, rank, world, local, with_prior=False):
                         "single GPU"),
         roofline=dict(bound="hbm", achieved=bytes_per_step * env_steps / (k_ms * 1e-3) / 1e9,
                       peak=HBM_PEAK_GBS, unit="GB/s",
-                      kernel="uct_kernel<5, {}>".format("ENV_TABLE, per-state policies" if with_prior else
-                                                        ("ENV_TABLE_LDSR (model resident in LDS)" if variant == "uct_ldsr" else "ENV_TABLE")),
+                      kernel={"uct_row_shared": "uct_row_kernel<5, SHARED> (four roots per wavefront, transitions + trees in LDS)",
+                              "uct_lone": "uct_lone_kernel<5> (one root per workgroup)",
+                              "uct_quad": "uct_kernel<5, ENV_TABLE_LDSR, QD> (four lanes per root)"}.get(variant) or
+                      "uct_kernel<5, {}>".format("ENV_TABLE, per-state policies" if with_prior else
+                                                 ("ENV_TABLE_LDSR (model resident in LDS)" if variant == "uct_ldsr" else "ENV_TABLE")),
                       kernel_variant=variant, model_bytes_staged_per_launch=staged,
                       hbm_side_bytes_per_launch=None if bytes_per_step_hbm is None else bytes_per_step_hbm * env_steps,
                       frac_hbm_side=None if bytes_per_step_hbm is None else bytes_per_step_hbm * env_steps / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -296,7 +299,12 @@ def bench_uct(args, rank, world, local, with_prior=False):
     # (the same run also launches the record-gather kernel on this grid -- `general_model_kernel` -- so the counters are looked
     # up by the full template name: ENV 3 = model resident in LDS, 0 = records gathered)
     kname = "uct_kernel<{}, {},".format(a_, 3 if variant in ("uct_ldsr", "uct_quad") else 0)
-    add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel" if with_prior else kname, n_roots)
+    if variant == "uct_row_shared":       # (257 .. 4096 roots: the row kernel on a shared model; 1024-thread workgroups)
+        add_traffic(res["roofline"], "uct", "uct_row_kernel<{}, true>".format(a_), None)
+    elif variant == "uct_lone":
+        add_traffic(res["roofline"], "uct", "uct_lone_kernel<{}".format(a_), n_roots * 1024)
+    else:
+        add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel" if with_prior else kname, n_roots)
     if not with_prior and rank == 0 and world == 1 and not args.headline_only:
         # the default run measures the headline kernel's HBM traffic itself (it used to be read from a committed
         # summary); the committed figure stays beside it as `traffic_committed`
@@ -408,7 +416,7 @@ def bench_uct_cartpole(args, rank, world, local):
                       kernel="uct_kernel<2, ENV_CARTPOLE>", kernel_ms=k_ms, algorithmic_bytes_per_launch=alg,
                       note="state lives in registers: compute/latency bound by construction"),
     )
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    add_traffic(res["roofline"], "uct_cartpole", "uct_kernel<2, 2", None)
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))
@@ -528,7 +536,7 @@ def bench_uct_stoch(args, rank, world, local):
                            "address units are 47 % busy at 65 536 roots and 83 % at 262 144 (profiles/r03_uct_stoch_units.txt, "
                            "before the 16-byte records): the bound is the count of scattered vector-memory instructions"),
     )
-    res["roofline"]["frac"] = res["roofline"]["achieved"] / HBM_PEAK_GBS
+    add_traffic(res["roofline"], "uct_stoch", "uct_stoch_kernel", n_roots)
     if not args.no_parity_sample and rank == 0:
         from oracle import oracle
         d_rng.copy_(torch.from_numpy(rng0.view(np.int64)).to(dev))

@@ -84,7 +84,12 @@ def bench_vi(args, rank, world, local, dense, robust=False, exact=False):
     if dense:
         add_traffic(res["roofline"], "vi_dense_exact" if exact else "vi_dense", name, None, pattern="stream")
     else:
-        res["roofline"].update(traffic=None, traffic_frac=None, frac=res["roofline"]["achieved"] / HBM_PEAK_GBS)
+        # committed PMC passes of this workload (profiles/*_pmc.json); the persistent kernel is ONE launch for every sweep
+        traffic, raw = pmc_traffic("rvi" if robust else "vi", name.split("<")[0].split(" ")[0], None, pattern="stream")
+        if traffic is not None and "persist" in name:
+            traffic /= float(sweeps)
+        res["roofline"].update(traffic=traffic, traffic_counters=raw, frac=res["roofline"]["achieved"] / HBM_PEAK_GBS,
+                               traffic_frac=None if traffic is None else traffic / (per_sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
     if dense and not exact:
         res["roofline"]["mfma_tflops"] = flops / (per_sweep_ms * 1e-3) / 1e12
         res["roofline"]["mfma_frac_of_f64_peak"] = res["roofline"]["mfma_tflops"] / MFMA_F64_PEAK_TFLOPS

@@ -28,7 +28,7 @@ for wl in ${TRACE_WLS:-uct uct4096 uct256 uct1 uct_per_root_model uct_prior uct_
 done
 # HBM traffic: FETCH_SIZE and WRITE_SIZE cannot share a pass (TCC slots) -> two runs each; counters only,
 # no tracing domains besides the kernel trace
-for wl in ${PMC_WLS:-uct uct_per_root_model uct_prior uct_stoch vi_batch_s10000 vi_batch_s10000_256 vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact opd opd8192 ropd saopd}; do
+for wl in ${PMC_WLS:-uct uct4096 uct_per_root_model uct_prior uct_cartpole uct_stoch vi rvi vi_batch vi_batch_s10000 vi_batch_s10000_256 vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact opd opd8192 ropd saopd}; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d $OUT/pmc_${wl}_$ctr -o $wl -- \
         python /root/repo/bench.py $(args_of $wl) --steps 3 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample > $OUT/pmc_${wl}_$ctr.log 2>&1

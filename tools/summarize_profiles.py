@@ -56,7 +56,7 @@ def main():
         if not os.path.exists(f):
             continue
         lines += ["## " + wl + (" (= --workload opd --roots 8192)" if wl == "opd8192" else
-                                " (= --workload uct --roots 4096: the four-lanes-per-root kernel)" if wl == "uct4096" else
+                                " (= --workload uct --roots 4096: the row kernel on a shared model, uct_row_kernel<5, true>)" if wl == "uct4096" else
                                 " (= --workload uct --roots 256: one root per workgroup, uct_lone_kernel)" if wl == "uct256" else
                                 " (= --workload uct --roots 1: a single agent's plan, uct_lone_kernel)" if wl == "uct1" else
                                 " (= --workload vi_batch --states 120 --roots 4096)" if wl == "vi_batch" else
@@ -78,7 +78,7 @@ def main():
                     name, grid, wg, vgpr, ldsb, n, mean, lo, hi))
             lines.append("")
     traffic = {}
-    for wl in ("uct", "uct_per_root_model", "uct_prior", "uct_stoch", "vi_batch_s10000", "vi_batch_s10000_256", "vi_dense", "vi_dense_exact",
+    for wl in ("uct", "uct4096", "uct_per_root_model", "uct_prior", "uct_cartpole", "uct_stoch", "vi", "rvi", "vi_batch", "vi_batch_s10000", "vi_batch_s10000_256", "vi_dense", "vi_dense_exact",
                "rvi_dense_shard", "rvi_dense_shard_exact", "opd", "opd8192", "ropd", "saopd"):
         entry = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -88,7 +88,7 @@ def main():
                     entry.setdefault(k, {})[ctr + "_KB_per_launch"] = mean_kb
                     entry[k]["launches_" + ctr] = n
         if entry:  # (bench.py looks a launch up by workload and grid size: the 8192-root pass belongs to "opd")
-            traffic.setdefault("opd" if wl == "opd8192" else ("vi_batch" if wl.startswith("vi_batch") else wl), {}).update(entry)
+            traffic.setdefault("opd" if wl == "opd8192" else ("vi_batch" if wl.startswith("vi_batch") else ("uct" if wl == "uct4096" else wl)), {}).update(entry)
     if traffic:
         lines += ["## HBM traffic (PMC, separate passes: `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE`)", "",
                   "Per launch, KB as rocprofv3 reports them.  To bytes: x2 for FETCH_SIZE (streams AND scattered 16-byte gathers: "
