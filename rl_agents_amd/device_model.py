@@ -12,6 +12,7 @@ A GPU kernel cannot call that, so the boundary extracts what the object *is* for
 Uploads are cached per context and keyed by a content hash of the tables, so agents that rebuild the
 MDP on every ``act`` (value_iteration.py:29-35) only pay for an upload when the tables changed.
 """
+import functools
 import hashlib
 import os
 
@@ -127,10 +128,19 @@ def grid_available(original_shape):
     """Action availability of a (speed V, lane L, time T) time-to-collision grid in highway-env's style [from memory,
     package absent]: LANE_LEFT (0) needs a lane to the left, LANE_RIGHT (2) one to the right, FASTER (3) a higher and
     SLOWER (4) a lower target speed; IDLE (1) is always available.  -> bool [V * L * T, 5]."""
-    n_speeds, n_lanes, n_times = (int(x) for x in original_shape)
+    return _grid_available(tuple(int(x) for x in original_shape))
+
+
+@functools.lru_cache(maxsize=64)
+def _grid_available(shape):
+    # (a function of the shape alone; a per-episode evaluation asks it for every environment at every step: cached, and
+    # handed out read-only so that no caller can edit the cached table)
+    n_speeds, n_lanes, n_times = shape
     v, l, _ = np.meshgrid(np.arange(n_speeds), np.arange(n_lanes), np.arange(n_times), indexing="ij")
     v, l = v.ravel(), l.ravel()
-    return np.stack([l > 0, np.ones_like(l, dtype=bool), l < n_lanes - 1, v < n_speeds - 1, v > 0], axis=1)
+    table = np.stack([l > 0, np.ones_like(l, dtype=bool), l < n_lanes - 1, v < n_speeds - 1, v > 0], axis=1)
+    table.setflags(write=False)
+    return table
 
 
 GRID_LISTING_ORDER = (1, 0, 2, 3, 4)   # highway-env lists IDLE first, then LANE_LEFT, LANE_RIGHT, FASTER, SLOWER [from memory]
