@@ -1305,8 +1305,12 @@ __global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
     // workgroup run at the same speed)
     // SHARED: a workgroup of sixteen wavefronts stages the model; p.waves of them stay to plan (four roots each)
     const int tid = threadIdx.x, lane = tid & 63, l16 = tid & 15, nthreads = blockDim.x;
-    const int nrows = SHARED ? p.waves * kRowRoots : nthreads >> 4;         // roots of this workgroup
-    const int row = SHARED ? min(tid >> 4, nrows - 1) : tid >> 4;
+    // SHARED: p.lanes = roots per wavefront, 4 or 2 (two: rows 2 and 3 of every wave idle -- twice the waves for the same roots,
+    // two per SIMD, which fill each other's issue gaps; their lanes alias the wave's last live row and write nothing)
+    const int rpw = SHARED ? p.lanes : kRowRoots;
+    const int nrows = SHARED ? p.waves * rpw : nthreads >> 4;         // roots of this workgroup
+    const bool row_used = !SHARED || ((tid >> 4) & 3) < rpw;
+    const int row = SHARED ? min((tid >> 6) * rpw + min((tid >> 4) & 3, rpw - 1), nrows - 1) : tid >> 4;
     const int H = p.horizon, E = p.episodes, TE = p.table_n;
     double *gpow = lds_d;                   // [H + 1]  gamma ** h
     double *tp = gpow + (H + 1) + A;        // [A]      temperature * |A| * prior[a]
@@ -1322,7 +1326,7 @@ __global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
     int32_t *path = reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + row * PH;                 // [rows][PH] path node ids
     uint16_t *t16 = reinterpret_cast<uint16_t *>(reinterpret_cast<int32_t *>(jump + (H + 5) * 8) + nrows * PH) + (SHARED ? 0 : row * SA8); // [rows][SA8]
     const int r = blockIdx.x * nrows + row;
-    const bool live = r < p.n_roots;          // (a last wavefront's spare rows run along on the last root's data and write nothing)
+    const bool live = row_used && r < p.n_roots; // (a last wavefront's spare rows run along on the last root's data and write nothing)
     const int rr = live ? r : p.n_roots - 1;
     const int32_t s0g = p.root_state[rr];     // global state of the batch model
     const int32_t sbase = SHARED ? 0 : (s0g / p.Sb) * p.Sb; // first global state of this root's MDP
@@ -1362,7 +1366,7 @@ __global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
     const int32_t st0 = p.root_steps ? p.root_steps[rr] : 0;
     const bool root_term = (p.rec[(long)s0g * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
     int n_nodes = 1, steps_taken = 0;
-    if (l16 == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; path[0] = 0; } // mcts.py:129-130 reset()
+    if (l16 == 0 && row_used) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; path[0] = 0; } // mcts.py:129-130 reset()
     lds_sync();
     const int la = l16 < A ? l16 : 0;
     const int row_lane0 = lane & 48;
@@ -2055,7 +2059,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // and sixteen (one round of four-wave workgroups) of a model whose transitions + the workgroup's trees fit the LDS.
     // MP_UCT_ROWS=1 / 0 forces it on (any batch size) / off.
     bool rowsh = false;
-    int rowsh_waves = 4;
+    int rowsh_waves = 4, rowsh_rpw = kRowRoots;   // planning wavefronts per workgroup, roots per wavefront
     size_t lds_rowsh = 0;
     {
         auto lds_rowsh_of = [&](int rows_wg) {
@@ -2063,11 +2067,16 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
                    rows_wg * (size_t)((H + 4) & ~3) * sizeof(int32_t) + (((size_t)model->S * A + 7) & ~(size_t)7) * 2;
         };
         const long cus_s = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+        // two roots per wavefront (rows 2 and 3 idle) while that still fits one wave per SIMD: a wave's rounds then run to the slower
+        // of 2 roots instead of 4 (2048 roots 0.197 -> 0.187 ms, 1024 roots 0.195 -> 0.184); two such waves per SIMD for 4096 roots
+        // measure the same as one wave of four (0.201 against 0.197)
+        if ((long)n_roots <= 2L * 4 * cus_s) rowsh_rpw = 2;
         // as few waves per workgroup as still put the batch on the chip in one round (fewer roots behind one staged copy)
-        while (rowsh_waves > 1 && ((long)n_roots + kRowRoots * (rowsh_waves / 2) - 1) / (kRowRoots * (rowsh_waves / 2)) <= cus_s) rowsh_waves >>= 1;
-        if (const char *e = getenv("MP_UCT_ROW_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4) rowsh_waves = v; }
-        while (rowsh_waves > 1 && lds_rowsh_of(kRowRoots * rowsh_waves) > kLdsBytes) rowsh_waves >>= 1;
-        lds_rowsh = lds_rowsh_of(kRowRoots * rowsh_waves);
+        while (rowsh_waves > 1 && ((long)n_roots + rowsh_rpw * (rowsh_waves / 2) - 1) / (rowsh_rpw * (rowsh_waves / 2)) <= cus_s) rowsh_waves >>= 1;
+        if (const char *e = getenv("MP_UCT_ROW_WAVES")) { const int v = atoi(e); if (v == 1 || v == 2 || v == 4 || v == 8) rowsh_waves = v; }
+        if (const char *e = getenv("MP_UCT_ROW_ROOTS")) { const int v = atoi(e); if (v == 2 || v == 4) rowsh_rpw = v; }
+        while (rowsh_waves > 1 && lds_rowsh_of(rowsh_rpw * rowsh_waves) > kLdsBytes) rowsh_waves >>= 1;
+        lds_rowsh = lds_rowsh_of(rowsh_rpw * rowsh_waves);
         const char *se = getenv("MP_UCT_ROWS");
         const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
         if (!cart && !pol && at_known && model->t16 != nullptr && model->NB <= 1 && want_il == 2 && H >= 1 && H <= 255 &&
@@ -2106,7 +2115,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     a.lanes = quad ? 16 : ((ldsm || ldsr) ? 64 : uct_lanes_per_wave());
     // LDS variant: few roots -> 4 waves per workgroup (one per SIMD); big batches -> 16
     a.waves = ldsm ? ((long)n_roots >= 64L * 16 * ctx->prop.multiProcessorCount ? 16 : 4) : 1;
-    if (rowsh) a.waves = rowsh_waves;   // (the wavefronts of a workgroup that plan; the launch adds staging waves)
+    if (rowsh) { a.waves = rowsh_waves; a.lanes = rowsh_rpw; }   // (the wavefronts of a workgroup that plan; the launch adds staging waves)
     if (cart) {
         // CartPole (round 6): a root is one lane, and a wavefront takes as long as its SLOWEST root's episodes -- rollouts end when
         // the pole falls, at very different lengths -- so a small batch is spread over more wavefronts of FEWER roots: 16 per
@@ -2314,7 +2323,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (lds > 64 * 1024)                                                                                                       \
             MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_row_kernel<k, true>),                                   \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
-        hipLaunchKernelGGL((uct_row_kernel<k, true>), dim3((unsigned)((c.n_roots + kRowRoots * rowsh_waves - 1) / (kRowRoots * rowsh_waves))), \
+        hipLaunchKernelGGL((uct_row_kernel<k, true>), dim3((unsigned)((c.n_roots + rowsh_rpw * rowsh_waves - 1) / (rowsh_rpw * rowsh_waves))), \
                            dim3(1024u), lds, s, c);                                                                                \
         break;
             switch (A) { MP_ROWS(2) MP_ROWS(3) MP_ROWS(4) MP_ROWS(5) MP_ROWS(6) MP_ROWS(7) MP_ROWS(8) default: break; }

@@ -52,13 +52,15 @@ def test_rows_headline_geometry_default(ctx, n_roots):
     _cmp(ctx, cfg, n_roots, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=n_roots)
 
 
-@pytest.mark.parametrize("n_roots,waves", [(1, 1), (5, 4), (64, 2), (6000, 4), (20000, 4)])
-def test_rows_forced_any_batch(ctx, monkeypatch, n_roots, waves):
-    """Forced (MP_UCT_ROWS=1) below and beyond its default range: ragged last workgroups, several rounds of workgroups."""
+@pytest.mark.parametrize("n_roots,waves,rpw", [(1, 1, 4), (5, 4, 2), (64, 2, 4), (777, 8, 2), (6000, 4, 4), (6001, 8, 2), (20000, 4, 4)])
+def test_rows_forced_any_batch(ctx, monkeypatch, n_roots, waves, rpw):
+    """Forced (MP_UCT_ROWS=1) below and beyond its default range: ragged last workgroups, several rounds of workgroups, two or four
+    roots per wavefront (MP_UCT_ROW_ROOTS) in one to eight planning wavefronts per workgroup."""
     from rl_agents_amd.envs import generators
     monkeypatch.setenv("MP_UCT_ROWS", "1")
     monkeypatch.setenv("MP_UCT_LONE", "0")
     monkeypatch.setenv("MP_UCT_ROW_WAVES", str(waves))
+    monkeypatch.setenv("MP_UCT_ROW_ROOTS", str(rpw))
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     p = np.ones(5) / 5
     _cmp(ctx, cfg, n_roots, 12, 30, 0.8, 10.0, p, p, seed=n_roots + 1)
