@@ -56,6 +56,7 @@ def eq(a, b, what, case):
         raise AssertionError("{} differs in case {}".format(what, case))
 
 
+VARIANTS = {}
 HEAVY = os.environ.get("FUZZ_HEAVY") == "1"   # larger budgets / horizons / batches (slower: the oracle is the long pole)
 
 
@@ -99,7 +100,29 @@ def one_case(ctx, g, case):
     quad = str(g.choice(["", "", "0", "1"]))
     if quad and kind in ("uct", "uct_subtree", "per_root_models", "update_rows"):
         os.environ["MP_UCT_QUAD"] = quad
-    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad, wide=wide)
+    # round 6: the row kernel on a shared model (default for 16 .. 4096 roots where uct_lone_kernel does not apply) forced on / off,
+    # two / four roots per wavefront, one to eight planning wavefronts; on batch models the row / wavefront-per-root forms; batched
+    # VI's cluster form (K workgroups per MDP)
+    for knob in ("MP_UCT_ROWS", "MP_UCT_ROW_ROOTS", "MP_UCT_ROW_WAVES", "MP_UCT_ROW", "MP_UCT_EACH", "MP_VI_BATCH_CLUSTER"):
+        os.environ.pop(knob, None)
+    rows = str(g.choice(["", "", "0", "1"]))
+    if rows and not quad and kind in ("uct", "uct_subtree", "update_rows"):
+        os.environ["MP_UCT_ROWS"] = rows
+    rpw, rwaves = str(g.choice(["", "2", "4"])), str(g.choice(["", "1", "2", "4", "8"]))
+    if rpw:
+        os.environ["MP_UCT_ROW_ROOTS"] = rpw
+    if rwaves:
+        os.environ["MP_UCT_ROW_WAVES"] = rwaves
+    each = str(g.choice(["", "", "row0", "each0"]))
+    if each == "row0" and kind == "per_root_models":
+        os.environ["MP_UCT_ROW"] = "0"
+    if each == "each0" and kind == "per_root_models":
+        os.environ["MP_UCT_EACH"] = "0"
+    cluster = str(g.choice(["", "", "0", "2", "4", "8"]))
+    if cluster and kind == "vi_batch":
+        os.environ["MP_VI_BATCH_CLUSTER"] = cluster
+    desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad, wide=wide,
+                rows=rows, rpw=rpw, rwaves=rwaves, each=each, cluster=cluster)
     if kind in ("vi_batch", "per_root_models"):
         # N independent MDPs of this shape (mp_model_load_table_batch): N value-iteration agents in one launch, each to its own
         # allclose exit, in every kernel form; UCT and OPD with one MDP per root; a second round after mp_model_update_tables
@@ -621,6 +644,8 @@ def run(n_cases, seed, ctx=None, verbose=False):
             except Exception as e:     # a device error code: say which case it was
                 raise RuntimeError("case {} (seed {}): {}".format(case, seed, e))
             kinds[d["kind"]] = kinds.get(d["kind"], 0) + 1
+            v = ctx.last_kernel_variant()        # (the LAST launch of the case: which kernel forms the sweep reached)
+            VARIANTS[v] = VARIANTS.get(v, 0) + 1
             if verbose:
                 print(d)
     finally:
@@ -628,7 +653,8 @@ def run(n_cases, seed, ctx=None, verbose=False):
         os.environ.pop("MP_OPD_CLOSING", None)
         os.environ.pop("MP_OPD_LOOP", None)
         os.environ.pop("MP_OPD_WIDE", None)
-        os.environ.pop("MP_UCT_QUAD", None)
+        for knob in ("MP_UCT_QUAD", "MP_UCT_ROWS", "MP_UCT_ROW_ROOTS", "MP_UCT_ROW_WAVES", "MP_UCT_ROW", "MP_UCT_EACH", "MP_VI_BATCH_CLUSTER"):
+            os.environ.pop(knob, None)
         if forced is not None:
             os.environ["MP_OPD_MODEL"] = forced
     if own:
@@ -640,3 +666,4 @@ if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     print("ok", run(n, seed, verbose=os.environ.get("FUZZ_VERBOSE") == "1"))
+    print("last kernel form of each case:", dict(sorted(VARIANTS.items(), key=lambda kv: -kv[1])))
