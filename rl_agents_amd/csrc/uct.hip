@@ -119,6 +119,8 @@ struct UctArgs {
     const double *root_x; // CartPole roots: [n_roots][4] = x, x_dot, theta, theta_dot
     mp_cartpole_params cp;
     int cp_sincos;       // how CartPole's sin / cos are evaluated (libm_sincos.hpp: 0 device, 1 / 2 the host libm's forms)
+    int cp_fastdiv;      // 1: the parameters qualify for div_by_const (host check in the launch code)
+    double cp_inv_tm;    // RN(1 / total_mass)
     const double *tab; // gpow[H+1] | thr[A] (uint64 bits) | tp[A] | rcp[TE+1] | tpdiv[A][TE+2]
     uint64_t thr_arg[8]; // the same thresholds by value (|A| <= 8), SHIFTED UP by 11 bits (compared with the raw 64-bit draw; 2^53 -> ~0): kernel arguments live in SGPRs
     int thr_valid;       // how many of the first |A| - 1 thresholds are below 2^53 (the others can never be reached)
@@ -143,6 +145,21 @@ struct UctArgs {
 };
 
 
+// a / b for a CONSTANT b whose correctly rounded reciprocal y = RN(1 / b) the host supplies, as five multiply-adds: q0 = RN(a y) is
+// within two ulps of a / b, q1 = RN(q0 + r0 y) with the exact residual r0 = a - b q0 lies within 2^-100 of a / b before its rounding,
+// hence is a faithful quotient, and q2 = RN(q1 + r1 y) is then the CORRECTLY ROUNDED a / b (Markstein 1990; Muller et al., Handbook
+// of Floating-Point Arithmetic, ch. 4.7: holds unless b's significand is all ones) -- the same bits as the IEEE division, which
+// the hardware does in thirteen instructions (v_div_scale x 2, v_rcp, four refinements, v_div_fmas, v_div_fixup).  Exact while
+// the residuals are: a = 0, or 2^-960 <= |a| <= 2^1000 (the CartPole rollout proves that range from a bound on the pole's
+// velocity it tracks; see there); b normal.
+__device__ __forceinline__ double div_by_const(double a, double b, double y)
+{
+    const double q0 = a * y;
+    const double r0 = __fma_rn(-q0, b, a);
+    const double q1 = __fma_rn(r0, y, q0);
+    const double r1 = __fma_rn(-q1, b, a);
+    return __fma_rn(r1, y, q1);
+}
 // lane Q of every quad, to the quad's four lanes (DPP quad_perm Q,Q,Q,Q)
 template <int Q>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
@@ -304,6 +321,11 @@ void uct_kernel(UctArgs p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) x0[i] = p.root_x[(long)r * 4 + i];
     }
+    // The pipelined CartPole rollouts evaluate the RESTATED sin / cos without its range test (|x| < 0.855: libm_sincos.hpp).  A
+    // live step's angle is within the env's threshold, so they are used only where the threshold and every root angle of the wave
+    // are inside that range; anything else (a root handed over with the pole already down, a wide threshold) takes the generic
+    // rollout, whose cartpole_step tests the range per call.
+    const bool cart_flat = CART && p.cp_sincos != SINCOS_DEVICE && p.cp.theta_threshold < 0.8 && !any64(!(fabs(x0[2]) < 0.8));
     int n_nodes = p.n_nodes_in ? p.n_nodes_in[r] : 0; // > 0: tree kept by step_strategy "subtree"
     constexpr int AR = AT > 0 ? AT : 1;
     // RC: the root and its children (node ids 0..A: the root is always the first node to expand, and a re-rooted
@@ -620,22 +642,33 @@ void uct_kernel(UctArgs p)
                 }
             }
         } else
-        if (CART && p.cp_sincos != SINCOS_DEVICE && p.rep_shift >= 2) {
+        if (CART && cart_flat && p.rep_shift >= 2) {
             // ---- CartPole rollout, REPLICATED ROOTS (round 6).  The launch code gives a root 2^rep_shift >= 4 lanes that all compute
             // the same plan (why: see there).  What the replicas can do differently is numpy's generator: the action sequence of a
             // rollout does not depend on the states it visits (uniform policy), so lane j of a quad holds the generator j + 1 steps
             // ahead and jumps by four per round (as the four-lanes-per-root table kernel, QD above): a step takes its force from a
             // quad broadcast, and the 128-bit generator step is executed once per FOUR env steps.  The rollout is software-pipelined
             // as the one-lane form below (sin / cos of the next angle beside this step's accelerations).  The walk consumes n draws; the
-            // generator then jumps by exactly n.  (Tried and dropped: the three divisions by the constant total mass as Markstein's
-            // five multiply-adds on RN(1 / total_mass) -- exact, 8 instructions shorter each, and 7 % SLOWER: the hardware sequence's
-            // reciprocal refinement runs beside the numerator's chain, the short form is one serial chain; profiles/r06_cartpole.md.)  Every value is cartpole_step's, operation for operation (same bits: tests/test_gpu_cartpole.py).
+            // generator then jumps by exactly n.  The three divisions by the constant total mass take the short exact form (div_by_const; FD below).  Every value is cartpole_step's, operation for operation (same bits: tests/test_gpu_cartpole.py).
             bool alive = !terminal && depth < H;
             if (any64(alive)) {
                 const mp_cartpole_params &c = p.cp;
                 const double total_mass = c.masspole + c.masscart, polemass_length = c.masspole * c.length;
-                auto roll = [&](auto fma_tag) {
-                constexpr bool FMA_FORM = decltype(fma_tag)::value;
+                const double inv_tm = p.cp_inv_tm;
+                // FD: the three divisions by the constant total mass as div_by_const (24 vector instructions fewer per step: 0.336 ->
+                // 0.298 ms).  Its numerators stay in {0} U [2^-960, 2^1000] while the pole's angular velocity stays below 2^300 with
+                // parameters in [2^-50, 2^50] (host check): |a1| = |force + pml thd^2 sn| <= 2^701 and is 0 or >= ulp(force) / 2;
+                // masspole cs^2 >= 2^-52 for a live angle; |thetaacc| <= 2^752 / den_min <= 2^802, so |a3| = |pml thetaacc cs| <=
+                // 2^902, and a3 is 0 or >= 2^-901 (thetaacc = num / den with num = g sn - cs temp: 0, or >= 2^-209 when a1 != 0, or
+                // = g sn >= 2^-747 when a1 = 0, which needs |sn| >= 2^-697 under the velocity bound).  The rollout tracks max |thd|
+                // (one v_max_f64 per step, finished roots included: their values stay finite) and is REDONE with IEEE divisions if
+                // the bound failed or the velocity is not a number -- nothing is committed before.
+                auto roll = [&](auto fma_tag, auto fd_tag, bool alive) -> bool {   // (`alive` by value: a redo starts from the same state)
+                constexpr bool FMA_FORM = decltype(fma_tag)::value, FD = decltype(fd_tag)::value;
+                auto divc = [&](double a) -> double {
+                    if constexpr (FD) return div_by_const(a, total_mass, inv_tm);
+                    else return a / total_mass;
+                };
                 const bool want = alive;
                 const uint64_t st_lo = g.s_lo, st_hi = g.s_hi;      // (the state the final jump by n starts from)
                 Pcg64 q = g;
@@ -668,6 +701,7 @@ void uct_kernel(UctArgs p)
                 // BRANCH-FREE steps: a lane whose rollout ended keeps stepping on values nobody reads (only its return, its step
                 // count and `alive` are frozen), so a round of four steps is one basic block for the scheduler to interleave.
                 double ret = total;
+                double vmax = fabs(theta_dot);             // FD: the largest |angular velocity| a division of this rollout saw
                 while (true) {
                     const uint32_t f4[4] = {quad_bcast<0>(f_cur), quad_bcast<1>(f_cur), quad_bcast<2>(f_cur), quad_bcast<3>(f_cur)};
                     const uint32_t f_next = force_hi(q);
@@ -682,14 +716,15 @@ void uct_kernel(UctArgs p)
                         libm_sincos_small_flat<FMA_FORM>(theta_n, &sn_n, &cs_n, sctab);
                         // chain 2: this step's accelerations from sin / cos of the CURRENT angle
                         const double a1 = force + polemass_length * (theta_dot * theta_dot) * sn;
-                        const double temp = a1 / total_mass;
-                        const double thetaacc = (c.gravity * sn - cs * temp) / (c.length * (4.0 / 3.0 - c.masspole * (cs * cs) / total_mass));
-                        const double xacc = temp - polemass_length * thetaacc * cs / total_mass;
+                        const double temp = divc(a1);
+                        const double thetaacc = (c.gravity * sn - cs * temp) / (c.length * (4.0 / 3.0 - divc(c.masspole * (cs * cs))));
+                        const double xacc = temp - divc(polemass_length * thetaacc * cs);
                         const double gp = gpow[h];
                         const bool fell = x_n < -c.x_threshold || x_n > c.x_threshold || theta_n < -c.theta_threshold || theta_n > c.theta_threshold;
                         x = x_n; theta = theta_n;
                         x_dot = x_dot + c.tau * xacc;
                         theta_dot = theta_dot + c.tau * thetaacc;
+                        if constexpr (FD) vmax = fmax(vmax, fabs(theta_dot));
                         sn = sn_n; cs = cs_n;
                         ret = libm_select(alive, ret + gp * 1.0, ret);
                         h += alive ? 1 : 0;
@@ -702,6 +737,8 @@ void uct_kernel(UctArgs p)
                     f_cur = f_next;
                     if (!any64(alive)) break;
                 }
+                if constexpr (FD)
+                    if (any64(want && (!(vmax <= 0x1p300) || theta_dot != theta_dot))) return false;   // (the IEEE form runs it again)
                 total = ret;
                 const int n = h - depth;                   // env steps = draws of this rollout
                 st += n; steps_taken += n;
@@ -712,12 +749,13 @@ void uct_kernel(UctArgs p)
                     g.s_lo = st_lo; g.s_hi = st_hi;
                     g.jump(an, gn);
                 }
+                return true;
                 };
-                if (p.cp_sincos == SINCOS_LIBM_FMA) roll(std::true_type{});
-                else roll(std::false_type{});
+                if (p.cp_sincos == SINCOS_LIBM_FMA) { if (!p.cp_fastdiv || !roll(std::true_type{}, std::true_type{}, alive)) roll(std::true_type{}, std::false_type{}, alive); }
+                else { if (!p.cp_fastdiv || !roll(std::false_type{}, std::true_type{}, alive)) roll(std::false_type{}, std::false_type{}, alive); }
             }
         } else
-        if (CART && p.cp_sincos != SINCOS_DEVICE) {
+        if (CART && cart_flat) {
             // ---- CartPole rollout, SOFTWARE-PIPELINED (round 6).  A step's new positions depend on the OLD state only
             // (x + tau x_dot, theta + tau theta_dot), so the sin / cos of the NEXT angle can be evaluated while this step's
             // accelerations -- three IEEE divisions on the velocity chain -- are: two independent dependency chains in one basic
@@ -1951,6 +1989,23 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         }
     }
     a.cp = model->cp; a.cp_sincos = model->cp_sincos; a.root_x = nullptr;
+    a.cp_fastdiv = 0; a.cp_inv_tm = 0.0;
+    if (cart) {
+        // div_by_const's conditions (see the rollout): every parameter a numerator is built from within [2^-50, 2^50], the divisor
+        // normal with a significand that is not all ones, the other denominator bounded away from zero.  MP_CART_FASTDIV=0: A/B.
+        const mp_cartpole_params &cq = model->cp;
+        const double tm = cq.masspole + cq.masscart;
+        auto mid = [](double v) { return std::isfinite(v) && fabs(v) >= 0x1p-50 && fabs(v) <= 0x1p50; };
+        uint64_t bits;
+        memcpy(&bits, &tm, 8);
+        const char *e = getenv("MP_CART_FASTDIV");
+        if (mid(tm) && tm > 0 && (bits & ((1ULL << 52) - 1)) != (1ULL << 52) - 1 && mid(cq.masspole) && cq.masspole > 0 && mid(cq.length) &&
+            cq.length > 0 && mid(cq.force_mag) && mid(cq.gravity) && mid(cq.tau) && cq.length * (4.0 / 3.0 - cq.masspole / tm) >= 0x1p-50 &&
+            !(e && atoi(e) == 0)) {
+            a.cp_fastdiv = 1;
+            a.cp_inv_tm = 1.0 / tm;
+        }
+    }
     a.pol_prior = pol ? pol->prior : nullptr; a.pol_thr = pol ? pol->thr : nullptr; a.pol_frec = pol ? pol->frec : nullptr;
     a.pol_frec_roll = pol ? (pol->frec_roll ? pol->frec_roll : pol->frec) : nullptr;
     a.pol_stride = pol ? pol->stride : 0;

@@ -137,6 +137,37 @@ def test_cartpole_long_horizons(ctx, horizon):
     np.testing.assert_array_equal(rng, ref["rng_after"])
 
 
+def test_cartpole_extreme_roots_and_wide_threshold(ctx):
+    """What the fast forms of the rollout must hand back to the careful ones (round 6): roots whose angular velocity leaves the range
+    the short exact division is proven for (1e200, inf, nan: the rollout is redone with IEEE divisions), roots handed over with the
+    pole already far down and a threshold beyond the restated sin / cos range (the generic rollout tests the range per call)."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import CartPoleEnv
+    p = np.ones(2) / 2
+    n = 96
+    x0 = np.random.Generator(np.random.PCG64(3)).uniform(-0.05, 0.05, size=(n, 4))
+    x0[5, 3], x0[6, 3], x0[7, 3], x0[8, 3] = 1e200, -1e120, np.inf, np.nan      # velocities beyond the proven range
+    x0[20, 2], x0[21, 2], x0[22, 2] = 1.0, -2.5, 0.81                           # angles outside the restated range
+    x0[40, 1] = 1e300                                                            # (cart velocity: not in any division)
+    for thr in (None, 1.2):
+        params = CartPoleEnv().cartpole_params()
+        if thr is not None:
+            params = dict(params, theta_threshold=thr)
+        model = ctx.load_cartpole(params)
+        rng = native.seed_sequence_states((), 4242, n)
+        rng_ref = rng.copy()
+        with np.errstate(all="ignore"):
+            out = ctx.uct_plan(model, x0, 10, 30, 0.9, 5.0, p, p, rng, max_plan_len=6)
+            ref = oracle.uct_plan_batch(None, None, None, x0, 10, 30, 0.9, 5.0, p, p, rng_ref, max_plan_len=6, n_threads=4, cartpole=params)
+        np.testing.assert_array_equal(out["plans"], ref["plans"])
+        np.testing.assert_array_equal(out["env_steps"], ref["env_steps"])
+        assert np.array_equal(out["root_value"], ref["root_value"], equal_nan=True)
+        np.testing.assert_array_equal(out["root_child_count"], ref["root_child_count"])
+        np.testing.assert_array_equal(rng, ref["rng_after"])
+        model.close()
+
+
 def test_device_sincos_equals_host_libm_on_ten_million_angles(ctx):
     """The device's restated sin / cos (the form mp_libm_sincos_variant picked for this host) against the host libm's --
     math.sin / math.cos, what gymnasium's CartPole calls -- on 10^7 angles: the pole's range, the whole restated range
