@@ -65,6 +65,19 @@ struct Pcg64 {
     {
         mul_add<0x42D45771u, 0xD194DFBEu, 0x27DB7A9Bu, 0xF4DD4173u>(g4_lo, g4_hi);
     }
+    // the same for k = 16: A^16 = 0xB6A4239F3B315F84_F6EF6D3D288C03C1, G_16 = 0x6ED699DB168FB143_A9072151352439F0 (Python integers;
+    // every CartPole rollout of sixteen-lane replicas compares the generator it leaves with numpy's)
+    __device__ __forceinline__ void inc_g16(uint64_t &lo, uint64_t &hi) const
+    {
+        Pcg64 t = *this;
+        t.s_lo = inc_lo; t.s_hi = inc_hi;
+        t.mul_add<0x352439F0u, 0xA9072151u, 0x168FB143u, 0x6ED699DBu>(0, 0);
+        lo = t.s_lo; hi = t.s_hi;
+    }
+    __device__ __forceinline__ void advance16(uint64_t g16_lo, uint64_t g16_hi)
+    {
+        mul_add<0x288C03C1u, 0xF6EF6D3Du, 0x3B315F84u, 0xB6A4239Fu>(g16_lo, g16_hi);
+    }
     // state <- A^n state + inc G_n for a PER-LANE n: the limbs of A^n and G_n come from a table (VGPR multipliers)
     __device__ __forceinline__ static uint64_t mad64v(uint32_t a, uint32_t m, uint64_t c)
     {

@@ -160,6 +160,12 @@ __device__ __forceinline__ double div_by_const(double a, double b, double y)
     const double r1 = __fma_rn(-q1, b, a);
     return __fma_rn(r1, y, q1);
 }
+// lane I of every DPP row (16 lanes), to the row's lanes (row_newbcast:I)
+template <int I>
+__device__ __forceinline__ uint32_t row_bcast(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x150 + I, 0xf, 0xf, false);
+}
 // lane Q of every quad, to the quad's four lanes (DPP quad_perm Q,Q,Q,Q)
 template <int Q>
 __device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
@@ -196,10 +202,6 @@ enum { ENV_TABLE = 0, ENV_TABLE_LDS = 1, ENV_CARTPOLE = 2, ENV_TABLE_LDSR = 3, E
 
 // AT > 0: |A| known at compile time (children scored from registers in one pass);
 // AT == 0: any |A| (three passes over the children).  ENV: where an env step comes from.
-// CartPole's replicated-root rollout: test for "every root of the wave is done" after every step (1) or every round of four (4)
-#ifndef MP_CART_CHECK_EVERY
-#define MP_CART_CHECK_EVERY 4
-#endif
 #ifndef MP_UCT_MIN_WAVES
 #define MP_UCT_MIN_WAVES 1
 #endif
@@ -311,6 +313,8 @@ void uct_kernel(UctArgs p)
     g.load(p.rng + (long)r * 6);
     uint64_t g4_lo = 0, g4_hi = 0;          // QD: inc * G_4, the additive term of a four-step jump of this root's generator
     if (QD || (CART && p.rep_shift >= 2)) g.inc_g4(g4_lo, g4_hi);
+    uint64_t g16_lo = 0, g16_hi = 0;        // CartPole, sixteen replicas: inc * G_16
+    if (CART && p.rep_shift >= 4) g.inc_g16(g16_lo, g16_hi);
     const int32_t s0 = CART ? 0 : p.root_state[r];
     const int32_t st0 = p.root_steps ? p.root_steps[r] : 0;
     const uint32_t done_bit = p.done_on_next ? 2u : 1u;
@@ -663,8 +667,11 @@ void uct_kernel(UctArgs p)
                 // = g sn >= 2^-747 when a1 = 0, which needs |sn| >= 2^-697 under the velocity bound).  The rollout tracks max |thd|
                 // (one v_max_f64 per step, finished roots included: their values stay finite) and is REDONE with IEEE divisions if
                 // the bound failed or the velocity is not a number -- nothing is committed before.
-                auto roll = [&](auto fma_tag, auto fd_tag, bool alive) -> bool {   // (`alive` by value: a redo starts from the same state)
+                // RL: draws per round = lanes of a root that hold the generator at consecutive steps -- 4 (a quad) or, with sixteen
+                // replicas, 16 (a DPP row: the generator step once per SIXTEEN env steps)
+                auto roll = [&](auto fma_tag, auto fd_tag, auto rl_tag, bool alive) -> bool {   // (`alive` by value: a redo starts from the same state)
                 constexpr bool FMA_FORM = decltype(fma_tag)::value, FD = decltype(fd_tag)::value;
+                constexpr int RL = decltype(rl_tag)::value;
                 auto divc = [&](double a) -> double {
                     if constexpr (FD) return div_by_const(a, total_mass, inv_tm);
                     else return a / total_mass;
@@ -673,12 +680,13 @@ void uct_kernel(UctArgs p)
                 const uint64_t st_lo = g.s_lo, st_hi = g.s_hi;      // (the state the final jump by n starts from)
                 Pcg64 q = g;
                 {
-                    const int j1 = (lane & 3) + 1;
+                    const int j1 = min((lane & (RL - 1)) + 1, H);     // (draws beyond the horizon are never used)
                     uint32_t an[4], gn[4];
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { an[i] = cjump[j1 * 8 + i]; gn[i] = cjump[j1 * 8 + 4 + i]; }
                     q.jump(an, gn);
                 }
+                auto next_round = [&] { if constexpr (RL == 16) q.advance16(g16_lo, g16_hi); else q.advance4(g4_lo, g4_hi); };
                 // the high word of the force this lane's draw selects (+- force_mag differ in the sign bit only)
                 const int f_lo = __double2loint(c.force_mag);
                 const uint32_t f_pos = (uint32_t)__double2hiint(c.force_mag), f_neg = (uint32_t)__double2hiint(-c.force_mag);
@@ -691,7 +699,7 @@ void uct_kernel(UctArgs p)
                     return act == 1 ? f_pos : f_neg;
                 };
                 uint32_t f_cur = force_hi(q);
-                q.advance4(g4_lo, g4_hi);
+                next_round();
                 int h = depth;
                 // the step after which the rollout stops at the latest: the horizon, or the environment's step limit
                 const int hmax = p.max_steps > 0 ? min(H, depth + p.max_steps - st) : H;
@@ -702,37 +710,50 @@ void uct_kernel(UctArgs p)
                 // count and `alive` are frozen), so a round of four steps is one basic block for the scheduler to interleave.
                 double ret = total;
                 double vmax = fabs(theta_dot);             // FD: the largest |angular velocity| a division of this rollout saw
-                while (true) {
-                    const uint32_t f4[4] = {quad_bcast<0>(f_cur), quad_bcast<1>(f_cur), quad_bcast<2>(f_cur), quad_bcast<3>(f_cur)};
-                    const uint32_t f_next = force_hi(q);
-                    q.advance4(g4_lo, g4_hi);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const double force = __hiloint2double((int)f4[i], f_lo);
-                        // chain 1: the new positions, then the sin / cos the NEXT step needs
-                        const double x_n = x + c.tau * x_dot;
-                        const double theta_n = theta + c.tau * theta_dot;
-                        double sn_n, cs_n;
-                        libm_sincos_small_flat<FMA_FORM>(theta_n, &sn_n, &cs_n, sctab);
-                        // chain 2: this step's accelerations from sin / cos of the CURRENT angle
-                        const double a1 = force + polemass_length * (theta_dot * theta_dot) * sn;
-                        const double temp = divc(a1);
-                        const double thetaacc = (c.gravity * sn - cs * temp) / (c.length * (4.0 / 3.0 - divc(c.masspole * (cs * cs))));
-                        const double xacc = temp - divc(polemass_length * thetaacc * cs);
-                        const double gp = gpow[h];
-                        const bool fell = x_n < -c.x_threshold || x_n > c.x_threshold || theta_n < -c.theta_threshold || theta_n > c.theta_threshold;
-                        x = x_n; theta = theta_n;
-                        x_dot = x_dot + c.tau * xacc;
-                        theta_dot = theta_dot + c.tau * thetaacc;
-                        if constexpr (FD) vmax = fmax(vmax, fabs(theta_dot));
-                        sn = sn_n; cs = cs_n;
-                        ret = libm_select(alive, ret + gp * 1.0, ret);
-                        h += alive ? 1 : 0;
+                auto one_step = [&](uint32_t f_hi) {
+                    const double force = __hiloint2double((int)f_hi, f_lo);
+                    // chain 1: the new positions, then the sin / cos the NEXT step needs
+                    const double x_n = x + c.tau * x_dot;
+                    const double theta_n = theta + c.tau * theta_dot;
+                    double sn_n, cs_n;
+                    libm_sincos_small_flat<FMA_FORM>(theta_n, &sn_n, &cs_n, sctab);
+                    // chain 2: this step's accelerations from sin / cos of the CURRENT angle
+                    const double a1 = force + polemass_length * (theta_dot * theta_dot) * sn;
+                    const double temp = divc(a1);
+                    const double thetaacc = (c.gravity * sn - cs * temp) / (c.length * (4.0 / 3.0 - divc(c.masspole * (cs * cs))));
+                    const double xacc = temp - divc(polemass_length * thetaacc * cs);
+                    const double gp = gpow[h];
+                    // (x < -T || x > T is |x| > T for every T, NaN included: two compares instead of four)
+                    const bool fell = fabs(x_n) > c.x_threshold || fabs(theta_n) > c.theta_threshold;
+                    x = x_n; theta = theta_n;
+                    x_dot = x_dot + c.tau * xacc;
+                    theta_dot = theta_dot + c.tau * thetaacc;
+                    if constexpr (FD) vmax = fmax(vmax, fabs(theta_dot));
+                    sn = sn_n; cs = cs_n;
+                    ret = libm_select(alive, ret + gp * 1.0, ret);
+                    h += alive ? 1 : 0;
 #ifdef MP_PROFILE
-                        n_roll += alive ? 1 : 0;
+                    n_roll += alive ? 1 : 0;
 #endif
-                        alive = alive && !(fell || h >= hmax);
-                        if (MP_CART_CHECK_EVERY == 1 && !any64(alive)) break;
+                    alive = alive && !(fell || h >= hmax);
+                };
+                while (true) {
+                    const uint32_t f_next = force_hi(q);
+                    next_round();
+                    if constexpr (RL == 4) {
+                        one_step(quad_bcast<0>(f_cur)); one_step(quad_bcast<1>(f_cur)); one_step(quad_bcast<2>(f_cur)); one_step(quad_bcast<3>(f_cur));
+                    } else {
+                        // (the test "is every root of the wave done" after every four steps, as with quads)
+                        one_step(row_bcast<0>(f_cur)); one_step(row_bcast<1>(f_cur)); one_step(row_bcast<2>(f_cur)); one_step(row_bcast<3>(f_cur));
+                        if (any64(alive)) {
+                            one_step(row_bcast<4>(f_cur)); one_step(row_bcast<5>(f_cur)); one_step(row_bcast<6>(f_cur)); one_step(row_bcast<7>(f_cur));
+                            if (any64(alive)) {
+                                one_step(row_bcast<8>(f_cur)); one_step(row_bcast<9>(f_cur)); one_step(row_bcast<10>(f_cur)); one_step(row_bcast<11>(f_cur));
+                                if (any64(alive)) {
+                                    one_step(row_bcast<12>(f_cur)); one_step(row_bcast<13>(f_cur)); one_step(row_bcast<14>(f_cur)); one_step(row_bcast<15>(f_cur));
+                                }
+                            }
+                        }
                     }
                     f_cur = f_next;
                     if (!any64(alive)) break;
@@ -751,8 +772,13 @@ void uct_kernel(UctArgs p)
                 }
                 return true;
                 };
-                if (p.cp_sincos == SINCOS_LIBM_FMA) { if (!p.cp_fastdiv || !roll(std::true_type{}, std::true_type{}, alive)) roll(std::true_type{}, std::false_type{}, alive); }
-                else { if (!p.cp_fastdiv || !roll(std::false_type{}, std::true_type{}, alive)) roll(std::false_type{}, std::false_type{}, alive); }
+                auto run = [&](auto fma_tag, auto rl_tag) {
+                    if (!p.cp_fastdiv || !roll(fma_tag, std::true_type{}, rl_tag, alive)) roll(fma_tag, std::false_type{}, rl_tag, alive);
+                };
+                typedef std::integral_constant<int, 4> R4;
+                typedef std::integral_constant<int, 16> R16;
+                if (p.cp_sincos == SINCOS_LIBM_FMA) { if (p.rep_shift >= 4) run(std::true_type{}, R16{}); else run(std::true_type{}, R4{}); }
+                else { if (p.rep_shift >= 4) run(std::false_type{}, R16{}); else run(std::false_type{}, R4{}); }
             }
         } else
         if (CART && cart_flat) {
