@@ -221,7 +221,8 @@ int mp_model_load_cartpole(mp_ctx *ctx, const mp_cartpole_params *params, mp_mod
  *   (SSE2 / AVX variants), 0 = neither matched the host's sin / cos on the probe sample -- the device then uses its own
  *   math library and CartPole plans carry the tolerance of rounds 1-4 (>= 99.5 % of roots identical); host only, cached.
  *   mp_libm_sincos: the restated functions on the HOST, variant 1 / 2 (0 = libm itself): s[i], c[i] = sin, cos of x[i].
- *   mp_selftest_sincos: the same on the DEVICE (host arrays in / out) -- tests compare 10^7 angles with the host's libm.
+ *   mp_selftest_sincos: the same on the DEVICE (host arrays in / out) -- tests compare 10^7 angles with the host's libm;
+ *   variant 3 / 4: the branch-free forms of variant 1 / 2 that the CartPole rollouts evaluate (|x| < 0.855 only).
  */
 int mp_libm_sincos_variant(void);
 int mp_libm_sincos(int32_t n, const double *x, int32_t variant, double *s, double *c);

@@ -1366,14 +1366,18 @@ namespace mp {
 __global__ void sincos_selftest_kernel(int n, int variant, const double *__restrict__ x, double *__restrict__ s, double *__restrict__ c)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) libm_sincos(variant, x[i], &s[i], &c[i]);
+    if (i >= n) return;
+    // 3 / 4: the branch-free forms the CartPole rollouts evaluate (FMA-contracted / every operation rounded), valid for |x| < 0.855
+    if (variant == 3) libm_sincos_small_flat<true>(x[i], &s[i], &c[i]);
+    else if (variant == 4) libm_sincos_small_flat<false>(x[i], &s[i], &c[i]);
+    else libm_sincos(variant, x[i], &s[i], &c[i]);
 }
 } // namespace mp
 }
 
 int mp_selftest_sincos(mp_ctx *ctx, int32_t n, const double *x, int32_t variant, double *s, double *c)
 {
-    if (!ctx || n < 1 || !x || !s || !c || variant < 0 || variant > 2) return fail(MP_ERR_ARG, "mp_selftest_sincos: bad argument");
+    if (!ctx || n < 1 || !x || !s || !c || variant < 0 || variant > 4) return fail(MP_ERR_ARG, "mp_selftest_sincos: bad argument");
     MP_HIP(hipSetDevice(ctx->device));
     double *d = nullptr;
     MP_HIP(hipMalloc(&d, (size_t)n * 3 * sizeof(double)));

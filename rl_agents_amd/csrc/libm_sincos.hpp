@@ -199,48 +199,35 @@ __host__ __device__ __forceinline__ void libm_sincos_small_flat(double x, double
     int i4 = libm_low_word(u) << 2;
     i4 = i4 < 0 ? 0 : (i4 > MP_SINCOS_ENTRIES - 4 ? MP_SINCOS_ENTRIES - 4 : i4);
     const double sn = tab[i4], ssn = tab[i4 + 1], cs = tab[i4 + 2], ccs = tab[i4 + 3];
+    // What the two table paths share.  cos works on r = r0 + dx with dx = +-0: that IS r0, bit for bit (r0 = ax - (u - big) is never
+    // -0, and r0 + (+-0) = r0 otherwise), so xx, r xx, the two polynomials and xx q are common; and sin's c = fma(r, dx, xx q) (plain
+    // form: r dx + xx q) equals xx q, bit for bit: r dx = +-0 changes nothing unless xx q = 0, i.e. r = 0, where both give +0.
     double sin_table, cos_table;
-    {   // sin
-        const double dx = x <= 0 ? -0.0 : 0.0;
+    {
         const double r = r0;
         const double xx = r * r;
-        double s, c, cor;
+        const double dxs = x <= 0 ? -0.0 : 0.0;
+        double s_sin, s_cos, c, cor_sin, cor_cos;
         if (FMA) {
             const double p = libm_fma(xx, K::sn5, K::sn3);
-            s = r + libm_fma(r * xx, p, dx);
-            double q = libm_fma(xx, K::cs6, K::cs4);
-            q = libm_fma(xx, q, K::cs2);
-            c = libm_fma(r, dx, xx * q);
-            const double e1 = libm_fma(s, ccs, ssn);
-            const double e2 = libm_fma(-c, sn, e1);
-            cor = libm_fma(s, cs, e2);
-        } else {
-            s = r + (dx + r * xx * (K::sn3 + xx * K::sn5));
-            c = r * dx + xx * (K::cs2 + xx * (K::cs4 + xx * K::cs6));
-            cor = (ssn + s * ccs - sn * c) + cs * s;
-        }
-        sin_table = copysign(sn + cor, x);
-    }
-    {   // cos
-        const double dx = x < 0 ? -0.0 : 0.0;
-        const double r = r0 + dx;
-        const double xx = r * r;
-        double s, c, cor;
-        if (FMA) {
-            const double p = libm_fma(xx, K::sn5, K::sn3);
-            s = libm_fma(r * xx, p, r);
+            const double rxx = r * xx;
+            s_sin = r + libm_fma(rxx, p, dxs);
+            s_cos = libm_fma(rxx, p, r);
             double q = libm_fma(xx, K::cs6, K::cs4);
             q = libm_fma(xx, q, K::cs2);
             c = xx * q;
-            const double e1 = libm_fma(-s, ssn, ccs);
-            const double e2 = libm_fma(-c, cs, e1);
-            cor = libm_fma(-s, sn, e2);
+            cor_sin = libm_fma(s_sin, cs, libm_fma(-c, sn, libm_fma(s_sin, ccs, ssn)));
+            cor_cos = libm_fma(-s_cos, sn, libm_fma(-c, cs, libm_fma(-s_cos, ssn, ccs)));
         } else {
-            s = r + r * xx * (K::sn3 + xx * K::sn5);
+            const double rp = r * xx * (K::sn3 + xx * K::sn5);
+            s_sin = r + (dxs + rp);
+            s_cos = r + rp;
             c = xx * (K::cs2 + xx * (K::cs4 + xx * K::cs6));
-            cor = (ccs - s * ssn - cs * c) - sn * s;
+            cor_sin = (ssn + s_sin * ccs - sn * c) + cs * s_sin;
+            cor_cos = (ccs - s_cos * ssn - cs * c) - sn * s_cos;
         }
-        cos_table = cs + cor;
+        sin_table = copysign(sn + cor_sin, x);
+        cos_table = cs + cor_cos;
     }
     // (selects the compiler cannot turn back into branches around the regimes' arithmetic -- it did, with the plain ternaries)
     *s_out = libm_select(k < 0x3e500000u, x, libm_select(ax < 0.126, sin_taylor, sin_table));

@@ -186,6 +186,10 @@ def test_device_sincos_equals_host_libm_on_ten_million_angles(ctx):
     import math
     probe = x[::5000]
     assert [math.sin(v) for v in probe] == s_dev[::5000].tolist() and [math.cos(v) for v in probe] == c_dev[::5000].tolist()
+    # the BRANCH-FREE form the rollouts evaluate (round 6: every regime computed, the table paths' common work shared): same bits
+    inside = np.abs(x) < 0.855468                         # (it has no range test: the rollouts use it under their own, uct.hip cart_flat)
+    s_flat, c_flat = ctx.selftest_sincos(x[inside], variant + 2)
+    assert inside.sum() > 9_999_000 and np.array_equal(s_flat, s_host[inside]) and np.array_equal(c_flat, c_host[inside])
     # outside the restated range (no pole angle gets there) the device math library answers: close, not claimed equal
     far = g.uniform(0.9, 6.0, 1000)
     s_far, c_far = ctx.selftest_sincos(far, variant)
