@@ -231,7 +231,9 @@ __host__ __device__ __forceinline__ void libm_sincos_small_flat(double x, double
     }
     // (selects the compiler cannot turn back into branches around the regimes' arithmetic -- it did, with the plain ternaries)
     *s_out = libm_select(k < 0x3e500000u, x, libm_select(ax < 0.126, sin_taylor, sin_table));
-    *c_out = libm_select(k < 0x3e400000u, 1.0, cos_table);
+    // (libm answers 1.0 below 2^-27 without computing; the table path's value there IS 1.0 -- grid point 0 has sn = ssn = ccs = 0,
+    // cs = 1, so cos_table = 1 - xx q with xx q < 2^-55 -- and no select is needed; tests compare the tiny angles too)
+    *c_out = cos_table;
 }
 
 enum { SINCOS_DEVICE = 0, SINCOS_LIBM_FMA = 1, SINCOS_LIBM_PLAIN = 2 };
