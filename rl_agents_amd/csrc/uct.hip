@@ -710,6 +710,107 @@ void uct_kernel(UctArgs p)
                 // count and `alive` are frozen), so a round of four steps is one basic block for the scheduler to interleave.
                 double ret = total;
                 double vmax = fabs(theta_dot);             // FD: the largest |angular velocity| a division of this rollout saw
+                // The same step with its instruction stream ORDERED BY HAND (FMA form of the host libm + the short exact divisions: what
+                // an MI355X host runs).  A lone wave issues in order -- a dependent f64 instruction ~10 cycles after its producer, an
+                // independent one after ~5 (tools/ilp_rate.hip) -- and the compiler emits the step's chains one after the other
+                // (profiles/r06_cartpole.md).  Here the chains are written side by side, one operation of each per group, and an EMPTY
+                // asm volatile that "modifies" the group's results ties them together: the next operation of every chain then has to be
+                // emitted after it (a scheduling barrier alone does not do it: instruction selection linearises the block chain by chain
+                // before the machine scheduler sees the barrier).  The chains: the velocity recurrence (a1 -> temp -> num -> thetaacc),
+                // the other divisor (masspole cs^2 / m -> den), sin's Taylor polynomial and the table path of sin / cos of the NEXT
+                // angle, then the IEEE division (the compiler's own sequence, spelled out) beside the table path's corrections, then the
+                // last short division beside the bookkeeping.  Operation for operation the arithmetic of one_step below (which stays
+                // for the other forms): the same bits.
+#define MP_T2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#define MP_T3(a, b, c_) asm volatile("" : "+v"(a), "+v"(b), "+v"(c_))
+#define MP_T4(a, b, c_, d) asm volatile("" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d))
+#define MP_T5(a, b, c_, d, e) asm volatile("" : "+v"(a), "+v"(b), "+v"(c_), "+v"(d), "+v"(e))
+                auto one_step_il = [&](uint32_t f_hi) {
+                    typedef LibmConst K;
+                    const double m = total_mass, y = inv_tm;
+                    const double force = __hiloint2double((int)f_hi, f_lo);
+                    double txd = c.tau * x_dot, tthd = c.tau * theta_dot, thd2 = theta_dot * theta_dot, cs2 = cs * cs;
+                    MP_T4(txd, tthd, thd2, cs2);
+                    double x_n = x + txd, th_n = theta + tthd, t2 = polemass_length * thd2, a2 = c.masspole * cs2, gsn = c.gravity * sn;
+                    MP_T5(x_n, th_n, t2, a2, gsn);
+                    const double ax = fabs(th_n);
+                    double u = K::big + ax, t3 = t2 * sn, qa0 = a2 * y, xxt = th_n * th_n;
+                    MP_T4(u, t3, qa0, xxt);
+                    double ub = u - K::big, a1 = force + t3, ra0 = __fma_rn(-qa0, m, a2), pt = __fma_rn(xxt, K::s5, K::s4);
+                    int i4 = libm_low_word(u) << 2;
+                    i4 = i4 < 0 ? 0 : (i4 > MP_SINCOS_ENTRIES - 4 ? MP_SINCOS_ENTRIES - 4 : i4);
+                    const double tsn = sctab[i4], tssn = sctab[i4 + 1], tcs = sctab[i4 + 2], tccs = sctab[i4 + 3];
+                    const double gp = gpow[h];
+                    MP_T4(ub, a1, ra0, pt);
+                    double r = ax - ub, q0 = a1 * y, qa1 = __fma_rn(ra0, y, qa0);
+                    pt = __fma_rn(xxt, pt, K::s3);
+                    MP_T4(r, q0, qa1, pt);
+                    double xx = r * r, r0m = __fma_rn(-q0, m, a1), ra1 = __fma_rn(-qa1, m, a2);
+                    pt = __fma_rn(xxt, pt, K::s2);
+                    MP_T4(xx, r0m, ra1, pt);
+                    double rxx = r * xx, pp = __fma_rn(xx, K::sn5, K::sn3), q1 = __fma_rn(r0m, y, q0), a2q = __fma_rn(ra1, y, qa1);
+                    pt = __fma_rn(xxt, pt, K::s1);
+                    MP_T5(rxx, pp, q1, a2q, pt);
+                    double qq = __fma_rn(xx, K::cs6, K::cs4), r1m = __fma_rn(-q1, m, a1), dd = 4.0 / 3.0 - a2q, tt = __fma_rn(th_n, pt, -0.0);
+                    const double dxs = th_n <= 0 ? -0.0 : 0.0;
+                    MP_T4(qq, r1m, dd, tt);
+                    qq = __fma_rn(xx, qq, K::cs2);
+                    double s_cos = __fma_rn(rxx, pp, r), temp = __fma_rn(r1m, y, q1), den = c.length * dd;
+                    tt = __fma_rn(tt, xxt, 0.0);
+                    MP_T5(qq, s_cos, temp, den, tt);
+                    double cc = xx * qq, ssi = __fma_rn(rxx, pp, dxs), cst = cs * temp, sin_taylor = th_n + tt;
+                    MP_T4(cc, ssi, cst, sin_taylor);
+                    double s_sin = r + ssi, num = gsn - cst;
+                    MP_T2(s_sin, num);
+                    // thetaacc = num / den: v_div_scale x 2, v_rcp, two refinements, quotient, residual, v_div_fmas, v_div_fixup
+                    bool fl0, fl1;
+                    double d0 = __builtin_amdgcn_div_scale(num, den, false, &fl0);
+                    double e1s = __fma_rn(s_sin, tccs, tssn), e1c = __fma_rn(-s_cos, tssn, tccs);
+                    MP_T3(d0, e1s, e1c);
+                    double d1 = __builtin_amdgcn_div_scale(num, den, true, &fl1);
+                    double rr = __builtin_amdgcn_rcp(d0);
+                    double e2s = __fma_rn(-cc, tsn, e1s), e2c = __fma_rn(-cc, tcs, e1c);
+                    MP_T4(d1, rr, e2s, e2c);
+                    double ea = __fma_rn(-d0, rr, 1.0), cor_s = __fma_rn(s_sin, tcs, e2s), cor_c = __fma_rn(-s_cos, tsn, e2c);
+                    MP_T3(ea, cor_s, cor_c);
+                    rr = __fma_rn(rr, ea, rr);
+                    double sin_tab0 = tsn + cor_s, cs_n = tcs + cor_c;
+                    MP_T3(rr, sin_tab0, cs_n);
+                    double eb = __fma_rn(-d0, rr, 1.0), sin_tab = copysign(sin_tab0, th_n);
+                    const bool fell = fabs(x_n) > c.x_threshold || fabs(th_n) > c.theta_threshold;
+                    MP_T2(eb, sin_tab);
+                    rr = __fma_rn(rr, eb, rr);
+                    double sn_n = libm_select(libm_high_abs(th_n) < 0x3e500000u, th_n, libm_select(ax < 0.126, sin_taylor, sin_tab));
+                    MP_T2(rr, sn_n);
+                    double qd = d1 * rr;
+                    ret = libm_select(alive, ret + gp * 1.0, ret);
+                    MP_T2(qd, ret);
+                    double ec = __fma_rn(-d0, qd, d1);
+                    h += alive ? 1 : 0;
+                    alive = alive && !(fell || h >= hmax);
+                    double qf = __builtin_amdgcn_div_fmas(ec, rr, qd, fl1);
+                    const double thetaacc = __builtin_amdgcn_div_fixup(qf, den, num);
+                    double a3a = polemass_length * thetaacc, tth = c.tau * thetaacc;
+                    MP_T2(a3a, tth);
+                    double a3 = a3a * cs, thd_n = theta_dot + tth;
+                    MP_T2(a3, thd_n);
+                    const double q30 = a3 * y;
+                    vmax = fmax(vmax, fabs(thd_n));
+                    const double r30 = __fma_rn(-q30, m, a3);
+                    const double q31 = __fma_rn(r30, y, q30);
+                    const double r31 = __fma_rn(-q31, m, a3);
+                    const double q3 = __fma_rn(r31, y, q31);
+                    const double xacc = temp - q3;
+                    const double txa = c.tau * xacc;
+                    x = x_n; theta = th_n;
+                    x_dot = x_dot + txa;
+                    theta_dot = thd_n;
+                    sn = sn_n; cs = cs_n;
+                };
+#undef MP_T2
+#undef MP_T3
+#undef MP_T4
+#undef MP_T5
                 auto one_step = [&](uint32_t f_hi) {
                     const double force = __hiloint2double((int)f_hi, f_lo);
                     // chain 1: the new positions, then the sin / cos the NEXT step needs
@@ -737,20 +838,27 @@ void uct_kernel(UctArgs p)
 #endif
                     alive = alive && !(fell || h >= hmax);
                 };
+                auto step = [&](uint32_t f_hi) {
+#ifndef MP_CART_NO_IL
+                    if constexpr (FMA_FORM && FD) one_step_il(f_hi); else one_step(f_hi);
+#else
+                    one_step(f_hi);
+#endif
+                };
                 while (true) {
                     const uint32_t f_next = force_hi(q);
                     next_round();
                     if constexpr (RL == 4) {
-                        one_step(quad_bcast<0>(f_cur)); one_step(quad_bcast<1>(f_cur)); one_step(quad_bcast<2>(f_cur)); one_step(quad_bcast<3>(f_cur));
+                        step(quad_bcast<0>(f_cur)); step(quad_bcast<1>(f_cur)); step(quad_bcast<2>(f_cur)); step(quad_bcast<3>(f_cur));
                     } else {
                         // (the test "is every root of the wave done" after every four steps, as with quads)
-                        one_step(row_bcast<0>(f_cur)); one_step(row_bcast<1>(f_cur)); one_step(row_bcast<2>(f_cur)); one_step(row_bcast<3>(f_cur));
+                        step(row_bcast<0>(f_cur)); step(row_bcast<1>(f_cur)); step(row_bcast<2>(f_cur)); step(row_bcast<3>(f_cur));
                         if (any64(alive)) {
-                            one_step(row_bcast<4>(f_cur)); one_step(row_bcast<5>(f_cur)); one_step(row_bcast<6>(f_cur)); one_step(row_bcast<7>(f_cur));
+                            step(row_bcast<4>(f_cur)); step(row_bcast<5>(f_cur)); step(row_bcast<6>(f_cur)); step(row_bcast<7>(f_cur));
                             if (any64(alive)) {
-                                one_step(row_bcast<8>(f_cur)); one_step(row_bcast<9>(f_cur)); one_step(row_bcast<10>(f_cur)); one_step(row_bcast<11>(f_cur));
+                                step(row_bcast<8>(f_cur)); step(row_bcast<9>(f_cur)); step(row_bcast<10>(f_cur)); step(row_bcast<11>(f_cur));
                                 if (any64(alive)) {
-                                    one_step(row_bcast<12>(f_cur)); one_step(row_bcast<13>(f_cur)); one_step(row_bcast<14>(f_cur)); one_step(row_bcast<15>(f_cur));
+                                    step(row_bcast<12>(f_cur)); step(row_bcast<13>(f_cur)); step(row_bcast<14>(f_cur)); step(row_bcast<15>(f_cur));
                                 }
                             }
                         }

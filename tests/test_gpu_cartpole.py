@@ -90,10 +90,11 @@ def test_cartpole_every_replication_factor_vs_oracle(ctx, n):
     np.testing.assert_array_equal(rng, ref["rng_after"])
 
 
-@pytest.mark.parametrize("lanes,rep", [(16, 0), (16, 2), (8, 3), (4, 2), (2, 5), (1, 6), (64, 0)])
-def test_cartpole_forced_layouts_agree(ctx, monkeypatch, lanes, rep):
-    """MP_UCT_LANES x MP_UCT_CART_REP (roots per wave x lanes per root, tools/cart_sweep.sh's knobs): the same plans, statistics
-    and generator records as the default layout."""
+@pytest.mark.parametrize("lanes,rep,fastdiv", [(16, 0, 1), (16, 2, 1), (8, 3, 0), (4, 2, 1), (4, 4, 0), (2, 5, 1), (1, 6, 0), (64, 0, 1)])
+def test_cartpole_forced_layouts_agree(ctx, monkeypatch, lanes, rep, fastdiv):
+    """MP_UCT_LANES x MP_UCT_CART_REP (roots per wave x lanes per root, tools/cart_sweep.sh's knobs), with the short exact divisions
+    and the hand-ordered step (default) or the IEEE divisions and the compiler-ordered step (MP_CART_FASTDIV=0): the same plans,
+    statistics and generator records as the default layout."""
     from rl_agents_amd import native
     from rl_agents_amd.envs import CartPoleEnv
     model = ctx.load_cartpole(CartPoleEnv().cartpole_params())
@@ -109,6 +110,7 @@ def test_cartpole_forced_layouts_agree(ctx, monkeypatch, lanes, rep):
     base, rng_base = plan()
     monkeypatch.setenv("MP_UCT_LANES", str(lanes))
     monkeypatch.setenv("MP_UCT_CART_REP", str(rep))
+    monkeypatch.setenv("MP_CART_FASTDIV", str(fastdiv))
     got, rng_got = plan()
     for k in ("plans", "plan_len", "env_steps", "root_value", "root_child_count", "root_child_value"):
         np.testing.assert_array_equal(got[k], base[k], err_msg=k)
