@@ -140,6 +140,34 @@ def lib_path():
     return os.environ.get("MI355PLAN_LIB") or _build.LIB_PATH
 
 
+def _bind_torch_hip_runtime():
+    """One HIP runtime per process: when PyTorch is installed, libmi355plan.so must bind to the copy of libamdhip64 that torch
+    ships (streams, events and device pointers then cross freely between the two).  Rounds 1-5 got that by importing torch before
+    loading the library -- 0.55 s of the first act() of a process that never uses torch (profiles/r06_first_act.txt).  Now: if
+    torch is already imported, nothing to do; else torch's libamdhip64 is loaded BY PATH (importlib finds the package without
+    importing it), so the library binds to it and a later `import torch` finds its runtime already in the process.
+    MI355PLAN_EAGER_TORCH=1 restores the import."""
+    import sys
+    if "torch" in sys.modules:
+        return
+    if os.environ.get("MI355PLAN_EAGER_TORCH"):
+        try:
+            import torch  # noqa: F401
+        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
+            pass
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        for root in (list(spec.submodule_search_locations) if spec is not None and spec.submodule_search_locations else []):
+            cand = os.path.join(root, "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+                return
+    except Exception:  # pragma: no cover - no torch, or an unusual layout: the library then loads the system runtime
+        pass
+
+
 def load():
     """Load libmi355plan.so; raises (never falls back) if it has not been built."""
     global _LIB
@@ -150,10 +178,7 @@ def load():
         raise RuntimeError("{} is missing: run `python -m rl_agents_amd.build` (hipcc, gfx950). "
                            "There is no CPU fallback for the planning kernels.".format(path))
     if not os.environ.get("MI355PLAN_NO_TORCH"):
-        try:  # share torch's copy of the HIP runtime when torch is in the process (same soname)
-            import torch  # noqa: F401
-        except Exception:  # pragma: no cover - torch is optional for the C ABI itself
-            pass
+        _bind_torch_hip_runtime()
     lib = C.CDLL(path, mode=C.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
