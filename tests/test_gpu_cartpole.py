@@ -170,6 +170,57 @@ def test_cartpole_extreme_roots_and_wide_threshold(ctx):
         model.close()
 
 
+def test_cartpole_random_parameters_and_layouts(ctx, monkeypatch):
+    """Forty random CartPole models (masses, length, force, gravity, tau, thresholds -- some outside the range the short exact
+    division is proven for, some beyond the restated sin / cos range), random budgets, skewed policies, step limits and root
+    layouts: plans, statistics and generator records of the device against the oracle."""
+    from oracle import oracle
+    from rl_agents_amd import native
+    from rl_agents_amd.envs import CartPoleEnv
+    g = np.random.Generator(np.random.PCG64(2026))
+    base = CartPoleEnv().cartpole_params()
+    for case in range(40):
+        params = dict(base)
+        params["masspole"] = float(g.choice([0.1, 0.05, 1.0, 1e-20, 3.0]))          # (1e-20: below 2^-50 -> IEEE divisions)
+        params["masscart"] = float(g.choice([1.0, 0.5, 10.0]))
+        params["length"] = float(g.choice([0.5, 0.25, 2.0]))
+        params["force_mag"] = float(g.choice([10.0, 1.0, 30.0]))
+        params["gravity"] = float(g.choice([9.8, 1.62, 24.8]))
+        params["tau"] = float(g.choice([0.02, 0.01, 0.05]))
+        params["theta_threshold"] = float(g.choice([12 * 2 * np.pi / 360, 0.1, 0.5, 0.79, 0.9, 2.0]))
+        params["x_threshold"] = float(g.choice([2.4, 0.5, 100.0]))
+        params["max_steps"] = int(g.choice([0, 30, 200]))
+        n = int(g.choice([1, 3, 17, 64, 300, 1500]))
+        episodes, horizon = int(g.choice([1, 5, 20])), int(g.choice([1, 7, 16, 17, 50, 70]))
+        x0 = g.uniform(-0.08, 0.08, size=(n, 4)) * np.array([1.0, 1.0, float(g.choice([0.5, 1.0, 4.0])), float(g.choice([1.0, 30.0]))])
+        steps0 = g.integers(0, 25, size=n).astype(np.int32)
+        pr = g.random(2) + 0.05
+        pr /= pr.sum()
+        ro = g.random(2) + 0.05
+        ro /= ro.sum()
+        temperature = float(g.choice([1.0, 10.0]))
+        for knob in ("MP_UCT_LANES", "MP_UCT_CART_REP"):
+            monkeypatch.delenv(knob, raising=False)
+        if g.random() < 0.5:
+            monkeypatch.setenv("MP_UCT_LANES", str(int(g.choice([1, 2, 4, 8, 16, 32, 64]))))
+            monkeypatch.setenv("MP_UCT_CART_REP", str(int(g.integers(0, 7))))
+        desc = dict(case=case, n=n, episodes=episodes, horizon=horizon, params=params, lanes=__import__("os").environ.get("MP_UCT_LANES"),
+                    rep=__import__("os").environ.get("MP_UCT_CART_REP"))
+        model = ctx.load_cartpole(params)
+        rng = native.seed_sequence_states((), 7000 + case, n)
+        rng_ref = rng.copy()
+        with np.errstate(all="ignore"):
+            out = ctx.uct_plan(model, x0, episodes, horizon, 0.9, temperature, pr, ro, rng, root_steps=steps0, max_plan_len=5)
+            ref = oracle.uct_plan_batch(None, None, None, x0, episodes, horizon, 0.9, temperature, pr, ro, rng_ref, steps0=steps0,
+                                        max_plan_len=5, n_threads=4, cartpole=params)
+        np.testing.assert_array_equal(out["plans"], ref["plans"], err_msg=str(desc))
+        np.testing.assert_array_equal(out["env_steps"], ref["env_steps"], err_msg=str(desc))
+        assert np.array_equal(out["root_value"], ref["root_value"], equal_nan=True), desc
+        np.testing.assert_array_equal(out["root_child_count"], ref["root_child_count"], err_msg=str(desc))
+        np.testing.assert_array_equal(rng, ref["rng_after"], err_msg=str(desc))
+        model.close()
+
+
 def test_device_sincos_equals_host_libm_on_ten_million_angles(ctx):
     """The device's restated sin / cos (the form mp_libm_sincos_variant picked for this host) against the host libm's --
     math.sin / math.cos, what gymnasium's CartPole calls -- on 10^7 angles: the pole's range, the whole restated range
