@@ -1678,22 +1678,34 @@ __global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
         if (SHARED) rwv[i_] = reward_of(idx); else rw4[j_] = rew[idx];                                  \
         sw = (int32_t)(e4[j_] & 0x7fffu);                                                               \
     }
-#define MP_ROW_BOOK(j_)                                                                                 \
+// pass 2, for the group as a whole: which of its four steps the row takes follows from four bits -- the terminal flags of the
+// states reached -- and the step limit, so the per-step if / select chain (fifteen instructions a step) becomes bit arithmetic:
+// stop bit j = "the rollout ends AFTER step j"; k = the steps taken = first stop bit + 1 (or 4).  The return's additions are the
+// reference's, in order: a step not taken adds +0.0, which changes no bit of a sum that is never -0.
+#define MP_ROW_BOOK4()                                                                                  \
     {                                                                                                   \
-        const uint32_t e = e4[j_];                                                                      \
-        const bool next_term = (e & 0x8000u) != 0;                                                      \
-        const bool term_h = p.done_on_next ? next_term : cur_term;                                      \
-        if (alive) {                                                                                    \
-            if (!SHARED) total += gpow[depth + n] * rw4[j_];                                            \
-            cur_term = next_term;                                                                       \
-            s = (int32_t)(e & 0x7fffu);                                                                 \
-            ++n;                                                                                        \
-            alive = !(term_h || n >= n_lim);                                                            \
+        const uint32_t nt = ((e4[0] >> 15) & 1u) | ((e4[1] >> 14) & 2u) | ((e4[2] >> 13) & 4u) | ((e4[3] >> 12) & 8u);  \
+        const uint32_t th = p.done_on_next ? nt : (((nt << 1) | (cur_term ? 1u : 0u)) & 15u);           \
+        const int left = n_lim - n;                              /* steps still allowed: >= 1 while alive */ \
+        const uint32_t lim = left <= 4 ? 1u << ((left - 1) & 3) : 0u;                                   \
+        const uint32_t stop = th | lim;                                                                 \
+        const int first = stop ? __ffs((int)stop) - 1 : 4;                                              \
+        const int k = alive ? min(first + 1, 4) : 0;                                                    \
+        if (!SHARED) {                                                                                  \
+            _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                             \
+                const double add = gpow[min(depth + n + j, H)] * rw4[j];                                \
+                total += j < k ? add : 0.0;                                                             \
+            }                                                                                           \
         }                                                                                               \
+        const uint32_t ek = k <= 1 ? e4[0] : (k == 2 ? e4[1] : (k == 3 ? e4[2] : e4[3]));               \
+        s = k > 0 ? (int32_t)(ek & 0x7fffu) : s;                                                        \
+        cur_term = k > 0 ? (ek & 0x8000u) != 0 : cur_term;                                              \
+        n += k;                                                                                         \
+        alive = alive && first >= 4;                                                                    \
     }
 #define MP_ROW_WALK4(g_)                                                                                \
     MP_ROW_CHAIN(4 * (g_), 0) MP_ROW_CHAIN(4 * (g_) + 1, 1) MP_ROW_CHAIN(4 * (g_) + 2, 2) MP_ROW_CHAIN(4 * (g_) + 3, 3)     \
-    MP_ROW_BOOK(0) MP_ROW_BOOK(1) MP_ROW_BOOK(2) MP_ROW_BOOK(3)
+    MP_ROW_BOOK4()
                 if (SHARED) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) rwv[i] = 0.0;
@@ -1707,7 +1719,7 @@ __global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
                     }
                 }
 #undef MP_ROW_WALK4
-#undef MP_ROW_BOOK
+#undef MP_ROW_BOOK4
 #undef MP_ROW_CHAIN
                 if (SHARED) {
 #pragma unroll
