@@ -1706,25 +1706,34 @@ __global__ __launch_bounds__(SHARED ? 1024 : 256) void uct_row_kernel(UctArgs p)
 #define MP_ROW_WALK4(g_)                                                                                \
     MP_ROW_CHAIN(4 * (g_), 0) MP_ROW_CHAIN(4 * (g_) + 1, 1) MP_ROW_CHAIN(4 * (g_) + 2, 2) MP_ROW_CHAIN(4 * (g_) + 3, 3)     \
     MP_ROW_BOOK4()
-                if (SHARED) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) rwv[i] = 0.0;
-                }
+                int groups = 1;                                   // groups of four this round walked (wave-uniform)
                 MP_ROW_WALK4(0)
                 if (any64(alive)) {
+                    groups = 2;
                     MP_ROW_WALK4(1)
                     if (any64(alive)) {
+                        groups = 3;
                         MP_ROW_WALK4(2)
-                        if (any64(alive)) { MP_ROW_WALK4(3) }
+                        if (any64(alive)) { groups = 4; MP_ROW_WALK4(3) }
                     }
                 }
 #undef MP_ROW_WALK4
 #undef MP_ROW_BOOK4
 #undef MP_ROW_CHAIN
                 if (SHARED) {
+                    // the round's return, in step order, over the groups that were walked; a step the row did not take adds +0.0
+                    const int taken = n - n_before;
 #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        if (n_before + i < n) total += gpow[depth + n_before + i] * rwv[i];
+                    for (int gq = 0; gq < 4; ++gq) {
+                        if (gq < groups) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const int i = 4 * gq + j;
+                                const double add = gpow[min(depth + n_before + i, H)] * rwv[i];
+                                total += i < taken ? add : 0.0;
+                            }
+                        }
+                    }
                 }
                 PROF_T(d2);
                 // a row whose rollout ended in this round: its generator after the n draws it consumed = the state the lane of
