@@ -954,6 +954,9 @@ void uct_kernel(UctArgs p)
         } else
         if (!terminal && depth < H) {
             int h = depth;
+            // the step after which the rollout stops at the latest: the horizon, or the environment's step limit (the first step
+            // is unconditional, as in the reference's loop: hmax <= depth stops after it)
+            const int hmax = p.max_steps > 0 ? min(H, depth + p.max_steps - st) : H;
             Pcg64 ga = g, gb = g;
             uint64_t u = ga.next64() >> USH; // the 53 random bits of Generator.random() (RAWU: all 64, see thr_arg)
             bool stopped_in_a = true;
@@ -1065,11 +1068,13 @@ void uct_kernel(UctArgs p)
                     s = rc.next;
                     total += g_mine * rc.reward;
                 }
-                ++st; ++steps_taken; ++h;
+                // (st and steps_taken advance with h: added once after the rollout; the env's step limit is folded into hmax --
+                // three vector instructions fewer in a step that issues ~50)
+                ++h;
 #ifdef MP_PROFILE
                 ++n_roll;
 #endif
-                return term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H;
+                return term_h || h >= hmax;
             };
             while (true) {
                 uint64_t un;
@@ -1081,6 +1086,7 @@ void uct_kernel(UctArgs p)
             }
             if (LDSM) total += stopped_in_a ? g_a * r_a : g_b * r_b;
             g = stopped_in_a ? ga : gb; // the generator whose draw was consumed last
+            st += h - depth; steps_taken += h - depth;
         }
         PROF_T(c3);
         // ---- backup, mcts.py:248-265: the same return for every node on the path
