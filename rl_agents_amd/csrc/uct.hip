@@ -1024,7 +1024,9 @@ void uct_kernel(UctArgs p)
                     r_mine = LDSR ? rdict[r8[idx]] : rec[idx].reward;
                     gspec = gcur;
                     unext = gspec.next64() >> USH;
-                    if (add_prev) total += g_prev * r_prev;
+                    // (the first step of a rollout has no previous reward: r_prev = g_prev = 0.0 then, and adding +0.0 changes no bit
+                    // of a return that is never -0 -- no select on `add_prev`)
+                    total += g_prev * r_prev;
                     const bool next_term = (e & 0x8000u) != 0;
                     term_h = p.done_on_next ? next_term : cur_term;
                     cur_term = next_term;
