@@ -612,31 +612,50 @@ void uct_kernel(UctArgs p)
                 // still rolling; the draws of round r + 1 are computed beside the walk of round r (independent instruction
                 // streams of one basic block: the walk's LDS round trips hide under the generator's multiplies).  Every step is
                 // unconditional arithmetic with selects -- a finished root re-reads a valid record and keeps its values.
+                // (round 6, as uct_row_kernel's walk) a round in two passes: the state chain alone -- index -> LDS read -> mask, SPECULATIVE
+                // past the rollout's end (valid records nobody uses) -- with the rewards' reads beside it; then the round's bookkeeping as
+                // bit arithmetic: stop bit j = "the rollout ends AFTER step j", steps taken = first stop bit + 1 (or 4); a step not taken
+                // adds +0.0 to a return that is never -0.  The step counters advance once, after the rollout.
                 bool alive = want;
-                int h = depth, n = 0;
+                int h = depth;
+                const int hmax = p.max_steps > 0 ? min(H, depth + p.max_steps - st) : H;   // (the first step is unconditional)
                 uint32_t act_cur = draw(q);
                 q.advance4(g4_lo, g4_hi);
                 while (__any(alive ? 1 : 0)) {
                     const uint32_t a4[4] = {bcastq(act_cur, 0), bcastq(act_cur, 1), bcastq(act_cur, 2), bcastq(act_cur, 3)};
                     const uint32_t act_next = draw(q);
                     q.advance4(g4_lo, g4_hi);
+                    uint32_t e4[4];
+                    double rw4[4];
+                    int32_t sw = s;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
-                        const unsigned idx = (unsigned)(s * A) + a4[i];
-                        const uint32_t e = t16[idx];
-                        const double rew = rdict[r8[idx]];
-                        const double tnew = total + gpow[h] * rew;
-                        const bool next_term = (e & 0x8000u) != 0;
-                        const bool term_h = p.done_on_next ? next_term : cur_term;
-                        total = alive ? tnew : total;
-                        cur_term = alive ? next_term : cur_term;
-                        s = alive ? (int32_t)(e & 0x7fffu) : s;
-                        const int inc1 = alive ? 1 : 0;
-                        st += inc1; steps_taken += inc1; h += inc1; n += inc1;
-                        alive = alive && !(term_h || (p.max_steps > 0 && st >= p.max_steps) || h >= H);
+                        const unsigned idx = (unsigned)(sw * A) + a4[i];
+                        e4[i] = t16[idx];
+                        rw4[i] = rdict[r8[idx]];
+                        sw = (int32_t)(e4[i] & 0x7fffu);
                     }
+                    const uint32_t nt = ((e4[0] >> 15) & 1u) | ((e4[1] >> 14) & 2u) | ((e4[2] >> 13) & 4u) | ((e4[3] >> 12) & 8u);
+                    const uint32_t th = p.done_on_next ? nt : (((nt << 1) | (cur_term ? 1u : 0u)) & 15u);
+                    const int left = hmax - h;                      // steps still allowed (the first one always is)
+                    const uint32_t lim = left <= 4 ? 1u << ((max(left, 1) - 1) & 3) : 0u;
+                    const uint32_t stop = th | lim;
+                    const int first = stop ? __ffs((int)stop) - 1 : 4;
+                    const int k = alive ? min(first + 1, 4) : 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const double add = gpow[min(h + j, H)] * rw4[j];
+                        total += j < k ? add : 0.0;
+                    }
+                    const uint32_t ek = k <= 1 ? e4[0] : (k == 2 ? e4[1] : (k == 3 ? e4[2] : e4[3]));
+                    s = k > 0 ? (int32_t)(ek & 0x7fffu) : s;
+                    cur_term = k > 0 ? (ek & 0x8000u) != 0 : cur_term;
+                    h += k;
+                    alive = alive && first >= 4;
                     act_cur = act_next;
                 }
+                const int n = h - depth;
+                st += n; steps_taken += n;
                 if (want) { // the generator after the n draws the walk consumed: A^n state + inc G_n
                     uint32_t an[4], gn[4];
 #pragma unroll
