@@ -1289,34 +1289,24 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     __builtin_amdgcn_wave_barrier();
     const int la = lane < A ? lane : 0;
     const double expl1 = explore(la, 1);          // a fresh child's term (count 0)
-    // An env step's reward comes through two more LDS reads (reward index -> reward) that the state chain does not need: a
-    // three-stage pipeline over the steps of an episode (descent and rollout alike).  A step issues its transition read, its
-    // reward-index read and the PREVIOUS step's reward read together, and adds the reward of the step before that from
-    // registers -- one LDS round trip per step on the chain, the sum still in the reference's order.
+    // (round 6, second pass) An env step's reward comes through two more LDS reads (reward index -> reward) that the state chain
+    // does not need.  A lone wave issues an instruction every ~5 cycles whatever it depends on, so what a step costs is its
+    // instruction COUNT: the steps of an episode (descent and rollout alike) only note their (s, a) index in lane `depth` of one
+    // register; after the walk the lanes look up their steps' rewards AT ONCE (two LDS reads for the whole episode), multiply by
+    // gamma ** lane, and the products are added one by one in the reference's order (mcts.py:160-177: total += gamma ** h * r).
+    // The three-stage reward pipeline this replaces cost ~25 of a rollout step's 43 instructions.
+    const double gpl = gpow[min(lane, H)];        // gamma ** lane
+    int idxv = 0;                                 // lane l: s * |A| + a of the episode's step l (stale beyond: valid, unused)
     for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
         int32_t s = s0, st = st0;
-        int node = 0, depth = 0;
+        int node = 0, depth = 0, n_roll = 0;
         bool terminal = false, cur_term = root_term;
-        double total = 0.0;
         if (lane == 0) path[0] = 0;
         int fc = __builtin_amdgcn_readfirstlane(tnode[0].first_child);
-        unsigned rb1 = 0; int h1 = 0; bool v1 = false;       // the last step: its reward index, its depth
-        double rd2 = 0.0, gp2 = 0.0; bool v2 = false;        // the step before: its reward, gamma ** depth
 #define MP_LONE_STEP(idx_, h_, e_out_)                                                                  \
     do {                                                                                                \
-        const uint32_t e_raw_ = t16[idx_];                                                              \
-        if constexpr (EACH) { /* the reward itself is in LDS: a two-stage pipeline (added one step later, in order) */ \
-            const double rdn_ = rew[idx_], gpn_ = gpow[(h_)];                                           \
-            if (v2) total += gp2 * rd2;                                                                 \
-            rd2 = rdn_; gp2 = gpn_; v2 = true;                                                          \
-        } else {                                                                                        \
-            const unsigned rbn_ = r8[idx_];                                                             \
-            const double rdn_ = rdict[rb1], gpn_ = gpow[h1];                                            \
-            if (v2) total += gp2 * rd2;                                                                 \
-            rd2 = rdn_; gp2 = gpn_; v2 = v1;                                                            \
-            rb1 = rbn_; h1 = (h_); v1 = true;                                                           \
-        }                                                                                               \
-        e_out_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)e_raw_);                                 \
+        idxv = lane == (h_) ? (int)(idx_) : idxv;                                                       \
+        e_out_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t16[idx_]);                    \
     } while (0)
         // ---- selection, mcts.py:143-149: a level's children one per lane
         while (depth < H && fc >= 0 && !terminal) {
@@ -1382,18 +1372,32 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             if (p.max_steps > 0 && p.max_steps - st < n_lim) n_lim = p.max_steps - st;
             if (n_lim < 1) n_lim = 1; // (the first step is unconditional, as in the reference's loop)
             int n = 0;
-            while (true) {
-                const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
-                const unsigned idx = (unsigned)(s * A + a_i);
-                uint32_t e;
-                MP_LONE_STEP(idx, depth + n, e);
-                const bool next_term = (e & 0x8000u) != 0;
-                const bool term_h = p.done_on_next ? next_term : cur_term;
-                cur_term = next_term;
-                s = (int32_t)(e & 0x7fffu);
-                ++n;
-                if (term_h || n >= n_lim) break;
+            // (two forms of the loop, by the terminal rule: each a dozen scalar instructions around the one dependent LDS read)
+            if (p.done_on_next) {
+                while (true) {
+                    const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
+                    const unsigned idx = (unsigned)(s * A + a_i);
+                    uint32_t e;
+                    MP_LONE_STEP(idx, depth + n, e);
+                    s = (int32_t)(e & 0x7fffu);
+                    ++n;
+                    if ((e & 0x8000u) != 0 || n >= n_lim) break;
+                }
+            } else {
+                uint32_t pe = cur_term ? 0x8000u : 0u;  // ("source" rule: the step FROM a terminal state is the last one)
+                while (true) {
+                    const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
+                    const unsigned idx = (unsigned)(s * A + a_i);
+                    uint32_t e;
+                    MP_LONE_STEP(idx, depth + n, e);
+                    const uint32_t stop = pe;
+                    pe = e;
+                    s = (int32_t)(e & 0x7fffu);
+                    ++n;
+                    if ((stop & 0x8000u) != 0 || n >= n_lim) break;
+                }
             }
+            n_roll = n;
             st += n; steps_taken += n;
             {   // the generator after the n draws the walk consumed = the state lane n - 1 jumped to for ITS draw
                 const int src = n - 1;
@@ -1404,8 +1408,21 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             }
         }
 #undef MP_LONE_STEP
-        if (v2) total += gp2 * rd2;                          // drain the pipeline: the last two steps (EACH: the last one)
-        if (!EACH && v1) total += gpow[h1] * rdict[rb1];
+        // the episode's return: its L steps' rewards looked up by L lanes, added in step order (a group of four per uniform test)
+        double total = 0.0;
+        {
+            const int L = depth + n_roll;
+            double rd;
+            if constexpr (EACH) rd = rew[idxv]; else rd = rdict[r8[idxv]];
+            double prod = gpl * rd;
+            prod = lane < L ? prod : 0.0;     // (+0.0 leaves a sum that started at +0.0 as it is, bit for bit)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q * 4 >= L) break;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) total += bcast_lane(prod, q * 4 + j);
+            }
+        }
         // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
         __builtin_amdgcn_wave_barrier();
         if (lane <= depth) {

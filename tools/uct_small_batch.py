@@ -30,7 +30,7 @@ def main():
         val = torch.zeros(n, dtype=torch.float64, device="cuda")
         es = torch.zeros(n, dtype=torch.int64, device="cuda")
         ms = []
-        for _ in range(8 if not os.environ.get("MI355PLAN_LIB") else 1):
+        for _ in range(8 if (not os.environ.get("MI355PLAN_LIB") or os.environ.get("MI355PLAN_AB")) else 1):
             rng.copy_(rng0)
             torch.cuda.synchronize()
             ctx.uct_plan_device(model, n, s0, 33, 30, 0.8, 10.0, p, p, rng, 8, plans=plans, plan_len=pl, root_value=val, env_steps=es)
