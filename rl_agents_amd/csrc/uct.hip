@@ -1297,7 +1297,20 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     // The three-stage reward pipeline this replaces cost ~25 of a rollout step's 43 instructions.
     const double gpl = gpow[min(lane, H)];        // gamma ** lane
     int idxv = 0;                                 // lane l: s * |A| + a of the episode's step l (stale beyond: valid, unused)
+    uint32_t sv = 0;                              // lane l: the state the rollout's step at depth l leaves from (noted by the walk)
+    typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
+    const uint32_t t16_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)t16; // byte offset of t16 in LDS
+#ifdef MP_PROFILE
+    long long pt[6] = {0, 0, 0, 0, 0, 0}, pn_sel = 0, pn_roll = 0;
+    const long long pt_all = clock64();
+#define MP_LT(i_) do { const long long c_ = clock64(); pt[i_] += c_ - pc; pc = c_; } while (0)
+#else
+#define MP_LT(i_) do { } while (0)
+#endif
     for (int ep = 0; ep < E; ++ep) { // mcts.py:179-184
+#ifdef MP_PROFILE
+        long long pc = clock64();
+#endif
         int32_t s = s0, st = st0;
         int node = 0, depth = 0, n_roll = 0;
         bool terminal = false, cur_term = root_term;
@@ -1339,6 +1352,10 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             if (lane == 0) path[depth] = node;
             fc = nfc;
         }
+#ifdef MP_PROFILE
+        pn_sel += depth;
+#endif
+        MP_LT(0);
         // ---- expansion, mcts.py:151-154 / 237-246
         if (fc < 0 && depth < H && (!terminal || node == 0)) {
             if (lane == 0) tnode[node].first_child = n_nodes;
@@ -1350,12 +1367,16 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             }
             n_nodes += A;
         }
+        MP_LT(1);
         // ---- rollout, mcts.py:156-157 / 160-177
         if (!terminal && depth < H) {
+            // Lane h holds what the step at depth h needs: its action (lane h draws action h - depth of the rollout, from the
+            // generator h - depth + 1 steps ahead) and, noted by the walk, the state it leaves from -- so the lanes form their
+            // steps' (s, a) indices themselves afterwards.
             uint32_t act_l;
             Pcg64 q = g;
             {
-                const int j1 = lane + 1 < H ? lane + 1 : H; // (draws beyond the horizon are never used)
+                const int j1 = min(max(lane - depth + 1, 1), H); // (draws beyond the horizon / of the descent's lanes are never used)
                 uint32_t an[4], gn[4];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) { an[i] = jump[j1 * 8 + i]; gn[i] = jump[j1 * 8 + 4 + i]; }
@@ -1366,41 +1387,72 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
                 for (int a = 0; a < NTH; ++a) act += p.thr_arg[a] <= u ? 1 : 0;
                 act_l = (uint32_t)min(act, p.thr_valid);
             }
-            // the walk: at most n_lim steps (horizon, the env's step limit), one dependent LDS read each; the reward of the
-            // previous step and the sum ride along
+            MP_LT(2);
+            // the walk: at most n_lim steps (horizon, the env's step limit).  The chain of a step is ONE multiply-add (LDS byte
+            // address of the record = state * 2|A| + (2 a + the table's offset), the second term a scalar read off the action's lane)
+            // and the read itself; the scalar side only tests the terminal bit and counts.
             int n_lim = H - depth;
             if (p.max_steps > 0 && p.max_steps - st < n_lim) n_lim = p.max_steps - st;
             if (n_lim < 1) n_lim = 1; // (the first step is unconditional, as in the reference's loop)
-            int n = 0;
-            // (two forms of the loop, by the terminal rule: each a dozen scalar instructions around the one dependent LDS read)
-            if (p.done_on_next) {
-                while (true) {
-                    const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
-                    const unsigned idx = (unsigned)(s * A + a_i);
-                    uint32_t e;
-                    MP_LONE_STEP(idx, depth + n, e);
-                    s = (int32_t)(e & 0x7fffu);
-                    ++n;
-                    if ((e & 0x8000u) != 0 || n >= n_lim) break;
-                }
-            } else {
-                uint32_t pe = cur_term ? 0x8000u : 0u;  // ("source" rule: the step FROM a terminal state is the last one)
-                while (true) {
-                    const int a_i = __builtin_amdgcn_readlane((int)act_l, n);
-                    const unsigned idx = (unsigned)(s * A + a_i);
-                    uint32_t e;
-                    MP_LONE_STEP(idx, depth + n, e);
-                    const uint32_t stop = pe;
-                    pe = e;
-                    s = (int32_t)(e & 0x7fffu);
-                    ++n;
-                    if ((stop & 0x8000u) != 0 || n >= n_lim) break;
-                }
+            const uint32_t act2 = 2u * act_l + t16_lds;
+            const int h_end = depth + n_lim;
+            sv = lane == depth ? (uint32_t)s : sv;
+            // The walk loop, written out (inline assembly: the compiler rotates any C form of it back into read -> wait -> test).
+            // The read of the NEXT step is issued before this step's terminal bit is tested (speculative: any record's next state
+            // is a valid state, its lane's action a valid action; the record of a step not taken is dropped), so the scalar side --
+            // readfirstlane, the tests, the note of the state in its lane, the next action's readlane -- runs under the LDS latency
+            // of the chain, which is v_and -> v_mad_u32_u24 (state * 2|A| + action term) -> ds_read_u16 and nothing else.  Two steps
+            // per backward branch, the exits not taken until the end.  Wait states by hand (the hazard pass does not look inside):
+            // a VALU that reads an SGPR / VCC a VALU wrote comes at least two instructions later.
+            uint32_t v1;
+            {   // the first step is unconditional (the reference's loop tests after the step)
+                const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)act2, depth);
+                uint32_t ad = (uint32_t)s * (2u * A) + a2;
+                v1 = *(lds_u16_t *)(uintptr_t)ad;
             }
+            int h = depth + 1;                          // (v1 = the record of the step at depth h - 1; h <= H <= 63: a lane)
+            {
+                uint32_t pe = cur_term ? 0x8000u : 0u;  // ("source" rule: the step FROM a terminal state is the last one)
+                uint32_t v2, t, a2, e, h1;
+#define MP_LONE_HALF(V1, V2, STOP)                                                                 \
+    "v_and_b32 %[t], 0x7fff, " V1 "\n\t"                                                          \
+    "v_mad_u32_u24 %[t], %[t], %[mul], %[a2]\n\t"                                                  \
+    "ds_read_u16 " V2 ", %[t]\n\t"                                                                 \
+    "v_cmp_eq_u32 vcc, %[h], %[lane]\n\t"                                                          \
+    "v_readfirstlane_b32 %[e], " V1 "\n\t"                                                         \
+    "s_add_i32 %[h1], %[h], 1\n\t"                                                                 \
+    "v_cndmask_b32 %[sv], %[sv], " V1 ", vcc\n\t"                                                  \
+    "v_readlane_b32 %[a2], %[act2], %[h1]\n\t"                                                     \
+    STOP                                                                                           \
+    "s_cbranch_scc1 2f\n\t"                                                                        \
+    "s_cmp_ge_u32 %[h], %[hend]\n\t"                                                               \
+    "s_cbranch_scc1 2f\n\t"                                                                        \
+    "s_mov_b32 %[h], %[h1]\n\t"                                                                    \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define MP_LONE_WALK(STOP)                                                                         \
+    asm volatile("s_nop 3\n\t"                                                                     \
+                 "v_readlane_b32 %[a2], %[act2], %[h]\n\t"                                          \
+                 "s_nop 1\n\t"                                                                      \
+                 "1:\n\t" MP_LONE_HALF("%[v1]", "%[v2]", STOP) MP_LONE_HALF("%[v2]", "%[v1]", STOP)  \
+                 "s_branch 1b\n\t"                                                                  \
+                 "2:\n\t"                                                                           \
+                 "s_waitcnt lgkmcnt(0)"                                                             \
+                 : [h] "+s"(h), [sv] "+v"(sv), [v1] "+v"(v1), [pe] "+s"(pe), [v2] "=&v"(v2), [t] "=&v"(t), [a2] "=&s"(a2),       \
+                   [e] "=&s"(e), [h1] "=&s"(h1)                                                     \
+                 : [act2] "v"(act2), [lane] "v"(lane), [hend] "s"(h_end), [mul] "n"(2 * A)          \
+                 : "vcc", "scc", "memory")
+                if (p.done_on_next) MP_LONE_WALK("s_bitcmp1_b32 %[e], 15\n\t");
+                else MP_LONE_WALK("s_bitcmp1_b32 %[pe], 15\n\ts_mov_b32 %[pe], %[e]\n\t");
+#undef MP_LONE_WALK
+#undef MP_LONE_HALF
+            }
+            MP_LT(3);
+            const int n = h - depth;
             n_roll = n;
             st += n; steps_taken += n;
-            {   // the generator after the n draws the walk consumed = the state lane n - 1 jumped to for ITS draw
-                const int src = n - 1;
+            idxv = lane >= depth ? (int)((sv & 0x7fffu) * A + act_l) : idxv;
+            {   // the generator after the n draws the walk consumed = the state the lane of the last step jumped to for ITS draw
+                const int src = h - 1;
                 g.s_lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q.s_lo >> 32), src) << 32) |
                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q.s_lo, src);
                 g.s_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(q.s_hi >> 32), src) << 32) |
@@ -1408,6 +1460,7 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             }
         }
 #undef MP_LONE_STEP
+        MP_LT(2);
         // the episode's return: its L steps' rewards looked up by L lanes, added in step order (a group of four per uniform test)
         double total = 0.0;
         {
@@ -1423,6 +1476,10 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
                 for (int j = 0; j < 4; ++j) total += bcast_lane(prod, q * 4 + j);
             }
         }
+#ifdef MP_PROFILE
+        pn_roll += n_roll;
+#endif
+        MP_LT(4);
         // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
         __builtin_amdgcn_wave_barrier();
         if (lane <= depth) {
@@ -1435,7 +1492,14 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             if (nd > 0) texpl[nd] = explore((nd - 1) % A, c.count + 1);
         }
         __builtin_amdgcn_wave_barrier();
+        MP_LT(5);
     }
+#undef MP_LT
+#ifdef MP_PROFILE
+    if (r == 0 && lane == 0)
+        printf("uct_lone prof: total=%lld select=%lld expand=%lld draw+gen=%lld walk=%lld sum=%lld backup=%lld | levels=%lld rollout steps=%lld\n",
+               (long long)(clock64() - pt_all), pt[0], pt[1], pt[2], pt[3], pt[4], pt[5], pn_sel, pn_roll);
+#endif
     // the tree, to global memory in the group-interleaved layout (export, re-rooting by step_by_subtree)
     const TreeRef<2, AT> tree = tree_of<2, AT>(p.tree, r, p.cap, A);
     for (int i = lane; i < n_nodes; i += 64) tree[i] = tnode[i];
