@@ -1247,7 +1247,7 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     uint32_t *jump = EACH ? reinterpret_cast<uint32_t *>(r8) : reinterpret_cast<uint32_t *>(r8 + ((SA + 15) & ~15)); // [H + 5][8]
     UctNode *tnode = reinterpret_cast<UctNode *>(jump + (H + 5) * 8);            // [cap]
     double *texpl = reinterpret_cast<double *>(tnode + p.cap);                   // [cap] a node's exploration term at its count
-    int32_t *path = reinterpret_cast<int32_t *>(texpl + p.cap);                  // [H + 1]
+    // (the [H + 1] words behind texpl held the path until round 6: it now lives in a register, one node per lane)
     const int r = blockIdx.x;
     const int32_t s0g = __builtin_amdgcn_readfirstlane(p.root_state[r]);         // (global state of a batch model)
     const int32_t sbase = EACH ? (s0g / p.Sb) * p.Sb : 0;                         // first global state of this root's MDP
@@ -1298,6 +1298,8 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     const double gpl = gpow[min(lane, H)];        // gamma ** lane
     int idxv = 0;                                 // lane l: s * |A| + a of the episode's step l (stale beyond: valid, unused)
     uint32_t sv = 0;                              // lane l: the state the rollout's step at depth l leaves from (noted by the walk)
+    int pathv = 0;                                // lane l: the tree node at depth l of the episode's path (lane 0: the root)
+    const uint32_t tshift = p.done_on_next ? 0u : 16u;
     typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
     const uint32_t t16_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)t16; // byte offset of t16 in LDS
 #ifdef MP_PROFILE
@@ -1313,25 +1315,24 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
 #endif
         int32_t s = s0, st = st0;
         int node = 0, depth = 0, n_roll = 0;
-        bool terminal = false, cur_term = root_term;
-        if (lane == 0) path[0] = 0;
+        bool terminal = false;
+        // the records of the last two steps, the newer in the low half: bit 15 of the one the terminal rule names ends the descent
+        // ("next" rule: the step just taken; "source" rule: the one before, i.e. the state the step left from was terminal)
+        uint32_t hist = root_term ? 0x8000u : 0u;
         int fc = __builtin_amdgcn_readfirstlane(tnode[0].first_child);
-#define MP_LONE_STEP(idx_, h_, e_out_)                                                                  \
-    do {                                                                                                \
-        idxv = lane == (h_) ? (int)(idx_) : idxv;                                                       \
-        e_out_ = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)t16[idx_]);                    \
-    } while (0)
         // ---- selection, mcts.py:143-149: a level's children one per lane
         while (depth < H && fc >= 0 && !terminal) {
             const UctNode c = tnode[fc + la];
-            double sc = c.value + texpl[fc + la];
-            if (lane >= A) sc = -INFINITY;
-            // (|A| <= 8 scores by readlane into scalar registers and a chain of |A| - 1 maxima: a third of the DPP reduction's
-            // dependent instructions -- a lone wave runs at the latency of its chain)
-            double m = bcast_lane(sc, 0);
+            const double ex = texpl[fc + la];
+            // (every child's transition is read with the children, one per lane: the step of the picked one is then a readlane,
+            // not a second LDS round trip behind the pick)
+            const uint32_t cand = t16[s * A + la];
+            const double sc = c.value + ex;
+            // Node.random_argmax, abstract.py:296-311: the maxima = the children no other child beats (|A| independent compares
+            // against the scores read off their lanes; a chain of maxima would be |A| dependent selects)
+            unsigned long long ties = (1ull << A) - 1ull;
 #pragma unroll
-            for (int a = 1; a < A; ++a) { const double o = bcast_lane(sc, a); m = o > m ? o : m; }
-            const unsigned long long ties = ballot64(lane < A && sc == m); // Node.random_argmax, abstract.py:296-311
+            for (int a = 0; a < A; ++a) ties &= ballot64(sc >= bcast_lane(sc, a));
             const int nt = __popcll(ties);
             int pick = nt > 1 ? (int)g.below((uint32_t)nt) : 0;
             pick = __builtin_amdgcn_readfirstlane(pick);
@@ -1339,19 +1340,18 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             while (pick-- > 0) t &= t - 1;
             const int act = __ffsll((long long)t) - 1;
             const int nfc = __builtin_amdgcn_readlane(c.first_child, act);
-            const unsigned idx = (unsigned)(s * A + act);
-            uint32_t e;
-            MP_LONE_STEP(idx, depth, e);
-            const bool next_term = (e & 0x8000u) != 0;
-            terminal = p.done_on_next ? next_term : cur_term;
-            cur_term = next_term;
+            const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)cand, act);
+            idxv = lane == depth ? s * A + act : idxv;
+            hist = (hist << 16) | e;
+            terminal = ((hist >> tshift) & 0x8000u) != 0;
             s = (int32_t)(e & 0x7fffu);
             ++st; ++steps_taken;
             node = fc + act;
             ++depth;
-            if (lane == 0) path[depth] = node;
+            pathv = lane == depth ? node : pathv;
             fc = nfc;
         }
+        const bool cur_term = (hist & 0x8000u) != 0;
 #ifdef MP_PROFILE
         pn_sel += depth;
 #endif
@@ -1459,7 +1459,6 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)q.s_hi, src);
             }
         }
-#undef MP_LONE_STEP
         MP_LT(2);
         // the episode's return: its L steps' rewards looked up by L lanes, added in step order (a group of four per uniform test)
         double total = 0.0;
@@ -1483,7 +1482,7 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
         // ---- backup, mcts.py:248-265: the same return for every node on the path, one node per lane
         __builtin_amdgcn_wave_barrier();
         if (lane <= depth) {
-            const int nd = path[lane];
+            const int nd = pathv;
             UctNode c = tnode[nd];
             c.count += 1;
             c.value += inv(c.count) * (total - c.value);
