@@ -187,4 +187,80 @@ struct Pcg64 {
     }
 };
 
+// The same generator for a WAVE-UNIFORM stream (uct_lone_kernel: one root per wavefront, every lane would hold the same state).
+// Plain 64-bit C arithmetic on values made uniform by readfirstlane: the compiler keeps state and products in scalar registers
+// (s_mul_i32 / s_mul_hi_u32 / s_addc_u32), which a lone wave issues several times faster than the quarter-rate v_mad_u64_u32
+// chain of Pcg64::advance -- a generator step sits on the chain of every tie-break of a descent.
+struct Pcg64U {
+    uint64_t s_hi, s_lo, inc_hi, inc_lo;
+    uint32_t has_uint32, uinteger;
+
+    __device__ __forceinline__ static uint64_t uni(uint64_t x)
+    {
+        return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(x >> 32)) << 32) |
+               (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)x);
+    }
+    __device__ __forceinline__ void load(const uint64_t *p)
+    {
+        s_hi = uni(p[0]); s_lo = uni(p[1]); inc_hi = uni(p[2]); inc_lo = uni(p[3]) | 1ULL; // (odd increment: see Pcg64::load)
+        has_uint32 = (uint32_t)uni(p[4]); uinteger = (uint32_t)uni(p[5]);
+    }
+    __device__ __forceinline__ void store(uint64_t *p) const
+    {
+        p[0] = s_hi; p[1] = s_lo; p[2] = inc_hi; p[3] = inc_lo;
+        p[4] = has_uint32; p[5] = uinteger;
+    }
+    __device__ __forceinline__ static uint64_t mulhi(uint64_t a, uint64_t b)
+    {
+        const uint64_t a0 = (uint32_t)a, a1 = a >> 32, b0 = (uint32_t)b, b1 = b >> 32;
+        const uint64_t p00 = a0 * b0, p01 = a0 * b1, p10 = a1 * b0, p11 = a1 * b1;
+        const uint64_t mid = (p00 >> 32) + (uint32_t)p01 + (uint32_t)p10;
+        return p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32);
+    }
+    __device__ __forceinline__ void advance()
+    {
+        const uint64_t m_lo = 0x4385DF649FCCF645ULL, m_hi = 0x2360ED051FC65DA4ULL;
+        const uint64_t lo = s_lo * m_lo;
+        const uint64_t hi = mulhi(s_lo, m_lo) + s_lo * m_hi + s_hi * m_lo;
+        const uint64_t lo2 = lo + inc_lo;
+        // (the carry as the majority bit of the top bits -- the scalar unit has no 64-bit unsigned compare, and a compare on the
+        // vector unit with a readfirstlane back would sit on the chain)
+        const uint64_t carry = ((lo & inc_lo) | ((lo | inc_lo) & ~lo2)) >> 63;
+        s_hi = hi + inc_hi + carry;
+        s_lo = lo2;
+    }
+    __device__ __forceinline__ uint64_t output() const
+    {
+        const uint64_t x = s_hi ^ s_lo;
+        const uint32_t rot = (uint32_t)(s_hi >> 58);
+        return (x >> rot) | (x << ((64u - rot) & 63u));
+    }
+    __device__ __forceinline__ uint64_t next64() { advance(); return output(); }
+    __device__ __forceinline__ uint32_t next32()
+    {
+        if (has_uint32) {
+            has_uint32 = 0;
+            return uinteger;
+        }
+        const uint64_t n = next64();
+        has_uint32 = 1;
+        uinteger = (uint32_t)(n >> 32);
+        return (uint32_t)n;
+    }
+    __device__ __forceinline__ uint32_t below(uint32_t k)   // Generator.integers(0, k): as Pcg64::below
+    {
+        if (k <= 1) return 0;
+        uint64_t m = (uint64_t)next32() * k;
+        uint32_t leftover = (uint32_t)m;
+        if (leftover < k) {
+            const uint32_t threshold = (uint32_t)(0u - k) % k;
+            while (leftover < threshold) {
+                m = (uint64_t)next32() * k;
+                leftover = (uint32_t)m;
+            }
+        }
+        return (uint32_t)(m >> 32);
+    }
+};
+
 } // namespace mp

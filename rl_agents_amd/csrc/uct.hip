@@ -1279,13 +1279,26 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     // changes the count), so that scoring a level is one LDS round trip, not two
     auto explore = [&](int a, int cnt1) { return cnt1 <= TE + 1 ? tpdiv[a * (TE + 2) + cnt1] : tp[a] / (double)cnt1; };
     auto inv = [&](int c) { return c <= TE ? rcp[c] : 1.0 / (double)c; };
-    Pcg64 g;                                     // (every lane holds the same generator)
+    Pcg64U g;                                    // (one generator for the wave, in scalar registers)
     g.load(p.rng + (long)r * 6);
     const int32_t s0 = s0g - sbase;                                    // (local to the staged MDP)
     const int32_t st0 = p.root_steps ? __builtin_amdgcn_readfirstlane(p.root_steps[r]) : 0;
     const bool root_term = (p.rec[(long)s0g * A].flags & 1u) != 0; // terminal flag of the root state itself ("source" rule)
     int n_nodes = 1, steps_taken = 0;
     if (lane == 0) { UctNode n; n.value = 0.0; n.count = 0; n.first_child = -1; tnode[0] = n; texpl[0] = 0.0; } // mcts.py:129-130 reset()
+    // A jump by j steps is state <- A^j state + inc G_j; the increment is the root's for the whole plan, so this workgroup's copy of
+    // the jump table gets inc G_j in place of G_j once (lane l: j = l + 1; the draws use j <= H <= 63) -- every rollout's draw is then
+    // ONE 128-bit product per lane, not two
+    if (lane < H) {
+        const int j = lane + 1;
+        uint32_t gn[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gn[i] = jump[j * 8 + 4 + i];
+        uint64_t lo, hi;
+        Pcg64::mul128v(g.inc_lo, g.inc_hi, gn, lo, hi);
+        jump[j * 8 + 4] = (uint32_t)lo; jump[j * 8 + 5] = (uint32_t)(lo >> 32);
+        jump[j * 8 + 6] = (uint32_t)hi; jump[j * 8 + 7] = (uint32_t)(hi >> 32);
+    }
     __builtin_amdgcn_wave_barrier();
     const int la = lane < A ? lane : 0;
     const double expl1 = explore(la, 1);          // a fresh child's term (count 0)
@@ -1374,13 +1387,19 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             // generator h - depth + 1 steps ahead) and, noted by the walk, the state it leaves from -- so the lanes form their
             // steps' (s, a) indices themselves afterwards.
             uint32_t act_l;
-            Pcg64 q = g;
+            Pcg64 q;                               // (the lanes' jumps: vector arithmetic on copies)
+            q.s_hi = g.s_hi; q.s_lo = g.s_lo; q.inc_hi = g.inc_hi; q.inc_lo = g.inc_lo; q.has_uint32 = 0; q.uinteger = 0;
             {
                 const int j1 = min(max(lane - depth + 1, 1), H); // (draws beyond the horizon / of the descent's lanes are never used)
-                uint32_t an[4], gn[4];
+                uint32_t an[4], ig[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) { an[i] = jump[j1 * 8 + i]; gn[i] = jump[j1 * 8 + 4 + i]; }
-                q.jump(an, gn);
+                for (int i = 0; i < 4; ++i) { an[i] = jump[j1 * 8 + i]; ig[i] = jump[j1 * 8 + 4 + i]; }
+                uint64_t p_lo, p_hi;                // A^j state + inc G_j, the second product from this root's table
+                Pcg64::mul128v(q.s_lo, q.s_hi, an, p_lo, p_hi);
+                const uint64_t q_lo = (uint64_t)ig[0] | ((uint64_t)ig[1] << 32), q_hi = (uint64_t)ig[2] | ((uint64_t)ig[3] << 32);
+                const uint64_t lo = p_lo + q_lo;
+                q.s_hi = p_hi + q_hi + (lo < p_lo ? 1ULL : 0ULL);
+                q.s_lo = lo;
                 const uint64_t u = q.output();     // searchsorted(cdf, u, 'right') on the raw 64-bit output
                 int act = 0;
 #pragma unroll
