@@ -1313,7 +1313,6 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     uint32_t sv = 0;                              // lane l: the state the rollout's step at depth l leaves from (noted by the walk)
     int pathv = 0;                                // lane l: the tree node at depth l of the episode's path (lane 0: the root)
     const uint32_t tshift = p.done_on_next ? 0u : 16u;
-    typedef __attribute__((address_space(3))) const uint16_t lds_u16_t;
     const uint32_t t16_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint16_t *)t16; // byte offset of t16 in LDS
 #ifdef MP_PROFILE
     long long pt[6] = {0, 0, 0, 0, 0, 0}, pn_sel = 0, pn_roll = 0;
@@ -1415,23 +1414,76 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             if (n_lim < 1) n_lim = 1; // (the first step is unconditional, as in the reference's loop)
             const uint32_t act2 = 2u * act_l + t16_lds;
             const int h_end = depth + n_lim;
-            sv = lane == depth ? (uint32_t)s : sv;
-            // The walk loop, written out (inline assembly: the compiler rotates any C form of it back into read -> wait -> test).
-            // The read of the NEXT step is issued before this step's terminal bit is tested (speculative: any record's next state
-            // is a valid state, its lane's action a valid action; the record of a step not taken is dropped), so the scalar side --
-            // readfirstlane, the tests, the note of the state in its lane, the next action's readlane -- runs under the LDS latency
-            // of the chain, which is v_and -> v_mad_u32_u24 (state * 2|A| + action term) -> ds_read_u16 and nothing else.  Two steps
-            // per backward branch, the exits not taken until the end.  Wait states by hand (the hazard pass does not look inside):
-            // a VALU that reads an SGPR / VCC a VALU wrote comes at least two instructions later.
-            uint32_t v1;
-            {   // the first step is unconditional (the reference's loop tests after the step)
-                const uint32_t a2 = (uint32_t)__builtin_amdgcn_readlane((int)act2, depth);
-                uint32_t ad = (uint32_t)s * (2u * A) + a2;
-                v1 = *(lds_u16_t *)(uintptr_t)ad;
+            // The walk, written out (inline assembly: the compiler rotates any C form of it back into read -> wait -> test, and a
+            // lone wave pays ~20 cycles for every branch, taken or not -- tools/lds_chain.hip: the bare chain v_and -> v_mad_u32_u24
+            // (state * 2|A| + action term) -> ds_read_u16 is 64 cycles a step, with two exit tests beside it 122).
+            //  * GROUPS OF FOUR steps without a branch: each slot issues the read of its step (speculative: any record's next state
+            //    is a valid state, its lane's action a valid action; what a step not taken leaves behind is never used) and, under
+            //    that read's latency, notes the state the step leaves from in its lane, fetches the next action term and shifts the
+            //    previous record's terminal bit into a scalar; ONE test per group finds the step the rollout ends with (the first set
+            //    bit: "next" rule = the records of the four steps, "source" rule = the records before them).  Groups run while four
+            //    more steps are within the horizon / step limit;
+            //  * the remaining (< 4) steps one by one, each with its two tests (the same slot otherwise).
+            // The walk starts from a VIRTUAL record: the state before the first step, bit 15 = "that state is terminal" under the
+            // "source" rule -- the first step is then an ordinary one (unconditional: the reference's loop tests after the step).
+            // Wait states by hand (the hazard pass does not look inside): a VALU that reads an SGPR / VCC a VALU wrote comes at
+            // least two instructions later.
+            uint32_t v1 = (uint32_t)s | (!p.done_on_next && cur_term ? 0x8000u : 0u);
+            int h = depth;                              // (v1 = the record of the step at depth h - 1; h <= H <= 63: a lane)
+            uint32_t done = 0;
+            if (h + 4 <= h_end) {
+                uint32_t w1, w2, w3, w4, t, a2, e, acc = 0, tst, h4;
+#define MP_LONE_SLOT(WP, WN)                                                                       \
+    "v_and_b32 %[t], 0x7fff, " WP "\n\t"                                                          \
+    "v_mad_u32_u24 %[t], %[t], %[mul], %[a2]\n\t"                                                  \
+    "ds_read_u16 " WN ", %[t]\n\t"                                                                 \
+    "v_cmp_eq_u32 vcc, %[h], %[lane]\n\t"                                                          \
+    "v_readfirstlane_b32 %[e], " WP "\n\t"                                                         \
+    "s_add_i32 %[h], %[h], 1\n\t"                                                                  \
+    "v_cndmask_b32 %[sv], %[sv], " WP ", vcc\n\t"                                                  \
+    "v_readlane_b32 %[a2], %[act2], %[h]\n\t"                                                      \
+    "s_lshr_b32 %[e], %[e], 15\n\t"                                                                \
+    "s_lshl1_add_u32 %[acc], %[acc], %[e]\n\t"                                                     \
+    "s_waitcnt lgkmcnt(0)\n\t"
+#define MP_LONE_GROUPS(TEST)                                                                       \
+    asm volatile("s_nop 3\n\t"                                                                     \
+                 "v_readlane_b32 %[a2], %[act2], %[h]\n\t"                                          \
+                 "s_nop 1\n\t"                                                                      \
+                 "1:\n\t"                                                                           \
+                 MP_LONE_SLOT("%[v1]", "%[w1]") MP_LONE_SLOT("%[w1]", "%[w2]")                      \
+                 MP_LONE_SLOT("%[w2]", "%[w3]") MP_LONE_SLOT("%[w3]", "%[w4]")                      \
+                 TEST                                                                               \
+                 "s_cbranch_scc1 2f\n\t"                                                            \
+                 "v_mov_b32 %[v1], %[w4]\n\t"                                                       \
+                 "s_add_i32 %[h4], %[h], 4\n\t"                                                     \
+                 "s_cmp_le_u32 %[h4], %[hend]\n\t"                                                  \
+                 "s_cbranch_scc1 1b\n\t"                                                            \
+                 "s_mov_b32 %[done], 0\n\t"                                                         \
+                 "s_branch 3f\n\t"                                                                  \
+                 "2:\n\t"               /* the group's step tst names is the last: (leading zeros of tst) - 27 of its 4 were taken */ \
+                 "s_flbit_i32_b32 %[tst], %[tst]\n\t"                                               \
+                 "s_add_i32 %[h], %[h], %[tst]\n\t"                                                 \
+                 "s_sub_i32 %[h], %[h], 31\n\t"                                                     \
+                 "s_mov_b32 %[done], 1\n\t"                                                         \
+                 "3:\n\t"                                                                           \
+                 : [h] "+s"(h), [sv] "+v"(sv), [v1] "+v"(v1), [acc] "+s"(acc), [done] "+s"(done), [w1] "=&v"(w1), [w2] "=&v"(w2), \
+                   [w3] "=&v"(w3), [w4] "=&v"(w4), [t] "=&v"(t), [a2] "=&s"(a2), [e] "=&s"(e), [tst] "=&s"(tst), [h4] "=&s"(h4)  \
+                 : [act2] "v"(act2), [lane] "v"(lane), [hend] "s"(h_end), [mul] "n"(2 * A)          \
+                 : "vcc", "scc", "memory")
+                if (p.done_on_next)
+                    MP_LONE_GROUPS("v_readfirstlane_b32 %[e], %[w4]\n\t"
+                                   "s_lshr_b32 %[e], %[e], 15\n\t"
+                                   "s_lshl1_add_u32 %[tst], %[acc], %[e]\n\t"
+                                   "s_and_b32 %[tst], %[tst], 15\n\t");
+                else
+                    MP_LONE_GROUPS("s_and_b32 %[tst], %[acc], 15\n\t");
+#undef MP_LONE_GROUPS
+#undef MP_LONE_SLOT
             }
-            int h = depth + 1;                          // (v1 = the record of the step at depth h - 1; h <= H <= 63: a lane)
-            {
-                uint32_t pe = cur_term ? 0x8000u : 0u;  // ("source" rule: the step FROM a terminal state is the last one)
+            done = (uint32_t)__builtin_amdgcn_readfirstlane((int)done);   // (scalar for the compiler too, whatever it made of the merge)
+            h = __builtin_amdgcn_readfirstlane(h);
+            if (!done) {
+                uint32_t pe = 0;                        // (the record before v1; a set bit 15 would have ended the walk already)
                 uint32_t v2, t, a2, e, h1;
 #define MP_LONE_HALF(V1, V2, STOP)                                                                 \
     "v_and_b32 %[t], 0x7fff, " V1 "\n\t"                                                          \
