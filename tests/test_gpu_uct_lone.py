@@ -147,3 +147,23 @@ def test_lone_hands_kept_subtrees_to_the_other_kernels(ctx):
         s = int(t[s, a])
     ctx.uct_reset_tree()
     model.close()
+
+
+@pytest.mark.parametrize("done_rule", ["source", "next"])
+@pytest.mark.parametrize("length", [1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 13])
+def test_lone_walk_every_group_phase(ctx, length, done_rule):
+    """The walk runs in groups of four speculative steps with one test per group, then step by step (round 6): a corridor whose
+    terminal state is `length` steps away makes every rollout end at a chosen phase of a group (every action moves on; the
+    states past the terminal one exist, so what a speculative step reads is a valid record) -- under both terminal rules, with
+    horizons that leave 0 .. 3 steps for the step-by-step tail, and with the env's step limit cutting the rollout instead."""
+    n_act, s = 3, 40
+    t = np.minimum(np.arange(s)[:, None] + 1, s - 1) * np.ones((1, n_act), dtype=np.int64)
+    g = np.random.Generator(np.random.PCG64(7 * length))
+    cfg = dict(transition=t, reward=g.choice(np.linspace(-1, 1, 9), size=(s, n_act)), terminal=np.arange(s) == length + 2)
+    p = np.ones(n_act) / n_act
+    for horizon in (length + 4, length + 5, length + 6, 63):
+        _cmp(ctx, cfg, 5, 9, horizon, 0.9, 3.0, p, p, seed=length, done_rule=done_rule)
+    cfg["terminal"] = np.zeros(s, dtype=bool)                      # no terminal state: the step limit ends the rollouts
+    for max_steps in (length, length + 1, length + 3):
+        _cmp(ctx, cfg, 5, 9, 30, 0.9, 3.0, p, p, seed=length, max_steps=max_steps, done_rule=done_rule,
+             steps0=np.array([0, 1, 2, 0, 1], dtype=np.int32))

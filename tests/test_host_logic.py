@@ -670,3 +670,44 @@ def test_product_never_imports_the_oracle():
             if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<][^\">]*oracle|planning_oracle|liboracle", text, re.M):
                 bad.append(os.path.relpath(os.path.join(root, f), REPO))
     assert not bad, bad
+
+
+def test_scalar_generator_step_restated_equals_numpy():
+    """csrc/pcg64.hpp Pcg64U (round 6: the wave-uniform generator of uct_lone_kernel in scalar registers) steps the 128-bit LCG with
+    64-bit pieces only: low product, high product by 32-bit limbs (mulhi), the add's carry as the majority bit of the top bits, and
+    XSL-RR as two 64-bit shifts.  Restated here with Python integers masked to 64 bits and checked against numpy's PCG64 stream
+    (the device result itself is compared with numpy by every GPU parity test that leaves a generator record)."""
+    m64 = (1 << 64) - 1
+
+    def mulhi(a, b):
+        a0, a1, b0, b1 = a & 0xffffffff, a >> 32, b & 0xffffffff, b >> 32
+        p00, p01, p10, p11 = a0 * b0, a0 * b1, a1 * b0, a1 * b1
+        mid = (p00 >> 32) + (p01 & 0xffffffff) + (p10 & 0xffffffff)
+        return (p11 + (p01 >> 32) + (p10 >> 32) + (mid >> 32)) & m64
+
+    def step(s_hi, s_lo, inc_hi, inc_lo):
+        m_lo, m_hi = 0x4385DF649FCCF645, 0x2360ED051FC65DA4
+        lo = (s_lo * m_lo) & m64
+        hi = (mulhi(s_lo, m_lo) + s_lo * m_hi + s_hi * m_lo) & m64
+        lo2 = (lo + inc_lo) & m64
+        carry = ((lo & inc_lo) | ((lo | inc_lo) & (~lo2 & m64))) >> 63
+        return (hi + inc_hi + carry) & m64, lo2
+
+    def output(s_hi, s_lo):
+        x, rot = s_hi ^ s_lo, s_hi >> 58
+        return ((x >> rot) | (x << ((64 - rot) & 63))) & m64
+
+    for seed in (0, 1, 12345, 2 ** 63 + 9):
+        bg = np.random.PCG64(seed)
+        st = bg.state["state"]
+        s_hi, s_lo = st["state"] >> 64, st["state"] & m64
+        inc_hi, inc_lo = st["inc"] >> 64, st["inc"] & m64
+        want = bg.random_raw(300)
+        for k in range(300):
+            s_hi, s_lo = step(s_hi, s_lo, inc_hi, inc_lo)
+            assert output(s_hi, s_lo) == int(want[k]), (seed, k)
+        assert (s_hi << 64) | s_lo == bg.state["state"]["state"]
+    # the carry formula on the corner cases of a 64-bit add
+    for a, b in ((m64, 1), (m64, m64), (1 << 63, 1 << 63), (0, 0), ((1 << 63) - 1, 1), (m64 - 5, 5), (m64 - 5, 6)):
+        lo2 = (a + b) & m64
+        assert ((a & b) | ((a | b) & (~lo2 & m64))) >> 63 == (a + b) >> 64
