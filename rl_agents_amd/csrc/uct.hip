@@ -2401,7 +2401,12 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             lds_lone <= kLdsBytes && !will_continue) {
             const char *le = getenv("MP_UCT_LONE");
             const long cus_l = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-            lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots <= cus_l); // (one workgroup per CU: 256 roots 0.14 ms, four lanes per root 0.27)
+            // One workgroup per CU for a model that fills its LDS (the headline table: 256 roots 0.088 ms); for smaller models as many
+            // as fit a CU's LDS together, up to two planning wavefronts per SIMD (tools/uct_small_batch.py with UCT_SB_SHAPE, round 6:
+            // S = 1 000: 1 024 roots 0.068 ms against the row kernel's 0.090; S = 250: 2 048 roots 0.083 / 0.094; S = 3 000: 512
+            // roots 0.088 / 0.128 -- and slower than the rows as soon as the workgroups need a second round)
+            const long fit_l = (long)(kLdsBytes / lds_lone);
+            lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots <= cus_l * (fit_l < 1 ? 1 : (fit_l > 8 ? 8 : fit_l)));
         }
     }
     // ONE MDP PER ROOT (uct_lone_kernel<.., EACH>): a batch model -- every root's own MDP staged into its workgroup's LDS from the
@@ -2436,10 +2441,14 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (!cart && !pol && at_known && model->NB > 1 && model->Sb > 0 && model->Sb < 32768 && want_il == 2 && H >= 1 && H <= 255 &&
             lds_row <= kLdsBytes && !will_continue && !force && !(getenv("MP_UCT_EACH") && atoi(getenv("MP_UCT_EACH")) == 0) &&
             !(re && atoi(re) == 0)) {
-            // measured (tools/micro_uct_row.py, S = 120, 33 x 30): 4096 roots 0.103 ms against 0.176 (a wavefront per root) and 0.175
-            // (a lane per root); 256 roots 0.090 against 0.081 -- with a CU to itself a root is served best by a whole wavefront
+            // measured (tools/each_ab.sh, S = 120, 33 x 30, after the lone kernel's rebuild in round 6): a wavefront per root against
+            // four roots per wavefront -- 256 roots 0.062 ms (lone), 512: 0.065 / 0.091, 1024: 0.067 / 0.090, 2048: 0.077 / 0.090,
+            // 4096: 0.143 / 0.098.  Up to two wavefronts per SIMD (and while their workgroups' LDS fits the CU together) a root is
+            // served best by a whole wavefront; beyond, the rows win (the SIMD is 16 lanes wide: four lone waves run at a quarter each).
             const long cus_r = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
-            rowk = (re && atoi(re) != 0) || !each || n_roots > cus_r;
+            const long fit_cu = lds_each > 0 ? (long)(kLdsBytes / lds_each) : 1;
+            const long lone_roots = cus_r * (fit_cu < 1 ? 1 : (fit_cu > 8 ? 8 : fit_cu));
+            rowk = (re && atoi(re) != 0) || !each || n_roots > lone_roots;
         }
     }
     if (rowk) each = false;

@@ -167,3 +167,16 @@ def test_lone_walk_every_group_phase(ctx, length, done_rule):
     for max_steps in (length, length + 1, length + 3):
         _cmp(ctx, cfg, 5, 9, 30, 0.9, 3.0, p, p, seed=length, max_steps=max_steps, done_rule=done_rule,
              steps0=np.array([0, 1, 2, 0, 1], dtype=np.int32))
+
+
+def test_lone_serves_as_many_roots_as_its_workgroups_fit_a_cu(ctx):
+    """Round 6: a model that leaves room in a CU's LDS plans as many roots on uct_lone_kernel as its workgroups fit the CU together
+    (at most two planning wavefronts per SIMD: 8 x the CUs); one root more, or a model that fills the LDS, takes the row kernel."""
+    from rl_agents_amd.envs import generators
+    p = np.ones(5) / 5
+    small = generators.highway_shaped(4, 5, 50, collision_rate=0.01, seed=9)       # S = 1 000: ~20 KB of LDS per workgroup
+    _cmp(ctx, small, 300, 20, 17, 0.95, 10.0, p, p, seed=17, trees=(0, 299))
+    _cmp(ctx, small, 1500, 12, 9, 0.9, 10.0, p, p, seed=18, trees=(0, 777, 1499))
+    tiny = generators.highway_shaped(3, 4, 10, seed=3)                               # S = 120
+    _cmp(ctx, tiny, 2048, 9, 8, 0.8, 10.0, p, p, seed=19, trees=(0, 2047))
+    _cmp(ctx, tiny, 2049, 9, 8, 0.8, 10.0, p, p, seed=19, expect="uct_row_shared", trees=())

@@ -90,17 +90,19 @@ def test_rows_every_action_count(ctx, n_actions):
 
 
 @pytest.mark.parametrize("horizon", [1, 2, 15, 16, 17, 33, 120, 255])
-def test_rows_horizons(ctx, horizon):
+def test_rows_horizons(ctx, monkeypatch, horizon):
     """Rollouts of every length around the rounds of sixteen draws, up to the 255 steps the jump table covers."""
     from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_ROWS", "1")     # (a model this small plans 300 roots on uct_lone_kernel by default since round 6)
     cfg = generators.highway_shaped(4, 5, 50, collision_rate=0.01, seed=9)
     p = np.ones(5) / 5
     _cmp(ctx, cfg, 300, 20, horizon, 0.95, 10.0, p, p, seed=horizon)
 
 
-def test_rows_truncation_terminal_conventions_and_zero_probabilities(ctx):
+def test_rows_truncation_terminal_conventions_and_zero_probabilities(ctx, monkeypatch):
     """TimeLimit truncation with per-root step counts, both terminal conventions, rollout policies with zero-probability actions."""
     from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_ROWS", "1")     # (as above: the small model's default is uct_lone_kernel)
     cfg = generators.highway_shaped(3, 4, 10, seed=3)
     n = 500
     steps0 = (np.arange(n) % 9).astype(np.int32)

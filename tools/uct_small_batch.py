@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the headline UCT plan (S = 10 000, |A| = 5, 33 x 30) at SURVEY 8(d)'s batch sizes, per kernel variant.
 
-    [MP_UCT_QUAD=0|1] [MI355PLAN_LIB=rl_agents_amd/lib/prof/libmi355plan.so] python tools/uct_small_batch.py ROOTS...
+    [UCT_SB_SHAPE=10,10,10] [MP_UCT_QUAD=0|1] [MI355PLAN_LIB=rl_agents_amd/lib/prof/libmi355plan.so] python tools/uct_small_batch.py ROOTS...
 """
 import os
 import sys
@@ -15,7 +15,8 @@ from rl_agents_amd.envs import generators  # noqa: E402
 
 
 def main():
-    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    shape = tuple(int(x) for x in os.environ.get("UCT_SB_SHAPE", "10,10,100").split(","))   # (lanes, speeds, cells): S = their product
+    cfg = generators.highway_shaped(*shape, seed=0)
     ctx = native.Context(0)
     model = ctx.load_table(cfg["transition"], cfg["reward"], cfg["terminal"])
     nt = np.flatnonzero(~np.asarray(cfg["terminal"]))
