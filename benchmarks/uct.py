@@ -266,6 +266,7 @@ def bench_uct(args, rank, world, local, with_prior=False):
                       peak=HBM_PEAK_GBS, unit="GB/s",
                       kernel={"uct_row_shared": "uct_row_kernel<5, SHARED> (four roots per wavefront, transitions + trees in LDS)",
                               "uct_lone": "uct_lone_kernel<5> (one root per workgroup)",
+                              "uct_lone_mw": "uct_lone_kernel<5, MW> (2 / 4 / 8 roots per workgroup, a wavefront each, one copy of the transitions in LDS)",
                               "uct_quad": "uct_kernel<5, ENV_TABLE_LDSR, QD> (four lanes per root)"}.get(variant) or
                       "uct_kernel<5, {}>".format("ENV_TABLE, per-state policies" if with_prior else
                                                  ("ENV_TABLE_LDSR (model resident in LDS)" if variant == "uct_ldsr" else "ENV_TABLE")),
@@ -303,6 +304,8 @@ def bench_uct(args, rank, world, local, with_prior=False):
         add_traffic(res["roofline"], "uct", "uct_row_kernel<{}, true>".format(a_), None)
     elif variant == "uct_lone":
         add_traffic(res["roofline"], "uct", "uct_lone_kernel<{}".format(a_), n_roots * 1024)
+    elif variant == "uct_lone_mw":
+        add_traffic(res["roofline"], "uct", "uct_lone_kernel<{}, false, true>".format(a_), None)
     else:
         add_traffic(res["roofline"], "uct_prior" if with_prior else "uct", "uct_kernel" if with_prior else kname, n_roots)
     if not with_prior and rank == 0 and world == 1 and not args.headline_only:

@@ -1224,9 +1224,15 @@ void uct_kernel(UctArgs p)
 // reward dictionary, any number of distinct rewards) -- 10 B per (s, a), 6 KB for a 120-state highway grid -- and everything
 // else is the lone-root kernel: tree in LDS, a level scored across lanes, the rollout's draws by jump-ahead in the lanes.  One
 // wave per workgroup (small MDPs) so that 4096 roots are 4096 wavefronts, four per SIMD.
-template <int AT, bool EACH = false>
+// MW (round 6): SEVERAL ROOTS PER WORKGROUP, A WAVEFRONT EACH, around ONE copy of a model that fills the LDS -- the headline table's
+// transitions are 100 of the CU's 160 KB, so with the reward indices beside them only one root fits a CU (256 roots per launch).
+// Here the workgroup keeps the transitions only, p.waves (2 / 4 / 8) planning wavefronts stay after the staging, each with its own
+// tree and its own copy of the jump table behind them, one or two per SIMD; an episode's rewards come from the model's 16-byte
+// records in L2 (ONE vector load for the whole episode: lane l its step's reward) instead of the two LDS round trips.
+template <int AT, bool EACH = false, bool MW = false>
 __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kernel(UctArgs p)
 {
+    static_assert(!(EACH && MW), "one MDP per root is staged per workgroup: one root each");
     static_assert(AT >= 2 && AT <= 8, "|A| with a compile-time specialisation");
     constexpr int A = AT, NTH = AT - 1;
     extern __shared__ __attribute__((aligned(16))) double lds_d[];
@@ -1239,19 +1245,25 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
     const int ntab = (H + 1) + 2 * A + (TE + 1) + A * (TE + 2);
     const int ntab2 = (ntab + 1) & ~1;
     const int SA = (EACH ? p.Sb : p.S) * A;                                       // (s, a) pairs of the model this root plans on
-    const double *rdict = lds_d + ntab2;                                          // shared model: [n_rdict] distinct rewards
+    const double *rdict = lds_d + ntab2;                                          // shared model: [n_rdict] distinct rewards (not MW)
     double *rew = lds_d + ntab2;                                                  // EACH: [SA] the rewards themselves
     uint16_t *t16 = EACH ? reinterpret_cast<uint16_t *>(rew + ((SA + 1) & ~1))
-                         : reinterpret_cast<uint16_t *>(lds_d + ntab2 + ((p.n_rdict + 1) & ~1));
-    uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((SA + 7) & ~7));             // shared model: [SA] reward indices
-    uint32_t *jump = EACH ? reinterpret_cast<uint32_t *>(r8) : reinterpret_cast<uint32_t *>(r8 + ((SA + 15) & ~15)); // [H + 5][8]
+                         : reinterpret_cast<uint16_t *>(lds_d + ntab2 + (MW ? 0 : ((p.n_rdict + 1) & ~1)));
+    uint8_t *r8 = reinterpret_cast<uint8_t *>(t16 + ((SA + 7) & ~7));             // shared model: [SA] reward indices (not MW)
+    // per planning wavefront: its copy of the jump table [H + 5][8] (it gets the root's inc G_j), its tree [cap] and a node's
+    // exploration term at its count [cap]
+    uint32_t *jump0 = (EACH || MW) ? reinterpret_cast<uint32_t *>(r8) : reinterpret_cast<uint32_t *>(r8 + ((SA + 15) & ~15));
+    const int W = MW ? p.waves : 1;
+    const int wstride = ((H + 5) * 8 + p.cap * 6 + 3) & ~3;                       // 32-bit words per wavefront (16-byte multiples)
+    uint32_t *jump = jump0 + (MW ? (tid >> 6 < W ? tid >> 6 : 0) * wstride : 0);
     UctNode *tnode = reinterpret_cast<UctNode *>(jump + (H + 5) * 8);            // [cap]
-    double *texpl = reinterpret_cast<double *>(tnode + p.cap);                   // [cap] a node's exploration term at its count
+    double *texpl = reinterpret_cast<double *>(tnode + p.cap);                   // [cap]
     // (the [H + 1] words behind texpl held the path until round 6: it now lives in a register, one node per lane)
-    const int r = blockIdx.x;
-    const int32_t s0g = __builtin_amdgcn_readfirstlane(p.root_state[r]);         // (global state of a batch model)
+    int r = blockIdx.x;
+    int32_t s0g = MW ? 0 : __builtin_amdgcn_readfirstlane(p.root_state[r]);      // (global state of a batch model)
     const int32_t sbase = EACH ? (s0g / p.Sb) * p.Sb : 0;                         // first global state of this root's MDP
-    for (int i = tid; i < (H + 5) * 8; i += nthreads) jump[i] = p.jump[i];
+    for (int w = 0; w < W; ++w)
+        for (int i = tid; i < (H + 5) * 8; i += nthreads) jump0[w * wstride + i] = p.jump[i];
     for (int i = tid; i < ntab; i += nthreads) lds_d[i] = p.tab[i];
     if constexpr (EACH) {
         const Rec *src = p.rec + (long)sbase * A;
@@ -1261,11 +1273,13 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
             rew[i] = rc.reward;
         }
     } else {
-        for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
-        const int n16 = (p.S * A + 15) >> 4; // (the device arrays are padded to whole 16-byte chunks)
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.r8);
-        uint4 *dst = reinterpret_cast<uint4 *>(r8);
-        for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+        if constexpr (!MW) {
+            for (int i = tid; i < p.n_rdict; i += nthreads) lds_d[ntab2 + i] = p.rdict[i];
+            const int n16 = (p.S * A + 15) >> 4; // (the device arrays are padded to whole 16-byte chunks)
+            const uint4 *src = reinterpret_cast<const uint4 *>(p.r8);
+            uint4 *dst = reinterpret_cast<uint4 *>(r8);
+            for (int i = tid; i < n16; i += nthreads) dst[i] = src[i];
+        }
         const int n = p.S * A, n8 = n >> 3;
         const uint4 *src2 = reinterpret_cast<const uint4 *>(p.t16);
         uint4 *dst2 = reinterpret_cast<uint4 *>(t16);
@@ -1273,7 +1287,12 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
         for (int i = (n8 << 3) + tid; i < n; i += nthreads) t16[i] = p.t16[i];
     }
     __syncthreads();
-    if (tid >= 64) return; // (the staging waves are done; no barrier below)
+    if (tid >= 64 * W) return; // (the staging waves are done; no barrier below)
+    if constexpr (MW) {
+        r = blockIdx.x * W + (tid >> 6);
+        if (r >= p.n_roots) return;
+        s0g = __builtin_amdgcn_readfirstlane(p.root_state[r]);
+    }
     // MCTSNode.selection_strategy's exploration term temperature |A| prior[a] / (count + 1) (mcts.py:275-286): from the host's
     // quotient table, or the same IEEE division beyond it.  Kept PER NODE beside the tree and refreshed by the backup (which
     // changes the count), so that scoring a level is one LDS round trip, not two
@@ -1536,7 +1555,7 @@ __global__ __launch_bounds__(EACH ? 256 : 1024, EACH ? 4 : 1) void uct_lone_kern
         {
             const int L = depth + n_roll;
             double rd;
-            if constexpr (EACH) rd = rew[idxv]; else rd = rdict[r8[idxv]];
+            if constexpr (EACH) rd = rew[idxv]; else if constexpr (MW) rd = p.rec[idxv].reward; else rd = rdict[r8[idxv]];
             double prod = gpl * rd;
             prod = lane < L ? prod : 0.0;     // (+0.0 leaves a sum that started at +0.0 as it is, bit for bit)
 #pragma unroll
@@ -2394,7 +2413,12 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
     // ONE ROOT PER WORKGROUP (uct_lone_kernel): batches of at most one root per CU -- a single agent's act() above all -- on fresh
     // trees: model, tables AND tree in LDS, the whole wavefront working for the root.  MP_UCT_LONE=1 / 0 forces it on (any batch) / off.
     bool lone = false;
+    int lone_w = 0;                 // > 0: the multi-wavefront form (MW), that many planning wavefronts per workgroup
     const size_t lds_lone = lds_quad + (size_t)cap * (sizeof(UctNode) + sizeof(double)) + (size_t)(H + 1) * sizeof(int32_t) + 16;
+    auto lds_lone_mw_of = [&](int w) {     // tables + the transitions + w x (jump table + tree + exploration terms)
+        return ((ntab + 1) & ~(size_t)1) * sizeof(double) + (((size_t)model->S * A + 7) & ~(size_t)7) * 2 +
+               (size_t)w * ((((size_t)(H + 5) * 8 + (size_t)cap * 6 + 3) & ~(size_t)3) * 4) + 16;
+    };
     {
         const bool will_continue = ctx->tree.armed && ctx->tree.kind == 1 && ctx->tree.n_roots == n_roots && ctx->tree.A == A;
         if (!cart && !pol && at_known && model->t16 != nullptr && model->r8 != nullptr && want_il == 2 && H >= 1 && H <= 63 &&
@@ -2407,6 +2431,20 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             // roots 0.088 / 0.128 -- and slower than the rows as soon as the workgroups need a second round)
             const long fit_l = (long)(kLdsBytes / lds_lone);
             lone = le ? atoi(le) != 0 : (!force && !getenv("MP_UCT_QUAD") && n_roots <= cus_l * (fit_l < 1 ? 1 : (fit_l > 8 ? 8 : fit_l)));
+        }
+        // ... and for a model that fills the LDS (the headline table: one such workgroup per CU), SEVERAL planning wavefronts per
+        // workgroup around one copy of the transitions, the rewards from the records in L2 (uct_lone_kernel<.., MW>): batches of up
+        // to 8 roots per CU (two wavefronts per SIMD).  MP_UCT_LONE_WAVES=2 / 4 / 8 forces the form (any batch), 0 turns it off.
+        const char *we = getenv("MP_UCT_LONE_WAVES");
+        const bool we_on = we && (atoi(we) == 2 || atoi(we) == 4 || atoi(we) == 8);
+        if (!cart && !pol && at_known && model->t16 != nullptr && model->NB <= 1 && want_il == 2 && H >= 1 && H <= 63 && !will_continue &&
+            (!lone || we_on) && !(getenv("MP_UCT_LONE") && atoi(getenv("MP_UCT_LONE")) == 0)) {
+            const long cus_l = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
+            int w = 0;
+            if (we) { if (we_on) w = atoi(we); }
+            else if (!force && !getenv("MP_UCT_QUAD") && !getenv("MP_UCT_ROWS") && !getenv("MP_UCT_PATH") && n_roots > cus_l && n_roots <= 8 * cus_l)
+                w = n_roots <= 2 * cus_l ? 2 : (n_roots <= 4 * cus_l ? 4 : 8);
+            if (w && lds_lone_mw_of(w) <= kLdsBytes) { lone = true; lone_w = w; }
         }
     }
     // ONE MDP PER ROOT (uct_lone_kernel<.., EACH>): a batch model -- every root's own MDP staged into its workgroup's LDS from the
@@ -2552,7 +2590,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         while (a.waves < w && a.waves < 16) a.waves <<= 1;
     }
     const size_t lds_base = ntab * sizeof(double) + (size_t)(H + 1) * a.waves * 64 * sizeof(int32_t);
-    size_t lds = rowsh ? lds_rowsh : rowk ? lds_row : each ? lds_each : lone ? lds_lone : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
+    size_t lds = rowsh ? lds_rowsh : rowk ? lds_row : each ? lds_each : lone ? (lone_w ? lds_lone_mw_of(lone_w) : lds_lone) : quad ? lds_quad : (ldsr ? lds_ldsr : lds_base + (ldsm ? (((size_t)model->S * A * 2 + 15) & ~(size_t)15) + 16 : 0));
     if (cart) lds += 8 + (size_t)MP_SINCOS_ENTRIES * sizeof(double) + (size_t)(H + 5) * 32; // the sin / cos table of libm_sincos.hpp behind the path stack, then the jump table
     if (ldsm && lds > kLdsBytes) {
         if (force && force[0] == 'l') return fail(MP_ERR_ARG, "mp_uct_plan: model does not fit LDS (%zu B)", lds);
@@ -2608,7 +2646,7 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         if (lds > 64 * 1024) { spill = true; lds = ntab * sizeof(double); }
     }
     if (spill && ctx->tree.il == 1) return fail(MP_ERR_ARG, "mp_uct_plan: horizon %d needs the spilled path stack, which the interleaved tree layout does not have", H);
-    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (rowsh ? "uct_row_shared" : rowk ? "uct_row_each" : each ? "uct_lone_each" : lone ? "uct_lone" : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
+    snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", cart ? "uct_cartpole" : (pol ? "uct_policy" : (rowsh ? "uct_row_shared" : rowk ? "uct_row_each" : each ? "uct_lone_each" : lone ? (lone_w ? "uct_lone_mw" : "uct_lone") : quad ? "uct_quad" : ldsr ? "uct_ldsr" : (ldsm ? "uct_lds" : (spill ? "uct_global_spill" : "uct_global")))));
     if (ldsr || spill) {
         a.spill_stride = ((long)n_roots + 63) & ~63L;
         MP_TRY(ws_get(ctx, WS_TREE4, (size_t)(H + 1) * (size_t)a.spill_stride, &a.path_spill));
@@ -2745,6 +2783,16 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
             MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_lone_kernel<k, true>),                                  \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                    \
         hipLaunchKernelGGL((uct_lone_kernel<k, true>), dim3((unsigned)c.n_roots), dim3(threads), lds, s, c);                      \
+        break;
+            switch (A) { MP_LONE(2) MP_LONE(3) MP_LONE(4) MP_LONE(5) MP_LONE(6) MP_LONE(7) MP_LONE(8) default: break; }
+#undef MP_LONE
+        } else if (lone && lone_w) {
+            c.waves = lone_w;          // the planning wavefronts of a workgroup (its sixteen stage the model first)
+#define MP_LONE(k)                                                                                                                 \
+    case k:                                                                                                                        \
+        MP_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(uct_lone_kernel<k, false, true>),                               \
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                                        \
+        hipLaunchKernelGGL((uct_lone_kernel<k, false, true>), dim3((unsigned)((c.n_roots + lone_w - 1) / lone_w)), dim3(1024), lds, s, c); \
         break;
             switch (A) { MP_LONE(2) MP_LONE(3) MP_LONE(4) MP_LONE(5) MP_LONE(6) MP_LONE(7) MP_LONE(8) default: break; }
 #undef MP_LONE

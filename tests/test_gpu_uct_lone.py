@@ -66,7 +66,8 @@ def test_lone_is_for_at_most_one_root_per_cu_and_by_request(ctx, monkeypatch):
     from rl_agents_amd.envs import generators
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     p = np.ones(5) / 5
-    _cmp(ctx, cfg, 257, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_row_shared")   # (round 6: trees in LDS for 257 .. 4096 roots too)
+    _cmp(ctx, cfg, 257, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_lone_mw")   # (round 6: two planning wavefronts per workgroup)
+    _cmp(ctx, cfg, 2049, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_row_shared", trees=())   # (beyond 8 roots per CU: the row kernel)
     monkeypatch.setenv("MP_UCT_LONE", "0")
     _cmp(ctx, cfg, 8, 6, 10, 0.8, 10.0, p, p, seed=2, expect="uct_global")
     monkeypatch.setenv("MP_UCT_LONE", "1")
@@ -180,3 +181,37 @@ def test_lone_serves_as_many_roots_as_its_workgroups_fit_a_cu(ctx):
     tiny = generators.highway_shaped(3, 4, 10, seed=3)                               # S = 120
     _cmp(ctx, tiny, 2048, 9, 8, 0.8, 10.0, p, p, seed=19, trees=(0, 2047))
     _cmp(ctx, tiny, 2049, 9, 8, 0.8, 10.0, p, p, seed=19, expect="uct_row_shared", trees=())
+
+
+@pytest.mark.parametrize("n_roots", [257, 700, 1024, 1025, 2048])
+def test_lone_multi_wave_headline_geometry(ctx, n_roots):
+    """uct_lone_kernel<.., MW> (round 6): 2 / 4 / 8 planning wavefronts per workgroup around ONE copy of the headline table's
+    transitions (S = 10 000: 100 of the CU's 160 KB), each root's tree and jump table behind them, an episode's rewards from the
+    16-byte records in L2 -- the default for 257 .. 2048 roots.  Plans, statistics, generator records and whole trees vs the oracle."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 10, 100, seed=0)
+    p = np.ones(5) / 5
+    _cmp(ctx, cfg, n_roots, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=n_roots, expect="uct_lone_mw", trees=(0, 1, n_roots // 2, n_roots - 1))
+
+
+@pytest.mark.parametrize("waves", [2, 4, 8])
+def test_lone_multi_wave_forced_ragged_and_rules(ctx, monkeypatch, waves):
+    """Forced (MP_UCT_LONE_WAVES) on batches that leave the last workgroup ragged or need several rounds of workgroups, both
+    terminal rules, a step limit with per-root step counts, non-uniform policies with zero-probability actions, |A| = 3 and 8, and
+    a reward table with more than 256 distinct values (no compact reward index exists: the records are the only source)."""
+    from rl_agents_amd.envs import generators
+    monkeypatch.setenv("MP_UCT_LONE_WAVES", str(waves))
+    cfg = generators.highway_shaped(4, 5, 50, collision_rate=0.02, seed=11)
+    prior = np.array([0.1, 0.5, 0.1, 0.2, 0.1])
+    for n_roots in (1, waves + 1, 3000):
+        for done_rule in ("source", "next"):
+            _cmp(ctx, cfg, n_roots, 12, 9, 0.9, 5.0, prior, np.array([0.0, 0.25, 0.5, 0.25, 0.0]), seed=waves, done_rule=done_rule,
+                 expect="uct_lone_mw", trees=(0, n_roots - 1))
+    steps0 = (np.arange(77) % 6).astype(np.int32)
+    _cmp(ctx, cfg, 77, 20, 14, 0.8, 10.0, prior, np.ones(5) / 5, seed=5, max_steps=9, steps0=steps0, expect="uct_lone_mw", trees=(0, 76))
+    g = np.random.Generator(np.random.PCG64(100 + waves))
+    for n_act in (3, 8):
+        s = 400
+        many = dict(transition=g.integers(0, s, size=(s, n_act)), reward=g.random((s, n_act)), terminal=g.random(s) < 0.05)
+        p = np.ones(n_act) / n_act
+        _cmp(ctx, many, 41, 15, 11, 0.95, 4.0, p, p, seed=n_act, expect="uct_lone_mw", trees=(0, 40))

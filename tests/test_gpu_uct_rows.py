@@ -17,6 +17,13 @@ def ctx():
     c.close()
 
 
+@pytest.fixture(autouse=True)
+def _rows_not_the_multi_wave_lone_form(monkeypatch):
+    """These are the row kernel's tests: since later in round 6 batches of up to 8 roots per CU take uct_lone_kernel<.., MW> by
+    default (tests/test_gpu_uct_lone.py covers it); with that form off the row kernel is the default from one root per CU up."""
+    monkeypatch.setenv("MP_UCT_LONE_WAVES", "0")
+
+
 def _cmp(ctx, cfg, n_roots, episodes, horizon, gamma, temperature, prior, rollout, seed=0, max_steps=0, steps0=None,
          done_rule="source", expect="uct_row_shared"):
     from oracle import oracle
@@ -43,12 +50,14 @@ def _cmp(ctx, cfg, n_roots, episodes, horizon, gamma, temperature, prior, rollou
 
 
 @pytest.mark.parametrize("n_roots", [257, 1000, 1024, 2049, 4096])
-def test_rows_headline_geometry_default(ctx, n_roots):
-    """Headline table (S = 10 000, |A| = 5), budget 1000 as 33 x 30: the default kernel from 257 to 4096 roots (one, two or four
-    waves per workgroup by batch size)."""
+def test_rows_headline_geometry_default(ctx, monkeypatch, n_roots):
+    """Headline table (S = 10 000, |A| = 5), budget 1000 as 33 x 30: the default kernel from 2049 to 4096 roots, and from 257 with
+    the multi-wavefront lone form turned off (one, two or four waves per workgroup by batch size)."""
     from rl_agents_amd.envs import generators
     cfg = generators.highway_shaped(10, 10, 100, seed=0)
     p = np.ones(5) / 5
+    if n_roots <= 2048:
+        monkeypatch.setenv("MP_UCT_LONE_WAVES", "0")     # (round 6, later: up to 8 roots per CU plan on uct_lone_kernel<.., MW>)
     _cmp(ctx, cfg, n_roots, 33, 30, 0.8, 2 / (1 - 0.8), p, p, seed=n_roots)
 
 

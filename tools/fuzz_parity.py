@@ -103,7 +103,7 @@ def one_case(ctx, g, case):
     # round 6: the row kernel on a shared model (default for 16 .. 4096 roots where uct_lone_kernel does not apply) forced on / off,
     # two / four roots per wavefront, one to eight planning wavefronts; on batch models the row / wavefront-per-root forms; batched
     # VI's cluster form (K workgroups per MDP)
-    for knob in ("MP_UCT_ROWS", "MP_UCT_ROW_ROOTS", "MP_UCT_ROW_WAVES", "MP_UCT_ROW", "MP_UCT_EACH", "MP_VI_BATCH_CLUSTER"):
+    for knob in ("MP_UCT_ROWS", "MP_UCT_ROW_ROOTS", "MP_UCT_ROW_WAVES", "MP_UCT_ROW", "MP_UCT_EACH", "MP_VI_BATCH_CLUSTER", "MP_UCT_LONE_WAVES"):
         os.environ.pop(knob, None)
     rows = str(g.choice(["", "", "0", "1"]))
     if rows and not quad and kind in ("uct", "uct_subtree", "update_rows"):
@@ -121,8 +121,13 @@ def one_case(ctx, g, case):
     cluster = str(g.choice(["", "", "0", "2", "4", "8"]))
     if cluster and kind == "vi_batch":
         os.environ["MP_VI_BATCH_CLUSTER"] = cluster
+    # round 6, later: several planning wavefronts per workgroup around one copy of the transitions (uct_lone_kernel<.., MW>: the
+    # default for batches of up to 8 roots per CU of a model that fills the LDS) forced on with 2 / 4 / 8 wavefronts, or off
+    lone_w = str(g.choice(["", "", "0", "2", "4", "8"]))
+    if lone_w and not quad and not rows and kind in ("uct", "uct_subtree", "update_rows"):
+        os.environ["MP_UCT_LONE_WAVES"] = lone_w
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad, wide=wide,
-                rows=rows, rpw=rpw, rwaves=rwaves, each=each, cluster=cluster)
+                rows=rows, rpw=rpw, rwaves=rwaves, each=each, cluster=cluster, lone_w=lone_w)
     if kind in ("vi_batch", "per_root_models"):
         # N independent MDPs of this shape (mp_model_load_table_batch): N value-iteration agents in one launch, each to its own
         # allclose exit, in every kernel form; UCT and OPD with one MDP per root; a second round after mp_model_update_tables
@@ -653,7 +658,7 @@ def run(n_cases, seed, ctx=None, verbose=False):
         os.environ.pop("MP_OPD_CLOSING", None)
         os.environ.pop("MP_OPD_LOOP", None)
         os.environ.pop("MP_OPD_WIDE", None)
-        for knob in ("MP_UCT_QUAD", "MP_UCT_ROWS", "MP_UCT_ROW_ROOTS", "MP_UCT_ROW_WAVES", "MP_UCT_ROW", "MP_UCT_EACH", "MP_VI_BATCH_CLUSTER"):
+        for knob in ("MP_UCT_QUAD", "MP_UCT_ROWS", "MP_UCT_ROW_ROOTS", "MP_UCT_ROW_WAVES", "MP_UCT_ROW", "MP_UCT_EACH", "MP_VI_BATCH_CLUSTER", "MP_UCT_LONE_WAVES"):
             os.environ.pop(knob, None)
         if forced is not None:
             os.environ["MP_OPD_MODEL"] = forced

@@ -17,12 +17,13 @@ args_of() {
   elif [ "$1" = uct4096 ]; then echo "--workload uct --roots 4096";
   elif [ "$1" = uct1 ]; then echo "--workload uct --roots 1";
   elif [ "$1" = uct256 ]; then echo "--workload uct --roots 256";
+  elif [ "$1" = uct1024 ]; then echo "--workload uct --roots 1024";
   elif [ "$1" = vi_batch ]; then echo "--workload vi_batch --states 120 --roots 4096";
   elif [ "$1" = vi_batch_s10000 ]; then echo "--workload vi_batch --states 10000 --roots 64";
   elif [ "$1" = vi_batch_s10000_256 ]; then echo "--workload vi_batch --states 10000 --roots 256";
   else echo "--workload $1"; fi; }
 # (TRACE_WLS / PMC_WLS: re-collect a subset after a kernel changed; summarize_profiles.py reads whatever is there)
-for wl in ${TRACE_WLS:-uct uct4096 uct256 uct1 uct_per_root_model uct_prior uct_cartpole uct_stoch opd opd8192 ropd saopd vi rvi vi_batch vi_batch_s10000 vi_batch_s10000_256 vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact}; do
+for wl in ${TRACE_WLS:-uct uct4096 uct1024 uct256 uct1 uct_per_root_model uct_prior uct_cartpole uct_stoch opd opd8192 ropd saopd vi rvi vi_batch vi_batch_s10000 vi_batch_s10000_256 vi_dense vi_dense_exact rvi_dense_shard rvi_dense_shard_exact}; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$wl -o $wl -- \
       python /root/repo/bench.py $(args_of $wl) --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample > $OUT/trace_$wl.log 2>&1
 done

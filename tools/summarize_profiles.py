@@ -50,13 +50,14 @@ def main():
     lines = ["# rocprofv3 --kernel-trace --stats summaries ({})".format(tag), "",
              "Command per workload: `rocprofv3 --kernel-trace --stats --output-format csv -- python bench.py "
              "--workload <wl> --steps 5 --warmup 1 --no-cpu-baseline --headline-only --no-parity-sample` on one MI355X (tools/profile_gpu.sh; BENCH_NO_LIVE_PMC unset is harmless: --headline-only skips it).", ""]
-    for wl in ("uct", "uct4096", "uct256", "uct1", "uct_per_root_model", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi",
+    for wl in ("uct", "uct4096", "uct1024", "uct256", "uct1", "uct_per_root_model", "uct_prior", "uct_cartpole", "uct_stoch", "opd", "opd8192", "ropd", "saopd", "vi", "rvi",
                "vi_batch", "vi_batch_s10000", "vi_batch_s10000_256", "vi_dense", "vi_dense_exact", "rvi_dense_shard", "rvi_dense_shard_exact"):
         f = os.path.join(src, "trace_" + wl, wl + "_kernel_stats.csv")
         if not os.path.exists(f):
             continue
         lines += ["## " + wl + (" (= --workload opd --roots 8192)" if wl == "opd8192" else
                                 " (= --workload uct --roots 4096: the row kernel on a shared model, uct_row_kernel<5, true>)" if wl == "uct4096" else
+                                " (= --workload uct --roots 1024: four roots per workgroup, a wavefront each, uct_lone_kernel<5, false, true>)" if wl == "uct1024" else
                                 " (= --workload uct --roots 256: one root per workgroup, uct_lone_kernel)" if wl == "uct256" else
                                 " (= --workload uct --roots 1: a single agent's plan, uct_lone_kernel)" if wl == "uct1" else
                                 " (= --workload vi_batch --states 120 --roots 4096)" if wl == "vi_batch" else
