@@ -630,7 +630,8 @@ int mp_olop_allocation(int32_t budget, double gamma, int32_t *episodes, int32_t 
  * the ctx stream around the kernel launches only (no copies).  Synchronises the stream. */
 int mp_last_kernel_ms(mp_ctx *ctx, double *ms, int32_t *n_launches);
 /* Name of the kernel variant the last mp_uct_plan* / mp_vi_solve_batch call launched -- "uct_global", "uct_ldsr" (model resident
- * in LDS), "uct_lds", "uct_quad" (four lanes per root), "uct_lone" (one root per workgroup), "uct_row_shared" / "uct_row_each" /
+ * in LDS), "uct_lds", "uct_quad" (four lanes per root), "uct_lone" (one root per workgroup), "uct_lone_mw" (2 / 4 / 8 roots per workgroup, a
+ * wavefront each, around one copy of the transitions), "uct_row_shared" / "uct_row_each" /
  * "uct_lone_each" (four roots per wavefront on DPP rows, trees in LDS: a shared model / one MDP per root; a wavefront per root),
  * "uct_policy", "uct_cartpole", "uct_global_spill"; "vi_batch_reg<own,block>", "vi_batch_cluster2|4|8" (K workgroups per MDP),
  * "vi_batch_wg_stream", "vi_batch_wg_lds", "vi_batch_wg_global": the host picks by model and batch size; reports and tests name
