@@ -2434,16 +2434,19 @@ static int uct_plan_impl(mp_ctx *ctx, mp_model *model, const mp_policy *pol, int
         }
         // ... and for a model that fills the LDS (the headline table: one such workgroup per CU), SEVERAL planning wavefronts per
         // workgroup around one copy of the transitions, the rewards from the records in L2 (uct_lone_kernel<.., MW>): batches of up
-        // to 8 roots per CU (two wavefronts per SIMD).  MP_UCT_LONE_WAVES=2 / 4 / 8 forces the form (any batch), 0 turns it off.
+        // to 8 roots per CU (two wavefronts per SIMD) -- and, with ONE planning wavefront, small batches of a model the plain form cannot
+        // take.  MP_UCT_LONE_WAVES=1 / 2 / 4 / 8 forces the form (any batch), 0 turns it off.
         const char *we = getenv("MP_UCT_LONE_WAVES");
-        const bool we_on = we && (atoi(we) == 2 || atoi(we) == 4 || atoi(we) == 8);
+        const bool we_on = we && (atoi(we) == 1 || atoi(we) == 2 || atoi(we) == 4 || atoi(we) == 8);
         if (!cart && !pol && at_known && model->t16 != nullptr && model->NB <= 1 && want_il == 2 && H >= 1 && H <= 63 && !will_continue &&
             (!lone || we_on) && !(getenv("MP_UCT_LONE") && atoi(getenv("MP_UCT_LONE")) == 0)) {
             const long cus_l = ctx->prop.multiProcessorCount > 0 ? ctx->prop.multiProcessorCount : 256;
             int w = 0;
             if (we) { if (we_on) w = atoi(we); }
-            else if (!force && !getenv("MP_UCT_QUAD") && !getenv("MP_UCT_ROWS") && !getenv("MP_UCT_PATH") && n_roots > cus_l && n_roots <= 8 * cus_l)
-                w = n_roots <= 2 * cus_l ? 2 : (n_roots <= 4 * cus_l ? 4 : 8);
+            else if (!force && !getenv("MP_UCT_QUAD") && !getenv("MP_UCT_ROWS") && !getenv("MP_UCT_PATH") && n_roots <= 8 * cus_l)
+                // (at most one root per CU gets here when the plain form is not to be had: no compact reward index -- more than 256
+                // distinct rewards -- or transitions + reward indices beyond the LDS; the transitions alone may still fit)
+                w = n_roots <= cus_l ? 1 : (n_roots <= 2 * cus_l ? 2 : (n_roots <= 4 * cus_l ? 4 : 8));
             if (w && lds_lone_mw_of(w) <= kLdsBytes) { lone = true; lone_w = w; }
         }
     }

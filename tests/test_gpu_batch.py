@@ -129,6 +129,11 @@ def test_uct_lds_resident_model_falls_back(ctx, monkeypatch):
         ctx.uct_plan(model, np.zeros(4, np.int32), 5, 5, 0.9, 5.0, p, p, _rng_states(4), max_plan_len=5)
     monkeypatch.delenv("MP_UCT_MODEL")
     ctx.uct_plan(model, np.zeros(4, np.int32), 5, 5, 0.9, 5.0, p, p, _rng_states(4), max_plan_len=5)
+    # (round 6: its TRANSITIONS alone -- 160 000 B -- fit the LDS beside this small plan's tree: the multi-wavefront lone form with
+    # one planning wavefront takes it, the rewards from the records; tests/test_gpu_uct_lone.py compares that form with the oracle)
+    assert ctx.last_kernel_variant() == "uct_lone_mw"
+    monkeypatch.setenv("MP_UCT_LONE_WAVES", "0")
+    ctx.uct_plan(model, np.zeros(4, np.int32), 5, 5, 0.9, 5.0, p, p, _rng_states(4), max_plan_len=5)
     assert ctx.last_kernel_variant() == "uct_global"
     model.close()
 

@@ -215,3 +215,27 @@ def test_lone_multi_wave_forced_ragged_and_rules(ctx, monkeypatch, waves):
         many = dict(transition=g.integers(0, s, size=(s, n_act)), reward=g.random((s, n_act)), terminal=g.random(s) < 0.05)
         p = np.ones(n_act) / n_act
         _cmp(ctx, many, 41, 15, 11, 0.95, 4.0, p, p, seed=n_act, expect="uct_lone_mw", trees=(0, 40))
+
+
+def test_lone_one_wave_for_models_without_a_compact_reward_index(ctx):
+    """A table with more than 256 distinct rewards has no one-byte reward index, so the plain one-root-per-workgroup form (model =
+    transitions + reward indices in LDS) does not apply; the MW form with ONE planning wavefront does (transitions in LDS, rewards
+    from the records): a single agent's act() on such a model, and every small batch of it."""
+    g = np.random.Generator(np.random.PCG64(21))
+    s, n_act = 3000, 5
+    cfg = dict(transition=g.integers(0, s, size=(s, n_act)), reward=g.random((s, n_act)), terminal=g.random(s) < 0.03)
+    p = np.ones(n_act) / n_act
+    for n_roots in (1, 7, 256):
+        _cmp(ctx, cfg, n_roots, 33, 30, 0.8, 10.0, p, p, seed=n_roots, expect="uct_lone_mw", trees=(0, n_roots - 1))
+    _cmp(ctx, cfg, 300, 12, 20, 0.9, 10.0, p, p, seed=3, done_rule="next", expect="uct_lone_mw", trees=(0, 299))
+
+
+def test_lone_one_wave_for_a_model_whose_transitions_alone_fit_the_lds(ctx):
+    """S = 15 000, |A| = 5: 150 KB of transitions + 75 KB of reward indices is beyond the CU's LDS for the plain form; the
+    transitions alone, one tree and the tables are 159 of its 160 KB -- the MW form with one planning wavefront, budget 1000."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.highway_shaped(10, 15, 100, seed=2)
+    assert cfg["reward"].shape == (15000, 5)
+    p = np.ones(5) / 5
+    for n_roots in (1, 40):
+        _cmp(ctx, cfg, n_roots, 33, 30, 0.8, 10.0, p, p, seed=4 + n_roots, expect="uct_lone_mw", trees=(0, n_roots - 1))

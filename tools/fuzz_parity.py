@@ -122,8 +122,8 @@ def one_case(ctx, g, case):
     if cluster and kind == "vi_batch":
         os.environ["MP_VI_BATCH_CLUSTER"] = cluster
     # round 6, later: several planning wavefronts per workgroup around one copy of the transitions (uct_lone_kernel<.., MW>: the
-    # default for batches of up to 8 roots per CU of a model that fills the LDS) forced on with 2 / 4 / 8 wavefronts, or off
-    lone_w = str(g.choice(["", "", "0", "2", "4", "8"]))
+    # default for batches of up to 8 roots per CU of a model that fills the LDS) forced on with 1 / 2 / 4 / 8 wavefronts, or off
+    lone_w = str(g.choice(["", "", "0", "1", "2", "4", "8"]))
     if lone_w and not quad and not rows and kind in ("uct", "uct_subtree", "update_rows"):
         os.environ["MP_UCT_LONE_WAVES"] = lone_w
     desc = dict(case=case, kind=kind, S=s, A=a, n=n, gamma=gamma, done_rule=done_rule, max_steps=max_steps, variant=variant, quad=quad, wide=wide,
