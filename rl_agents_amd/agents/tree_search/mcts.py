@@ -447,13 +447,10 @@ class MCTS(AbstractPlanner):
             self._last_tables = (np.asarray(device_model.finite_mdp_of(state).transition), prior_ids,
                                  np.asarray(root_states, dtype=np.int64))
         else:
-            self._log_plan(model, root_states, root_steps, rng_states, None,
-                           ("flat", policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A)),
-                           continued)
+            prior_p, rollout_p = policy_probabilities(self.prior_policy, model.A), policy_probabilities(self.rollout_policy, model.A)
+            self._log_plan(model, root_states, root_steps, rng_states, None, ("flat", prior_p, rollout_p), continued)
             out = ctx.uct_plan(model, root_states, cfg["episodes"], cfg["horizon"], cfg["gamma"], cfg["temperature"],
-                               policy_probabilities(self.prior_policy, model.A),
-                               policy_probabilities(self.rollout_policy, model.A), rng_states,
-                               root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1))
+                               prior_p, rollout_p, rng_states, root_steps=root_steps, max_plan_len=max(cfg["horizon"], 1))
             self._last_tables = None
         out["rng_states"] = rng_states
         self.relabel(out, model)

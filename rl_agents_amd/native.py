@@ -727,18 +727,40 @@ class Context(object):
               and not os.environ.get("MP_NO_PINNED_SCRATCH")):
             mpl = int(horizon if max_plan_len is None else max_plan_len)
             a_ = int(model.A)
-            scratch = self._scratch("uct", n, dict(
-                root_state=((n,), np.int32), root_steps=((n,), np.int32), rng=((n, 6), np.uint64), plans=((n, mpl), np.int32),
-                plan_len=((n,), np.int32), root_value=((n,), np.float64), root_child_count=((n, a_), np.int64),
-                root_child_value=((n, a_), np.float64), env_steps=((n,), np.int64)))
+            # (the arrays and their addresses are looked up by the plan's shape alone: building the spec and asking numpy for ten
+            # ctypes addresses cost a single agent's act() ~10 us of its ~120 -- tools/act_profile.py)
+            small = self.__dict__.setdefault("_small_plans", {})
+            hit = small.get((n, mpl, a_))
+            if hit is None or hit[0]._ptr is None:       # (evicted from the pinned-array cache: freed)
+                scratch = self._scratch("uct", n, dict(
+                    root_state=((n,), np.int32), root_steps=((n,), np.int32), rng=((n, 6), np.uint64), plans=((n, mpl), np.int32),
+                    plan_len=((n,), np.int32), root_value=((n,), np.float64), root_child_count=((n, a_), np.int64),
+                    root_child_value=((n, a_), np.float64), env_steps=((n,), np.int64)))
+                if len(small) >= 8:
+                    small.clear()
+                hit = small[(n, mpl, a_)] = (scratch, {k: scratch[k].ctypes.data for k in (
+                    "root_state", "root_steps", "rng", "plans", "plan_len", "root_value", "root_child_count", "root_child_value",
+                    "env_steps")})
+            scratch, sp = hit
             scratch["root_state"][:] = rs
             scratch["rng"][:] = rng_state.reshape(n, 6)
             scratch["plans"][:] = -1
-            rs, rng_ptr = scratch["root_state"], scratch["rng"].ctypes.data
             if st is not None:
                 scratch["root_steps"][:] = st
-                st = scratch["root_steps"]
             out = {k: scratch[k] for k in ("plans", "plan_len", "root_value", "root_child_count", "root_child_value", "env_steps")}
+            if policy is None and mi is None:
+                pp = np.ascontiguousarray(prior_p, dtype=np.float64)
+                rp = np.ascontiguousarray(rollout_p, dtype=np.float64)
+                if pp.shape != (model.A,) or rp.shape != (model.A,):
+                    raise ValueError("prior_p / rollout_p must have one entry per action")
+                _check(self._lib.mp_uct_plan(self._h, model._h, n, sp["root_state"], None if st is None else sp["root_steps"],
+                                             int(episodes), int(horizon), float(gamma), float(temperature), pp.ctypes.data,
+                                             rp.ctypes.data, sp["rng"], mpl, sp["plans"], sp["plan_len"], sp["root_value"],
+                                             sp["root_child_count"], sp["root_child_value"], sp["env_steps"], mem))
+                return self._from_scratch(scratch, out, rng_state)
+            rs, rng_ptr = scratch["root_state"], sp["rng"]
+            if st is not None:
+                st = scratch["root_steps"]
         else:
             mpl = int(horizon if max_plan_len is None else max_plan_len)
             out = dict(plans=np.full((n, mpl), -1, np.int32), plan_len=np.zeros(n, np.int32),
