@@ -181,6 +181,20 @@ def test_uct_zero_episodes_and_single_root(ctx):
     _cmp_uct(ctx, cfg, 1, 90, 11, 0.8, 10.0, p, p)
 
 
+def test_uct_small_plans_survive_the_eviction_of_their_pinned_arrays(ctx):
+    """Host-array plans of few roots go through pinned arrays the context keeps per plan shape, their addresses remembered beside
+    them (round 6); the context holds a handful of shapes and frees the oldest: a dozen shapes in turn, then the first again --
+    every plan (with step counts on every other one) equal to the oracle."""
+    from rl_agents_amd.envs import generators
+    cfg = generators.random_deterministic(200, 4, seed=12, terminal_rate=0.03)
+    p = np.ones(4) / 4
+    for rnd in range(2):
+        for horizon in list(range(2, 14)) + [2]:
+            n = 1 + horizon % 3
+            _cmp_uct(ctx, cfg, n, 6, horizon, 0.9, 3.0, p, p, seed=horizon + rnd, max_steps=9 if horizon % 2 else 0,
+                     steps0=(np.arange(n) % 4).astype(np.int32) if horizon % 2 else None)
+
+
 def test_uct_stream_continues_across_calls(ctx):
     """Two plan() calls on one agent continue one PCG64 stream (tree reset in between), as the reference does."""
     from oracle import oracle
